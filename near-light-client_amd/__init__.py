@@ -1,0 +1,11 @@
+"""nlx_amd - MI355X-native prover backend for the nearx plonky2x circuits (host-side mirror).
+
+The compute path is the HIP library `libnlx.so` (C ABI in include/nlx.h).  This package is
+the thin host layer above it, mirroring the plonky2 / plonky2x interface names the reference
+calls (nearx/src/test_utils.rs:29,62,66): PolynomialBatch, MerkleTree, prove, ...
+There is NO CPU fallback: importing `nlx_amd.lib` raises if libnlx.so is missing, and creating
+a Context raises if no gfx950 device is usable.
+"""
+from . import _lib as lib  # noqa: F401  (raises loudly when the HIP extension is absent)
+from ._lib import Context, NlxError, GOLDILOCKS_P  # noqa: F401
+from .batch import PolynomialBatch, MerkleTree, poseidon_permute, hash_rows, ntt  # noqa: F401

@@ -1,0 +1,123 @@
+"""ctypes binding of libnlx.so (include/nlx.h).  Fails loudly when the library is missing."""
+import ctypes
+import os
+
+import numpy as np
+
+GOLDILOCKS_P = 0xFFFFFFFF00000001
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnlx.so")
+
+# If torch is going to be used in this process (bench.py, multi-GPU dispatch) it must load its
+# bundled HIP runtime first; libnlx.so then binds to the same libamdhip64.so.7 instance so
+# device pointers and streams can be shared.
+if os.environ.get("NLX_SKIP_TORCH_PRELOAD") != "1":
+    try:  # pragma: no cover - environment dependent
+        import torch  # noqa: F401
+    except Exception:  # torch absent: the C ABI works on its own
+        pass
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "nlx_amd: HIP extension %s not found. Build it with `python near-light-client_amd/build.py` "
+        "(or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+
+_dll = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+u64p = ctypes.POINTER(ctypes.c_uint64)
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); kept in one table so tests can check every symbol of nlx.h
+SIGNATURES = {
+    "nlx_version": (ctypes.c_uint32, []),
+    "nlx_strerror": (ctypes.c_char_p, [ctypes.c_int32]),
+    "nlx_ctx_create": (ctypes.c_int32, [ctypes.c_int, c_void_pp]),
+    "nlx_ctx_destroy": (None, [ctypes.c_void_p]),
+    "nlx_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "nlx_ctx_set_stream": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "nlx_ctx_synchronize": (ctypes.c_int32, [ctypes.c_void_p]),
+    "nlx_poseidon_permute_batch": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "nlx_hash_rows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                       ctypes.c_void_p]),
+    "nlx_merkle_digest_words": (ctypes.c_size_t, [ctypes.c_size_t, ctypes.c_uint32]),
+    "nlx_merkle_build": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                          ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),
+    "nlx_ntt_batch": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
+                                       ctypes.c_int, ctypes.c_uint64]),
+    "nlx_commit_from_values": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
+                                                ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, c_void_pp]),
+    "nlx_commit_from_coeffs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
+                                                ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, c_void_pp]),
+    "nlx_commit_destroy": (None, [ctypes.c_void_p]),
+    "nlx_commit_get_coeffs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "nlx_commit_get_cap": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "nlx_commit_open_rows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                              ctypes.c_void_p]),
+    "nlx_commit_eval_at": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "nlx_commit_get_leaves": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "nlx_commit_get_digests": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(_dll, _name)  # AttributeError here = ABI mismatch: fail at import
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+dll = _dll
+
+
+class NlxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("nlx error %d (%s): %s" % (code, dll.nlx_strerror(code).decode(), msg))
+        self.code = code
+
+
+def ptr(a):
+    """Raw address of a numpy array, a torch tensor (host or device) or None."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        if a.dtype != np.uint64 or not a.flags["C_CONTIGUOUS"]:
+            raise TypeError("expected a C-contiguous uint64 array")
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        if not a.is_contiguous():
+            raise TypeError("expected a contiguous tensor")
+        return a.data_ptr()
+    if isinstance(a, int):
+        return a
+    raise TypeError("unsupported buffer type %r" % type(a))
+
+
+class Context:
+    """One per HIP device and host thread (nlx.h threading contract)."""
+
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        rc = dll.nlx_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise NlxError(rc, "nlx_ctx_create(device=%d) failed: no usable gfx950 device "
+                               "(there is no CPU fallback)" % device)
+        self.handle = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != 0:
+            raise NlxError(rc, dll.nlx_last_error(self.handle).decode())
+
+    def synchronize(self):
+        self.check(dll.nlx_ctx_synchronize(self.handle))
+
+    def set_stream(self, hip_stream):
+        self.check(dll.nlx_ctx_set_stream(self.handle, hip_stream))
+
+    def close(self):
+        if self.handle:
+            dll.nlx_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,144 @@
+"""Host-side mirror of plonky2's PolynomialBatch / MerkleTree / fft helpers over the C ABI.
+
+Names and argument meaning follow plonky2::fri::oracle::PolynomialBatch and
+plonky2::hash::merkle_tree::MerkleTree; arrays are numpy uint64
+(host) or torch int64/uint64 tensors on the context's device (used in place).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import dll, ptr
+
+
+def poseidon_permute(ctx, states):
+    """plonky2 Poseidon::poseidon on a batch: states (n, 12) uint64, returns a new array."""
+    s = np.ascontiguousarray(states, dtype=np.uint64).copy()
+    if s.ndim != 2 or s.shape[1] != 12:
+        raise ValueError("states must have shape (n, 12)")
+    ctx.check(dll.nlx_poseidon_permute_batch(ctx.handle, ptr(s), s.shape[0]))
+    return s
+
+
+def hash_rows(ctx, rows):
+    """PoseidonHash::hash_or_noop of every row of a row-major (n_rows, row_len) matrix."""
+    r = np.ascontiguousarray(rows, dtype=np.uint64)
+    out = np.zeros((r.shape[0], 4), dtype=np.uint64)
+    ctx.check(dll.nlx_hash_rows(ctx.handle, ptr(r), r.shape[0], r.shape[1], ptr(out)))
+    return out
+
+
+def ntt(ctx, cols, inverse=False, coset_shift=1):
+    """fft / ifft / coset_fft / coset_ifft of each row of `cols` ((n_cols, n), natural order)."""
+    c = np.ascontiguousarray(cols, dtype=np.uint64).copy()
+    n = c.shape[1]
+    log_n = n.bit_length() - 1
+    if 1 << log_n != n:
+        raise ValueError("length must be a power of two")
+    ctx.check(dll.nlx_ntt_batch(ctx.handle, ptr(c), c.shape[0], log_n, 1 if inverse else 0, int(coset_shift)))
+    return c
+
+
+class MerkleTree:
+    """MerkleTree::new(leaves, cap_height): leaves (n_leaves, leaf_len) row-major."""
+
+    def __init__(self, ctx, leaves, cap_height):
+        lv = np.ascontiguousarray(leaves, dtype=np.uint64)
+        self.n_leaves, self.leaf_len = lv.shape
+        self.cap_height = cap_height
+        words = dll.nlx_merkle_digest_words(self.n_leaves, cap_height)
+        if words == 0:
+            raise ValueError("n_leaves must be a power of two")
+        self.digests = np.zeros(words, dtype=np.uint64)
+        self.cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+        ctx.check(dll.nlx_merkle_build(ctx.handle, ptr(lv), self.n_leaves, self.leaf_len, cap_height,
+                                       ptr(self.digests), ptr(self.cap)))
+        self.leaves = lv
+
+    def prove(self, leaf_index):
+        """Sibling digests bottom-up (MerkleTree::prove)."""
+        sib, off, lvl, idx = [], 0, self.n_leaves, leaf_index
+        while lvl > (1 << self.cap_height):
+            s = off + (idx ^ 1) * 4
+            sib.append(self.digests[s:s + 4].copy())
+            off += lvl * 4
+            lvl >>= 1
+            idx >>= 1
+        return np.array(sib, dtype=np.uint64).reshape(-1, 4)
+
+
+class PolynomialBatch:
+    """Device-resident PolynomialBatch (coefficients + LDE table + Merkle tree in HBM)."""
+
+    def __init__(self, ctx, handle, n_cols, log_n, rate_bits, cap_height, cap):
+        self.ctx, self.handle = ctx, handle
+        self.n_cols, self.log_n, self.rate_bits, self.cap_height = n_cols, log_n, rate_bits, cap_height
+        self.cap = cap
+
+    @classmethod
+    def _make(cls, fn, ctx, data, rate_bits, cap_height):
+        if isinstance(data, np.ndarray):
+            data = np.ascontiguousarray(data, dtype=np.uint64)
+        n_cols, n = data.shape
+        log_n = int(n).bit_length() - 1
+        if 1 << log_n != n:
+            raise ValueError("polynomial length must be a power of two")
+        cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+        h = ctypes.c_void_p()
+        ctx.check(fn(ctx.handle, ptr(data), n_cols, log_n, rate_bits, cap_height, ptr(cap), ctypes.byref(h)))
+        return cls(ctx, h, n_cols, log_n, rate_bits, cap_height, cap)
+
+    @classmethod
+    def from_values(cls, ctx, values, rate_bits, cap_height):
+        """values: (n_cols, n) — one polynomial's subgroup evaluations per row."""
+        return cls._make(dll.nlx_commit_from_values, ctx, values, rate_bits, cap_height)
+
+    @classmethod
+    def from_coeffs(cls, ctx, coeffs, rate_bits, cap_height):
+        return cls._make(dll.nlx_commit_from_coeffs, ctx, coeffs, rate_bits, cap_height)
+
+    @property
+    def lde_size(self):
+        return 1 << (self.log_n + self.rate_bits)
+
+    def coeffs(self):
+        out = np.zeros((self.n_cols, 1 << self.log_n), dtype=np.uint64)
+        self.ctx.check(dll.nlx_commit_get_coeffs(self.handle, ptr(out)))
+        return out
+
+    def leaves(self):
+        out = np.zeros((self.lde_size, self.n_cols), dtype=np.uint64)
+        self.ctx.check(dll.nlx_commit_get_leaves(self.handle, ptr(out)))
+        return out
+
+    def digests(self):
+        out = np.zeros(dll.nlx_merkle_digest_words(self.lde_size, self.cap_height), dtype=np.uint64)
+        self.ctx.check(dll.nlx_commit_get_digests(self.handle, ptr(out)))
+        return out
+
+    def open_rows(self, indices, with_paths=True):
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        k = idx.shape[0]
+        rows = np.zeros((k, self.n_cols), dtype=np.uint64)
+        plen = self.log_n + self.rate_bits - self.cap_height
+        paths = np.zeros((k, plen, 4), dtype=np.uint64) if with_paths else None
+        self.ctx.check(dll.nlx_commit_open_rows(self.handle, ptr(idx), k, ptr(rows), ptr(paths)))
+        return rows, paths
+
+    def eval_at(self, zeta):
+        z = np.array(zeta, dtype=np.uint64)
+        out = np.zeros((self.n_cols, 2), dtype=np.uint64)
+        self.ctx.check(dll.nlx_commit_eval_at(self.handle, ptr(z), ptr(out)))
+        return out
+
+    def close(self):
+        if self.handle:
+            dll.nlx_commit_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

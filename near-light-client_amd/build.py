@@ -1,0 +1,72 @@
+"""Build the HIP/C-ABI shared library (libnlx.so) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container as well as
+on the MI355X box.  Objects are cached under csrc/.obj and rebuilt when a source or header is
+newer.  The workload generator (libnlx_synth.so, plain C++) is built by the same entry point.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, ".obj")
+LIB = os.path.join(HERE, "libnlx.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
+         "-I", os.path.join(HERE, "..", "include")]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers_mtime():
+    m = 0.0
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for f in os.listdir(root):
+            if f.endswith((".hpp", ".h", ".inc")):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return m
+
+
+def _compile(src, verbose):
+    obj = os.path.join(OBJ, src + ".o")
+    cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if verbose and r.stderr.strip():
+        print(r.stderr, file=sys.stderr)
+    return obj
+
+
+def build_lib(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hm = _headers_mtime()
+    todo, objs = [], []
+    for src in _sources():
+        obj = os.path.join(OBJ, src + ".o")
+        objs.append(obj)
+        sm = max(os.path.getmtime(os.path.join(CSRC, src)), hm)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < sm:
+            todo.append(src)
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(6, len(todo))) as ex:
+            list(ex.map(lambda s: _compile(s, verbose), todo))
+    if todo or not os.path.exists(LIB):
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

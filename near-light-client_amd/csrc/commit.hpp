@@ -1,0 +1,28 @@
+// Device-resident polynomial batch commitment (plonky2::fri::oracle::PolynomialBatch).
+#pragma once
+#include "ctx.hpp"
+
+struct nlx_commit {
+    nlx_ctx* ctx = nullptr;
+    uint32_t n_cols = 0;
+    uint32_t log_n = 0;
+    uint32_t rate_bits = 0;
+    uint32_t cap_height = 0;
+    uint64_t* coeffs_br = nullptr;  // [col][n], coefficient i at position bitrev(i)
+    uint64_t* lde = nullptr;        // [col][r][k] = p_col(g * w_L^(8k + r)), L = n << rate_bits
+    uint64_t* digests = nullptr;    // level-major; level 0 in plonky2 leaf order
+    const uint64_t* cap = nullptr;  // inside digests
+    size_t n() const { return (size_t)1 << log_n; }
+    size_t L() const { return (size_t)1 << (log_n + rate_bits); }
+    unsigned log_L() const { return log_n + rate_bits; }
+};
+
+namespace nlx {
+size_t merkle_digest_words(size_t n_leaves, uint32_t cap_height);
+// Input kinds for commit_build
+enum class CommitInput { ValuesNatural, CoeffsNatural, CoeffsBitrev };
+// d_in: device pointer, [col][n] with column stride in_stride.  Enqueues all work on ctx->stream;
+// no synchronisation.  On success *out owns coeffs_br / lde / digests.
+int32_t commit_build(nlx_ctx* ctx, const uint64_t* d_in, size_t in_stride, CommitInput kind, uint32_t n_cols,
+                     uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, nlx_commit** out);
+}  // namespace nlx

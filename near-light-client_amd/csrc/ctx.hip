@@ -1,0 +1,218 @@
+// Context implementation: device selection (gfx950 only, no CPU fallback), caching allocator,
+// lazily built twiddle / coset-scale tables.
+#include "ctx.hpp"
+#include <cstring>
+#include "gl.hpp"
+
+void* nlx_ctx::alloc(size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = free_blocks.lower_bound(bytes);
+    // reuse a cached block if it wastes < 25 %
+    if (it != free_blocks.end() && it->first <= bytes + bytes / 4) {
+        void* p = it->second;
+        live_blocks[p] = it->first;
+        free_blocks.erase(it);
+        return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        trim();
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            hip_fail(e, "hipMalloc");
+            return nullptr;
+        }
+    }
+    bytes_reserved += bytes;
+    live_blocks[p] = bytes;
+    return p;
+}
+
+void nlx_ctx::release(void* p) {
+    if (!p) return;
+    auto it = live_blocks.find(p);
+    if (it == live_blocks.end()) return;
+    free_blocks.emplace(it->second, p);
+    live_blocks.erase(it);
+}
+
+void nlx_ctx::trim() {
+    if (free_blocks.empty()) return;
+    (void)hipStreamSynchronize(stream);
+    for (auto& kv : free_blocks) {
+        (void)hipFree(kv.second);
+        bytes_reserved -= kv.first;
+    }
+    free_blocks.clear();
+}
+
+int32_t nlx_ctx::ensure_tables(unsigned log_n) {
+    if (log_n > 32) return fail(NLX_E_RANGE, "log_n %u exceeds the field's two-adicity (32)", log_n);
+    for (unsigned k = tables.max_log + 1; k <= log_n; k++) {
+        size_t half = (size_t)1 << (k - 1);
+        uint64_t* f = (uint64_t*)alloc(half * 8);
+        uint64_t* i = (uint64_t*)alloc(half * 8);
+        if (!f || !i) return NLX_E_NOMEM;
+        uint64_t w = gl::root_of_unity(k);
+        nlx::launch_fill_powers(stream, f, half, w, 1);
+        nlx::launch_fill_powers(stream, i, half, gl::inv(w), 1);
+        tables.fwd[k] = f;
+        tables.inv[k] = i;
+        tables.max_log = k;
+    }
+    return NLX_OK;
+}
+
+int32_t nlx_ctx::get_coset_scale(unsigned log_n, unsigned rate_bits, const uint64_t** out) {
+    uint32_t key = (log_n << 8) | rate_bits;
+    auto it = coset_scale.find(key);
+    if (it == coset_scale.end()) {
+        uint64_t* t = (uint64_t*)alloc(((size_t)8 << (log_n + rate_bits)));
+        if (!t) return NLX_E_NOMEM;
+        nlx::launch_fill_coset_scale_br(stream, t, log_n, rate_bits, gl::GEN);
+        it = coset_scale.emplace(key, t).first;
+    }
+    *out = it->second;
+    return NLX_OK;
+}
+
+int32_t nlx_ctx::get_nat_scale(unsigned log_n, uint64_t shift, const uint64_t** out) {
+    auto key = std::make_pair((uint32_t)log_n, shift);
+    auto it = nat_scale.find(key);
+    if (it == nat_scale.end()) {
+        uint64_t* t = (uint64_t*)alloc((size_t)8 << log_n);
+        if (!t) return NLX_E_NOMEM;
+        nlx::launch_fill_powers(stream, t, (size_t)1 << log_n, shift, 1);
+        it = nat_scale.emplace(key, t).first;
+    }
+    *out = it->second;
+    return NLX_OK;
+}
+
+namespace nlx {
+
+bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain host memory: not an error for us
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+Staged::Staged(nlx_ctx* c, const void* user_ptr, size_t nbytes, bool copy_in, bool copy_out)
+    : ctx(c), user(const_cast<void*>(user_ptr)), bytes(nbytes), out(copy_out) {
+    if (!user_ptr || nbytes == 0) {
+        dev = user;
+        return;
+    }
+    if (is_device_ptr(user_ptr)) {
+        dev = user;
+        return;
+    }
+    dev = ctx->alloc(nbytes);
+    if (!dev) {
+        status = NLX_E_NOMEM;
+        return;
+    }
+    owned = true;
+    if (copy_in) {
+        hipError_t e = hipMemcpyAsync(dev, user, nbytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) status = ctx->hip_fail(e, "hipMemcpyAsync(H2D)");
+    }
+}
+
+int32_t Staged::finish() {
+    if (owned && out && status == 0) {
+        hipError_t e = hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) status = ctx->hip_fail(e, "hipMemcpyAsync(D2H)");
+    }
+    return status;
+}
+
+Staged::~Staged() {
+    if (owned) {
+        // the block may still be in use by queued work on ctx->stream; the allocator only hands
+        // it to later work on the same stream, which is ordered after it.
+        ctx->release(dev);
+    }
+}
+
+}  // namespace nlx
+
+extern "C" {
+
+uint32_t nlx_version(void) { return (0u << 16) | 1u; }
+
+const char* nlx_strerror(int32_t code) {
+    switch (code) {
+        case NLX_OK: return "ok";
+        case NLX_E_INVAL: return "invalid argument";
+        case NLX_E_NOMEM: return "out of device memory";
+        case NLX_E_HIP: return "HIP runtime error";
+        case NLX_E_RANGE: return "argument out of range";
+        case NLX_E_UNSUPPORTED: return "unsupported";
+        default: return "unknown error";
+    }
+}
+
+int32_t nlx_ctx_create(int device, nlx_ctx** out) {
+    if (!out) return NLX_E_INVAL;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return NLX_E_HIP;  // no CPU fallback by design
+    }
+    if (device < 0 || device >= count) return NLX_E_RANGE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return NLX_E_HIP;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return NLX_E_UNSUPPORTED;  // kernels are built for gfx950 only
+    if (hipSetDevice(device) != hipSuccess) return NLX_E_HIP;
+    nlx_ctx* c = new (std::nothrow) nlx_ctx();
+    if (!c) return NLX_E_NOMEM;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return NLX_E_HIP;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return NLX_OK;
+}
+
+void nlx_ctx_destroy(nlx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->live_blocks) (void)hipFree(kv.first);
+    for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* nlx_last_error(const nlx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int32_t nlx_ctx_set_stream(nlx_ctx* c, void* hip_stream) {
+    if (!c) return NLX_E_INVAL;
+    (void)hipSetDevice(c->device);
+    NLX_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return NLX_OK;
+}
+
+int32_t nlx_ctx_synchronize(nlx_ctx* c) {
+    if (!c) return NLX_E_INVAL;
+    NLX_HIP(c, hipStreamSynchronize(c->stream));
+    return NLX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// Goldilocks field F_p, p = 2^64 - 2^32 + 1, and its quadratic extension F_p[X]/(X^2 - 7),
+// for gfx950 device code and for the C++ host orchestration (same source, both sides).
+//
+// Replaces plonky2_field::goldilocks_field::GoldilocksField and extension::quadratic
+// (crate pinned at /root/reference/Cargo.lock:4912-4914; reached from every prover call
+// behind nearx/src/test_utils.rs:62).  Written for CDNA4: there is no 64-bit integer MFMA, so
+// a field multiply is four v_mad_u64_u32 plus a shift/add reduction that never divides.
+//
+// Representation: values in memory are canonical (< p).  Inside kernels a value may be any
+// u64 congruent to the element ("loose"); functions say which they accept and return.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#define GL_HD __host__ __device__ __forceinline__
+#else
+#define GL_HD inline
+#endif
+
+namespace gl {
+
+constexpr uint64_t P = 0xFFFFFFFF00000001ULL;
+constexpr uint64_t EPS = 0xFFFFFFFFULL;  // 2^64 mod p
+constexpr uint64_t GEN = 14293326489335486720ULL;       // multiplicative generator = coset shift
+constexpr uint64_t POW2_GEN = 7277203076849721926ULL;   // order 2^32
+constexpr unsigned TWO_ADICITY = 32;
+constexpr uint64_t W = 7;  // X^2 = W in the quadratic extension
+
+GL_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+GL_HD uint64_t canon(uint64_t a) { return a >= P ? a - P : a; }
+
+// canonical + canonical -> canonical
+GL_HD uint64_t add(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    return (s < a || s >= P) ? s - P : s;
+}
+// canonical - canonical -> canonical
+GL_HD uint64_t sub(uint64_t a, uint64_t b) {
+    uint64_t d = a - b;
+    return a < b ? d + P : d;
+}
+GL_HD uint64_t neg(uint64_t a) { return a ? P - a : 0; }
+
+// loose + canonical -> loose (single conditional fix-up; see plonky2 GoldilocksField::add)
+GL_HD uint64_t add_loose(uint64_t a, uint64_t c) {
+    uint64_t s = a + c;
+    return s < a ? s + EPS : s;
+}
+
+// (hi:lo) mod p, any 128-bit input -> loose u64
+GL_HD uint64_t reduce128_loose(uint64_t lo, uint64_t hi) {
+    uint64_t hi_hi = hi >> 32, hi_lo = hi & EPS;
+    uint64_t t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= EPS;
+    uint64_t t1 = (hi_lo << 32) - hi_lo;  // hi_lo * (2^32 - 1)
+    uint64_t r = t0 + t1;
+    if (r < t1) r += EPS;
+    return r;
+}
+GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) { return canon(reduce128_loose(lo, hi)); }
+
+// loose * loose -> loose
+GL_HD uint64_t mul_loose(uint64_t a, uint64_t b) { return reduce128_loose(a * b, mulhi64(a, b)); }
+// any * any -> canonical
+GL_HD uint64_t mul(uint64_t a, uint64_t b) { return canon(mul_loose(a, b)); }
+GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
+
+GL_HD uint64_t pow(uint64_t b, uint64_t e) {
+    uint64_t r = 1;
+    while (e) {
+        if (e & 1) r = mul(r, b);
+        b = sqr(b);
+        e >>= 1;
+    }
+    return r;
+}
+GL_HD uint64_t exp_pow2(uint64_t a, unsigned k) {
+    while (k--) a = sqr(a);
+    return a;
+}
+// a^(p-2); addition chain: p-2 = 2^64 - 2^32 - 1  (72 multiplications)
+GL_HD uint64_t inv(uint64_t a) {
+    // t_k = a^(2^k - 1)
+    uint64_t t2 = mul(sqr(a), a);
+    uint64_t t3 = mul(sqr(t2), a);
+    uint64_t t6 = mul(exp_pow2(t3, 3), t3);
+    uint64_t t12 = mul(exp_pow2(t6, 6), t6);
+    uint64_t t24 = mul(exp_pow2(t12, 12), t12);
+    uint64_t t30 = mul(exp_pow2(t24, 6), t6);
+    uint64_t t31 = mul(sqr(t30), a);
+    // p - 2 = (2^31 - 1) * 2^33 + (2^32 - 1)   [= 2^64 - 2^33 + 2^32 - 1]
+    uint64_t t32 = mul(sqr(t31), a);
+    return mul(exp_pow2(t31, 33), t32);
+}
+GL_HD uint64_t root_of_unity(unsigned n_log) { return exp_pow2(POW2_GEN, TWO_ADICITY - n_log); }
+
+// ---- quadratic extension ----
+struct Ext {
+    uint64_t a, b;  // a + b X, canonical
+};
+GL_HD Ext ext(uint64_t a, uint64_t b = 0) { return Ext{a, b}; }
+GL_HD Ext add(Ext x, Ext y) { return Ext{add(x.a, y.a), add(x.b, y.b)}; }
+GL_HD Ext sub(Ext x, Ext y) { return Ext{sub(x.a, y.a), sub(x.b, y.b)}; }
+GL_HD Ext mul(Ext x, Ext y) {
+    uint64_t bb = mul(x.b, y.b);
+    // 7*bb without a full multiply: 8*bb - bb, done in 128 bits
+    uint64_t c0 = add(mul(x.a, y.a), reduce128(bb * W, mulhi64(bb, W)));
+    uint64_t c1 = add(mul(x.a, y.b), mul(x.b, y.a));
+    return Ext{c0, c1};
+}
+GL_HD Ext mul(Ext x, uint64_t s) { return Ext{mul(x.a, s), mul(x.b, s)}; }
+GL_HD Ext inv(Ext x) {
+    uint64_t n = sub(sqr(x.a), mul(W, sqr(x.b)));
+    uint64_t ni = inv(n);
+    return Ext{mul(x.a, ni), mul(neg(x.b), ni)};
+}
+GL_HD Ext pow(Ext b, uint64_t e) {
+    Ext r{1, 0};
+    while (e) {
+        if (e & 1) r = mul(r, b);
+        b = mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+GL_HD bool eq(Ext x, Ext y) { return x.a == y.a && x.b == y.b; }
+
+GL_HD uint32_t bitrev32(uint32_t x, unsigned bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? (__brev(x) >> (32 - bits)) : 0;
+#else
+    uint32_t r = 0;
+    for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+#endif
+}
+
+}  // namespace gl

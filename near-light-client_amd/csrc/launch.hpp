@@ -1,0 +1,46 @@
+// Internal launcher declarations shared by the HIP translation units and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace nlx {
+
+// ---- hash_kernels.hip ----
+void launch_permute_batch(hipStream_t st, uint64_t* d_states, size_t n);
+void launch_hash_leaves_colmajor(hipStream_t st, const uint64_t* d_cols, size_t col_stride, uint32_t n_cols,
+                                 size_t n_rows, uint64_t* d_digests);
+void launch_hash_leaves_rowmajor(hipStream_t st, const uint64_t* d_rows, uint32_t row_len, size_t n_rows,
+                                 uint64_t* d_digests);
+const uint64_t* launch_merkle_levels(hipStream_t st, uint64_t* d_digests, size_t n_leaves, unsigned cap_height);
+// LDE-table leaf hashing: table is [col][coset r][k] (coset-major natural order);
+// the digest of point (r,k) is written at tree position bitrev3(r)*n + bitrev(k).
+void launch_hash_lde_leaves(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols,
+                            unsigned log_n, unsigned rate_bits, uint64_t* d_digests);
+
+// ---- ntt_kernels.hip ----
+struct NttTables {
+    // fwd[k] / inv[k]: device pointer to w_{2^k}^e (resp. w^-e), e in [0, 2^(k-1)); k in [1, max_log]
+    const uint64_t* fwd[33];
+    const uint64_t* inv[33];
+    unsigned max_log;
+};
+// values (natural) -> coefficients in bit-reversed order, scaled by 1/n.  src and dst may alias.
+void launch_intt_dif(hipStream_t st, const NttTables& tb, const uint64_t* src, size_t src_stride, uint64_t* dst,
+                     size_t dst_stride, uint32_t n_cols, unsigned log_n);
+// coefficients (bit-reversed) -> values on 2^rate_bits cosets, table dst[col][r][k].
+// scale_br: [2^rate_bits][n] table, scale_br[r][j] = (shift * w_L^r)^bitrev(j).
+void launch_lde_dit(hipStream_t st, const NttTables& tb, const uint64_t* coeffs_br, size_t src_stride,
+                    uint64_t* dst, size_t dst_stride, uint32_t n_cols, unsigned log_n, unsigned rate_bits,
+                    const uint64_t* scale_br);
+// plain forward transform pieces for the nlx_ntt_batch entry point
+void launch_ntt_dif_fwd(hipStream_t st, const NttTables& tb, uint64_t* data, size_t stride, uint32_t n_cols,
+                        unsigned log_n, bool inverse, const uint64_t* prescale_nat);
+void launch_bitrev_permute(hipStream_t st, const uint64_t* src, uint64_t* dst, size_t stride, uint32_t n_cols,
+                           unsigned log_n, const uint64_t* postscale_nat);
+void launch_fill_root_table(hipStream_t st, uint64_t* d_table, unsigned log_size, uint64_t root);
+void launch_fill_coset_scale_br(hipStream_t st, uint64_t* d_table, unsigned log_n, unsigned rate_bits,
+                                uint64_t shift);
+void launch_fill_powers(hipStream_t st, uint64_t* d_table, size_t count, uint64_t base, uint64_t first);
+
+}  // namespace nlx

@@ -1,0 +1,303 @@
+// Goldilocks NTT / LDE kernels for gfx950.
+//
+// Replaces plonky2_field::fft::{fft_classic, ifft_with_options}, PolynomialCoeffs::{lde, coset_fft}
+// and the transpose + reverse_index_bits_in_place of PolynomialBatch::lde_values
+// (pinned crates at /root/reference/Cargo.lock:4912-4974).
+//
+// MI355X-first design:
+//  * No bit-reversal or transpose pass exists anywhere.  The inverse transform runs
+//    decimation-in-frequency (natural values -> bit-reversed coefficients), the forward
+//    low-degree extension runs decimation-in-time (bit-reversed coefficients -> natural
+//    values), so coefficients simply LIVE in bit-reversed order in HBM.
+//  * An LDE of rate 2^b is 2^b independent size-n transforms of pre-scaled coefficients
+//    (coset r uses scale (g*w_L^r)^i), not one zero-padded size-(n<<b) transform: 3 fewer
+//    butterfly levels and no zero traffic at rate 8.  The table is stored coset-major,
+//    [col][r][k] = p_col(g * w_L^(8k+r)).
+//  * Each pass stages a tile of 4096 field elements (32 KiB) in LDS, runs up to 12 radix-2
+//    levels there, and touches HBM once per pass with >=128-byte contiguous segments.
+#include <hip/hip_runtime.h>
+#include "gl.hpp"
+#include "launch.hpp"
+
+namespace nlx {
+
+constexpr unsigned TILE_LOG = 12;
+constexpr unsigned TILE = 1u << TILE_LOG;
+constexpr unsigned NTT_THREADS = 256;
+constexpr unsigned STRIDED_BITS_MAX = 8;  // 256-point strided sub-transform, 16-element (128 B) rows
+
+struct PassParams {
+    const uint64_t* src;   // read base (column 0)
+    uint64_t* dst;         // write base (column 0)
+    size_t src_stride;     // elements between columns
+    size_t dst_stride;
+    size_t src_z_stride;   // elements between blockIdx.z slices (cosets) on the read side
+    size_t dst_z_stride;
+    const uint64_t* tw;    // w_N^e, e in [0, N/2), N = 2^log_N = sub-problem size of this pass
+    const uint64_t* scale; // optional per-element factor applied on load (indexed like src within a z slice)
+    size_t scale_z_stride;
+    uint64_t final_scale;  // multiplied into every output (1 = none)
+    unsigned log_n;        // column length
+    unsigned log_N;        // sub-problem size at this pass (A * M)
+    unsigned log_A;        // transform length inside the tile
+    unsigned log_T;        // consecutive elements per tile row (strided pass) ; 0 for contiguous
+    unsigned log_Q;        // sub-problems per tile (contiguous pass); 0 for strided
+};
+
+__device__ __forceinline__ uint64_t tw_full(const uint64_t* __restrict__ tw, uint32_t e, uint32_t half_N) {
+    // w_N^e for e in [0, N): the table holds the first half, the second half is its negation
+    return e < half_N ? tw[e] : gl::P - tw[e - half_N];
+}
+
+// One pass of a decimation-in-frequency (DIT = false) or decimation-in-time (DIT = true)
+// transform over a tile held in LDS.
+//   strided pass   : element (j1, jt) of tile (q, t) lives at q*N + j1*M + t*T + jt
+//   contiguous pass: element (qq, j1) of tile `tile` lives at (tile*Q + qq)*A + j1   (M = T = 1)
+template <bool DIT>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
+    __shared__ uint64_t lds[TILE];
+    const unsigned tid = threadIdx.x;
+    const unsigned log_A = p.log_A, log_T = p.log_T, log_Q = p.log_Q;
+    const uint32_t A = 1u << log_A, T = 1u << log_T;
+    const unsigned log_M = p.log_N - log_A;
+    const uint32_t tile_elems = 1u << (log_A + log_T + log_Q);
+    const uint32_t half_N = p.log_N ? 1u << (p.log_N - 1) : 0u;
+    const bool strided = log_M != 0;
+
+    const uint64_t* __restrict__ src = p.src + (size_t)blockIdx.y * p.src_stride + (size_t)blockIdx.z * p.src_z_stride;
+    uint64_t* __restrict__ dst = p.dst + (size_t)blockIdx.y * p.dst_stride + (size_t)blockIdx.z * p.dst_z_stride;
+    const uint64_t* __restrict__ scale = p.scale ? p.scale + (size_t)blockIdx.z * p.scale_z_stride : nullptr;
+    const uint64_t* __restrict__ tw = p.tw;
+
+    // tile origin
+    size_t base;      // global index of element (j1 = 0, jt = 0, qq = 0)
+    uint32_t j0_base; // first j0 (= t*T) of this tile within its sub-problem (strided pass)
+    if (strided) {
+        const uint32_t tiles_per_sub = 1u << (log_M - log_T);
+        const uint32_t q = blockIdx.x >> (log_M - log_T);
+        const uint32_t t = blockIdx.x & (tiles_per_sub - 1);
+        j0_base = t << log_T;
+        base = ((size_t)q << p.log_N) + j0_base;
+    } else {
+        j0_base = 0;
+        base = (size_t)blockIdx.x << (log_A + log_Q);
+    }
+
+    // ---- load (with optional pre-scale, and for DIT strided passes the inter-pass twiddle) ----
+    for (uint32_t idx = tid; idx < tile_elems; idx += NTT_THREADS) {
+        const uint32_t jt = idx & (T - 1);
+        const uint32_t j1 = (idx >> log_T) & (A - 1);
+        const size_t g = strided ? base + ((size_t)j1 << log_M) + jt : base + idx;
+        uint64_t v = src[g];
+        if (scale) v = gl::mul(v, scale[g]);
+        if (DIT && strided) {
+            // Y[i1][k0] *= w_N^(i1*k0), i1 = bitrev_A(block j1), k0 = j0
+            const uint32_t i1 = gl::bitrev32(j1, log_A);
+            const uint32_t e = i1 * (j0_base + jt);  // < N
+            if (e) v = gl::mul(v, tw_full(tw, e, half_N));
+        }
+        lds[idx] = v;
+    }
+    __syncthreads();
+
+    // ---- radix-2 levels along j1 ----
+    const uint32_t n_bfly = tile_elems >> 1;
+    for (unsigned s = 0; s < log_A; s++) {
+        // DIF: half = A >> (s+1) (large -> small).  DIT: half = 1 << s (small -> large).
+        const unsigned log_half = DIT ? s : (log_A - 1 - s);
+        const uint32_t half = 1u << log_half;
+        // twiddle exponent step in units of w_N: w_{2*half}^u = w_N^(u * N/(2*half))
+        const unsigned tw_shift = p.log_N - (log_half + 1);
+        for (uint32_t b = tid; b < n_bfly; b += NTT_THREADS) {
+            const uint32_t jt = b & (T - 1);
+            const uint32_t r = b >> log_T;
+            const uint32_t pair = r & ((A >> 1) - 1);
+            const uint32_t qq = r >> (log_A - 1);
+            const uint32_t u = pair & (half - 1);
+            const uint32_t blk = pair >> log_half;
+            const uint32_t j1 = (blk << (log_half + 1)) + u;
+            const uint32_t i0 = (((qq << log_A) + j1) << log_T) + jt;
+            const uint32_t i1 = i0 + (half << log_T);
+            const uint64_t w = tw[(size_t)u << tw_shift];
+            uint64_t a = lds[i0], c = lds[i1];
+            if (DIT) {
+                c = gl::mul(c, w);
+                lds[i0] = gl::add(a, c);
+                lds[i1] = gl::sub(a, c);
+            } else {
+                lds[i0] = gl::add(a, c);
+                lds[i1] = gl::mul(gl::sub(a, c), w);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- store (DIF strided passes apply the inter-pass twiddle; optional final scale) ----
+    for (uint32_t idx = tid; idx < tile_elems; idx += NTT_THREADS) {
+        const uint32_t jt = idx & (T - 1);
+        const uint32_t j1 = (idx >> log_T) & (A - 1);
+        const size_t g = strided ? base + ((size_t)j1 << log_M) + jt : base + idx;
+        uint64_t v = lds[idx];
+        if (!DIT && strided) {
+            // y[k1][j0] *= w_N^(j0*k1), stored at block bitrev_A(k1)
+            const uint32_t k1 = gl::bitrev32(j1, log_A);
+            const uint32_t e = k1 * (j0_base + jt);
+            if (e) v = gl::mul(v, tw_full(tw, e, half_N));
+        }
+        if (p.final_scale != 1) v = gl::mul(v, p.final_scale);
+        dst[g] = v;
+    }
+}
+
+// Pass planning: contiguous pass of `c` bits, then strided passes of <= STRIDED_BITS_MAX bits.
+struct Plan {
+    unsigned n_pass;
+    unsigned log_A[8];
+};
+static Plan make_plan(unsigned log_n) {
+    Plan pl{};
+    unsigned c = log_n < TILE_LOG ? log_n : TILE_LOG;
+    unsigned rem = log_n - c;
+    unsigned n_strided = (rem + STRIDED_BITS_MAX - 1) / STRIDED_BITS_MAX;
+    pl.n_pass = 0;
+    pl.log_A[pl.n_pass++] = c;  // index 0 = contiguous pass
+    for (unsigned i = 0; i < n_strided; i++) {
+        unsigned bits = (rem + (n_strided - i) - 1) / (n_strided - i);  // balanced split
+        pl.log_A[pl.n_pass++] = bits;
+        rem -= bits;
+    }
+    return pl;
+}
+
+template <bool DIT>
+static void run_passes(hipStream_t st, const NttTables& tb, bool inverse_roots, const uint64_t* src,
+                       size_t src_stride, size_t src_z_stride, uint64_t* dst, size_t dst_stride,
+                       size_t dst_z_stride, uint32_t n_cols, uint32_t n_z, unsigned log_n, const uint64_t* scale,
+                       size_t scale_z_stride, uint64_t final_scale) {
+    if (log_n == 0) {  // length-1 transform: copy with scaling
+        // handled by a 1-element "contiguous" pass with log_A = 0
+    }
+    Plan pl = make_plan(log_n);
+    const uint64_t* const* roots = inverse_roots ? tb.inv : tb.fwd;
+    // DIF order: strided passes from the largest sub-problem down, contiguous pass last.
+    // DIT order: contiguous pass first, strided passes with growing sub-problem.
+    // Sub-problem sizes: contiguous N = 2^c; strided pass i (i = 1..) N_i = 2^(c + bits_1 + ... + bits_i).
+    unsigned logN_of[8];
+    unsigned acc = pl.log_A[0];
+    logN_of[0] = acc;
+    for (unsigned i = 1; i < pl.n_pass; i++) {
+        acc += pl.log_A[i];
+        logN_of[i] = acc;
+    }
+    for (unsigned step = 0; step < pl.n_pass; step++) {
+        unsigned i = DIT ? step : (pl.n_pass - 1 - step);
+        const bool first = step == 0, last = step + 1 == pl.n_pass;
+        PassParams p{};
+        p.src = first ? src : dst;
+        p.src_stride = first ? src_stride : dst_stride;
+        p.src_z_stride = first ? src_z_stride : dst_z_stride;
+        p.dst = dst;
+        p.dst_stride = dst_stride;
+        p.dst_z_stride = dst_z_stride;
+        p.log_n = log_n;
+        p.log_N = logN_of[i];
+        p.log_A = pl.log_A[i];
+        p.tw = p.log_N >= 1 ? roots[p.log_N] : nullptr;
+        p.scale = first ? scale : nullptr;
+        p.scale_z_stride = scale_z_stride;
+        p.final_scale = last ? final_scale : 1;
+        unsigned tiles;
+        if (i == 0) {  // contiguous
+            p.log_T = 0;
+            p.log_Q = (log_n >= TILE_LOG) ? 0 : 0;
+            // pack several sub-problems into a tile when the transform is shorter than the tile
+            unsigned log_subs = log_n - p.log_A;  // sub-problems per column
+            unsigned q = TILE_LOG - p.log_A;
+            p.log_Q = q < log_subs ? q : log_subs;
+            tiles = 1u << (log_n - p.log_A - p.log_Q);
+        } else {
+            p.log_Q = 0;
+            unsigned log_M = p.log_N - p.log_A;
+            unsigned t = TILE_LOG - p.log_A;
+            p.log_T = t < log_M ? t : log_M;
+            tiles = 1u << (log_n - p.log_A - p.log_T);
+        }
+        hipLaunchKernelGGL(k_ntt_pass<DIT>, dim3(tiles, n_cols, n_z), dim3(NTT_THREADS), 0, st, p);
+    }
+}
+
+void launch_intt_dif(hipStream_t st, const NttTables& tb, const uint64_t* src, size_t src_stride, uint64_t* dst,
+                     size_t dst_stride, uint32_t n_cols, unsigned log_n) {
+    if (!n_cols) return;
+    uint64_t n_inv = gl::inv((uint64_t)1 << log_n);
+    run_passes<false>(st, tb, true, src, src_stride, 0, dst, dst_stride, 0, n_cols, 1, log_n, nullptr, 0, n_inv);
+}
+
+void launch_lde_dit(hipStream_t st, const NttTables& tb, const uint64_t* coeffs_br, size_t src_stride,
+                    uint64_t* dst, size_t dst_stride, uint32_t n_cols, unsigned log_n, unsigned rate_bits,
+                    const uint64_t* scale_br) {
+    if (!n_cols) return;
+    const size_t n = (size_t)1 << log_n;
+    run_passes<true>(st, tb, false, coeffs_br, src_stride, 0, dst, dst_stride, n, n_cols, 1u << rate_bits, log_n,
+                     scale_br, n, 1);
+}
+
+void launch_ntt_dif_fwd(hipStream_t st, const NttTables& tb, uint64_t* data, size_t stride, uint32_t n_cols,
+                        unsigned log_n, bool inverse, const uint64_t* prescale_nat) {
+    if (!n_cols) return;
+    uint64_t fs = inverse ? gl::inv((uint64_t)1 << log_n) : 1;
+    run_passes<false>(st, tb, inverse, data, stride, 0, data, stride, 0, n_cols, 1, log_n, prescale_nat, 0, fs);
+}
+
+__global__ void k_bitrev_permute(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, size_t stride,
+                                 unsigned log_n, const uint64_t* __restrict__ postscale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> log_n) return;
+    const uint64_t* s = src + (size_t)blockIdx.y * stride;
+    uint64_t* d = dst + (size_t)blockIdx.y * stride;
+    uint64_t v = s[gl::bitrev32((uint32_t)i, log_n)];
+    if (postscale) v = gl::mul(v, postscale[i]);
+    d[i] = v;
+}
+void launch_bitrev_permute(hipStream_t st, const uint64_t* src, uint64_t* dst, size_t stride, uint32_t n_cols,
+                           unsigned log_n, const uint64_t* postscale_nat) {
+    if (!n_cols) return;
+    size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(k_bitrev_permute, dim3((unsigned)((n + 255) / 256), n_cols), dim3(256), 0, st, src, dst, stride,
+                       log_n, postscale_nat);
+}
+
+// table[e] = root^e for e in [0, 2^log_size)
+__global__ void k_fill_powers(uint64_t* __restrict__ table, size_t count, uint64_t base, uint64_t first) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    table[i] = gl::mul(first, gl::pow(base, i));
+}
+void launch_fill_powers(hipStream_t st, uint64_t* d_table, size_t count, uint64_t base, uint64_t first) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_fill_powers, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, d_table, count, base,
+                       first);
+}
+void launch_fill_root_table(hipStream_t st, uint64_t* d_table, unsigned log_size, uint64_t root) {
+    launch_fill_powers(st, d_table, (size_t)1 << log_size, root, 1);
+}
+
+// scale_br[r][j] = (shift * w_L^r)^bitrev_n(j), L = n << rate_bits
+__global__ void k_fill_coset_scale_br(uint64_t* __restrict__ table, unsigned log_n, unsigned rate_bits,
+                                      uint64_t shift, uint64_t w_L) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)1 << log_n;
+    if (i >= (n << rate_bits)) return;
+    uint32_t r = (uint32_t)(i >> log_n), j = (uint32_t)(i & (n - 1));
+    uint64_t base = gl::mul(shift, gl::pow(w_L, r));
+    table[i] = gl::pow(base, gl::bitrev32(j, log_n));
+}
+void launch_fill_coset_scale_br(hipStream_t st, uint64_t* d_table, unsigned log_n, unsigned rate_bits,
+                                uint64_t shift) {
+    size_t total = (size_t)1 << (log_n + rate_bits);
+    uint64_t w_L = gl::root_of_unity(log_n + rate_bits);
+    hipLaunchKernelGGL(k_fill_coset_scale_br, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_table, log_n,
+                       rate_bits, shift, w_L);
+}
+
+}  // namespace nlx

@@ -1,0 +1,181 @@
+// Polynomial helper kernels: extension-field evaluation of bit-reversed coefficient columns,
+// row / Merkle-path gathers for query openings, de-interleaving.
+//
+// Replaces plonky2::plonk::proof::OpeningSet::new -> PolynomialCoeffs::eval (SURVEY.md §8a row
+// a10) and the row / sibling lookups of MerkleTree::prove + PolynomialBatch::get_lde_values
+// used by fri_prover_query_rounds (row a11).
+#include <hip/hip_runtime.h>
+#include "gl.hpp"
+#include "launch.hpp"
+#include "poly.hpp"
+
+namespace nlx {
+
+// ---- evaluation at an extension point ----
+// Coefficients are stored bit-reversed: position j holds c_{bitrev(j)}.  Then
+//   p(z) = E(whole array),  E(block of size 2m) = E(first half) + z^(n/(2m)) * E(second half),
+// i.e. a pairwise tree reduction whose level-l multiplier is z^(n / 2^(l+1)).  zpow[k] = z^(2^k).
+//
+// Stage 1: each workgroup folds a chunk of EVAL_CHUNK base-field coefficients to one
+// extension element.  Stage 2 folds the per-chunk partials.
+constexpr unsigned EVAL_CHUNK_LOG = 11;
+constexpr unsigned EVAL_CHUNK = 1u << EVAL_CHUNK_LOG;
+
+template <bool EXT_IN>
+__global__ __launch_bounds__(256) void k_eval_fold(const uint64_t* __restrict__ in, size_t in_stride,
+                                                   unsigned log_count,  // elements per column = 2^log_count
+                                                   unsigned level0,     // tree level of the first fold
+                                                   unsigned log_n, const uint64_t* __restrict__ zpow,
+                                                   uint64_t* __restrict__ out, size_t out_stride) {
+    __shared__ uint64_t sa[EVAL_CHUNK], sb[EVAL_CHUNK];
+    const unsigned tid = threadIdx.x;
+    const unsigned log_chunk = log_count < EVAL_CHUNK_LOG ? log_count : EVAL_CHUNK_LOG;
+    const uint32_t chunk = 1u << log_chunk;
+    const size_t elem0 = (size_t)blockIdx.x << log_chunk;
+    const uint64_t* col = in + (size_t)blockIdx.y * in_stride;
+    for (uint32_t i = tid; i < chunk; i += 256) {
+        if (EXT_IN) {
+            sa[i] = col[2 * (elem0 + i)];
+            sb[i] = col[2 * (elem0 + i) + 1];
+        } else {
+            sa[i] = col[elem0 + i];
+            sb[i] = 0;
+        }
+    }
+    __syncthreads();
+    uint32_t cur = chunk;
+    for (unsigned l = 0; l < log_chunk; l++) {
+        const unsigned level = level0 + l;
+        const gl::Ext y = gl::Ext{zpow[2 * (log_n - 1 - level)], zpow[2 * (log_n - 1 - level) + 1]};
+        const uint32_t half = cur >> 1;
+        // pairs are adjacent (2i, 2i+1); results are compacted to position i.  Two-phase
+        // (read, barrier, write) keeps the in-place compaction race-free.
+        gl::Ext res[EVAL_CHUNK / 2 / 256 > 0 ? EVAL_CHUNK / 2 / 256 : 1];
+        int cnt = 0;
+        for (uint32_t i = tid; i < half; i += 256) {
+            gl::Ext a{sa[2 * i], sb[2 * i]}, b{sa[2 * i + 1], sb[2 * i + 1]};
+            res[cnt++] = gl::add(a, gl::mul(b, y));
+        }
+        __syncthreads();
+        cnt = 0;
+        for (uint32_t i = tid; i < half; i += 256) {
+            sa[i] = res[cnt].a;
+            sb[i] = res[cnt].b;
+            cnt++;
+        }
+        __syncthreads();
+        cur = half;
+    }
+    if (tid == 0) {
+        uint64_t* o = out + (size_t)blockIdx.y * out_stride + 2 * (size_t)blockIdx.x;
+        o[0] = sa[0];
+        o[1] = sb[0];
+    }
+}
+
+// zpow[k] = z^(2^k), k in [0, count)
+__global__ void k_zpow(const uint64_t* __restrict__ z, unsigned count, uint64_t* __restrict__ zpow) {
+    if (threadIdx.x | blockIdx.x) return;
+    gl::Ext v{z[0], z[1]};
+    for (unsigned k = 0; k < count; k++) {
+        zpow[2 * k] = v.a;
+        zpow[2 * k + 1] = v.b;
+        v = gl::mul(v, v);
+    }
+}
+
+size_t eval_scratch_words(uint32_t n_cols, unsigned log_n) {
+    // zpow (2 * 64) + two partial buffers
+    size_t partial = log_n > EVAL_CHUNK_LOG ? ((size_t)1 << (log_n - EVAL_CHUNK_LOG)) : 1;
+    return 128 + 2 * (size_t)n_cols * 2 * partial;
+}
+
+void launch_eval_br(hipStream_t st, const uint64_t* d_coeffs_br, size_t stride, uint32_t n_cols, unsigned log_n,
+                    const uint64_t* d_z, uint64_t* d_out_ext, uint64_t* d_scratch) {
+    if (!n_cols) return;
+    uint64_t* zpow = d_scratch;
+    size_t partial = log_n > EVAL_CHUNK_LOG ? ((size_t)1 << (log_n - EVAL_CHUNK_LOG)) : 1;
+    uint64_t* bufA = d_scratch + 128;
+    uint64_t* bufB = bufA + (size_t)n_cols * 2 * partial;
+    hipLaunchKernelGGL(k_zpow, dim3(1), dim3(1), 0, st, d_z, log_n ? log_n : 1, zpow);
+    if (log_n <= EVAL_CHUNK_LOG) {
+        hipLaunchKernelGGL(k_eval_fold<false>, dim3(1, n_cols), dim3(256), 0, st, d_coeffs_br, stride, log_n, 0u, log_n,
+                           zpow, d_out_ext, (size_t)2);
+        return;
+    }
+    unsigned log_count = log_n - EVAL_CHUNK_LOG;  // partials per column after stage 1
+    hipLaunchKernelGGL(k_eval_fold<false>, dim3(1u << log_count, n_cols), dim3(256), 0, st, d_coeffs_br, stride, log_n,
+                       0u, log_n, zpow, bufA, (size_t)2 << log_count);
+    unsigned level = EVAL_CHUNK_LOG;
+    uint64_t* src = bufA;
+    uint64_t* dst = bufB;
+    while (log_count > EVAL_CHUNK_LOG) {
+        unsigned next = log_count - EVAL_CHUNK_LOG;
+        hipLaunchKernelGGL(k_eval_fold<true>, dim3(1u << next, n_cols), dim3(256), 0, st, src, (size_t)2 << log_count,
+                           log_count, level, log_n, zpow, dst, (size_t)2 << next);
+        level += EVAL_CHUNK_LOG;
+        log_count = next;
+        uint64_t* t = src; src = dst; dst = t;
+    }
+    hipLaunchKernelGGL(k_eval_fold<true>, dim3(1, n_cols), dim3(256), 0, st, src, (size_t)2 << log_count, log_count,
+                       level, log_n, zpow, d_out_ext, (size_t)2);
+}
+
+// ---- query openings ----
+// leaf index l (plonky2 order = bit-reversed LDE index) -> position in the coset-major table
+__device__ __forceinline__ size_t leaf_to_pos(uint64_t leaf, unsigned log_n, unsigned rate_bits) {
+    uint32_t hi = (uint32_t)(leaf >> log_n), lo = (uint32_t)(leaf & (((uint64_t)1 << log_n) - 1));
+    return ((size_t)gl::bitrev32(hi, rate_bits) << log_n) + gl::bitrev32(lo, log_n);
+}
+
+__global__ void k_gather_rows(const uint64_t* __restrict__ lde, size_t col_stride, uint32_t n_cols, unsigned log_n,
+                              unsigned rate_bits, const uint64_t* __restrict__ idx, size_t k,
+                              uint64_t* __restrict__ rows_out) {
+    size_t q = blockIdx.x;
+    if (q >= k) return;
+    size_t pos = leaf_to_pos(idx[q], log_n, rate_bits);
+    for (uint32_t c = threadIdx.x; c < n_cols; c += blockDim.x) rows_out[q * n_cols + c] = lde[(size_t)c * col_stride + pos];
+}
+void launch_gather_rows(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols, unsigned log_n,
+                        unsigned rate_bits, const uint64_t* d_idx, size_t k, uint64_t* d_rows_out) {
+    if (!k || !n_cols) return;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)k), dim3(128), 0, st, d_lde, col_stride, n_cols, log_n, rate_bits,
+                       d_idx, k, d_rows_out);
+}
+
+// siblings bottom-up from level-major digests
+__global__ void k_gather_paths(const uint64_t* __restrict__ digests, unsigned log_leaves, unsigned cap_height,
+                               const uint64_t* __restrict__ idx, size_t k, uint64_t* __restrict__ paths_out) {
+    size_t q = blockIdx.x;
+    unsigned path_len = log_leaves - cap_height;
+    unsigned lvl = threadIdx.x >> 2, w = threadIdx.x & 3;
+    if (q >= k || lvl >= path_len) return;
+    // offset of level `lvl` in words: 4 * (L + L/2 + ... ) = 4 * (2L - L >> (lvl-1)) ...
+    size_t L = (size_t)1 << log_leaves;
+    size_t off = 4 * (2 * L - (2 * L >> lvl));
+    size_t node = (idx[q] >> lvl) ^ 1;
+    paths_out[(q * path_len + lvl) * 4 + w] = digests[off + node * 4 + w];
+}
+void launch_gather_paths(hipStream_t st, const uint64_t* d_digests, unsigned log_leaves, unsigned cap_height,
+                         const uint64_t* d_idx, size_t k, uint64_t* d_paths_out) {
+    if (!k || log_leaves <= cap_height) return;
+    hipLaunchKernelGGL(k_gather_paths, dim3((unsigned)k), dim3(128), 0, st, d_digests, log_leaves, cap_height, d_idx,
+                       k, d_paths_out);
+}
+
+// whole table in plonky2 leaf order, row-major (tests / debugging only)
+__global__ void k_table_to_leaves(const uint64_t* __restrict__ lde, size_t col_stride, uint32_t n_cols,
+                                  unsigned log_n, unsigned rate_bits, uint64_t* __restrict__ leaves) {
+    size_t leaf = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >> (log_n + rate_bits)) return;
+    size_t pos = leaf_to_pos(leaf, log_n, rate_bits);
+    for (uint32_t c = 0; c < n_cols; c++) leaves[leaf * n_cols + c] = lde[(size_t)c * col_stride + pos];
+}
+void launch_table_to_leaves(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols,
+                            unsigned log_n, unsigned rate_bits, uint64_t* d_leaves) {
+    size_t rows = (size_t)1 << (log_n + rate_bits);
+    hipLaunchKernelGGL(k_table_to_leaves, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, d_lde, col_stride,
+                       n_cols, log_n, rate_bits, d_leaves);
+}
+
+}  // namespace nlx

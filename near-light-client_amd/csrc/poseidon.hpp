@@ -1,0 +1,104 @@
+// Poseidon-12 permutation over Goldilocks for gfx950 (one sponge state per lane, 12 x u64 in
+// VGPRs, round constants read through the scalar cache: every lane of a wave is in the same
+// round, so the constant operand is wave-uniform and costs no vector memory traffic).
+//
+// Replaces plonky2::hash::poseidon::Poseidon::poseidon and hashing::{hash_n_to_m_no_pad, compress}
+// (plonky2 0.1.4 @ d2598bd, /root/reference/Cargo.lock:4864-4866).
+// Schedule: 4 full rounds, 22 partial rounds, 4 full rounds; S-box x^7;
+// MDS = circ(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,...,0).
+#pragma once
+#include "gl.hpp"
+#include "poseidon_constants.inc"
+
+namespace poseidon {
+
+constexpr int WIDTH = 12;
+constexpr int RATE = 8;
+constexpr int N_ROUNDS = 30;
+constexpr int HALF_FULL = 4;
+constexpr int N_PARTIAL = 22;
+
+#if defined(__HIPCC__)
+__constant__ static const uint64_t RC_DEV[360] = NLX_POSEIDON_ROUND_CONSTANTS_INIT;
+#endif
+static const uint64_t RC_HOST[360] = NLX_POSEIDON_ROUND_CONSTANTS_INIT;
+
+GL_HD const uint64_t* rc_table() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return RC_DEV;
+#else
+    return RC_HOST;
+#endif
+}
+
+GL_HD uint64_t sbox7(uint64_t x) {
+    uint64_t x2 = gl::mul_loose(x, x);
+    uint64_t x4 = gl::mul_loose(x2, x2);
+    uint64_t x3 = gl::mul_loose(x, x2);
+    return gl::mul_loose(x3, x4);
+}
+
+// Linear layer on loose inputs.  Each lane is split into 32-bit halves; the 12 products by the
+// (<= 6-bit) circulant entries accumulate in u64 without overflow (12 * 2^32 * 41 < 2^42), then
+// lo + 2^32*hi is folded once: a 96-bit reduction instead of twelve 128-bit ones.
+GL_HD void mds_layer(uint64_t (&s)[12]) {
+    constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    uint32_t lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        lo[i] = (uint32_t)s[i];
+        hi[i] = (uint32_t)(s[i] >> 32);
+    }
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        uint64_t al = 0, ah = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            al += (uint64_t)lo[(i + r) % 12] * C[i];
+            ah += (uint64_t)hi[(i + r) % 12] * C[i];
+        }
+        if (r == 0) {
+            al += (uint64_t)lo[0] * 8u;
+            ah += (uint64_t)hi[0] * 8u;
+        }
+        // value = al + ah * 2^32, with ah < 2^42
+        uint64_t l = al + (ah << 32);
+        uint64_t h = (ah >> 32) + (l < al ? 1u : 0u);  // < 2^11
+        uint64_t t1 = (h << 32) - h;                    // h * (2^32 - 1)
+        uint64_t res = l + t1;
+        if (res < t1) res += gl::EPS;
+        s[r] = res;
+    }
+}
+
+// In-place permutation; input loose, output loose.
+GL_HD void permute_loose(uint64_t (&s)[12]) {
+    const uint64_t* rc = rc_table();
+#pragma unroll 1
+    for (int r = 0; r < HALF_FULL; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox7(gl::add_loose(s[i], rc[r * 12 + i]));
+        mds_layer(s);
+    }
+#pragma unroll 1
+    for (int r = HALF_FULL; r < HALF_FULL + N_PARTIAL; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl::add_loose(s[i], rc[r * 12 + i]);
+        s[0] = sbox7(s[0]);
+        mds_layer(s);
+    }
+#pragma unroll 1
+    for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox7(gl::add_loose(s[i], rc[r * 12 + i]));
+        mds_layer(s);
+    }
+}
+
+GL_HD void permute(uint64_t (&s)[12]) {
+    permute_loose(s);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
+}
+
+}  // namespace poseidon

@@ -1,0 +1,146 @@
+"""ORACLE - TEST INFRASTRUCTURE ONLY.  ctypes wrapper over oracle/liboracle.so.
+
+May be imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+(never by the product package).  Builds the library with `make` on first use.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+P = 0xFFFFFFFF00000001
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+    return _LIB
+
+
+_dll = None
+u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+def dll():
+    global _dll
+    if _dll is None:
+        _dll = ctypes.CDLL(build())
+        _dll.orc_merkle_digest_words.restype = ctypes.c_size_t
+        _dll.orc_merkle_digest_words.argtypes = [ctypes.c_size_t, ctypes.c_uint]
+        _dll.orc_merkle_verify.restype = ctypes.c_int
+    return _dll
+
+
+def _p(a):
+    return a.ctypes.data_as(u64p) if a is not None else None
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def poseidon_permute(states):
+    s = _u64(states).copy().reshape(-1, 12)
+    for i in range(s.shape[0]):
+        dll().orc_poseidon_permute(_p(s[i]))
+    return s
+
+
+def hash_or_noop(xs):
+    x = _u64(xs)
+    out = np.zeros(4, dtype=np.uint64)
+    dll().orc_hash_or_noop(_p(x), ctypes.c_size_t(x.size), _p(out))
+    return out
+
+
+def two_to_one(l, r):
+    out = np.zeros(4, dtype=np.uint64)
+    dll().orc_two_to_one(_p(_u64(l)), _p(_u64(r)), _p(out))
+    return out
+
+
+def fft(a, inverse=False, shift=1):
+    x = _u64(a).copy()
+    log_n = x.size.bit_length() - 1
+    d = dll()
+    if shift in (0, 1):
+        (d.orc_ifft if inverse else d.orc_fft)(_p(x), ctypes.c_uint(log_n))
+    else:
+        (d.orc_coset_ifft if inverse else d.orc_coset_fft)(_p(x), ctypes.c_uint(log_n), ctypes.c_uint64(shift))
+    return x
+
+
+def merkle_build(leaves, cap_height):
+    lv = _u64(leaves)
+    n, ln = lv.shape
+    words = dll().orc_merkle_digest_words(n, cap_height)
+    dig = np.zeros(words, dtype=np.uint64)
+    cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+    dll().orc_merkle_build(_p(lv), ctypes.c_size_t(n), ctypes.c_size_t(ln), ctypes.c_uint(cap_height), _p(dig), _p(cap))
+    return dig, cap
+
+
+def merkle_prove(digests, n_leaves, cap_height, idx):
+    plen = (n_leaves.bit_length() - 1) - cap_height
+    out = np.zeros((max(plen, 0), 4), dtype=np.uint64)
+    dll().orc_merkle_prove(_p(_u64(digests)), ctypes.c_size_t(n_leaves), ctypes.c_uint(cap_height),
+                           ctypes.c_size_t(idx), _p(out))
+    return out
+
+
+def merkle_verify(leaf, idx, siblings, cap, cap_height):
+    lf, sb, cp = _u64(leaf), _u64(siblings), _u64(cap)
+    return bool(dll().orc_merkle_verify(_p(lf), ctypes.c_size_t(lf.size), ctypes.c_size_t(idx), _p(sb),
+                                        ctypes.c_uint(sb.size // 4), _p(cp), ctypes.c_uint(cap_height)))
+
+
+def commit(data, rate_bits, cap_height, from_coeffs=False):
+    """returns dict(coeffs, leaves, digests, cap) following PolynomialBatch::from_values/from_coeffs."""
+    v = _u64(data)
+    n_cols, n = v.shape
+    log_n = n.bit_length() - 1
+    L = n << rate_bits
+    coeffs = np.zeros((n_cols, n), dtype=np.uint64)
+    leaves = np.zeros((L, n_cols), dtype=np.uint64)
+    dig = np.zeros(dll().orc_merkle_digest_words(L, cap_height), dtype=np.uint64)
+    cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+    if from_coeffs:
+        coeffs[:] = v
+        dll().orc_commit_from_coeffs(_p(v), ctypes.c_size_t(n_cols), ctypes.c_uint(log_n), ctypes.c_uint(rate_bits),
+                                     ctypes.c_uint(cap_height), _p(leaves), _p(dig), _p(cap))
+    else:
+        dll().orc_commit_from_values(_p(v), ctypes.c_size_t(n_cols), ctypes.c_uint(log_n), ctypes.c_uint(rate_bits),
+                                     ctypes.c_uint(cap_height), _p(coeffs), _p(leaves), _p(dig), _p(cap))
+    return {"coeffs": coeffs, "leaves": leaves, "digests": dig, "cap": cap}
+
+
+class Challenger:
+    class _S(ctypes.Structure):
+        _fields_ = [("state", ctypes.c_uint64 * 12), ("in_buf", ctypes.c_uint64 * 8), ("n_in", ctypes.c_uint),
+                    ("out_buf", ctypes.c_uint64 * 8), ("n_out", ctypes.c_uint)]
+
+    def __init__(self):
+        self.s = self._S()
+        dll().orc_ch_init(ctypes.byref(self.s))
+        dll().orc_ch_challenge.restype = ctypes.c_uint64
+
+    def observe(self, x):
+        dll().orc_ch_observe(ctypes.byref(self.s), ctypes.c_uint64(int(x)))
+
+    def challenge(self):
+        return int(dll().orc_ch_challenge(ctypes.byref(self.s)))
+
+
+def eval_poly_ext(coeffs, z):
+    """Horner evaluation of base-field coefficients at z = (a, b) in F_p[X]/(X^2-7) (python ints)."""
+    a, b = 0, 0
+    za, zb = int(z[0]), int(z[1])
+    for c in reversed([int(x) for x in coeffs]):
+        na = (a * za + 7 * b * zb + c) % P
+        nb = (a * zb + b * za) % P
+        a, b = na, nb
+    return a, b

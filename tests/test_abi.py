@@ -1,0 +1,53 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/nlx.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "nlx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nlx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(nlx):
+    dll = ctypes.CDLL(os.path.join(ROOT, "near-light-client_amd", "libnlx.so"))
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(dll, name), "libnlx.so does not export %s" % name
+
+
+def test_python_binding_covers_header(nlx):
+    assert sorted(nlx.lib.SIGNATURES) == _declared_symbols()
+
+
+def test_version_and_strerror(nlx):
+    assert nlx.lib.dll.nlx_version() >= 1
+    assert nlx.lib.dll.nlx_strerror(0) == b"ok"
+    assert nlx.lib.dll.nlx_strerror(-5) == b"unsupported"
+
+
+def test_no_cpu_fallback(nlx):
+    """Without a gfx950 device context creation must fail loudly, never fall back to the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(nlx.NlxError):
+        nlx.Context(0)
+
+
+def test_product_does_not_reference_oracle():
+    """The shipped package and ABI must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "near-light-client_amd")
+    for base, _, files in os.walk(pkg):
+        if ".obj" in base:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".inc")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "oracle_py" not in text and "liboracle" not in text and "orc_" not in text, f

@@ -1,0 +1,161 @@
+"""GPU parity tests (through the C ABI) for the hashing / NTT / commitment primitives:
+HIP path vs the CPU oracle on seeded inputs, and vs the committed golden fixtures."""
+import numpy as np
+import pytest
+
+from conftest import P, rand_field
+
+pytestmark = pytest.mark.gpu
+GEN = 14293326489335486720
+
+
+def test_poseidon_kats_gpu(nlx, ctx, golden):
+    ins = np.array([k["in"] for k in golden["poseidon_kat"]], dtype=np.uint64)
+    out = nlx.poseidon_permute(ctx, ins)
+    for k, o in zip(golden["poseidon_kat"], out):
+        assert [int(x) for x in o] == k["out"], k["source"]
+
+
+def test_poseidon_batch_vs_oracle(nlx, ctx, orc):
+    rng = np.random.default_rng(7)
+    n = 4099  # ragged: not a multiple of the workgroup size
+    st = rand_field(rng, (n, 12))
+    st[0] = P - 1
+    st[1] = 0
+    st[2, :6] = 0xFFFFFFFF  # 2^32-1: carry edge of the reduction
+    st[3] = 0xFFFFFFFF00000000
+    got = nlx.poseidon_permute(ctx, st)
+    want = orc.poseidon_permute(st)
+    assert np.array_equal(got, want)
+    assert (got < np.uint64(P)).all()
+
+
+def test_hash_rows_lengths(nlx, ctx, orc, golden):
+    for case in golden["hash_or_noop"]:
+        if not case["in"]:
+            continue
+        rows = np.array([case["in"]] * 3, dtype=np.uint64)
+        out = nlx.hash_rows(ctx, rows)
+        assert out[0].tolist() == case["out"] and out[2].tolist() == case["out"]
+    rng = np.random.default_rng(8)
+    for row_len in (1, 3, 4, 5, 7, 8, 9, 16, 20, 135):
+        rows = rand_field(rng, (130, row_len))
+        got = nlx.hash_rows(ctx, rows)
+        want = np.array([orc.hash_or_noop(r) for r in rows])
+        assert np.array_equal(got, want), row_len
+
+
+def test_merkle_tree(nlx, ctx, orc, golden):
+    for key in ("merkle", "merkle_noop"):
+        m = golden[key]
+        t = nlx.MerkleTree(ctx, np.array(m["leaves"], dtype=np.uint64), m["cap_height"])
+        flat = [w for lvl in m["levels"] for d in lvl for w in d]
+        assert [int(x) for x in t.digests] == flat
+        assert t.cap.tolist() == m["levels"][-1]
+    rng = np.random.default_rng(9)
+    for (n_leaves, leaf_len, cap_h) in ((1, 5, 0), (2, 9, 1), (1024, 135, 4), (4096, 20, 0), (256, 2, 4)):
+        leaves = rand_field(rng, (n_leaves, leaf_len))
+        t = nlx.MerkleTree(ctx, leaves, cap_h)
+        dig, cap = orc.merkle_build(leaves, cap_h)
+        assert np.array_equal(t.digests, dig)
+        assert np.array_equal(t.cap, cap)
+        idx = n_leaves // 3
+        assert orc.merkle_verify(leaves[idx], idx, t.prove(idx), t.cap, cap_h)
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 3, 8, 12, 13, 14, 16, 17])
+def test_ntt_vs_oracle(nlx, ctx, orc, log_n):
+    rng = np.random.default_rng(100 + log_n)
+    n_cols = 3
+    a = rand_field(rng, (n_cols, 1 << log_n))
+    fwd = nlx.ntt(ctx, a)
+    assert np.array_equal(fwd[1], orc.fft(a[1]))
+    assert np.array_equal(nlx.ntt(ctx, fwd, inverse=True), a)
+    cf = nlx.ntt(ctx, a, coset_shift=GEN)
+    assert np.array_equal(cf[2], orc.fft(a[2], shift=GEN))
+    assert np.array_equal(nlx.ntt(ctx, cf, inverse=True, coset_shift=GEN), a)
+
+
+def test_ntt_linearity_large(nlx, ctx):
+    """size-independent property at a size the oracle is too slow for: NTT(a+b) = NTT(a)+NTT(b), roundtrip."""
+    rng = np.random.default_rng(5)
+    log_n = 20
+    a = rand_field(rng, (1, 1 << log_n))
+    b = rand_field(rng, (1, 1 << log_n))
+    s = ((a.astype(object) + b.astype(object)) % P).astype(np.uint64)
+    fa, fb, fs = nlx.ntt(ctx, a), nlx.ntt(ctx, b), nlx.ntt(ctx, s)
+    assert np.array_equal(((fa.astype(object) + fb.astype(object)) % P).astype(np.uint64), fs)
+    assert np.array_equal(nlx.ntt(ctx, fa, inverse=True), a)
+    # value at index 0 is the coefficient sum
+    assert int(fa[0, 0]) == int(a.astype(object).sum() % P)
+
+
+def test_commit_golden(nlx, ctx, golden):
+    for key in ("commit", "commit_wide"):
+        g = golden[key]
+        pb = nlx.PolynomialBatch.from_values(ctx, np.array(g["values"], dtype=np.uint64), g["rate_bits"], g["cap_height"])
+        assert pb.cap.tolist() == g["cap"]
+        assert pb.coeffs().tolist() == g["coeffs"]
+        assert pb.leaves().tolist() == g["leaves"]
+        pc = nlx.PolynomialBatch.from_coeffs(ctx, np.array(g["coeffs"], dtype=np.uint64), g["rate_bits"], g["cap_height"])
+        assert pc.cap.tolist() == g["cap"]
+
+
+@pytest.mark.parametrize("shape", [(135, 10, 3, 4), (20, 12, 3, 4), (16, 13, 3, 4), (2, 14, 1, 4), (84, 9, 3, 0),
+                                   (5, 4, 3, 4), (1, 0, 3, 1), (7, 15, 1, 2)])
+def test_commit_vs_oracle(nlx, ctx, orc, shape):
+    n_cols, log_n, rate_bits, cap_h = shape
+    rng = np.random.default_rng(sum(shape))
+    vals = rand_field(rng, (n_cols, 1 << log_n))
+    pb = nlx.PolynomialBatch.from_values(ctx, vals, rate_bits, cap_h)
+    ref = orc.commit(vals, rate_bits, cap_h)
+    assert np.array_equal(pb.cap, ref["cap"])
+    assert np.array_equal(pb.coeffs(), ref["coeffs"])
+    assert np.array_equal(pb.digests(), ref["digests"])
+    L = 1 << (log_n + rate_bits)
+    idx = np.unique(rng.integers(0, L, size=28).astype(np.uint64))
+    rows, paths = pb.open_rows(idx)
+    for j, i in enumerate(idx):
+        assert np.array_equal(rows[j], ref["leaves"][int(i)])
+        assert np.array_equal(paths[j], orc.merkle_prove(ref["digests"], L, cap_h, int(i)))
+        assert orc.merkle_verify(rows[j], int(i), paths[j], pb.cap, cap_h)
+    # openings at an extension point
+    zeta = (int(rand_field(rng, 1)[0]), int(rand_field(rng, 1)[0]))
+    ev = pb.eval_at(zeta)
+    for c in (0, n_cols - 1):
+        assert tuple(int(x) for x in ev[c]) == orc.eval_poly_ext(ref["coeffs"][c], zeta)
+
+
+def test_commit_large_roundtrip_properties(nlx, ctx, orc):
+    """BASELINE-size table (135 x 2^16, rate 8): properties that need no full oracle run."""
+    rng = np.random.default_rng(77)
+    n_cols, log_n, rate_bits, cap_h = 135, 16, 3, 4
+    vals = rand_field(rng, (n_cols, 1 << log_n))
+    pb = nlx.PolynomialBatch.from_values(ctx, vals, rate_bits, cap_h)
+    # (1) coefficients invert back to the values (oracle fft on 2 columns)
+    co = pb.coeffs()
+    for c in (0, 134):
+        assert np.array_equal(orc.fft(co[c]), vals[c])
+    # (2) opened rows are the polynomial evaluated at g*w^bitrev(idx) and verify against the cap
+    L = 1 << (log_n + rate_bits)
+    idx = np.array([0, 1, L // 2 + 3, L - 1, 12345], dtype=np.uint64)
+    rows, paths = pb.open_rows(idx)
+    w = pow(7277203076849721926, 1 << (32 - log_n - rate_bits), P)
+    for j, i in enumerate(idx):
+        br = int(format(int(i), "0%db" % (log_n + rate_bits))[::-1], 2)
+        x = GEN * pow(w, br, P) % P
+        assert orc.eval_poly_ext(co[5], (x, 0)) == (int(rows[j][5]), 0)
+        assert orc.merkle_verify(rows[j], int(i), paths[j], pb.cap, cap_h)
+    # (3) determinism
+    pb2 = nlx.PolynomialBatch.from_values(ctx, vals, rate_bits, cap_h)
+    assert np.array_equal(pb.cap, pb2.cap)
+
+
+def test_error_paths(nlx, ctx):
+    with pytest.raises(ValueError):
+        nlx.MerkleTree(ctx, np.zeros((3, 5), dtype=np.uint64), 0)
+    with pytest.raises(nlx.NlxError):
+        nlx.MerkleTree(ctx, np.zeros((4, 5), dtype=np.uint64), 3)
+    pb = nlx.PolynomialBatch.from_values(ctx, np.ones((2, 8), dtype=np.uint64), 3, 2)
+    with pytest.raises(nlx.NlxError):
+        pb.open_rows(np.array([64], dtype=np.uint64))
