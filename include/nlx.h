@@ -109,6 +109,96 @@ int32_t nlx_commit_get_leaves(nlx_commit* c, uint64_t* leaves_out);
 /* level-major digests as in nlx_merkle_build */
 int32_t nlx_commit_get_digests(nlx_commit* c, uint64_t* digests_out);
 
+/* ===================================================================================
+ * Whole-proof interface: plonky2::plonk::circuit_data / prover (a14) and its stages
+ * (a8 partial products, a9 quotient, a10 openings, a11 FRI), SURVEY.md §3.4.
+ * =================================================================================== */
+
+/* gate kinds understood by the constraint combiner (plonky2::gates::*) */
+#define NLX_GATE_NOOP 0          /* gates::noop::NoopGate */
+#define NLX_GATE_CONSTANT 1      /* gates::constant::ConstantGate { num_consts = param0 } */
+#define NLX_GATE_PUBLIC_INPUT 2  /* gates::public_input::PublicInputGate */
+#define NLX_GATE_ARITHMETIC 3    /* gates::arithmetic_base::ArithmeticGate { num_ops = param0 } */
+#define NLX_GATE_BASE_SUM 4      /* gates::base_sum::BaseSumGate<B = param0> { num_limbs = param1 } */
+#define NLX_GATE_POSEIDON 5      /* gates::poseidon::PoseidonGate */
+
+typedef struct {
+    uint32_t kind;
+    uint32_t selector_index; /* selector polynomial used by this gate (gates::selectors::SelectorsInfo) */
+    uint32_t group_start;    /* gate-index range [start, end) that shares the selector */
+    uint32_t group_end;
+    uint32_t index;          /* position in the sorted gate list = selector value on the gate's rows */
+    uint32_t param0, param1;
+} nlx_gate_desc;
+
+/* CommonCircuitData + CircuitConfig + FriParams, flattened (standard_recursion_config values in
+ * comments).  Same field order as the oracle's orc_circuit_desc. */
+typedef struct {
+    uint32_t degree_bits;
+    uint32_t num_wires;              /* 135 */
+    uint32_t num_routed_wires;       /* 80 */
+    uint32_t num_constants;          /* 2 (gate constants per row, selectors excluded) */
+    uint32_t num_challenges;         /* 2 */
+    uint32_t rate_bits;              /* 3 */
+    uint32_t cap_height;             /* 4 */
+    uint32_t quotient_degree_factor; /* 8 */
+    uint32_t num_partial_products;   /* 9 */
+    uint32_t fri_pow_bits;           /* 16 */
+    uint32_t fri_num_queries;        /* 28 */
+    uint32_t fri_arity_bits;         /* 4 */
+    uint32_t fri_final_poly_bits;    /* 5 */
+    uint32_t num_selectors;
+    uint32_t num_gates;
+    uint32_t num_public_inputs;
+    const nlx_gate_desc* gates;
+    const uint64_t* k_is;            /* num_routed_wires coset shifts (host pointer) */
+    uint64_t circuit_digest[4];      /* all zero: computed by nlx_circuit_build as plonky2 does */
+} nlx_circuit_desc;
+
+typedef struct nlx_circuit nlx_circuit;
+
+/* CircuitBuilder::build's prover data: commits the constants (selectors first, then gate
+ * constants; (num_selectors + num_constants) x n) and the sigma polynomials (num_routed_wires x n),
+ * both column-major subgroup evaluations, and keeps everything the prover needs resident in HBM. */
+int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint64_t* constants,
+                          const uint64_t* sigmas, nlx_circuit** out);
+void nlx_circuit_destroy(nlx_circuit* c);
+int32_t nlx_circuit_digest(const nlx_circuit* c, uint64_t out[4]);
+int32_t nlx_circuit_constants_sigmas_cap(const nlx_circuit* c, uint64_t* cap_out);
+size_t nlx_proof_max_bytes(const nlx_circuit* c);
+
+/* prove_with_partition_witness + ProofWithPublicInputs::to_bytes.
+ * wires: num_wires x n column-major (host or device).  proof_out: host buffer of proof_cap bytes.
+ * Fails with NLX_E_INVAL if the witness does not satisfy the circuit (quotient degree check). */
+int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, uint8_t* proof_out,
+                  size_t proof_cap, size_t* proof_len);
+
+/* Per-stage device time of the most recent nlx_prove on this circuit, in milliseconds
+ * (HIP events on the context's stream).  names_out receives static strings. */
+#define NLX_MAX_STAGES 24
+int32_t nlx_prove_stage_times(const nlx_circuit* c, uint32_t* n_stages, const char** names_out, float* ms_out);
+
+/* a11 fri_proof_of_work: smallest nonce w such that the Poseidon duplex of `state` with w written
+ * at `pos` has at least `bits` leading zero bits in output word 7. */
+int32_t nlx_pow_grind(nlx_ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t* nonce_out);
+
+/* ---- synthetic nearx-shaped workload (inputs only) ---- */
+typedef struct {
+    uint32_t log_n;
+    uint32_t num_public_inputs;
+    uint32_t pct_poseidon;    /* share of rows (percent) that are PoseidonGate rows */
+    uint32_t pct_arithmetic;
+    uint32_t pct_base_sum;
+    uint32_t pct_constant;    /* remaining rows are NoopGate */
+    uint64_t seed;
+} nlx_synth_params;
+/* number of gates / selector polynomials the generator will emit for these parameters */
+void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_selectors);
+/* Fills host buffers: gates[n_gates], k_is[80], constants[(n_selectors+2) x n], sigmas[80 x n],
+ * wires[135 x n], public_inputs[num_public_inputs].  The witness satisfies every constraint. */
+int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint64_t* k_is, uint64_t* constants,
+                          uint64_t* sigmas, uint64_t* wires, uint64_t* public_inputs);
+
 #ifdef __cplusplus
 }
 #endif

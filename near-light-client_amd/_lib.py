@@ -56,6 +56,19 @@ SIGNATURES = {
     "nlx_commit_eval_at": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_commit_get_leaves": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_commit_get_digests": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "nlx_circuit_build": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_void_pp]),
+    "nlx_circuit_destroy": (None, [ctypes.c_void_p]),
+    "nlx_circuit_digest": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "nlx_circuit_constants_sigmas_cap": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "nlx_proof_max_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "nlx_prove": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                   ctypes.POINTER(ctypes.c_size_t)]),
+    "nlx_prove_stage_times": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p,
+                                               ctypes.c_void_p]),
+    "nlx_pow_grind": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                       ctypes.POINTER(ctypes.c_uint64)]),
+    "nlx_synth_shape": (None, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
+    "nlx_synth_circuit": (ctypes.c_int32, [ctypes.c_void_p] * 7),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -20,7 +20,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-
 
 
 def _sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
 def _headers_mtime():

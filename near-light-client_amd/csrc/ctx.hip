@@ -67,13 +67,13 @@ int32_t nlx_ctx::ensure_tables(unsigned log_n) {
     return NLX_OK;
 }
 
-int32_t nlx_ctx::get_coset_scale(unsigned log_n, unsigned rate_bits, const uint64_t** out) {
-    uint32_t key = (log_n << 8) | rate_bits;
+int32_t nlx_ctx::get_coset_scale(unsigned log_n, unsigned rate_bits, const uint64_t** out, bool inverse) {
+    uint32_t key = (log_n << 8) | rate_bits | (inverse ? 0x80000000u : 0u);
     auto it = coset_scale.find(key);
     if (it == coset_scale.end()) {
         uint64_t* t = (uint64_t*)alloc(((size_t)8 << (log_n + rate_bits)));
         if (!t) return NLX_E_NOMEM;
-        nlx::launch_fill_coset_scale_br(stream, t, log_n, rate_bits, gl::GEN);
+        nlx::launch_fill_coset_scale_br(stream, t, log_n, rate_bits, gl::GEN, inverse);
         it = coset_scale.emplace(key, t).first;
     }
     *out = it->second;

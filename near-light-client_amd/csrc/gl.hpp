@@ -12,7 +12,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
-#if defined(__HIPCC__)
+#if defined(__HIP__)
+#include <hip/hip_runtime.h>
 #define GL_HD __host__ __device__ __forceinline__
 #else
 #define GL_HD inline

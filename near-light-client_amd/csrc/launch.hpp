@@ -40,7 +40,9 @@ void launch_bitrev_permute(hipStream_t st, const uint64_t* src, uint64_t* dst, s
                            unsigned log_n, const uint64_t* postscale_nat);
 void launch_fill_root_table(hipStream_t st, uint64_t* d_table, unsigned log_size, uint64_t root);
 void launch_fill_coset_scale_br(hipStream_t st, uint64_t* d_table, unsigned log_n, unsigned rate_bits,
-                                uint64_t shift);
+                                uint64_t shift, bool inverse);
+void launch_intt_dif_cosets(hipStream_t st, const NttTables& tb, uint64_t* data, uint32_t n_y, unsigned log_n,
+                            unsigned rate_bits, const uint64_t* post_scale_br);
 void launch_fill_powers(hipStream_t st, uint64_t* d_table, size_t count, uint64_t base, uint64_t first);
 
 }  // namespace nlx

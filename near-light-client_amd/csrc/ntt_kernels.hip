@@ -37,6 +37,8 @@ struct PassParams {
     const uint64_t* scale; // optional per-element factor applied on load (indexed like src within a z slice)
     size_t scale_z_stride;
     uint64_t final_scale;  // multiplied into every output (1 = none)
+    const uint64_t* post_scale;  // optional per-element factor applied on store (indexed like dst within a z slice)
+    size_t post_scale_z_stride;
     unsigned log_n;        // column length
     unsigned log_N;        // sub-problem size at this pass (A * M)
     unsigned log_A;        // transform length inside the tile
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
             if (e) v = gl::mul(v, tw_full(tw, e, half_N));
         }
         if (p.final_scale != 1) v = gl::mul(v, p.final_scale);
+        if (p.post_scale) v = gl::mul(v, p.post_scale[(size_t)blockIdx.z * p.post_scale_z_stride + g]);
         dst[g] = v;
     }
 }
@@ -173,7 +176,8 @@ template <bool DIT>
 static void run_passes(hipStream_t st, const NttTables& tb, bool inverse_roots, const uint64_t* src,
                        size_t src_stride, size_t src_z_stride, uint64_t* dst, size_t dst_stride,
                        size_t dst_z_stride, uint32_t n_cols, uint32_t n_z, unsigned log_n, const uint64_t* scale,
-                       size_t scale_z_stride, uint64_t final_scale) {
+                       size_t scale_z_stride, uint64_t final_scale, const uint64_t* post_scale = nullptr,
+                       size_t post_scale_z_stride = 0) {
     if (log_n == 0) {  // length-1 transform: copy with scaling
         // handled by a 1-element "contiguous" pass with log_A = 0
     }
@@ -206,6 +210,8 @@ static void run_passes(hipStream_t st, const NttTables& tb, bool inverse_roots, 
         p.scale = first ? scale : nullptr;
         p.scale_z_stride = scale_z_stride;
         p.final_scale = last ? final_scale : 1;
+        p.post_scale = last ? post_scale : nullptr;
+        p.post_scale_z_stride = post_scale_z_stride;
         unsigned tiles;
         if (i == 0) {  // contiguous
             p.log_T = 0;
@@ -240,6 +246,17 @@ void launch_lde_dit(hipStream_t st, const NttTables& tb, const uint64_t* coeffs_
     const size_t n = (size_t)1 << log_n;
     run_passes<true>(st, tb, false, coeffs_br, src_stride, 0, dst, dst_stride, n, n_cols, 1u << rate_bits, log_n,
                      scale_br, n, 1);
+}
+
+// Per-coset inverse transform of an LDE-shaped table [y][r][k] (in place): natural values ->
+// bit-reversed coefficients, scaled by 1/n and by post_scale_br[r][j] (the inverse coset powers).
+void launch_intt_dif_cosets(hipStream_t st, const NttTables& tb, uint64_t* data, uint32_t n_y, unsigned log_n,
+                            unsigned rate_bits, const uint64_t* post_scale_br) {
+    if (!n_y) return;
+    const size_t n = (size_t)1 << log_n;
+    uint64_t n_inv = gl::inv((uint64_t)1 << log_n);
+    run_passes<false>(st, tb, true, data, n << rate_bits, n, data, n << rate_bits, n, n_y, 1u << rate_bits, log_n,
+                      nullptr, 0, n_inv, post_scale_br, n);
 }
 
 void launch_ntt_dif_fwd(hipStream_t st, const NttTables& tb, uint64_t* data, size_t stride, uint32_t n_cols,
@@ -293,9 +310,13 @@ __global__ void k_fill_coset_scale_br(uint64_t* __restrict__ table, unsigned log
     table[i] = gl::pow(base, gl::bitrev32(j, log_n));
 }
 void launch_fill_coset_scale_br(hipStream_t st, uint64_t* d_table, unsigned log_n, unsigned rate_bits,
-                                uint64_t shift) {
+                                uint64_t shift, bool inverse) {
     size_t total = (size_t)1 << (log_n + rate_bits);
     uint64_t w_L = gl::root_of_unity(log_n + rate_bits);
+    if (inverse) {
+        shift = gl::inv(shift);
+        w_L = gl::inv(w_L);
+    }
     hipLaunchKernelGGL(k_fill_coset_scale_br, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_table, log_n,
                        rate_bits, shift, w_L);
 }

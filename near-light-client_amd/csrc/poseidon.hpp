@@ -18,7 +18,7 @@ constexpr int N_ROUNDS = 30;
 constexpr int HALF_FULL = 4;
 constexpr int N_PARTIAL = 22;
 
-#if defined(__HIPCC__)
+#if defined(__HIP__)
 __constant__ static const uint64_t RC_DEV[360] = NLX_POSEIDON_ROUND_CONSTANTS_INIT;
 #endif
 static const uint64_t RC_HOST[360] = NLX_POSEIDON_ROUND_CONSTANTS_INIT;

@@ -1,0 +1,677 @@
+// Host orchestration of a whole plonky2 proof on one MI355X (C ABI: nlx_circuit_build, nlx_prove).
+//
+// Replaces plonky2::plonk::prover::prove_with_partition_witness (after witness generation),
+// plonky2::plonk::circuit_builder::CircuitBuilder::build's constants/sigmas commitment and
+// util::serialization's ProofWithPublicInputs::to_bytes, reached
+// from nearx/src/test_utils.rs:29 (build) and :62 (prove).
+//
+// Division of labour: every O(n) stage runs on the GPU with tables
+// resident in HBM; the Fiat-Shamir transcript is ~120 strictly sequential Poseidon permutations
+// over a few KB and runs on the host, as it does in the reference - only
+// Merkle caps (512 B), openings (~4.5 KB), the final polynomial and the query answers cross
+// PCIe.  It is not a fallback for any device stage.
+#include <cstring>
+#include <vector>
+#include "commit.hpp"
+#include "gl.hpp"
+#include "poly.hpp"
+#include "poseidon.hpp"
+#include "prover.hpp"
+
+using namespace nlx;
+
+namespace {
+
+// plonky2::iop::challenger::Challenger (host)
+struct Challenger {
+    uint64_t state[12] = {0};
+    uint64_t in_buf[8];
+    unsigned n_in = 0;
+    uint64_t out_buf[8];
+    unsigned n_out = 0;
+    void duplex() {
+        for (unsigned i = 0; i < n_in; i++) state[i] = in_buf[i];
+        n_in = 0;
+        poseidon::permute(state);
+        for (int i = 0; i < 8; i++) out_buf[i] = state[i];
+        n_out = 8;
+    }
+    void observe(uint64_t e) {
+        n_out = 0;
+        in_buf[n_in++] = e;
+        if (n_in == 8) duplex();
+    }
+    void observe(const uint64_t* e, size_t n) {
+        for (size_t i = 0; i < n; i++) observe(e[i]);
+    }
+    uint64_t challenge() {
+        if (n_in != 0 || n_out == 0) duplex();
+        return out_buf[--n_out];
+    }
+    void ext_challenge(uint64_t out[2]) {
+        out[0] = challenge();
+        out[1] = challenge();
+    }
+};
+
+void hash_no_pad_host(const uint64_t* in, size_t len, uint64_t out[4]) {
+    uint64_t st[12] = {0};
+    for (size_t off = 0; off < len; off += 8) {
+        size_t k = len - off < 8 ? len - off : 8;
+        for (size_t j = 0; j < k; j++) st[j] = in[off + j];
+        poseidon::permute(st);
+    }
+    memcpy(out, st, 32);
+}
+
+struct Writer {
+    uint8_t* p;
+    size_t len = 0, cap;
+    bool overflow = false;
+    void bytes(const void* src, size_t n) {
+        if (len + n > cap) { overflow = true; return; }
+        memcpy(p + len, src, n);
+        len += n;
+    }
+    void u64s(const uint64_t* v, size_t n) { bytes(v, n * 8); }
+    void u8(uint8_t v) { bytes(&v, 1); }
+    void u32(uint32_t v) { bytes(&v, 4); }
+};
+
+uint32_t fri_num_rounds(const nlx_circuit_desc& d) {
+    uint32_t degree_bits = d.degree_bits, r = 0;
+    while (degree_bits > d.fri_final_poly_bits && degree_bits + d.rate_bits >= d.cap_height + d.fri_arity_bits) {
+        if (degree_bits < d.fri_arity_bits) break;
+        degree_bits -= d.fri_arity_bits;
+        r++;
+    }
+    return r;
+}
+
+}  // namespace
+
+struct nlx_circuit {
+    nlx_ctx* ctx = nullptr;
+    nlx_circuit_desc d{};
+    std::vector<nlx_gate_desc> gates;
+    std::vector<uint64_t> k_is;
+    uint32_t n_consts_all = 0, n_cs = 0, n_zs = 0, n_q = 0, n_fri_rounds = 0, n_terms = 0;
+    nlx_commit* cs = nullptr;           // constants + sigmas commitment
+    std::vector<uint64_t> cs_cap;       // host copy
+    uint64_t* d_sigma_values = nullptr; // [routed][n]
+    GateDev* d_gates = nullptr;
+    uint64_t* d_small = nullptr;        // k_is | coset_base | zh_inv | w_R_inv_pows | chunk_scale | w_A_inv_pows
+    uint64_t *d_k_is = nullptr, *d_coset_base = nullptr, *d_zh_inv = nullptr, *d_wR_inv = nullptr,
+             *d_chunk_scale = nullptr, *d_wA_inv = nullptr;
+    uint64_t* d_l0_scaled = nullptr;
+    const uint64_t* d_inv_scale_br = nullptr;  // ctx-owned
+    // stage timing
+    hipEvent_t ev[NLX_MAX_STAGES + 1]{};
+    const char* stage_names[NLX_MAX_STAGES]{};
+    uint32_t n_stages = 0;
+    bool timed = false;
+    size_t n() const { return (size_t)1 << d.degree_bits; }
+    size_t L() const { return (size_t)1 << (d.degree_bits + d.rate_bits); }
+};
+
+static int32_t ensure_pinned(nlx_ctx* ctx, size_t bytes) {
+    if (ctx->pinned_bytes >= bytes) return NLX_OK;
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
+    hipError_t e = hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return ctx->hip_fail(e, "hipHostMalloc");
+    ctx->pinned_bytes = bytes;
+    return NLX_OK;
+}
+
+// device -> host through the pinned staging buffer, synchronous
+static int32_t fetch(nlx_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+    int32_t rc = ensure_pinned(ctx, bytes < (1u << 20) ? (1u << 20) : bytes);
+    if (rc) return rc;
+    NLX_HIP(ctx, hipMemcpyAsync(ctx->pinned, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host_dst, ctx->pinned, bytes);
+    return NLX_OK;
+}
+
+extern "C" {
+
+int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint64_t* constants,
+                          const uint64_t* sigmas, nlx_circuit** out) {
+    if (!ctx) return NLX_E_INVAL;
+    if (!desc || !constants || !sigmas || !out || !desc->gates || !desc->k_is)
+        return ctx->fail(NLX_E_INVAL, "NULL argument");
+    *out = nullptr;
+    const nlx_circuit_desc& d = *desc;
+    if (d.num_challenges < 1 || d.num_challenges > 2) return ctx->fail(NLX_E_UNSUPPORTED, "num_challenges must be 1 or 2");
+    if (d.rate_bits < 1 || d.rate_bits > 3) return ctx->fail(NLX_E_UNSUPPORTED, "rate_bits must be in [1, 3]");
+    if ((1u << d.rate_bits) != d.quotient_degree_factor)
+        return ctx->fail(NLX_E_UNSUPPORTED, "quotient_degree_factor must equal 2^rate_bits");
+    if (d.fri_arity_bits < 2 || d.fri_arity_bits > 4) return ctx->fail(NLX_E_UNSUPPORTED, "fri_arity_bits must be in [2, 4]");
+    if (d.degree_bits < d.fri_arity_bits || d.degree_bits + d.rate_bits > 30) return ctx->fail(NLX_E_RANGE, "degree_bits out of range");
+    if (d.num_routed_wires > d.num_wires || d.num_routed_wires == 0) return ctx->fail(NLX_E_INVAL, "bad wire counts");
+    const uint32_t n_chunks = (d.num_routed_wires + d.quotient_degree_factor - 1) / d.quotient_degree_factor;
+    if (n_chunks > 10 || n_chunks != d.num_partial_products + 1) return ctx->fail(NLX_E_INVAL, "num_partial_products mismatch");
+    if (d.fri_num_queries > 128 || d.cap_height > 6) return ctx->fail(NLX_E_RANGE, "FRI parameters out of range");
+    for (uint32_t g = 0; g < d.num_gates; g++) {
+        const nlx_gate_desc& gt = d.gates[g];
+        if (gt.kind > NLX_GATE_POSEIDON) return ctx->fail(NLX_E_UNSUPPORTED, "gate kind %u not supported", gt.kind);
+        if (gt.selector_index >= d.num_selectors || gt.group_end > d.num_gates || gt.group_start > gt.group_end)
+            return ctx->fail(NLX_E_INVAL, "gate %u: bad selector group", g);
+        if (gt.kind == NLX_GATE_POSEIDON && d.num_wires < 135) return ctx->fail(NLX_E_INVAL, "PoseidonGate needs 135 wires");
+        if (gt.kind == NLX_GATE_ARITHMETIC && 4 * gt.param0 > d.num_wires) return ctx->fail(NLX_E_INVAL, "ArithmeticGate too wide");
+        if (gt.kind == NLX_GATE_BASE_SUM && 1 + gt.param1 > d.num_wires) return ctx->fail(NLX_E_INVAL, "BaseSumGate too wide");
+        if (gt.kind == NLX_GATE_CONSTANT && gt.param0 > d.num_constants) return ctx->fail(NLX_E_INVAL, "ConstantGate too wide");
+    }
+    (void)hipSetDevice(ctx->device);
+    nlx_circuit* c = new (std::nothrow) nlx_circuit();
+    if (!c) return ctx->fail(NLX_E_NOMEM, "host allocation failed");
+    c->ctx = ctx;
+    c->d = d;
+    c->gates.assign(d.gates, d.gates + d.num_gates);
+    c->k_is.assign(d.k_is, d.k_is + d.num_routed_wires);
+    c->d.gates = c->gates.data();
+    c->d.k_is = c->k_is.data();
+    c->n_consts_all = d.num_selectors + d.num_constants;
+    c->n_cs = c->n_consts_all + d.num_routed_wires;
+    c->n_zs = d.num_challenges * (1 + d.num_partial_products);
+    c->n_q = d.num_challenges * d.quotient_degree_factor;
+    c->n_fri_rounds = fri_num_rounds(d);
+    const size_t n = c->n(), L = c->L();
+    const unsigned log_n = d.degree_bits, log_L = d.degree_bits + d.rate_bits;
+    const uint32_t R = 1u << d.rate_bits, A = 1u << d.fri_arity_bits;
+    int32_t rc = ctx->ensure_tables(log_L);
+    auto fail = [&](int32_t code) {
+        nlx_circuit_destroy(c);
+        return code;
+    };
+    if (rc) return fail(rc);
+    rc = ctx->get_coset_scale(log_n, d.rate_bits, &c->d_inv_scale_br, true);
+    if (rc) return fail(rc);
+
+    // constants ++ sigmas -> one device matrix -> commitment
+    {
+        uint64_t* d_vals = (uint64_t*)ctx->alloc((size_t)c->n_cs * n * 8);
+        if (!d_vals) return fail(NLX_E_NOMEM);
+        const size_t cb = (size_t)c->n_consts_all * n * 8, sb = (size_t)d.num_routed_wires * n * 8;
+        hipError_t e1 = hipMemcpyAsync(d_vals, constants, cb, is_device_ptr(constants) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e2 = hipMemcpyAsync((uint8_t*)d_vals + cb, sigmas, sb, is_device_ptr(sigmas) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
+        if (e1 != hipSuccess || e2 != hipSuccess) { ctx->release(d_vals); return fail(ctx->hip_fail(e1 != hipSuccess ? e1 : e2, "hipMemcpyAsync")); }
+        rc = commit_build(ctx, d_vals, n, CommitInput::ValuesNatural, c->n_cs, log_n, d.rate_bits, d.cap_height, &c->cs);
+        if (rc) { ctx->release(d_vals); return fail(rc); }
+        c->d_sigma_values = (uint64_t*)ctx->alloc(sb);
+        if (!c->d_sigma_values) { ctx->release(d_vals); return fail(NLX_E_NOMEM); }
+        (void)hipMemcpyAsync(c->d_sigma_values, (uint8_t*)d_vals + cb, sb, hipMemcpyDeviceToDevice, ctx->stream);
+        ctx->release(d_vals);
+    }
+    // small tables
+    {
+        const uint32_t routed = d.num_routed_wires;
+        std::vector<uint64_t> small(routed + 3 * R + R + A);
+        uint64_t* h_k = small.data();
+        uint64_t* h_cb = h_k + routed;
+        uint64_t* h_zh = h_cb + R;
+        uint64_t* h_wR = h_zh + R;
+        uint64_t* h_cs = h_wR + R;
+        uint64_t* h_wA = h_cs + R;
+        memcpy(h_k, c->k_is.data(), routed * 8);
+        const uint64_t w_L = gl::root_of_unity(log_L), w_R = gl::root_of_unity(d.rate_bits);
+        const uint64_t g_n = gl::exp_pow2(gl::GEN, log_n);
+        const uint64_t g_n_inv = gl::inv(g_n), R_inv = gl::inv((uint64_t)R);
+        for (uint32_t r = 0; r < R; r++) {
+            h_cb[r] = gl::mul(gl::GEN, gl::pow(w_L, r));
+            h_zh[r] = gl::inv(gl::sub(gl::mul(g_n, gl::pow(w_R, r)), 1));  // 1 / (x^n - 1) on coset r
+            h_wR[r] = gl::pow(gl::inv(w_R), r);
+            h_cs[r] = gl::mul(gl::pow(g_n_inv, r), R_inv);
+        }
+        const uint64_t w_A_inv = gl::inv(gl::root_of_unity(d.fri_arity_bits));
+        for (uint32_t i = 0; i < A; i++) h_wA[i] = gl::pow(w_A_inv, i);
+        c->d_small = (uint64_t*)ctx->alloc(small.size() * 8);
+        c->d_gates = (GateDev*)ctx->alloc(sizeof(GateDev) * (d.num_gates ? d.num_gates : 1));
+        c->d_l0_scaled = (uint64_t*)ctx->alloc(L * 8);
+        if (!c->d_small || !c->d_gates || !c->d_l0_scaled) return fail(NLX_E_NOMEM);
+        static_assert(sizeof(GateDev) == sizeof(nlx_gate_desc), "gate descriptor layout");
+        hipError_t e = hipMemcpy(c->d_small, small.data(), small.size() * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess && d.num_gates) e = hipMemcpy(c->d_gates, c->gates.data(), sizeof(GateDev) * d.num_gates, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(ctx->hip_fail(e, "hipMemcpy(tables)"));
+        c->d_k_is = c->d_small;
+        c->d_coset_base = c->d_k_is + routed;
+        c->d_zh_inv = c->d_coset_base + R;
+        c->d_wR_inv = c->d_zh_inv + R;
+        c->d_chunk_scale = c->d_wR_inv + R;
+        c->d_wA_inv = c->d_chunk_scale + R;
+        launch_l0_table(ctx->stream, c->d_l0_scaled, log_n, d.rate_bits, c->d_coset_base, ctx->tables.fwd[log_n]);
+    }
+    c->cs_cap.resize((size_t)4 << d.cap_height);
+    rc = fetch(ctx, c->cs_cap.data(), c->cs->cap, c->cs_cap.size() * 8);
+    if (rc) return fail(rc);
+    bool zero = true;
+    for (int i = 0; i < 4; i++) zero = zero && d.circuit_digest[i] == 0;
+    if (zero) {
+        // circuit_digest = hash_no_pad(cap || hash_pad([]) || degree_bits)   (CircuitBuilder::build)
+        std::vector<uint64_t> parts(c->cs_cap);
+        uint64_t pad[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1}, dom[4];
+        hash_no_pad_host(pad, 12, dom);
+        parts.insert(parts.end(), dom, dom + 4);
+        parts.push_back(d.degree_bits);
+        hash_no_pad_host(parts.data(), parts.size(), c->d.circuit_digest);
+    }
+    for (int i = 0; i <= NLX_MAX_STAGES; i++)
+        if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(ctx->fail(NLX_E_HIP, "hipEventCreate failed"));
+    *out = c;
+    return NLX_OK;
+}
+
+void nlx_circuit_destroy(nlx_circuit* c) {
+    if (!c) return;
+    nlx_ctx* ctx = c->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (c->cs) nlx_commit_destroy(c->cs);
+    ctx->release(c->d_sigma_values);
+    ctx->release(c->d_gates);
+    ctx->release(c->d_small);
+    ctx->release(c->d_l0_scaled);
+    for (int i = 0; i <= NLX_MAX_STAGES; i++)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+}
+
+int32_t nlx_circuit_digest(const nlx_circuit* c, uint64_t out[4]) {
+    if (!c || !out) return NLX_E_INVAL;
+    memcpy(out, c->d.circuit_digest, 32);
+    return NLX_OK;
+}
+
+int32_t nlx_circuit_constants_sigmas_cap(const nlx_circuit* c, uint64_t* cap_out) {
+    if (!c || !cap_out) return NLX_E_INVAL;
+    memcpy(cap_out, c->cs_cap.data(), c->cs_cap.size() * 8);
+    return NLX_OK;
+}
+
+size_t nlx_proof_max_bytes(const nlx_circuit* c) {
+    if (!c) return 0;
+    const nlx_circuit_desc& d = c->d;
+    const size_t capb = (size_t)32 << d.cap_height;
+    const unsigned log_L = d.degree_bits + d.rate_bits;
+    size_t bytes = 3 * capb + 16 * (size_t)(c->n_cs + d.num_wires + c->n_zs + d.num_challenges + c->n_q) + c->n_fri_rounds * capb;
+    size_t per_query = 0;
+    const uint32_t cols[4] = {c->n_cs, d.num_wires, c->n_zs, c->n_q};
+    for (int o = 0; o < 4; o++) per_query += cols[o] * 8 + 1 + 32 * (size_t)(log_L - d.cap_height);
+    per_query += c->n_fri_rounds * ((size_t)16 << d.fri_arity_bits) + c->n_fri_rounds * (1 + 32 * (size_t)log_L);
+    bytes += per_query * d.fri_num_queries;
+    bytes += ((size_t)16 << (d.degree_bits - c->n_fri_rounds * d.fri_arity_bits)) + 8 + 4 + 8 * (size_t)d.num_public_inputs;
+    return bytes + 64;
+}
+
+int32_t nlx_pow_grind(nlx_ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t* nonce_out) {
+    if (!ctx) return NLX_E_INVAL;
+    if (!state || !nonce_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
+    if (pos >= 8 || bits > 40) return ctx->fail(NLX_E_RANGE, "pos must be < 8 and bits <= 40");
+    (void)hipSetDevice(ctx->device);
+    unsigned long long* d_best = (unsigned long long*)ctx->alloc(256);
+    if (!d_best) return NLX_E_NOMEM;
+    PowParams pp{};
+    for (int i = 0; i < 12; i++) pp.state[i] = state[i];
+    pp.pos = pos;
+    pp.bits = bits;
+    pp.max_rounds = (uint64_t)1 << 24;
+    launch_pow_grind(ctx->stream, pp, d_best);
+    uint64_t best = 0;
+    int32_t rc = fetch(ctx, &best, d_best, 8);
+    ctx->release(d_best);
+    if (rc) return rc;
+    if (best == ~0ull) return ctx->fail(NLX_E_RANGE, "proof of work: no witness found");
+    *nonce_out = best;
+    return NLX_OK;
+}
+
+int32_t nlx_prove_stage_times(const nlx_circuit* c, uint32_t* n_stages, const char** names_out, float* ms_out) {
+    if (!c || !n_stages) return NLX_E_INVAL;
+    if (!c->timed) { *n_stages = 0; return NLX_OK; }
+    *n_stages = c->n_stages;
+    for (uint32_t i = 0; i < c->n_stages; i++) {
+        if (names_out) names_out[i] = c->stage_names[i];
+        if (ms_out) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) != hipSuccess) ms = -1.f;
+            ms_out[i] = ms;
+        }
+    }
+    return NLX_OK;
+}
+
+int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, uint8_t* proof_out,
+                  size_t proof_cap, size_t* proof_len) {
+    if (!c) return NLX_E_INVAL;
+    nlx_ctx* ctx = c->ctx;
+    const nlx_circuit_desc& d = c->d;
+    if (!wires || !proof_out || !proof_len || (!public_inputs && d.num_public_inputs))
+        return ctx->fail(NLX_E_INVAL, "NULL argument");
+    *proof_len = 0;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    const size_t n = c->n(), L = c->L();
+    const unsigned log_n = d.degree_bits, log_L = log_n + d.rate_bits, cap_h = d.cap_height;
+    const uint32_t nc = d.num_challenges, npp = d.num_partial_products, routed = d.num_routed_wires;
+    const uint32_t arity = 1u << d.fri_arity_bits, NR = c->n_fri_rounds;
+    const size_t capw = (size_t)4 << cap_h;
+    int32_t rc = NLX_OK;
+
+    // everything allocated here is released at `done`
+    std::vector<void*> scratch;
+    auto dalloc = [&](size_t bytes) -> uint64_t* {
+        void* p = ctx->alloc(bytes);
+        if (p) scratch.push_back(p);
+        return (uint64_t*)p;
+    };
+    nlx_commit *cw = nullptr, *cz = nullptr, *cq = nullptr;
+    c->n_stages = 0;
+    c->timed = false;
+    auto stage = [&](const char* name) {
+        if (c->n_stages < NLX_MAX_STAGES) {
+            (void)hipEventRecord(c->ev[c->n_stages], st);
+            c->stage_names[c->n_stages++] = name;
+        }
+    };
+    Writer w{proof_out, 0, proof_cap};
+    Challenger ch;
+    std::vector<uint64_t> cap(capw);
+    uint64_t pih[4];
+    std::vector<uint64_t> h_pis(public_inputs, public_inputs + d.num_public_inputs);
+    hash_no_pad_host(h_pis.data(), h_pis.size(), pih);
+
+#define CHECK(x) do { rc = (x); if (rc) goto done; } while (0)
+#define HIPCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { rc = ctx->hip_fail(e__, #call); goto done; } } while (0)
+#define CHECK_ALLOC(p) do { if (!(p)) { rc = NLX_E_NOMEM; goto done; } } while (0)
+    {
+        // ---- 2. wires commitment ----
+        stage("commit_wires");
+        Staged sw(ctx, wires, (size_t)d.num_wires * n * 8, true, false);
+        CHECK(sw.status);
+        CHECK(commit_build(ctx, sw.as<uint64_t>(), n, CommitInput::ValuesNatural, d.num_wires, log_n, d.rate_bits, cap_h, &cw));
+        CHECK(fetch(ctx, cap.data(), cw->cap, capw * 8));
+        w.u64s(cap.data(), capw);
+        ch.observe(d.circuit_digest, 4);
+        ch.observe(pih, 4);
+        ch.observe(cap.data(), capw);
+        uint64_t betas[2] = {0, 0}, gammas[2] = {0, 0}, alphas[2] = {0, 0};
+        for (uint32_t i = 0; i < nc; i++) betas[i] = ch.challenge();
+        for (uint32_t i = 0; i < nc; i++) gammas[i] = ch.challenge();
+
+        // ---- 4. partial products and Z ----
+        stage("zs_partial_products");
+        uint64_t* d_zs = dalloc((size_t)c->n_zs * n * 8);
+        uint64_t* d_zs_scratch = dalloc(zs_scratch_words(log_n, nc) * 8);
+        CHECK_ALLOC(d_zs && d_zs_scratch);
+        {
+            ZsParams zp{};
+            zp.wires = sw.as<uint64_t>();
+            zp.wires_stride = n;
+            zp.sigmas = c->d_sigma_values;
+            zp.k_is = c->d_k_is;
+            zp.w_n_table = ctx->tables.fwd[log_n];
+            for (int i = 0; i < 2; i++) { zp.betas[i] = betas[i]; zp.gammas[i] = gammas[i]; }
+            zp.out = d_zs;
+            zp.log_n = log_n; zp.routed = routed; zp.chunk = d.quotient_degree_factor; zp.nc = nc; zp.npp = npp;
+            launch_zs(st, zp, d_zs_scratch);
+        }
+        stage("commit_zs");
+        CHECK(commit_build(ctx, d_zs, n, CommitInput::ValuesNatural, c->n_zs, log_n, d.rate_bits, cap_h, &cz));
+        CHECK(fetch(ctx, cap.data(), cz->cap, capw * 8));
+        w.u64s(cap.data(), capw);
+        ch.observe(cap.data(), capw);
+        for (uint32_t i = 0; i < nc; i++) alphas[i] = ch.challenge();
+
+        // ---- 5. quotient ----
+        stage("quotient_eval");
+        c->n_terms = nc + nc * (npp + 1) + 128;
+        uint64_t* d_alpha_pows = dalloc((size_t)2 * c->n_terms * 8);
+        uint64_t* d_qvals = dalloc((size_t)nc * L * 8);
+        uint64_t* d_qchunks = dalloc((size_t)nc * L * 8);
+        CHECK_ALLOC(d_alpha_pows && d_qvals && d_qchunks);
+        launch_pow_table(st, d_alpha_pows, alphas[0], alphas[1], c->n_terms, c->n_terms);
+        {
+            QuotientParams qp{};
+            qp.cs = c->cs->lde; qp.wires = cw->lde; qp.zs = cz->lde;
+            qp.gates = c->d_gates; qp.k_is = c->d_k_is; qp.coset_base = c->d_coset_base;
+            qp.w_n_table = ctx->tables.fwd[log_n];
+            qp.zh_inv = c->d_zh_inv; qp.l0_scaled = c->d_l0_scaled; qp.alpha_pows = d_alpha_pows;
+            qp.out = d_qvals;
+            for (int i = 0; i < 2; i++) { qp.betas[i] = betas[i]; qp.gammas[i] = gammas[i]; }
+            for (int i = 0; i < 4; i++) qp.pih[i] = pih[i];
+            qp.alpha_stride = c->n_terms;
+            qp.log_n = log_n; qp.rate_bits = d.rate_bits; qp.n_gates = d.num_gates; qp.n_selectors = d.num_selectors;
+            qp.n_consts_all = c->n_consts_all; qp.routed = routed; qp.chunk = d.quotient_degree_factor; qp.nc = nc; qp.npp = npp;
+            launch_quotient(st, qp);
+        }
+        stage("quotient_intt");
+        launch_intt_dif_cosets(st, ctx->tables, d_qvals, nc, log_n, d.rate_bits, c->d_inv_scale_br);
+        launch_quotient_chunks(st, d_qvals, d_qchunks, log_n, d.rate_bits, nc, c->d_wR_inv, c->d_chunk_scale);
+        stage("commit_quotient");
+        CHECK(commit_build(ctx, d_qchunks, n, CommitInput::CoeffsBitrev, c->n_q, log_n, d.rate_bits, cap_h, &cq));
+        CHECK(fetch(ctx, cap.data(), cq->cap, capw * 8));
+        w.u64s(cap.data(), capw);
+        ch.observe(cap.data(), capw);
+
+        // ---- 6. openings ----
+        stage("openings");
+        uint64_t zeta[2], gzeta[2];
+        ch.ext_challenge(zeta);
+        {
+            const uint64_t g = gl::root_of_unity(log_n);
+            gzeta[0] = gl::mul(zeta[0], g);
+            gzeta[1] = gl::mul(zeta[1], g);
+        }
+        const nlx_commit* oracles[4] = {c->cs, cw, cz, cq};
+        const uint32_t n_open = c->n_cs + d.num_wires + c->n_zs + c->n_q;
+        uint64_t* d_points = dalloc(64);
+        uint64_t* d_open = dalloc((size_t)(n_open + nc) * 16);
+        uint64_t* d_eval_scratch = dalloc(eval_scratch_words(d.num_wires > c->n_cs ? d.num_wires : c->n_cs, log_n) * 8);
+        CHECK_ALLOC(d_points && d_open && d_eval_scratch);
+        {
+            uint64_t pts[4] = {zeta[0], zeta[1], gzeta[0], gzeta[1]};
+            HIPCHK(hipMemcpyAsync(d_points, pts, 32, hipMemcpyHostToDevice, st));
+            // pts lives on this stack frame until the synchronising fetch below
+            uint32_t off = 0;
+            for (int o = 0; o < 4; o++) {
+                launch_eval_br(st, oracles[o]->coeffs_br, n, oracles[o]->n_cols, log_n, d_points, d_open + 2 * (size_t)off, d_eval_scratch);
+                off += oracles[o]->n_cols;
+            }
+            launch_eval_br(st, cz->coeffs_br, n, nc, log_n, d_points + 2, d_open + 2 * (size_t)n_open, d_eval_scratch);
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        std::vector<uint64_t> open((size_t)(n_open + nc) * 2);
+        CHECK(fetch(ctx, open.data(), d_open, open.size() * 8));
+        {
+            // OpeningSet wire order: constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys
+            const uint64_t* o_cs = open.data();
+            const uint64_t* o_w = o_cs + 2 * (size_t)c->n_cs;
+            const uint64_t* o_zs = o_w + 2 * (size_t)d.num_wires;
+            const uint64_t* o_pp = o_zs + 2 * (size_t)nc;
+            const uint64_t* o_q = o_zs + 2 * (size_t)c->n_zs;
+            const uint64_t* o_next = open.data() + 2 * (size_t)n_open;
+            w.u64s(o_cs, 2 * (size_t)c->n_cs);
+            w.u64s(o_w, 2 * (size_t)d.num_wires);
+            w.u64s(o_zs, 2 * (size_t)nc);
+            w.u64s(o_next, 2 * (size_t)nc);
+            w.u64s(o_pp, 2 * (size_t)nc * npp);
+            w.u64s(o_q, 2 * (size_t)c->n_q);
+            ch.observe(open.data(), 2 * (size_t)n_open);
+            ch.observe(o_next, 2 * (size_t)nc);
+        }
+
+        // ---- 7. FRI ----
+        stage("fri_combine");
+        uint64_t fri_alpha[2];
+        ch.ext_challenge(fri_alpha);
+        uint64_t* d_fri_alpha_pows = dalloc((size_t)n_open * 16);
+        uint64_t* d_fri_a = dalloc(L * 16);
+        uint64_t* d_fri_b = dalloc((L >> d.fri_arity_bits) * 16 + 256);
+        CHECK_ALLOC(d_fri_alpha_pows && d_fri_a && d_fri_b);
+        launch_ext_pow_table(st, d_fri_alpha_pows, fri_alpha, n_open);
+        {
+            // reduced openings C0 = sum alpha^i open_i (zeta batch), C1 = sum alpha^i zs_next_i
+            const gl::Ext al{fri_alpha[0], fri_alpha[1]};
+            gl::Ext c0{0, 0}, c1{0, 0}, ap{1, 0};
+            for (uint32_t i = 0; i < n_open; i++) {
+                c0 = gl::add(c0, gl::mul(ap, gl::Ext{open[2 * i], open[2 * i + 1]}));
+                ap = gl::mul(ap, al);
+            }
+            ap = gl::Ext{1, 0};
+            for (uint32_t i = 0; i < nc; i++) {
+                c1 = gl::add(c1, gl::mul(ap, gl::Ext{open[2 * (size_t)(n_open + i)], open[2 * (size_t)(n_open + i) + 1]}));
+                ap = gl::mul(ap, al);
+            }
+            FriCombineParams fp{};
+            for (int o = 0; o < 4; o++) { fp.tables[o] = oracles[o]->lde; fp.n_cols[o] = oracles[o]->n_cols; }
+            fp.alpha_pows = d_fri_alpha_pows;
+            fp.coset_base = c->d_coset_base;
+            fp.w_n_table = ctx->tables.fwd[log_n];
+            fp.zeta[0] = zeta[0]; fp.zeta[1] = zeta[1]; fp.gzeta[0] = gzeta[0]; fp.gzeta[1] = gzeta[1];
+            fp.c0[0] = c0.a; fp.c0[1] = c0.b; fp.c1[0] = c1.a; fp.c1[1] = c1.b;
+            fp.alpha_nz[0] = ap.a; fp.alpha_nz[1] = ap.b;  // alpha^nc
+            fp.out = d_fri_a;
+            fp.log_n = log_n; fp.rate_bits = d.rate_bits; fp.nz = nc;
+            launch_fri_combine(st, fp);
+        }
+        // commit phase: layer values ping-pong between d_fri_a / d_fri_b; digests kept per layer
+        stage("fri_commit_phase");
+        std::vector<uint64_t*> layer_values(NR + 1), layer_digests(NR);
+        std::vector<unsigned> layer_log_n(NR + 1);
+        layer_values[0] = d_fri_a;
+        layer_log_n[0] = log_n;
+        uint64_t shift = gl::GEN;
+        for (uint32_t r = 0; r < NR; r++) {
+            const unsigned ln = layer_log_n[r];
+            const size_t n_leaves = (size_t)1 << (ln - d.fri_arity_bits + d.rate_bits);
+            uint64_t* dg = dalloc(merkle_digest_words(n_leaves, cap_h) * 8);
+            CHECK_ALLOC(dg);
+            layer_digests[r] = dg;
+            launch_fri_leaves(st, layer_values[r], ln, d.rate_bits, d.fri_arity_bits, dg);
+            const uint64_t* d_cap = launch_merkle_levels(st, dg, n_leaves, cap_h);
+            CHECK(fetch(ctx, cap.data(), d_cap, capw * 8));
+            w.u64s(cap.data(), capw);
+            ch.observe(cap.data(), capw);
+            uint64_t beta[2];
+            ch.ext_challenge(beta);
+            uint64_t* nxt = (r == 0) ? d_fri_b : dalloc(((size_t)16 << (ln - d.fri_arity_bits + d.rate_bits)) + 256);
+            CHECK_ALLOC(nxt);
+            launch_fri_fold(st, layer_values[r], nxt, ln, d.rate_bits, d.fri_arity_bits, beta, gl::inv(shift),
+                            ctx->tables.inv[ln + d.rate_bits], c->d_wA_inv);
+            layer_values[r + 1] = nxt;
+            layer_log_n[r + 1] = ln - d.fri_arity_bits;
+            shift = gl::exp_pow2(shift, d.fri_arity_bits);
+        }
+        // final polynomial
+        const uint32_t final_len = 1u << layer_log_n[NR];
+        uint64_t* d_final = dalloc((size_t)final_len * 16 + 256);
+        CHECK_ALLOC(d_final);
+        launch_fri_final_coeffs(st, layer_values[NR], layer_log_n[NR], d.rate_bits, shift, d_final, final_len);
+        std::vector<uint64_t> final_poly((size_t)final_len * 2);
+        CHECK(fetch(ctx, final_poly.data(), d_final, final_poly.size() * 8));
+        ch.observe(final_poly.data(), final_poly.size());
+
+        // proof of work
+        stage("fri_pow");
+        uint64_t pow_witness = 0;
+        {
+            PowParams pp{};
+            for (int i = 0; i < 12; i++) pp.state[i] = ch.state[i];
+            for (unsigned i = 0; i < ch.n_in; i++) pp.state[i] = ch.in_buf[i];
+            pp.pos = ch.n_in;
+            pp.bits = d.fri_pow_bits;
+            pp.max_rounds = (uint64_t)1 << 24;
+            unsigned long long* d_best = (unsigned long long*)dalloc(256);
+            CHECK_ALLOC(d_best);
+            launch_pow_grind(st, pp, d_best);
+            CHECK(fetch(ctx, &pow_witness, d_best, 8));
+            if (pow_witness == ~0ull) { rc = ctx->fail(NLX_E_RANGE, "proof of work: no witness found"); goto done; }
+            ch.observe(pow_witness);
+            (void)ch.challenge();
+        }
+        // query phase
+        stage("fri_queries");
+        const uint32_t NQ = d.fri_num_queries;
+        std::vector<uint64_t> qidx(NQ);
+        for (uint32_t q = 0; q < NQ; q++) qidx[q] = ch.challenge() % L;
+        {
+            const unsigned plen0 = log_L - cap_h;
+            // device layout of the answers (words)
+            size_t off = 0;
+            size_t rows_off[4], paths_off[4];
+            for (int o = 0; o < 4; o++) {
+                rows_off[o] = off; off += (size_t)NQ * oracles[o]->n_cols;
+                paths_off[o] = off; off += (size_t)NQ * plen0 * 4;
+            }
+            std::vector<size_t> ev_off(NR), fp_off(NR);
+            std::vector<unsigned> fplen(NR);
+            for (uint32_t r = 0; r < NR; r++) {
+                const unsigned lg = layer_log_n[r] - d.fri_arity_bits + d.rate_bits;
+                fplen[r] = lg > cap_h ? lg - cap_h : 0;
+                ev_off[r] = off; off += (size_t)NQ * 2 * arity;
+                fp_off[r] = off; off += (size_t)NQ * fplen[r] * 4;
+            }
+            uint64_t* d_ans = dalloc(off * 8 + 256);
+            uint64_t* d_idx = dalloc((size_t)(NR + 1) * NQ * 8 + 256);
+            CHECK_ALLOC(d_ans && d_idx);
+            HIPCHK(hipMemcpyAsync(d_idx, qidx.data(), (size_t)NQ * 8, hipMemcpyHostToDevice, st));
+            for (int o = 0; o < 4; o++) {
+                launch_gather_rows(st, oracles[o]->lde, L, oracles[o]->n_cols, log_n, d.rate_bits, d_idx, NQ, d_ans + rows_off[o]);
+                launch_gather_paths(st, oracles[o]->digests, log_L, cap_h, d_idx, NQ, d_ans + paths_off[o]);
+            }
+            unsigned total_shift = 0;
+            for (uint32_t r = 0; r < NR; r++) {
+                total_shift += d.fri_arity_bits;
+                uint64_t* idx_r = d_idx + (size_t)(r + 1) * NQ;
+                launch_shift_indices(st, d_idx, idx_r, NQ, total_shift);
+                launch_fri_gather_leaf(st, layer_values[r], layer_log_n[r], d.rate_bits, d.fri_arity_bits, idx_r, NQ,
+                                       d_ans + ev_off[r], (size_t)2 * arity);
+                const unsigned lg = layer_log_n[r] - d.fri_arity_bits + d.rate_bits;
+                launch_gather_paths(st, layer_digests[r], lg, cap_h, idx_r, NQ, d_ans + fp_off[r]);
+            }
+            std::vector<uint64_t> ans(off);
+            CHECK(fetch(ctx, ans.data(), d_ans, off * 8));
+            for (uint32_t q = 0; q < NQ; q++) {
+                for (int o = 0; o < 4; o++) {
+                    const uint32_t ncol = oracles[o]->n_cols;
+                    w.u64s(ans.data() + rows_off[o] + (size_t)q * ncol, ncol);
+                    w.u8((uint8_t)plen0);
+                    w.u64s(ans.data() + paths_off[o] + (size_t)q * plen0 * 4, (size_t)plen0 * 4);
+                }
+                for (uint32_t r = 0; r < NR; r++) {
+                    w.u64s(ans.data() + ev_off[r] + (size_t)q * 2 * arity, (size_t)2 * arity);
+                    w.u8((uint8_t)fplen[r]);
+                    w.u64s(ans.data() + fp_off[r] + (size_t)q * fplen[r] * 4, (size_t)fplen[r] * 4);
+                }
+            }
+        }
+        w.u64s(final_poly.data(), final_poly.size());
+        w.u64s(&pow_witness, 1);
+        w.u32(d.num_public_inputs);
+        w.u64s(h_pis.data(), h_pis.size());
+        stage("end");
+        c->n_stages--;  // "end" only closes the last interval
+        c->timed = true;
+        if (w.overflow) { rc = ctx->fail(NLX_E_RANGE, "proof buffer too small (need %zu bytes)", nlx_proof_max_bytes(c)); goto done; }
+        *proof_len = w.len;
+    }
+done:
+    {
+        hipError_t e = hipStreamSynchronize(st);
+        if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
+        hipError_t le = hipGetLastError();
+        if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
+    }
+    for (void* p : scratch) ctx->release(p);
+    if (cw) nlx_commit_destroy(cw);
+    if (cz) nlx_commit_destroy(cz);
+    if (cq) nlx_commit_destroy(cq);
+#undef CHECK
+#undef HIPCHK
+#undef CHECK_ALLOC
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,705 @@
+// Prover-stage kernels for gfx950: permutation-argument partial products / Z (a8), the
+// constraint + quotient combiner (a9), FRI batching / folding / layer commitment (a11), the
+// proof-of-work grind and the query gathers.
+//
+// Replaces plonky2::plonk::prover::{wires_permutation_partial_products_and_zs, compute_quotient_polys},
+// vanishing_poly::eval_vanishing_poly_base_batch, gates::*::eval_unfiltered_base_batch,
+// fri::oracle::PolynomialBatch::prove_openings, fri::prover::{fri_committed_trees,
+// fri_proof_of_work, fri_prover_query_rounds}  (SURVEY.md §3.4 steps 4-7, §8a rows a8-a11).
+//
+// All tables are coset-major natural order ([col][r][k] <-> LDE point g*w_L^(8k+r)), so every
+// kernel below reads 512 contiguous bytes per column per wave; "next row" (x*w_n) is k+1 in the
+// same coset.  FRI is folded in the VALUE domain (16-point inverse DFT per coset + Horner in
+// beta/x): bit-identical to plonky2's coefficient-domain fold followed by a fresh FFT, with no
+// transform at all between rounds.
+#include <hip/hip_runtime.h>
+#include "gl.hpp"
+#include "poseidon.hpp"
+#include "poseidon_fast_constants.inc"
+#include "prover.hpp"
+
+namespace nlx {
+
+__constant__ static const uint64_t FAST_FIRST[12] = NLX_POSEIDON_FAST_FIRST_RC_INIT;
+__constant__ static const uint64_t FAST_RC[22] = NLX_POSEIDON_FAST_RC_INIT;
+__constant__ static const uint64_t FAST_VS[22][11] = NLX_POSEIDON_FAST_VS_INIT;
+__constant__ static const uint64_t FAST_W[22][11] = NLX_POSEIDON_FAST_W_HATS_INIT;
+__constant__ static const uint64_t FAST_INIT[11][11] = NLX_POSEIDON_FAST_INITIAL_MATRIX_INIT;
+
+__device__ __forceinline__ uint64_t root_pow(const uint64_t* __restrict__ half_table, uint32_t e, uint32_t half) {
+    return e < half ? half_table[e] : gl::P - half_table[e - half];
+}
+
+// =====================================================================================
+// a8: partial products and Z
+// =====================================================================================
+// Stage 1: per row i and challenge c, the cumulative chunk quotients
+//   cum_q = prod_{q' <= q} prod_{j in chunk q'} (w_j + beta k_j x + gamma) / (w_j + beta sigma_j + gamma)
+// cum_0..cum_8 go to the partial-product columns, cum_9 (the row product) to the Z column.
+// One lane per row; all denominators of a row (both challenges) share ONE field inversion.
+__global__ __launch_bounds__(256) void k_zs_row_products(ZsParams p) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)1 << p.log_n;
+    if (i >= n) return;
+    const uint64_t x = root_pow(p.w_n_table, (uint32_t)i, (uint32_t)(n >> 1));
+    constexpr int MAXQ = 10;  // chunks per challenge (ceil(80 / 8))
+    uint64_t num[2 * MAXQ], den[2 * MAXQ];
+    const uint32_t n_chunks = (p.routed + p.chunk - 1) / p.chunk;
+    for (uint32_t c = 0; c < p.nc; c++) {
+        const uint64_t beta = p.betas[c], gamma = p.gammas[c];
+        const uint64_t bx = gl::mul(beta, x);
+#pragma unroll 1
+        for (uint32_t q = 0; q < n_chunks; q++) {
+            uint64_t nm = 1, dn = 1;
+            for (uint32_t j = q * p.chunk; j < (q + 1) * p.chunk && j < p.routed; j++) {
+                const uint64_t w = p.wires[(size_t)j * p.wires_stride + i];
+                const uint64_t sg = p.sigmas[(size_t)j * n + i];
+                nm = gl::mul(nm, gl::add(gl::add(w, gl::mul(bx, p.k_is[j])), gamma));
+                dn = gl::mul(dn, gl::add(gl::add(w, gl::mul(beta, sg)), gamma));
+            }
+            num[c * MAXQ + q] = nm;
+            den[c * MAXQ + q] = dn;
+        }
+    }
+    // batch inversion of all denominators of this row
+    const uint32_t total = p.nc * n_chunks;
+    uint64_t pref[2 * MAXQ];
+    uint64_t acc = 1;
+    for (uint32_t t = 0; t < total; t++) {
+        const uint32_t idx = (t / n_chunks) * MAXQ + (t % n_chunks);
+        pref[t] = acc;
+        acc = gl::mul(acc, den[idx]);
+    }
+    uint64_t inv = gl::inv(acc);
+    for (uint32_t t = total; t-- > 0;) {
+        const uint32_t idx = (t / n_chunks) * MAXQ + (t % n_chunks);
+        const uint64_t d = den[idx];
+        den[idx] = gl::mul(inv, pref[t]);  // 1 / den
+        inv = gl::mul(inv, d);
+    }
+    for (uint32_t c = 0; c < p.nc; c++) {
+        uint64_t cum = 1;
+        for (uint32_t q = 0; q < n_chunks; q++) {
+            cum = gl::mul(cum, gl::mul(num[c * MAXQ + q], den[c * MAXQ + q]));
+            if (q + 1 < n_chunks) p.out[(size_t)(p.nc + c * p.npp + q) * n + i] = cum;
+            else p.out[(size_t)c * n + i] = cum;  // row product, turned into Z by the scan
+        }
+    }
+}
+
+// Stage 2: exclusive prefix product down the rows (Z_0 = 1, Z_{i+1} = Z_i * P_i).
+// Block-local scan of SCAN_ELEMS elements + block totals; totals are scanned by one block.
+constexpr unsigned SCAN_PER_THREAD = 8;
+constexpr unsigned SCAN_ELEMS = 256 * SCAN_PER_THREAD;
+
+__device__ __forceinline__ uint64_t wave_scan_incl_mul(uint64_t v) {
+    const unsigned lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t lo = __shfl_up((uint32_t)v, off, 64);
+        uint32_t hi = __shfl_up((uint32_t)(v >> 32), off, 64);
+        uint64_t o = ((uint64_t)hi << 32) | lo;
+        if (lane >= (unsigned)off) v = gl::mul(v, o);
+    }
+    return v;
+}
+
+// in-place: data[col][i] <- exclusive prefix product within the block; totals[col][block] <- block product
+__global__ __launch_bounds__(256) void k_scan_mul_local(uint64_t* __restrict__ data, size_t stride, size_t count,
+                                                        uint64_t* __restrict__ totals, size_t totals_stride) {
+    __shared__ uint64_t wave_tot[4];
+    uint64_t* col = data + (size_t)blockIdx.y * stride;
+    const size_t base = (size_t)blockIdx.x * SCAN_ELEMS + (size_t)threadIdx.x * SCAN_PER_THREAD;
+    uint64_t v[SCAN_PER_THREAD];
+    uint64_t prod = 1;
+#pragma unroll
+    for (unsigned k = 0; k < SCAN_PER_THREAD; k++) {
+        v[k] = base + k < count ? col[base + k] : 1;
+        prod = gl::mul(prod, v[k]);
+    }
+    uint64_t incl = wave_scan_incl_mul(prod);
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint64_t wave_prefix = 1;
+    for (unsigned w2 = 0; w2 < wave; w2++) wave_prefix = gl::mul(wave_prefix, wave_tot[w2]);
+    // exclusive prefix of this thread = wave_prefix * (inclusive of previous lane)
+    uint32_t plo = __shfl_up((uint32_t)incl, 1, 64), phi = __shfl_up((uint32_t)(incl >> 32), 1, 64);
+    uint64_t prev = lane ? (((uint64_t)phi << 32) | plo) : 1;
+    uint64_t run = gl::mul(wave_prefix, prev);
+#pragma unroll
+    for (unsigned k = 0; k < SCAN_PER_THREAD; k++) {
+        if (base + k < count) col[base + k] = run;
+        run = gl::mul(run, v[k]);
+    }
+    if (threadIdx.x == 255) totals[(size_t)blockIdx.y * totals_stride + blockIdx.x] = run;
+}
+
+// data[col][i] *= prefix[col][i / SCAN_ELEMS]  (prefix = exclusive scan of block totals)
+__global__ __launch_bounds__(256) void k_scan_mul_apply(uint64_t* __restrict__ data, size_t stride, size_t count,
+                                                        const uint64_t* __restrict__ prefix, size_t prefix_stride) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint64_t* col = data + (size_t)blockIdx.y * stride;
+    const uint64_t f = prefix[(size_t)blockIdx.y * prefix_stride + i / SCAN_ELEMS];
+    col[i] = gl::mul(col[i], f);
+}
+
+// Stage 3: partial products pp_q(i) = Z_i * cum_q(i)
+__global__ __launch_bounds__(256) void k_zs_apply(uint64_t* __restrict__ out, unsigned log_n, uint32_t nc, uint32_t npp) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)1 << log_n;
+    if (i >= n) return;
+    const uint32_t c = blockIdx.y / npp, q = blockIdx.y % npp;
+    const uint64_t z = out[(size_t)c * n + i];
+    uint64_t* pp = out + (size_t)(nc + c * npp + q) * n;
+    pp[i] = gl::mul(pp[i], z);
+}
+
+void launch_zs(hipStream_t st, const ZsParams& p, uint64_t* d_scratch) {
+    const size_t n = (size_t)1 << p.log_n;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_zs_row_products, dim3(blocks), dim3(256), 0, st, p);
+    // exclusive scan of the nc Z columns (columns 0..nc-1 of p.out)
+    size_t count = n;
+    size_t nb = (count + SCAN_ELEMS - 1) / SCAN_ELEMS;
+    uint64_t* tot1 = d_scratch;                 // nc x nb
+    uint64_t* tot2 = d_scratch + p.nc * nb;     // nc x nb2
+    hipLaunchKernelGGL(k_scan_mul_local, dim3((unsigned)nb, p.nc), dim3(256), 0, st, p.out, n, count, tot1, nb);
+    if (nb > 1) {
+        size_t nb2 = (nb + SCAN_ELEMS - 1) / SCAN_ELEMS;  // 1 for n <= 2^22
+        hipLaunchKernelGGL(k_scan_mul_local, dim3((unsigned)nb2, p.nc), dim3(256), 0, st, tot1, nb, nb, tot2, nb2);
+        if (nb2 > 1) {
+            // n > 2^22 rows: third level (nb2 <= 2048 -> one block)
+            uint64_t* tot3 = tot2 + p.nc * nb2;
+            hipLaunchKernelGGL(k_scan_mul_local, dim3(1, p.nc), dim3(256), 0, st, tot2, nb2, nb2, tot3, (size_t)1);
+            hipLaunchKernelGGL(k_scan_mul_apply, dim3((unsigned)((nb + 255) / 256), p.nc), dim3(256), 0, st, tot1, nb, nb,
+                               tot2, nb2);
+        }
+        hipLaunchKernelGGL(k_scan_mul_apply, dim3(blocks, p.nc), dim3(256), 0, st, p.out, n, count, tot1, nb);
+    }
+    hipLaunchKernelGGL(k_zs_apply, dim3(blocks, p.nc * p.npp), dim3(256), 0, st, p.out, p.log_n, p.nc, p.npp);
+}
+size_t zs_scratch_words(unsigned log_n, uint32_t nc) {
+    size_t n = (size_t)1 << log_n;
+    size_t nb = (n + SCAN_ELEMS - 1) / SCAN_ELEMS;
+    size_t nb2 = (nb + SCAN_ELEMS - 1) / SCAN_ELEMS;
+    return nc * (nb + nb2 + 2) + 16;
+}
+
+// =====================================================================================
+// a9: constraint / quotient combiner
+// =====================================================================================
+struct GateAcc {
+    // running sums S_c = sum_k alpha_c^(T0 + k) * constraint_k for the gate being evaluated
+    const uint64_t* __restrict__ ap0;
+    const uint64_t* __restrict__ ap1;
+    uint64_t s0, s1;
+    uint32_t k;
+    __device__ __forceinline__ void emit(uint64_t c) {
+        s0 = gl::add(s0, gl::mul(c, ap0[k]));
+        s1 = gl::add(s1, gl::mul(c, ap1[k]));
+        k++;
+    }
+};
+
+__device__ __forceinline__ uint64_t sbox7c(uint64_t x) {
+    uint64_t x2 = gl::mul(x, x), x4 = gl::mul(x2, x2), x3 = gl::mul(x, x2);
+    return gl::mul(x3, x4);
+}
+__device__ __forceinline__ void mds_canon(uint64_t (&s)[12]) {
+    poseidon::mds_layer(s);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
+}
+
+// PoseidonGate::eval_unfiltered_base (fast partial-round formulation, as upstream)
+template <class WireFn>
+__device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc) {
+    const uint64_t* RC = poseidon::RC_DEV;
+    const uint64_t swap = W(24);
+    acc.emit(gl::mul(swap, gl::sub(swap, 1)));
+    uint64_t st[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint64_t lhs = W(i), rhs = W(i + 4), delta = W(25 + i);
+        acc.emit(gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
+        st[i] = gl::add(lhs, delta);
+        st[i + 4] = gl::sub(rhs, delta);
+    }
+#pragma unroll
+    for (int i = 8; i < 12; i++) st[i] = W(i);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], RC[r * 12 + i]);
+        if (r != 0) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const uint64_t in = W(29 + 12 * (r - 1) + i);
+                acc.emit(gl::sub(st[i], in));
+                st[i] = in;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = sbox7c(st[i]);
+        mds_canon(st);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], FAST_FIRST[i]);
+    {
+        uint64_t res[12];
+        res[0] = st[0];
+#pragma unroll
+        for (int c = 1; c < 12; c++) res[c] = 0;
+#pragma unroll 1
+        for (int r = 1; r < 12; r++) {
+            // dynamic r: select st[r] without indexing registers dynamically
+            uint64_t sr = 0;
+#pragma unroll
+            for (int t = 1; t < 12; t++) sr = (t == r) ? st[t] : sr;
+#pragma unroll
+            for (int c = 1; c < 12; c++) res[c] = gl::add(res[c], gl::mul(sr, FAST_INIT[r - 1][c - 1]));
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = res[i];
+    }
+#pragma unroll 1
+    for (int r = 0; r < 22; r++) {
+        const uint64_t in = W(65 + r);
+        acc.emit(gl::sub(st[0], in));
+        uint64_t s0 = sbox7c(in);
+        if (r < 21) s0 = gl::add(s0, FAST_RC[r]);
+        uint64_t d = gl::mul(s0, 25);
+#pragma unroll
+        for (int i = 1; i < 12; i++) {
+            d = gl::add(d, gl::mul(st[i], FAST_W[r][i - 1]));
+            st[i] = gl::add(st[i], gl::mul(s0, FAST_VS[r][i - 1]));
+        }
+        st[0] = d;
+    }
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const uint64_t v = gl::add(st[i], RC[(26 + r) * 12 + i]);
+            const uint64_t in = W(87 + 12 * r + i);
+            acc.emit(gl::sub(v, in));
+            st[i] = sbox7c(in);
+        }
+        mds_canon(st);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) acc.emit(gl::sub(st[i], W(12 + i)));
+}
+
+// One lane per LDE point.  All gates are evaluated at every point (the selector filter zeroes
+// the inactive ones), so control flow is wave-uniform.
+__global__ __launch_bounds__(256) void k_quotient(QuotientParams p) {
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned log_L = p.log_n + p.rate_bits;
+    if (pos >> log_L) return;
+    const size_t n = (size_t)1 << p.log_n, L = (size_t)1 << log_L;
+    const uint32_t r = (uint32_t)(pos >> p.log_n), k = (uint32_t)(pos & (n - 1));
+    const size_t pos_next = ((size_t)r << p.log_n) + ((k + 1) & (n - 1));
+    const uint64_t x = gl::mul(p.coset_base[r], root_pow(p.w_n_table, k, (uint32_t)(n >> 1)));
+
+    auto CS = [&](uint32_t c) { return p.cs[(size_t)c * L + pos]; };
+    auto W = [&](uint32_t c) { return p.wires[(size_t)c * L + pos]; };
+    auto ZS = [&](uint32_t c) { return p.zs[(size_t)c * L + pos]; };
+
+    const uint32_t nc = p.nc, npp = p.npp;
+    const uint32_t T0 = nc + nc * (npp + 1);
+    const uint64_t* ap0 = p.alpha_pows;
+    const uint64_t* ap1 = p.alpha_pows + p.alpha_stride;
+
+    uint64_t tot0 = 0, tot1 = 0;  // sum over all terms EXCEPT the L_0 term (divided by Z_H later)
+    // ---- gate constraints ----
+    for (uint32_t g = 0; g < p.n_gates; g++) {
+        const GateDev gd = p.gates[g];
+        // filter
+        const uint64_t s = CS(gd.selector_index);
+        uint64_t f = 1;
+        for (uint32_t i = gd.group_start; i < gd.group_end; i++)
+            if (i != gd.index) f = gl::mul(f, gl::sub((uint64_t)i, s));
+        if (p.n_selectors > 1) f = gl::mul(f, gl::sub(0xFFFFFFFFULL, s));
+        GateAcc acc{ap0 + T0, ap1 + T0, 0, 0, 0};
+        switch (gd.kind) {
+            case NLX_GATE_CONSTANT:
+                for (uint32_t i = 0; i < gd.param0; i++) acc.emit(gl::sub(CS(p.n_selectors + i), W(i)));
+                break;
+            case NLX_GATE_PUBLIC_INPUT:
+                for (uint32_t i = 0; i < 4; i++) acc.emit(gl::sub(W(i), p.pih[i]));
+                break;
+            case NLX_GATE_ARITHMETIC: {
+                const uint64_t c0 = CS(p.n_selectors), c1 = CS(p.n_selectors + 1);
+                for (uint32_t i = 0; i < gd.param0; i++) {
+                    const uint64_t m0 = W(4 * i), m1 = W(4 * i + 1), ad = W(4 * i + 2), o = W(4 * i + 3);
+                    acc.emit(gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1))));
+                }
+                break;
+            }
+            case NLX_GATE_BASE_SUM: {
+                const uint32_t B = gd.param0, nl = gd.param1;
+                uint64_t sum = 0;
+                for (uint32_t i = nl; i-- > 0;) sum = gl::add(gl::mul(sum, (uint64_t)B), W(1 + i));
+                acc.emit(gl::sub(sum, W(0)));
+                for (uint32_t i = 0; i < nl; i++) {
+                    const uint64_t limb = W(1 + i);
+                    uint64_t prod = 1;
+                    for (uint32_t t = 0; t < B; t++) prod = gl::mul(prod, gl::sub(limb, (uint64_t)t));
+                    acc.emit(prod);
+                }
+                break;
+            }
+            case NLX_GATE_POSEIDON:
+                gate_poseidon(W, acc);
+                break;
+            default: break;  // NoopGate
+        }
+        tot0 = gl::add(tot0, gl::mul(f, acc.s0));
+        tot1 = gl::add(tot1, gl::mul(f, acc.s1));
+    }
+    // ---- permutation argument ----
+    // vanishing_terms = [L_0 (Z_i - 1)]_i ++ [partial-product checks]_i ++ gate constraints, and EVERY
+    // alpha_c reduces the whole list, so each term feeds both sums.
+    const uint32_t n_chunks = (p.routed + p.chunk - 1) / p.chunk;
+    uint64_t l0a = 0, l0b = 0;  // sum_i (Z_i - 1) alpha_c^i, multiplied by L_0(x)/Z_H(x) below
+    for (uint32_t c = 0; c < nc; c++) {
+        const uint64_t beta = p.betas[c], gamma = p.gammas[c];
+        const uint64_t bx = gl::mul(beta, x);
+        const uint64_t z_x = ZS(c);
+        const uint64_t z_gx = p.zs[(size_t)c * L + pos_next];
+        const uint64_t zm1 = gl::sub(z_x, 1);
+        l0a = gl::add(l0a, gl::mul(zm1, ap0[c]));
+        l0b = gl::add(l0b, gl::mul(zm1, ap1[c]));
+        uint64_t accv = z_x;
+#pragma unroll 1
+        for (uint32_t q = 0; q < n_chunks; q++) {
+            uint64_t nm = 1, dn = 1;
+            for (uint32_t j = q * p.chunk; j < (q + 1) * p.chunk && j < p.routed; j++) {
+                const uint64_t w = W(j);
+                nm = gl::mul(nm, gl::add(gl::add(w, gl::mul(bx, p.k_is[j])), gamma));
+                dn = gl::mul(dn, gl::add(gl::add(w, gl::mul(beta, CS(p.n_consts_all + j))), gamma));
+            }
+            const uint64_t new_acc = (q + 1 < n_chunks) ? ZS(nc + c * npp + q) : z_gx;
+            const uint64_t term = gl::sub(gl::mul(accv, nm), gl::mul(new_acc, dn));
+            const uint32_t t = nc + c * (npp + 1) + q;
+            tot0 = gl::add(tot0, gl::mul(term, ap0[t]));
+            tot1 = gl::add(tot1, gl::mul(term, ap1[t]));
+            accv = new_acc;
+        }
+    }
+    // quotient = (L_0 terms + rest) / Z_H(x);  L_0(x)/Z_H(x) = 1 / (n (x - 1)) = l0_scaled[pos]
+    const uint64_t zh_inv = p.zh_inv[r];
+    const uint64_t l0s = p.l0_scaled[pos];
+    p.out[pos] = gl::add(gl::mul(tot0, zh_inv), gl::mul(l0a, l0s));
+    if (nc > 1) p.out[L + pos] = gl::add(gl::mul(tot1, zh_inv), gl::mul(l0b, l0s));
+}
+
+void launch_quotient(hipStream_t st, const QuotientParams& p) {
+    const size_t L = (size_t)1 << (p.log_n + p.rate_bits);
+    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, p);
+}
+
+// l0_scaled[pos] = 1 / (n * (x_pos - 1)), batch-inverted 8 per thread
+__global__ __launch_bounds__(256) void k_l0_table(uint64_t* __restrict__ out, unsigned log_n, unsigned rate_bits,
+                                                  const uint64_t* __restrict__ coset_base,
+                                                  const uint64_t* __restrict__ w_n_table) {
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >> (log_n + rate_bits)) return;
+    const size_t n = (size_t)1 << log_n;
+    const uint32_t r = (uint32_t)(pos >> log_n), k = (uint32_t)(pos & (n - 1));
+    const uint64_t x = gl::mul(coset_base[r], root_pow(w_n_table, k, (uint32_t)(n >> 1)));
+    out[pos] = gl::inv(gl::mul((uint64_t)(n % gl::P), gl::sub(x, 1)));
+}
+void launch_l0_table(hipStream_t st, uint64_t* d_out, unsigned log_n, unsigned rate_bits, const uint64_t* d_coset_base,
+                     const uint64_t* d_w_n_table) {
+    const size_t L = (size_t)1 << (log_n + rate_bits);
+    hipLaunchKernelGGL(k_l0_table, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, d_out, log_n, rate_bits,
+                       d_coset_base, d_w_n_table);
+}
+
+// After the per-coset inverse transforms (A_r[m] in bit-reversed m order, already multiplied by
+// (g w_L^r)^-m), the 2^rate coefficient chunks are an inverse DFT across the cosets:
+//   chunk_c[m] = g^(-n c) / R * sum_r w_R^(-c r) A_r[m]
+// in:  [challenge][r][j]   out: [challenge * R + c][j]   (j = bit-reversed m; R = 2^rate_bits <= 8)
+__global__ __launch_bounds__(256) void k_quotient_chunks(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                         unsigned log_n, unsigned rate_bits,
+                                                         const uint64_t* __restrict__ w_R_inv_pows,  // R entries
+                                                         const uint64_t* __restrict__ chunk_scale) { // R entries
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)1 << log_n;
+    if (j >= n) return;
+    const uint32_t R = 1u << rate_bits;
+    const uint64_t* src = in + ((size_t)blockIdx.y << (log_n + rate_bits));
+    uint64_t* dst = out + ((size_t)blockIdx.y << (log_n + rate_bits));
+    uint64_t a[8];
+    for (uint32_t r = 0; r < R; r++) a[r] = src[(size_t)r * n + j];
+    for (uint32_t c = 0; c < R; c++) {
+        uint64_t s = 0;
+        for (uint32_t r = 0; r < R; r++) s = gl::add(s, gl::mul(a[r], w_R_inv_pows[(c * r) & (R - 1)]));
+        dst[(size_t)c * n + j] = gl::mul(s, chunk_scale[c]);
+    }
+}
+void launch_quotient_chunks(hipStream_t st, const uint64_t* d_in, uint64_t* d_out, unsigned log_n, unsigned rate_bits,
+                            uint32_t nc, const uint64_t* d_w_R_inv_pows, const uint64_t* d_chunk_scale) {
+    const size_t n = (size_t)1 << log_n;
+    hipLaunchKernelGGL(k_quotient_chunks, dim3((unsigned)((n + 255) / 256), nc), dim3(256), 0, st, d_in, d_out, log_n,
+                       rate_bits, d_w_R_inv_pows, d_chunk_scale);
+}
+
+// =====================================================================================
+// a11: FRI
+// =====================================================================================
+// F(x) = alpha^nz * (sum_i alpha^i p_i(x) - C0) / (x - zeta) + (sum_{i<nz} alpha^i z_i(x) - C1) / (x - g zeta)
+// over every LDE point; p_i runs over the four oracles in FRI order.
+__global__ __launch_bounds__(256) void k_fri_combine(FriCombineParams p) {
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned log_L = p.log_n + p.rate_bits;
+    if (pos >> log_L) return;
+    const size_t n = (size_t)1 << p.log_n, L = (size_t)1 << log_L;
+    const uint32_t r = (uint32_t)(pos >> p.log_n), k = (uint32_t)(pos & (n - 1));
+    const uint64_t x = gl::mul(p.coset_base[r], root_pow(p.w_n_table, k, (uint32_t)(n >> 1)));
+    gl::Ext s0{0, 0}, s1{0, 0};
+    uint32_t idx = 0;
+    for (int o = 0; o < 4; o++) {
+        const uint64_t* tab = p.tables[o];
+        const uint32_t nco = p.n_cols[o];
+#pragma unroll 4
+        for (uint32_t c = 0; c < nco; c++, idx++) {
+            const uint64_t v = tab[(size_t)c * L + pos];
+            const gl::Ext ap{p.alpha_pows[2 * idx], p.alpha_pows[2 * idx + 1]};
+            s0 = gl::add(s0, gl::mul(ap, v));
+            if (o == 2 && c < p.nz) {
+                const gl::Ext az{p.alpha_pows[2 * c], p.alpha_pows[2 * c + 1]};
+                s1 = gl::add(s1, gl::mul(az, v));
+            }
+        }
+    }
+    const gl::Ext zeta{p.zeta[0], p.zeta[1]}, gzeta{p.gzeta[0], p.gzeta[1]};
+    const gl::Ext d0 = gl::sub(gl::ext(x), zeta), d1 = gl::sub(gl::ext(x), gzeta);
+    const gl::Ext inv01 = gl::inv(gl::mul(d0, d1));
+    const gl::Ext i0 = gl::mul(inv01, d1), i1 = gl::mul(inv01, d0);
+    gl::Ext q0 = gl::mul(gl::sub(s0, gl::Ext{p.c0[0], p.c0[1]}), i0);
+    q0 = gl::mul(q0, gl::Ext{p.alpha_nz[0], p.alpha_nz[1]});
+    const gl::Ext q1 = gl::mul(gl::sub(s1, gl::Ext{p.c1[0], p.c1[1]}), i1);
+    const gl::Ext res = gl::add(q0, q1);
+    reinterpret_cast<ulonglong2*>(p.out)[pos] = make_ulonglong2(res.a, res.b);
+}
+void launch_fri_combine(hipStream_t st, const FriCombineParams& p) {
+    const size_t L = (size_t)1 << (p.log_n + p.rate_bits);
+    hipLaunchKernelGGL(k_fri_combine, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, p);
+}
+
+// Layer leaf digests.  values: ext (2 words), coset-major with sub-domain size n = 2^log_n
+// (L = n << rate_bits points).  Leaf of folded index j' = (r, k') holds the `arity` points
+// (r, k' + mm * n/arity), in-leaf slot m = bitrev(mm); its tree position is
+// bitrev(r) * n' + bitrev(k').
+template <int ARITY_BITS>
+__global__ __launch_bounds__(256) void k_fri_leaves(const uint64_t* __restrict__ values, unsigned log_n,
+                                                    unsigned rate_bits, uint64_t* __restrict__ digests) {
+    constexpr int ARITY = 1 << ARITY_BITS;
+    const unsigned log_np = log_n - ARITY_BITS;
+    const size_t jp = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (jp >> (log_np + rate_bits)) return;
+    const size_t np = (size_t)1 << log_np, n = (size_t)1 << log_n;
+    const uint32_t r = (uint32_t)(jp >> log_np), kp = (uint32_t)(jp & (np - 1));
+    const ulonglong2* v = reinterpret_cast<const ulonglong2*>(values) + ((size_t)r * n + kp);
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    // absorb 8 words = 4 ext elements per permutation, in slot order m = 0..ARITY-1
+#pragma unroll
+    for (int m0 = 0; m0 < ARITY; m0 += 4) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int m = m0 + t;
+            const int mm = (int)(__brev((unsigned)m) >> (32 - ARITY_BITS));
+            const ulonglong2 e = v[(size_t)mm * np];
+            s[2 * t] = e.x;
+            s[2 * t + 1] = e.y;
+        }
+        poseidon::permute_loose(s);
+    }
+    const size_t leaf = ((size_t)gl::bitrev32(r, rate_bits) << log_np) + gl::bitrev32(kp, log_np);
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(digests + leaf * 4);
+    dst[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));
+    dst[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
+}
+void launch_fri_leaves(hipStream_t st, const uint64_t* d_values, unsigned log_n, unsigned rate_bits,
+                       unsigned arity_bits, uint64_t* d_digests) {
+    const size_t leaves = (size_t)1 << (log_n - arity_bits + rate_bits);
+    const unsigned blocks = (unsigned)((leaves + 255) / 256);
+    if (arity_bits == 4) hipLaunchKernelGGL(k_fri_leaves<4>, dim3(blocks), dim3(256), 0, st, d_values, log_n, rate_bits, d_digests);
+    else if (arity_bits == 3) hipLaunchKernelGGL(k_fri_leaves<3>, dim3(blocks), dim3(256), 0, st, d_values, log_n, rate_bits, d_digests);
+    else if (arity_bits == 2) hipLaunchKernelGGL(k_fri_leaves<2>, dim3(blocks), dim3(256), 0, st, d_values, log_n, rate_bits, d_digests);
+}
+
+// Fold: out[j'] = sum_t (beta/x)^t * (1/A) sum_mm w_A^(-t mm) v[mm],  x = shift * w_L^(i'), i' = 8k' + r
+template <int ARITY_BITS>
+__global__ __launch_bounds__(256) void k_fri_fold(const uint64_t* __restrict__ values, uint64_t* __restrict__ out,
+                                                  unsigned log_n, unsigned rate_bits, uint64_t beta_a, uint64_t beta_b,
+                                                  uint64_t shift_inv, const uint64_t* __restrict__ w_L_inv_table,
+                                                  const uint64_t* __restrict__ w_A_inv_pows, uint64_t arity_inv) {
+    constexpr int ARITY = 1 << ARITY_BITS;
+    const unsigned log_np = log_n - ARITY_BITS;
+    const unsigned log_L = log_n + rate_bits;
+    const size_t jp = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (jp >> (log_np + rate_bits)) return;
+    const size_t np = (size_t)1 << log_np, n = (size_t)1 << log_n;
+    const uint32_t r = (uint32_t)(jp >> log_np), kp = (uint32_t)(jp & (np - 1));
+    const ulonglong2* v = reinterpret_cast<const ulonglong2*>(values) + ((size_t)r * n + kp);
+    gl::Ext a[ARITY];
+#pragma unroll
+    for (int mm = 0; mm < ARITY; mm++) {
+        const ulonglong2 e = v[(size_t)mm * np];
+        a[mm] = gl::Ext{e.x, e.y};
+    }
+    // x^-1 = shift^-1 * w_L^-(i'), i' = (kp << rate_bits) + r  (old-layer index of the mm = 0 point)
+    const uint32_t ip = (kp << rate_bits) + r;
+    const uint64_t x_inv = gl::mul(shift_inv, root_pow(w_L_inv_table, ip, 1u << (log_L - 1)));
+    const gl::Ext bx = gl::mul(gl::Ext{beta_a, beta_b}, x_inv);
+    // naive inverse DFT fused with Horner in (beta/x): res = sum_t bx^t * (1/A) * sum_mm w^(-t mm) a[mm]
+    gl::Ext res{0, 0};
+#pragma unroll 1
+    for (int t = ARITY - 1; t >= 0; t--) {
+        gl::Ext c{0, 0};
+#pragma unroll
+        for (int mm = 0; mm < ARITY; mm++) c = gl::add(c, gl::mul(a[mm], w_A_inv_pows[(t * mm) & (ARITY - 1)]));
+        res = gl::add(gl::mul(res, bx), c);
+    }
+    res = gl::mul(res, arity_inv);
+    reinterpret_cast<ulonglong2*>(out)[jp] = make_ulonglong2(res.a, res.b);
+}
+void launch_fri_fold(hipStream_t st, const uint64_t* d_values, uint64_t* d_out, unsigned log_n, unsigned rate_bits,
+                     unsigned arity_bits, const uint64_t beta[2], uint64_t shift_inv, const uint64_t* d_w_L_inv_table,
+                     const uint64_t* d_w_A_inv_pows) {
+    const size_t outs = (size_t)1 << (log_n - arity_bits + rate_bits);
+    const unsigned blocks = (unsigned)((outs + 255) / 256);
+    const uint64_t ainv = gl::inv((uint64_t)1 << arity_bits);
+    if (arity_bits == 4) hipLaunchKernelGGL(k_fri_fold<4>, dim3(blocks), dim3(256), 0, st, d_values, d_out, log_n, rate_bits, beta[0], beta[1], shift_inv, d_w_L_inv_table, d_w_A_inv_pows, ainv);
+    else if (arity_bits == 3) hipLaunchKernelGGL(k_fri_fold<3>, dim3(blocks), dim3(256), 0, st, d_values, d_out, log_n, rate_bits, beta[0], beta[1], shift_inv, d_w_L_inv_table, d_w_A_inv_pows, ainv);
+    else if (arity_bits == 2) hipLaunchKernelGGL(k_fri_fold<2>, dim3(blocks), dim3(256), 0, st, d_values, d_out, log_n, rate_bits, beta[0], beta[1], shift_inv, d_w_L_inv_table, d_w_A_inv_pows, ainv);
+}
+
+// Final polynomial: coefficients of the degree < n_f polynomial whose values on
+// shift * <w_Lf> are given (coset-major).  Direct O(Lf * n_f) evaluation of the inverse transform;
+// Lf <= 2^(final_poly_bits + arity_bits - 1 + rate_bits) is a few hundred points.
+__global__ void k_fri_final_coeffs(const uint64_t* __restrict__ values, unsigned log_n, unsigned rate_bits,
+                                   uint64_t shift_inv, uint64_t w_L_inv, uint64_t L_inv, uint64_t* __restrict__ out,
+                                   uint32_t n_out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    const unsigned log_L = log_n + rate_bits;
+    const size_t L = (size_t)1 << log_L, n = (size_t)1 << log_n;
+    // c_j = shift^-j / L * sum_i v_i w_L^(-i j)
+    const uint64_t wj = gl::pow(w_L_inv, j);
+    uint64_t wij = 1;
+    gl::Ext acc{0, 0};
+    for (size_t i = 0; i < L; i++) {
+        const size_t pos = ((i & ((1u << rate_bits) - 1)) * n) + (i >> rate_bits);
+        const gl::Ext v{values[2 * pos], values[2 * pos + 1]};
+        acc = gl::add(acc, gl::mul(v, wij));
+        wij = gl::mul(wij, wj);
+    }
+    acc = gl::mul(acc, gl::mul(gl::pow(shift_inv, j), L_inv));
+    out[2 * j] = acc.a;
+    out[2 * j + 1] = acc.b;
+}
+void launch_fri_final_coeffs(hipStream_t st, const uint64_t* d_values, unsigned log_n, unsigned rate_bits,
+                             uint64_t shift, uint64_t* d_out, uint32_t n_out) {
+    const unsigned log_L = log_n + rate_bits;
+    hipLaunchKernelGGL(k_fri_final_coeffs, dim3((n_out + 63) / 64), dim3(64), 0, st, d_values, log_n, rate_bits,
+                       gl::inv(shift), gl::inv(gl::root_of_unity(log_L)), gl::inv((uint64_t)1 << log_L), d_out, n_out);
+}
+
+// ---- proof of work: smallest nonce whose duplex output word 7 has >= bits leading zeros ----
+constexpr uint32_t POW_GRID = 1024, POW_BLOCK = 256;
+__global__ __launch_bounds__(POW_BLOCK) void k_pow_grind(PowParams p, unsigned long long* __restrict__ best) {
+    const uint64_t stride = (uint64_t)POW_GRID * POW_BLOCK;
+    const uint64_t gid = (uint64_t)blockIdx.x * POW_BLOCK + threadIdx.x;
+    for (uint64_t round = 0; round < p.max_rounds; round++) {
+        const uint64_t cand = round * stride + gid;
+        // a smaller nonce found in an earlier round (or earlier in this one) ends the search:
+        // every candidate below it has been or is being tested by a lane that cannot skip it.
+        const unsigned long long b = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b < round * stride) return;
+        if (cand >= gl::P) return;
+        uint64_t s[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = p.state[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if ((uint32_t)i == p.pos) s[i] = cand;
+        poseidon::permute(s);
+        const uint64_t resp = s[7];
+        const unsigned lz = resp ? (unsigned)__clzll((long long)resp) : 64u;
+        if (lz >= p.bits) atomicMin(best, (unsigned long long)cand);
+    }
+}
+void launch_pow_grind(hipStream_t st, const PowParams& p, unsigned long long* d_best) {
+    (void)hipMemsetAsync(d_best, 0xFF, 8, st);
+    hipLaunchKernelGGL(k_pow_grind, dim3(POW_GRID), dim3(POW_BLOCK), 0, st, p, d_best);
+}
+
+// ---- query gathers ----
+// FRI layer openings: for query q and layer values (coset-major, sub-domain 2^log_n), the leaf
+// with tree index leaf_idx[q]: `arity` ext values in slot order.
+__global__ void k_fri_gather_leaf(const uint64_t* __restrict__ values, unsigned log_n, unsigned rate_bits,
+                                  unsigned arity_bits, const uint64_t* __restrict__ leaf_idx, uint64_t* __restrict__ out,
+                                  size_t out_stride_words) {
+    const uint32_t q = blockIdx.x;
+    const uint32_t m = threadIdx.x;
+    const uint32_t arity = 1u << arity_bits;
+    if (m >= arity) return;
+    const unsigned log_np = log_n - arity_bits;
+    const size_t np = (size_t)1 << log_np, n = (size_t)1 << log_n;
+    const uint64_t leaf = leaf_idx[q];
+    const uint32_t r = gl::bitrev32((uint32_t)(leaf >> log_np), rate_bits);
+    const uint32_t kp = gl::bitrev32((uint32_t)(leaf & (np - 1)), log_np);
+    const uint32_t mm = gl::bitrev32(m, arity_bits);
+    const size_t pos = (size_t)r * n + kp + (size_t)mm * np;
+    uint64_t* o = out + (size_t)q * out_stride_words + 2 * m;
+    o[0] = values[2 * pos];
+    o[1] = values[2 * pos + 1];
+}
+void launch_fri_gather_leaf(hipStream_t st, const uint64_t* d_values, unsigned log_n, unsigned rate_bits,
+                            unsigned arity_bits, const uint64_t* d_leaf_idx, uint32_t n_q, uint64_t* d_out,
+                            size_t out_stride_words) {
+    hipLaunchKernelGGL(k_fri_gather_leaf, dim3(n_q), dim3(64), 0, st, d_values, log_n, rate_bits, arity_bits,
+                       d_leaf_idx, d_out, out_stride_words);
+}
+
+// idx_out[q] = idx_in[q] >> shift
+__global__ void k_shift_indices(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n, unsigned shift) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) out[q] = in[q] >> shift;
+}
+void launch_shift_indices(hipStream_t st, const uint64_t* d_in, uint64_t* d_out, uint32_t n, unsigned shift) {
+    hipLaunchKernelGGL(k_shift_indices, dim3((n + 63) / 64), dim3(64), 0, st, d_in, d_out, n, shift);
+}
+
+// alpha power tables: out[c][t] = alpha_c^t (base field)
+__global__ void k_pow_table(uint64_t* __restrict__ out, uint64_t a0, uint64_t a1, uint32_t count, uint32_t stride) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    out[t] = gl::pow(a0, t);
+    out[stride + t] = gl::pow(a1, t);
+}
+void launch_pow_table(hipStream_t st, uint64_t* d_out, uint64_t a0, uint64_t a1, uint32_t count, uint32_t stride) {
+    hipLaunchKernelGGL(k_pow_table, dim3((count + 63) / 64), dim3(64), 0, st, d_out, a0, a1, count, stride);
+}
+// ext power table: out[t] = alpha^t (2 words each)
+__global__ void k_ext_pow_table(uint64_t* __restrict__ out, uint64_t a, uint64_t b, uint32_t count) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const gl::Ext v = gl::pow(gl::Ext{a, b}, t);
+    out[2 * t] = v.a;
+    out[2 * t + 1] = v.b;
+}
+void launch_ext_pow_table(hipStream_t st, uint64_t* d_out, const uint64_t alpha[2], uint32_t count) {
+    hipLaunchKernelGGL(k_ext_pow_table, dim3((count + 63) / 64), dim3(64), 0, st, d_out, alpha[0], alpha[1], count);
+}
+
+}  // namespace nlx

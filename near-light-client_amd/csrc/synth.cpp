@@ -1,0 +1,343 @@
+// Synthetic nearx-shaped circuit + witness generator (host C++, workload generation only).
+//
+// The real SyncCircuit / VerifyCircuit witnesses need the Rust plonky2x CircuitBuilder and live
+// NEAR RPC data (nearx/src/hint.rs:45-93), neither available here, so the bench and the parity
+// tests prove SYNTHETIC circuits of the same static shape: 135 wires / 80 routed,
+// standard_recursion_config, a gate mix of PoseidonGate / ArithmeticGate / BaseSumGate /
+// ConstantGate / PublicInputGate / NoopGate rows with real copy constraints.  The witness
+// satisfies every constraint, so the resulting proof verifies.
+//
+// This file produces INPUTS (constants, sigmas, wires, public inputs); it is not on the timed
+// path and is shared by the HIP prover's tests/bench and the oracle's tests.
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <vector>
+#include "../../include/nlx.h"
+#include "gl.hpp"
+#include "poseidon.hpp"
+#include "poseidon_fast_constants.inc"
+
+namespace {
+
+struct Rng {  // SplitMix64
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        s += 0x9E3779B97F4A7C15ULL;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    }
+    uint64_t field() { return next() % gl::P; }
+    uint32_t below(uint32_t n) { return (uint32_t)(next() % n); }
+};
+
+const uint64_t FAST_FIRST[12] = NLX_POSEIDON_FAST_FIRST_RC_INIT;
+const uint64_t FAST_RC[22] = NLX_POSEIDON_FAST_RC_INIT;
+const uint64_t FAST_VS[22][11] = NLX_POSEIDON_FAST_VS_INIT;
+const uint64_t FAST_W[22][11] = NLX_POSEIDON_FAST_W_HATS_INIT;
+const uint64_t FAST_INIT[11][11] = NLX_POSEIDON_FAST_INITIAL_MATRIX_INIT;
+const uint64_t CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+
+uint64_t sbox(uint64_t x) {
+    uint64_t x2 = gl::sqr(x), x4 = gl::sqr(x2);
+    return gl::mul(gl::mul(x, x2), x4);
+}
+void mds(uint64_t* s) {
+    uint64_t o[12];
+    for (int r = 0; r < 12; r++) {
+        uint64_t acc = 0;
+        for (int i = 0; i < 12; i++) acc = gl::add(acc, gl::mul(s[(i + r) % 12], CIRC[i]));
+        if (r == 0) acc = gl::add(acc, gl::mul(s[0], 8));
+        o[r] = acc;
+    }
+    memcpy(s, o, sizeof o);
+}
+
+// PoseidonGate witness (plonky2 PoseidonGenerator::run_once): fills the 135 wires of one row
+// for the given 12 inputs and swap bit.
+void poseidon_gate_row(const uint64_t in[12], uint64_t swap, uint64_t* w /*135*/) {
+    const uint64_t* RC = poseidon::RC_HOST;
+    for (int i = 0; i < 12; i++) w[i] = in[i];
+    w[24] = swap;
+    uint64_t st[12];
+    for (int i = 0; i < 4; i++) {
+        uint64_t delta = gl::mul(swap, gl::sub(in[i + 4], in[i]));
+        w[25 + i] = delta;
+        st[i] = gl::add(in[i], delta);
+        st[i + 4] = gl::sub(in[i + 4], delta);
+    }
+    for (int i = 8; i < 12; i++) st[i] = in[i];
+    int rc = 0;
+    for (int r = 0; r < 4; r++, rc++) {
+        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], RC[rc * 12 + i]);
+        if (r != 0)
+            for (int i = 0; i < 12; i++) w[29 + 12 * (r - 1) + i] = st[i];
+        for (int i = 0; i < 12; i++) st[i] = sbox(st[i]);
+        mds(st);
+    }
+    for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], FAST_FIRST[i]);
+    {
+        uint64_t res[12] = {st[0]};
+        for (int r = 1; r < 12; r++)
+            for (int c = 1; c < 12; c++) res[c] = gl::add(res[c], gl::mul(st[r], FAST_INIT[r - 1][c - 1]));
+        memcpy(st, res, sizeof res);
+    }
+    for (int r = 0; r < 22; r++) {
+        w[65 + r] = st[0];
+        st[0] = sbox(st[0]);
+        if (r < 21) st[0] = gl::add(st[0], FAST_RC[r]);
+        uint64_t d = gl::mul(st[0], 25);
+        for (int i = 1; i < 12; i++) d = gl::add(d, gl::mul(st[i], FAST_W[r][i - 1]));
+        for (int i = 1; i < 12; i++) st[i] = gl::add(st[i], gl::mul(st[0], FAST_VS[r][i - 1]));
+        st[0] = d;
+    }
+    rc += 22;
+    for (int r = 0; r < 4; r++, rc++) {
+        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], RC[rc * 12 + i]);
+        for (int i = 0; i < 12; i++) w[87 + 12 * r + i] = st[i];
+        for (int i = 0; i < 12; i++) st[i] = sbox(st[i]);
+        mds(st);
+    }
+    for (int i = 0; i < 12; i++) w[12 + i] = st[i];
+}
+
+uint32_t gate_degree(uint32_t kind, uint32_t p0) {
+    switch (kind) {
+        case NLX_GATE_NOOP: return 0;
+        case NLX_GATE_CONSTANT: return 1;
+        case NLX_GATE_PUBLIC_INPUT: return 1;
+        case NLX_GATE_ARITHMETIC: return 3;
+        case NLX_GATE_BASE_SUM: return p0;
+        case NLX_GATE_POSEIDON: return 7;
+    }
+    return 0;
+}
+
+struct Dsu {
+    std::vector<uint32_t> p;
+    explicit Dsu(size_t n) : p(n) { std::iota(p.begin(), p.end(), 0u); }
+    uint32_t find(uint32_t x) {
+        while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; }
+        return x;
+    }
+    void unite(uint32_t a, uint32_t b) {
+        a = find(a); b = find(b);
+        if (a != b) p[b] = a;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_selectors) {
+    // gate list sorted by (degree, id) as plonky2's CircuitBuilder does; the set depends on the mix
+    uint32_t g = 3;  // noop, constant, public input always present
+    if (sp->pct_base_sum) g++;
+    if (sp->pct_arithmetic) g++;
+    if (sp->pct_poseidon) g++;
+    *n_gates = g;
+    // greedy selector groups with max_degree = 8 (gates::selectors::selector_polynomials)
+    uint32_t kinds[6], p0[6], k = 0;
+    kinds[k] = NLX_GATE_NOOP; p0[k++] = 0;
+    kinds[k] = NLX_GATE_CONSTANT; p0[k++] = 2;
+    kinds[k] = NLX_GATE_PUBLIC_INPUT; p0[k++] = 0;
+    if (sp->pct_base_sum) { kinds[k] = NLX_GATE_BASE_SUM; p0[k++] = 2; }
+    if (sp->pct_arithmetic) { kinds[k] = NLX_GATE_ARITHMETIC; p0[k++] = 20; }
+    if (sp->pct_poseidon) { kinds[k] = NLX_GATE_POSEIDON; p0[k++] = 0; }
+    uint32_t max_deg = gate_degree(kinds[g - 1], p0[g - 1]);
+    if (max_deg + g - 1 <= 8) { *n_selectors = 1; return; }
+    uint32_t sel = 0, start = 0;
+    while (start < g) {
+        uint32_t size = 0;
+        while (start + size < g && size + gate_degree(kinds[start + size], p0[start + size]) < 8) size++;
+        start += size;
+        sel++;
+    }
+    *n_selectors = sel;
+}
+
+int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint64_t* k_is, uint64_t* constants,
+                          uint64_t* sigmas, uint64_t* wires, uint64_t* public_inputs) {
+    const uint32_t W = 135, ROUTED = 80, NCONST = 2;
+    const uint32_t log_n = sp->log_n;
+    if (log_n < 3 || log_n > 26) return NLX_E_RANGE;
+    const size_t n = (size_t)1 << log_n;
+    Rng rng(sp->seed ^ 0x6e6c78ULL);
+
+    // ---- gate table + selector groups ----
+    uint32_t n_gates, n_sel;
+    nlx_synth_shape(sp, &n_gates, &n_sel);
+    uint32_t k = 0;
+    auto add_gate = [&](uint32_t kind, uint32_t p0, uint32_t p1) {
+        gates[k].kind = kind; gates[k].param0 = p0; gates[k].param1 = p1; gates[k].index = k; k++;
+    };
+    add_gate(NLX_GATE_NOOP, 0, 0);
+    add_gate(NLX_GATE_CONSTANT, 2, 0);
+    add_gate(NLX_GATE_PUBLIC_INPUT, 0, 0);
+    int g_base = -1, g_arith = -1, g_pos = -1;
+    if (sp->pct_base_sum) { g_base = k; add_gate(NLX_GATE_BASE_SUM, 2, 63); }
+    if (sp->pct_arithmetic) { g_arith = k; add_gate(NLX_GATE_ARITHMETIC, 20, 0); }
+    if (sp->pct_poseidon) { g_pos = k; add_gate(NLX_GATE_POSEIDON, 0, 0); }
+    if (n_sel == 1) {
+        for (uint32_t g = 0; g < n_gates; g++) { gates[g].selector_index = 0; gates[g].group_start = 0; gates[g].group_end = n_gates; }
+    } else {
+        uint32_t start = 0, sel = 0;
+        while (start < n_gates) {
+            uint32_t size = 0;
+            while (start + size < n_gates && size + gate_degree(gates[start + size].kind, gates[start + size].param0) < 8) size++;
+            for (uint32_t g = start; g < start + size; g++) { gates[g].selector_index = sel; gates[g].group_start = start; gates[g].group_end = start + size; }
+            start += size;
+            sel++;
+        }
+    }
+    // k_is = g^i (plonk_common::get_unique_coset_shifts)
+    k_is[0] = 1;
+    for (uint32_t j = 1; j < ROUTED; j++) k_is[j] = gl::mul(k_is[j - 1], gl::GEN);
+
+    // ---- rows ----
+    std::vector<uint8_t> row_gate(n, 0);
+    auto W_at = [&](uint32_t col, size_t row) -> uint64_t& { return wires[(size_t)col * n + row]; };
+    auto C_at = [&](uint32_t col, size_t row) -> uint64_t& { return constants[(size_t)col * n + row]; };
+    memset(constants, 0, (size_t)(n_sel + NCONST) * n * 8);
+    Dsu dsu((size_t)ROUTED * n);
+    auto slot = [&](uint32_t col, size_t row) { return (uint32_t)((size_t)col * n + row); };
+    std::vector<uint32_t> pool;  // routed slots whose value later rows may copy
+    pool.reserve(n * 4);
+    uint64_t prev_pos_out[12];
+    size_t prev_pos_row = (size_t)-1;
+
+    // public inputs and their hash at row 0
+    for (uint32_t i = 0; i < sp->num_public_inputs; i++) public_inputs[i] = rng.field();
+    uint64_t pih[4];
+    {
+        uint64_t st[12] = {0};
+        for (uint32_t off = 0; off < sp->num_public_inputs; off += 8) {
+            uint32_t m = sp->num_public_inputs - off < 8 ? sp->num_public_inputs - off : 8;
+            for (uint32_t j = 0; j < m; j++) st[j] = public_inputs[off + j];
+            poseidon::permute(st);
+        }
+        memcpy(pih, st, 32);
+    }
+    for (size_t row = 0; row < n; row++) {
+        // random fill first (unconstrained wires stay random)
+        for (uint32_t c = 0; c < W; c++) W_at(c, row) = rng.field();
+        uint32_t kind = NLX_GATE_NOOP;
+        int gidx = 0;
+        if (row == 0) {
+            kind = NLX_GATE_PUBLIC_INPUT; gidx = 2;
+        } else if (row + 2 >= n) {
+            kind = NLX_GATE_NOOP; gidx = 0;  // padding rows, as plonky2 pads with NoopGate
+        } else {
+            uint32_t r = rng.below(100);
+            uint32_t t = sp->pct_poseidon;
+            if (r < t && g_pos >= 0) { kind = NLX_GATE_POSEIDON; gidx = g_pos; }
+            else if (r < (t += sp->pct_arithmetic) && g_arith >= 0) { kind = NLX_GATE_ARITHMETIC; gidx = g_arith; }
+            else if (r < (t += sp->pct_base_sum) && g_base >= 0) { kind = NLX_GATE_BASE_SUM; gidx = g_base; }
+            else if (r < (t += sp->pct_constant)) { kind = NLX_GATE_CONSTANT; gidx = 1; }
+        }
+        row_gate[row] = (uint8_t)gidx;
+        switch (kind) {
+            case NLX_GATE_PUBLIC_INPUT:
+                for (int i = 0; i < 4; i++) W_at(i, row) = pih[i];
+                break;
+            case NLX_GATE_CONSTANT:
+                for (int i = 0; i < 2; i++) {
+                    uint64_t v = rng.field();
+                    C_at(n_sel + i, row) = v;
+                    W_at(i, row) = v;
+                    pool.push_back(slot(i, row));
+                }
+                break;
+            case NLX_GATE_ARITHMETIC: {
+                uint64_t c0 = rng.field(), c1 = rng.field();
+                C_at(n_sel, row) = c0;
+                C_at(n_sel + 1, row) = c1;
+                for (uint32_t op = 0; op < 20; op++) {
+                    for (uint32_t q = 0; q < 3; q++) {
+                        // half of the operands are copies of earlier routed values (copy constraints)
+                        if (!pool.empty() && (rng.next() & 1)) {
+                            uint32_t src = pool[rng.below((uint32_t)pool.size())];
+                            W_at(4 * op + q, row) = wires[src];
+                            dsu.unite(src, slot(4 * op + q, row));
+                        }
+                    }
+                    uint64_t m0 = W_at(4 * op, row), m1 = W_at(4 * op + 1, row), ad = W_at(4 * op + 2, row);
+                    W_at(4 * op + 3, row) = gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1));
+                    if ((op & 3) == 0) pool.push_back(slot(4 * op + 3, row));
+                }
+                break;
+            }
+            case NLX_GATE_BASE_SUM: {
+                uint64_t sum = 0;
+                for (uint32_t i = 63; i-- > 0;) {
+                    uint64_t bit = rng.next() & 1;
+                    W_at(1 + i, row) = bit;
+                    sum = gl::add(gl::add(sum, sum), bit);
+                }
+                W_at(0, row) = sum;
+                pool.push_back(slot(0, row));
+                break;
+            }
+            case NLX_GATE_POSEIDON: {
+                uint64_t in[12];
+                bool chain = prev_pos_row != (size_t)-1 && (rng.next() & 3) != 0;
+                for (int i = 0; i < 12; i++) in[i] = chain ? prev_pos_out[i] : rng.field();
+                if (!chain && !pool.empty()) {  // absorb a few earlier values
+                    for (int i = 0; i < 4; i++) {
+                        uint32_t src = pool[rng.below((uint32_t)pool.size())];
+                        in[i] = wires[src];
+                        dsu.unite(src, slot(i, row));
+                    }
+                }
+                uint64_t tmp[135];
+                for (uint32_t c = 0; c < W; c++) tmp[c] = W_at(c, row);
+                poseidon_gate_row(in, rng.next() & 1, tmp);
+                for (uint32_t c = 0; c < W; c++) W_at(c, row) = tmp[c];
+                if (chain)
+                    for (int i = 0; i < 12; i++) dsu.unite(slot(12 + i, prev_pos_row), slot(i, row));
+                for (int i = 0; i < 12; i++) prev_pos_out[i] = tmp[12 + i];
+                prev_pos_row = row;
+                pool.push_back(slot(12, row));
+                break;
+            }
+            default: break;
+        }
+        // keep the pool bounded so copies stay "recent" (locality like a real circuit)
+        if (pool.size() > 4096) pool.erase(pool.begin(), pool.begin() + 2048);
+    }
+    // selector columns
+    for (size_t row = 0; row < n; row++) {
+        uint32_t g = row_gate[row];
+        for (uint32_t s = 0; s < n_sel; s++)
+            C_at(s, row) = (gates[g].selector_index == s) ? gates[g].index : 0xFFFFFFFFULL;
+    }
+    // ---- sigma: each copy class becomes one cycle (next slot in increasing order, wrapping) ----
+    const size_t total = (size_t)ROUTED * n;
+    std::vector<uint32_t> next_in_class(total), last_seen(total, 0xFFFFFFFFu), first_seen(total, 0xFFFFFFFFu);
+    for (size_t s = 0; s < total; s++) {
+        uint32_t r = dsu.find((uint32_t)s);
+        if (first_seen[r] == 0xFFFFFFFFu) first_seen[r] = (uint32_t)s;
+        else next_in_class[last_seen[r]] = (uint32_t)s;
+        last_seen[r] = (uint32_t)s;
+    }
+    for (size_t s = 0; s < total; s++) {
+        uint32_t r = dsu.find((uint32_t)s);
+        if (last_seen[r] == s) next_in_class[s] = first_seen[r];
+    }
+    std::vector<uint64_t> subgroup(n);
+    {
+        uint64_t w = gl::root_of_unity(log_n), x = 1;
+        for (size_t i = 0; i < n; i++) { subgroup[i] = x; x = gl::mul(x, w); }
+    }
+    for (size_t s = 0; s < total; s++) {
+        uint32_t t = next_in_class[s];
+        sigmas[s] = gl::mul(k_is[t / n], subgroup[t % n]);
+    }
+    return NLX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+"""Host-side mirror of the plonky2 circuit / prover interface over the C ABI.
+
+Mirrors plonky2::plonk::circuit_data::{CircuitConfig, CircuitData} and
+plonk::prover::prove as reached from nearx/src/test_utils.rs:29,62 (builder.build(),
+circuit.prove()).  Real nearx circuits come from the Rust CircuitBuilder; here
+`SyntheticCircuit` produces circuits of the same static shape for tests and benchmarks.
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import dll, ptr, NlxError
+
+GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_BASE_SUM, GATE_POSEIDON = range(6)
+
+
+class GateDesc(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint32) for k in
+                ("kind", "selector_index", "group_start", "group_end", "index", "param0", "param1")]
+
+
+class CircuitDesc(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint32) for k in (
+        "degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_challenges", "rate_bits",
+        "cap_height", "quotient_degree_factor", "num_partial_products", "fri_pow_bits", "fri_num_queries",
+        "fri_arity_bits", "fri_final_poly_bits", "num_selectors", "num_gates", "num_public_inputs")] + [
+        ("gates", ctypes.POINTER(GateDesc)), ("k_is", ctypes.POINTER(ctypes.c_uint64)),
+        ("circuit_digest", ctypes.c_uint64 * 4)]
+
+
+class SynthParams(ctypes.Structure):
+    _fields_ = [("log_n", ctypes.c_uint32), ("num_public_inputs", ctypes.c_uint32),
+                ("pct_poseidon", ctypes.c_uint32), ("pct_arithmetic", ctypes.c_uint32),
+                ("pct_base_sum", ctypes.c_uint32), ("pct_constant", ctypes.c_uint32), ("seed", ctypes.c_uint64)]
+
+
+class CircuitConfig:
+    """CircuitConfig::standard_recursion_config() (plonky2x DefaultParameters)."""
+
+    def __init__(self, **kw):
+        self.num_wires = 135
+        self.num_routed_wires = 80
+        self.num_constants = 2
+        self.num_challenges = 2
+        self.rate_bits = 3
+        self.cap_height = 4
+        self.quotient_degree_factor = 8
+        self.fri_pow_bits = 16
+        self.fri_num_queries = 28
+        self.fri_arity_bits = 4
+        self.fri_final_poly_bits = 5
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise TypeError("unknown config field %s" % k)
+            setattr(self, k, v)
+
+    @property
+    def num_partial_products(self):
+        return (self.num_routed_wires + self.quotient_degree_factor - 1) // self.quotient_degree_factor - 1
+
+
+class SyntheticCircuit:
+    """A satisfiable nearx-shaped circuit + witness (see csrc/synth.cpp)."""
+
+    def __init__(self, log_n, seed=1, num_public_inputs=4, pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5,
+                 pct_constant=5, config=None):
+        self.config = config or CircuitConfig()
+        self.log_n = log_n
+        sp = SynthParams(log_n, num_public_inputs, pct_poseidon, pct_arithmetic, pct_base_sum, pct_constant, seed)
+        ng, ns = ctypes.c_uint32(), ctypes.c_uint32()
+        dll.nlx_synth_shape(ctypes.byref(sp), ctypes.byref(ng), ctypes.byref(ns))
+        n = 1 << log_n
+        self.num_selectors, self.num_gates = ns.value, ng.value
+        self.gates = (GateDesc * ng.value)()
+        self.k_is = np.zeros(80, dtype=np.uint64)
+        self.constants = np.zeros((ns.value + 2, n), dtype=np.uint64)
+        self.sigmas = np.zeros((80, n), dtype=np.uint64)
+        self.wires = np.zeros((135, n), dtype=np.uint64)
+        self.public_inputs = np.zeros(max(num_public_inputs, 1), dtype=np.uint64)[:num_public_inputs]
+        rc = dll.nlx_synth_circuit(ctypes.byref(sp), self.gates, ptr(self.k_is), ptr(self.constants),
+                                   ptr(self.sigmas), ptr(self.wires), ptr(self.public_inputs) if num_public_inputs else None)
+        if rc != 0:
+            raise NlxError(rc, "nlx_synth_circuit failed")
+
+    def desc(self):
+        c = self.config
+        d = CircuitDesc(self.log_n, c.num_wires, c.num_routed_wires, c.num_constants, c.num_challenges, c.rate_bits,
+                        c.cap_height, c.quotient_degree_factor, c.num_partial_products, c.fri_pow_bits,
+                        c.fri_num_queries, c.fri_arity_bits, c.fri_final_poly_bits, self.num_selectors,
+                        self.num_gates, len(self.public_inputs), self.gates,
+                        self.k_is.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+        return d
+
+
+class CircuitData:
+    """Prover-side circuit data resident on the GPU (CircuitBuilder::build output)."""
+
+    def __init__(self, ctx, desc, constants, sigmas):
+        self.ctx = ctx
+        self._desc = desc  # keeps gates / k_is alive
+        h = ctypes.c_void_p()
+        ctx.check(dll.nlx_circuit_build(ctx.handle, ctypes.byref(desc), ptr(constants), ptr(sigmas), ctypes.byref(h)))
+        self.handle = h
+        self.cap_height = desc.cap_height
+        self.num_wires = desc.num_wires
+        self.n = 1 << desc.degree_bits
+        self._buf = np.zeros(dll.nlx_proof_max_bytes(h), dtype=np.uint8)
+
+    @classmethod
+    def from_synthetic(cls, ctx, syn):
+        return cls(ctx, syn.desc(), syn.constants, syn.sigmas)
+
+    @property
+    def circuit_digest(self):
+        out = np.zeros(4, dtype=np.uint64)
+        dll.nlx_circuit_digest(self.handle, ptr(out))
+        return out
+
+    @property
+    def constants_sigmas_cap(self):
+        out = np.zeros((1 << self.cap_height, 4), dtype=np.uint64)
+        dll.nlx_circuit_constants_sigmas_cap(self.handle, ptr(out))
+        return out
+
+    def prove(self, wires, public_inputs):
+        """prove_with_partition_witness + to_bytes: returns the serialized ProofWithPublicInputs."""
+        pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        ln = ctypes.c_size_t()
+        self.ctx.check(dll.nlx_prove(self.handle, ptr(wires), ptr(pis) if pis.size else None,
+                                     self._buf.ctypes.data, self._buf.size, ctypes.byref(ln)))
+        return self._buf[:ln.value].tobytes()
+
+    def prove_into(self, wires, public_inputs_ptr):
+        """Hot-loop variant: no copies of the result; returns the proof length."""
+        ln = ctypes.c_size_t()
+        self.ctx.check(dll.nlx_prove(self.handle, ptr(wires), public_inputs_ptr, self._buf.ctypes.data,
+                                     self._buf.size, ctypes.byref(ln)))
+        return ln.value
+
+    def stage_times(self):
+        n = ctypes.c_uint32()
+        names = (ctypes.c_char_p * 24)()
+        ms = (ctypes.c_float * 24)()
+        dll.nlx_prove_stage_times(self.handle, ctypes.byref(n), names, ms)
+        return [(names[i].decode(), ms[i]) for i in range(n.value)]
+
+    def close(self):
+        if self.handle:
+            dll.nlx_circuit_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pow_grind(ctx, state, pos, bits):
+    st = np.ascontiguousarray(state, dtype=np.uint64)
+    out = ctypes.c_uint64()
+    ctx.check(dll.nlx_pow_grind(ctx.handle, ptr(st), pos, bits, ctypes.byref(out)))
+    return out.value

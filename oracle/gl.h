@@ -37,7 +37,17 @@ static inline uint64_t gl_add(uint64_t a, uint64_t b) {
 }
 static inline uint64_t gl_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + (GL_P - b); }
 static inline uint64_t gl_neg(uint64_t a) { return a ? GL_P - a : 0; }
-static inline uint64_t gl_reduce128(u128 x) { return (uint64_t)(x % GL_P); }
+/* 2^64 = 2^32 - 1 and 2^96 = -1 (mod p): fold hi_hi and hi_lo into lo (plonky2 reduce128) */
+static inline uint64_t gl_reduce128(u128 x) {
+    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+    uint64_t t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= GL_EPS;
+    uint64_t t1 = hi_lo * GL_EPS;
+    uint64_t r = t0 + t1;
+    if (r < t1) r += GL_EPS;
+    return r >= GL_P ? r - GL_P : r;
+}
 static inline uint64_t gl_mul(uint64_t a, uint64_t b) { return gl_reduce128((u128)a * b); }
 static inline uint64_t gl_sqr(uint64_t a) { return gl_mul(a, a); }
 

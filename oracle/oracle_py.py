@@ -144,3 +144,101 @@ def eval_poly_ext(coeffs, z):
         nb = (a * zb + b * za) % P
         a, b = na, nb
     return a, b
+
+
+# ---------------- whole-proof oracle (plonk.h) ----------------
+class _Gate(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint32) for k in
+                ("kind", "selector_index", "group_start", "group_end", "index", "param0", "param1")]
+
+
+class _Desc(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint32) for k in (
+        "degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_challenges", "rate_bits",
+        "cap_height", "quotient_degree_factor", "num_partial_products", "fri_pow_bits", "fri_num_queries",
+        "fri_arity_bits", "fri_final_poly_bits", "num_selectors", "num_gates", "num_public_inputs")] + [
+        ("gates", ctypes.POINTER(_Gate)), ("k_is", u64p), ("circuit_digest", ctypes.c_uint64 * 4)]
+
+
+class _Trace(ctypes.Structure):
+    _fields_ = [("betas", ctypes.c_uint64 * 4), ("gammas", ctypes.c_uint64 * 4), ("alphas", ctypes.c_uint64 * 4),
+                ("zeta", ctypes.c_uint64 * 2), ("fri_alpha", ctypes.c_uint64 * 2), ("fri_betas", ctypes.c_uint64 * 32),
+                ("pow_witness", ctypes.c_uint64), ("n_fri_rounds", ctypes.c_uint32),
+                ("query_indices", ctypes.c_uint64 * 128), ("zs_partial_values", u64p),
+                ("quotient_chunk_coeffs", u64p), ("fri_final_values", u64p)]
+
+
+class Circuit:
+    """orc_circuit: built from the same flat description the product ABI takes (field-for-field)."""
+
+    def __init__(self, desc_bytes_like, gates_like, k_is, constants, sigmas):
+        d = dll()
+        d.orc_circuit_build.restype = ctypes.c_void_p
+        d.orc_proof_max_bytes.restype = ctypes.c_size_t
+        d.orc_proof_max_bytes.argtypes = [ctypes.c_void_p]
+        d.orc_prove.restype = ctypes.c_size_t
+        d.orc_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        d.orc_prove_traced.restype = ctypes.c_size_t
+        d.orc_prove_traced.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_size_t, ctypes.c_void_p]
+        d.orc_verify.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        d.orc_circuit_free.argtypes = [ctypes.c_void_p]
+        d.orc_circuit_digest.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        d.orc_circuit_constants_sigmas_cap.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._gates = (_Gate * len(gates_like))()
+        for i, g in enumerate(gates_like):
+            for f, _ in _Gate._fields_:
+                setattr(self._gates[i], f, getattr(g, f))
+        self._k = _u64(k_is).copy()
+        self.desc = _Desc()
+        for f, _ in _Desc._fields_[:16]:
+            setattr(self.desc, f, getattr(desc_bytes_like, f))
+        self.desc.gates = self._gates
+        self.desc.k_is = _p(self._k)
+        self.h = d.orc_circuit_build(ctypes.byref(self.desc), _p(_u64(constants)), _p(_u64(sigmas)))
+        self.max_bytes = d.orc_proof_max_bytes(self.h)
+
+    @classmethod
+    def from_synthetic(cls, syn):
+        return cls(syn.desc(), list(syn.gates), syn.k_is, syn.constants, syn.sigmas)
+
+    def digest(self):
+        out = np.zeros(4, dtype=np.uint64)
+        dll().orc_circuit_digest(self.h, out.ctypes.data)
+        return out
+
+    def constants_sigmas_cap(self):
+        out = np.zeros((1 << self.desc.cap_height, 4), dtype=np.uint64)
+        dll().orc_circuit_constants_sigmas_cap(self.h, out.ctypes.data)
+        return out
+
+    def prove(self, wires, public_inputs, trace=False):
+        w, pi = _u64(wires), _u64(public_inputs)
+        buf = np.zeros(self.max_bytes, dtype=np.uint8)
+        if not trace:
+            ln = dll().orc_prove(self.h, w.ctypes.data, pi.ctypes.data, buf.ctypes.data, buf.size)
+            return buf[:ln].tobytes()
+        tr = _Trace()
+        n = 1 << self.desc.degree_bits
+        L = n << self.desc.rate_bits
+        nzs = self.desc.num_challenges * (1 + self.desc.num_partial_products)
+        nq = self.desc.num_challenges * self.desc.quotient_degree_factor
+        zs = np.zeros((nzs, n), dtype=np.uint64)
+        qc = np.zeros((nq, n), dtype=np.uint64)
+        fv = np.zeros((L, 2), dtype=np.uint64)
+        tr.zs_partial_values, tr.quotient_chunk_coeffs, tr.fri_final_values = _p(zs), _p(qc), _p(fv)
+        ln = dll().orc_prove_traced(self.h, w.ctypes.data, pi.ctypes.data, buf.ctypes.data, buf.size, ctypes.byref(tr))
+        info = {"betas": list(tr.betas)[:2], "gammas": list(tr.gammas)[:2], "alphas": list(tr.alphas)[:2],
+                "zeta": list(tr.zeta), "fri_alpha": list(tr.fri_alpha), "pow_witness": tr.pow_witness,
+                "n_fri_rounds": tr.n_fri_rounds, "query_indices": list(tr.query_indices)[:self.desc.fri_num_queries],
+                "zs_partial_values": zs, "quotient_chunk_coeffs": qc, "fri_final_values": fv}
+        return buf[:ln].tobytes(), info
+
+    def verify(self, proof):
+        b = np.frombuffer(proof, dtype=np.uint8)
+        return int(dll().orc_verify(self.h, b.ctypes.data, b.size))
+
+    def close(self):
+        if self.h:
+            dll().orc_circuit_free(self.h)
+            self.h = None

@@ -1,0 +1,118 @@
+/* ORACLE - TEST INFRASTRUCTURE ONLY (see gl.h header).
+ *
+ * CPU restatement of the plonky2 prover and verifier for the gate set the synthetic nearx-shaped
+ * circuits use.  Follows (by module name; source absent from /root/reference):
+ *   plonky2::plonk::prover::{prove_with_partition_witness, wires_permutation_partial_products_and_zs,
+ *     compute_quotient_polys}, vanishing_poly::{eval_vanishing_poly, eval_vanishing_poly_base_batch},
+ *   plonk_common::{eval_l_0, reduce_with_powers_multi, ZeroPolyOnCoset}, proof::OpeningSet,
+ *   gates::{noop, constant, public_input, arithmetic_base, base_sum, poseidon}, gates::selectors,
+ *   fri::{oracle::PolynomialBatch::prove_openings, prover::*, verifier::*, reduction_strategies},
+ *   util::serialization::Buffer (proof wire format).
+ * Reached from the reference at nearx/src/test_utils.rs:62 (prove) and :66 (verify).
+ */
+#ifndef NLX_ORACLE_PLONK_H
+#define NLX_ORACLE_PLONK_H
+#include "oracle.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* gate kinds (same numbering as include/nlx.h) */
+enum {
+    ORC_GATE_NOOP = 0,
+    ORC_GATE_CONSTANT = 1,     /* param0 = num_consts */
+    ORC_GATE_PUBLIC_INPUT = 2,
+    ORC_GATE_ARITHMETIC = 3,   /* param0 = num_ops */
+    ORC_GATE_BASE_SUM = 4,     /* param0 = base B, param1 = num_limbs */
+    ORC_GATE_POSEIDON = 5
+};
+
+typedef struct {
+    uint32_t kind;
+    uint32_t selector_index; /* which selector polynomial this gate uses */
+    uint32_t group_start;    /* gate-index range [start, end) sharing that selector */
+    uint32_t group_end;
+    uint32_t index;          /* this gate's index in the sorted gate list (value of the selector on its rows) */
+    uint32_t param0, param1;
+} orc_gate;
+
+typedef struct {
+    uint32_t degree_bits;
+    uint32_t num_wires;            /* 135 */
+    uint32_t num_routed_wires;     /* 80 */
+    uint32_t num_constants;        /* gate constants per row (2), excluding selectors */
+    uint32_t num_challenges;       /* 2 */
+    uint32_t rate_bits;            /* 3 */
+    uint32_t cap_height;           /* 4 */
+    uint32_t quotient_degree_factor; /* 8 */
+    uint32_t num_partial_products; /* 9 */
+    uint32_t fri_pow_bits;         /* 16 */
+    uint32_t fri_num_queries;      /* 28 */
+    uint32_t fri_arity_bits;       /* 4 */
+    uint32_t fri_final_poly_bits;  /* 5 */
+    uint32_t num_selectors;
+    uint32_t num_gates;
+    uint32_t num_public_inputs;
+    const orc_gate* gates;
+    const uint64_t* k_is;          /* num_routed_wires coset shifts */
+    uint64_t circuit_digest[4];
+} orc_circuit_desc;
+
+typedef struct orc_circuit orc_circuit;
+
+/* CircuitBuilder::build's prover-side products: commits constants (selectors first, then gate
+ * constants) and sigma polynomials.  constants: (num_selectors+num_constants) x n column-major,
+ * sigmas: num_routed_wires x n column-major.  If desc->circuit_digest is all zero it is computed
+ * as hash_no_pad(cap || hash_pad([]) || degree_bits) and stored. */
+orc_circuit* orc_circuit_build(const orc_circuit_desc* desc, const uint64_t* constants, const uint64_t* sigmas);
+void orc_circuit_free(orc_circuit* c);
+void orc_circuit_digest(const orc_circuit* c, uint64_t out[4]);
+void orc_circuit_constants_sigmas_cap(const orc_circuit* c, uint64_t* cap_out);
+
+/* upper bound of the serialized proof size in bytes */
+size_t orc_proof_max_bytes(const orc_circuit* c);
+/* prove_with_partition_witness + ProofWithPublicInputs::to_bytes.  wires: num_wires x n column-major.
+ * Returns the number of bytes written, 0 on failure (e.g. unsatisfied witness makes the quotient
+ * exceed its degree bound). */
+size_t orc_prove(const orc_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, uint8_t* proof_out,
+                 size_t cap_bytes);
+/* verify(): 1 = accept, <= 0 = reject (negative values name the failing check) */
+int orc_verify(const orc_circuit* c, const uint8_t* proof, size_t len);
+
+/* stage-level access for stage-by-stage parity tests */
+typedef struct {
+    uint64_t betas[4], gammas[4], alphas[4];
+    uint64_t zeta[2];
+    uint64_t fri_alpha[2];
+    uint64_t fri_betas[2 * 16];
+    uint64_t pow_witness;
+    uint32_t n_fri_rounds;
+    uint64_t query_indices[128];
+    /* optional dumps (caller-allocated or NULL) */
+    uint64_t* zs_partial_values;   /* (num_challenges*(1+num_partial_products)) x n column-major */
+    uint64_t* quotient_chunk_coeffs; /* (num_challenges*quotient_degree_factor) x n column-major */
+    uint64_t* fri_final_values;    /* L ext values (2 words each), natural LDE order */
+} orc_trace;
+size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint64_t* public_inputs,
+                        uint8_t* proof_out, size_t cap_bytes, orc_trace* trace);
+
+/* hash_pad (pad10*1 to a multiple of the sponge width) */
+void orc_hash_pad(const uint64_t* in, size_t len, uint64_t out[4]);
+
+/* Poseidon fast-partial-round constants derived from the MDS matrix and round constants
+ * (hadeshash calc_equivalent_constants / calc_equivalent_matrices); used by the PoseidonGate. */
+typedef struct {
+    uint64_t first_round_constant[12];
+    uint64_t round_constants[22];       /* last entry unused (0) */
+    uint64_t vs[22][11];
+    uint64_t w_hats[22][11];
+    uint64_t initial_matrix[11][11];
+} orc_poseidon_fast;
+const orc_poseidon_fast* orc_poseidon_fast_constants(void);
+void orc_poseidon_permute_fast(uint64_t state[12]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,115 @@
+"""GPU parity tests for the whole-proof path (nlx_circuit_build / nlx_prove through the C ABI):
+proof BYTES must equal the CPU oracle's on the same synthetic circuits, the oracle's verifier
+must accept them, and at BASELINE size the proof must verify (no full oracle prove needed)."""
+import numpy as np
+import pytest
+
+from conftest import P
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    (5, dict(pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)),   # no FRI reduction round
+    (6, dict(pct_poseidon=0, pct_arithmetic=50, pct_base_sum=10, pct_constant=10)),  # single selector
+    (8, dict(pct_poseidon=25, pct_arithmetic=25, pct_base_sum=5, pct_constant=5)),
+    (9, dict(pct_poseidon=10, pct_arithmetic=0, pct_base_sum=0, pct_constant=5)),
+    (10, dict(pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)),
+    (12, dict(pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)),
+    (13, dict(pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)),  # two NTT passes
+]
+
+
+@pytest.mark.parametrize("log_n,kw", SHAPES)
+def test_proof_bytes_equal_oracle(nlx, ctx, orc, log_n, kw):
+    syn = nlx.SyntheticCircuit(log_n, seed=100 + log_n, **kw)
+    ref = orc.Circuit.from_synthetic(syn)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    assert np.array_equal(cd.constants_sigmas_cap, ref.constants_sigmas_cap())
+    assert np.array_equal(cd.circuit_digest, ref.digest())
+    want = ref.prove(syn.wires, syn.public_inputs)
+    got = cd.prove(syn.wires, syn.public_inputs)
+    assert len(got) == len(want)
+    if got != want:
+        a, b = np.frombuffer(got, np.uint8), np.frombuffer(want, np.uint8)
+        first = int(np.nonzero(a != b)[0][0])
+        pytest.fail("proof bytes differ from the oracle, first at byte %d of %d" % (first, len(want)))
+    assert ref.verify(got) == 1
+    # determinism + device-resident witness gives the same bytes
+    assert cd.prove(syn.wires, syn.public_inputs) == got
+    cd.close()
+    ref.close()
+
+
+def test_stagewise_against_oracle_trace(nlx, ctx, orc):
+    """Localises a mismatch: challenges and intermediate polynomials of the oracle trace vs what the
+    GPU commits (Z / partial products and quotient chunks recovered from the proof's openings)."""
+    syn = nlx.SyntheticCircuit(8, seed=42)
+    ref = orc.Circuit.from_synthetic(syn)
+    want, tr = ref.prove(syn.wires, syn.public_inputs, trace=True)
+    # Z / partial products: commit the oracle's values on the GPU and compare caps with the proof's
+    pb = nlx.PolynomialBatch.from_values(ctx, tr["zs_partial_values"], 3, 4)
+    zs_cap = np.frombuffer(want[512:1024], dtype=np.uint64).reshape(16, 4)
+    assert np.array_equal(pb.cap, zs_cap)
+    pq = nlx.PolynomialBatch.from_coeffs(ctx, tr["quotient_chunk_coeffs"], 3, 4)
+    q_cap = np.frombuffer(want[1024:1536], dtype=np.uint64).reshape(16, 4)
+    assert np.array_equal(pq.cap, q_cap)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    got = cd.prove(syn.wires, syn.public_inputs)
+    assert got[:512] == want[:512], "wires cap"
+    assert got[512:1024] == want[512:1024], "Z/partial-products cap"
+    assert got[1024:1536] == want[1024:1536], "quotient cap"
+    assert got == want
+    ref.close()
+
+
+def test_pow_grind_smallest_nonce(nlx, ctx, orc):
+    rng = np.random.default_rng(11)
+    for bits in (4, 10, 16):
+        state = rng.integers(0, P, 12, dtype=np.uint64)
+        pos = 3
+        nonce = nlx.pow_grind(ctx, state, pos, bits)
+
+        def lz(w):
+            st = state.copy()
+            st[pos] = w
+            out = orc.poseidon_permute(st.reshape(1, 12))[0]
+            return 64 - int(out[7]).bit_length()
+        assert lz(nonce) >= bits
+        lo = max(0, nonce - 2000)
+        assert all(lz(w) < bits for w in range(lo, nonce)), "a smaller valid nonce exists"
+
+
+def test_unsatisfied_witness_rejected_by_verifier(nlx, ctx, orc):
+    syn = nlx.SyntheticCircuit(7, seed=3)
+    ref = orc.Circuit.from_synthetic(syn)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    w = syn.wires.copy()
+    w[0, 0] = (int(w[0, 0]) + 1) % P
+    bad = cd.prove(w, syn.public_inputs)
+    assert ref.verify(bad) < 1
+    assert bad == ref.prove(w, syn.public_inputs)  # still the same bytes as the CPU prover
+    ref.close()
+
+
+def test_baseline_size_proof_verifies(nlx, ctx, orc):
+    """2^15 rows, full standard_recursion_config: the oracle VERIFIER (cheap) accepts the GPU proof."""
+    syn = nlx.SyntheticCircuit(15, seed=7)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    proof = cd.prove(syn.wires, syn.public_inputs)
+    ref = orc.Circuit.from_synthetic(syn)
+    assert np.array_equal(cd.constants_sigmas_cap, ref.constants_sigmas_cap())
+    assert ref.verify(proof) == 1
+    ref.close()
+
+
+def test_circuit_build_errors(nlx, ctx):
+    syn = nlx.SyntheticCircuit(5, seed=1)
+    d = syn.desc()
+    d.rate_bits = 5
+    with pytest.raises(nlx.NlxError):
+        nlx.CircuitData(ctx, d, syn.constants, syn.sigmas)
+    d = syn.desc()
+    d.gates[0].kind = 99
+    with pytest.raises(nlx.NlxError):
+        nlx.CircuitData(ctx, d, syn.constants, syn.sigmas)
+    d.gates[0].kind = 0
