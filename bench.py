@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py - proofs/s of the MI355X-native prover on the SyncCircuit-shaped workload.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line from
+rank 0.  For N > 1 the driver launches it under torch.distributed.run (one rank per GPU, RCCL).
+
+Workload ("step" = one whole plonky2 proof through the C ABI, nlx_prove):
+  sync (default, BASELINE.json configs[1]): a synthetic circuit of SyncCircuit's static shape -
+    standard_recursion_config (135 wires / 80 routed, rate 8, cap height 4, 2 challenges,
+    28 FRI queries, 16 PoW bits), 2^16 rows, gate mix PoseidonGate / ArithmeticGate / BaseSumGate /
+    ConstantGate / PublicInputGate / NoopGate with real copy constraints and a satisfying witness
+    (the true row count of SyncCircuit is not recorded in the reference - SURVEY.md §7 - so
+    --log-n sweeps it).  Witness tables are resident in HBM before the timed region.
+  SyncCircuit does not shard: with N GPUs each rank proves its own independent
+  request ("replicas only"), scaling = weak, no data-path collective.
+  verify128 (--workload verify128): the VerifyCircuit 128x4 map-reduce job - 32 map proofs, a
+    binary reduce tree (16+8+4+2+1) and one outer proof, sharded over the ranks with an RCCL
+    all-gather of the children's digests between levels (scaling = strong).
+
+roofline: the dominant kernel is the Poseidon leaf hashing of the LDE tables
+  (k_hash_lde_leaves); its algorithmic bytes per launch are 8*c*L + 32*L and its
+  average duration is measured live with HIP events on the launch stream.
+cpu_baseline: the CPU oracle (C port of the same algorithm, OpenMP over the host cores) timed
+  on a bounded sample (one proof at 2^(log_n-3) rows), scaled linearly in rows.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="sync", choices=["sync", "verify128"])
+    ap.add_argument("--log-n", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--map-log-n", type=int, default=15)
+    ap.add_argument("--reduce-log-n", type=int, default=13)
+    return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+    """one process per GPU; returns (rank, world, local_rank, torch.distributed or None)"""
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        dist = dist_mod
+    else:
+        torch.cuda.set_device(local)
+    if world != n_gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (n_gpus, world), file=sys.stderr)
+    return rank, world, local, dist
+
+
+def barrier(dist, torch):
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def cpu_baseline(nlx, log_n, gate_mix):
+    """oracle (port) on a bounded sample: one proof at 2^(log_n - 3) rows"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    sample_log_n = max(log_n - 3, 8)
+    syn = nlx.SyntheticCircuit(sample_log_n, seed=99, **gate_mix)
+    circ = oracle_py.Circuit.from_synthetic(syn)
+    t = time.time()
+    proof = circ.prove(syn.wires, syn.public_inputs)
+    dt = time.time() - t
+    ok = circ.verify(proof) == 1
+    circ.close()
+    scale = 2.0 ** (log_n - sample_log_n)
+    return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "1 proof at 2^%d rows (1/%d of the workload's rows) in %.2f s, scaled linearly in rows; "
+                      "oracle verifier accepted: %s" % (sample_log_n, int(scale), dt, ok)}
+
+
+def run_sync(args, nlx, torch, rank, world, local, dist):
+    import numpy as np
+    gate_mix = dict(pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)
+    ctx = nlx.Context(local)
+    syn = nlx.SyntheticCircuit(args.log_n, seed=1000 + rank, **gate_mix)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    # witness resident in HBM before the timed region (device tensor handed over by pointer)
+    wires = torch.from_numpy(syn.wires.view(np.int64)).cuda()
+    pis = np.ascontiguousarray(syn.public_inputs)
+    pis_ptr = pis.ctypes.data
+    for _ in range(args.warmup):
+        cd.prove_into(wires, pis_ptr)
+    ctx.kernel_timing(True)
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cd.prove_into(wires, pis_ptr)
+    barrier(dist, torch)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    calls, ms, alg = ctx.kernel_stats("hash_lde_leaves")
+    stages = cd.stage_times()
+    kstats = {k: ctx.kernel_stats(k) for k in ("intt", "lde", "hash_lde_leaves", "merkle_levels", "quotient", "fri_combine")}
+    ctx.kernel_timing(False)
+    out = None
+    if rank == 0:
+        achieved = (alg / calls) / (ms / calls * 1e-3) / 1e9 if calls else 0.0
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                t = json.load(open(prof))
+                if t.get("log_n") == args.log_n:
+                    traffic = t.get("hash_lde_leaves_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Sync/Verify proofs/sec at 1/2/4/8 MI355X + achieved HBM GB/s vs roofline",
+            "value": world * args.steps / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
+            "config": {"workload": "SyncCircuit-shaped plonky2 proof (standard_recursion_config, 2^%d rows, "
+                                   "135 wires, rate 8, 28 queries, 16 PoW bits), replicas only" % args.log_n,
+                       "log_n": args.log_n, "gate_mix_pct": gate_mix, "proof_bytes": len(cd.prove(wires, pis)),
+                       "parallelism": "replicas x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_hash_lde_leaves", "launches": calls, "avg_launch_ms": ms / calls if calls else None,
+                         "alg_bytes_per_launch": alg / calls if calls else None,
+                         "note": "Poseidon leaf hashing is VALU-integer bound (17 permutations per 135-wide row); "
+                                 "the HBM fraction is low by construction"},
+            "stage_ms_last_proof": {k: round(v, 3) for k, v in stages},
+            "kernel_ms_per_proof": {k: round(v[1] / args.steps, 3) for k, v in kstats.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(nlx, args.log_n, gate_mix)
+        else:
+            out["cpu_baseline"] = None
+    cd.close()
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (there is no CPU fallback)")
+    rank, world, local, dist = dist_setup(args.gpus)
+    import nlxpkg
+    nlx = nlxpkg.load()
+    if args.workload == "sync":
+        out = run_sync(args, nlx, torch, rank, world, local, dist)
+    else:
+        from importlib import import_module
+        mr = import_module("nlx_amd.mapreduce")
+        out = mr.bench_verify128(args, nlx, torch, rank, world, local, dist)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

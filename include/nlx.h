@@ -55,6 +55,11 @@ const char* nlx_last_error(const nlx_ctx* ctx);
  * NULL restores the context's own stream.  The caller keeps ownership of the stream. */
 int32_t nlx_ctx_set_stream(nlx_ctx* ctx, void* hip_stream);
 int32_t nlx_ctx_synchronize(nlx_ctx* ctx);
+/* Per-kernel device timing for measurement (bench.py's roofline): when enabled, the library brackets
+ * its main kernels ("intt", "lde", "hash_lde_leaves", "merkle_levels", "quotient", "fri_combine")
+ * with HIP events on the context's stream.  nlx_ctx_kernel_timing(ctx, x) also clears the samples. */
+int32_t nlx_ctx_kernel_timing(nlx_ctx* ctx, int enable);
+int32_t nlx_ctx_kernel_stats(nlx_ctx* ctx, const char* name, uint64_t* calls, double* total_ms, double* alg_bytes);
 
 /* ---- a5: plonky2::hash::poseidon::Poseidon::poseidon ----
  * states: n x 12 u64, row-major, permuted in place. */

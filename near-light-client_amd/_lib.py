@@ -36,6 +36,9 @@ SIGNATURES = {
     "nlx_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "nlx_ctx_set_stream": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_ctx_synchronize": (ctypes.c_int32, [ctypes.c_void_p]),
+    "nlx_ctx_kernel_timing": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int]),
+    "nlx_ctx_kernel_stats": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
+                                              ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "nlx_poseidon_permute_batch": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "nlx_hash_rows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
                                        ctypes.c_void_p]),
@@ -123,6 +126,15 @@ class Context:
 
     def set_stream(self, hip_stream):
         self.check(dll.nlx_ctx_set_stream(self.handle, hip_stream))
+
+    def kernel_timing(self, enable=True):
+        self.check(dll.nlx_ctx_kernel_timing(self.handle, 1 if enable else 0))
+
+    def kernel_stats(self, name):
+        """(calls, total_ms, algorithmic_bytes) of the named kernel since timing was enabled."""
+        n, ms, b = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
+        self.check(dll.nlx_ctx_kernel_stats(self.handle, name.encode(), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(b)))
+        return n.value, ms.value, b.value
 
     def close(self):
         if self.handle:

@@ -54,7 +54,9 @@ int32_t commit_build(nlx_ctx* ctx, const uint64_t* d_in, size_t in_stride, Commi
     hipStream_t st = ctx->stream;
     switch (kind) {
         case CommitInput::ValuesNatural:
+            ctx->begin_kernel("intt", 16.0 * n * n_cols);
             launch_intt_dif(st, ctx->tables, d_in, in_stride, c->coeffs_br, n, n_cols, log_n);
+            ctx->end_kernel();
             break;
         case CommitInput::CoeffsNatural:
             if (in_stride == n) {
@@ -74,9 +76,16 @@ int32_t commit_build(nlx_ctx* ctx, const uint64_t* d_in, size_t in_stride, Commi
             }
             break;
     }
+    // algorithmic bytes per SURVEY.md §8(d): LDE 8n + 8L per column; leaf hash 8cL + 32L; tree 64L
+    ctx->begin_kernel("lde", (8.0 * n + 8.0 * L) * n_cols);
     launch_lde_dit(st, ctx->tables, c->coeffs_br, n, c->lde, L, n_cols, log_n, rate_bits, scale);
+    ctx->end_kernel();
+    ctx->begin_kernel("hash_lde_leaves", 8.0 * n_cols * L + 32.0 * L);
     launch_hash_lde_leaves(st, c->lde, L, n_cols, log_n, rate_bits, c->digests);
+    ctx->end_kernel();
+    ctx->begin_kernel("merkle_levels", 64.0 * L);
     c->cap = launch_merkle_levels(st, c->digests, L, cap_height);
+    ctx->end_kernel();
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         ctx->release(c->coeffs_br);

@@ -93,6 +93,27 @@ int32_t nlx_ctx::get_nat_scale(unsigned log_n, uint64_t shift, const uint64_t** 
     return NLX_OK;
 }
 
+hipEvent_t nlx_ctx::get_event() {
+    if (!event_pool.empty()) {
+        hipEvent_t e = event_pool.back();
+        event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void nlx_ctx::begin_kernel(const char* name, double alg_bytes) {
+    if (!kernel_timing) return;
+    KernelSample ks{name, alg_bytes, get_event(), get_event()};
+    (void)hipEventRecord(ks.e0, stream);
+    samples.push_back(ks);
+}
+void nlx_ctx::end_kernel() {
+    if (!kernel_timing || samples.empty()) return;
+    (void)hipEventRecord(samples.back().e1, stream);
+}
+
 namespace nlx {
 
 bool is_device_ptr(const void* p) {
@@ -195,6 +216,8 @@ void nlx_ctx_destroy(nlx_ctx* c) {
     for (auto& kv : c->live_blocks) (void)hipFree(kv.first);
     for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (auto& ks : c->samples) { (void)hipEventDestroy(ks.e0); (void)hipEventDestroy(ks.e1); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -206,6 +229,39 @@ int32_t nlx_ctx_set_stream(nlx_ctx* c, void* hip_stream) {
     (void)hipSetDevice(c->device);
     NLX_HIP(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return NLX_OK;
+}
+
+int32_t nlx_ctx_kernel_timing(nlx_ctx* c, int enable) {
+    if (!c) return NLX_E_INVAL;
+    (void)hipSetDevice(c->device);
+    NLX_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& ks : c->samples) {
+        c->event_pool.push_back(ks.e0);
+        c->event_pool.push_back(ks.e1);
+    }
+    c->samples.clear();
+    c->kernel_timing = enable != 0;
+    return NLX_OK;
+}
+
+int32_t nlx_ctx_kernel_stats(nlx_ctx* c, const char* name, uint64_t* calls, double* total_ms, double* alg_bytes) {
+    if (!c || !name) return NLX_E_INVAL;
+    (void)hipSetDevice(c->device);
+    NLX_HIP(c, hipStreamSynchronize(c->stream));
+    uint64_t n = 0;
+    double ms = 0, bytes = 0;
+    for (auto& ks : c->samples) {
+        if (strcmp(ks.name, name) != 0) continue;
+        float t = 0;
+        if (hipEventElapsedTime(&t, ks.e0, ks.e1) != hipSuccess) continue;
+        n++;
+        ms += t;
+        bytes += ks.alg_bytes;
+    }
+    if (calls) *calls = n;
+    if (total_ms) *total_ms = ms;
+    if (alg_bytes) *alg_bytes = bytes;
     return NLX_OK;
 }
 

@@ -29,6 +29,16 @@ struct nlx_ctx {
     // shift^i (natural order) tables for nlx_ntt_batch keyed by (log_n, shift)
     std::map<std::pair<uint32_t, uint64_t>, uint64_t*> nat_scale;
 
+    // Optional per-kernel device timing (HIP events on `stream` around selected launches); used by
+    // bench.py to report the dominant kernel's average duration from inside the timed region.
+    struct KernelSample { const char* name; double alg_bytes; hipEvent_t e0, e1; };
+    bool kernel_timing = false;
+    std::vector<KernelSample> samples;
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t get_event();
+    void begin_kernel(const char* name, double alg_bytes);
+    void end_kernel();
+
     // pinned staging buffer for small device->host reads
     void* pinned = nullptr;
     size_t pinned_bytes = 0;

@@ -444,7 +444,9 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
             qp.alpha_stride = c->n_terms;
             qp.log_n = log_n; qp.rate_bits = d.rate_bits; qp.n_gates = d.num_gates; qp.n_selectors = d.num_selectors;
             qp.n_consts_all = c->n_consts_all; qp.routed = routed; qp.chunk = d.quotient_degree_factor; qp.nc = nc; qp.npp = npp;
+            ctx->begin_kernel("quotient", 8.0 * L * (c->n_cs + d.num_wires + c->n_zs + nc) + 8.0 * L * nc);
             launch_quotient(st, qp);
+            ctx->end_kernel();
         }
         stage("quotient_intt");
         launch_intt_dif_cosets(st, ctx->tables, d_qvals, nc, log_n, d.rate_bits, c->d_inv_scale_br);
@@ -534,7 +536,9 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
             fp.alpha_nz[0] = ap.a; fp.alpha_nz[1] = ap.b;  // alpha^nc
             fp.out = d_fri_a;
             fp.log_n = log_n; fp.rate_bits = d.rate_bits; fp.nz = nc;
+            ctx->begin_kernel("fri_combine", 8.0 * L * n_open + 16.0 * L);
             launch_fri_combine(st, fp);
+            ctx->end_kernel();
         }
         // commit phase: layer values ping-pong between d_fri_a / d_fri_b; digests kept per layer
         stage("fri_commit_phase");

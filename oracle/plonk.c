@@ -368,12 +368,15 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
     /* 4. wires_permutation_partial_products_and_zs: column order [Z_0..Z_{nc-1}, pp(0,·), pp(1,·)..] */
     uint64_t* zs_values = (uint64_t*)malloc(8 * n * c->n_zs);
     {
+        /* (i) per row, in parallel: cumulative chunk quotients; (ii) serial running product down the
+         * rows (Z_0 = 1, Z_{i+1} = Z_i * rowprod_i); (iii) partial products = Z_i * cumulative quotient */
         uint64_t w_n = gl_root_of_unity(c->log_n);
         uint32_t n_chunks = (routed + chunk - 1) / chunk;
         for (uint32_t ci = 0; ci < nc; ci++) {
-            uint64_t z_x = 1, x = 1;
+#pragma omp parallel for schedule(static)
             for (size_t i = 0; i < n; i++) {
-                uint64_t acc = z_x;
+                uint64_t x = gl_pow(w_n, i);
+                uint64_t acc = 1;
                 for (uint32_t q = 0; q < n_chunks; q++) {
                     uint64_t num = 1, den = 1;
                     for (uint32_t j = q * chunk; j < (q + 1) * chunk && j < routed; j++) {
@@ -384,11 +387,21 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
                     }
                     acc = gl_mul(acc, gl_mul(num, gl_inv(den)));
                     if (q + 1 < n_chunks) zs_values[(size_t)(nc + ci * npp + q) * n + i] = acc;
+                    else zs_values[(size_t)ci * n + i] = acc;
                 }
-                zs_values[(size_t)ci * n + i] = z_x;
-                z_x = acc; /* Z(g x) */
-                x = gl_mul(x, w_n);
             }
+            uint64_t z_x = 1;
+            for (size_t i = 0; i < n; i++) {
+                uint64_t rowprod = zs_values[(size_t)ci * n + i];
+                zs_values[(size_t)ci * n + i] = z_x;
+                z_x = gl_mul(z_x, rowprod);
+            }
+#pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < n; i++)
+                for (uint32_t q = 0; q + 1 < n_chunks; q++) {
+                    uint64_t* pp = &zs_values[(size_t)(nc + ci * npp + q) * n + i];
+                    *pp = gl_mul(*pp, zs_values[(size_t)ci * n + i]);
+                }
         }
     }
     if (tr && tr->zs_partial_values) memcpy(tr->zs_partial_values, zs_values, 8 * n * c->n_zs);
@@ -452,10 +465,14 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
     gl2* open_zeta = (gl2*)malloc(sizeof(gl2) * n_open);
     gl2* open_next = (gl2*)malloc(sizeof(gl2) * nc);
     {
-        uint32_t k = 0;
-        for (int o = 0; o < 4; o++)
-            for (uint32_t p = 0; p < oracles[o]->n_cols; p++, k++)
-                open_zeta[k] = eval_base_poly_ext(oracles[o]->coeffs + (size_t)p * n, n, zeta);
+        uint32_t base_k[5] = {0, 0, 0, 0, 0};
+        for (int o = 0; o < 4; o++) base_k[o + 1] = base_k[o] + oracles[o]->n_cols;
+#pragma omp parallel for schedule(dynamic)
+        for (uint32_t k = 0; k < n_open; k++) {
+            int o = 0;
+            while (k >= base_k[o + 1]) o++;
+            open_zeta[k] = eval_base_poly_ext(oracles[o]->coeffs + (size_t)(k - base_k[o]) * n, n, zeta);
+        }
         for (uint32_t p = 0; p < nc; p++) open_next[p] = eval_base_poly_ext(bz.coeffs + (size_t)p * n, n, g_zeta);
     }
     /* proof: caps + OpeningSet {constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys} */
@@ -482,13 +499,20 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
     {
         /* batch 0: all polynomials at zeta */
         gl2* comp = (gl2*)calloc(n, sizeof(gl2));
-        gl2 apow = gl2_from(1);
-        for (int o = 0; o < 4; o++)
-            for (uint32_t p = 0; p < oracles[o]->n_cols; p++) {
-                const uint64_t* co = oracles[o]->coeffs + (size_t)p * n;
-                for (size_t i = 0; i < n; i++) comp[i] = gl2_add(comp[i], gl2_scale(apow, co[i]));
-                apow = gl2_mul(apow, alpha);
-            }
+        gl2* apows = (gl2*)malloc(sizeof(gl2) * (n_open + 1));
+        apows[0] = gl2_from(1);
+        for (uint32_t k = 0; k < n_open; k++) apows[k + 1] = gl2_mul(apows[k], alpha);
+        gl2 apow;
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < n; i++) {
+            gl2 acc = gl2_from(0);
+            uint32_t k = 0;
+            for (int o = 0; o < 4; o++)
+                for (uint32_t p = 0; p < oracles[o]->n_cols; p++, k++)
+                    acc = gl2_add(acc, gl2_scale(apows[k], oracles[o]->coeffs[(size_t)p * n + i]));
+            comp[i] = acc;
+        }
+        free(apows);
         /* divide_by_linear(zeta): q_{i-1} = c_i + z q_i */
         gl2 acc = gl2_from(0);
         for (size_t i = n; i-- > 1;) { acc = gl2_add(gl2_mul(acc, zeta), comp[i]); final_poly[i - 1] = acc; }
@@ -563,14 +587,21 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
         memcpy(st0, ch.state, sizeof st0);
         memcpy(st0, ch.in_buf, ch.n_in * 8);
         unsigned pos = ch.n_in;
-        for (uint64_t cand = 0;; cand++) {
-            uint64_t st[12];
-            memcpy(st, st0, sizeof st);
-            st[pos] = cand;
-            orc_poseidon_permute(st);
-            uint64_t resp = st[7]; /* squeeze().last() */
-            unsigned lz = resp ? (unsigned)__builtin_clzll(resp) : 64;
-            if (lz >= min_lz) { pow_witness = cand; break; }
+        const uint64_t CH = 1 << 14;
+        int found = 0;
+        for (uint64_t start = 0; !found; start += CH) {
+            uint64_t best = ~0ULL;
+#pragma omp parallel for schedule(static) reduction(min : best)
+            for (uint64_t cand = start; cand < start + CH; cand++) {
+                uint64_t st[12];
+                memcpy(st, st0, sizeof st);
+                st[pos] = cand;
+                orc_poseidon_permute(st);
+                uint64_t resp = st[7]; /* squeeze().last() */
+                unsigned lz = resp ? (unsigned)__builtin_clzll(resp) : 64;
+                if (lz >= min_lz && cand < best) best = cand;
+            }
+            if (best != ~0ULL) { pow_witness = best; found = 1; }
         }
         orc_ch_observe(&ch, pow_witness);
         (void)orc_ch_challenge(&ch); /* pow_response */
