@@ -122,6 +122,9 @@ __global__ __launch_bounds__(256) void k_merkle_level(const uint64_t* __restrict
     store_digest(parents, i, s);
 }
 
+constexpr size_t MERKLE_WIDE_MAX_PARENTS = (size_t)1 << 14;
+void launch_merkle_level_wide(hipStream_t st, const uint64_t* children, uint64_t* parents, size_t n_parents);
+
 // ---- host launchers (stream-ordered, no synchronisation) ----
 void launch_permute_batch(hipStream_t st, uint64_t* d_states, size_t n) {
     if (!n) return;
@@ -151,7 +154,10 @@ const uint64_t* launch_merkle_levels(hipStream_t st, uint64_t* d_digests, size_t
     while (lvl > cap) {
         uint64_t* nxt = cur + lvl * 4;
         size_t half = lvl >> 1;
-        hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, cur, nxt, half);
+        // below ~2^14 parents a level no longer fills the chip with one lane per permutation:
+        // switch to the 16-lanes-per-permutation kernel (latency ~1/5)
+        if (half <= MERKLE_WIDE_MAX_PARENTS) launch_merkle_level_wide(st, cur, nxt, half);
+        else hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, cur, nxt, half);
         cur = nxt;
         lvl = half;
     }
@@ -206,6 +212,106 @@ void launch_hash_lde_leaves(hipStream_t st, const uint64_t* d_lde, size_t col_st
     size_t rows = (size_t)1 << (log_n + rate_bits);
     hipLaunchKernelGGL(k_hash_lde_leaves, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, d_lde, col_stride,
                        n_cols, log_n, rate_bits, d_digests);
+}
+
+}  // namespace nlx
+
+// =====================================================================================
+// Latency-optimised ("wide") Poseidon for small tree levels
+// =====================================================================================
+// One permutation per 16-lane group, one state element per lane (lanes 12..15 idle).  A level
+// with m parents occupies 16*m lanes, so levels too small to fill the chip finish in ~1/5 of
+// the one-lane-per-permutation latency (the dependent chain per round is one S-box plus one
+// 12-term dot product instead of twelve of each).  The linear layer exchanges elements through
+// a per-group LDS slot (1 ds_write_b64 + 12 broadcast ds_read_b64 per round).
+namespace nlx {
+
+constexpr unsigned WIDE_GROUPS_PER_BLOCK = 16;  // 256 threads
+
+__device__ __forceinline__ gl32::F permute_wide(gl32::F x, uint32_t j, volatile uint64_t* slot) {
+    constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const uint64_t* rc = poseidon::RC_DEV;
+    const uint32_t jj = j < 12 ? j : 0;
+    const uint32_t diag = j == 0 ? 8u : 0u;
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+        x = gl32::add_const_v(x, rc[r * 12 + jj]);
+        const gl32::F x7 = gl32::sbox7(x);
+        const bool full = (r < 4) || (r >= 26);
+        if (full || j == 0) x = x7;
+        __syncthreads();  // previous round's reads are done
+        if (j < 12) slot[j] = gl32::to_u64(x);
+        __syncthreads();
+        uint64_t al = (uint64_t)x.lo * diag, ah = (uint64_t)x.hi * diag;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            uint32_t src = jj + i;
+            src = src >= 12 ? src - 12 : src;
+            const uint64_t v = slot[src];
+            al += (uint64_t)(uint32_t)v * C[i];
+            ah += (uint64_t)(uint32_t)(v >> 32) * C[i];
+        }
+        x = gl32::fold_acc(al, ah);
+    }
+    return x;
+}
+
+// parents[i] = two_to_one(children[2i], children[2i+1]), one parent per 16 lanes
+__global__ __launch_bounds__(256) void k_merkle_level_wide(const uint64_t* __restrict__ children,
+                                                           uint64_t* __restrict__ parents, size_t n_parents) {
+    __shared__ uint64_t lds[WIDE_GROUPS_PER_BLOCK * 12];
+    const uint32_t j = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * WIDE_GROUPS_PER_BLOCK + g;
+    const bool live = i < n_parents;
+    uint64_t v = 0;
+    if (live && j < 8) v = children[i * 8 + j];
+    gl32::F x = permute_wide(gl32::from_u64(v), j, lds + g * 12);
+    if (live && j < 4) parents[i * 4 + j] = gl::canon(gl32::to_u64(x));
+}
+
+// FRI layer leaves, one leaf per 16 lanes (see k_fri_leaves for the index maps)
+template <int ARITY_BITS>
+__global__ __launch_bounds__(256) void k_fri_leaves_wide(const uint64_t* __restrict__ values, unsigned log_n,
+                                                         unsigned rate_bits, uint64_t* __restrict__ digests) {
+    __shared__ uint64_t lds[WIDE_GROUPS_PER_BLOCK * 12];
+    constexpr int ARITY = 1 << ARITY_BITS;
+    const unsigned log_np = log_n - ARITY_BITS;
+    const uint32_t j = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const size_t jp = (size_t)blockIdx.x * WIDE_GROUPS_PER_BLOCK + g;
+    const bool live = (jp >> (log_np + rate_bits)) == 0;
+    const size_t np = (size_t)1 << log_np, n = (size_t)1 << log_n;
+    const uint32_t r = (uint32_t)(jp >> log_np), kp = (uint32_t)(jp & (np - 1));
+    gl32::F x = gl32::from_u64(0);
+    // absorb 8 words (4 extension elements, slots m0..m0+3) per permutation; lane j < 8 owns word j
+#pragma unroll 1
+    for (int m0 = 0; m0 < ARITY; m0 += 4) {
+        if (j < 8) {
+            const int m = m0 + (int)(j >> 1);
+            const uint32_t mm = gl::bitrev32((uint32_t)m, ARITY_BITS);
+            uint64_t v = 0;
+            if (live) v = values[2 * ((size_t)r * n + kp + (size_t)mm * np) + (j & 1)];
+            x = gl32::from_u64(v);  // overwrite-mode absorb
+        }
+        x = permute_wide(x, j, lds + g * 12);
+    }
+    if (live && j < 4) {
+        const size_t leaf = ((size_t)gl::bitrev32(r, rate_bits) << log_np) + gl::bitrev32(kp, log_np);
+        digests[leaf * 4 + j] = gl::canon(gl32::to_u64(x));
+    }
+}
+
+void launch_fri_leaves_wide(hipStream_t st, const uint64_t* d_values, unsigned log_n, unsigned rate_bits,
+                            unsigned arity_bits, uint64_t* d_digests) {
+    const size_t leaves = (size_t)1 << (log_n - arity_bits + rate_bits);
+    const unsigned blocks = (unsigned)((leaves + WIDE_GROUPS_PER_BLOCK - 1) / WIDE_GROUPS_PER_BLOCK);
+    if (arity_bits == 4) hipLaunchKernelGGL(k_fri_leaves_wide<4>, dim3(blocks), dim3(256), 0, st, d_values, log_n, rate_bits, d_digests);
+    else if (arity_bits == 3) hipLaunchKernelGGL(k_fri_leaves_wide<3>, dim3(blocks), dim3(256), 0, st, d_values, log_n, rate_bits, d_digests);
+    else if (arity_bits == 2) hipLaunchKernelGGL(k_fri_leaves_wide<2>, dim3(blocks), dim3(256), 0, st, d_values, log_n, rate_bits, d_digests);
+}
+
+void launch_merkle_level_wide(hipStream_t st, const uint64_t* children, uint64_t* parents, size_t n_parents) {
+    hipLaunchKernelGGL(k_merkle_level_wide, dim3((unsigned)((n_parents + WIDE_GROUPS_PER_BLOCK - 1) / WIDE_GROUPS_PER_BLOCK)),
+                       dim3(256), 0, st, children, parents, n_parents);
 }
 
 }  // namespace nlx

@@ -553,7 +553,8 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
             uint64_t* dg = dalloc(merkle_digest_words(n_leaves, cap_h) * 8);
             CHECK_ALLOC(dg);
             layer_digests[r] = dg;
-            launch_fri_leaves(st, layer_values[r], ln, d.rate_bits, d.fri_arity_bits, dg);
+            if (n_leaves <= ((size_t)1 << 13)) launch_fri_leaves_wide(st, layer_values[r], ln, d.rate_bits, d.fri_arity_bits, dg);
+            else launch_fri_leaves(st, layer_values[r], ln, d.rate_bits, d.fri_arity_bits, dg);
             const uint64_t* d_cap = launch_merkle_levels(st, dg, n_leaves, cap_h);
             CHECK(fetch(ctx, cap.data(), d_cap, capw * 8));
             w.u64s(cap.data(), capw);

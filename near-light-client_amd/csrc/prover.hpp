@@ -59,6 +59,8 @@ struct FriCombineParams {
 void launch_fri_combine(hipStream_t st, const FriCombineParams& p);
 void launch_fri_leaves(hipStream_t st, const uint64_t* d_values, unsigned log_n, unsigned rate_bits,
                        unsigned arity_bits, uint64_t* d_digests);
+void launch_fri_leaves_wide(hipStream_t st, const uint64_t* d_values, unsigned log_n, unsigned rate_bits,
+                            unsigned arity_bits, uint64_t* d_digests);
 void launch_fri_fold(hipStream_t st, const uint64_t* d_values, uint64_t* d_out, unsigned log_n, unsigned rate_bits,
                      unsigned arity_bits, const uint64_t beta[2], uint64_t shift_inv, const uint64_t* d_w_L_inv_table,
                      const uint64_t* d_w_A_inv_pows);

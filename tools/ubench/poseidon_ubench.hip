@@ -1,0 +1,230 @@
+// Development micro-benchmark: instruction issue rates on gfx950 and Poseidon permutation variants.
+// Build: hipcc -O3 --offload-arch=gfx950 -I near-light-client_amd/csrc tools/ubench/poseidon_ubench.hip -o /tmp/pub
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "poseidon.hpp"
+#include "gl32.hpp"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+// ---- issue-rate probes: N dependent-free instructions per lane, 8 independent chains ----
+template <int OP>
+__global__ void k_rate(uint32_t* out, uint32_t a, uint32_t b, int iters) {
+    uint32_t x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    uint64_t y0 = x0, y1 = x1, y2 = x2, y3 = x3, y4 = x4, y5 = x5, y6 = x6, y7 = x7;
+    for (int i = 0; i < iters; i++) {
+        if (OP == 0) {  // v_mad_u32_u24
+            asm volatile("v_mad_u32_u24 %0, %0, %8, %9\n v_mad_u32_u24 %1, %1, %8, %9\n v_mad_u32_u24 %2, %2, %8, %9\n v_mad_u32_u24 %3, %3, %8, %9\n"
+                         "v_mad_u32_u24 %4, %4, %8, %9\n v_mad_u32_u24 %5, %5, %8, %9\n v_mad_u32_u24 %6, %6, %8, %9\n v_mad_u32_u24 %7, %7, %8, %9\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+        } else if (OP == 1) {  // v_mul_lo_u32
+            asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n"
+                         "v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+        } else if (OP == 2) {  // v_mul_hi_u32
+            asm volatile("v_mul_hi_u32 %0, %0, %8\n v_mul_hi_u32 %1, %1, %8\n v_mul_hi_u32 %2, %2, %8\n v_mul_hi_u32 %3, %3, %8\n"
+                         "v_mul_hi_u32 %4, %4, %8\n v_mul_hi_u32 %5, %5, %8\n v_mul_hi_u32 %6, %6, %8\n v_mul_hi_u32 %7, %7, %8\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+        } else if (OP == 3) {  // v_mad_u64_u32
+            asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+                         "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n"
+                         : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7) : "v"(a), "v"(b) : "vcc");
+        } else if (OP == 4) {  // v_add_u32 (reference full-rate op)
+            asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                         "v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+        } else if (OP == 5) {  // v_lshl_add_u64
+            asm volatile("v_lshl_add_u64 %0, %0, 1, %0\n v_lshl_add_u64 %1, %1, 1, %1\n v_lshl_add_u64 %2, %2, 1, %2\n v_lshl_add_u64 %3, %3, 1, %3\n"
+                         "v_lshl_add_u64 %4, %4, 1, %4\n v_lshl_add_u64 %5, %5, 1, %5\n v_lshl_add_u64 %6, %6, 1, %6\n v_lshl_add_u64 %7, %7, 1, %7\n"
+                         : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7));
+        } else if (OP == 6) {  // v_fma_f64
+            double d0 = __longlong_as_double(y0), d1 = __longlong_as_double(y1), d2 = __longlong_as_double(y2), d3 = __longlong_as_double(y3);
+            double d4 = __longlong_as_double(y4), d5 = __longlong_as_double(y5), d6 = __longlong_as_double(y6), d7 = __longlong_as_double(y7);
+            double c = (double)a;
+            asm volatile("v_fma_f64 %0, %0, %8, %8\n v_fma_f64 %1, %1, %8, %8\n v_fma_f64 %2, %2, %8, %8\n v_fma_f64 %3, %3, %8, %8\n"
+                         "v_fma_f64 %4, %4, %8, %8\n v_fma_f64 %5, %5, %8, %8\n v_fma_f64 %6, %6, %8, %8\n v_fma_f64 %7, %7, %8, %8\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(c));
+            y0 = __double_as_longlong(d0); y1 = __double_as_longlong(d1); y2 = __double_as_longlong(d2); y3 = __double_as_longlong(d3);
+            y4 = __double_as_longlong(d4); y5 = __double_as_longlong(d5); y6 = __double_as_longlong(d6); y7 = __double_as_longlong(d7);
+        } else if (OP == 7) {  // v_mul_u32_u24
+            asm volatile("v_mul_u32_u24 %0, %0, %8\n v_mul_u32_u24 %1, %1, %8\n v_mul_u32_u24 %2, %2, %8\n v_mul_u32_u24 %3, %3, %8\n"
+                         "v_mul_u32_u24 %4, %4, %8\n v_mul_u32_u24 %5, %5, %8\n v_mul_u32_u24 %6, %6, %8\n v_mul_u32_u24 %7, %7, %8\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+        } else if (OP == 8) {  // v_mul_hi_u32_u24
+            asm volatile("v_mul_hi_u32_u24 %0, %0, %8\n v_mul_hi_u32_u24 %1, %1, %8\n v_mul_hi_u32_u24 %2, %2, %8\n v_mul_hi_u32_u24 %3, %3, %8\n"
+                         "v_mul_hi_u32_u24 %4, %4, %8\n v_mul_hi_u32_u24 %5, %5, %8\n v_mul_hi_u32_u24 %6, %6, %8\n v_mul_hi_u32_u24 %7, %7, %8\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7 ^ (uint32_t)(y0 ^ y1 ^ y2 ^ y3 ^ y4 ^ y5 ^ y6 ^ y7);
+}
+
+template <int OP>
+int rate(const char* name, uint32_t* d_out) {
+    const int iters = 4096, blocks = 256 * 8, threads = 256;  // 8 waves per SIMD
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_rate<OP>, dim3(blocks), dim3(threads), 0, 0, d_out, 12345u, 678u, 16);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_rate<OP>, dim3(blocks), dim3(threads), 0, 0, d_out, 12345u, 678u, iters);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double wave_instrs = (double)blocks * (threads / 64) * iters * 8;
+    double per_simd = wave_instrs / 1024.0;  // 256 CUs x 4 SIMDs
+    printf("%-18s %.3f ms  -> %.2f ns per wave-instruction per SIMD (%.1f cycles @2.4GHz)\n", name, ms, ms * 1e6 / per_simd, ms * 1e6 / per_simd * 2.4);
+    return 0;
+}
+
+// ---- Poseidon variants ----
+namespace v1 {
+// MDS on three 22-bit limbs with full-rate 24-bit multiply-adds
+__device__ __forceinline__ void mds_layer(uint64_t (&s)[12]) {
+    constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    uint32_t l0[12], l1[12], l2[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        l0[i] = (uint32_t)s[i] & 0x3FFFFFu;
+        l1[i] = (uint32_t)(s[i] >> 22) & 0x3FFFFFu;
+        l2[i] = (uint32_t)(s[i] >> 44);
+    }
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        uint32_t a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            a0 = __umul24(l0[(i + r) % 12], C[i]) + a0;
+            a1 = __umul24(l1[(i + r) % 12], C[i]) + a1;
+            a2 = __umul24(l2[(i + r) % 12], C[i]) + a2;
+        }
+        if (r == 0) {
+            a0 += l0[0] << 3; a1 += l1[0] << 3; a2 += l2[0] << 3;
+        }
+        // value = a0 + a1 * 2^22 + a2 * 2^44   (a_k < 2^31)
+        uint64_t lo = (uint64_t)a0 + ((uint64_t)a1 << 22);
+        uint64_t add = (uint64_t)(a2 & 0xFFFFFu) << 44;
+        uint64_t l = lo + add;
+        uint64_t h = (uint64_t)(a2 >> 20) + (l < add ? 1u : 0u);
+        uint64_t t1 = (h << 32) - h;
+        uint64_t res = l + t1;
+        if (res < t1) res += gl::EPS;
+        s[r] = res;
+    }
+}
+__device__ __forceinline__ void permute_loose(uint64_t (&s)[12]) {
+    const uint64_t* rc = poseidon::RC_DEV;
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = poseidon::sbox7(gl::add_loose(s[i], rc[r * 12 + i]));
+        mds_layer(s);
+    }
+#pragma unroll 1
+    for (int r = 4; r < 26; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl::add_loose(s[i], rc[r * 12 + i]);
+        s[0] = poseidon::sbox7(s[0]);
+        mds_layer(s);
+    }
+#pragma unroll 1
+    for (int r = 26; r < 30; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = poseidon::sbox7(gl::add_loose(s[i], rc[r * 12 + i]));
+        mds_layer(s);
+    }
+}
+}  // namespace v1
+
+namespace v2 {
+__device__ __forceinline__ void permute_loose(uint64_t (&st)[12]) {
+    const uint64_t* rc = poseidon::RC_DEV;
+    gl32::F s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl32::from_u64(st[i]);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl32::sbox7(gl32::add_const(s[i], rc[r * 12 + i]));
+        gl32::mds_layer(s);
+    }
+#pragma unroll 1
+    for (int r = 4; r < 26; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl32::add_const(s[i], rc[r * 12 + i]);
+        s[0] = gl32::sbox7(s[0]);
+        gl32::mds_layer(s);
+    }
+#pragma unroll 1
+    for (int r = 26; r < 30; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl32::sbox7(gl32::add_const(s[i], rc[r * 12 + i]));
+        gl32::mds_layer(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = gl32::to_u64(s[i]);
+}
+}  // namespace v2
+
+template <int V>
+__global__ __launch_bounds__(256) void k_perm(uint64_t* states, size_t n, int reps) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = states[i * n + t];
+    for (int k = 0; k < reps; k++) {
+        if (V == 0) poseidon::permute_loose(s);
+        else if (V == 1) v1::permute_loose(s);
+        else v2::permute_loose(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) states[i * n + t] = gl::canon(s[i]);
+}
+
+template <int V>
+int bench_perm(const char* name, uint64_t* d_states, size_t n, std::vector<uint64_t>& out) {
+    std::vector<uint64_t> init(12 * n);
+    uint64_t x = 88172645463325252ull;
+    for (auto& v : init) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = x % gl::P; }
+    CK(hipMemcpy(d_states, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 4;
+    hipLaunchKernelGGL(k_perm<V>, dim3((unsigned)(n / 256)), dim3(256), 0, 0, d_states, n, 1);
+    CK(hipMemcpy(d_states, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_perm<V>, dim3((unsigned)(n / 256)), dim3(256), 0, 0, d_states, n, reps);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    out.resize(12 * n);
+    CK(hipMemcpy(out.data(), d_states, out.size() * 8, hipMemcpyDeviceToHost));
+    printf("%-28s %.3f ms for %zu x %d perms -> %.3f Gperm/s\n", name, ms, n, reps, n * reps / ms / 1e6);
+    return 0;
+}
+
+int main() {
+    uint32_t* d_out;
+    CK(hipMalloc(&d_out, 256 * 8 * 256 * 4));
+    rate<4>("v_add_u32", d_out);
+    rate<0>("v_mad_u32_u24", d_out);
+    rate<7>("v_mul_u32_u24", d_out);
+    rate<8>("v_mul_hi_u32_u24", d_out);
+    rate<1>("v_mul_lo_u32", d_out);
+    rate<2>("v_mul_hi_u32", d_out);
+    rate<3>("v_mad_u64_u32", d_out);
+    rate<5>("v_lshl_add_u64", d_out);
+    rate<6>("v_fma_f64", d_out);
+    size_t n = 1 << 21;
+    uint64_t* d_states;
+    CK(hipMalloc(&d_states, 12 * n * 8));
+    std::vector<uint64_t> o0, o1;
+    bench_perm<0>("poseidon v0 (mad_u64_u32 MDS)", d_states, n, o0);
+    bench_perm<1>("poseidon v1 (u24 limb MDS)", d_states, n, o1);
+    printf("v1 == v0: %s\n", o0 == o1 ? "yes" : "NO");
+    std::vector<uint64_t> o2;
+    bench_perm<2>("poseidon v2 (u32-pair asm)", d_states, n, o2);
+    printf("v2 == v0: %s\n", o0 == o2 ? "yes" : "NO");
+    return 0;
+}
