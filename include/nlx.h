@@ -203,6 +203,10 @@ void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_
  * wires[135 x n], public_inputs[num_public_inputs].  The witness satisfies every constraint. */
 int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint64_t* k_is, uint64_t* constants,
                           uint64_t* sigmas, uint64_t* wires, uint64_t* public_inputs);
+/* Re-target a generated witness (host buffer, 135 x n column-major) to other public inputs: rewrites the
+ * PublicInputGate row so the witness stays satisfying.  Used by the map-reduce workload, where a reduce
+ * job's public inputs are its children's digests. */
+int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint64_t* public_inputs, uint32_t count);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,7 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_uint64)]),
     "nlx_synth_shape": (None, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     "nlx_synth_circuit": (ctypes.c_int32, [ctypes.c_void_p] * 7),
+    "nlx_synth_set_public_inputs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -160,6 +160,24 @@ void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_
     *n_selectors = sel;
 }
 
+// Re-target a generated witness to new public inputs: only the PublicInputGate row (row 0, wires
+// 0..3 = hash_no_pad(public_inputs)) depends on them.
+int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint64_t* public_inputs, uint32_t count) {
+    if (!wires || (!public_inputs && count)) return NLX_E_INVAL;
+    const size_t n = (size_t)1 << log_n;
+    uint64_t st[12] = {0};
+    for (uint32_t off = 0; off < count; off += 8) {
+        uint32_t m = count - off < 8 ? count - off : 8;
+        for (uint32_t j = 0; j < m; j++) {
+            if (public_inputs[off + j] >= gl::P) return NLX_E_INVAL;
+            st[j] = public_inputs[off + j];
+        }
+        poseidon::permute(st);
+    }
+    for (int i = 0; i < 4; i++) wires[(size_t)i * n] = st[i];
+    return NLX_OK;
+}
+
 int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint64_t* k_is, uint64_t* constants,
                           uint64_t* sigmas, uint64_t* wires, uint64_t* public_inputs) {
     const uint32_t W = 135, ROUTED = 80, NCONST = 2;

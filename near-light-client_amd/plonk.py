@@ -82,6 +82,16 @@ class SyntheticCircuit:
         if rc != 0:
             raise NlxError(rc, "nlx_synth_circuit failed")
 
+    def set_public_inputs(self, public_inputs):
+        """Re-target the witness to other public inputs (keeps it satisfying)."""
+        pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        if pis.size != self.public_inputs.size:
+            raise ValueError("the number of public inputs is fixed by the circuit")
+        rc = dll.nlx_synth_set_public_inputs(ptr(self.wires), self.log_n, ptr(pis), pis.size)
+        if rc != 0:
+            raise NlxError(rc, "nlx_synth_set_public_inputs failed")
+        self.public_inputs = pis.copy()
+
     def desc(self):
         c = self.config
         d = CircuitDesc(self.log_n, c.num_wires, c.num_routed_wires, c.num_constants, c.num_challenges, c.rate_bits,
