@@ -233,25 +233,35 @@ __device__ __forceinline__ gl32::F permute_wide(gl32::F x, uint32_t j, volatile 
     const uint64_t* rc = poseidon::RC_DEV;
     const uint32_t jj = j < 12 ? j : 0;
     const uint32_t diag = j == 0 ? 8u : 0u;
+    // A 16-lane group lives inside ONE wave and LDS operations of a wave execute in order, so no
+    // workgroup barrier is needed: a wave-level fence keeps the compiler from reordering the slot
+    // write and the reads around it.  Two slots alternate so a round's reads never race the next
+    // round's write.
 #pragma unroll 1
     for (int r = 0; r < 30; r++) {
         x = gl32::add_const_v(x, rc[r * 12 + jj]);
         const gl32::F x7 = gl32::sbox7(x);
         const bool full = (r < 4) || (r >= 26);
         if (full || j == 0) x = x7;
-        __syncthreads();  // previous round's reads are done
-        if (j < 12) slot[j] = gl32::to_u64(x);
-        __syncthreads();
-        uint64_t al = (uint64_t)x.lo * diag, ah = (uint64_t)x.hi * diag;
+        volatile uint64_t* sl = slot + (r & 1) * 12;
+        if (j < 12) sl[j] = gl32::to_u64(x);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // two accumulator pairs shorten the dependent multiply-add chain
+        uint64_t al = (uint64_t)x.lo * diag, ah = (uint64_t)x.hi * diag, bl = 0, bh = 0;
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            uint32_t src = jj + i;
-            src = src >= 12 ? src - 12 : src;
-            const uint64_t v = slot[src];
-            al += (uint64_t)(uint32_t)v * C[i];
-            ah += (uint64_t)(uint32_t)(v >> 32) * C[i];
+        for (int i = 0; i < 12; i += 2) {
+            uint32_t s0 = jj + i, s1 = jj + i + 1;
+            s0 = s0 >= 12 ? s0 - 12 : s0;
+            s1 = s1 >= 12 ? s1 - 12 : s1;
+            const uint64_t v0 = sl[s0], v1 = sl[s1];
+            al += (uint64_t)(uint32_t)v0 * C[i];
+            ah += (uint64_t)(uint32_t)(v0 >> 32) * C[i];
+            bl += (uint64_t)(uint32_t)v1 * C[i + 1];
+            bh += (uint64_t)(uint32_t)(v1 >> 32) * C[i + 1];
         }
-        x = gl32::fold_acc(al, ah);
+        x = gl32::fold_acc(al + bl, ah + bh);
     }
     return x;
 }
@@ -259,13 +269,13 @@ __device__ __forceinline__ gl32::F permute_wide(gl32::F x, uint32_t j, volatile 
 // parents[i] = two_to_one(children[2i], children[2i+1]), one parent per 16 lanes
 __global__ __launch_bounds__(256) void k_merkle_level_wide(const uint64_t* __restrict__ children,
                                                            uint64_t* __restrict__ parents, size_t n_parents) {
-    __shared__ uint64_t lds[WIDE_GROUPS_PER_BLOCK * 12];
+    __shared__ uint64_t lds[WIDE_GROUPS_PER_BLOCK * 24];
     const uint32_t j = threadIdx.x & 15, g = threadIdx.x >> 4;
     const size_t i = (size_t)blockIdx.x * WIDE_GROUPS_PER_BLOCK + g;
     const bool live = i < n_parents;
     uint64_t v = 0;
     if (live && j < 8) v = children[i * 8 + j];
-    gl32::F x = permute_wide(gl32::from_u64(v), j, lds + g * 12);
+    gl32::F x = permute_wide(gl32::from_u64(v), j, lds + g * 24);
     if (live && j < 4) parents[i * 4 + j] = gl::canon(gl32::to_u64(x));
 }
 
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(256) void k_merkle_level_wide(const uint64_t* __res
 template <int ARITY_BITS>
 __global__ __launch_bounds__(256) void k_fri_leaves_wide(const uint64_t* __restrict__ values, unsigned log_n,
                                                          unsigned rate_bits, uint64_t* __restrict__ digests) {
-    __shared__ uint64_t lds[WIDE_GROUPS_PER_BLOCK * 12];
+    __shared__ uint64_t lds[WIDE_GROUPS_PER_BLOCK * 24];
     constexpr int ARITY = 1 << ARITY_BITS;
     const unsigned log_np = log_n - ARITY_BITS;
     const uint32_t j = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(256) void k_fri_leaves_wide(const uint64_t* __restr
             if (live) v = values[2 * ((size_t)r * n + kp + (size_t)mm * np) + (j & 1)];
             x = gl32::from_u64(v);  // overwrite-mode absorb
         }
-        x = permute_wide(x, j, lds + g * 12);
+        x = permute_wide(x, j, lds + g * 24);
     }
     if (live && j < 4) {
         const size_t leaf = ((size_t)gl::bitrev32(r, rate_bits) << log_np) + gl::bitrev32(kp, log_np);

@@ -295,7 +295,7 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc) {
 
 // One lane per LDE point.  All gates are evaluated at every point (the selector filter zeroes
 // the inactive ones), so control flow is wave-uniform.
-__global__ __launch_bounds__(256) void k_quotient(QuotientParams p) {
+__global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
     const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned log_L = p.log_n + p.rate_bits;
     if (pos >> log_L) return;
