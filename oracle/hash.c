@@ -23,15 +23,27 @@ static inline uint64_t sbox7(uint64_t x) {
     return gl_mul(x3, x4);
 }
 
+/* Linear layer.  Same arithmetic as plonky2's mds_layer: each element is split into 32-bit halves,
+ * the circulant products accumulate in u64 without overflow (12 * 2^32 * 41 < 2^42) and
+ * lo + 2^32 * hi is reduced once.  The doubled arrays make the inner loop contiguous so the
+ * compiler can vectorise it (32x32->64 multiplies). */
 static void mds_layer(uint64_t s[12]) {
-    uint64_t o[12];
-    for (int r = 0; r < 12; r++) {
-        u128 acc = 0; /* 12 * 2^64 * 41 < 2^128 */
-        for (int i = 0; i < 12; i++) acc += (u128)s[(i + r) % 12] * MDS_CIRC[i];
-        acc += (u128)s[r] * MDS_DIAG[r];
-        o[r] = gl_reduce128(acc);
+    uint64_t lo2[24], hi2[24], al[12], ah[12];
+    for (int i = 0; i < 12; i++) {
+        lo2[i] = lo2[i + 12] = s[i] & 0xFFFFFFFFu;
+        hi2[i] = hi2[i + 12] = s[i] >> 32;
     }
-    memcpy(s, o, sizeof o);
+    for (int r = 0; r < 12; r++) { al[r] = 0; ah[r] = 0; }
+    for (int i = 0; i < 12; i++) {
+        const uint64_t c = MDS_CIRC[i];
+        for (int r = 0; r < 12; r++) {
+            al[r] += lo2[i + r] * c;
+            ah[r] += hi2[i + r] * c;
+        }
+    }
+    al[0] += lo2[0] * MDS_DIAG[0];
+    ah[0] += hi2[0] * MDS_DIAG[0];
+    for (int r = 0; r < 12; r++) s[r] = gl_reduce128((u128)al[r] + ((u128)ah[r] << 32));
 }
 
 void orc_poseidon_permute(uint64_t s[12]) {

@@ -159,3 +159,22 @@ def test_error_paths(nlx, ctx):
     pb = nlx.PolynomialBatch.from_values(ctx, np.ones((2, 8), dtype=np.uint64), 3, 2)
     with pytest.raises(nlx.NlxError):
         pb.open_rows(np.array([64], dtype=np.uint64))
+
+
+def _sum_mod_p(a):
+    lo = int((a & np.uint64(0xFFFFFFFF)).sum(dtype=np.uint64))
+    hi = int((a >> np.uint64(32)).sum(dtype=np.uint64))
+    return (lo + (hi << 32)) % P
+
+
+def test_ntt_2p24_three_passes(nlx, ctx):
+    """BASELINE config 5's size (NTT at 2^24, three LDS passes): round trip, DC term, Nyquist term."""
+    rng = np.random.default_rng(24)
+    log_n = 24
+    a = rand_field(rng, (1, 1 << log_n))
+    f = nlx.ntt(ctx, a)
+    assert int(f[0, 0]) == _sum_mod_p(a[0])                       # value at w^0 = sum of coefficients
+    alt = (_sum_mod_p(a[0, 0::2]) - _sum_mod_p(a[0, 1::2])) % P  # value at w^(n/2) = -1: alternating sum
+    assert int(f[0, 1 << (log_n - 1)]) == alt
+    assert np.array_equal(nlx.ntt(ctx, f, inverse=True), a)
+    assert (f < np.uint64(P)).all()

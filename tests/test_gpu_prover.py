@@ -113,3 +113,16 @@ def test_circuit_build_errors(nlx, ctx):
     with pytest.raises(nlx.NlxError):
         nlx.CircuitData(ctx, d, syn.constants, syn.sigmas)
     d.gates[0].kind = 0
+
+
+def test_large_proof_2p17_verifies(nlx, ctx, orc):
+    """2^17 rows (9 GB-class tables are 2^20; this is the largest the CPU verifier setup handles in
+    seconds): three-pass-free NTT path at 2^17, 2^20-point LDE, oracle verifier accepts."""
+    syn = nlx.SyntheticCircuit(17, seed=17, pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    proof = cd.prove(syn.wires, syn.public_inputs)
+    ref = orc.Circuit.from_synthetic(syn)
+    assert np.array_equal(cd.constants_sigmas_cap, ref.constants_sigmas_cap())
+    assert ref.verify(proof) == 1
+    ref.close()
+    cd.close()
