@@ -126,6 +126,11 @@ int32_t nlx_commit_get_digests(nlx_commit* c, uint64_t* digests_out);
 #define NLX_GATE_ARITHMETIC 3    /* gates::arithmetic_base::ArithmeticGate { num_ops = param0 } */
 #define NLX_GATE_BASE_SUM 4      /* gates::base_sum::BaseSumGate<B = param0> { num_limbs = param1 } */
 #define NLX_GATE_POSEIDON 5      /* gates::poseidon::PoseidonGate */
+#define NLX_GATE_ARITHMETIC_EXT 6 /* gates::arithmetic_extension::ArithmeticExtensionGate<2> { num_ops = param0 } */
+#define NLX_GATE_MUL_EXT 7        /* gates::multiplication_extension::MulExtensionGate<2> { num_ops = param0 } */
+#define NLX_GATE_REDUCING 8       /* gates::reducing::ReducingGate<2> { num_coeffs = param0 } */
+#define NLX_GATE_REDUCING_EXT 9   /* gates::reducing_extension::ReducingExtensionGate<2> { num_coeffs = param0 } */
+#define NLX_GATE_KIND_MAX 9
 
 typedef struct {
     uint32_t kind;
@@ -196,6 +201,8 @@ typedef struct {
     uint32_t pct_base_sum;
     uint32_t pct_constant;    /* remaining rows are NoopGate */
     uint64_t seed;
+    uint32_t pct_extension;   /* rows split evenly over ArithmeticExtension / MulExtension / Reducing / ReducingExtension */
+    uint32_t reserved;
 } nlx_synth_params;
 /* number of gates / selector polynomials the generator will emit for these parameters */
 void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_selectors);

@@ -156,7 +156,11 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
     if (d.fri_num_queries > 128 || d.cap_height > 6) return ctx->fail(NLX_E_RANGE, "FRI parameters out of range");
     for (uint32_t g = 0; g < d.num_gates; g++) {
         const nlx_gate_desc& gt = d.gates[g];
-        if (gt.kind > NLX_GATE_POSEIDON) return ctx->fail(NLX_E_UNSUPPORTED, "gate kind %u not supported", gt.kind);
+        if (gt.kind > NLX_GATE_KIND_MAX) return ctx->fail(NLX_E_UNSUPPORTED, "gate kind %u not supported", gt.kind);
+        if (gt.kind == NLX_GATE_ARITHMETIC_EXT && (8 * gt.param0 > d.num_wires || d.num_constants < 2)) return ctx->fail(NLX_E_INVAL, "ArithmeticExtensionGate too wide");
+        if (gt.kind == NLX_GATE_MUL_EXT && 6 * gt.param0 > d.num_wires) return ctx->fail(NLX_E_INVAL, "MulExtensionGate too wide");
+        if (gt.kind == NLX_GATE_REDUCING && (gt.param0 < 1 || 6 + gt.param0 + 2 * (gt.param0 - 1) > d.num_wires)) return ctx->fail(NLX_E_INVAL, "ReducingGate too wide");
+        if (gt.kind == NLX_GATE_REDUCING_EXT && (gt.param0 < 1 || 6 + 2 * gt.param0 + 2 * (gt.param0 - 1) > d.num_wires)) return ctx->fail(NLX_E_INVAL, "ReducingExtensionGate too wide");
         if (gt.selector_index >= d.num_selectors || gt.group_end > d.num_gates || gt.group_start > gt.group_end)
             return ctx->fail(NLX_E_INVAL, "gate %u: bad selector group", g);
         if (gt.kind == NLX_GATE_POSEIDON && d.num_wires < 135) return ctx->fail(NLX_E_INVAL, "PoseidonGate needs 135 wires");

@@ -355,6 +355,48 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
             case NLX_GATE_POSEIDON:
                 gate_poseidon(W, acc);
                 break;
+            case NLX_GATE_ARITHMETIC_EXT: {
+                const uint64_t c0 = CS(p.n_selectors), c1 = CS(p.n_selectors + 1);
+                for (uint32_t i = 0; i < gd.param0; i++) {
+                    const gl::Ext m0{W(8 * i), W(8 * i + 1)}, m1{W(8 * i + 2), W(8 * i + 3)};
+                    const gl::Ext pr = gl::mul(m0, m1);
+                    acc.emit(gl::sub(W(8 * i + 6), gl::add(gl::mul(pr.a, c0), gl::mul(W(8 * i + 4), c1))));
+                    acc.emit(gl::sub(W(8 * i + 7), gl::add(gl::mul(pr.b, c0), gl::mul(W(8 * i + 5), c1))));
+                }
+                break;
+            }
+            case NLX_GATE_MUL_EXT: {
+                const uint64_t c0 = CS(p.n_selectors);
+                for (uint32_t i = 0; i < gd.param0; i++) {
+                    const gl::Ext m0{W(6 * i), W(6 * i + 1)}, m1{W(6 * i + 2), W(6 * i + 3)};
+                    const gl::Ext pr = gl::mul(m0, m1);
+                    acc.emit(gl::sub(W(6 * i + 4), gl::mul(pr.a, c0)));
+                    acc.emit(gl::sub(W(6 * i + 5), gl::mul(pr.b, c0)));
+                }
+                break;
+            }
+            case NLX_GATE_REDUCING:
+            case NLX_GATE_REDUCING_EXT: {
+                const uint32_t nco = gd.param0;
+                const bool ext = gd.kind == NLX_GATE_REDUCING_EXT;
+                const uint32_t start_coeffs = 6, start_accs = start_coeffs + (ext ? 2 * nco : nco);
+                const gl::Ext alpha{W(2), W(3)};
+                gl::Ext a{W(4), W(5)};
+                for (uint32_t i = 0; i < nco; i++) {
+                    const uint32_t aw = (i == nco - 1) ? 0 : start_accs + 2 * i;  // last accumulator = output wires
+                    const gl::Ext nxt{W(aw), W(aw + 1)};
+                    const gl::Ext pr = gl::mul(a, alpha);
+                    if (ext) {
+                        acc.emit(gl::sub(gl::add(pr.a, W(start_coeffs + 2 * i)), nxt.a));
+                        acc.emit(gl::sub(gl::add(pr.b, W(start_coeffs + 2 * i + 1)), nxt.b));
+                    } else {
+                        acc.emit(gl::sub(gl::add(pr.a, W(start_coeffs + i)), nxt.a));
+                        acc.emit(gl::sub(pr.b, nxt.b));
+                    }
+                    a = nxt;
+                }
+                break;
+            }
             default: break;  // NoopGate
         }
         tot0 = gl::add(tot0, gl::mul(f, acc.s0));

@@ -112,6 +112,10 @@ uint32_t gate_degree(uint32_t kind, uint32_t p0) {
         case NLX_GATE_ARITHMETIC: return 3;
         case NLX_GATE_BASE_SUM: return p0;
         case NLX_GATE_POSEIDON: return 7;
+        case NLX_GATE_ARITHMETIC_EXT: return 3;
+        case NLX_GATE_MUL_EXT: return 3;
+        case NLX_GATE_REDUCING: return 2;
+        case NLX_GATE_REDUCING_EXT: return 2;
     }
     return 0;
 }
@@ -133,21 +137,28 @@ struct Dsu {
 
 extern "C" {
 
+// gate list sorted by (degree, id) as plonky2's CircuitBuilder does; the set depends on the mix
+static uint32_t build_gate_list(const nlx_synth_params* sp, uint32_t* kinds, uint32_t* p0, uint32_t* p1) {
+    uint32_t k = 0;
+    auto add = [&](uint32_t kind, uint32_t a, uint32_t b) { kinds[k] = kind; p0[k] = a; p1[k] = b; k++; };
+    add(NLX_GATE_NOOP, 0, 0);                                    // degree 0
+    add(NLX_GATE_CONSTANT, 2, 0);                                // degree 1: "ConstantGate" < "PublicInputGate"
+    add(NLX_GATE_PUBLIC_INPUT, 0, 0);
+    if (sp->pct_base_sum) add(NLX_GATE_BASE_SUM, 2, 63);         // degree 2: "BaseSum" < "ReducingExtension" < "Reducing"
+    if (sp->pct_extension) add(NLX_GATE_REDUCING_EXT, 32, 0);
+    if (sp->pct_extension) add(NLX_GATE_REDUCING, 43, 0);
+    if (sp->pct_extension) add(NLX_GATE_ARITHMETIC_EXT, 10, 0);  // degree 3: "ArithmeticExtension" < "ArithmeticGate" < "Mul..."
+    if (sp->pct_arithmetic) add(NLX_GATE_ARITHMETIC, 20, 0);
+    if (sp->pct_extension) add(NLX_GATE_MUL_EXT, 13, 0);
+    if (sp->pct_poseidon) add(NLX_GATE_POSEIDON, 0, 0);          // degree 7
+    return k;
+}
+
 void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_selectors) {
-    // gate list sorted by (degree, id) as plonky2's CircuitBuilder does; the set depends on the mix
-    uint32_t g = 3;  // noop, constant, public input always present
-    if (sp->pct_base_sum) g++;
-    if (sp->pct_arithmetic) g++;
-    if (sp->pct_poseidon) g++;
+    uint32_t kinds[16], p0[16], p1[16];
+    const uint32_t g = build_gate_list(sp, kinds, p0, p1);
     *n_gates = g;
     // greedy selector groups with max_degree = 8 (gates::selectors::selector_polynomials)
-    uint32_t kinds[6], p0[6], k = 0;
-    kinds[k] = NLX_GATE_NOOP; p0[k++] = 0;
-    kinds[k] = NLX_GATE_CONSTANT; p0[k++] = 2;
-    kinds[k] = NLX_GATE_PUBLIC_INPUT; p0[k++] = 0;
-    if (sp->pct_base_sum) { kinds[k] = NLX_GATE_BASE_SUM; p0[k++] = 2; }
-    if (sp->pct_arithmetic) { kinds[k] = NLX_GATE_ARITHMETIC; p0[k++] = 20; }
-    if (sp->pct_poseidon) { kinds[k] = NLX_GATE_POSEIDON; p0[k++] = 0; }
     uint32_t max_deg = gate_degree(kinds[g - 1], p0[g - 1]);
     if (max_deg + g - 1 <= 8) { *n_selectors = 1; return; }
     uint32_t sel = 0, start = 0;
@@ -189,17 +200,24 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
     // ---- gate table + selector groups ----
     uint32_t n_gates, n_sel;
     nlx_synth_shape(sp, &n_gates, &n_sel);
-    uint32_t k = 0;
-    auto add_gate = [&](uint32_t kind, uint32_t p0, uint32_t p1) {
-        gates[k].kind = kind; gates[k].param0 = p0; gates[k].param1 = p1; gates[k].index = k; k++;
-    };
-    add_gate(NLX_GATE_NOOP, 0, 0);
-    add_gate(NLX_GATE_CONSTANT, 2, 0);
-    add_gate(NLX_GATE_PUBLIC_INPUT, 0, 0);
-    int g_base = -1, g_arith = -1, g_pos = -1;
-    if (sp->pct_base_sum) { g_base = k; add_gate(NLX_GATE_BASE_SUM, 2, 63); }
-    if (sp->pct_arithmetic) { g_arith = k; add_gate(NLX_GATE_ARITHMETIC, 20, 0); }
-    if (sp->pct_poseidon) { g_pos = k; add_gate(NLX_GATE_POSEIDON, 0, 0); }
+    int g_base = -1, g_arith = -1, g_pos = -1, g_aext = -1, g_mext = -1, g_red = -1, g_rext = -1;
+    {
+        uint32_t kinds[16], p0[16], p1[16];
+        const uint32_t k = build_gate_list(sp, kinds, p0, p1);
+        for (uint32_t g = 0; g < k; g++) {
+            gates[g].kind = kinds[g]; gates[g].param0 = p0[g]; gates[g].param1 = p1[g]; gates[g].index = g;
+            switch (kinds[g]) {
+                case NLX_GATE_BASE_SUM: g_base = (int)g; break;
+                case NLX_GATE_ARITHMETIC: g_arith = (int)g; break;
+                case NLX_GATE_POSEIDON: g_pos = (int)g; break;
+                case NLX_GATE_ARITHMETIC_EXT: g_aext = (int)g; break;
+                case NLX_GATE_MUL_EXT: g_mext = (int)g; break;
+                case NLX_GATE_REDUCING: g_red = (int)g; break;
+                case NLX_GATE_REDUCING_EXT: g_rext = (int)g; break;
+                default: break;
+            }
+        }
+    }
     if (n_sel == 1) {
         for (uint32_t g = 0; g < n_gates; g++) { gates[g].selector_index = 0; gates[g].group_start = 0; gates[g].group_end = n_gates; }
     } else {
@@ -256,6 +274,14 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
             else if (r < (t += sp->pct_arithmetic) && g_arith >= 0) { kind = NLX_GATE_ARITHMETIC; gidx = g_arith; }
             else if (r < (t += sp->pct_base_sum) && g_base >= 0) { kind = NLX_GATE_BASE_SUM; gidx = g_base; }
             else if (r < (t += sp->pct_constant)) { kind = NLX_GATE_CONSTANT; gidx = 1; }
+            else if (r < (t += sp->pct_extension) && g_aext >= 0) {
+                switch (row & 3) {
+                    case 0: kind = NLX_GATE_ARITHMETIC_EXT; gidx = g_aext; break;
+                    case 1: kind = NLX_GATE_MUL_EXT; gidx = g_mext; break;
+                    case 2: kind = NLX_GATE_REDUCING; gidx = g_red; break;
+                    default: kind = NLX_GATE_REDUCING_EXT; gidx = g_rext; break;
+                }
+            }
         }
         row_gate[row] = (uint8_t)gidx;
         switch (kind) {
@@ -320,6 +346,57 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
                 for (int i = 0; i < 12; i++) prev_pos_out[i] = tmp[12 + i];
                 prev_pos_row = row;
                 pool.push_back(slot(12, row));
+                break;
+            }
+            case NLX_GATE_ARITHMETIC_EXT: {
+                const uint64_t c0 = rng.field(), c1 = rng.field();
+                C_at(n_sel, row) = c0;
+                C_at(n_sel + 1, row) = c1;
+                for (uint32_t op = 0; op < 10; op++) {
+                    const uint32_t b = 8 * op;
+                    if (!pool.empty() && (rng.next() & 1)) {  // one operand limb copied from an earlier value
+                        uint32_t src = pool[rng.below((uint32_t)pool.size())];
+                        W_at(b, row) = wires[src];
+                        dsu.unite(src, slot(b, row));
+                    }
+                    const gl::Ext m0{W_at(b, row), W_at(b + 1, row)}, m1{W_at(b + 2, row), W_at(b + 3, row)};
+                    const gl::Ext ad{W_at(b + 4, row), W_at(b + 5, row)};
+                    const gl::Ext o = gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1));
+                    W_at(b + 6, row) = o.a;
+                    W_at(b + 7, row) = o.b;
+                    if (op == 0) pool.push_back(slot(b + 6, row));
+                }
+                break;
+            }
+            case NLX_GATE_MUL_EXT: {
+                const uint64_t c0 = rng.field();
+                C_at(n_sel, row) = c0;
+                for (uint32_t op = 0; op < 13; op++) {
+                    const uint32_t b = 6 * op;
+                    const gl::Ext m0{W_at(b, row), W_at(b + 1, row)}, m1{W_at(b + 2, row), W_at(b + 3, row)};
+                    const gl::Ext o = gl::mul(gl::mul(m0, m1), c0);
+                    W_at(b + 4, row) = o.a;
+                    W_at(b + 5, row) = o.b;
+                    if (op == 0) pool.push_back(slot(b + 4, row));
+                }
+                break;
+            }
+            case NLX_GATE_REDUCING:
+            case NLX_GATE_REDUCING_EXT: {
+                const bool ext = kind == NLX_GATE_REDUCING_EXT;
+                const uint32_t nco = ext ? 32 : 43;
+                const uint32_t start_coeffs = 6, start_accs = start_coeffs + (ext ? 2 * nco : nco);
+                const gl::Ext alpha{W_at(2, row), W_at(3, row)};
+                gl::Ext acc{W_at(4, row), W_at(5, row)};
+                for (uint32_t i = 0; i < nco; i++) {
+                    gl::Ext co = ext ? gl::Ext{W_at(start_coeffs + 2 * i, row), W_at(start_coeffs + 2 * i + 1, row)}
+                                     : gl::Ext{W_at(start_coeffs + i, row), 0};
+                    acc = gl::add(gl::mul(acc, alpha), co);
+                    const uint32_t aw = (i == nco - 1) ? 0 : start_accs + 2 * i;
+                    W_at(aw, row) = acc.a;
+                    W_at(aw + 1, row) = acc.b;
+                }
+                pool.push_back(slot(0, row));
                 break;
             }
             default: break;

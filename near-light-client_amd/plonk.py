@@ -11,7 +11,8 @@ import numpy as np
 
 from ._lib import dll, ptr, NlxError
 
-GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_BASE_SUM, GATE_POSEIDON = range(6)
+(GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_BASE_SUM, GATE_POSEIDON, GATE_ARITHMETIC_EXT,
+ GATE_MUL_EXT, GATE_REDUCING, GATE_REDUCING_EXT) = range(10)
 
 
 class GateDesc(ctypes.Structure):
@@ -31,7 +32,8 @@ class CircuitDesc(ctypes.Structure):
 class SynthParams(ctypes.Structure):
     _fields_ = [("log_n", ctypes.c_uint32), ("num_public_inputs", ctypes.c_uint32),
                 ("pct_poseidon", ctypes.c_uint32), ("pct_arithmetic", ctypes.c_uint32),
-                ("pct_base_sum", ctypes.c_uint32), ("pct_constant", ctypes.c_uint32), ("seed", ctypes.c_uint64)]
+                ("pct_base_sum", ctypes.c_uint32), ("pct_constant", ctypes.c_uint32), ("seed", ctypes.c_uint64),
+                ("pct_extension", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class CircuitConfig:
@@ -63,10 +65,11 @@ class SyntheticCircuit:
     """A satisfiable nearx-shaped circuit + witness (see csrc/synth.cpp)."""
 
     def __init__(self, log_n, seed=1, num_public_inputs=4, pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5,
-                 pct_constant=5, config=None):
+                 pct_constant=5, pct_extension=0, config=None):
         self.config = config or CircuitConfig()
         self.log_n = log_n
-        sp = SynthParams(log_n, num_public_inputs, pct_poseidon, pct_arithmetic, pct_base_sum, pct_constant, seed)
+        sp = SynthParams(log_n, num_public_inputs, pct_poseidon, pct_arithmetic, pct_base_sum, pct_constant, seed,
+                         pct_extension, 0)
         ng, ns = ctypes.c_uint32(), ctypes.c_uint32()
         dll.nlx_synth_shape(ctypes.byref(sp), ctypes.byref(ng), ctypes.byref(ns))
         n = 1 << log_n

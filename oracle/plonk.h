@@ -25,7 +25,11 @@ enum {
     ORC_GATE_PUBLIC_INPUT = 2,
     ORC_GATE_ARITHMETIC = 3,   /* param0 = num_ops */
     ORC_GATE_BASE_SUM = 4,     /* param0 = base B, param1 = num_limbs */
-    ORC_GATE_POSEIDON = 5
+    ORC_GATE_POSEIDON = 5,
+    ORC_GATE_ARITHMETIC_EXT = 6, /* param0 = num_ops (10) */
+    ORC_GATE_MUL_EXT = 7,        /* param0 = num_ops (13) */
+    ORC_GATE_REDUCING = 8,       /* param0 = num_coeffs (43) */
+    ORC_GATE_REDUCING_EXT = 9    /* param0 = num_coeffs (32) */
 };
 
 typedef struct {

@@ -16,6 +16,9 @@ SHAPES = [
     (10, dict(pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)),
     (12, dict(pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)),
     (13, dict(pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)),  # two NTT passes
+    (8, dict(pct_poseidon=15, pct_arithmetic=20, pct_base_sum=5, pct_constant=5, pct_extension=30)),  # all 10 gates
+    (11, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=50)),
+    (7, dict(pct_poseidon=0, pct_arithmetic=0, pct_base_sum=0, pct_constant=5, pct_extension=60)),
 ]
 
 

@@ -14,6 +14,8 @@ from conftest import P
     (6, dict(pct_poseidon=0, pct_arithmetic=50, pct_base_sum=10, pct_constant=10)),  # one selector polynomial
     (8, dict(pct_poseidon=25, pct_arithmetic=25, pct_base_sum=5, pct_constant=5)),
     (9, dict(pct_poseidon=10, pct_arithmetic=0, pct_base_sum=0, pct_constant=5)),
+    (8, dict(pct_poseidon=15, pct_arithmetic=20, pct_base_sum=5, pct_constant=5, pct_extension=30)),  # 10 gates, 3 selectors
+    (7, dict(pct_poseidon=0, pct_arithmetic=0, pct_base_sum=0, pct_constant=5, pct_extension=60)),
 ])
 def test_prove_verify_roundtrip(nlx, orc, log_n, kw):
     syn = nlx.SyntheticCircuit(log_n, seed=log_n, **kw)
@@ -106,3 +108,23 @@ def test_fast_poseidon_tables(orc):
     f = d.orc_poseidon_fast_constants().contents
     assert f.first[0] == 0x3cc3f892184df408 and f.rc[0] == 0x74cb2e819ae421ab
     assert f.vs[0] == 0x94877900674181c3 and f.w[0] == 0x3d999c961b7c63b0 and f.init[0] == 0x80772dc2645b280b
+
+
+def test_extension_gates_constrain_their_rows(nlx, orc):
+    """each of the four extension-field gates rejects a witness broken on one of its rows"""
+    syn = nlx.SyntheticCircuit(8, seed=21, pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5,
+                               pct_extension=50)
+    assert syn.num_gates == 10 and syn.num_selectors == 3
+    kinds = [g.kind for g in syn.gates]
+    assert kinds == [0, 1, 2, 4, 9, 8, 6, 3, 7, 5]  # sorted by (degree, id) as CircuitBuilder does
+    circ = orc.Circuit.from_synthetic(syn)
+    good = circ.prove(syn.wires, syn.public_inputs)
+    assert circ.verify(good) == 1
+    for kind, out_wire in ((6, 6), (7, 4), (8, 0), (9, 1)):
+        g = syn.gates[kinds.index(kind)]
+        rows = np.nonzero(syn.constants[g.selector_index] == g.index)[0]
+        assert rows.size > 0, kind
+        w = syn.wires.copy()
+        w[out_wire, rows[0]] = (int(w[out_wire, rows[0]]) + 1) % P
+        assert circ.verify(circ.prove(w, syn.public_inputs)) < 1, kind
+    circ.close()
