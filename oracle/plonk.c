@@ -232,7 +232,7 @@ size_t orc_proof_max_bytes(const orc_circuit* c) {
     size_t per_query = 0;
     uint32_t cols[4] = {c->n_cs, d->num_wires, c->n_zs, c->n_q};
     for (int o = 0; o < 4; o++) per_query += cols[o] * 8 + 1 + 32 * (c->log_L - d->cap_height);
-    for (uint32_t r = 0; r < c->n_fri_rounds; r++) per_query += 16 * 2 * 8 * ((size_t)1 << (d->fri_arity_bits - 4)) + 1 + 32 * c->log_L;
+    for (uint32_t r = 0; r < c->n_fri_rounds; r++) per_query += ((size_t)16 << d->fri_arity_bits) + 1 + 32 * c->log_L;
     bytes += per_query * d->fri_num_queries;
     bytes += 16 * ((size_t)1 << d->degree_bits) /* final poly upper bound */ + 8 + 4 + 8 * d->num_public_inputs;
     return bytes + 64;

@@ -129,3 +129,24 @@ def test_large_proof_2p17_verifies(nlx, ctx, orc):
     assert ref.verify(proof) == 1
     ref.close()
     cd.close()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(num_challenges=1, cap_height=0, fri_num_queries=5, fri_pow_bits=4, fri_arity_bits=2, fri_final_poly_bits=2),
+    dict(cap_height=5, fri_num_queries=40, fri_pow_bits=0),
+    dict(fri_arity_bits=3, fri_final_poly_bits=3, cap_height=2, fri_num_queries=11, fri_pow_bits=8),
+])
+def test_other_configs_match_oracle(nlx, ctx, orc, cfg):
+    """the ABI is parametric in CircuitConfig / FriParams: non-default challenge counts, cap heights,
+    FRI arities, query counts and PoW bits must stay bit-exact too"""
+    config = nlx.CircuitConfig(**cfg)
+    syn = nlx.SyntheticCircuit(9, seed=77, config=config, pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5,
+                               pct_constant=5, pct_extension=10)
+    ref = orc.Circuit.from_synthetic(syn)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    want = ref.prove(syn.wires, syn.public_inputs)
+    got = cd.prove(syn.wires, syn.public_inputs)
+    assert got == want
+    assert ref.verify(got) == 1
+    cd.close()
+    ref.close()
