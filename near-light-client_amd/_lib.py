@@ -117,6 +117,13 @@ class Context:
                                "(there is no CPU fallback)" % device)
         self.handle = h
         self.device = device
+        # handles created on this context (commitments, circuits); closed before the context so that
+        # garbage-collection order at interpreter exit can never free a context under its children
+        import weakref
+        self._children = weakref.WeakSet()
+
+    def _adopt(self, child):
+        self._children.add(child)
 
     def check(self, rc):
         if rc != 0:
@@ -139,6 +146,11 @@ class Context:
 
     def close(self):
         if self.handle:
+            for child in list(self._children):
+                try:
+                    child.close()
+                except Exception:
+                    pass
             dll.nlx_ctx_destroy(self.handle)
             self.handle = None
 

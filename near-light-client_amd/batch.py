@@ -75,6 +75,7 @@ class PolynomialBatch:
         self.ctx, self.handle = ctx, handle
         self.n_cols, self.log_n, self.rate_bits, self.cap_height = n_cols, log_n, rate_bits, cap_height
         self.cap = cap
+        ctx._adopt(self)
 
     @classmethod
     def _make(cls, fn, ctx, data, rate_bits, cap_height):
@@ -133,9 +134,9 @@ class PolynomialBatch:
         return out
 
     def close(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             dll.nlx_commit_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:

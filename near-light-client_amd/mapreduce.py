@@ -72,21 +72,27 @@ def run_tree(plan, prove_fn, rank=0, world=1, dist=None, device=None):
     is "map" | "reduce" | "outer"; map jobs get no children (public_inputs=None -> the job's own).
     Returns (root_digest, stats) on every rank; stats counts the proofs this rank produced."""
     done = 0
+
+    def run_level(jobs):
+        """jobs: list of (kind, level, index, public_inputs) owned by this rank -> {index: digest}.
+        A prover may offer prove_many() to keep several independent jobs of a level in flight."""
+        if hasattr(prove_fn, "prove_many"):
+            proofs = prove_fn.prove_many(jobs)
+        else:
+            proofs = [prove_fn(*job) for job in jobs]
+        return {job[2]: proof_digest(pr) for job, pr in zip(jobs, proofs)}
+
     # ---- map level ----
-    local = {}
-    for j in range(plan.n_map):
-        if owner(j, world) == rank:
-            local[j] = proof_digest(prove_fn("map", 0, j, None))
-            done += 1
+    jobs = [("map", 0, j, None) for j in range(plan.n_map) if owner(j, world) == rank]
+    local = run_level(jobs)
+    done += len(jobs)
     digests = all_gather_digests(local, plan.n_map, rank, world, dist, device)
     # ---- reduce levels ----
     for lvl, n_jobs in enumerate(plan.levels):
-        local = {}
-        for j in range(n_jobs):
-            if owner(j, world) == rank:
-                pis = np.concatenate([digests[2 * j], digests[2 * j + 1]])
-                local[j] = proof_digest(prove_fn("reduce", lvl, j, pis))
-                done += 1
+        jobs = [("reduce", lvl, j, np.concatenate([digests[2 * j], digests[2 * j + 1]]))
+                for j in range(n_jobs) if owner(j, world) == rank]
+        local = run_level(jobs)
+        done += len(jobs)
         digests = all_gather_digests(local, n_jobs, rank, world, dist, device)
     # ---- outer proof (rank 0), digest broadcast through the same collective ----
     local = {}
@@ -100,32 +106,59 @@ def run_tree(plan, prove_fn, rank=0, world=1, dist=None, device=None):
 
 class GpuTreeProver:
     """prove_fn backed by nlx_prove: one map circuit, one reduce circuit per level, one outer circuit,
-    all resident on this rank's GPU; map witnesses differ per job (seeded), reduce / outer witnesses are
-    re-targeted to the children's digests."""
+    all resident on this rank's GPU.  `workers` independent contexts (stream + host thread each) keep
+    several jobs of a level in flight.  Witness tables live in HBM; a job only re-targets the
+    PublicInputGate row (4 words) to its public inputs - map jobs to a per-job seed, reduce / outer jobs
+    to their children's digests."""
 
-    def __init__(self, nlx, ctx, plan, map_log_n, reduce_log_n, gate_mix=None, torch=None):
-        self.nlx, self.ctx, self.plan = nlx, ctx, plan
+    def __init__(self, nlx, ctx, plan, map_log_n, reduce_log_n, gate_mix=None, torch=None, workers=1):
+        import queue
+        self.nlx, self.plan, self.torch = nlx, plan, torch
         mix = gate_mix or dict(pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)
-        self.map_syn = nlx.SyntheticCircuit(map_log_n, seed=7001, num_public_inputs=8, **mix)
-        self.map_cd = nlx.CircuitData.from_synthetic(ctx, self.map_syn)
-        self.red_syn, self.red_cd = [], []
-        for lvl in range(len(plan.levels)):
-            s = nlx.SyntheticCircuit(reduce_log_n, seed=7100 + lvl, num_public_inputs=8, **mix)
-            self.red_syn.append(s)
-            self.red_cd.append(nlx.CircuitData.from_synthetic(ctx, s))
-        self.out_syn = nlx.SyntheticCircuit(reduce_log_n, seed=7200, num_public_inputs=8, **mix)
-        self.out_cd = nlx.CircuitData.from_synthetic(ctx, self.out_syn)
+        self.workers = []
+        self.free = queue.Queue()
+        for w in range(max(1, workers)):
+            c = ctx if w == 0 else nlx.Context(ctx.device)
+            wk = {"ctx": c, "circ": {}}
+            specs = [("map", 0, map_log_n, 7001)] + [("reduce", lvl, reduce_log_n, 7100 + lvl)
+                                                     for lvl in range(len(plan.levels))] + [("outer", 0, reduce_log_n, 7200)]
+            for kind, lvl, log_n, seed in specs:
+                syn = nlx.SyntheticCircuit(log_n, seed=seed, num_public_inputs=8, **mix)
+                cd = nlx.CircuitData.from_synthetic(c, syn)
+                dev = None
+                if torch is not None:
+                    dev = torch.from_numpy(syn.wires.view(np.int64)).to(torch.device("cuda", ctx.device))
+                wk["circ"][(kind, lvl)] = (syn, cd, dev)
+            self.workers.append(wk)
+            self.free.put(wk)
+
+    def _prove(self, wk, kind, level, index, public_inputs):
+        syn, cd, dev = wk["circ"][(kind, level if kind == "reduce" else 0)]
+        if kind == "map":
+            pis = np.array([(index * 0x9E3779B97F4A7C15 + k) % P for k in range(8)], dtype=np.uint64)
+        else:
+            pis = public_inputs
+        syn.set_public_inputs(pis)
+        if dev is None:
+            return cd.prove(syn.wires, syn.public_inputs)
+        # patch the 4 words of the PublicInputGate row in the HBM-resident witness
+        dev[0:4, 0] = self.torch.from_numpy(syn.wires[0:4, 0].copy().view(np.int64)).to(dev.device)
+        self.torch.cuda.current_stream().synchronize()
+        return cd.prove(dev, syn.public_inputs)
 
     def __call__(self, kind, level, index, public_inputs):
-        if kind == "map":
-            syn, cd = self.map_syn, self.map_cd
-            pis = np.array([(index * 0x9E3779B97F4A7C15 + k) % P for k in range(8)], dtype=np.uint64)
-        elif kind == "reduce":
-            syn, cd, pis = self.red_syn[level], self.red_cd[level], public_inputs
-        else:
-            syn, cd, pis = self.out_syn, self.out_cd, public_inputs
-        syn.set_public_inputs(pis)
-        return cd.prove(syn.wires, syn.public_inputs)
+        wk = self.free.get()
+        try:
+            return self._prove(wk, kind, level, index, public_inputs)
+        finally:
+            self.free.put(wk)
+
+    def prove_many(self, jobs):
+        if len(self.workers) == 1 or len(jobs) <= 1:
+            return [self(*job) for job in jobs]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=len(self.workers)) as ex:
+            return list(ex.map(lambda job: self(*job), jobs))
 
 
 def bench_verify128(args, nlx, torch, rank, world, local, dist):
@@ -133,7 +166,7 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist):
     import time
     plan = TreePlan(32)
     ctx = nlx.Context(local)
-    prover = GpuTreeProver(nlx, ctx, plan, args.map_log_n, args.reduce_log_n, torch=torch)
+    prover = GpuTreeProver(nlx, ctx, plan, args.map_log_n, args.reduce_log_n, torch=torch, workers=args.inflight)
     device = torch.device("cuda", local)
 
     def sync():
@@ -164,6 +197,6 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist):
         "config": {"workload": "VerifyCircuit 128x4-shaped map-reduce job: 32 map proofs (2^%d rows) + 31 reduce "
                                "proofs + 1 outer proof (2^%d rows), sharded round-robin, one RCCL all-gather of "
                                "digests per level" % (args.map_log_n, args.reduce_log_n),
-                   "jobs": plan.n_jobs, "root_digest": [int(x) for x in root], "parallelism": "mapreduce x%d" % world},
+                   "jobs": plan.n_jobs, "proofs_in_flight_per_gpu": args.inflight, "root_digest": [int(x) for x in root], "parallelism": "mapreduce x%d" % world},
         "roofline": None, "cpu_baseline": None,
     }

@@ -118,6 +118,7 @@ class CircuitData:
         self.num_wires = desc.num_wires
         self.n = 1 << desc.degree_bits
         self._buf = np.zeros(dll.nlx_proof_max_bytes(h), dtype=np.uint8)
+        ctx._adopt(self)
 
     @classmethod
     def from_synthetic(cls, ctx, syn):
@@ -158,9 +159,9 @@ class CircuitData:
         return [(names[i].decode(), ms[i]) for i in range(n.value)]
 
     def close(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             dll.nlx_circuit_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:

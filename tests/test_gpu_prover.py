@@ -150,3 +150,24 @@ def test_other_configs_match_oracle(nlx, ctx, orc, cfg):
     assert ref.verify(got) == 1
     cd.close()
     ref.close()
+
+
+def test_repeated_proving_is_stable(nlx, orc):
+    """200 proofs on one context: identical bytes every time, no growth of the device allocation cache,
+    and closing the context first is safe for its children."""
+    import ctypes
+    c = nlx.Context(0)
+    syn = nlx.SyntheticCircuit(10, seed=4)
+    cd = nlx.CircuitData.from_synthetic(c, syn)
+    first = cd.prove(syn.wires, syn.public_inputs)
+    import torch
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(200):
+        assert cd.prove_into(syn.wires, syn.public_inputs.ctypes.data) == len(first)
+    assert cd.prove(syn.wires, syn.public_inputs) == first
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, "device memory grew by %d MiB over 200 proofs" % ((free0 - free1) >> 20)
+    pb = nlx.PolynomialBatch.from_values(c, np.ones((2, 16), dtype=np.uint64), 3, 2)
+    c.close()          # closes cd and pb first
+    assert cd.handle is None and pb.handle is None
+    cd.close()         # idempotent
