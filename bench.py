@@ -102,7 +102,6 @@ def cpu_baseline(nlx, log_n, gate_mix):
 
 
 def run_sync(args, nlx, torch, rank, world, local, dist):
-    import threading
     import numpy as np
     gate_mix = dict(pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)
     syn = nlx.SyntheticCircuit(args.log_n, seed=1000 + rank, **gate_mix)
@@ -121,32 +120,26 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
             cd.prove_into(wires, pis_ptr)
     for c in ctxs:
         c.kernel_timing(True)
-    lock = threading.Lock()
-    remaining = [args.steps]
-    errors = []
-
-    def worker(cd):
-        try:
-            while True:
-                with lock:
-                    if remaining[0] <= 0:
-                        return
-                    remaining[0] -= 1
-                cd.prove_into(wires, pis_ptr)
-        except Exception as e:  # surfaced after join
-            errors.append(e)
-
-    threads = [threading.Thread(target=worker, args=(cd,)) for cd in cds]
+    # the K timed steps go through ONE C-ABI call (nlx_batch_prove): the library's worker threads take
+    # jobs in order, one proof at a time per context
+    import ctypes
+    cap = nlx.lib.dll.nlx_proof_max_bytes(cds[0].handle)
+    bufs = [np.zeros(cap, dtype=np.uint8) for _ in range(args.steps)]
+    jobs = (nlx.ProveJob * args.steps)()
+    for i in range(args.steps):
+        jobs[i].wires = wires.data_ptr()
+        jobs[i].public_inputs = pis_ptr
+        jobs[i].proof_out = bufs[i].ctypes.data
+        jobs[i].proof_cap = cap
+    handles = (ctypes.c_void_p * n_workers)(*[cd.handle for cd in cds])
     barrier(dist, torch)
     t0 = time.perf_counter()
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    rc = nlx.lib.dll.nlx_batch_prove(handles, n_workers, jobs, args.steps)
     barrier(dist, torch)
     dt = time.perf_counter() - t0
-    if errors:
-        raise errors[0]
+    if rc != 0:
+        raise RuntimeError("nlx_batch_prove failed with %d" % rc)
+    assert all(jobs[i].proof_len == jobs[0].proof_len for i in range(args.steps))
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -183,6 +183,22 @@ size_t nlx_proof_max_bytes(const nlx_circuit* c);
 int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, uint8_t* proof_out,
                   size_t proof_cap, size_t* proof_len);
 
+/* a13: plonky2x LocalProver::batch_prove.  Proves n_jobs independent jobs with n_workers concurrent
+ * workers.  workers[i] are circuits built from the SAME description on DISTINCT contexts (one stream +
+ * one host thread each; contexts may be on the same GPU - overlapping one proof's latency-bound phases
+ * with another's throughput-bound kernels - or on different GPUs).  Jobs are taken in order by whichever
+ * worker is free; each job's outcome is written to its own status / proof_len.  Returns NLX_OK if every
+ * job succeeded, else the first failing job's code. */
+typedef struct {
+    const uint64_t* wires;          /* num_wires x n column-major, host or device (device of the worker that runs it) */
+    const uint64_t* public_inputs;
+    uint8_t* proof_out;             /* host buffer */
+    size_t proof_cap;
+    size_t proof_len;               /* out */
+    int32_t status;                 /* out */
+} nlx_prove_job;
+int32_t nlx_batch_prove(nlx_circuit* const* workers, uint32_t n_workers, nlx_prove_job* jobs, size_t n_jobs);
+
 /* Per-stage device time of the most recent nlx_prove on this circuit, in milliseconds
  * (HIP events on the context's stream).  names_out receives static strings. */
 #define NLX_MAX_STAGES 24

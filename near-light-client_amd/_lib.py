@@ -66,6 +66,7 @@ SIGNATURES = {
     "nlx_proof_max_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "nlx_prove": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                    ctypes.POINTER(ctypes.c_size_t)]),
+    "nlx_batch_prove": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]),
     "nlx_prove_stage_times": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p,
                                                ctypes.c_void_p]),
     "nlx_pow_grind": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,

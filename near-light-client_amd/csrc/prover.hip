@@ -10,7 +10,9 @@
 // over a few KB and runs on the host, as it does in the reference - only
 // Merkle caps (512 B), openings (~4.5 KB), the final polynomial and the query answers cross
 // PCIe.  It is not a fallback for any device stage.
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <vector>
 #include "commit.hpp"
 #include "gl.hpp"
@@ -681,6 +683,37 @@ done:
 #undef HIPCHK
 #undef CHECK_ALLOC
     return rc;
+}
+
+int32_t nlx_batch_prove(nlx_circuit* const* workers, uint32_t n_workers, nlx_prove_job* jobs, size_t n_jobs) {
+    if (!workers || n_workers == 0 || (!jobs && n_jobs)) return NLX_E_INVAL;
+    for (uint32_t w = 0; w < n_workers; w++) {
+        if (!workers[w]) return NLX_E_INVAL;
+        for (uint32_t v = 0; v < w; v++)
+            if (workers[v]->ctx == workers[w]->ctx) return workers[w]->ctx->fail(NLX_E_INVAL, "nlx_batch_prove: workers must use distinct contexts");
+    }
+    std::atomic<size_t> next{0};
+    auto run = [&](nlx_circuit* c) {
+        (void)hipSetDevice(c->ctx->device);
+        for (;;) {
+            const size_t j = next.fetch_add(1);
+            if (j >= n_jobs) return;
+            nlx_prove_job& job = jobs[j];
+            job.proof_len = 0;
+            job.status = nlx_prove(c, job.wires, job.public_inputs, job.proof_out, job.proof_cap, &job.proof_len);
+        }
+    };
+    if (n_workers == 1) {
+        run(workers[0]);
+    } else {
+        std::vector<std::thread> threads;
+        threads.reserve(n_workers);
+        for (uint32_t w = 0; w < n_workers; w++) threads.emplace_back(run, workers[w]);
+        for (auto& t : threads) t.join();
+    }
+    for (size_t j = 0; j < n_jobs; j++)
+        if (jobs[j].status != NLX_OK) return jobs[j].status;
+    return NLX_OK;
 }
 
 }  // extern "C"

@@ -170,6 +170,35 @@ class CircuitData:
             pass
 
 
+class ProveJob(ctypes.Structure):
+    _fields_ = [("wires", ctypes.c_void_p), ("public_inputs", ctypes.c_void_p), ("proof_out", ctypes.c_void_p),
+                ("proof_cap", ctypes.c_size_t), ("proof_len", ctypes.c_size_t), ("status", ctypes.c_int32)]
+
+
+def batch_prove(workers, jobs):
+    """plonky2x LocalProver::batch_prove over nlx_batch_prove.  workers: CircuitData objects of the same
+    circuit on distinct contexts; jobs: list of (wires, public_inputs).  Returns the list of proofs."""
+    n = len(jobs)
+    arr = (ProveJob * n)()
+    bufs, keep = [], []
+    cap = dll.nlx_proof_max_bytes(workers[0].handle)
+    for i, (wires, pis) in enumerate(jobs):
+        pis = np.ascontiguousarray(pis, dtype=np.uint64)
+        buf = np.zeros(cap, dtype=np.uint8)
+        keep.append(pis)
+        bufs.append(buf)
+        arr[i].wires = ptr(wires)
+        arr[i].public_inputs = ptr(pis) if pis.size else None
+        arr[i].proof_out = buf.ctypes.data
+        arr[i].proof_cap = cap
+    handles = (ctypes.c_void_p * len(workers))(*[w.handle for w in workers])
+    rc = dll.nlx_batch_prove(handles, len(workers), arr, n)
+    if rc != 0:
+        bad = next(i for i in range(n) if arr[i].status != 0)
+        raise NlxError(rc, "job %d failed" % bad)
+    return [bufs[i][:arr[i].proof_len].tobytes() for i in range(n)]
+
+
 def pow_grind(ctx, state, pos, bits):
     st = np.ascontiguousarray(state, dtype=np.uint64)
     out = ctypes.c_uint64()

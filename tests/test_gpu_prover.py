@@ -171,3 +171,27 @@ def test_repeated_proving_is_stable(nlx, orc):
     c.close()          # closes cd and pb first
     assert cd.handle is None and pb.handle is None
     cd.close()         # idempotent
+
+
+def test_batch_prove_concurrent_workers(nlx, orc):
+    """nlx_batch_prove: three contexts on one GPU, 7 jobs with different public inputs; every proof
+    equals what a single context produces and is accepted by the oracle verifier."""
+    ctxs = [nlx.Context(0) for _ in range(3)]
+    syn = nlx.SyntheticCircuit(10, seed=31, num_public_inputs=8)
+    workers = [nlx.CircuitData.from_synthetic(c, syn) for c in ctxs]
+    ref = orc.Circuit.from_synthetic(syn)
+    jobs, expect = [], []
+    for j in range(7):
+        s = nlx.SyntheticCircuit(10, seed=31, num_public_inputs=8)
+        s.set_public_inputs(np.arange(8, dtype=np.uint64) + np.uint64(100 * j))
+        jobs.append((s.wires, s.public_inputs))
+        expect.append(workers[0].prove(s.wires, s.public_inputs))
+    proofs = nlx.batch_prove(workers, jobs)
+    assert proofs == expect
+    assert all(ref.verify(p) == 1 for p in proofs)
+    assert len(set(proofs)) == 7
+    with pytest.raises(nlx.NlxError):
+        nlx.batch_prove([workers[0], workers[0]], jobs[:1])  # same context twice
+    ref.close()
+    for c in ctxs:
+        c.close()
