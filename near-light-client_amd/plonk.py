@@ -194,8 +194,9 @@ def batch_prove(workers, jobs):
     handles = (ctypes.c_void_p * len(workers))(*[w.handle for w in workers])
     rc = dll.nlx_batch_prove(handles, len(workers), arr, n)
     if rc != 0:
-        bad = next(i for i in range(n) if arr[i].status != 0)
-        raise NlxError(rc, "job %d failed" % bad)
+        bad = next((i for i in range(n) if arr[i].status != 0), None)
+        raise NlxError(rc, "nlx_batch_prove: " + ("job %d failed" % bad if bad is not None else
+                                                  dll.nlx_last_error(workers[0].ctx.handle).decode()))
     return [bufs[i][:arr[i].proof_len].tobytes() for i in range(n)]
 
 
