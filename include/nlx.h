@@ -61,6 +61,12 @@ int32_t nlx_ctx_synchronize(nlx_ctx* ctx);
 int32_t nlx_ctx_kernel_timing(nlx_ctx* ctx, int enable);
 int32_t nlx_ctx_kernel_stats(nlx_ctx* ctx, const char* name, uint64_t* calls, double* total_ms, double* alg_bytes);
 
+/* ---- a1: GoldilocksField arithmetic, element-wise (device self-test of the field core) ----
+ * a, b: n arbitrary u64 (values >= p are reduced first, except for row 4).  out: 5 x n:
+ * row 0 a*b, row 1 a+b, row 2 a-b, row 3 a^-1 (0 if a = 0), row 4 the raw multiply path applied to
+ * the UNREDUCED inputs (carry/borrow edges), all canonical. */
+int32_t nlx_field_ops(nlx_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+
 /* ---- a5: plonky2::hash::poseidon::Poseidon::poseidon ----
  * states: n x 12 u64, row-major, permuted in place. */
 int32_t nlx_poseidon_permute_batch(nlx_ctx* ctx, uint64_t* states, size_t n);

@@ -8,5 +8,5 @@ a Context raises if no gfx950 device is usable.
 """
 from . import _lib as lib  # noqa: F401  (raises loudly when the HIP extension is absent)
 from ._lib import Context, NlxError, GOLDILOCKS_P  # noqa: F401
-from .batch import PolynomialBatch, MerkleTree, poseidon_permute, hash_rows, ntt  # noqa: F401
+from .batch import PolynomialBatch, MerkleTree, poseidon_permute, hash_rows, ntt, field_ops  # noqa: F401
 from .plonk import CircuitConfig, CircuitData, SyntheticCircuit, pow_grind, batch_prove, ProveJob  # noqa: F401

@@ -39,6 +39,7 @@ SIGNATURES = {
     "nlx_ctx_kernel_timing": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int]),
     "nlx_ctx_kernel_stats": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "nlx_field_ops": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "nlx_poseidon_permute_batch": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "nlx_hash_rows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
                                        ctypes.c_void_p]),

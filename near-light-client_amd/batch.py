@@ -21,6 +21,15 @@ def poseidon_permute(ctx, states):
     return s
 
 
+def field_ops(ctx, a, b):
+    """element-wise a*b, a+b, a-b, 1/a and the raw multiply path on unreduced inputs: (5, n) uint64"""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.zeros((5, a.size), dtype=np.uint64)
+    ctx.check(dll.nlx_field_ops(ctx.handle, ptr(a), ptr(b), a.size, ptr(out)))
+    return out
+
+
 def hash_rows(ctx, rows):
     """PoseidonHash::hash_or_noop of every row of a row-major (n_rows, row_len) matrix."""
     r = np.ascontiguousarray(rows, dtype=np.uint64)

@@ -111,6 +111,22 @@ using namespace nlx;
 
 extern "C" {
 
+int32_t nlx_field_ops(nlx_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    if (!ctx) return NLX_E_INVAL;
+    if (n == 0) return NLX_OK;
+    if (!a || !b || !out) return ctx->fail(NLX_E_INVAL, "NULL buffer");
+    (void)hipSetDevice(ctx->device);
+    Staged sa(ctx, a, n * 8, true, false), sb(ctx, b, n * 8, true, false), so(ctx, out, 5 * n * 8, false, true);
+    if (sa.status) return sa.status;
+    if (sb.status) return sb.status;
+    if (so.status) return so.status;
+    launch_field_ops(ctx->stream, sa.as<uint64_t>(), sb.as<uint64_t>(), n, so.as<uint64_t>());
+    int32_t rc = so.finish();
+    if (rc) return rc;
+    NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NLX_OK;
+}
+
 int32_t nlx_poseidon_permute_batch(nlx_ctx* ctx, uint64_t* states, size_t n) {
     if (!ctx) return NLX_E_INVAL;
     if (n == 0) return NLX_OK;

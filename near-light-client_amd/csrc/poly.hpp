@@ -15,4 +15,5 @@ void launch_gather_paths(hipStream_t st, const uint64_t* d_digests, unsigned log
                          const uint64_t* d_idx, size_t k, uint64_t* d_paths_out);
 void launch_table_to_leaves(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols,
                             unsigned log_n, unsigned rate_bits, uint64_t* d_leaves);
+void launch_field_ops(hipStream_t st, const uint64_t* d_a, const uint64_t* d_b, size_t n, uint64_t* d_out);
 }  // namespace nlx

@@ -178,4 +178,25 @@ void launch_table_to_leaves(hipStream_t st, const uint64_t* d_lde, size_t col_st
                        n_cols, log_n, rate_bits, d_leaves);
 }
 
+// ---- element-wise field operations (self-test entry point nlx_field_ops) ----
+// out[0][i] = a*b, out[1][i] = a+b, out[2][i] = a-b, out[3][i] = a^-1 (0 for a = 0),
+// out[4][i] = mul_loose(a_raw, b_raw) canonicalised, where a_raw / b_raw are the inputs WITHOUT prior
+// canonicalisation (exercises the carry / borrow edges of the hand-written multiply on values >= p).
+__global__ void k_field_ops(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, size_t n,
+                            uint64_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t ar = a[i], br = b[i];
+    const uint64_t x = gl::canon(ar), y = gl::canon(br);
+    out[i] = gl::mul(x, y);
+    out[n + i] = gl::add(x, y);
+    out[2 * n + i] = gl::sub(x, y);
+    out[3 * n + i] = x ? gl::inv(x) : 0;
+    out[4 * n + i] = gl::canon(gl::mul_loose(ar, br));
+}
+void launch_field_ops(hipStream_t st, const uint64_t* d_a, const uint64_t* d_b, size_t n, uint64_t* d_out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_field_ops, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_a, d_b, n, d_out);
+}
+
 }  // namespace nlx

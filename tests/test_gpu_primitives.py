@@ -178,3 +178,29 @@ def test_ntt_2p24_three_passes(nlx, ctx):
     assert int(f[0, 1 << (log_n - 1)]) == alt
     assert np.array_equal(nlx.ntt(ctx, f, inverse=True), a)
     assert (f < np.uint64(P)).all()
+
+
+def test_field_core_edge_values(nlx, ctx):
+    """GoldilocksField core (incl. the hand-written carry-chain multiply) on every pair of edge values:
+    0, 1, 2^32 +-1, p +-1, 2^64-1, ... plus random pairs, against Python big integers."""
+    E = 0xFFFFFFFF
+    edge = [0, 1, 2, 3, E - 1, E, E + 1, E + 2, 2 * E, (1 << 33) - 1, 1 << 33, (1 << 48), (1 << 63) - 1, 1 << 63,
+            (1 << 63) + 1, P - 2, P - 1, P, P + 1, P + E - 1, (1 << 64) - E - 1, (1 << 64) - E, (1 << 64) - 2, (1 << 64) - 1,
+            0xFFFFFFFE00000001, 0xFFFFFFFF00000000, 0x00000001FFFFFFFF, 0x0000000100000000, 0xFFFFFFFEFFFFFFFF,
+            0x8000000080000000, 0x7FFFFFFF7FFFFFFF, 0xAAAAAAAA55555555]
+    rng = np.random.default_rng(3)
+    rnd = [int(x) for x in rng.integers(0, 2**63, 64, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 64, dtype=np.uint64)]
+    vals = edge + rnd
+    a = np.array([x for x in vals for _ in vals], dtype=np.uint64)
+    b = np.array([y for _ in vals for y in vals], dtype=np.uint64)
+    out = nlx.field_ops(ctx, a, b)
+    for i in range(a.size):
+        x, y = int(a[i]), int(b[i])
+        xc, yc = x % P, y % P
+        assert int(out[0, i]) == xc * yc % P, (hex(x), hex(y), "mul")
+        assert int(out[1, i]) == (xc + yc) % P, (hex(x), hex(y), "add")
+        assert int(out[2, i]) == (xc - yc) % P, (hex(x), hex(y), "sub")
+        assert int(out[4, i]) == x * y % P, (hex(x), hex(y), "mul_loose on unreduced inputs")
+        if xc:
+            assert int(out[3, i]) * xc % P == 1, (hex(x), "inv")
+    assert (out < np.uint64(P)).all()
