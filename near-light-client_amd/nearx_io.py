@@ -1,0 +1,92 @@
+"""Host-side data formats either side of the hot path: the NEAR header hash that
+SyncCircuit outputs and the EVM byte encodings of the circuits' inputs / outputs.
+
+Follows the reference directly (sources present in /root/reference):
+  * header hash: nearx/src/variables.rs:66-73 (HeaderVariable::hash) and :161-187, 278-312
+    (HeaderInnerVariable::encode_borsh / EncodeInner): sha256( sha256( sha256(inner_lite_208B) ||
+    inner_rest_hash ) || prev_block_hash ), inner_lite = height LE u64 | epoch_id | next_epoch_id |
+    prev_state_root | outcome_root | timestamp LE u64 | next_bp_hash | block_merkle_root.
+  * SyncCircuit I/O: 32-byte trusted header hash in, 32-byte new head hash out (nearx/src/sync.rs:37,43).
+  * VerifyCircuit input: 32-byte header hash + N x 97-byte ids = 1 flag byte | 32-byte hash | account id
+    right-padded with ',' to 64 bytes (nearx/src/variables.rs:686-693, crates/primitives/src/lib.rs:12-22,
+    nearx/contract/src/interfaces/INearX.sol:47-69); output N x 33 bytes (verify.rs:94-98).
+No GPU work happens here; the prover's public inputs are derived from these bytes.
+"""
+import hashlib
+import json
+
+_B58 = "123456789ABCDEFGHJKLMNPQRSTUVWXYZabcdefghijkmnopqrstuvwxyz"
+ACCOUNT_LEN = 64
+ID_LEN = 1 + 32 + ACCOUNT_LEN  # 97
+
+
+def b58decode32(s):
+    n = 0
+    for ch in s:
+        n = n * 58 + _B58.index(ch)
+    raw = n.to_bytes(32, "big") if n.bit_length() <= 256 else None
+    if raw is None:
+        raise ValueError("not a 32-byte base58 value")
+    return raw
+
+
+def inner_lite_bytes(inner):
+    ts = inner["timestamp"] if int(inner.get("timestamp", 0)) > 0 else int(inner["timestamp_nanosec"])
+    out = int(inner["height"]).to_bytes(8, "little")
+    for k in ("epoch_id", "next_epoch_id", "prev_state_root", "outcome_root"):
+        out += b58decode32(inner[k])
+    out += int(ts).to_bytes(8, "little")
+    for k in ("next_bp_hash", "block_merkle_root"):
+        out += b58decode32(inner[k])
+    assert len(out) == 208
+    return out
+
+
+def header_hash(block_view):
+    """CryptoHash of a LightClientBlockView's header."""
+    inner = hashlib.sha256(inner_lite_bytes(block_view["inner_lite"])).digest()
+    lite_rest = hashlib.sha256(inner + b58decode32(block_view["inner_rest_hash"])).digest()
+    return hashlib.sha256(lite_rest + b58decode32(block_view["prev_block_hash"])).digest()
+
+
+def load_fixture(path):
+    """LightClientFixture { last_block_hash, body } (crates/test-utils/src/lib.rs:11-15)"""
+    with open(path) as f:
+        return json.load(f)
+
+
+def sync_io(fixture):
+    """(input_bytes, output_bytes) of SyncCircuit for a fixture: trusted hash in, new head hash out."""
+    return b58decode32(fixture["last_block_hash"]), header_hash(fixture["body"])
+
+
+def encode_id(is_transaction, id_hash, account):
+    acct = account.encode()
+    if len(acct) > ACCOUNT_LEN:
+        raise ValueError("account id longer than 64 bytes")
+    return bytes([1 if is_transaction else 0]) + id_hash + acct + b"," * (ACCOUNT_LEN - len(acct))
+
+
+def decode_id(raw):
+    if len(raw) != ID_LEN:
+        raise ValueError("an id is 97 bytes")
+    return bool(raw[0]), raw[1:33], raw[33:].rstrip(b",").decode()
+
+
+def encode_verify_input(header, ids):
+    out = bytes(header)
+    for is_tx, h, acct in ids:
+        out += encode_id(is_tx, h, acct)
+    return out
+
+
+def decode_verify_input(raw):
+    if (len(raw) - 32) % ID_LEN:
+        raise ValueError("length must be 32 + 97 k")
+    return raw[:32], [decode_id(raw[32 + i * ID_LEN: 32 + (i + 1) * ID_LEN]) for i in range((len(raw) - 32) // ID_LEN)]
+
+
+def bytes_to_field_elements(raw):
+    """one field element per byte (plonky2x ByteVariable-style public I/O)"""
+    import numpy as np
+    return np.frombuffer(bytes(raw), dtype=np.uint8).astype(np.uint64)
