@@ -4,9 +4,9 @@
 // Replaces plonky2::hash::merkle_tree::MerkleTree::new (leaf hashing + fill_subtree),
 // hashing::{hash_n_to_m_no_pad, compress} — SURVEY.md §8a rows a5, a6.
 //
-// Layout: the LDE table is column-major ([col][row], row index already bit-reversed) so that a
-// wave hashing 64 consecutive rows reads 512 contiguous bytes per column; the row-major
-// "leaves" matrix of the CPU prover is never materialised.
+// Layout: the LDE table is column-major and coset-major ([col][r][k]) so that a wave
+// hashing 64 consecutive points reads 512 contiguous bytes per column; the row-major "leaves"
+// matrix of the CPU prover is never materialised - each digest is scattered to its tree position.
 #include <hip/hip_runtime.h>
 #include "poseidon.hpp"
 #include "launch.hpp"
@@ -34,41 +34,6 @@ __device__ __forceinline__ void store_digest(uint64_t* __restrict__ out, size_t 
     ulonglong2* dst = reinterpret_cast<ulonglong2*>(out + idx * 4);
     dst[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));
     dst[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
-}
-
-// Leaf digests of a column-major table: element (c, row) at cols[c * col_stride + row].
-// One lane per row; columns are absorbed eight at a time (overwrite-mode sponge, no padding).
-__global__ __launch_bounds__(256) void k_hash_leaves_colmajor(const uint64_t* __restrict__ cols, size_t col_stride,
-                                                              uint32_t n_cols, size_t n_rows,
-                                                              uint64_t* __restrict__ digests) {
-    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
-    uint64_t s[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = 0;
-    const uint64_t* p = cols + row;
-    if (n_cols <= 4) {  // hash_or_noop: copy, zero padded
-        for (uint32_t c = 0; c < n_cols; c++) {
-            uint64_t v = p[(size_t)c * col_stride];
-            if (c == 0) s[0] = v; else if (c == 1) s[1] = v; else if (c == 2) s[2] = v; else s[3] = v;
-        }
-        store_digest(digests, row, s);
-        return;
-    }
-    uint32_t c = 0;
-    for (; c + 8 <= n_cols; c += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = p[(size_t)(c + j) * col_stride];
-        poseidon::permute_loose(s);
-    }
-    if (c < n_cols) {
-        uint32_t rem = n_cols - c;
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if ((uint32_t)j < rem) s[j] = p[(size_t)(c + j) * col_stride];
-        poseidon::permute_loose(s);
-    }
-    store_digest(digests, row, s);
 }
 
 // Leaf digests of row-major leaves (the MerkleTree::new(leaves, cap_height) calling convention).
@@ -129,13 +94,6 @@ void launch_merkle_level_wide(hipStream_t st, const uint64_t* children, uint64_t
 void launch_permute_batch(hipStream_t st, uint64_t* d_states, size_t n) {
     if (!n) return;
     hipLaunchKernelGGL(k_permute_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_states, n);
-}
-
-void launch_hash_leaves_colmajor(hipStream_t st, const uint64_t* d_cols, size_t col_stride, uint32_t n_cols,
-                                 size_t n_rows, uint64_t* d_digests) {
-    if (!n_rows) return;
-    hipLaunchKernelGGL(k_hash_leaves_colmajor, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, d_cols,
-                       col_stride, n_cols, n_rows, d_digests);
 }
 
 void launch_hash_leaves_rowmajor(hipStream_t st, const uint64_t* d_rows, uint32_t row_len, size_t n_rows,

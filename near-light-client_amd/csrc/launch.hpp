@@ -8,8 +8,6 @@ namespace nlx {
 
 // ---- hash_kernels.hip ----
 void launch_permute_batch(hipStream_t st, uint64_t* d_states, size_t n);
-void launch_hash_leaves_colmajor(hipStream_t st, const uint64_t* d_cols, size_t col_stride, uint32_t n_cols,
-                                 size_t n_rows, uint64_t* d_digests);
 void launch_hash_leaves_rowmajor(hipStream_t st, const uint64_t* d_rows, uint32_t row_len, size_t n_rows,
                                  uint64_t* d_digests);
 const uint64_t* launch_merkle_levels(hipStream_t st, uint64_t* d_digests, size_t n_leaves, unsigned cap_height);
@@ -38,7 +36,6 @@ void launch_ntt_dif_fwd(hipStream_t st, const NttTables& tb, uint64_t* data, siz
                         unsigned log_n, bool inverse, const uint64_t* prescale_nat);
 void launch_bitrev_permute(hipStream_t st, const uint64_t* src, uint64_t* dst, size_t stride, uint32_t n_cols,
                            unsigned log_n, const uint64_t* postscale_nat);
-void launch_fill_root_table(hipStream_t st, uint64_t* d_table, unsigned log_size, uint64_t root);
 void launch_fill_coset_scale_br(hipStream_t st, uint64_t* d_table, unsigned log_n, unsigned rate_bits,
                                 uint64_t shift, bool inverse);
 void launch_intt_dif_cosets(hipStream_t st, const NttTables& tb, uint64_t* data, uint32_t n_y, unsigned log_n,

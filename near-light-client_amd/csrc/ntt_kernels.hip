@@ -260,9 +260,6 @@ static void run_passes(hipStream_t st, const NttTables& tb, bool inverse_roots, 
                        size_t dst_z_stride, uint32_t n_cols, uint32_t n_z, unsigned log_n, const uint64_t* scale,
                        size_t scale_z_stride, uint64_t final_scale, const uint64_t* post_scale = nullptr,
                        size_t post_scale_z_stride = 0) {
-    if (log_n == 0) {  // length-1 transform: copy with scaling
-        // handled by a 1-element "contiguous" pass with log_A = 0
-    }
     Plan pl = make_plan(log_n);
     const uint64_t* const* roots = inverse_roots ? tb.inv : tb.fwd;
     // DIF order: strided passes from the largest sub-problem down, contiguous pass last.
@@ -303,7 +300,6 @@ static void run_passes(hipStream_t st, const NttTables& tb, bool inverse_roots, 
         unsigned tiles;
         if (i == 0) {  // contiguous
             p.log_T = 0;
-            p.log_Q = (log_n >= TILE_LOG) ? 0 : 0;
             // pack several sub-problems into a tile when the transform is shorter than the tile
             unsigned log_subs = log_n - p.log_A;  // sub-problems per column
             unsigned q = TILE_LOG - p.log_A;
@@ -383,10 +379,6 @@ void launch_fill_powers(hipStream_t st, uint64_t* d_table, size_t count, uint64_
     hipLaunchKernelGGL(k_fill_powers, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, d_table, count, base,
                        first);
 }
-void launch_fill_root_table(hipStream_t st, uint64_t* d_table, unsigned log_size, uint64_t root) {
-    launch_fill_powers(st, d_table, (size_t)1 << log_size, root, 1);
-}
-
 // scale_br[r][j] = (shift * w_L^r)^bitrev_n(j), L = n << rate_bits
 __global__ void k_fill_coset_scale_br(uint64_t* __restrict__ table, unsigned log_n, unsigned rate_bits,
                                       uint64_t shift, uint64_t w_L) {
