@@ -90,3 +90,71 @@ def bytes_to_field_elements(raw):
     """one field element per byte (plonky2x ByteVariable-style public I/O)"""
     import numpy as np
     return np.frombuffer(bytes(raw), dtype=np.uint8).astype(np.uint64)
+
+
+# ---- VerifyCircuit semantics: NEAR transaction / receipt inclusion proof -------------------------
+# Follows crates/protocol/src/lib.rs:118-151 (Protocol::inclusion_proof_verify, Proof::Basic) and
+# crates/protocol/src/merkle_util.rs:7-30; the circuit restates the same checks in
+# nearx/src/builder.rs:344-363 (Verify::verify) with nearx/src/merkle.rs:17-51.
+import base64
+
+
+def _sha(b):
+    return hashlib.sha256(b).digest()
+
+
+def combine_hash(a, b):
+    return _sha(a + b)
+
+
+def compute_root_from_path(path, item_hash):
+    h = item_hash
+    for uncle in path:
+        u = b58decode32(uncle["hash"])
+        h = combine_hash(u, h) if uncle["direction"] == "Left" else combine_hash(h, u)
+    return h
+
+
+def _borsh_partial_outcome(outcome):
+    """borsh(PartialExecutionOutcome { receipt_ids, gas_burnt, tokens_burnt, executor_id, status })"""
+    out = len(outcome["receipt_ids"]).to_bytes(4, "little")
+    for r in outcome["receipt_ids"]:
+        out += b58decode32(r)
+    out += int(outcome["gas_burnt"]).to_bytes(8, "little")
+    out += int(outcome["tokens_burnt"]).to_bytes(16, "little")
+    ex = outcome["executor_id"].encode()
+    out += len(ex).to_bytes(4, "little") + ex
+    st = outcome["status"]
+    if st == "Unknown" or (isinstance(st, dict) and "Unknown" in st):
+        out += b"\x00"
+    elif isinstance(st, dict) and "Failure" in st:
+        out += b"\x01"
+    elif isinstance(st, dict) and "SuccessValue" in st:
+        v = base64.b64decode(st["SuccessValue"])
+        out += b"\x02" + len(v).to_bytes(4, "little") + v
+    elif isinstance(st, dict) and "SuccessReceiptId" in st:
+        out += b"\x03" + b58decode32(st["SuccessReceiptId"])
+    else:
+        raise ValueError("unknown execution status %r" % (st,))
+    return out
+
+
+def outcome_hashes(outcome_proof):
+    """ExecutionOutcomeWithIdView::to_hashes: [id, hash(partial outcome), hash(log)...]"""
+    hs = [b58decode32(outcome_proof["id"]), _sha(_borsh_partial_outcome(outcome_proof["outcome"]))]
+    hs += [_sha(log.encode()) for log in outcome_proof["outcome"]["logs"]]
+    return hs
+
+
+def inclusion_proof_verify(head_block_root, proof):
+    """Proof::Basic: True iff the header hashes to the outcome's block, the outcome is under the header's
+    outcome_root and the block is under head_block_root."""
+    block_hash = header_hash(proof["block_header_lite"])
+    block_hash_matches = block_hash == b58decode32(proof["outcome_proof"]["block_hash"])
+    hs = outcome_hashes(proof["outcome_proof"])
+    outcome_hash = _sha(len(hs).to_bytes(4, "little") + b"".join(hs))
+    shard_root = compute_root_from_path(proof["outcome_proof"]["proof"], outcome_hash)
+    outcome_root = compute_root_from_path(proof["outcome_root_proof"], _sha(shard_root))
+    outcome_verified = outcome_root == b58decode32(proof["block_header_lite"]["inner_lite"]["outcome_root"])
+    block_verified = compute_root_from_path(proof["block_proof"], block_hash) == head_block_root
+    return block_hash_matches and outcome_verified and block_verified

@@ -62,3 +62,31 @@ def test_public_inputs_from_real_sync_io(nlx):
     syn = nlx.SyntheticCircuit(6, seed=1, num_public_inputs=64)
     syn.set_public_inputs(pis)
     assert np.array_equal(syn.public_inputs, pis)
+
+# nearx/src/builder.rs:642, nearx/src/merkle.rs:95, crates/protocol/src/experimental.rs:337
+BLOCK_MERKLE_ROOT = "WWrLWbWHwSmjtTn5oBZPYgRCuCYn6fkYVa4yhPWNK4L"
+
+
+def _b58_any(io, s):
+    n = 0
+    for ch in s:
+        n = n * 58 + io._B58.index(ch)
+    return n.to_bytes(32, "big")
+
+
+def test_inclusion_proof_blackbox_fixture(nlx):
+    """beefy_builder_test_proof_blackbox (nearx/src/builder.rs:637-662): fixtures/old.json verifies
+    under the block root literal; any broken link is rejected."""
+    io = _io(nlx)
+    root = _b58_any(io, BLOCK_MERKLE_ROOT)
+    proof = json.load(open(os.path.join(NEAR, "old.json")))
+    assert io.inclusion_proof_verify(root, proof) is True
+    bad = json.loads(json.dumps(proof))
+    bad["block_proof"][3]["direction"] = "Left" if bad["block_proof"][3]["direction"] == "Right" else "Right"
+    assert io.inclusion_proof_verify(root, bad) is False
+    bad = json.loads(json.dumps(proof))
+    bad["outcome_proof"]["outcome"]["gas_burnt"] += 1
+    assert io.inclusion_proof_verify(root, bad) is False
+    assert io.inclusion_proof_verify(b"\x00" * 32, proof) is False
+    # the header of the proven block hashes to the block hash the outcome proof names
+    assert io.header_hash(proof["block_header_lite"]) == io.b58decode32(proof["outcome_proof"]["block_hash"])
