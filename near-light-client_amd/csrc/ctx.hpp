@@ -62,6 +62,7 @@ struct nlx_ctx {
     int32_t ensure_tables(unsigned log_n);
     int32_t get_coset_scale(unsigned log_n, unsigned rate_bits, const uint64_t** out, bool inverse = false);
     int32_t get_nat_scale(unsigned log_n, uint64_t shift, const uint64_t** out);
+
 };
 
 #define NLX_HIP(ctx, call)                                   \

@@ -16,6 +16,7 @@
 //  * Each pass stages a tile of 4096 field elements (32 KiB) in LDS, runs up to 12 radix-2
 //    levels there, and touches HBM once per pass with >=128-byte contiguous segments.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "gl.hpp"
 #include "launch.hpp"
 
@@ -36,6 +37,7 @@ struct PassParams {
     const uint64_t* tw;    // w_N^e, e in [0, N/2), N = 2^log_N = sub-problem size of this pass
     const uint64_t* scale; // optional per-element factor applied on load (indexed like src within a z slice)
     size_t scale_z_stride;
+    uint32_t debug_flags;  // measurement only (env NLX_NTT_DEBUG): 1 = skip butterfly groups, 2 = skip multiplies
     uint64_t r16[8];       // w_16^e (forward or inverse), constant twiddles of the register sub-transforms
     uint64_t final_scale;  // multiplied into every output (1 = none)
     const uint64_t* post_scale;  // optional per-element factor applied on store (indexed like dst within a z slice)
@@ -52,6 +54,9 @@ __device__ __forceinline__ uint64_t tw_full(const uint64_t* __restrict__ tw, uin
     return e < half_N ? tw[e] : gl::P - tw[e - half_N];
 }
 
+#ifndef NTT_SKIP_MUL
+#define NTT_SKIP_MUL 0
+#endif
 // ---- in-register radix-2^g sub-transforms with constant twiddles (w_16 powers) ----
 // DIF: natural in, bit-reversed out.  DIT: bit-reversed in, natural out.  r16[e] = w_16^e (e < 8).
 template <int g>
@@ -68,7 +73,7 @@ __device__ __forceinline__ void dft_dif(uint64_t (&x)[1 << g], const uint64_t (&
                 x[b + u] = gl::add(a, c);
                 uint64_t d = gl::sub(a, c);
                 const int e = (u << t) * (16 / G);  // w_{2 half}^u = w_G^(u << t) = w_16^(...)
-                if (e != 0) d = gl::mul(d, r16[e]);
+                if (e != 0 && !NTT_SKIP_MUL) d = gl::mul(d, r16[e]);
                 x[b + u + half] = d;
             }
         }
@@ -87,7 +92,7 @@ __device__ __forceinline__ void dft_dit(uint64_t (&x)[1 << g], const uint64_t (&
                 const uint64_t a = x[b + u];
                 uint64_t c = x[b + u + half];
                 const int e = (u << (g - 1 - t)) * (16 / G);
-                if (e != 0) c = gl::mul(c, r16[e]);
+                if (e != 0 && !NTT_SKIP_MUL) c = gl::mul(c, r16[e]);
                 x[b + u] = gl::add(a, c);
                 x[b + u + half] = gl::sub(a, c);
             }
@@ -185,23 +190,41 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
     if (log_A >= 1)
         for (uint32_t e = tid; e < (A >> 1); e += NTT_THREADS) twl[e] = tw[(size_t)e << log_M];
     // ---- load (optional pre-scale; DIT strided passes apply the inter-pass twiddle here) ----
-    for (uint32_t idx = tid; idx < tile_elems; idx += NTT_THREADS) {
-        const uint32_t jt = idx & (T - 1);
-        const uint32_t j1 = (idx >> log_T) & (A - 1);
-        const size_t g = strided ? base + ((size_t)j1 << log_M) + jt : base + idx;
-        uint64_t v = src[g];
-        if (scale) v = gl::mul(v, scale[g]);
-        if (DIT && strided) {
-            const uint32_t i1 = gl::bitrev32(j1, log_A);
-            const uint32_t e = i1 * (j0_base + jt);
-            if (e) v = gl::mul(v, tw_full(tw, e, half_N));
+    if (!strided && tile_elems >= 2 * NTT_THREADS) {
+        // contiguous tile: 16-byte accesses (two consecutive elements per lane); 8-byte accesses reach
+        // only 0.5-0.7x of the 16-byte streaming rate on this part
+        const ulonglong2* __restrict__ src2 = reinterpret_cast<const ulonglong2*>(src + base);
+        const ulonglong2* __restrict__ sc2 = scale ? reinterpret_cast<const ulonglong2*>(scale + base) : nullptr;
+        for (uint32_t i2 = tid; i2 < (tile_elems >> 1); i2 += NTT_THREADS) {
+            ulonglong2 v = src2[i2];
+            if (sc2) {
+                const ulonglong2 sc = sc2[i2];
+                v.x = gl::mul(v.x, sc.x);
+                v.y = gl::mul(v.y, sc.y);
+            }
+            const uint32_t li = lds_pad(2 * i2);  // 2*i2 is even: its neighbour shares the 16-element pad group
+            lds[li] = v.x;
+            lds[li + 1] = v.y;
         }
-        lds[lds_pad(idx)] = v;
+    } else {
+        for (uint32_t idx = tid; idx < tile_elems; idx += NTT_THREADS) {
+            const uint32_t jt = idx & (T - 1);
+            const uint32_t j1 = (idx >> log_T) & (A - 1);
+            const size_t g = strided ? base + ((size_t)j1 << log_M) + jt : base + idx;
+            uint64_t v = src[g];
+            if (scale) v = gl::mul(v, scale[g]);
+            if (DIT && strided) {
+                const uint32_t i1 = gl::bitrev32(j1, log_A);
+                const uint32_t e = i1 * (j0_base + jt);
+                if (e) v = gl::mul(v, tw_full(tw, e, half_N));
+            }
+            lds[lds_pad(idx)] = v;
+        }
     }
     __syncthreads();
 
     // ---- butterfly levels along j1, four at a time ----
-    unsigned done = 0;
+    unsigned done = (p.debug_flags & 1) ? log_A : 0;
     while (done < log_A) {
         const unsigned rem = log_A - done;
         const unsigned g = rem >= 4 ? 4 : rem;
@@ -218,6 +241,26 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
     }
 
     // ---- store (DIF strided passes apply the inter-pass twiddle; optional scales) ----
+    if (!strided && tile_elems >= 2 * NTT_THREADS) {
+        ulonglong2* __restrict__ dst2 = reinterpret_cast<ulonglong2*>(dst + base);
+        const ulonglong2* __restrict__ ps2 =
+            p.post_scale ? reinterpret_cast<const ulonglong2*>(p.post_scale + (size_t)blockIdx.z * p.post_scale_z_stride + base) : nullptr;
+        for (uint32_t i2 = tid; i2 < (tile_elems >> 1); i2 += NTT_THREADS) {
+            const uint32_t li = lds_pad(2 * i2);
+            ulonglong2 v = make_ulonglong2(lds[li], lds[li + 1]);
+            if (p.final_scale != 1) {
+                v.x = gl::mul(v.x, p.final_scale);
+                v.y = gl::mul(v.y, p.final_scale);
+            }
+            if (ps2) {
+                const ulonglong2 sc = ps2[i2];
+                v.x = gl::mul(v.x, sc.x);
+                v.y = gl::mul(v.y, sc.y);
+            }
+            dst2[i2] = v;
+        }
+        return;
+    }
     for (uint32_t idx = tid; idx < tile_elems; idx += NTT_THREADS) {
         const uint32_t jt = idx & (T - 1);
         const uint32_t j1 = (idx >> log_T) & (A - 1);
@@ -231,6 +274,56 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
         if (p.final_scale != 1) v = gl::mul(v, p.final_scale);
         if (p.post_scale) v = gl::mul(v, p.post_scale[(size_t)blockIdx.z * p.post_scale_z_stride + g]);
         dst[g] = v;
+    }
+}
+
+// Strided pass with a transform length of at most 16 (log_A <= 4): no LDS at all.  One lane owns one
+// column j0 of one sub-problem, loads its A elements with A wave-coalesced loads (lanes = consecutive
+// j0), forms the inter-pass twiddles w_N^(j0 * i) by repeated multiplication from ONE coalesced table
+// read (instead of A gathered reads), transforms in registers and stores back in place.
+template <bool DIT, int g>
+__global__ __launch_bounds__(256) void k_ntt_strided_reg(PassParams p) {
+    constexpr int G = 1 << g;
+    const unsigned log_M = p.log_N - g;
+    const size_t col_elems = (size_t)1 << p.log_n;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // index over (q, j0)
+    if (t >= (col_elems >> g)) return;
+    const uint32_t j0 = (uint32_t)(t & (((size_t)1 << log_M) - 1));
+    const size_t q = t >> log_M;
+    const size_t base = (q << p.log_N) + j0;
+    const uint64_t* __restrict__ src = p.src + (size_t)blockIdx.y * p.src_stride + (size_t)blockIdx.z * p.src_z_stride;
+    uint64_t* __restrict__ dst = p.dst + (size_t)blockIdx.y * p.dst_stride + (size_t)blockIdx.z * p.dst_z_stride;
+    uint64_t x[G];
+#pragma unroll
+    for (int m = 0; m < G; m++) x[m] = src[base + ((size_t)m << log_M)];
+    if (p.scale) {
+        const uint64_t* __restrict__ sc = p.scale + (size_t)blockIdx.z * p.scale_z_stride;
+#pragma unroll
+        for (int m = 0; m < G; m++) x[m] = gl::mul(x[m], sc[base + ((size_t)m << log_M)]);
+    }
+    // pw[i] = w_N^(j0 * i), i < G  (j0 < M <= N/2: direct table entry)
+    uint64_t pw[G];
+    pw[0] = 1;
+    pw[1] = p.tw[j0];
+#pragma unroll
+    for (int i = 2; i < G; i++) pw[i] = (i & 1) ? gl::mul(pw[i - 1], pw[1]) : gl::mul(pw[i / 2], pw[i / 2]);
+    if (DIT) {
+#pragma unroll
+        for (int m = 1; m < G; m++) x[m] = gl::mul(x[m], pw[__brev((unsigned)m) >> (32 - g)]);
+        dft_dit<g>(x, p.r16);
+    } else {
+        dft_dif<g>(x, p.r16);
+#pragma unroll
+        for (int m = 1; m < G; m++) x[m] = gl::mul(x[m], pw[__brev((unsigned)m) >> (32 - g)]);
+    }
+    const uint64_t* __restrict__ ps = p.post_scale ? p.post_scale + (size_t)blockIdx.z * p.post_scale_z_stride : nullptr;
+#pragma unroll
+    for (int m = 0; m < G; m++) {
+        const size_t gi = base + ((size_t)m << log_M);
+        uint64_t v = x[m];
+        if (p.final_scale != 1) v = gl::mul(v, p.final_scale);
+        if (ps) v = gl::mul(v, ps[gi]);
+        dst[gi] = v;
     }
 }
 
@@ -285,6 +378,10 @@ static void run_passes(hipStream_t st, const NttTables& tb, bool inverse_roots, 
         p.log_n = log_n;
         p.log_N = logN_of[i];
         p.log_A = pl.log_A[i];
+        {
+            static const int dbg = getenv("NLX_NTT_DEBUG") ? atoi(getenv("NLX_NTT_DEBUG")) : 0;
+            p.debug_flags = (uint32_t)dbg;
+        }
         p.tw = p.log_N >= 1 ? roots[p.log_N] : nullptr;
         {
             uint64_t w16 = gl::root_of_unity(4);
@@ -311,6 +408,18 @@ static void run_passes(hipStream_t st, const NttTables& tb, bool inverse_roots, 
             unsigned t = TILE_LOG - p.log_A;
             p.log_T = t < log_M ? t : log_M;
             tiles = 1u << (log_n - p.log_A - p.log_T);
+        }
+        if (i != 0 && p.log_A >= 1 && p.log_A <= 4) {
+            // short strided transform: register-only kernel, one lane per (sub-problem, column)
+            const size_t threads = ((size_t)1 << log_n) >> p.log_A;
+            const dim3 grid((unsigned)((threads + 255) / 256), n_cols, n_z);
+            switch (p.log_A) {
+                case 4: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, 4>), grid, dim3(256), 0, st, p); break;
+                case 3: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, 3>), grid, dim3(256), 0, st, p); break;
+                case 2: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, 2>), grid, dim3(256), 0, st, p); break;
+                default: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, 1>), grid, dim3(256), 0, st, p); break;
+            }
+            continue;
         }
         hipLaunchKernelGGL(k_ntt_pass<DIT>, dim3(tiles, n_cols, n_z), dim3(NTT_THREADS), 0, st, p);
     }
