@@ -21,55 +21,91 @@ namespace nlx {
 constexpr unsigned EVAL_CHUNK_LOG = 11;
 constexpr unsigned EVAL_CHUNK = 1u << EVAL_CHUNK_LOG;
 
+__device__ __forceinline__ gl::Ext shfl_down_ext(gl::Ext v, int d) {
+    gl::Ext r;
+    r.a = ((uint64_t)__shfl_down((uint32_t)(v.a >> 32), d, 64) << 32) | __shfl_down((uint32_t)v.a, d, 64);
+    r.b = ((uint64_t)__shfl_down((uint32_t)(v.b >> 32), d, 64) << 32) | __shfl_down((uint32_t)v.b, d, 64);
+    return r;
+}
+
+// One workgroup folds a chunk of up to 2^11 elements: 8 consecutive elements per lane are folded in
+// registers (3 levels), 64 lanes by wave shuffles (6 levels, no barrier), the 4 waves through LDS
+// (2 levels, one barrier).
 template <bool EXT_IN>
 __global__ __launch_bounds__(256) void k_eval_fold(const uint64_t* __restrict__ in, size_t in_stride,
                                                    unsigned log_count,  // elements per column = 2^log_count
                                                    unsigned level0,     // tree level of the first fold
                                                    unsigned log_n, const uint64_t* __restrict__ zpow,
                                                    uint64_t* __restrict__ out, size_t out_stride) {
-    __shared__ uint64_t sa[EVAL_CHUNK], sb[EVAL_CHUNK];
+    __shared__ uint64_t wave_part[8];
     const unsigned tid = threadIdx.x;
     const unsigned log_chunk = log_count < EVAL_CHUNK_LOG ? log_count : EVAL_CHUNK_LOG;
     const uint32_t chunk = 1u << log_chunk;
     const size_t elem0 = (size_t)blockIdx.x << log_chunk;
     const uint64_t* col = in + (size_t)blockIdx.y * in_stride;
-    for (uint32_t i = tid; i < chunk; i += 256) {
-        if (EXT_IN) {
-            sa[i] = col[2 * (elem0 + i)];
-            sb[i] = col[2 * (elem0 + i) + 1];
-        } else {
-            sa[i] = col[elem0 + i];
-            sb[i] = 0;
+    auto Y = [&](unsigned l) {  // multiplier of tree level level0 + l
+        const unsigned k = log_n - 1 - (level0 + l);
+        return gl::Ext{zpow[2 * k], zpow[2 * k + 1]};
+    };
+    // ---- registers: up to 8 consecutive elements per lane ----
+    const unsigned log_per = log_chunk >= 3 ? 3 : log_chunk;
+    const uint32_t per = 1u << log_per;
+    const uint32_t active = chunk >> log_per;  // lanes holding data (<= 256)
+    gl::Ext v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = gl::Ext{0, 0};
+    if (tid < active) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if ((uint32_t)i < per) {
+                const size_t e = elem0 + (size_t)tid * per + i;
+                v[i] = EXT_IN ? gl::Ext{col[2 * e], col[2 * e + 1]} : gl::Ext{col[e], 0};
+            }
         }
     }
-    __syncthreads();
-    uint32_t cur = chunk;
-    for (unsigned l = 0; l < log_chunk; l++) {
-        const unsigned level = level0 + l;
-        const gl::Ext y = gl::Ext{zpow[2 * (log_n - 1 - level)], zpow[2 * (log_n - 1 - level) + 1]};
-        const uint32_t half = cur >> 1;
-        // pairs are adjacent (2i, 2i+1); results are compacted to position i.  Two-phase
-        // (read, barrier, write) keeps the in-place compaction race-free.
-        gl::Ext res[EVAL_CHUNK / 2 / 256 > 0 ? EVAL_CHUNK / 2 / 256 : 1];
-        int cnt = 0;
-        for (uint32_t i = tid; i < half; i += 256) {
-            gl::Ext a{sa[2 * i], sb[2 * i]}, b{sa[2 * i + 1], sb[2 * i + 1]};
-            res[cnt++] = gl::add(a, gl::mul(b, y));
+    unsigned l = 0;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        if ((unsigned)s < log_per) {
+            const gl::Ext y = Y(l);
+#pragma unroll
+            for (int i = 0; i < (4 >> s); i++) v[i] = gl::add(v[2 * i], gl::mul(v[2 * i + 1], y));
+            l++;
+        }
+    }
+    gl::Ext acc = v[0];
+    // ---- wave: pairwise folds at distance 1, 2, 4, ... (lanes that are not a multiple of 2d carry garbage) ----
+    unsigned lanes = active < 64 ? active : 64;
+    for (int d = 1; (unsigned)d < lanes; d <<= 1) {
+        const gl::Ext other = shfl_down_ext(acc, d);
+        acc = gl::add(acc, gl::mul(other, Y(l)));
+        l++;
+    }
+    // ---- workgroup: 4 waves ----
+    const uint32_t n_waves = (active + 63) / 64;
+    if (n_waves > 1) {
+        if ((tid & 63) == 0) {
+            wave_part[2 * (tid >> 6)] = acc.a;
+            wave_part[2 * (tid >> 6) + 1] = acc.b;
         }
         __syncthreads();
-        cnt = 0;
-        for (uint32_t i = tid; i < half; i += 256) {
-            sa[i] = res[cnt].a;
-            sb[i] = res[cnt].b;
-            cnt++;
+        if (tid == 0) {
+            gl::Ext w[4];
+            for (uint32_t i = 0; i < 4; i++) w[i] = i < n_waves ? gl::Ext{wave_part[2 * i], wave_part[2 * i + 1]} : gl::Ext{0, 0};
+            uint32_t cnt = n_waves;
+            while (cnt > 1) {
+                const gl::Ext y = Y(l);
+                for (uint32_t i = 0; i < cnt / 2; i++) w[i] = gl::add(w[2 * i], gl::mul(w[2 * i + 1], y));
+                cnt >>= 1;
+                l++;
+            }
+            acc = w[0];
         }
-        __syncthreads();
-        cur = half;
     }
     if (tid == 0) {
         uint64_t* o = out + (size_t)blockIdx.y * out_stride + 2 * (size_t)blockIdx.x;
-        o[0] = sa[0];
-        o[1] = sb[0];
+        o[0] = acc.a;
+        o[1] = acc.b;
     }
 }
 
@@ -91,13 +127,16 @@ size_t eval_scratch_words(uint32_t n_cols, unsigned log_n) {
 }
 
 void launch_eval_br(hipStream_t st, const uint64_t* d_coeffs_br, size_t stride, uint32_t n_cols, unsigned log_n,
-                    const uint64_t* d_z, uint64_t* d_out_ext, uint64_t* d_scratch) {
+                    const uint64_t* d_z, uint64_t* d_out_ext, uint64_t* d_scratch, const uint64_t* d_zpow) {
     if (!n_cols) return;
-    uint64_t* zpow = d_scratch;
+    const uint64_t* zpow = d_zpow;
     size_t partial = log_n > EVAL_CHUNK_LOG ? ((size_t)1 << (log_n - EVAL_CHUNK_LOG)) : 1;
     uint64_t* bufA = d_scratch + 128;
     uint64_t* bufB = bufA + (size_t)n_cols * 2 * partial;
-    hipLaunchKernelGGL(k_zpow, dim3(1), dim3(1), 0, st, d_z, log_n ? log_n : 1, zpow);
+    if (!zpow) {  // powers z^(2^k) not supplied by the host: one-lane kernel
+        hipLaunchKernelGGL(k_zpow, dim3(1), dim3(1), 0, st, d_z, log_n ? log_n : 1, d_scratch);
+        zpow = d_scratch;
+    }
     if (log_n <= EVAL_CHUNK_LOG) {
         hipLaunchKernelGGL(k_eval_fold<false>, dim3(1, n_cols), dim3(256), 0, st, d_coeffs_br, stride, log_n, 0u, log_n,
                            zpow, d_out_ext, (size_t)2);

@@ -474,20 +474,29 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
         }
         const nlx_commit* oracles[4] = {c->cs, cw, cz, cq};
         const uint32_t n_open = c->n_cs + d.num_wires + c->n_zs + c->n_q;
-        uint64_t* d_points = dalloc(64);
+        uint64_t* d_points = dalloc(2048);
         uint64_t* d_open = dalloc((size_t)(n_open + nc) * 16);
         uint64_t* d_eval_scratch = dalloc(eval_scratch_words(d.num_wires > c->n_cs ? d.num_wires : c->n_cs, log_n) * 8);
         CHECK_ALLOC(d_points && d_open && d_eval_scratch);
         {
-            uint64_t pts[4] = {zeta[0], zeta[1], gzeta[0], gzeta[1]};
-            HIPCHK(hipMemcpyAsync(d_points, pts, 32, hipMemcpyHostToDevice, st));
-            // pts lives on this stack frame until the synchronising fetch below
+            // zeta^(2^k) and (g zeta)^(2^k), k < log_n, computed on the host (zeta is known here) so the
+            // evaluation kernels start immediately
+            uint64_t pts[4 + 2 * 2 * 32] = {zeta[0], zeta[1], gzeta[0], gzeta[1]};
+            gl::Ext za{zeta[0], zeta[1]}, zb{gzeta[0], gzeta[1]};
+            for (unsigned k = 0; k < 32; k++) {
+                pts[4 + 2 * k] = za.a; pts[4 + 2 * k + 1] = za.b;
+                pts[4 + 64 + 2 * k] = zb.a; pts[4 + 64 + 2 * k + 1] = zb.b;
+                if (k + 1 < log_n) { za = gl::mul(za, za); zb = gl::mul(zb, zb); }
+            }
+            HIPCHK(hipMemcpyAsync(d_points, pts, sizeof pts, hipMemcpyHostToDevice, st));
             uint32_t off = 0;
             for (int o = 0; o < 4; o++) {
-                launch_eval_br(st, oracles[o]->coeffs_br, n, oracles[o]->n_cols, log_n, d_points, d_open + 2 * (size_t)off, d_eval_scratch);
+                launch_eval_br(st, oracles[o]->coeffs_br, n, oracles[o]->n_cols, log_n, d_points, d_open + 2 * (size_t)off,
+                               d_eval_scratch, d_points + 4);
                 off += oracles[o]->n_cols;
             }
-            launch_eval_br(st, cz->coeffs_br, n, nc, log_n, d_points + 2, d_open + 2 * (size_t)n_open, d_eval_scratch);
+            launch_eval_br(st, cz->coeffs_br, n, nc, log_n, d_points + 2, d_open + 2 * (size_t)n_open, d_eval_scratch,
+                           d_points + 4 + 64);
             HIPCHK(hipStreamSynchronize(st));
         }
         std::vector<uint64_t> open((size_t)(n_open + nc) * 2);

@@ -657,7 +657,9 @@ void launch_fri_final_coeffs(hipStream_t st, const uint64_t* d_values, unsigned 
 }
 
 // ---- proof of work: smallest nonce whose duplex output word 7 has >= bits leading zeros ----
-constexpr uint32_t POW_GRID = 1024, POW_BLOCK = 256;
+// 2^16 candidates per round: with 16 PoW bits a round succeeds with probability 1 - 1/e and costs one
+// permutation latency (a 2^18 round is throughput-bound and takes ~4x longer)
+constexpr uint32_t POW_GRID = 256, POW_BLOCK = 256;
 __global__ __launch_bounds__(POW_BLOCK) void k_pow_grind(PowParams p, unsigned long long* __restrict__ best) {
     const uint64_t stride = (uint64_t)POW_GRID * POW_BLOCK;
     const uint64_t gid = (uint64_t)blockIdx.x * POW_BLOCK + threadIdx.x;
