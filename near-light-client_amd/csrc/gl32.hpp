@@ -142,12 +142,20 @@ __device__ __forceinline__ F fold_acc(uint64_t al, uint64_t ah) {
     return r;
 }
 
-__device__ __forceinline__ void mds_layer(F (&s)[12]) {
+// Linear layer; `rc_next` (12 canonical constants, wave-uniform, or nullptr) is the NEXT round's
+// constant vector: it seeds the accumulators, so the constant addition costs no vector instruction
+// (the 64-bit addend operand of the first multiply-add comes straight from scalar registers).
+__device__ __forceinline__ void mds_layer(F (&s)[12], const uint64_t* __restrict__ rc_next = nullptr) {
     constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     F o[12];
 #pragma unroll
     for (int r = 0; r < 12; r++) {
         uint64_t al = 0, ah = 0;
+        if (rc_next) {
+            const uint64_t c = rc_next[r];
+            al = (uint32_t)c;
+            ah = c >> 32;
+        }
 #pragma unroll
         for (int i = 0; i < 12; i++) {
             al += (uint64_t)s[(i + r) % 12].lo * C[i];

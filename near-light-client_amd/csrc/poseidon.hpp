@@ -78,29 +78,31 @@ GL_HD void mds_layer(uint64_t (&s)[12]) {
 GL_HD void permute_loose(uint64_t (&s)[12]) {
     const uint64_t* rc = rc_table();
 #if defined(__HIP_DEVICE_COMPILE__)
-    // device: {lo, hi} u32 pairs with hand-placed carry chains (gl32.hpp), ~20 % fewer instructions
+    // device: {lo, hi} u32 pairs with hand-placed carry chains (gl32.hpp); every round's constants
+    // seed the accumulators of the PREVIOUS linear layer (only round 0 adds them explicitly)
     gl32::F t[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) t[i] = gl32::from_u64(s[i]);
+    for (int i = 0; i < 12; i++) t[i] = gl32::add_const(gl32::from_u64(s[i]), rc[i]);
 #pragma unroll 1
     for (int r = 0; r < HALF_FULL; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) t[i] = gl32::sbox7(gl32::add_const(t[i], rc[r * 12 + i]));
-        gl32::mds_layer(t);
+        for (int i = 0; i < 12; i++) t[i] = gl32::sbox7(t[i]);
+        gl32::mds_layer(t, rc + (r + 1) * 12);
     }
 #pragma unroll 1
     for (int r = HALF_FULL; r < HALF_FULL + N_PARTIAL; r++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) t[i] = gl32::add_const(t[i], rc[r * 12 + i]);
         t[0] = gl32::sbox7(t[0]);
-        gl32::mds_layer(t);
+        gl32::mds_layer(t, rc + (r + 1) * 12);
     }
 #pragma unroll 1
-    for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS; r++) {
+    for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS - 1; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) t[i] = gl32::sbox7(gl32::add_const(t[i], rc[r * 12 + i]));
-        gl32::mds_layer(t);
+        for (int i = 0; i < 12; i++) t[i] = gl32::sbox7(t[i]);
+        gl32::mds_layer(t, rc + (r + 1) * 12);
     }
+#pragma unroll
+    for (int i = 0; i < 12; i++) t[i] = gl32::sbox7(t[i]);
+    gl32::mds_layer(t);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl32::to_u64(t[i]);
 #else

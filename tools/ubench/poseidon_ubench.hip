@@ -166,6 +166,38 @@ __device__ __forceinline__ void permute_loose(uint64_t (&st)[12]) {
 }
 }  // namespace v2
 
+namespace v3 {
+// round constants folded into the previous linear layer's accumulators
+__device__ __forceinline__ void permute_loose(uint64_t (&st)[12]) {
+    const uint64_t* rc = poseidon::RC_DEV;
+    gl32::F s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl32::add_const(gl32::from_u64(st[i]), rc[i]);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl32::sbox7(s[i]);
+        gl32::mds_layer(s, rc + (r + 1) * 12);
+    }
+#pragma unroll 1
+    for (int r = 4; r < 26; r++) {
+        s[0] = gl32::sbox7(s[0]);
+        gl32::mds_layer(s, rc + (r + 1) * 12);
+    }
+#pragma unroll 1
+    for (int r = 26; r < 29; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl32::sbox7(s[i]);
+        gl32::mds_layer(s, rc + (r + 1) * 12);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl32::sbox7(s[i]);
+    gl32::mds_layer(s);
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = gl32::to_u64(s[i]);
+}
+}  // namespace v3
+
 template <int V>
 __global__ __launch_bounds__(256) void k_perm(uint64_t* states, size_t n, int reps) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -176,7 +208,8 @@ __global__ __launch_bounds__(256) void k_perm(uint64_t* states, size_t n, int re
     for (int k = 0; k < reps; k++) {
         if (V == 0) poseidon::permute_loose(s);
         else if (V == 1) v1::permute_loose(s);
-        else v2::permute_loose(s);
+        else if (V == 2) v2::permute_loose(s);
+        else v3::permute_loose(s);
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) states[i * n + t] = gl::canon(s[i]);
@@ -226,5 +259,8 @@ int main() {
     std::vector<uint64_t> o2;
     bench_perm<2>("poseidon v2 (u32-pair asm)", d_states, n, o2);
     printf("v2 == v0: %s\n", o0 == o2 ? "yes" : "NO");
+    std::vector<uint64_t> o3;
+    bench_perm<3>("poseidon v3 (rc in accumulators)", d_states, n, o3);
+    printf("v3 == v0: %s\n", o0 == o3 ? "yes" : "NO");
     return 0;
 }
