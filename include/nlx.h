@@ -136,7 +136,11 @@ int32_t nlx_commit_get_digests(nlx_commit* c, uint64_t* digests_out);
 #define NLX_GATE_MUL_EXT 7        /* gates::multiplication_extension::MulExtensionGate<2> { num_ops = param0 } */
 #define NLX_GATE_REDUCING 8       /* gates::reducing::ReducingGate<2> { num_coeffs = param0 } */
 #define NLX_GATE_REDUCING_EXT 9   /* gates::reducing_extension::ReducingExtensionGate<2> { num_coeffs = param0 } */
-#define NLX_GATE_KIND_MAX 9
+#define NLX_GATE_POSEIDON_MDS 10   /* gates::poseidon_mds::PoseidonMdsGate */
+#define NLX_GATE_EXPONENTIATION 11 /* gates::exponentiation::ExponentiationGate { num_power_bits = param0 } */
+#define NLX_GATE_RANDOM_ACCESS 12  /* gates::random_access::RandomAccessGate { bits = param0, num_copies = param1 & 0xFFFF,
+                                      num_extra_constants = param1 >> 16 } */
+#define NLX_GATE_KIND_MAX 12
 
 typedef struct {
     uint32_t kind;
@@ -224,7 +228,7 @@ typedef struct {
     uint32_t pct_constant;    /* remaining rows are NoopGate */
     uint64_t seed;
     uint32_t pct_extension;   /* rows split evenly over ArithmeticExtension / MulExtension / Reducing / ReducingExtension */
-    uint32_t reserved;
+    uint32_t pct_misc;        /* rows split evenly over PoseidonMds / Exponentiation / RandomAccess */
 } nlx_synth_params;
 /* number of gates / selector polynomials the generator will emit for these parameters */
 void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_selectors);

@@ -162,6 +162,14 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
         if (gt.kind == NLX_GATE_ARITHMETIC_EXT && (8 * gt.param0 > d.num_wires || d.num_constants < 2)) return ctx->fail(NLX_E_INVAL, "ArithmeticExtensionGate too wide");
         if (gt.kind == NLX_GATE_MUL_EXT && 6 * gt.param0 > d.num_wires) return ctx->fail(NLX_E_INVAL, "MulExtensionGate too wide");
         if (gt.kind == NLX_GATE_REDUCING && (gt.param0 < 1 || 6 + gt.param0 + 2 * (gt.param0 - 1) > d.num_wires)) return ctx->fail(NLX_E_INVAL, "ReducingGate too wide");
+        if (gt.kind == NLX_GATE_POSEIDON_MDS && d.num_wires < 48) return ctx->fail(NLX_E_INVAL, "PoseidonMdsGate needs 48 wires");
+        if (gt.kind == NLX_GATE_EXPONENTIATION && (gt.param0 < 1 || 2 + 2 * gt.param0 > d.num_wires)) return ctx->fail(NLX_E_INVAL, "ExponentiationGate too wide");
+        if (gt.kind == NLX_GATE_RANDOM_ACCESS) {
+            const uint32_t bits = gt.param0, copies = gt.param1 & 0xFFFF, extra = gt.param1 >> 16;
+            if (bits < 1 || bits > 6 || copies < 1 || extra > d.num_constants ||
+                (2 + (1u << bits)) * copies + extra + copies * bits > d.num_wires)
+                return ctx->fail(NLX_E_INVAL, "RandomAccessGate does not fit the wires");
+        }
         if (gt.kind == NLX_GATE_REDUCING_EXT && (gt.param0 < 1 || 6 + 2 * gt.param0 + 2 * (gt.param0 - 1) > d.num_wires)) return ctx->fail(NLX_E_INVAL, "ReducingExtensionGate too wide");
         if (gt.selector_index >= d.num_selectors || gt.group_end > d.num_gates || gt.group_start > gt.group_end)
             return ctx->fail(NLX_E_INVAL, "gate %u: bad selector group", g);

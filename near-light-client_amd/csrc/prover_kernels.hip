@@ -397,6 +397,78 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 }
                 break;
             }
+            case NLX_GATE_POSEIDON_MDS: {
+                constexpr uint64_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+                for (uint32_t rr = 0; rr < 12; rr++) {
+                    uint64_t c0 = 0, c1 = 0;
+#pragma unroll
+                    for (uint32_t i = 0; i < 12; i++) {
+                        uint32_t src = rr + i;
+                        src = src >= 12 ? src - 12 : src;
+                        c0 = gl::add(c0, gl::mul(W(2 * src), C[i]));
+                        c1 = gl::add(c1, gl::mul(W(2 * src + 1), C[i]));
+                    }
+                    if (rr == 0) {
+                        c0 = gl::add(c0, gl::mul(W(0), 8));
+                        c1 = gl::add(c1, gl::mul(W(1), 8));
+                    }
+                    acc.emit(gl::sub(W(24 + 2 * rr), c0));
+                    acc.emit(gl::sub(W(24 + 2 * rr + 1), c1));
+                }
+                break;
+            }
+            case NLX_GATE_EXPONENTIATION: {
+                const uint32_t nb = gd.param0;
+                const uint64_t base = W(0);
+                uint64_t prev_iv = 1;
+                for (uint32_t i = 0; i < nb; i++) {
+                    const uint64_t prev = i ? gl::mul(prev_iv, prev_iv) : 1;
+                    const uint64_t bit = W(1 + (nb - 1 - i));
+                    const uint64_t sel = gl::add(gl::mul(bit, base), gl::sub(1, bit));
+                    const uint64_t iv = W(2 + nb + i);
+                    acc.emit(gl::sub(gl::mul(prev, sel), iv));
+                    prev_iv = iv;
+                }
+                acc.emit(gl::sub(W(1 + nb), prev_iv));
+                break;
+            }
+            case NLX_GATE_RANDOM_ACCESS: {
+                const uint32_t bits = gd.param0, copies = gd.param1 & 0xFFFF, extra = gd.param1 >> 16;
+                const uint32_t vec = 1u << bits, rt = (2 + vec) * copies + extra;
+                for (uint32_t cpy = 0; cpy < copies; cpy++) {
+                    const uint32_t b0 = (2 + vec) * cpy, bw = rt + cpy * bits;
+                    for (uint32_t i = 0; i < bits; i++) {
+                        const uint64_t b = W(bw + i);
+                        acc.emit(gl::mul(b, gl::sub(b, 1)));
+                    }
+                    uint64_t rec = 0;
+                    for (uint32_t i = bits; i-- > 0;) rec = gl::add(gl::add(rec, rec), W(bw + i));
+                    acc.emit(gl::sub(rec, W(b0)));
+                    // fold the list by the index bits; level i consumes bit i.  The selected element is
+                    // computed by a recursive descent so that no list array lives in registers:
+                    // value(level, j) = value(level-1, 2j) + bit * (value(level-1, 2j+1) - value(level-1, 2j))
+                    // evaluated iteratively over the 2^bits leaves with a small stack.
+                    uint64_t stack[7];
+                    uint32_t depth_of[7];
+                    int sp = 0;
+                    for (uint32_t leaf = 0; leaf < vec; leaf++) {
+                        uint64_t v = W(b0 + 2 + leaf);
+                        uint32_t lvl = 0;
+                        while (sp > 0 && depth_of[sp - 1] == lvl) {
+                            const uint64_t left = stack[--sp];
+                            const uint64_t b = W(bw + lvl);
+                            v = gl::add(left, gl::mul(b, gl::sub(v, left)));
+                            lvl++;
+                        }
+                        stack[sp] = v;
+                        depth_of[sp] = lvl;
+                        sp++;
+                    }
+                    acc.emit(gl::sub(stack[0], W(b0 + 1)));
+                }
+                for (uint32_t i = 0; i < extra; i++) acc.emit(gl::sub(CS(p.n_selectors + i), W((2 + vec) * copies + i)));
+                break;
+            }
             default: break;  // NoopGate
         }
         tot0 = gl::add(tot0, gl::mul(f, acc.s0));

@@ -116,6 +116,9 @@ uint32_t gate_degree(uint32_t kind, uint32_t p0) {
         case NLX_GATE_MUL_EXT: return 3;
         case NLX_GATE_REDUCING: return 2;
         case NLX_GATE_REDUCING_EXT: return 2;
+        case NLX_GATE_POSEIDON_MDS: return 1;
+        case NLX_GATE_EXPONENTIATION: return 4;
+        case NLX_GATE_RANDOM_ACCESS: return p0 + 1;
     }
     return 0;
 }
@@ -142,7 +145,8 @@ static uint32_t build_gate_list(const nlx_synth_params* sp, uint32_t* kinds, uin
     uint32_t k = 0;
     auto add = [&](uint32_t kind, uint32_t a, uint32_t b) { kinds[k] = kind; p0[k] = a; p1[k] = b; k++; };
     add(NLX_GATE_NOOP, 0, 0);                                    // degree 0
-    add(NLX_GATE_CONSTANT, 2, 0);                                // degree 1: "ConstantGate" < "PublicInputGate"
+    add(NLX_GATE_CONSTANT, 2, 0);                                // degree 1: "ConstantGate" < "PoseidonMdsGate" < "PublicInputGate"
+    if (sp->pct_misc) add(NLX_GATE_POSEIDON_MDS, 0, 0);
     add(NLX_GATE_PUBLIC_INPUT, 0, 0);
     if (sp->pct_base_sum) add(NLX_GATE_BASE_SUM, 2, 63);         // degree 2: "BaseSum" < "ReducingExtension" < "Reducing"
     if (sp->pct_extension) add(NLX_GATE_REDUCING_EXT, 32, 0);
@@ -150,6 +154,8 @@ static uint32_t build_gate_list(const nlx_synth_params* sp, uint32_t* kinds, uin
     if (sp->pct_extension) add(NLX_GATE_ARITHMETIC_EXT, 10, 0);  // degree 3: "ArithmeticExtension" < "ArithmeticGate" < "Mul..."
     if (sp->pct_arithmetic) add(NLX_GATE_ARITHMETIC, 20, 0);
     if (sp->pct_extension) add(NLX_GATE_MUL_EXT, 13, 0);
+    if (sp->pct_misc) add(NLX_GATE_EXPONENTIATION, 66, 0);       // degree 4
+    if (sp->pct_misc) add(NLX_GATE_RANDOM_ACCESS, 4, 4 | (2u << 16));  // degree 5: bits 4, 4 copies, 2 extra constants
     if (sp->pct_poseidon) add(NLX_GATE_POSEIDON, 0, 0);          // degree 7
     return k;
 }
@@ -200,7 +206,8 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
     // ---- gate table + selector groups ----
     uint32_t n_gates, n_sel;
     nlx_synth_shape(sp, &n_gates, &n_sel);
-    int g_base = -1, g_arith = -1, g_pos = -1, g_aext = -1, g_mext = -1, g_red = -1, g_rext = -1;
+    int g_base = -1, g_arith = -1, g_pos = -1, g_aext = -1, g_mext = -1, g_red = -1, g_rext = -1, g_pmds = -1, g_exp = -1,
+        g_ra = -1, g_const = 1, g_pi = 2;
     {
         uint32_t kinds[16], p0[16], p1[16];
         const uint32_t k = build_gate_list(sp, kinds, p0, p1);
@@ -214,6 +221,11 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
                 case NLX_GATE_MUL_EXT: g_mext = (int)g; break;
                 case NLX_GATE_REDUCING: g_red = (int)g; break;
                 case NLX_GATE_REDUCING_EXT: g_rext = (int)g; break;
+                case NLX_GATE_POSEIDON_MDS: g_pmds = (int)g; break;
+                case NLX_GATE_EXPONENTIATION: g_exp = (int)g; break;
+                case NLX_GATE_RANDOM_ACCESS: g_ra = (int)g; break;
+                case NLX_GATE_CONSTANT: g_const = (int)g; break;
+                case NLX_GATE_PUBLIC_INPUT: g_pi = (int)g; break;
                 default: break;
             }
         }
@@ -264,7 +276,7 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
         uint32_t kind = NLX_GATE_NOOP;
         int gidx = 0;
         if (row == 0) {
-            kind = NLX_GATE_PUBLIC_INPUT; gidx = 2;
+            kind = NLX_GATE_PUBLIC_INPUT; gidx = g_pi;
         } else if (row + 2 >= n) {
             kind = NLX_GATE_NOOP; gidx = 0;  // padding rows, as plonky2 pads with NoopGate
         } else {
@@ -273,13 +285,20 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
             if (r < t && g_pos >= 0) { kind = NLX_GATE_POSEIDON; gidx = g_pos; }
             else if (r < (t += sp->pct_arithmetic) && g_arith >= 0) { kind = NLX_GATE_ARITHMETIC; gidx = g_arith; }
             else if (r < (t += sp->pct_base_sum) && g_base >= 0) { kind = NLX_GATE_BASE_SUM; gidx = g_base; }
-            else if (r < (t += sp->pct_constant)) { kind = NLX_GATE_CONSTANT; gidx = 1; }
+            else if (r < (t += sp->pct_constant)) { kind = NLX_GATE_CONSTANT; gidx = g_const; }
             else if (r < (t += sp->pct_extension) && g_aext >= 0) {
                 switch (row & 3) {
                     case 0: kind = NLX_GATE_ARITHMETIC_EXT; gidx = g_aext; break;
                     case 1: kind = NLX_GATE_MUL_EXT; gidx = g_mext; break;
                     case 2: kind = NLX_GATE_REDUCING; gidx = g_red; break;
                     default: kind = NLX_GATE_REDUCING_EXT; gidx = g_rext; break;
+                }
+            }
+            else if (r < (t += sp->pct_misc) && g_pmds >= 0) {
+                switch (row % 3) {
+                    case 0: kind = NLX_GATE_POSEIDON_MDS; gidx = g_pmds; break;
+                    case 1: kind = NLX_GATE_EXPONENTIATION; gidx = g_exp; break;
+                    default: kind = NLX_GATE_RANDOM_ACCESS; gidx = g_ra; break;
                 }
             }
         }
@@ -397,6 +416,52 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
                     W_at(aw + 1, row) = acc.b;
                 }
                 pool.push_back(slot(0, row));
+                break;
+            }
+            case NLX_GATE_POSEIDON_MDS: {
+                for (int rr = 0; rr < 12; rr++) {
+                    gl::Ext c{0, 0};
+                    for (int i = 0; i < 12; i++) {
+                        const int src = (i + rr) % 12;
+                        c = gl::add(c, gl::mul(gl::Ext{W_at(2 * src, row), W_at(2 * src + 1, row)}, CIRC[i]));
+                    }
+                    if (rr == 0) c = gl::add(c, gl::mul(gl::Ext{W_at(0, row), W_at(1, row)}, (uint64_t)8));
+                    W_at(24 + 2 * rr, row) = c.a;
+                    W_at(24 + 2 * rr + 1, row) = c.b;
+                }
+                pool.push_back(slot(24, row));
+                break;
+            }
+            case NLX_GATE_EXPONENTIATION: {
+                const uint32_t nb = 66;
+                const uint64_t base = W_at(0, row);
+                uint64_t cur = 1;
+                for (uint32_t i = 0; i < nb; i++) W_at(1 + i, row) = rng.next() & 1;  // power bits, little-endian
+                for (uint32_t i = 0; i < nb; i++) {
+                    const uint64_t bit = W_at(1 + (nb - 1 - i), row);
+                    const uint64_t prev = i ? gl::sqr(cur) : 1;
+                    cur = gl::mul(prev, bit ? base : 1);
+                    W_at(2 + nb + i, row) = cur;
+                }
+                W_at(1 + nb, row) = cur;
+                pool.push_back(slot(1 + nb, row));
+                break;
+            }
+            case NLX_GATE_RANDOM_ACCESS: {
+                const uint32_t bits = 4, copies = 4, extra = 2, vec = 16, routed = (2 + vec) * copies + extra;
+                for (uint32_t cpy = 0; cpy < copies; cpy++) {
+                    const uint32_t b0 = (2 + vec) * cpy;
+                    const uint32_t idx = rng.below(vec);
+                    W_at(b0, row) = idx;
+                    W_at(b0 + 1, row) = W_at(b0 + 2 + idx, row);
+                    for (uint32_t i = 0; i < bits; i++) W_at(routed + cpy * bits + i, row) = (idx >> i) & 1;
+                    pool.push_back(slot(b0 + 1, row));
+                }
+                for (uint32_t i = 0; i < extra; i++) {
+                    const uint64_t v = rng.field();
+                    C_at(n_sel + i, row) = v;
+                    W_at((2 + vec) * copies + i, row) = v;
+                }
                 break;
             }
             default: break;

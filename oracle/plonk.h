@@ -29,7 +29,10 @@ enum {
     ORC_GATE_ARITHMETIC_EXT = 6, /* param0 = num_ops (10) */
     ORC_GATE_MUL_EXT = 7,        /* param0 = num_ops (13) */
     ORC_GATE_REDUCING = 8,       /* param0 = num_coeffs (43) */
-    ORC_GATE_REDUCING_EXT = 9    /* param0 = num_coeffs (32) */
+    ORC_GATE_REDUCING_EXT = 9,   /* param0 = num_coeffs (32) */
+    ORC_GATE_POSEIDON_MDS = 10,
+    ORC_GATE_EXPONENTIATION = 11, /* param0 = num_power_bits (66) */
+    ORC_GATE_RANDOM_ACCESS = 12   /* param0 = bits, param1 = num_copies | num_extra_constants << 16 */
 };
 
 typedef struct {

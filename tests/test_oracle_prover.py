@@ -16,6 +16,7 @@ from conftest import P
     (9, dict(pct_poseidon=10, pct_arithmetic=0, pct_base_sum=0, pct_constant=5)),
     (8, dict(pct_poseidon=15, pct_arithmetic=20, pct_base_sum=5, pct_constant=5, pct_extension=30)),  # 10 gates, 3 selectors
     (7, dict(pct_poseidon=0, pct_arithmetic=0, pct_base_sum=0, pct_constant=5, pct_extension=60)),
+    (8, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=20, pct_misc=30)),  # 13 gates, 4 selectors
 ])
 def test_prove_verify_roundtrip(nlx, orc, log_n, kw):
     syn = nlx.SyntheticCircuit(log_n, seed=log_n, **kw)
@@ -127,4 +128,23 @@ def test_extension_gates_constrain_their_rows(nlx, orc):
         w = syn.wires.copy()
         w[out_wire, rows[0]] = (int(w[out_wire, rows[0]]) + 1) % P
         assert circ.verify(circ.prove(w, syn.public_inputs)) < 1, kind
+    circ.close()
+
+
+def test_misc_gates_constrain_their_rows(nlx, orc):
+    """PoseidonMdsGate, ExponentiationGate, RandomAccessGate: a witness broken on one of their rows is rejected"""
+    syn = nlx.SyntheticCircuit(8, seed=23, pct_poseidon=5, pct_arithmetic=5, pct_base_sum=5, pct_constant=5,
+                               pct_extension=10, pct_misc=50)
+    assert syn.num_gates == 13 and syn.num_selectors == 4
+    kinds = [g.kind for g in syn.gates]
+    assert kinds == [0, 1, 10, 2, 4, 9, 8, 6, 3, 7, 11, 12, 5]
+    circ = orc.Circuit.from_synthetic(syn)
+    assert circ.verify(circ.prove(syn.wires, syn.public_inputs)) == 1
+    for kind, wire in ((10, 25), (11, 1), (11, 70), (12, 0), (12, 74)):   # outputs, a power bit, an index, a bit wire
+        g = syn.gates[kinds.index(kind)]
+        rows = np.nonzero(syn.constants[g.selector_index] == g.index)[0]
+        assert rows.size > 0, kind
+        w = syn.wires.copy()
+        w[wire, rows[0]] = (int(w[wire, rows[0]]) + 1) % P
+        assert circ.verify(circ.prove(w, syn.public_inputs)) < 1, (kind, wire)
     circ.close()
