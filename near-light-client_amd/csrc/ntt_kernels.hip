@@ -16,7 +16,6 @@
 //  * Each pass stages a tile of 4096 field elements (32 KiB) in LDS, runs up to 12 radix-2
 //    levels there, and touches HBM once per pass with >=128-byte contiguous segments.
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include "gl.hpp"
 #include "launch.hpp"
 
@@ -37,7 +36,6 @@ struct PassParams {
     const uint64_t* tw;    // w_N^e, e in [0, N/2), N = 2^log_N = sub-problem size of this pass
     const uint64_t* scale; // optional per-element factor applied on load (indexed like src within a z slice)
     size_t scale_z_stride;
-    uint32_t debug_flags;  // measurement only (env NLX_NTT_DEBUG): 1 = skip butterfly groups, 2 = skip multiplies
     uint64_t r16[8];       // w_16^e (forward or inverse), constant twiddles of the register sub-transforms
     uint64_t final_scale;  // multiplied into every output (1 = none)
     const uint64_t* post_scale;  // optional per-element factor applied on store (indexed like dst within a z slice)
@@ -54,9 +52,6 @@ __device__ __forceinline__ uint64_t tw_full(const uint64_t* __restrict__ tw, uin
     return e < half_N ? tw[e] : gl::P - tw[e - half_N];
 }
 
-#ifndef NTT_SKIP_MUL
-#define NTT_SKIP_MUL 0
-#endif
 // ---- in-register radix-2^g sub-transforms with constant twiddles (w_16 powers) ----
 // DIF: natural in, bit-reversed out.  DIT: bit-reversed in, natural out.  r16[e] = w_16^e (e < 8).
 template <int g>
@@ -73,7 +68,7 @@ __device__ __forceinline__ void dft_dif(uint64_t (&x)[1 << g], const uint64_t (&
                 x[b + u] = gl::add(a, c);
                 uint64_t d = gl::sub(a, c);
                 const int e = (u << t) * (16 / G);  // w_{2 half}^u = w_G^(u << t) = w_16^(...)
-                if (e != 0 && !NTT_SKIP_MUL) d = gl::mul(d, r16[e]);
+                if (e != 0) d = gl::mul(d, r16[e]);
                 x[b + u + half] = d;
             }
         }
@@ -92,7 +87,7 @@ __device__ __forceinline__ void dft_dit(uint64_t (&x)[1 << g], const uint64_t (&
                 const uint64_t a = x[b + u];
                 uint64_t c = x[b + u + half];
                 const int e = (u << (g - 1 - t)) * (16 / G);
-                if (e != 0 && !NTT_SKIP_MUL) c = gl::mul(c, r16[e]);
+                if (e != 0) c = gl::mul(c, r16[e]);
                 x[b + u] = gl::add(a, c);
                 x[b + u + half] = gl::sub(a, c);
             }
@@ -224,7 +219,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
     __syncthreads();
 
     // ---- butterfly levels along j1, four at a time ----
-    unsigned done = (p.debug_flags & 1) ? log_A : 0;
+    unsigned done = 0;
     while (done < log_A) {
         const unsigned rem = log_A - done;
         const unsigned g = rem >= 4 ? 4 : rem;
@@ -378,10 +373,6 @@ static void run_passes(hipStream_t st, const NttTables& tb, bool inverse_roots, 
         p.log_n = log_n;
         p.log_N = logN_of[i];
         p.log_A = pl.log_A[i];
-        {
-            static const int dbg = getenv("NLX_NTT_DEBUG") ? atoi(getenv("NLX_NTT_DEBUG")) : 0;
-            p.debug_flags = (uint32_t)dbg;
-        }
         p.tw = p.log_N >= 1 ? roots[p.log_N] : nullptr;
         {
             uint64_t w16 = gl::root_of_unity(4);
