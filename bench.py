@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent proofs in flight per GPU (one context + stream + host thread each); the K "
                          "timed steps are shared between them")
+    ap.add_argument("--host-witness", default="", choices=["", "pageable", "pinned"],
+                    help="hand the witness over as a HOST buffer (PCIe inside the timed region); reported separately "
+                         "in DESIGN.md, never the headline value")
     ap.add_argument("--map-log-n", type=int, default=15)
     ap.add_argument("--reduce-log-n", type=int, default=13)
     return ap.parse_args()
@@ -113,6 +116,10 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
     syn.set_public_inputs(io.bytes_to_field_elements(sync_in + sync_out))
     # witness resident in HBM before the timed region (device tensor handed over by pointer)
     wires = torch.from_numpy(syn.wires.view(np.int64)).cuda()
+    if args.host_witness == "pageable":
+        wires = torch.from_numpy(syn.wires.view(np.int64))
+    elif args.host_witness == "pinned":
+        wires = torch.from_numpy(syn.wires.view(np.int64)).pin_memory()
     pis = np.ascontiguousarray(syn.public_inputs)
     pis_ptr = pis.ctypes.data
     # SyncCircuit requests are independent: `inflight` of them are proved concurrently, each on its own
@@ -197,7 +204,7 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
                                    "135 wires, rate 8, 28 queries, 16 PoW bits), replicas only" % args.log_n,
                        "log_n": args.log_n, "gate_mix_pct": gate_mix,
                        "public_inputs": "64 bytes of real Sync I/O (fixtures/test_0.json): new head hash 0x%s" % sync_out.hex(), "proof_bytes": len(cds[0].prove(wires, pis)),
-                       "proofs_in_flight_per_gpu": n_workers, "parallelism": "replicas x%d" % world},
+                       "proofs_in_flight_per_gpu": n_workers, "witness": args.host_witness or "resident in HBM", "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_hash_lde_leaves", "launches": calls, "avg_launch_ms": ms / calls if calls else None,

@@ -172,6 +172,7 @@ __global__ void k_gather_rows(const uint64_t* __restrict__ lde, size_t col_strid
                               uint64_t* __restrict__ rows_out) {
     size_t q = blockIdx.x;
     if (q >= k) return;
+    if (idx[q] >> (log_n + rate_bits)) return;  // device-resident indices cannot be checked on the host: never read out of range
     size_t pos = leaf_to_pos(idx[q], log_n, rate_bits);
     for (uint32_t c = threadIdx.x; c < n_cols; c += blockDim.x) rows_out[q * n_cols + c] = lde[(size_t)c * col_stride + pos];
 }
@@ -189,6 +190,7 @@ __global__ void k_gather_paths(const uint64_t* __restrict__ digests, unsigned lo
     unsigned path_len = log_leaves - cap_height;
     unsigned lvl = threadIdx.x >> 2, w = threadIdx.x & 3;
     if (q >= k || lvl >= path_len) return;
+    if (idx[q] >> log_leaves) return;  // out-of-range leaf index: leave the output untouched
     // offset of level `lvl` in words: 4 * (L + L/2 + ... ) = 4 * (2L - L >> (lvl-1)) ...
     size_t L = (size_t)1 << log_leaves;
     size_t off = 4 * (2 * L - (2 * L >> lvl));
