@@ -1,0 +1,74 @@
+/* Plain-C use of the nlx C ABI (include/nlx.h): build a synthetic nearx-shaped circuit, prove it on
+ * GPU 0, prove it again and check the two proofs are byte-identical.  This is what a cgo / Rust FFI
+ * caller does, minus the language binding.
+ *
+ *   gcc -O2 -I include examples/prove_example.c -L near-light-client_amd -lnlx \
+ *       -Wl,-rpath,$PWD/near-light-client_amd -o /tmp/prove_example && /tmp/prove_example 12
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "nlx.h"
+
+#define CHECK(call)                                                                        \
+    do {                                                                                   \
+        int32_t rc__ = (call);                                                             \
+        if (rc__ != NLX_OK) {                                                              \
+            fprintf(stderr, "%s failed: %d (%s) %s\n", #call, rc__, nlx_strerror(rc__),    \
+                    ctx ? nlx_last_error(ctx) : "");                                       \
+            return 1;                                                                      \
+        }                                                                                  \
+    } while (0)
+
+int main(int argc, char** argv) {
+    const uint32_t log_n = argc > 1 ? (uint32_t)atoi(argv[1]) : 10;
+    const size_t n = (size_t)1 << log_n;
+    nlx_ctx* ctx = NULL;
+    CHECK(nlx_ctx_create(0, &ctx));
+
+    nlx_synth_params sp;
+    memset(&sp, 0, sizeof sp);
+    sp.log_n = log_n;
+    sp.num_public_inputs = 4;
+    sp.pct_poseidon = 20; sp.pct_arithmetic = 30; sp.pct_base_sum = 5; sp.pct_constant = 5; sp.pct_extension = 10;
+    sp.seed = 42;
+    uint32_t n_gates = 0, n_sel = 0;
+    nlx_synth_shape(&sp, &n_gates, &n_sel);
+
+    nlx_gate_desc* gates = calloc(n_gates, sizeof *gates);
+    uint64_t* k_is = malloc(80 * 8);
+    uint64_t* constants = malloc((n_sel + 2) * n * 8);
+    uint64_t* sigmas = malloc(80 * n * 8);
+    uint64_t* wires = malloc(135 * n * 8);
+    uint64_t pis[4];
+    CHECK(nlx_synth_circuit(&sp, gates, k_is, constants, sigmas, wires, pis));
+
+    nlx_circuit_desc d;
+    memset(&d, 0, sizeof d);
+    d.degree_bits = log_n; d.num_wires = 135; d.num_routed_wires = 80; d.num_constants = 2; d.num_challenges = 2;
+    d.rate_bits = 3; d.cap_height = 4; d.quotient_degree_factor = 8; d.num_partial_products = 9;
+    d.fri_pow_bits = 16; d.fri_num_queries = 28; d.fri_arity_bits = 4; d.fri_final_poly_bits = 5;
+    d.num_selectors = n_sel; d.num_gates = n_gates; d.num_public_inputs = 4; d.gates = gates; d.k_is = k_is;
+
+    nlx_circuit* circuit = NULL;
+    CHECK(nlx_circuit_build(ctx, &d, constants, sigmas, &circuit));
+    const size_t cap = nlx_proof_max_bytes(circuit);
+    uint8_t* p1 = malloc(cap);
+    uint8_t* p2 = malloc(cap);
+    size_t l1 = 0, l2 = 0;
+    CHECK(nlx_prove(circuit, wires, pis, p1, cap, &l1));
+    CHECK(nlx_prove(circuit, wires, pis, p2, cap, &l2));
+    if (l1 != l2 || memcmp(p1, p2, l1) != 0) {
+        fprintf(stderr, "proofs differ between runs\n");
+        return 2;
+    }
+    uint64_t digest[4];
+    CHECK(nlx_circuit_digest(circuit, digest));
+    printf("ok: 2^%u rows, %u gates, %u selectors, proof %zu bytes, circuit digest %016llx...\n", log_n, n_gates, n_sel, l1,
+           (unsigned long long)digest[0]);
+    nlx_circuit_destroy(circuit);
+    nlx_ctx_destroy(ctx);
+    free(gates); free(k_is); free(constants); free(sigmas); free(wires); free(p1); free(p2);
+    return 0;
+}
