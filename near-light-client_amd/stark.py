@@ -1,0 +1,323 @@
+"""Host-side mirror of the starky STARK interface over the C ABI.
+
+nearx's Ed25519 / SHA-256 gadgets are proved by curta/starkyx STARKs inside plonky2x
+(nearx/src/builder.rs: `curta_eddsa_verify`, `curta_sha256`; Cargo.lock:6515 `starkyx`, un-vendored).
+Their prover is the starky flow (`starky::prover::prove`, `StarkConfig::standard_fast_config`): commit the
+trace, draw alphas, evaluate the AIR over a coset, commit the quotient, open at zeta and g*zeta, FRI.
+
+The AIR is *data*: `Air` records constraints written with ordinary Python operators against
+`local(i)`, `next(i)`, `public(i)` and compiles them into the register program both the HIP kernel
+and the CPU oracle interpret (include/nlx.h NLX_AIR_*), mirroring starky's
+`Stark::eval_packed_generic` + `ConstraintConsumer::{constraint, constraint_transition,
+constraint_first_row, constraint_last_row}`.
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import dll, ptr, NlxError
+
+P = 0xFFFFFFFF00000001
+(AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_CONST, AIR_ADD, AIR_SUB, AIR_MUL, AIR_EMIT_TRANSITION, AIR_EMIT_FIRST,
+ AIR_EMIT_LAST, AIR_EMIT) = range(11)
+AIR_NUM_REGS = 64
+
+
+class StarkDesc(ctypes.Structure):
+    """nlx_stark_desc (include/nlx.h) == orc_stark_desc (oracle/stark.h)."""
+    _fields_ = [(k, ctypes.c_uint32) for k in (
+        "degree_bits", "n_cols", "num_challenges", "rate_bits", "cap_height", "quotient_degree_factor",
+        "fri_pow_bits", "fri_num_queries", "fri_arity_bits", "fri_final_poly_bits", "num_public_inputs",
+        "n_words")] + [("program", ctypes.POINTER(ctypes.c_uint64))]
+
+
+class StarkConfig:
+    """starky::config::StarkConfig::standard_fast_config()."""
+
+    def __init__(self, **kw):
+        self.num_challenges = 2
+        self.rate_bits = 1
+        self.cap_height = 4
+        self.fri_pow_bits = 16
+        self.fri_num_queries = 84
+        self.fri_arity_bits = 4
+        self.fri_final_poly_bits = 5
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise TypeError("unknown config field %s" % k)
+            setattr(self, k, v)
+
+
+class _Expr:
+    """Node of the constraint DAG.  degree = polynomial degree in the trace columns."""
+    __slots__ = ("air", "op", "a", "b", "degree", "uses", "reg")
+
+    def __init__(self, air, op, a=None, b=None, degree=0):
+        self.air, self.op, self.a, self.b, self.degree = air, op, a, b, degree
+        self.uses = 0
+        self.reg = None
+
+    def _lift(self, o):
+        return o if isinstance(o, _Expr) else self.air.const(o)
+
+    def __add__(self, o):
+        o = self._lift(o)
+        return _Expr(self.air, AIR_ADD, self, o, max(self.degree, o.degree))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        o = self._lift(o)
+        return _Expr(self.air, AIR_SUB, self, o, max(self.degree, o.degree))
+
+    def __rsub__(self, o):
+        return self._lift(o) - self
+
+    def __mul__(self, o):
+        o = self._lift(o)
+        return _Expr(self.air, AIR_MUL, self, o, self.degree + o.degree)
+
+    __rmul__ = __mul__
+
+
+class Air:
+    """An AIR over `n_cols` trace columns and `num_public_inputs` public inputs."""
+
+    def __init__(self, n_cols, num_public_inputs=0):
+        self.n_cols = n_cols
+        self.num_public_inputs = num_public_inputs
+        self._emits = []  # (op, expr)
+        self._leaf_cache = {}
+
+    def _leaf(self, op, idx, degree):
+        key = (op, idx)
+        if key not in self._leaf_cache:
+            self._leaf_cache[key] = _Expr(self, op, idx, None, degree)
+        return self._leaf_cache[key]
+
+    def local(self, i):
+        assert 0 <= i < self.n_cols
+        return self._leaf(AIR_LOCAL, i, 1)
+
+    def next(self, i):
+        assert 0 <= i < self.n_cols
+        return self._leaf(AIR_NEXT, i, 1)
+
+    def public(self, i):
+        assert 0 <= i < self.num_public_inputs
+        return self._leaf(AIR_PUBLIC, i, 0)
+
+    def const(self, v):
+        return self._leaf(AIR_CONST, int(v) % P, 0)
+
+    # ConstraintConsumer
+    def constraint_transition(self, e):
+        self._emits.append((AIR_EMIT_TRANSITION, e))
+
+    def constraint_first_row(self, e):
+        self._emits.append((AIR_EMIT_FIRST, e))
+
+    def constraint_last_row(self, e):
+        self._emits.append((AIR_EMIT_LAST, e))
+
+    def constraint(self, e):
+        self._emits.append((AIR_EMIT, e))
+
+    @property
+    def num_constraints(self):
+        return len(self._emits)
+
+    @property
+    def constraint_degree(self):
+        """Stark::constraint_degree(): filters (z_last / lagrange) add one to the expression degree."""
+        d = 1
+        for op, e in self._emits:
+            d = max(d, e.degree + (0 if op == AIR_EMIT else 1))
+        return d
+
+    def quotient_degree_factor(self):
+        """Stark::quotient_degree_factor() = max(1, constraint_degree - 1), rounded up to a power of two
+        (compute_quotient_polys works on the coset of size n << log2_ceil(factor))."""
+        q = max(1, self.constraint_degree - 1)
+        return 1 << (q - 1).bit_length()
+
+    def compile(self):
+        """Flatten the DAG into program words.  Shared sub-expressions are evaluated once and kept in
+        their register until the last use; trace / public / constant leaves are re-loaded per constraint
+        so live ranges stay short.  Constraints are emitted in declaration order (alpha powers)."""
+        ops = (AIR_ADD, AIR_SUB, AIR_MUL)
+        computed, per_emit, all_ops = set(), [], []
+        for _, root in self._emits:
+            nodes, seen, stack = [], set(), [(root, False)]
+            while stack:
+                x, done = stack.pop()
+                if done:
+                    nodes.append(x)
+                    continue
+                if id(x) in seen or (x.op in ops and id(x) in computed):
+                    continue
+                seen.add(id(x))
+                stack.append((x, True))
+                if x.op in ops:
+                    stack.append((x.b, False))
+                    stack.append((x.a, False))
+            for x in nodes:
+                if x.op in ops:
+                    computed.add(id(x))
+                    all_ops.append(x)
+            per_emit.append(nodes)
+        for x in all_ops:
+            x.uses, x.reg = 0, None
+        for x in all_ops:
+            for y in (x.a, x.b):
+                if y.op in ops:
+                    y.uses += 1
+        for _, root in self._emits:
+            if root.op in ops:
+                root.uses += 1
+
+        words = []
+        free = list(range(AIR_NUM_REGS - 1, -1, -1))
+
+        def alloc():
+            if not free:
+                raise ValueError("AIR needs more than %d live registers" % AIR_NUM_REGS)
+            return free.pop()
+
+        def release(x):
+            x.uses -= 1
+            if x.uses == 0:
+                free.append(x.reg)
+                x.reg = None
+
+        for (op, root), nodes in zip(self._emits, per_emit):
+            for x in nodes:  # leaves: uses within this constraint only
+                if x.op not in ops:
+                    x.uses, x.reg = 0, None
+            for x in nodes:
+                if x.op in ops:
+                    for y in (x.a, x.b):
+                        if y.op not in ops:
+                            y.uses += 1
+            if root.op not in ops:
+                root.uses += 1
+            for x in nodes:
+                if x.op in ops:
+                    ra, rb = x.a.reg, x.b.reg
+                    release(x.a)
+                    release(x.b)
+                    x.reg = alloc()
+                    words.append(x.op | x.reg << 8 | ra << 24 | rb << 40)
+                else:
+                    x.reg = alloc()
+                    if x.op == AIR_CONST:
+                        words.append(AIR_CONST | x.reg << 8)
+                        words.append(x.a)
+                    else:
+                        words.append(x.op | x.reg << 8 | x.a << 24)
+            words.append(op | root.reg << 24)
+            release(root)
+        return np.array(words, dtype=np.uint64)
+
+
+class Stark:
+    """A compiled AIR + config at a fixed trace length: what starky's `prove(stark, config, trace, pis)`
+    takes.  `desc` is the C-ABI descriptor shared by the HIP prover and the oracle."""
+
+    def __init__(self, air, degree_bits, config=None):
+        self.air = air
+        self.config = config or StarkConfig()
+        self.program = air.compile()
+        cfg = self.config
+        qdf = air.quotient_degree_factor()
+        if qdf > (1 << cfg.rate_bits):
+            raise ValueError("constraint degree %d needs rate_bits >= %d" % (air.constraint_degree, qdf.bit_length() - 1))
+        self.desc = StarkDesc(degree_bits, air.n_cols, cfg.num_challenges, cfg.rate_bits, cfg.cap_height, qdf,
+                              cfg.fri_pow_bits, cfg.fri_num_queries, cfg.fri_arity_bits, cfg.fri_final_poly_bits,
+                              air.num_public_inputs, len(self.program),
+                              self.program.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+        self.degree_bits = degree_bits
+
+    def proof_max_bytes(self):
+        return int(dll().nlx_stark_proof_max_bytes(ctypes.byref(self.desc)))
+
+    def prove(self, ctx, trace, public_inputs=()):
+        """trace: (n_cols, n) uint64 host array, column-major as starky's Vec<PolynomialValues>.
+        Returns the proof bytes (StarkProofWithPublicInputs wire format)."""
+        trace = np.ascontiguousarray(trace, dtype=np.uint64)
+        assert trace.shape == (self.air.n_cols, 1 << self.degree_bits)
+        pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        assert pis.size == self.air.num_public_inputs
+        out = np.empty(self.proof_max_bytes(), dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        rc = dll().nlx_stark_prove(ctx.handle, ctypes.byref(self.desc), ptr(trace), ptr(pis) if pis.size else None,
+                                   out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(n))
+        if rc != 0:
+            raise NlxError(rc, ctx.last_error())
+        return out[:n.value].tobytes()
+
+
+# ---------------------------------------------------------------------------------------------
+# Example AIRs (starky's own FibonacciStark, and a wide synthetic AIR shaped like a hash-round table)
+# ---------------------------------------------------------------------------------------------
+def fibonacci_air():
+    """starky::fibonacci_stark::FibonacciStark: columns (x0, x1); public inputs (x0[0], x1[0], x1[n-1])."""
+    air = Air(2, 3)
+    air.constraint_first_row(air.local(0) - air.public(0))
+    air.constraint_first_row(air.local(1) - air.public(1))
+    air.constraint_last_row(air.local(1) - air.public(2))
+    air.constraint_transition(air.next(0) - air.local(1))
+    air.constraint_transition(air.next(1) - air.local(0) - air.local(1))
+    return air
+
+
+def fibonacci_trace(degree_bits, x0=0, x1=1):
+    n = 1 << degree_bits
+    t = np.zeros((2, n), dtype=np.uint64)
+    a, b = x0 % P, x1 % P
+    for i in range(n):
+        t[0, i], t[1, i] = a, b
+        a, b = b, (a + b) % P
+    return t, np.array([t[0, 0], t[1, 0], t[1, n - 1]], dtype=np.uint64)
+
+
+def wide_air(n_cols=64, seed=1):
+    """Synthetic degree-3 AIR, n_cols columns in groups of four (a, b, c, d):
+         next.a = a*b + c        next.b = b*c + k1      next.c = (a + b + c) * d      d boolean: d*(d-1) = 0, next.d = d
+       plus first-row pins on the public inputs.  Column count and multiplicative depth are those of a
+       byte-oriented hash-round table (curta's SHA-256 / Ed25519 AIRs are hundreds of such columns)."""
+    assert n_cols % 4 == 0
+    air = Air(n_cols, 2)
+    rng = np.random.default_rng(seed)
+    for g in range(n_cols // 4):
+        a, b, c, d = (air.local(4 * g + k) for k in range(4))
+        na, nb, nc, nd = (air.next(4 * g + k) for k in range(4))
+        k1 = int(rng.integers(1, P, dtype=np.uint64))
+        air.constraint_transition(na - (a * b + c))
+        air.constraint_transition(nb - (b * c + k1))
+        air.constraint_transition(nc - (a + b + c) * d)
+        air.constraint(d * (d - 1))
+        air.constraint_transition(nd - d)
+    air.constraint_first_row(air.local(0) - air.public(0))
+    air.constraint_first_row(air.local(1) - air.public(1))
+    return air
+
+
+def wide_trace(air, degree_bits, seed=1):
+    """Witness for wide_air(air.n_cols, seed): object-dtype python ints would be slow, so step with
+    numpy uint64 limbs through Python ints per row group (n small in tests) or vectorised across groups."""
+    n = 1 << degree_bits
+    G = air.n_cols // 4
+    rng = np.random.default_rng(seed)
+    k1 = [int(rng.integers(1, P, dtype=np.uint64)) for _ in range(G)]
+    rng2 = np.random.default_rng(seed + 1000)
+    a = [int(x) for x in rng2.integers(0, P, G, dtype=np.uint64)]
+    b = [int(x) for x in rng2.integers(0, P, G, dtype=np.uint64)]
+    c = [int(x) for x in rng2.integers(0, P, G, dtype=np.uint64)]
+    d = [int(x) for x in rng2.integers(0, 2, G, dtype=np.uint64)]
+    t = np.zeros((air.n_cols, n), dtype=np.uint64)
+    for i in range(n):
+        for g in range(G):
+            t[4 * g, i], t[4 * g + 1, i], t[4 * g + 2, i], t[4 * g + 3, i] = a[g], b[g], c[g], d[g]
+            a[g], b[g], c[g] = (a[g] * b[g] + c[g]) % P, (b[g] * c[g] + k1[g]) % P, ((a[g] + b[g] + c[g]) * d[g]) % P
+    return t, np.array([t[0, 0], t[1, 0]], dtype=np.uint64)

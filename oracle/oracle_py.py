@@ -242,3 +242,35 @@ class Circuit:
         if self.h:
             dll().orc_circuit_free(self.h)
             self.h = None
+
+
+# ---------------- STARK oracle (stark.h) ----------------
+def _stark_sigs():
+    d = dll()
+    d.orc_stark_proof_max_bytes.restype = ctypes.c_size_t
+    d.orc_stark_proof_max_bytes.argtypes = [ctypes.c_void_p]
+    d.orc_stark_prove.restype = ctypes.c_size_t
+    d.orc_stark_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    d.orc_stark_verify.restype = ctypes.c_int
+    d.orc_stark_verify.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    return d
+
+
+def stark_prove(desc, trace, public_inputs):
+    """desc: a ctypes structure laid out as orc_stark_desc (the package's StarkDesc is).  trace (n_cols, n)."""
+    d = _stark_sigs()
+    trace = _u64(trace)
+    pis = _u64(public_inputs)
+    assert trace.shape == (desc.n_cols, 1 << desc.degree_bits) and pis.size == desc.num_public_inputs
+    out = np.empty(d.orc_stark_proof_max_bytes(ctypes.addressof(desc)), dtype=np.uint8)
+    n = d.orc_stark_prove(ctypes.addressof(desc), trace.ctypes.data, pis.ctypes.data if pis.size else None,
+                          out.ctypes.data, out.size)
+    if n == 0:
+        raise RuntimeError("orc_stark_prove failed (bad descriptor or buffer overflow)")
+    return out[:n].tobytes()
+
+
+def stark_verify(desc, proof):
+    d = _stark_sigs()
+    buf = np.frombuffer(proof, dtype=np.uint8)
+    return int(d.orc_stark_verify(ctypes.addressof(desc), buf.ctypes.data, buf.size))

@@ -183,26 +183,7 @@ void orc_circuit_constants_sigmas_cap(const orc_circuit* c, uint64_t* cap_out) {
     memcpy(cap_out, c->cs_cap, 32 << c->d.cap_height);
 }
 
-/* ---------------- byte writer / reader (util::serialization::Buffer) ---------------- */
-typedef struct { uint8_t* p; size_t len, cap; int overflow; } wbuf;
-static void w_bytes(wbuf* w, const void* src, size_t n) {
-    if (w->len + n > w->cap) { w->overflow = 1; return; }
-    memcpy(w->p + w->len, src, n);
-    w->len += n;
-}
-static void w_u64s(wbuf* w, const uint64_t* v, size_t n) { w_bytes(w, v, n * 8); } /* little-endian host */
-static void w_u8(wbuf* w, uint8_t v) { w_bytes(w, &v, 1); }
-static void w_u32(wbuf* w, uint32_t v) { w_bytes(w, &v, 4); }
-typedef struct { const uint8_t* p; size_t len, pos; int bad; } rbuf;
-static void r_bytes(rbuf* r, void* dst, size_t n) {
-    if (r->pos + n > r->len) { r->bad = 1; memset(dst, 0, n); return; }
-    memcpy(dst, r->p + r->pos, n);
-    r->pos += n;
-}
-static void r_u64s(rbuf* r, uint64_t* v, size_t n) {
-    r_bytes(r, v, n * 8);
-    for (size_t i = 0; i < n; i++) if (v[i] >= GL_P) r->bad = 1; /* read_field rejects non-canonical */
-}
+#include "bytes.h"
 
 /* ---------------- helpers ---------------- */
 static gl2 gl2_add_base(gl2 x, uint64_t b) { return gl2_make(gl_add(x.a, b), x.b); }

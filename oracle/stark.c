@@ -1,0 +1,550 @@
+/* ORACLE - TEST INFRASTRUCTURE ONLY (see gl.h and stark.h headers).
+ *
+ * Generic FRI (prove_openings / verify) over arbitrary batches, and the starky-style STARK prover and
+ * verifier built on it.  Written the reference's way: row-major bit-reversed leaves, natural-order
+ * coefficients, one zero-padded coset FFT per polynomial, coefficient-domain FRI folding.
+ */
+#include "stark.h"
+#include "bytes.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------- helpers shared with plonk.c's style ---------------- */
+static void observe_cap(orc_challenger* ch, const uint64_t* cap, unsigned cap_height) {
+    orc_ch_observe_many(ch, cap, (size_t)4 << cap_height);
+}
+static gl2 gl2_add_base(gl2 x, uint64_t b) { return gl2_make(gl_add(x.a, b), x.b); }
+static gl2 eval_base_poly_ext(const uint64_t* coeffs, size_t n, gl2 z) {
+    gl2 acc = gl2_from(0);
+    for (size_t i = n; i-- > 0;) acc = gl2_add_base(gl2_mul(acc, z), coeffs[i]);
+    return acc;
+}
+static void ext_coset_fft(gl2* v, unsigned log_n, uint64_t shift) {
+    size_t n = (size_t)1 << log_n;
+    uint64_t* a = (uint64_t*)malloc(16 * n);
+    uint64_t* b = a + n;
+    for (size_t i = 0; i < n; i++) { a[i] = v[i].a; b[i] = v[i].b; }
+    orc_coset_fft(a, log_n, shift);
+    orc_coset_fft(b, log_n, shift);
+    for (size_t i = 0; i < n; i++) { v[i].a = a[i]; v[i].b = b[i]; }
+    free(a);
+}
+static uint32_t fri_num_rounds(const orc_fri_params* p) {
+    uint32_t degree_bits = p->degree_bits, r = 0;
+    while (degree_bits > p->final_poly_bits && degree_bits + p->rate_bits >= p->cap_height + p->arity_bits) {
+        if (degree_bits < p->arity_bits) break;
+        degree_bits -= p->arity_bits;
+        r++;
+    }
+    return r;
+}
+
+/* ---------------- FRI prover: PolynomialBatch::prove_openings + fri_proof ---------------- */
+static void fri_prove(const orc_fri_params* p, const orc_fri_oracle* oracles, uint32_t n_oracles,
+                      const orc_fri_batch* batches, uint32_t n_batches, orc_challenger* ch, wbuf* w) {
+    const unsigned log_n = p->degree_bits, log_L = log_n + p->rate_bits, cap_h = p->cap_height;
+    const size_t n = (size_t)1 << log_n, L = (size_t)1 << log_L;
+    const uint32_t arity = 1u << p->arity_bits, R = fri_num_rounds(p);
+    gl2 alpha = orc_ch_ext_challenge(ch);
+    gl2* final_poly = (gl2*)calloc(L, sizeof(gl2));
+    gl2* comp = (gl2*)malloc(sizeof(gl2) * n);
+    for (uint32_t b = 0; b < n_batches; b++) {
+        /* composition polynomial sum alpha^j f_j, then (F(X) - F(z)) / (X - z); earlier batches are
+         * shifted by alpha^(number of polynomials of this batch) (ReducingFactor::shift_poly) */
+        const orc_fri_batch* bt = &batches[b];
+        gl2 apow = gl2_from(1);
+        memset(comp, 0, sizeof(gl2) * n);
+        for (uint32_t j = 0; j < bt->n_polys; j++) {
+            const uint64_t* co = oracles[bt->oracle[j]].coeffs + (size_t)bt->poly[j] * n;
+#pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < n; i++) comp[i] = gl2_add(comp[i], gl2_scale(apow, co[i]));
+            apow = gl2_mul(apow, alpha);
+        }
+        if (b > 0)
+            for (size_t i = 0; i < n; i++) final_poly[i] = gl2_mul(final_poly[i], apow);
+        gl2 acc = gl2_from(0);
+        for (size_t i = n; i-- > 1;) {
+            acc = gl2_add(gl2_mul(acc, bt->point), comp[i]);
+            final_poly[i - 1] = gl2_add(final_poly[i - 1], acc);
+        }
+    }
+    free(comp);
+    gl2* coeffs = final_poly;
+    gl2* values = (gl2*)malloc(sizeof(gl2) * L);
+    memcpy(values, coeffs, sizeof(gl2) * L);
+    ext_coset_fft(values, log_L, GL_GEN);
+
+    uint64_t** tree_leaves = (uint64_t**)calloc(R + 1, sizeof(uint64_t*));
+    uint64_t** tree_digests = (uint64_t**)calloc(R + 1, sizeof(uint64_t*));
+    size_t* tree_nleaves = (size_t*)calloc(R + 1, sizeof(size_t));
+    size_t cur_len = L;
+    uint64_t shift = GL_GEN;
+    for (uint32_t r = 0; r < R; r++) {
+        unsigned lg = gl_log2_strict(cur_len);
+        size_t n_leaves = cur_len / arity;
+        uint64_t* lv = (uint64_t*)malloc(16 * cur_len);
+        for (size_t j = 0; j < cur_len; j++) {
+            gl2 v = values[gl_bitrev(j, lg)];
+            lv[2 * j] = v.a;
+            lv[2 * j + 1] = v.b;
+        }
+        uint64_t* dg = (uint64_t*)malloc(8 * orc_merkle_digest_words(n_leaves, cap_h));
+        uint64_t capbuf[4 * 64];
+        orc_merkle_build(lv, n_leaves, 2 * arity, cap_h, dg, capbuf);
+        tree_leaves[r] = lv; tree_digests[r] = dg; tree_nleaves[r] = n_leaves;
+        w_u64s(w, capbuf, (size_t)4 << cap_h);
+        observe_cap(ch, capbuf, cap_h);
+        gl2 beta = orc_ch_ext_challenge(ch);
+        size_t new_len = cur_len / arity;
+        for (size_t j = 0; j < new_len; j++) {
+            gl2 acc = gl2_from(0);
+            for (uint32_t t = arity; t-- > 0;) acc = gl2_add(gl2_mul(acc, beta), coeffs[j * arity + t]);
+            coeffs[j] = acc;
+        }
+        cur_len = new_len;
+        shift = gl_exp_pow2(shift, p->arity_bits);
+        memcpy(values, coeffs, sizeof(gl2) * cur_len);
+        ext_coset_fft(values, gl_log2_strict(cur_len), shift);
+    }
+    size_t final_len = cur_len >> p->rate_bits;
+    orc_ch_observe_many(ch, (uint64_t*)coeffs, 2 * final_len);
+    /* proof of work: smallest witness */
+    uint64_t pow_witness = 0;
+    {
+        uint64_t st0[12];
+        memcpy(st0, ch->state, sizeof st0);
+        memcpy(st0, ch->in_buf, ch->n_in * 8);
+        unsigned pos = ch->n_in;
+        const uint64_t CH = 1 << 14;
+        int found = 0;
+        for (uint64_t start = 0; !found; start += CH) {
+            uint64_t best = ~0ULL;
+#pragma omp parallel for schedule(static) reduction(min : best)
+            for (uint64_t cand = start; cand < start + CH; cand++) {
+                uint64_t st[12];
+                memcpy(st, st0, sizeof st);
+                st[pos] = cand;
+                orc_poseidon_permute(st);
+                unsigned lz = st[7] ? (unsigned)__builtin_clzll(st[7]) : 64;
+                if (lz >= p->pow_bits && cand < best) best = cand;
+            }
+            if (best != ~0ULL) { pow_witness = best; found = 1; }
+        }
+        orc_ch_observe(ch, pow_witness);
+        (void)orc_ch_challenge(ch);
+    }
+    for (uint32_t q = 0; q < p->n_queries; q++) {
+        size_t x_index = orc_ch_challenge(ch) % L;
+        for (uint32_t o = 0; o < n_oracles; o++) {
+            const orc_fri_oracle* b = &oracles[o];
+            w_u64s(w, b->leaves + x_index * b->n_cols, b->n_cols);
+            unsigned plen = log_L - cap_h;
+            uint64_t sib[64 * 4];
+            orc_merkle_prove(b->digests, L, cap_h, x_index, sib);
+            w_u8(w, (uint8_t)plen);
+            w_u64s(w, sib, 4 * plen);
+        }
+        for (uint32_t r = 0; r < R; r++) {
+            size_t leaf = x_index >> p->arity_bits;
+            w_u64s(w, tree_leaves[r] + leaf * 2 * arity, 2 * arity);
+            unsigned lg = gl_log2_strict(tree_nleaves[r]);
+            unsigned plen = lg > cap_h ? lg - cap_h : 0;
+            uint64_t sib[64 * 4];
+            orc_merkle_prove(tree_digests[r], tree_nleaves[r], cap_h, leaf, sib);
+            w_u8(w, (uint8_t)plen);
+            w_u64s(w, sib, 4 * plen);
+            x_index = leaf;
+        }
+    }
+    w_u64s(w, (uint64_t*)coeffs, 2 * final_len);
+    w_u64s(w, &pow_witness, 1);
+    for (uint32_t r = 0; r < R; r++) { free(tree_leaves[r]); free(tree_digests[r]); }
+    free(tree_leaves); free(tree_digests); free(tree_nleaves); free(values); free(final_poly);
+}
+
+/* ---------------- FRI verifier: verify_fri_proof ---------------- */
+/* opened[b][j] = claimed value of batch b's j-th polynomial at its point.  Reads the FRI part of the
+ * proof from r (commit caps, query rounds, final polynomial, pow witness).  1 = accept. */
+static int fri_verify(const orc_fri_params* p, const uint64_t* const* caps, const uint32_t* n_cols, uint32_t n_oracles,
+                      const orc_fri_batch* batches, uint32_t n_batches, const gl2* const* opened, orc_challenger* ch,
+                      rbuf* r) {
+    const unsigned log_n = p->degree_bits, log_L = log_n + p->rate_bits, cap_h = p->cap_height;
+    const size_t L = (size_t)1 << log_L, capw = (size_t)4 << cap_h;
+    const uint32_t arity = 1u << p->arity_bits, R = fri_num_rounds(p);
+    int rc = 1;
+    gl2 fri_alpha = orc_ch_ext_challenge(ch);
+    uint64_t* fri_caps = (uint64_t*)malloc(8 * capw * (R + 1));
+    r_u64s(r, fri_caps, R * capw);
+    gl2 fri_betas[16];
+    for (uint32_t k = 0; k < R; k++) {
+        orc_ch_observe_many(ch, fri_caps + k * capw, capw);
+        fri_betas[k] = orc_ch_ext_challenge(ch);
+    }
+    size_t per_query = 0;
+    for (uint32_t o = 0; o < n_oracles; o++) per_query += n_cols[o] * 8 + 1 + 32 * (size_t)(log_L - cap_h);
+    {
+        size_t nl = L;
+        for (uint32_t k = 0; k < R; k++) {
+            nl >>= p->arity_bits;
+            unsigned lg = gl_log2_strict(nl);
+            per_query += 16 * arity + 1 + 32 * (lg > cap_h ? lg - cap_h : 0);
+        }
+    }
+    size_t q_start = r->pos;
+    r->pos += per_query * p->n_queries;
+    size_t final_len = (size_t)1 << (p->degree_bits - R * p->arity_bits);
+    gl2* final_poly = (gl2*)malloc(sizeof(gl2) * final_len);
+    uint64_t pow_witness = 0;
+    r_u64s(r, (uint64_t*)final_poly, 2 * final_len);
+    r_u64s(r, &pow_witness, 1);
+    if (r->bad) { rc = -1; goto done; }
+    orc_ch_observe_many(ch, (uint64_t*)final_poly, 2 * final_len);
+    orc_ch_observe(ch, pow_witness);
+    {
+        uint64_t pow_response = orc_ch_challenge(ch);
+        if (p->pow_bits && (pow_response >> (64 - p->pow_bits)) != 0) { rc = -3; goto done; }
+    }
+    {
+        /* reduced openings per batch, and the shift exponents (number of polys of later batches) */
+        gl2* red = (gl2*)malloc(sizeof(gl2) * n_batches);
+        for (uint32_t b = 0; b < n_batches; b++) {
+            gl2 apow = gl2_from(1), acc = gl2_from(0);
+            for (uint32_t j = 0; j < batches[b].n_polys; j++) { acc = gl2_add(acc, gl2_mul(apow, opened[b][j])); apow = gl2_mul(apow, fri_alpha); }
+            red[b] = acc;
+        }
+        uint32_t max_cols = 0;
+        for (uint32_t o = 0; o < n_oracles; o++) if (n_cols[o] > max_cols) max_cols = n_cols[o];
+        uint64_t** rows = (uint64_t**)malloc(sizeof(uint64_t*) * n_oracles);
+        for (uint32_t o = 0; o < n_oracles; o++) rows[o] = (uint64_t*)malloc(8 * (n_cols[o] + 1));
+        rbuf qr = {r->p, r->len, q_start, 0};
+        for (uint32_t q = 0; q < p->n_queries && rc == 1; q++) {
+            size_t x_index = orc_ch_challenge(ch) % L;
+            for (uint32_t o = 0; o < n_oracles; o++) {
+                r_u64s(&qr, rows[o], n_cols[o]);
+                uint8_t plen = 0;
+                r_bytes(&qr, &plen, 1);
+                uint64_t sib[64 * 4];
+                if (plen != log_L - cap_h) { rc = -4; break; }
+                r_u64s(&qr, sib, 4 * plen);
+                if (!orc_merkle_verify(rows[o], n_cols[o], x_index, sib, plen, caps[o], cap_h)) { rc = -5; break; }
+            }
+            if (rc != 1) break;
+            uint64_t subgroup_x = gl_mul(GL_GEN, gl_pow(gl_root_of_unity(log_L), gl_bitrev(x_index, log_L)));
+            gl2 sx = gl2_from(subgroup_x);
+            /* fri_combine_initial */
+            gl2 sum = gl2_from(0);
+            for (uint32_t b = 0; b < n_batches; b++) {
+                gl2 apow = gl2_from(1), acc = gl2_from(0);
+                for (uint32_t j = 0; j < batches[b].n_polys; j++) {
+                    acc = gl2_add(acc, gl2_scale(apow, rows[batches[b].oracle[j]][batches[b].poly[j]]));
+                    apow = gl2_mul(apow, fri_alpha);
+                }
+                sum = gl2_mul(sum, apow); /* alpha.shift: times alpha^(count of this batch) */
+                sum = gl2_add(sum, gl2_mul(gl2_sub(acc, red[b]), gl2_inv(gl2_sub(sx, batches[b].point))));
+            }
+            gl2 old_eval = sum;
+            size_t nl = L;
+            for (uint32_t k = 0; k < R; k++) {
+                nl >>= p->arity_bits;
+                gl2 evals[64];
+                r_u64s(&qr, (uint64_t*)evals, 2 * arity);
+                uint8_t plen = 0;
+                r_bytes(&qr, &plen, 1);
+                uint64_t sib[64 * 4];
+                unsigned lg = gl_log2_strict(nl);
+                if (plen != (lg > cap_h ? lg - cap_h : 0)) { rc = -6; break; }
+                r_u64s(&qr, sib, 4 * plen);
+                size_t coset_index = x_index >> p->arity_bits;
+                size_t within = x_index & (arity - 1);
+                if (!gl2_eq(evals[within], old_eval)) { rc = -7; break; }
+                uint64_t gA = gl_root_of_unity(p->arity_bits);
+                size_t rev_within = gl_bitrev(within, p->arity_bits);
+                uint64_t coset_start = gl_mul(subgroup_x, gl_pow(gA, arity - rev_within));
+                gl2 res = gl2_from(0);
+                for (uint32_t i = 0; i < arity; i++) {
+                    gl2 yi = evals[gl_bitrev(i, p->arity_bits)];
+                    uint64_t pi_ = gl_mul(coset_start, gl_pow(gA, i));
+                    gl2 numr = gl2_from(1);
+                    uint64_t den = 1;
+                    for (uint32_t j = 0; j < arity; j++) {
+                        if (j == i) continue;
+                        uint64_t pj = gl_mul(coset_start, gl_pow(gA, j));
+                        numr = gl2_mul(numr, gl2_sub(fri_betas[k], gl2_from(pj)));
+                        den = gl_mul(den, gl_sub(pi_, pj));
+                    }
+                    res = gl2_add(res, gl2_mul(yi, gl2_scale(numr, gl_inv(den))));
+                }
+                old_eval = res;
+                if (!orc_merkle_verify((uint64_t*)evals, 2 * arity, coset_index, sib, plen, fri_caps + k * capw, cap_h)) { rc = -8; break; }
+                subgroup_x = gl_exp_pow2(subgroup_x, p->arity_bits);
+                x_index = coset_index;
+            }
+            if (rc != 1) break;
+            gl2 fe = gl2_from(0), sxe = gl2_from(subgroup_x);
+            for (size_t i = final_len; i-- > 0;) fe = gl2_add(gl2_mul(fe, sxe), final_poly[i]);
+            if (!gl2_eq(fe, old_eval)) rc = -9;
+        }
+        if (qr.bad) rc = -10;
+        for (uint32_t o = 0; o < n_oracles; o++) free(rows[o]);
+        free(rows);
+        free(red);
+    }
+done:
+    free(fri_caps);
+    free(final_poly);
+    return rc;
+}
+
+/* ---------------- AIR program interpreter (base field and extension field) ---------------- */
+#define AIR_OP(w) ((uint32_t)((w) & 0xFF))
+#define AIR_DST(w) ((uint32_t)(((w) >> 8) & 0xFFFF))
+#define AIR_A(w) ((uint32_t)(((w) >> 24) & 0xFFFF))
+#define AIR_B(w) ((uint32_t)(((w) >> 40) & 0xFFFF))
+#define AIR_REGS 64
+
+/* ConstraintConsumer over the base field: acc_j = acc_j * alpha_j + c */
+static void air_eval_base(const orc_stark_desc* d, const uint64_t* local, const uint64_t* next, const uint64_t* pis,
+                          uint64_t z_last, uint64_t l_first, uint64_t l_last, const uint64_t* alphas, uint64_t* accs) {
+    uint64_t reg[AIR_REGS] = {0};
+    for (uint32_t j = 0; j < d->num_challenges; j++) accs[j] = 0;
+    for (uint32_t pc = 0; pc < d->n_words; pc++) {
+        uint64_t w = d->program[pc];
+        uint32_t dst = AIR_DST(w) % AIR_REGS, a = AIR_A(w), b = AIR_B(w);
+        uint64_t c = 0;
+        int emit = 0;
+        switch (AIR_OP(w)) {
+            case ORC_AIR_LOCAL: reg[dst] = local[a]; break;
+            case ORC_AIR_NEXT: reg[dst] = next[a]; break;
+            case ORC_AIR_PUBLIC: reg[dst] = pis[a]; break;
+            case ORC_AIR_CONST: reg[dst] = d->program[++pc] % GL_P; break;
+            case ORC_AIR_ADD: reg[dst] = gl_add(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
+            case ORC_AIR_SUB: reg[dst] = gl_sub(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
+            case ORC_AIR_MUL: reg[dst] = gl_mul(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
+            case ORC_AIR_EMIT_TRANSITION: c = gl_mul(reg[a % AIR_REGS], z_last); emit = 1; break;
+            case ORC_AIR_EMIT_FIRST: c = gl_mul(reg[a % AIR_REGS], l_first); emit = 1; break;
+            case ORC_AIR_EMIT_LAST: c = gl_mul(reg[a % AIR_REGS], l_last); emit = 1; break;
+            case ORC_AIR_EMIT: c = reg[a % AIR_REGS]; emit = 1; break;
+            default: break;
+        }
+        if (emit)
+            for (uint32_t j = 0; j < d->num_challenges; j++) accs[j] = gl_add(gl_mul(accs[j], alphas[j]), c);
+    }
+}
+static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* next, const uint64_t* pis, gl2 z_last,
+                         gl2 l_first, gl2 l_last, const uint64_t* alphas, gl2* accs) {
+    gl2 reg[AIR_REGS];
+    for (int i = 0; i < AIR_REGS; i++) reg[i] = gl2_from(0);
+    for (uint32_t j = 0; j < d->num_challenges; j++) accs[j] = gl2_from(0);
+    for (uint32_t pc = 0; pc < d->n_words; pc++) {
+        uint64_t w = d->program[pc];
+        uint32_t dst = AIR_DST(w) % AIR_REGS, a = AIR_A(w), b = AIR_B(w);
+        gl2 c = gl2_from(0);
+        int emit = 0;
+        switch (AIR_OP(w)) {
+            case ORC_AIR_LOCAL: reg[dst] = local[a]; break;
+            case ORC_AIR_NEXT: reg[dst] = next[a]; break;
+            case ORC_AIR_PUBLIC: reg[dst] = gl2_from(pis[a]); break;
+            case ORC_AIR_CONST: reg[dst] = gl2_from(d->program[++pc] % GL_P); break;
+            case ORC_AIR_ADD: reg[dst] = gl2_add(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
+            case ORC_AIR_SUB: reg[dst] = gl2_sub(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
+            case ORC_AIR_MUL: reg[dst] = gl2_mul(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
+            case ORC_AIR_EMIT_TRANSITION: c = gl2_mul(reg[a % AIR_REGS], z_last); emit = 1; break;
+            case ORC_AIR_EMIT_FIRST: c = gl2_mul(reg[a % AIR_REGS], l_first); emit = 1; break;
+            case ORC_AIR_EMIT_LAST: c = gl2_mul(reg[a % AIR_REGS], l_last); emit = 1; break;
+            case ORC_AIR_EMIT: c = reg[a % AIR_REGS]; emit = 1; break;
+            default: break;
+        }
+        if (emit)
+            for (uint32_t j = 0; j < d->num_challenges; j++) accs[j] = gl2_add(gl2_scale(accs[j], alphas[j]), c);
+    }
+}
+
+static int desc_ok(const orc_stark_desc* d) {
+    uint32_t q = d->quotient_degree_factor;
+    if (!q || (q & (q - 1)) || q > (1u << d->rate_bits)) return 0;
+    if (d->num_challenges < 1 || d->num_challenges > 2 || d->n_cols == 0) return 0;
+    for (uint32_t pc = 0; pc < d->n_words; pc++) {
+        uint64_t w = d->program[pc];
+        switch (AIR_OP(w)) {
+            case ORC_AIR_LOCAL: case ORC_AIR_NEXT: if (AIR_A(w) >= d->n_cols) return 0; break;
+            case ORC_AIR_PUBLIC: if (AIR_A(w) >= d->num_public_inputs) return 0; break;
+            case ORC_AIR_CONST: if (++pc >= d->n_words) return 0; break;
+            default: if (AIR_OP(w) > ORC_AIR_EMIT) return 0;
+        }
+    }
+    return 1;
+}
+
+size_t orc_stark_proof_max_bytes(const orc_stark_desc* d) {
+    const size_t capb = (size_t)32 << d->cap_height;
+    const unsigned log_L = d->degree_bits + d->rate_bits;
+    const uint32_t nq = d->num_challenges * d->quotient_degree_factor;
+    orc_fri_params fp = {d->degree_bits, d->rate_bits, d->cap_height, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits};
+    uint32_t R = fri_num_rounds(&fp);
+    size_t bytes = 2 * capb + 16 * (size_t)(2 * d->n_cols + nq) + R * capb;
+    size_t per_query = (d->n_cols + nq) * 8 + 2 * (1 + 32 * (size_t)log_L) + R * (((size_t)16 << d->fri_arity_bits) + 1 + 32 * (size_t)log_L);
+    bytes += per_query * d->fri_num_queries + ((size_t)16 << d->degree_bits) + 8 + 4 + 8 * (size_t)d->num_public_inputs;
+    return bytes + 64;
+}
+
+size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uint64_t* public_inputs,
+                       uint8_t* proof_out, size_t cap_bytes) {
+    if (!desc_ok(d)) return 0;
+    const unsigned log_n = d->degree_bits, log_L = log_n + d->rate_bits, cap_h = d->cap_height;
+    const size_t n = (size_t)1 << log_n, L = (size_t)1 << log_L;
+    const uint32_t nc = d->num_challenges, qdf = d->quotient_degree_factor, ncols = d->n_cols, nq = nc * qdf;
+    const unsigned qdb = gl_log2_strict(qdf);
+    wbuf w = {proof_out, 0, cap_bytes, 0};
+    /* trace commitment */
+    uint64_t* t_coeffs = (uint64_t*)malloc(8 * n * ncols);
+    uint64_t* t_leaves = (uint64_t*)malloc(8 * L * ncols);
+    uint64_t* t_dig = (uint64_t*)malloc(8 * orc_merkle_digest_words(L, cap_h));
+    uint64_t t_cap[4 * 64];
+    orc_commit_from_values(trace, ncols, log_n, d->rate_bits, cap_h, t_coeffs, t_leaves, t_dig, t_cap);
+    orc_challenger ch;
+    orc_ch_init(&ch);
+    observe_cap(&ch, t_cap, cap_h);
+    uint64_t alphas[4];
+    for (uint32_t j = 0; j < nc; j++) alphas[j] = orc_ch_challenge(&ch);
+    /* compute_quotient_polys on the coset of size n << qdb (LDE index step = 2^(rate_bits - qdb)) */
+    const size_t size = n << qdb, step = (size_t)1 << (d->rate_bits - qdb), next_step = (size_t)1 << qdb;
+    const unsigned log_size = log_n + qdb;
+    uint64_t* qvals = (uint64_t*)malloc(8 * size * nc);
+    {
+        const uint64_t g = gl_root_of_unity(log_n), last = gl_inv(g);
+        const uint64_t w_s = gl_root_of_unity(log_size);
+        const uint64_t n_f = (uint64_t)n % GL_P;
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < size; i++) {
+            uint64_t x = gl_mul(GL_GEN, gl_pow(w_s, i));
+            uint64_t zh = gl_sub(gl_exp_pow2(x, log_n), 1);
+            uint64_t l_first = gl_mul(zh, gl_inv(gl_mul(n_f, gl_sub(x, 1))));
+            uint64_t l_last = gl_mul(zh, gl_inv(gl_mul(n_f, gl_sub(gl_mul(g, x), 1))));
+            size_t li = gl_bitrev(i * step, log_L), ln = gl_bitrev(((i + next_step) % size) * step, log_L);
+            uint64_t accs[4];
+            air_eval_base(d, t_leaves + li * ncols, t_leaves + ln * ncols, public_inputs, gl_sub(x, last), l_first, l_last, alphas, accs);
+            uint64_t zh_inv = gl_inv(zh);
+            for (uint32_t j = 0; j < nc; j++) qvals[(size_t)j * size + i] = gl_mul(accs[j], zh_inv);
+        }
+    }
+    uint64_t* q_coeffs = (uint64_t*)malloc(8 * n * nq);
+    for (uint32_t j = 0; j < nc; j++) {
+        orc_coset_ifft(qvals + (size_t)j * size, log_size, GL_GEN);
+        memcpy(q_coeffs + (size_t)j * qdf * n, qvals + (size_t)j * size, 8 * n * qdf); /* trim_to_len(n * qdf), chunks(n) */
+    }
+    free(qvals);
+    uint64_t* q_leaves = (uint64_t*)malloc(8 * L * nq);
+    uint64_t* q_dig = (uint64_t*)malloc(8 * orc_merkle_digest_words(L, cap_h));
+    uint64_t q_cap[4 * 64];
+    orc_commit_from_coeffs(q_coeffs, nq, log_n, d->rate_bits, cap_h, q_leaves, q_dig, q_cap);
+    observe_cap(&ch, q_cap, cap_h);
+    gl2 zeta = orc_ch_ext_challenge(&ch);
+    gl2 g_zeta = gl2_scale(zeta, gl_root_of_unity(log_n));
+    /* StarkOpeningSet */
+    gl2* o_local = (gl2*)malloc(sizeof(gl2) * (2 * ncols + nq));
+    gl2* o_next = o_local + ncols;
+    gl2* o_q = o_next + ncols;
+#pragma omp parallel for schedule(dynamic)
+    for (uint32_t c = 0; c < ncols; c++) {
+        o_local[c] = eval_base_poly_ext(t_coeffs + (size_t)c * n, n, zeta);
+        o_next[c] = eval_base_poly_ext(t_coeffs + (size_t)c * n, n, g_zeta);
+    }
+    for (uint32_t c = 0; c < nq; c++) o_q[c] = eval_base_poly_ext(q_coeffs + (size_t)c * n, n, zeta);
+    w_u64s(&w, t_cap, (size_t)4 << cap_h);
+    w_u64s(&w, q_cap, (size_t)4 << cap_h);
+    w_u64s(&w, (uint64_t*)o_local, 2 * ncols);
+    w_u64s(&w, (uint64_t*)o_next, 2 * ncols);
+    w_u64s(&w, (uint64_t*)o_q, 2 * nq);
+    /* observe_openings: zeta batch (local ++ quotient), then zeta_next batch (next) */
+    orc_ch_observe_many(&ch, (uint64_t*)o_local, 2 * ncols);
+    orc_ch_observe_many(&ch, (uint64_t*)o_q, 2 * nq);
+    orc_ch_observe_many(&ch, (uint64_t*)o_next, 2 * ncols);
+    /* fri_instance: batch 0 at zeta = trace ++ quotient, batch 1 at g*zeta = trace */
+    orc_fri_oracle oracles[2] = {{t_coeffs, t_leaves, t_dig, t_cap, ncols}, {q_coeffs, q_leaves, q_dig, q_cap, nq}};
+    uint32_t* idx_o = (uint32_t*)malloc(4 * 2 * (ncols + nq));
+    uint32_t* idx_p = idx_o + ncols + nq;
+    for (uint32_t c = 0; c < ncols; c++) { idx_o[c] = 0; idx_p[c] = c; }
+    for (uint32_t c = 0; c < nq; c++) { idx_o[ncols + c] = 1; idx_p[ncols + c] = c; }
+    orc_fri_batch batches[2] = {{zeta, ncols + nq, idx_o, idx_p}, {g_zeta, ncols, idx_o, idx_p}};
+    orc_fri_params fp = {d->degree_bits, d->rate_bits, cap_h, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits};
+    fri_prove(&fp, oracles, 2, batches, 2, &ch, &w);
+    w_u32(&w, d->num_public_inputs);
+    w_u64s(&w, public_inputs, d->num_public_inputs);
+    free(idx_o); free(o_local); free(t_coeffs); free(t_leaves); free(t_dig); free(q_coeffs); free(q_leaves); free(q_dig);
+    return w.overflow ? 0 : w.len;
+}
+
+int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) {
+    if (!desc_ok(d)) return -20;
+    const unsigned log_n = d->degree_bits, cap_h = d->cap_height;
+    const size_t n = (size_t)1 << log_n, capw = (size_t)4 << cap_h;
+    const uint32_t nc = d->num_challenges, qdf = d->quotient_degree_factor, ncols = d->n_cols, nq = nc * qdf;
+    rbuf r = {proof, len, 0, 0};
+    int rc = 1;
+    uint64_t* caps = (uint64_t*)malloc(8 * 2 * capw);
+    r_u64s(&r, caps, 2 * capw);
+    gl2* o_local = (gl2*)malloc(sizeof(gl2) * (2 * ncols + nq));
+    gl2* o_next = o_local + ncols;
+    gl2* o_q = o_next + ncols;
+    r_u64s(&r, (uint64_t*)o_local, 2 * (2 * ncols + nq));
+    /* public inputs are at the very end */
+    uint64_t* pis = (uint64_t*)malloc(8 * (d->num_public_inputs + 1));
+    if (len < 4 + 8 * (size_t)d->num_public_inputs) { rc = -1; goto done; }
+    {
+        size_t tail = len - 4 - 8 * (size_t)d->num_public_inputs;
+        uint32_t n_pi;
+        memcpy(&n_pi, proof + tail, 4);
+        if (n_pi != d->num_public_inputs) { rc = -1; goto done; }
+        memcpy(pis, proof + tail + 4, 8 * (size_t)n_pi);
+        for (uint32_t i = 0; i < n_pi; i++) if (pis[i] >= GL_P) { rc = -1; goto done; }
+        r.len = tail; /* the FRI reader must consume exactly up to here */
+    }
+    if (r.bad) { rc = -1; goto done; }
+    {
+        orc_challenger ch;
+        orc_ch_init(&ch);
+        orc_ch_observe_many(&ch, caps, capw);
+        uint64_t alphas[4];
+        for (uint32_t j = 0; j < nc; j++) alphas[j] = orc_ch_challenge(&ch);
+        orc_ch_observe_many(&ch, caps + capw, capw);
+        gl2 zeta = orc_ch_ext_challenge(&ch);
+        orc_ch_observe_many(&ch, (uint64_t*)o_local, 2 * ncols);
+        orc_ch_observe_many(&ch, (uint64_t*)o_q, 2 * nq);
+        orc_ch_observe_many(&ch, (uint64_t*)o_next, 2 * ncols);
+        /* vanishing polynomial identity at zeta */
+        const uint64_t g = gl_root_of_unity(log_n), last = gl_inv(g);
+        gl2 zeta_n = zeta;
+        for (unsigned i = 0; i < log_n; i++) zeta_n = gl2_mul(zeta_n, zeta_n);
+        gl2 z_h = gl2_sub(zeta_n, gl2_from(1));
+        gl2 l_first = gl2_mul(z_h, gl2_inv(gl2_scale(gl2_sub(zeta, gl2_from(1)), (uint64_t)n % GL_P)));
+        gl2 l_last = gl2_mul(z_h, gl2_inv(gl2_scale(gl2_sub(gl2_scale(zeta, g), gl2_from(1)), (uint64_t)n % GL_P)));
+        gl2 accs[4];
+        air_eval_ext(d, o_local, o_next, pis, gl2_sub(zeta, gl2_from(last)), l_first, l_last, alphas, accs);
+        for (uint32_t j = 0; j < nc && rc == 1; j++) {
+            gl2 t = gl2_from(0);
+            for (uint32_t k = qdf; k-- > 0;) t = gl2_add(gl2_mul(t, zeta_n), o_q[j * qdf + k]);
+            if (!gl2_eq(accs[j], gl2_mul(z_h, t))) rc = -2;
+        }
+        if (rc != 1) goto done;
+        gl2 g_zeta = gl2_scale(zeta, g);
+        uint32_t* idx_o = (uint32_t*)malloc(4 * 2 * (ncols + nq));
+        uint32_t* idx_p = idx_o + ncols + nq;
+        for (uint32_t c = 0; c < ncols; c++) { idx_o[c] = 0; idx_p[c] = c; }
+        for (uint32_t c = 0; c < nq; c++) { idx_o[ncols + c] = 1; idx_p[ncols + c] = c; }
+        orc_fri_batch batches[2] = {{zeta, ncols + nq, idx_o, idx_p}, {g_zeta, ncols, idx_o, idx_p}};
+        gl2* open0 = (gl2*)malloc(sizeof(gl2) * (ncols + nq));
+        memcpy(open0, o_local, sizeof(gl2) * ncols);
+        memcpy(open0 + ncols, o_q, sizeof(gl2) * nq);
+        const gl2* opened[2] = {open0, o_next};
+        const uint64_t* cap_ptrs[2] = {caps, caps + capw};
+        uint32_t n_cols[2] = {ncols, nq};
+        orc_fri_params fp = {d->degree_bits, d->rate_bits, cap_h, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits};
+        rc = fri_verify(&fp, cap_ptrs, n_cols, 2, batches, 2, opened, &ch, &r);
+        if (rc == 1 && r.pos != r.len) rc = -11;
+        free(open0);
+        free(idx_o);
+    }
+done:
+    free(caps); free(o_local); free(pis);
+    return rc;
+}

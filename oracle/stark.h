@@ -1,0 +1,81 @@
+/* ORACLE - TEST INFRASTRUCTURE ONLY (see gl.h header).
+ *
+ * CPU restatement of the starky STARK prover / verifier (plonky2's `starky` crate: prover::prove,
+ * compute_quotient_polys, constraint_consumer::ConstraintConsumer, proof::StarkOpeningSet,
+ * stark::Stark::fri_instance, verifier::verify_stark_proof, config::StarkConfig::standard_fast_config)
+ * - the public ancestor of the reference's un-vendored `starkyx` / curta prover (Cargo.lock:6515-6517,
+ * SURVEY.md §8a row a12), whose own source and AIRs (SHA-256, Ed25519) are absent.  The AIR is DATA here:
+ * a small register program interpreted identically by this oracle (base field and extension field)
+ * and by the HIP kernel, so any AIR can be plugged in without touching the prover.
+ *
+ * Parity status: "parity unpinned" - no STARK proof bytes exist in the reference; internal consistency
+ * (this verifier accepts this prover, rejects tampering) is the pin.
+ */
+#ifndef NLX_ORACLE_STARK_H
+#define NLX_ORACLE_STARK_H
+#include "oracle.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- generic FRI over a list of committed batches (plonky2::fri::{oracle::prove_openings, prover, verifier}) ---- */
+typedef struct {
+    const uint64_t* coeffs;  /* n_cols x n column-major */
+    const uint64_t* leaves;  /* L x n_cols, plonky2 leaf order */
+    const uint64_t* digests; /* level-major */
+    const uint64_t* cap;
+    uint32_t n_cols;
+} orc_fri_oracle;
+typedef struct {
+    gl2 point;
+    uint32_t n_polys;
+    const uint32_t* oracle; /* oracle index of each polynomial */
+    const uint32_t* poly;   /* column inside that oracle */
+} orc_fri_batch;
+typedef struct {
+    uint32_t degree_bits, rate_bits, cap_height, pow_bits, n_queries, arity_bits, final_poly_bits;
+} orc_fri_params;
+
+/* AIR program: 64-bit words, op | dst << 8 | a << 24 | b << 40 (16-bit fields); OP_CONST is followed by
+ * one immediate word.  Registers r0..r63.  Same numbering as include/nlx.h (NLX_AIR_*). */
+enum {
+    ORC_AIR_LOCAL = 0,      /* dst = local_values[a] */
+    ORC_AIR_NEXT = 1,       /* dst = next_values[a] */
+    ORC_AIR_PUBLIC = 2,     /* dst = public_inputs[a] */
+    ORC_AIR_CONST = 3,      /* dst = immediate */
+    ORC_AIR_ADD = 4,
+    ORC_AIR_SUB = 5,
+    ORC_AIR_MUL = 6,
+    ORC_AIR_EMIT_TRANSITION = 7, /* constraint_transition(r[a]) : times (x - g^-1) */
+    ORC_AIR_EMIT_FIRST = 8,      /* constraint_first_row(r[a]) : times L_0(x) */
+    ORC_AIR_EMIT_LAST = 9,       /* constraint_last_row(r[a])  : times L_{n-1}(x) */
+    ORC_AIR_EMIT = 10            /* constraint(r[a]) on every row */
+};
+
+typedef struct {
+    uint32_t degree_bits;
+    uint32_t n_cols;
+    uint32_t num_challenges;          /* 2 */
+    uint32_t rate_bits;               /* 1 */
+    uint32_t cap_height;              /* 4 */
+    uint32_t quotient_degree_factor;  /* power of two <= 2^rate_bits (max(1, constraint_degree - 1) rounded up) */
+    uint32_t fri_pow_bits;            /* 16 */
+    uint32_t fri_num_queries;         /* 84 */
+    uint32_t fri_arity_bits;          /* 4 */
+    uint32_t fri_final_poly_bits;     /* 5 */
+    uint32_t num_public_inputs;
+    uint32_t n_words;                 /* program length in words */
+    const uint64_t* program;
+} orc_stark_desc;
+
+size_t orc_stark_proof_max_bytes(const orc_stark_desc* d);
+/* trace: n_cols x n column-major.  Returns bytes written (0 on overflow). */
+size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uint64_t* public_inputs,
+                       uint8_t* proof_out, size_t cap_bytes);
+int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
