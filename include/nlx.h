@@ -241,6 +241,58 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
  * job's public inputs are its children's digests. */
 int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint64_t* public_inputs, uint32_t count);
 
+/* ---- a12: starky-style STARK prover ----
+ * Replaces starky::prover::prove / compute_quotient_polys / StarkOpeningSet::new / Stark::fri_instance -
+ * the public ancestor of the un-vendored starkyx (curta) prover that plonky2x runs for nearx's
+ * curta_eddsa_verify / curta_sha256 calls (nearx/src/builder.rs; Cargo.lock:6515).  The AIR is data: a
+ * register program replacing Stark::eval_packed_generic + ConstraintConsumer, interpreted per point of
+ * the quotient coset.  Words are op | dst << 8 | a << 24 | b << 40 (16-bit fields); NLX_AIR_CONST is
+ * followed by one immediate word.  Registers r0 .. r63; a register must be written before it is read.
+ * Each EMIT feeds every challenge's accumulator: acc_j = acc_j * alpha_j + c. */
+#define NLX_AIR_LOCAL 0            /* r[dst] = local_values[a] */
+#define NLX_AIR_NEXT 1             /* r[dst] = next_values[a] */
+#define NLX_AIR_PUBLIC 2           /* r[dst] = public_inputs[a] */
+#define NLX_AIR_CONST 3            /* r[dst] = immediate (next word) */
+#define NLX_AIR_ADD 4              /* r[dst] = r[a] + r[b] */
+#define NLX_AIR_SUB 5
+#define NLX_AIR_MUL 6
+#define NLX_AIR_EMIT_TRANSITION 7  /* ConstraintConsumer::constraint_transition(r[a]): times (x - g^-1) */
+#define NLX_AIR_EMIT_FIRST 8       /* constraint_first_row(r[a]): times L_0(x) */
+#define NLX_AIR_EMIT_LAST 9        /* constraint_last_row(r[a]): times L_{n-1}(x) */
+#define NLX_AIR_EMIT 10            /* constraint(r[a]) on every row */
+#define NLX_AIR_NUM_REGS 64
+
+typedef struct {
+    uint32_t degree_bits;
+    uint32_t n_cols;                  /* Stark::COLUMNS */
+    uint32_t num_challenges;          /* StarkConfig::standard_fast_config: 2 */
+    uint32_t rate_bits;               /* 1 */
+    uint32_t cap_height;              /* 4 */
+    uint32_t quotient_degree_factor;  /* Stark::quotient_degree_factor() rounded up to a power of two, <= 2^rate_bits */
+    uint32_t fri_pow_bits;            /* 16 */
+    uint32_t fri_num_queries;         /* 84 */
+    uint32_t fri_arity_bits;          /* 4 */
+    uint32_t fri_final_poly_bits;     /* 5 */
+    uint32_t num_public_inputs;       /* Stark::PUBLIC_INPUTS */
+    uint32_t n_words;
+    const uint64_t* program;          /* host */
+} nlx_stark_desc;
+typedef struct nlx_stark nlx_stark;
+
+/* Validates the program and keeps it and the coset tables resident on the device. */
+int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** out);
+void nlx_stark_destroy(nlx_stark* s);
+size_t nlx_stark_proof_max_bytes(const nlx_stark* s);
+/* starky::prover::prove + StarkProofWithPublicInputs serialisation (wire format in DESIGN.md):
+ * trace: n_cols x n column-major (host or device), every value canonical. */
+int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* public_inputs, uint8_t* proof_out,
+                        size_t proof_cap, size_t* proof_len);
+int32_t nlx_stark_stage_times(const nlx_stark* s, uint32_t* n_stages, const char** names_out, float* ms_out);
+/* Synthetic wide-AIR witness (inputs only): n_cols (multiple of 4) x n column-major host buffer, k1 = the
+ * n_cols/4 per-group constants of the AIR, public_inputs[2] = first-row values of columns 0 and 1. */
+int32_t nlx_synth_stark_trace(uint32_t n_cols, uint32_t log_n, uint64_t seed, const uint64_t* k1, uint64_t* trace,
+                              uint64_t* public_inputs);
+
 #ifdef __cplusplus
 }
 #endif

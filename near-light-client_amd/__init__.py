@@ -10,3 +10,4 @@ from . import _lib as lib  # noqa: F401  (raises loudly when the HIP extension i
 from ._lib import Context, NlxError, GOLDILOCKS_P  # noqa: F401
 from .batch import PolynomialBatch, MerkleTree, poseidon_permute, hash_rows, ntt, field_ops  # noqa: F401
 from .plonk import CircuitConfig, CircuitData, SyntheticCircuit, pow_grind, batch_prove, ProveJob  # noqa: F401
+from .stark import Air, Stark, StarkConfig, StarkProver, fibonacci_air, fibonacci_trace, wide_air, wide_trace  # noqa: F401

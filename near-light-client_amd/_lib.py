@@ -72,6 +72,15 @@ SIGNATURES = {
                                                ctypes.c_void_p]),
     "nlx_pow_grind": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                        ctypes.POINTER(ctypes.c_uint64)]),
+    "nlx_stark_build": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, c_void_pp]),
+    "nlx_stark_destroy": (None, [ctypes.c_void_p]),
+    "nlx_stark_proof_max_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "nlx_stark_prove": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.POINTER(ctypes.c_size_t)]),
+    "nlx_stark_stage_times": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p,
+                                               ctypes.c_void_p]),
+    "nlx_synth_stark_trace": (ctypes.c_int32, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_synth_shape": (None, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     "nlx_synth_circuit": (ctypes.c_int32, [ctypes.c_void_p] * 7),
     "nlx_synth_set_public_inputs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]),

@@ -19,77 +19,15 @@
 #include "poly.hpp"
 #include "poseidon.hpp"
 #include "prover.hpp"
+#include "fri.hpp"
+#include "transcript.hpp"
 
 using namespace nlx;
 
 namespace {
-
-// plonky2::iop::challenger::Challenger (host)
-struct Challenger {
-    uint64_t state[12] = {0};
-    uint64_t in_buf[8];
-    unsigned n_in = 0;
-    uint64_t out_buf[8];
-    unsigned n_out = 0;
-    void duplex() {
-        for (unsigned i = 0; i < n_in; i++) state[i] = in_buf[i];
-        n_in = 0;
-        poseidon::permute(state);
-        for (int i = 0; i < 8; i++) out_buf[i] = state[i];
-        n_out = 8;
-    }
-    void observe(uint64_t e) {
-        n_out = 0;
-        in_buf[n_in++] = e;
-        if (n_in == 8) duplex();
-    }
-    void observe(const uint64_t* e, size_t n) {
-        for (size_t i = 0; i < n; i++) observe(e[i]);
-    }
-    uint64_t challenge() {
-        if (n_in != 0 || n_out == 0) duplex();
-        return out_buf[--n_out];
-    }
-    void ext_challenge(uint64_t out[2]) {
-        out[0] = challenge();
-        out[1] = challenge();
-    }
-};
-
-void hash_no_pad_host(const uint64_t* in, size_t len, uint64_t out[4]) {
-    uint64_t st[12] = {0};
-    for (size_t off = 0; off < len; off += 8) {
-        size_t k = len - off < 8 ? len - off : 8;
-        for (size_t j = 0; j < k; j++) st[j] = in[off + j];
-        poseidon::permute(st);
-    }
-    memcpy(out, st, 32);
-}
-
-struct Writer {
-    uint8_t* p;
-    size_t len = 0, cap;
-    bool overflow = false;
-    void bytes(const void* src, size_t n) {
-        if (len + n > cap) { overflow = true; return; }
-        memcpy(p + len, src, n);
-        len += n;
-    }
-    void u64s(const uint64_t* v, size_t n) { bytes(v, n * 8); }
-    void u8(uint8_t v) { bytes(&v, 1); }
-    void u32(uint32_t v) { bytes(&v, 4); }
-};
-
 uint32_t fri_num_rounds(const nlx_circuit_desc& d) {
-    uint32_t degree_bits = d.degree_bits, r = 0;
-    while (degree_bits > d.fri_final_poly_bits && degree_bits + d.rate_bits >= d.cap_height + d.fri_arity_bits) {
-        if (degree_bits < d.fri_arity_bits) break;
-        degree_bits -= d.fri_arity_bits;
-        r++;
-    }
-    return r;
+    return nlx::fri_num_rounds(d.degree_bits, d.rate_bits, d.cap_height, d.fri_arity_bits, d.fri_final_poly_bits);
 }
-
 }  // namespace
 
 struct nlx_circuit {
@@ -115,27 +53,6 @@ struct nlx_circuit {
     size_t n() const { return (size_t)1 << d.degree_bits; }
     size_t L() const { return (size_t)1 << (d.degree_bits + d.rate_bits); }
 };
-
-static int32_t ensure_pinned(nlx_ctx* ctx, size_t bytes) {
-    if (ctx->pinned_bytes >= bytes) return NLX_OK;
-    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    ctx->pinned = nullptr;
-    ctx->pinned_bytes = 0;
-    hipError_t e = hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault);
-    if (e != hipSuccess) return ctx->hip_fail(e, "hipHostMalloc");
-    ctx->pinned_bytes = bytes;
-    return NLX_OK;
-}
-
-// device -> host through the pinned staging buffer, synchronous
-static int32_t fetch(nlx_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
-    int32_t rc = ensure_pinned(ctx, bytes < (1u << 20) ? (1u << 20) : bytes);
-    if (rc) return rc;
-    NLX_HIP(ctx, hipMemcpyAsync(ctx->pinned, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(host_dst, ctx->pinned, bytes);
-    return NLX_OK;
-}
 
 extern "C" {
 
@@ -369,7 +286,7 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
     const size_t n = c->n(), L = c->L();
     const unsigned log_n = d.degree_bits, log_L = log_n + d.rate_bits, cap_h = d.cap_height;
     const uint32_t nc = d.num_challenges, npp = d.num_partial_products, routed = d.num_routed_wires;
-    const uint32_t arity = 1u << d.fri_arity_bits, NR = c->n_fri_rounds;
+    const uint32_t NR = c->n_fri_rounds;
     const size_t capw = (size_t)4 << cap_h;
     int32_t rc = NLX_OK;
 
@@ -528,155 +445,21 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
         }
 
         // ---- 7. FRI ----
-        stage("fri_combine");
-        uint64_t fri_alpha[2];
-        ch.ext_challenge(fri_alpha);
-        uint64_t* d_fri_alpha_pows = dalloc((size_t)n_open * 16);
-        uint64_t* d_fri_a = dalloc(L * 16);
-        uint64_t* d_fri_b = dalloc((L >> d.fri_arity_bits) * 16 + 256);
-        CHECK_ALLOC(d_fri_alpha_pows && d_fri_a && d_fri_b);
-        launch_ext_pow_table(st, d_fri_alpha_pows, fri_alpha, n_open);
         {
-            // reduced openings C0 = sum alpha^i open_i (zeta batch), C1 = sum alpha^i zs_next_i
-            const gl::Ext al{fri_alpha[0], fri_alpha[1]};
-            gl::Ext c0{0, 0}, c1{0, 0}, ap{1, 0};
-            for (uint32_t i = 0; i < n_open; i++) {
-                c0 = gl::add(c0, gl::mul(ap, gl::Ext{open[2 * i], open[2 * i + 1]}));
-                ap = gl::mul(ap, al);
-            }
-            ap = gl::Ext{1, 0};
-            for (uint32_t i = 0; i < nc; i++) {
-                c1 = gl::add(c1, gl::mul(ap, gl::Ext{open[2 * (size_t)(n_open + i)], open[2 * (size_t)(n_open + i) + 1]}));
-                ap = gl::mul(ap, al);
-            }
-            FriCombineParams fp{};
-            for (int o = 0; o < 4; o++) { fp.tables[o] = oracles[o]->lde; fp.n_cols[o] = oracles[o]->n_cols; }
-            fp.alpha_pows = d_fri_alpha_pows;
-            fp.coset_base = c->d_coset_base;
-            fp.w_n_table = ctx->tables.fwd[log_n];
-            fp.zeta[0] = zeta[0]; fp.zeta[1] = zeta[1]; fp.gzeta[0] = gzeta[0]; fp.gzeta[1] = gzeta[1];
-            fp.c0[0] = c0.a; fp.c0[1] = c0.b; fp.c1[0] = c1.a; fp.c1[1] = c1.b;
-            fp.alpha_nz[0] = ap.a; fp.alpha_nz[1] = ap.b;  // alpha^nc
-            fp.out = d_fri_a;
-            fp.log_n = log_n; fp.rate_bits = d.rate_bits; fp.nz = nc;
-            ctx->begin_kernel("fri_combine", 8.0 * L * n_open + 16.0 * L);
-            launch_fri_combine(st, fp);
-            ctx->end_kernel();
+            FriProveArgs fa;
+            for (int o = 0; o < 4; o++) fa.oracles[o] = oracles[o];
+            fa.n_oracles = 4;
+            fa.next_table = 2;  // plonk_zs_next: the first nc columns of the Zs / partial-products oracle
+            fa.nz = nc;
+            for (int i = 0; i < 2; i++) { fa.zeta[i] = zeta[i]; fa.gzeta[i] = gzeta[i]; }
+            fa.open0 = open.data();
+            fa.open1 = open.data() + 2 * (size_t)n_open;
+            fa.log_n = log_n; fa.rate_bits = d.rate_bits; fa.cap_height = cap_h; fa.arity_bits = d.fri_arity_bits;
+            fa.pow_bits = d.fri_pow_bits; fa.n_queries = d.fri_num_queries; fa.n_rounds = NR;
+            fa.d_coset_base = c->d_coset_base;
+            fa.d_wA_inv = c->d_wA_inv;
+            CHECK(fri_prove(ctx, fa, ch, w, scratch, stage));
         }
-        // commit phase: layer values ping-pong between d_fri_a / d_fri_b; digests kept per layer
-        stage("fri_commit_phase");
-        std::vector<uint64_t*> layer_values(NR + 1), layer_digests(NR);
-        std::vector<unsigned> layer_log_n(NR + 1);
-        layer_values[0] = d_fri_a;
-        layer_log_n[0] = log_n;
-        uint64_t shift = gl::GEN;
-        for (uint32_t r = 0; r < NR; r++) {
-            const unsigned ln = layer_log_n[r];
-            const size_t n_leaves = (size_t)1 << (ln - d.fri_arity_bits + d.rate_bits);
-            uint64_t* dg = dalloc(merkle_digest_words(n_leaves, cap_h) * 8);
-            CHECK_ALLOC(dg);
-            layer_digests[r] = dg;
-            if (n_leaves <= ((size_t)1 << 13)) launch_fri_leaves_wide(st, layer_values[r], ln, d.rate_bits, d.fri_arity_bits, dg);
-            else launch_fri_leaves(st, layer_values[r], ln, d.rate_bits, d.fri_arity_bits, dg);
-            const uint64_t* d_cap = launch_merkle_levels(st, dg, n_leaves, cap_h);
-            CHECK(fetch(ctx, cap.data(), d_cap, capw * 8));
-            w.u64s(cap.data(), capw);
-            ch.observe(cap.data(), capw);
-            uint64_t beta[2];
-            ch.ext_challenge(beta);
-            uint64_t* nxt = (r == 0) ? d_fri_b : dalloc(((size_t)16 << (ln - d.fri_arity_bits + d.rate_bits)) + 256);
-            CHECK_ALLOC(nxt);
-            launch_fri_fold(st, layer_values[r], nxt, ln, d.rate_bits, d.fri_arity_bits, beta, gl::inv(shift),
-                            ctx->tables.inv[ln + d.rate_bits], c->d_wA_inv);
-            layer_values[r + 1] = nxt;
-            layer_log_n[r + 1] = ln - d.fri_arity_bits;
-            shift = gl::exp_pow2(shift, d.fri_arity_bits);
-        }
-        // final polynomial
-        const uint32_t final_len = 1u << layer_log_n[NR];
-        uint64_t* d_final = dalloc((size_t)final_len * 16 + 256);
-        CHECK_ALLOC(d_final);
-        launch_fri_final_coeffs(st, layer_values[NR], layer_log_n[NR], d.rate_bits, shift, d_final, final_len);
-        std::vector<uint64_t> final_poly((size_t)final_len * 2);
-        CHECK(fetch(ctx, final_poly.data(), d_final, final_poly.size() * 8));
-        ch.observe(final_poly.data(), final_poly.size());
-
-        // proof of work
-        stage("fri_pow");
-        uint64_t pow_witness = 0;
-        {
-            PowParams pp{};
-            for (int i = 0; i < 12; i++) pp.state[i] = ch.state[i];
-            for (unsigned i = 0; i < ch.n_in; i++) pp.state[i] = ch.in_buf[i];
-            pp.pos = ch.n_in;
-            pp.bits = d.fri_pow_bits;
-            pp.max_rounds = (uint64_t)1 << 24;
-            unsigned long long* d_best = (unsigned long long*)dalloc(256);
-            CHECK_ALLOC(d_best);
-            launch_pow_grind(st, pp, d_best);
-            CHECK(fetch(ctx, &pow_witness, d_best, 8));
-            if (pow_witness == ~0ull) { rc = ctx->fail(NLX_E_RANGE, "proof of work: no witness found"); goto done; }
-            ch.observe(pow_witness);
-            (void)ch.challenge();
-        }
-        // query phase
-        stage("fri_queries");
-        const uint32_t NQ = d.fri_num_queries;
-        std::vector<uint64_t> qidx(NQ);
-        for (uint32_t q = 0; q < NQ; q++) qidx[q] = ch.challenge() % L;
-        {
-            const unsigned plen0 = log_L - cap_h;
-            // device layout of the answers (words)
-            size_t off = 0;
-            size_t rows_off[4], paths_off[4];
-            for (int o = 0; o < 4; o++) {
-                rows_off[o] = off; off += (size_t)NQ * oracles[o]->n_cols;
-                paths_off[o] = off; off += (size_t)NQ * plen0 * 4;
-            }
-            std::vector<size_t> ev_off(NR), fp_off(NR);
-            std::vector<unsigned> fplen(NR);
-            for (uint32_t r = 0; r < NR; r++) {
-                const unsigned lg = layer_log_n[r] - d.fri_arity_bits + d.rate_bits;
-                fplen[r] = lg > cap_h ? lg - cap_h : 0;
-                ev_off[r] = off; off += (size_t)NQ * 2 * arity;
-                fp_off[r] = off; off += (size_t)NQ * fplen[r] * 4;
-            }
-            uint64_t* d_ans = dalloc(off * 8 + 256);
-            uint64_t* d_idx = dalloc((size_t)(NR + 1) * NQ * 8 + 256);
-            CHECK_ALLOC(d_ans && d_idx);
-            HIPCHK(hipMemcpyAsync(d_idx, qidx.data(), (size_t)NQ * 8, hipMemcpyHostToDevice, st));
-            for (int o = 0; o < 4; o++) {
-                launch_gather_rows(st, oracles[o]->lde, L, oracles[o]->n_cols, log_n, d.rate_bits, d_idx, NQ, d_ans + rows_off[o]);
-                launch_gather_paths(st, oracles[o]->digests, log_L, cap_h, d_idx, NQ, d_ans + paths_off[o]);
-            }
-            unsigned total_shift = 0;
-            for (uint32_t r = 0; r < NR; r++) {
-                total_shift += d.fri_arity_bits;
-                uint64_t* idx_r = d_idx + (size_t)(r + 1) * NQ;
-                launch_shift_indices(st, d_idx, idx_r, NQ, total_shift);
-                launch_fri_gather_leaf(st, layer_values[r], layer_log_n[r], d.rate_bits, d.fri_arity_bits, idx_r, NQ,
-                                       d_ans + ev_off[r], (size_t)2 * arity);
-                const unsigned lg = layer_log_n[r] - d.fri_arity_bits + d.rate_bits;
-                launch_gather_paths(st, layer_digests[r], lg, cap_h, idx_r, NQ, d_ans + fp_off[r]);
-            }
-            std::vector<uint64_t> ans(off);
-            CHECK(fetch(ctx, ans.data(), d_ans, off * 8));
-            for (uint32_t q = 0; q < NQ; q++) {
-                for (int o = 0; o < 4; o++) {
-                    const uint32_t ncol = oracles[o]->n_cols;
-                    w.u64s(ans.data() + rows_off[o] + (size_t)q * ncol, ncol);
-                    w.u8((uint8_t)plen0);
-                    w.u64s(ans.data() + paths_off[o] + (size_t)q * plen0 * 4, (size_t)plen0 * 4);
-                }
-                for (uint32_t r = 0; r < NR; r++) {
-                    w.u64s(ans.data() + ev_off[r] + (size_t)q * 2 * arity, (size_t)2 * arity);
-                    w.u8((uint8_t)fplen[r]);
-                    w.u64s(ans.data() + fp_off[r] + (size_t)q * fplen[r] * 4, (size_t)fplen[r] * 4);
-                }
-            }
-        }
-        w.u64s(final_poly.data(), final_poly.size());
-        w.u64s(&pow_witness, 1);
         w.u32(d.num_public_inputs);
         w.u64s(h_pis.data(), h_pis.size());
         stage("end");

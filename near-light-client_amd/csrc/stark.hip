@@ -1,0 +1,423 @@
+// starky-style STARK prover on one MI355X (C ABI: nlx_stark_build, nlx_stark_prove).
+//
+// Replaces starky::prover::prove (trace commitment, compute_quotient_polys, StarkOpeningSet, FRI) - the
+// public ancestor of the un-vendored starkyx/curta prover that plonky2x runs for nearx's Ed25519 and
+// SHA-256 gadgets (nearx/src/builder.rs curta_* calls; Cargo.lock:6515).
+//
+// MI355X-first choices:
+//  * the AIR is data: a register program (NLX_AIR_*) interpreted by k_air_quotient, one lane per point of
+//    the quotient coset, with the VM registers in LDS ([reg][lane], conflict-free) so a program of any
+//    shape runs without recompiling a kernel and without spilling to scratch;
+//  * the quotient domain {g w^(i*step)} is exactly 2^qdb of the LDE table's cosets in the coset-major
+//    layout, so "next row" is the neighbouring element of the same coset and the
+//    trace LDE is read in place - no second low-degree extension as in the reference flow;
+//  * quotient chunks come from per-coset inverse transforms + a 2^qdb-point DFT across cosets, as in the
+//    plonky2 path; commitments, openings and FRI are the same device code as nlx_prove.
+#include <vector>
+#include "commit.hpp"
+#include "fri.hpp"
+#include "gl.hpp"
+#include "poly.hpp"
+#include "prover.hpp"
+#include "transcript.hpp"
+
+using namespace nlx;
+
+namespace nlx {
+
+struct AirParams {
+    const uint64_t* trace;      // LDE table [col][r][k], L = n << rate_bits
+    const uint64_t* program;    // device, n_words (constants canonical)
+    const uint64_t* pis;        // device
+    const uint64_t* coset_base; // device: g * w_{n q}^r', r' < q = 2^qdb
+    const uint64_t* zh_inv;     // device: 1 / Z_H on quotient coset r'
+    const uint64_t* l_inv;      // device: 1 / (n (x - 1)) on the quotient cosets, [r'][k]
+    const uint64_t* w_n_table;
+    uint64_t* out;              // [challenge][r'][k]
+    uint64_t alphas[2];
+    uint64_t g_inv;             // last = g^-1 (g generates the size-n subgroup)
+    uint32_t log_n, rate_bits, qdb, n_words, nc, n_regs;
+};
+
+static __device__ __forceinline__ uint64_t root_pow_(const uint64_t* __restrict__ half_table, uint32_t e, uint32_t half) {
+    return e < half ? half_table[e] : gl::P - half_table[e - half];
+}
+
+// One lane per point (r', k) of the quotient domain.  Registers live in LDS as regs[reg * blockDim + lane]:
+// every access of a wave touches 64 consecutive 8-byte words (no bank conflicts); the program counter, the
+// opcode and the operands are wave-uniform, so decode runs on the scalar unit.
+__global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
+    extern __shared__ uint64_t regs[];
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned log_Q = p.log_n + p.qdb;
+    if (pos >> log_Q) return;  // n >= blockDim.x is checked on the host: whole blocks are in or out
+    const size_t n = (size_t)1 << p.log_n, L = n << p.rate_bits;
+    const uint32_t rq = (uint32_t)(pos >> p.log_n), k = (uint32_t)(pos & (n - 1));
+    const uint32_t r = rq << (p.rate_bits - p.qdb);  // LDE coset of quotient coset rq
+    const size_t row = ((size_t)r << p.log_n) + k, row_next = ((size_t)r << p.log_n) + ((k + 1) & (n - 1));
+    const size_t qrow_next = ((size_t)rq << p.log_n) + ((k + 1) & (n - 1));
+    const uint64_t x = gl::mul(p.coset_base[rq], root_pow_(p.w_n_table, k, (uint32_t)(n >> 1)));
+    const uint64_t zh = gl::inv(p.zh_inv[rq]);  // wave-uniform; one inversion per lane is noise next to the program
+    const uint64_t z_last = gl::sub(x, p.g_inv);
+    const uint64_t l_first = gl::mul(zh, p.l_inv[pos]);
+    const uint64_t l_last = gl::mul(zh, p.l_inv[qrow_next]);  // 1 / (n (g x - 1)): g x is the next point of the coset
+    uint64_t* my = regs + threadIdx.x;
+    const uint32_t bd = blockDim.x;
+    uint64_t acc0 = 0, acc1 = 0;
+    const uint64_t a0 = p.alphas[0], a1 = p.alphas[1];
+    const bool two = p.nc > 1;
+    for (uint32_t pc = 0; pc < p.n_words; pc++) {
+        const uint64_t w = p.program[pc];
+        const uint32_t op = (uint32_t)(w & 0xFF), dst = (uint32_t)((w >> 8) & 0xFFFF);
+        const uint32_t a = (uint32_t)((w >> 24) & 0xFFFF), b = (uint32_t)((w >> 40) & 0xFFFF);
+        uint64_t c;
+        switch (op) {
+            case NLX_AIR_LOCAL: my[dst * bd] = p.trace[(size_t)a * L + row]; continue;
+            case NLX_AIR_NEXT: my[dst * bd] = p.trace[(size_t)a * L + row_next]; continue;
+            case NLX_AIR_PUBLIC: my[dst * bd] = p.pis[a]; continue;
+            case NLX_AIR_CONST: my[dst * bd] = p.program[++pc]; continue;
+            case NLX_AIR_ADD: my[dst * bd] = gl::add(my[a * bd], my[b * bd]); continue;
+            case NLX_AIR_SUB: my[dst * bd] = gl::sub(my[a * bd], my[b * bd]); continue;
+            case NLX_AIR_MUL: my[dst * bd] = gl::mul(my[a * bd], my[b * bd]); continue;
+            case NLX_AIR_EMIT_TRANSITION: c = gl::mul(my[a * bd], z_last); break;
+            case NLX_AIR_EMIT_FIRST: c = gl::mul(my[a * bd], l_first); break;
+            case NLX_AIR_EMIT_LAST: c = gl::mul(my[a * bd], l_last); break;
+            default: c = my[a * bd]; break;  // NLX_AIR_EMIT (the host validated the opcode range)
+        }
+        acc0 = gl::add(gl::mul(acc0, a0), c);
+        if (two) acc1 = gl::add(gl::mul(acc1, a1), c);
+    }
+    const uint64_t zi = p.zh_inv[rq];
+    const size_t Q = (size_t)1 << log_Q;
+    p.out[pos] = gl::mul(acc0, zi);
+    if (two) p.out[Q + pos] = gl::mul(acc1, zi);
+}
+
+}  // namespace nlx
+
+struct nlx_stark {
+    nlx_ctx* ctx = nullptr;
+    nlx_stark_desc d{};
+    std::vector<uint64_t> program;  // canonicalised copy
+    uint32_t qdb = 0, nq = 0, n_regs = 0, n_fri_rounds = 0;
+    uint64_t* d_program = nullptr;
+    uint64_t* d_small = nullptr;  // FRI coset tables (rate_bits) | quotient coset tables (qdb) | w_A^-i
+    uint64_t *d_coset_base = nullptr, *d_q_coset_base = nullptr, *d_q_zh_inv = nullptr, *d_q_wR_inv = nullptr,
+             *d_q_chunk_scale = nullptr, *d_wA_inv = nullptr;
+    uint64_t* d_l_inv = nullptr;               // [2^qdb][n]
+    const uint64_t* d_q_inv_scale_br = nullptr;  // ctx-owned
+    hipEvent_t ev[NLX_MAX_STAGES + 1]{};
+    const char* stage_names[NLX_MAX_STAGES]{};
+    uint32_t n_stages = 0;
+    bool timed = false;
+};
+
+static size_t stark_proof_max_bytes(const nlx_stark_desc& d, uint32_t n_rounds) {
+    const size_t capb = (size_t)32 << d.cap_height;
+    const unsigned log_L = d.degree_bits + d.rate_bits;
+    const uint32_t nq = d.num_challenges * d.quotient_degree_factor;
+    size_t bytes = 2 * capb + 16 * (size_t)(2 * d.n_cols + nq) + n_rounds * capb;
+    size_t per_query = (size_t)(d.n_cols + nq) * 8 + 2 * (1 + 32 * (size_t)log_L) +
+                       n_rounds * (((size_t)16 << d.fri_arity_bits) + 1 + 32 * (size_t)log_L);
+    bytes += per_query * d.fri_num_queries + ((size_t)16 << d.degree_bits) + 8 + 4 + 8 * (size_t)d.num_public_inputs;
+    return bytes + 64;
+}
+
+extern "C" {
+
+int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** out) {
+    if (!ctx) return NLX_E_INVAL;
+    if (!desc || !out || (!desc->program && desc->n_words)) return ctx->fail(NLX_E_INVAL, "NULL argument");
+    *out = nullptr;
+    const nlx_stark_desc& d = *desc;
+    const uint32_t q = d.quotient_degree_factor;
+    if (d.num_challenges < 1 || d.num_challenges > 2) return ctx->fail(NLX_E_UNSUPPORTED, "num_challenges must be 1 or 2");
+    if (d.rate_bits < 1 || d.rate_bits > 3) return ctx->fail(NLX_E_UNSUPPORTED, "rate_bits must be in [1, 3]");
+    if (!q || (q & (q - 1)) || q > (1u << d.rate_bits))
+        return ctx->fail(NLX_E_INVAL, "quotient_degree_factor must be a power of two <= 2^rate_bits");
+    if (d.fri_arity_bits < 2 || d.fri_arity_bits > 4) return ctx->fail(NLX_E_UNSUPPORTED, "fri_arity_bits must be in [2, 4]");
+    if (d.degree_bits < 4 || d.degree_bits < d.fri_arity_bits || d.degree_bits + d.rate_bits > 30)
+        return ctx->fail(NLX_E_RANGE, "degree_bits out of range");
+    if (d.fri_num_queries > 128 || d.fri_num_queries == 0 || d.cap_height > 6 || d.cap_height > d.degree_bits + d.rate_bits)
+        return ctx->fail(NLX_E_RANGE, "FRI parameters out of range");
+    if (d.n_cols == 0 || d.n_cols > 4096 || d.num_public_inputs > 4096 || d.n_words > (1u << 20))
+        return ctx->fail(NLX_E_RANGE, "AIR shape out of range");
+    // program validation: opcodes, operand ranges, no register read before it is written
+    std::vector<uint64_t> prog(d.program, d.program + d.n_words);
+    uint32_t n_regs = 1;
+    {
+        bool written[NLX_AIR_NUM_REGS] = {false};
+        for (uint32_t pc = 0; pc < d.n_words; pc++) {
+            const uint64_t w = prog[pc];
+            const uint32_t op = (uint32_t)(w & 0xFF), dst = (uint32_t)((w >> 8) & 0xFFFF);
+            const uint32_t a = (uint32_t)((w >> 24) & 0xFFFF), b = (uint32_t)((w >> 40) & 0xFFFF);
+            if (op > NLX_AIR_EMIT) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
+            const bool writes = op <= NLX_AIR_MUL;
+            if (writes && dst >= NLX_AIR_NUM_REGS) return ctx->fail(NLX_E_INVAL, "AIR word %u: register out of range", pc);
+            if ((op == NLX_AIR_LOCAL || op == NLX_AIR_NEXT) && a >= d.n_cols) return ctx->fail(NLX_E_INVAL, "AIR word %u: column out of range", pc);
+            if (op == NLX_AIR_PUBLIC && a >= d.num_public_inputs) return ctx->fail(NLX_E_INVAL, "AIR word %u: public input out of range", pc);
+            if (op >= NLX_AIR_ADD) {
+                const bool two_src = op <= NLX_AIR_MUL;
+                if (a >= NLX_AIR_NUM_REGS || !written[a] || (two_src && (b >= NLX_AIR_NUM_REGS || !written[b])))
+                    return ctx->fail(NLX_E_INVAL, "AIR word %u: reads an unwritten register", pc);
+            }
+            if (op == NLX_AIR_CONST) {
+                if (pc + 1 >= d.n_words) return ctx->fail(NLX_E_INVAL, "AIR: CONST without immediate");
+                pc++;
+                prog[pc] %= gl::P;
+            }
+            if (writes) {
+                written[dst] = true;
+                if (dst + 1 > n_regs) n_regs = dst + 1;
+            }
+        }
+    }
+    (void)hipSetDevice(ctx->device);
+    nlx_stark* s = new (std::nothrow) nlx_stark();
+    if (!s) return ctx->fail(NLX_E_NOMEM, "host allocation failed");
+    s->ctx = ctx;
+    s->d = d;
+    s->program.swap(prog);
+    s->d.program = s->program.data();
+    s->n_regs = n_regs;
+    s->nq = d.num_challenges * q;
+    while ((1u << s->qdb) < q) s->qdb++;
+    s->n_fri_rounds = fri_num_rounds(d.degree_bits, d.rate_bits, d.cap_height, d.fri_arity_bits, d.fri_final_poly_bits);
+    auto fail = [&](int32_t code) {
+        nlx_stark_destroy(s);
+        return code;
+    };
+    const unsigned log_n = d.degree_bits;
+    int32_t rc = ctx->ensure_tables(log_n + d.rate_bits);
+    if (rc) return fail(rc);
+    rc = ctx->get_coset_scale(log_n, s->qdb, &s->d_q_inv_scale_br, true);
+    if (rc) return fail(rc);
+    {
+        const uint32_t R = 1u << d.rate_bits, Q = 1u << s->qdb, A = 1u << d.fri_arity_bits;
+        std::vector<uint64_t> small(4 * R + 4 * Q + A);
+        coset_tables_host(log_n, d.rate_bits, small.data());
+        coset_tables_host(log_n, s->qdb, small.data() + 4 * R);
+        const uint64_t w_A_inv = gl::inv(gl::root_of_unity(d.fri_arity_bits));
+        for (uint32_t i = 0; i < A; i++) small[4 * R + 4 * Q + i] = gl::pow(w_A_inv, i);
+        s->d_small = (uint64_t*)ctx->alloc(small.size() * 8);
+        s->d_program = (uint64_t*)ctx->alloc((size_t)(d.n_words ? d.n_words : 1) * 8);
+        s->d_l_inv = (uint64_t*)ctx->alloc(((size_t)8 << (log_n + s->qdb)));
+        if (!s->d_small || !s->d_program || !s->d_l_inv) return fail(NLX_E_NOMEM);
+        hipError_t e = hipMemcpy(s->d_small, small.data(), small.size() * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess && d.n_words) e = hipMemcpy(s->d_program, s->program.data(), (size_t)d.n_words * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(ctx->hip_fail(e, "hipMemcpy(tables)"));
+        s->d_coset_base = s->d_small;
+        s->d_q_coset_base = s->d_small + 4 * R;
+        s->d_q_zh_inv = s->d_q_coset_base + Q;
+        s->d_q_wR_inv = s->d_q_zh_inv + Q;
+        s->d_q_chunk_scale = s->d_q_wR_inv + Q;
+        s->d_wA_inv = s->d_small + 4 * R + 4 * Q;
+        launch_l0_table(ctx->stream, s->d_l_inv, log_n, s->qdb, s->d_q_coset_base, ctx->tables.fwd[log_n]);
+    }
+    for (int i = 0; i <= NLX_MAX_STAGES; i++)
+        if (hipEventCreate(&s->ev[i]) != hipSuccess) return fail(ctx->fail(NLX_E_HIP, "hipEventCreate failed"));
+    NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = s;
+    return NLX_OK;
+}
+
+void nlx_stark_destroy(nlx_stark* s) {
+    if (!s) return;
+    nlx_ctx* ctx = s->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->release(s->d_small);
+    ctx->release(s->d_program);
+    ctx->release(s->d_l_inv);
+    for (int i = 0; i <= NLX_MAX_STAGES; i++)
+        if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
+    delete s;
+}
+
+size_t nlx_stark_proof_max_bytes(const nlx_stark* s) {
+    return s ? stark_proof_max_bytes(s->d, s->n_fri_rounds) : 0;
+}
+
+int32_t nlx_stark_stage_times(const nlx_stark* s, uint32_t* n_stages, const char** names_out, float* ms_out) {
+    if (!s || !n_stages) return NLX_E_INVAL;
+    if (!s->timed) { *n_stages = 0; return NLX_OK; }
+    *n_stages = s->n_stages;
+    for (uint32_t i = 0; i < s->n_stages; i++) {
+        if (names_out) names_out[i] = s->stage_names[i];
+        if (ms_out) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, s->ev[i], s->ev[i + 1]) != hipSuccess) ms = -1.f;
+            ms_out[i] = ms;
+        }
+    }
+    return NLX_OK;
+}
+
+int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* public_inputs, uint8_t* proof_out,
+                        size_t proof_cap, size_t* proof_len) {
+    if (!s) return NLX_E_INVAL;
+    nlx_ctx* ctx = s->ctx;
+    const nlx_stark_desc& d = s->d;
+    if (!trace || !proof_out || !proof_len || (!public_inputs && d.num_public_inputs))
+        return ctx->fail(NLX_E_INVAL, "NULL argument");
+    *proof_len = 0;
+    for (uint32_t i = 0; i < d.num_public_inputs; i++)
+        if (public_inputs[i] >= gl::P) return ctx->fail(NLX_E_RANGE, "public input %u is not canonical", i);
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    const unsigned log_n = d.degree_bits, cap_h = d.cap_height, qdb = s->qdb;
+    const size_t n = (size_t)1 << log_n, capw = (size_t)4 << cap_h;
+    const uint32_t nc = d.num_challenges, ncols = d.n_cols, nq = s->nq;
+    int32_t rc = NLX_OK;
+    std::vector<void*> scratch;
+    auto dalloc = [&](size_t bytes) -> uint64_t* {
+        void* p = ctx->alloc(bytes);
+        if (p) scratch.push_back(p);
+        return (uint64_t*)p;
+    };
+    nlx_commit *ct = nullptr, *cq = nullptr;
+    s->n_stages = 0;
+    s->timed = false;
+    auto stage = [&](const char* name) {
+        if (s->n_stages < NLX_MAX_STAGES) {
+            (void)hipEventRecord(s->ev[s->n_stages], st);
+            s->stage_names[s->n_stages++] = name;
+        }
+    };
+    Writer w{proof_out, 0, proof_cap};
+    Challenger ch;
+    std::vector<uint64_t> cap(capw);
+#define CHECK(x) do { rc = (x); if (rc) goto done; } while (0)
+#define HIPCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { rc = ctx->hip_fail(e__, #call); goto done; } } while (0)
+#define CHECK_ALLOC(p) do { if (!(p)) { rc = NLX_E_NOMEM; goto done; } } while (0)
+    {
+        // ---- trace commitment (prover.rs: PolynomialBatch::from_values(trace_poly_values, rate_bits, ..)) ----
+        stage("commit_trace");
+        Staged tr(ctx, trace, (size_t)ncols * n * 8, true, false);
+        CHECK(tr.status);
+        CHECK(commit_build(ctx, tr.as<uint64_t>(), n, CommitInput::ValuesNatural, ncols, log_n, d.rate_bits, cap_h, &ct));
+        CHECK(fetch(ctx, cap.data(), ct->cap, capw * 8));
+        w.u64s(cap.data(), capw);
+        ch.observe(cap.data(), capw);
+        uint64_t alphas[2] = {0, 0};
+        for (uint32_t i = 0; i < nc; i++) alphas[i] = ch.challenge();
+
+        // ---- compute_quotient_polys ----
+        stage("quotient_eval");
+        const size_t Q = n << qdb;
+        uint64_t* d_pis = dalloc((size_t)(d.num_public_inputs + 1) * 8);
+        uint64_t* d_qvals = dalloc((size_t)nc * Q * 8);
+        uint64_t* d_qchunks = dalloc((size_t)nc * Q * 8);
+        CHECK_ALLOC(d_pis && d_qvals && d_qchunks);
+        if (d.num_public_inputs)
+            HIPCHK(hipMemcpyAsync(d_pis, public_inputs, (size_t)d.num_public_inputs * 8, hipMemcpyHostToDevice, st));
+        {
+            AirParams ap{};
+            ap.trace = ct->lde; ap.program = s->d_program; ap.pis = d_pis;
+            ap.coset_base = s->d_q_coset_base; ap.zh_inv = s->d_q_zh_inv; ap.l_inv = s->d_l_inv;
+            ap.w_n_table = ctx->tables.fwd[log_n];
+            ap.out = d_qvals;
+            ap.alphas[0] = alphas[0]; ap.alphas[1] = alphas[1];
+            ap.g_inv = gl::inv(gl::root_of_unity(log_n));
+            ap.log_n = log_n; ap.rate_bits = d.rate_bits; ap.qdb = qdb; ap.n_words = d.n_words; ap.nc = nc;
+            ap.n_regs = s->n_regs;
+            // block size: as many lanes as the LDS register file allows (64 KB budget), power of two <= n
+            unsigned bs = 256;
+            while (bs > 64 && (size_t)bs * s->n_regs * 8 > (64u << 10)) bs >>= 1;
+            while (bs > n) bs >>= 1;
+            const size_t lds = (size_t)bs * s->n_regs * 8;
+            ctx->begin_kernel("air_quotient", 8.0 * Q * (2.0 * ncols + nc));
+            hipLaunchKernelGGL(k_air_quotient, dim3((unsigned)(Q / bs)), dim3(bs), lds, st, ap);
+            ctx->end_kernel();
+        }
+        stage("quotient_intt");
+        launch_intt_dif_cosets(st, ctx->tables, d_qvals, nc, log_n, qdb, s->d_q_inv_scale_br);
+        launch_quotient_chunks(st, d_qvals, d_qchunks, log_n, qdb, nc, s->d_q_wR_inv, s->d_q_chunk_scale);
+        stage("commit_quotient");
+        CHECK(commit_build(ctx, d_qchunks, n, CommitInput::CoeffsBitrev, nq, log_n, d.rate_bits, cap_h, &cq));
+        CHECK(fetch(ctx, cap.data(), cq->cap, capw * 8));
+        w.u64s(cap.data(), capw);
+        ch.observe(cap.data(), capw);
+
+        // ---- StarkOpeningSet: local = trace(zeta), next = trace(g zeta), quotient(zeta) ----
+        stage("openings");
+        uint64_t zeta[2], gzeta[2];
+        ch.ext_challenge(zeta);
+        {
+            const uint64_t g = gl::root_of_unity(log_n);
+            gzeta[0] = gl::mul(zeta[0], g);
+            gzeta[1] = gl::mul(zeta[1], g);
+        }
+        const uint32_t n_open = ncols + nq;
+        uint64_t* d_points = dalloc(2048);
+        uint64_t* d_open = dalloc((size_t)(n_open + ncols) * 16);
+        uint64_t* d_eval_scratch = dalloc(eval_scratch_words(ncols > nq ? ncols : nq, log_n) * 8);
+        CHECK_ALLOC(d_points && d_open && d_eval_scratch);
+        {
+            uint64_t pts[4 + 2 * 2 * 32] = {zeta[0], zeta[1], gzeta[0], gzeta[1]};
+            gl::Ext za{zeta[0], zeta[1]}, zb{gzeta[0], gzeta[1]};
+            for (unsigned k = 0; k < 32; k++) {
+                pts[4 + 2 * k] = za.a; pts[4 + 2 * k + 1] = za.b;
+                pts[4 + 64 + 2 * k] = zb.a; pts[4 + 64 + 2 * k + 1] = zb.b;
+                if (k + 1 < log_n) { za = gl::mul(za, za); zb = gl::mul(zb, zb); }
+            }
+            HIPCHK(hipMemcpyAsync(d_points, pts, sizeof pts, hipMemcpyHostToDevice, st));
+            launch_eval_br(st, ct->coeffs_br, n, ncols, log_n, d_points, d_open, d_eval_scratch, d_points + 4);
+            launch_eval_br(st, cq->coeffs_br, n, nq, log_n, d_points, d_open + 2 * (size_t)ncols, d_eval_scratch, d_points + 4);
+            launch_eval_br(st, ct->coeffs_br, n, ncols, log_n, d_points + 2, d_open + 2 * (size_t)n_open, d_eval_scratch,
+                           d_points + 4 + 64);
+        }
+        std::vector<uint64_t> open((size_t)(n_open + ncols) * 2);
+        CHECK(fetch(ctx, open.data(), d_open, open.size() * 8));
+        const uint64_t* o_local = open.data();
+        const uint64_t* o_q = o_local + 2 * (size_t)ncols;
+        const uint64_t* o_next = open.data() + 2 * (size_t)n_open;
+        w.u64s(o_local, 2 * (size_t)ncols);
+        w.u64s(o_next, 2 * (size_t)ncols);
+        w.u64s(o_q, 2 * (size_t)nq);
+        // observe_openings(&openings.to_fri_openings()): zeta batch (local ++ quotient), then the g*zeta batch
+        ch.observe(open.data(), 2 * (size_t)n_open);
+        ch.observe(o_next, 2 * (size_t)ncols);
+
+        // ---- FRI: Stark::fri_instance = [zeta: trace ++ quotient], [g zeta: trace] ----
+        {
+            FriProveArgs fa;
+            fa.oracles[0] = ct;
+            fa.oracles[1] = cq;
+            fa.n_oracles = 2;
+            fa.next_table = 0;
+            fa.nz = ncols;
+            for (int i = 0; i < 2; i++) { fa.zeta[i] = zeta[i]; fa.gzeta[i] = gzeta[i]; }
+            fa.open0 = open.data();
+            fa.open1 = o_next;
+            fa.log_n = log_n; fa.rate_bits = d.rate_bits; fa.cap_height = cap_h; fa.arity_bits = d.fri_arity_bits;
+            fa.pow_bits = d.fri_pow_bits; fa.n_queries = d.fri_num_queries; fa.n_rounds = s->n_fri_rounds;
+            fa.d_coset_base = s->d_coset_base;
+            fa.d_wA_inv = s->d_wA_inv;
+            CHECK(fri_prove(ctx, fa, ch, w, scratch, stage));
+        }
+        w.u32(d.num_public_inputs);
+        w.u64s(public_inputs, d.num_public_inputs);
+        stage("end");
+        s->n_stages--;
+        s->timed = true;
+        if (w.overflow) { rc = ctx->fail(NLX_E_RANGE, "proof buffer too small (need %zu bytes)", nlx_stark_proof_max_bytes(s)); goto done; }
+        *proof_len = w.len;
+    }
+done:
+    {
+        hipError_t e = hipStreamSynchronize(st);
+        if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
+        hipError_t le = hipGetLastError();
+        if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
+    }
+    for (void* p : scratch) ctx->release(p);
+    if (ct) nlx_commit_destroy(ct);
+    if (cq) nlx_commit_destroy(cq);
+#undef CHECK
+#undef HIPCHK
+#undef CHECK_ALLOC
+    return rc;
+}
+
+}  // extern "C"

@@ -195,6 +195,31 @@ int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint6
     return NLX_OK;
 }
 
+// Witness of the synthetic wide AIR (host mirror: stark.py wide_air): columns in groups of four (a, b, c, d),
+//   next.a = a*b + c,  next.b = b*c + k1[g],  next.c = (a + b + c) * d,  d boolean and constant down the trace.
+int32_t nlx_synth_stark_trace(uint32_t n_cols, uint32_t log_n, uint64_t seed, const uint64_t* k1, uint64_t* trace,
+                              uint64_t* public_inputs) {
+    if (!k1 || !trace || !public_inputs || n_cols == 0 || (n_cols & 3)) return NLX_E_INVAL;
+    if (log_n < 1 || log_n > 28) return NLX_E_RANGE;
+    const size_t n = (size_t)1 << log_n;
+    Rng rng(seed ^ 0x737461726bULL);
+    for (uint32_t g = 0; g < n_cols / 4; g++) {
+        if (k1[g] >= gl::P) return NLX_E_INVAL;
+        uint64_t a = rng.field(), b = rng.field(), c = rng.field();
+        const uint64_t d = rng.next() & 1;
+        uint64_t *ca = trace + (size_t)(4 * g) * n, *cb = ca + n, *cc = cb + n, *cd = cc + n;
+        for (size_t i = 0; i < n; i++) {
+            ca[i] = a; cb[i] = b; cc[i] = c; cd[i] = d;
+            const uint64_t na = gl::add(gl::mul(a, b), c), nb = gl::add(gl::mul(b, c), k1[g]);
+            const uint64_t nc = d ? gl::add(gl::add(a, b), c) : 0;
+            a = na; b = nb; c = nc;
+        }
+    }
+    public_inputs[0] = trace[0];
+    public_inputs[1] = trace[n];
+    return NLX_OK;
+}
+
 int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint64_t* k_is, uint64_t* constants,
                           uint64_t* sigmas, uint64_t* wires, uint64_t* public_inputs) {
     const uint32_t W = 135, ROUTED = 80, NCONST = 2;

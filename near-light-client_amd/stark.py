@@ -6,8 +6,8 @@ Their prover is the starky flow (`starky::prover::prove`, `StarkConfig::standard
 trace, draw alphas, evaluate the AIR over a coset, commit the quotient, open at zeta and g*zeta, FRI.
 
 The AIR is *data*: `Air` records constraints written with ordinary Python operators against
-`local(i)`, `next(i)`, `public(i)` and compiles them into the register program both the HIP kernel
-and the CPU oracle interpret (include/nlx.h NLX_AIR_*), mirroring starky's
+`local(i)`, `next(i)`, `public(i)` and compiles them into the register program the HIP quotient kernel
+interprets (include/nlx.h NLX_AIR_*), mirroring starky's
 `Stark::eval_packed_generic` + `ConstraintConsumer::{constraint, constraint_transition,
 constraint_first_row, constraint_last_row}`.
 """
@@ -24,7 +24,7 @@ AIR_NUM_REGS = 64
 
 
 class StarkDesc(ctypes.Structure):
-    """nlx_stark_desc (include/nlx.h) == orc_stark_desc (oracle/stark.h)."""
+    """nlx_stark_desc (include/nlx.h)."""
     _fields_ = [(k, ctypes.c_uint32) for k in (
         "degree_bits", "n_cols", "num_challenges", "rate_bits", "cap_height", "quotient_degree_factor",
         "fri_pow_bits", "fri_num_queries", "fri_arity_bits", "fri_final_poly_bits", "num_public_inputs",
@@ -222,7 +222,7 @@ class Air:
 
 class Stark:
     """A compiled AIR + config at a fixed trace length: what starky's `prove(stark, config, trace, pis)`
-    takes.  `desc` is the C-ABI descriptor shared by the HIP prover and the oracle."""
+    takes.  `desc` is the C-ABI descriptor (nlx_stark_desc); `build(ctx)` makes it resident on a GPU."""
 
     def __init__(self, air, degree_bits, config=None):
         self.air = air
@@ -238,23 +238,59 @@ class Stark:
                               self.program.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
         self.degree_bits = degree_bits
 
-    def proof_max_bytes(self):
-        return int(dll().nlx_stark_proof_max_bytes(ctypes.byref(self.desc)))
+    def build(self, ctx):
+        return StarkProver(ctx, self)
 
-    def prove(self, ctx, trace, public_inputs=()):
-        """trace: (n_cols, n) uint64 host array, column-major as starky's Vec<PolynomialValues>.
-        Returns the proof bytes (StarkProofWithPublicInputs wire format)."""
-        trace = np.ascontiguousarray(trace, dtype=np.uint64)
-        assert trace.shape == (self.air.n_cols, 1 << self.degree_bits)
+
+class StarkProver:
+    """Device-resident prover for one Stark (nlx_stark_build / nlx_stark_prove)."""
+
+    def __init__(self, ctx, stark):
+        self.ctx = ctx
+        self.stark = stark
+        h = ctypes.c_void_p()
+        ctx.check(dll.nlx_stark_build(ctx.handle, ctypes.byref(stark.desc), ctypes.byref(h)))
+        self.handle = h
+        self._buf = np.zeros(dll.nlx_stark_proof_max_bytes(h), dtype=np.uint8)
+        ctx._adopt(self)
+
+    def prove(self, trace, public_inputs=()):
+        """starky::prover::prove.  trace: (n_cols, n) uint64, column-major as starky's
+        Vec<PolynomialValues> (host array or device tensor).  Returns the proof bytes."""
+        air = self.stark.air
+        if tuple(trace.shape) != (air.n_cols, 1 << self.stark.degree_bits):
+            raise ValueError("trace must be (n_cols, n)")
         pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
-        assert pis.size == self.air.num_public_inputs
-        out = np.empty(self.proof_max_bytes(), dtype=np.uint8)
-        n = ctypes.c_size_t(0)
-        rc = dll().nlx_stark_prove(ctx.handle, ctypes.byref(self.desc), ptr(trace), ptr(pis) if pis.size else None,
-                                   out.ctypes.data_as(ctypes.c_void_p), out.size, ctypes.byref(n))
-        if rc != 0:
-            raise NlxError(rc, ctx.last_error())
-        return out[:n.value].tobytes()
+        if pis.size != air.num_public_inputs:
+            raise ValueError("expected %d public inputs" % air.num_public_inputs)
+        ln = ctypes.c_size_t()
+        self.ctx.check(dll.nlx_stark_prove(self.handle, ptr(trace), ptr(pis) if pis.size else None,
+                                           self._buf.ctypes.data, self._buf.size, ctypes.byref(ln)))
+        return self._buf[:ln.value].tobytes()
+
+    def prove_into(self, trace, public_inputs_ptr):
+        ln = ctypes.c_size_t()
+        self.ctx.check(dll.nlx_stark_prove(self.handle, ptr(trace), public_inputs_ptr, self._buf.ctypes.data,
+                                           self._buf.size, ctypes.byref(ln)))
+        return ln.value
+
+    def stage_times(self):
+        n = ctypes.c_uint32()
+        names = (ctypes.c_char_p * 24)()
+        ms = (ctypes.c_float * 24)()
+        dll.nlx_stark_stage_times(self.handle, ctypes.byref(n), names, ms)
+        return [(names[i].decode(), ms[i]) for i in range(n.value)]
+
+    def close(self):
+        if self.handle and self.ctx.handle:
+            dll.nlx_stark_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---------------------------------------------------------------------------------------------
@@ -289,12 +325,12 @@ def wide_air(n_cols=64, seed=1):
     assert n_cols % 4 == 0
     air = Air(n_cols, 2)
     rng = np.random.default_rng(seed)
+    air.k1 = np.array([int(rng.integers(1, P, dtype=np.uint64)) for _ in range(n_cols // 4)], dtype=np.uint64)
     for g in range(n_cols // 4):
         a, b, c, d = (air.local(4 * g + k) for k in range(4))
         na, nb, nc, nd = (air.next(4 * g + k) for k in range(4))
-        k1 = int(rng.integers(1, P, dtype=np.uint64))
         air.constraint_transition(na - (a * b + c))
-        air.constraint_transition(nb - (b * c + k1))
+        air.constraint_transition(nb - (b * c + int(air.k1[g])))
         air.constraint_transition(nc - (a + b + c) * d)
         air.constraint(d * (d - 1))
         air.constraint_transition(nd - d)
@@ -304,20 +340,10 @@ def wide_air(n_cols=64, seed=1):
 
 
 def wide_trace(air, degree_bits, seed=1):
-    """Witness for wide_air(air.n_cols, seed): object-dtype python ints would be slow, so step with
-    numpy uint64 limbs through Python ints per row group (n small in tests) or vectorised across groups."""
-    n = 1 << degree_bits
-    G = air.n_cols // 4
-    rng = np.random.default_rng(seed)
-    k1 = [int(rng.integers(1, P, dtype=np.uint64)) for _ in range(G)]
-    rng2 = np.random.default_rng(seed + 1000)
-    a = [int(x) for x in rng2.integers(0, P, G, dtype=np.uint64)]
-    b = [int(x) for x in rng2.integers(0, P, G, dtype=np.uint64)]
-    c = [int(x) for x in rng2.integers(0, P, G, dtype=np.uint64)]
-    d = [int(x) for x in rng2.integers(0, 2, G, dtype=np.uint64)]
-    t = np.zeros((air.n_cols, n), dtype=np.uint64)
-    for i in range(n):
-        for g in range(G):
-            t[4 * g, i], t[4 * g + 1, i], t[4 * g + 2, i], t[4 * g + 3, i] = a[g], b[g], c[g], d[g]
-            a[g], b[g], c[g] = (a[g] * b[g] + c[g]) % P, (b[g] * c[g] + k1[g]) % P, ((a[g] + b[g] + c[g]) * d[g]) % P
-    return t, np.array([t[0, 0], t[1, 0]], dtype=np.uint64)
+    """Satisfying witness of wide_air (generated by the native workload generator, nlx_synth_stark_trace)."""
+    t = np.zeros((air.n_cols, 1 << degree_bits), dtype=np.uint64)
+    pis = np.zeros(2, dtype=np.uint64)
+    rc = dll.nlx_synth_stark_trace(air.n_cols, degree_bits, seed, ptr(air.k1), ptr(t), ptr(pis))
+    if rc != 0:
+        raise NlxError(rc, "nlx_synth_stark_trace")
+    return t, pis

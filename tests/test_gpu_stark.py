@@ -1,0 +1,114 @@
+"""GPU parity tests for the STARK path (nlx_stark_build / nlx_stark_prove through the C ABI): proof BYTES
+must equal the CPU oracle's starky restatement on the same AIR, config, trace and public inputs, and the
+oracle's verifier must accept them."""
+import numpy as np
+import pytest
+
+from conftest import P
+from test_stark_cpu import make_case
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("fib", 5, {}),                                   # no FRI reduction round, quotient factor 1 (one of two cosets)
+    ("fib", 8, {}),
+    ("fib", 12, {}),
+    ("fib", 7, dict(num_challenges=1, fri_arity_bits=3, fri_num_queries=20, fri_pow_bits=8, cap_height=2)),
+    ("wide16", 6, {}),
+    ("wide16", 10, {}),
+    ("wide16", 13, {}),                               # two NTT passes
+    ("wide64", 12, {}),
+    ("wide16", 8, dict(rate_bits=2, fri_arity_bits=2, fri_final_poly_bits=3, fri_num_queries=30)),
+    ("deg4", 8, dict(rate_bits=2)),
+    ("deg4", 9, dict(rate_bits=3, fri_num_queries=28)),
+]
+
+
+@pytest.mark.parametrize("kind,db,cfg", CASES)
+def test_stark_proof_bytes_equal_oracle(nlx, ctx, orc, kind, db, cfg):
+    S = nlx.stark
+    air, t, pis = make_case(S, kind, db)
+    st = S.Stark(air, db, S.StarkConfig(**cfg))
+    want = orc.stark_prove(st.desc, t, pis)
+    pr = st.build(ctx)
+    got = pr.prove(t, pis)
+    assert len(got) == len(want)
+    if got != want:
+        a, b = np.frombuffer(got, np.uint8), np.frombuffer(want, np.uint8)
+        first = int(np.nonzero(a != b)[0][0])
+        pytest.fail("STARK proof bytes differ from the oracle, first at byte %d of %d" % (first, len(want)))
+    assert orc.stark_verify(st.desc, got) == 1
+    assert pr.prove(t, pis) == got  # deterministic
+    pr.close()
+
+
+def test_stark_device_resident_trace(nlx, ctx, orc):
+    import torch
+    S = nlx.stark
+    air, t, pis = make_case(S, "wide16", 9)
+    st = S.Stark(air, 9)
+    pr = st.build(ctx)
+    d_t = torch.from_numpy(t.view(np.int64)).to("cuda:0")
+    assert pr.prove(d_t, pis) == orc.stark_prove(st.desc, t, pis)
+    pr.close()
+
+
+def test_stark_large_trace_verifies(nlx, ctx, orc):
+    """2^16 rows x 64 columns: too slow to compare against a full oracle prove in the test budget on a
+    small host; the oracle's verifier (size-independent check) must accept the GPU proof."""
+    S = nlx.stark
+    air = S.wide_air(64, seed=2)
+    t, pis = S.wide_trace(air, 16, seed=3)
+    st = S.Stark(air, 16)
+    pr = st.build(ctx)
+    proof = pr.prove(t, pis)
+    assert orc.stark_verify(st.desc, proof) == 1
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 4
+    assert orc.stark_verify(st.desc, bytes(bad)) != 1
+    names = [n for n, _ in pr.stage_times()]
+    assert names[0] == "commit_trace" and "fri_queries" in names
+    pr.close()
+
+
+def test_stark_unsatisfied_witness_does_not_verify(nlx, ctx, orc):
+    S = nlx.stark
+    air, t, pis = make_case(S, "wide16", 8)
+    st = S.Stark(air, 8)
+    pr = st.build(ctx)
+    t[5, 17] = (int(t[5, 17]) + 1) % P
+    assert orc.stark_verify(st.desc, pr.prove(t, pis)) != 1
+    pr.close()
+
+
+def test_stark_build_rejects_bad_programs(nlx, ctx):
+    S = nlx.stark
+    air = S.fibonacci_air()
+
+    def build_with(words, **over):
+        st = S.Stark(air, 6)
+        st.program = np.array(words, dtype=np.uint64)
+        st.desc.n_words = len(words)
+        st.desc.program = st.program.ctypes.data_as(type(st.desc.program))
+        for k, v in over.items():
+            setattr(st.desc, k, v)
+        return st.build(ctx)
+
+    good = [int(w) for w in air.compile()]
+    build_with(good).close()
+    with pytest.raises(nlx.NlxError):
+        build_with([S.AIR_ADD | 1 << 8 | 2 << 24 | 3 << 40])          # reads unwritten registers
+    with pytest.raises(nlx.NlxError):
+        build_with([S.AIR_LOCAL | 0 << 8 | 2 << 24])                  # column 2 of a 2-column trace
+    with pytest.raises(nlx.NlxError):
+        build_with([S.AIR_PUBLIC | 0 << 8 | 3 << 24])                 # public input 3 of 3
+    with pytest.raises(nlx.NlxError):
+        build_with([S.AIR_LOCAL | 64 << 8])                           # register 64
+    with pytest.raises(nlx.NlxError):
+        build_with([S.AIR_CONST | 0 << 8])                            # CONST without immediate
+    with pytest.raises(nlx.NlxError):
+        build_with([11])                                              # unknown opcode
+    with pytest.raises(nlx.NlxError):
+        build_with(good, quotient_degree_factor=4)                    # > 2^rate_bits
+    with pytest.raises(nlx.NlxError):
+        build_with(good, quotient_degree_factor=3)                    # not a power of two

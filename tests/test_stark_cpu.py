@@ -1,0 +1,185 @@
+"""CPU tests of the STARK path: the AIR assembler (host logic of the product),
+and the oracle's starky restatement - internal consistency (its verifier accepts what its prover emits,
+rejects tampered proofs and unsatisfied witnesses).  "Parity unpinned": the reference holds no STARK
+proof bytes (oracle/stark.h header)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import P
+
+
+def run_program(words, local, nxt, pis):
+    """Reference interpreter of the AIR register program (python ints): returns [(emit_op, value)]."""
+    reg, out, pc = {}, [], 0
+    while pc < len(words):
+        w = int(words[pc])
+        op, dst, a, b = w & 0xFF, (w >> 8) & 0xFFFF, (w >> 24) & 0xFFFF, (w >> 40) & 0xFFFF
+        if op == 0: reg[dst] = int(local[a])
+        elif op == 1: reg[dst] = int(nxt[a])
+        elif op == 2: reg[dst] = int(pis[a])
+        elif op == 3:
+            pc += 1
+            reg[dst] = int(words[pc]) % P
+        elif op == 4: reg[dst] = (reg[a] + reg[b]) % P
+        elif op == 5: reg[dst] = (reg[a] - reg[b]) % P
+        elif op == 6: reg[dst] = (reg[a] * reg[b]) % P
+        else: out.append((op, reg[a]))
+        pc += 1
+    return out
+
+
+def test_air_compile_semantics(nlx):
+    S = nlx.stark
+    rng = np.random.default_rng(3)
+    air = S.Air(6, 2)
+    l = [air.local(i) for i in range(6)]
+    nx = [air.next(i) for i in range(6)]
+    shared = l[0] * l[1] + 7               # shared sub-expression: computed once
+    air.constraint_transition(nx[0] - shared)
+    air.constraint(shared * l[2] - l[3])
+    air.constraint_first_row(l[4] - air.public(1))
+    air.constraint_last_row(5 - l[5] * l[5])
+    air.constraint_transition((l[0] + l[1]) * (l[2] - 3) * l[3] - nx[1] + air.public(0))
+    air.constraint(l[2])                   # a leaf as root
+    assert air.num_constraints == 6
+    assert air.constraint_degree == 4      # degree-3 product + the transition filter
+    assert air.quotient_degree_factor() == 4
+    words = air.compile()
+    n_mul = sum(1 for w in words if int(w) & 0xFF == 6)
+    assert n_mul == 5                      # l0*l1 once, *l2, l5*l5, two in the last product
+    lo = [int(x) for x in rng.integers(0, P, 6, dtype=np.uint64)]
+    ne = [int(x) for x in rng.integers(0, P, 6, dtype=np.uint64)]
+    pi = [int(x) for x in rng.integers(0, P, 2, dtype=np.uint64)]
+    got = run_program(words, lo, ne, pi)
+    sh = (lo[0] * lo[1] + 7) % P
+    want = [(7, (ne[0] - sh) % P), (10, (sh * lo[2] - lo[3]) % P), (8, (lo[4] - pi[1]) % P), (9, (5 - lo[5] * lo[5]) % P),
+            (7, ((lo[0] + lo[1]) * (lo[2] - 3) * lo[3] - ne[1] + pi[0]) % P), (10, lo[2])]
+    assert got == want
+
+
+def test_air_register_pressure(nlx):
+    S = nlx.stark
+    air = S.Air(128, 0)
+    # a long chain keeps few registers live; 100 independent products summed pairwise must still fit
+    acc = air.local(0)
+    for i in range(1, 128):
+        acc = acc * air.local(i) + air.next(i)
+    air.constraint(acc)
+    words = air.compile()
+    assert max((int(w) >> 8) & 0xFFFF for w in words if int(w) & 0xFF <= 6) < 8
+    # 70 squares summed left to right: post-order evaluation frees operands as it goes
+    wide = S.Air(200, 0)
+    tot = wide.local(0) * wide.local(0)
+    for i in range(1, 70):
+        tot = tot + wide.local(i) * wide.local(i)
+    wide.constraint(tot)
+    assert max((int(w) >> 8) & 0xFFFF for w in wide.compile() if int(w) & 0xFF <= 6) < 8
+    # 70 values that are all still needed later do not fit 64 registers: refused, not miscompiled
+    over = S.Air(200, 0)
+    sq = [over.local(i) * over.local(i) for i in range(70)]
+    s1 = sq[0]
+    for q in sq[1:]:
+        s1 = s1 + q
+    over.constraint(s1)
+    p1 = sq[0]
+    for q in sq[1:]:
+        p1 = p1 * q
+    over.constraint(p1)
+    with pytest.raises(ValueError):
+        over.compile()
+
+
+def test_wide_trace_satisfies_air(nlx):
+    S = nlx.stark
+    air = S.wide_air(16, seed=5)
+    t, pis = S.wide_trace(air, 6, seed=9)
+    words = air.compile()
+    n = t.shape[1]
+    assert t.max() < P
+    for i in (0, 1, n // 2, n - 2, n - 1):
+        for op, v in run_program(words, t[:, i], t[:, (i + 1) % n], pis):
+            if op == 7 and i == n - 1:
+                continue  # transition constraints are off on the last row
+            if op == 8 and i != 0:
+                continue
+            if op == 9 and i != n - 1:
+                continue
+            assert v == 0, (i, op)
+
+
+def _tamper_offsets(n):
+    return (5, 600, 1100, n // 3, n // 2, (2 * n) // 3, n - 100, n - 30, n - 3)
+
+
+@pytest.mark.parametrize("kind,db,cfg", [
+    ("fib", 5, {}),                                   # no FRI reduction round, quotient factor 1
+    ("fib", 9, {}),
+    ("fib", 7, dict(num_challenges=1, fri_arity_bits=3, fri_num_queries=20, fri_pow_bits=8, cap_height=2)),
+    ("wide16", 6, {}),                                # quotient factor 2 = 2^rate_bits
+    ("wide16", 10, {}),
+    ("wide16", 8, dict(rate_bits=2, fri_arity_bits=2, fri_final_poly_bits=3, fri_num_queries=30)),  # factor 2 < 2^rate_bits
+    ("deg4", 8, dict(rate_bits=2)),                   # quotient factor 3 -> 4
+    ("deg4", 9, dict(rate_bits=3, fri_num_queries=28)),
+])
+def test_stark_prove_verify_roundtrip(nlx, orc, kind, db, cfg):
+    S = nlx.stark
+    air, t, pis = make_case(S, kind, db)
+    st = S.Stark(air, db, S.StarkConfig(**cfg))
+    proof = orc.stark_prove(st.desc, t, pis)
+    assert orc.stark_verify(st.desc, proof) == 1
+    for off in _tamper_offsets(len(proof)):
+        bad = bytearray(proof)
+        bad[off] ^= 1
+        assert orc.stark_verify(st.desc, bytes(bad)) != 1, off
+    assert orc.stark_verify(st.desc, proof[:-8]) != 1
+    assert orc.stark_verify(st.desc, proof + b"\0" * 8) != 1
+    # an unsatisfied witness does not verify
+    t2 = t.copy()
+    t2[1, 3] = (int(t2[1, 3]) + 1) % P
+    assert orc.stark_verify(st.desc, orc.stark_prove(st.desc, t2, pis)) != 1
+    # wrong public input
+    pis2 = pis.copy()
+    pis2[0] = (int(pis2[0]) + 1) % P
+    assert orc.stark_verify(st.desc, orc.stark_prove(st.desc, t, pis2)) != 1
+
+
+def make_case(S, kind, db):
+    if kind == "fib":
+        air = S.fibonacci_air()
+        t, pis = S.fibonacci_trace(db, 3, 5)
+    elif kind.startswith("wide"):
+        air = S.wide_air(int(kind[4:]), seed=db)
+        t, pis = S.wide_trace(air, db, seed=db + 1)
+    elif kind == "deg4":
+        # x' = x^3 + y, y' = y + 1 : transition degree 3 (+1 for the filter) -> quotient factor 3 -> 4
+        air = S.Air(2, 1)
+        x, y = air.local(0), air.local(1)
+        air.constraint_transition(air.next(0) - (x * x * x + y))
+        air.constraint_transition(air.next(1) - (y + 1))
+        air.constraint_first_row(x - air.public(0))
+        n = 1 << db
+        t = np.zeros((2, n), dtype=np.uint64)
+        a, b = 11, 2
+        for i in range(n):
+            t[0, i], t[1, i] = a, b
+            a, b = (a * a * a + b) % P, (b + 1) % P
+        pis = np.array([11], dtype=np.uint64)
+    else:
+        raise KeyError(kind)
+    return air, t, pis
+
+
+def test_stark_abi_rejects_null(nlx):
+    """No GPU here: only the argument checks that run before any device call."""
+    d = nlx.lib.dll
+    assert d.nlx_stark_build(None, None, None) != 0
+    assert d.nlx_stark_proof_max_bytes(None) == 0
+    n = ctypes.c_size_t()
+    assert d.nlx_stark_prove(None, None, None, None, 0, ctypes.byref(n)) != 0
+    k1 = np.ones(1, dtype=np.uint64)
+    t = np.zeros((4, 8), dtype=np.uint64)
+    pis = np.zeros(2, dtype=np.uint64)
+    assert d.nlx_synth_stark_trace(3, 3, 1, k1.ctypes.data, t.ctypes.data, pis.ctypes.data) != 0  # n_cols % 4
+    assert d.nlx_synth_stark_trace(4, 3, 1, k1.ctypes.data, t.ctypes.data, pis.ctypes.data) == 0
