@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sync", choices=["sync", "verify128"])
+    ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark"])
+    ap.add_argument("--stark-cols", type=int, default=256)
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3,
@@ -225,6 +226,108 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
     return out
 
 
+def run_stark(args, nlx, torch, rank, world, local, dist):
+    """Secondary workload: one starky-style proof of the synthetic wide AIR
+    (--stark-cols columns x 2^--log-n rows, StarkConfig::standard_fast_config) per step, `inflight`
+    independent proofs concurrently (one context + host thread each; ctypes releases the GIL)."""
+    import threading
+    import numpy as np
+    S = nlx.stark
+    air = S.wide_air(args.stark_cols, seed=7)
+    t, pis = S.wide_trace(air, args.log_n, seed=11 + rank)
+    st = S.Stark(air, args.log_n)
+    d_t = torch.from_numpy(t.view(np.int64)).cuda()
+    n_workers = max(1, min(args.inflight, args.steps))
+    ctxs = [nlx.Context(local) for _ in range(n_workers)]
+    prs = [st.build(c) for c in ctxs]
+    pis_ptr = pis.ctypes.data
+    for pr in prs:
+        for _ in range(args.warmup):
+            pr.prove_into(d_t, pis_ptr)
+    for c in ctxs:
+        c.kernel_timing(True)
+    counter = iter(range(args.steps))
+    lock = threading.Lock()
+
+    def worker(pr):
+        while True:
+            with lock:
+                i = next(counter, None)
+            if i is None:
+                return
+            pr.prove_into(d_t, pis_ptr)
+
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=worker, args=(pr,)) for pr in prs]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    barrier(dist, torch)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    names = ("intt", "lde", "hash_lde_leaves", "merkle_levels", "air_quotient", "fri_combine")
+    kstats = {k: [0, 0.0, 0.0] for k in names}
+    for c in ctxs:
+        for k in names:
+            n_, ms_, b_ = c.kernel_stats(k)
+            kstats[k][0] += n_
+            kstats[k][1] += ms_
+            kstats[k][2] += b_
+        c.kernel_timing(False)
+    stages = prs[0].stage_times()
+    out = None
+    if rank == 0:
+        calls, ms, alg = kstats["hash_lde_leaves"]
+        achieved = (alg / calls) / (ms / calls * 1e-3) / 1e9 if calls else 0.0
+        proof = prs[0].prove(d_t, pis)
+        out = {
+            "metric": "STARK proofs/sec (starky-style, secondary workload)", "value": world * args.steps / dt,
+            "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
+            "config": {"workload": "starky-style STARK of the synthetic wide AIR: %d columns x 2^%d rows, degree-3 "
+                                   "constraints, standard_fast_config (rate 2, 84 queries, 16 PoW bits), replicas only"
+                                   % (args.stark_cols, args.log_n),
+                       "air_program_words": int(st.desc.n_words), "constraints": air.num_constraints,
+                       "proof_bytes": len(proof), "proofs_in_flight_per_gpu": n_workers, "trace": "resident in HBM"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_hash_lde_leaves",
+                         "launches": calls, "avg_launch_ms": ms / calls if calls else None,
+                         "alg_bytes_per_launch": alg / calls if calls else None},
+            "stage_ms_last_proof": {k: round(v, 3) for k, v in stages},
+            "kernel_ms_per_proof": {k: round(v[1] / args.steps, 3) for k, v in kstats.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py
+            cores = min(len(os.sched_getaffinity(0)), 16)
+            os.environ["OMP_NUM_THREADS"] = str(cores)
+            s_log = max(args.log_n - 3, 8)
+            t2, pis2 = S.wide_trace(air, s_log, seed=5)
+            st2 = S.Stark(air, s_log)
+            tc = time.time()
+            pr2 = oracle_py.stark_prove(st2.desc, t2, pis2)
+            dtc = time.time() - tc
+            ok = oracle_py.stark_verify(st2.desc, pr2) == 1
+            scale = 2.0 ** (args.log_n - s_log)
+            out["cpu_baseline"] = {"value": 1.0 / (dtc * scale), "unit": "proofs/s", "cores": cores, "kind": "port",
+                                   "sample": "1 proof at 2^%d rows in %.2f s, scaled linearly in rows; oracle verifier "
+                                             "accepted: %s; GPU proof accepted: %s"
+                                             % (s_log, dtc, ok, oracle_py.stark_verify(st.desc, proof) == 1)}
+        else:
+            out["cpu_baseline"] = None
+    for pr in prs:
+        pr.close()
+    for c in ctxs:
+        c.close()
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -235,6 +338,8 @@ def main():
     nlx = nlxpkg.load()
     if args.workload == "sync":
         out = run_sync(args, nlx, torch, rank, world, local, dist)
+    elif args.workload == "stark":
+        out = run_stark(args, nlx, torch, rank, world, local, dist)
     else:
         from importlib import import_module
         mr = import_module("nlx_amd.mapreduce")
