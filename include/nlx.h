@@ -260,7 +260,9 @@ int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint6
 #define NLX_AIR_EMIT_FIRST 8       /* constraint_first_row(r[a]): times L_0(x) */
 #define NLX_AIR_EMIT_LAST 9        /* constraint_last_row(r[a]): times L_{n-1}(x) */
 #define NLX_AIR_EMIT 10            /* constraint(r[a]) on every row */
+#define NLX_AIR_PERIODIC 11        /* r[dst] = periodic column a at this row (values[a][row mod period]) */
 #define NLX_AIR_NUM_REGS 64
+#define NLX_AIR_MAX_PERIODIC 16
 
 typedef struct {
     uint32_t degree_bits;
@@ -276,6 +278,13 @@ typedef struct {
     uint32_t num_public_inputs;       /* Stark::PUBLIC_INPUTS */
     uint32_t n_words;
     const uint64_t* program;          /* host */
+    /* Periodic columns (round constants, round selectors): known to the verifier, not committed.  Column a
+     * has the value periodic[a * period + (row mod period)], period = 2^period_bits <= n; as a polynomial it
+     * is P_a(x^(n/period)) with P_a the interpolation over the period-th roots of unity (degree < n, counts
+     * as degree 1 in the constraint degree). */
+    uint32_t n_periodic;              /* <= NLX_AIR_MAX_PERIODIC */
+    uint32_t period_bits;
+    const uint64_t* periodic;         /* host, n_periodic x period */
 } nlx_stark_desc;
 typedef struct nlx_stark nlx_stark;
 
@@ -288,6 +297,15 @@ size_t nlx_stark_proof_max_bytes(const nlx_stark* s);
 int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* public_inputs, uint8_t* proof_out,
                         size_t proof_cap, size_t* proof_len);
 int32_t nlx_stark_stage_times(const nlx_stark* s, uint32_t* n_stages, const char** names_out, float* ms_out);
+/* f.1: trace generation on the GPU for the SHA-256 compression AIR (column layout and constraints:
+ * near-light-client_amd/sha256_air.py; callers in the reference: curta_sha256 at nearx/src/merkle.rs:49,
+ * nearx/src/variables.rs:71-72).  blocks: 2^log_blocks padded 512-bit blocks as 16 big-endian-decoded words
+ * each; is_first[b] != 0 where block b starts a new message (block 0 always does).  Writes the
+ * NLX_SHA256_COLS x (64 << log_blocks) column-major trace (host or device buffer) and, if digest_out is
+ * not NULL, the eight words of the last block's output chaining value (the AIR's public inputs). */
+#define NLX_SHA256_COLS 302
+int32_t nlx_sha256_trace(nlx_ctx* ctx, const uint32_t* blocks, const uint8_t* is_first, uint32_t log_blocks,
+                         uint64_t* trace_out, uint64_t digest_out[8]);
 /* Synthetic wide-AIR witness (inputs only): n_cols (multiple of 4) x n column-major host buffer, k1 = the
  * n_cols/4 per-group constants of the AIR, public_inputs[2] = first-row values of columns 0 and 1. */
 int32_t nlx_synth_stark_trace(uint32_t n_cols, uint32_t log_n, uint64_t seed, const uint64_t* k1, uint64_t* trace,

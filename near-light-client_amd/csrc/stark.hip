@@ -32,11 +32,12 @@ struct AirParams {
     const uint64_t* coset_base; // device: g * w_{n q}^r', r' < q = 2^qdb
     const uint64_t* zh_inv;     // device: 1 / Z_H on quotient coset r'
     const uint64_t* l_inv;      // device: 1 / (n (x - 1)) on the quotient cosets, [r'][k]
+    const uint64_t* periodic;   // device: [column][r'][k mod period] = P_a((g w^r')^(n/period) * w_period^k)
     const uint64_t* w_n_table;
     uint64_t* out;              // [challenge][r'][k]
     uint64_t alphas[2];
     uint64_t g_inv;             // last = g^-1 (g generates the size-n subgroup)
-    uint32_t log_n, rate_bits, qdb, n_words, nc, n_regs;
+    uint32_t log_n, rate_bits, qdb, n_words, nc, n_regs, period_bits;
 };
 
 static __device__ __forceinline__ uint64_t root_pow_(const uint64_t* __restrict__ half_table, uint32_t e, uint32_t half) {
@@ -75,6 +76,9 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
             case NLX_AIR_LOCAL: my[dst * bd] = p.trace[(size_t)a * L + row]; continue;
             case NLX_AIR_NEXT: my[dst * bd] = p.trace[(size_t)a * L + row_next]; continue;
             case NLX_AIR_PUBLIC: my[dst * bd] = p.pis[a]; continue;
+            case NLX_AIR_PERIODIC:
+                my[dst * bd] = p.periodic[((((size_t)a << p.qdb) + rq) << p.period_bits) + (k & ((1u << p.period_bits) - 1))];
+                continue;
             case NLX_AIR_CONST: my[dst * bd] = p.program[++pc]; continue;
             case NLX_AIR_ADD: my[dst * bd] = gl::add(my[a * bd], my[b * bd]); continue;
             case NLX_AIR_SUB: my[dst * bd] = gl::sub(my[a * bd], my[b * bd]); continue;
@@ -105,6 +109,8 @@ struct nlx_stark {
     uint64_t *d_coset_base = nullptr, *d_q_coset_base = nullptr, *d_q_zh_inv = nullptr, *d_q_wR_inv = nullptr,
              *d_q_chunk_scale = nullptr, *d_wA_inv = nullptr;
     uint64_t* d_l_inv = nullptr;               // [2^qdb][n]
+    uint64_t* d_periodic = nullptr;            // [n_periodic][2^qdb][period]
+    std::vector<uint64_t> periodic;            // canonicalised host copy
     const uint64_t* d_q_inv_scale_br = nullptr;  // ctx-owned
     hipEvent_t ev[NLX_MAX_STAGES + 1]{};
     const char* stage_names[NLX_MAX_STAGES]{};
@@ -142,6 +148,8 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
         return ctx->fail(NLX_E_RANGE, "FRI parameters out of range");
     if (d.n_cols == 0 || d.n_cols > 4096 || d.num_public_inputs > 4096 || d.n_words > (1u << 20))
         return ctx->fail(NLX_E_RANGE, "AIR shape out of range");
+    if (d.n_periodic > NLX_AIR_MAX_PERIODIC || (d.n_periodic && (!d.periodic || d.period_bits > d.degree_bits || d.period_bits > 12)))
+        return ctx->fail(NLX_E_RANGE, "periodic columns out of range");
     // program validation: opcodes, operand ranges, no register read before it is written
     std::vector<uint64_t> prog(d.program, d.program + d.n_words);
     uint32_t n_regs = 1;
@@ -151,12 +159,13 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
             const uint64_t w = prog[pc];
             const uint32_t op = (uint32_t)(w & 0xFF), dst = (uint32_t)((w >> 8) & 0xFFFF);
             const uint32_t a = (uint32_t)((w >> 24) & 0xFFFF), b = (uint32_t)((w >> 40) & 0xFFFF);
-            if (op > NLX_AIR_EMIT) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
-            const bool writes = op <= NLX_AIR_MUL;
+            if (op > NLX_AIR_PERIODIC) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
+            const bool writes = op <= NLX_AIR_MUL || op == NLX_AIR_PERIODIC;
             if (writes && dst >= NLX_AIR_NUM_REGS) return ctx->fail(NLX_E_INVAL, "AIR word %u: register out of range", pc);
             if ((op == NLX_AIR_LOCAL || op == NLX_AIR_NEXT) && a >= d.n_cols) return ctx->fail(NLX_E_INVAL, "AIR word %u: column out of range", pc);
             if (op == NLX_AIR_PUBLIC && a >= d.num_public_inputs) return ctx->fail(NLX_E_INVAL, "AIR word %u: public input out of range", pc);
-            if (op >= NLX_AIR_ADD) {
+            if (op == NLX_AIR_PERIODIC && a >= d.n_periodic) return ctx->fail(NLX_E_INVAL, "AIR word %u: periodic column out of range", pc);
+            if (op >= NLX_AIR_ADD && op <= NLX_AIR_EMIT) {
                 const bool two_src = op <= NLX_AIR_MUL;
                 if (a >= NLX_AIR_NUM_REGS || !written[a] || (two_src && (b >= NLX_AIR_NUM_REGS || !written[b])))
                     return ctx->fail(NLX_E_INVAL, "AIR word %u: reads an unwritten register", pc);
@@ -213,6 +222,39 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
         s->d_q_chunk_scale = s->d_q_wR_inv + Q;
         s->d_wA_inv = s->d_small + 4 * R + 4 * Q;
         launch_l0_table(ctx->stream, s->d_l_inv, log_n, s->qdb, s->d_q_coset_base, ctx->tables.fwd[log_n]);
+        if (d.n_periodic) {
+            // P_a = interpolation of column a over the period-th roots of unity (naive inverse DFT: tiny), then
+            // its values at y = (g w_{nQ}^r')^(n/period) * w_period^k for every quotient coset r' and k < period
+            const uint32_t period = 1u << d.period_bits;
+            s->periodic.assign(d.periodic, d.periodic + (size_t)d.n_periodic * period);
+            for (auto& v : s->periodic) v %= gl::P;
+            s->d.periodic = s->periodic.data();
+            const uint64_t w_p = gl::root_of_unity(d.period_bits), w_p_inv = gl::inv(w_p), p_inv = gl::inv((uint64_t)period);
+            std::vector<uint64_t> coeffs(period), table((size_t)d.n_periodic * Q * period), wpow(period), winv(period);
+            wpow[0] = winv[0] = 1;
+            for (uint32_t i = 1; i < period; i++) { wpow[i] = gl::mul(wpow[i - 1], w_p); winv[i] = gl::mul(winv[i - 1], w_p_inv); }
+            for (uint32_t a = 0; a < d.n_periodic; a++) {
+                const uint64_t* v = s->periodic.data() + (size_t)a * period;
+                for (uint32_t m = 0; m < period; m++) {
+                    uint64_t acc = 0;
+                    for (uint32_t j = 0; j < period; j++) acc = gl::add(acc, gl::mul(v[j], winv[(uint32_t)(((uint64_t)m * j) & (period - 1))]));
+                    coeffs[m] = gl::mul(acc, p_inv);
+                }
+                for (uint32_t r = 0; r < Q; r++) {
+                    const uint64_t base = gl::exp_pow2(small[4 * R + r], log_n - d.period_bits);  // (g w^r')^(n/period)
+                    for (uint32_t k = 0; k < period; k++) {
+                        const uint64_t y = gl::mul(base, wpow[k]);
+                        uint64_t acc = 0;
+                        for (uint32_t m = period; m-- > 0;) acc = gl::add(gl::mul(acc, y), coeffs[m]);
+                        table[((size_t)a * Q + r) * period + k] = acc;
+                    }
+                }
+            }
+            s->d_periodic = (uint64_t*)ctx->alloc(table.size() * 8);
+            if (!s->d_periodic) return fail(NLX_E_NOMEM);
+            hipError_t e2 = hipMemcpy(s->d_periodic, table.data(), table.size() * 8, hipMemcpyHostToDevice);
+            if (e2 != hipSuccess) return fail(ctx->hip_fail(e2, "hipMemcpy(periodic)"));
+        }
     }
     for (int i = 0; i <= NLX_MAX_STAGES; i++)
         if (hipEventCreate(&s->ev[i]) != hipSuccess) return fail(ctx->fail(NLX_E_HIP, "hipEventCreate failed"));
@@ -229,6 +271,7 @@ void nlx_stark_destroy(nlx_stark* s) {
     ctx->release(s->d_small);
     ctx->release(s->d_program);
     ctx->release(s->d_l_inv);
+    ctx->release(s->d_periodic);
     for (int i = 0; i <= NLX_MAX_STAGES; i++)
         if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
     delete s;
@@ -315,6 +358,7 @@ int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* pub
             AirParams ap{};
             ap.trace = ct->lde; ap.program = s->d_program; ap.pis = d_pis;
             ap.coset_base = s->d_q_coset_base; ap.zh_inv = s->d_q_zh_inv; ap.l_inv = s->d_l_inv;
+            ap.periodic = s->d_periodic; ap.period_bits = d.period_bits;
             ap.w_n_table = ctx->tables.fwd[log_n];
             ap.out = d_qvals;
             ap.alphas[0] = alphas[0]; ap.alphas[1] = alphas[1];

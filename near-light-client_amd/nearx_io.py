@@ -49,6 +49,16 @@ def header_hash(block_view):
     return hashlib.sha256(lite_rest + b58decode32(block_view["prev_block_hash"])).digest()
 
 
+def header_hash_preimages(fixture_or_view):
+    """The three SHA-256 preimages behind header_hash, in evaluation order (each hash feeds the next): what
+    curta_sha256 is asked to prove for one header (nearx/src/variables.rs:66-73)."""
+    view = fixture_or_view.get("body", fixture_or_view)
+    m0 = inner_lite_bytes(view["inner_lite"])
+    m1 = hashlib.sha256(m0).digest() + b58decode32(view["inner_rest_hash"])
+    m2 = hashlib.sha256(m1).digest() + b58decode32(view["prev_block_hash"])
+    return [m0, m1, m2]
+
+
 def load_fixture(path):
     """LightClientFixture { last_block_hash, body } (crates/test-utils/src/lib.rs:11-15)"""
     with open(path) as f:

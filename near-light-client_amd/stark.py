@@ -19,7 +19,7 @@ from ._lib import dll, ptr, NlxError
 
 P = 0xFFFFFFFF00000001
 (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_CONST, AIR_ADD, AIR_SUB, AIR_MUL, AIR_EMIT_TRANSITION, AIR_EMIT_FIRST,
- AIR_EMIT_LAST, AIR_EMIT) = range(11)
+ AIR_EMIT_LAST, AIR_EMIT, AIR_PERIODIC) = range(12)
 AIR_NUM_REGS = 64
 
 
@@ -28,7 +28,8 @@ class StarkDesc(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint32) for k in (
         "degree_bits", "n_cols", "num_challenges", "rate_bits", "cap_height", "quotient_degree_factor",
         "fri_pow_bits", "fri_num_queries", "fri_arity_bits", "fri_final_poly_bits", "num_public_inputs",
-        "n_words")] + [("program", ctypes.POINTER(ctypes.c_uint64))]
+        "n_words")] + [("program", ctypes.POINTER(ctypes.c_uint64)), ("n_periodic", ctypes.c_uint32),
+                       ("period_bits", ctypes.c_uint32), ("periodic", ctypes.POINTER(ctypes.c_uint64))]
 
 
 class StarkConfig:
@@ -88,6 +89,8 @@ class Air:
         self.num_public_inputs = num_public_inputs
         self._emits = []  # (op, expr)
         self._leaf_cache = {}
+        self.period_bits = 0
+        self._periodic = []  # value arrays, each of length 2^period_bits
 
     def _leaf(self, op, idx, degree):
         key = (op, idx)
@@ -109,6 +112,17 @@ class Air:
 
     def const(self, v):
         return self._leaf(AIR_CONST, int(v) % P, 0)
+
+    def periodic(self, values):
+        """A verifier-computable column repeating `values` (length a power of two, the same for every
+        periodic column of the AIR) down the trace - round constants, round selectors.  Degree 1."""
+        values = [int(v) % P for v in values]
+        bits = (len(values) - 1).bit_length()
+        if len(values) != 1 << bits or (self._periodic and bits != self.period_bits):
+            raise ValueError("periodic columns must share one power-of-two period")
+        self.period_bits = bits
+        self._periodic.append(np.array(values, dtype=np.uint64))
+        return self._leaf(AIR_PERIODIC, len(self._periodic) - 1, 1)
 
     # ConstraintConsumer
     def constraint_transition(self, e):
@@ -142,9 +156,12 @@ class Air:
         return 1 << (q - 1).bit_length()
 
     def compile(self):
-        """Flatten the DAG into program words.  Shared sub-expressions are evaluated once and kept in
-        their register until the last use; trace / public / constant leaves are re-loaded per constraint
-        so live ranges stay short.  Constraints are emitted in declaration order (alpha powers)."""
+        """Flatten the DAG into program words.  Shared sub-expressions (ADD/SUB/MUL nodes) are evaluated once
+        and stay in their register until the last use.  Leaves (trace / public / periodic / constant loads)
+        are loaded at their first use inside a constraint, kept while registers last and otherwise evicted
+        (least recently used first) and simply re-loaded - they are rematerialisable, so register pressure
+        only ever comes from live sub-expressions.  Constraints are emitted in declaration order (alpha
+        powers)."""
         ops = (AIR_ADD, AIR_SUB, AIR_MUL)
         computed, per_emit, all_ops = set(), [], []
         for _, root in self._emits:
@@ -154,17 +171,15 @@ class Air:
                 if done:
                     nodes.append(x)
                     continue
-                if id(x) in seen or (x.op in ops and id(x) in computed):
+                if x.op not in ops or id(x) in seen or id(x) in computed:
                     continue
                 seen.add(id(x))
                 stack.append((x, True))
-                if x.op in ops:
-                    stack.append((x.b, False))
-                    stack.append((x.a, False))
+                stack.append((x.b, False))
+                stack.append((x.a, False))
             for x in nodes:
-                if x.op in ops:
-                    computed.add(id(x))
-                    all_ops.append(x)
+                computed.add(id(x))
+                all_ops.append(x)
             per_emit.append(nodes)
         for x in all_ops:
             x.uses, x.reg = 0, None
@@ -178,45 +193,69 @@ class Air:
 
         words = []
         free = list(range(AIR_NUM_REGS - 1, -1, -1))
+        resident = []  # leaves currently holding a register, least recently used first
 
-        def alloc():
-            if not free:
-                raise ValueError("AIR needs more than %d live registers" % AIR_NUM_REGS)
-            return free.pop()
+        def alloc(pinned=()):
+            if free:
+                return free.pop()
+            for i, y in enumerate(resident):
+                if not any(y is q for q in pinned):
+                    resident.pop(i)
+                    r, y.reg = y.reg, None
+                    return r
+            raise ValueError("AIR needs more than %d live registers" % AIR_NUM_REGS)
 
-        def release(x):
-            x.uses -= 1
-            if x.uses == 0:
-                free.append(x.reg)
-                x.reg = None
+        def ensure(y, pinned=()):
+            if y.op in ops:
+                return y.reg
+            if y.reg is None:
+                y.reg = alloc(pinned)
+                if y.op == AIR_CONST:
+                    words.append(AIR_CONST | y.reg << 8)
+                    words.append(y.a)
+                else:
+                    words.append(y.op | y.reg << 8 | y.a << 24)
+            else:
+                resident[:] = [q for q in resident if q is not y]
+            resident.append(y)
+            return y.reg
+
+        def release(y):
+            y.uses -= 1
+            if y.uses == 0:
+                if y.reg is not None:
+                    free.append(y.reg)
+                y.reg = None
+                if y.op not in ops:
+                    resident[:] = [q for q in resident if q is not y]
 
         for (op, root), nodes in zip(self._emits, per_emit):
-            for x in nodes:  # leaves: uses within this constraint only
-                if x.op not in ops:
-                    x.uses, x.reg = 0, None
+            # leaf use counts within this constraint
+            leaves = {}
             for x in nodes:
-                if x.op in ops:
-                    for y in (x.a, x.b):
-                        if y.op not in ops:
-                            y.uses += 1
+                for y in (x.a, x.b):
+                    if y.op not in ops:
+                        leaves[id(y)] = y
+            if root.op not in ops:
+                leaves[id(root)] = root
+            for y in leaves.values():
+                y.uses, y.reg = 0, None
+            for x in nodes:
+                for y in (x.a, x.b):
+                    if y.op not in ops:
+                        y.uses += 1
             if root.op not in ops:
                 root.uses += 1
             for x in nodes:
-                if x.op in ops:
-                    ra, rb = x.a.reg, x.b.reg
-                    release(x.a)
-                    release(x.b)
-                    x.reg = alloc()
-                    words.append(x.op | x.reg << 8 | ra << 24 | rb << 40)
-                else:
-                    x.reg = alloc()
-                    if x.op == AIR_CONST:
-                        words.append(AIR_CONST | x.reg << 8)
-                        words.append(x.a)
-                    else:
-                        words.append(x.op | x.reg << 8 | x.a << 24)
-            words.append(op | root.reg << 24)
+                ra = ensure(x.a)
+                rb = ensure(x.b, (x.a,))
+                release(x.a)
+                release(x.b)
+                x.reg = alloc()
+                words.append(x.op | x.reg << 8 | ra << 24 | rb << 40)
+            words.append(op | ensure(root) << 24)
             release(root)
+            assert not resident
         return np.array(words, dtype=np.uint64)
 
 
@@ -232,10 +271,14 @@ class Stark:
         qdf = air.quotient_degree_factor()
         if qdf > (1 << cfg.rate_bits):
             raise ValueError("constraint degree %d needs rate_bits >= %d" % (air.constraint_degree, qdf.bit_length() - 1))
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        self.periodic = (np.concatenate(air._periodic) if air._periodic else np.zeros(1, dtype=np.uint64))
+        if air._periodic and air.period_bits > degree_bits:
+            raise ValueError("period longer than the trace")
         self.desc = StarkDesc(degree_bits, air.n_cols, cfg.num_challenges, cfg.rate_bits, cfg.cap_height, qdf,
                               cfg.fri_pow_bits, cfg.fri_num_queries, cfg.fri_arity_bits, cfg.fri_final_poly_bits,
-                              air.num_public_inputs, len(self.program),
-                              self.program.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+                              air.num_public_inputs, len(self.program), self.program.ctypes.data_as(u64p),
+                              len(air._periodic), air.period_bits, self.periodic.ctypes.data_as(u64p))
         self.degree_bits = degree_bits
 
     def build(self, ctx):

@@ -304,7 +304,8 @@ done:
 
 /* ConstraintConsumer over the base field: acc_j = acc_j * alpha_j + c */
 static void air_eval_base(const orc_stark_desc* d, const uint64_t* local, const uint64_t* next, const uint64_t* pis,
-                          uint64_t z_last, uint64_t l_first, uint64_t l_last, const uint64_t* alphas, uint64_t* accs) {
+                          const uint64_t* per, uint64_t z_last, uint64_t l_first, uint64_t l_last, const uint64_t* alphas,
+                          uint64_t* accs) {
     uint64_t reg[AIR_REGS] = {0};
     for (uint32_t j = 0; j < d->num_challenges; j++) accs[j] = 0;
     for (uint32_t pc = 0; pc < d->n_words; pc++) {
@@ -316,6 +317,7 @@ static void air_eval_base(const orc_stark_desc* d, const uint64_t* local, const 
             case ORC_AIR_LOCAL: reg[dst] = local[a]; break;
             case ORC_AIR_NEXT: reg[dst] = next[a]; break;
             case ORC_AIR_PUBLIC: reg[dst] = pis[a]; break;
+            case ORC_AIR_PERIODIC: reg[dst] = per[a]; break;
             case ORC_AIR_CONST: reg[dst] = d->program[++pc] % GL_P; break;
             case ORC_AIR_ADD: reg[dst] = gl_add(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
             case ORC_AIR_SUB: reg[dst] = gl_sub(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
@@ -330,8 +332,8 @@ static void air_eval_base(const orc_stark_desc* d, const uint64_t* local, const 
             for (uint32_t j = 0; j < d->num_challenges; j++) accs[j] = gl_add(gl_mul(accs[j], alphas[j]), c);
     }
 }
-static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* next, const uint64_t* pis, gl2 z_last,
-                         gl2 l_first, gl2 l_last, const uint64_t* alphas, gl2* accs) {
+static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* next, const uint64_t* pis, const gl2* per,
+                         gl2 z_last, gl2 l_first, gl2 l_last, const uint64_t* alphas, gl2* accs) {
     gl2 reg[AIR_REGS];
     for (int i = 0; i < AIR_REGS; i++) reg[i] = gl2_from(0);
     for (uint32_t j = 0; j < d->num_challenges; j++) accs[j] = gl2_from(0);
@@ -344,6 +346,7 @@ static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* n
             case ORC_AIR_LOCAL: reg[dst] = local[a]; break;
             case ORC_AIR_NEXT: reg[dst] = next[a]; break;
             case ORC_AIR_PUBLIC: reg[dst] = gl2_from(pis[a]); break;
+            case ORC_AIR_PERIODIC: reg[dst] = per[a]; break;
             case ORC_AIR_CONST: reg[dst] = gl2_from(d->program[++pc] % GL_P); break;
             case ORC_AIR_ADD: reg[dst] = gl2_add(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
             case ORC_AIR_SUB: reg[dst] = gl2_sub(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
@@ -359,17 +362,31 @@ static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* n
     }
 }
 
+#define ORC_MAX_PERIODIC 16
+/* interpolation of each periodic column over the period-th roots of unity (coefficients, natural order) */
+static uint64_t* periodic_coeffs(const orc_stark_desc* d) {
+    if (!d->n_periodic) return NULL;
+    const size_t period = (size_t)1 << d->period_bits;
+    uint64_t* c = (uint64_t*)malloc(8 * period * d->n_periodic);
+    for (size_t i = 0; i < period * d->n_periodic; i++) c[i] = d->periodic[i] % GL_P;
+    for (uint32_t a = 0; a < d->n_periodic; a++) orc_ifft(c + a * period, d->period_bits);
+    return c;
+}
+
 static int desc_ok(const orc_stark_desc* d) {
     uint32_t q = d->quotient_degree_factor;
     if (!q || (q & (q - 1)) || q > (1u << d->rate_bits)) return 0;
     if (d->num_challenges < 1 || d->num_challenges > 2 || d->n_cols == 0) return 0;
+    if (d->n_periodic > ORC_MAX_PERIODIC) return 0;
+    if (d->n_periodic && (d->period_bits > d->degree_bits || d->period_bits > 12 || !d->periodic)) return 0;
     for (uint32_t pc = 0; pc < d->n_words; pc++) {
         uint64_t w = d->program[pc];
         switch (AIR_OP(w)) {
             case ORC_AIR_LOCAL: case ORC_AIR_NEXT: if (AIR_A(w) >= d->n_cols) return 0; break;
             case ORC_AIR_PUBLIC: if (AIR_A(w) >= d->num_public_inputs) return 0; break;
+            case ORC_AIR_PERIODIC: if (AIR_A(w) >= d->n_periodic) return 0; break;
             case ORC_AIR_CONST: if (++pc >= d->n_words) return 0; break;
-            default: if (AIR_OP(w) > ORC_AIR_EMIT) return 0;
+            default: if (AIR_OP(w) > ORC_AIR_PERIODIC) return 0;
         }
     }
     return 1;
@@ -410,6 +427,7 @@ size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uin
     const size_t size = n << qdb, step = (size_t)1 << (d->rate_bits - qdb), next_step = (size_t)1 << qdb;
     const unsigned log_size = log_n + qdb;
     uint64_t* qvals = (uint64_t*)malloc(8 * size * nc);
+    uint64_t* per_coeffs = periodic_coeffs(d);
     {
         const uint64_t g = gl_root_of_unity(log_n), last = gl_inv(g);
         const uint64_t w_s = gl_root_of_unity(log_size);
@@ -421,8 +439,18 @@ size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uin
             uint64_t l_first = gl_mul(zh, gl_inv(gl_mul(n_f, gl_sub(x, 1))));
             uint64_t l_last = gl_mul(zh, gl_inv(gl_mul(n_f, gl_sub(gl_mul(g, x), 1))));
             size_t li = gl_bitrev(i * step, log_L), ln = gl_bitrev(((i + next_step) % size) * step, log_L);
-            uint64_t accs[4];
-            air_eval_base(d, t_leaves + li * ncols, t_leaves + ln * ncols, public_inputs, gl_sub(x, last), l_first, l_last, alphas, accs);
+            uint64_t accs[4], per[ORC_MAX_PERIODIC];
+            if (d->n_periodic) {
+                /* P_a(x^(n/period)) by Horner */
+                const size_t period = (size_t)1 << d->period_bits;
+                uint64_t y = gl_exp_pow2(x, log_n - d->period_bits);
+                for (uint32_t a = 0; a < d->n_periodic; a++) {
+                    uint64_t acc = 0;
+                    for (size_t m = period; m-- > 0;) acc = gl_add(gl_mul(acc, y), per_coeffs[a * period + m]);
+                    per[a] = acc;
+                }
+            }
+            air_eval_base(d, t_leaves + li * ncols, t_leaves + ln * ncols, public_inputs, per, gl_sub(x, last), l_first, l_last, alphas, accs);
             uint64_t zh_inv = gl_inv(zh);
             for (uint32_t j = 0; j < nc; j++) qvals[(size_t)j * size + i] = gl_mul(accs[j], zh_inv);
         }
@@ -433,6 +461,7 @@ size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uin
         memcpy(q_coeffs + (size_t)j * qdf * n, qvals + (size_t)j * size, 8 * n * qdf); /* trim_to_len(n * qdf), chunks(n) */
     }
     free(qvals);
+    free(per_coeffs);
     uint64_t* q_leaves = (uint64_t*)malloc(8 * L * nq);
     uint64_t* q_dig = (uint64_t*)malloc(8 * orc_merkle_digest_words(L, cap_h));
     uint64_t q_cap[4 * 64];
@@ -518,8 +547,20 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
         gl2 z_h = gl2_sub(zeta_n, gl2_from(1));
         gl2 l_first = gl2_mul(z_h, gl2_inv(gl2_scale(gl2_sub(zeta, gl2_from(1)), (uint64_t)n % GL_P)));
         gl2 l_last = gl2_mul(z_h, gl2_inv(gl2_scale(gl2_sub(gl2_scale(zeta, g), gl2_from(1)), (uint64_t)n % GL_P)));
-        gl2 accs[4];
-        air_eval_ext(d, o_local, o_next, pis, gl2_sub(zeta, gl2_from(last)), l_first, l_last, alphas, accs);
+        gl2 accs[4], per[ORC_MAX_PERIODIC];
+        if (d->n_periodic) {
+            const size_t period = (size_t)1 << d->period_bits;
+            uint64_t* pc_ = periodic_coeffs(d);
+            gl2 y = zeta;
+            for (unsigned i = 0; i < log_n - d->period_bits; i++) y = gl2_mul(y, y);
+            for (uint32_t a = 0; a < d->n_periodic; a++) {
+                gl2 acc = gl2_from(0);
+                for (size_t m = period; m-- > 0;) acc = gl2_add_base(gl2_mul(acc, y), pc_[a * period + m]);
+                per[a] = acc;
+            }
+            free(pc_);
+        }
+        air_eval_ext(d, o_local, o_next, pis, per, gl2_sub(zeta, gl2_from(last)), l_first, l_last, alphas, accs);
         for (uint32_t j = 0; j < nc && rc == 1; j++) {
             gl2 t = gl2_from(0);
             for (uint32_t k = qdf; k-- > 0;) t = gl2_add(gl2_mul(t, zeta_n), o_q[j * qdf + k]);

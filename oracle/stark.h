@@ -50,7 +50,8 @@ enum {
     ORC_AIR_EMIT_TRANSITION = 7, /* constraint_transition(r[a]) : times (x - g^-1) */
     ORC_AIR_EMIT_FIRST = 8,      /* constraint_first_row(r[a]) : times L_0(x) */
     ORC_AIR_EMIT_LAST = 9,       /* constraint_last_row(r[a])  : times L_{n-1}(x) */
-    ORC_AIR_EMIT = 10            /* constraint(r[a]) on every row */
+    ORC_AIR_EMIT = 10,           /* constraint(r[a]) on every row */
+    ORC_AIR_PERIODIC = 11        /* dst = periodic column a at this row: values[a][row mod 2^period_bits] */
 };
 
 typedef struct {
@@ -67,6 +68,11 @@ typedef struct {
     uint32_t num_public_inputs;
     uint32_t n_words;                 /* program length in words */
     const uint64_t* program;
+    /* periodic (verifier-computable) columns: column a takes values[a * period + (row mod period)]; as a
+     * polynomial it is P_a(x^(n/period)), P_a = interpolation of the values over the period-th roots of unity */
+    uint32_t n_periodic;
+    uint32_t period_bits;
+    const uint64_t* periodic;
 } orc_stark_desc;
 
 size_t orc_stark_proof_max_bytes(const orc_stark_desc* d);

@@ -21,6 +21,9 @@ CASES = [
     ("wide16", 8, dict(rate_bits=2, fri_arity_bits=2, fri_final_poly_bits=3, fri_num_queries=30)),
     ("deg4", 8, dict(rate_bits=2)),
     ("deg4", 9, dict(rate_bits=3, fri_num_queries=28)),
+    ("periodic", 6, {}),
+    ("periodic", 9, dict(rate_bits=2)),
+    ("periodic", 12, {}),
 ]
 
 

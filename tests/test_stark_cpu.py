@@ -10,7 +10,7 @@ import pytest
 from conftest import P
 
 
-def run_program(words, local, nxt, pis):
+def run_program(words, local, nxt, pis, periodic=()):
     """Reference interpreter of the AIR register program (python ints): returns [(emit_op, value)]."""
     reg, out, pc = {}, [], 0
     while pc < len(words):
@@ -25,6 +25,7 @@ def run_program(words, local, nxt, pis):
         elif op == 4: reg[dst] = (reg[a] + reg[b]) % P
         elif op == 5: reg[dst] = (reg[a] - reg[b]) % P
         elif op == 6: reg[dst] = (reg[a] * reg[b]) % P
+        elif op == 11: reg[dst] = int(periodic[a])
         else: out.append((op, reg[a]))
         pc += 1
     return out
@@ -122,6 +123,8 @@ def _tamper_offsets(n):
     ("wide16", 8, dict(rate_bits=2, fri_arity_bits=2, fri_final_poly_bits=3, fri_num_queries=30)),  # factor 2 < 2^rate_bits
     ("deg4", 8, dict(rate_bits=2)),                   # quotient factor 3 -> 4
     ("deg4", 9, dict(rate_bits=3, fri_num_queries=28)),
+    ("periodic", 6, {}),
+    ("periodic", 9, dict(rate_bits=2)),
 ])
 def test_stark_prove_verify_roundtrip(nlx, orc, kind, db, cfg):
     S = nlx.stark
@@ -166,6 +169,23 @@ def make_case(S, kind, db):
             t[0, i], t[1, i] = a, b
             a, b = (a * a * a + b) % P, (b + 1) % P
         pis = np.array([11], dtype=np.uint64)
+    elif kind == "periodic":
+        # periodic columns: x' = x^2 + K[t mod 4] (transition); y counts 0..3 cyclically, reset by a periodic
+        # selector - an all-rows constraint that also holds across the wrap from the last row to the first
+        air = S.Air(2, 1)
+        K = air.periodic([3, 5, 7, 11])
+        sel = air.periodic([0, 0, 0, 1])
+        x, y = air.local(0), air.local(1)
+        air.constraint_transition(air.next(0) - (x * x + K))
+        air.constraint((1 - sel) * (air.next(1) - y - 1) + sel * air.next(1))
+        air.constraint_first_row(x - air.public(0))
+        n = 1 << db
+        t = np.zeros((2, n), dtype=np.uint64)
+        a = 9
+        for i in range(n):
+            t[0, i], t[1, i] = a, i % 4
+            a = (a * a + [3, 5, 7, 11][i % 4]) % P
+        pis = np.array([9], dtype=np.uint64)
     else:
         raise KeyError(kind)
     return air, t, pis
