@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark"])
+    ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark", "sha256"])
+    ap.add_argument("--log-blocks", type=int, default=14, help="sha256 workload: 2^k compression blocks per proof")
     ap.add_argument("--stark-cols", type=int, default=256)
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -328,6 +329,109 @@ def run_stark(args, nlx, torch, rank, world, local, dist):
     return out
 
 
+def run_sha256(args, nlx, torch, rank, world, local, dist):
+    """Secondary workload: one STARK proof of 2^--log-blocks SHA-256 compression blocks
+    per step - trace generation on the GPU (nlx_sha256_trace) + nlx_stark_prove, both inside the timed
+    region.  Messages are 64-byte Merkle-node preimages (two blocks each), as nearx's inclusion proofs hash
+    (nearx/src/merkle.rs:43-50)."""
+    import hashlib
+    import struct
+    import numpy as np
+    SA = nlx.sha256_air
+    rng = np.random.default_rng(5 + rank)
+    n_blocks = 1 << args.log_blocks
+    n_msgs = max(1, n_blocks // 2)
+    raw = rng.integers(0, 256, (n_msgs, 64), dtype=np.uint8)
+    # padded blocks of a 64-byte message: the message, then 0x80 .. length 512
+    pad = np.zeros((n_msgs, 64), dtype=np.uint8)
+    pad[:, 0] = 0x80
+    pad[:, 62] = 0x02
+    blocks8 = np.concatenate([raw, pad], axis=1).reshape(n_msgs * 2, 64) if n_blocks > 1 else None
+    if n_blocks == 1:
+        blocks, first, _ = SA.blocks_for_messages([b"abc"], 0)
+    else:
+        blocks = blocks8.view(">u4").astype(np.uint32)
+        first = np.tile(np.array([1, 0], dtype=np.uint8), n_msgs)
+    want = np.array(struct.unpack(">8I", hashlib.sha256(raw[-1].tobytes() if n_blocks > 1 else b"abc").digest()), dtype=np.uint64)
+    ctx = nlx.Context(local)
+    sp = SA.Sha256Prover(ctx, args.log_blocks)
+    digest = None
+    for _ in range(args.warmup):
+        trace, digest = sp.generate_trace(blocks, first)
+        sp.prover.prove_into(trace, digest.ctypes.data)
+    ctx.kernel_timing(True)
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    t_trace = 0.0
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        trace, digest = sp.generate_trace(blocks, first)
+        t_trace += time.perf_counter() - t1
+        sp.prover.prove_into(trace, digest.ctypes.data)
+    barrier(dist, torch)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    names = ("intt", "lde", "hash_lde_leaves", "merkle_levels", "air_quotient", "fri_combine")
+    kstats = {k: ctx.kernel_stats(k) for k in names}
+    ctx.kernel_timing(False)
+    stages = sp.prover.stage_times()
+    out = None
+    if rank == 0:
+        assert np.array_equal(digest, want), "GPU chaining value is not the SHA-256 digest"
+        calls, ms, alg = kstats["hash_lde_leaves"]
+        achieved = (alg / calls) / (ms / calls * 1e-3) / 1e9 if calls else 0.0
+        proof = sp.prover.prove(trace, digest)
+        n_rows = 64 << args.log_blocks
+        out = {
+            "metric": "SHA-256 STARK: compression blocks proved per second (secondary workload)",
+            "value": world * args.steps * n_blocks / dt, "unit": "blocks/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
+            "config": {"workload": "STARK of 2^%d SHA-256 compression blocks (%d rows x %d columns, degree-3 AIR, "
+                                   "standard_fast_config: rate 2, 84 queries, 16 PoW bits); trace generated on the GPU "
+                                   "inside the timed region; replicas only" % (args.log_blocks, n_rows, SA.N_COLS),
+                       "messages": "%d random 64-byte messages (2 blocks each)" % n_msgs,
+                       "air_program_words": int(sp.stark.desc.n_words), "constraints": sp.stark.air.num_constraints,
+                       "proof_bytes": len(proof), "trace_gen_ms_per_step": t_trace / args.steps * 1e3,
+                       "trace_bytes": int(SA.N_COLS) * n_rows * 8},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_hash_lde_leaves",
+                         "launches": calls, "avg_launch_ms": ms / calls if calls else None,
+                         "alg_bytes_per_launch": alg / calls if calls else None},
+            "stage_ms_last_proof": {k: round(v, 3) for k, v in stages},
+            "kernel_ms_per_proof": {k: round(v[1] / args.steps, 3) for k, v in kstats.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py
+            cores = min(len(os.sched_getaffinity(0)), 16)
+            os.environ["OMP_NUM_THREADS"] = str(cores)
+            s_lb = max(min(args.log_blocks - 3, 8), 0)
+            sp2 = SA.Sha256Prover(ctx, s_lb)
+            b2, f2 = blocks[: 1 << s_lb], first[: 1 << s_lb].copy()
+            f2[0] = 1
+            tr2, dg2 = sp2.generate_trace(b2, f2)
+            host_trace = tr2.cpu().numpy().view(np.uint64)
+            tc = time.time()
+            pr2 = oracle_py.stark_prove(sp2.stark.desc, host_trace, dg2)
+            dtc = time.time() - tc
+            ok = oracle_py.stark_verify(sp2.stark.desc, pr2) == 1
+            sp2.close()
+            out["cpu_baseline"] = {"value": (1 << s_lb) / dtc, "unit": "blocks/s", "cores": cores, "kind": "port",
+                                   "sample": "oracle STARK prover on 2^%d blocks in %.2f s (trace taken from the GPU "
+                                             "generator, not timed); oracle verifier accepted: %s; oracle verifier on "
+                                             "the GPU proof of the full workload: %s"
+                                             % (s_lb, dtc, ok, oracle_py.stark_verify(sp.stark.desc, proof) == 1)}
+        else:
+            out["cpu_baseline"] = None
+    sp.close()
+    ctx.close()
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -340,6 +444,8 @@ def main():
         out = run_sync(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "stark":
         out = run_stark(args, nlx, torch, rank, world, local, dist)
+    elif args.workload == "sha256":
+        out = run_sha256(args, nlx, torch, rank, world, local, dist)
     else:
         from importlib import import_module
         mr = import_module("nlx_amd.mapreduce")

@@ -253,14 +253,17 @@ int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint6
 #define NLX_AIR_NEXT 1             /* r[dst] = next_values[a] */
 #define NLX_AIR_PUBLIC 2           /* r[dst] = public_inputs[a] */
 #define NLX_AIR_CONST 3            /* r[dst] = immediate (next word) */
-#define NLX_AIR_ADD 4              /* r[dst] = r[a] + r[b] */
-#define NLX_AIR_SUB 5
+#define NLX_AIR_ADD 4              /* r[dst] = r[a] + r[b] * 2^sh, sh = word bits 56..61 (0 = plain add) */
+#define NLX_AIR_SUB 5              /* r[dst] = r[a] - r[b] * 2^sh */
 #define NLX_AIR_MUL 6
 #define NLX_AIR_EMIT_TRANSITION 7  /* ConstraintConsumer::constraint_transition(r[a]): times (x - g^-1) */
 #define NLX_AIR_EMIT_FIRST 8       /* constraint_first_row(r[a]): times L_0(x) */
 #define NLX_AIR_EMIT_LAST 9        /* constraint_last_row(r[a]): times L_{n-1}(x) */
 #define NLX_AIR_EMIT 10            /* constraint(r[a]) on every row */
 #define NLX_AIR_PERIODIC 11        /* r[dst] = periodic column a at this row (values[a][row mod period]) */
+#define NLX_AIR_PACK_LOCAL 12      /* r[dst] = sum_{i<b} 2^i local_values[a+i], 1 <= b <= 32 (bits -> word) */
+#define NLX_AIR_PACK_NEXT 13       /* r[dst] = sum_{i<b} 2^i next_values[a+i] */
+#define NLX_AIR_EMIT_BOOL 14       /* constraint(x * (x - 1)), x = local_values[a] */
 #define NLX_AIR_NUM_REGS 64
 #define NLX_AIR_MAX_PERIODIC 16
 

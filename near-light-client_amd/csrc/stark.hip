@@ -40,6 +40,12 @@ struct AirParams {
     uint32_t log_n, rate_bits, qdb, n_words, nc, n_regs, period_bits;
 };
 
+// x * 2^sh (sh < 64): a 128-bit shift and one reduction instead of a general multiplication
+static __device__ __forceinline__ uint64_t mul_pow2(uint64_t x, uint32_t sh) {
+    if (sh == 0) return x;
+    return gl::reduce128(x << sh, x >> (64 - sh));
+}
+
 static __device__ __forceinline__ uint64_t root_pow_(const uint64_t* __restrict__ half_table, uint32_t e, uint32_t half) {
     return e < half ? half_table[e] : gl::P - half_table[e - half];
 }
@@ -71,6 +77,7 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
         const uint64_t w = p.program[pc];
         const uint32_t op = (uint32_t)(w & 0xFF), dst = (uint32_t)((w >> 8) & 0xFFFF);
         const uint32_t a = (uint32_t)((w >> 24) & 0xFFFF), b = (uint32_t)((w >> 40) & 0xFFFF);
+        const uint32_t sh = (uint32_t)(w >> 56) & 0x3F;
         uint64_t c;
         switch (op) {
             case NLX_AIR_LOCAL: my[dst * bd] = p.trace[(size_t)a * L + row]; continue;
@@ -80,9 +87,24 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
                 my[dst * bd] = p.periodic[((((size_t)a << p.qdb) + rq) << p.period_bits) + (k & ((1u << p.period_bits) - 1))];
                 continue;
             case NLX_AIR_CONST: my[dst * bd] = p.program[++pc]; continue;
-            case NLX_AIR_ADD: my[dst * bd] = gl::add(my[a * bd], my[b * bd]); continue;
-            case NLX_AIR_SUB: my[dst * bd] = gl::sub(my[a * bd], my[b * bd]); continue;
+            case NLX_AIR_ADD: my[dst * bd] = gl::add(my[a * bd], mul_pow2(my[b * bd], sh)); continue;
+            case NLX_AIR_SUB: my[dst * bd] = gl::sub(my[a * bd], mul_pow2(my[b * bd], sh)); continue;
             case NLX_AIR_MUL: my[dst * bd] = gl::mul(my[a * bd], my[b * bd]); continue;
+            case NLX_AIR_PACK_LOCAL:
+            case NLX_AIR_PACK_NEXT: {
+                // b loads in flight at once (wave-uniform trip count), then shift-accumulate
+                const uint64_t* src = p.trace + (size_t)a * L + (op == NLX_AIR_PACK_LOCAL ? row : row_next);
+                uint64_t acc = 0;
+#pragma unroll 8
+                for (uint32_t i = 0; i < b; i++) acc = gl::add(acc, mul_pow2(src[(size_t)i * L], i));
+                my[dst * bd] = acc;
+                continue;
+            }
+            case NLX_AIR_EMIT_BOOL: {
+                const uint64_t v = p.trace[(size_t)a * L + row];
+                c = gl::mul(v, gl::sub(v, 1));
+                break;
+            }
             case NLX_AIR_EMIT_TRANSITION: c = gl::mul(my[a * bd], z_last); break;
             case NLX_AIR_EMIT_FIRST: c = gl::mul(my[a * bd], l_first); break;
             case NLX_AIR_EMIT_LAST: c = gl::mul(my[a * bd], l_last); break;
@@ -159,8 +181,13 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
             const uint64_t w = prog[pc];
             const uint32_t op = (uint32_t)(w & 0xFF), dst = (uint32_t)((w >> 8) & 0xFFFF);
             const uint32_t a = (uint32_t)((w >> 24) & 0xFFFF), b = (uint32_t)((w >> 40) & 0xFFFF);
-            if (op > NLX_AIR_PERIODIC) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
-            const bool writes = op <= NLX_AIR_MUL || op == NLX_AIR_PERIODIC;
+            if (op > NLX_AIR_EMIT_BOOL) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
+            const bool writes = op <= NLX_AIR_MUL || (op >= NLX_AIR_PERIODIC && op <= NLX_AIR_PACK_NEXT);
+            if ((op == NLX_AIR_PACK_LOCAL || op == NLX_AIR_PACK_NEXT) && (b < 1 || b > 32 || a + b > d.n_cols))
+                return ctx->fail(NLX_E_INVAL, "AIR word %u: PACK range out of the trace", pc);
+            if (op == NLX_AIR_EMIT_BOOL && a >= d.n_cols) return ctx->fail(NLX_E_INVAL, "AIR word %u: column out of range", pc);
+            if ((w >> 56) != 0 && op != NLX_AIR_ADD && op != NLX_AIR_SUB) return ctx->fail(NLX_E_INVAL, "AIR word %u: shift on a non-ADD/SUB word", pc);
+            if ((w >> 62) != 0) return ctx->fail(NLX_E_INVAL, "AIR word %u: reserved bits set", pc);
             if (writes && dst >= NLX_AIR_NUM_REGS) return ctx->fail(NLX_E_INVAL, "AIR word %u: register out of range", pc);
             if ((op == NLX_AIR_LOCAL || op == NLX_AIR_NEXT) && a >= d.n_cols) return ctx->fail(NLX_E_INVAL, "AIR word %u: column out of range", pc);
             if (op == NLX_AIR_PUBLIC && a >= d.num_public_inputs) return ctx->fail(NLX_E_INVAL, "AIR word %u: public input out of range", pc);
@@ -365,9 +392,9 @@ int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* pub
             ap.g_inv = gl::inv(gl::root_of_unity(log_n));
             ap.log_n = log_n; ap.rate_bits = d.rate_bits; ap.qdb = qdb; ap.n_words = d.n_words; ap.nc = nc;
             ap.n_regs = s->n_regs;
-            // block size: as many lanes as the LDS register file allows (64 KB budget), power of two <= n
-            unsigned bs = 256;
-            while (bs > 64 && (size_t)bs * s->n_regs * 8 > (64u << 10)) bs >>= 1;
+            // one wave per block: the LDS register file (n_regs x 64 lanes x 8 B) is the occupancy limiter, and
+            // single-wave blocks pack the 160 KB of a CU at the finest granularity
+            unsigned bs = 64;
             while (bs > n) bs >>= 1;
             const size_t lds = (size_t)bs * s->n_regs * 8;
             ctx->begin_kernel("air_quotient", 8.0 * Q * (2.0 * ncols + nc));

@@ -79,16 +79,13 @@ assert K[0] == 0x428a2f98 and K[63] == 0xc67178f2
 def sha256_air():
     air = Air(N_COLS, 8)
     L = air.local
-    N = air.next
+    N = air.next  # noqa: N806
     k_t = air.periodic(K)
     is63 = air.periodic([0] * 63 + [1])
     two32 = 1 << 32
 
     def pk(row, base, nbits=32):
-        acc = row(base)
-        for i in range(1, nbits):
-            acc = acc + row(base + i) * (1 << i)
-        return acc
+        return air.pack(base, nbits, next_row=(row is N))
 
     def xor2(x, y):
         return x + y - 2 * (x * y)
@@ -105,8 +102,7 @@ def sha256_air():
     # 1. booleanity
     for base, cnt in ((A, 192), (W1B, 64), (CA, 8), (CY, 8), (IS_FIRST, 1)):
         for i in range(cnt):
-            x = L(base + i)
-            air.constraint(x * (x - 1))
+            air.constraint_boolean(base + i)
     # 2. the two decomposed schedule words
     air.constraint(pk(L, W1B) - L(WIN + 1))
     air.constraint(pk(L, W14B) - L(WIN + 14))

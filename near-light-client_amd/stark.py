@@ -19,8 +19,9 @@ from ._lib import dll, ptr, NlxError
 
 P = 0xFFFFFFFF00000001
 (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_CONST, AIR_ADD, AIR_SUB, AIR_MUL, AIR_EMIT_TRANSITION, AIR_EMIT_FIRST,
- AIR_EMIT_LAST, AIR_EMIT, AIR_PERIODIC) = range(12)
+ AIR_EMIT_LAST, AIR_EMIT, AIR_PERIODIC, AIR_PACK_LOCAL, AIR_PACK_NEXT, AIR_EMIT_BOOL) = range(15)
 AIR_NUM_REGS = 64
+AIR_MAX_RESIDENT_LEAVES = 6
 
 
 class StarkDesc(ctypes.Structure):
@@ -49,12 +50,23 @@ class StarkConfig:
             setattr(self, k, v)
 
 
-class _Expr:
-    """Node of the constraint DAG.  degree = polynomial degree in the trace columns."""
-    __slots__ = ("air", "op", "a", "b", "degree", "uses", "reg")
+def _pow2_factor(e):
+    """(other, s) if e is MUL(other, 2^s) with 1 <= s < 62, else None."""
+    if e.op != AIR_MUL:
+        return None
+    for c, o in ((e.a, e.b), (e.b, e.a)):
+        if c.op == AIR_CONST and c.a > 1 and c.a & (c.a - 1) == 0 and c.a.bit_length() - 1 < 62:
+            return o, c.a.bit_length() - 1
+    return None
 
-    def __init__(self, air, op, a=None, b=None, degree=0):
-        self.air, self.op, self.a, self.b, self.degree = air, op, a, b, degree
+
+class _Expr:
+    """Node of the constraint DAG.  degree = polynomial degree in the trace columns.  ADD / SUB nodes carry
+    a shift: a +- b * 2^sh (multiplications by powers of two are folded into the neighbouring sum)."""
+    __slots__ = ("air", "op", "a", "b", "degree", "uses", "reg", "sh")
+
+    def __init__(self, air, op, a=None, b=None, degree=0, sh=0):
+        self.air, self.op, self.a, self.b, self.degree, self.sh = air, op, a, b, degree, sh
         self.uses = 0
         self.reg = None
 
@@ -63,13 +75,24 @@ class _Expr:
 
     def __add__(self, o):
         o = self._lift(o)
-        return _Expr(self.air, AIR_ADD, self, o, max(self.degree, o.degree))
+        deg = max(self.degree, o.degree)
+        f = _pow2_factor(o)
+        if f:
+            return _Expr(self.air, AIR_ADD, self, f[0], deg, f[1])
+        f = _pow2_factor(self)
+        if f:
+            return _Expr(self.air, AIR_ADD, o, f[0], deg, f[1])
+        return _Expr(self.air, AIR_ADD, self, o, deg)
 
     __radd__ = __add__
 
     def __sub__(self, o):
         o = self._lift(o)
-        return _Expr(self.air, AIR_SUB, self, o, max(self.degree, o.degree))
+        deg = max(self.degree, o.degree)
+        f = _pow2_factor(o)
+        if f:
+            return _Expr(self.air, AIR_SUB, self, f[0], deg, f[1])
+        return _Expr(self.air, AIR_SUB, self, o, deg)
 
     def __rsub__(self, o):
         return self._lift(o) - self
@@ -92,11 +115,17 @@ class Air:
         self.period_bits = 0
         self._periodic = []  # value arrays, each of length 2^period_bits
 
-    def _leaf(self, op, idx, degree):
-        key = (op, idx)
+    def _leaf(self, op, idx, degree, cnt=None):
+        key = (op, idx, cnt)
         if key not in self._leaf_cache:
-            self._leaf_cache[key] = _Expr(self, op, idx, None, degree)
+            self._leaf_cache[key] = _Expr(self, op, idx, cnt, degree)
         return self._leaf_cache[key]
+
+    def pack(self, base, nbits, next_row=False):
+        """sum_i 2^i * column[base + i] of the local (or next) row as ONE VM instruction: the word behind
+        `nbits` bit columns.  Loads like a leaf (re-computable), degree 1."""
+        assert 1 <= nbits <= 32 and 0 <= base and base + nbits <= self.n_cols
+        return self._leaf(AIR_PACK_NEXT if next_row else AIR_PACK_LOCAL, base, 1, nbits)
 
     def local(self, i):
         assert 0 <= i < self.n_cols
@@ -137,6 +166,11 @@ class Air:
     def constraint(self, e):
         self._emits.append((AIR_EMIT, e))
 
+    def constraint_boolean(self, col):
+        """constraint(x * (x - 1)) for x = local(col), as one VM instruction."""
+        assert 0 <= col < self.n_cols
+        self._emits.append((AIR_EMIT_BOOL, self._leaf(AIR_LOCAL, col, 1)))
+
     @property
     def num_constraints(self):
         return len(self._emits)
@@ -146,7 +180,7 @@ class Air:
         """Stark::constraint_degree(): filters (z_last / lagrange) add one to the expression degree."""
         d = 1
         for op, e in self._emits:
-            d = max(d, e.degree + (0 if op == AIR_EMIT else 1))
+            d = max(d, 2 if op == AIR_EMIT_BOOL else e.degree + (0 if op == AIR_EMIT else 1))
         return d
 
     def quotient_degree_factor(self):
@@ -164,7 +198,10 @@ class Air:
         powers)."""
         ops = (AIR_ADD, AIR_SUB, AIR_MUL)
         computed, per_emit, all_ops = set(), [], []
-        for _, root in self._emits:
+        for eop, root in self._emits:
+            if eop == AIR_EMIT_BOOL:
+                per_emit.append([])
+                continue
             nodes, seen, stack = [], set(), [(root, False)]
             while stack:
                 x, done = stack.pop()
@@ -187,34 +224,43 @@ class Air:
             for y in (x.a, x.b):
                 if y.op in ops:
                     y.uses += 1
-        for _, root in self._emits:
-            if root.op in ops:
+        for eop, root in self._emits:
+            if root.op in ops and eop != AIR_EMIT_BOOL:
                 root.uses += 1
 
         words = []
         free = list(range(AIR_NUM_REGS - 1, -1, -1))
         resident = []  # leaves currently holding a register, least recently used first
 
-        def alloc(pinned=()):
-            if free:
-                return free.pop()
+        def alloc(pinned=(), for_leaf=False):
+            # leaves beyond a small resident set are evicted first: they are one load away, and the size of the
+            # register file (highest register ever used) sets the quotient kernel's LDS footprint / occupancy
+            if free and not (for_leaf and len(resident) >= AIR_MAX_RESIDENT_LEAVES):
+                return min_pop(free)
             for i, y in enumerate(resident):
                 if not any(y is q for q in pinned):
                     resident.pop(i)
                     r, y.reg = y.reg, None
                     return r
+            if free:
+                return min_pop(free)
             raise ValueError("AIR needs more than %d live registers" % AIR_NUM_REGS)
+
+        def min_pop(lst):
+            r = min(lst)
+            lst.remove(r)
+            return r
 
         def ensure(y, pinned=()):
             if y.op in ops:
                 return y.reg
             if y.reg is None:
-                y.reg = alloc(pinned)
+                y.reg = alloc(pinned, True)
                 if y.op == AIR_CONST:
                     words.append(AIR_CONST | y.reg << 8)
                     words.append(y.a)
                 else:
-                    words.append(y.op | y.reg << 8 | y.a << 24)
+                    words.append(y.op | y.reg << 8 | y.a << 24 | (y.b or 0) << 40)
             else:
                 resident[:] = [q for q in resident if q is not y]
             resident.append(y)
@@ -230,6 +276,9 @@ class Air:
                     resident[:] = [q for q in resident if q is not y]
 
         for (op, root), nodes in zip(self._emits, per_emit):
+            if op == AIR_EMIT_BOOL:
+                words.append(AIR_EMIT_BOOL | root.a << 24)
+                continue
             # leaf use counts within this constraint
             leaves = {}
             for x in nodes:
@@ -252,7 +301,7 @@ class Air:
                 release(x.a)
                 release(x.b)
                 x.reg = alloc()
-                words.append(x.op | x.reg << 8 | ra << 24 | rb << 40)
+                words.append(x.op | x.reg << 8 | ra << 24 | rb << 40 | x.sh << 56)
             words.append(op | ensure(root) << 24)
             release(root)
             assert not resident

@@ -300,6 +300,7 @@ done:
 #define AIR_DST(w) ((uint32_t)(((w) >> 8) & 0xFFFF))
 #define AIR_A(w) ((uint32_t)(((w) >> 24) & 0xFFFF))
 #define AIR_B(w) ((uint32_t)(((w) >> 40) & 0xFFFF))
+#define AIR_SH(w) ((uint32_t)(((w) >> 56) & 0x3F))
 #define AIR_REGS 64
 
 /* ConstraintConsumer over the base field: acc_j = acc_j * alpha_j + c */
@@ -319,9 +320,17 @@ static void air_eval_base(const orc_stark_desc* d, const uint64_t* local, const 
             case ORC_AIR_PUBLIC: reg[dst] = pis[a]; break;
             case ORC_AIR_PERIODIC: reg[dst] = per[a]; break;
             case ORC_AIR_CONST: reg[dst] = d->program[++pc] % GL_P; break;
-            case ORC_AIR_ADD: reg[dst] = gl_add(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
-            case ORC_AIR_SUB: reg[dst] = gl_sub(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
+            case ORC_AIR_ADD: reg[dst] = gl_add(reg[a % AIR_REGS], gl_mul(reg[b % AIR_REGS], 1ULL << AIR_SH(w))); break;
+            case ORC_AIR_SUB: reg[dst] = gl_sub(reg[a % AIR_REGS], gl_mul(reg[b % AIR_REGS], 1ULL << AIR_SH(w))); break;
             case ORC_AIR_MUL: reg[dst] = gl_mul(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
+            case ORC_AIR_PACK_LOCAL: case ORC_AIR_PACK_NEXT: {
+                const uint64_t* rowv = AIR_OP(w) == ORC_AIR_PACK_LOCAL ? local : next;
+                uint64_t acc = 0;
+                for (uint32_t i = 0; i < b; i++) acc = gl_add(acc, gl_mul(rowv[a + i], 1ULL << i));
+                reg[dst] = acc;
+                break;
+            }
+            case ORC_AIR_EMIT_BOOL: c = gl_mul(local[a], gl_sub(local[a], 1)); emit = 1; break;
             case ORC_AIR_EMIT_TRANSITION: c = gl_mul(reg[a % AIR_REGS], z_last); emit = 1; break;
             case ORC_AIR_EMIT_FIRST: c = gl_mul(reg[a % AIR_REGS], l_first); emit = 1; break;
             case ORC_AIR_EMIT_LAST: c = gl_mul(reg[a % AIR_REGS], l_last); emit = 1; break;
@@ -348,9 +357,17 @@ static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* n
             case ORC_AIR_PUBLIC: reg[dst] = gl2_from(pis[a]); break;
             case ORC_AIR_PERIODIC: reg[dst] = per[a]; break;
             case ORC_AIR_CONST: reg[dst] = gl2_from(d->program[++pc] % GL_P); break;
-            case ORC_AIR_ADD: reg[dst] = gl2_add(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
-            case ORC_AIR_SUB: reg[dst] = gl2_sub(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
+            case ORC_AIR_ADD: reg[dst] = gl2_add(reg[a % AIR_REGS], gl2_scale(reg[b % AIR_REGS], 1ULL << AIR_SH(w))); break;
+            case ORC_AIR_SUB: reg[dst] = gl2_sub(reg[a % AIR_REGS], gl2_scale(reg[b % AIR_REGS], 1ULL << AIR_SH(w))); break;
             case ORC_AIR_MUL: reg[dst] = gl2_mul(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
+            case ORC_AIR_PACK_LOCAL: case ORC_AIR_PACK_NEXT: {
+                const gl2* rowv = AIR_OP(w) == ORC_AIR_PACK_LOCAL ? local : next;
+                gl2 acc = gl2_from(0);
+                for (uint32_t i = 0; i < b; i++) acc = gl2_add(acc, gl2_scale(rowv[a + i], 1ULL << i));
+                reg[dst] = acc;
+                break;
+            }
+            case ORC_AIR_EMIT_BOOL: c = gl2_mul(local[a], gl2_sub(local[a], gl2_from(1))); emit = 1; break;
             case ORC_AIR_EMIT_TRANSITION: c = gl2_mul(reg[a % AIR_REGS], z_last); emit = 1; break;
             case ORC_AIR_EMIT_FIRST: c = gl2_mul(reg[a % AIR_REGS], l_first); emit = 1; break;
             case ORC_AIR_EMIT_LAST: c = gl2_mul(reg[a % AIR_REGS], l_last); emit = 1; break;
@@ -385,8 +402,12 @@ static int desc_ok(const orc_stark_desc* d) {
             case ORC_AIR_LOCAL: case ORC_AIR_NEXT: if (AIR_A(w) >= d->n_cols) return 0; break;
             case ORC_AIR_PUBLIC: if (AIR_A(w) >= d->num_public_inputs) return 0; break;
             case ORC_AIR_PERIODIC: if (AIR_A(w) >= d->n_periodic) return 0; break;
+            case ORC_AIR_PACK_LOCAL: case ORC_AIR_PACK_NEXT:
+                if (AIR_B(w) < 1 || AIR_B(w) > 32 || AIR_A(w) + AIR_B(w) > d->n_cols) return 0;
+                break;
+            case ORC_AIR_EMIT_BOOL: if (AIR_A(w) >= d->n_cols) return 0; break;
             case ORC_AIR_CONST: if (++pc >= d->n_words) return 0; break;
-            default: if (AIR_OP(w) > ORC_AIR_PERIODIC) return 0;
+            default: if (AIR_OP(w) > ORC_AIR_EMIT_BOOL) return 0;
         }
     }
     return 1;

@@ -51,8 +51,12 @@ enum {
     ORC_AIR_EMIT_FIRST = 8,      /* constraint_first_row(r[a]) : times L_0(x) */
     ORC_AIR_EMIT_LAST = 9,       /* constraint_last_row(r[a])  : times L_{n-1}(x) */
     ORC_AIR_EMIT = 10,           /* constraint(r[a]) on every row */
-    ORC_AIR_PERIODIC = 11        /* dst = periodic column a at this row: values[a][row mod 2^period_bits] */
+    ORC_AIR_PERIODIC = 11,       /* dst = periodic column a at this row: values[a][row mod 2^period_bits] */
+    ORC_AIR_PACK_LOCAL = 12,     /* dst = sum_{i<b} 2^i local_values[a+i]   (b <= 32) */
+    ORC_AIR_PACK_NEXT = 13,      /* dst = sum_{i<b} 2^i next_values[a+i] */
+    ORC_AIR_EMIT_BOOL = 14       /* constraint(x * (x - 1)), x = local_values[a] */
 };
+/* ADD / SUB carry a shift in bits 56..61 of the word: dst = r[a] +- r[b] * 2^shift. */
 
 typedef struct {
     uint32_t degree_bits;

@@ -15,17 +15,21 @@ def run_program(words, local, nxt, pis, periodic=()):
     reg, out, pc = {}, [], 0
     while pc < len(words):
         w = int(words[pc])
-        op, dst, a, b = w & 0xFF, (w >> 8) & 0xFFFF, (w >> 24) & 0xFFFF, (w >> 40) & 0xFFFF
+        op, dst, a, b, sh = w & 0xFF, (w >> 8) & 0xFFFF, (w >> 24) & 0xFFFF, (w >> 40) & 0xFFFF, (w >> 56) & 0x3F
         if op == 0: reg[dst] = int(local[a])
         elif op == 1: reg[dst] = int(nxt[a])
         elif op == 2: reg[dst] = int(pis[a])
         elif op == 3:
             pc += 1
             reg[dst] = int(words[pc]) % P
-        elif op == 4: reg[dst] = (reg[a] + reg[b]) % P
-        elif op == 5: reg[dst] = (reg[a] - reg[b]) % P
+        elif op == 4: reg[dst] = (reg[a] + (reg[b] << sh)) % P
+        elif op == 5: reg[dst] = (reg[a] - (reg[b] << sh)) % P
         elif op == 6: reg[dst] = (reg[a] * reg[b]) % P
         elif op == 11: reg[dst] = int(periodic[a])
+        elif op in (12, 13):
+            src = local if op == 12 else nxt
+            reg[dst] = sum(int(src[a + i]) << i for i in range(b)) % P
+        elif op == 14: out.append((10, int(local[a]) * (int(local[a]) - 1) % P))
         else: out.append((op, reg[a]))
         pc += 1
     return out
@@ -203,3 +207,27 @@ def test_stark_abi_rejects_null(nlx):
     pis = np.zeros(2, dtype=np.uint64)
     assert d.nlx_synth_stark_trace(3, 3, 1, k1.ctypes.data, t.ctypes.data, pis.ctypes.data) != 0  # n_cols % 4
     assert d.nlx_synth_stark_trace(4, 3, 1, k1.ctypes.data, t.ctypes.data, pis.ctypes.data) == 0
+
+
+def test_air_fused_forms(nlx):
+    """Multiplications by powers of two fold into the neighbouring ADD / SUB; pack() and
+    constraint_boolean() are single instructions; all agree with the plain formulas."""
+    S = nlx.stark
+    rng = np.random.default_rng(11)
+    air = S.Air(40, 0)
+    x, y, z = air.local(32), air.local(33), air.next(34)
+    air.constraint(x + y * 8 - 2 * (x * y) + 4 * z)          # three shifted forms, one MUL
+    air.constraint(air.pack(0, 32) - air.pack(4, 5, next_row=True) * 3)
+    air.constraint_boolean(7)
+    air.constraint_transition(air.pack(0, 1) - air.local(0))
+    words = air.compile()
+    ops = [int(w) & 0xFF for w in words]
+    assert ops.count(6) == 2 and ops.count(12) == 2 and ops.count(13) == 1 and ops.count(14) == 1
+    assert air.constraint_degree == 2
+    lo = [int(v) for v in rng.integers(0, P, 40, dtype=np.uint64)]
+    ne = [int(v) for v in rng.integers(0, P, 40, dtype=np.uint64)]
+    got = run_program(words, lo, ne, [])
+    want = [(10, (lo[32] + 8 * lo[33] - 2 * lo[32] * lo[33] + 4 * ne[34]) % P),
+            (10, (sum(lo[i] << i for i in range(32)) - 3 * sum(ne[4 + i] << i for i in range(5))) % P),
+            (10, lo[7] * (lo[7] - 1) % P), (7, 0)]
+    assert got == want
