@@ -62,6 +62,11 @@ def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 path on a one-GPU box: NLX_BENCH_REHEARSAL=1 puts every rank on device 0 and
+    # uses gloo (RCCL refuses two ranks on one device).  Never set by the driver; the line says so.
+    rehearsal = os.environ.get("NLX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -69,14 +74,27 @@ def dist_setup(n_gpus):
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist_mod.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local))
         dist = dist_mod
     else:
         torch.cuda.set_device(local)
     if world != n_gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (n_gpus, world), file=sys.stderr)
     return rank, world, local, dist
+
+
+def reduce_max(dist, torch, dt):
+    """MAX over ranks of a host scalar (device tensor for RCCL, host tensor in the gloo rehearsal)."""
+    if dist is None:
+        return dt
+    dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
 
 
 def barrier(dist, torch):
@@ -155,10 +173,7 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
     if rc != 0:
         raise RuntimeError("nlx_batch_prove failed with %d" % rc)
     assert all(jobs[i].proof_len == jobs[0].proof_len for i in range(args.steps))
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = reduce_max(dist, torch, dt)
     names = ("intt", "lde", "hash_lde_leaves", "merkle_levels", "quotient", "fri_combine")
     kstats = {k: [0, 0.0, 0.0] for k in names}
     for c in ctxs:
@@ -267,10 +282,7 @@ def run_stark(args, nlx, torch, rank, world, local, dist):
         th.join()
     barrier(dist, torch)
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = reduce_max(dist, torch, dt)
     names = ("intt", "lde", "hash_lde_leaves", "merkle_levels", "air_quotient", "fri_combine")
     kstats = {k: [0, 0.0, 0.0] for k in names}
     for c in ctxs:
@@ -370,10 +382,7 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
         sp.prover.prove_into(trace, digest.ctypes.data)
     barrier(dist, torch)
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = reduce_max(dist, torch, dt)
     names = ("intt", "lde", "hash_lde_leaves", "merkle_levels", "air_quotient", "fri_combine")
     kstats = {k: ctx.kernel_stats(k) for k in names}
     ctx.kernel_timing(False)
@@ -451,6 +460,8 @@ def main():
         mr = import_module("nlx_amd.mapreduce")
         out = mr.bench_verify128(args, nlx, torch, rank, world, local, dist)
     if rank == 0:
+        if os.environ.get("NLX_BENCH_REHEARSAL") == "1":
+            out["config"]["rehearsal"] = "all ranks share GPU 0, gloo backend: NOT a scaling measurement"
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

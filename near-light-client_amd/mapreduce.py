@@ -168,6 +168,8 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist):
     ctx = nlx.Context(local)
     prover = GpuTreeProver(nlx, ctx, plan, args.map_log_n, args.reduce_log_n, torch=torch, workers=args.inflight)
     device = torch.device("cuda", local)
+    if dist is not None and dist.get_backend() == "gloo":  # one-GPU rehearsal of the N > 1 path (bench.py)
+        device = torch.device("cpu")
 
     def sync():
         torch.cuda.synchronize()
