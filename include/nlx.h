@@ -140,7 +140,9 @@ int32_t nlx_commit_get_digests(nlx_commit* c, uint64_t* digests_out);
 #define NLX_GATE_EXPONENTIATION 11 /* gates::exponentiation::ExponentiationGate { num_power_bits = param0 } */
 #define NLX_GATE_RANDOM_ACCESS 12  /* gates::random_access::RandomAccessGate { bits = param0, num_copies = param1 & 0xFFFF,
                                       num_extra_constants = param1 >> 16 } */
-#define NLX_GATE_KIND_MAX 12
+#define NLX_GATE_COSET_INTERPOLATION 13 /* gates::coset_interpolation::CosetInterpolationGate<2> { subgroup_bits = param0,
+                                           degree = param1 } - the FRI-verifier gate of every recursive (reduce) proof */
+#define NLX_GATE_KIND_MAX 13
 
 typedef struct {
     uint32_t kind;

@@ -81,6 +81,12 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
         if (gt.kind == NLX_GATE_REDUCING && (gt.param0 < 1 || 6 + gt.param0 + 2 * (gt.param0 - 1) > d.num_wires)) return ctx->fail(NLX_E_INVAL, "ReducingGate too wide");
         if (gt.kind == NLX_GATE_POSEIDON_MDS && d.num_wires < 48) return ctx->fail(NLX_E_INVAL, "PoseidonMdsGate needs 48 wires");
         if (gt.kind == NLX_GATE_EXPONENTIATION && (gt.param0 < 1 || 2 + 2 * gt.param0 > d.num_wires)) return ctx->fail(NLX_E_INVAL, "ExponentiationGate too wide");
+        if (gt.kind == NLX_GATE_COSET_INTERPOLATION) {
+            const uint32_t np = gt.param0 <= 5 ? 1u << gt.param0 : 0;
+            if (np < 4 || gt.param1 < 2 || gt.param1 > np || d.degree_bits < gt.param0 + 1 ||
+                1 + 2 * np + 4 + 4 * ((np - 2) / (gt.param1 - 1)) + 2 > d.num_wires)
+                return ctx->fail(NLX_E_INVAL, "CosetInterpolationGate does not fit");
+        }
         if (gt.kind == NLX_GATE_RANDOM_ACCESS) {
             const uint32_t bits = gt.param0, copies = gt.param1 & 0xFFFF, extra = gt.param1 >> 16;
             if (bits < 1 || bits > 6 || copies < 1 || extra > d.num_constants ||

@@ -432,6 +432,44 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 acc.emit(gl::sub(W(1 + nb), prev_iv));
                 break;
             }
+            case NLX_GATE_COSET_INTERPOLATION: {
+                const uint32_t bits = gd.param0, deg = gd.param1, np = 1u << bits;
+                const uint32_t sep = 1 + 2 * np, sev = sep + 2, si = sev + 2, ni = (np - 2) / (deg - 1), ssh = si + 4 * ni;
+                const uint64_t shift = W(0);
+                const gl::Ext pt{W(ssh), W(ssh + 1)};
+                acc.emit(gl::sub(W(sep), gl::mul(pt.a, shift)));
+                acc.emit(gl::sub(W(sep + 1), gl::mul(pt.b, shift)));
+                // domain x_j = w_np^j comes from the w_n table; on a multiplicative subgroup the barycentric
+                // weight 1 / prod_{i != j} (x_j - x_i) is x_j / np
+                uint64_t np_inv = 1;
+                for (uint32_t i = 0; i < bits; i++) np_inv = gl::mul(np_inv, 0x7FFFFFFF80000001ULL);  // 2^-1
+                const uint32_t stride = (uint32_t)(n >> bits), half = (uint32_t)(n >> 1);
+                gl::Ext ev{0, 0}, pr{1, 0};
+                for (uint32_t c = 0; c <= ni; c++) {
+                    const uint32_t start = c == 0 ? 0 : 1 + (deg - 1) * c;
+                    uint32_t end = c == 0 ? deg : start + deg - 1;
+                    end = end > np ? np : end;
+                    for (uint32_t j = start; j < end; j++) {
+                        const uint64_t xj = root_pow(p.w_n_table, j * stride, half);
+                        const gl::Ext term{gl::sub(pt.a, xj), pt.b};
+                        const gl::Ext vp = gl::mul(gl::Ext{W(1 + 2 * j), W(2 + 2 * j)}, pr);
+                        ev = gl::add(gl::mul(ev, term), gl::mul(vp, gl::mul(xj, np_inv)));
+                        pr = gl::mul(pr, term);
+                    }
+                    if (c < ni) {
+                        const gl::Ext ie{W(si + 2 * c), W(si + 2 * c + 1)}, ip{W(si + 2 * (ni + c)), W(si + 2 * (ni + c) + 1)};
+                        acc.emit(gl::sub(ie.a, ev.a));
+                        acc.emit(gl::sub(ie.b, ev.b));
+                        acc.emit(gl::sub(ip.a, pr.a));
+                        acc.emit(gl::sub(ip.b, pr.b));
+                        ev = ie;
+                        pr = ip;
+                    }
+                }
+                acc.emit(gl::sub(W(sev), ev.a));
+                acc.emit(gl::sub(W(sev + 1), ev.b));
+                break;
+            }
             case NLX_GATE_RANDOM_ACCESS: {
                 const uint32_t bits = gd.param0, copies = gd.param1 & 0xFFFF, extra = gd.param1 >> 16;
                 const uint32_t vec = 1u << bits, rt = (2 + vec) * copies + extra;

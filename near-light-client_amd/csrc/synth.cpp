@@ -119,6 +119,7 @@ uint32_t gate_degree(uint32_t kind, uint32_t p0) {
         case NLX_GATE_POSEIDON_MDS: return 1;
         case NLX_GATE_EXPONENTIATION: return 4;
         case NLX_GATE_RANDOM_ACCESS: return p0 + 1;
+        case NLX_GATE_COSET_INTERPOLATION: return 6;  // with_max_degree(4, 8) -> degree 6 (p1)
     }
     return 0;
 }
@@ -156,6 +157,7 @@ static uint32_t build_gate_list(const nlx_synth_params* sp, uint32_t* kinds, uin
     if (sp->pct_extension) add(NLX_GATE_MUL_EXT, 13, 0);
     if (sp->pct_misc) add(NLX_GATE_EXPONENTIATION, 66, 0);       // degree 4
     if (sp->pct_misc) add(NLX_GATE_RANDOM_ACCESS, 4, 4 | (2u << 16));  // degree 5: bits 4, 4 copies, 2 extra constants
+    if (sp->pct_misc) add(NLX_GATE_COSET_INTERPOLATION, 4, 6);   // degree 6: CosetInterpolationGate::with_max_degree(4, 8)
     if (sp->pct_poseidon) add(NLX_GATE_POSEIDON, 0, 0);          // degree 7
     return k;
 }
@@ -232,7 +234,7 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
     uint32_t n_gates, n_sel;
     nlx_synth_shape(sp, &n_gates, &n_sel);
     int g_base = -1, g_arith = -1, g_pos = -1, g_aext = -1, g_mext = -1, g_red = -1, g_rext = -1, g_pmds = -1, g_exp = -1,
-        g_ra = -1, g_const = 1, g_pi = 2;
+        g_ra = -1, g_ci = -1, g_const = 1, g_pi = 2;
     {
         uint32_t kinds[16], p0[16], p1[16];
         const uint32_t k = build_gate_list(sp, kinds, p0, p1);
@@ -249,6 +251,7 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
                 case NLX_GATE_POSEIDON_MDS: g_pmds = (int)g; break;
                 case NLX_GATE_EXPONENTIATION: g_exp = (int)g; break;
                 case NLX_GATE_RANDOM_ACCESS: g_ra = (int)g; break;
+                case NLX_GATE_COSET_INTERPOLATION: g_ci = (int)g; break;
                 case NLX_GATE_CONSTANT: g_const = (int)g; break;
                 case NLX_GATE_PUBLIC_INPUT: g_pi = (int)g; break;
                 default: break;
@@ -320,9 +323,10 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
                 }
             }
             else if (r < (t += sp->pct_misc) && g_pmds >= 0) {
-                switch (row % 3) {
+                switch (row % 4) {
                     case 0: kind = NLX_GATE_POSEIDON_MDS; gidx = g_pmds; break;
                     case 1: kind = NLX_GATE_EXPONENTIATION; gidx = g_exp; break;
+                    case 2: kind = NLX_GATE_COSET_INTERPOLATION; gidx = g_ci; break;
                     default: kind = NLX_GATE_RANDOM_ACCESS; gidx = g_ra; break;
                 }
             }
@@ -487,6 +491,50 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
                     C_at(n_sel + i, row) = v;
                     W_at((2 + vec) * copies + i, row) = v;
                 }
+                break;
+            }
+            case NLX_GATE_COSET_INTERPOLATION: {
+                // 16 extension values on the coset shift*<g>, interpolated at an extension point (the FRI verifier's
+                // compute_evaluation); intermediates every degree-1 = 5 points
+                const uint32_t bits = 4, deg = 6, np = 16, sep = 1 + 2 * np, sev = sep + 2, si = sev + 2;
+                const uint32_t ni = (np - 2) / (deg - 1), ssh = si + 4 * ni;
+                uint64_t shift = rng.field();
+                if (shift == 0) shift = 1;
+                W_at(0, row) = shift;
+                if (!pool.empty() && (rng.next() & 1)) {  // a value copied from earlier in the circuit
+                    const uint32_t src = pool[rng.below((uint32_t)pool.size())];
+                    W_at(1, row) = wires[src];
+                    dsu.unite(slot(1, row), src);
+                }
+                const gl::Ext point{W_at(sep, row), W_at(sep + 1, row)};
+                const gl::Ext pt = gl::mul(point, gl::inv(shift));
+                W_at(ssh, row) = pt.a;
+                W_at(ssh + 1, row) = pt.b;
+                const uint64_t gen = gl::root_of_unity(bits), np_inv = gl::inv((uint64_t)np);
+                gl::Ext ev{0, 0}, pr{1, 0};
+                uint64_t xj = 1;
+                uint32_t j = 0;
+                for (uint32_t c = 0; c <= ni; c++) {
+                    const uint32_t start = c == 0 ? 0 : 1 + (deg - 1) * c;
+                    uint32_t end = c == 0 ? deg : start + deg - 1;
+                    end = end > np ? np : end;
+                    for (; j < end; j++) {
+                        const gl::Ext term{gl::sub(pt.a, xj), pt.b};
+                        const gl::Ext vp = gl::mul(gl::Ext{W_at(1 + 2 * j, row), W_at(2 + 2 * j, row)}, pr);
+                        ev = gl::add(gl::mul(ev, term), gl::mul(vp, gl::mul(xj, np_inv)));
+                        pr = gl::mul(pr, term);
+                        xj = gl::mul(xj, gen);
+                    }
+                    (void)start;
+                    if (c < ni) {
+                        W_at(si + 2 * c, row) = ev.a; W_at(si + 2 * c + 1, row) = ev.b;
+                        W_at(si + 2 * (ni + c), row) = pr.a; W_at(si + 2 * (ni + c) + 1, row) = pr.b;
+                    }
+                }
+                W_at(sev, row) = ev.a;
+                W_at(sev + 1, row) = ev.b;
+                pool.push_back(slot(sev, row));
+                pool.push_back(slot(sev + 1, row));
                 break;
             }
             default: break;

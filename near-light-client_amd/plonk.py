@@ -12,7 +12,8 @@ import numpy as np
 from ._lib import dll, ptr, NlxError
 
 (GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_BASE_SUM, GATE_POSEIDON, GATE_ARITHMETIC_EXT,
- GATE_MUL_EXT, GATE_REDUCING, GATE_REDUCING_EXT, GATE_POSEIDON_MDS, GATE_EXPONENTIATION, GATE_RANDOM_ACCESS) = range(13)
+ GATE_MUL_EXT, GATE_REDUCING, GATE_REDUCING_EXT, GATE_POSEIDON_MDS, GATE_EXPONENTIATION, GATE_RANDOM_ACCESS,
+ GATE_COSET_INTERPOLATION) = range(14)
 
 
 class GateDesc(ctypes.Structure):

@@ -32,7 +32,8 @@ enum {
     ORC_GATE_REDUCING_EXT = 9,   /* param0 = num_coeffs (32) */
     ORC_GATE_POSEIDON_MDS = 10,
     ORC_GATE_EXPONENTIATION = 11, /* param0 = num_power_bits (66) */
-    ORC_GATE_RANDOM_ACCESS = 12   /* param0 = bits, param1 = num_copies | num_extra_constants << 16 */
+    ORC_GATE_RANDOM_ACCESS = 12,  /* param0 = bits, param1 = num_copies | num_extra_constants << 16 */
+    ORC_GATE_COSET_INTERPOLATION = 13 /* param0 = subgroup_bits (4), param1 = degree (6) */
 };
 
 typedef struct {

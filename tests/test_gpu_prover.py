@@ -19,7 +19,7 @@ SHAPES = [
     (8, dict(pct_poseidon=15, pct_arithmetic=20, pct_base_sum=5, pct_constant=5, pct_extension=30)),  # all 10 gates
     (11, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=50)),
     (7, dict(pct_poseidon=0, pct_arithmetic=0, pct_base_sum=0, pct_constant=5, pct_extension=60)),
-    (9, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=20, pct_misc=30)),  # all 13 gates
+    (9, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=20, pct_misc=30)),  # all 14 gates
     (10, dict(pct_poseidon=0, pct_arithmetic=0, pct_base_sum=0, pct_constant=5, pct_extension=0, pct_misc=70)),
 ]
 

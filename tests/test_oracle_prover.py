@@ -16,7 +16,7 @@ from conftest import P
     (9, dict(pct_poseidon=10, pct_arithmetic=0, pct_base_sum=0, pct_constant=5)),
     (8, dict(pct_poseidon=15, pct_arithmetic=20, pct_base_sum=5, pct_constant=5, pct_extension=30)),  # 10 gates, 3 selectors
     (7, dict(pct_poseidon=0, pct_arithmetic=0, pct_base_sum=0, pct_constant=5, pct_extension=60)),
-    (8, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=20, pct_misc=30)),  # 13 gates, 4 selectors
+    (8, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=20, pct_misc=30)),  # 14 gates
 ])
 def test_prove_verify_roundtrip(nlx, orc, log_n, kw):
     syn = nlx.SyntheticCircuit(log_n, seed=log_n, **kw)
@@ -132,15 +132,18 @@ def test_extension_gates_constrain_their_rows(nlx, orc):
 
 
 def test_misc_gates_constrain_their_rows(nlx, orc):
-    """PoseidonMdsGate, ExponentiationGate, RandomAccessGate: a witness broken on one of their rows is rejected"""
+    """PoseidonMdsGate, ExponentiationGate, RandomAccessGate, CosetInterpolationGate: a witness broken on one of
+    their rows is rejected"""
     syn = nlx.SyntheticCircuit(8, seed=23, pct_poseidon=5, pct_arithmetic=5, pct_base_sum=5, pct_constant=5,
                                pct_extension=10, pct_misc=50)
-    assert syn.num_gates == 13 and syn.num_selectors == 4
+    assert syn.num_gates == 14
     kinds = [g.kind for g in syn.gates]
-    assert kinds == [0, 1, 10, 2, 4, 9, 8, 6, 3, 7, 11, 12, 5]
+    assert kinds == [0, 1, 10, 2, 4, 9, 8, 6, 3, 7, 11, 12, 13, 5]
     circ = orc.Circuit.from_synthetic(syn)
     assert circ.verify(circ.prove(syn.wires, syn.public_inputs)) == 1
-    for kind, wire in ((10, 25), (11, 1), (11, 70), (12, 0), (12, 74)):   # outputs, a power bit, an index, a bit wire
+    # outputs, a power bit, an index, a bit wire; coset interpolation: shift, a value, the evaluation value, an
+    # intermediate eval / prod, the shifted point
+    for kind, wire in ((10, 25), (11, 1), (11, 70), (12, 0), (12, 74), (13, 0), (13, 8), (13, 35), (13, 37), (13, 43), (13, 45)):
         g = syn.gates[kinds.index(kind)]
         rows = np.nonzero(syn.constants[g.selector_index] == g.index)[0]
         assert rows.size > 0, kind
