@@ -142,7 +142,14 @@ int32_t nlx_commit_get_digests(nlx_commit* c, uint64_t* digests_out);
                                       num_extra_constants = param1 >> 16 } */
 #define NLX_GATE_COSET_INTERPOLATION 13 /* gates::coset_interpolation::CosetInterpolationGate<2> { subgroup_bits = param0,
                                            degree = param1 } - the FRI-verifier gate of every recursive (reduce) proof */
-#define NLX_GATE_KIND_MAX 13
+/* plonky2x frontend::num::u32::gates (from plonky2-u32), 2-bit range-check limbs: the u32 / u64 arithmetic and
+ * comparisons of nearx's header, height and stake logic (nearx/src/builder.rs ensure_height / ensure_stake ...) */
+#define NLX_GATE_U32_ADD_MANY 14    /* U32AddManyGate { num_addends = param0, num_ops = param1 } */
+#define NLX_GATE_U32_ARITHMETIC 15  /* U32ArithmeticGate { num_ops = param0 } */
+#define NLX_GATE_U32_SUBTRACTION 16 /* U32SubtractionGate { num_ops = param0 } */
+#define NLX_GATE_U32_RANGE_CHECK 17 /* U32RangeCheckGate { num_input_limbs = param0 } */
+#define NLX_GATE_COMPARISON 18      /* ComparisonGate { num_bits = param0, num_chunks = param1 } */
+#define NLX_GATE_KIND_MAX 18
 
 typedef struct {
     uint32_t kind;
@@ -230,7 +237,9 @@ typedef struct {
     uint32_t pct_constant;    /* remaining rows are NoopGate */
     uint64_t seed;
     uint32_t pct_extension;   /* rows split evenly over ArithmeticExtension / MulExtension / Reducing / ReducingExtension */
-    uint32_t pct_misc;        /* rows split evenly over PoseidonMds / Exponentiation / RandomAccess */
+    uint32_t pct_misc;        /* rows split evenly over PoseidonMds / Exponentiation / CosetInterpolation / RandomAccess */
+    uint32_t pct_u32;         /* rows split evenly over U32AddMany / U32Arithmetic / U32Subtraction / U32RangeCheck / Comparison */
+    uint32_t reserved;
 } nlx_synth_params;
 /* number of gates / selector polynomials the generator will emit for these parameters */
 void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_selectors);

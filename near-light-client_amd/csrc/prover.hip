@@ -81,6 +81,16 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
         if (gt.kind == NLX_GATE_REDUCING && (gt.param0 < 1 || 6 + gt.param0 + 2 * (gt.param0 - 1) > d.num_wires)) return ctx->fail(NLX_E_INVAL, "ReducingGate too wide");
         if (gt.kind == NLX_GATE_POSEIDON_MDS && d.num_wires < 48) return ctx->fail(NLX_E_INVAL, "PoseidonMdsGate needs 48 wires");
         if (gt.kind == NLX_GATE_EXPONENTIATION && (gt.param0 < 1 || 2 + 2 * gt.param0 > d.num_wires)) return ctx->fail(NLX_E_INVAL, "ExponentiationGate too wide");
+        if (gt.kind == NLX_GATE_U32_ADD_MANY && (gt.param0 < 1 || gt.param0 > 15 || gt.param1 < 1 || (gt.param0 + 3 + 18) * gt.param1 > d.num_wires))
+            return ctx->fail(NLX_E_INVAL, "U32AddManyGate does not fit the wires");
+        if (gt.kind == NLX_GATE_U32_ARITHMETIC && (gt.param0 < 1 || (6 + 32) * gt.param0 > d.num_wires)) return ctx->fail(NLX_E_INVAL, "U32ArithmeticGate too wide");
+        if (gt.kind == NLX_GATE_U32_SUBTRACTION && (gt.param0 < 1 || (5 + 16) * gt.param0 > d.num_wires)) return ctx->fail(NLX_E_INVAL, "U32SubtractionGate too wide");
+        if (gt.kind == NLX_GATE_U32_RANGE_CHECK && (gt.param0 < 1 || 17 * gt.param0 > d.num_wires)) return ctx->fail(NLX_E_INVAL, "U32RangeCheckGate too wide");
+        if (gt.kind == NLX_GATE_COMPARISON) {
+            const uint32_t cb = gt.param1 ? (gt.param0 + gt.param1 - 1) / gt.param1 : 0;
+            if (gt.param1 < 1 || cb < 1 || cb > 3 || 4 + 5 * gt.param1 + cb + 1 > d.num_wires)
+                return ctx->fail(NLX_E_INVAL, "ComparisonGate: chunk_bits must be in [1, 3] and the gate must fit the wires");
+        }
         if (gt.kind == NLX_GATE_COSET_INTERPOLATION) {
             const uint32_t np = gt.param0 <= 5 ? 1u << gt.param0 : 0;
             if (np < 4 || gt.param1 < 2 || gt.param1 > np || d.degree_bits < gt.param0 + 1 ||

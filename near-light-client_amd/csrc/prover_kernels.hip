@@ -203,6 +203,11 @@ struct GateAcc {
     }
 };
 
+// prod_{x < 4} (l - x): the 2-bit limb range check of the u32 gates
+__device__ __forceinline__ uint64_t limb4(uint64_t l) {
+    return gl::mul(gl::mul(l, gl::sub(l, 1)), gl::mul(gl::sub(l, 2), gl::sub(l, 3)));
+}
+
 __device__ __forceinline__ uint64_t sbox7c(uint64_t x) {
     uint64_t x2 = gl::mul(x, x), x4 = gl::mul(x2, x2), x3 = gl::mul(x, x2);
     return gl::mul(x3, x4);
@@ -430,6 +435,113 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                     prev_iv = iv;
                 }
                 acc.emit(gl::sub(W(1 + nb), prev_iv));
+                break;
+            }
+            case NLX_GATE_U32_ADD_MANY: {
+                const uint32_t na = gd.param0, nops = gd.param1, nl = 18, nrl = 16;
+                for (uint32_t i = 0; i < nops; i++) {
+                    const uint32_t b0 = (na + 3) * i, lb = (na + 3) * nops + nl * i;
+                    uint64_t computed = W(b0 + na);
+                    for (uint32_t j = 0; j < na; j++) computed = gl::add(computed, W(b0 + j));
+                    const uint64_t res = W(b0 + na + 1), cy = W(b0 + na + 2);
+                    acc.emit(gl::sub(gl::add(gl::mul(cy, 1ULL << 32), res), computed));
+                    uint64_t cr = 0, cc = 0;
+                    for (uint32_t j = nl; j-- > 0;) {
+                        const uint64_t l = W(lb + j);
+                        acc.emit(limb4(l));
+                        if (j < nrl) cr = gl::add(gl::mul(cr, 4), l);
+                        else cc = gl::add(gl::mul(cc, 4), l);
+                    }
+                    acc.emit(gl::sub(cr, res));
+                    acc.emit(gl::sub(cc, cy));
+                }
+                break;
+            }
+            case NLX_GATE_U32_ARITHMETIC: {
+                const uint32_t nops = gd.param0;
+                for (uint32_t i = 0; i < nops; i++) {
+                    const uint32_t b0 = 6 * i, lb = 6 * nops + 32 * i;
+                    const uint64_t computed = gl::add(gl::mul(W(b0), W(b0 + 1)), W(b0 + 2));
+                    const uint64_t lo = W(b0 + 3), hi = W(b0 + 4), inv = W(b0 + 5);
+                    const uint64_t hi_not_max = gl::sub(gl::mul(inv, gl::sub(0xFFFFFFFFULL, hi)), 1);
+                    acc.emit(gl::mul(hi_not_max, lo));
+                    acc.emit(gl::sub(gl::add(gl::mul(hi, 1ULL << 32), lo), computed));
+                    uint64_t cl = 0, ch = 0;
+                    for (uint32_t j = 32; j-- > 0;) {
+                        const uint64_t l = W(lb + j);
+                        acc.emit(limb4(l));
+                        if (j < 16) cl = gl::add(gl::mul(cl, 4), l);
+                        else ch = gl::add(gl::mul(ch, 4), l);
+                    }
+                    acc.emit(gl::sub(cl, lo));
+                    acc.emit(gl::sub(ch, hi));
+                }
+                break;
+            }
+            case NLX_GATE_U32_SUBTRACTION: {
+                const uint32_t nops = gd.param0;
+                for (uint32_t i = 0; i < nops; i++) {
+                    const uint32_t b0 = 5 * i, lb = 5 * nops + 16 * i;
+                    const uint64_t initial = gl::sub(gl::sub(W(b0), W(b0 + 1)), W(b0 + 2));
+                    const uint64_t res = W(b0 + 3), bo = W(b0 + 4);
+                    acc.emit(gl::sub(res, gl::add(initial, gl::mul(bo, 1ULL << 32))));
+                    uint64_t c = 0;
+                    for (uint32_t j = 16; j-- > 0;) {
+                        const uint64_t l = W(lb + j);
+                        acc.emit(limb4(l));
+                        c = gl::add(gl::mul(c, 4), l);
+                    }
+                    acc.emit(gl::sub(c, res));
+                    acc.emit(gl::mul(bo, gl::sub(1, bo)));
+                }
+                break;
+            }
+            case NLX_GATE_U32_RANGE_CHECK: {
+                const uint32_t nin = gd.param0;
+                for (uint32_t i = 0; i < nin; i++) {
+                    const uint32_t ab = nin + 16 * i;
+                    uint64_t sum = 0;
+                    for (uint32_t j = 16; j-- > 0;) sum = gl::add(gl::mul(sum, 4), W(ab + j));
+                    acc.emit(gl::sub(sum, W(i)));
+                    for (uint32_t j = 0; j < 16; j++) acc.emit(limb4(W(ab + j)));
+                }
+                break;
+            }
+            case NLX_GATE_COMPARISON: {
+                const uint32_t nbits = gd.param0, nch = gd.param1, cb = (nbits + nch - 1) / nch;
+                const uint32_t fc = 4, sc = 4 + nch, eqd = 4 + 2 * nch, ceq = 4 + 3 * nch, iv = 4 + 4 * nch, msb = 4 + 5 * nch;
+                uint64_t fcomb = 0, scomb = 0;
+                for (uint32_t i = nch; i-- > 0;) {
+                    fcomb = gl::add(gl::mul(fcomb, 1ULL << cb), W(fc + i));
+                    scomb = gl::add(gl::mul(scomb, 1ULL << cb), W(sc + i));
+                }
+                acc.emit(gl::sub(fcomb, W(0)));
+                acc.emit(gl::sub(scomb, W(1)));
+                uint64_t msd = 0;
+                for (uint32_t i = 0; i < nch; i++) {
+                    const uint64_t f = W(fc + i), s2 = W(sc + i);
+                    uint64_t p1 = 1, p2 = 1;
+                    for (uint32_t x2 = 0; x2 < (1u << cb); x2++) {
+                        p1 = gl::mul(p1, gl::sub(f, (uint64_t)x2));
+                        p2 = gl::mul(p2, gl::sub(s2, (uint64_t)x2));
+                    }
+                    acc.emit(p1);
+                    acc.emit(p2);
+                    const uint64_t diff = gl::sub(s2, f), e = W(ceq + i), ivv = W(iv + i);
+                    acc.emit(gl::sub(gl::mul(diff, W(eqd + i)), gl::sub(1, e)));
+                    acc.emit(gl::mul(e, diff));
+                    acc.emit(gl::sub(ivv, gl::mul(e, msd)));
+                    msd = gl::add(ivv, gl::mul(gl::sub(1, e), diff));
+                }
+                acc.emit(gl::sub(W(3), msd));
+                uint64_t bc = 0;
+                for (uint32_t b = 0; b <= cb; b++) {
+                    const uint64_t bit = W(msb + b);
+                    acc.emit(gl::mul(bit, gl::sub(1, bit)));
+                }
+                for (uint32_t b = cb + 1; b-- > 0;) bc = gl::add(gl::add(bc, bc), W(msb + b));
+                acc.emit(gl::sub(gl::add(1ULL << cb, W(3)), bc));
+                acc.emit(gl::sub(W(2), W(msb + cb)));
                 break;
             }
             case NLX_GATE_COSET_INTERPOLATION: {

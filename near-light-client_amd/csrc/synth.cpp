@@ -120,6 +120,11 @@ uint32_t gate_degree(uint32_t kind, uint32_t p0) {
         case NLX_GATE_EXPONENTIATION: return 4;
         case NLX_GATE_RANDOM_ACCESS: return p0 + 1;
         case NLX_GATE_COSET_INTERPOLATION: return 6;  // with_max_degree(4, 8) -> degree 6 (p1)
+        case NLX_GATE_U32_ADD_MANY:
+        case NLX_GATE_U32_ARITHMETIC:
+        case NLX_GATE_U32_SUBTRACTION:
+        case NLX_GATE_U32_RANGE_CHECK:
+        case NLX_GATE_COMPARISON: return 4;  // 1 << limb_bits / 1 << chunk_bits
     }
     return 0;
 }
@@ -155,7 +160,12 @@ static uint32_t build_gate_list(const nlx_synth_params* sp, uint32_t* kinds, uin
     if (sp->pct_extension) add(NLX_GATE_ARITHMETIC_EXT, 10, 0);  // degree 3: "ArithmeticExtension" < "ArithmeticGate" < "Mul..."
     if (sp->pct_arithmetic) add(NLX_GATE_ARITHMETIC, 20, 0);
     if (sp->pct_extension) add(NLX_GATE_MUL_EXT, 13, 0);
-    if (sp->pct_misc) add(NLX_GATE_EXPONENTIATION, 66, 0);       // degree 4
+    if (sp->pct_u32) add(NLX_GATE_COMPARISON, 32, 16);           // degree 4: "ComparisonGate" < "ExponentiationGate" < "U32..."
+    if (sp->pct_misc) add(NLX_GATE_EXPONENTIATION, 66, 0);
+    if (sp->pct_u32) add(NLX_GATE_U32_ADD_MANY, 2, 5);           // num_ops as plonky2x derives them for 135 / 80 wires
+    if (sp->pct_u32) add(NLX_GATE_U32_ARITHMETIC, 3, 0);
+    if (sp->pct_u32) add(NLX_GATE_U32_RANGE_CHECK, 7, 0);
+    if (sp->pct_u32) add(NLX_GATE_U32_SUBTRACTION, 6, 0);
     if (sp->pct_misc) add(NLX_GATE_RANDOM_ACCESS, 4, 4 | (2u << 16));  // degree 5: bits 4, 4 copies, 2 extra constants
     if (sp->pct_misc) add(NLX_GATE_COSET_INTERPOLATION, 4, 6);   // degree 6: CosetInterpolationGate::with_max_degree(4, 8)
     if (sp->pct_poseidon) add(NLX_GATE_POSEIDON, 0, 0);          // degree 7
@@ -163,7 +173,7 @@ static uint32_t build_gate_list(const nlx_synth_params* sp, uint32_t* kinds, uin
 }
 
 void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_selectors) {
-    uint32_t kinds[16], p0[16], p1[16];
+    uint32_t kinds[24], p0[24], p1[24];
     const uint32_t g = build_gate_list(sp, kinds, p0, p1);
     *n_gates = g;
     // greedy selector groups with max_degree = 8 (gates::selectors::selector_polynomials)
@@ -234,9 +244,9 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
     uint32_t n_gates, n_sel;
     nlx_synth_shape(sp, &n_gates, &n_sel);
     int g_base = -1, g_arith = -1, g_pos = -1, g_aext = -1, g_mext = -1, g_red = -1, g_rext = -1, g_pmds = -1, g_exp = -1,
-        g_ra = -1, g_ci = -1, g_const = 1, g_pi = 2;
+        g_ra = -1, g_ci = -1, g_cmp = -1, g_uadd = -1, g_uari = -1, g_usub = -1, g_urc = -1, g_const = 1, g_pi = 2;
     {
-        uint32_t kinds[16], p0[16], p1[16];
+        uint32_t kinds[24], p0[24], p1[24];
         const uint32_t k = build_gate_list(sp, kinds, p0, p1);
         for (uint32_t g = 0; g < k; g++) {
             gates[g].kind = kinds[g]; gates[g].param0 = p0[g]; gates[g].param1 = p1[g]; gates[g].index = g;
@@ -252,6 +262,11 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
                 case NLX_GATE_EXPONENTIATION: g_exp = (int)g; break;
                 case NLX_GATE_RANDOM_ACCESS: g_ra = (int)g; break;
                 case NLX_GATE_COSET_INTERPOLATION: g_ci = (int)g; break;
+                case NLX_GATE_COMPARISON: g_cmp = (int)g; break;
+                case NLX_GATE_U32_ADD_MANY: g_uadd = (int)g; break;
+                case NLX_GATE_U32_ARITHMETIC: g_uari = (int)g; break;
+                case NLX_GATE_U32_SUBTRACTION: g_usub = (int)g; break;
+                case NLX_GATE_U32_RANGE_CHECK: g_urc = (int)g; break;
                 case NLX_GATE_CONSTANT: g_const = (int)g; break;
                 case NLX_GATE_PUBLIC_INPUT: g_pi = (int)g; break;
                 default: break;
@@ -281,6 +296,7 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
     memset(constants, 0, (size_t)(n_sel + NCONST) * n * 8);
     Dsu dsu((size_t)ROUTED * n);
     auto slot = [&](uint32_t col, size_t row) { return (uint32_t)((size_t)col * n + row); };
+    std::vector<uint32_t> pool32;  // routed slots holding 32-bit values (inputs of the u32 gates)
     std::vector<uint32_t> pool;  // routed slots whose value later rows may copy
     pool.reserve(n * 4);
     uint64_t prev_pos_out[12];
@@ -328,6 +344,15 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
                     case 1: kind = NLX_GATE_EXPONENTIATION; gidx = g_exp; break;
                     case 2: kind = NLX_GATE_COSET_INTERPOLATION; gidx = g_ci; break;
                     default: kind = NLX_GATE_RANDOM_ACCESS; gidx = g_ra; break;
+                }
+            }
+            else if (r < (t += sp->pct_u32) && g_cmp >= 0) {
+                switch (row % 5) {
+                    case 0: kind = NLX_GATE_U32_ADD_MANY; gidx = g_uadd; break;
+                    case 1: kind = NLX_GATE_U32_ARITHMETIC; gidx = g_uari; break;
+                    case 2: kind = NLX_GATE_U32_SUBTRACTION; gidx = g_usub; break;
+                    case 3: kind = NLX_GATE_U32_RANGE_CHECK; gidx = g_urc; break;
+                    default: kind = NLX_GATE_COMPARISON; gidx = g_cmp; break;
                 }
             }
         }
@@ -493,6 +518,121 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
                 }
                 break;
             }
+            case NLX_GATE_U32_ADD_MANY: {
+                const uint32_t na = 2, nops = 5, nl = 18;
+                for (uint32_t i = 0; i < nops; i++) {
+                    const uint32_t b0 = (na + 3) * i, lb = (na + 3) * nops + nl * i;
+                    uint64_t sum = 0;
+                    for (uint32_t j = 0; j < na; j++) {
+                        uint64_t v = rng.next() & 0xFFFFFFFFULL;
+                        if (j == 0 && !pool32.empty() && (rng.next() & 1)) {  // a u32 produced earlier in the circuit
+                            const uint32_t src = pool32[rng.below((uint32_t)pool32.size())];
+                            v = wires[src];
+                            dsu.unite(slot(b0 + j, row), src);
+                        }
+                        W_at(b0 + j, row) = v;
+                        sum += v;
+                    }
+                    const uint64_t cin = rng.next() & 1;
+                    W_at(b0 + na, row) = cin;
+                    sum += cin;
+                    const uint64_t res = sum & 0xFFFFFFFFULL, cy = sum >> 32;
+                    W_at(b0 + na + 1, row) = res;
+                    W_at(b0 + na + 2, row) = cy;
+                    for (uint32_t j = 0; j < 16; j++) W_at(lb + j, row) = (res >> (2 * j)) & 3;
+                    for (uint32_t j = 0; j < 2; j++) W_at(lb + 16 + j, row) = (cy >> (2 * j)) & 3;
+                    pool32.push_back(slot(b0 + na + 1, row));
+                }
+                break;
+            }
+            case NLX_GATE_U32_ARITHMETIC: {
+                const uint32_t nops = 3;
+                for (uint32_t i = 0; i < nops; i++) {
+                    const uint32_t b0 = 6 * i, lb = 6 * nops + 32 * i;
+                    uint64_t m0 = rng.next() & 0xFFFFFFFFULL;
+                    const uint64_t m1 = rng.next() & 0xFFFFFFFFULL, ad = rng.next() & 0xFFFFFFFFULL;
+                    if (!pool32.empty() && (rng.next() & 1)) {
+                        const uint32_t src = pool32[rng.below((uint32_t)pool32.size())];
+                        m0 = wires[src];
+                        dsu.unite(slot(b0, row), src);
+                    }
+                    const uint64_t out = m0 * m1 + ad;  // < 2^64, and never a non-canonical field element: hi = 2^32-1 forces lo = 0
+                    const uint64_t lo = out & 0xFFFFFFFFULL, hi = out >> 32;
+                    W_at(b0, row) = m0; W_at(b0 + 1, row) = m1; W_at(b0 + 2, row) = ad;
+                    W_at(b0 + 3, row) = lo; W_at(b0 + 4, row) = hi;
+                    const uint64_t diff = 0xFFFFFFFFULL - hi;
+                    W_at(b0 + 5, row) = diff ? gl::inv(diff) : 0;  // u32::MAX - hi is invertible unless hi = u32::MAX (then lo = 0)
+                    for (uint32_t j = 0; j < 32; j++) W_at(lb + j, row) = (out >> (2 * j)) & 3;
+                    pool32.push_back(slot(b0 + 3, row));
+                    pool32.push_back(slot(b0 + 4, row));
+                }
+                break;
+            }
+            case NLX_GATE_U32_SUBTRACTION: {
+                const uint32_t nops = 6;
+                for (uint32_t i = 0; i < nops; i++) {
+                    const uint32_t b0 = 5 * i, lb = 5 * nops + 16 * i;
+                    uint64_t x = rng.next() & 0xFFFFFFFFULL;
+                    const uint64_t y = rng.next() & 0xFFFFFFFFULL, bin = rng.next() & 1;
+                    if (!pool32.empty() && (rng.next() & 1)) {
+                        const uint32_t src = pool32[rng.below((uint32_t)pool32.size())];
+                        x = wires[src];
+                        dsu.unite(slot(b0, row), src);
+                    }
+                    const bool borrow = x < y + bin;
+                    const uint64_t res = (x + (borrow ? (1ULL << 32) : 0)) - y - bin;
+                    W_at(b0, row) = x; W_at(b0 + 1, row) = y; W_at(b0 + 2, row) = bin;
+                    W_at(b0 + 3, row) = res; W_at(b0 + 4, row) = borrow ? 1 : 0;
+                    for (uint32_t j = 0; j < 16; j++) W_at(lb + j, row) = (res >> (2 * j)) & 3;
+                    pool32.push_back(slot(b0 + 3, row));
+                }
+                break;
+            }
+            case NLX_GATE_U32_RANGE_CHECK: {
+                const uint32_t nin = 7;
+                for (uint32_t i = 0; i < nin; i++) {
+                    uint64_t v = rng.next() & 0xFFFFFFFFULL;
+                    if (!pool32.empty() && (rng.next() & 1)) {
+                        const uint32_t src = pool32[rng.below((uint32_t)pool32.size())];
+                        v = wires[src];
+                        dsu.unite(slot(i, row), src);
+                    }
+                    W_at(i, row) = v;
+                    for (uint32_t j = 0; j < 16; j++) W_at(nin + 16 * i + j, row) = (v >> (2 * j)) & 3;
+                }
+                break;
+            }
+            case NLX_GATE_COMPARISON: {
+                // result = (first <= second) on 32-bit inputs, 16 chunks of 2 bits
+                const uint32_t nch = 16, cb = 2;
+                uint64_t a = rng.next() & 0xFFFFFFFFULL, b = rng.next() & 0xFFFFFFFFULL;
+                if ((rng.next() & 7) == 0) b = a;  // exercise the all-chunks-equal path
+                if (!pool32.empty() && (rng.next() & 1)) {
+                    const uint32_t src = pool32[rng.below((uint32_t)pool32.size())];
+                    a = wires[src];
+                    dsu.unite(slot(0, row), src);
+                }
+                W_at(0, row) = a; W_at(1, row) = b;
+                uint64_t msd = 0;
+                for (uint32_t i = 0; i < nch; i++) {
+                    const uint64_t f = (a >> (cb * i)) & 3, s2 = (b >> (cb * i)) & 3;
+                    const uint64_t diff = gl::sub(s2, f);
+                    const uint64_t eq = f == s2 ? 1 : 0;
+                    W_at(4 + i, row) = f;
+                    W_at(4 + nch + i, row) = s2;
+                    W_at(4 + 2 * nch + i, row) = eq ? 1 : gl::inv(diff);  // equality_dummy: diff * dummy = 1 - chunks_equal
+                    W_at(4 + 3 * nch + i, row) = eq;
+                    const uint64_t iv = eq ? msd : 0;
+                    W_at(4 + 4 * nch + i, row) = iv;
+                    msd = gl::add(iv, eq ? 0 : diff);
+                }
+                W_at(3, row) = msd;
+                const uint64_t shifted = gl::add(1ULL << cb, msd);  // in [1, 2^(cb+1)): msd in (-2^cb, 2^cb)
+                for (uint32_t bb = 0; bb <= cb; bb++) W_at(4 + 5 * nch + bb, row) = (shifted >> bb) & 1;
+                W_at(2, row) = (shifted >> cb) & 1;
+                pool.push_back(slot(2, row));
+                break;
+            }
             case NLX_GATE_COSET_INTERPOLATION: {
                 // 16 extension values on the coset shift*<g>, interpolated at an extension point (the FRI verifier's
                 // compute_evaluation); intermediates every degree-1 = 5 points
@@ -541,6 +681,7 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
         }
         // keep the pool bounded so copies stay "recent" (locality like a real circuit)
         if (pool.size() > 4096) pool.erase(pool.begin(), pool.begin() + 2048);
+        if (pool32.size() > 4096) pool32.erase(pool32.begin(), pool32.begin() + 2048);
     }
     // selector columns
     for (size_t row = 0; row < n; row++) {

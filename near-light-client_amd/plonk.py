@@ -13,7 +13,8 @@ from ._lib import dll, ptr, NlxError
 
 (GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_BASE_SUM, GATE_POSEIDON, GATE_ARITHMETIC_EXT,
  GATE_MUL_EXT, GATE_REDUCING, GATE_REDUCING_EXT, GATE_POSEIDON_MDS, GATE_EXPONENTIATION, GATE_RANDOM_ACCESS,
- GATE_COSET_INTERPOLATION) = range(14)
+ GATE_COSET_INTERPOLATION, GATE_U32_ADD_MANY, GATE_U32_ARITHMETIC, GATE_U32_SUBTRACTION, GATE_U32_RANGE_CHECK,
+ GATE_COMPARISON) = range(19)
 
 
 class GateDesc(ctypes.Structure):
@@ -34,7 +35,8 @@ class SynthParams(ctypes.Structure):
     _fields_ = [("log_n", ctypes.c_uint32), ("num_public_inputs", ctypes.c_uint32),
                 ("pct_poseidon", ctypes.c_uint32), ("pct_arithmetic", ctypes.c_uint32),
                 ("pct_base_sum", ctypes.c_uint32), ("pct_constant", ctypes.c_uint32), ("seed", ctypes.c_uint64),
-                ("pct_extension", ctypes.c_uint32), ("pct_misc", ctypes.c_uint32)]
+                ("pct_extension", ctypes.c_uint32), ("pct_misc", ctypes.c_uint32), ("pct_u32", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
 
 
 class CircuitConfig:
@@ -66,11 +68,11 @@ class SyntheticCircuit:
     """A satisfiable nearx-shaped circuit + witness (see csrc/synth.cpp)."""
 
     def __init__(self, log_n, seed=1, num_public_inputs=4, pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5,
-                 pct_constant=5, pct_extension=0, pct_misc=0, config=None):
+                 pct_constant=5, pct_extension=0, pct_misc=0, pct_u32=0, config=None):
         self.config = config or CircuitConfig()
         self.log_n = log_n
         sp = SynthParams(log_n, num_public_inputs, pct_poseidon, pct_arithmetic, pct_base_sum, pct_constant, seed,
-                         pct_extension, pct_misc)
+                         pct_extension, pct_misc, pct_u32, 0)
         ng, ns = ctypes.c_uint32(), ctypes.c_uint32()
         dll.nlx_synth_shape(ctypes.byref(sp), ctypes.byref(ng), ctypes.byref(ns))
         n = 1 << log_n

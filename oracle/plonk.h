@@ -33,7 +33,13 @@ enum {
     ORC_GATE_POSEIDON_MDS = 10,
     ORC_GATE_EXPONENTIATION = 11, /* param0 = num_power_bits (66) */
     ORC_GATE_RANDOM_ACCESS = 12,  /* param0 = bits, param1 = num_copies | num_extra_constants << 16 */
-    ORC_GATE_COSET_INTERPOLATION = 13 /* param0 = subgroup_bits (4), param1 = degree (6) */
+    ORC_GATE_COSET_INTERPOLATION = 13, /* param0 = subgroup_bits (4), param1 = degree (6) */
+    /* plonky2x frontend::num::u32::gates (plonky2-u32): 2-bit limbs throughout */
+    ORC_GATE_U32_ADD_MANY = 14,    /* param0 = num_addends, param1 = num_ops */
+    ORC_GATE_U32_ARITHMETIC = 15,  /* param0 = num_ops */
+    ORC_GATE_U32_SUBTRACTION = 16, /* param0 = num_ops */
+    ORC_GATE_U32_RANGE_CHECK = 17, /* param0 = num_input_limbs */
+    ORC_GATE_COMPARISON = 18       /* param0 = num_bits, param1 = num_chunks */
 };
 
 typedef struct {

@@ -21,6 +21,9 @@ SHAPES = [
     (7, dict(pct_poseidon=0, pct_arithmetic=0, pct_base_sum=0, pct_constant=5, pct_extension=60)),
     (9, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=20, pct_misc=30)),  # all 14 gates
     (10, dict(pct_poseidon=0, pct_arithmetic=0, pct_base_sum=0, pct_constant=5, pct_extension=0, pct_misc=70)),
+    (9, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=10, pct_misc=20, pct_u32=30)),  # all 19 gates
+    (10, dict(pct_poseidon=0, pct_arithmetic=0, pct_base_sum=0, pct_constant=5, pct_u32=80)),  # u32 / comparison gates only
+    (12, dict(pct_poseidon=20, pct_arithmetic=20, pct_base_sum=5, pct_constant=5, pct_u32=30)),  # nearx-like: hashing + u32 arithmetic
 ]
 
 

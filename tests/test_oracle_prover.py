@@ -17,6 +17,8 @@ from conftest import P
     (8, dict(pct_poseidon=15, pct_arithmetic=20, pct_base_sum=5, pct_constant=5, pct_extension=30)),  # 10 gates, 3 selectors
     (7, dict(pct_poseidon=0, pct_arithmetic=0, pct_base_sum=0, pct_constant=5, pct_extension=60)),
     (8, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=20, pct_misc=30)),  # 14 gates
+    (8, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=10, pct_misc=20, pct_u32=30)),  # all 19 gates
+    (7, dict(pct_poseidon=0, pct_arithmetic=0, pct_base_sum=0, pct_constant=5, pct_u32=80)),
 ])
 def test_prove_verify_roundtrip(nlx, orc, log_n, kw):
     syn = nlx.SyntheticCircuit(log_n, seed=log_n, **kw)
@@ -144,6 +146,29 @@ def test_misc_gates_constrain_their_rows(nlx, orc):
     # outputs, a power bit, an index, a bit wire; coset interpolation: shift, a value, the evaluation value, an
     # intermediate eval / prod, the shifted point
     for kind, wire in ((10, 25), (11, 1), (11, 70), (12, 0), (12, 74), (13, 0), (13, 8), (13, 35), (13, 37), (13, 43), (13, 45)):
+        g = syn.gates[kinds.index(kind)]
+        rows = np.nonzero(syn.constants[g.selector_index] == g.index)[0]
+        assert rows.size > 0, kind
+        w = syn.wires.copy()
+        w[wire, rows[0]] = (int(w[wire, rows[0]]) + 1) % P
+        assert circ.verify(circ.prove(w, syn.public_inputs)) < 1, (kind, wire)
+    circ.close()
+
+
+def test_u32_gates_constrain_their_rows(nlx, orc):
+    """plonky2x's u32 gates (U32AddMany, U32Arithmetic, U32Subtraction, U32RangeCheck) and ComparisonGate: the
+    generated witness is accepted, a witness broken on one of their rows is rejected"""
+    syn = nlx.SyntheticCircuit(8, seed=29, pct_poseidon=5, pct_arithmetic=5, pct_base_sum=5, pct_constant=5, pct_u32=60)
+    kinds = [g.kind for g in syn.gates]
+    assert kinds == [0, 1, 2, 4, 3, 18, 14, 15, 17, 16, 5]  # (degree, id): Comparison < U32AddMany < U32Arithmetic < U32RangeCheck < U32Subtraction
+    circ = orc.Circuit.from_synthetic(syn)
+    assert circ.verify(circ.prove(syn.wires, syn.public_inputs)) == 1
+    cases = ((14, 3), (14, 4), (14, 25), (14, 41),        # add-many: result, carry, a result limb, a carry limb
+             (15, 3), (15, 4), (15, 5), (15, 18), (15, 40),  # arithmetic: low, high, inverse, low limb, high limb
+             (16, 3), (16, 4), (16, 30),                  # subtraction: result, borrow, limb
+             (17, 0), (17, 7),                            # range check: input, aux limb
+             (18, 0), (18, 2), (18, 3), (18, 4), (18, 36), (18, 52), (18, 68), (18, 84))  # comparison wires of every class
+    for kind, wire in cases:
         g = syn.gates[kinds.index(kind)]
         rows = np.nonzero(syn.constants[g.selector_index] == g.index)[0]
         assert rows.size > 0, kind
