@@ -285,7 +285,10 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
     }
     for (int i = 0; i <= NLX_MAX_STAGES; i++)
         if (hipEventCreate(&s->ev[i]) != hipSuccess) return fail(ctx->fail(NLX_E_HIP, "hipEventCreate failed"));
-    NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(ctx->hip_fail(e, "hipStreamSynchronize"));
+    }
     *out = s;
     return NLX_OK;
 }
