@@ -115,3 +115,69 @@ def test_stark_build_rejects_bad_programs(nlx, ctx):
         build_with(good, quotient_degree_factor=4)                    # > 2^rate_bits
     with pytest.raises(nlx.NlxError):
         build_with(good, quotient_degree_factor=3)                    # not a power of two
+
+
+def _random_air(S, rng, n_cols, n_pis, with_periodic):
+    """A random constraint DAG over every VM feature.  The trace will NOT satisfy it - byte equality between
+    the two provers does not need that (the quotient path is a fixed linear map of the constraint values)."""
+    air = S.Air(n_cols, n_pis)
+    leaves = [air.local(i) for i in range(n_cols)] + [air.next(i) for i in range(n_cols)]
+    leaves += [air.public(i) for i in range(n_pis)]
+    if with_periodic:
+        leaves += [air.periodic([int(v) for v in rng.integers(0, P, 8, dtype=np.uint64)]) for _ in range(2)]
+    if n_cols >= 8:
+        leaves += [air.pack(0, 8), air.pack(n_cols - 5, 5, next_row=True), air.pack(1, 1)]
+    pool = list(leaves)
+    for _ in range(int(rng.integers(6, 14))):
+        # one constraint: a few random binary ops, degree kept <= 3
+        e = pool[int(rng.integers(0, len(pool)))]
+        for _ in range(int(rng.integers(1, 6))):
+            o = pool[int(rng.integers(0, len(pool)))]
+            k = int(rng.integers(0, 6))
+            if k == 0 and e.degree + o.degree <= 3:
+                e = e * o
+            elif k == 1:
+                e = e + o * (1 << int(rng.integers(1, 40)))
+            elif k == 2:
+                e = e - (1 << int(rng.integers(1, 33))) * o
+            elif k == 3:
+                e = e - o
+            elif k == 4:
+                e = e + int(rng.integers(0, P, dtype=np.uint64))
+            else:
+                e = int(rng.integers(0, P, dtype=np.uint64)) * e + o
+        pool.append(e)
+        kind = int(rng.integers(0, 5))
+        if kind == 0 and e.degree <= 2:
+            air.constraint_transition(e)
+        elif kind == 1 and e.degree <= 2:
+            air.constraint_first_row(e)
+        elif kind == 2 and e.degree <= 2:
+            air.constraint_last_row(e)
+        elif kind == 3:
+            air.constraint_boolean(int(rng.integers(0, n_cols)))
+        else:
+            air.constraint(e)
+    return air
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_stark_random_programs_bytes_equal_oracle(nlx, ctx, orc, seed):
+    S = nlx.stark
+    rng = np.random.default_rng(1000 + seed)
+    n_cols = int(rng.integers(2, 24))
+    n_pis = int(rng.integers(0, 4))
+    air = _random_air(S, rng, n_cols, n_pis, with_periodic=bool(seed & 1))
+    db = int(rng.integers(5, 12))
+    rate_bits = 1 if air.quotient_degree_factor() <= 2 else 2
+    cfg = S.StarkConfig(rate_bits=rate_bits + (seed % 3 == 2), fri_num_queries=12, fri_pow_bits=6,
+                        num_challenges=1 + (seed % 2), fri_arity_bits=2 + seed % 3)
+    st = S.Stark(air, db, cfg)
+    from conftest import rand_field
+    t = rand_field(rng, (n_cols, 1 << db))
+    pis = rand_field(rng, (n_pis,))
+    want = orc.stark_prove(st.desc, t, pis)
+    pr = st.build(ctx)
+    got = pr.prove(t, pis)
+    assert got == want, "seed %d: %d cols, 2^%d rows, %d words" % (seed, n_cols, db, st.desc.n_words)
+    pr.close()

@@ -1,0 +1,25 @@
+"""Differential fuzz (run on the GPU box): random gate mixes / sizes / public-input counts; GPU proof bytes must
+equal the oracle prover and the oracle verifier must accept.  `python tools/fuzz_plonk.py`."""
+import sys, time
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle'); sys.path.insert(0,'/root/repo/tests')
+import nlxpkg; nlx=nlxpkg.load()
+import oracle_py as orc
+import numpy as np
+ctx=nlx.Context(0)
+rng=np.random.default_rng(77)
+bad=0; n=0; t0=time.time()
+for it in range(60):
+    log_n=int(rng.integers(5,11))
+    pct=[int(x) for x in rng.integers(0,30,7)]
+    tot=sum(pct)
+    if tot>95: pct=[p*90//tot for p in pct]
+    kw=dict(pct_poseidon=pct[0],pct_arithmetic=pct[1],pct_base_sum=pct[2],pct_constant=max(pct[3],1),pct_extension=pct[4],pct_misc=pct[5],pct_u32=pct[6])
+    syn=nlx.SyntheticCircuit(log_n, seed=5000+it, num_public_inputs=int(rng.integers(0,9)), **kw)
+    ref=orc.Circuit.from_synthetic(syn); cd=nlx.CircuitData.from_synthetic(ctx, syn)
+    want=ref.prove(syn.wires, syn.public_inputs); got=cd.prove(syn.wires, syn.public_inputs)
+    ok = got==want and ref.verify(got)==1
+    n+=1
+    if not ok:
+        bad+=1; print("MISMATCH", it, log_n, kw)
+    cd.close(); ref.close()
+print("fuzz: %d circuits, %d mismatches, %.1fs" % (n,bad,time.time()-t0))
