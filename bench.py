@@ -128,11 +128,11 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
     import numpy as np
     gate_mix = dict(pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)
     syn = nlx.SyntheticCircuit(args.log_n, seed=1000 + rank, num_public_inputs=64, **gate_mix)
-    # public inputs = the real SyncCircuit I/O of the reference's fixture test_0.json: 32-byte trusted
+    # public inputs = the real SyncCircuit I/O of the reference's fixture main_2.json (BASELINE.json configs[0]/[1]): 32-byte trusted
     # header hash in, 32-byte new head hash out (nearx/src/sync.rs:37,43), one field element per byte
     from importlib import import_module
     io = import_module("nlx_amd.nearx_io")
-    sync_in, sync_out = io.sync_io(io.load_fixture(os.path.join(ROOT, "tests", "golden", "near", "test_0.json")))
+    sync_in, sync_out = io.sync_io(io.load_fixture(os.path.join(ROOT, "tests", "golden", "near", "main_2.json")))
     syn.set_public_inputs(io.bytes_to_field_elements(sync_in + sync_out))
     # witness resident in HBM before the timed region (device tensor handed over by pointer)
     wires = torch.from_numpy(syn.wires.view(np.int64)).cuda()
@@ -220,7 +220,7 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
             "config": {"workload": "SyncCircuit-shaped plonky2 proof (standard_recursion_config, 2^%d rows, "
                                    "135 wires, rate 8, 28 queries, 16 PoW bits), replicas only" % args.log_n,
                        "log_n": args.log_n, "gate_mix_pct": gate_mix,
-                       "public_inputs": "64 bytes of real Sync I/O (fixtures/test_0.json): new head hash 0x%s" % sync_out.hex(), "proof_bytes": len(cds[0].prove(wires, pis)),
+                       "public_inputs": "64 bytes of real Sync I/O (fixtures/main_2.json): new head hash 0x%s" % sync_out.hex(), "proof_bytes": len(cds[0].prove(wires, pis)),
                        "proofs_in_flight_per_gpu": n_workers, "witness": args.host_witness or "resident in HBM", "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

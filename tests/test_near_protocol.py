@@ -121,3 +121,20 @@ def test_gpu_sha256_stark_of_a_real_sync_step(nlx, ctx, orc):
     assert got == nlx.nearx_io.b58decode32(nxt["inner_lite"]["next_bp_hash"])
     assert orc.stark_verify(sp.stark.desc, proof) == 1
     sp.close()
+
+
+def test_mainnet_walk_to_the_bench_fixture(nlx):
+    """main_0 -> main_1 -> main_2: the Sync step whose I/O bytes are the bench's public inputs
+    (BASELINE.json configs[0]: "SyncCircuit prove on fixtures/main_2.json")."""
+    P, io = nlx.near_protocol, nlx.nearx_io
+    head = load("main_0.json")
+    bps = head["next_bps"]
+    for name in ("main_1.json", "main_2.json"):
+        nxt = load(name)
+        out = P.sync(head, bps, nxt)
+        head = nxt
+        bps = out["next_bps"] or bps
+    fx = io.load_fixture(os.path.join(NEAR, "main_2.json"))
+    sync_in, sync_out = io.sync_io(fx)
+    assert sync_out == out["new_head_hash"] and len(sync_in) == 32
+    assert sync_in == io.header_hash(load("main_1.json"))   # the trusted hash of step 2 is the head step 1 produced
