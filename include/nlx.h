@@ -274,7 +274,9 @@ int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint6
 #define NLX_AIR_PERIODIC 11        /* r[dst] = periodic column a at this row (values[a][row mod period]) */
 #define NLX_AIR_PACK_LOCAL 12      /* r[dst] = sum_{i<b} 2^i local_values[a+i], 1 <= b <= 32 (bits -> word) */
 #define NLX_AIR_PACK_NEXT 13       /* r[dst] = sum_{i<b} 2^i next_values[a+i] */
-#define NLX_AIR_EMIT_BOOL 14       /* constraint(x * (x - 1)), x = local_values[a] */
+#define NLX_AIR_EMIT_BOOL 14       /* constraint(x * (x - 1)) for x = local_values[a .. a + max(b, 1)), in column order */
+#define NLX_AIR_LOADV 15           /* scheduling hint: the next `dst` (<= 8) words are independent LOCAL / NEXT / PUBLIC /
+                                      PERIODIC loads with distinct destinations; the kernel issues them together */
 #define NLX_AIR_NUM_REGS 64
 #define NLX_AIR_MAX_PERIODIC 16
 

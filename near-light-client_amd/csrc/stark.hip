@@ -101,9 +101,48 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
                 continue;
             }
             case NLX_AIR_EMIT_BOOL: {
-                const uint64_t v = p.trace[(size_t)a * L + row];
-                c = gl::mul(v, gl::sub(v, 1));
-                break;
+                // x (x - 1) for b consecutive columns: eight loads in flight, constraints emitted in column order
+                const uint64_t* src = p.trace + (size_t)a * L + row;
+                const uint32_t cnt = b ? b : 1;
+                for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
+                    uint64_t v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = i0 + i < cnt ? src[(size_t)(i0 + i) * L] : 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        if (i0 + i < cnt) {
+                            const uint64_t cb = gl::mul(v[i], gl::sub(v[i], 1));
+                            acc0 = gl::add(gl::mul(acc0, a0), cb);
+                            if (two) acc1 = gl::add(gl::mul(acc1, a1), cb);
+                        }
+                    }
+                }
+                continue;
+            }
+            case NLX_AIR_LOADV: {
+                // the next `dst` words are independent loads: issue them all, then write the register file
+                uint64_t v[8];
+                uint32_t d8[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    v[i] = 0;
+                    d8[i] = 0;
+                    if ((uint32_t)i < dst) {
+                        const uint64_t w2 = p.program[pc + 1 + i];
+                        const uint32_t op2 = (uint32_t)(w2 & 0xFF), a2 = (uint32_t)((w2 >> 24) & 0xFFFF);
+                        d8[i] = (uint32_t)((w2 >> 8) & 0xFFFF);
+                        const uint64_t* src = op2 == NLX_AIR_LOCAL ? p.trace + (size_t)a2 * L + row
+                                            : op2 == NLX_AIR_NEXT ? p.trace + (size_t)a2 * L + row_next
+                                            : op2 == NLX_AIR_PUBLIC ? p.pis + a2
+                                            : p.periodic + ((((size_t)a2 << p.qdb) + rq) << p.period_bits) + (k & ((1u << p.period_bits) - 1));
+                        v[i] = *src;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if ((uint32_t)i < dst) my[d8[i] * bd] = v[i];
+                pc += dst;
+                continue;
             }
             case NLX_AIR_EMIT_TRANSITION: c = gl::mul(my[a * bd], z_last); break;
             case NLX_AIR_EMIT_FIRST: c = gl::mul(my[a * bd], l_first); break;
@@ -181,11 +220,26 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
             const uint64_t w = prog[pc];
             const uint32_t op = (uint32_t)(w & 0xFF), dst = (uint32_t)((w >> 8) & 0xFFFF);
             const uint32_t a = (uint32_t)((w >> 24) & 0xFFFF), b = (uint32_t)((w >> 40) & 0xFFFF);
-            if (op > NLX_AIR_EMIT_BOOL) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
+            if (op > NLX_AIR_LOADV) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
+            if (op == NLX_AIR_LOADV) {
+                // a hint: the following words are validated as the ordinary loads they are
+                if (dst < 1 || dst > 8 || pc + dst >= d.n_words) return ctx->fail(NLX_E_INVAL, "AIR word %u: LOADV count", pc);
+                uint32_t seen_dst[8];
+                for (uint32_t i = 0; i < dst; i++) {
+                    const uint64_t w2 = prog[pc + 1 + i];
+                    const uint32_t op2 = (uint32_t)(w2 & 0xFF), d2 = (uint32_t)((w2 >> 8) & 0xFFFF);
+                    if (op2 != NLX_AIR_LOCAL && op2 != NLX_AIR_NEXT && op2 != NLX_AIR_PUBLIC && op2 != NLX_AIR_PERIODIC)
+                        return ctx->fail(NLX_E_INVAL, "AIR word %u: LOADV must be followed by plain loads", pc);
+                    for (uint32_t j = 0; j < i; j++)
+                        if (seen_dst[j] == d2) return ctx->fail(NLX_E_INVAL, "AIR word %u: LOADV destinations must be distinct", pc);
+                    seen_dst[i] = d2;
+                }
+                continue;
+            }
             const bool writes = op <= NLX_AIR_MUL || (op >= NLX_AIR_PERIODIC && op <= NLX_AIR_PACK_NEXT);
             if ((op == NLX_AIR_PACK_LOCAL || op == NLX_AIR_PACK_NEXT) && (b < 1 || b > 32 || a + b > d.n_cols))
                 return ctx->fail(NLX_E_INVAL, "AIR word %u: PACK range out of the trace", pc);
-            if (op == NLX_AIR_EMIT_BOOL && a >= d.n_cols) return ctx->fail(NLX_E_INVAL, "AIR word %u: column out of range", pc);
+            if (op == NLX_AIR_EMIT_BOOL && a + (b ? b : 1) > d.n_cols) return ctx->fail(NLX_E_INVAL, "AIR word %u: column out of range", pc);
             if ((w >> 56) != 0 && op != NLX_AIR_ADD && op != NLX_AIR_SUB) return ctx->fail(NLX_E_INVAL, "AIR word %u: shift on a non-ADD/SUB word", pc);
             if ((w >> 62) != 0) return ctx->fail(NLX_E_INVAL, "AIR word %u: reserved bits set", pc);
             if (writes && dst >= NLX_AIR_NUM_REGS) return ctx->fail(NLX_E_INVAL, "AIR word %u: register out of range", pc);

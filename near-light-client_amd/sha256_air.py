@@ -101,8 +101,7 @@ def sha256_air():
 
     # 1. booleanity
     for base, cnt in ((A, 192), (W1B, 64), (CA, 8), (CY, 8), (IS_FIRST, 1)):
-        for i in range(cnt):
-            air.constraint_boolean(base + i)
+        air.constraint_boolean(base, cnt)
     # 2. the two decomposed schedule words
     air.constraint(pk(L, W1B) - L(WIN + 1))
     air.constraint(pk(L, W14B) - L(WIN + 14))

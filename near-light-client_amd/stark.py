@@ -19,9 +19,10 @@ from ._lib import dll, ptr, NlxError
 
 P = 0xFFFFFFFF00000001
 (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_CONST, AIR_ADD, AIR_SUB, AIR_MUL, AIR_EMIT_TRANSITION, AIR_EMIT_FIRST,
- AIR_EMIT_LAST, AIR_EMIT, AIR_PERIODIC, AIR_PACK_LOCAL, AIR_PACK_NEXT, AIR_EMIT_BOOL) = range(15)
+ AIR_EMIT_LAST, AIR_EMIT, AIR_PERIODIC, AIR_PACK_LOCAL, AIR_PACK_NEXT, AIR_EMIT_BOOL, AIR_LOADV) = range(16)
 AIR_NUM_REGS = 64
-AIR_MAX_RESIDENT_LEAVES = 6
+AIR_MAX_RESIDENT_LEAVES = 12   # loads kept in registers (LRU) before they are re-loaded
+AIR_LOAD_BATCH = 8             # loads issued together (NLX_AIR_LOADV): memory-level parallelism of the VM
 
 
 class StarkDesc(ctypes.Structure):
@@ -155,31 +156,32 @@ class Air:
 
     # ConstraintConsumer
     def constraint_transition(self, e):
-        self._emits.append((AIR_EMIT_TRANSITION, e))
+        self._emits.append((AIR_EMIT_TRANSITION, e, 1))
 
     def constraint_first_row(self, e):
-        self._emits.append((AIR_EMIT_FIRST, e))
+        self._emits.append((AIR_EMIT_FIRST, e, 1))
 
     def constraint_last_row(self, e):
-        self._emits.append((AIR_EMIT_LAST, e))
+        self._emits.append((AIR_EMIT_LAST, e, 1))
 
     def constraint(self, e):
-        self._emits.append((AIR_EMIT, e))
+        self._emits.append((AIR_EMIT, e, 1))
 
-    def constraint_boolean(self, col):
-        """constraint(x * (x - 1)) for x = local(col), as one VM instruction."""
-        assert 0 <= col < self.n_cols
-        self._emits.append((AIR_EMIT_BOOL, self._leaf(AIR_LOCAL, col, 1)))
+    def constraint_boolean(self, col, count=1):
+        """constraint(x * (x - 1)) for x = local(col) .. local(col + count - 1), in column order, as one VM
+        instruction (eight loads in flight)."""
+        assert 0 <= col and count >= 1 and col + count <= self.n_cols
+        self._emits.append((AIR_EMIT_BOOL, self._leaf(AIR_LOCAL, col, 1), count))
 
     @property
     def num_constraints(self):
-        return len(self._emits)
+        return sum(cnt for _, _, cnt in self._emits)
 
     @property
     def constraint_degree(self):
         """Stark::constraint_degree(): filters (z_last / lagrange) add one to the expression degree."""
         d = 1
-        for op, e in self._emits:
+        for op, e, _ in self._emits:
             d = max(d, 2 if op == AIR_EMIT_BOOL else e.degree + (0 if op == AIR_EMIT else 1))
         return d
 
@@ -190,15 +192,27 @@ class Air:
         return 1 << (q - 1).bit_length()
 
     def compile(self):
-        """Flatten the DAG into program words.  Shared sub-expressions (ADD/SUB/MUL nodes) are evaluated once
-        and stay in their register until the last use.  Leaves (trace / public / periodic / constant loads)
-        are loaded at their first use inside a constraint, kept while registers last and otherwise evicted
-        (least recently used first) and simply re-loaded - they are rematerialisable, so register pressure
-        only ever comes from live sub-expressions.  Constraints are emitted in declaration order (alpha
-        powers)."""
+        """Flatten the DAG into program words.
+
+        * Shared sub-expressions (ADD / SUB / MUL nodes) and PACK words are computed once and stay in their
+          register until the last use anywhere in the program.
+        * Plain loads (trace / public / periodic / constant) are rematerialisable: at most
+          AIR_MAX_RESIDENT_LEAVES stay resident (LRU), the rest are re-loaded, so the register file - the LDS
+          footprint that bounds the quotient kernel's occupancy - stays small.
+        * Loads are issued in batches: at a miss the assembler looks ahead in the constraint for the next
+          loads it will need and emits them together behind one NLX_AIR_LOADV hint, so the kernel has up to
+          AIR_LOAD_BATCH loads in flight per lane instead of one.
+        Constraints are emitted in declaration order (that order defines the alpha powers for prover and
+        verifier alike)."""
         ops = (AIR_ADD, AIR_SUB, AIR_MUL)
-        computed, per_emit, all_ops = set(), [], []
-        for eop, root in self._emits:
+        packs = (AIR_PACK_LOCAL, AIR_PACK_NEXT)
+        batchable = (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_PERIODIC)
+
+        def is_value(x):
+            return x.op in ops or x.op in packs
+
+        computed, per_emit, all_vals = set(), [], []
+        for eop, root, _ in self._emits:
             if eop == AIR_EMIT_BOOL:
                 per_emit.append([])
                 continue
@@ -208,62 +222,106 @@ class Air:
                 if done:
                     nodes.append(x)
                     continue
-                if x.op not in ops or id(x) in seen or id(x) in computed:
+                if not is_value(x) or id(x) in seen or id(x) in computed:
                     continue
                 seen.add(id(x))
                 stack.append((x, True))
-                stack.append((x.b, False))
-                stack.append((x.a, False))
+                if x.op in ops:
+                    stack.append((x.b, False))
+                    stack.append((x.a, False))
             for x in nodes:
                 computed.add(id(x))
-                all_ops.append(x)
+                all_vals.append(x)
             per_emit.append(nodes)
-        for x in all_ops:
+        for x in all_vals:
             x.uses, x.reg = 0, None
-        for x in all_ops:
-            for y in (x.a, x.b):
-                if y.op in ops:
-                    y.uses += 1
-        for eop, root in self._emits:
-            if root.op in ops and eop != AIR_EMIT_BOOL:
+        for x in all_vals:
+            if x.op in ops:
+                for y in (x.a, x.b):
+                    if is_value(y):
+                        y.uses += 1
+        for eop, root, _ in self._emits:
+            if eop != AIR_EMIT_BOOL and is_value(root):
                 root.uses += 1
 
         words = []
-        free = list(range(AIR_NUM_REGS - 1, -1, -1))
-        resident = []  # leaves currently holding a register, least recently used first
+        free = list(range(AIR_NUM_REGS))
+        resident = []  # plain loads currently holding a register, least recently used first
 
-        def alloc(pinned=(), for_leaf=False):
-            # leaves beyond a small resident set are evicted first: they are one load away, and the size of the
-            # register file (highest register ever used) sets the quotient kernel's LDS footprint / occupancy
-            if free and not (for_leaf and len(resident) >= AIR_MAX_RESIDENT_LEAVES):
-                return min_pop(free)
-            for i, y in enumerate(resident):
-                if not any(y is q for q in pinned):
-                    resident.pop(i)
-                    r, y.reg = y.reg, None
-                    return r
-            if free:
-                return min_pop(free)
-            raise ValueError("AIR needs more than %d live registers" % AIR_NUM_REGS)
-
-        def min_pop(lst):
-            r = min(lst)
-            lst.remove(r)
+        def take_free():
+            r = min(free)
+            free.remove(r)
             return r
 
-        def ensure(y, pinned=()):
-            if y.op in ops:
-                return y.reg
-            if y.reg is None:
-                y.reg = alloc(pinned, True)
-                if y.op == AIR_CONST:
-                    words.append(AIR_CONST | y.reg << 8)
-                    words.append(y.a)
-                else:
-                    words.append(y.op | y.reg << 8 | y.a << 24 | (y.b or 0) << 40)
-            else:
-                resident[:] = [q for q in resident if q is not y]
+        cur = {"seq": [], "pos": 0}
+
+        def next_use(y):
+            seq = cur["seq"]
+            for i in range(cur["pos"], len(seq)):
+                if seq[i] is y:
+                    return i
+            return 1 << 30
+
+        def alloc(pinned=(), for_leaf=False, needed_at=None):
+            """A free register, or the one of the resident load whose next use is farthest away (Belady).
+            With `needed_at` (prefetch) the eviction is refused - returns None - when every candidate is needed
+            sooner than the load being prefetched."""
+            if free and not (for_leaf and len(resident) >= AIR_MAX_RESIDENT_LEAVES):
+                return take_free()
+            best, best_use = None, -1
+            for y in resident:
+                if any(y is q for q in pinned):
+                    continue
+                u = next_use(y)
+                if u > best_use:
+                    best, best_use = y, u
+            if best is not None and (needed_at is None or best_use > needed_at):
+                resident[:] = [q for q in resident if q is not best]
+                r, best.reg = best.reg, None
+                return r
+            if needed_at is not None:
+                return None
+            if free:
+                return take_free()
+            raise ValueError("AIR needs more than %d live registers" % AIR_NUM_REGS)
+
+        def touch(y):
+            resident[:] = [q for q in resident if q is not y]
             resident.append(y)
+
+        def load_word(y):
+            return y.op | y.reg << 8 | y.a << 24
+
+        def ensure(y, pinned, upcoming):
+            """Register of operand y; `upcoming` = the plain loads this constraint will need next."""
+            if is_value(y):
+                return y.reg
+            if y.reg is not None:
+                touch(y)
+                return y.reg
+            if y.op == AIR_CONST:
+                y.reg = alloc(pinned, True)
+                words.append(AIR_CONST | y.reg << 8)
+                words.append(y.a)
+                touch(y)
+                return y.reg
+            y.reg = alloc(pinned, True)
+            touch(y)
+            batch = [y]
+            for z in upcoming:
+                if len(batch) >= AIR_LOAD_BATCH:
+                    break
+                if z.op in batchable and z.reg is None and not any(z is q for q in batch):
+                    r = alloc(tuple(pinned) + tuple(batch), True, needed_at=next_use(z))
+                    if r is None:
+                        break
+                    z.reg = r
+                    touch(z)
+                    batch.append(z)
+            if len(batch) > 1:
+                words.append(AIR_LOADV | len(batch) << 8)
+            for z in batch:
+                words.append(load_word(z))
             return y.reg
 
         def release(y):
@@ -272,37 +330,43 @@ class Air:
                 if y.reg is not None:
                     free.append(y.reg)
                 y.reg = None
-                if y.op not in ops:
+                if not is_value(y):
                     resident[:] = [q for q in resident if q is not y]
 
-        for (op, root), nodes in zip(self._emits, per_emit):
+        for (op, root, cnt), nodes in zip(self._emits, per_emit):
             if op == AIR_EMIT_BOOL:
-                words.append(AIR_EMIT_BOOL | root.a << 24)
+                words.append(AIR_EMIT_BOOL | root.a << 24 | cnt << 40)
                 continue
-            # leaf use counts within this constraint
-            leaves = {}
+            # plain-load use counts within this constraint, and their order of use
+            leaf_seq = []
             for x in nodes:
-                for y in (x.a, x.b):
-                    if y.op not in ops:
-                        leaves[id(y)] = y
-            if root.op not in ops:
-                leaves[id(root)] = root
-            for y in leaves.values():
+                if x.op in ops:
+                    for y in (x.a, x.b):
+                        if not is_value(y):
+                            leaf_seq.append(y)
+            if not is_value(root):
+                leaf_seq.append(root)
+            for y in leaf_seq:
                 y.uses, y.reg = 0, None
+            for y in leaf_seq:
+                y.uses += 1
+            pos = 0
+            cur["seq"], cur["pos"] = leaf_seq, 0
             for x in nodes:
-                for y in (x.a, x.b):
-                    if y.op not in ops:
-                        y.uses += 1
-            if root.op not in ops:
-                root.uses += 1
-            for x in nodes:
-                ra = ensure(x.a)
-                rb = ensure(x.b, (x.a,))
+                if x.op in packs:
+                    x.reg = alloc()
+                    words.append(x.op | x.reg << 8 | x.a << 24 | x.b << 40)
+                    continue
+                n_leaf = sum(1 for y in (x.a, x.b) if not is_value(y))
+                ra = ensure(x.a, (), leaf_seq[pos:pos + 4 * AIR_LOAD_BATCH])
+                rb = ensure(x.b, (x.a,), leaf_seq[pos:pos + 4 * AIR_LOAD_BATCH])
+                pos += n_leaf
+                cur["pos"] = pos
                 release(x.a)
                 release(x.b)
                 x.reg = alloc()
                 words.append(x.op | x.reg << 8 | ra << 24 | rb << 40 | x.sh << 56)
-            words.append(op | ensure(root) << 24)
+            words.append(op | ensure(root, (), leaf_seq[pos:]) << 24)
             release(root)
             assert not resident
         return np.array(words, dtype=np.uint64)

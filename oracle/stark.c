@@ -330,7 +330,12 @@ static void air_eval_base(const orc_stark_desc* d, const uint64_t* local, const 
                 reg[dst] = acc;
                 break;
             }
-            case ORC_AIR_EMIT_BOOL: c = gl_mul(local[a], gl_sub(local[a], 1)); emit = 1; break;
+            case ORC_AIR_EMIT_BOOL:
+                for (uint32_t i = 0; i < (b ? b : 1); i++) {
+                    const uint64_t cb = gl_mul(local[a + i], gl_sub(local[a + i], 1));
+                    for (uint32_t j = 0; j < d->num_challenges; j++) accs[j] = gl_add(gl_mul(accs[j], alphas[j]), cb);
+                }
+                break;
             case ORC_AIR_EMIT_TRANSITION: c = gl_mul(reg[a % AIR_REGS], z_last); emit = 1; break;
             case ORC_AIR_EMIT_FIRST: c = gl_mul(reg[a % AIR_REGS], l_first); emit = 1; break;
             case ORC_AIR_EMIT_LAST: c = gl_mul(reg[a % AIR_REGS], l_last); emit = 1; break;
@@ -367,7 +372,12 @@ static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* n
                 reg[dst] = acc;
                 break;
             }
-            case ORC_AIR_EMIT_BOOL: c = gl2_mul(local[a], gl2_sub(local[a], gl2_from(1))); emit = 1; break;
+            case ORC_AIR_EMIT_BOOL:
+                for (uint32_t i = 0; i < (b ? b : 1); i++) {
+                    const gl2 cb = gl2_mul(local[a + i], gl2_sub(local[a + i], gl2_from(1)));
+                    for (uint32_t j = 0; j < d->num_challenges; j++) accs[j] = gl2_add(gl2_scale(accs[j], alphas[j]), cb);
+                }
+                break;
             case ORC_AIR_EMIT_TRANSITION: c = gl2_mul(reg[a % AIR_REGS], z_last); emit = 1; break;
             case ORC_AIR_EMIT_FIRST: c = gl2_mul(reg[a % AIR_REGS], l_first); emit = 1; break;
             case ORC_AIR_EMIT_LAST: c = gl2_mul(reg[a % AIR_REGS], l_last); emit = 1; break;
@@ -405,9 +415,9 @@ static int desc_ok(const orc_stark_desc* d) {
             case ORC_AIR_PACK_LOCAL: case ORC_AIR_PACK_NEXT:
                 if (AIR_B(w) < 1 || AIR_B(w) > 32 || AIR_A(w) + AIR_B(w) > d->n_cols) return 0;
                 break;
-            case ORC_AIR_EMIT_BOOL: if (AIR_A(w) >= d->n_cols) return 0; break;
+            case ORC_AIR_EMIT_BOOL: if (AIR_A(w) + (AIR_B(w) ? AIR_B(w) : 1) > d->n_cols) return 0; break;
             case ORC_AIR_CONST: if (++pc >= d->n_words) return 0; break;
-            default: if (AIR_OP(w) > ORC_AIR_EMIT_BOOL) return 0;
+            default: if (AIR_OP(w) > ORC_AIR_LOADV) return 0;
         }
     }
     return 1;

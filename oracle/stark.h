@@ -54,7 +54,8 @@ enum {
     ORC_AIR_PERIODIC = 11,       /* dst = periodic column a at this row: values[a][row mod 2^period_bits] */
     ORC_AIR_PACK_LOCAL = 12,     /* dst = sum_{i<b} 2^i local_values[a+i]   (b <= 32) */
     ORC_AIR_PACK_NEXT = 13,      /* dst = sum_{i<b} 2^i next_values[a+i] */
-    ORC_AIR_EMIT_BOOL = 14       /* constraint(x * (x - 1)), x = local_values[a] */
+    ORC_AIR_EMIT_BOOL = 14,      /* constraint(x * (x - 1)) for x = local_values[a .. a + max(b, 1)), in column order */
+    ORC_AIR_LOADV = 15           /* scheduling hint: the next `dst` words are independent loads (no semantics) */
 };
 /* ADD / SUB carry a shift in bits 56..61 of the word: dst = r[a] +- r[b] * 2^shift. */
 

@@ -29,7 +29,10 @@ def run_program(words, local, nxt, pis, periodic=()):
         elif op in (12, 13):
             src = local if op == 12 else nxt
             reg[dst] = sum(int(src[a + i]) << i for i in range(b)) % P
-        elif op == 14: out.append((10, int(local[a]) * (int(local[a]) - 1) % P))
+        elif op == 14:
+            for i in range(max(b, 1)):
+                out.append((10, int(local[a + i]) * (int(local[a + i]) - 1) % P))
+        elif op == 15: pass  # LOADV: scheduling hint
         else: out.append((op, reg[a]))
         pc += 1
     return out
@@ -73,14 +76,14 @@ def test_air_register_pressure(nlx):
         acc = acc * air.local(i) + air.next(i)
     air.constraint(acc)
     words = air.compile()
-    assert max((int(w) >> 8) & 0xFFFF for w in words if int(w) & 0xFF <= 6) < 8
+    assert max((int(w) >> 8) & 0xFFFF for w in words if int(w) & 0xFF <= 6) < S.AIR_MAX_RESIDENT_LEAVES + 4
     # 70 squares summed left to right: post-order evaluation frees operands as it goes
     wide = S.Air(200, 0)
     tot = wide.local(0) * wide.local(0)
     for i in range(1, 70):
         tot = tot + wide.local(i) * wide.local(i)
     wide.constraint(tot)
-    assert max((int(w) >> 8) & 0xFFFF for w in wide.compile() if int(w) & 0xFF <= 6) < 8
+    assert max((int(w) >> 8) & 0xFFFF for w in wide.compile() if int(w) & 0xFF <= 6) < S.AIR_MAX_RESIDENT_LEAVES + 4
     # 70 values that are all still needed later do not fit 64 registers: refused, not miscompiled
     over = S.Air(200, 0)
     sq = [over.local(i) * over.local(i) for i in range(70)]
