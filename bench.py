@@ -7,8 +7,8 @@ rank 0.  For N > 1 the driver launches it under torch.distributed.run (one rank 
 Workload ("step" = one whole plonky2 proof through the C ABI, nlx_prove):
   sync (default, BASELINE.json configs[1]): a synthetic circuit of SyncCircuit's static shape -
     standard_recursion_config (135 wires / 80 routed, rate 8, cap height 4, 2 challenges,
-    28 FRI queries, 16 PoW bits), 2^16 rows, gate mix PoseidonGate / ArithmeticGate / BaseSumGate /
-    ConstantGate / PublicInputGate / NoopGate with real copy constraints and a satisfying witness
+    28 FRI queries, 16 PoW bits), 2^16 rows, all nineteen gate kinds (GATE_MIXES below) with real copy
+    constraints and a satisfying witness
     (the true row count of SyncCircuit is not recorded in the reference - SURVEY.md §7 - so
     --log-n sweeps it).  Witness tables are resident in HBM before the timed region.
   SyncCircuit does not shard: with N GPUs each rank proves its own independent
@@ -34,6 +34,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
+# Row shares (percent) of the synthetic SyncCircuit-shaped workload; the rest are NoopGate rows.  "nearx" (default)
+# contains all nineteen gate kinds the library implements - Poseidon hashing, base-field and extension arithmetic,
+# the recursion gates and plonky2x's u32 / comparison gates - because every gate of a circuit is evaluated at every
+# LDE point whatever its share of rows; "basic" is the six-gate mix of the round's earlier measurements.
+GATE_MIXES = {
+    "nearx": dict(pct_poseidon=25, pct_arithmetic=20, pct_base_sum=5, pct_constant=5, pct_extension=10, pct_misc=10,
+                  pct_u32=15),
+    "basic": dict(pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -44,6 +54,7 @@ def parse():
     ap.add_argument("--log-blocks", type=int, default=14, help="sha256 workload: 2^k compression blocks per proof")
     ap.add_argument("--stark-cols", type=int, default=256)
     ap.add_argument("--log-n", type=int, default=16)
+    ap.add_argument("--gate-mix", default="nearx", choices=["nearx", "basic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent proofs in flight per GPU (one context + stream + host thread each); the K "
@@ -126,7 +137,7 @@ def cpu_baseline(nlx, log_n, gate_mix):
 
 def run_sync(args, nlx, torch, rank, world, local, dist):
     import numpy as np
-    gate_mix = dict(pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)
+    gate_mix = GATE_MIXES[args.gate_mix]
     syn = nlx.SyntheticCircuit(args.log_n, seed=1000 + rank, num_public_inputs=64, **gate_mix)
     # public inputs = the real SyncCircuit I/O of the reference's fixture main_2.json (BASELINE.json configs[0]/[1]): 32-byte trusted
     # header hash in, 32-byte new head hash out (nearx/src/sync.rs:37,43), one field element per byte
@@ -218,7 +229,8 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
             "config": {"workload": "SyncCircuit-shaped plonky2 proof (standard_recursion_config, 2^%d rows, "
-                                   "135 wires, rate 8, 28 queries, 16 PoW bits), replicas only" % args.log_n,
+                                   "135 wires, rate 8, 28 queries, 16 PoW bits, %d gate kinds), replicas only"
+                                   % (args.log_n, syn.num_gates),
                        "log_n": args.log_n, "gate_mix_pct": gate_mix,
                        "public_inputs": "64 bytes of real Sync I/O (fixtures/main_2.json): new head hash 0x%s" % sync_out.hex(), "proof_bytes": len(cds[0].prove(wires, pis)),
                        "proofs_in_flight_per_gpu": n_workers, "witness": args.host_witness or "resident in HBM", "parallelism": "replicas x%d" % world},

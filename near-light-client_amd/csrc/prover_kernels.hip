@@ -203,9 +203,11 @@ struct GateAcc {
     }
 };
 
-// prod_{x < 4} (l - x): the 2-bit limb range check of the u32 gates
+// prod_{x < 4} (l - x): the 2-bit limb range check of the u32 gates, as u (u + 2) with u = l (l - 3)
+// (l (l - 3) = l^2 - 3l and (l - 1)(l - 2) = l^2 - 3l + 2): two multiplications instead of three
 __device__ __forceinline__ uint64_t limb4(uint64_t l) {
-    return gl::mul(gl::mul(l, gl::sub(l, 1)), gl::mul(gl::sub(l, 2), gl::sub(l, 3)));
+    const uint64_t u = gl::mul(l, gl::sub(l, 3));
+    return gl::mul(u, gl::add(u, 2));
 }
 
 __device__ __forceinline__ uint64_t sbox7c(uint64_t x) {
@@ -520,10 +522,17 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 uint64_t msd = 0;
                 for (uint32_t i = 0; i < nch; i++) {
                     const uint64_t f = W(fc + i), s2 = W(sc + i);
-                    uint64_t p1 = 1, p2 = 1;
-                    for (uint32_t x2 = 0; x2 < (1u << cb); x2++) {
-                        p1 = gl::mul(p1, gl::sub(f, (uint64_t)x2));
-                        p2 = gl::mul(p2, gl::sub(s2, (uint64_t)x2));
+                    uint64_t p1, p2;
+                    if (cb == 2) {
+                        p1 = limb4(f);
+                        p2 = limb4(s2);
+                    } else {
+                        p1 = f;
+                        p2 = s2;
+                        for (uint32_t x2 = 1; x2 < (1u << cb); x2++) {
+                            p1 = gl::mul(p1, gl::sub(f, (uint64_t)x2));
+                            p2 = gl::mul(p2, gl::sub(s2, (uint64_t)x2));
+                        }
                     }
                     acc.emit(p1);
                     acc.emit(p2);

@@ -7,7 +7,9 @@ ctx = nlx.Context(0)
 for name, kw in [("all six", dict(pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)),
                  ("no poseidon", dict(pct_poseidon=0, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)),
                  ("only const/pi/noop", dict(pct_poseidon=0, pct_arithmetic=0, pct_base_sum=0, pct_constant=5)),
-                 ("all ten", dict(pct_poseidon=20, pct_arithmetic=20, pct_base_sum=5, pct_constant=5, pct_extension=20))]:
+                 ("all ten", dict(pct_poseidon=20, pct_arithmetic=20, pct_base_sum=5, pct_constant=5, pct_extension=20)),
+                 ("no arithmetic/base", dict(pct_poseidon=30, pct_arithmetic=0, pct_base_sum=0, pct_constant=5)),
+                 ("all nineteen", dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=10, pct_misc=20, pct_u32=30))]:
     syn = nlx.SyntheticCircuit(16, seed=1, **kw)
     cd = nlx.CircuitData.from_synthetic(ctx, syn)
     w = torch.from_numpy(syn.wires.view(np.int64)).cuda()
