@@ -88,7 +88,7 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
         if (gt.kind == NLX_GATE_U32_RANGE_CHECK && (gt.param0 < 1 || 17 * gt.param0 > d.num_wires)) return ctx->fail(NLX_E_INVAL, "U32RangeCheckGate too wide");
         if (gt.kind == NLX_GATE_COMPARISON) {
             const uint32_t cb = gt.param1 ? (gt.param0 + gt.param1 - 1) / gt.param1 : 0;
-            if (gt.param1 < 1 || cb < 1 || cb > 3 || 4 + 5 * gt.param1 + cb + 1 > d.num_wires)
+            if (gt.param1 < 1 || cb < 1 || cb > 3 || cb * gt.param1 > 62 || 4 + 5 * gt.param1 + cb + 1 > d.num_wires)
                 return ctx->fail(NLX_E_INVAL, "ComparisonGate: chunk_bits must be in [1, 3] and the gate must fit the wires");
         }
         if (gt.kind == NLX_GATE_COSET_INTERPOLATION) {

@@ -190,17 +190,75 @@ size_t zs_scratch_words(unsigned log_n, uint32_t nc) {
 // =====================================================================================
 // a9: constraint / quotient combiner
 // =====================================================================================
+// Running sums S_c = sum_k alpha_c^k * constraint_k of the gate being evaluated, for both challenges, with
+// LAZY reduction: each 64x64 product is accumulated as four 32x32 partial products into four 64-bit columns
+// (+ a carry counter each) - two instructions per partial product - and the 160-bit total is reduced once per
+// gate.  A reduced multiply-add costs ~30 instructions; this costs 8 per challenge.
 struct GateAcc {
-    // running sums S_c = sum_k alpha_c^(T0 + k) * constraint_k for the gate being evaluated
-    const uint64_t* __restrict__ ap0;
+    const uint64_t* __restrict__ ap0;  // alpha_0^(T0 + k), wave-uniform
     const uint64_t* __restrict__ ap1;
-    uint64_t s0, s1;
+    uint64_t a[8];
+    uint32_t kc[8];
     uint32_t k;
-    __device__ __forceinline__ void emit(uint64_t c) {
-        s0 = gl::add(s0, gl::mul(c, ap0[k]));
-        s1 = gl::add(s1, gl::mul(c, ap1[k]));
-        k++;
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { a[i] = 0; kc[i] = 0; }
+        k = 0;
     }
+    __device__ __forceinline__ void emit_at(uint32_t idx, uint64_t c) {
+        const uint64_t b0 = ap0[idx], b1 = ap1[idx];
+        const uint32_t c0 = (uint32_t)c, c1 = (uint32_t)(c >> 32);
+        asm("v_mad_u64_u32 %[a0], vcc, %[c0], %[p0], %[a0]\n\t"
+            "v_addc_co_u32 %[k0], vcc, 0, %[k0], vcc\n\t"
+            "v_mad_u64_u32 %[a1], vcc, %[c0], %[p1], %[a1]\n\t"
+            "v_addc_co_u32 %[k1], vcc, 0, %[k1], vcc\n\t"
+            "v_mad_u64_u32 %[a2], vcc, %[c1], %[p0], %[a2]\n\t"
+            "v_addc_co_u32 %[k2], vcc, 0, %[k2], vcc\n\t"
+            "v_mad_u64_u32 %[a3], vcc, %[c1], %[p1], %[a3]\n\t"
+            "v_addc_co_u32 %[k3], vcc, 0, %[k3], vcc\n\t"
+            "v_mad_u64_u32 %[a4], vcc, %[c0], %[q0], %[a4]\n\t"
+            "v_addc_co_u32 %[k4], vcc, 0, %[k4], vcc\n\t"
+            "v_mad_u64_u32 %[a5], vcc, %[c0], %[q1], %[a5]\n\t"
+            "v_addc_co_u32 %[k5], vcc, 0, %[k5], vcc\n\t"
+            "v_mad_u64_u32 %[a6], vcc, %[c1], %[q0], %[a6]\n\t"
+            "v_addc_co_u32 %[k6], vcc, 0, %[k6], vcc\n\t"
+            "v_mad_u64_u32 %[a7], vcc, %[c1], %[q1], %[a7]\n\t"
+            "v_addc_co_u32 %[k7], vcc, 0, %[k7], vcc"
+            : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [a4] "+v"(a[4]), [a5] "+v"(a[5]),
+              [a6] "+v"(a[6]), [a7] "+v"(a[7]), [k0] "+v"(kc[0]), [k1] "+v"(kc[1]), [k2] "+v"(kc[2]), [k3] "+v"(kc[3]),
+              [k4] "+v"(kc[4]), [k5] "+v"(kc[5]), [k6] "+v"(kc[6]), [k7] "+v"(kc[7])
+            : [c0] "v"(c0), [c1] "v"(c1), [p0] "s"((uint32_t)b0), [p1] "s"((uint32_t)(b0 >> 32)), [q0] "s"((uint32_t)b1),
+              [q1] "s"((uint32_t)(b1 >> 32))
+            : "vcc");
+    }
+    __device__ __forceinline__ void emit(uint64_t c) { emit_at(k++, c); }
+    // sum for challenge ch: A0 + (A1 + A2) 2^32 + A3 2^64 + K0 2^64 + (K1 + K2) 2^96 + K3 2^128 (mod p), with
+    // 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32
+    __device__ __forceinline__ uint64_t finish(int ch) const {
+        const uint64_t* A = a + 4 * ch;
+        const uint32_t* K = kc + 4 * ch;
+        const uint64_t m1 = gl::canon(A[1]), m2 = gl::canon(A[2]);
+        uint64_t r = gl::canon(A[0]);
+        r = gl::add(r, gl::reduce128(m1 << 32, m1 >> 32));
+        r = gl::add(r, gl::reduce128(m2 << 32, m2 >> 32));
+        r = gl::add(r, gl::mul(gl::canon(A[3]), gl::EPS));
+        r = gl::add(r, gl::mul((uint64_t)K[0], gl::EPS));
+        r = gl::sub(r, (uint64_t)K[1] + K[2]);
+        r = gl::sub(r, (uint64_t)K[3] << 32);
+        return r;
+    }
+};
+
+// sum_j x_j 2^(s_j) kept as a 128-bit integer and reduced once (Horner recombination of range-check limbs
+// without a multiplication per limb); the caller keeps the total below 2^128
+struct Sum128 {
+    uint64_t lo = 0, hi = 0;
+    __device__ __forceinline__ void add(uint64_t x, uint32_t sh) {
+        const uint64_t tl = x << sh, th = sh ? x >> (64 - sh) : 0;
+        lo += tl;
+        hi += th + (lo < tl ? 1u : 0u);
+    }
+    __device__ __forceinline__ uint64_t value() const { return gl::reduce128(lo, hi); }
 };
 
 // prod_{x < 4} (l - x): the 2-bit limb range check of the u32 gates, as u (u + 2) with u = l (l - 3)
@@ -321,6 +379,9 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
     const uint64_t* ap1 = p.alpha_pows + p.alpha_stride;
 
     uint64_t tot0 = 0, tot1 = 0;  // sum over all terms EXCEPT the L_0 term (divided by Z_H later)
+    GateAcc acc;
+    acc.ap0 = ap0 + T0;
+    acc.ap1 = ap1 + T0;
     // ---- gate constraints ----
     for (uint32_t g = 0; g < p.n_gates; g++) {
         const GateDev gd = p.gates[g];
@@ -330,7 +391,7 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
         for (uint32_t i = gd.group_start; i < gd.group_end; i++)
             if (i != gd.index) f = gl::mul(f, gl::sub((uint64_t)i, s));
         if (p.n_selectors > 1) f = gl::mul(f, gl::sub(0xFFFFFFFFULL, s));
-        GateAcc acc{ap0 + T0, ap1 + T0, 0, 0, 0};
+        acc.reset();
         switch (gd.kind) {
             case NLX_GATE_CONSTANT:
                 for (uint32_t i = 0; i < gd.param0; i++) acc.emit(gl::sub(CS(p.n_selectors + i), W(i)));
@@ -340,6 +401,7 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 break;
             case NLX_GATE_ARITHMETIC: {
                 const uint64_t c0 = CS(p.n_selectors), c1 = CS(p.n_selectors + 1);
+#pragma unroll 4
                 for (uint32_t i = 0; i < gd.param0; i++) {
                     const uint64_t m0 = W(4 * i), m1 = W(4 * i + 1), ad = W(4 * i + 2), o = W(4 * i + 3);
                     acc.emit(gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1))));
@@ -349,8 +411,10 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
             case NLX_GATE_BASE_SUM: {
                 const uint32_t B = gd.param0, nl = gd.param1;
                 uint64_t sum = 0;
+#pragma unroll 8
                 for (uint32_t i = nl; i-- > 0;) sum = gl::add(gl::mul(sum, (uint64_t)B), W(1 + i));
                 acc.emit(gl::sub(sum, W(0)));
+#pragma unroll 8
                 for (uint32_t i = 0; i < nl; i++) {
                     const uint64_t limb = W(1 + i);
                     uint64_t prod = 1;
@@ -364,6 +428,7 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 break;
             case NLX_GATE_ARITHMETIC_EXT: {
                 const uint64_t c0 = CS(p.n_selectors), c1 = CS(p.n_selectors + 1);
+#pragma unroll 2
                 for (uint32_t i = 0; i < gd.param0; i++) {
                     const gl::Ext m0{W(8 * i), W(8 * i + 1)}, m1{W(8 * i + 2), W(8 * i + 3)};
                     const gl::Ext pr = gl::mul(m0, m1);
@@ -374,6 +439,7 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
             }
             case NLX_GATE_MUL_EXT: {
                 const uint64_t c0 = CS(p.n_selectors);
+#pragma unroll 2
                 for (uint32_t i = 0; i < gd.param0; i++) {
                     const gl::Ext m0{W(6 * i), W(6 * i + 1)}, m1{W(6 * i + 2), W(6 * i + 3)};
                     const gl::Ext pr = gl::mul(m0, m1);
@@ -389,6 +455,7 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 const uint32_t start_coeffs = 6, start_accs = start_coeffs + (ext ? 2 * nco : nco);
                 const gl::Ext alpha{W(2), W(3)};
                 gl::Ext a{W(4), W(5)};
+#pragma unroll 4
                 for (uint32_t i = 0; i < nco; i++) {
                     const uint32_t aw = (i == nco - 1) ? 0 : start_accs + 2 * i;  // last accumulator = output wires
                     const gl::Ext nxt{W(aw), W(aw + 1)};
@@ -405,29 +472,24 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 break;
             }
             case NLX_GATE_POSEIDON_MDS: {
-                constexpr uint64_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-                for (uint32_t rr = 0; rr < 12; rr++) {
-                    uint64_t c0 = 0, c1 = 0;
+                // outputs = MDS * inputs on both components of the extension algebra: the linear layer of the
+                // permutation itself (32-bit halves, multiply-accumulate, one reduction per output)
+                for (uint32_t comp = 0; comp < 2; comp++) {
+                    uint64_t st[12];
 #pragma unroll
-                    for (uint32_t i = 0; i < 12; i++) {
-                        uint32_t src = rr + i;
-                        src = src >= 12 ? src - 12 : src;
-                        c0 = gl::add(c0, gl::mul(W(2 * src), C[i]));
-                        c1 = gl::add(c1, gl::mul(W(2 * src + 1), C[i]));
-                    }
-                    if (rr == 0) {
-                        c0 = gl::add(c0, gl::mul(W(0), 8));
-                        c1 = gl::add(c1, gl::mul(W(1), 8));
-                    }
-                    acc.emit(gl::sub(W(24 + 2 * rr), c0));
-                    acc.emit(gl::sub(W(24 + 2 * rr + 1), c1));
+                    for (int i = 0; i < 12; i++) st[i] = W(2 * i + comp);
+                    mds_canon(st);
+#pragma unroll
+                    for (int rr = 0; rr < 12; rr++) acc.emit_at(2 * rr + comp, gl::sub(W(24 + 2 * rr + comp), st[rr]));
                 }
+                acc.k += 24;
                 break;
             }
             case NLX_GATE_EXPONENTIATION: {
                 const uint32_t nb = gd.param0;
                 const uint64_t base = W(0);
                 uint64_t prev_iv = 1;
+#pragma unroll 4
                 for (uint32_t i = 0; i < nb; i++) {
                     const uint64_t prev = i ? gl::mul(prev_iv, prev_iv) : 1;
                     const uint64_t bit = W(1 + (nb - 1 - i));
@@ -447,15 +509,15 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                     for (uint32_t j = 0; j < na; j++) computed = gl::add(computed, W(b0 + j));
                     const uint64_t res = W(b0 + na + 1), cy = W(b0 + na + 2);
                     acc.emit(gl::sub(gl::add(gl::mul(cy, 1ULL << 32), res), computed));
-                    uint64_t cr = 0, cc = 0;
+                    Sum128 cr, cc;
                     for (uint32_t j = nl; j-- > 0;) {
                         const uint64_t l = W(lb + j);
                         acc.emit(limb4(l));
-                        if (j < nrl) cr = gl::add(gl::mul(cr, 4), l);
-                        else cc = gl::add(gl::mul(cc, 4), l);
+                        if (j < nrl) cr.add(l, 2 * j);
+                        else cc.add(l, 2 * (j - nrl));
                     }
-                    acc.emit(gl::sub(cr, res));
-                    acc.emit(gl::sub(cc, cy));
+                    acc.emit(gl::sub(cr.value(), res));
+                    acc.emit(gl::sub(cc.value(), cy));
                 }
                 break;
             }
@@ -468,15 +530,15 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                     const uint64_t hi_not_max = gl::sub(gl::mul(inv, gl::sub(0xFFFFFFFFULL, hi)), 1);
                     acc.emit(gl::mul(hi_not_max, lo));
                     acc.emit(gl::sub(gl::add(gl::mul(hi, 1ULL << 32), lo), computed));
-                    uint64_t cl = 0, ch = 0;
+                    Sum128 cl, ch;
                     for (uint32_t j = 32; j-- > 0;) {
                         const uint64_t l = W(lb + j);
                         acc.emit(limb4(l));
-                        if (j < 16) cl = gl::add(gl::mul(cl, 4), l);
-                        else ch = gl::add(gl::mul(ch, 4), l);
+                        if (j < 16) cl.add(l, 2 * j);
+                        else ch.add(l, 2 * (j - 16));
                     }
-                    acc.emit(gl::sub(cl, lo));
-                    acc.emit(gl::sub(ch, hi));
+                    acc.emit(gl::sub(cl.value(), lo));
+                    acc.emit(gl::sub(ch.value(), hi));
                 }
                 break;
             }
@@ -487,13 +549,13 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                     const uint64_t initial = gl::sub(gl::sub(W(b0), W(b0 + 1)), W(b0 + 2));
                     const uint64_t res = W(b0 + 3), bo = W(b0 + 4);
                     acc.emit(gl::sub(res, gl::add(initial, gl::mul(bo, 1ULL << 32))));
-                    uint64_t c = 0;
+                    Sum128 c;
                     for (uint32_t j = 16; j-- > 0;) {
                         const uint64_t l = W(lb + j);
                         acc.emit(limb4(l));
-                        c = gl::add(gl::mul(c, 4), l);
+                        c.add(l, 2 * j);
                     }
-                    acc.emit(gl::sub(c, res));
+                    acc.emit(gl::sub(c.value(), res));
                     acc.emit(gl::mul(bo, gl::sub(1, bo)));
                 }
                 break;
@@ -502,9 +564,9 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 const uint32_t nin = gd.param0;
                 for (uint32_t i = 0; i < nin; i++) {
                     const uint32_t ab = nin + 16 * i;
-                    uint64_t sum = 0;
-                    for (uint32_t j = 16; j-- > 0;) sum = gl::add(gl::mul(sum, 4), W(ab + j));
-                    acc.emit(gl::sub(sum, W(i)));
+                    Sum128 sum;
+                    for (uint32_t j = 0; j < 16; j++) sum.add(W(ab + j), 2 * j);
+                    acc.emit(gl::sub(sum.value(), W(i)));
                     for (uint32_t j = 0; j < 16; j++) acc.emit(limb4(W(ab + j)));
                 }
                 break;
@@ -512,14 +574,16 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
             case NLX_GATE_COMPARISON: {
                 const uint32_t nbits = gd.param0, nch = gd.param1, cb = (nbits + nch - 1) / nch;
                 const uint32_t fc = 4, sc = 4 + nch, eqd = 4 + 2 * nch, ceq = 4 + 3 * nch, iv = 4 + 4 * nch, msb = 4 + 5 * nch;
-                uint64_t fcomb = 0, scomb = 0;
-                for (uint32_t i = nch; i-- > 0;) {
-                    fcomb = gl::add(gl::mul(fcomb, 1ULL << cb), W(fc + i));
-                    scomb = gl::add(gl::mul(scomb, 1ULL << cb), W(sc + i));
+                Sum128 fcomb, scomb;  // nch * cb = num_bits <= 62 (checked at circuit build)
+#pragma unroll 8
+                for (uint32_t i = 0; i < nch; i++) {
+                    fcomb.add(W(fc + i), cb * i);
+                    scomb.add(W(sc + i), cb * i);
                 }
-                acc.emit(gl::sub(fcomb, W(0)));
-                acc.emit(gl::sub(scomb, W(1)));
+                acc.emit(gl::sub(fcomb.value(), W(0)));
+                acc.emit(gl::sub(scomb.value(), W(1)));
                 uint64_t msd = 0;
+#pragma unroll 4
                 for (uint32_t i = 0; i < nch; i++) {
                     const uint64_t f = W(fc + i), s2 = W(sc + i);
                     uint64_t p1, p2;
@@ -630,8 +694,8 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
             }
             default: break;  // NoopGate
         }
-        tot0 = gl::add(tot0, gl::mul(f, acc.s0));
-        tot1 = gl::add(tot1, gl::mul(f, acc.s1));
+        tot0 = gl::add(tot0, gl::mul(f, acc.finish(0)));
+        tot1 = gl::add(tot1, gl::mul(f, acc.finish(1)));
     }
     // ---- permutation argument ----
     // vanishing_terms = [L_0 (Z_i - 1)]_i ++ [partial-product checks]_i ++ gate constraints, and EVERY
@@ -650,6 +714,7 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
 #pragma unroll 1
         for (uint32_t q = 0; q < n_chunks; q++) {
             uint64_t nm = 1, dn = 1;
+#pragma unroll 8
             for (uint32_t j = q * p.chunk; j < (q + 1) * p.chunk && j < p.routed; j++) {
                 const uint64_t w = W(j);
                 nm = gl::mul(nm, gl::add(gl::add(w, gl::mul(bx, p.k_is[j])), gamma));
