@@ -257,8 +257,7 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
 def run_stark(args, nlx, torch, rank, world, local, dist):
     """Secondary workload: one starky-style proof of the synthetic wide AIR
     (--stark-cols columns x 2^--log-n rows, StarkConfig::standard_fast_config) per step, `inflight`
-    independent proofs concurrently (one context + host thread each; ctypes releases the GIL)."""
-    import threading
+    independent proofs concurrently (one context + host thread each, nlx_stark_batch_prove)."""
     import numpy as np
     S = nlx.stark
     air = S.wide_air(args.stark_cols, seed=7)
@@ -274,26 +273,24 @@ def run_stark(args, nlx, torch, rank, world, local, dist):
             pr.prove_into(d_t, pis_ptr)
     for c in ctxs:
         c.kernel_timing(True)
-    counter = iter(range(args.steps))
-    lock = threading.Lock()
-
-    def worker(pr):
-        while True:
-            with lock:
-                i = next(counter, None)
-            if i is None:
-                return
-            pr.prove_into(d_t, pis_ptr)
-
+    # the K timed proofs go through ONE C-ABI call (nlx_stark_batch_prove), as the plonky2 workload does
+    import ctypes
+    cap = nlx.lib.dll.nlx_stark_proof_max_bytes(prs[0].handle)
+    bufs = [np.zeros(cap, dtype=np.uint8) for _ in range(args.steps)]
+    jobs = (nlx.ProveJob * args.steps)()
+    for i in range(args.steps):
+        jobs[i].wires = d_t.data_ptr()
+        jobs[i].public_inputs = pis_ptr
+        jobs[i].proof_out = bufs[i].ctypes.data
+        jobs[i].proof_cap = cap
+    handles = (ctypes.c_void_p * n_workers)(*[pr.handle for pr in prs])
     barrier(dist, torch)
     t0 = time.perf_counter()
-    ths = [threading.Thread(target=worker, args=(pr,)) for pr in prs]
-    for th in ths:
-        th.start()
-    for th in ths:
-        th.join()
+    rc = nlx.lib.dll.nlx_stark_batch_prove(handles, n_workers, jobs, args.steps)
     barrier(dist, torch)
     dt = time.perf_counter() - t0
+    if rc != 0:
+        raise RuntimeError("nlx_stark_batch_prove failed with %d" % rc)
     dt = reduce_max(dist, torch, dt)
     names = ("intt", "lde", "hash_lde_leaves", "merkle_levels", "air_quotient", "fri_combine")
     kstats = {k: [0, 0.0, 0.0] for k in names}

@@ -313,6 +313,9 @@ size_t nlx_stark_proof_max_bytes(const nlx_stark* s);
 int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* public_inputs, uint8_t* proof_out,
                         size_t proof_cap, size_t* proof_len);
 int32_t nlx_stark_stage_times(const nlx_stark* s, uint32_t* n_stages, const char** names_out, float* ms_out);
+/* As nlx_batch_prove, for STARK jobs: workers = provers built from the SAME description on DISTINCT contexts;
+ * a job's `wires` field is its trace (n_cols x n, host or device). */
+int32_t nlx_stark_batch_prove(nlx_stark* const* workers, uint32_t n_workers, nlx_prove_job* jobs, size_t n_jobs);
 /* f.1: trace generation on the GPU for the SHA-256 compression AIR (column layout and constraints:
  * near-light-client_amd/sha256_air.py; callers in the reference: curta_sha256 at nearx/src/merkle.rs:49,
  * nearx/src/variables.rs:71-72).  blocks: 2^log_blocks padded 512-bit blocks as 16 big-endian-decoded words

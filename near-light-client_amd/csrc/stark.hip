@@ -13,6 +13,8 @@
 //    trace LDE is read in place - no second low-degree extension as in the reference flow;
 //  * quotient chunks come from per-coset inverse transforms + a 2^qdb-point DFT across cosets, as in the
 //    plonky2 path; commitments, openings and FRI are the same device code as nlx_prove.
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "commit.hpp"
 #include "fri.hpp"
@@ -546,6 +548,38 @@ done:
 #undef HIPCHK
 #undef CHECK_ALLOC
     return rc;
+}
+
+int32_t nlx_stark_batch_prove(nlx_stark* const* workers, uint32_t n_workers, nlx_prove_job* jobs, size_t n_jobs) {
+    if (!workers || n_workers == 0 || (!jobs && n_jobs)) return NLX_E_INVAL;
+    for (uint32_t w = 0; w < n_workers; w++) {
+        if (!workers[w]) return NLX_E_INVAL;
+        for (uint32_t v = 0; v < w; v++)
+            if (workers[v]->ctx == workers[w]->ctx)
+                return workers[w]->ctx->fail(NLX_E_INVAL, "nlx_stark_batch_prove: workers must use distinct contexts");
+    }
+    std::atomic<size_t> next{0};
+    auto run = [&](nlx_stark* s) {
+        (void)hipSetDevice(s->ctx->device);
+        for (;;) {
+            const size_t j = next.fetch_add(1);
+            if (j >= n_jobs) return;
+            nlx_prove_job& job = jobs[j];
+            job.proof_len = 0;
+            job.status = nlx_stark_prove(s, job.wires, job.public_inputs, job.proof_out, job.proof_cap, &job.proof_len);
+        }
+    };
+    if (n_workers == 1) {
+        run(workers[0]);
+    } else {
+        std::vector<std::thread> threads;
+        threads.reserve(n_workers);
+        for (uint32_t w = 0; w < n_workers; w++) threads.emplace_back(run, workers[w]);
+        for (auto& t : threads) t.join();
+    }
+    for (size_t j = 0; j < n_jobs; j++)
+        if (jobs[j].status != NLX_OK) return jobs[j].status;
+    return NLX_OK;
 }
 
 }  // extern "C"

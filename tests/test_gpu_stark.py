@@ -181,3 +181,35 @@ def test_stark_random_programs_bytes_equal_oracle(nlx, ctx, orc, seed):
     got = pr.prove(t, pis)
     assert got == want, "seed %d: %d cols, 2^%d rows, %d words" % (seed, n_cols, db, st.desc.n_words)
     pr.close()
+
+
+def test_stark_batch_prove(nlx, orc):
+    """nlx_stark_batch_prove: three workers on distinct contexts, six jobs with different traces; every proof
+    equals the oracle's for its trace."""
+    import ctypes
+    S = nlx.stark
+    air = S.wide_air(16, seed=4)
+    st = S.Stark(air, 9)
+    ctxs = [nlx.Context(0) for _ in range(3)]
+    prs = [st.build(c) for c in ctxs]
+    traces = [S.wide_trace(air, 9, seed=50 + i) for i in range(6)]
+    cap = nlx.lib.dll.nlx_stark_proof_max_bytes(prs[0].handle)
+    bufs = [np.zeros(cap, dtype=np.uint8) for _ in traces]
+    jobs = (nlx.ProveJob * len(traces))()
+    for i, (t, pis) in enumerate(traces):
+        jobs[i].wires = t.ctypes.data
+        jobs[i].public_inputs = pis.ctypes.data
+        jobs[i].proof_out = bufs[i].ctypes.data
+        jobs[i].proof_cap = cap
+    handles = (ctypes.c_void_p * 3)(*[p.handle for p in prs])
+    assert nlx.lib.dll.nlx_stark_batch_prove(handles, 3, jobs, len(traces)) == 0
+    for i, (t, pis) in enumerate(traces):
+        assert jobs[i].status == 0
+        assert bufs[i][:jobs[i].proof_len].tobytes() == orc.stark_prove(st.desc, t, pis), i
+    # two workers on the same context are refused
+    same = (ctypes.c_void_p * 2)(prs[0].handle, prs[0].handle)
+    assert nlx.lib.dll.nlx_stark_batch_prove(same, 2, jobs, 1) != 0
+    for p in prs:
+        p.close()
+    for c in ctxs:
+        c.close()
