@@ -55,6 +55,11 @@ const char* nlx_last_error(const nlx_ctx* ctx);
  * NULL restores the context's own stream.  The caller keeps ownership of the stream. */
 int32_t nlx_ctx_set_stream(nlx_ctx* ctx, void* hip_stream);
 int32_t nlx_ctx_synchronize(nlx_ctx* ctx);
+/* The context keeps freed device blocks for reuse (hipMalloc / hipFree synchronise the device).
+ * nlx_ctx_memory reports the bytes it holds from the driver and the part currently in use by live handles and
+ * tables; nlx_ctx_trim returns the unused part to the driver (it synchronises the stream first). */
+int32_t nlx_ctx_memory(const nlx_ctx* ctx, size_t* reserved_bytes, size_t* in_use_bytes);
+int32_t nlx_ctx_trim(nlx_ctx* ctx);
 /* Per-kernel device timing for measurement (bench.py's roofline): when enabled, the library brackets
  * its main kernels ("intt", "lde", "hash_lde_leaves", "merkle_levels", "quotient", "fri_combine")
  * with HIP events on the context's stream.  nlx_ctx_kernel_timing(ctx, x) also clears the samples. */

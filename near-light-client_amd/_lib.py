@@ -36,6 +36,8 @@ SIGNATURES = {
     "nlx_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "nlx_ctx_set_stream": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_ctx_synchronize": (ctypes.c_int32, [ctypes.c_void_p]),
+    "nlx_ctx_memory": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    "nlx_ctx_trim": (ctypes.c_int32, [ctypes.c_void_p]),
     "nlx_ctx_kernel_timing": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int]),
     "nlx_ctx_kernel_stats": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
@@ -138,6 +140,16 @@ class Context:
 
     def _adopt(self, child):
         self._children.add(child)
+
+    def memory(self):
+        """(bytes held from the driver, bytes in use by live handles and tables)"""
+        r, u = ctypes.c_size_t(), ctypes.c_size_t()
+        self.check(dll.nlx_ctx_memory(self.handle, ctypes.byref(r), ctypes.byref(u)))
+        return r.value, u.value
+
+    def trim(self):
+        """Return cached free device blocks to the driver."""
+        self.check(dll.nlx_ctx_trim(self.handle))
 
     def check(self, rc):
         if rc != 0:

@@ -265,6 +265,22 @@ int32_t nlx_ctx_kernel_stats(nlx_ctx* c, const char* name, uint64_t* calls, doub
     return NLX_OK;
 }
 
+int32_t nlx_ctx_trim(nlx_ctx* c) {
+    if (!c) return NLX_E_INVAL;
+    (void)hipSetDevice(c->device);
+    c->trim();
+    return NLX_OK;
+}
+
+int32_t nlx_ctx_memory(const nlx_ctx* c, size_t* reserved_bytes, size_t* in_use_bytes) {
+    if (!c) return NLX_E_INVAL;
+    size_t used = 0;
+    for (const auto& kv : c->live_blocks) used += kv.second;
+    if (reserved_bytes) *reserved_bytes = c->bytes_reserved;
+    if (in_use_bytes) *in_use_bytes = used;
+    return NLX_OK;
+}
+
 int32_t nlx_ctx_synchronize(nlx_ctx* c) {
     if (!c) return NLX_E_INVAL;
     NLX_HIP(c, hipStreamSynchronize(c->stream));

@@ -204,3 +204,23 @@ def test_field_core_edge_values(nlx, ctx):
         if xc:
             assert int(out[3, i]) * xc % P == 1, (hex(x), "inv")
     assert (out < np.uint64(P)).all()
+
+
+def test_context_memory_accounting(nlx, orc):
+    """nlx_ctx_memory / nlx_ctx_trim: handles account for their bytes, freed blocks are cached until trimmed"""
+    c = nlx.Context(0)
+    vals = np.zeros((16, 1 << 12), dtype=np.uint64)
+    nlx.PolynomialBatch.from_values(c, vals, 3, 4).close()   # builds the twiddle / coset tables, which stay live
+    c.trim()
+    r0, u0 = c.memory()
+    assert r0 == u0 > 0
+    pb = nlx.PolynomialBatch.from_values(c, vals, 3, 4)
+    r1, u1 = c.memory()
+    assert u1 - u0 >= 16 * (1 << 15) * 8          # at least the LDE table
+    assert r1 >= u1
+    pb.close()
+    r2, u2 = c.memory()
+    assert u2 == u0 and r2 == r1                  # released to the cache, not to the driver
+    c.trim()
+    assert c.memory() == (r0, u0)                 # only the tables remain
+    c.close()
