@@ -207,6 +207,55 @@ size_t nlx_proof_max_bytes(const nlx_circuit* c);
 int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, uint8_t* proof_out,
                   size_t proof_cap, size_t* proof_len);
 
+/* ---- stage-level entry points: the fine seam for callers that keep plonky2's own
+ * prove_with_partition_witness loop and replace it stage by stage (SURVEY.md §8b call list) ---- */
+
+/* The circuit's constants + sigmas commitment (FRI oracle 0), borrowed: owned by the circuit, do not destroy. */
+const nlx_commit* nlx_circuit_constants_sigmas(const nlx_circuit* c);
+/* a8 wires_permutation_partial_products_and_zs + PolynomialBatch::from_values: wires = num_wires x n subgroup
+ * values (host or device); the commitment holds num_challenges Z columns followed by the partial products. */
+int32_t nlx_partial_products_and_zs(nlx_circuit* c, const uint64_t* wires, const uint64_t betas[2], const uint64_t gammas[2],
+                                    nlx_commit** zs_out);
+/* a9 compute_quotient_polys + PolynomialBatch::from_coeffs: the num_challenges * quotient_degree_factor quotient
+ * chunks, committed.  public_inputs_hash = hash_no_pad(public inputs) (nlx_hash_no_pad). */
+int32_t nlx_quotient_eval(nlx_circuit* c, const nlx_commit* wires, const nlx_commit* zs, const uint64_t betas[2],
+                          const uint64_t gammas[2], const uint64_t alphas[2], const uint64_t public_inputs_hash[4],
+                          nlx_commit** quotient_out);
+
+/* plonky2::iop::challenger::Challenger state: sponge_state, input_buffer, output_buffer (popped from the end). */
+typedef struct {
+    uint64_t state[12];
+    uint64_t input[8];
+    uint32_t n_input;
+    uint32_t pad0;
+    uint64_t output[8];
+    uint32_t n_output;
+    uint32_t pad1;
+} nlx_challenger;
+void nlx_challenger_init(nlx_challenger* c);
+int32_t nlx_challenger_observe(nlx_challenger* c, const uint64_t* elements, size_t n);
+int32_t nlx_challenger_challenge(nlx_challenger* c, uint64_t* out, size_t n);
+/* PoseidonHash::hash_no_pad on the host (public-inputs hash, circuit digest) */
+int32_t nlx_hash_no_pad(const uint64_t* elements, size_t n, uint64_t out[4]);
+
+typedef struct {
+    uint32_t arity_bits;       /* FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits) */
+    uint32_t final_poly_bits;
+    uint32_t pow_bits;         /* proof_of_work_bits */
+    uint32_t num_queries;      /* num_query_rounds */
+} nlx_fri_params;
+/* a11 PolynomialBatch::prove_openings / fri_proof for an instance of the shape every caller on this path has:
+ * batch 0 = every column of every oracle (in order) opened at zeta, batch 1 = the first n_next columns of
+ * oracles[next_oracle] opened at g * zeta (plonky2: oracles = constants_sigmas, wires, zs_partial_products,
+ * quotient; next_oracle = 2, n_next = num_challenges).  openings_* are the extension values (2 words each)
+ * already observed by the caller's challenger; the challenger is advanced exactly as upstream's
+ * (fri alpha, commit-phase caps and betas, final polynomial, proof of work, query indices).  Writes the FriProof
+ * bytes: commit_phase_merkle_caps, query_round_proofs, final_poly, pow_witness. */
+int32_t nlx_fri_prove(nlx_ctx* ctx, const nlx_commit* const* oracles, uint32_t n_oracles, uint32_t next_oracle, uint32_t n_next,
+                      const uint64_t zeta[2], const uint64_t* openings_zeta, const uint64_t* openings_next,
+                      const nlx_fri_params* params, nlx_challenger* challenger, uint8_t* proof_out, size_t proof_cap,
+                      size_t* proof_len);
+
 /* a13: plonky2x LocalProver::batch_prove.  Proves n_jobs independent jobs with n_workers concurrent
  * workers.  workers[i] are circuits built from the SAME description on DISTINCT contexts (one stream +
  * one host thread each; contexts may be on the same GPU - overlapping one proof's latency-bound phases

@@ -69,6 +69,17 @@ SIGNATURES = {
     "nlx_proof_max_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "nlx_prove": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                    ctypes.POINTER(ctypes.c_size_t)]),
+    "nlx_circuit_constants_sigmas": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "nlx_partial_products_and_zs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_void_pp]),
+    "nlx_quotient_eval": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, c_void_pp]),
+    "nlx_challenger_init": (None, [ctypes.c_void_p]),
+    "nlx_challenger_observe": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "nlx_challenger_challenge": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "nlx_hash_no_pad": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "nlx_fri_prove": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     "nlx_batch_prove": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]),
     "nlx_prove_stage_times": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p,
                                                ctypes.c_void_p]),

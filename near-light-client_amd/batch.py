@@ -84,6 +84,7 @@ class PolynomialBatch:
         self.ctx, self.handle = ctx, handle
         self.n_cols, self.log_n, self.rate_bits, self.cap_height = n_cols, log_n, rate_bits, cap_height
         self.cap = cap
+        self._borrowed = False
         ctx._adopt(self)
 
     @classmethod
@@ -98,6 +99,13 @@ class PolynomialBatch:
         h = ctypes.c_void_p()
         ctx.check(fn(ctx.handle, ptr(data), n_cols, log_n, rate_bits, cap_height, ptr(cap), ctypes.byref(h)))
         return cls(ctx, h, n_cols, log_n, rate_bits, cap_height, cap)
+
+    @classmethod
+    def _adopt_handle(cls, ctx, handle, n_cols, log_n, rate_bits, cap_height):
+        """Wrap a commitment produced by a stage call (nlx_partial_products_and_zs, nlx_quotient_eval)."""
+        cap = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+        ctx.check(dll.nlx_commit_get_cap(handle, ptr(cap)))
+        return cls(ctx, handle, n_cols, log_n, rate_bits, cap_height, cap)
 
     @classmethod
     def from_values(cls, ctx, values, rate_bits, cap_height):
@@ -143,7 +151,7 @@ class PolynomialBatch:
         return out
 
     def close(self):
-        if self.handle and self.ctx.handle:
+        if self.handle and self.ctx.handle and not self._borrowed:
             dll.nlx_commit_destroy(self.handle)
         self.handle = None
 

@@ -12,6 +12,7 @@
 // PCIe.  It is not a fallback for any device stage.
 #include <atomic>
 #include <cstring>
+#include <functional>
 #include <thread>
 #include <vector>
 #include "commit.hpp"
@@ -289,6 +290,103 @@ int32_t nlx_prove_stage_times(const nlx_circuit* c, uint32_t* n_stages, const ch
     return NLX_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// a8: Z and partial-product polynomials from the wires' subgroup values (device), committed.
+// Temporaries are handed to `defer` (released by the caller after it has synchronised) or, without one,
+// released here after a stream synchronisation.
+int32_t zs_stage(nlx_circuit* c, const uint64_t* d_wire_values, const uint64_t betas[2], const uint64_t gammas[2],
+                 nlx_commit** cz, std::vector<void*>* defer) {
+    nlx_ctx* ctx = c->ctx;
+    const nlx_circuit_desc& d = c->d;
+    const unsigned log_n = d.degree_bits;
+    const size_t n = c->n();
+    uint64_t* d_zs = (uint64_t*)ctx->alloc((size_t)c->n_zs * n * 8);
+    uint64_t* d_zs_scratch = (uint64_t*)ctx->alloc(zs_scratch_words(log_n, d.num_challenges) * 8);
+    int32_t rc = NLX_OK;
+    if (!d_zs || !d_zs_scratch) rc = NLX_E_NOMEM;
+    if (!rc) {
+        ZsParams zp{};
+        zp.wires = d_wire_values;
+        zp.wires_stride = n;
+        zp.sigmas = c->d_sigma_values;
+        zp.k_is = c->d_k_is;
+        zp.w_n_table = ctx->tables.fwd[log_n];
+        for (int i = 0; i < 2; i++) { zp.betas[i] = betas[i]; zp.gammas[i] = gammas[i]; }
+        zp.out = d_zs;
+        zp.log_n = log_n; zp.routed = d.num_routed_wires; zp.chunk = d.quotient_degree_factor; zp.nc = d.num_challenges;
+        zp.npp = d.num_partial_products;
+        launch_zs(ctx->stream, zp, d_zs_scratch);
+        rc = commit_build(ctx, d_zs, n, CommitInput::ValuesNatural, c->n_zs, log_n, d.rate_bits, d.cap_height, cz);
+    }
+    // commit_build only enqueues: the inputs must outlive the stream work
+    if (defer) {
+        if (d_zs) defer->push_back(d_zs);
+        if (d_zs_scratch) defer->push_back(d_zs_scratch);
+    } else {
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->release(d_zs);
+        ctx->release(d_zs_scratch);
+    }
+    return rc;
+}
+
+// a9: quotient polynomials (compute_quotient_polys) from the three LDE tables, committed from coefficients.
+int32_t quotient_stage(nlx_circuit* c, const nlx_commit* cw, const nlx_commit* cz, const uint64_t betas[2],
+                       const uint64_t gammas[2], const uint64_t alphas[2], const uint64_t pih[4], nlx_commit** cq,
+                       const std::function<void(const char*)>& stage, std::vector<void*>* defer) {
+    nlx_ctx* ctx = c->ctx;
+    const nlx_circuit_desc& d = c->d;
+    hipStream_t st = ctx->stream;
+    const unsigned log_n = d.degree_bits;
+    const size_t n = c->n(), L = c->L();
+    const uint32_t nc = d.num_challenges, npp = d.num_partial_products;
+    c->n_terms = nc + nc * (npp + 1) + 128;
+    uint64_t* d_alpha_pows = (uint64_t*)ctx->alloc((size_t)2 * c->n_terms * 8);
+    uint64_t* d_qvals = (uint64_t*)ctx->alloc((size_t)nc * L * 8);
+    uint64_t* d_qchunks = (uint64_t*)ctx->alloc((size_t)nc * L * 8);
+    int32_t rc = NLX_OK;
+    if (!d_alpha_pows || !d_qvals || !d_qchunks) rc = NLX_E_NOMEM;
+    if (!rc) {
+        launch_pow_table(st, d_alpha_pows, alphas[0], alphas[1], c->n_terms, c->n_terms);
+        QuotientParams qp{};
+        qp.cs = c->cs->lde; qp.wires = cw->lde; qp.zs = cz->lde;
+        qp.gates = c->d_gates; qp.k_is = c->d_k_is; qp.coset_base = c->d_coset_base;
+        qp.w_n_table = ctx->tables.fwd[log_n];
+        qp.zh_inv = c->d_zh_inv; qp.l0_scaled = c->d_l0_scaled; qp.alpha_pows = d_alpha_pows;
+        qp.out = d_qvals;
+        for (int i = 0; i < 2; i++) { qp.betas[i] = betas[i]; qp.gammas[i] = gammas[i]; }
+        for (int i = 0; i < 4; i++) qp.pih[i] = pih[i];
+        qp.alpha_stride = c->n_terms;
+        qp.log_n = log_n; qp.rate_bits = d.rate_bits; qp.n_gates = d.num_gates; qp.n_selectors = d.num_selectors;
+        qp.n_consts_all = c->n_consts_all; qp.routed = d.num_routed_wires; qp.chunk = d.quotient_degree_factor; qp.nc = nc; qp.npp = npp;
+        ctx->begin_kernel("quotient", 8.0 * L * (c->n_cs + d.num_wires + c->n_zs + nc) + 8.0 * L * nc);
+        launch_quotient(st, qp);
+        ctx->end_kernel();
+        stage("quotient_intt");
+        launch_intt_dif_cosets(st, ctx->tables, d_qvals, nc, log_n, d.rate_bits, c->d_inv_scale_br);
+        launch_quotient_chunks(st, d_qvals, d_qchunks, log_n, d.rate_bits, nc, c->d_wR_inv, c->d_chunk_scale);
+        stage("commit_quotient");
+        rc = commit_build(ctx, d_qchunks, n, CommitInput::CoeffsBitrev, c->n_q, log_n, d.rate_bits, d.cap_height, cq);
+    }
+    if (defer) {
+        for (void* q : {(void*)d_alpha_pows, (void*)d_qvals, (void*)d_qchunks})
+            if (q) defer->push_back(q);
+    } else {
+        (void)hipStreamSynchronize(st);
+        ctx->release(d_alpha_pows);
+        ctx->release(d_qvals);
+        ctx->release(d_qchunks);
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
 int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, uint8_t* proof_out,
                   size_t proof_cap, size_t* proof_len) {
     if (!c) return NLX_E_INVAL;
@@ -349,23 +447,7 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
 
         // ---- 4. partial products and Z ----
         stage("zs_partial_products");
-        uint64_t* d_zs = dalloc((size_t)c->n_zs * n * 8);
-        uint64_t* d_zs_scratch = dalloc(zs_scratch_words(log_n, nc) * 8);
-        CHECK_ALLOC(d_zs && d_zs_scratch);
-        {
-            ZsParams zp{};
-            zp.wires = sw.as<uint64_t>();
-            zp.wires_stride = n;
-            zp.sigmas = c->d_sigma_values;
-            zp.k_is = c->d_k_is;
-            zp.w_n_table = ctx->tables.fwd[log_n];
-            for (int i = 0; i < 2; i++) { zp.betas[i] = betas[i]; zp.gammas[i] = gammas[i]; }
-            zp.out = d_zs;
-            zp.log_n = log_n; zp.routed = routed; zp.chunk = d.quotient_degree_factor; zp.nc = nc; zp.npp = npp;
-            launch_zs(st, zp, d_zs_scratch);
-        }
-        stage("commit_zs");
-        CHECK(commit_build(ctx, d_zs, n, CommitInput::ValuesNatural, c->n_zs, log_n, d.rate_bits, cap_h, &cz));
+        CHECK(zs_stage(c, sw.as<uint64_t>(), betas, gammas, &cz, &scratch));
         CHECK(fetch(ctx, cap.data(), cz->cap, capw * 8));
         w.u64s(cap.data(), capw);
         ch.observe(cap.data(), capw);
@@ -373,33 +455,7 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
 
         // ---- 5. quotient ----
         stage("quotient_eval");
-        c->n_terms = nc + nc * (npp + 1) + 128;
-        uint64_t* d_alpha_pows = dalloc((size_t)2 * c->n_terms * 8);
-        uint64_t* d_qvals = dalloc((size_t)nc * L * 8);
-        uint64_t* d_qchunks = dalloc((size_t)nc * L * 8);
-        CHECK_ALLOC(d_alpha_pows && d_qvals && d_qchunks);
-        launch_pow_table(st, d_alpha_pows, alphas[0], alphas[1], c->n_terms, c->n_terms);
-        {
-            QuotientParams qp{};
-            qp.cs = c->cs->lde; qp.wires = cw->lde; qp.zs = cz->lde;
-            qp.gates = c->d_gates; qp.k_is = c->d_k_is; qp.coset_base = c->d_coset_base;
-            qp.w_n_table = ctx->tables.fwd[log_n];
-            qp.zh_inv = c->d_zh_inv; qp.l0_scaled = c->d_l0_scaled; qp.alpha_pows = d_alpha_pows;
-            qp.out = d_qvals;
-            for (int i = 0; i < 2; i++) { qp.betas[i] = betas[i]; qp.gammas[i] = gammas[i]; }
-            for (int i = 0; i < 4; i++) qp.pih[i] = pih[i];
-            qp.alpha_stride = c->n_terms;
-            qp.log_n = log_n; qp.rate_bits = d.rate_bits; qp.n_gates = d.num_gates; qp.n_selectors = d.num_selectors;
-            qp.n_consts_all = c->n_consts_all; qp.routed = routed; qp.chunk = d.quotient_degree_factor; qp.nc = nc; qp.npp = npp;
-            ctx->begin_kernel("quotient", 8.0 * L * (c->n_cs + d.num_wires + c->n_zs + nc) + 8.0 * L * nc);
-            launch_quotient(st, qp);
-            ctx->end_kernel();
-        }
-        stage("quotient_intt");
-        launch_intt_dif_cosets(st, ctx->tables, d_qvals, nc, log_n, d.rate_bits, c->d_inv_scale_br);
-        launch_quotient_chunks(st, d_qvals, d_qchunks, log_n, d.rate_bits, nc, c->d_wR_inv, c->d_chunk_scale);
-        stage("commit_quotient");
-        CHECK(commit_build(ctx, d_qchunks, n, CommitInput::CoeffsBitrev, c->n_q, log_n, d.rate_bits, cap_h, &cq));
+        CHECK(quotient_stage(c, cw, cz, betas, gammas, alphas, pih, &cq, stage, &scratch));
         CHECK(fetch(ctx, cap.data(), cq->cap, capw * 8));
         w.u64s(cap.data(), capw);
         ch.observe(cap.data(), capw);
@@ -529,6 +585,155 @@ int32_t nlx_batch_prove(nlx_circuit* const* workers, uint32_t n_workers, nlx_pro
     }
     for (size_t j = 0; j < n_jobs; j++)
         if (jobs[j].status != NLX_OK) return jobs[j].status;
+    return NLX_OK;
+}
+
+
+// ---- stage-level entry points (the fine seam of INTEGRATION.md §3) ----
+
+const nlx_commit* nlx_circuit_constants_sigmas(const nlx_circuit* c) { return c ? c->cs : nullptr; }
+
+int32_t nlx_partial_products_and_zs(nlx_circuit* c, const uint64_t* wires, const uint64_t betas[2], const uint64_t gammas[2],
+                                    nlx_commit** zs_out) {
+    if (!c) return NLX_E_INVAL;
+    nlx_ctx* ctx = c->ctx;
+    if (!wires || !betas || !gammas || !zs_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
+    *zs_out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    Staged sw(ctx, wires, (size_t)c->d.num_wires * c->n() * 8, true, false);
+    if (sw.status) return sw.status;
+    int32_t rc = zs_stage(c, sw.as<uint64_t>(), betas, gammas, zs_out, nullptr);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
+    return rc;
+}
+
+int32_t nlx_quotient_eval(nlx_circuit* c, const nlx_commit* wires, const nlx_commit* zs, const uint64_t betas[2],
+                          const uint64_t gammas[2], const uint64_t alphas[2], const uint64_t public_inputs_hash[4],
+                          nlx_commit** quotient_out) {
+    if (!c) return NLX_E_INVAL;
+    nlx_ctx* ctx = c->ctx;
+    if (!wires || !zs || !betas || !gammas || !alphas || !public_inputs_hash || !quotient_out)
+        return ctx->fail(NLX_E_INVAL, "NULL argument");
+    *quotient_out = nullptr;
+    const nlx_circuit_desc& d = c->d;
+    if (wires->ctx != ctx || zs->ctx != ctx) return ctx->fail(NLX_E_INVAL, "commitments belong to another context");
+    if (wires->n_cols != d.num_wires || zs->n_cols != c->n_zs || wires->log_n != d.degree_bits || zs->log_n != d.degree_bits ||
+        wires->rate_bits != d.rate_bits || zs->rate_bits != d.rate_bits)
+        return ctx->fail(NLX_E_INVAL, "commitment shapes do not match the circuit");
+    for (int i = 0; i < 4; i++)
+        if (public_inputs_hash[i] >= gl::P) return ctx->fail(NLX_E_RANGE, "public inputs hash is not canonical");
+    (void)hipSetDevice(ctx->device);
+    int32_t rc = quotient_stage(c, wires, zs, betas, gammas, alphas, public_inputs_hash, quotient_out, [](const char*) {}, nullptr);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
+    return rc;
+}
+
+int32_t nlx_fri_prove(nlx_ctx* ctx, const nlx_commit* const* oracles, uint32_t n_oracles, uint32_t next_oracle, uint32_t n_next,
+                      const uint64_t zeta[2], const uint64_t* openings_zeta, const uint64_t* openings_next,
+                      const nlx_fri_params* params, nlx_challenger* challenger, uint8_t* proof_out, size_t proof_cap,
+                      size_t* proof_len) {
+    if (!ctx) return NLX_E_INVAL;
+    if (!oracles || !zeta || !openings_zeta || (!openings_next && n_next) || !params || !challenger || !proof_out || !proof_len)
+        return ctx->fail(NLX_E_INVAL, "NULL argument");
+    *proof_len = 0;
+    if (n_oracles < 1 || n_oracles > 4 || next_oracle >= n_oracles) return ctx->fail(NLX_E_RANGE, "1..4 oracles, next_oracle among them");
+    for (uint32_t o = 0; o < n_oracles; o++) {
+        if (!oracles[o] || oracles[o]->ctx != ctx) return ctx->fail(NLX_E_INVAL, "oracle %u: NULL or from another context", o);
+        if (oracles[o]->log_n != oracles[0]->log_n || oracles[o]->rate_bits != oracles[0]->rate_bits ||
+            oracles[o]->cap_height != oracles[0]->cap_height)
+            return ctx->fail(NLX_E_INVAL, "oracles must share degree, rate and cap height");
+    }
+    if (n_next > oracles[next_oracle]->n_cols) return ctx->fail(NLX_E_RANGE, "n_next exceeds the oracle's columns");
+    if (params->arity_bits < 2 || params->arity_bits > 4 || params->num_queries == 0 || params->num_queries > 128 ||
+        params->pow_bits > 40 || oracles[0]->log_n < params->arity_bits)
+        return ctx->fail(NLX_E_RANGE, "FRI parameters out of range");
+    if (challenger->n_input > 8 || challenger->n_output > 8) return ctx->fail(NLX_E_INVAL, "challenger buffers hold at most 8 elements");
+    (void)hipSetDevice(ctx->device);
+    const unsigned log_n = oracles[0]->log_n, rate_bits = oracles[0]->rate_bits;
+    int32_t rc = ctx->ensure_tables(log_n + rate_bits);
+    if (rc) return rc;
+    std::vector<void*> scratch;
+    // coset bases g * w_L^r and w_A^-i
+    const uint32_t R = 1u << rate_bits, A = 1u << params->arity_bits;
+    std::vector<uint64_t> small(4 * R + A);
+    coset_tables_host(log_n, rate_bits, small.data());
+    const uint64_t w_A_inv = gl::inv(gl::root_of_unity(params->arity_bits));
+    for (uint32_t i = 0; i < A; i++) small[4 * R + i] = gl::pow(w_A_inv, i);
+    uint64_t* d_small = (uint64_t*)ctx->alloc(small.size() * 8);
+    if (!d_small) return NLX_E_NOMEM;
+    scratch.push_back(d_small);
+    hipError_t e = hipMemcpyAsync(d_small, small.data(), small.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->release(d_small); return ctx->hip_fail(e, "hipMemcpyAsync(tables)"); }
+    FriProveArgs fa;
+    for (uint32_t o = 0; o < n_oracles; o++) fa.oracles[o] = oracles[o];
+    fa.n_oracles = n_oracles;
+    fa.next_table = next_oracle;
+    fa.nz = n_next;
+    const uint64_t g = gl::root_of_unity(log_n);
+    for (int i = 0; i < 2; i++) { fa.zeta[i] = zeta[i]; fa.gzeta[i] = gl::mul(zeta[i], g); }
+    fa.open0 = openings_zeta;
+    fa.open1 = openings_next;
+    fa.log_n = log_n; fa.rate_bits = rate_bits; fa.cap_height = oracles[0]->cap_height; fa.arity_bits = params->arity_bits;
+    fa.pow_bits = params->pow_bits; fa.n_queries = params->num_queries;
+    fa.n_rounds = fri_num_rounds(log_n, rate_bits, oracles[0]->cap_height, params->arity_bits, params->final_poly_bits);
+    fa.d_coset_base = d_small;
+    fa.d_wA_inv = d_small + 4 * R;
+    Challenger ch;
+    memcpy(ch.state, challenger->state, sizeof ch.state);
+    memcpy(ch.in_buf, challenger->input, sizeof ch.in_buf);
+    memcpy(ch.out_buf, challenger->output, sizeof ch.out_buf);
+    ch.n_in = challenger->n_input;
+    ch.n_out = challenger->n_output;
+    Writer w{proof_out, 0, proof_cap};
+    rc = fri_prove(ctx, fa, ch, w, scratch, [](const char*) {});
+    e = hipStreamSynchronize(ctx->stream);
+    if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
+    for (void* q : scratch) ctx->release(q);
+    if (rc) return rc;
+    if (w.overflow) return ctx->fail(NLX_E_RANGE, "proof buffer too small");
+    memcpy(challenger->state, ch.state, sizeof ch.state);
+    memcpy(challenger->input, ch.in_buf, sizeof ch.in_buf);
+    memcpy(challenger->output, ch.out_buf, sizeof ch.out_buf);
+    challenger->n_input = ch.n_in;
+    challenger->n_output = ch.n_out;
+    *proof_len = w.len;
+    return NLX_OK;
+}
+
+// plonky2::iop::challenger::Challenger on the host, for callers without their own (tests, the C example)
+void nlx_challenger_init(nlx_challenger* c) { if (c) memset(c, 0, sizeof *c); }
+int32_t nlx_challenger_observe(nlx_challenger* c, const uint64_t* elements, size_t n) {
+    if (!c || (!elements && n) || c->n_input > 8 || c->n_output > 8) return NLX_E_INVAL;
+    Challenger ch;
+    memcpy(ch.state, c->state, sizeof ch.state); memcpy(ch.in_buf, c->input, sizeof ch.in_buf);
+    memcpy(ch.out_buf, c->output, sizeof ch.out_buf); ch.n_in = c->n_input; ch.n_out = c->n_output;
+    for (size_t i = 0; i < n; i++) {
+        if (elements[i] >= gl::P) return NLX_E_RANGE;
+        ch.observe(elements[i]);
+    }
+    memcpy(c->state, ch.state, sizeof ch.state); memcpy(c->input, ch.in_buf, sizeof ch.in_buf);
+    memcpy(c->output, ch.out_buf, sizeof ch.out_buf); c->n_input = ch.n_in; c->n_output = ch.n_out;
+    return NLX_OK;
+}
+int32_t nlx_challenger_challenge(nlx_challenger* c, uint64_t* out, size_t n) {
+    if (!c || (!out && n) || c->n_input > 8 || c->n_output > 8) return NLX_E_INVAL;
+    Challenger ch;
+    memcpy(ch.state, c->state, sizeof ch.state); memcpy(ch.in_buf, c->input, sizeof ch.in_buf);
+    memcpy(ch.out_buf, c->output, sizeof ch.out_buf); ch.n_in = c->n_input; ch.n_out = c->n_output;
+    for (size_t i = 0; i < n; i++) out[i] = ch.challenge();
+    memcpy(c->state, ch.state, sizeof ch.state); memcpy(c->input, ch.in_buf, sizeof ch.in_buf);
+    memcpy(c->output, ch.out_buf, sizeof ch.out_buf); c->n_input = ch.n_in; c->n_output = ch.n_out;
+    return NLX_OK;
+}
+int32_t nlx_hash_no_pad(const uint64_t* elements, size_t n, uint64_t out[4]) {
+    if ((!elements && n) || !out) return NLX_E_INVAL;
+    for (size_t i = 0; i < n; i++)
+        if (elements[i] >= gl::P) return NLX_E_RANGE;
+    hash_no_pad_host(elements, n, out);
+    for (int i = 0; i < 4; i++) out[i] = gl::canon(out[i]);
     return NLX_OK;
 }
 

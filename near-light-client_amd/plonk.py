@@ -147,6 +147,37 @@ class CircuitData:
                                      self._buf.ctypes.data, self._buf.size, ctypes.byref(ln)))
         return self._buf[:ln.value].tobytes()
 
+    # ---- stage-level calls (the fine seam) ----
+    def constants_sigmas_batch(self):
+        """The circuit's constants + sigmas commitment (FRI oracle 0); borrowed, lives as long as the circuit."""
+        from .batch import PolynomialBatch
+        d = self._desc
+        h = ctypes.c_void_p(dll.nlx_circuit_constants_sigmas(self.handle))
+        pb = PolynomialBatch._adopt_handle(self.ctx, h, d.num_selectors + d.num_constants + d.num_routed_wires, d.degree_bits,
+                                           d.rate_bits, d.cap_height)
+        pb._borrowed = True
+        return pb
+
+    def partial_products_and_zs(self, wires, betas, gammas):
+        from .batch import PolynomialBatch
+        b = np.ascontiguousarray(betas, dtype=np.uint64)
+        g = np.ascontiguousarray(gammas, dtype=np.uint64)
+        h = ctypes.c_void_p()
+        self.ctx.check(dll.nlx_partial_products_and_zs(self.handle, ptr(wires), ptr(b), ptr(g), ctypes.byref(h)))
+        d = self._desc
+        n_zs = d.num_challenges * (1 + d.num_partial_products)
+        return PolynomialBatch._adopt_handle(self.ctx, h, n_zs, d.degree_bits, d.rate_bits, d.cap_height)
+
+    def quotient_eval(self, wires_batch, zs_batch, betas, gammas, alphas, public_inputs_hash):
+        from .batch import PolynomialBatch
+        arrs = [np.ascontiguousarray(x, dtype=np.uint64) for x in (betas, gammas, alphas, public_inputs_hash)]
+        h = ctypes.c_void_p()
+        self.ctx.check(dll.nlx_quotient_eval(self.handle, wires_batch.handle, zs_batch.handle, ptr(arrs[0]), ptr(arrs[1]),
+                                             ptr(arrs[2]), ptr(arrs[3]), ctypes.byref(h)))
+        d = self._desc
+        return PolynomialBatch._adopt_handle(self.ctx, h, d.num_challenges * d.quotient_degree_factor, d.degree_bits,
+                                             d.rate_bits, d.cap_height)
+
     def prove_into(self, wires, public_inputs_ptr):
         """Hot-loop variant: no copies of the result; returns the proof length."""
         ln = ctypes.c_size_t()
@@ -171,6 +202,60 @@ class CircuitData:
             self.close()
         except Exception:
             pass
+
+
+class ChallengerState(ctypes.Structure):
+    """nlx_challenger (include/nlx.h)"""
+    _fields_ = [("state", ctypes.c_uint64 * 12), ("input", ctypes.c_uint64 * 8), ("n_input", ctypes.c_uint32),
+                ("pad0", ctypes.c_uint32), ("output", ctypes.c_uint64 * 8), ("n_output", ctypes.c_uint32),
+                ("pad1", ctypes.c_uint32)]
+
+
+class Challenger:
+    """plonky2::iop::challenger::Challenger on the host (nlx_challenger_*), for the stage-by-stage flow."""
+
+    def __init__(self):
+        self.s = ChallengerState()
+        dll.nlx_challenger_init(ctypes.byref(self.s))
+
+    def observe(self, elements):
+        e = np.ascontiguousarray(np.asarray(elements, dtype=np.uint64).reshape(-1))
+        rc = dll.nlx_challenger_observe(ctypes.byref(self.s), ptr(e) if e.size else None, e.size)
+        if rc != 0:
+            raise NlxError(rc, "nlx_challenger_observe")
+
+    def challenges(self, n):
+        out = np.zeros(n, dtype=np.uint64)
+        rc = dll.nlx_challenger_challenge(ctypes.byref(self.s), ptr(out), n)
+        if rc != 0:
+            raise NlxError(rc, "nlx_challenger_challenge")
+        return out
+
+
+def hash_no_pad(elements):
+    e = np.ascontiguousarray(np.asarray(elements, dtype=np.uint64).reshape(-1))
+    out = np.zeros(4, dtype=np.uint64)
+    rc = dll.nlx_hash_no_pad(ptr(e) if e.size else None, e.size, ptr(out))
+    if rc != 0:
+        raise NlxError(rc, "nlx_hash_no_pad")
+    return out
+
+
+class FriParams(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint32) for k in ("arity_bits", "final_poly_bits", "pow_bits", "num_queries")]
+
+
+def fri_prove(ctx, oracles, next_oracle, n_next, zeta, openings_zeta, openings_next, params, challenger, cap_bytes=1 << 22):
+    """nlx_fri_prove: oracles = PolynomialBatch list; returns the FriProof bytes and advances `challenger`."""
+    hs = (ctypes.c_void_p * len(oracles))(*[o.handle for o in oracles])
+    z = np.ascontiguousarray(zeta, dtype=np.uint64)
+    o0 = np.ascontiguousarray(np.asarray(openings_zeta, dtype=np.uint64).reshape(-1))
+    o1 = np.ascontiguousarray(np.asarray(openings_next, dtype=np.uint64).reshape(-1))
+    buf = np.zeros(cap_bytes, dtype=np.uint8)
+    n = ctypes.c_size_t()
+    ctx.check(dll.nlx_fri_prove(ctx.handle, hs, len(oracles), next_oracle, n_next, ptr(z), ptr(o0), ptr(o1) if o1.size else None,
+                                ctypes.byref(params), ctypes.byref(challenger.s), buf.ctypes.data, buf.size, ctypes.byref(n)))
+    return buf[:n.value].tobytes()
 
 
 class ProveJob(ctypes.Structure):
