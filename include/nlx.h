@@ -55,6 +55,16 @@ const char* nlx_last_error(const nlx_ctx* ctx);
  * NULL restores the context's own stream.  The caller keeps ownership of the stream. */
 int32_t nlx_ctx_set_stream(nlx_ctx* ctx, void* hip_stream);
 int32_t nlx_ctx_synchronize(nlx_ctx* ctx);
+/* Device buffers for callers without HIP bindings of their own (SURVEY.md §8b `nlx_buf`): every entry point that
+ * takes a "host or device" pointer accepts nlx_buf_device_ptr(buf) (+ an offset).  A buffer belongs to its context
+ * and must be destroyed before it; upload / download are synchronous. */
+typedef struct nlx_buf nlx_buf;
+int32_t nlx_buf_create(nlx_ctx* ctx, size_t bytes, nlx_buf** out);
+void nlx_buf_destroy(nlx_buf* buf);
+void* nlx_buf_device_ptr(const nlx_buf* buf);
+size_t nlx_buf_size(const nlx_buf* buf);
+int32_t nlx_buf_upload(nlx_buf* buf, size_t offset, const void* src, size_t bytes);
+int32_t nlx_buf_download(nlx_buf* buf, size_t offset, void* dst, size_t bytes);
 /* The context keeps freed device blocks for reuse (hipMalloc / hipFree synchronise the device).
  * nlx_ctx_memory reports the bytes it holds from the driver and the part currently in use by live handles and
  * tables; nlx_ctx_trim returns the unused part to the driver (it synchronises the stream first). */

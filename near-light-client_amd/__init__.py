@@ -7,7 +7,7 @@ There is NO CPU fallback: importing `nlx_amd.lib` raises if libnlx.so is missing
 a Context raises if no gfx950 device is usable.
 """
 from . import _lib as lib  # noqa: F401  (raises loudly when the HIP extension is absent)
-from ._lib import Context, NlxError, GOLDILOCKS_P  # noqa: F401
+from ._lib import Context, DeviceBuffer, NlxError, GOLDILOCKS_P  # noqa: F401
 from .batch import PolynomialBatch, MerkleTree, poseidon_permute, hash_rows, ntt, field_ops  # noqa: F401
 from .plonk import CircuitConfig, CircuitData, SyntheticCircuit, pow_grind, batch_prove, ProveJob  # noqa: F401
 from .stark import Air, Stark, StarkConfig, StarkProver, fibonacci_air, fibonacci_trace, wide_air, wide_trace  # noqa: F401

@@ -36,6 +36,12 @@ SIGNATURES = {
     "nlx_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "nlx_ctx_set_stream": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_ctx_synchronize": (ctypes.c_int32, [ctypes.c_void_p]),
+    "nlx_buf_create": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_size_t, c_void_pp]),
+    "nlx_buf_destroy": (None, [ctypes.c_void_p]),
+    "nlx_buf_device_ptr": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "nlx_buf_size": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "nlx_buf_upload": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]),
+    "nlx_buf_download": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]),
     "nlx_ctx_memory": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "nlx_ctx_trim": (ctypes.c_int32, [ctypes.c_void_p]),
     "nlx_ctx_kernel_timing": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int]),
@@ -131,6 +137,50 @@ def ptr(a):
     if isinstance(a, int):
         return a
     raise TypeError("unsupported buffer type %r" % type(a))
+
+
+class DeviceBuffer:
+    """nlx_buf: a device buffer owned by a Context (for callers without HIP bindings of their own)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        ctx.check(dll.nlx_buf_create(ctx.handle, nbytes, ctypes.byref(h)))
+        self.handle = h
+        self.nbytes = nbytes
+        ctx._adopt(self)
+
+    @classmethod
+    def from_array(cls, ctx, a):
+        a = np.ascontiguousarray(a)
+        b = cls(ctx, a.nbytes)
+        b.upload(a)
+        return b
+
+    @property
+    def ptr(self):
+        return dll.nlx_buf_device_ptr(self.handle)
+
+    def upload(self, a, offset=0):
+        a = np.ascontiguousarray(a)
+        self.ctx.check(dll.nlx_buf_upload(self.handle, offset, a.ctypes.data, a.nbytes))
+
+    def download(self, dtype=np.uint64, offset=0, nbytes=None):
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self.ctx.check(dll.nlx_buf_download(self.handle, offset, out.ctypes.data, out.nbytes))
+        return out
+
+    def close(self):
+        if self.handle and self.ctx.handle:
+            dll.nlx_buf_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

@@ -2,6 +2,7 @@
 // lazily built twiddle / coset-scale tables.
 #include "ctx.hpp"
 #include <cstring>
+#include <new>
 #include "gl.hpp"
 
 void* nlx_ctx::alloc(size_t bytes) {
@@ -262,6 +263,59 @@ int32_t nlx_ctx_kernel_stats(nlx_ctx* c, const char* name, uint64_t* calls, doub
     if (calls) *calls = n;
     if (total_ms) *total_ms = ms;
     if (alg_bytes) *alg_bytes = bytes;
+    return NLX_OK;
+}
+
+// ---- nlx_buf: device buffers for callers without their own HIP bindings ----
+struct nlx_buf {
+    nlx_ctx* ctx;
+    void* dev;
+    size_t bytes;
+};
+
+int32_t nlx_buf_create(nlx_ctx* c, size_t bytes, nlx_buf** out) {
+    if (!c) return NLX_E_INVAL;
+    if (!out || bytes == 0) return c->fail(NLX_E_INVAL, "nlx_buf_create: NULL out or zero size");
+    *out = nullptr;
+    (void)hipSetDevice(c->device);
+    void* p = c->alloc(bytes);
+    if (!p) return NLX_E_NOMEM;
+    nlx_buf* b = new (std::nothrow) nlx_buf{c, p, bytes};
+    if (!b) { c->release(p); return c->fail(NLX_E_NOMEM, "host allocation failed"); }
+    *out = b;
+    return NLX_OK;
+}
+
+void nlx_buf_destroy(nlx_buf* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    b->ctx->release(b->dev);
+    delete b;
+}
+
+void* nlx_buf_device_ptr(const nlx_buf* b) { return b ? b->dev : nullptr; }
+size_t nlx_buf_size(const nlx_buf* b) { return b ? b->bytes : 0; }
+
+int32_t nlx_buf_upload(nlx_buf* b, size_t offset, const void* src, size_t bytes) {
+    if (!b) return NLX_E_INVAL;
+    nlx_ctx* c = b->ctx;
+    if (!src && bytes) return c->fail(NLX_E_INVAL, "NULL source");
+    if (offset > b->bytes || bytes > b->bytes - offset) return c->fail(NLX_E_RANGE, "upload exceeds the buffer");
+    (void)hipSetDevice(c->device);
+    NLX_HIP(c, hipMemcpyAsync((uint8_t*)b->dev + offset, src, bytes, hipMemcpyHostToDevice, c->stream));
+    NLX_HIP(c, hipStreamSynchronize(c->stream));
+    return NLX_OK;
+}
+
+int32_t nlx_buf_download(nlx_buf* b, size_t offset, void* dst, size_t bytes) {
+    if (!b) return NLX_E_INVAL;
+    nlx_ctx* c = b->ctx;
+    if (!dst && bytes) return c->fail(NLX_E_INVAL, "NULL destination");
+    if (offset > b->bytes || bytes > b->bytes - offset) return c->fail(NLX_E_RANGE, "download exceeds the buffer");
+    (void)hipSetDevice(c->device);
+    NLX_HIP(c, hipMemcpyAsync(dst, (const uint8_t*)b->dev + offset, bytes, hipMemcpyDeviceToHost, c->stream));
+    NLX_HIP(c, hipStreamSynchronize(c->stream));
     return NLX_OK;
 }
 

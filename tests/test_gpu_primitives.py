@@ -224,3 +224,24 @@ def test_context_memory_accounting(nlx, orc):
     c.trim()
     assert c.memory() == (r0, u0)                 # only the tables remain
     c.close()
+
+
+def test_device_buffer_roundtrip_and_use(nlx, ctx):
+    """nlx_buf: upload / download round trip, range checks, and a buffer's device pointer as a prover input"""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, P, (3, 1000), dtype=np.uint64)
+    b = nlx.DeviceBuffer.from_array(ctx, a)
+    assert b.nbytes == a.nbytes and np.array_equal(b.download().reshape(3, 1000), a)
+    b.upload(np.arange(10, dtype=np.uint64), offset=80)
+    assert np.array_equal(b.download(offset=80, nbytes=80), np.arange(10, dtype=np.uint64))
+    with pytest.raises(nlx.NlxError):
+        b.upload(np.zeros(8, dtype=np.uint64), offset=a.nbytes - 8)
+    with pytest.raises(nlx.NlxError):
+        b.download(offset=a.nbytes + 8, nbytes=8)
+    b.close()
+    syn = nlx.SyntheticCircuit(8, seed=3)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    w = nlx.DeviceBuffer.from_array(ctx, syn.wires)
+    assert cd.prove(w.ptr, syn.public_inputs) == cd.prove(syn.wires, syn.public_inputs)
+    w.close()
+    cd.close()
