@@ -341,6 +341,10 @@ int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint6
 #define NLX_AIR_EMIT_BOOL 14       /* constraint(x * (x - 1)) for x = local_values[a .. a + max(b, 1)), in column order */
 #define NLX_AIR_LOADV 15           /* scheduling hint: the next `dst` (<= 8) words are independent LOCAL / NEXT / PUBLIC /
                                       PERIODIC loads with distinct destinations; the kernel issues them together */
+/* three-operand forms for bit-valued columns (bitwise hash AIRs); the third register index is in bits 56..61 */
+#define NLX_AIR_XOR3 16            /* r[dst] = a ^ b ^ c as a polynomial: s = a + b - 2ab, s + c - 2sc */
+#define NLX_AIR_CH 17              /* r[dst] = c + a (b - c) */
+#define NLX_AIR_MAJ 18             /* r[dst] = ab + c (a + b - 2ab) */
 #define NLX_AIR_NUM_REGS 64
 #define NLX_AIR_MAX_PERIODIC 16
 

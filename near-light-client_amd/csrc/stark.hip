@@ -92,6 +92,26 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
             case NLX_AIR_ADD: my[dst * bd] = gl::add(my[a * bd], mul_pow2(my[b * bd], sh)); continue;
             case NLX_AIR_SUB: my[dst * bd] = gl::sub(my[a * bd], mul_pow2(my[b * bd], sh)); continue;
             case NLX_AIR_MUL: my[dst * bd] = gl::mul(my[a * bd], my[b * bd]); continue;
+            case NLX_AIR_XOR3:
+            case NLX_AIR_CH:
+            case NLX_AIR_MAJ: {
+                const uint64_t x = my[a * bd], y = my[b * bd], z = my[sh * bd];
+                uint64_t res;
+                if (op == NLX_AIR_CH) {
+                    res = gl::add(z, gl::mul(x, gl::sub(y, z)));
+                } else {
+                    const uint64_t xy = gl::mul(x, y);
+                    const uint64_t sx = gl::sub(gl::add(x, y), gl::add(xy, xy));
+                    if (op == NLX_AIR_XOR3) {
+                        const uint64_t sz = gl::mul(sx, z);
+                        res = gl::sub(gl::add(sx, z), gl::add(sz, sz));
+                    } else {
+                        res = gl::add(xy, gl::mul(z, sx));
+                    }
+                }
+                my[dst * bd] = res;
+                continue;
+            }
             case NLX_AIR_PACK_LOCAL:
             case NLX_AIR_PACK_NEXT: {
                 // b loads in flight at once (wave-uniform trip count), then shift-accumulate
@@ -222,7 +242,7 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
             const uint64_t w = prog[pc];
             const uint32_t op = (uint32_t)(w & 0xFF), dst = (uint32_t)((w >> 8) & 0xFFFF);
             const uint32_t a = (uint32_t)((w >> 24) & 0xFFFF), b = (uint32_t)((w >> 40) & 0xFFFF);
-            if (op > NLX_AIR_LOADV) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
+            if (op > NLX_AIR_MAJ) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
             if (op == NLX_AIR_LOADV) {
                 // a hint: the following words are validated as the ordinary loads they are
                 if (dst < 1 || dst > 8 || pc + dst >= d.n_words) return ctx->fail(NLX_E_INVAL, "AIR word %u: LOADV count", pc);
@@ -238,11 +258,17 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
                 }
                 continue;
             }
-            const bool writes = op <= NLX_AIR_MUL || (op >= NLX_AIR_PERIODIC && op <= NLX_AIR_PACK_NEXT);
+            const bool three = op >= NLX_AIR_XOR3 && op <= NLX_AIR_MAJ;
+            const bool writes = op <= NLX_AIR_MUL || (op >= NLX_AIR_PERIODIC && op <= NLX_AIR_PACK_NEXT) || three;
+            if (three) {
+                const uint32_t c3 = (uint32_t)(w >> 56) & 0x3F;
+                if (a >= NLX_AIR_NUM_REGS || b >= NLX_AIR_NUM_REGS || !written[a] || !written[b] || !written[c3])
+                    return ctx->fail(NLX_E_INVAL, "AIR word %u: reads an unwritten register", pc);
+            }
             if ((op == NLX_AIR_PACK_LOCAL || op == NLX_AIR_PACK_NEXT) && (b < 1 || b > 32 || a + b > d.n_cols))
                 return ctx->fail(NLX_E_INVAL, "AIR word %u: PACK range out of the trace", pc);
             if (op == NLX_AIR_EMIT_BOOL && a + (b ? b : 1) > d.n_cols) return ctx->fail(NLX_E_INVAL, "AIR word %u: column out of range", pc);
-            if ((w >> 56) != 0 && op != NLX_AIR_ADD && op != NLX_AIR_SUB) return ctx->fail(NLX_E_INVAL, "AIR word %u: shift on a non-ADD/SUB word", pc);
+            if ((w >> 56) != 0 && op != NLX_AIR_ADD && op != NLX_AIR_SUB && !three) return ctx->fail(NLX_E_INVAL, "AIR word %u: shift on a non-ADD/SUB word", pc);
             if ((w >> 62) != 0) return ctx->fail(NLX_E_INVAL, "AIR word %u: reserved bits set", pc);
             if (writes && dst >= NLX_AIR_NUM_REGS) return ctx->fail(NLX_E_INVAL, "AIR word %u: register out of range", pc);
             if ((op == NLX_AIR_LOCAL || op == NLX_AIR_NEXT) && a >= d.n_cols) return ctx->fail(NLX_E_INVAL, "AIR word %u: column out of range", pc);

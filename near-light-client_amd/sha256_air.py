@@ -90,8 +90,7 @@ def sha256_air():
     def xor2(x, y):
         return x + y - 2 * (x * y)
 
-    def xor3(x, y, z):
-        return xor2(xor2(x, y), z)
+    xor3 = air.xor3
 
     def weighted(terms):
         acc = terms[0]
@@ -114,13 +113,9 @@ def sha256_air():
     f = [L(F + i) for i in range(32)]
     g = [L(G + i) for i in range(32)]
     sig1 = weighted([xor3(e[(i + 6) % 32], e[(i + 11) % 32], e[(i + 25) % 32]) for i in range(32)])
-    ch = weighted([g[i] + e[i] * (f[i] - g[i]) for i in range(32)])
+    ch = weighted([air.ch(e[i], f[i], g[i]) for i in range(32)])
     sig0 = weighted([xor3(a[(i + 2) % 32], a[(i + 13) % 32], a[(i + 22) % 32]) for i in range(32)])
-    maj_terms = []
-    for i in range(32):
-        ab = a[i] * b[i]
-        maj_terms.append(ab + c[i] * (a[i] + b[i] - 2 * ab))
-    maj = weighted(maj_terms)
+    maj = weighted([air.maj(a[i], b[i], c[i]) for i in range(32)])
     t1 = L(H) + sig1 + ch + k_t + L(WIN)
     air.constraint(L(NEW_A) + pk(L, CA, 3) * two32 - (t1 + sig0 + maj))
     air.constraint(L(NEW_E) + pk(L, CE, 3) * two32 - (L(D) + t1))

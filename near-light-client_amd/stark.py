@@ -19,7 +19,10 @@ from ._lib import dll, ptr, NlxError
 
 P = 0xFFFFFFFF00000001
 (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_CONST, AIR_ADD, AIR_SUB, AIR_MUL, AIR_EMIT_TRANSITION, AIR_EMIT_FIRST,
- AIR_EMIT_LAST, AIR_EMIT, AIR_PERIODIC, AIR_PACK_LOCAL, AIR_PACK_NEXT, AIR_EMIT_BOOL, AIR_LOADV) = range(16)
+ AIR_EMIT_LAST, AIR_EMIT, AIR_PERIODIC, AIR_PACK_LOCAL, AIR_PACK_NEXT, AIR_EMIT_BOOL, AIR_LOADV, AIR_XOR3, AIR_CH,
+ AIR_MAJ) = range(19)
+_AIR_BINARY = (AIR_ADD, AIR_SUB, AIR_MUL)
+_AIR_TERNARY = (AIR_XOR3, AIR_CH, AIR_MAJ)
 AIR_NUM_REGS = 64
 AIR_MAX_RESIDENT_LEAVES = 12   # loads kept in registers (LRU) before they are re-loaded
 AIR_LOAD_BATCH = 8             # loads issued together (NLX_AIR_LOADV): memory-level parallelism of the VM
@@ -64,12 +67,19 @@ def _pow2_factor(e):
 class _Expr:
     """Node of the constraint DAG.  degree = polynomial degree in the trace columns.  ADD / SUB nodes carry
     a shift: a +- b * 2^sh (multiplications by powers of two are folded into the neighbouring sum)."""
-    __slots__ = ("air", "op", "a", "b", "degree", "uses", "reg", "sh")
+    __slots__ = ("air", "op", "a", "b", "c", "degree", "uses", "reg", "sh")
 
-    def __init__(self, air, op, a=None, b=None, degree=0, sh=0):
-        self.air, self.op, self.a, self.b, self.degree, self.sh = air, op, a, b, degree, sh
+    def __init__(self, air, op, a=None, b=None, degree=0, sh=0, c=None):
+        self.air, self.op, self.a, self.b, self.c, self.degree, self.sh = air, op, a, b, c, degree, sh
         self.uses = 0
         self.reg = None
+
+    def operands(self):
+        if self.op in _AIR_BINARY:
+            return (self.a, self.b)
+        if self.op in _AIR_TERNARY:
+            return (self.a, self.b, self.c)
+        return ()
 
     def _lift(self, o):
         return o if isinstance(o, _Expr) else self.air.const(o)
@@ -121,6 +131,25 @@ class Air:
         if key not in self._leaf_cache:
             self._leaf_cache[key] = _Expr(self, op, idx, cnt, degree)
         return self._leaf_cache[key]
+
+    # three-operand forms for bit-valued columns (one VM instruction each)
+    def _lift(self, x):
+        return x if isinstance(x, _Expr) else self.const(x)
+
+    def xor3(self, x, y, z):
+        """x ^ y ^ z as a polynomial (exact on {0,1}): s = x + y - 2xy, s + z - 2sz."""
+        x, y, z = self._lift(x), self._lift(y), self._lift(z)
+        return _Expr(self, AIR_XOR3, x, y, x.degree + y.degree + z.degree, c=z)
+
+    def ch(self, e, f, g):
+        """g + e (f - g): e ? f : g."""
+        e, f, g = self._lift(e), self._lift(f), self._lift(g)
+        return _Expr(self, AIR_CH, e, f, e.degree + max(f.degree, g.degree), c=g)
+
+    def maj(self, x, y, z):
+        """xy + z (x + y - 2xy): majority of three bits."""
+        x, y, z = self._lift(x), self._lift(y), self._lift(z)
+        return _Expr(self, AIR_MAJ, x, y, x.degree + y.degree + z.degree, c=z)
 
     def pack(self, base, nbits, next_row=False):
         """sum_i 2^i * column[base + i] of the local (or next) row as ONE VM instruction: the word behind
@@ -204,7 +233,7 @@ class Air:
           AIR_LOAD_BATCH loads in flight per lane instead of one.
         Constraints are emitted in declaration order (that order defines the alpha powers for prover and
         verifier alike)."""
-        ops = (AIR_ADD, AIR_SUB, AIR_MUL)
+        ops = _AIR_BINARY + _AIR_TERNARY
         packs = (AIR_PACK_LOCAL, AIR_PACK_NEXT)
         batchable = (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_PERIODIC)
 
@@ -226,9 +255,8 @@ class Air:
                     continue
                 seen.add(id(x))
                 stack.append((x, True))
-                if x.op in ops:
-                    stack.append((x.b, False))
-                    stack.append((x.a, False))
+                for y in reversed(x.operands()):
+                    stack.append((y, False))
             for x in nodes:
                 computed.add(id(x))
                 all_vals.append(x)
@@ -236,10 +264,9 @@ class Air:
         for x in all_vals:
             x.uses, x.reg = 0, None
         for x in all_vals:
-            if x.op in ops:
-                for y in (x.a, x.b):
-                    if is_value(y):
-                        y.uses += 1
+            for y in x.operands():
+                if is_value(y):
+                    y.uses += 1
         for eop, root, _ in self._emits:
             if eop != AIR_EMIT_BOOL and is_value(root):
                 root.uses += 1
@@ -340,10 +367,9 @@ class Air:
             # plain-load use counts within this constraint, and their order of use
             leaf_seq = []
             for x in nodes:
-                if x.op in ops:
-                    for y in (x.a, x.b):
-                        if not is_value(y):
-                            leaf_seq.append(y)
+                for y in x.operands():
+                    if not is_value(y):
+                        leaf_seq.append(y)
             if not is_value(root):
                 leaf_seq.append(root)
             for y in leaf_seq:
@@ -357,15 +383,18 @@ class Air:
                     x.reg = alloc()
                     words.append(x.op | x.reg << 8 | x.a << 24 | x.b << 40)
                     continue
-                n_leaf = sum(1 for y in (x.a, x.b) if not is_value(y))
-                ra = ensure(x.a, (), leaf_seq[pos:pos + 4 * AIR_LOAD_BATCH])
-                rb = ensure(x.b, (x.a,), leaf_seq[pos:pos + 4 * AIR_LOAD_BATCH])
+                opnds = x.operands()
+                n_leaf = sum(1 for y in opnds if not is_value(y))
+                regs = []
+                for i, y in enumerate(opnds):
+                    regs.append(ensure(y, opnds[:i], leaf_seq[pos:pos + 4 * AIR_LOAD_BATCH]))
                 pos += n_leaf
                 cur["pos"] = pos
-                release(x.a)
-                release(x.b)
+                for y in opnds:
+                    release(y)
                 x.reg = alloc()
-                words.append(x.op | x.reg << 8 | ra << 24 | rb << 40 | x.sh << 56)
+                third = regs[2] if len(regs) == 3 else x.sh
+                words.append(x.op | x.reg << 8 | regs[0] << 24 | regs[1] << 40 | third << 56)
             words.append(op | ensure(root, (), leaf_seq[pos:]) << 24)
             release(root)
             assert not resident

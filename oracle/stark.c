@@ -336,6 +336,22 @@ static void air_eval_base(const orc_stark_desc* d, const uint64_t* local, const 
                     for (uint32_t j = 0; j < d->num_challenges; j++) accs[j] = gl_add(gl_mul(accs[j], alphas[j]), cb);
                 }
                 break;
+            case ORC_AIR_XOR3: case ORC_AIR_CH: case ORC_AIR_MAJ: {
+                const uint64_t x = reg[a % AIR_REGS], y = reg[b % AIR_REGS], z = reg[AIR_SH(w)];
+                if (AIR_OP(w) == ORC_AIR_CH) {
+                    reg[dst] = gl_add(z, gl_mul(x, gl_sub(y, z)));
+                } else {
+                    const uint64_t xy = gl_mul(x, y);
+                    const uint64_t sx = gl_sub(gl_add(x, y), gl_add(xy, xy)); /* x ^ y */
+                    if (AIR_OP(w) == ORC_AIR_XOR3) {
+                        const uint64_t sz = gl_mul(sx, z);
+                        reg[dst] = gl_sub(gl_add(sx, z), gl_add(sz, sz));
+                    } else {
+                        reg[dst] = gl_add(xy, gl_mul(z, sx));
+                    }
+                }
+                break;
+            }
             case ORC_AIR_EMIT_TRANSITION: c = gl_mul(reg[a % AIR_REGS], z_last); emit = 1; break;
             case ORC_AIR_EMIT_FIRST: c = gl_mul(reg[a % AIR_REGS], l_first); emit = 1; break;
             case ORC_AIR_EMIT_LAST: c = gl_mul(reg[a % AIR_REGS], l_last); emit = 1; break;
@@ -378,6 +394,22 @@ static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* n
                     for (uint32_t j = 0; j < d->num_challenges; j++) accs[j] = gl2_add(gl2_scale(accs[j], alphas[j]), cb);
                 }
                 break;
+            case ORC_AIR_XOR3: case ORC_AIR_CH: case ORC_AIR_MAJ: {
+                const gl2 x = reg[a % AIR_REGS], y = reg[b % AIR_REGS], z = reg[AIR_SH(w)];
+                if (AIR_OP(w) == ORC_AIR_CH) {
+                    reg[dst] = gl2_add(z, gl2_mul(x, gl2_sub(y, z)));
+                } else {
+                    const gl2 xy = gl2_mul(x, y);
+                    const gl2 sx = gl2_sub(gl2_add(x, y), gl2_add(xy, xy));
+                    if (AIR_OP(w) == ORC_AIR_XOR3) {
+                        const gl2 sz = gl2_mul(sx, z);
+                        reg[dst] = gl2_sub(gl2_add(sx, z), gl2_add(sz, sz));
+                    } else {
+                        reg[dst] = gl2_add(xy, gl2_mul(z, sx));
+                    }
+                }
+                break;
+            }
             case ORC_AIR_EMIT_TRANSITION: c = gl2_mul(reg[a % AIR_REGS], z_last); emit = 1; break;
             case ORC_AIR_EMIT_FIRST: c = gl2_mul(reg[a % AIR_REGS], l_first); emit = 1; break;
             case ORC_AIR_EMIT_LAST: c = gl2_mul(reg[a % AIR_REGS], l_last); emit = 1; break;
@@ -417,7 +449,7 @@ static int desc_ok(const orc_stark_desc* d) {
                 break;
             case ORC_AIR_EMIT_BOOL: if (AIR_A(w) + (AIR_B(w) ? AIR_B(w) : 1) > d->n_cols) return 0; break;
             case ORC_AIR_CONST: if (++pc >= d->n_words) return 0; break;
-            default: if (AIR_OP(w) > ORC_AIR_LOADV) return 0;
+            default: if (AIR_OP(w) > ORC_AIR_MAJ) return 0;
         }
     }
     return 1;

@@ -55,7 +55,11 @@ enum {
     ORC_AIR_PACK_LOCAL = 12,     /* dst = sum_{i<b} 2^i local_values[a+i]   (b <= 32) */
     ORC_AIR_PACK_NEXT = 13,      /* dst = sum_{i<b} 2^i next_values[a+i] */
     ORC_AIR_EMIT_BOOL = 14,      /* constraint(x * (x - 1)) for x = local_values[a .. a + max(b, 1)), in column order */
-    ORC_AIR_LOADV = 15           /* scheduling hint: the next `dst` words are independent loads (no semantics) */
+    ORC_AIR_LOADV = 15,          /* scheduling hint: the next `dst` words are independent loads (no semantics) */
+    /* three-operand forms for bit-valued columns; the third register is in bits 56..61 */
+    ORC_AIR_XOR3 = 16,           /* dst = a ^ b ^ c as a polynomial: s = a + b - 2ab, dst = s + c - 2sc */
+    ORC_AIR_CH = 17,             /* dst = c + a (b - c)            (choose: a ? b : c) */
+    ORC_AIR_MAJ = 18             /* dst = ab + c (a + b - 2ab)     (majority) */
 };
 /* ADD / SUB carry a shift in bits 56..61 of the word: dst = r[a] +- r[b] * 2^shift. */
 

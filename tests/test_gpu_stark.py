@@ -133,8 +133,12 @@ def _random_air(S, rng, n_cols, n_pis, with_periodic):
         e = pool[int(rng.integers(0, len(pool)))]
         for _ in range(int(rng.integers(1, 6))):
             o = pool[int(rng.integers(0, len(pool)))]
-            k = int(rng.integers(0, 6))
-            if k == 0 and e.degree + o.degree <= 3:
+            k = int(rng.integers(0, 8))
+            if k == 6 and e.degree + o.degree <= 2:
+                e = air.xor3(e, o, pool[int(rng.integers(0, len(leaves)))]) if e.degree + o.degree + 1 <= 3 else air.ch(e, o, o)
+            elif k == 7 and e.degree + o.degree + 1 <= 3:
+                e = air.maj(o, e, pool[int(rng.integers(0, len(leaves)))]) if (seed_bit := int(rng.integers(0, 2))) else air.ch(o, e, 3)
+            elif k == 0 and e.degree + o.degree <= 3:
                 e = e * o
             elif k == 1:
                 e = e + o * (1 << int(rng.integers(1, 40)))

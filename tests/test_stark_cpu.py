@@ -33,6 +33,12 @@ def run_program(words, local, nxt, pis, periodic=()):
             for i in range(max(b, 1)):
                 out.append((10, int(local[a + i]) * (int(local[a + i]) - 1) % P))
         elif op == 15: pass  # LOADV: scheduling hint
+        elif op in (16, 17, 18):
+            x, y, z = reg[a], reg[b], reg[sh]
+            if op == 17: reg[dst] = (z + x * (y - z)) % P
+            else:
+                s2 = (x + y - 2 * x * y) % P
+                reg[dst] = (s2 + z - 2 * s2 * z) % P if op == 16 else (x * y + z * s2) % P
         else: out.append((op, reg[a]))
         pc += 1
     return out
@@ -234,3 +240,30 @@ def test_air_fused_forms(nlx):
             (10, (sum(lo[i] << i for i in range(32)) - 3 * sum(ne[4 + i] << i for i in range(5))) % P),
             (10, lo[7] * (lo[7] - 1) % P), (7, 0)]
     assert got == want
+
+
+def test_air_ternary_forms(nlx):
+    """xor3 / ch / maj are single instructions, exact on bits and equal to their polynomial on any field element"""
+    S = nlx.stark
+    rng = np.random.default_rng(13)
+    air = S.Air(4, 0)
+    x, y, z, w = (air.local(i) for i in range(4))
+    air.constraint(air.xor3(x, y, z) - w)
+    air.constraint(air.ch(x, y, z) + air.maj(x, y, z) * 5)
+    air.constraint(air.xor3(air.xor3(x, y, z), w, 1))
+    assert air.constraint_degree == 4   # xor3 of a degree-3 node with a column and a constant
+    words = air.compile()
+    ops = [int(v) & 0xFF for v in words]
+    assert ops.count(16) == 3 and ops.count(17) == 1 and ops.count(18) == 1 and ops.count(6) == 1  # the "* 5"
+    for bits in ((0, 0, 0, 0), (1, 0, 1, 1), (1, 1, 1, 0), (0, 1, 0, 1)):
+        got = run_program(words, bits, bits, [])
+        bx, by, bz, bw = bits
+        assert got[0] == (10, ((bx ^ by ^ bz) - bw) % P)
+        assert got[1] == (10, ((by if bx else bz) + 5 * ((bx & by) | (bz & (bx ^ by)))) % P)
+        assert got[2] == (10, (bx ^ by ^ bz ^ bw ^ 1) % P)
+    lo = [int(v) for v in rng.integers(0, P, 4, dtype=np.uint64)]
+    got = run_program(words, lo, lo, [])
+    s2 = (lo[0] + lo[1] - 2 * lo[0] * lo[1]) % P
+    x3 = (s2 + lo[2] - 2 * s2 * lo[2]) % P
+    assert got[0] == (10, (x3 - lo[3]) % P)
+    assert got[1] == (10, (lo[2] + lo[0] * (lo[1] - lo[2]) + 5 * (lo[0] * lo[1] + lo[2] * s2)) % P)
