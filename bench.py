@@ -62,7 +62,8 @@ def parse():
     ap.add_argument("--host-witness", default="", choices=["", "pageable", "pinned"],
                     help="hand the witness over as a HOST buffer (PCIe inside the timed region); reported separately "
                          "in DESIGN.md, never the headline value")
-    ap.add_argument("--map-log-n", type=int, default=15)
+    ap.add_argument("--map-log-n", type=int, default=18,
+                    help="rows of a map proof; SURVEY.md §8d: 18-20 = Sync / map sized (estimate), 12-14 = reduce sized")
     ap.add_argument("--reduce-log-n", type=int, default=13)
     return ap.parse_args()
 

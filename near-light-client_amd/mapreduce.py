@@ -71,7 +71,9 @@ def run_tree(plan, prove_fn, rank=0, world=1, dist=None, device=None):
     """Executes the whole tree.  prove_fn(kind, level, index, public_inputs) -> proof bytes, where kind
     is "map" | "reduce" | "outer"; map jobs get no children (public_inputs=None -> the job's own).
     Returns (root_digest, stats) on every rank; stats counts the proofs this rank produced."""
+    import time
     done = 0
+    level_ms = []
 
     def run_level(jobs):
         """jobs: list of (kind, level, index, public_inputs) owned by this rank -> {index: digest}.
@@ -83,25 +85,31 @@ def run_tree(plan, prove_fn, rank=0, world=1, dist=None, device=None):
         return {job[2]: proof_digest(pr) for job, pr in zip(jobs, proofs)}
 
     # ---- map level ----
+    t0 = time.perf_counter()
     jobs = [("map", 0, j, None) for j in range(plan.n_map) if owner(j, world) == rank]
     local = run_level(jobs)
     done += len(jobs)
     digests = all_gather_digests(local, plan.n_map, rank, world, dist, device)
+    level_ms.append(("map", plan.n_map, (time.perf_counter() - t0) * 1e3))
     # ---- reduce levels ----
     for lvl, n_jobs in enumerate(plan.levels):
         jobs = [("reduce", lvl, j, np.concatenate([digests[2 * j], digests[2 * j + 1]]))
                 for j in range(n_jobs) if owner(j, world) == rank]
+        t0 = time.perf_counter()
         local = run_level(jobs)
         done += len(jobs)
         digests = all_gather_digests(local, n_jobs, rank, world, dist, device)
+        level_ms.append(("reduce%d" % lvl, n_jobs, (time.perf_counter() - t0) * 1e3))
     # ---- outer proof (rank 0), digest broadcast through the same collective ----
+    t0 = time.perf_counter()
     local = {}
     if rank == 0:
         pis = np.concatenate([digests[0], digests[0]])
         local[0] = proof_digest(prove_fn("outer", 0, 0, pis))
         done += 1
     root = all_gather_digests(local, 1, rank, world, dist, device)[0]
-    return root, {"proofs_by_this_rank": done}
+    level_ms.append(("outer", 1, (time.perf_counter() - t0) * 1e3))
+    return root, {"proofs_by_this_rank": done, "level_ms": level_ms}
 
 
 class GpuTreeProver:
@@ -199,6 +207,7 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist):
         "config": {"workload": "VerifyCircuit 128x4-shaped map-reduce job: 32 map proofs (2^%d rows) + 31 reduce "
                                "proofs + 1 outer proof (2^%d rows), sharded round-robin, one RCCL all-gather of "
                                "digests per level" % (args.map_log_n, args.reduce_log_n),
-                   "jobs": plan.n_jobs, "proofs_in_flight_per_gpu": args.inflight, "root_digest": [int(x) for x in root], "parallelism": "mapreduce x%d" % world},
+                   "jobs": plan.n_jobs, "proofs_in_flight_per_gpu": args.inflight,
+                   "level_ms_last_step": [[k, n, round(ms, 3)] for k, n, ms in stats["level_ms"]], "root_digest": [int(x) for x in root], "parallelism": "mapreduce x%d" % world},
         "roofline": None, "cpu_baseline": None,
     }
