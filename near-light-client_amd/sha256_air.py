@@ -178,7 +178,9 @@ def pad_message(msg):
 
 
 def blocks_for_messages(messages, log_blocks=None):
-    """Concatenate the padded blocks of `messages`; fill up to 2^log_blocks with empty messages.
+    """The padded blocks of `messages`, preceded by as many empty messages as it takes to fill 2^log_blocks
+    blocks - the filler goes FIRST so that the AIR's public output (the last block's chaining value) is the
+    digest of the caller's last message.
     Returns (blocks uint32 [n_blocks,16], is_first uint8 [n_blocks], digest of the last message)."""
     blocks, first = [], []
     for m in messages:
@@ -189,12 +191,10 @@ def blocks_for_messages(messages, log_blocks=None):
     lb = (need - 1).bit_length() if log_blocks is None else log_blocks
     if need > (1 << lb):
         raise ValueError("messages need %d blocks > 2^%d" % (need, lb))
-    last = messages[-1] if messages else b""
-    while len(blocks) < (1 << lb):
-        blocks += pad_message(b"")
-        first.append(1)
-        last = b""
-    digest = struct.unpack(">8I", hashlib.sha256(last).digest())
+    fill = (1 << lb) - len(blocks)
+    blocks = pad_message(b"") * fill + blocks
+    first = [1] * fill + first
+    digest = struct.unpack(">8I", hashlib.sha256(messages[-1] if messages else b"").digest())
     return (np.array(blocks, dtype=np.uint32), np.array(first, dtype=np.uint8),
             np.array(digest, dtype=np.uint64))
 

@@ -110,12 +110,7 @@ def test_gpu_sha256_stark_of_a_real_sync_step(nlx, ctx, orc):
     msgs = P.sync_sha256_messages(nxt)
     n_blocks = sum(len(SA.pad_message(m)) for m in msgs)
     log_blocks = (n_blocks - 1).bit_length()
-    blocks, first, want = SA.blocks_for_messages(msgs, log_blocks)
-    assert len(blocks) == n_blocks or (1 << log_blocks) > n_blocks
-    if (1 << log_blocks) != n_blocks:
-        # padding messages were appended: put the next_bps message last again
-        msgs = [b""] * ((1 << log_blocks) - n_blocks) + msgs
-    sp = SA.Sha256Prover(ctx, log_blocks)
+    sp = SA.Sha256Prover(ctx, log_blocks)   # 129 blocks -> 256: the filler messages come first
     proof, digest = sp.prove(msgs)
     got = b"".join(struct.pack(">I", int(x)) for x in digest)
     assert got == nlx.nearx_io.b58decode32(nxt["inner_lite"]["next_bp_hash"])

@@ -28,11 +28,12 @@ def test_reference_trace_is_sha256_and_satisfies_air(nlx):
     SA = nlx.sha256_air
     msgs = _messages()
     blocks, first, digest = SA.blocks_for_messages(msgs, 4)
-    assert first.tolist()[:9] == [1, 1, 0, 1, 1, 1, 0, 1, 0] and all(first[9:] == 1)
+    assert all(first[:7] == 1) and first.tolist()[7:] == [1, 1, 0, 1, 1, 1, 0, 1, 0]   # seven filler blocks come first
+    assert [int(x) for x in digest] == list(struct.unpack(">8I", hashlib.sha256(msgs[-1]).digest()))
     t, hout = SA.reference_trace(blocks, first)
     assert t.shape == (SA.N_COLS, 1024) and int(t.max()) < 2 ** 32
     # the chaining value after each message's last block is hashlib's digest
-    b = 0
+    b = 7
     for m in msgs:
         nb = len(SA.pad_message(m))
         row = 64 * (b + nb - 1) + 63
@@ -65,10 +66,10 @@ def test_header_hash_through_the_air(nlx):
     msgs = io.header_hash_preimages(fx)
     blocks, first, digest = SA.blocks_for_messages(msgs)
     t, hout = SA.reference_trace(blocks, first)
-    # messages are [inner_lite, inner_lite_hash || inner_rest_hash, that_hash || prev_hash]; the last digest
-    # is the header hash (unless padding blocks were appended, in which case look the row up)
-    nb = sum(len(SA.pad_message(m)) for m in msgs)
-    row = 64 * (nb - 1) + 63
+    # messages are [inner_lite, inner_lite_hash || inner_rest_hash, that_hash || prev_hash]; filler blocks come
+    # first, so the last row's output chaining value - the AIR's public digest - is the header hash
+    row = t.shape[1] - 1
+    assert bytes(b"".join(struct.pack(">I", int(x)) for x in digest)).hex().startswith("63b87190")
     words = [int(t[SA.NEW_A, row])] + [sum(int(t[base + i, row]) << i for i in range(32)) for base in (SA.A, SA.B, SA.C)]
     words += [int(t[SA.NEW_E, row])] + [sum(int(t[base + i, row]) << i for i in range(32)) for base in (SA.E, SA.F, SA.G)]
     got = b"".join(struct.pack(">I", (int(t[SA.HIN + k, row]) + words[k]) & 0xFFFFFFFF) for k in range(8))
