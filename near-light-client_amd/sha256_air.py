@@ -274,7 +274,6 @@ class Sha256Prover:
 
     def generate_trace(self, blocks, is_first):
         """Returns (device trace tensor [N_COLS, n] int64, digest words uint64[8])."""
-        import ctypes
         import torch
         from ._lib import dll
         blocks = np.ascontiguousarray(blocks, dtype=np.uint32)

@@ -160,7 +160,6 @@ def test_other_configs_match_oracle(nlx, ctx, orc, cfg):
 def test_repeated_proving_is_stable(nlx, orc):
     """200 proofs on one context: identical bytes every time, no growth of the device allocation cache,
     and closing the context first is safe for its children."""
-    import ctypes
     c = nlx.Context(0)
     syn = nlx.SyntheticCircuit(10, seed=4)
     cd = nlx.CircuitData.from_synthetic(c, syn)
