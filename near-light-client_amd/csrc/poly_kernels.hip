@@ -16,10 +16,9 @@ namespace nlx {
 //   p(z) = E(whole array),  E(block of size 2m) = E(first half) + z^(n/(2m)) * E(second half),
 // i.e. a pairwise tree reduction whose level-l multiplier is z^(n / 2^(l+1)).  zpow[k] = z^(2^k).
 //
-// Stage 1: each workgroup folds a chunk of EVAL_CHUNK base-field coefficients to one
+// Stage 1: each workgroup folds a chunk of 2^EVAL_CHUNK_LOG base-field coefficients to one
 // extension element.  Stage 2 folds the per-chunk partials.
 constexpr unsigned EVAL_CHUNK_LOG = 11;
-constexpr unsigned EVAL_CHUNK = 1u << EVAL_CHUNK_LOG;
 
 __device__ __forceinline__ gl::Ext shfl_down_ext(gl::Ext v, int d) {
     gl::Ext r;

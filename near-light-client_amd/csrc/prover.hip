@@ -397,9 +397,9 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
     *proof_len = 0;
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
-    const size_t n = c->n(), L = c->L();
-    const unsigned log_n = d.degree_bits, log_L = log_n + d.rate_bits, cap_h = d.cap_height;
-    const uint32_t nc = d.num_challenges, npp = d.num_partial_products, routed = d.num_routed_wires;
+    const size_t n = c->n();
+    const unsigned log_n = d.degree_bits, cap_h = d.cap_height;
+    const uint32_t nc = d.num_challenges, npp = d.num_partial_products;
     const uint32_t NR = c->n_fri_rounds;
     const size_t capw = (size_t)4 << cap_h;
     int32_t rc = NLX_OK;

@@ -401,7 +401,6 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 break;
             case NLX_GATE_ARITHMETIC: {
                 const uint64_t c0 = CS(p.n_selectors), c1 = CS(p.n_selectors + 1);
-#pragma unroll 4
                 for (uint32_t i = 0; i < gd.param0; i++) {
                     const uint64_t m0 = W(4 * i), m1 = W(4 * i + 1), ad = W(4 * i + 2), o = W(4 * i + 3);
                     acc.emit(gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1))));
@@ -411,10 +410,8 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
             case NLX_GATE_BASE_SUM: {
                 const uint32_t B = gd.param0, nl = gd.param1;
                 uint64_t sum = 0;
-#pragma unroll 8
                 for (uint32_t i = nl; i-- > 0;) sum = gl::add(gl::mul(sum, (uint64_t)B), W(1 + i));
                 acc.emit(gl::sub(sum, W(0)));
-#pragma unroll 8
                 for (uint32_t i = 0; i < nl; i++) {
                     const uint64_t limb = W(1 + i);
                     uint64_t prod = 1;
@@ -428,7 +425,6 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 break;
             case NLX_GATE_ARITHMETIC_EXT: {
                 const uint64_t c0 = CS(p.n_selectors), c1 = CS(p.n_selectors + 1);
-#pragma unroll 2
                 for (uint32_t i = 0; i < gd.param0; i++) {
                     const gl::Ext m0{W(8 * i), W(8 * i + 1)}, m1{W(8 * i + 2), W(8 * i + 3)};
                     const gl::Ext pr = gl::mul(m0, m1);
@@ -439,7 +435,6 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
             }
             case NLX_GATE_MUL_EXT: {
                 const uint64_t c0 = CS(p.n_selectors);
-#pragma unroll 2
                 for (uint32_t i = 0; i < gd.param0; i++) {
                     const gl::Ext m0{W(6 * i), W(6 * i + 1)}, m1{W(6 * i + 2), W(6 * i + 3)};
                     const gl::Ext pr = gl::mul(m0, m1);
@@ -455,7 +450,6 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 const uint32_t start_coeffs = 6, start_accs = start_coeffs + (ext ? 2 * nco : nco);
                 const gl::Ext alpha{W(2), W(3)};
                 gl::Ext a{W(4), W(5)};
-#pragma unroll 4
                 for (uint32_t i = 0; i < nco; i++) {
                     const uint32_t aw = (i == nco - 1) ? 0 : start_accs + 2 * i;  // last accumulator = output wires
                     const gl::Ext nxt{W(aw), W(aw + 1)};
@@ -489,7 +483,6 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 const uint32_t nb = gd.param0;
                 const uint64_t base = W(0);
                 uint64_t prev_iv = 1;
-#pragma unroll 4
                 for (uint32_t i = 0; i < nb; i++) {
                     const uint64_t prev = i ? gl::mul(prev_iv, prev_iv) : 1;
                     const uint64_t bit = W(1 + (nb - 1 - i));
@@ -575,7 +568,6 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 const uint32_t nbits = gd.param0, nch = gd.param1, cb = (nbits + nch - 1) / nch;
                 const uint32_t fc = 4, sc = 4 + nch, eqd = 4 + 2 * nch, ceq = 4 + 3 * nch, iv = 4 + 4 * nch, msb = 4 + 5 * nch;
                 Sum128 fcomb, scomb;  // nch * cb = num_bits <= 62 (checked at circuit build)
-#pragma unroll 8
                 for (uint32_t i = 0; i < nch; i++) {
                     fcomb.add(W(fc + i), cb * i);
                     scomb.add(W(sc + i), cb * i);
@@ -583,7 +575,6 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
                 acc.emit(gl::sub(fcomb.value(), W(0)));
                 acc.emit(gl::sub(scomb.value(), W(1)));
                 uint64_t msd = 0;
-#pragma unroll 4
                 for (uint32_t i = 0; i < nch; i++) {
                     const uint64_t f = W(fc + i), s2 = W(sc + i);
                     uint64_t p1, p2;
@@ -714,7 +705,6 @@ __global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
 #pragma unroll 1
         for (uint32_t q = 0; q < n_chunks; q++) {
             uint64_t nm = 1, dn = 1;
-#pragma unroll 8
             for (uint32_t j = q * p.chunk; j < (q + 1) * p.chunk && j < p.routed; j++) {
                 const uint64_t w = W(j);
                 nm = gl::mul(nm, gl::add(gl::add(w, gl::mul(bx, p.k_is[j])), gamma));
@@ -805,7 +795,6 @@ __global__ __launch_bounds__(256) void k_fri_combine(FriCombineParams p) {
     for (int o = 0; o < 4; o++) {
         const uint64_t* tab = p.tables[o];
         const uint32_t nco = p.n_cols[o];
-#pragma unroll 4
         for (uint32_t c = 0; c < nco; c++, idx++) {
             const uint64_t v = tab[(size_t)c * L + pos];
             const gl::Ext ap{p.alpha_pows[2 * idx], p.alpha_pows[2 * idx + 1]};
@@ -848,8 +837,8 @@ __global__ __launch_bounds__(256) void k_fri_leaves(const uint64_t* __restrict__
     uint64_t s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
-    // absorb 8 words = 4 ext elements per permutation, in slot order m = 0..ARITY-1
-#pragma unroll
+    // absorb 8 words = 4 ext elements per permutation, in slot order m = 0..ARITY-1 (the permutation's own
+    // rolled round loops keep this loop from being unrolled; the compiler decides)
     for (int m0 = 0; m0 < ARITY; m0 += 4) {
 #pragma unroll
         for (int t = 0; t < 4; t++) {
