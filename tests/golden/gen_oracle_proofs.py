@@ -1,0 +1,55 @@
+"""Regression vectors for the ORACLE itself: SHA-256 of the proof bytes it produces for fixed workloads.  They do
+not pin parity with the reference (nothing can); they pin this round's definition of the
+transcript / wire format so that a later change to oracle AND product together cannot drift unnoticed.
+Regenerate deliberately (python tests/golden/gen_oracle_proofs.py) when the workload generator or the proof format
+is changed on purpose, and say so in the commit."""
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def cases():
+    import nlxpkg
+    import oracle_py as orc
+    from test_stark_cpu import make_case
+    nlx = nlxpkg.load()
+    out = {}
+    for name, log_n, kw in (("plonk_basic_2p8", 8, dict(pct_poseidon=25, pct_arithmetic=25, pct_base_sum=5, pct_constant=5)),
+                            ("plonk_all19_2p8", 8, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5,
+                                                        pct_extension=10, pct_misc=20, pct_u32=30)),
+                            ("plonk_2p5_no_fri_round", 5, dict(pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5, pct_constant=5))):
+        syn = nlx.SyntheticCircuit(log_n, seed=4242, **kw)
+        c = orc.Circuit.from_synthetic(syn)
+        proof = c.prove(syn.wires, syn.public_inputs)
+        assert c.verify(proof) == 1
+        c.close()
+        out[name] = {"bytes": len(proof), "sha256": hashlib.sha256(proof).hexdigest()}
+    S, SA = nlx.stark, nlx.sha256_air
+    for name, kind, db, cfg in (("stark_fib_2p8", "fib", 8, {}), ("stark_periodic_2p6", "periodic", 6, {}),
+                                ("stark_deg4_rate4_2p8", "deg4", 8, dict(rate_bits=2))):
+        air, t, pis = make_case(S, kind, db)
+        st = S.Stark(air, db, S.StarkConfig(**cfg))
+        proof = orc.stark_prove(st.desc, t, pis)
+        assert orc.stark_verify(st.desc, proof) == 1
+        out[name] = {"bytes": len(proof), "sha256": hashlib.sha256(proof).hexdigest(), "program_words": int(st.desc.n_words)}
+    blocks, first, digest = SA.blocks_for_messages([b"abc", b"near light client"], 1)
+    t, _ = SA.reference_trace(blocks, first)
+    st = S.Stark(SA.sha256_air(), 7)
+    proof = orc.stark_prove(st.desc, t, digest)
+    assert orc.stark_verify(st.desc, proof) == 1
+    out["stark_sha256_2_blocks"] = {"bytes": len(proof), "sha256": hashlib.sha256(proof).hexdigest(),
+                                    "program_words": int(st.desc.n_words)}
+    return out
+
+
+if __name__ == "__main__":
+    path = os.path.join(ROOT, "tests", "golden", "oracle_proofs.json")
+    with open(path, "w") as f:
+        json.dump(cases(), f, indent=1, sort_keys=True)
+    print("wrote", path)

@@ -76,3 +76,18 @@ def test_fft_roundtrip_and_definition(orc):
             for k in (0, 1, 7, 31):
                 acc = sum(int(a[j]) * pow(w, j * k, P) for j in range(32)) % P
                 assert int(v[k]) == acc
+
+
+def test_oracle_proof_regression_vectors(nlx, orc):
+    """The oracle's own outputs for fixed workloads (tests/golden/oracle_proofs.json, generator beside it): a change
+    of transcript order, wire format, workload generator or AIR assembler shows up here, on the CPU."""
+    import importlib.util
+    import json
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("gen_oracle_proofs", os.path.join(ROOT, "tests", "golden", "gen_oracle_proofs.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_proofs.json")) as f:
+        want = json.load(f)
+    assert gen.cases() == want
