@@ -8,7 +8,7 @@ import numpy as np
 ctx=nlx.Context(0)
 rng=np.random.default_rng(77)
 bad=0; n=0; t0=time.time()
-for it in range(60):
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     log_n=int(rng.integers(5,11))
     pct=[int(x) for x in rng.integers(0,30,7)]
     tot=sum(pct)
