@@ -34,7 +34,9 @@ class StarkDesc(ctypes.Structure):
         "degree_bits", "n_cols", "num_challenges", "rate_bits", "cap_height", "quotient_degree_factor",
         "fri_pow_bits", "fri_num_queries", "fri_arity_bits", "fri_final_poly_bits", "num_public_inputs",
         "n_words")] + [("program", ctypes.POINTER(ctypes.c_uint64)), ("n_periodic", ctypes.c_uint32),
-                       ("period_bits", ctypes.c_uint32), ("periodic", ctypes.POINTER(ctypes.c_uint64))]
+                       ("period_bits", ctypes.c_uint32), ("periodic", ctypes.POINTER(ctypes.c_uint64)),
+                       ("n_rounds", ctypes.c_uint32), ("round_cols", ctypes.c_uint32 * 3),
+                       ("round_challenges", ctypes.c_uint32 * 3), ("reserved", ctypes.c_uint32)]
 
 
 class StarkConfig:
@@ -118,9 +120,16 @@ class _Expr:
 class Air:
     """An AIR over `n_cols` trace columns and `num_public_inputs` public inputs."""
 
-    def __init__(self, n_cols, num_public_inputs=0):
+    def __init__(self, n_cols, num_public_inputs=0, rounds=None):
+        """rounds: None for a classic single-round AIR, or [(columns, verifier_challenges), ...] - round r commits
+        that many columns (column indices run through the rounds in order) and, once its Merkle cap is in the
+        transcript, that many base-field challenges are drawn; `challenge(k)` reads them in the order drawn."""
         self.n_cols = n_cols
         self.num_public_inputs = num_public_inputs
+        self.rounds = rounds
+        if rounds is not None:
+            if not 1 <= len(rounds) <= 3 or sum(c for c, _ in rounds) != n_cols or any(c < 1 for c, _ in rounds):
+                raise ValueError("rounds must split the columns into 1..3 non-empty groups")
         self._emits = []  # (op, expr)
         self._leaf_cache = {}
         self.period_bits = 0
@@ -168,6 +177,11 @@ class Air:
     def public(self, i):
         assert 0 <= i < self.num_public_inputs
         return self._leaf(AIR_PUBLIC, i, 0)
+
+    def challenge(self, k):
+        """The k-th verifier challenge of a multi-round AIR (a constant for the constraint degree)."""
+        assert self.rounds is not None and 0 <= k < sum(n for _, n in self.rounds)
+        return self._leaf(AIR_PUBLIC, self.num_public_inputs + k, 0)
 
     def const(self, v):
         return self._leaf(AIR_CONST, int(v) % P, 0)
@@ -421,6 +435,11 @@ class Stark:
                               cfg.fri_pow_bits, cfg.fri_num_queries, cfg.fri_arity_bits, cfg.fri_final_poly_bits,
                               air.num_public_inputs, len(self.program), self.program.ctypes.data_as(u64p),
                               len(air._periodic), air.period_bits, self.periodic.ctypes.data_as(u64p))
+        if air.rounds is not None:
+            self.desc.n_rounds = len(air.rounds)
+            for r, (c, k) in enumerate(air.rounds):
+                self.desc.round_cols[r] = c
+                self.desc.round_challenges[r] = k
         self.degree_bits = degree_bits
 
     def build(self, ctx):

@@ -274,3 +274,31 @@ def stark_verify(desc, proof):
     d = _stark_sigs()
     buf = np.frombuffer(proof, dtype=np.uint8)
     return int(d.orc_stark_verify(ctypes.addressof(desc), buf.ctypes.data, buf.size))
+
+
+ROUND_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32)
+
+
+def stark_prove_rounds(desc, round_fn, public_inputs):
+    """Multi-round STARK (orc_stark_prove_rounds).  round_fn(round, challenges: list[int]) -> (round_cols, n) uint64
+    array: round r's columns, computed from the challenges drawn after the earlier rounds."""
+    d = _stark_sigs()
+    d.orc_stark_prove_rounds.restype = ctypes.c_size_t
+    d.orc_stark_prove_rounds.argtypes = [ctypes.c_void_p, ROUND_FN, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_size_t]
+    pis = _u64(public_inputs)
+    keep = []
+
+    def cb(_user, rnd, ch_ptr, n_ch):
+        chal = [int(ch_ptr[i]) for i in range(n_ch)]
+        arr = _u64(round_fn(rnd, chal))
+        assert arr.shape == (desc.round_cols[rnd] if desc.n_rounds else desc.n_cols, 1 << desc.degree_bits)
+        keep.append(arr)
+        return arr.ctypes.data
+
+    out = np.empty(d.orc_stark_proof_max_bytes(ctypes.addressof(desc)), dtype=np.uint8)
+    n = d.orc_stark_prove_rounds(ctypes.addressof(desc), ROUND_FN(cb), None, pis.ctypes.data if pis.size else None,
+                                 out.ctypes.data, out.size)
+    if n == 0:
+        raise RuntimeError("orc_stark_prove_rounds failed (bad descriptor, callback or buffer overflow)")
+    return out[:n].tobytes()

@@ -432,17 +432,36 @@ static uint64_t* periodic_coeffs(const orc_stark_desc* d) {
     return c;
 }
 
+/* rounds of commitment: classic starky = one round, no verifier challenges before the alphas */
+static uint32_t n_rounds_of(const orc_stark_desc* d) { return d->n_rounds ? d->n_rounds : 1; }
+static uint32_t round_cols_of(const orc_stark_desc* d, uint32_t r) { return d->n_rounds ? d->round_cols[r] : d->n_cols; }
+static uint32_t total_round_challenges(const orc_stark_desc* d) {
+    uint32_t t = 0;
+    for (uint32_t r = 0; r < d->n_rounds; r++) t += d->round_challenges[r];
+    return t;
+}
+
 static int desc_ok(const orc_stark_desc* d) {
     uint32_t q = d->quotient_degree_factor;
     if (!q || (q & (q - 1)) || q > (1u << d->rate_bits)) return 0;
     if (d->num_challenges < 1 || d->num_challenges > 2 || d->n_cols == 0) return 0;
     if (d->n_periodic > ORC_MAX_PERIODIC) return 0;
     if (d->n_periodic && (d->period_bits > d->degree_bits || d->period_bits > 12 || !d->periodic)) return 0;
+    if (d->n_rounds > 3) return 0;
+    if (d->n_rounds) {
+        uint32_t tot = 0;
+        for (uint32_t r = 0; r < d->n_rounds; r++) {
+            if (!d->round_cols[r] || d->round_challenges[r] > 16) return 0;
+            tot += d->round_cols[r];
+        }
+        if (tot != d->n_cols) return 0;
+    }
+    const uint32_t n_values = d->num_public_inputs + total_round_challenges(d);
     for (uint32_t pc = 0; pc < d->n_words; pc++) {
         uint64_t w = d->program[pc];
         switch (AIR_OP(w)) {
             case ORC_AIR_LOCAL: case ORC_AIR_NEXT: if (AIR_A(w) >= d->n_cols) return 0; break;
-            case ORC_AIR_PUBLIC: if (AIR_A(w) >= d->num_public_inputs) return 0; break;
+            case ORC_AIR_PUBLIC: if (AIR_A(w) >= n_values) return 0; break;
             case ORC_AIR_PERIODIC: if (AIR_A(w) >= d->n_periodic) return 0; break;
             case ORC_AIR_PACK_LOCAL: case ORC_AIR_PACK_NEXT:
                 if (AIR_B(w) < 1 || AIR_B(w) > 32 || AIR_A(w) + AIR_B(w) > d->n_cols) return 0;
@@ -458,32 +477,56 @@ static int desc_ok(const orc_stark_desc* d) {
 size_t orc_stark_proof_max_bytes(const orc_stark_desc* d) {
     const size_t capb = (size_t)32 << d->cap_height;
     const unsigned log_L = d->degree_bits + d->rate_bits;
-    const uint32_t nq = d->num_challenges * d->quotient_degree_factor;
+    const uint32_t nq = d->num_challenges * d->quotient_degree_factor, NRD = n_rounds_of(d);
     orc_fri_params fp = {d->degree_bits, d->rate_bits, d->cap_height, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits};
     uint32_t R = fri_num_rounds(&fp);
-    size_t bytes = 2 * capb + 16 * (size_t)(2 * d->n_cols + nq) + R * capb;
-    size_t per_query = (d->n_cols + nq) * 8 + 2 * (1 + 32 * (size_t)log_L) + R * (((size_t)16 << d->fri_arity_bits) + 1 + 32 * (size_t)log_L);
+    size_t bytes = (NRD + 1) * capb + 16 * (size_t)(2 * d->n_cols + nq) + R * capb;
+    size_t per_query = (d->n_cols + nq) * 8 + (NRD + 1) * (1 + 32 * (size_t)log_L) + R * (((size_t)16 << d->fri_arity_bits) + 1 + 32 * (size_t)log_L);
     bytes += per_query * d->fri_num_queries + ((size_t)16 << d->degree_bits) + 8 + 4 + 8 * (size_t)d->num_public_inputs;
     return bytes + 64;
 }
 
-size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uint64_t* public_inputs,
-                       uint8_t* proof_out, size_t cap_bytes) {
-    if (!desc_ok(d)) return 0;
+/* Multi-round prover: round r's columns are obtained from `fn` AFTER the challenges of rounds < r are known
+ * (starkyx's TraceWriter rounds: lookup / bus accumulators are functions of earlier challenges).  One round with no
+ * challenges is exactly starky::prover::prove. */
+size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* user, const uint64_t* public_inputs,
+                              uint8_t* proof_out, size_t cap_bytes) {
+    if (!desc_ok(d) || !fn) return 0;
     const unsigned log_n = d->degree_bits, log_L = log_n + d->rate_bits, cap_h = d->cap_height;
-    const size_t n = (size_t)1 << log_n, L = (size_t)1 << log_L;
+    const size_t n = (size_t)1 << log_n, L = (size_t)1 << log_L, capw = (size_t)4 << cap_h;
     const uint32_t nc = d->num_challenges, qdf = d->quotient_degree_factor, ncols = d->n_cols, nq = nc * qdf;
+    const uint32_t NRD = n_rounds_of(d), n_rch = total_round_challenges(d);
     const unsigned qdb = gl_log2_strict(qdf);
     wbuf w = {proof_out, 0, cap_bytes, 0};
-    /* trace commitment */
-    uint64_t* t_coeffs = (uint64_t*)malloc(8 * n * ncols);
-    uint64_t* t_leaves = (uint64_t*)malloc(8 * L * ncols);
-    uint64_t* t_dig = (uint64_t*)malloc(8 * orc_merkle_digest_words(L, cap_h));
-    uint64_t t_cap[4 * 64];
-    orc_commit_from_values(trace, ncols, log_n, d->rate_bits, cap_h, t_coeffs, t_leaves, t_dig, t_cap);
     orc_challenger ch;
     orc_ch_init(&ch);
-    observe_cap(&ch, t_cap, cap_h);
+    /* values readable by PUBLIC: public inputs, then the verifier challenges in the order they are drawn */
+    uint64_t* values = (uint64_t*)calloc(d->num_public_inputs + n_rch + 1, 8);
+    memcpy(values, public_inputs, 8 * (size_t)d->num_public_inputs);
+    uint32_t n_drawn = 0;
+    uint64_t *r_coeffs[3] = {0}, *r_leaves[3] = {0}, *r_dig[3] = {0};
+    uint64_t r_cap[3][4 * 64];
+    uint32_t col0[4] = {0};
+    int ok = 1;
+    for (uint32_t r = 0; r < NRD && ok; r++) {
+        const uint32_t rc = round_cols_of(d, r);
+        const uint64_t* tr = fn(user, r, values + d->num_public_inputs, n_drawn);
+        if (!tr) { ok = 0; break; }
+        r_coeffs[r] = (uint64_t*)malloc(8 * n * rc);
+        r_leaves[r] = (uint64_t*)malloc(8 * L * rc);
+        r_dig[r] = (uint64_t*)malloc(8 * orc_merkle_digest_words(L, cap_h));
+        orc_commit_from_values(tr, rc, log_n, d->rate_bits, cap_h, r_coeffs[r], r_leaves[r], r_dig[r], r_cap[r]);
+        w_u64s(&w, r_cap[r], capw);
+        observe_cap(&ch, r_cap[r], cap_h);
+        if (d->n_rounds)
+            for (uint32_t k = 0; k < d->round_challenges[r]; k++) values[d->num_public_inputs + n_drawn++] = orc_ch_challenge(&ch);
+        col0[r + 1] = col0[r] + rc;
+    }
+    if (!ok) {
+        for (uint32_t r = 0; r < NRD; r++) { free(r_coeffs[r]); free(r_leaves[r]); free(r_dig[r]); }
+        free(values);
+        return 0;
+    }
     uint64_t alphas[4];
     for (uint32_t j = 0; j < nc; j++) alphas[j] = orc_ch_challenge(&ch);
     /* compute_quotient_polys on the coset of size n << qdb (LDE index step = 2^(rate_bits - qdb)) */
@@ -495,27 +538,38 @@ size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uin
         const uint64_t g = gl_root_of_unity(log_n), last = gl_inv(g);
         const uint64_t w_s = gl_root_of_unity(log_size);
         const uint64_t n_f = (uint64_t)n % GL_P;
-#pragma omp parallel for schedule(static)
-        for (size_t i = 0; i < size; i++) {
-            uint64_t x = gl_mul(GL_GEN, gl_pow(w_s, i));
-            uint64_t zh = gl_sub(gl_exp_pow2(x, log_n), 1);
-            uint64_t l_first = gl_mul(zh, gl_inv(gl_mul(n_f, gl_sub(x, 1))));
-            uint64_t l_last = gl_mul(zh, gl_inv(gl_mul(n_f, gl_sub(gl_mul(g, x), 1))));
-            size_t li = gl_bitrev(i * step, log_L), ln = gl_bitrev(((i + next_step) % size) * step, log_L);
-            uint64_t accs[4], per[ORC_MAX_PERIODIC];
-            if (d->n_periodic) {
-                /* P_a(x^(n/period)) by Horner */
-                const size_t period = (size_t)1 << d->period_bits;
-                uint64_t y = gl_exp_pow2(x, log_n - d->period_bits);
-                for (uint32_t a = 0; a < d->n_periodic; a++) {
-                    uint64_t acc = 0;
-                    for (size_t m = period; m-- > 0;) acc = gl_add(gl_mul(acc, y), per_coeffs[a * period + m]);
-                    per[a] = acc;
+#pragma omp parallel
+        {
+            uint64_t* loc = (uint64_t*)malloc(16 * (size_t)ncols);
+            uint64_t* nxt = loc + ncols;
+#pragma omp for schedule(static)
+            for (size_t i = 0; i < size; i++) {
+                uint64_t x = gl_mul(GL_GEN, gl_pow(w_s, i));
+                uint64_t zh = gl_sub(gl_exp_pow2(x, log_n), 1);
+                uint64_t l_first = gl_mul(zh, gl_inv(gl_mul(n_f, gl_sub(x, 1))));
+                uint64_t l_last = gl_mul(zh, gl_inv(gl_mul(n_f, gl_sub(gl_mul(g, x), 1))));
+                size_t li = gl_bitrev(i * step, log_L), ln = gl_bitrev(((i + next_step) % size) * step, log_L);
+                for (uint32_t r = 0; r < NRD; r++) {
+                    const uint32_t rc = col0[r + 1] - col0[r];
+                    memcpy(loc + col0[r], r_leaves[r] + li * rc, 8 * (size_t)rc);
+                    memcpy(nxt + col0[r], r_leaves[r] + ln * rc, 8 * (size_t)rc);
                 }
+                uint64_t accs[4], per[ORC_MAX_PERIODIC];
+                if (d->n_periodic) {
+                    /* P_a(x^(n/period)) by Horner */
+                    const size_t period = (size_t)1 << d->period_bits;
+                    uint64_t y = gl_exp_pow2(x, log_n - d->period_bits);
+                    for (uint32_t a = 0; a < d->n_periodic; a++) {
+                        uint64_t acc = 0;
+                        for (size_t m = period; m-- > 0;) acc = gl_add(gl_mul(acc, y), per_coeffs[a * period + m]);
+                        per[a] = acc;
+                    }
+                }
+                air_eval_base(d, loc, nxt, values, per, gl_sub(x, last), l_first, l_last, alphas, accs);
+                uint64_t zh_inv = gl_inv(zh);
+                for (uint32_t j = 0; j < nc; j++) qvals[(size_t)j * size + i] = gl_mul(accs[j], zh_inv);
             }
-            air_eval_base(d, t_leaves + li * ncols, t_leaves + ln * ncols, public_inputs, per, gl_sub(x, last), l_first, l_last, alphas, accs);
-            uint64_t zh_inv = gl_inv(zh);
-            for (uint32_t j = 0; j < nc; j++) qvals[(size_t)j * size + i] = gl_mul(accs[j], zh_inv);
+            free(loc);
         }
     }
     uint64_t* q_coeffs = (uint64_t*)malloc(8 * n * nq);
@@ -529,21 +583,23 @@ size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uin
     uint64_t* q_dig = (uint64_t*)malloc(8 * orc_merkle_digest_words(L, cap_h));
     uint64_t q_cap[4 * 64];
     orc_commit_from_coeffs(q_coeffs, nq, log_n, d->rate_bits, cap_h, q_leaves, q_dig, q_cap);
+    w_u64s(&w, q_cap, capw);
     observe_cap(&ch, q_cap, cap_h);
     gl2 zeta = orc_ch_ext_challenge(&ch);
     gl2 g_zeta = gl2_scale(zeta, gl_root_of_unity(log_n));
-    /* StarkOpeningSet */
+    /* StarkOpeningSet: local and next values of every committed column (round order), quotient at zeta */
     gl2* o_local = (gl2*)malloc(sizeof(gl2) * (2 * ncols + nq));
     gl2* o_next = o_local + ncols;
     gl2* o_q = o_next + ncols;
+    for (uint32_t r = 0; r < NRD; r++) {
+        const uint32_t rc = col0[r + 1] - col0[r];
 #pragma omp parallel for schedule(dynamic)
-    for (uint32_t c = 0; c < ncols; c++) {
-        o_local[c] = eval_base_poly_ext(t_coeffs + (size_t)c * n, n, zeta);
-        o_next[c] = eval_base_poly_ext(t_coeffs + (size_t)c * n, n, g_zeta);
+        for (uint32_t c = 0; c < rc; c++) {
+            o_local[col0[r] + c] = eval_base_poly_ext(r_coeffs[r] + (size_t)c * n, n, zeta);
+            o_next[col0[r] + c] = eval_base_poly_ext(r_coeffs[r] + (size_t)c * n, n, g_zeta);
+        }
     }
     for (uint32_t c = 0; c < nq; c++) o_q[c] = eval_base_poly_ext(q_coeffs + (size_t)c * n, n, zeta);
-    w_u64s(&w, t_cap, (size_t)4 << cap_h);
-    w_u64s(&w, q_cap, (size_t)4 << cap_h);
     w_u64s(&w, (uint64_t*)o_local, 2 * ncols);
     w_u64s(&w, (uint64_t*)o_next, 2 * ncols);
     w_u64s(&w, (uint64_t*)o_q, 2 * nq);
@@ -551,19 +607,40 @@ size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uin
     orc_ch_observe_many(&ch, (uint64_t*)o_local, 2 * ncols);
     orc_ch_observe_many(&ch, (uint64_t*)o_q, 2 * nq);
     orc_ch_observe_many(&ch, (uint64_t*)o_next, 2 * ncols);
-    /* fri_instance: batch 0 at zeta = trace ++ quotient, batch 1 at g*zeta = trace */
-    orc_fri_oracle oracles[2] = {{t_coeffs, t_leaves, t_dig, t_cap, ncols}, {q_coeffs, q_leaves, q_dig, q_cap, nq}};
+    /* fri_instance: batch 0 at zeta = every round's columns ++ quotient, batch 1 at g*zeta = every round's columns */
+    orc_fri_oracle oracles[4];
+    for (uint32_t r = 0; r < NRD; r++) {
+        orc_fri_oracle o = {r_coeffs[r], r_leaves[r], r_dig[r], r_cap[r], col0[r + 1] - col0[r]};
+        oracles[r] = o;
+    }
+    {
+        orc_fri_oracle o = {q_coeffs, q_leaves, q_dig, q_cap, nq};
+        oracles[NRD] = o;
+    }
     uint32_t* idx_o = (uint32_t*)malloc(4 * 2 * (ncols + nq));
     uint32_t* idx_p = idx_o + ncols + nq;
-    for (uint32_t c = 0; c < ncols; c++) { idx_o[c] = 0; idx_p[c] = c; }
-    for (uint32_t c = 0; c < nq; c++) { idx_o[ncols + c] = 1; idx_p[ncols + c] = c; }
+    for (uint32_t r = 0; r < NRD; r++)
+        for (uint32_t c = col0[r]; c < col0[r + 1]; c++) { idx_o[c] = r; idx_p[c] = c - col0[r]; }
+    for (uint32_t c = 0; c < nq; c++) { idx_o[ncols + c] = NRD; idx_p[ncols + c] = c; }
     orc_fri_batch batches[2] = {{zeta, ncols + nq, idx_o, idx_p}, {g_zeta, ncols, idx_o, idx_p}};
     orc_fri_params fp = {d->degree_bits, d->rate_bits, cap_h, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits};
-    fri_prove(&fp, oracles, 2, batches, 2, &ch, &w);
+    fri_prove(&fp, oracles, NRD + 1, batches, 2, &ch, &w);
     w_u32(&w, d->num_public_inputs);
     w_u64s(&w, public_inputs, d->num_public_inputs);
-    free(idx_o); free(o_local); free(t_coeffs); free(t_leaves); free(t_dig); free(q_coeffs); free(q_leaves); free(q_dig);
+    free(idx_o); free(o_local); free(q_coeffs); free(q_leaves); free(q_dig); free(values);
+    for (uint32_t r = 0; r < NRD; r++) { free(r_coeffs[r]); free(r_leaves[r]); free(r_dig[r]); }
     return w.overflow ? 0 : w.len;
+}
+
+static const uint64_t* single_round_fn(void* user, uint32_t round, const uint64_t* challenges, uint32_t n_challenges) {
+    (void)challenges; (void)n_challenges;
+    return round == 0 ? (const uint64_t*)user : NULL;
+}
+
+size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uint64_t* public_inputs,
+                       uint8_t* proof_out, size_t cap_bytes) {
+    if (d->n_rounds > 1) return 0;
+    return orc_stark_prove_rounds(d, single_round_fn, (void*)trace, public_inputs, proof_out, cap_bytes);
 }
 
 int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) {
@@ -571,16 +648,17 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
     const unsigned log_n = d->degree_bits, cap_h = d->cap_height;
     const size_t n = (size_t)1 << log_n, capw = (size_t)4 << cap_h;
     const uint32_t nc = d->num_challenges, qdf = d->quotient_degree_factor, ncols = d->n_cols, nq = nc * qdf;
+    const uint32_t NRD = n_rounds_of(d), n_rch = total_round_challenges(d);
     rbuf r = {proof, len, 0, 0};
     int rc = 1;
-    uint64_t* caps = (uint64_t*)malloc(8 * 2 * capw);
-    r_u64s(&r, caps, 2 * capw);
+    uint64_t* caps = (uint64_t*)malloc(8 * (NRD + 1) * capw);
+    r_u64s(&r, caps, (NRD + 1) * capw);
     gl2* o_local = (gl2*)malloc(sizeof(gl2) * (2 * ncols + nq));
     gl2* o_next = o_local + ncols;
     gl2* o_q = o_next + ncols;
     r_u64s(&r, (uint64_t*)o_local, 2 * (2 * ncols + nq));
-    /* public inputs are at the very end */
-    uint64_t* pis = (uint64_t*)malloc(8 * (d->num_public_inputs + 1));
+    /* public inputs are at the very end; the verifier challenges follow them in the values array */
+    uint64_t* pis = (uint64_t*)calloc(d->num_public_inputs + n_rch + 1, 8);
     if (len < 4 + 8 * (size_t)d->num_public_inputs) { rc = -1; goto done; }
     {
         size_t tail = len - 4 - 8 * (size_t)d->num_public_inputs;
@@ -595,10 +673,15 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
     {
         orc_challenger ch;
         orc_ch_init(&ch);
-        orc_ch_observe_many(&ch, caps, capw);
+        uint32_t n_drawn = 0;
+        for (uint32_t rd = 0; rd < NRD; rd++) {
+            orc_ch_observe_many(&ch, caps + rd * capw, capw);
+            if (d->n_rounds)
+                for (uint32_t k = 0; k < d->round_challenges[rd]; k++) pis[d->num_public_inputs + n_drawn++] = orc_ch_challenge(&ch);
+        }
         uint64_t alphas[4];
         for (uint32_t j = 0; j < nc; j++) alphas[j] = orc_ch_challenge(&ch);
-        orc_ch_observe_many(&ch, caps + capw, capw);
+        orc_ch_observe_many(&ch, caps + NRD * capw, capw);
         gl2 zeta = orc_ch_ext_challenge(&ch);
         orc_ch_observe_many(&ch, (uint64_t*)o_local, 2 * ncols);
         orc_ch_observe_many(&ch, (uint64_t*)o_q, 2 * nq);
@@ -631,19 +714,25 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
         }
         if (rc != 1) goto done;
         gl2 g_zeta = gl2_scale(zeta, g);
+        uint32_t col0[4] = {0};
+        for (uint32_t rd = 0; rd < NRD; rd++) col0[rd + 1] = col0[rd] + round_cols_of(d, rd);
         uint32_t* idx_o = (uint32_t*)malloc(4 * 2 * (ncols + nq));
         uint32_t* idx_p = idx_o + ncols + nq;
-        for (uint32_t c = 0; c < ncols; c++) { idx_o[c] = 0; idx_p[c] = c; }
-        for (uint32_t c = 0; c < nq; c++) { idx_o[ncols + c] = 1; idx_p[ncols + c] = c; }
+        for (uint32_t rd = 0; rd < NRD; rd++)
+            for (uint32_t c = col0[rd]; c < col0[rd + 1]; c++) { idx_o[c] = rd; idx_p[c] = c - col0[rd]; }
+        for (uint32_t c = 0; c < nq; c++) { idx_o[ncols + c] = NRD; idx_p[ncols + c] = c; }
         orc_fri_batch batches[2] = {{zeta, ncols + nq, idx_o, idx_p}, {g_zeta, ncols, idx_o, idx_p}};
         gl2* open0 = (gl2*)malloc(sizeof(gl2) * (ncols + nq));
         memcpy(open0, o_local, sizeof(gl2) * ncols);
         memcpy(open0 + ncols, o_q, sizeof(gl2) * nq);
         const gl2* opened[2] = {open0, o_next};
-        const uint64_t* cap_ptrs[2] = {caps, caps + capw};
-        uint32_t n_cols[2] = {ncols, nq};
+        const uint64_t* cap_ptrs[4];
+        uint32_t n_cols[4];
+        for (uint32_t rd = 0; rd < NRD; rd++) { cap_ptrs[rd] = caps + rd * capw; n_cols[rd] = col0[rd + 1] - col0[rd]; }
+        cap_ptrs[NRD] = caps + NRD * capw;
+        n_cols[NRD] = nq;
         orc_fri_params fp = {d->degree_bits, d->rate_bits, cap_h, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits};
-        rc = fri_verify(&fp, cap_ptrs, n_cols, 2, batches, 2, opened, &ch, &r);
+        rc = fri_verify(&fp, cap_ptrs, n_cols, NRD + 1, batches, 2, opened, &ch, &r);
         if (rc == 1 && r.pos != r.len) rc = -11;
         free(open0);
         free(idx_o);

@@ -82,8 +82,19 @@ typedef struct {
     uint32_t n_periodic;
     uint32_t period_bits;
     const uint64_t* periodic;
+    /* rounds of commitment (starkyx's TraceWriter rounds).  0 = classic single-round starky.  Round r commits
+     * round_cols[r] columns (sum = n_cols, program column indices run through the rounds in order); after its cap is
+     * observed the verifier draws round_challenges[r] base-field challenges, which the program reads as PUBLIC
+     * indices num_public_inputs + k in the order drawn. */
+    uint32_t n_rounds;
+    uint32_t round_cols[3];
+    uint32_t round_challenges[3];
 } orc_stark_desc;
 
+/* returns round `round`'s columns (round_cols[round] x n, column-major) given the challenges drawn so far */
+typedef const uint64_t* (*orc_round_fn)(void* user, uint32_t round, const uint64_t* challenges, uint32_t n_challenges);
+size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* user, const uint64_t* public_inputs,
+                              uint8_t* proof_out, size_t cap_bytes);
 size_t orc_stark_proof_max_bytes(const orc_stark_desc* d);
 /* trace: n_cols x n column-major.  Returns bytes written (0 on overflow). */
 size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uint64_t* public_inputs,

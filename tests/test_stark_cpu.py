@@ -267,3 +267,72 @@ def test_air_ternary_forms(nlx):
     x3 = (s2 + lo[2] - 2 * s2 * lo[2]) % P
     assert got[0] == (10, (x3 - lo[3]) % P)
     assert got[1] == (10, (lo[2] + lo[0] * (lo[1] - lo[2]) + 5 * (lo[0] * lo[1] + lo[2] * s2)) % P)
+
+
+def logup_air(S):
+    """Two-round AIR: a log-derivative lookup of column v into table column t with multiplicities m.
+    Round 0 commits (v, t, m) and draws one challenge alpha; round 1 commits h1 = 1/(alpha + v),
+    h2 = m/(alpha + t) and the running sum z.  All-rows constraints (the sum telescopes to zero around the cycle)."""
+    air = S.Air(6, 0, rounds=[(3, 1), (3, 0)])
+    v, t, m, h1, h2, z = (air.local(i) for i in range(6))
+    al = air.challenge(0)
+    air.constraint(h1 * (al + v) - 1)
+    air.constraint(h2 * (al + t) - m)
+    air.constraint(air.next(5) - z - h1 + h2)
+    air.constraint_first_row(z)
+    return air
+
+
+def logup_rounds(v, t, m):
+    def fn(rnd, chal):
+        n = len(v)
+        if rnd == 0:
+            return np.array([v, t, m], dtype=np.uint64)
+        al = chal[0]
+        h1 = [pow((al + int(x)) % P, P - 2, P) for x in v]
+        h2 = [int(mm) * pow((al + int(x)) % P, P - 2, P) % P for x, mm in zip(t, m)]
+        z, acc = [], 0
+        for i in range(n):
+            z.append(acc)
+            acc = (acc + h1[i] - h2[i]) % P
+        return np.array([h1, h2, z], dtype=np.uint64)
+    return fn
+
+
+def logup_case(db=7, bad=False, seed=3):
+    rng = np.random.default_rng(seed)
+    n = 1 << db
+    t = np.arange(n, dtype=np.uint64) % np.uint64(64)           # table: 0..63 repeated
+    v = rng.integers(0, 64, n, dtype=np.uint64)
+    if bad:
+        v[5] = 64                                              # not in the table
+    m = np.zeros(n, dtype=np.uint64)
+    for x in v:
+        if int(x) < 64:
+            m[int(x)] += 1                                      # multiplicities on the first copy of each table value
+    return v, t, m
+
+
+def test_multi_round_logup_oracle(nlx, orc):
+    """Two commitment rounds with a verifier challenge in between (starkyx's round structure): the oracle's
+    verifier accepts a correct lookup and rejects a value outside the table, a wrong multiplicity, tampering."""
+    S = nlx.stark
+    air = logup_air(S)
+    assert air.constraint_degree == 2
+    st = S.Stark(air, 7, S.StarkConfig(fri_num_queries=20))
+    assert st.desc.n_rounds == 2 and list(st.desc.round_cols)[:2] == [3, 3] and st.desc.round_challenges[0] == 1
+    v, t, m = logup_case()
+    proof = orc.stark_prove_rounds(st.desc, logup_rounds(v, t, m), [])
+    assert orc.stark_verify(st.desc, proof) == 1
+    for off in (10, 700, 1300, len(proof) // 2, len(proof) - 40):
+        bad = bytearray(proof)
+        bad[off] ^= 1
+        assert orc.stark_verify(st.desc, bytes(bad)) != 1, off
+    vb, tb, mb = logup_case(bad=True)
+    assert orc.stark_verify(st.desc, orc.stark_prove_rounds(st.desc, logup_rounds(vb, tb, mb), [])) != 1
+    m2 = m.copy()
+    m2[3] += 1
+    assert orc.stark_verify(st.desc, orc.stark_prove_rounds(st.desc, logup_rounds(v, t, m2), [])) != 1
+    # a classic single-round prove call refuses a multi-round descriptor
+    with pytest.raises(RuntimeError):
+        orc.stark_prove(st.desc, np.zeros((6, 128), dtype=np.uint64), [])
