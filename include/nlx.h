@@ -255,13 +255,13 @@ typedef struct {
     uint32_t num_queries;      /* num_query_rounds */
 } nlx_fri_params;
 /* a11 PolynomialBatch::prove_openings / fri_proof for an instance of the shape every caller on this path has:
- * batch 0 = every column of every oracle (in order) opened at zeta, batch 1 = the first n_next columns of
- * oracles[next_oracle] opened at g * zeta (plonky2: oracles = constants_sigmas, wires, zs_partial_products,
- * quotient; next_oracle = 2, n_next = num_challenges).  openings_* are the extension values (2 words each)
+ * batch 0 = every column of every oracle (in order) opened at zeta, batch 1 = the first n_next[o] columns of
+ * every oracle o (in order) opened at g * zeta (plonky2: oracles = constants_sigmas, wires, zs_partial_products,
+ * quotient and n_next = {0, 0, num_challenges, 0}; a STARK: n_next = all columns of every trace oracle).  openings_* are the extension values (2 words each)
  * already observed by the caller's challenger; the challenger is advanced exactly as upstream's
  * (fri alpha, commit-phase caps and betas, final polynomial, proof of work, query indices).  Writes the FriProof
  * bytes: commit_phase_merkle_caps, query_round_proofs, final_poly, pow_witness. */
-int32_t nlx_fri_prove(nlx_ctx* ctx, const nlx_commit* const* oracles, uint32_t n_oracles, uint32_t next_oracle, uint32_t n_next,
+int32_t nlx_fri_prove(nlx_ctx* ctx, const nlx_commit* const* oracles, uint32_t n_oracles, const uint32_t* n_next,
                       const uint64_t zeta[2], const uint64_t* openings_zeta, const uint64_t* openings_next,
                       const nlx_fri_params* params, nlx_challenger* challenger, uint8_t* proof_out, size_t proof_cap,
                       size_t* proof_len);
@@ -369,6 +369,15 @@ typedef struct {
     uint32_t n_periodic;              /* <= NLX_AIR_MAX_PERIODIC */
     uint32_t period_bits;
     const uint64_t* periodic;         /* host, n_periodic x period */
+    /* Rounds of commitment (starkyx's TraceWriter rounds: lookup / bus accumulators are functions of challenges
+     * drawn after the main trace is committed).  0 = classic single-round starky.  Round r commits round_cols[r]
+     * columns (sum = n_cols; program column indices run through the rounds in order); once its Merkle cap is in the
+     * transcript the verifier draws round_challenges[r] base-field challenges, which the program reads as
+     * NLX_AIR_PUBLIC indices num_public_inputs + k in the order drawn.  The alphas follow the last round. */
+    uint32_t n_rounds;                /* 0..3 */
+    uint32_t round_cols[3];
+    uint32_t round_challenges[3];
+    uint32_t reserved;
 } nlx_stark_desc;
 typedef struct nlx_stark nlx_stark;
 
@@ -380,6 +389,13 @@ size_t nlx_stark_proof_max_bytes(const nlx_stark* s);
  * trace: n_cols x n column-major (host or device), every value canonical. */
 int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* public_inputs, uint8_t* proof_out,
                         size_t proof_cap, size_t* proof_len);
+/* Multi-round proving: round_fn(user, r, challenges, n) returns round r's columns (round_cols[r] x n, column-major,
+ * host or device pointer, valid until the next callback or the end of the call) given the challenges drawn after the
+ * earlier rounds.  Proof bytes: one cap per round, the quotient cap, local / next values of every column in round
+ * order, quotient values, FriProof (one oracle per round + the quotient oracle), public inputs. */
+typedef const uint64_t* (*nlx_round_fn)(void* user, uint32_t round, const uint64_t* challenges, uint32_t n_challenges);
+int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, const uint64_t* public_inputs,
+                               uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
 int32_t nlx_stark_stage_times(const nlx_stark* s, uint32_t* n_stages, const char** names_out, float* ms_out);
 /* As nlx_batch_prove, for STARK jobs: workers = provers built from the SAME description on DISTINCT contexts;
  * a job's `wires` field is its trace (n_cols x n, host or device). */

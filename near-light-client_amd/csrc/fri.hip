@@ -58,13 +58,15 @@ int32_t fri_prove(nlx_ctx* ctx, const FriProveArgs& a, Challenger& ch, Writer& w
             ap = gl::mul(ap, al);
         }
         ap = gl::Ext{1, 0};
-        for (uint32_t i = 0; i < a.nz; i++) {
+        uint32_t nz_total = 0;
+        for (uint32_t o = 0; o < NO; o++) nz_total += a.nz[o];
+        for (uint32_t i = 0; i < nz_total; i++) {
             c1 = gl::add(c1, gl::mul(ap, gl::Ext{a.open1[2 * (size_t)i], a.open1[2 * (size_t)i + 1]}));
             ap = gl::mul(ap, al);
         }
         FriCombineParams fp{};
         for (uint32_t o = 0; o < NO; o++) { fp.tables[o] = oracles[o]->lde; fp.n_cols[o] = oracles[o]->n_cols; }
-        fp.next_table = a.next_table;
+        for (uint32_t o = 0, off = 0; o < NO; o++) { fp.nz[o] = a.nz[o]; fp.nz_off[o] = off; off += a.nz[o]; }
         fp.alpha_pows = d_fri_alpha_pows;
         fp.coset_base = a.d_coset_base;
         fp.w_n_table = ctx->tables.fwd[log_n];
@@ -72,7 +74,7 @@ int32_t fri_prove(nlx_ctx* ctx, const FriProveArgs& a, Challenger& ch, Writer& w
         fp.c0[0] = c0.a; fp.c0[1] = c0.b; fp.c1[0] = c1.a; fp.c1[1] = c1.b;
         fp.alpha_nz[0] = ap.a; fp.alpha_nz[1] = ap.b;  // alpha^nz
         fp.out = d_fri_a;
-        fp.log_n = log_n; fp.rate_bits = a.rate_bits; fp.nz = a.nz;
+        fp.log_n = log_n; fp.rate_bits = a.rate_bits;
         ctx->begin_kernel("fri_combine", 8.0 * L * n_open + 16.0 * L);
         launch_fri_combine(st, fp);
         ctx->end_kernel();

@@ -2,7 +2,7 @@
 // plonky2::fri::oracle::PolynomialBatch::prove_openings + fri::prover::fri_proof, value-domain version
 // (DESIGN.md §FRI).  The FRI instance has the shape both callers need:
 //   batch 0: every column of every oracle, in oracle order, opened at zeta
-//   batch 1: the first `nz` columns of oracle `next_table`, opened at g * zeta
+//   batch 1: the first nz[o] columns of every oracle o (in oracle order), opened at g * zeta
 #pragma once
 #include <functional>
 #include <vector>
@@ -14,7 +14,7 @@ namespace nlx {
 struct FriProveArgs {
     const nlx_commit* oracles[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t n_oracles = 0;
-    uint32_t next_table = 0, nz = 0;
+    uint32_t nz[4] = {0, 0, 0, 0};  // columns of each oracle that are also opened at g * zeta
     uint64_t zeta[2], gzeta[2];
     const uint64_t* open0 = nullptr;  // host: ext openings of batch 0 (2 words each), oracle order
     const uint64_t* open1 = nullptr;  // host: ext openings of batch 1

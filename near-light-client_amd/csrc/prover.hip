@@ -521,8 +521,7 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
             FriProveArgs fa;
             for (int o = 0; o < 4; o++) fa.oracles[o] = oracles[o];
             fa.n_oracles = 4;
-            fa.next_table = 2;  // plonk_zs_next: the first nc columns of the Zs / partial-products oracle
-            fa.nz = nc;
+            fa.nz[2] = nc;  // plonk_zs_next: the first nc columns of the Zs / partial-products oracle
             for (int i = 0; i < 2; i++) { fa.zeta[i] = zeta[i]; fa.gzeta[i] = gzeta[i]; }
             fa.open0 = open.data();
             fa.open1 = open.data() + 2 * (size_t)n_open;
@@ -630,22 +629,27 @@ int32_t nlx_quotient_eval(nlx_circuit* c, const nlx_commit* wires, const nlx_com
     return rc;
 }
 
-int32_t nlx_fri_prove(nlx_ctx* ctx, const nlx_commit* const* oracles, uint32_t n_oracles, uint32_t next_oracle, uint32_t n_next,
+int32_t nlx_fri_prove(nlx_ctx* ctx, const nlx_commit* const* oracles, uint32_t n_oracles, const uint32_t* n_next,
                       const uint64_t zeta[2], const uint64_t* openings_zeta, const uint64_t* openings_next,
                       const nlx_fri_params* params, nlx_challenger* challenger, uint8_t* proof_out, size_t proof_cap,
                       size_t* proof_len) {
     if (!ctx) return NLX_E_INVAL;
-    if (!oracles || !zeta || !openings_zeta || (!openings_next && n_next) || !params || !challenger || !proof_out || !proof_len)
+    if (!oracles || !n_next || !zeta || !openings_zeta || !params || !challenger || !proof_out || !proof_len)
         return ctx->fail(NLX_E_INVAL, "NULL argument");
     *proof_len = 0;
-    if (n_oracles < 1 || n_oracles > 4 || next_oracle >= n_oracles) return ctx->fail(NLX_E_RANGE, "1..4 oracles, next_oracle among them");
+    if (n_oracles < 1 || n_oracles > 4) return ctx->fail(NLX_E_RANGE, "1..4 oracles");
     for (uint32_t o = 0; o < n_oracles; o++) {
         if (!oracles[o] || oracles[o]->ctx != ctx) return ctx->fail(NLX_E_INVAL, "oracle %u: NULL or from another context", o);
         if (oracles[o]->log_n != oracles[0]->log_n || oracles[o]->rate_bits != oracles[0]->rate_bits ||
             oracles[o]->cap_height != oracles[0]->cap_height)
             return ctx->fail(NLX_E_INVAL, "oracles must share degree, rate and cap height");
     }
-    if (n_next > oracles[next_oracle]->n_cols) return ctx->fail(NLX_E_RANGE, "n_next exceeds the oracle's columns");
+    uint32_t n_next_total = 0;
+    for (uint32_t o = 0; o < n_oracles; o++) {
+        if (n_next[o] > oracles[o]->n_cols) return ctx->fail(NLX_E_RANGE, "n_next[%u] exceeds the oracle's columns", o);
+        n_next_total += n_next[o];
+    }
+    if (n_next_total && !openings_next) return ctx->fail(NLX_E_INVAL, "NULL openings_next");
     if (params->arity_bits < 2 || params->arity_bits > 4 || params->num_queries == 0 || params->num_queries > 128 ||
         params->pow_bits > 40 || oracles[0]->log_n < params->arity_bits)
         return ctx->fail(NLX_E_RANGE, "FRI parameters out of range");
@@ -670,8 +674,7 @@ int32_t nlx_fri_prove(nlx_ctx* ctx, const nlx_commit* const* oracles, uint32_t n
     FriProveArgs fa;
     for (uint32_t o = 0; o < n_oracles; o++) fa.oracles[o] = oracles[o];
     fa.n_oracles = n_oracles;
-    fa.next_table = next_oracle;
-    fa.nz = n_next;
+    for (uint32_t o = 0; o < n_oracles; o++) fa.nz[o] = n_next[o];
     const uint64_t g = gl::root_of_unity(log_n);
     for (int i = 0; i < 2; i++) { fa.zeta[i] = zeta[i]; fa.gzeta[i] = gl::mul(zeta[i], g); }
     fa.open0 = openings_zeta;

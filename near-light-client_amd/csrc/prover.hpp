@@ -54,8 +54,9 @@ struct FriCombineParams {
     const uint64_t* w_n_table;
     uint64_t zeta[2], gzeta[2], c0[2], c1[2], alpha_nz[2];
     uint64_t* out;              // L ext values
-    uint32_t log_n, rate_bits, nz;
-    uint32_t next_table;        // the g*zeta batch = first nz columns of tables[next_table]
+    uint32_t log_n, rate_bits;
+    uint32_t nz[4];             // the g*zeta batch = first nz[o] columns of every table o, in table order
+    uint32_t nz_off[4];         // index of table o's first g*zeta polynomial in that batch
 };
 void launch_fri_combine(hipStream_t st, const FriCombineParams& p);
 void launch_fri_leaves(hipStream_t st, const uint64_t* d_values, unsigned log_n, unsigned rate_bits,

@@ -782,7 +782,7 @@ void launch_quotient_chunks(hipStream_t st, const uint64_t* d_in, uint64_t* d_ou
 // =====================================================================================
 // F(x) = alpha^nz * (sum_i alpha^i p_i(x) - C0) / (x - zeta) + (sum_{i<nz} alpha^i z_i(x) - C1) / (x - g zeta)
 // over every LDE point; p_i runs over the (up to four) oracles in FRI order, z_i over the first nz columns
-// of oracle `next_table` (plonk_zs_next for plonky2, the whole trace for a STARK).
+// of every oracle o with nz[o] > 0 (plonk_zs_next for plonky2, every committed trace column for a STARK).
 __global__ __launch_bounds__(256) void k_fri_combine(FriCombineParams p) {
     const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned log_L = p.log_n + p.rate_bits;
@@ -799,8 +799,9 @@ __global__ __launch_bounds__(256) void k_fri_combine(FriCombineParams p) {
             const uint64_t v = tab[(size_t)c * L + pos];
             const gl::Ext ap{p.alpha_pows[2 * idx], p.alpha_pows[2 * idx + 1]};
             s0 = gl::add(s0, gl::mul(ap, v));
-            if (o == (int)p.next_table && c < p.nz) {
-                const gl::Ext az{p.alpha_pows[2 * c], p.alpha_pows[2 * c + 1]};
+            if (c < p.nz[o]) {
+                const uint32_t zi = p.nz_off[o] + c;
+                const gl::Ext az{p.alpha_pows[2 * zi], p.alpha_pows[2 * zi + 1]};
                 s1 = gl::add(s1, gl::mul(az, v));
             }
         }

@@ -28,7 +28,7 @@ using namespace nlx;
 namespace nlx {
 
 struct AirParams {
-    const uint64_t* trace;      // LDE table [col][r][k], L = n << rate_bits
+    const uint64_t* const* cols; // device: cols[c] = LDE column c ([r][k], L = n << rate_bits) of whichever committed oracle holds it
     const uint64_t* program;    // device, n_words (constants canonical)
     const uint64_t* pis;        // device
     const uint64_t* coset_base; // device: g * w_{n q}^r', r' < q = 2^qdb
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
     const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned log_Q = p.log_n + p.qdb;
     if (pos >> log_Q) return;  // n >= blockDim.x is checked on the host: whole blocks are in or out
-    const size_t n = (size_t)1 << p.log_n, L = n << p.rate_bits;
+    const size_t n = (size_t)1 << p.log_n;
     const uint32_t rq = (uint32_t)(pos >> p.log_n), k = (uint32_t)(pos & (n - 1));
     const uint32_t r = rq << (p.rate_bits - p.qdb);  // LDE coset of quotient coset rq
     const size_t row = ((size_t)r << p.log_n) + k, row_next = ((size_t)r << p.log_n) + ((k + 1) & (n - 1));
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
         const uint32_t sh = (uint32_t)(w >> 56) & 0x3F;
         uint64_t c;
         switch (op) {
-            case NLX_AIR_LOCAL: my[dst * bd] = p.trace[(size_t)a * L + row]; continue;
-            case NLX_AIR_NEXT: my[dst * bd] = p.trace[(size_t)a * L + row_next]; continue;
+            case NLX_AIR_LOCAL: my[dst * bd] = p.cols[a][row]; continue;
+            case NLX_AIR_NEXT: my[dst * bd] = p.cols[a][row_next]; continue;
             case NLX_AIR_PUBLIC: my[dst * bd] = p.pis[a]; continue;
             case NLX_AIR_PERIODIC:
                 my[dst * bd] = p.periodic[((((size_t)a << p.qdb) + rq) << p.period_bits) + (k & ((1u << p.period_bits) - 1))];
@@ -115,21 +115,20 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
             case NLX_AIR_PACK_LOCAL:
             case NLX_AIR_PACK_NEXT: {
                 // b loads in flight at once (wave-uniform trip count), then shift-accumulate
-                const uint64_t* src = p.trace + (size_t)a * L + (op == NLX_AIR_PACK_LOCAL ? row : row_next);
+                const size_t rr = op == NLX_AIR_PACK_LOCAL ? row : row_next;
                 uint64_t acc = 0;
 #pragma unroll 8
-                for (uint32_t i = 0; i < b; i++) acc = gl::add(acc, mul_pow2(src[(size_t)i * L], i));
+                for (uint32_t i = 0; i < b; i++) acc = gl::add(acc, mul_pow2(p.cols[a + i][rr], i));
                 my[dst * bd] = acc;
                 continue;
             }
             case NLX_AIR_EMIT_BOOL: {
                 // x (x - 1) for b consecutive columns: eight loads in flight, constraints emitted in column order
-                const uint64_t* src = p.trace + (size_t)a * L + row;
                 const uint32_t cnt = b ? b : 1;
                 for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
                     uint64_t v[8];
 #pragma unroll
-                    for (int i = 0; i < 8; i++) v[i] = i0 + i < cnt ? src[(size_t)(i0 + i) * L] : 0;
+                    for (int i = 0; i < 8; i++) v[i] = i0 + i < cnt ? p.cols[a + i0 + i][row] : 0;
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         if (i0 + i < cnt) {
@@ -153,8 +152,8 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
                         const uint64_t w2 = p.program[pc + 1 + i];
                         const uint32_t op2 = (uint32_t)(w2 & 0xFF), a2 = (uint32_t)((w2 >> 24) & 0xFFFF);
                         d8[i] = (uint32_t)((w2 >> 8) & 0xFFFF);
-                        const uint64_t* src = op2 == NLX_AIR_LOCAL ? p.trace + (size_t)a2 * L + row
-                                            : op2 == NLX_AIR_NEXT ? p.trace + (size_t)a2 * L + row_next
+                        const uint64_t* src = op2 == NLX_AIR_LOCAL ? p.cols[a2] + row
+                                            : op2 == NLX_AIR_NEXT ? p.cols[a2] + row_next
                                             : op2 == NLX_AIR_PUBLIC ? p.pis + a2
                                             : p.periodic + ((((size_t)a2 << p.qdb) + rq) << p.period_bits) + (k & ((1u << p.period_bits) - 1));
                         v[i] = *src;
@@ -187,6 +186,7 @@ struct nlx_stark {
     nlx_stark_desc d{};
     std::vector<uint64_t> program;  // canonicalised copy
     uint32_t qdb = 0, nq = 0, n_regs = 0, n_fri_rounds = 0;
+    uint32_t n_rounds = 1, round_cols[3] = {0, 0, 0}, round_challenges[3] = {0, 0, 0}, n_round_challenges = 0;
     uint64_t* d_program = nullptr;
     uint64_t* d_small = nullptr;  // FRI coset tables (rate_bits) | quotient coset tables (qdb) | w_A^-i
     uint64_t *d_coset_base = nullptr, *d_q_coset_base = nullptr, *d_q_zh_inv = nullptr, *d_q_wR_inv = nullptr,
@@ -204,9 +204,9 @@ struct nlx_stark {
 static size_t stark_proof_max_bytes(const nlx_stark_desc& d, uint32_t n_rounds) {
     const size_t capb = (size_t)32 << d.cap_height;
     const unsigned log_L = d.degree_bits + d.rate_bits;
-    const uint32_t nq = d.num_challenges * d.quotient_degree_factor;
-    size_t bytes = 2 * capb + 16 * (size_t)(2 * d.n_cols + nq) + n_rounds * capb;
-    size_t per_query = (size_t)(d.n_cols + nq) * 8 + 2 * (1 + 32 * (size_t)log_L) +
+    const uint32_t nq = d.num_challenges * d.quotient_degree_factor, n_oracles = (d.n_rounds ? d.n_rounds : 1) + 1;
+    size_t bytes = n_oracles * capb + 16 * (size_t)(2 * d.n_cols + nq) + n_rounds * capb;
+    size_t per_query = (size_t)(d.n_cols + nq) * 8 + n_oracles * (1 + 32 * (size_t)log_L) +
                        n_rounds * (((size_t)16 << d.fri_arity_bits) + 1 + 32 * (size_t)log_L);
     bytes += per_query * d.fri_num_queries + ((size_t)16 << d.degree_bits) + 8 + 4 + 8 * (size_t)d.num_public_inputs;
     return bytes + 64;
@@ -233,6 +233,17 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
         return ctx->fail(NLX_E_RANGE, "AIR shape out of range");
     if (d.n_periodic > NLX_AIR_MAX_PERIODIC || (d.n_periodic && (!d.periodic || d.period_bits > d.degree_bits || d.period_bits > 12)))
         return ctx->fail(NLX_E_RANGE, "periodic columns out of range");
+    if (d.n_rounds > 3) return ctx->fail(NLX_E_RANGE, "at most three commitment rounds");
+    uint32_t n_round_challenges = 0;
+    if (d.n_rounds) {
+        uint32_t tot = 0;
+        for (uint32_t r = 0; r < d.n_rounds; r++) {
+            if (d.round_cols[r] == 0 || d.round_challenges[r] > 16) return ctx->fail(NLX_E_RANGE, "round %u: columns / challenges out of range", r);
+            tot += d.round_cols[r];
+            n_round_challenges += d.round_challenges[r];
+        }
+        if (tot != d.n_cols) return ctx->fail(NLX_E_INVAL, "round_cols must add up to n_cols");
+    }
     // program validation: opcodes, operand ranges, no register read before it is written
     std::vector<uint64_t> prog(d.program, d.program + d.n_words);
     uint32_t n_regs = 1;
@@ -272,7 +283,8 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
             if ((w >> 62) != 0) return ctx->fail(NLX_E_INVAL, "AIR word %u: reserved bits set", pc);
             if (writes && dst >= NLX_AIR_NUM_REGS) return ctx->fail(NLX_E_INVAL, "AIR word %u: register out of range", pc);
             if ((op == NLX_AIR_LOCAL || op == NLX_AIR_NEXT) && a >= d.n_cols) return ctx->fail(NLX_E_INVAL, "AIR word %u: column out of range", pc);
-            if (op == NLX_AIR_PUBLIC && a >= d.num_public_inputs) return ctx->fail(NLX_E_INVAL, "AIR word %u: public input out of range", pc);
+            if (op == NLX_AIR_PUBLIC && a >= d.num_public_inputs + n_round_challenges)
+                return ctx->fail(NLX_E_INVAL, "AIR word %u: public input / challenge out of range", pc);
             if (op == NLX_AIR_PERIODIC && a >= d.n_periodic) return ctx->fail(NLX_E_INVAL, "AIR word %u: periodic column out of range", pc);
             if (op >= NLX_AIR_ADD && op <= NLX_AIR_EMIT) {
                 const bool two_src = op <= NLX_AIR_MUL;
@@ -298,6 +310,12 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
     s->program.swap(prog);
     s->d.program = s->program.data();
     s->n_regs = n_regs;
+    s->n_rounds = d.n_rounds ? d.n_rounds : 1;
+    for (uint32_t r = 0; r < s->n_rounds; r++) {
+        s->round_cols[r] = d.n_rounds ? d.round_cols[r] : d.n_cols;
+        s->round_challenges[r] = d.n_rounds ? d.round_challenges[r] : 0;
+    }
+    s->n_round_challenges = n_round_challenges;
     s->nq = d.num_challenges * q;
     while ((1u << s->qdb) < q) s->qdb++;
     s->n_fri_rounds = fri_num_rounds(d.degree_bits, d.rate_bits, d.cap_height, d.fri_arity_bits, d.fri_final_poly_bits);
@@ -408,12 +426,12 @@ int32_t nlx_stark_stage_times(const nlx_stark* s, uint32_t* n_stages, const char
     return NLX_OK;
 }
 
-int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* public_inputs, uint8_t* proof_out,
-                        size_t proof_cap, size_t* proof_len) {
+int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, const uint64_t* public_inputs,
+                               uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
     if (!s) return NLX_E_INVAL;
     nlx_ctx* ctx = s->ctx;
     const nlx_stark_desc& d = s->d;
-    if (!trace || !proof_out || !proof_len || (!public_inputs && d.num_public_inputs))
+    if (!round_fn || !proof_out || !proof_len || (!public_inputs && d.num_public_inputs))
         return ctx->fail(NLX_E_INVAL, "NULL argument");
     *proof_len = 0;
     for (uint32_t i = 0; i < d.num_public_inputs; i++)
@@ -421,8 +439,8 @@ int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* pub
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     const unsigned log_n = d.degree_bits, cap_h = d.cap_height, qdb = s->qdb;
-    const size_t n = (size_t)1 << log_n, capw = (size_t)4 << cap_h;
-    const uint32_t nc = d.num_challenges, ncols = d.n_cols, nq = s->nq;
+    const size_t n = (size_t)1 << log_n, L = n << d.rate_bits, capw = (size_t)4 << cap_h;
+    const uint32_t nc = d.num_challenges, ncols = d.n_cols, nq = s->nq, NRD = s->n_rounds;
     int32_t rc = NLX_OK;
     std::vector<void*> scratch;
     auto dalloc = [&](size_t bytes) -> uint64_t* {
@@ -430,7 +448,9 @@ int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* pub
         if (p) scratch.push_back(p);
         return (uint64_t*)p;
     };
-    nlx_commit *ct = nullptr, *cq = nullptr;
+    nlx_commit* cr[3] = {nullptr, nullptr, nullptr};
+    nlx_commit* cq = nullptr;
+    uint32_t col0[4] = {0, 0, 0, 0};
     s->n_stages = 0;
     s->timed = false;
     auto stage = [&](const char* name) {
@@ -442,33 +462,46 @@ int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* pub
     Writer w{proof_out, 0, proof_cap};
     Challenger ch;
     std::vector<uint64_t> cap(capw);
+    // values readable by NLX_AIR_PUBLIC: the public inputs, then the verifier challenges in the order drawn
+    std::vector<uint64_t> values(public_inputs, public_inputs + d.num_public_inputs);
+    std::vector<const uint64_t*> h_cols(ncols);
 #define CHECK(x) do { rc = (x); if (rc) goto done; } while (0)
 #define HIPCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { rc = ctx->hip_fail(e__, #call); goto done; } } while (0)
 #define CHECK_ALLOC(p) do { if (!(p)) { rc = NLX_E_NOMEM; goto done; } } while (0)
     {
-        // ---- trace commitment (prover.rs: PolynomialBatch::from_values(trace_poly_values, rate_bits, ..)) ----
+        // ---- trace commitments, one per round (prover.rs: PolynomialBatch::from_values(trace_poly_values, ..);
+        //      starkyx: one TraceWriter round per commitment, challenges drawn in between) ----
         stage("commit_trace");
-        Staged tr(ctx, trace, (size_t)ncols * n * 8, true, false);
-        CHECK(tr.status);
-        CHECK(commit_build(ctx, tr.as<uint64_t>(), n, CommitInput::ValuesNatural, ncols, log_n, d.rate_bits, cap_h, &ct));
-        CHECK(fetch(ctx, cap.data(), ct->cap, capw * 8));
-        w.u64s(cap.data(), capw);
-        ch.observe(cap.data(), capw);
+        for (uint32_t r = 0; r < NRD; r++) {
+            const uint32_t rcols = s->round_cols[r];
+            const uint64_t* tr_ptr = round_fn(user, r, values.data() + d.num_public_inputs, (uint32_t)(values.size() - d.num_public_inputs));
+            if (!tr_ptr) { rc = ctx->fail(NLX_E_INVAL, "round %u: the round callback returned NULL", r); goto done; }
+            Staged tr(ctx, tr_ptr, (size_t)rcols * n * 8, true, false);
+            CHECK(tr.status);
+            CHECK(commit_build(ctx, tr.as<uint64_t>(), n, CommitInput::ValuesNatural, rcols, log_n, d.rate_bits, cap_h, &cr[r]));
+            CHECK(fetch(ctx, cap.data(), cr[r]->cap, capw * 8));
+            w.u64s(cap.data(), capw);
+            ch.observe(cap.data(), capw);
+            for (uint32_t k = 0; k < s->round_challenges[r]; k++) values.push_back(ch.challenge());
+            for (uint32_t c = 0; c < rcols; c++) h_cols[col0[r] + c] = cr[r]->lde + (size_t)c * L;
+            col0[r + 1] = col0[r] + rcols;
+        }
         uint64_t alphas[2] = {0, 0};
         for (uint32_t i = 0; i < nc; i++) alphas[i] = ch.challenge();
 
         // ---- compute_quotient_polys ----
         stage("quotient_eval");
         const size_t Q = n << qdb;
-        uint64_t* d_pis = dalloc((size_t)(d.num_public_inputs + 1) * 8);
+        uint64_t* d_pis = dalloc((values.size() + 1) * 8);
+        const uint64_t** d_cols = (const uint64_t**)dalloc((size_t)ncols * 8);
         uint64_t* d_qvals = dalloc((size_t)nc * Q * 8);
         uint64_t* d_qchunks = dalloc((size_t)nc * Q * 8);
-        CHECK_ALLOC(d_pis && d_qvals && d_qchunks);
-        if (d.num_public_inputs)
-            HIPCHK(hipMemcpyAsync(d_pis, public_inputs, (size_t)d.num_public_inputs * 8, hipMemcpyHostToDevice, st));
+        CHECK_ALLOC(d_pis && d_cols && d_qvals && d_qchunks);
+        if (!values.empty()) HIPCHK(hipMemcpyAsync(d_pis, values.data(), values.size() * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_cols, h_cols.data(), (size_t)ncols * 8, hipMemcpyHostToDevice, st));
         {
             AirParams ap{};
-            ap.trace = ct->lde; ap.program = s->d_program; ap.pis = d_pis;
+            ap.cols = d_cols; ap.program = s->d_program; ap.pis = d_pis;
             ap.coset_base = s->d_q_coset_base; ap.zh_inv = s->d_q_zh_inv; ap.l_inv = s->d_l_inv;
             ap.periodic = s->d_periodic; ap.period_bits = d.period_bits;
             ap.w_n_table = ctx->tables.fwd[log_n];
@@ -495,7 +528,7 @@ int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* pub
         w.u64s(cap.data(), capw);
         ch.observe(cap.data(), capw);
 
-        // ---- StarkOpeningSet: local = trace(zeta), next = trace(g zeta), quotient(zeta) ----
+        // ---- StarkOpeningSet: local = columns(zeta), next = columns(g zeta), quotient(zeta) ----
         stage("openings");
         uint64_t zeta[2], gzeta[2];
         ch.ext_challenge(zeta);
@@ -505,9 +538,11 @@ int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* pub
             gzeta[1] = gl::mul(zeta[1], g);
         }
         const uint32_t n_open = ncols + nq;
+        uint32_t widest = nq;
+        for (uint32_t r = 0; r < NRD; r++) widest = s->round_cols[r] > widest ? s->round_cols[r] : widest;
         uint64_t* d_points = dalloc(2048);
         uint64_t* d_open = dalloc((size_t)(n_open + ncols) * 16);
-        uint64_t* d_eval_scratch = dalloc(eval_scratch_words(ncols > nq ? ncols : nq, log_n) * 8);
+        uint64_t* d_eval_scratch = dalloc(eval_scratch_words(widest, log_n) * 8);
         CHECK_ALLOC(d_points && d_open && d_eval_scratch);
         {
             uint64_t pts[4 + 2 * 2 * 32] = {zeta[0], zeta[1], gzeta[0], gzeta[1]};
@@ -518,10 +553,13 @@ int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* pub
                 if (k + 1 < log_n) { za = gl::mul(za, za); zb = gl::mul(zb, zb); }
             }
             HIPCHK(hipMemcpyAsync(d_points, pts, sizeof pts, hipMemcpyHostToDevice, st));
-            launch_eval_br(st, ct->coeffs_br, n, ncols, log_n, d_points, d_open, d_eval_scratch, d_points + 4);
+            for (uint32_t r = 0; r < NRD; r++) {
+                launch_eval_br(st, cr[r]->coeffs_br, n, s->round_cols[r], log_n, d_points, d_open + 2 * (size_t)col0[r],
+                               d_eval_scratch, d_points + 4);
+                launch_eval_br(st, cr[r]->coeffs_br, n, s->round_cols[r], log_n, d_points + 2,
+                               d_open + 2 * (size_t)(n_open + col0[r]), d_eval_scratch, d_points + 4 + 64);
+            }
             launch_eval_br(st, cq->coeffs_br, n, nq, log_n, d_points, d_open + 2 * (size_t)ncols, d_eval_scratch, d_points + 4);
-            launch_eval_br(st, ct->coeffs_br, n, ncols, log_n, d_points + 2, d_open + 2 * (size_t)n_open, d_eval_scratch,
-                           d_points + 4 + 64);
         }
         std::vector<uint64_t> open((size_t)(n_open + ncols) * 2);
         CHECK(fetch(ctx, open.data(), d_open, open.size() * 8));
@@ -535,14 +573,15 @@ int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* pub
         ch.observe(open.data(), 2 * (size_t)n_open);
         ch.observe(o_next, 2 * (size_t)ncols);
 
-        // ---- FRI: Stark::fri_instance = [zeta: trace ++ quotient], [g zeta: trace] ----
+        // ---- FRI: Stark::fri_instance = [zeta: every round's columns ++ quotient], [g zeta: every round's columns] ----
         {
             FriProveArgs fa;
-            fa.oracles[0] = ct;
-            fa.oracles[1] = cq;
-            fa.n_oracles = 2;
-            fa.next_table = 0;
-            fa.nz = ncols;
+            for (uint32_t r = 0; r < NRD; r++) {
+                fa.oracles[r] = cr[r];
+                fa.nz[r] = s->round_cols[r];
+            }
+            fa.oracles[NRD] = cq;
+            fa.n_oracles = NRD + 1;
             for (int i = 0; i < 2; i++) { fa.zeta[i] = zeta[i]; fa.gzeta[i] = gzeta[i]; }
             fa.open0 = open.data();
             fa.open1 = o_next;
@@ -568,12 +607,25 @@ done:
         if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
     }
     for (void* p : scratch) ctx->release(p);
-    if (ct) nlx_commit_destroy(ct);
+    for (uint32_t r = 0; r < 3; r++)
+        if (cr[r]) nlx_commit_destroy(cr[r]);
     if (cq) nlx_commit_destroy(cq);
 #undef CHECK
 #undef HIPCHK
 #undef CHECK_ALLOC
     return rc;
+}
+
+static const uint64_t* single_round_fn(void* user, uint32_t round, const uint64_t*, uint32_t) {
+    return round == 0 ? (const uint64_t*)user : nullptr;
+}
+
+int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* public_inputs, uint8_t* proof_out,
+                        size_t proof_cap, size_t* proof_len) {
+    if (!s) return NLX_E_INVAL;
+    if (!trace) return s->ctx->fail(NLX_E_INVAL, "NULL argument");
+    if (s->n_rounds != 1) return s->ctx->fail(NLX_E_INVAL, "a multi-round STARK is proved with nlx_stark_prove_rounds");
+    return nlx_stark_prove_rounds(s, single_round_fn, (void*)trace, public_inputs, proof_out, proof_cap, proof_len);
 }
 
 int32_t nlx_stark_batch_prove(nlx_stark* const* workers, uint32_t n_workers, nlx_prove_job* jobs, size_t n_jobs) {

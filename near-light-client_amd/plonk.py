@@ -245,15 +245,17 @@ class FriParams(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint32) for k in ("arity_bits", "final_poly_bits", "pow_bits", "num_queries")]
 
 
-def fri_prove(ctx, oracles, next_oracle, n_next, zeta, openings_zeta, openings_next, params, challenger, cap_bytes=1 << 22):
-    """nlx_fri_prove: oracles = PolynomialBatch list; returns the FriProof bytes and advances `challenger`."""
+def fri_prove(ctx, oracles, n_next, zeta, openings_zeta, openings_next, params, challenger, cap_bytes=1 << 22):
+    """nlx_fri_prove: oracles = PolynomialBatch list, n_next[o] = leading columns of oracle o also opened at g*zeta;
+    returns the FriProof bytes and advances `challenger`."""
     hs = (ctypes.c_void_p * len(oracles))(*[o.handle for o in oracles])
+    nn = (ctypes.c_uint32 * len(oracles))(*[int(x) for x in n_next])
     z = np.ascontiguousarray(zeta, dtype=np.uint64)
     o0 = np.ascontiguousarray(np.asarray(openings_zeta, dtype=np.uint64).reshape(-1))
     o1 = np.ascontiguousarray(np.asarray(openings_next, dtype=np.uint64).reshape(-1))
     buf = np.zeros(cap_bytes, dtype=np.uint8)
     n = ctypes.c_size_t()
-    ctx.check(dll.nlx_fri_prove(ctx.handle, hs, len(oracles), next_oracle, n_next, ptr(z), ptr(o0), ptr(o1) if o1.size else None,
+    ctx.check(dll.nlx_fri_prove(ctx.handle, hs, len(oracles), nn, ptr(z), ptr(o0), ptr(o1) if o1.size else None,
                                 ctypes.byref(params), ctypes.byref(challenger.s), buf.ctypes.data, buf.size, ctypes.byref(n)))
     return buf[:n.value].tobytes()
 

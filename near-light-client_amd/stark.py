@@ -446,6 +446,9 @@ class Stark:
         return StarkProver(ctx, self)
 
 
+_ROUND_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32)
+
+
 class StarkProver:
     """Device-resident prover for one Stark (nlx_stark_build / nlx_stark_prove)."""
 
@@ -470,6 +473,39 @@ class StarkProver:
         ln = ctypes.c_size_t()
         self.ctx.check(dll.nlx_stark_prove(self.handle, ptr(trace), ptr(pis) if pis.size else None,
                                            self._buf.ctypes.data, self._buf.size, ctypes.byref(ln)))
+        return self._buf[:ln.value].tobytes()
+
+    def prove_rounds(self, round_fn, public_inputs=()):
+        """Multi-round proving (nlx_stark_prove_rounds).  round_fn(round, challenges: list[int]) returns round r's
+        columns - a (round_cols[r], n) uint64 host array or a device tensor - computed from the challenges drawn
+        after the earlier rounds."""
+        pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+        if pis.size != self.stark.air.num_public_inputs:
+            raise ValueError("expected %d public inputs" % self.stark.air.num_public_inputs)
+        desc = self.stark.desc
+        keep, errors = [], []
+
+        def cb(_user, rnd, ch_ptr, n_ch):
+            try:
+                arr = round_fn(rnd, [int(ch_ptr[i]) for i in range(n_ch)])
+                want = (desc.round_cols[rnd] if desc.n_rounds else desc.n_cols, 1 << desc.degree_bits)
+                if tuple(arr.shape) != want:
+                    raise ValueError("round %d: expected columns of shape %r" % (rnd, want))
+                if isinstance(arr, np.ndarray):
+                    arr = np.ascontiguousarray(arr, dtype=np.uint64)
+                keep.append(arr)
+                return ptr(arr)
+            except Exception as e:  # an exception must not cross the C frame: NULL makes the call fail cleanly
+                errors.append(e)
+                return None
+
+        fn = _ROUND_FN(cb)
+        ln = ctypes.c_size_t()
+        rc = dll.nlx_stark_prove_rounds(self.handle, fn, None, ptr(pis) if pis.size else None, self._buf.ctypes.data,
+                                        self._buf.size, ctypes.byref(ln))
+        if errors:
+            raise errors[0]
+        self.ctx.check(rc)
         return self._buf[:ln.value].tobytes()
 
     def prove_into(self, trace, public_inputs_ptr):

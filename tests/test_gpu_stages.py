@@ -61,7 +61,7 @@ def test_stagewise_proof_equals_whole_proof(nlx, ctx, orc, log_n, kw):
     ch.observe(o_next)
     # 5. FRI
     fp = pk.FriParams(cfg.fri_arity_bits, cfg.fri_final_poly_bits, cfg.fri_pow_bits, cfg.fri_num_queries)
-    out += pk.fri_prove(ctx, [cs, cw, cz, cq], 2, nc, zeta, openings_zeta, o_next, fp, ch)
+    out += pk.fri_prove(ctx, [cs, cw, cz, cq], [0, 0, nc, 0], zeta, openings_zeta, o_next, fp, ch)
     out += np.uint32(syn.public_inputs.size).tobytes() + syn.public_inputs.tobytes()
     assert len(out) == len(want)
     if bytes(out) != want:
@@ -86,7 +86,7 @@ def test_stage_calls_reject_mismatched_inputs(nlx, ctx):
         cd.quotient_eval(cw, cw, z, z, z, np.zeros(4, np.uint64))         # zs batch has the wrong width
     fp = pk.FriParams(cfg.fri_arity_bits, cfg.fri_final_poly_bits, cfg.fri_pow_bits, cfg.fri_num_queries)
     with pytest.raises(nlx.NlxError):
-        pk.fri_prove(ctx, [cw], 1, 1, z, np.zeros((135, 2), np.uint64), np.zeros((1, 2), np.uint64), fp, pk.Challenger())
+        pk.fri_prove(ctx, [cw], [136], z, np.zeros((135, 2), np.uint64), np.zeros((136, 2), np.uint64), fp, pk.Challenger())
     with pytest.raises(nlx.NlxError):
         pk.Challenger().observe(np.array([P], dtype=np.uint64))           # non-canonical element
     cw.close()

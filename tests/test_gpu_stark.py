@@ -217,3 +217,33 @@ def test_stark_batch_prove(nlx, orc):
         p.close()
     for c in ctxs:
         c.close()
+
+
+def test_multi_round_logup_bytes_equal_oracle(nlx, ctx, orc):
+    """Two commitment rounds with a verifier challenge in between (nlx_stark_prove_rounds): GPU proof bytes equal
+    the oracle's, with the round columns handed over as host arrays and as device tensors."""
+    import torch
+    from test_stark_cpu import logup_air, logup_case, logup_rounds
+    S = nlx.stark
+    for db, cfg in ((7, dict(fri_num_queries=20)), (10, dict()), (6, dict(rate_bits=2, num_challenges=1, fri_arity_bits=2))):
+        st = S.Stark(logup_air(S), db, S.StarkConfig(**cfg))
+        v, t, m = logup_case(db)
+        rounds = logup_rounds(v, t, m)
+        want = orc.stark_prove_rounds(st.desc, rounds, [])
+        pr = st.build(ctx)
+        got = pr.prove_rounds(rounds)
+        assert got == want, db
+        assert orc.stark_verify(st.desc, got) == 1
+        dev = pr.prove_rounds(lambda r, ch: torch.from_numpy(rounds(r, ch).view(np.int64)).to("cuda:0"))
+        assert dev == want
+        with pytest.raises(nlx.NlxError):
+            pr.prove(np.zeros((6, 1 << db), dtype=np.uint64))          # single-round entry point refuses
+        with pytest.raises(ValueError):
+            pr.prove_rounds(lambda r, ch: np.zeros((2, 1 << db), dtype=np.uint64))   # wrong shape from the callback
+        pr.close()
+    # a value outside the table: the GPU proof is rejected by the verifier
+    st = S.Stark(logup_air(S), 7, S.StarkConfig(fri_num_queries=20))
+    pr = st.build(ctx)
+    vb, tb, mb = logup_case(7, bad=True)
+    assert orc.stark_verify(st.desc, pr.prove_rounds(logup_rounds(vb, tb, mb))) != 1
+    pr.close()
