@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark", "sha256"])
     ap.add_argument("--log-blocks", type=int, default=14, help="sha256 workload: 2^k compression blocks per proof")
+    ap.add_argument("--segment-nodes", type=int, default=None, help="sha256 workload: AIR program segment size (0 = one segment)")
     ap.add_argument("--stark-cols", type=int, default=256)
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--gate-mix", default="nearx", choices=["nearx", "basic"])
@@ -373,15 +374,13 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
     pad = np.zeros((n_msgs, 64), dtype=np.uint8)
     pad[:, 0] = 0x80
     pad[:, 62] = 0x02
-    blocks8 = np.concatenate([raw, pad], axis=1).reshape(n_msgs * 2, 64) if n_blocks > 1 else None
-    if n_blocks == 1:
-        blocks, first, _ = SA.blocks_for_messages([b"abc"], 0)
-    else:
-        blocks = blocks8.view(">u4").astype(np.uint32)
-        first = np.tile(np.array([1, 0], dtype=np.uint8), n_msgs)
-    want = np.array(struct.unpack(">8I", hashlib.sha256(raw[-1].tobytes() if n_blocks > 1 else b"abc").digest()), dtype=np.uint64)
+    if args.log_blocks < 2:
+        raise SystemExit("--log-blocks must be >= 2 (a block is four trace rows)")
+    blocks = np.concatenate([raw, pad], axis=1).reshape(n_msgs * 2, 64).view(">u4").astype(np.uint32)
+    first = np.tile(np.array([1, 0], dtype=np.uint8), n_msgs)
+    want = np.array(struct.unpack(">8I", hashlib.sha256(raw[-1].tobytes()).digest()), dtype=np.uint64)
     ctx = nlx.Context(local)
-    sp = SA.Sha256Prover(ctx, args.log_blocks)
+    sp = SA.Sha256Prover(ctx, args.log_blocks, segment_nodes=args.segment_nodes)
     digest = None
     for _ in range(args.warmup):
         trace, digest = sp.generate_trace(blocks, first)
@@ -408,7 +407,7 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
         calls, ms, alg = kstats["hash_lde_leaves"]
         achieved = (alg / calls) / (ms / calls * 1e-3) / 1e9 if calls else 0.0
         proof = sp.prover.prove(trace, digest)
-        n_rows = 64 << args.log_blocks
+        n_rows = SA.ROWS_PER_BLOCK << args.log_blocks
         out = {
             "metric": "SHA-256 STARK: compression blocks proved per second (secondary workload)",
             "value": world * args.steps * n_blocks / dt, "unit": "blocks/s", "n_gpus": world, "steps": args.steps,
@@ -433,7 +432,7 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
             import oracle_py
             cores = min(len(os.sched_getaffinity(0)), 16)
             os.environ["OMP_NUM_THREADS"] = str(cores)
-            s_lb = max(min(args.log_blocks - 3, 8), 0)
+            s_lb = max(min(args.log_blocks - 3, 9), 2)
             sp2 = SA.Sha256Prover(ctx, s_lb)
             b2, f2 = blocks[: 1 << s_lb], first[: 1 << s_lb].copy()
             f2[0] = 1

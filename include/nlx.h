@@ -345,8 +345,15 @@ int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint6
 #define NLX_AIR_XOR3 16            /* r[dst] = a ^ b ^ c as a polynomial: s = a + b - 2ab, s + c - 2sc */
 #define NLX_AIR_CH 17              /* r[dst] = c + a (b - c) */
 #define NLX_AIR_MAJ 18             /* r[dst] = ab + c (a + b - 2ab) */
+/* A segment boundary: no register value is carried across this word (the builder rejects a read of a register not
+ * written since the last boundary).  A sequential interpreter may ignore it; the GPU evaluates the segments of a
+ * long program as independent work items - (quotient points) x (segments) waves instead of (quotient points) -
+ * and adds the segments' partial sums with the alpha powers their position in the program implies, so a wide AIR
+ * on a short trace still fills the chip.  At most NLX_AIR_MAX_SEGMENTS - 1 boundaries per program. */
+#define NLX_AIR_SEGMENT 19
+#define NLX_AIR_MAX_SEGMENTS 256
 #define NLX_AIR_NUM_REGS 64
-#define NLX_AIR_MAX_PERIODIC 16
+#define NLX_AIR_MAX_PERIODIC 32
 
 typedef struct {
     uint32_t degree_bits;
@@ -404,9 +411,9 @@ int32_t nlx_stark_batch_prove(nlx_stark* const* workers, uint32_t n_workers, nlx
  * near-light-client_amd/sha256_air.py; callers in the reference: curta_sha256 at nearx/src/merkle.rs:49,
  * nearx/src/variables.rs:71-72).  blocks: 2^log_blocks padded 512-bit blocks as 16 big-endian-decoded words
  * each; is_first[b] != 0 where block b starts a new message (block 0 always does).  Writes the
- * NLX_SHA256_COLS x (64 << log_blocks) column-major trace (host or device buffer) and, if digest_out is
+ * NLX_SHA256_COLS x (4 << log_blocks) column-major trace (host or device buffer) and, if digest_out is
  * not NULL, the eight words of the last block's output chaining value (the AIR's public inputs). */
-#define NLX_SHA256_COLS 302
+#define NLX_SHA256_COLS 1953
 int32_t nlx_sha256_trace(nlx_ctx* ctx, const uint32_t* blocks, const uint8_t* is_first, uint32_t log_blocks,
                          uint64_t* trace_out, uint64_t digest_out[8]);
 /* Synthetic wide-AIR witness (inputs only): n_cols (multiple of 4) x n column-major host buffer, k1 = the

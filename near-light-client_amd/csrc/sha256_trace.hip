@@ -1,11 +1,9 @@
 // Trace generation for the SHA-256 compression AIR ("AIR evaluators + trace generation on
 // GPU"; callers nearx/src/merkle.rs:43-50, nearx/src/variables.rs:71-72 via curta_sha256).  Column layout:
-// near-light-client_amd/sha256_air.py (NLX_SHA256_COLS columns, one row per round, 64 rows per block).
+// near-light-client_amd/sha256_air.py (NLX_SHA256_COLS columns, sixteen rounds per row, four rows per block).
 //
 // Two kernels.  k_sha_chain: one lane per message start walks that message's blocks and records every
-// block's input chaining value.  k_sha_trace: one wave per block; the 64 lanes run the 64 rounds in
-// lock-step on wave-uniform values and lane t keeps a snapshot of round t, then every lane writes its own
-// row - each column store of a wave is 64 consecutive words (the trace is column-major, [col][row]).
+// block's input chaining value.  k_sha_trace: one lane per trace row (below).
 #include "ctx.hpp"
 #include "transcript.hpp"
 
@@ -67,68 +65,89 @@ __global__ __launch_bounds__(64) void k_sha_chain(const uint32_t* __restrict__ b
     }
 }
 
-// Column offsets (sha256_air.py)
-enum : uint32_t { cA = 0, cB = 32, cC = 64, cE = 96, cF = 128, cG = 160, cD = 192, cH = 193, cHIN = 194, cWIN = 202,
-                  cW1B = 218, cW14B = 250, cNEW_A = 282, cNEW_E = 283, cNEW_W = 284, cCA = 285, cCE = 288, cCW = 291,
-                  cCY = 293, cIS_FIRST = 301 };
+// Column layout (sha256_air.py): sixteen round slots of 105 columns, then the row's start state and block data
+enum : uint32_t { kSLOT = 105, oA = 0, oE = 32, oW = 64, oCA = 96, oCE = 99, oCW = 102, oSW = 104, cPA = 16 * kSLOT,
+                  cPE = cPA + 128, cHIN = cPE + 128, cCY = cHIN + 8, cIS_FIRST = cCY + 8 };
 static_assert(cIS_FIRST + 1 == NLX_SHA256_COLS, "column map");
 
+// One lane per trace row (four rows per block, sixteen rounds per row).  Every lane replays its block's 64 rounds
+// (a few hundred integer instructions, 4x redundant per block - noise next to the 15.6 KB it then writes) and
+// emits its row; a wave's 64 lanes are 64 consecutive rows, so each of the 1 953 column stores is 512 contiguous
+// bytes.
 __global__ __launch_bounds__(256) void k_sha_trace(const uint32_t* __restrict__ blocks, const uint8_t* __restrict__ is_first,
                                                    const uint32_t* __restrict__ hin, uint32_t n_blocks,
                                                    uint64_t* __restrict__ trace) {
-    const uint32_t blk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (blk >= n_blocks) return;
-    const size_t n = (size_t)n_blocks << 6, row = ((size_t)blk << 6) + lane;
-    uint32_t h0[8], w[16];
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)n_blocks << 2;
+    if (row >= n) return;
+    const uint32_t blk = (uint32_t)(row >> 2), q = (uint32_t)(row & 3);
+    const uint32_t prev = blk ? blk - 1 : n_blocks - 1;  // the schedule recurrence of row 0 looks back cyclically
+    uint32_t w[80];  // w[16 + t] = W_t of this block for t = 0..63; w[0..15] = W_48..63 of the previous block
+    {
+        uint32_t wp[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) wp[i] = blocks[(size_t)prev * 16 + i];
+#pragma unroll 1
+        for (int t = 16; t < 64; t++) {
+            const uint32_t v = wp[t & 15] + sha::s0(wp[(t + 1) & 15]) + wp[(t + 9) & 15] + sha::s1(wp[(t + 14) & 15]);
+            wp[t & 15] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = wp[(48 + i) & 15];
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[16 + i] = blocks[(size_t)blk * 16 + i];
+#pragma unroll 1
+        for (int t = 16; t < 64; t++) w[16 + t] = w[t] + sha::s0(w[t + 1]) + w[t + 9] + sha::s1(w[t + 14]);
+    }
+    uint32_t h0[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) h0[k] = hin[(size_t)blk * 8 + k];
-#pragma unroll
-    for (int i = 0; i < 16; i++) w[i] = blocks[(size_t)blk * 16 + i];
-    uint32_t a = h0[0], b = h0[1], c = h0[2], d = h0[3], e = h0[4], f = h0[5], g = h0[6], hh = h0[7];
-    // snapshot of my round
-    uint32_t ma = 0, mb = 0, mc = 0, md = 0, me = 0, mf = 0, mg = 0, mh = 0, mw[16], m_na = 0, m_ne = 0, m_nw = 0;
-    uint32_t m_ca = 0, m_ce = 0, m_cw = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) mw[i] = 0;
+    // a[t + 4], e[t + 4] for t = -4..63, with the carries of every round
+    uint32_t a[68], e[68];
+    uint8_t ca[64], ce[64];
+    a[3] = h0[0]; a[2] = h0[1]; a[1] = h0[2]; a[0] = h0[3];
+    e[3] = h0[4]; e[2] = h0[5]; e[1] = h0[6]; e[0] = h0[7];
 #pragma unroll 1
-    for (int r0 = 0; r0 < 64; r0 += 16) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const uint64_t t1 = (uint64_t)hh + sha::S1(e) + ((e & f) ^ (~e & g)) + sha::K[r0 + i] + w[i];
-            const uint64_t sa = t1 + sha::S0(a) + ((a & b) ^ (a & c) ^ (b & c));
-            const uint64_t se = (uint64_t)d + t1;
-            const uint64_t sw = (uint64_t)sha::s1(w[(i + 14) & 15]) + w[(i + 9) & 15] + sha::s0(w[(i + 1) & 15]) + w[i];
-            if (lane == r0 + i) {
-                ma = a; mb = b; mc = c; md = d; me = e; mf = f; mg = g; mh = hh;
-#pragma unroll
-                for (int j = 0; j < 16; j++) mw[j] = w[(i + j) & 15];
-                m_na = (uint32_t)sa; m_ne = (uint32_t)se; m_nw = (uint32_t)sw;
-                m_ca = (uint32_t)(sa >> 32); m_ce = (uint32_t)(se >> 32); m_cw = (uint32_t)(sw >> 32);
-            }
-            w[i] = (uint32_t)sw;
-            hh = g; g = f; f = e; e = (uint32_t)se; d = c; c = b; b = a; a = (uint32_t)sa;
-        }
+    for (int r = 0; r < 64; r++) {
+        const uint32_t a1 = a[r + 3], a2 = a[r + 2], a3 = a[r + 1], a4 = a[r];
+        const uint32_t e1 = e[r + 3], e2 = e[r + 2], e3 = e[r + 1], e4 = e[r];
+        const uint64_t t1 = (uint64_t)e4 + sha::S1(e1) + ((e1 & e2) ^ (~e1 & e3)) + sha::K[r] + w[16 + r];
+        const uint64_t sa = t1 + sha::S0(a1) + ((a1 & a2) ^ (a1 & a3) ^ (a2 & a3));
+        const uint64_t se = (uint64_t)a4 + t1;
+        a[r + 4] = (uint32_t)sa;
+        e[r + 4] = (uint32_t)se;
+        ca[r] = (uint8_t)(sa >> 32);
+        ce[r] = (uint8_t)(se >> 32);
     }
-    // write my row
     auto put = [&](uint32_t col, uint64_t v) { trace[(size_t)col * n + row] = v; };
     auto put_bits = [&](uint32_t base, uint32_t v, int cnt) {
         for (int i = 0; i < cnt; i++) put(base + i, (v >> i) & 1u);
     };
-    put_bits(cA, ma, 32); put_bits(cB, mb, 32); put_bits(cC, mc, 32);
-    put_bits(cE, me, 32); put_bits(cF, mf, 32); put_bits(cG, mg, 32);
-    put(cD, md); put(cH, mh);
+#pragma unroll 1
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t r = 16 * q + j, base = j * kSLOT;
+        put_bits(base + oA, a[r + 4], 32);
+        put_bits(base + oE, e[r + 4], 32);
+        put_bits(base + oW, w[16 + r], 32);
+        put_bits(base + oCA, ca[r], 3);
+        put_bits(base + oCE, ce[r], 3);
+        // w[16 + r + k] is W_{r + k}, k >= -16 (k < 0 in row 0 reaches the previous block's W_48..63)
+        const uint64_t sw = (uint64_t)sha::s1(w[16 + r - 2]) + w[16 + r - 7] + sha::s0(w[16 + r - 15]) + w[16 + r - 16];
+        put(base + oSW, (uint32_t)sw);
+        put_bits(base + oCW, (uint32_t)(sw >> 32), 2);
+    }
+#pragma unroll 1
+    for (uint32_t k = 0; k < 4; k++) {
+        put_bits(cPA + 32 * k, a[16 * q + 3 - k], 32);
+        put_bits(cPE + 32 * k, e[16 * q + 3 - k], 32);
+    }
+    const uint32_t fin[8] = {a[67], a[66], a[65], a[64], e[67], e[66], e[65], e[64]};
 #pragma unroll
-    for (int k = 0; k < 8; k++) put(cHIN + k, h0[k]);
-#pragma unroll
-    for (int j = 0; j < 16; j++) put(cWIN + j, mw[j]);
-    put_bits(cW1B, mw[1], 32); put_bits(cW14B, mw[14], 32);
-    put(cNEW_A, m_na); put(cNEW_E, m_ne); put(cNEW_W, m_nw);
-    put_bits(cCA, m_ca, 3); put_bits(cCE, m_ce, 3); put_bits(cCW, m_cw, 2);
-    const uint32_t out[8] = {m_na, ma, mb, mc, m_ne, me, mf, mg};
-#pragma unroll
-    for (int k = 0; k < 8; k++) put(cCY + k, lane == 63 ? (uint32_t)(((uint64_t)h0[k] + out[k]) >> 32) : 0u);
-    put(cIS_FIRST, (lane == 0 && (is_first[blk] || blk == 0)) ? 1u : 0u);
+    for (int k = 0; k < 8; k++) {
+        put(cHIN + k, h0[k]);
+        put(cCY + k, q == 3 ? (uint32_t)(((uint64_t)h0[k] + fin[k]) >> 32) : 0u);
+    }
+    put(cIS_FIRST, (q == 0 && (is_first[blk] || blk == 0)) ? 1u : 0u);
 }
 
 }  // namespace nlx
@@ -139,10 +158,10 @@ extern "C" int32_t nlx_sha256_trace(nlx_ctx* ctx, const uint32_t* blocks, const 
                                     uint64_t* trace_out, uint64_t digest_out[8]) {
     if (!ctx) return NLX_E_INVAL;
     if (!blocks || !is_first || !trace_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
-    if (log_blocks > 22) return ctx->fail(NLX_E_RANGE, "log_blocks must be <= 22");
+    if (log_blocks > 20) return ctx->fail(NLX_E_RANGE, "log_blocks must be <= 20");
     (void)hipSetDevice(ctx->device);
     const uint32_t n_blocks = 1u << log_blocks;
-    const size_t n = (size_t)n_blocks << 6;
+    const size_t n = (size_t)n_blocks << 2;  // four rows per block
     Staged sb(ctx, blocks, (size_t)n_blocks * 64, true, false);
     if (sb.status) return sb.status;
     Staged sf(ctx, is_first, n_blocks, true, false);
@@ -153,7 +172,7 @@ extern "C" int32_t nlx_sha256_trace(nlx_ctx* ctx, const uint32_t* blocks, const 
     if (!d_hin) return NLX_E_NOMEM;
     hipLaunchKernelGGL(k_sha_chain, dim3((n_blocks + 63) / 64), dim3(64), 0, ctx->stream, sb.as<uint32_t>(),
                        sf.as<uint8_t>(), n_blocks, d_hin);
-    hipLaunchKernelGGL(k_sha_trace, dim3((n_blocks + 3) / 4), dim3(256), 0, ctx->stream, sb.as<uint32_t>(),
+    hipLaunchKernelGGL(k_sha_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sb.as<uint32_t>(),
                        sf.as<uint8_t>(), d_hin, n_blocks, st.as<uint64_t>());
     int32_t rc = st.finish();
     if (!rc && digest_out) {

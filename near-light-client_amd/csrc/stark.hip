@@ -37,6 +37,10 @@ struct AirParams {
     const uint64_t* periodic;   // device: [column][r'][k mod period] = P_a((g w^r')^(n/period) * w_period^k)
     const uint64_t* w_n_table;
     uint64_t* out;              // [challenge][r'][k]
+    const uint32_t* seg;        // device: [segment] = {first word, end word} (n_seg > 1)
+    const uint64_t* seg_mul;    // device: [segment][challenge] = alpha^(constraints after the segment)
+    uint64_t* part;             // [segment][challenge][r'][k] partial sums (n_seg > 1)
+    uint32_t n_seg;
     uint64_t alphas[2];
     uint64_t g_inv;             // last = g^-1 (g generates the size-n subgroup)
     uint32_t log_n, rate_bits, qdb, n_words, nc, n_regs, period_bits;
@@ -54,7 +58,8 @@ static __device__ __forceinline__ uint64_t root_pow_(const uint64_t* __restrict_
 
 // One lane per point (r', k) of the quotient domain.  Registers live in LDS as regs[reg * blockDim + lane]:
 // every access of a wave touches 64 consecutive 8-byte words (no bank conflicts); the program counter, the
-// opcode and the operands are wave-uniform, so decode runs on the scalar unit.
+// opcode and the operands are wave-uniform, so decode runs on the scalar unit.  blockIdx.y selects the program
+// segment (NLX_AIR_SEGMENT): the segments of one point run on different waves and k_air_combine adds them.
 __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
     extern __shared__ uint64_t regs[];
     const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,7 +80,9 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
     uint64_t acc0 = 0, acc1 = 0;
     const uint64_t a0 = p.alphas[0], a1 = p.alphas[1];
     const bool two = p.nc > 1;
-    for (uint32_t pc = 0; pc < p.n_words; pc++) {
+    const uint32_t sg = blockIdx.y;
+    const uint32_t pc_end = p.n_seg > 1 ? p.seg[2 * sg + 1] : p.n_words;
+    for (uint32_t pc = p.n_seg > 1 ? p.seg[2 * sg] : 0; pc < pc_end; pc++) {
         const uint64_t w = p.program[pc];
         const uint32_t op = (uint32_t)(w & 0xFF), dst = (uint32_t)((w >> 8) & 0xFFFF);
         const uint32_t a = (uint32_t)((w >> 24) & 0xFFFF), b = (uint32_t)((w >> 40) & 0xFFFF);
@@ -173,10 +180,29 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
         acc0 = gl::add(gl::mul(acc0, a0), c);
         if (two) acc1 = gl::add(gl::mul(acc1, a1), c);
     }
-    const uint64_t zi = p.zh_inv[rq];
     const size_t Q = (size_t)1 << log_Q;
+    if (p.n_seg > 1) {
+        // this segment's share of sum_i alpha^(N-1-i) c_i: its own Horner sum times alpha^(constraints after it)
+        uint64_t* dst = p.part + (((size_t)sg * p.nc) << log_Q) + pos;
+        dst[0] = gl::mul(acc0, p.seg_mul[2 * sg]);
+        if (two) dst[Q] = gl::mul(acc1, p.seg_mul[2 * sg + 1]);
+        return;
+    }
+    const uint64_t zi = p.zh_inv[rq];
     p.out[pos] = gl::mul(acc0, zi);
     if (two) p.out[Q + pos] = gl::mul(acc1, zi);
+}
+
+// out[c][pos] = (sum over segments of part[s][c][pos]) / Z_H(x)
+__global__ __launch_bounds__(256) void k_air_combine(const uint64_t* __restrict__ part, const uint64_t* __restrict__ zh_inv,
+                                                     uint64_t* __restrict__ out, uint32_t n_seg, uint32_t nc, uint32_t log_n,
+                                                     uint32_t log_Q) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over [challenge][pos]
+    if (i >= ((size_t)nc << log_Q)) return;
+    const size_t pos = i & (((size_t)1 << log_Q) - 1);
+    uint64_t acc = 0;
+    for (uint32_t sgm = 0; sgm < n_seg; sgm++) acc = gl::add(acc, part[(((size_t)sgm * nc) << log_Q) + i]);
+    out[i] = gl::mul(acc, zh_inv[pos >> log_n]);
 }
 
 }  // namespace nlx
@@ -188,6 +214,9 @@ struct nlx_stark {
     uint32_t qdb = 0, nq = 0, n_regs = 0, n_fri_rounds = 0;
     uint32_t n_rounds = 1, round_cols[3] = {0, 0, 0}, round_challenges[3] = {0, 0, 0}, n_round_challenges = 0;
     uint64_t* d_program = nullptr;
+    std::vector<uint32_t> seg;        // {first word, end word} per program segment
+    std::vector<uint32_t> seg_after;  // constraints emitted after each segment
+    uint32_t* d_seg = nullptr;
     uint64_t* d_small = nullptr;  // FRI coset tables (rate_bits) | quotient coset tables (qdb) | w_A^-i
     uint64_t *d_coset_base = nullptr, *d_q_coset_base = nullptr, *d_q_zh_inv = nullptr, *d_q_wR_inv = nullptr,
              *d_q_chunk_scale = nullptr, *d_wA_inv = nullptr;
@@ -246,14 +275,25 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
     }
     // program validation: opcodes, operand ranges, no register read before it is written
     std::vector<uint64_t> prog(d.program, d.program + d.n_words);
-    uint32_t n_regs = 1;
+    uint32_t n_regs = 1, n_emits = 0;
+    std::vector<uint32_t> seg_bounds, seg_emits;  // word index of each boundary, constraints emitted before it
     {
         bool written[NLX_AIR_NUM_REGS] = {false};
         for (uint32_t pc = 0; pc < d.n_words; pc++) {
             const uint64_t w = prog[pc];
             const uint32_t op = (uint32_t)(w & 0xFF), dst = (uint32_t)((w >> 8) & 0xFFFF);
             const uint32_t a = (uint32_t)((w >> 24) & 0xFFFF), b = (uint32_t)((w >> 40) & 0xFFFF);
-            if (op > NLX_AIR_MAJ) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
+            if (op > NLX_AIR_SEGMENT) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
+            if (op == NLX_AIR_SEGMENT) {
+                if (w != NLX_AIR_SEGMENT) return ctx->fail(NLX_E_INVAL, "AIR word %u: operands on a segment boundary", pc);
+                if (seg_bounds.size() + 2 > NLX_AIR_MAX_SEGMENTS) return ctx->fail(NLX_E_RANGE, "AIR: too many segments");
+                seg_bounds.push_back(pc);
+                seg_emits.push_back(n_emits);
+                for (bool& wr : written) wr = false;
+                continue;
+            }
+            if (op >= NLX_AIR_EMIT_TRANSITION && op <= NLX_AIR_EMIT) n_emits++;
+            if (op == NLX_AIR_EMIT_BOOL) n_emits += b ? b : 1;
             if (op == NLX_AIR_LOADV) {
                 // a hint: the following words are validated as the ordinary loads they are
                 if (dst < 1 || dst > 8 || pc + dst >= d.n_words) return ctx->fail(NLX_E_INVAL, "AIR word %u: LOADV count", pc);
@@ -310,6 +350,19 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
     s->program.swap(prog);
     s->d.program = s->program.data();
     s->n_regs = n_regs;
+    {
+        uint32_t lo = 0, before = 0;
+        seg_bounds.push_back(d.n_words);
+        seg_emits.push_back(n_emits);
+        for (size_t i = 0; i < seg_bounds.size(); i++) {
+            s->seg.push_back(lo);
+            s->seg.push_back(seg_bounds[i]);
+            s->seg_after.push_back(n_emits - seg_emits[i]);
+            lo = seg_bounds[i] + 1;
+            before = seg_emits[i];
+        }
+        (void)before;
+    }
     s->n_rounds = d.n_rounds ? d.n_rounds : 1;
     for (uint32_t r = 0; r < s->n_rounds; r++) {
         s->round_cols[r] = d.n_rounds ? d.round_cols[r] : d.n_cols;
@@ -338,8 +391,10 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
         s->d_small = (uint64_t*)ctx->alloc(small.size() * 8);
         s->d_program = (uint64_t*)ctx->alloc((size_t)(d.n_words ? d.n_words : 1) * 8);
         s->d_l_inv = (uint64_t*)ctx->alloc(((size_t)8 << (log_n + s->qdb)));
-        if (!s->d_small || !s->d_program || !s->d_l_inv) return fail(NLX_E_NOMEM);
+        s->d_seg = (uint32_t*)ctx->alloc(s->seg.size() * 4);
+        if (!s->d_small || !s->d_program || !s->d_l_inv || !s->d_seg) return fail(NLX_E_NOMEM);
         hipError_t e = hipMemcpy(s->d_small, small.data(), small.size() * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->d_seg, s->seg.data(), s->seg.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess && d.n_words) e = hipMemcpy(s->d_program, s->program.data(), (size_t)d.n_words * 8, hipMemcpyHostToDevice);
         if (e != hipSuccess) return fail(ctx->hip_fail(e, "hipMemcpy(tables)"));
         s->d_coset_base = s->d_small;
@@ -400,6 +455,7 @@ void nlx_stark_destroy(nlx_stark* s) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->release(s->d_small);
     ctx->release(s->d_program);
+    ctx->release(s->d_seg);
     ctx->release(s->d_l_inv);
     ctx->release(s->d_periodic);
     for (int i = 0; i <= NLX_MAX_STAGES; i++)
@@ -492,12 +548,18 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
         // ---- compute_quotient_polys ----
         stage("quotient_eval");
         const size_t Q = n << qdb;
-        uint64_t* d_pis = dalloc((values.size() + 1) * 8);
+        // public inputs ++ round challenges, then each segment's alpha^(constraints after it) per challenge
+        const uint32_t n_seg = (uint32_t)s->seg_after.size();
+        const size_t n_values = values.size();
+        for (uint32_t sg = 0; sg < n_seg; sg++)
+            for (uint32_t i = 0; i < 2; i++) values.push_back(gl::pow(alphas[i], s->seg_after[sg]));
+        uint64_t* d_pis = dalloc(values.size() * 8);
         const uint64_t** d_cols = (const uint64_t**)dalloc((size_t)ncols * 8);
         uint64_t* d_qvals = dalloc((size_t)nc * Q * 8);
         uint64_t* d_qchunks = dalloc((size_t)nc * Q * 8);
-        CHECK_ALLOC(d_pis && d_cols && d_qvals && d_qchunks);
-        if (!values.empty()) HIPCHK(hipMemcpyAsync(d_pis, values.data(), values.size() * 8, hipMemcpyHostToDevice, st));
+        uint64_t* d_part = n_seg > 1 ? dalloc((size_t)n_seg * nc * Q * 8) : nullptr;
+        CHECK_ALLOC(d_pis && d_cols && d_qvals && d_qchunks && (n_seg == 1 || d_part));
+        HIPCHK(hipMemcpyAsync(d_pis, values.data(), values.size() * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(d_cols, h_cols.data(), (size_t)ncols * 8, hipMemcpyHostToDevice, st));
         {
             AirParams ap{};
@@ -510,13 +572,17 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
             ap.g_inv = gl::inv(gl::root_of_unity(log_n));
             ap.log_n = log_n; ap.rate_bits = d.rate_bits; ap.qdb = qdb; ap.n_words = d.n_words; ap.nc = nc;
             ap.n_regs = s->n_regs;
+            ap.seg = s->d_seg; ap.seg_mul = d_pis + n_values; ap.part = d_part; ap.n_seg = n_seg;
             // one wave per block: the LDS register file (n_regs x 64 lanes x 8 B) is the occupancy limiter, and
             // single-wave blocks pack the 160 KB of a CU at the finest granularity
             unsigned bs = 64;
             while (bs > n) bs >>= 1;
             const size_t lds = (size_t)bs * s->n_regs * 8;
             ctx->begin_kernel("air_quotient", 8.0 * Q * (2.0 * ncols + nc));
-            hipLaunchKernelGGL(k_air_quotient, dim3((unsigned)(Q / bs)), dim3(bs), lds, st, ap);
+            hipLaunchKernelGGL(k_air_quotient, dim3((unsigned)(Q / bs), n_seg), dim3(bs), lds, st, ap);
+            if (n_seg > 1)
+                hipLaunchKernelGGL(k_air_combine, dim3((unsigned)((nc * Q + 255) / 256)), dim3(256), 0, st, d_part, s->d_q_zh_inv,
+                                   d_qvals, n_seg, nc, log_n, log_n + qdb);
             ctx->end_kernel();
         }
         stage("quotient_intt");

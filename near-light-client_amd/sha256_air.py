@@ -3,30 +3,36 @@
 nearx hashes headers, Merkle nodes and approval messages with `curta_sha256` (nearx/src/variables.rs:71-72,
 nearx/src/merkle.rs:49, nearx/src/builder.rs:220,316); curta proves those hashes with a STARK whose AIR is
 not in the reference (starkyx is un-vendored).  This is an independent AIR for the same function, written
-for the register-program VM of include/nlx.h: one row per round, 64 rows per 512-bit block, all
-constraints of degree <= 3 so the quotient fits two chunks at rate_bits = 1.
+for the register-program VM of include/nlx.h and laid out for the MI355X: a WIDE trace, sixteen rounds per
+row and four rows per 512-bit block, so that every state bit is stored exactly once.  A narrow one-round-per-row
+layout has to carry copies of the working variables and of the message window from row to row (302 columns x 64
+rows = 19 328 cells per block in the first version of this file); here a row sees the sixteen rounds before it
+through the (local, next) window, and a block costs 4 x 1 953 = 7 812 cells - 2.5x less to extend, hash and open.
+All constraints have degree <= 3, so the quotient fits two chunks at rate_bits = 1.
 
-Column layout (bits are LSB first).  Row t of a block holds the working state *before* round t:
+Row layout.  Round slot j (0..15) of a row holds, for round t = 16 q + j of its block (q = row within the block):
 
-    A, B, C, E, F, G   32 bit columns each      D, H  one word column each
-    HIN[8]             the block's input chaining value (constant over the block)
-    WIN[16]            message-schedule window: WIN[j] = W[t + j]
-    W1B, W14B          bits of WIN[1] and WIN[14] (for sigma0 / sigma1)
-    NEW_A, NEW_E       the round's outputs;  CA[3], CE[3] carry bits of the two additions
-    NEW_W              W[t + 16];            CW[2] carry bits
-    CY[8]              carries of HIN + state-after-round-63 (meaningful in the last row of a block)
-    IS_FIRST           1 in round 0 of a block that starts a new message (chaining value = IV)
+    A[32], E[32]    bits of the working variables a_t, e_t produced by round t      (LSB first)
+    W[32]           bits of the schedule word W_t
+    CA[3], CE[3]    carry bits of the two additions of the round;  CW[2] carries of the schedule addition
+    SW              the word the schedule recurrence gives for this slot (equal to W_t in rows q >= 1)
 
-Periodic columns (period 64): K[t] and the last-round selector.  Because the round index is periodic and
-a block boundary either chains or resets to the IV, every transition also holds across the wrap from the
-last row to the first, so all transition-type constraints are plain all-rows constraints (no `x - g^-1`
-filter, which would cost a degree).
+followed by
 
-Soundness notes: every word that is only ever used inside additions (D, H, HIN, WIN[j], NEW_*) may be off
-by a multiple of 2^32 without consequence, because each addition's result is re-derived from boolean bit
-columns and the carries are bounded; bit-for-bit equalities between boolean vectors are enforced as one
-packed-word equality.  Public inputs: the eight words of the last block's output chaining value (the
-digest of the last message).
+    PA[4][32], PE[4][32]   bits of a_{t0-1..t0-4}, e_{t0-1..t0-4} (t0 = 16 q): the state the row starts from
+    HIN[8]                 the block's input chaining value (constant over its four rows)
+    CY[8]                  carries of HIN + final state (meaningful in the last row of a block)
+    IS_FIRST               1 in the first row of a block that starts a new message (chaining value = IV)
+
+Periodic columns (period 4 rows): K_t for each of the sixteen slots, the first-row and last-row selectors.
+The program (15 k instructions) is cut into segments (NLX_AIR_SEGMENT) that the GPU evaluates in parallel.
+Every constraint is an all-rows constraint: a block boundary either chains or resets to the IV, so the relations
+between consecutive rows also hold across the wrap from the last row to the first.
+
+Soundness notes: a word that only ever enters additions (HIN, SW) may be off by a multiple of 2^32 without
+consequence, because every sum is re-derived from boolean bit columns and the carries are bounded; equalities
+between boolean vectors are enforced as packed-word equalities.  Public inputs: the eight words of the last
+block's output chaining value (the digest of the last message).
 """
 import hashlib
 import struct
@@ -35,17 +41,15 @@ import numpy as np
 
 from .stark import Air
 
-A, B, C, E, F, G = 0, 32, 64, 96, 128, 160
-D, H = 192, 193
-HIN = 194
-WIN = 202
-W1B = 218
-W14B = 250
-NEW_A, NEW_E, NEW_W = 282, 283, 284
-CA, CE, CW = 285, 288, 291
-CY = 293
-IS_FIRST = 301
-N_COLS = 302
+SLOT = 105                      # columns per round slot
+oA, oE, oW, oCA, oCE, oCW, oSW = 0, 32, 64, 96, 99, 102, 104
+PA = 16 * SLOT                  # 1680
+PE = PA + 128                   # 1808
+HIN = PE + 128                  # 1936
+CY = HIN + 8                    # 1944
+IS_FIRST = CY + 8               # 1952
+N_COLS = IS_FIRST + 1           # 1953
+ROWS_PER_BLOCK = 4
 
 IV = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
 
@@ -78,19 +82,11 @@ assert K[0] == 0x428a2f98 and K[63] == 0xc67178f2
 
 def sha256_air():
     air = Air(N_COLS, 8)
-    L = air.local
-    N = air.next  # noqa: N806
-    k_t = air.periodic(K)
-    is63 = air.periodic([0] * 63 + [1])
+    L, N = air.local, air.next  # noqa: N806
     two32 = 1 << 32
-
-    def pk(row, base, nbits=32):
-        return air.pack(base, nbits, next_row=(row is N))
-
-    def xor2(x, y):
-        return x + y - 2 * (x * y)
-
-    xor3 = air.xor3
+    k_slot = [air.periodic([K[16 * q + j] for q in range(4)]) for j in range(16)]
+    is_q0 = air.periodic([1, 0, 0, 0])
+    is_q3 = air.periodic([0, 0, 0, 1])
 
     def weighted(terms):
         acc = terms[0]
@@ -98,65 +94,78 @@ def sha256_air():
             acc = acc + terms[i] * (1 << i)
         return acc
 
-    # 1. booleanity
-    for base, cnt in ((A, 192), (W1B, 64), (CA, 8), (CY, 8), (IS_FIRST, 1)):
-        air.constraint_boolean(base, cnt)
-    # 2. the two decomposed schedule words
-    air.constraint(pk(L, W1B) - L(WIN + 1))
-    air.constraint(pk(L, W14B) - L(WIN + 14))
+    # bit vectors of a_t / e_t for t relative to the row start (-4..15), on the local row
+    def a_bits(t):
+        base = t * SLOT + oA if t >= 0 else PA + 32 * (-t - 1)
+        return [L(base + i) for i in range(32)]
 
-    # 3. the round
-    a = [L(A + i) for i in range(32)]
-    b = [L(B + i) for i in range(32)]
-    c = [L(C + i) for i in range(32)]
-    e = [L(E + i) for i in range(32)]
-    f = [L(F + i) for i in range(32)]
-    g = [L(G + i) for i in range(32)]
-    sig1 = weighted([xor3(e[(i + 6) % 32], e[(i + 11) % 32], e[(i + 25) % 32]) for i in range(32)])
-    ch = weighted([air.ch(e[i], f[i], g[i]) for i in range(32)])
-    sig0 = weighted([xor3(a[(i + 2) % 32], a[(i + 13) % 32], a[(i + 22) % 32]) for i in range(32)])
-    maj = weighted([air.maj(a[i], b[i], c[i]) for i in range(32)])
-    t1 = L(H) + sig1 + ch + k_t + L(WIN)
-    air.constraint(L(NEW_A) + pk(L, CA, 3) * two32 - (t1 + sig0 + maj))
-    air.constraint(L(NEW_E) + pk(L, CE, 3) * two32 - (L(D) + t1))
+    def e_bits(t):
+        base = t * SLOT + oE if t >= 0 else PE + 32 * (-t - 1)
+        return [L(base + i) for i in range(32)]
 
-    # 4. message schedule: W[t+16] = s1(W[t+14]) + W[t+9] + s0(W[t+1]) + W[t]
-    w1 = [L(W1B + i) for i in range(32)]
-    w14 = [L(W14B + i) for i in range(32)]
-    s0 = weighted([xor3(w1[(i + 7) % 32], w1[(i + 18) % 32], w1[i + 3]) if i + 3 < 32
-                   else xor2(w1[(i + 7) % 32], w1[(i + 18) % 32]) for i in range(32)])
-    s1 = weighted([xor3(w14[(i + 17) % 32], w14[(i + 19) % 32], w14[i + 10]) if i + 10 < 32
-                   else xor2(w14[(i + 17) % 32], w14[(i + 19) % 32]) for i in range(32)])
-    air.constraint(L(NEW_W) + pk(L, CW, 2) * two32 - (s1 + L(WIN + 9) + s0 + L(WIN)))
+    def a_word(t, row_next=False):
+        return air.pack(t * SLOT + oA if t >= 0 else PA + 32 * (-t - 1), 32, next_row=row_next)
 
-    # 5. inside a block (not after round 63): the state and the window shift
-    nb = 1 - is63
-    pa, pb, pc_, pe, pf, pg = (pk(L, X) for X in (A, B, C, E, F, G))
-    npa, npb, npc, npe, npf, npg = (pk(N, X) for X in (A, B, C, E, F, G))
-    air.constraint(nb * (npb - pa))
-    air.constraint(nb * (npc - pb))
-    air.constraint(nb * (N(D) - pc_))
-    air.constraint(nb * (npf - pe))
-    air.constraint(nb * (npg - pf))
-    air.constraint(nb * (N(H) - pg))
-    air.constraint(nb * (npa - L(NEW_A)))
-    air.constraint(nb * (npe - L(NEW_E)))
+    def e_word(t, row_next=False):
+        return air.pack(t * SLOT + oE if t >= 0 else PE + 32 * (-t - 1), 32, next_row=row_next)
+
+    # schedule words relative to the CURRENT row = `next`; negative indices reach into `local` (the previous row)
+    def w_bits_cur(t):
+        return [N(t * SLOT + oW + i) for i in range(32)] if t >= 0 else [L((16 + t) * SLOT + oW + i) for i in range(32)]
+
+    def w_word_cur(t):
+        return air.pack(t * SLOT + oW, 32, next_row=True) if t >= 0 else air.pack((16 + t) * SLOT + oW, 32)
+
+    # 1. booleanity: all bits of the sixteen slots, the start state, the boundary carries and the flag
+    for j in range(16):
+        air.constraint_boolean(j * SLOT, 104)
+    air.constraint_boolean(PA, 256)
+    air.constraint_boolean(CY, 9)
+
+    # 2. the sixteen rounds of the row
+    for j in range(16):
+        a1, a2, a3 = a_bits(j - 1), a_bits(j - 2), a_bits(j - 3)
+        e1, e2, e3 = e_bits(j - 1), e_bits(j - 2), e_bits(j - 3)
+        sig1 = weighted([air.xor3(e1[(i + 6) % 32], e1[(i + 11) % 32], e1[(i + 25) % 32]) for i in range(32)])
+        ch = weighted([air.ch(e1[i], e2[i], e3[i]) for i in range(32)])
+        sig0 = weighted([air.xor3(a1[(i + 2) % 32], a1[(i + 13) % 32], a1[(i + 22) % 32]) for i in range(32)])
+        maj = weighted([air.maj(a1[i], a2[i], a3[i]) for i in range(32)])
+        t1 = e_word(j - 4) + sig1 + ch + k_slot[j] + air.pack(j * SLOT + oW, 32)
+        air.constraint(a_word(j) + air.pack(j * SLOT + oCA, 3) * two32 - (t1 + sig0 + maj))
+        air.constraint(e_word(j) + air.pack(j * SLOT + oCE, 3) * two32 - (a_word(j - 4) + t1))
+        # in rows q >= 1 the schedule word IS the recurrence's value (row 0 holds the message block)
+        air.constraint((1 - is_q0) * (air.pack(j * SLOT + oW, 32) - L(j * SLOT + oSW)))
+
+    # 3. the schedule recurrence, written on the current (= next) row with the previous row behind it:
+    #    SW_t + 2^32 cw = s1(W[t-2]) + W[t-7] + s0(W[t-15]) + W[t-16]
+    for j in range(16):
+        w2, w15 = w_bits_cur(j - 2), w_bits_cur(j - 15)
+        s0 = weighted([air.xor3(w15[(i + 7) % 32], w15[(i + 18) % 32], w15[i + 3]) if i + 3 < 32
+                       else air.xor3(w15[(i + 7) % 32], w15[(i + 18) % 32], 0) for i in range(32)])
+        s1 = weighted([air.xor3(w2[(i + 17) % 32], w2[(i + 19) % 32], w2[i + 10]) if i + 10 < 32
+                       else air.xor3(w2[(i + 17) % 32], w2[(i + 19) % 32], 0) for i in range(32)])
+        air.constraint(N(j * SLOT + oSW) + air.pack(j * SLOT + oCW, 2, next_row=True) * two32
+                       - (s1 + w_word_cur(j - 7) + s0 + w_word_cur(j - 16)))
+
+    # 4. row to row inside a block: the next row starts from this row's last four rounds; HIN is carried along
+    nb = 1 - is_q3
+    for k in range(4):
+        air.constraint(nb * (a_word(-k - 1, True) - a_word(15 - k)))
+        air.constraint(nb * (e_word(-k - 1, True) - e_word(15 - k)))
     for k in range(8):
         air.constraint(nb * (N(HIN + k) - L(HIN + k)))
-    for j in range(15):
-        air.constraint(nb * (N(WIN + j) - L(WIN + j + 1)))
-    air.constraint(nb * (N(WIN + 15) - L(NEW_W)))
 
-    # 6. block boundary (after round 63): next state = IV if the next block starts a message, else HIN + state
-    out = [L(NEW_A), pa, pb, pc_, L(NEW_E), pe, pf, pg]
-    nxt = [npa, npb, npc, N(D), npe, npf, npg, N(H)]
+    # 5. block boundary (this row is the last of its block): the next block starts from IV or from HIN + final state
+    out = [a_word(15), a_word(14), a_word(13), a_word(12), e_word(15), e_word(14), e_word(13), e_word(12)]
+    nxt = [a_word(-1, True), a_word(-2, True), a_word(-3, True), a_word(-4, True),
+           e_word(-1, True), e_word(-2, True), e_word(-3, True), e_word(-4, True)]
     ho = [L(HIN + k) + out[k] - L(CY + k) * two32 for k in range(8)]
     for k in range(8):
-        air.constraint(is63 * (nxt[k] - ho[k] - N(IS_FIRST) * (IV[k] - ho[k])))
-        air.constraint(is63 * (N(HIN + k) - nxt[k]))
+        air.constraint(is_q3 * (nxt[k] - ho[k] - N(IS_FIRST) * (IV[k] - ho[k])))
+        air.constraint(is_q3 * (N(HIN + k) - nxt[k]))
 
-    # 7. first row starts a message; 8. the last row's output chaining value is the public digest
-    cur = [pa, pb, pc_, L(D), pe, pf, pg, L(H)]
+    # 6. the first row starts a message; 7. the last row's output chaining value is the public digest
+    cur = [a_word(-1), a_word(-2), a_word(-3), a_word(-4), e_word(-1), e_word(-2), e_word(-3), e_word(-4)]
     air.constraint_first_row(L(IS_FIRST) - 1)
     for k in range(8):
         air.constraint_first_row(cur[k] - IV[k])
@@ -203,60 +212,84 @@ def _rotr(x, r):
     return ((x >> r) | (x << (32 - r))) & 0xFFFFFFFF
 
 
+def _s0(x):
+    return _rotr(x, 7) ^ _rotr(x, 18) ^ (x >> 3)
+
+
+def _s1(x):
+    return _rotr(x, 17) ^ _rotr(x, 19) ^ (x >> 10)
+
+
+def _schedule(block):
+    w = [int(x) for x in block]
+    for i in range(16, 64):
+        w.append((w[i - 16] + _s0(w[i - 15]) + w[i - 7] + _s1(w[i - 2])) & 0xFFFFFFFF)
+    return w
+
+
 def reference_trace(blocks, is_first):
-    """(N_COLS, 64 * n_blocks) trace, plain Python.  Mirrors the column semantics documented above."""
+    """(N_COLS, 4 * n_blocks) trace, plain Python.  Mirrors the column semantics documented above."""
     nb = len(blocks)
-    n = 64 * nb
+    n = ROWS_PER_BLOCK * nb
     t = np.zeros((N_COLS, n), dtype=np.uint64)
 
     def put_bits(base, row, v, cnt=32):
         for i in range(cnt):
             t[base + i, row] = (v >> i) & 1
 
+    scheds = [_schedule(b) for b in blocks]
     h = list(IV)
     for bi in range(nb):
-        if is_first[bi]:
+        if is_first[bi] or bi == 0:
             h = list(IV)
-        w = [int(x) for x in blocks[bi]]
-        for i in range(16, 80):
-            x1, x14 = w[i - 15], w[i - 2]
-            s0 = _rotr(x1, 7) ^ _rotr(x1, 18) ^ (x1 >> 3)
-            s1 = _rotr(x14, 17) ^ _rotr(x14, 19) ^ (x14 >> 10)
-            w.append((w[i - 16] + s0 + w[i - 7] + s1) & 0xFFFFFFFF)
-        a, b, c, d, e, f, g, hh = h
+        w = scheds[bi]
+        wprev = scheds[bi - 1]                       # the recurrence of row 0 looks back into the previous block (cyclic)
+        # a[t + 4], e[t + 4] for t = -4..63
+        a = [h[3], h[2], h[1], h[0]]
+        e = [h[7], h[6], h[5], h[4]]
+        ca, ce = [], []
         for r in range(64):
-            row = 64 * bi + r
-            for base, v in ((A, a), (B, b), (C, c), (E, e), (F, f), (G, g)):
-                put_bits(base, row, v)
-            t[D, row], t[H, row] = d, hh
+            a1, a2, a3, a4 = a[-1], a[-2], a[-3], a[-4]
+            e1, e2, e3, e4 = e[-1], e[-2], e[-3], e[-4]
+            s1 = _rotr(e1, 6) ^ _rotr(e1, 11) ^ _rotr(e1, 25)
+            ch = (e1 & e2) ^ (~e1 & e3 & 0xFFFFFFFF)
+            s0 = _rotr(a1, 2) ^ _rotr(a1, 13) ^ _rotr(a1, 22)
+            mj = (a1 & a2) ^ (a1 & a3) ^ (a2 & a3)
+            t1 = e4 + s1 + ch + K[r] + w[r]
+            sa, se = t1 + s0 + mj, a4 + t1
+            a.append(sa & 0xFFFFFFFF)
+            e.append(se & 0xFFFFFFFF)
+            ca.append(sa >> 32)
+            ce.append(se >> 32)
+        for q in range(4):
+            row = 4 * bi + q
+            for j in range(16):
+                r = 16 * q + j
+                base = j * SLOT
+                put_bits(base + oA, row, a[r + 4])
+                put_bits(base + oE, row, e[r + 4])
+                put_bits(base + oW, row, w[r])
+                put_bits(base + oCA, row, ca[r], 3)
+                put_bits(base + oCE, row, ce[r], 3)
+                ext = (wprev[48:] + w) if q == 0 else None   # W[-16..-1] of row 0 = previous block's W[48..63]
+                if q == 0:
+                    wm = lambda k: ext[16 + k]               # noqa: E731  k in -16..15
+                    sw = _s1(wm(j - 2)) + wm(j - 7) + _s0(wm(j - 15)) + wm(j - 16)
+                else:
+                    sw = _s1(w[r - 2]) + w[r - 7] + _s0(w[r - 15]) + w[r - 16]
+                t[base + oSW, row] = sw & 0xFFFFFFFF
+                put_bits(base + oCW, row, sw >> 32, 2)
+            for k in range(4):
+                put_bits(PA + 32 * k, row, a[16 * q + 4 - 1 - k])
+                put_bits(PE + 32 * k, row, e[16 * q + 4 - 1 - k])
             for k in range(8):
                 t[HIN + k, row] = h[k]
-            for j in range(16):
-                t[WIN + j, row] = w[r + j]
-            put_bits(W1B, row, w[r + 1])
-            put_bits(W14B, row, w[r + 14])
-            s1 = _rotr(e, 6) ^ _rotr(e, 11) ^ _rotr(e, 25)
-            ch = (e & f) ^ (~e & g & 0xFFFFFFFF)
-            s0 = _rotr(a, 2) ^ _rotr(a, 13) ^ _rotr(a, 22)
-            mj = (a & b) ^ (a & c) ^ (b & c)
-            t1 = hh + s1 + ch + K[r] + w[r]
-            sa, se = t1 + s0 + mj, d + t1
-            na, ne = sa & 0xFFFFFFFF, se & 0xFFFFFFFF
-            t[NEW_A, row], t[NEW_E, row] = na, ne
-            put_bits(CA, row, sa >> 32, 3)
-            put_bits(CE, row, se >> 32, 3)
-            x1, x14 = w[r + 1], w[r + 14]
-            sw = (_rotr(x14, 17) ^ _rotr(x14, 19) ^ (x14 >> 10)) + w[r + 9] + (_rotr(x1, 7) ^ _rotr(x1, 18) ^ (x1 >> 3)) + w[r]
-            t[NEW_W, row] = sw & 0xFFFFFFFF
-            put_bits(CW, row, sw >> 32, 2)
-            if r == 0:
-                t[IS_FIRST, row] = int(is_first[bi])
-            if r == 63:
-                out = [na, a, b, c, ne, e, f, g]
-                for k in range(8):
-                    t[CY + k, row] = (h[k] + out[k]) >> 32
-                h = [(h[k] + out[k]) & 0xFFFFFFFF for k in range(8)]
-            a, b, c, d, e, f, g, hh = na, a, b, c, ne, e, f, g
+            if q == 0:
+                t[IS_FIRST, row] = 1 if (is_first[bi] or bi == 0) else 0
+        fin = [a[67], a[66], a[65], a[64], e[67], e[66], e[65], e[64]]
+        for k in range(8):
+            t[CY + k, 4 * bi + 3] = (h[k] + fin[k]) >> 32
+        h = [(h[k] + fin[k]) & 0xFFFFFFFF for k in range(8)]
     return t, np.array(h, dtype=np.uint64)
 
 
@@ -264,11 +297,16 @@ class Sha256Prover:
     """Proves SHA-256 of a batch of messages on one GPU: trace generation (nlx_sha256_trace) straight into
     HBM, then nlx_stark_prove on the device-resident trace.  2^log_blocks compression blocks per proof."""
 
-    def __init__(self, ctx, log_blocks, config=None):
+    def __init__(self, ctx, log_blocks, config=None, segment_nodes=None):
         from .stark import Stark
         self.ctx = ctx
         self.log_blocks = log_blocks
-        self.stark = Stark(sha256_air(), log_blocks + 6, config)
+        if log_blocks < 2:
+            raise ValueError("at least four blocks per proof (a block is four trace rows, a STARK at least sixteen)")
+        air = sha256_air()
+        if segment_nodes is not None:
+            air.segment_nodes = segment_nodes
+        self.stark = Stark(air, log_blocks + 2, config)
         self.prover = self.stark.build(ctx)
         self._trace = None
 
@@ -280,7 +318,7 @@ class Sha256Prover:
         is_first = np.ascontiguousarray(is_first, dtype=np.uint8)
         if blocks.shape != (1 << self.log_blocks, 16) or is_first.shape != (1 << self.log_blocks,):
             raise ValueError("expected 2^%d blocks" % self.log_blocks)
-        n = 64 << self.log_blocks
+        n = ROWS_PER_BLOCK << self.log_blocks
         if self._trace is None:
             self._trace = torch.empty((N_COLS, n), dtype=torch.int64, device="cuda:%d" % self.ctx.device)
         digest = np.zeros(8, dtype=np.uint64)

@@ -20,12 +20,14 @@ from ._lib import dll, ptr, NlxError
 P = 0xFFFFFFFF00000001
 (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_CONST, AIR_ADD, AIR_SUB, AIR_MUL, AIR_EMIT_TRANSITION, AIR_EMIT_FIRST,
  AIR_EMIT_LAST, AIR_EMIT, AIR_PERIODIC, AIR_PACK_LOCAL, AIR_PACK_NEXT, AIR_EMIT_BOOL, AIR_LOADV, AIR_XOR3, AIR_CH,
- AIR_MAJ) = range(19)
+ AIR_MAJ, AIR_SEGMENT) = range(20)
 _AIR_BINARY = (AIR_ADD, AIR_SUB, AIR_MUL)
 _AIR_TERNARY = (AIR_XOR3, AIR_CH, AIR_MAJ)
 AIR_NUM_REGS = 64
 AIR_MAX_RESIDENT_LEAVES = 12   # loads kept in registers (LRU) before they are re-loaded
 AIR_LOAD_BATCH = 8             # loads issued together (NLX_AIR_LOADV): memory-level parallelism of the VM
+AIR_SEGMENT_NODES = 1024       # arithmetic nodes per program segment (NLX_AIR_SEGMENT): the GPU runs segments in parallel
+AIR_MAX_SEGMENTS = 256
 
 
 class StarkDesc(ctypes.Structure):
@@ -131,6 +133,7 @@ class Air:
             if not 1 <= len(rounds) <= 3 or sum(c for c, _ in rounds) != n_cols or any(c < 1 for c, _ in rounds):
                 raise ValueError("rounds must split the columns into 1..3 non-empty groups")
         self._emits = []  # (op, expr)
+        self.segment_nodes = AIR_SEGMENT_NODES
         self._leaf_cache = {}
         self.period_bits = 0
         self._periodic = []  # value arrays, each of length 2^period_bits
@@ -234,7 +237,7 @@ class Air:
         q = max(1, self.constraint_degree - 1)
         return 1 << (q - 1).bit_length()
 
-    def compile(self):
+    def compile(self, segment_nodes=None):
         """Flatten the DAG into program words.
 
         * Shared sub-expressions (ADD / SUB / MUL nodes) and PACK words are computed once and stay in their
@@ -245,17 +248,56 @@ class Air:
         * Loads are issued in batches: at a miss the assembler looks ahead in the constraint for the next
           loads it will need and emits them together behind one NLX_AIR_LOADV hint, so the kernel has up to
           AIR_LOAD_BATCH loads in flight per lane instead of one.
+        * A long program is cut into segments (NLX_AIR_SEGMENT) of about `segment_nodes` arithmetic nodes
+          (default: self.segment_nodes; 0 = one segment): no register is live across a boundary, so the GPU can
+          evaluate the segments of one point on different waves.
         Constraints are emitted in declaration order (that order defines the alpha powers for prover and
         verifier alike)."""
         ops = _AIR_BINARY + _AIR_TERNARY
         packs = (AIR_PACK_LOCAL, AIR_PACK_NEXT)
-        batchable = (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_PERIODIC)
 
         def is_value(x):
             return x.op in ops or x.op in packs
 
+        # cut the constraint list into segments of about `segment_nodes` arithmetic nodes; a shared
+        # sub-expression is recomputed in every segment that uses it
+        budget = self.segment_nodes if segment_nodes is None else segment_nodes
+
+        def new_nodes(emit, seen):
+            eop, root, cnt = emit
+            if eop == AIR_EMIT_BOOL:
+                return cnt, []
+            fresh, stack = [], [root]
+            while stack:
+                x = stack.pop()
+                if is_value(x) and id(x) not in seen:
+                    seen.add(id(x))
+                    fresh.append(x)
+                    stack.extend(x.operands())
+            return len(fresh), fresh
+
+        segments, cur, cur_cost, seen = [], [], 0, set()
+        for emit in self._emits:
+            cost, fresh = new_nodes(emit, seen)
+            if budget and cur and cur_cost + cost > budget and len(segments) < AIR_MAX_SEGMENTS - 1:
+                segments.append(cur)
+                cur, cur_cost, seen = [], 0, set()
+                cost, fresh = new_nodes(emit, seen)   # nothing is shared with the previous segment any more
+            cur.append(emit)
+            cur_cost += cost
+        segments.append(cur)
+        words = []
+        for i, seg in enumerate(segments):
+            if i:
+                words.append(AIR_SEGMENT)
+            words += self._compile_segment(seg, is_value, packs)
+        return np.array(words, dtype=np.uint64)
+
+    def _compile_segment(self, emits, is_value, packs):
+        """Program words of one segment (register allocation starts from an empty register file)."""
+        batchable = (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_PERIODIC)
         computed, per_emit, all_vals = set(), [], []
-        for eop, root, _ in self._emits:
+        for eop, root, _ in emits:
             if eop == AIR_EMIT_BOOL:
                 per_emit.append([])
                 continue
@@ -281,7 +323,7 @@ class Air:
             for y in x.operands():
                 if is_value(y):
                     y.uses += 1
-        for eop, root, _ in self._emits:
+        for eop, root, _ in emits:
             if eop != AIR_EMIT_BOOL and is_value(root):
                 root.uses += 1
 
@@ -374,7 +416,7 @@ class Air:
                 if not is_value(y):
                     resident[:] = [q for q in resident if q is not y]
 
-        for (op, root, cnt), nodes in zip(self._emits, per_emit):
+        for (op, root, cnt), nodes in zip(emits, per_emit):
             if op == AIR_EMIT_BOOL:
                 words.append(AIR_EMIT_BOOL | root.a << 24 | cnt << 40)
                 continue
@@ -412,7 +454,7 @@ class Air:
             words.append(op | ensure(root, (), leaf_seq[pos:]) << 24)
             release(root)
             assert not resident
-        return np.array(words, dtype=np.uint64)
+        return words
 
 
 class Stark:

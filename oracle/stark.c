@@ -356,6 +356,7 @@ static void air_eval_base(const orc_stark_desc* d, const uint64_t* local, const 
             case ORC_AIR_EMIT_FIRST: c = gl_mul(reg[a % AIR_REGS], l_first); emit = 1; break;
             case ORC_AIR_EMIT_LAST: c = gl_mul(reg[a % AIR_REGS], l_last); emit = 1; break;
             case ORC_AIR_EMIT: c = reg[a % AIR_REGS]; emit = 1; break;
+            case ORC_AIR_SEGMENT: memset(reg, 0, sizeof reg); break;
             default: break;
         }
         if (emit)
@@ -414,6 +415,9 @@ static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* n
             case ORC_AIR_EMIT_FIRST: c = gl2_mul(reg[a % AIR_REGS], l_first); emit = 1; break;
             case ORC_AIR_EMIT_LAST: c = gl2_mul(reg[a % AIR_REGS], l_last); emit = 1; break;
             case ORC_AIR_EMIT: c = reg[a % AIR_REGS]; emit = 1; break;
+            case ORC_AIR_SEGMENT:
+                for (int i = 0; i < AIR_REGS; i++) reg[i] = gl2_from(0);
+                break;
             default: break;
         }
         if (emit)
@@ -421,7 +425,7 @@ static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* n
     }
 }
 
-#define ORC_MAX_PERIODIC 16
+#define ORC_MAX_PERIODIC 32
 /* interpolation of each periodic column over the period-th roots of unity (coefficients, natural order) */
 static uint64_t* periodic_coeffs(const orc_stark_desc* d) {
     if (!d->n_periodic) return NULL;
@@ -468,7 +472,7 @@ static int desc_ok(const orc_stark_desc* d) {
                 break;
             case ORC_AIR_EMIT_BOOL: if (AIR_A(w) + (AIR_B(w) ? AIR_B(w) : 1) > d->n_cols) return 0; break;
             case ORC_AIR_CONST: if (++pc >= d->n_words) return 0; break;
-            default: if (AIR_OP(w) > ORC_AIR_MAJ) return 0;
+            default: if (AIR_OP(w) > ORC_AIR_SEGMENT) return 0;
         }
     }
     return 1;

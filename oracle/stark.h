@@ -59,7 +59,8 @@ enum {
     /* three-operand forms for bit-valued columns; the third register is in bits 56..61 */
     ORC_AIR_XOR3 = 16,           /* dst = a ^ b ^ c as a polynomial: s = a + b - 2ab, dst = s + c - 2sc */
     ORC_AIR_CH = 17,             /* dst = c + a (b - c)            (choose: a ? b : c) */
-    ORC_AIR_MAJ = 18             /* dst = ab + c (a + b - 2ab)     (majority) */
+    ORC_AIR_MAJ = 18,            /* dst = ab + c (a + b - 2ab)     (majority) */
+    ORC_AIR_SEGMENT = 19         /* no register is carried across this word (registers are cleared here) */
 };
 /* ADD / SUB carry a shift in bits 56..61 of the word: dst = r[a] +- r[b] * 2^shift. */
 

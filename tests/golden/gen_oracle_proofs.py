@@ -38,12 +38,12 @@ def cases():
         proof = orc.stark_prove(st.desc, t, pis)
         assert orc.stark_verify(st.desc, proof) == 1
         out[name] = {"bytes": len(proof), "sha256": hashlib.sha256(proof).hexdigest(), "program_words": int(st.desc.n_words)}
-    blocks, first, digest = SA.blocks_for_messages([b"abc", b"near light client"], 1)
+    blocks, first, digest = SA.blocks_for_messages([b"abc", b"near light client" * 4], 2)
     t, _ = SA.reference_trace(blocks, first)
-    st = S.Stark(SA.sha256_air(), 7)
+    st = S.Stark(SA.sha256_air(), 4)
     proof = orc.stark_prove(st.desc, t, digest)
     assert orc.stark_verify(st.desc, proof) == 1
-    out["stark_sha256_2_blocks"] = {"bytes": len(proof), "sha256": hashlib.sha256(proof).hexdigest(),
+    out["stark_sha256_4_blocks"] = {"bytes": len(proof), "sha256": hashlib.sha256(proof).hexdigest(),
                                     "program_words": int(st.desc.n_words)}
     return out
 

@@ -110,11 +110,38 @@ def test_stark_build_rejects_bad_programs(nlx, ctx):
     with pytest.raises(nlx.NlxError):
         build_with([S.AIR_CONST | 0 << 8])                            # CONST without immediate
     with pytest.raises(nlx.NlxError):
-        build_with([11])                                              # unknown opcode
+        build_with([20])                                              # unknown opcode
+    with pytest.raises(nlx.NlxError):                                 # a register carried across a segment boundary
+        build_with([S.AIR_LOCAL | 0 << 8, S.AIR_SEGMENT, S.AIR_EMIT | 0 << 24])
+    with pytest.raises(nlx.NlxError):
+        build_with([S.AIR_SEGMENT | 1 << 8])                          # operands on a boundary word
+    with pytest.raises(nlx.NlxError):
+        build_with([S.AIR_SEGMENT] * 256)                             # more than NLX_AIR_MAX_SEGMENTS segments
+    build_with([S.AIR_SEGMENT] + good + [S.AIR_SEGMENT, S.AIR_SEGMENT]).close()   # empty segments are legal
     with pytest.raises(nlx.NlxError):
         build_with(good, quotient_degree_factor=4)                    # > 2^rate_bits
     with pytest.raises(nlx.NlxError):
         build_with(good, quotient_degree_factor=3)                    # not a power of two
+
+
+@pytest.mark.parametrize("kind,db,seg,cfg", [("wide24", 6, 4, {}), ("wide96", 7, 16, {}), ("wide96", 10, 64, dict(num_challenges=1)),
+                                             ("fib", 5, 1, {}), ("periodic", 9, 2, dict(rate_bits=2))])
+def test_segmented_programs_bytes_equal_oracle(nlx, ctx, orc, kind, db, seg, cfg):
+    """The same AIR cut into program segments (NLX_AIR_SEGMENT; the GPU runs them on different waves and adds
+    the partial sums) proves to the same bytes as the unsegmented program, on the GPU and on the oracle."""
+    S = nlx.stark
+    air, t, pis = make_case(S, kind, db)
+    air.segment_nodes = 0
+    whole = S.Stark(air, db, S.StarkConfig(**cfg))
+    air.segment_nodes = seg
+    cut = S.Stark(air, db, S.StarkConfig(**cfg))
+    assert len(cut.program) > len(whole.program)
+    want = orc.stark_prove(whole.desc, t, pis)
+    assert orc.stark_prove(cut.desc, t, pis) == want
+    for st in (whole, cut):
+        pr = st.build(ctx)
+        assert pr.prove(t, pis) == want
+        pr.close()
 
 
 def _random_air(S, rng, n_cols, n_pis, with_periodic):

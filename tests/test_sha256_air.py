@@ -1,4 +1,4 @@
-"""SHA-256 compression AIR.  CPU part: the AIR's reference trace computes real SHA-256
+"""SHA-256 compression AIR (sixteen rounds per row, four rows per block).  CPU part: the AIR's reference trace computes real SHA-256
 (hashlib; and the reference's own pinned header hash), satisfies every constraint row by row, and the
 oracle's STARK verifier accepts / rejects as it should.  GPU part: the trace generated on the GPU equals
 the reference trace bit for bit and the GPU proof bytes equal the oracle's."""
@@ -24,6 +24,22 @@ def test_round_constants_and_padding(nlx):
     assert SA.pad_message(b"abc")[0][0] == 0x61626380 and SA.pad_message(b"abc")[0][15] == 24
 
 
+def _word(t, base, row):
+    return sum(int(t[base + i, row]) << i for i in range(32))
+
+
+def _block_output(SA, t, blk):
+    """HIN + the state after round 63, read from the last row of block `blk`."""
+    row = 4 * blk + 3
+    fin = [_word(t, (15 - k) * SA.SLOT + SA.oA, row) for k in range(4)] + [_word(t, (15 - k) * SA.SLOT + SA.oE, row) for k in range(4)]
+    return [(int(t[SA.HIN + k, row]) + fin[k]) & 0xFFFFFFFF for k in range(8)]
+
+
+def _periodic_values(SA, row):
+    q = row % 4
+    return [SA.K[16 * q + j] for j in range(16)] + [1 if q == 0 else 0, 1 if q == 3 else 0]
+
+
 def test_reference_trace_is_sha256_and_satisfies_air(nlx):
     SA = nlx.sha256_air
     msgs = _messages()
@@ -31,26 +47,21 @@ def test_reference_trace_is_sha256_and_satisfies_air(nlx):
     assert all(first[:7] == 1) and first.tolist()[7:] == [1, 1, 0, 1, 1, 1, 0, 1, 0]   # seven filler blocks come first
     assert [int(x) for x in digest] == list(struct.unpack(">8I", hashlib.sha256(msgs[-1]).digest()))
     t, hout = SA.reference_trace(blocks, first)
-    assert t.shape == (SA.N_COLS, 1024) and int(t.max()) < 2 ** 32
+    assert t.shape == (SA.N_COLS, 64) and int(t.max()) < 2 ** 32
     # the chaining value after each message's last block is hashlib's digest
     b = 7
     for m in msgs:
         nb = len(SA.pad_message(m))
-        row = 64 * (b + nb - 1) + 63
-        out_cols = [int(t[SA.NEW_A, row])] + [sum(int(t[base + i, row]) << i for i in range(32)) for base in (SA.A, SA.B, SA.C)]
-        out_cols += [int(t[SA.NEW_E, row])] + [sum(int(t[base + i, row]) << i for i in range(32)) for base in (SA.E, SA.F, SA.G)]
-        got = [(int(t[SA.HIN + k, row]) + out_cols[k]) & 0xFFFFFFFF for k in range(8)]
-        assert got == list(struct.unpack(">8I", hashlib.sha256(m).digest())), m
+        assert _block_output(SA, t, b + nb - 1) == list(struct.unpack(">8I", hashlib.sha256(m).digest())), m
         b += nb
     assert [int(x) for x in hout] == [int(x) for x in digest]
     # every constraint vanishes on every row (all-rows constraints also across the wrap n-1 -> 0)
     air = SA.sha256_air()
     words = air.compile()
-    per = [np.array(SA.K, dtype=np.uint64), np.array([0] * 63 + [1], dtype=np.uint64)]
     n = t.shape[1]
-    rows = list(range(0, 3)) + [62, 63, 64, 65, 127, 128, 191, 192, 300, n - 2, n - 1]
-    for i in rows:
-        vals = run_program(words, t[:, i], t[:, (i + 1) % n], digest, periodic=[int(c[i % 64]) for c in per])
+    for i in list(range(0, 9)) + [27, 28, 35, 36, 39, 40, n - 2, n - 1]:
+        vals = run_program(words, t[:, i], t[:, (i + 1) % n], digest, periodic=_periodic_values(SA, i))
+        assert len(vals) == 2042
         for op, v in vals:
             if (op == 8 and i != 0) or (op == 9 and i != n - 1):
                 continue
@@ -67,30 +78,35 @@ def test_header_hash_through_the_air(nlx):
     blocks, first, digest = SA.blocks_for_messages(msgs)
     t, hout = SA.reference_trace(blocks, first)
     # messages are [inner_lite, inner_lite_hash || inner_rest_hash, that_hash || prev_hash]; filler blocks come
-    # first, so the last row's output chaining value - the AIR's public digest - is the header hash
-    row = t.shape[1] - 1
+    # first, so the last block's output chaining value - the AIR's public digest - is the header hash
     assert bytes(b"".join(struct.pack(">I", int(x)) for x in digest)).hex().startswith("63b87190")
-    words = [int(t[SA.NEW_A, row])] + [sum(int(t[base + i, row]) << i for i in range(32)) for base in (SA.A, SA.B, SA.C)]
-    words += [int(t[SA.NEW_E, row])] + [sum(int(t[base + i, row]) << i for i in range(32)) for base in (SA.E, SA.F, SA.G)]
-    got = b"".join(struct.pack(">I", (int(t[SA.HIN + k, row]) + words[k]) & 0xFFFFFFFF) for k in range(8))
+    got = b"".join(struct.pack(">I", x) for x in _block_output(SA, t, len(blocks) - 1))
     assert got.hex() == "63b87190ffbaa36d7dab50f918fe36f70ab26910a0e9d797161e2356561598e3"
 
 
 def test_oracle_stark_on_sha256(nlx, orc):
     SA, S = nlx.sha256_air, nlx.stark
-    blocks, first, digest = SA.blocks_for_messages(_messages()[:3], 2)
+    blocks, first, digest = SA.blocks_for_messages(_messages()[:3], 2)     # abc | 100 bytes (2 blocks) | empty
+    assert first.tolist() == [1, 1, 0, 1]
     t, _ = SA.reference_trace(blocks, first)
-    st = S.Stark(SA.sha256_air(), 8)
-    assert st.desc.quotient_degree_factor == 2 and st.desc.n_periodic == 2 and st.desc.period_bits == 6
+    st = S.Stark(SA.sha256_air(), 4)
+    assert st.desc.quotient_degree_factor == 2 and st.desc.n_periodic == 18 and st.desc.period_bits == 2
     proof = orc.stark_prove(st.desc, t, digest)
     assert orc.stark_verify(st.desc, proof) == 1
-    for col, row in ((SA.E + 3, 70), (SA.CA, 5), (SA.WIN + 4, 64), (SA.IS_FIRST, 64), (SA.CY + 2, 127), (SA.CY + 5, 255), (SA.HIN, 100)):  # row 127: block 1 chains into block 2
+    slot = SA.SLOT
+    tampered = [(3 * slot + SA.oE + 3, 5), (SA.oA + 31, 0), (9 * slot + SA.oCA, 6), (2 * slot + SA.oCE + 1, 9), (4 * slot + SA.oW + 4, 5),
+                (4 * slot + SA.oSW, 6), (slot + SA.oCW, 13), (SA.PA + 40, 2), (SA.PE + 127, 15), (SA.IS_FIRST, 8), (SA.IS_FIRST, 4),
+                (SA.CY + 2, 7), (SA.CY + 5, 15), (SA.HIN, 9), (SA.HIN + 7, 12)]   # row 7: block 1 chains into block 2
+    for col, row in tampered:
         t2 = t.copy()
         t2[col, row] = (int(t2[col, row]) + 1) % P
         assert orc.stark_verify(st.desc, orc.stark_prove(st.desc, t2, digest)) != 1, (col, row)
     d2 = digest.copy()
     d2[7] ^= np.uint64(1)
     assert orc.stark_verify(st.desc, orc.stark_prove(st.desc, t, d2)) != 1
+    # a different message in row 0 of a block (free columns) is a different statement: the digest no longer matches
+    t3, _ = SA.reference_trace(SA.blocks_for_messages([b"abd", bytes(range(100)), b"x"], 2)[0], first)
+    assert orc.stark_verify(st.desc, orc.stark_prove(st.desc, t3, digest)) != 1
 
 
 @pytest.mark.gpu
@@ -110,13 +126,12 @@ def test_gpu_trace_equals_reference(nlx, ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("log_blocks", [0, 2, 5])
+@pytest.mark.parametrize("log_blocks", [2, 3, 6])
 def test_gpu_sha256_proof_bytes_equal_oracle(nlx, ctx, orc, log_blocks):
     SA = nlx.sha256_air
     rng = np.random.default_rng(log_blocks)
     msgs = [bytes(rng.integers(0, 256, int(rng.integers(0, 120)), dtype=np.uint8)) for _ in range(max(1, (1 << log_blocks) // 2))]
-    msgs = msgs[:1] if log_blocks == 0 else msgs
-    if log_blocks == 0:
+    if log_blocks == 2:
         msgs = [b"abc"]
     sp = SA.Sha256Prover(ctx, log_blocks)
     proof, digest = sp.prove(msgs)
@@ -134,7 +149,7 @@ def test_gpu_sha256_proof_bytes_equal_oracle(nlx, ctx, orc, log_blocks):
 
 @pytest.mark.gpu
 def test_gpu_sha256_1024_blocks_verifies(nlx, ctx, orc):
-    """2^10 blocks (65 536 rows x 302 columns): oracle verifier accepts, digest = hashlib."""
+    """2^10 blocks (4 096 rows x 1 953 columns): oracle verifier accepts, digest = hashlib."""
     SA = nlx.sha256_air
     rng = np.random.default_rng(7)
     msgs = [bytes(rng.integers(0, 256, 64, dtype=np.uint8)) for _ in range(512)]  # Merkle-node sized: 2 blocks each

@@ -33,6 +33,7 @@ def run_program(words, local, nxt, pis, periodic=()):
             for i in range(max(b, 1)):
                 out.append((10, int(local[a + i]) * (int(local[a + i]) - 1) % P))
         elif op == 15: pass  # LOADV: scheduling hint
+        elif op == 19: reg = {}  # SEGMENT: nothing is carried across
         elif op in (16, 17, 18):
             x, y, z = reg[a], reg[b], reg[sh]
             if op == 17: reg[dst] = (z + x * (y - z)) % P
@@ -336,3 +337,21 @@ def test_multi_round_logup_oracle(nlx, orc):
     # a classic single-round prove call refuses a multi-round descriptor
     with pytest.raises(RuntimeError):
         orc.stark_prove(st.desc, np.zeros((6, 128), dtype=np.uint64), [])
+
+
+def test_program_segments_do_not_change_the_proof(nlx, orc):
+    """NLX_AIR_SEGMENT boundaries (no register carried across; shared sub-expressions recomputed per segment) leave
+    every constraint value, and so the proof bytes, unchanged."""
+    S = nlx.stark
+    for kind, db in (("wide24", 6), ("wide96", 7), ("fib", 5), ("periodic", 6)):
+        air, t, pis = make_case(S, kind, db)
+        proofs, sizes = [], []
+        for seg in (0, 1, 16, 1024):
+            air.segment_nodes = seg
+            st = S.Stark(air, db)
+            sizes.append(len(st.program))
+            proofs.append(orc.stark_prove(st.desc, t, pis))
+            assert orc.stark_verify(st.desc, proofs[-1]) == 1
+            row = run_program(st.program, t[:, 3], t[:, 4], pis, periodic=[int(c[3 % len(c)]) for c in air._periodic])
+            assert len(row) == air.num_constraints
+        assert all(p == proofs[0] for p in proofs) and sizes[1] > sizes[0]
