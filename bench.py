@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark", "sha256"])
+    ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark", "sha256", "sha512"])
     ap.add_argument("--log-blocks", type=int, default=14, help="sha256 workload: 2^k compression blocks per proof")
     ap.add_argument("--segment-nodes", type=int, default=None, help="sha256 workload: AIR program segment size (0 = one segment)")
     ap.add_argument("--stark-cols", type=int, default=256)
@@ -365,26 +365,41 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
     import hashlib
     import struct
     import numpy as np
-    SA = nlx.sha256_air
+    wide = args.workload == "sha512"
+    SA = nlx.sha512_air if wide else nlx.sha256_air
     rng = np.random.default_rng(5 + rank)
     n_blocks = 1 << args.log_blocks
-    n_msgs = max(1, n_blocks // 2)
-    raw = rng.integers(0, 256, (n_msgs, 64), dtype=np.uint8)
-    # padded blocks of a 64-byte message: the message, then 0x80 .. length 512
-    pad = np.zeros((n_msgs, 64), dtype=np.uint8)
-    pad[:, 0] = 0x80
-    pad[:, 62] = 0x02
     if args.log_blocks < 2:
         raise SystemExit("--log-blocks must be >= 2 (a block is four trace rows)")
-    blocks = np.concatenate([raw, pad], axis=1).reshape(n_msgs * 2, 64).view(">u4").astype(np.uint32)
-    first = np.tile(np.array([1, 0], dtype=np.uint8), n_msgs)
-    want = np.array(struct.unpack(">8I", hashlib.sha256(raw[-1].tobytes()).digest()), dtype=np.uint64)
+    if wide:
+        # one block per message: R || A || approval message = 105 bytes, the SHA-512 of an Ed25519 check
+        n_msgs, msg_len = n_blocks, 105
+        raw = rng.integers(0, 256, (n_msgs, msg_len), dtype=np.uint8)
+        pad = np.zeros((n_msgs, 128 - msg_len), dtype=np.uint8)
+        pad[:, 0] = 0x80
+        pad[:, -2], pad[:, -1] = (8 * msg_len) >> 8, (8 * msg_len) & 0xFF
+        blocks = np.concatenate([raw, pad], axis=1).reshape(n_msgs, 128).view(">u8").astype(np.uint64)
+        first = np.ones(n_msgs, dtype=np.uint8)
+        want = np.array(struct.unpack(">8Q", hashlib.sha512(raw[-1].tobytes()).digest()), dtype=np.uint64)
+    else:
+        n_msgs, msg_len = max(1, n_blocks // 2), 64
+        raw = rng.integers(0, 256, (n_msgs, 64), dtype=np.uint8)
+        # padded blocks of a 64-byte message: the message, then 0x80 .. length 512
+        pad = np.zeros((n_msgs, 64), dtype=np.uint8)
+        pad[:, 0] = 0x80
+        pad[:, 62] = 0x02
+        blocks = np.concatenate([raw, pad], axis=1).reshape(n_msgs * 2, 64).view(">u4").astype(np.uint32)
+        first = np.tile(np.array([1, 0], dtype=np.uint8), n_msgs)
+        want = np.array(struct.unpack(">8I", hashlib.sha256(raw[-1].tobytes()).digest()), dtype=np.uint64)
+    pis_of = SA.digest_halves if wide else (lambda d: d)
+    make_prover = SA.Sha512Prover if wide else SA.Sha256Prover
     ctx = nlx.Context(local)
-    sp = SA.Sha256Prover(ctx, args.log_blocks, segment_nodes=args.segment_nodes)
+    sp = make_prover(ctx, args.log_blocks, segment_nodes=args.segment_nodes)
     digest = None
     for _ in range(args.warmup):
         trace, digest = sp.generate_trace(blocks, first)
-        sp.prover.prove_into(trace, digest.ctypes.data)
+        pis = pis_of(digest)
+        sp.prover.prove_into(trace, pis.ctypes.data)
     ctx.kernel_timing(True)
     barrier(dist, torch)
     t0 = time.perf_counter()
@@ -393,7 +408,8 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
         t1 = time.perf_counter()
         trace, digest = sp.generate_trace(blocks, first)
         t_trace += time.perf_counter() - t1
-        sp.prover.prove_into(trace, digest.ctypes.data)
+        pis = pis_of(digest)
+        sp.prover.prove_into(trace, pis.ctypes.data)
     barrier(dist, torch)
     dt = time.perf_counter() - t0
     dt = reduce_max(dist, torch, dt)
@@ -403,20 +419,22 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
     stages = sp.prover.stage_times()
     out = None
     if rank == 0:
-        assert np.array_equal(digest, want), "GPU chaining value is not the SHA-256 digest"
+        assert np.array_equal(digest, want), "GPU chaining value is not the real digest"
         calls, ms, alg = kstats["hash_lde_leaves"]
         achieved = (alg / calls) / (ms / calls * 1e-3) / 1e9 if calls else 0.0
-        proof = sp.prover.prove(trace, digest)
+        proof = sp.prover.prove(trace, pis_of(digest))
         n_rows = SA.ROWS_PER_BLOCK << args.log_blocks
         out = {
-            "metric": "SHA-256 STARK: compression blocks proved per second (secondary workload)",
+            "metric": "%s STARK: compression blocks proved per second (secondary workload)" % ("SHA-512" if wide else "SHA-256"),
             "value": world * args.steps * n_blocks / dt, "unit": "blocks/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
-            "config": {"workload": "STARK of 2^%d SHA-256 compression blocks (%d rows x %d columns, degree-3 AIR, "
+            "config": {"workload": "STARK of 2^%d %s compression blocks (%d rows x %d columns, degree-3 AIR, "
                                    "standard_fast_config: rate 2, 84 queries, 16 PoW bits); trace generated on the GPU "
-                                   "inside the timed region; replicas only" % (args.log_blocks, n_rows, SA.N_COLS),
-                       "messages": "%d random 64-byte messages (2 blocks each)" % n_msgs,
+                                   "inside the timed region; replicas only"
+                                   % (args.log_blocks, "SHA-512" if wide else "SHA-256", n_rows, SA.N_COLS),
+                       "messages": "%d random %d-byte messages (%s)" % (n_msgs, msg_len, "1 block each, the shape of an Ed25519 "
+                                                                         "hash of a NEAR approval" if wide else "2 blocks each"),
                        "air_program_words": int(sp.stark.desc.n_words), "constraints": sp.stark.air.num_constraints,
                        "proof_bytes": len(proof), "trace_gen_ms_per_step": t_trace / args.steps * 1e3,
                        "trace_bytes": int(SA.N_COLS) * n_rows * 8},
@@ -433,13 +451,13 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
             cores = min(len(os.sched_getaffinity(0)), 16)
             os.environ["OMP_NUM_THREADS"] = str(cores)
             s_lb = max(min(args.log_blocks - 3, 9), 2)
-            sp2 = SA.Sha256Prover(ctx, s_lb)
+            sp2 = make_prover(ctx, s_lb)
             b2, f2 = blocks[: 1 << s_lb], first[: 1 << s_lb].copy()
             f2[0] = 1
             tr2, dg2 = sp2.generate_trace(b2, f2)
             host_trace = tr2.cpu().numpy().view(np.uint64)
             tc = time.time()
-            pr2 = oracle_py.stark_prove(sp2.stark.desc, host_trace, dg2)
+            pr2 = oracle_py.stark_prove(sp2.stark.desc, host_trace, pis_of(dg2))
             dtc = time.time() - tc
             ok = oracle_py.stark_verify(sp2.stark.desc, pr2) == 1
             sp2.close()
@@ -467,7 +485,7 @@ def main():
         out = run_sync(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "stark":
         out = run_stark(args, nlx, torch, rank, world, local, dist)
-    elif args.workload == "sha256":
+    elif args.workload in ("sha256", "sha512"):
         out = run_sha256(args, nlx, torch, rank, world, local, dist)
     else:
         from importlib import import_module

@@ -103,6 +103,8 @@ SIGNATURES = {
     "nlx_stark_batch_prove": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]),
     "nlx_sha256_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                           ctypes.c_void_p, ctypes.c_void_p]),
+    "nlx_sha512_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                          ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_synth_stark_trace": (ctypes.c_int32, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_synth_shape": (None, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),

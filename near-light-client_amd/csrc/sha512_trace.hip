@@ -1,0 +1,215 @@
+// Trace generation for the SHA-512 compression AIR (the hash inside every Ed25519
+// verification nearx proves, curta_eddsa_verify_sigs_conditional at nearx/src/builder.rs:152).  Column layout:
+// near-light-client_amd/sha512_air.py (NLX_SHA512_COLS columns, twenty rounds per row, four rows per block; 64-bit
+// words are committed as bits and added as two 32-bit halves).
+//
+// Two kernels, as for SHA-256.  k_sha512_chain: one lane per message start walks that message's blocks and records
+// every block's input chaining value.  k_sha512_trace: one lane per trace row.
+#include "ctx.hpp"
+#include "transcript.hpp"
+
+namespace nlx {
+
+namespace sha512 {
+// FIPS 180-4 §4.2.3 / §5.3.5
+__constant__ static const uint64_t K[80] = {
+    0x428a2f98d728ae22ULL, 0x7137449123ef65cdULL, 0xb5c0fbcfec4d3b2fULL, 0xe9b5dba58189dbbcULL,
+    0x3956c25bf348b538ULL, 0x59f111f1b605d019ULL, 0x923f82a4af194f9bULL, 0xab1c5ed5da6d8118ULL,
+    0xd807aa98a3030242ULL, 0x12835b0145706fbeULL, 0x243185be4ee4b28cULL, 0x550c7dc3d5ffb4e2ULL,
+    0x72be5d74f27b896fULL, 0x80deb1fe3b1696b1ULL, 0x9bdc06a725c71235ULL, 0xc19bf174cf692694ULL,
+    0xe49b69c19ef14ad2ULL, 0xefbe4786384f25e3ULL, 0x0fc19dc68b8cd5b5ULL, 0x240ca1cc77ac9c65ULL,
+    0x2de92c6f592b0275ULL, 0x4a7484aa6ea6e483ULL, 0x5cb0a9dcbd41fbd4ULL, 0x76f988da831153b5ULL,
+    0x983e5152ee66dfabULL, 0xa831c66d2db43210ULL, 0xb00327c898fb213fULL, 0xbf597fc7beef0ee4ULL,
+    0xc6e00bf33da88fc2ULL, 0xd5a79147930aa725ULL, 0x06ca6351e003826fULL, 0x142929670a0e6e70ULL,
+    0x27b70a8546d22ffcULL, 0x2e1b21385c26c926ULL, 0x4d2c6dfc5ac42aedULL, 0x53380d139d95b3dfULL,
+    0x650a73548baf63deULL, 0x766a0abb3c77b2a8ULL, 0x81c2c92e47edaee6ULL, 0x92722c851482353bULL,
+    0xa2bfe8a14cf10364ULL, 0xa81a664bbc423001ULL, 0xc24b8b70d0f89791ULL, 0xc76c51a30654be30ULL,
+    0xd192e819d6ef5218ULL, 0xd69906245565a910ULL, 0xf40e35855771202aULL, 0x106aa07032bbd1b8ULL,
+    0x19a4c116b8d2d0c8ULL, 0x1e376c085141ab53ULL, 0x2748774cdf8eeb99ULL, 0x34b0bcb5e19b48a8ULL,
+    0x391c0cb3c5c95a63ULL, 0x4ed8aa4ae3418acbULL, 0x5b9cca4f7763e373ULL, 0x682e6ff3d6b2b8a3ULL,
+    0x748f82ee5defb2fcULL, 0x78a5636f43172f60ULL, 0x84c87814a1f0ab72ULL, 0x8cc702081a6439ecULL,
+    0x90befffa23631e28ULL, 0xa4506cebde82bde9ULL, 0xbef9a3f7b2c67915ULL, 0xc67178f2e372532bULL,
+    0xca273eceea26619cULL, 0xd186b8c721c0c207ULL, 0xeada7dd6cde0eb1eULL, 0xf57d4f7fee6ed178ULL,
+    0x06f067aa72176fbaULL, 0x0a637dc5a2c898a6ULL, 0x113f9804bef90daeULL, 0x1b710b35131c471bULL,
+    0x28db77f523047d84ULL, 0x32caab7b40c72493ULL, 0x3c9ebe0a15c9bebcULL, 0x431d67c49c100d4cULL,
+    0x4cc5d4becb3e42b6ULL, 0x597f299cfc657e2aULL, 0x5fcb6fab3ad6faecULL, 0x6c44198c4a475817ULL};
+__constant__ static const uint64_t IV[8] = {
+    0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+    0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+
+__device__ __forceinline__ uint64_t rotr(uint64_t x, int r) { return (x >> r) | (x << (64 - r)); }
+__device__ __forceinline__ uint64_t s0(uint64_t x) { return rotr(x, 1) ^ rotr(x, 8) ^ (x >> 7); }
+__device__ __forceinline__ uint64_t s1(uint64_t x) { return rotr(x, 19) ^ rotr(x, 61) ^ (x >> 6); }
+__device__ __forceinline__ uint64_t S0(uint64_t x) { return rotr(x, 28) ^ rotr(x, 34) ^ rotr(x, 39); }
+__device__ __forceinline__ uint64_t S1(uint64_t x) { return rotr(x, 14) ^ rotr(x, 18) ^ rotr(x, 41); }
+__device__ __forceinline__ uint64_t lo32(uint64_t x) { return x & 0xFFFFFFFFull; }
+
+// one block: h <- h + compress(h, m)
+__device__ void compress(uint64_t h[8], const uint64_t* __restrict__ m) {
+    uint64_t w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = m[i];
+    uint64_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll 1
+    for (int r0 = 0; r0 < 80; r0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint64_t t1 = hh + S1(e) + ((e & f) ^ (~e & g)) + K[r0 + i] + w[i];
+            const uint64_t t2 = S0(a) + ((a & b) ^ (a & c) ^ (b & c));
+            w[i] = w[i] + s0(w[(i + 1) & 15]) + w[(i + 9) & 15] + s1(w[(i + 14) & 15]);
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+}  // namespace sha512
+
+__global__ __launch_bounds__(64) void k_sha512_chain(const uint64_t* __restrict__ blocks, const uint8_t* __restrict__ is_first,
+                                                     uint32_t n_blocks, uint64_t* __restrict__ hin) {
+    const uint32_t b0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b0 >= n_blocks || !(is_first[b0] || b0 == 0)) return;
+    uint64_t h[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = sha512::IV[k];
+    for (uint32_t b = b0; b < n_blocks && (b == b0 || !is_first[b]); b++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) hin[(size_t)b * 8 + k] = h[k];
+        sha512::compress(h, blocks + (size_t)b * 16);
+        if (b == n_blocks - 1) {  // output chaining value of the last block = digest of the last message
+#pragma unroll
+            for (int k = 0; k < 8; k++) hin[(size_t)n_blocks * 8 + k] = h[k];
+        }
+    }
+}
+
+// Column layout (sha512_air.py): twenty round slots of 210 columns, then the row's start state and block data
+enum : uint32_t { kSLOTS = 20, kSLOT = 210, oA = 0, oE = 64, oW = 128, oCA = 192, oCE = 198, oCW = 204, oSW = 208,
+                  cPA = kSLOTS * kSLOT, cPE = cPA + 256, cHIN = cPE + 256, cCY = cHIN + 16, cIS_FIRST = cCY + 16 };
+static_assert(cIS_FIRST + 1 == NLX_SHA512_COLS, "column map");
+
+// One lane per trace row (four rows per block, twenty rounds per row).  Every lane replays its block's 80 rounds
+// (4x redundant per block - noise next to the 38 KB it then writes) and emits its row; a wave's 64 lanes are 64
+// consecutive rows, so each of the 4 745 column stores is 512 contiguous bytes.
+__global__ __launch_bounds__(256) void k_sha512_trace(const uint64_t* __restrict__ blocks, const uint8_t* __restrict__ is_first,
+                                                      const uint64_t* __restrict__ hin, uint32_t n_blocks,
+                                                      uint64_t* __restrict__ trace) {
+    using sha512::lo32;
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)n_blocks << 2;
+    if (row >= n) return;
+    const uint32_t blk = (uint32_t)(row >> 2), q = (uint32_t)(row & 3);
+    const uint32_t prev = blk ? blk - 1 : n_blocks - 1;  // the schedule recurrence of row 0 looks back cyclically
+    uint64_t w[96];  // w[16 + t] = W_t of this block for t = 0..79; w[0..15] = W_64..79 of the previous block
+    {
+        uint64_t wp[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) wp[i] = blocks[(size_t)prev * 16 + i];
+#pragma unroll 1
+        for (int t = 16; t < 80; t++) {
+            const uint64_t v = wp[t & 15] + sha512::s0(wp[(t + 1) & 15]) + wp[(t + 9) & 15] + sha512::s1(wp[(t + 14) & 15]);
+            wp[t & 15] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = wp[(64 + i) & 15];
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[16 + i] = blocks[(size_t)blk * 16 + i];
+#pragma unroll 1
+        for (int t = 16; t < 80; t++) w[16 + t] = w[t] + sha512::s0(w[t + 1]) + w[t + 9] + sha512::s1(w[t + 14]);
+    }
+    uint64_t h0[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) h0[k] = hin[(size_t)blk * 8 + k];
+    // a[t + 4], e[t + 4] for t = -4..79, with the low-half and high-half carries of every round's two additions
+    uint64_t a[84], e[84];
+    uint8_t ca[80], ce[80];  // low-half carry | high-half carry << 4
+    a[3] = h0[0]; a[2] = h0[1]; a[1] = h0[2]; a[0] = h0[3];
+    e[3] = h0[4]; e[2] = h0[5]; e[1] = h0[6]; e[0] = h0[7];
+#pragma unroll 1
+    for (int r = 0; r < 80; r++) {
+        const uint64_t a1 = a[r + 3], a2 = a[r + 2], a3 = a[r + 1], a4 = a[r];
+        const uint64_t e1 = e[r + 3], e2 = e[r + 2], e3 = e[r + 1], e4 = e[r];
+        const uint64_t s1v = sha512::S1(e1), chv = (e1 & e2) ^ (~e1 & e3), kv = sha512::K[r], wv = w[16 + r];
+        const uint64_t s0v = sha512::S0(a1), mjv = (a1 & a2) ^ (a1 & a3) ^ (a2 & a3);
+        const uint64_t t1_lo = lo32(e4) + lo32(s1v) + lo32(chv) + lo32(kv) + lo32(wv);
+        const uint64_t t1_hi = (e4 >> 32) + (s1v >> 32) + (chv >> 32) + (kv >> 32) + (wv >> 32);
+        const uint64_t sa_lo = t1_lo + lo32(s0v) + lo32(mjv), sa_hi = t1_hi + (s0v >> 32) + (mjv >> 32) + (sa_lo >> 32);
+        const uint64_t se_lo = lo32(a4) + t1_lo, se_hi = (a4 >> 32) + t1_hi + (se_lo >> 32);
+        a[r + 4] = (sa_hi << 32) | lo32(sa_lo);
+        e[r + 4] = (se_hi << 32) | lo32(se_lo);
+        ca[r] = (uint8_t)((sa_lo >> 32) | ((sa_hi >> 32) << 4));
+        ce[r] = (uint8_t)((se_lo >> 32) | ((se_hi >> 32) << 4));
+    }
+    auto put = [&](uint32_t col, uint64_t v) { trace[(size_t)col * n + row] = v; };
+    auto put_bits = [&](uint32_t base, uint64_t v, int cnt) {
+        for (int i = 0; i < cnt; i++) put(base + i, (v >> i) & 1u);
+    };
+#pragma unroll 1
+    for (uint32_t j = 0; j < kSLOTS; j++) {
+        const uint32_t r = kSLOTS * q + j, base = j * kSLOT;
+        put_bits(base + oA, a[r + 4], 64);
+        put_bits(base + oE, e[r + 4], 64);
+        put_bits(base + oW, w[16 + r], 64);
+        put_bits(base + oCA, ca[r] & 15u, 3);
+        put_bits(base + oCA + 3, ca[r] >> 4, 3);
+        put_bits(base + oCE, ce[r] & 15u, 3);
+        put_bits(base + oCE + 3, ce[r] >> 4, 3);
+        // w[16 + r + k] is W_{r + k}, k >= -16 (k < 0 in row 0 reaches the previous block's W_64..79)
+        const uint64_t x1 = sha512::s1(w[16 + r - 2]), x2 = w[16 + r - 7], x3 = sha512::s0(w[16 + r - 15]), x4 = w[16 + r - 16];
+        const uint64_t sw_lo = lo32(x1) + lo32(x2) + lo32(x3) + lo32(x4);
+        const uint64_t sw_hi = (x1 >> 32) + (x2 >> 32) + (x3 >> 32) + (x4 >> 32) + (sw_lo >> 32);
+        put(base + oSW, lo32(sw_lo));
+        put(base + oSW + 1, lo32(sw_hi));
+        put_bits(base + oCW, sw_lo >> 32, 2);
+        put_bits(base + oCW + 2, sw_hi >> 32, 2);
+    }
+#pragma unroll 1
+    for (uint32_t k = 0; k < 4; k++) {
+        put_bits(cPA + 64 * k, a[kSLOTS * q + 3 - k], 64);
+        put_bits(cPE + 64 * k, e[kSLOTS * q + 3 - k], 64);
+    }
+    const uint64_t fin[8] = {a[83], a[82], a[81], a[80], e[83], e[82], e[81], e[80]};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        put(cHIN + 2 * k, lo32(h0[k]));
+        put(cHIN + 2 * k + 1, h0[k] >> 32);
+        const uint64_t c_lo = (lo32(h0[k]) + lo32(fin[k])) >> 32;
+        const uint64_t c_hi = ((h0[k] >> 32) + (fin[k] >> 32) + c_lo) >> 32;
+        put(cCY + 2 * k, q == 3 ? c_lo : 0u);
+        put(cCY + 2 * k + 1, q == 3 ? c_hi : 0u);
+    }
+    put(cIS_FIRST, (q == 0 && (is_first[blk] || blk == 0)) ? 1u : 0u);
+}
+
+}  // namespace nlx
+
+using namespace nlx;
+
+extern "C" int32_t nlx_sha512_trace(nlx_ctx* ctx, const uint64_t* blocks, const uint8_t* is_first, uint32_t log_blocks,
+                                    uint64_t* trace_out, uint64_t digest_out[8]) {
+    if (!ctx) return NLX_E_INVAL;
+    if (!blocks || !is_first || !trace_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
+    if (log_blocks > 18) return ctx->fail(NLX_E_RANGE, "log_blocks must be <= 18");
+    (void)hipSetDevice(ctx->device);
+    const uint32_t n_blocks = 1u << log_blocks;
+    const size_t n = (size_t)n_blocks << 2;  // four rows per block
+    Staged sb(ctx, blocks, (size_t)n_blocks * 128, true, false);
+    if (sb.status) return sb.status;
+    Staged sf(ctx, is_first, n_blocks, true, false);
+    if (sf.status) return sf.status;
+    Staged st(ctx, trace_out, (size_t)NLX_SHA512_COLS * n * 8, false, true);
+    if (st.status) return st.status;
+    uint64_t* d_hin = (uint64_t*)ctx->alloc((size_t)(n_blocks + 1) * 64);
+    if (!d_hin) return NLX_E_NOMEM;
+    hipLaunchKernelGGL(k_sha512_chain, dim3((n_blocks + 63) / 64), dim3(64), 0, ctx->stream, sb.as<uint64_t>(),
+                       sf.as<uint8_t>(), n_blocks, d_hin);
+    hipLaunchKernelGGL(k_sha512_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sb.as<uint64_t>(),
+                       sf.as<uint8_t>(), d_hin, n_blocks, st.as<uint64_t>());
+    int32_t rc = st.finish();
+    if (!rc && digest_out) rc = fetch(ctx, digest_out, d_hin + (size_t)n_blocks * 8, 64);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    ctx->release(d_hin);
+    if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
+    hipError_t le = hipGetLastError();
+    if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
+    return rc;
+}

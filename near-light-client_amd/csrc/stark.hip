@@ -258,7 +258,7 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
         return ctx->fail(NLX_E_RANGE, "degree_bits out of range");
     if (d.fri_num_queries > 128 || d.fri_num_queries == 0 || d.cap_height > 6 || d.cap_height > d.degree_bits + d.rate_bits)
         return ctx->fail(NLX_E_RANGE, "FRI parameters out of range");
-    if (d.n_cols == 0 || d.n_cols > 4096 || d.num_public_inputs > 4096 || d.n_words > (1u << 20))
+    if (d.n_cols == 0 || d.n_cols > 8192 || d.num_public_inputs > 4096 || d.n_words > (1u << 20))
         return ctx->fail(NLX_E_RANGE, "AIR shape out of range");
     if (d.n_periodic > NLX_AIR_MAX_PERIODIC || (d.n_periodic && (!d.periodic || d.period_bits > d.degree_bits || d.period_bits > 12)))
         return ctx->fail(NLX_E_RANGE, "periodic columns out of range");

@@ -263,28 +263,32 @@ class Air:
         # sub-expression is recomputed in every segment that uses it
         budget = self.segment_nodes if segment_nodes is None else segment_nodes
 
-        def new_nodes(emit, seen):
+        def dag(emit):
+            """ids of the arithmetic nodes under a constraint"""
             eop, root, cnt = emit
-            if eop == AIR_EMIT_BOOL:
-                return cnt, []
-            fresh, stack = [], [root]
+            out, stack = set(), ([] if eop == AIR_EMIT_BOOL else [root])
             while stack:
                 x = stack.pop()
-                if is_value(x) and id(x) not in seen:
-                    seen.add(id(x))
-                    fresh.append(x)
+                if is_value(x) and id(x) not in out:
+                    out.add(id(x))
                     stack.extend(x.operands())
-            return len(fresh), fresh
+            return out
 
+        # A boundary is free where the next constraint shares nothing with the segment so far; otherwise the
+        # shared nodes are computed again.  Cut at the first free boundary past the budget, or at twice the
+        # budget if none comes.
         segments, cur, cur_cost, seen = [], [], 0, set()
         for emit in self._emits:
-            cost, fresh = new_nodes(emit, seen)
-            if budget and cur and cur_cost + cost > budget and len(segments) < AIR_MAX_SEGMENTS - 1:
+            nodes = dag(emit)
+            full = len(nodes) if nodes else emit[2]
+            cost = len(nodes - seen) if nodes else emit[2]
+            over = budget and cur and cur_cost + cost > budget and len(segments) < AIR_MAX_SEGMENTS - 1
+            if over and (cost == full or cur_cost + cost > 2 * budget):
                 segments.append(cur)
-                cur, cur_cost, seen = [], 0, set()
-                cost, fresh = new_nodes(emit, seen)   # nothing is shared with the previous segment any more
+                cur, cur_cost, seen, cost = [], 0, set(), full
             cur.append(emit)
             cur_cost += cost
+            seen |= nodes
         segments.append(cur)
         words = []
         for i, seg in enumerate(segments):

@@ -425,7 +425,7 @@ static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* n
     }
 }
 
-#define ORC_MAX_PERIODIC 32
+#define ORC_MAX_PERIODIC 64
 /* interpolation of each periodic column over the period-th roots of unity (coefficients, natural order) */
 static uint64_t* periodic_coeffs(const orc_stark_desc* d) {
     if (!d->n_periodic) return NULL;

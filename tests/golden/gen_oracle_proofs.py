@@ -45,6 +45,14 @@ def cases():
     assert orc.stark_verify(st.desc, proof) == 1
     out["stark_sha256_4_blocks"] = {"bytes": len(proof), "sha256": hashlib.sha256(proof).hexdigest(),
                                     "program_words": int(st.desc.n_words)}
+    SB = nlx.sha512_air
+    blocks, first, digest = SB.blocks_for_messages([b"abc", b"near light client" * 9], 2)
+    t, _ = SB.reference_trace(blocks, first)
+    st = S.Stark(SB.sha512_air(), 4)
+    proof = orc.stark_prove(st.desc, t, SB.digest_halves(digest))
+    assert orc.stark_verify(st.desc, proof) == 1
+    out["stark_sha512_4_blocks"] = {"bytes": len(proof), "sha256": hashlib.sha256(proof).hexdigest(),
+                                    "program_words": int(st.desc.n_words)}
     return out
 
 
