@@ -101,6 +101,11 @@ SIGNATURES = {
     "nlx_stark_stage_times": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p,
                                                ctypes.c_void_p]),
     "nlx_stark_batch_prove": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]),
+    "nlx_logup_multiplicities": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                                  ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
+    "nlx_logup_round_cols": (ctypes.c_uint32, [ctypes.c_uint32]),
+    "nlx_logup_round": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                         ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_sha256_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                           ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_sha512_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,

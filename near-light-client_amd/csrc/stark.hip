@@ -207,6 +207,34 @@ __global__ __launch_bounds__(256) void k_air_combine(const uint64_t* __restrict_
 
 }  // namespace nlx
 
+// natural order in, natural order out; inverse includes the 1/len factor (host side, build time only)
+static void host_ntt(std::vector<uint64_t>& a, unsigned log_len, bool inverse) {
+    const size_t len = (size_t)1 << log_len;
+    for (size_t i = 0; i < len; i++) {
+        size_t j = 0;
+        for (unsigned b = 0; b < log_len; b++) j |= ((i >> b) & 1) << (log_len - 1 - b);
+        if (j > i) std::swap(a[i], a[j]);
+    }
+    for (unsigned st = 1; st <= log_len; st++) {
+        const size_t half = (size_t)1 << (st - 1);
+        uint64_t w_st = gl::root_of_unity(st);
+        if (inverse) w_st = gl::inv(w_st);
+        for (size_t base = 0; base < len; base += 2 * half) {
+            uint64_t w = 1;
+            for (size_t k = 0; k < half; k++) {
+                const uint64_t u = a[base + k], v = gl::mul(a[base + k + half], w);
+                a[base + k] = gl::add(u, v);
+                a[base + k + half] = gl::sub(u, v);
+                w = gl::mul(w, w_st);
+            }
+        }
+    }
+    if (inverse) {
+        const uint64_t inv_len = gl::inv((uint64_t)len);
+        for (auto& v : a) v = gl::mul(v, inv_len);
+    }
+}
+
 struct nlx_stark {
     nlx_ctx* ctx = nullptr;
     nlx_stark_desc d{};
@@ -260,7 +288,7 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
         return ctx->fail(NLX_E_RANGE, "FRI parameters out of range");
     if (d.n_cols == 0 || d.n_cols > 8192 || d.num_public_inputs > 4096 || d.n_words > (1u << 20))
         return ctx->fail(NLX_E_RANGE, "AIR shape out of range");
-    if (d.n_periodic > NLX_AIR_MAX_PERIODIC || (d.n_periodic && (!d.periodic || d.period_bits > d.degree_bits || d.period_bits > 12)))
+    if (d.n_periodic > NLX_AIR_MAX_PERIODIC || (d.n_periodic && (!d.periodic || d.period_bits > d.degree_bits || d.period_bits > 16)))
         return ctx->fail(NLX_E_RANGE, "periodic columns out of range");
     if (d.n_rounds > 3) return ctx->fail(NLX_E_RANGE, "at most three commitment rounds");
     uint32_t n_round_challenges = 0;
@@ -405,31 +433,27 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
         s->d_wA_inv = s->d_small + 4 * R + 4 * Q;
         launch_l0_table(ctx->stream, s->d_l_inv, log_n, s->qdb, s->d_q_coset_base, ctx->tables.fwd[log_n]);
         if (d.n_periodic) {
-            // P_a = interpolation of column a over the period-th roots of unity (naive inverse DFT: tiny), then
-            // its values at y = (g w_{nQ}^r')^(n/period) * w_period^k for every quotient coset r' and k < period
+            // P_a = interpolation of column a over the period-th roots of unity, then its values at
+            // y = (g w_{nQ}^r')^(n/period) * w_period^k for every quotient coset r' and k < period (host transforms:
+            // a period is at most 2^16)
             const uint32_t period = 1u << d.period_bits;
             s->periodic.assign(d.periodic, d.periodic + (size_t)d.n_periodic * period);
             for (auto& v : s->periodic) v %= gl::P;
             s->d.periodic = s->periodic.data();
-            const uint64_t w_p = gl::root_of_unity(d.period_bits), w_p_inv = gl::inv(w_p), p_inv = gl::inv((uint64_t)period);
-            std::vector<uint64_t> coeffs(period), table((size_t)d.n_periodic * Q * period), wpow(period), winv(period);
-            wpow[0] = winv[0] = 1;
-            for (uint32_t i = 1; i < period; i++) { wpow[i] = gl::mul(wpow[i - 1], w_p); winv[i] = gl::mul(winv[i - 1], w_p_inv); }
+            std::vector<uint64_t> coeffs(period), shifted(period), table((size_t)d.n_periodic * Q * period);
             for (uint32_t a = 0; a < d.n_periodic; a++) {
-                const uint64_t* v = s->periodic.data() + (size_t)a * period;
-                for (uint32_t m = 0; m < period; m++) {
-                    uint64_t acc = 0;
-                    for (uint32_t j = 0; j < period; j++) acc = gl::add(acc, gl::mul(v[j], winv[(uint32_t)(((uint64_t)m * j) & (period - 1))]));
-                    coeffs[m] = gl::mul(acc, p_inv);
-                }
+                std::copy(s->periodic.begin() + (size_t)a * period, s->periodic.begin() + (size_t)(a + 1) * period, coeffs.begin());
+                host_ntt(coeffs, d.period_bits, true);
                 for (uint32_t r = 0; r < Q; r++) {
-                    const uint64_t base = gl::exp_pow2(small[4 * R + r], log_n - d.period_bits);  // (g w^r')^(n/period)
-                    for (uint32_t k = 0; k < period; k++) {
-                        const uint64_t y = gl::mul(base, wpow[k]);
-                        uint64_t acc = 0;
-                        for (uint32_t m = period; m-- > 0;) acc = gl::add(gl::mul(acc, y), coeffs[m]);
-                        table[((size_t)a * Q + r) * period + k] = acc;
+                    // P_a on the coset y0 * <w_period>, y0 = (g w^r')^(n/period): transform of coeffs[m] * y0^m
+                    const uint64_t y0 = gl::exp_pow2(small[4 * R + r], log_n - d.period_bits);
+                    uint64_t pw = 1;
+                    for (uint32_t m = 0; m < period; m++) {
+                        shifted[m] = gl::mul(coeffs[m], pw);
+                        pw = gl::mul(pw, y0);
                     }
+                    host_ntt(shifted, d.period_bits, false);
+                    std::copy(shifted.begin(), shifted.end(), table.begin() + ((size_t)a * Q + r) * period);
                 }
             }
             s->d_periodic = (uint64_t*)ctx->alloc(table.size() * 8);

@@ -190,14 +190,16 @@ class Air:
         return self._leaf(AIR_CONST, int(v) % P, 0)
 
     def periodic(self, values):
-        """A verifier-computable column repeating `values` (length a power of two, the same for every
-        periodic column of the AIR) down the trace - round constants, round selectors.  Degree 1."""
-        values = [int(v) % P for v in values]
+        """A verifier-computable column repeating `values` (length a power of two) down the trace - round
+        constants, round selectors, a lookup table.  Columns of different periods are tiled to the longest one.
+        Degree 1."""
+        values = np.array([int(v) % P for v in values], dtype=np.uint64)
         bits = (len(values) - 1).bit_length()
-        if len(values) != 1 << bits or (self._periodic and bits != self.period_bits):
-            raise ValueError("periodic columns must share one power-of-two period")
-        self.period_bits = bits
-        self._periodic.append(np.array(values, dtype=np.uint64))
+        if len(values) != 1 << bits or bits > 16:
+            raise ValueError("the period must be a power of two <= 2^16")
+        if bits > self.period_bits:
+            self.period_bits = bits
+        self._periodic = [np.tile(c, (1 << self.period_bits) // len(c)) for c in self._periodic + [values]]
         return self._leaf(AIR_PERIODIC, len(self._periodic) - 1, 1)
 
     # ConstraintConsumer

@@ -302,3 +302,35 @@ def stark_prove_rounds(desc, round_fn, public_inputs):
     if n == 0:
         raise RuntimeError("orc_stark_prove_rounds failed (bad descriptor, callback or buffer overflow)")
     return out[:n].tobytes()
+
+
+def logup_multiplicities(trace, cols, table_bits):
+    """orc_logup_multiplicities: trace (n_cols, n) uint64, cols = the looked-up columns.  Returns m (n,) or raises."""
+    d = dll()
+    t = _u64(trace)
+    c = np.ascontiguousarray(cols, dtype=np.uint32)
+    n = t.shape[1]
+    m = np.zeros(n, dtype=np.uint64)
+    d.orc_logup_multiplicities.restype = ctypes.c_int
+    d.orc_logup_multiplicities.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.c_void_p]
+    if not d.orc_logup_multiplicities(t.ctypes.data, n.bit_length() - 1, c.ctypes.data, c.size, table_bits, m.ctypes.data):
+        raise ValueError("a looked-up cell is outside the table")
+    return m
+
+
+def logup_round(trace, cols, table_bits, mult, alpha):
+    """orc_logup_round: the round-1 columns (helpers, g, phi) as a (2 * ceil(k / 2) + 4, n) array."""
+    d = dll()
+    t = _u64(trace)
+    c = np.ascontiguousarray(cols, dtype=np.uint32)
+    m = _u64(mult)
+    n = t.shape[1]
+    al = np.array([int(alpha[0]), int(alpha[1])], dtype=np.uint64)
+    out = np.zeros((2 * ((c.size + 1) // 2) + 4, n), dtype=np.uint64)
+    d.orc_logup_round.restype = None
+    d.orc_logup_round.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    d.orc_logup_round(t.ctypes.data, n.bit_length() - 1, c.ctypes.data, c.size, table_bits, m.ctypes.data, al.ctypes.data,
+                        out.ctypes.data)
+    return out

@@ -450,7 +450,7 @@ static int desc_ok(const orc_stark_desc* d) {
     if (!q || (q & (q - 1)) || q > (1u << d->rate_bits)) return 0;
     if (d->num_challenges < 1 || d->num_challenges > 2 || d->n_cols == 0) return 0;
     if (d->n_periodic > ORC_MAX_PERIODIC) return 0;
-    if (d->n_periodic && (d->period_bits > d->degree_bits || d->period_bits > 12 || !d->periodic)) return 0;
+    if (d->n_periodic && (d->period_bits > d->degree_bits || d->period_bits > 16 || !d->periodic)) return 0;
     if (d->n_rounds > 3) return 0;
     if (d->n_rounds) {
         uint32_t tot = 0;
@@ -537,7 +537,21 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
     const size_t size = n << qdb, step = (size_t)1 << (d->rate_bits - qdb), next_step = (size_t)1 << qdb;
     const unsigned log_size = log_n + qdb;
     uint64_t* qvals = (uint64_t*)malloc(8 * size * nc);
-    uint64_t* per_coeffs = periodic_coeffs(d);
+    /* periodic column a at point i of the quotient domain is P_a(y_i), y_i = x_i^(n/period) = G rho^i with rho of
+     * order period << qdb: one coset transform of the zero-padded coefficients gives all of them */
+    uint64_t* per_table = NULL;
+    const size_t per_len = d->n_periodic ? ((size_t)1 << (d->period_bits + qdb)) : 0;
+    if (d->n_periodic) {
+        uint64_t* per_coeffs = periodic_coeffs(d);
+        const size_t period = (size_t)1 << d->period_bits;
+        per_table = (uint64_t*)calloc(per_len * d->n_periodic, 8);
+        const uint64_t G = gl_exp_pow2(GL_GEN, log_n - d->period_bits);
+        for (uint32_t a = 0; a < d->n_periodic; a++) {
+            memcpy(per_table + a * per_len, per_coeffs + a * period, 8 * period);
+            orc_coset_fft(per_table + a * per_len, d->period_bits + qdb, G);
+        }
+        free(per_coeffs);
+    }
     {
         const uint64_t g = gl_root_of_unity(log_n), last = gl_inv(g);
         const uint64_t w_s = gl_root_of_unity(log_size);
@@ -559,16 +573,7 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
                     memcpy(nxt + col0[r], r_leaves[r] + ln * rc, 8 * (size_t)rc);
                 }
                 uint64_t accs[4], per[ORC_MAX_PERIODIC];
-                if (d->n_periodic) {
-                    /* P_a(x^(n/period)) by Horner */
-                    const size_t period = (size_t)1 << d->period_bits;
-                    uint64_t y = gl_exp_pow2(x, log_n - d->period_bits);
-                    for (uint32_t a = 0; a < d->n_periodic; a++) {
-                        uint64_t acc = 0;
-                        for (size_t m = period; m-- > 0;) acc = gl_add(gl_mul(acc, y), per_coeffs[a * period + m]);
-                        per[a] = acc;
-                    }
-                }
+                for (uint32_t a = 0; a < d->n_periodic; a++) per[a] = per_table[a * per_len + (i & (per_len - 1))];
                 air_eval_base(d, loc, nxt, values, per, gl_sub(x, last), l_first, l_last, alphas, accs);
                 uint64_t zh_inv = gl_inv(zh);
                 for (uint32_t j = 0; j < nc; j++) qvals[(size_t)j * size + i] = gl_mul(accs[j], zh_inv);
@@ -582,7 +587,7 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
         memcpy(q_coeffs + (size_t)j * qdf * n, qvals + (size_t)j * size, 8 * n * qdf); /* trim_to_len(n * qdf), chunks(n) */
     }
     free(qvals);
-    free(per_coeffs);
+    free(per_table);
     uint64_t* q_leaves = (uint64_t*)malloc(8 * L * nq);
     uint64_t* q_dig = (uint64_t*)malloc(8 * orc_merkle_digest_words(L, cap_h));
     uint64_t q_cap[4 * 64];
