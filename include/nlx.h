@@ -422,6 +422,13 @@ int32_t nlx_logup_multiplicities(nlx_ctx* ctx, uint64_t* trace, uint32_t n_cols,
 uint32_t nlx_logup_round_cols(uint32_t n_lookups);
 int32_t nlx_logup_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t n_cols, uint32_t log_n, const uint32_t* cols,
                         uint32_t n_lookups, uint32_t table_bits, uint32_t mult_col, const uint64_t alpha[2], uint64_t* out);
+/* a12: the multiplication unit mod 2^255 - 19 (the field under the Ed25519 verifications of
+ * curta_eddsa_verify_sigs_conditional, nearx/src/builder.rs:152) as a stand-alone chip: one a * b = c (mod p) per row.
+ * Constraints: near-light-client_amd/fp25519.py::FpMulChip.  a, b: 2^log_rows operands of four little-endian 64-bit
+ * words each (any value < 2^256).  Writes the NLX_FP25519_CHIP_COLS x 2^log_rows round-0 trace (16-bit limbs of a, b,
+ * the canonical c, the quotient, the carries; the multiplicity column zeroed - fill it with nlx_logup_multiplicities). */
+#define NLX_FP25519_CHIP_COLS 111
+int32_t nlx_fp25519_chip_trace(nlx_ctx* ctx, const uint64_t* a, const uint64_t* b, uint32_t log_rows, uint64_t* trace_out);
 /* f.1: trace generation on the GPU for the SHA-256 compression AIR (column layout and constraints:
  * near-light-client_amd/sha256_air.py; callers in the reference: curta_sha256 at nearx/src/merkle.rs:49,
  * nearx/src/variables.rs:71-72).  blocks: 2^log_blocks padded 512-bit blocks as 16 big-endian-decoded words

@@ -1,0 +1,172 @@
+"""Arithmetic mod p = 2^255 - 19 inside an AIR over Goldilocks (the field under the Ed25519
+verifications nearx proves with curta_eddsa_verify_sigs_conditional, nearx/src/builder.rs:152; curta's own field /
+curve tables are not in the reference tree, Cargo.lock:6515 - this is an independent construction).
+
+Representation: an element is 16 limbs of 16 bits, little-endian, any representative < 2^256.  One multiplication
+unit proves  sum_t a_t * b_t = c + q * p  over the integers for range-checked limbs:
+
+    D_k = sum_t sum_{i+j=k} a_t[i] b_t[j]  -  c[k]  -  sum_{i+j=k} q[i] p[j]            k = 0 .. 31
+    G_m = D_2m + 2^16 D_2m+1,      G_m + r_(m-1) = 2^32 r_m,      r_(-1) = r_15 = 0       m = 0 .. 15
+
+with q of 17 limbs and signed carries r_m = R_m - 2^22, R_m = lo + 2^16 hi < 2^23 (lo and hi range-checked by lookup,
+hi < 2^7 through a second lookup of 2^9 hi).  Every |G_m + r_(m-1) - 2^32 r_m| < 2^56 < p_Goldilocks, so each field
+equation holds over the integers and the chain telescopes to sum_k D_k 2^(16 k) = 0.  All constraints have degree 2.
+Range checks are near-light-client_amd/logup.py lookups into the 2^16 table.
+
+`FpMulChip` is the unit on its own as a two-round STARK (one multiplication per row): the building block, its tests
+and its measurements; the Ed25519 AIR arranges many units per row.
+"""
+import numpy as np
+
+from . import logup
+from .stark import Air, Stark
+
+P25519 = (1 << 255) - 19
+LIMBS = 16
+LIMB_BITS = 16
+Q_LIMBS = 17
+N_CARRY = 15
+CARRY_OFFSET = 1 << 22
+P_LIMBS = [(P25519 >> (16 * i)) & 0xFFFF for i in range(LIMBS)]
+UNIT_CELLS = LIMBS + Q_LIMBS + 3 * N_CARRY      # c, q, (lo, hi, 2^9 hi) per carry = 78 range-checked cells
+
+
+def to_limbs(x, n=LIMBS):
+    return [(x >> (16 * i)) & 0xFFFF for i in range(n)]
+
+
+def from_limbs(limbs):
+    return sum(int(v) << (16 * i) for i, v in enumerate(limbs))
+
+
+def mul_unit_constraints(air, products, c, q, carries, c_scale=1):
+    """Adds the 16 carry-chain constraints of one unit.  products: list of (a, b) with a, b lists of 16 limb
+    expressions; c: 16 limb expressions (the result, or any linear expression of range-checked limbs); q: 17 limb
+    expressions; carries: list of 15 (lo, hi, hi9) expression triples.  Also ties hi9 = 2^9 hi."""
+    d = []
+    for k in range(2 * LIMBS):
+        terms = []
+        for a, b in products:
+            terms += [a[i] * b[k - i] for i in range(max(0, k - LIMBS + 1), min(LIMBS, k + 1))]
+        if k < LIMBS:
+            terms.append(c[k] * (-c_scale))
+        terms += [q[i] * (-P_LIMBS[k - i]) for i in range(max(0, k - LIMBS + 1), min(Q_LIMBS, k + 1))]
+        acc = terms[0]
+        for t in terms[1:]:
+            acc = acc + t
+        d.append(acc)
+    prev = None
+    for m in range(LIMBS):
+        g = d[2 * m] + d[2 * m + 1] * (1 << 16)
+        if prev is not None:
+            g = g + prev
+        if m < N_CARRY:
+            lo, hi, hi9 = carries[m]
+            r = lo + hi * (1 << 16) - CARRY_OFFSET
+            air.constraint(g - r * (1 << 32))
+            air.constraint(hi9 - hi * (1 << 9))
+            prev = r
+        else:
+            air.constraint(g)
+
+
+def mul_unit_witness(products, c=None):
+    """Integer witness of one unit: (c limbs, q limbs, [(lo, hi, hi9)] * 15).  products: list of (a, b) integers or limb
+    lists (limbs may exceed 16 bits, e.g. sums of reduced values); c: the result to use (default: canonical)."""
+    pl = [(to_limbs(a) if isinstance(a, int) else [int(v) for v in a], to_limbs(b) if isinstance(b, int) else [int(v) for v in b])
+          for a, b in products]
+    total = sum(from_limbs(a) * from_limbs(b) for a, b in pl)
+    cv = total % P25519 if c is None else c
+    assert (total - cv) % P25519 == 0 and 0 <= cv < (1 << 256)
+    qv = (total - cv) // P25519
+    assert 0 <= qv < (1 << (16 * Q_LIMBS))
+    cl, ql = to_limbs(cv), to_limbs(qv, Q_LIMBS)
+    d = []
+    for k in range(2 * LIMBS):
+        acc = 0
+        for a, b in pl:
+            for i in range(max(0, k - LIMBS + 1), min(LIMBS, k + 1)):
+                acc += a[i] * b[k - i]
+        if k < LIMBS:
+            acc -= cl[k]
+        for i in range(max(0, k - LIMBS + 1), min(Q_LIMBS, k + 1)):
+            acc -= ql[i] * P_LIMBS[k - i]
+        d.append(acc)
+    carries, prev = [], 0
+    for m in range(LIMBS):
+        g = d[2 * m] + (d[2 * m + 1] << 16) + prev
+        assert g % (1 << 32) == 0
+        prev = g >> 32
+        if m < N_CARRY:
+            big = prev + CARRY_OFFSET
+            assert 0 <= big < (1 << 23), "carry out of range: operands too large"
+            carries.append((big & 0xFFFF, big >> 16, (big >> 16) << 9))
+        else:
+            assert prev == 0
+    return cl, ql, carries
+
+
+class FpMulChip:
+    """One multiplication a * b = c (mod p) per row as a two-round STARK.
+
+    Round 0: a[16], b[16], c[16], q[17], carries[15 x 3], multiplicity;  round 1: the lookup columns.  All 110 value
+    cells are range-checked (a and b too: the chip stands alone)."""
+    A, B, C, Q, R = 0, 16, 32, 48, 65
+    MULT = R + 3 * N_CARRY                      # 110
+    N_COLS0 = MULT + 1                          # 111
+
+    def __init__(self, log_rows, config=None):
+        if log_rows < LIMB_BITS:
+            raise ValueError("the 2^16-entry range table needs at least 2^16 rows")
+        self.log_rows = log_rows
+        n_lookups = self.MULT
+        self.n_cols1 = logup.round_cols(n_lookups)
+        air = Air(self.N_COLS0 + self.n_cols1, 0, rounds=[(self.N_COLS0, 2), (self.n_cols1, 0)])
+        L = air.local  # noqa: N806
+        a = [L(self.A + i) for i in range(16)]
+        b = [L(self.B + i) for i in range(16)]
+        c = [L(self.C + i) for i in range(16)]
+        q = [L(self.Q + i) for i in range(17)]
+        carries = [(L(self.R + 3 * m), L(self.R + 3 * m + 1), L(self.R + 3 * m + 2)) for m in range(N_CARRY)]
+        mul_unit_constraints(air, [(a, b)], c, q, carries)
+        self.range_check = logup.RangeCheck(air, range(n_lookups), LIMB_BITS, self.MULT, self.N_COLS0)
+        self.air = air
+        self.stark = Stark(air, log_rows, config)
+
+    def reference_trace(self, a_vals, b_vals):
+        """Round-0 columns (multiplicity column left zero) for integer operands, plain Python."""
+        n = 1 << self.log_rows
+        assert len(a_vals) == n and len(b_vals) == n
+        t = np.zeros((self.N_COLS0, n), dtype=np.uint64)
+        for i, (x, y) in enumerate(zip(a_vals, b_vals)):
+            cl, ql, carries = mul_unit_witness([(int(x), int(y))])
+            t[self.A:self.A + 16, i] = to_limbs(int(x))
+            t[self.B:self.B + 16, i] = to_limbs(int(y))
+            t[self.C:self.C + 16, i] = cl
+            t[self.Q:self.Q + 17, i] = ql
+            t[self.R:self.R + 45, i] = [v for tr in carries for v in tr]
+        return t
+
+
+def operands_to_words(vals):
+    """integers < 2^256 -> (n, 4) uint64 little-endian words (the input format of nlx_fp25519_chip_trace)"""
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        v = int(v)
+        for w in range(4):
+            out[i, w] = (v >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def chip_trace_on_gpu(ctx, chip, a_vals, b_vals):
+    """Round-0 trace of the chip generated on the device (nlx_fp25519_chip_trace + nlx_logup_multiplicities):
+    returns the device tensor [N_COLS0, n]."""
+    import torch
+    from ._lib import dll
+    n = 1 << chip.log_rows
+    a, b = operands_to_words(a_vals), operands_to_words(b_vals)
+    assert a.shape == (n, 4) and b.shape == (n, 4)
+    trace = torch.empty((chip.N_COLS0, n), dtype=torch.int64, device="cuda:%d" % ctx.device)
+    ctx.check(dll.nlx_fp25519_chip_trace(ctx.handle, a.ctypes.data, b.ctypes.data, chip.log_rows, trace.data_ptr()))
+    chip.range_check.multiplicities(ctx, trace)
+    return trace

@@ -1,0 +1,133 @@
+"""Multiplication mod 2^255 - 19 as an AIR unit (near-light-client_amd/fp25519.py): integer witness against Python's
+big integers, the chip STARK (unit + range-check lookups) through the oracle prover / verifier, and on the GPU the
+device-generated trace and proof bytes against the reference trace and the oracle."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import P
+
+
+def _operands(n, seed=7, distinct=256):
+    rnd = random.Random(seed)
+    m = (1 << 256) - 1
+    base = [(m, m), (0, 0), (1, m), ((1 << 255) - 19, 5), ((1 << 255) - 20, (1 << 255) - 20)]
+    base += [(rnd.getrandbits(256), rnd.getrandbits(256)) for _ in range(distinct - len(base))]
+    reps = (n + len(base) - 1) // len(base)
+    a = [x for x, _ in base] * reps
+    b = [y for _, y in base] * reps
+    return a[:n], b[:n]
+
+
+def test_unit_witness_matches_big_integers(nlx):
+    F = nlx.fp25519
+    rnd = random.Random(1)
+    for _ in range(500):
+        a, b = rnd.getrandbits(256), rnd.getrandbits(256)
+        cl, ql, carries = F.mul_unit_witness([(a, b)])
+        assert F.from_limbs(cl) == a * b % F.P25519 and F.from_limbs(ql) * F.P25519 + F.from_limbs(cl) == a * b
+        assert all(0 <= lo < 65536 and 0 <= hi < 128 and hi9 == hi << 9 for lo, hi, hi9 in carries)
+    # two products into one reduction, and a non-canonical result
+    a, b, c, d = (rnd.getrandbits(256) for _ in range(4))
+    cl, ql, _ = F.mul_unit_witness([(a, b), (c, d)])
+    assert F.from_limbs(cl) == (a * b + c * d) % F.P25519
+    big = (1 << 200) * (1 << 100) % F.P25519                      # 19 * 2^45: c + p still fits 256 bits
+    cl, _, _ = F.mul_unit_witness([(1 << 200, 1 << 100)], c=big + F.P25519)
+    assert F.from_limbs(cl) == big + F.P25519
+    with pytest.raises(AssertionError):
+        F.mul_unit_witness([(3, 5)], c=16)
+
+
+def test_device_witness_code_on_the_host(nlx, tmp_path):
+    """csrc/fp25519.hpp (the arithmetic the GPU trace generators run) compiled for the host with g++ and compared
+    with Python's big integers: canonical c, quotient and carries, single and double products, edge values."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    F = nlx.fp25519
+    exe = str(tmp_path / "fpcheck")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "near-light-client_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "native", "fp25519_host_check.cpp"), "-o", exe], check=True, capture_output=True)
+    rnd = random.Random(3)
+    m, p = (1 << 256) - 1, F.P25519
+    cases = [[(m, m)], [(0, 0)], [(1, m)], [(p, 5)], [(p - 1, p - 1)], [(m, m), (m, m)], [(p, 1)], [(p + 18, 1)], [(1 << 255, 1)],
+             [((1 << 255) - 1, 1)]]
+    cases += [[(rnd.getrandbits(256), rnd.getrandbits(256))] for _ in range(200)]
+    cases += [[(rnd.getrandbits(256), rnd.getrandbits(256)), (rnd.getrandbits(256), rnd.getrandbits(256))] for _ in range(200)]
+    text = "\n".join(" ".join("%064x" % v for pr in c for v in pr) for c in cases) + "\n"
+    out = subprocess.run([exe], input=text, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert len(out) == len(cases)
+    for c, line in zip(cases, out):
+        f = line.split()
+        cl, ql, carries = F.mul_unit_witness(c)
+        assert int(f[0], 16) == F.from_limbs(cl) and int(f[1], 16) == F.from_limbs(ql), c
+        assert [int(x) for x in f[2:]] == [lo + (hi << 16) for lo, hi, _ in carries], c
+
+
+@pytest.fixture(scope="module")
+def chip_case(nlx, orc):
+    F = nlx.fp25519
+    chip = F.FpMulChip(16, nlx.StarkConfig(fri_num_queries=20))
+    a, b = _operands(1 << 16)
+    t0 = chip.reference_trace(a, b)
+    t0[chip.MULT] = orc.logup_multiplicities(t0, range(chip.MULT), 16)
+    return chip, t0, a, b
+
+
+def _rounds(orc, chip, t0):
+    def fn(rnd, chal):
+        return t0 if rnd == 0 else orc.logup_round(t0, range(chip.MULT), 16, t0[chip.MULT], chal[:2])
+    return fn
+
+
+def test_chip_oracle_accepts_and_rejects(nlx, orc, chip_case):
+    chip, t0, a, b = chip_case
+    F = nlx.fp25519
+    assert chip.air.constraint_degree == 3 and chip.stark.desc.n_cols == 225 and chip.stark.desc.period_bits == 16
+    assert int(t0[chip.MULT].sum()) == chip.MULT << 16
+    for i in (0, 1, 4, 77):
+        assert F.from_limbs(t0[chip.C:chip.C + 16, i]) == a[i] * b[i] % F.P25519
+    proof = orc.stark_prove_rounds(chip.stark.desc, _rounds(orc, chip, t0), [])
+    assert orc.stark_verify(chip.stark.desc, proof) == 1
+
+    def rejected(t):
+        t = t.copy()
+        try:
+            t[chip.MULT] = orc.logup_multiplicities(t, range(chip.MULT), 16)
+        except ValueError:
+            pass            # outside the table: keep the old multiplicities, the sums cannot agree
+        return orc.stark_verify(chip.stark.desc, orc.stark_prove_rounds(chip.stark.desc, _rounds(orc, chip, t), [])) != 1
+    # a wrong product limb (still 16 bits), a wrong quotient limb, a wrong carry
+    for col, row in ((chip.C + 3, 9), (chip.Q + 16, 10), (chip.R + 3 * 7, 11), (chip.R + 3 * 7 + 1, 12)):
+        bad = t0.copy()
+        bad[col, row] = int(bad[col, row]) ^ 1
+        assert rejected(bad), (col, row)
+    # c + p as a result where it does not fit 256 bits: limb 15 would need 17 bits -> out of the table
+    bad = t0.copy()
+    bad[chip.C + 15, 5] = int(bad[chip.C + 15, 5]) + 0x8000
+    bad[chip.C, 5] = (int(bad[chip.C, 5]) - 19) % P
+    assert rejected(bad)
+    # "a * b = c + q p" with a field-sized fake limb: equations can hold mod the Goldilocks prime only if limbs leave
+    # the table - the lookup rejects it
+    bad = t0.copy()
+    bad[chip.A, 6] = P - 1
+    assert rejected(bad)
+
+
+@pytest.mark.gpu
+def test_gpu_chip_trace_and_proof_equal_oracle(nlx, ctx, orc, chip_case):
+    import torch
+    chip, t0, a, b = chip_case
+    F = nlx.fp25519
+    dev = F.chip_trace_on_gpu(ctx, chip, a, b)
+    got = dev.cpu().numpy().view(np.uint64)
+    if not np.array_equal(got, t0):
+        bad = np.argwhere(got != t0)[0]
+        pytest.fail("GPU chip trace differs from the reference at column %d row %d" % (bad[0], bad[1]))
+    pr = chip.stark.build(ctx)
+    out = torch.empty((chip.n_cols1, 1 << 16), dtype=torch.int64, device=dev.device)
+    proof = pr.prove_rounds(lambda rnd, chal: dev if rnd == 0 else chip.range_check.round1(ctx, dev, chal[:2], out), [])
+    assert proof == orc.stark_prove_rounds(chip.stark.desc, _rounds(orc, chip, t0), [])
+    assert orc.stark_verify(chip.stark.desc, proof) == 1
+    pr.close()
