@@ -50,8 +50,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark", "sha256", "sha512"])
+    ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark", "sha256", "sha512", "ed25519"])
     ap.add_argument("--log-blocks", type=int, default=14, help="sha256 workload: 2^k compression blocks per proof")
+    ap.add_argument("--log-slots", type=int, default=10, help="ed25519 workload: 2^k signature slots per proof (>= 8)")
     ap.add_argument("--segment-nodes", type=int, default=None, help="sha256 workload: AIR program segment size (0 = one segment)")
     ap.add_argument("--stark-cols", type=int, default=256)
     ap.add_argument("--log-n", type=int, default=16)
@@ -473,6 +474,87 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
     return out
 
 
+def run_ed25519(args, nlx, torch, rank, world, local, dist):
+    """Secondary workload: one STARK proof of 2^--log-slots Ed25519 verifications per step - trace
+    generation (nlx_ed25519_trace), multiplicities and lookup columns (nlx_logup_*) and the two-round STARK, all on the
+    GPU inside the timed region.  Statements: synthetic true (A, R, S, h) tuples (64 distinct, tiled)."""
+    import numpy as np
+    E = nlx.ed25519_air
+    n_slots = 1 << args.log_slots
+    distinct = E.synthetic_slots(64, seed=9 + rank)
+    words = np.tile(E.slots_to_words(distinct), (n_slots // 64, 1))
+    ctx = nlx.Context(local)
+    pr = E.Ed25519Prover(ctx, args.log_slots)
+    for _ in range(args.warmup):
+        pr.prove(words)
+    ctx.kernel_timing(True)
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    t_trace = 0.0
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        pr.generate_trace(words)
+        t_trace += time.perf_counter() - t1
+        rc = pr.es.range_check
+        proof = pr.prover.prove_rounds(lambda rnd, chal: pr._t0 if rnd == 0 else rc.round1(ctx, pr._t0, chal[:2], pr._t1), [])
+    barrier(dist, torch)
+    dt = time.perf_counter() - t0
+    dt = reduce_max(dist, torch, dt)
+    names = ("intt", "lde", "hash_lde_leaves", "merkle_levels", "air_quotient", "fri_combine")
+    kstats = {k: ctx.kernel_stats(k) for k in names}
+    ctx.kernel_timing(False)
+    stages = pr.prover.stage_times()
+    out = None
+    if rank == 0:
+        calls, ms, alg = kstats["hash_lde_leaves"]
+        achieved = (alg / calls) / (ms / calls * 1e-3) / 1e9 if calls else 0.0
+        n_rows = n_slots * E.ROWS
+        out = {
+            "metric": "Ed25519 STARK: signature verifications proved per second (secondary workload)",
+            "value": world * args.steps * n_slots / dt, "unit": "signatures/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
+            "config": {"workload": "two-round STARK of 2^%d Ed25519 verifications (%d rows x %d + %d columns, degree-3 AIR, 22 "
+                                   "multiplication units mod 2^255-19 per row, %d range-check lookups per row; standard_fast_config: "
+                                   "rate 2, 84 queries, 16 PoW bits); trace, multiplicities and lookup columns generated on the "
+                                   "GPU inside the timed region; replicas only"
+                                   % (args.log_slots, n_rows, E.N_COLS0, E.N_COLS1, len(E.LOOKUPS)),
+                       "air_program_words": int(pr.stark.desc.n_words), "constraints": pr.es.air.num_constraints,
+                       "proof_bytes": len(proof), "trace_gen_ms_per_step": t_trace / args.steps * 1e3,
+                       "trace_bytes": int(E.N_COLS0 + E.N_COLS1) * n_rows * 8},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_hash_lde_leaves",
+                         "launches": calls, "avg_launch_ms": ms / calls if calls else None,
+                         "alg_bytes_per_launch": alg / calls if calls else None},
+            "stage_ms_last_proof": {k: round(v, 3) for k, v in stages},
+            "kernel_ms_per_proof": {k: round(v[1] / args.steps, 3) for k, v in kstats.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py
+            cores = min(len(os.sched_getaffinity(0)), 16)
+            os.environ["OMP_NUM_THREADS"] = str(cores)
+            pr2 = pr if args.log_slots == 8 else E.Ed25519Prover(ctx, 8)
+            host = pr2.generate_trace(words[:256]).cpu().numpy().view(np.uint64)
+            tc = time.time()
+            p2 = oracle_py.stark_prove_rounds(pr2.stark.desc, lambda rnd, chal: host if rnd == 0 else
+                                              oracle_py.logup_round(host, E.LOOKUPS, 16, host[E.MULT], chal[:2]), [])
+            dtc = time.time() - tc
+            out["cpu_baseline"] = {"value": 256 / dtc, "unit": "signatures/s", "cores": cores, "kind": "port",
+                                   "sample": "oracle two-round STARK prover (incl. its lookup columns) on 2^8 slots in %.1f s (trace "
+                                             "taken from the GPU generator, not timed); oracle verifier accepted it: %s; oracle "
+                                             "verifier on the GPU proof of the full workload: %s"
+                                             % (dtc, oracle_py.stark_verify(pr2.stark.desc, p2) == 1,
+                                                oracle_py.stark_verify(pr.stark.desc, proof) == 1)}
+            if pr2 is not pr:
+                pr2.close()
+        else:
+            out["cpu_baseline"] = None
+    pr.close()
+    ctx.close()
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -485,6 +567,8 @@ def main():
         out = run_sync(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "stark":
         out = run_stark(args, nlx, torch, rank, world, local, dist)
+    elif args.workload == "ed25519":
+        out = run_ed25519(args, nlx, torch, rank, world, local, dist)
     elif args.workload in ("sha256", "sha512"):
         out = run_sha256(args, nlx, torch, rank, world, local, dist)
     else:

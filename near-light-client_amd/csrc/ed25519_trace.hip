@@ -1,0 +1,107 @@
+// Trace generation for the Ed25519 verification AIR (near-light-client_amd/ed25519_air.py; SURVEY.md §8a row a12 /
+// §8f.1: curta_eddsa_verify_sigs_conditional, nearx/src/builder.rs:152).  Two kernels over the row code of
+// ed25519_rows.hpp:
+//   k_ed_scan  one lane per slot walks its 256 rows (the point after each row depends on the one before) and
+//              records the input point of every row - the only sequential part;
+//   k_ed_rows  one lane per row recomputes its 22 units from that input point (results are canonical, so the
+//              recomputation is bit-identical) and writes its 1 945 cells; a wave's 64 lanes are 64 consecutive rows,
+//              so every column store is 512 contiguous bytes.
+#include "ctx.hpp"
+#include "ed25519_rows.hpp"
+#include "transcript.hpp"
+
+namespace nlx {
+
+static_assert(ed::N_COLS0 == NLX_ED25519_COLS0, "column map");
+
+__global__ __launch_bounds__(64) void k_ed_scan(const uint64_t* __restrict__ words, uint32_t n_slots, ed::Slot* __restrict__ slots,
+                                                ed::Point* __restrict__ in, ed::Point* __restrict__ fin) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_slots) return;
+    ed::Slot s;
+    ed::slot_from_words(words + (size_t)k * 24, s);
+    slots[k] = s;
+    ed::Point q;
+    for (int i = 0; i < 16; i++) { q.x[i] = 0; q.y[i] = q.z[i] = i == 0; }
+    ed::NoSink none;
+#pragma unroll 1
+    for (int r = 0; r < ed::ROWS; r++) {
+        in[(size_t)k * ed::ROWS + r] = q;
+        const int bit = ed::ROWS - 1 - r;
+        ed::Point o;
+        ed::row_main(none, q, (int)((s.sw[bit >> 4] >> (bit & 15)) & 1), (int)((s.hw[bit >> 4] >> (bit & 15)) & 1), s, o);
+        q = o;
+    }
+    fin[k] = q;
+}
+
+struct TracePut {
+    uint64_t* trace;
+    size_t n, row;
+    __device__ __forceinline__ void operator()(uint32_t col, uint64_t v) { trace[(size_t)col * n + row] = v; }
+};
+
+__global__ __launch_bounds__(64) void k_ed_rows(const ed::Slot* __restrict__ slots, const ed::Point* __restrict__ in,
+                                                const ed::Point* __restrict__ fin, uint32_t n_slots, uint64_t* __restrict__ trace,
+                                                uint32_t* __restrict__ bad_slot) {
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)n_slots * ed::ROWS;
+    if (row >= n) return;
+    const uint32_t k = (uint32_t)(row / ed::ROWS), prev = k ? k - 1 : n_slots - 1;
+    const int r = (int)(row % ed::ROWS);
+    const ed::Slot s = slots[k];
+    const ed::Point p = in[row];
+    ed::Point prev_fin;
+    uint32_t prev_ry[16];
+    if (r == ed::STEP_YCMP) {
+        prev_fin = fin[prev];
+        for (int i = 0; i < 16; i++) prev_ry[i] = slots[prev].ry[i];
+    }
+    TracePut put{trace, n, row};
+    ed::Point o;
+    // row 0 checks the previous slot's Y comparison
+    if (!ed::emit_row(r, s, p, prev_ry, &prev_fin, put, o)) atomicMin(bad_slot, r == ed::STEP_YCMP ? prev : k);
+}
+
+}  // namespace nlx
+
+using namespace nlx;
+
+extern "C" int32_t nlx_ed25519_trace(nlx_ctx* ctx, const uint64_t* slots, uint32_t log_slots, uint64_t* trace_out) {
+    if (!ctx) return NLX_E_INVAL;
+    if (!slots || !trace_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
+    if (log_slots > 16) return ctx->fail(NLX_E_RANGE, "log_slots must be <= 16");
+    (void)hipSetDevice(ctx->device);
+    const uint32_t n_slots = 1u << log_slots;
+    const size_t n = (size_t)n_slots * ed::ROWS;
+    Staged sw(ctx, slots, (size_t)n_slots * 24 * 8, true, false);
+    if (sw.status) return sw.status;
+    Staged st(ctx, trace_out, (size_t)ed::N_COLS0 * n * 8, false, true);
+    if (st.status) return st.status;
+    const size_t bytes = (size_t)n_slots * sizeof(ed::Slot) + (n + n_slots) * sizeof(ed::Point) + 16;
+    char* d = (char*)ctx->alloc(bytes);
+    if (!d) return NLX_E_NOMEM;
+    ed::Slot* d_slots = (ed::Slot*)d;
+    ed::Point* d_in = (ed::Point*)(d + (size_t)n_slots * sizeof(ed::Slot));
+    ed::Point* d_fin = d_in + n;
+    uint32_t* d_bad = (uint32_t*)(d_fin + n_slots);
+    uint32_t bad = 0xFFFFFFFFu;
+    hipError_t e0 = hipMemcpyAsync(d_bad, &bad, 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e0 != hipSuccess) { ctx->release(d); return ctx->hip_fail(e0, "hipMemcpyAsync"); }
+    hipLaunchKernelGGL(k_ed_scan, dim3((n_slots + 63) / 64), dim3(64), 0, ctx->stream, sw.as<uint64_t>(), n_slots, d_slots, d_in,
+                       d_fin);
+    hipLaunchKernelGGL(k_ed_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_slots, d_in, d_fin, n_slots,
+                       st.as<uint64_t>(), d_bad);
+    e0 = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream);
+    int32_t rc = st.finish();
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    ctx->release(d);
+    if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
+    hipError_t le = hipGetLastError();
+    if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
+    if (!rc && e0 != hipSuccess) rc = ctx->hip_fail(e0, "hipMemcpyAsync");
+    if (!rc && bad != 0xFFFFFFFFu)
+        rc = ctx->fail(NLX_E_INVAL, "slot %u: the statement is false (the signature does not verify, or A / R is not on the curve); "
+                                    "the trace was written but cannot satisfy the AIR", bad);
+    return rc;
+}

@@ -6,106 +6,161 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define FP_HD __host__ __device__
+#define FP_UNROLL _Pragma("unroll")
+#define FP_NOINLINE __attribute__((noinline))
 #else
 #define FP_HD  // plain C++ build: tests/native/fp25519_host_check.cpp checks this arithmetic on the CPU
+#define FP_UNROLL
+#define FP_NOINLINE
 #endif
 
 namespace nlx {
 namespace fp {
 
 constexpr int LIMBS = 16, Q_LIMBS = 17, N_CARRY = 15;
-constexpr int64_t CARRY_OFFSET = (int64_t)1 << 22;
+constexpr int64_t CARRY_OFFSET = (int64_t)1 << 24;  // committed carry R = r + 2^24 < 2^25
+constexpr int CARRY_HI_SHIFT = 7;                    // second lookup cell of a carry: 2^7 * (R >> 16)
+constexpr int Q0_LIMB16 = 16;                        // Q0 = 2^260: the committed quotient is q + Q0 >= 0
 
 struct Unit {
     uint32_t c[LIMBS];
-    uint32_t q[Q_LIMBS];
-    uint32_t carry[N_CARRY];  // R = r + 2^22 < 2^23
+    uint32_t q[Q_LIMBS];      // quotient + Q0
+    uint32_t carry[N_CARRY];  // R
 };
 
-FP_HD inline uint32_t p_limb(int j) { return j == 0 ? 0xFFEDu : (j == 15 ? 0x7FFFu : 0xFFFFu); }
-
-// prod[k] += sum_{i+j=k} a[i] b[j]   (limbs may be a little wider than 16 bits: sums of reduced values)
-FP_HD inline void mul_acc(uint64_t prod[32], const uint32_t a[LIMBS], const uint32_t b[LIMBS]) {
+// prod[k] += sign * sum_{i+j=k} a[i] b[j]   (signed limbs: operands may be differences of reduced values)
+FP_HD inline void mul_acc(int64_t prod[32], const int32_t a[LIMBS], const int32_t b[LIMBS], int sign = 1) {
+    FP_UNROLL
     for (int i = 0; i < LIMBS; i++)
-        for (int j = 0; j < LIMBS; j++) prod[i + j] += (uint64_t)a[i] * b[j];
+        FP_UNROLL
+        for (int j = 0; j < LIMBS; j++) prod[i + j] += sign * ((int64_t)a[i] * b[j]);
 }
 
-// Given the column sums of the products (prod[31] = 0 on entry for a single product): canonical c = total mod p,
-// q = (total - c) / p, and the carries of the unit's equations.
-FP_HD inline void finish(const uint64_t prod[32], Unit& u) {
-    // t = the integer total in 16-bit limbs (34 of them cover two full products)
-    uint32_t t[34];
-    uint64_t cy = 0;
-    for (int k = 0; k < 34; k++) {
-        const uint64_t v = (k < 32 ? prod[k] : 0) + cy;
-        t[k] = (uint32_t)(v & 0xFFFF);
-        cy = v >> 16;
+// Given the signed column sums of the products: canonical c = total mod p, committed q = (total - c) / p + Q0, and
+// the carries of the unit's equations.  If c_fixed is given (a result that already exists, any representative of the
+// right class below 2^256) it is used instead of the canonical one.  Returns false if c_fixed is of another class.
+FP_HD inline bool finish(const int64_t prod[32], Unit& u, const uint32_t* c_fixed = nullptr) {
+    bool ok = true;
+    // total + Q0 p >= 0 as 16-bit limbs; Q0 p = 2^260 p = (p << 4) at limb 16
+    int64_t col[34];
+    FP_UNROLL
+    for (int k = 0; k < 34; k++) col[k] = k < 32 ? prod[k] : 0;
+    {
+        // p << 4 = 2^259 - 304: limbs 0xFED0, 0xFFFF x 14, 0xFFFF, 0x0007
+        col[16] += 0xFED0;
+        FP_UNROLL
+        for (int k = 17; k < 32; k++) col[k] += 0xFFFF;
+        col[32] += 0x7;
     }
-    // total = hi * 2^255 + lo;  total = hi * p + (lo + 19 hi)
-    uint32_t hi[19];
-    for (int k = 0; k < 19; k++) {
-        const uint32_t lo_part = k + 15 < 34 ? t[k + 15] >> 15 : 0, hi_part = k + 16 < 34 ? (t[k + 16] << 1) & 0xFFFF : 0;
+    uint32_t t[35];
+    int64_t cy = 0;
+    FP_UNROLL
+    for (int k = 0; k < 35; k++) {
+        const int64_t v = (k < 34 ? col[k] : 0) + cy;
+        t[k] = (uint32_t)(v & 0xFFFF);
+        cy = v >> 16;  // arithmetic shift: floor division
+    }
+    // t = hi * 2^255 + lo;  t = hi * p + (lo + 19 hi)
+    uint32_t hi[20];
+    FP_UNROLL
+    for (int k = 0; k < 20; k++) {
+        const uint32_t lo_part = k + 15 < 35 ? t[k + 15] >> 15 : 0, hi_part = k + 16 < 35 ? (t[k + 16] << 1) & 0xFFFF : 0;
         hi[k] = lo_part | hi_part;
     }
-    uint32_t s[20];
-    cy = 0;
-    for (int k = 0; k < 20; k++) {
-        uint64_t v = cy + (k < 19 ? 19ull * hi[k] : 0);
+    uint32_t s[21];
+    uint64_t ucy = 0;
+    FP_UNROLL
+    for (int k = 0; k < 21; k++) {
+        uint64_t v = ucy + (k < 20 ? 19ull * hi[k] : 0);
         if (k < 15) v += t[k];
         if (k == 15) v += t[15] & 0x7FFF;
         s[k] = (uint32_t)(v & 0xFFFF);
-        cy = v >> 16;
+        ucy = v >> 16;
     }
     // second fold: s = hi2 * 2^255 + lo2, hi2 small
-    uint64_t hi2 = (s[15] >> 15) | ((uint64_t)s[16] << 1) | ((uint64_t)s[17] << 17) | ((uint64_t)s[18] << 33);
+    const uint64_t hi2 = (s[15] >> 15) | ((uint64_t)s[16] << 1) | ((uint64_t)s[17] << 17) | ((uint64_t)s[18] << 33) |
+                         ((uint64_t)s[19] << 49);
     uint32_t c[LIMBS];
-    cy = 19 * hi2;
+    ucy = 19 * hi2;
+    FP_UNROLL
     for (int k = 0; k < LIMBS; k++) {
-        const uint64_t v = cy + (k == 15 ? (s[15] & 0x7FFF) : s[k]);
+        const uint64_t v = ucy + (k == 15 ? (s[15] & 0x7FFF) : s[k]);
         c[k] = (uint32_t)(v & 0xFFFF);
-        cy = v >> 16;
+        ucy = v >> 16;
     }
-    // q = hi + hi2 (+ 1 if c >= p)
     bool ge = c[15] >= 0x7FFF;
-    if (ge) {
-        if (c[15] == 0x7FFF) {
-            for (int k = 14; k >= 1 && ge; k--) ge = c[k] == 0xFFFF;
-            ge = ge && c[0] >= 0xFFED;
-        }
+    if (ge && c[15] == 0x7FFF) {
+        FP_UNROLL
+        for (int k = 1; k <= 14; k++) ge = ge && c[k] == 0xFFFF;
+        ge = ge && c[0] >= 0xFFED;
     }
-    if (ge) {  // c -= p  <=>  c += 19 - 2^255
-        uint64_t v = (uint64_t)c[0] + 19;
-        c[0] = (uint32_t)(v & 0xFFFF);
-        uint64_t k2 = v >> 16;
-        for (int k = 1; k < LIMBS; k++) {
-            v = (uint64_t)c[k] + k2;
+    if (ge) {  // c -= p  <=>  c += 19, drop bit 255
+        uint64_t k2 = 19;
+        FP_UNROLL
+        for (int k = 0; k < LIMBS; k++) {
+            const uint64_t v = (uint64_t)c[k] + k2;
             c[k] = (uint32_t)(v & 0xFFFF);
             k2 = v >> 16;
         }
         c[15] &= 0x7FFF;
     }
-    cy = hi2 + (ge ? 1 : 0);
+    // committed quotient = hi + hi2 (+ 1 if c >= p): t = (q) p + c with t = total + Q0 p
+    ucy = hi2 + (ge ? 1 : 0);
+    FP_UNROLL
     for (int k = 0; k < Q_LIMBS; k++) {
-        const uint64_t v = cy + hi[k];
+        const uint64_t v = ucy + hi[k];
         u.q[k] = (uint32_t)(v & 0xFFFF);
-        cy = v >> 16;
+        ucy = v >> 16;
     }
+    if (c_fixed) {
+        // the caller's representative is the canonical one plus 0, p or 2p (it is below 2^256): move that many p
+        // from the quotient into c.  A c_fixed of the wrong class leaves the canonical result and returns false: the
+        // statement the unit was asked to witness is not true.
+        ok = false;
+        for (int dq = 0; dq < 3; dq++) {
+            int64_t carry2 = 0;
+            bool same = true;
+            FP_UNROLL
+            for (int k = 0; k < LIMBS; k++) {
+                const int64_t pk = k == 0 ? 0xFFED : (k == 15 ? 0x7FFF : 0xFFFF);
+                const int64_t v = (int64_t)c[k] + dq * pk + carry2;
+                same = same && (uint32_t)(v & 0xFFFF) == c_fixed[k];
+                carry2 = v >> 16;
+            }
+            if (!same || carry2 != 0) continue;
+            int64_t borrow = -dq;
+            FP_UNROLL
+            for (int k = 0; k < Q_LIMBS; k++) {
+                const int64_t v = (int64_t)u.q[k] + borrow;
+                u.q[k] = (uint32_t)(v & 0xFFFF);
+                borrow = v >> 16;
+            }
+            FP_UNROLL
+            for (int k = 0; k < LIMBS; k++) c[k] = c_fixed[k];
+            ok = true;
+            break;
+        }
+    }
+    FP_UNROLL
     for (int k = 0; k < LIMBS; k++) u.c[k] = c[k];
-    // carries: D_k = prod[k] - c[k] - sum q_i p_(k-i);  G_m = D_2m + 2^16 D_2m+1;  G_m + r_(m-1) = 2^32 r_m
+    // carries: D_k = prod[k] - c[k] + 19 (q - Q0)[k] - 2^15 (q - Q0)[k - 15];  G_m = D_2m + 2^16 D_2m+1
     int64_t prev = 0;
+    FP_UNROLL
     for (int m = 0; m < LIMBS; m++) {
         int64_t d2[2];
+        FP_UNROLL
         for (int h = 0; h < 2; h++) {
             const int k = 2 * m + h;
-            int64_t d = (int64_t)prod[k] - (k < LIMBS ? (int64_t)c[k] : 0);
-            const int i0 = k - LIMBS + 1 > 0 ? k - LIMBS + 1 : 0, i1 = k < Q_LIMBS - 1 ? k : Q_LIMBS - 1;
-            for (int i = i0; i <= i1; i++) d -= (int64_t)u.q[i] * p_limb(k - i);
+            int64_t d = prod[k] - (k < LIMBS ? (int64_t)c[k] : 0);
+            if (k < Q_LIMBS) d += 19 * ((int64_t)u.q[k] - (k == 16 ? Q0_LIMB16 : 0));
+            if (k >= 15 && k - 15 < Q_LIMBS) d -= ((int64_t)u.q[k - 15] - (k - 15 == 16 ? Q0_LIMB16 : 0)) * 32768;
             d2[h] = d;
         }
         const int64_t g = d2[0] + d2[1] * 65536 + prev;
         prev = g >> 32;  // exact: g is a multiple of 2^32
         if (m < N_CARRY) u.carry[m] = (uint32_t)(prev + CARRY_OFFSET);
     }
+    return ok;
 }
 
 }  // namespace fp

@@ -8,7 +8,7 @@
 
 namespace nlx {
 
-// chip columns: a[16] b[16] c[16] q[17] (lo, hi, 2^9 hi)[15] multiplicity
+// chip columns: a[16] b[16] c[16] q[17] (lo, hi, 2^7 hi)[15] multiplicity
 enum : uint32_t { cA = 0, cB = 16, cC = 32, cQ = 48, cR = 65, cMULT = 110 };
 static_assert(cMULT + 1 == NLX_FP25519_CHIP_COLS, "column map");
 
@@ -16,17 +16,17 @@ __global__ __launch_bounds__(256) void k_fp25519_chip_trace(const uint64_t* __re
                                                             uint32_t log_n, uint64_t* __restrict__ trace) {
     const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >> log_n) return;
-    uint32_t al[16], bl[16];
+    int32_t al[16], bl[16];
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         const uint64_t x = a[row * 4 + w], y = b[row * 4 + w];
 #pragma unroll
         for (int h = 0; h < 4; h++) {
-            al[4 * w + h] = (uint32_t)((x >> (16 * h)) & 0xFFFF);
-            bl[4 * w + h] = (uint32_t)((y >> (16 * h)) & 0xFFFF);
+            al[4 * w + h] = (int32_t)((x >> (16 * h)) & 0xFFFF);
+            bl[4 * w + h] = (int32_t)((y >> (16 * h)) & 0xFFFF);
         }
     }
-    uint64_t prod[32];
+    int64_t prod[32];
     for (int k = 0; k < 32; k++) prod[k] = 0;
     fp::mul_acc(prod, al, bl);
     fp::Unit u;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_fp25519_chip_trace(const uint64_t* __re
         const uint32_t lo = u.carry[m] & 0xFFFF, hi = u.carry[m] >> 16;
         put(cR + 3 * m, lo);
         put(cR + 3 * m + 1, hi);
-        put(cR + 3 * m + 2, hi << 9);
+        put(cR + 3 * m + 2, hi << fp::CARRY_HI_SHIFT);
     }
     put(cMULT, 0);
 }

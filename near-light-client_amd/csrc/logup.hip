@@ -2,8 +2,8 @@
 // accumulators can depend on verifier challenges; the argument itself - curta's is not in the reference tree - is
 // the log-derivative lookup with the challenge in the quadratic extension, see near-light-client_amd/logup.py).
 //
-// Witness side, all on the device: multiplicities of the looked-up cells (64-bit atomics into the row of each
-// value), then for a challenge alpha the round-1 columns: one helper h = 1/(alpha+v1) + 1/(alpha+v2) per pair of
+// Witness side, all on the device: multiplicities of the looked-up cells (LDS histograms per block, then one
+// global add per non-zero bin), then for a challenge alpha the round-1 columns: one helper h = 1/(alpha+v1) + 1/(alpha+v2) per pair of
 // lookups, g = m/(alpha+t) and the running sum phi (a two-level additive scan).  One extension inversion per
 // looked-up cell (a base-field inversion of the norm): ~130 multiplications, nothing next to hashing the columns.
 #include "ctx.hpp"
@@ -12,17 +12,40 @@
 
 namespace nlx {
 
-__global__ __launch_bounds__(256) void k_logup_count(const uint64_t* __restrict__ trace, const uint32_t* __restrict__ cols,
-                                                     uint32_t log_n, uint32_t table_bits, unsigned long long* __restrict__ mult,
-                                                     uint32_t* __restrict__ err) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >> log_n) return;
-    const uint64_t v = trace[((size_t)cols[blockIdx.y] << log_n) + i];
-    if (v >> table_bits) {
-        atomicOr(err, 1u);
-        return;
+// Multiplicities: a histogram of n_lookups * n cells over up to 2^16 bins.  Many cells are far from uniform (the high
+// parts of carries, constant columns), so global atomics straight from the cells serialise on a few addresses (154 ms
+// for the Ed25519 trace).  Each block instead counts a contiguous chunk of cells in an LDS histogram - one pass per
+// 2^14 bins (64 KB of 32-bit counters) - and adds its non-zero bins to the global column once per pass.
+constexpr uint32_t COUNT_BINS = 1u << 14;
+constexpr uint32_t COUNT_THREADS = 1024;
+
+__global__ __launch_bounds__(COUNT_THREADS) void k_logup_count(const uint64_t* __restrict__ trace, const uint32_t* __restrict__ cols,
+                                                               uint32_t log_n, uint32_t n_lookups, uint32_t table_bits,
+                                                               unsigned long long* __restrict__ mult, uint32_t* __restrict__ err) {
+    __shared__ uint32_t bins[COUNT_BINS];
+    const size_t total = (size_t)n_lookups << log_n;
+    const size_t chunk = (total + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < total ? lo + chunk : total;
+    const uint32_t n_pass = table_bits > 14 ? 1u << (table_bits - 14) : 1u;
+    const size_t n_mask = ((size_t)1 << log_n) - 1;
+    for (uint32_t pass = 0; pass < n_pass; pass++) {
+        for (uint32_t i = threadIdx.x; i < COUNT_BINS; i += COUNT_THREADS) bins[i] = 0;
+        __syncthreads();
+        for (size_t idx = lo + threadIdx.x; idx < hi; idx += COUNT_THREADS) {
+            const uint64_t v = trace[((size_t)cols[idx >> log_n] << log_n) + (idx & n_mask)];
+            if (v >> table_bits) {
+                if (pass == 0) atomicOr(err, 1u);
+            } else if ((uint32_t)(v >> 14) == pass) {
+                atomicAdd(&bins[(uint32_t)v & (COUNT_BINS - 1)], 1u);
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < COUNT_BINS; i += COUNT_THREADS) {
+            const uint32_t c = bins[i];
+            if (c) atomicAdd(mult + ((size_t)pass << 14) + i, (unsigned long long)c);
+        }
+        __syncthreads();
     }
-    atomicAdd(mult + v, 1ull);
 }
 
 struct LogupParams {
@@ -172,8 +195,10 @@ extern "C" int32_t nlx_logup_multiplicities(nlx_ctx* ctx, uint64_t* trace, uint3
     if (e == hipSuccess) e = hipMemsetAsync(mult, 0, n * 8, st);
     uint32_t err = 0;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_logup_count, dim3((unsigned)((n + 255) / 256), n_lookups), dim3(256), 0, st, tr.as<uint64_t>(), d_cols,
-                           log_n, table_bits, (unsigned long long*)mult, d_err);
+        const size_t total = (size_t)n_lookups << log_n;
+        const unsigned blocks = (unsigned)(total < ((size_t)512 << 12) ? (total + 4095) / 4096 : 512);  // >= 4096 cells per block
+        hipLaunchKernelGGL(k_logup_count, dim3(blocks), dim3(COUNT_THREADS), 0, st, tr.as<uint64_t>(), d_cols, log_n, n_lookups,
+                           table_bits, (unsigned long long*)mult, d_err);
         e = hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) rc = tr.finish();

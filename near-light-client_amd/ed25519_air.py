@@ -1,0 +1,478 @@
+"""Ed25519 signature verification as an AIR (`curta_eddsa_verify_sigs_conditional`,
+nearx/src/builder.rs:152 - the largest share of a Sync proof; curta's own tables are not in the reference tree,
+Cargo.lock:6515, so this is an independent construction on the pieces of this package: fp25519 units, logup range
+checks, the multi-round prover).
+
+Statement per signature slot (256 consecutive rows):  [S] B + [h] (-A) = R  on the twisted Edwards curve
+-x^2 + y^2 = 1 + d x^2 y^2 over F_p, p = 2^255 - 19, for the slot's A = (AX, AY), R = (RX, RY) (affine, 16-bit limbs),
+S and h (16 limbs each; h is the SHA-512 digest already reduced mod L - sha512_air.py proves the digest itself), with
+A and R checked to be on the curve.  Row r of a slot handles bit 255 - r of both scalars:
+
+    Q <- 2 Q                  8 units   (dbl-2008-hwcd, a = -1)
+    Q <- Q + s_bit * B        7 units   (madd-2008-hwcd-3 with the precomputed affine triple (y-x, y+x, 2dxy); a zero bit
+    Q <- Q + h_bit * (-A)     6 units    adds the neutral triple (1, 1, 0); the last T is not needed)
+
+21 multiplication units per row plus one auxiliary unit that runs a small per-slot program in otherwise idle rows:
+2d*x*y of A (the addend's third coordinate), the curve equation of A and of R, and the final comparison
+RX * Z = X, RY * Z = Y.  Everything a unit reads is either a range-checked cell, a constant, or a cell tied by a
+degree <= 3 constraint to one of those; all unit results, quotients and carries (and the limbs of A and R) go through
+the 2^16-table lookup.  Constraint degree 3, two commitment rounds (the second is logup.py's columns).
+
+Scope of this version: the slot's (A, R, S, h) are witness columns constant over the slot - binding them to data
+outside the proof (curta does that with its bus; here it would be one more running accumulator over a challenge) and
+the reduction of the 512-bit digest mod L are left to the caller.  The check is the cofactorless one
+(ed25519-dalek's `verify`: [S]B - [h]A == R).
+"""
+import numpy as np
+
+from . import fp25519 as fp
+from . import logup
+from .stark import Air, Stark
+
+P = fp.P25519
+D = (-121665 * pow(121666, P - 2, P)) % P
+D2 = 2 * D % P
+L_ORDER = (1 << 252) + 27742317777372353535851937790883648493
+BY = 4 * pow(5, P - 2, P) % P
+
+
+def _recover_x(y, sign):
+    x2 = (y * y - 1) * pow(D * y * y + 1, P - 2, P) % P
+    x = pow(x2, (P + 3) // 8, P)
+    if (x * x - x2) % P:
+        x = x * pow(2, (P - 1) // 4, P) % P
+    if (x * x - x2) % P:
+        return None
+    if (x & 1) != sign:
+        x = P - x
+    return x
+
+
+BX = _recover_x(BY, 0)
+ROWS = 256                       # rows per signature slot
+N_MAIN = 21
+UNIT = fp.UNIT_CELLS             # 78 range-checked cells per unit
+
+
+class _Layout:
+    """Round-0 column allocation; `lookups` collects the range-checked cells."""
+
+    def __init__(self):
+        self.n = 0
+        self.lookups = []
+
+    def take(self, count, lookup=False):
+        base = self.n
+        self.n += count
+        if lookup:
+            self.lookups += list(range(base, base + count))
+        return base
+
+
+LAY = _Layout()
+SIN = LAY.take(48)                               # the row's input point X, Y, Z
+SB, HB, SA, HA = (LAY.take(1) for _ in range(4))  # scalar bits and their 16-bit limb accumulators
+AX, AY, RX, RY = (LAY.take(16, True) for _ in range(4))
+NT, SW, HW = (LAY.take(16) for _ in range(3))     # 2d x y of A; limbs of S and h
+MAIN = [LAY.take(UNIT, True) for _ in range(N_MAIN)]
+AUX_A, AUX_B, AUX_E, AUX_F = (LAY.take(16) for _ in range(4))
+AUX = LAY.take(UNIT, True)
+MULT = LAY.take(1)
+N_COLS0 = LAY.n
+LOOKUPS = list(LAY.lookups)
+N_COLS1 = logup.round_cols(len(LOOKUPS))
+# main unit indices
+(U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2,
+ U_BA, U_BB, U_BC, U_X3, U_Y3, U_T3, U_Z3,
+ U_AA, U_AB, U_AC, U_X4, U_Y4, U_Z4) = range(N_MAIN)
+AUX_STEPS = {"ycmp": 0, "a_u": 1, "a_nt": 2, "a_u2": 3, "a_v": 4, "a_chk": 5, "r_u": 6, "r_v": 7, "r_chk": 8, "xcmp": 255}
+
+
+class _Vec:
+    """16 limb expressions (or integers) with a bound on their magnitude."""
+
+    def __init__(self, limbs, bound):
+        self.limbs, self.bound = list(limbs), bound
+
+    def __add__(self, o):
+        return _Vec([a + b for a, b in zip(self.limbs, o.limbs)], self.bound + o.bound)
+
+    def __sub__(self, o):
+        return _Vec([a - b for a, b in zip(self.limbs, o.limbs)], self.bound + o.bound)
+
+    def scale(self, k):
+        return _Vec([a * k for a in self.limbs], self.bound * abs(k))
+
+
+def _const_vec(value):
+    return _Vec(fp.to_limbs(value % P), 1 << 16)
+
+
+def ed25519_air():
+    air = Air(N_COLS0 + N_COLS1, 0, rounds=[(N_COLS0, 2), (N_COLS1, 0)])
+    L, N = air.local, air.next  # noqa: N806
+
+    def cells(base, nxt=False):
+        return _Vec([(N if nxt else L)(base + i) for i in range(16)], 1 << 16)
+
+    def unit_cells(base):
+        q = [L(base + 16 + i) for i in range(17)]
+        carries = [(L(base + 33 + 3 * m), L(base + 34 + 3 * m), L(base + 35 + 3 * m)) for m in range(fp.N_CARRY)]
+        return q, carries
+
+    def unit(base, products, c=None):
+        """products: [(vec a, vec b, sign)]; result cells at `base` unless c (a _Vec of cells / constants) is given."""
+        q, carries = unit_cells(base)
+        out = cells(base) if c is None else c
+        fp.mul_unit_constraints(air, [(a.limbs, b.limbs, sg, a.bound * b.bound) for a, b, sg in products], out.limbs, q, carries)
+        return cells(base)
+
+    def periodic_rows(rows):
+        return air.periodic([1 if r in rows else 0 for r in range(ROWS)])
+
+    is_last = periodic_rows({ROWS - 1})
+    limb_end = periodic_rows({r for r in range(ROWS) if r % 16 == 15})      # also: "the next row starts a limb"
+    block = [periodic_rows(set(range(16 * (15 - j), 16 * (15 - j) + 16))) for j in range(16)]   # rows of limb j (MSB first)
+    step = {name: periodic_rows({r}) for name, r in AUX_STEPS.items()}
+
+    # ---- scalars: bits, limb accumulators, limbs ----
+    sb, hb = L(SB), L(HB)
+    air.constraint(sb * (sb - 1))
+    air.constraint(hb * (hb - 1))
+    for acc, bit, words in ((SA, SB, SW), (HA, HB, HW)):
+        air.constraint(N(acc) - (1 - limb_end) * L(acc) * 2 - N(bit))
+        cur = block[0] * L(words)
+        for j in range(1, 16):
+            cur = cur + block[j] * L(words + j)
+        air.constraint(limb_end * (L(acc) - cur))
+    # ---- per-slot columns stay constant inside a slot ----
+    for base in (AX, AY, RX, RY, NT, SW, HW):
+        for i in range(16):
+            air.constraint((1 - is_last) * (N(base + i) - L(base + i)))
+
+    # ---- doubling of the input point ----
+    x1, y1, z1 = cells(SIN), cells(SIN + 16), cells(SIN + 32)
+    a_ = unit(MAIN[U_A], [(x1, x1, 1)])
+    b_ = unit(MAIN[U_B], [(y1, y1, 1)])
+    zz = unit(MAIN[U_ZZ], [(z1, z1, 1)])
+    xy = x1 + y1
+    e1 = unit(MAIN[U_E], [(xy, xy, 1)])
+    e = e1 - a_ - b_
+    g = b_ - a_
+    f = g - zz.scale(2)
+    h = (a_ + b_).scale(-1)
+    x2 = unit(MAIN[U_X2], [(e, f, 1)])
+    y2 = unit(MAIN[U_Y2], [(g, h, 1)])
+    t2 = unit(MAIN[U_T2], [(e, h, 1)])
+    z2 = unit(MAIN[U_Z2], [(f, g, 1)])
+
+    def madd(units, x, y, z, t, ymx, ypx, t2d, want_t):
+        aa = unit(MAIN[units[0]], [(y - x, ymx, 1)])
+        bb = unit(MAIN[units[1]], [(y + x, ypx, 1)])
+        cc = unit(MAIN[units[2]], [(t, t2d, 1)])
+        dd = z.scale(2)
+        e_, f_, g_, h_ = bb - aa, dd - cc, dd + cc, bb + aa
+        x3 = unit(MAIN[units[3]], [(e_, f_, 1)])
+        y3 = unit(MAIN[units[4]], [(g_, h_, 1)])
+        t3 = unit(MAIN[units[5]], [(e_, h_, 1)]) if want_t else None
+        z3 = unit(MAIN[units[6 if want_t else 5]], [(f_, g_, 1)])
+        return x3, y3, z3, t3
+
+    def select(bit, vec_limbs, neutral_first, bound):
+        """bit * v + (1 - bit) * neutral, neutral = (neutral_first, 0, .., 0)"""
+        out = []
+        for i, v in enumerate(vec_limbs):
+            n0 = neutral_first if i == 0 else 0
+            out.append(bit * (v - n0) + n0 if n0 else bit * v)
+        return _Vec(out, bound)
+
+    # ---- + s_bit * B (constants) ----
+    b_ymx, b_ypx, b_t2d = (BY - BX) % P, (BY + BX) % P, D2 * BX * BY % P
+    x3, y3, z3, t3 = madd((U_BA, U_BB, U_BC, U_X3, U_Y3, U_T3, U_Z3), x2, y2, z2, t2,
+                          select(sb, fp.to_limbs(b_ymx), 1, 1 << 16), select(sb, fp.to_limbs(b_ypx), 1, 1 << 16),
+                          select(sb, fp.to_limbs(b_t2d), 0, 1 << 16), True)
+    # ---- + h_bit * (-A): the triple of (-x, y) is (y + x, y - x, -2dxy) ----
+    ax, ay, nt = cells(AX), cells(AY), cells(NT)
+    x4, y4, z4, _ = madd((U_AA, U_AB, U_AC, U_X4, U_Y4, U_Z4), x3, y3, z3, t3,
+                         select(hb, (ay + ax).limbs, 1, 1 << 17), select(hb, (ay - ax).limbs, 1, 1 << 16),
+                         select(hb, nt.scale(-1).limbs, 0, 1 << 16), False)
+    # ---- the next row starts from this row's result, a new slot from the neutral element (0, 1, 1) ----
+    for k, vec in enumerate((x4, y4, z4)):
+        for i in range(16):
+            neutral = 1 if (k > 0 and i == 0) else 0
+            air.constraint(N(SIN + 16 * k + i) - (vec.limbs[i] + is_last * (neutral - vec.limbs[i])))
+
+    # ---- the auxiliary unit:  A * B + E * E - F * F = C ----
+    ua, ub, ue, uf, uc = cells(AUX_A), cells(AUX_B), cells(AUX_E), cells(AUX_F), cells(AUX)
+    unit(AUX, [(ua, ub, 1), (ue, ue, 1), (uf, uf, -1)])
+    rx, ry = cells(RX), cells(RY)
+    d_l, d2_l, m1_l = fp.to_limbs(D), fp.to_limbs(D2), fp.to_limbs(P - 1)
+
+    def tie(sel, lhs, rhs):
+        for i in range(16):
+            r = rhs[i] if isinstance(rhs, list) else rhs.limbs[i]
+            air.constraint(sel * (lhs.limbs[i] - r))
+
+    nxt_a, nxt_b, nxt_c = cells(AUX_A, True), cells(AUX_B, True), cells(AUX, True)
+    for pre, u_, v_, chk, px, py in (("a", "a_u2", "a_v", "a_chk", ax, ay), ("r", "r_u", "r_v", "r_chk", rx, ry)):
+        tie(step[u_], ua, px)                     # u = x y
+        tie(step[u_], ub, py)
+        tie(step[u_], nxt_a, uc)                  # v = u u   (the next row reads this row's result)
+        tie(step[u_], nxt_b, uc)
+        tie(step[v_], nxt_b, uc)                  # check: d v + x x - y y = -1
+        tie(step[chk], ua, d_l)
+        tie(step[chk], ue, px)
+        tie(step[chk], uf, py)
+        tie(step[chk], uc, m1_l)
+    tie(step["a_u"], ua, ax)                      # u = x y, then NT = 2d u
+    tie(step["a_u"], ub, ay)
+    tie(step["a_u"], nxt_b, uc)
+    tie(step["a_nt"], ua, d2_l)
+    tie(step["a_nt"], nt, uc)
+    tie(step["xcmp"], ua, rx)                     # RX * Z = X on the slot's last row ...
+    tie(step["xcmp"], ub, z4)
+    tie(step["xcmp"], uc, x4)
+    tie(step["xcmp"], nxt_a, ry)                  # ... RY * Z = Y on the row after it
+    tie(step["xcmp"], nxt_b, z4)
+    tie(step["xcmp"], nxt_c, y4)
+    no_sq = 1 - step["a_chk"] - step["r_chk"]
+    for i in range(16):
+        air.constraint(no_sq * L(AUX_E + i))
+        air.constraint(no_sq * L(AUX_F + i))
+
+    rc = logup.RangeCheck(air, LOOKUPS, 16, MULT, N_COLS0)
+    return air, rc
+
+
+# ---------------------------------------------------------------------------------------------
+# plain-Python witness (tests only; the product path generates the trace on the GPU)
+# ---------------------------------------------------------------------------------------------
+def _signed(vals):
+    return [int(v) for v in vals]
+
+
+def _vadd(a, b):
+    return [x + y for x, y in zip(a, b)]
+
+
+def _vsub(a, b):
+    return [x - y for x, y in zip(a, b)]
+
+
+def _vscale(a, k):
+    return [x * k for x in a]
+
+
+def reference_slot(ax, ay, rx, ry, s, h):
+    """The 256 round-0 rows of one slot (multiplicity column zero): (N_COLS0, 256) uint64 in the Goldilocks field.
+    Raises AssertionError if the statement is false (a unit has no witness)."""
+    gl = 0xFFFFFFFF00000001
+    t = np.zeros((N_COLS0, ROWS), dtype=np.uint64)
+
+    def put_unit(base, row, products, c=None):
+        cl, ql, carries = fp.mul_unit_witness(products, c=c)
+        t[base:base + 16, row] = cl
+        t[base + 16:base + 33, row] = ql
+        t[base + 33:base + 78, row] = [v for tr in carries for v in tr]
+        return cl
+
+    def put_vec(base, row, limbs):
+        t[base:base + 16, row] = [v % gl for v in limbs]
+
+    axl, ayl, rxl, ryl = (fp.to_limbs(v) for v in (ax, ay, rx, ry))
+    ntv = D2 * ax * ay % P
+    ntl = fp.to_limbs(ntv)
+    one = fp.to_limbs(1)
+    b_ymx, b_ypx, b_t2d = fp.to_limbs((BY - BX) % P), fp.to_limbs((BY + BX) % P), fp.to_limbs(D2 * BX * BY % P)
+    zero = [0] * 16
+    q = (zero, one, one)                                   # X, Y, Z limbs
+    sa = ha = 0
+    aux_prev_c = None
+    for r in range(ROWS):
+        bit = ROWS - 1 - r
+        sbit, hbit = (s >> bit) & 1, (h >> bit) & 1
+        sa = (0 if r % 16 == 0 else 2 * sa) + sbit
+        ha = (0 if r % 16 == 0 else 2 * ha) + hbit
+        t[SB, r], t[HB, r], t[SA, r], t[HA, r] = sbit, hbit, sa, ha
+        for base, limbs in ((AX, axl), (AY, ayl), (RX, rxl), (RY, ryl), (NT, ntl), (SW, fp.to_limbs(s)), (HW, fp.to_limbs(h))):
+            put_vec(base, r, limbs)
+        x1, y1, z1 = q
+        put_vec(SIN, r, x1)
+        put_vec(SIN + 16, r, y1)
+        put_vec(SIN + 32, r, z1)
+        a_ = put_unit(MAIN[U_A], r, [(x1, x1)])
+        b_ = put_unit(MAIN[U_B], r, [(y1, y1)])
+        zz = put_unit(MAIN[U_ZZ], r, [(z1, z1)])
+        xy = _vadd(x1, y1)
+        e1 = put_unit(MAIN[U_E], r, [(xy, xy)])
+        e = _vsub(_vsub(e1, a_), b_)
+        g = _vsub(b_, a_)
+        f = _vsub(g, _vscale(zz, 2))
+        hh = _vscale(_vadd(a_, b_), -1)
+        x2 = put_unit(MAIN[U_X2], r, [(e, f)])
+        y2 = put_unit(MAIN[U_Y2], r, [(g, hh)])
+        t2 = put_unit(MAIN[U_T2], r, [(e, hh)])
+        z2 = put_unit(MAIN[U_Z2], r, [(f, g)])
+
+        def madd(units, x, y, z, tt, ymx, ypx, t2d, want_t):
+            aa = put_unit(MAIN[units[0]], r, [(_vsub(y, x), ymx)])
+            bb = put_unit(MAIN[units[1]], r, [(_vadd(y, x), ypx)])
+            cc = put_unit(MAIN[units[2]], r, [(tt, t2d)])
+            dd = _vscale(z, 2)
+            e_, f_, g_, h_ = _vsub(bb, aa), _vsub(dd, cc), _vadd(dd, cc), _vadd(bb, aa)
+            x3 = put_unit(MAIN[units[3]], r, [(e_, f_)])
+            y3 = put_unit(MAIN[units[4]], r, [(g_, h_)])
+            t3 = put_unit(MAIN[units[5]], r, [(e_, h_)]) if want_t else None
+            z3 = put_unit(MAIN[units[6 if want_t else 5]], r, [(f_, g_)])
+            return x3, y3, z3, t3
+
+        x3, y3, z3, t3 = madd((U_BA, U_BB, U_BC, U_X3, U_Y3, U_T3, U_Z3), x2, y2, z2, t2,
+                              b_ymx if sbit else one, b_ypx if sbit else one, b_t2d if sbit else zero, True)
+        x4, y4, z4, _ = madd((U_AA, U_AB, U_AC, U_X4, U_Y4, U_Z4), x3, y3, z3, t3,
+                             _vadd(ayl, axl) if hbit else one, _vsub(ayl, axl) if hbit else one,
+                             _vscale(ntl, -1) if hbit else zero, False)
+        # auxiliary program
+        ua = ub = ue = uf = zero
+        c_fixed = None
+        if r == AUX_STEPS["a_u"] or r == AUX_STEPS["a_u2"]:
+            ua, ub = axl, ayl
+        elif r == AUX_STEPS["a_nt"]:
+            ua, ub = fp.to_limbs(D2), aux_prev_c
+        elif r in (AUX_STEPS["a_v"], AUX_STEPS["r_v"]):
+            ua = ub = aux_prev_c
+        elif r == AUX_STEPS["a_chk"]:
+            ua, ub, ue, uf, c_fixed = fp.to_limbs(D), aux_prev_c, axl, ayl, P - 1
+        elif r == AUX_STEPS["r_u"]:
+            ua, ub = rxl, ryl
+        elif r == AUX_STEPS["r_chk"]:
+            ua, ub, ue, uf, c_fixed = fp.to_limbs(D), aux_prev_c, rxl, ryl, P - 1
+        elif r == AUX_STEPS["xcmp"]:
+            ua, ub, c_fixed = rxl, z4, fp.from_limbs(x4)
+        for base, limbs in ((AUX_A, ua), (AUX_B, ub), (AUX_E, ue), (AUX_F, uf)):
+            put_vec(base, r, limbs)
+        if r != AUX_STEPS["ycmp"]:
+            aux_prev_c = put_unit(AUX, r, [(ua, ub, 1), (ue, ue, 1), (uf, uf, -1)], c=c_fixed)
+        q = (x4, y4, z4)
+    return t, q
+
+
+def reference_trace(slots):
+    """Round-0 trace of a list of slots (ax, ay, rx, ry, s, h): the Y comparison of slot k sits in row 0 of slot k + 1
+    (cyclically)."""
+    parts, finals = [], []
+    for sl in slots:
+        tr, q = reference_slot(*sl)
+        parts.append(tr)
+        finals.append(q)
+    for k, sl in enumerate(slots):
+        prev = (k - 1) % len(slots)
+        ry, (x4, y4, z4) = fp.to_limbs(slots[prev][3]), finals[prev]
+        tr = parts[k]
+        tr[AUX_A:AUX_A + 16, 0] = ry
+        tr[AUX_B:AUX_B + 16, 0] = z4
+        cl, ql, carries = fp.mul_unit_witness([(ry, z4, 1)], c=fp.from_limbs(y4))
+        tr[AUX:AUX + 16, 0] = cl
+        tr[AUX + 16:AUX + 33, 0] = ql
+        tr[AUX + 33:AUX + 78, 0] = [v for c3 in carries for v in c3]
+    return np.concatenate(parts, axis=1)
+
+
+def slot_from_signature(public_key, message, signature):
+    """(ax, ay, rx, ry, s, h) for an RFC 8032 signature, or None if the encodings are invalid."""
+    import hashlib
+    if len(public_key) != 32 or len(signature) != 64:
+        return None
+
+    def decode(b):
+        y = int.from_bytes(b, "little")
+        sign, y = y >> 255, y & ((1 << 255) - 1)
+        if y >= P:
+            return None
+        x = _recover_x(y, sign)
+        return None if x is None else (x, y)
+
+    a, r = decode(public_key), decode(signature[:32])
+    s = int.from_bytes(signature[32:], "little")
+    if a is None or r is None or s >= L_ORDER:
+        return None
+    h = int.from_bytes(hashlib.sha512(signature[:32] + public_key + message).digest(), "little") % L_ORDER
+    return a[0], a[1], r[0], r[1], s, h
+
+
+def synthetic_slots(count, seed=1):
+    """`count` true statements [S]B = R + [h]A with random keys, nonces and h (the AIR does not tie h to a hash, so any
+    h with S = r + h a mod L makes a valid slot): the bench's workload."""
+    import random
+    from .near_protocol import _G, _mul
+    rnd = random.Random(seed)
+
+    def affine(pt):
+        zi = pow(pt[2], P - 2, P)
+        return pt[0] * zi % P, pt[1] * zi % P
+    out = []
+    for _ in range(count):
+        a, r, h = (rnd.randrange(1, L_ORDER) for _ in range(3))
+        (ax, ay), (rx, ry) = affine(_mul(a, _G)), affine(_mul(r, _G))
+        out.append((ax, ay, rx, ry, (r + h * a) % L_ORDER, h))
+    return out
+
+
+def slots_to_words(slots):
+    """[(ax, ay, rx, ry, s, h)] -> (n, 24) uint64: the input format of nlx_ed25519_trace"""
+    out = np.zeros((len(slots), 24), dtype=np.uint64)
+    for k, sl in enumerate(slots):
+        for v, x in enumerate(sl):
+            for w in range(4):
+                out[k, 4 * v + w] = (int(x) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+class Ed25519Stark:
+    """The AIR compiled for 2^log_slots signature slots (256 rows each)."""
+
+    def __init__(self, log_slots, config=None):
+        if log_slots < 8:
+            raise ValueError("at least 2^8 slots per proof (the 2^16-entry range table needs 2^16 rows)")
+        self.log_slots = log_slots
+        self.air, self.range_check = ed25519_air()
+        self.stark = Stark(self.air, log_slots + 8, config)
+
+
+class Ed25519Prover:
+    """Proves 2^log_slots Ed25519 verifications on one GPU: trace generation (nlx_ed25519_trace), multiplicities and
+    lookup columns (nlx_logup_*), two-round STARK (nlx_stark_prove_rounds) - nothing of the trace touches the host."""
+
+    def __init__(self, ctx, log_slots, config=None):
+        self.ctx = ctx
+        self.es = Ed25519Stark(log_slots, config)
+        self.stark = self.es.stark
+        self.prover = self.stark.build(ctx)
+        self._t0 = self._t1 = None
+
+    def generate_trace(self, slots):
+        """slots: list of 2^log_slots (ax, ay, rx, ry, s, h).  Returns the device round-0 trace with multiplicities;
+        raises NlxError if a statement is false (its comparison unit has no in-range witness)."""
+        import torch
+        from ._lib import dll
+        n_slots = 1 << self.es.log_slots
+        words = slots if isinstance(slots, np.ndarray) else slots_to_words(slots)
+        if words.shape != (n_slots, 24):
+            raise ValueError("expected 2^%d slots" % self.es.log_slots)
+        n = n_slots * ROWS
+        if self._t0 is None:
+            dev = "cuda:%d" % self.ctx.device
+            self._t0 = torch.empty((N_COLS0, n), dtype=torch.int64, device=dev)
+            self._t1 = torch.empty((N_COLS1, n), dtype=torch.int64, device=dev)
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        self.ctx.check(dll.nlx_ed25519_trace(self.ctx.handle, words.ctypes.data, self.es.log_slots, self._t0.data_ptr()))
+        self.es.range_check.multiplicities(self.ctx, self._t0)
+        return self._t0
+
+    def prove(self, slots):
+        t0 = self.generate_trace(slots)
+        rc = self.es.range_check
+        return self.prover.prove_rounds(lambda rnd, chal: t0 if rnd == 0 else rc.round1(self.ctx, t0, chal[:2], self._t1), [])
+
+    def close(self):
+        self.prover.close()
+        self._t0 = self._t1 = None

@@ -2,15 +2,19 @@
 verifications nearx proves with curta_eddsa_verify_sigs_conditional, nearx/src/builder.rs:152; curta's own field /
 curve tables are not in the reference tree, Cargo.lock:6515 - this is an independent construction).
 
-Representation: an element is 16 limbs of 16 bits, little-endian, any representative < 2^256.  One multiplication
-unit proves  sum_t a_t * b_t = c + q * p  over the integers for range-checked limbs:
+Representation: an element is 16 limbs of 16 bits, little-endian, any representative < 2^256; operands of a unit may
+be signed linear combinations of such limb vectors (limb magnitudes up to 2^18).  One multiplication unit proves
+sum_t s_t a_t * b_t = c + (q - Q0) * p  over the integers (s_t = +-1, Q0 = 2^260 keeps the committed q non-negative
+when the left side is negative) for range-checked c, q and carries:
 
-    D_k = sum_t sum_{i+j=k} a_t[i] b_t[j]  -  c[k]  -  sum_{i+j=k} q[i] p[j]            k = 0 .. 31
-    G_m = D_2m + 2^16 D_2m+1,      G_m + r_(m-1) = 2^32 r_m,      r_(-1) = r_15 = 0       m = 0 .. 15
+    D_k = sum_t s_t sum_{i+j=k} a_t[i] b_t[j]  -  c[k]  +  19 (q - Q0)[k]  -  2^15 (q - Q0)[k - 15]          k = 0 .. 31
+    G_m = D_2m + 2^16 D_2m+1,      G_m + r_(m-1) = 2^32 r_m,      r_(-1) = r_15 = 0                          m = 0 .. 15
 
-with q of 17 limbs and signed carries r_m = R_m - 2^22, R_m = lo + 2^16 hi < 2^23 (lo and hi range-checked by lookup,
-hi < 2^7 through a second lookup of 2^9 hi).  Every |G_m + r_(m-1) - 2^32 r_m| < 2^56 < p_Goldilocks, so each field
-equation holds over the integers and the chain telescopes to sum_k D_k 2^(16 k) = 0.  All constraints have degree 2.
+(p = 2^255 - 19 written with the two signed "limbs" -19 and 2^15 X^15, X = 2^16: two terms per quotient limb instead
+of sixteen), q of 17 limbs and signed carries r_m = R_m - 2^24, R_m = lo + 2^16 hi < 2^25 (lo and hi range-checked by
+lookup, hi < 2^9 through a second lookup of 2^7 hi).  With sum_t 16 |a_t|_max |b_t|_max < 2^40 (checked when a unit is
+built) every |G_m + r_(m-1) - 2^32 r_m| < 2^58 < p_Goldilocks, so each field equation holds over the integers and the
+chain telescopes to sum_k D_k 2^(16 k) = 0.  All unit constraints have degree <= the product of its operand degrees.
 Range checks are near-light-client_amd/logup.py lookups into the 2^16 table.
 
 `FpMulChip` is the unit on its own as a two-round STARK (one multiplication per row): the building block, its tests
@@ -26,7 +30,10 @@ LIMBS = 16
 LIMB_BITS = 16
 Q_LIMBS = 17
 N_CARRY = 15
-CARRY_OFFSET = 1 << 22
+CARRY_OFFSET = 1 << 24
+CARRY_HI_SHIFT = 7                                  # hi < 2^9  <=>  hi and 2^7 hi are both in the 2^16 table
+Q0 = 1 << 260
+Q0_LIMBS = [(Q0 >> (16 * i)) & 0xFFFF for i in range(Q_LIMBS)]   # only limb 16 is non-zero (= 16)
 P_LIMBS = [(P25519 >> (16 * i)) & 0xFFFF for i in range(LIMBS)]
 UNIT_CELLS = LIMBS + Q_LIMBS + 3 * N_CARRY      # c, q, (lo, hi, 2^9 hi) per carry = 78 range-checked cells
 
@@ -39,21 +46,37 @@ def from_limbs(limbs):
     return sum(int(v) << (16 * i) for i, v in enumerate(limbs))
 
 
-def mul_unit_constraints(air, products, c, q, carries, c_scale=1):
-    """Adds the 16 carry-chain constraints of one unit.  products: list of (a, b) with a, b lists of 16 limb
-    expressions; c: 16 limb expressions (the result, or any linear expression of range-checked limbs); q: 17 limb
-    expressions; carries: list of 15 (lo, hi, hi9) expression triples.  Also ties hi9 = 2^9 hi."""
+def mul_unit_constraints(air, products, c, q, carries):
+    """Adds the 16 carry-chain constraints of one unit (+ 15 ties of the carries' second lookup cell).
+
+    products: list of (a, b, sign, bound): a, b lists of 16 limb expressions, sign = +-1, bound >= max |a_i| max |b_j|;
+    c: 16 limb expressions or integers (the result cells, or a constant); q: 17 limb expressions;
+    carries: list of 15 (lo, hi, hi_shifted) expression triples."""
+    assert sum(16 * bound for _, _, _, bound in products) < (1 << 40), "operand limbs too large for the carry range"
     d = []
     for k in range(2 * LIMBS):
-        terms = []
-        for a, b in products:
-            terms += [a[i] * b[k - i] for i in range(max(0, k - LIMBS + 1), min(LIMBS, k + 1))]
+        terms, const = [], 0
+        for a, b, sign, _ in products:
+            for i in range(max(0, k - LIMBS + 1), min(LIMBS, k + 1)):
+                t = a[i] * b[k - i]
+                terms.append(t if sign > 0 else t * (-1))
         if k < LIMBS:
-            terms.append(c[k] * (-c_scale))
-        terms += [q[i] * (-P_LIMBS[k - i]) for i in range(max(0, k - LIMBS + 1), min(Q_LIMBS, k + 1))]
+            if isinstance(c[k], int):
+                const -= c[k]
+            else:
+                terms.append(c[k] * (-1))
+        # - (q - Q0) p  with  p = -19 + 2^15 X^15
+        if k < Q_LIMBS:
+            terms.append(q[k] * 19)
+            const -= 19 * Q0_LIMBS[k]
+        if 0 <= k - 15 < Q_LIMBS:
+            terms.append(q[k - 15] * (-(1 << 15)))
+            const += (1 << 15) * Q0_LIMBS[k - 15]
         acc = terms[0]
         for t in terms[1:]:
             acc = acc + t
+        if const:
+            acc = acc + const
         d.append(acc)
     prev = None
     for m in range(LIMBS):
@@ -61,36 +84,41 @@ def mul_unit_constraints(air, products, c, q, carries, c_scale=1):
         if prev is not None:
             g = g + prev
         if m < N_CARRY:
-            lo, hi, hi9 = carries[m]
+            lo, hi, his = carries[m]
             r = lo + hi * (1 << 16) - CARRY_OFFSET
             air.constraint(g - r * (1 << 32))
-            air.constraint(hi9 - hi * (1 << 9))
+            air.constraint(his - hi * (1 << CARRY_HI_SHIFT))
             prev = r
         else:
             air.constraint(g)
 
 
+def _limbs_signed(x):
+    return to_limbs(x) if isinstance(x, int) else [int(v) for v in x]
+
+
 def mul_unit_witness(products, c=None):
-    """Integer witness of one unit: (c limbs, q limbs, [(lo, hi, hi9)] * 15).  products: list of (a, b) integers or limb
-    lists (limbs may exceed 16 bits, e.g. sums of reduced values); c: the result to use (default: canonical)."""
-    pl = [(to_limbs(a) if isinstance(a, int) else [int(v) for v in a], to_limbs(b) if isinstance(b, int) else [int(v) for v in b])
-          for a, b in products]
-    total = sum(from_limbs(a) * from_limbs(b) for a, b in pl)
+    """Integer witness of one unit: (c limbs, q limbs, [(lo, hi, hi_shifted)] * 15).  products: list of (a, b) or
+    (a, b, sign): integers or (possibly signed) limb lists; c: the result to use (default: canonical)."""
+    pl = [(_limbs_signed(pr[0]), _limbs_signed(pr[1]), pr[2] if len(pr) > 2 else 1) for pr in products]
+    total = sum(sg * from_limbs(a) * from_limbs(b) for a, b, sg in pl)
     cv = total % P25519 if c is None else c
     assert (total - cv) % P25519 == 0 and 0 <= cv < (1 << 256)
-    qv = (total - cv) // P25519
+    qv = (total - cv) // P25519 + Q0
     assert 0 <= qv < (1 << (16 * Q_LIMBS))
     cl, ql = to_limbs(cv), to_limbs(qv, Q_LIMBS)
     d = []
     for k in range(2 * LIMBS):
         acc = 0
-        for a, b in pl:
+        for a, b, sg in pl:
             for i in range(max(0, k - LIMBS + 1), min(LIMBS, k + 1)):
-                acc += a[i] * b[k - i]
+                acc += sg * a[i] * b[k - i]
         if k < LIMBS:
             acc -= cl[k]
-        for i in range(max(0, k - LIMBS + 1), min(Q_LIMBS, k + 1)):
-            acc -= ql[i] * P_LIMBS[k - i]
+        if k < Q_LIMBS:
+            acc += 19 * (ql[k] - Q0_LIMBS[k])
+        if 0 <= k - 15 < Q_LIMBS:
+            acc -= (ql[k - 15] - Q0_LIMBS[k - 15]) << 15
         d.append(acc)
     carries, prev = [], 0
     for m in range(LIMBS):
@@ -99,8 +127,8 @@ def mul_unit_witness(products, c=None):
         prev = g >> 32
         if m < N_CARRY:
             big = prev + CARRY_OFFSET
-            assert 0 <= big < (1 << 23), "carry out of range: operands too large"
-            carries.append((big & 0xFFFF, big >> 16, (big >> 16) << 9))
+            assert 0 <= big < (1 << 25), "carry out of range: operands too large"
+            carries.append((big & 0xFFFF, big >> 16, (big >> 16) << CARRY_HI_SHIFT))
         else:
             assert prev == 0
     return cl, ql, carries
@@ -128,7 +156,7 @@ class FpMulChip:
         c = [L(self.C + i) for i in range(16)]
         q = [L(self.Q + i) for i in range(17)]
         carries = [(L(self.R + 3 * m), L(self.R + 3 * m + 1), L(self.R + 3 * m + 2)) for m in range(N_CARRY)]
-        mul_unit_constraints(air, [(a, b)], c, q, carries)
+        mul_unit_constraints(air, [(a, b, 1, 1 << 32)], c, q, carries)
         self.range_check = logup.RangeCheck(air, range(n_lookups), LIMB_BITS, self.MULT, self.N_COLS0)
         self.air = air
         self.stark = Stark(air, log_rows, config)

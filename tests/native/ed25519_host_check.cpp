@@ -1,0 +1,57 @@
+// Host build of the Ed25519 trace generator's row code (csrc/ed25519_rows.hpp): reads slots as six 64-hex-digit numbers
+// (ax ay rx ry s h) per line and writes the round-0 trace of all slots, column-major u64, to the file named in argv[1].
+// tests/test_ed25519_air.py compares it with the Python reference trace.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "ed25519_rows.hpp"
+
+using namespace nlx;
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    std::vector<ed::Slot> slots;
+    char buf[6][80];
+    while (scanf("%64s %64s %64s %64s %64s %64s", buf[0], buf[1], buf[2], buf[3], buf[4], buf[5]) == 6) {
+        uint64_t w[24];
+        for (int v = 0; v < 6; v++)
+            for (int k = 0; k < 4; k++) {
+                unsigned long long x = 0;
+                sscanf(buf[v] + 16 * (3 - k), "%16llx", &x);
+                w[4 * v + k] = x;
+            }
+        ed::Slot s;
+        ed::slot_from_words(w, s);
+        slots.push_back(s);
+    }
+    const size_t ns = slots.size(), n = ns * ed::ROWS;
+    std::vector<uint64_t> trace((size_t)ed::N_COLS0 * n);
+    // pass 1: the input point of every row, and every slot's final point
+    std::vector<ed::Point> in(n), fin(ns);
+    for (size_t k = 0; k < ns; k++) {
+        ed::Point q;
+        for (int i = 0; i < 16; i++) { q.x[i] = 0; q.y[i] = q.z[i] = i == 0; }
+        ed::NoSink none;
+        for (int r = 0; r < ed::ROWS; r++) {
+            in[k * ed::ROWS + r] = q;
+            const int bit = ed::ROWS - 1 - r;
+            ed::Point o;
+            ed::row_main(none, q, (slots[k].sw[bit >> 4] >> (bit & 15)) & 1, (slots[k].hw[bit >> 4] >> (bit & 15)) & 1, slots[k], o);
+            q = o;
+        }
+        fin[k] = q;
+    }
+    // pass 2: every row on its own
+    for (size_t k = 0; k < ns; k++)
+        for (int r = 0; r < ed::ROWS; r++) {
+            const size_t row = k * ed::ROWS + r, prev = (k + ns - 1) % ns;
+            auto put = [&](uint32_t col, uint64_t v) { trace[(size_t)col * n + row] = v; };
+            ed::Point o;
+            ed::emit_row(r, slots[k], in[row], slots[prev].ry, &fin[prev], put, o);
+        }
+    FILE* f = fopen(argv[1], "wb");
+    if (!f) return 3;
+    fwrite(trace.data(), 8, trace.size(), f);
+    fclose(f);
+    return 0;
+}

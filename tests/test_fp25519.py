@@ -26,12 +26,14 @@ def test_unit_witness_matches_big_integers(nlx):
     for _ in range(500):
         a, b = rnd.getrandbits(256), rnd.getrandbits(256)
         cl, ql, carries = F.mul_unit_witness([(a, b)])
-        assert F.from_limbs(cl) == a * b % F.P25519 and F.from_limbs(ql) * F.P25519 + F.from_limbs(cl) == a * b
-        assert all(0 <= lo < 65536 and 0 <= hi < 128 and hi9 == hi << 9 for lo, hi, hi9 in carries)
+        assert F.from_limbs(cl) == a * b % F.P25519 and (F.from_limbs(ql) - F.Q0) * F.P25519 + F.from_limbs(cl) == a * b
+        assert all(0 <= lo < 65536 and 0 <= hi < 512 and his == hi << 7 for lo, hi, his in carries)
     # two products into one reduction, and a non-canonical result
     a, b, c, d = (rnd.getrandbits(256) for _ in range(4))
     cl, ql, _ = F.mul_unit_witness([(a, b), (c, d)])
     assert F.from_limbs(cl) == (a * b + c * d) % F.P25519
+    cl, ql, _ = F.mul_unit_witness([(a, b, 1), (c, d, -1)])                 # a negative total: the committed q stays >= 0
+    assert F.from_limbs(cl) == (a * b - c * d) % F.P25519 and F.from_limbs(ql) >= 0
     big = (1 << 200) * (1 << 100) % F.P25519                      # 19 * 2^45: c + p still fits 256 bits
     cl, _, _ = F.mul_unit_witness([(1 << 200, 1 << 100)], c=big + F.P25519)
     assert F.from_limbs(cl) == big + F.P25519
@@ -51,18 +53,23 @@ def test_device_witness_code_on_the_host(nlx, tmp_path):
                     os.path.join(ROOT, "tests", "native", "fp25519_host_check.cpp"), "-o", exe], check=True, capture_output=True)
     rnd = random.Random(3)
     m, p = (1 << 256) - 1, F.P25519
-    cases = [[(m, m)], [(0, 0)], [(1, m)], [(p, 5)], [(p - 1, p - 1)], [(m, m), (m, m)], [(p, 1)], [(p + 18, 1)], [(1 << 255, 1)],
-             [((1 << 255) - 1, 1)]]
-    cases += [[(rnd.getrandbits(256), rnd.getrandbits(256))] for _ in range(200)]
-    cases += [[(rnd.getrandbits(256), rnd.getrandbits(256)), (rnd.getrandbits(256), rnd.getrandbits(256))] for _ in range(200)]
-    text = "\n".join(" ".join("%064x" % v for pr in c for v in pr) for c in cases) + "\n"
-    out = subprocess.run([exe], input=text, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    cases = [([(m, m, 1)], None), ([(0, 0, 1)], None), ([(1, m, 1)], None), ([(p, 5, 1)], None), ([(p - 1, p - 1, 1)], None),
+             ([(m, m, 1), (m, m, 1)], None), ([(m, m, -1)], None), ([(m, m, -1), (m, m, -1)], None), ([(p + 18, 1, 1)], None),
+             ([(1 << 255, 1, 1)], None), ([(1 << 200, 1 << 100, 1)], (1 << 300) % p + p), ([(3, 5, 1)], 15),
+             ([(m, m, 1), (m, m, 1), (m, m, -1)], None)]
+    for _ in range(300):
+        cases.append(([(rnd.getrandbits(256), rnd.getrandbits(256), rnd.choice([1, -1])) for _ in range(rnd.choice([1, 2, 3]))], None))
+    lines = []
+    for prods, c in cases:
+        head = "" if c is None else "f %064x " % c
+        lines.append(head + " ".join("%s %064x %064x" % ("+" if sg > 0 else "-", a, b) for a, b, sg in prods))
+    out = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.strip().split("\n")
     assert len(out) == len(cases)
-    for c, line in zip(cases, out):
+    for (prods, c), line in zip(cases, out):
         f = line.split()
-        cl, ql, carries = F.mul_unit_witness(c)
-        assert int(f[0], 16) == F.from_limbs(cl) and int(f[1], 16) == F.from_limbs(ql), c
-        assert [int(x) for x in f[2:]] == [lo + (hi << 16) for lo, hi, _ in carries], c
+        cl, ql, carries = F.mul_unit_witness(prods, c=c)
+        assert int(f[0], 16) == F.from_limbs(cl) and int(f[1], 16) == F.from_limbs(ql), prods
+        assert [int(x) for x in f[2:]] == [lo + (hi << 16) for lo, hi, _ in carries], prods
 
 
 @pytest.fixture(scope="module")
