@@ -351,6 +351,11 @@ int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint6
  * and adds the segments' partial sums with the alpha powers their position in the program implies, so a wide AIR
  * on a short trace still fills the chip.  At most NLX_AIR_MAX_SEGMENTS - 1 boundaries per program. */
 #define NLX_AIR_SEGMENT 19
+/* The two base-field constraints of one LogUp helper (near-light-client_amd/logup.py) as one instruction:
+ *   h (alpha + v1)(alpha + v2) = (alpha + v1) + (alpha + v2)   in F_p[X]/(X^2 - 7),
+ * v1 = local[a], v2 = local[dst] (dst = 0xFFFF: a single lookup, h (alpha + v1) = 1), h = local[b] + local[b+1] X,
+ * alpha = challenge k + challenge k+1 X with k in word bits 56..61.  Emits the X^0 then the X^1 coefficient. */
+#define NLX_AIR_EMIT_LOGUP 20
 #define NLX_AIR_MAX_SEGMENTS 256
 #define NLX_AIR_NUM_REGS 64
 #define NLX_AIR_MAX_PERIODIC 64

@@ -43,7 +43,7 @@ struct AirParams {
     uint32_t n_seg;
     uint64_t alphas[2];
     uint64_t g_inv;             // last = g^-1 (g generates the size-n subgroup)
-    uint32_t log_n, rate_bits, qdb, n_words, nc, n_regs, period_bits;
+    uint32_t log_n, rate_bits, qdb, n_words, nc, n_regs, period_bits, n_pis;
 };
 
 // x * 2^sh (sh < 64): a 128-bit shift and one reduction instead of a general multiplication
@@ -145,6 +145,29 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
                         }
                     }
                 }
+                continue;
+            }
+            case NLX_AIR_EMIT_LOGUP: {
+                // both coefficients of h (al + v1)(al + v2) - (al + v1) - (al + v2) over F_p[X]/(X^2 - 7), in registers
+                const uint64_t al0 = p.pis[p.n_pis + sh], al1 = p.pis[p.n_pis + sh + 1];
+                const uint64_t h0 = p.cols[b][row], h1 = p.cols[b + 1][row], v1 = p.cols[a][row];
+                uint64_t c0, c1;
+                if (dst == 0xFFFF) {
+                    const uint64_t d0 = gl::add(al0, v1);
+                    c0 = gl::sub(gl::add(gl::mul(h0, d0), mul_pow2(gl::mul(h1, al1), 3)), gl::add(gl::mul(h1, al1), 1));
+                    c1 = gl::add(gl::mul(h0, al1), gl::mul(h1, d0));
+                } else {
+                    const uint64_t v2 = p.cols[dst][row];
+                    const uint64_t s2 = gl::add(gl::add(al0, al0), gl::add(v1, v2));
+                    const uint64_t a1sq = gl::mul(al1, al1);
+                    const uint64_t u0 = gl::add(gl::mul(gl::add(al0, v1), gl::add(al0, v2)), gl::sub(mul_pow2(a1sq, 3), a1sq));
+                    const uint64_t u1 = gl::mul(al1, s2);
+                    const uint64_t hu = gl::mul(h1, u1);
+                    c0 = gl::sub(gl::add(gl::mul(h0, u0), gl::sub(mul_pow2(hu, 3), hu)), s2);
+                    c1 = gl::sub(gl::add(gl::mul(h0, u1), gl::mul(h1, u0)), gl::add(al1, al1));
+                }
+                acc0 = gl::add(gl::mul(gl::add(gl::mul(acc0, a0), c0), a0), c1);
+                if (two) acc1 = gl::add(gl::mul(gl::add(gl::mul(acc1, a1), c0), a1), c1);
                 continue;
             }
             case NLX_AIR_LOADV: {
@@ -311,7 +334,14 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
             const uint64_t w = prog[pc];
             const uint32_t op = (uint32_t)(w & 0xFF), dst = (uint32_t)((w >> 8) & 0xFFFF);
             const uint32_t a = (uint32_t)((w >> 24) & 0xFFFF), b = (uint32_t)((w >> 40) & 0xFFFF);
-            if (op > NLX_AIR_SEGMENT) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
+            if (op > NLX_AIR_EMIT_LOGUP) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
+            if (op == NLX_AIR_EMIT_LOGUP) {
+                const uint32_t k = (uint32_t)(w >> 56) & 0x3F;
+                if ((w >> 62) != 0 || a >= d.n_cols || b + 1 >= d.n_cols || (dst != 0xFFFF && dst >= d.n_cols) || k + 1 >= n_round_challenges)
+                    return ctx->fail(NLX_E_INVAL, "AIR word %u: EMIT_LOGUP column / challenge out of range", pc);
+                n_emits += 2;
+                continue;
+            }
             if (op == NLX_AIR_SEGMENT) {
                 if (w != NLX_AIR_SEGMENT) return ctx->fail(NLX_E_INVAL, "AIR word %u: operands on a segment boundary", pc);
                 if (seg_bounds.size() + 2 > NLX_AIR_MAX_SEGMENTS) return ctx->fail(NLX_E_RANGE, "AIR: too many segments");
@@ -595,7 +625,7 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
             ap.alphas[0] = alphas[0]; ap.alphas[1] = alphas[1];
             ap.g_inv = gl::inv(gl::root_of_unity(log_n));
             ap.log_n = log_n; ap.rate_bits = d.rate_bits; ap.qdb = qdb; ap.n_words = d.n_words; ap.nc = nc;
-            ap.n_regs = s->n_regs;
+            ap.n_regs = s->n_regs; ap.n_pis = d.num_public_inputs;
             ap.seg = s->d_seg; ap.seg_mul = d_pis + n_values; ap.part = d_part; ap.n_seg = n_seg;
             // one wave per block: the LDS register file (n_regs x 64 lanes x 8 B) is the occupancy limiter, and
             // single-wave blocks pack the 160 KB of a CU at the finest granularity

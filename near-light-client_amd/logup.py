@@ -31,28 +31,32 @@ class RangeCheck:
     """Adds the lookup constraints to `air` (a two-round Air whose round 0 draws at least two challenges).
 
     cols: the looked-up round-0 columns; mult_col: the round-0 multiplicity column; first: index of the first round-1
-    column used (round_cols(len(cols)) consecutive columns); challenge: index of alpha's first base challenge."""
+    column used (round_cols(len(cols)) consecutive columns); challenge: index of alpha's first base challenge;
+    fused=False writes the helper constraints out with the DSL instead of NLX_AIR_EMIT_LOGUP (same constraint values,
+    same proof, thirty times the program words: kept for the tests that compare the two)."""
 
-    def __init__(self, air, cols, bits, mult_col, first, challenge=0):
+    def __init__(self, air, cols, bits, mult_col, first, challenge=0, fused=True):
         self.cols, self.bits, self.mult_col, self.first = [int(c) for c in cols], bits, mult_col, first
         self.n_helpers = (len(self.cols) + 1) // 2
         self.n_round_cols = round_cols(len(self.cols))
         L, N = air.local, air.next  # noqa: N806
         a0, a1 = air.challenge(challenge), air.challenge(challenge + 1)
         t = air.periodic(range(1 << bits))
-        w_a1_sq = a1 * a1 * W
         sum0, sum1 = None, None
         for j in range(self.n_helpers):
             h0, h1 = L(first + 2 * j), L(first + 2 * j + 1)
-            v1 = L(self.cols[2 * j])
-            if 2 * j + 1 < len(self.cols):
-                v2 = L(self.cols[2 * j + 1])
-                # u = (alpha + v1)(alpha + v2);  h u = (alpha + v1) + (alpha + v2)
-                u0 = (a0 + v1) * (a0 + v2) + w_a1_sq
+            v2 = self.cols[2 * j + 1] if 2 * j + 1 < len(self.cols) else None
+            if fused:
+                # h (alpha + v1)(alpha + v2) = (alpha + v1) + (alpha + v2): both coefficients as one VM instruction
+                air.constraint_logup(self.cols[2 * j], v2, first + 2 * j, challenge)
+            elif v2 is not None:
+                v1, v2 = L(self.cols[2 * j]), L(v2)
+                u0 = (a0 + v1) * (a0 + v2) + a1 * a1 * W
                 u1 = a1 * (a0 * 2 + v1 + v2)
                 air.constraint(h0 * u0 + h1 * u1 * W - (a0 * 2 + v1 + v2))
                 air.constraint(h0 * u1 + h1 * u0 - a1 * 2)
             else:
+                v1 = L(self.cols[2 * j])
                 air.constraint(h0 * (a0 + v1) + h1 * a1 * W - 1)
                 air.constraint(h0 * a1 + h1 * (a0 + v1))
             sum0 = h0 if sum0 is None else sum0 + h0

@@ -20,9 +20,10 @@ from ._lib import dll, ptr, NlxError
 P = 0xFFFFFFFF00000001
 (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_CONST, AIR_ADD, AIR_SUB, AIR_MUL, AIR_EMIT_TRANSITION, AIR_EMIT_FIRST,
  AIR_EMIT_LAST, AIR_EMIT, AIR_PERIODIC, AIR_PACK_LOCAL, AIR_PACK_NEXT, AIR_EMIT_BOOL, AIR_LOADV, AIR_XOR3, AIR_CH,
- AIR_MAJ, AIR_SEGMENT) = range(20)
+ AIR_MAJ, AIR_SEGMENT, AIR_EMIT_LOGUP) = range(21)
 _AIR_BINARY = (AIR_ADD, AIR_SUB, AIR_MUL)
 _AIR_TERNARY = (AIR_XOR3, AIR_CH, AIR_MAJ)
+_AIR_FUSED_EMITS = (AIR_EMIT_BOOL, AIR_EMIT_LOGUP)   # constraints that are one instruction over columns, no expression
 AIR_NUM_REGS = 64
 AIR_MAX_RESIDENT_LEAVES = 12   # loads kept in registers (LRU) before they are re-loaded
 AIR_LOAD_BATCH = 8             # loads issued together (NLX_AIR_LOADV): memory-level parallelism of the VM
@@ -221,6 +222,16 @@ class Air:
         assert 0 <= col and count >= 1 and col + count <= self.n_cols
         self._emits.append((AIR_EMIT_BOOL, self._leaf(AIR_LOCAL, col, 1), count))
 
+    def constraint_logup(self, v1_col, v2_col, h_col, challenge=0):
+        """The two base-field constraints of one LogUp helper h = 1/(alpha + v1) + 1/(alpha + v2) in the quadratic
+        extension (logup.py), as ONE VM instruction: v1, v2 (None: a single-lookup helper) and (h, h + 1) are local
+        columns, alpha = challenge(k) + challenge(k + 1) X.  Same constraint values as writing them out with the
+        DSL, a thirtieth of the program words."""
+        assert self.rounds is not None and 0 <= challenge and challenge + 1 < sum(n for _, n in self.rounds) and challenge < 63
+        for c in (v1_col, h_col, h_col + 1) + (() if v2_col is None else (v2_col,)):
+            assert 0 <= c < self.n_cols
+        self._emits.append((AIR_EMIT_LOGUP, (v1_col, 0xFFFF if v2_col is None else v2_col, h_col, challenge), 2))
+
     @property
     def num_constraints(self):
         return sum(cnt for _, _, cnt in self._emits)
@@ -230,6 +241,9 @@ class Air:
         """Stark::constraint_degree(): filters (z_last / lagrange) add one to the expression degree."""
         d = 1
         for op, e, _ in self._emits:
+            if op == AIR_EMIT_LOGUP:
+                d = max(d, 2 if e[1] == 0xFFFF else 3)
+                continue
             d = max(d, 2 if op == AIR_EMIT_BOOL else e.degree + (0 if op == AIR_EMIT else 1))
         return d
 
@@ -268,7 +282,7 @@ class Air:
         def dag(emit):
             """ids of the arithmetic nodes under a constraint"""
             eop, root, cnt = emit
-            out, stack = set(), ([] if eop == AIR_EMIT_BOOL else [root])
+            out, stack = set(), ([] if eop in _AIR_FUSED_EMITS else [root])
             while stack:
                 x = stack.pop()
                 if is_value(x) and id(x) not in out:
@@ -304,7 +318,7 @@ class Air:
         batchable = (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_PERIODIC)
         computed, per_emit, all_vals = set(), [], []
         for eop, root, _ in emits:
-            if eop == AIR_EMIT_BOOL:
+            if eop in _AIR_FUSED_EMITS:
                 per_emit.append([])
                 continue
             nodes, seen, stack = [], set(), [(root, False)]
@@ -330,7 +344,7 @@ class Air:
                 if is_value(y):
                     y.uses += 1
         for eop, root, _ in emits:
-            if eop != AIR_EMIT_BOOL and is_value(root):
+            if eop not in _AIR_FUSED_EMITS and is_value(root):
                 root.uses += 1
 
         words = []
@@ -425,6 +439,10 @@ class Air:
         for (op, root, cnt), nodes in zip(emits, per_emit):
             if op == AIR_EMIT_BOOL:
                 words.append(AIR_EMIT_BOOL | root.a << 24 | cnt << 40)
+                continue
+            if op == AIR_EMIT_LOGUP:
+                v1, v2, hcol, k = root
+                words.append(AIR_EMIT_LOGUP | v2 << 8 | v1 << 24 | hcol << 40 | k << 56)
                 continue
             # plain-load use counts within this constraint, and their order of use
             leaf_seq = []

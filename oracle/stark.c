@@ -357,6 +357,29 @@ static void air_eval_base(const orc_stark_desc* d, const uint64_t* local, const 
             case ORC_AIR_EMIT_LAST: c = gl_mul(reg[a % AIR_REGS], l_last); emit = 1; break;
             case ORC_AIR_EMIT: c = reg[a % AIR_REGS]; emit = 1; break;
             case ORC_AIR_SEGMENT: memset(reg, 0, sizeof reg); break;
+            case ORC_AIR_EMIT_LOGUP: {
+                /* h (al + v1)(al + v2) = (al + v1) + (al + v2) in F_p[X]/(X^2 - 7), al = a0 + a1 X, h = h0 + h1 X */
+                const uint64_t a0 = pis[d->num_public_inputs + AIR_SH(w)], a1 = pis[d->num_public_inputs + AIR_SH(w) + 1];
+                const uint64_t h0 = local[b], h1 = local[b + 1], v1 = local[a];
+                uint64_t c0, c1;
+                if (AIR_DST(w) == 0xFFFF) {
+                    const uint64_t d0 = gl_add(a0, v1);
+                    c0 = gl_sub(gl_add(gl_mul(h0, d0), gl_mul(7, gl_mul(h1, a1))), 1);
+                    c1 = gl_add(gl_mul(h0, a1), gl_mul(h1, d0));
+                } else {
+                    const uint64_t v2 = local[AIR_DST(w)];
+                    const uint64_t s = gl_add(gl_add(a0, a0), gl_add(v1, v2));
+                    const uint64_t u0 = gl_add(gl_mul(gl_add(a0, v1), gl_add(a0, v2)), gl_mul(7, gl_mul(a1, a1)));
+                    const uint64_t u1 = gl_mul(a1, s);
+                    c0 = gl_sub(gl_add(gl_mul(h0, u0), gl_mul(7, gl_mul(h1, u1))), s);
+                    c1 = gl_sub(gl_add(gl_mul(h0, u1), gl_mul(h1, u0)), gl_add(a1, a1));
+                }
+                for (uint32_t j = 0; j < d->num_challenges; j++) {
+                    accs[j] = gl_add(gl_mul(accs[j], alphas[j]), c0);
+                    accs[j] = gl_add(gl_mul(accs[j], alphas[j]), c1);
+                }
+                break;
+            }
             default: break;
         }
         if (emit)
@@ -418,6 +441,28 @@ static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* n
             case ORC_AIR_SEGMENT:
                 for (int i = 0; i < AIR_REGS; i++) reg[i] = gl2_from(0);
                 break;
+            case ORC_AIR_EMIT_LOGUP: {
+                const uint64_t a0 = pis[d->num_public_inputs + AIR_SH(w)], a1 = pis[d->num_public_inputs + AIR_SH(w) + 1];
+                const gl2 h0 = local[b], h1 = local[b + 1], v1 = local[a];
+                gl2 c0, c1;
+                if (AIR_DST(w) == 0xFFFF) {
+                    const gl2 d0 = gl2_add(gl2_from(a0), v1);
+                    c0 = gl2_sub(gl2_add(gl2_mul(h0, d0), gl2_scale(h1, gl_mul(7, a1))), gl2_from(1));
+                    c1 = gl2_add(gl2_scale(h0, a1), gl2_mul(h1, d0));
+                } else {
+                    const gl2 v2 = local[AIR_DST(w)];
+                    const gl2 s = gl2_add(gl2_from(gl_add(a0, a0)), gl2_add(v1, v2));
+                    const gl2 u0 = gl2_add(gl2_mul(gl2_add(gl2_from(a0), v1), gl2_add(gl2_from(a0), v2)), gl2_from(gl_mul(7, gl_mul(a1, a1))));
+                    const gl2 u1 = gl2_scale(s, a1);
+                    c0 = gl2_sub(gl2_add(gl2_mul(h0, u0), gl2_scale(gl2_mul(h1, u1), 7)), s);
+                    c1 = gl2_sub(gl2_add(gl2_mul(h0, u1), gl2_mul(h1, u0)), gl2_from(gl_add(a1, a1)));
+                }
+                for (uint32_t j = 0; j < d->num_challenges; j++) {
+                    accs[j] = gl2_add(gl2_scale(accs[j], alphas[j]), c0);
+                    accs[j] = gl2_add(gl2_scale(accs[j], alphas[j]), c1);
+                }
+                break;
+            }
             default: break;
         }
         if (emit)
@@ -472,7 +517,12 @@ static int desc_ok(const orc_stark_desc* d) {
                 break;
             case ORC_AIR_EMIT_BOOL: if (AIR_A(w) + (AIR_B(w) ? AIR_B(w) : 1) > d->n_cols) return 0; break;
             case ORC_AIR_CONST: if (++pc >= d->n_words) return 0; break;
-            default: if (AIR_OP(w) > ORC_AIR_SEGMENT) return 0;
+            case ORC_AIR_EMIT_LOGUP:
+                if (AIR_A(w) >= d->n_cols || AIR_B(w) + 1 >= d->n_cols || (AIR_DST(w) != 0xFFFF && AIR_DST(w) >= d->n_cols) ||
+                    AIR_SH(w) + 1 >= total_round_challenges(d))
+                    return 0;
+                break;
+            default: if (AIR_OP(w) > ORC_AIR_EMIT_LOGUP) return 0;
         }
     }
     return 1;

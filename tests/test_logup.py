@@ -7,11 +7,11 @@ import pytest
 from conftest import P
 
 
-def range_air(nlx, n_values, bits):
+def range_air(nlx, n_values, bits, fused=True):
     """n_values looked-up columns, then the multiplicity column; round 1 = the lookup columns."""
     S, LU = nlx.stark, nlx.logup
     air = S.Air(n_values + 1 + LU.round_cols(n_values), 0, rounds=[(n_values + 1, 2), (LU.round_cols(n_values), 0)])
-    rc = LU.RangeCheck(air, range(n_values), bits, n_values, n_values + 1)
+    rc = LU.RangeCheck(air, range(n_values), bits, n_values, n_values + 1, fused=fused)
     return air, rc
 
 
@@ -66,6 +66,31 @@ def test_range_check_oracle(nlx, orc, n_values, bits, db):
         return fn
     for col in (0, rc.n_round_cols - 4, rc.n_round_cols - 1):
         assert orc.stark_verify(st.desc, orc.stark_prove_rounds(st.desc, tampered(col, 9), [])) != 1
+
+
+@pytest.mark.parametrize("n_values", [5, 4, 1])
+def test_fused_instruction_equals_written_out_constraints(nlx, orc, n_values):
+    """NLX_AIR_EMIT_LOGUP computes the same two constraint values as the DSL expressions: same proof bytes from a
+    program a fraction of the size; and row by row in the reference interpreter."""
+    from test_stark_cpu import run_program
+    S = nlx.stark
+    bits, db = 6, 7
+    t0 = make_trace(orc, n_values, bits, db, seed=9)
+    proofs, sizes = [], []
+    for fused in (True, False):
+        air, rc = range_air(nlx, n_values, bits, fused)
+        st = S.Stark(air, db, S.StarkConfig(fri_num_queries=20))
+        sizes.append(len(st.program))
+        proofs.append(orc.stark_prove_rounds(st.desc, rounds_fn(orc, t0, n_values, bits), []))
+        assert orc.stark_verify(st.desc, proofs[-1]) == 1
+        alpha = (12345678901234567, 7654321987654321)
+        full = np.concatenate([t0, orc.logup_round(t0, range(n_values), bits, t0[n_values], alpha)], axis=0)
+        vals = run_program(st.program, full[:, 5], full[:, 6], list(alpha), periodic=[int(c[5 % len(c)]) for c in air._periodic], n_public=0)
+        assert len(vals) == air.num_constraints and all(v == 0 for _, v in vals)
+        full[0, 5] = (int(full[0, 5]) + 1) % (1 << bits)                   # another in-table value: the helper no longer matches
+        vals = run_program(st.program, full[:, 5], full[:, 6], list(alpha), periodic=[int(c[5 % len(c)]) for c in air._periodic], n_public=0)
+        assert any(v != 0 for _, v in vals)
+    assert proofs[0] == proofs[1] and sizes[0] < sizes[1]
 
 
 def test_mixed_periods_tile(nlx):

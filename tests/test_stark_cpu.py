@@ -10,7 +10,7 @@ import pytest
 from conftest import P
 
 
-def run_program(words, local, nxt, pis, periodic=()):
+def run_program(words, local, nxt, pis, periodic=(), n_public=None):
     """Reference interpreter of the AIR register program (python ints): returns [(emit_op, value)]."""
     reg, out, pc = {}, [], 0
     while pc < len(words):
@@ -34,6 +34,19 @@ def run_program(words, local, nxt, pis, periodic=()):
                 out.append((10, int(local[a + i]) * (int(local[a + i]) - 1) % P))
         elif op == 15: pass  # LOADV: scheduling hint
         elif op == 19: reg = {}  # SEGMENT: nothing is carried across
+        elif op == 20:           # EMIT_LOGUP: v2 col in dst, v1 col in a, h cols b / b+1, challenge index in sh
+            n_pis = len(pis) - 2 if n_public is None else n_public
+            a0, a1 = int(pis[n_pis + sh]), int(pis[n_pis + sh + 1])
+            h0, h1, v1 = int(local[b]), int(local[b + 1]), int(local[a])
+            if dst == 0xFFFF:
+                out.append((10, (h0 * (a0 + v1) + 7 * h1 * a1 - 1) % P))
+                out.append((10, (h0 * a1 + h1 * (a0 + v1)) % P))
+            else:
+                v2 = int(local[dst])
+                s_ = 2 * a0 + v1 + v2
+                u0, u1 = (a0 + v1) * (a0 + v2) + 7 * a1 * a1, a1 * s_
+                out.append((10, (h0 * u0 + 7 * h1 * u1 - s_) % P))
+                out.append((10, (h0 * u1 + h1 * u0 - 2 * a1) % P))
         elif op in (16, 17, 18):
             x, y, z = reg[a], reg[b], reg[sh]
             if op == 17: reg[dst] = (z + x * (y - z)) % P
