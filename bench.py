@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark", "sha256", "sha512", "ed25519"])
+    ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark", "sha256", "sha512", "ed25519", "sync_starks"])
     ap.add_argument("--log-blocks", type=int, default=14, help="sha256 workload: 2^k compression blocks per proof")
     ap.add_argument("--log-slots", type=int, default=10, help="ed25519 workload: 2^k signature slots per proof (>= 8)")
     ap.add_argument("--segment-nodes", type=int, default=None, help="sha256 workload: AIR program segment size (0 = one segment)")
@@ -555,6 +555,100 @@ def run_ed25519(args, nlx, torch, rank, world, local, dist):
     return out
 
 
+def run_sync_starks(args, nlx, torch, rank, world, local, dist):
+    """Secondary workload: every STARK sub-proof of ONE real Sync step (mainnet fixtures main_0 -> main_1, the step the
+    reference's tests walk, crates/protocol/src/lib.rs:364-405): the SHA-256 of its header / next_bps hashing
+    (curta_sha256), the SHA-512 of every signed approval and the Ed25519 verification of every signed approval
+    (curta_eddsa_verify_sigs_conditional, nearx/src/builder.rs:152) - plus the outer plonky2 proof of the bench's
+    default shape, one after the other on one GPU.  A step = all four proofs, traces generated on the GPU."""
+    import json
+    import numpy as np
+    NP, SA, SB, E = nlx.near_protocol, nlx.sha256_air, nlx.sha512_air, nlx.ed25519_air
+    near = os.path.join(ROOT, "tests", "golden", "near")
+    with open(os.path.join(near, "main_0.json")) as f:
+        bps = json.load(f)["body"]["next_bps"]
+    with open(os.path.join(near, "main_1.json")) as f:
+        nxt = json.load(f)["body"]
+    msg = NP.reconstruct_approval_message(nxt)
+    sha_msgs = NP.sync_sha256_messages(nxt)
+    sig_msgs, slots = [], []
+    for sig, bp in zip(nxt["approvals_after_next"], bps):
+        if sig is None:
+            continue
+        pk, raw = NP._key_bytes(bp["public_key"], 32), NP._key_bytes(sig, 64)
+        sig_msgs.append(raw[:32] + pk + msg)
+        slots.append(E.slot_from_signature(pk, msg, raw))
+    n_sigs = len(slots)
+    lb256 = max(2, (sum(len(SA.pad_message(m)) for m in sha_msgs) - 1).bit_length())
+    lb512 = max(2, (n_sigs - 1).bit_length())
+    log_slots = max(8, (n_sigs - 1).bit_length())
+    slot_words = E.slots_to_words((slots * ((1 << log_slots) // n_sigs + 1))[: 1 << log_slots])
+    ctx = nlx.Context(local)
+    p256, p512, ped = SA.Sha256Prover(ctx, lb256), SB.Sha512Prover(ctx, lb512), E.Ed25519Prover(ctx, log_slots)
+    syn = nlx.SyntheticCircuit(args.log_n, seed=1000 + rank, num_public_inputs=64, **GATE_MIXES[args.gate_mix])
+    io = nlx.nearx_io
+    sync_in, sync_out = io.sync_io(io.load_fixture(os.path.join(near, "main_1.json")))
+    syn.set_public_inputs(io.bytes_to_field_elements(sync_in + sync_out))
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    wires = torch.from_numpy(syn.wires.view(np.int64)).cuda()
+    pis = np.ascontiguousarray(syn.public_inputs)
+
+    def step():
+        t = [time.perf_counter()]
+        a = p256.prove(sha_msgs)
+        t.append(time.perf_counter())
+        b = p512.prove(sig_msgs)
+        t.append(time.perf_counter())
+        c = ped.prove(slot_words)
+        t.append(time.perf_counter())
+        cd.prove_into(wires, pis.ctypes.data)
+        t.append(time.perf_counter())
+        return a, b, c, [1e3 * (y - x) for x, y in zip(t, t[1:])]
+    for _ in range(args.warmup):
+        step()
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    parts = np.zeros(4)
+    for _ in range(args.steps):
+        a, b, c, ms = step()
+        parts += ms
+    barrier(dist, torch)
+    dt = reduce_max(dist, torch, time.perf_counter() - t0)
+    out = None
+    if rank == 0:
+        import hashlib
+        import struct
+        assert b"".join(struct.pack(">I", int(x)) for x in a[1]) == io.b58decode32(nxt["inner_lite"]["next_bp_hash"])
+        assert [int(x) for x in b[1]] == list(struct.unpack(">8Q", hashlib.sha512(sig_msgs[-1]).digest()))
+        parts /= args.steps
+        out = {
+            "metric": "Sync step: all STARK sub-proofs (SHA-256, SHA-512, Ed25519) + the outer proof, per second (secondary workload)",
+            "value": world * args.steps / dt, "unit": "sync steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 (Goldilocks field, integer)", "data": "real mainnet Sync step (fixtures main_0 -> main_1) for the STARKs; synthetic outer circuit",
+            "config": {"workload": "one real Sync step: SHA-256 STARK of %d messages (2^%d blocks), SHA-512 STARK of %d approval "
+                                   "hashes (2^%d blocks), Ed25519 STARK of %d approval signatures (2^%d slots), outer plonky2 proof "
+                                   "(2^%d rows, synthetic nearx-shaped); sequential on one GPU; replicas only"
+                                   % (len(sha_msgs), lb256, n_sigs, lb512, n_sigs, log_slots, args.log_n),
+                       "ms": {"sha256": round(parts[0], 2), "sha512": round(parts[1], 2), "ed25519": round(parts[2], 2),
+                              "outer_plonky2": round(parts[3], 2)},
+                       "proof_bytes": {"sha256": len(a[0]), "sha512": len(b[0]), "ed25519": len(c)},
+                       "public_digest": "SHA-256 STARK output = the header's next_bp_hash; SHA-512 STARK output = hashlib's digest of the last approval"},
+            "roofline": None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py
+            out["cpu_baseline"] = None
+            out["oracle_verifier_accepts"] = {"sha256": oracle_py.stark_verify(p256.stark.desc, a[0]) == 1,
+                                              "sha512": oracle_py.stark_verify(p512.stark.desc, b[0]) == 1,
+                                              "ed25519": oracle_py.stark_verify(ped.stark.desc, c) == 1}
+    for pr in (p256, p512, ped):
+        pr.close()
+    ctx.close()
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -567,6 +661,8 @@ def main():
         out = run_sync(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "stark":
         out = run_stark(args, nlx, torch, rank, world, local, dist)
+    elif args.workload == "sync_starks":
+        out = run_sync_starks(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "ed25519":
         out = run_ed25519(args, nlx, torch, rank, world, local, dist)
     elif args.workload in ("sha256", "sha512"):
