@@ -130,6 +130,8 @@ namespace nlx {
 // g*w_L^(8k+r)).  plonky2 orders Merkle leaves by the bit-reversed LDE index, so the digest of
 // (r,k) lands at tree position bitrev_b(r)*n + bitrev_logn(k): a 32-byte scatter per row
 // instead of a transposed copy of the whole table.
+constexpr size_t HASH_LEAVES_WIDE_MAX_ROWS = (size_t)1 << 13;  // measured crossover (4 745 columns): 2^13 rows 16 vs 24 ms, 2^14 rows 31 vs 26 ms
+
 __global__ __launch_bounds__(256) void k_hash_lde_leaves(const uint64_t* __restrict__ lde, size_t col_stride,
                                                          uint32_t n_cols, unsigned log_n, unsigned rate_bits,
                                                          uint64_t* __restrict__ digests) {
@@ -165,9 +167,18 @@ __global__ __launch_bounds__(256) void k_hash_lde_leaves(const uint64_t* __restr
     store_digest(digests, leaf, s);
 }
 
+void launch_hash_lde_leaves_wide(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols, unsigned log_n,
+                                 unsigned rate_bits, uint64_t* d_digests);
+
 void launch_hash_lde_leaves(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols,
                             unsigned log_n, unsigned rate_bits, uint64_t* d_digests) {
     size_t rows = (size_t)1 << (log_n + rate_bits);
+    // Few rows of many columns (a short wide STARK trace): one lane per leaf leaves most SIMDs idle while every lane
+    // walks its ceil(c/8) permutations one after the other; sixteen lanes per leaf cut that chain's latency ~5x.
+    if (rows <= HASH_LEAVES_WIDE_MAX_ROWS && n_cols > 16) {
+        launch_hash_lde_leaves_wide(st, d_lde, col_stride, n_cols, log_n, rate_bits, d_digests);
+        return;
+    }
     hipLaunchKernelGGL(k_hash_lde_leaves, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, d_lde, col_stride,
                        n_cols, log_n, rate_bits, d_digests);
 }
@@ -266,6 +277,35 @@ __global__ __launch_bounds__(256) void k_fri_leaves_wide(const uint64_t* __restr
         const size_t leaf = ((size_t)gl::bitrev32(r, rate_bits) << log_np) + gl::bitrev32(kp, log_np);
         digests[leaf * 4 + j] = gl::canon(gl32::to_u64(x));
     }
+}
+
+// LDE leaf digests, one leaf per 16 lanes (index maps as in k_hash_lde_leaves): lane j < 8 of a group owns the j-th
+// word of each 8-column chunk.
+__global__ __launch_bounds__(256) void k_hash_lde_leaves_wide(const uint64_t* __restrict__ lde, size_t col_stride, uint32_t n_cols,
+                                                              unsigned log_n, unsigned rate_bits, uint64_t* __restrict__ digests) {
+    __shared__ uint64_t lds[WIDE_GROUPS_PER_BLOCK * 24];
+    const uint32_t j = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const size_t pos = (size_t)blockIdx.x * WIDE_GROUPS_PER_BLOCK + g;
+    const bool live = (pos >> (log_n + rate_bits)) == 0;
+    const uint64_t* p = lde + pos;
+    gl32::F x = gl32::from_u64(0);
+#pragma unroll 1
+    for (uint32_t c = 0; c < n_cols; c += 8) {
+        if (j < 8 && c + j < n_cols) x = gl32::from_u64(live ? p[(size_t)(c + j) * col_stride] : 0);  // overwrite-mode absorb
+        x = permute_wide(x, j, lds + g * 24);
+    }
+    if (live && j < 4) {
+        const uint32_t r = (uint32_t)(pos >> log_n), k = (uint32_t)(pos & (((size_t)1 << log_n) - 1));
+        const size_t leaf = ((size_t)gl::bitrev32(r, rate_bits) << log_n) + gl::bitrev32(k, log_n);
+        digests[leaf * 4 + j] = gl::canon(gl32::to_u64(x));
+    }
+}
+
+void launch_hash_lde_leaves_wide(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols, unsigned log_n,
+                                 unsigned rate_bits, uint64_t* d_digests) {
+    const size_t rows = (size_t)1 << (log_n + rate_bits);
+    hipLaunchKernelGGL(k_hash_lde_leaves_wide, dim3((unsigned)((rows + WIDE_GROUPS_PER_BLOCK - 1) / WIDE_GROUPS_PER_BLOCK)), dim3(256), 0,
+                       st, d_lde, col_stride, n_cols, log_n, rate_bits, d_digests);
 }
 
 void launch_fri_leaves_wide(hipStream_t st, const uint64_t* d_values, unsigned log_n, unsigned rate_bits,
