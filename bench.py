@@ -495,8 +495,7 @@ def run_ed25519(args, nlx, torch, rank, world, local, dist):
         t1 = time.perf_counter()
         pr.generate_trace(words)
         t_trace += time.perf_counter() - t1
-        rc = pr.es.range_check
-        proof = pr.prover.prove_rounds(lambda rnd, chal: pr._t0 if rnd == 0 else rc.round1(ctx, pr._t0, chal[:2], pr._t1), [])
+        proof = pr.prover.prove_rounds(lambda rnd, chal: pr._t0 if rnd == 0 else pr.round1(chal[:2]), [])
     barrier(dist, torch)
     dt = time.perf_counter() - t0
     dt = reduce_max(dist, torch, dt)
@@ -515,10 +514,10 @@ def run_ed25519(args, nlx, torch, rank, world, local, dist):
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
             "config": {"workload": "two-round STARK of 2^%d Ed25519 verifications (%d rows x %d + %d columns, degree-3 AIR, 22 "
-                                   "multiplication units mod 2^255-19 per row, %d range-check lookups per row; standard_fast_config: "
+                                   "multiplication units mod 2^255-19 per row, %d + %d range-check lookups per row (2^16 / 2^9 tables); standard_fast_config: "
                                    "rate 2, 84 queries, 16 PoW bits); trace, multiplicities and lookup columns generated on the "
                                    "GPU inside the timed region; replicas only"
-                                   % (args.log_slots, n_rows, E.N_COLS0, E.N_COLS1, len(E.LOOKUPS)),
+                                   % (args.log_slots, n_rows, E.N_COLS0, E.N_COLS1, len(E.LOOKUPS), len(E.LOOKUPS9)),
                        "air_program_words": int(pr.stark.desc.n_words), "constraints": pr.es.air.num_constraints,
                        "proof_bytes": len(proof), "trace_gen_ms_per_step": t_trace / args.steps * 1e3,
                        "trace_bytes": int(E.N_COLS0 + E.N_COLS1) * n_rows * 8},
@@ -537,8 +536,9 @@ def run_ed25519(args, nlx, torch, rank, world, local, dist):
             pr2 = pr if args.log_slots == 8 else E.Ed25519Prover(ctx, 8)
             host = pr2.generate_trace(words[:256]).cpu().numpy().view(np.uint64)
             tc = time.time()
-            p2 = oracle_py.stark_prove_rounds(pr2.stark.desc, lambda rnd, chal: host if rnd == 0 else
-                                              oracle_py.logup_round(host, E.LOOKUPS, 16, host[E.MULT], chal[:2]), [])
+            p2 = oracle_py.stark_prove_rounds(pr2.stark.desc, lambda rnd, chal: host if rnd == 0 else np.concatenate(
+                [oracle_py.logup_round(host, E.LOOKUPS, 16, host[E.MULT], chal[:2]),
+                 oracle_py.logup_round(host, E.LOOKUPS9, 9, host[E.MULT9], chal[:2])], axis=0), [])
             dtc = time.time() - tc
             out["cpu_baseline"] = {"value": 256 / dtc, "unit": "signatures/s", "cores": cores, "kind": "port",
                                    "sample": "oracle two-round STARK prover (incl. its lookup columns) on 2^8 slots in %.1f s (trace "

@@ -431,17 +431,18 @@ int32_t nlx_logup_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t n_cols, ui
  * curta_eddsa_verify_sigs_conditional, nearx/src/builder.rs:152) as a stand-alone chip: one a * b = c (mod p) per row.
  * Constraints: near-light-client_amd/fp25519.py::FpMulChip.  a, b: 2^log_rows operands of four little-endian 64-bit
  * words each (any value < 2^256).  Writes the NLX_FP25519_CHIP_COLS x 2^log_rows round-0 trace (16-bit limbs of a, b,
- * the canonical c, the quotient, the carries; the multiplicity column zeroed - fill it with nlx_logup_multiplicities). */
-#define NLX_FP25519_CHIP_COLS 111
+ * the canonical c, the quotient, the carries' low and high parts; the two multiplicity columns - of the 2^16 table and of
+ * the 2^9 table of the carries' high parts - zeroed: fill them with nlx_logup_multiplicities). */
+#define NLX_FP25519_CHIP_COLS 97
 int32_t nlx_fp25519_chip_trace(nlx_ctx* ctx, const uint64_t* a, const uint64_t* b, uint32_t log_rows, uint64_t* trace_out);
 /* a12 / f.1: trace generation on the GPU for the Ed25519 verification AIR (constraints and column layout:
  * near-light-client_amd/ed25519_air.py; caller in the reference: curta_eddsa_verify_sigs_conditional,
  * nearx/src/builder.rs:152).  slots: 2^log_slots signatures, each six 256-bit little-endian numbers of four 64-bit
  * words: A.x, A.y, R.x, R.y (affine, reduced), S, h (the SHA-512 digest reduced mod L).  Writes the NLX_ED25519_COLS0 x
- * (256 << log_slots) round-0 trace (host or device), the multiplicity column zeroed (nlx_logup_multiplicities fills
- * it).  Returns NLX_E_INVAL naming the first slot whose statement is false (the signature does not verify, or a point
+ * (256 << log_slots) round-0 trace (host or device), the two multiplicity columns (2^16 table, 2^9 table of the
+ * carries' high parts) zeroed (nlx_logup_multiplicities fills them).  Returns NLX_E_INVAL naming the first slot whose statement is false (the signature does not verify, or a point
  * is off the curve): no trace satisfies the AIR for it. */
-#define NLX_ED25519_COLS0 1945
+#define NLX_ED25519_COLS0 1616
 int32_t nlx_ed25519_trace(nlx_ctx* ctx, const uint64_t* slots, uint32_t log_slots, uint64_t* trace_out);
 /* f.1: trace generation on the GPU for the SHA-256 compression AIR (column layout and constraints:
  * near-light-client_amd/sha256_air.py; callers in the reference: curta_sha256 at nearx/src/merkle.rs:49,

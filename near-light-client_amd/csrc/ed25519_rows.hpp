@@ -9,12 +9,12 @@
 namespace nlx {
 namespace ed {
 
-constexpr int ROWS = 256, N_MAIN = 21, UNIT_CELLS = 78;
+constexpr int ROWS = 256, N_MAIN = 21, UNIT_CELLS = fp::UNIT_CELLS;
 // round-0 column map (ed25519_air.py)
 constexpr uint32_t cSIN = 0, cSB = 48, cHB = 49, cSA = 50, cHA = 51, cAX = 52, cAY = 68, cRX = 84, cRY = 100, cNT = 116,
                    cSW = 132, cHW = 148, cMAIN = 164, cAUX_A = cMAIN + N_MAIN * UNIT_CELLS, cAUX_B = cAUX_A + 16,
                    cAUX_E = cAUX_B + 16, cAUX_F = cAUX_E + 16, cAUX = cAUX_F + 16, cMULT = cAUX + UNIT_CELLS,
-                   N_COLS0 = cMULT + 1;
+                   cMULT9 = cMULT + 1, N_COLS0 = cMULT9 + 1;
 enum { U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2, U_BA, U_BB, U_BC, U_X3, U_Y3, U_T3, U_Z3, U_AA, U_AB, U_AC, U_X4, U_Y4, U_Z4 };
 enum { STEP_YCMP = 0, STEP_A_U = 1, STEP_A_NT = 2, STEP_A_U2 = 3, STEP_A_V = 4, STEP_A_CHK = 5, STEP_R_U = 6, STEP_R_V = 7,
        STEP_R_CHK = 8, STEP_XCMP = 255 };
@@ -243,16 +243,7 @@ template <class Put>
 struct EmitSink {
     Put& put;
     FP_HD void unit(int index, const fp::Unit& u) { cells(cMAIN + (uint32_t)index * UNIT_CELLS, u); }
-    FP_HD void cells(uint32_t base, const fp::Unit& u) {
-        for (int i = 0; i < 16; i++) put(base + i, u.c[i]);
-        for (int i = 0; i < 17; i++) put(base + 16 + i, u.q[i]);
-        for (int m = 0; m < fp::N_CARRY; m++) {
-            const uint32_t lo = u.carry[m] & 0xFFFF, hi = u.carry[m] >> 16;
-            put(base + 33 + 3 * m, lo);
-            put(base + 34 + 3 * m, hi);
-            put(base + 35 + 3 * m, hi << fp::CARRY_HI_SHIFT);
-        }
-    }
+    FP_HD void cells(uint32_t base, const fp::Unit& u) { u.cells(base, put); }
 };
 FP_HD inline uint64_t gl_signed(int32_t v) { return v >= 0 ? (uint64_t)v : 0xFFFFFFFF00000001ull - (uint64_t)(-(int64_t)v); }
 
@@ -291,6 +282,7 @@ FP_HD inline bool emit_row(int r, const Slot& s, const Point& in, const uint32_t
     }
     sink.cells(cAUX, ax.u);
     put(cMULT, 0);
+    put(cMULT9, 0);
     return ok;
 }
 

@@ -19,13 +19,23 @@ namespace fp {
 
 constexpr int LIMBS = 16, Q_LIMBS = 17, N_CARRY = 15;
 constexpr int64_t CARRY_OFFSET = (int64_t)1 << 24;  // committed carry R = r + 2^24 < 2^25
-constexpr int CARRY_HI_SHIFT = 7;                    // second lookup cell of a carry: 2^7 * (R >> 16)
+constexpr int UNIT_CELLS = 63;                       // c[16] q[17] lo[15] hi[15] (lo = R & 0xFFFF, hi = R >> 16 < 2^9)
 constexpr int Q0_LIMB16 = 16;                        // Q0 = 2^260: the committed quotient is q + Q0 >= 0
 
 struct Unit {
     uint32_t c[LIMBS];
     uint32_t q[Q_LIMBS];      // quotient + Q0
     uint32_t carry[N_CARRY];  // R
+    // the unit's 63 cells in column order
+    template <class Put>
+    FP_HD void cells(uint32_t base, Put& put) const {
+        for (int i = 0; i < LIMBS; i++) put(base + i, c[i]);
+        for (int i = 0; i < Q_LIMBS; i++) put(base + 16 + i, q[i]);
+        for (int m = 0; m < N_CARRY; m++) {
+            put(base + 33 + m, carry[m] & 0xFFFF);
+            put(base + 48 + m, carry[m] >> 16);
+        }
+    }
 };
 
 // prod[k] += sign * sum_{i+j=k} a[i] b[j]   (signed limbs: operands may be differences of reduced values)

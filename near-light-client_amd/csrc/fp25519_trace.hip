@@ -1,6 +1,6 @@
 // Trace generation for the mod-(2^255 - 19) multiplication chip (near-light-client_amd/fp25519.py::FpMulChip; SURVEY.md
 // §8a row a12 - the field arithmetic under curta_eddsa_verify_sigs_conditional, nearx/src/builder.rs:152): one lane per
-// row computes c = a b mod p, the quotient and the carries in 16-bit limbs and writes its 110 cells; a wave's 64
+// row computes c = a b mod p, the quotient and the carries in 16-bit limbs and writes its 97 cells; a wave's 64
 // lanes are 64 consecutive rows, so every column store is 512 contiguous bytes.
 #include "ctx.hpp"
 #include "fp25519.hpp"
@@ -8,9 +8,9 @@
 
 namespace nlx {
 
-// chip columns: a[16] b[16] c[16] q[17] (lo, hi, 2^7 hi)[15] multiplicity
-enum : uint32_t { cA = 0, cB = 16, cC = 32, cQ = 48, cR = 65, cMULT = 110 };
-static_assert(cMULT + 1 == NLX_FP25519_CHIP_COLS, "column map");
+// chip columns: a[16] b[16] | unit cells c[16] q[17] lo[15] hi[15] | the two multiplicity columns
+enum : uint32_t { cA = 0, cB = 16, cC = 32, cMULT16 = 95, cMULT9 = 96 };
+static_assert(cC + fp::UNIT_CELLS == cMULT16 && cMULT9 + 1 == NLX_FP25519_CHIP_COLS, "column map");
 
 __global__ __launch_bounds__(256) void k_fp25519_chip_trace(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b,
                                                             uint32_t log_n, uint64_t* __restrict__ trace) {
@@ -33,18 +33,12 @@ __global__ __launch_bounds__(256) void k_fp25519_chip_trace(const uint64_t* __re
     fp::finish(prod, u);
     auto put = [&](uint32_t col, uint64_t v) { trace[((size_t)col << log_n) + row] = v; };
     for (int i = 0; i < 16; i++) {
-        put(cA + i, al[i]);
-        put(cB + i, bl[i]);
-        put(cC + i, u.c[i]);
+        put(cA + i, (uint64_t)al[i]);
+        put(cB + i, (uint64_t)bl[i]);
     }
-    for (int i = 0; i < 17; i++) put(cQ + i, u.q[i]);
-    for (int m = 0; m < 15; m++) {
-        const uint32_t lo = u.carry[m] & 0xFFFF, hi = u.carry[m] >> 16;
-        put(cR + 3 * m, lo);
-        put(cR + 3 * m + 1, hi);
-        put(cR + 3 * m + 2, hi << fp::CARRY_HI_SHIFT);
-    }
-    put(cMULT, 0);
+    u.cells(cC, put);
+    put(cMULT16, 0);
+    put(cMULT9, 0);
 }
 
 }  // namespace nlx

@@ -16,7 +16,8 @@ A and R checked to be on the curve.  Row r of a slot handles bit 255 - r of both
 2d*x*y of A (the addend's third coordinate), the curve equation of A and of R, and the final comparison
 RX * Z = X, RY * Z = Y.  Everything a unit reads is either a range-checked cell, a constant, or a cell tied by a
 degree <= 3 constraint to one of those; all unit results, quotients and carries (and the limbs of A and R) go through
-the 2^16-table lookup.  Constraint degree 3, two commitment rounds (the second is logup.py's columns).
+the 2^16-table lookup (the carries' high parts through a 2^9 table).  Constraint degree 3, two commitment rounds
+(the second is logup.py's columns for the two tables).
 
 Scope of this version: the slot's (A, R, S, h) are witness columns constant over the slot - binding them to data
 outside the proof (curta does that with its bus; here it would be one more running accumulator over a challenge) and
@@ -51,21 +52,29 @@ def _recover_x(y, sign):
 BX = _recover_x(BY, 0)
 ROWS = 256                       # rows per signature slot
 N_MAIN = 21
-UNIT = fp.UNIT_CELLS             # 78 range-checked cells per unit
+UNIT = fp.UNIT_CELLS             # 63 range-checked cells per unit
 
 
 class _Layout:
-    """Round-0 column allocation; `lookups` collects the range-checked cells."""
+    """Round-0 column allocation; `lookups16` / `lookups9` collect the cells checked against the two range tables."""
 
     def __init__(self):
         self.n = 0
-        self.lookups = []
+        self.lookups16, self.lookups9 = [], []
 
     def take(self, count, lookup=False):
         base = self.n
         self.n += count
         if lookup:
-            self.lookups += list(range(base, base + count))
+            self.lookups16 += list(range(base, base + count))
+        return base
+
+    def take_unit(self):
+        """c[16] q[17] lo[15] in the 2^16 table, hi[15] in the 2^9 table"""
+        base = self.n
+        self.n += fp.UNIT_CELLS
+        self.lookups16 += list(range(base, base + fp.UNIT_CELLS16))
+        self.lookups9 += list(range(base + fp.UNIT_CELLS16, base + fp.UNIT_CELLS))
         return base
 
 
@@ -74,13 +83,14 @@ SIN = LAY.take(48)                               # the row's input point X, Y, Z
 SB, HB, SA, HA = (LAY.take(1) for _ in range(4))  # scalar bits and their 16-bit limb accumulators
 AX, AY, RX, RY = (LAY.take(16, True) for _ in range(4))
 NT, SW, HW = (LAY.take(16) for _ in range(3))     # 2d x y of A; limbs of S and h
-MAIN = [LAY.take(UNIT, True) for _ in range(N_MAIN)]
+MAIN = [LAY.take_unit() for _ in range(N_MAIN)]
 AUX_A, AUX_B, AUX_E, AUX_F = (LAY.take(16) for _ in range(4))
-AUX = LAY.take(UNIT, True)
-MULT = LAY.take(1)
+AUX = LAY.take_unit()
+MULT, MULT9 = LAY.take(1), LAY.take(1)     # multiplicities of the 2^16 table and of the 2^9 table
 N_COLS0 = LAY.n
-LOOKUPS = list(LAY.lookups)
-N_COLS1 = logup.round_cols(len(LOOKUPS))
+LOOKUPS, LOOKUPS9 = list(LAY.lookups16), list(LAY.lookups9)
+N_COLS1A, N_COLS1B = logup.round_cols(len(LOOKUPS)), logup.round_cols(len(LOOKUPS9))
+N_COLS1 = N_COLS1A + N_COLS1B
 # main unit indices
 (U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2,
  U_BA, U_BB, U_BC, U_X3, U_Y3, U_T3, U_Z3,
@@ -117,7 +127,7 @@ def ed25519_air():
 
     def unit_cells(base):
         q = [L(base + 16 + i) for i in range(17)]
-        carries = [(L(base + 33 + 3 * m), L(base + 34 + 3 * m), L(base + 35 + 3 * m)) for m in range(fp.N_CARRY)]
+        carries = [(L(base + 33 + m), L(base + 48 + m)) for m in range(fp.N_CARRY)]
         return q, carries
 
     def unit(base, products, c=None):
@@ -241,7 +251,8 @@ def ed25519_air():
         air.constraint(no_sq * L(AUX_F + i))
 
     rc = logup.RangeCheck(air, LOOKUPS, 16, MULT, N_COLS0)
-    return air, rc
+    rc9 = logup.RangeCheck(air, LOOKUPS9, fp.CARRY_HI_BITS, MULT9, N_COLS0 + N_COLS1A)
+    return air, (rc, rc9)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -271,9 +282,7 @@ def reference_slot(ax, ay, rx, ry, s, h):
 
     def put_unit(base, row, products, c=None):
         cl, ql, carries = fp.mul_unit_witness(products, c=c)
-        t[base:base + 16, row] = cl
-        t[base + 16:base + 33, row] = ql
-        t[base + 33:base + 78, row] = [v for tr in carries for v in tr]
+        t[base:base + fp.UNIT_CELLS, row] = fp.unit_cell_values(cl, ql, carries)
         return cl
 
     def put_vec(base, row, limbs):
@@ -370,10 +379,7 @@ def reference_trace(slots):
         tr = parts[k]
         tr[AUX_A:AUX_A + 16, 0] = ry
         tr[AUX_B:AUX_B + 16, 0] = z4
-        cl, ql, carries = fp.mul_unit_witness([(ry, z4, 1)], c=fp.from_limbs(y4))
-        tr[AUX:AUX + 16, 0] = cl
-        tr[AUX + 16:AUX + 33, 0] = ql
-        tr[AUX + 33:AUX + 78, 0] = [v for c3 in carries for v in c3]
+        tr[AUX:AUX + fp.UNIT_CELLS, 0] = fp.unit_cell_values(*fp.mul_unit_witness([(ry, z4, 1)], c=fp.from_limbs(y4)))
     return np.concatenate(parts, axis=1)
 
 
@@ -434,7 +440,7 @@ class Ed25519Stark:
         if log_slots < 8:
             raise ValueError("at least 2^8 slots per proof (the 2^16-entry range table needs 2^16 rows)")
         self.log_slots = log_slots
-        self.air, self.range_check = ed25519_air()
+        self.air, self.range_checks = ed25519_air()
         self.stark = Stark(self.air, log_slots + 8, config)
 
 
@@ -465,13 +471,20 @@ class Ed25519Prover:
             self._t1 = torch.empty((N_COLS1, n), dtype=torch.int64, device=dev)
         words = np.ascontiguousarray(words, dtype=np.uint64)
         self.ctx.check(dll.nlx_ed25519_trace(self.ctx.handle, words.ctypes.data, self.es.log_slots, self._t0.data_ptr()))
-        self.es.range_check.multiplicities(self.ctx, self._t0)
+        for rc in self.es.range_checks:
+            rc.multiplicities(self.ctx, self._t0)
         return self._t0
+
+    def round1(self, alpha):
+        """the lookup columns of both tables for challenge alpha, into the device round-1 buffer"""
+        rc16, rc9 = self.es.range_checks
+        rc16.round1(self.ctx, self._t0, alpha, self._t1[:N_COLS1A])
+        rc9.round1(self.ctx, self._t0, alpha, self._t1[N_COLS1A:])
+        return self._t1
 
     def prove(self, slots):
         t0 = self.generate_trace(slots)
-        rc = self.es.range_check
-        return self.prover.prove_rounds(lambda rnd, chal: t0 if rnd == 0 else rc.round1(self.ctx, t0, chal[:2], self._t1), [])
+        return self.prover.prove_rounds(lambda rnd, chal: t0 if rnd == 0 else self.round1(chal[:2]), [])
 
     def close(self):
         self.prover.close()

@@ -11,8 +11,9 @@ when the left side is negative) for range-checked c, q and carries:
     G_m = D_2m + 2^16 D_2m+1,      G_m + r_(m-1) = 2^32 r_m,      r_(-1) = r_15 = 0                          m = 0 .. 15
 
 (p = 2^255 - 19 written with the two signed "limbs" -19 and 2^15 X^15, X = 2^16: two terms per quotient limb instead
-of sixteen), q of 17 limbs and signed carries r_m = R_m - 2^24, R_m = lo + 2^16 hi < 2^25 (lo and hi range-checked by
-lookup, hi < 2^9 through a second lookup of 2^7 hi).  With sum_t 16 |a_t|_max |b_t|_max < 2^40 (checked when a unit is
+of sixteen), q of 17 limbs and signed carries r_m = R_m - 2^24, R_m = lo + 2^16 hi < 2^25: lo goes through the 2^16
+lookup table like the limbs, hi through a second, 2^9-entry table (two logup.RangeCheck instances sharing the challenge;
+a single table would need a third cell 2^7 hi per carry - a fifth of a unit's cells and of their helper columns).  With sum_t 16 |a_t|_max |b_t|_max < 2^40 (checked when a unit is
 built) every |G_m + r_(m-1) - 2^32 r_m| < 2^58 < p_Goldilocks, so each field equation holds over the integers and the
 chain telescopes to sum_k D_k 2^(16 k) = 0.  All unit constraints have degree <= the product of its operand degrees.
 Range checks are near-light-client_amd/logup.py lookups into the 2^16 table.
@@ -31,11 +32,12 @@ LIMB_BITS = 16
 Q_LIMBS = 17
 N_CARRY = 15
 CARRY_OFFSET = 1 << 24
-CARRY_HI_SHIFT = 7                                  # hi < 2^9  <=>  hi and 2^7 hi are both in the 2^16 table
+CARRY_HI_BITS = 9                                   # the carries' high parts are looked up in a 2^9-entry table
 Q0 = 1 << 260
 Q0_LIMBS = [(Q0 >> (16 * i)) & 0xFFFF for i in range(Q_LIMBS)]   # only limb 16 is non-zero (= 16)
 P_LIMBS = [(P25519 >> (16 * i)) & 0xFFFF for i in range(LIMBS)]
-UNIT_CELLS = LIMBS + Q_LIMBS + 3 * N_CARRY      # c, q, (lo, hi, 2^9 hi) per carry = 78 range-checked cells
+UNIT_CELLS = LIMBS + Q_LIMBS + 2 * N_CARRY      # c[16] q[17] lo[15] | hi[15]: 48 cells for the 2^16 table, 15 for the 2^9 one
+UNIT_CELLS16 = LIMBS + Q_LIMBS + N_CARRY
 
 
 def to_limbs(x, n=LIMBS):
@@ -47,11 +49,11 @@ def from_limbs(limbs):
 
 
 def mul_unit_constraints(air, products, c, q, carries):
-    """Adds the 16 carry-chain constraints of one unit (+ 15 ties of the carries' second lookup cell).
+    """Adds the 16 carry-chain constraints of one unit.
 
     products: list of (a, b, sign, bound): a, b lists of 16 limb expressions, sign = +-1, bound >= max |a_i| max |b_j|;
     c: 16 limb expressions or integers (the result cells, or a constant); q: 17 limb expressions;
-    carries: list of 15 (lo, hi, hi_shifted) expression triples."""
+    carries: list of 15 (lo, hi) expression pairs."""
     assert sum(16 * bound for _, _, _, bound in products) < (1 << 40), "operand limbs too large for the carry range"
     d = []
     for k in range(2 * LIMBS):
@@ -84,10 +86,9 @@ def mul_unit_constraints(air, products, c, q, carries):
         if prev is not None:
             g = g + prev
         if m < N_CARRY:
-            lo, hi, his = carries[m]
+            lo, hi = carries[m]
             r = lo + hi * (1 << 16) - CARRY_OFFSET
             air.constraint(g - r * (1 << 32))
-            air.constraint(his - hi * (1 << CARRY_HI_SHIFT))
             prev = r
         else:
             air.constraint(g)
@@ -98,7 +99,7 @@ def _limbs_signed(x):
 
 
 def mul_unit_witness(products, c=None):
-    """Integer witness of one unit: (c limbs, q limbs, [(lo, hi, hi_shifted)] * 15).  products: list of (a, b) or
+    """Integer witness of one unit: (c limbs, q limbs, [(lo, hi)] * 15).  products: list of (a, b) or
     (a, b, sign): integers or (possibly signed) limb lists; c: the result to use (default: canonical)."""
     pl = [(_limbs_signed(pr[0]), _limbs_signed(pr[1]), pr[2] if len(pr) > 2 else 1) for pr in products]
     total = sum(sg * from_limbs(a) * from_limbs(b) for a, b, sg in pl)
@@ -128,52 +129,69 @@ def mul_unit_witness(products, c=None):
         if m < N_CARRY:
             big = prev + CARRY_OFFSET
             assert 0 <= big < (1 << 25), "carry out of range: operands too large"
-            carries.append((big & 0xFFFF, big >> 16, (big >> 16) << CARRY_HI_SHIFT))
+            carries.append((big & 0xFFFF, big >> 16))
         else:
             assert prev == 0
     return cl, ql, carries
 
 
+def unit_cell_values(cl, ql, carries):
+    """the 63 cells of a unit in column order: c, q, the carries' low parts, the carries' high parts"""
+    return list(cl) + list(ql) + [lo for lo, _ in carries] + [hi for _, hi in carries]
+
+
 class FpMulChip:
     """One multiplication a * b = c (mod p) per row as a two-round STARK.
 
-    Round 0: a[16], b[16], c[16], q[17], carries[15 x 3], multiplicity;  round 1: the lookup columns.  All 110 value
-    cells are range-checked (a and b too: the chip stands alone)."""
-    A, B, C, Q, R = 0, 16, 32, 48, 65
-    MULT = R + 3 * N_CARRY                      # 110
-    N_COLS0 = MULT + 1                          # 111
+    Round 0: a[16], b[16], then the unit's cells c[16], q[17], lo[15], hi[15], and the two multiplicity columns;
+    round 1: the lookup columns of the 2^16 table (a, b, c, q, lo: the chip stands alone, so its inputs are checked
+    too) and of the 2^9 table (hi)."""
+    A, B, C, Q, RLO, RHI = 0, 16, 32, 48, 65, 80
+    MULT16, MULT9 = 95, 96
+    N_COLS0 = 97
 
     def __init__(self, log_rows, config=None):
         if log_rows < LIMB_BITS:
             raise ValueError("the 2^16-entry range table needs at least 2^16 rows")
         self.log_rows = log_rows
-        n_lookups = self.MULT
-        self.n_cols1 = logup.round_cols(n_lookups)
+        self.lookups16 = list(range(self.RHI))
+        self.lookups9 = list(range(self.RHI, self.RHI + N_CARRY))
+        n1a, n1b = logup.round_cols(len(self.lookups16)), logup.round_cols(len(self.lookups9))
+        self.n_cols1 = n1a + n1b
         air = Air(self.N_COLS0 + self.n_cols1, 0, rounds=[(self.N_COLS0, 2), (self.n_cols1, 0)])
         L = air.local  # noqa: N806
         a = [L(self.A + i) for i in range(16)]
         b = [L(self.B + i) for i in range(16)]
         c = [L(self.C + i) for i in range(16)]
         q = [L(self.Q + i) for i in range(17)]
-        carries = [(L(self.R + 3 * m), L(self.R + 3 * m + 1), L(self.R + 3 * m + 2)) for m in range(N_CARRY)]
+        carries = [(L(self.RLO + m), L(self.RHI + m)) for m in range(N_CARRY)]
         mul_unit_constraints(air, [(a, b, 1, 1 << 32)], c, q, carries)
-        self.range_check = logup.RangeCheck(air, range(n_lookups), LIMB_BITS, self.MULT, self.N_COLS0)
+        self.range_check = logup.RangeCheck(air, self.lookups16, LIMB_BITS, self.MULT16, self.N_COLS0)
+        self.range_check9 = logup.RangeCheck(air, self.lookups9, CARRY_HI_BITS, self.MULT9, self.N_COLS0 + n1a)
         self.air = air
         self.stark = Stark(air, log_rows, config)
 
     def reference_trace(self, a_vals, b_vals):
-        """Round-0 columns (multiplicity column left zero) for integer operands, plain Python."""
+        """Round-0 columns (multiplicity columns left zero) for integer operands, plain Python."""
         n = 1 << self.log_rows
         assert len(a_vals) == n and len(b_vals) == n
         t = np.zeros((self.N_COLS0, n), dtype=np.uint64)
         for i, (x, y) in enumerate(zip(a_vals, b_vals)):
-            cl, ql, carries = mul_unit_witness([(int(x), int(y))])
             t[self.A:self.A + 16, i] = to_limbs(int(x))
             t[self.B:self.B + 16, i] = to_limbs(int(y))
-            t[self.C:self.C + 16, i] = cl
-            t[self.Q:self.Q + 17, i] = ql
-            t[self.R:self.R + 45, i] = [v for tr in carries for v in tr]
+            t[self.C:self.C + UNIT_CELLS, i] = unit_cell_values(*mul_unit_witness([(int(x), int(y))]))
         return t
+
+    def multiplicities(self, ctx, trace):
+        self.range_check.multiplicities(ctx, trace)
+        self.range_check9.multiplicities(ctx, trace)
+
+    def round1(self, ctx, trace, alpha, out):
+        """both tables' lookup columns into `out` ([n_cols1, n])"""
+        n1a = self.range_check.n_round_cols
+        self.range_check.round1(ctx, trace, alpha, out[:n1a])
+        self.range_check9.round1(ctx, trace, alpha, out[n1a:])
+        return out
 
 
 def operands_to_words(vals):
@@ -196,5 +214,5 @@ def chip_trace_on_gpu(ctx, chip, a_vals, b_vals):
     assert a.shape == (n, 4) and b.shape == (n, 4)
     trace = torch.empty((chip.N_COLS0, n), dtype=torch.int64, device="cuda:%d" % ctx.device)
     ctx.check(dll.nlx_fp25519_chip_trace(ctx.handle, a.ctypes.data, b.ctypes.data, chip.log_rows, trace.data_ptr()))
-    chip.range_check.multiplicities(ctx, trace)
+    chip.multiplicities(ctx, trace)
     return trace

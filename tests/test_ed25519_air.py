@@ -72,17 +72,23 @@ def tiled_case(nlx, orc):
     slots = rfc_slots(nlx)[:2]
     t0 = np.tile(E.reference_trace(slots), (1, 128))
     t0[E.MULT] = orc.logup_multiplicities(t0, E.LOOKUPS, 16)
+    t0[E.MULT9] = orc.logup_multiplicities(t0, E.LOOKUPS9, 9)
     return slots, t0
+
+
+def oracle_round1(orc, E, t0, alpha):
+    return np.concatenate([orc.logup_round(t0, E.LOOKUPS, 16, t0[E.MULT], alpha),
+                           orc.logup_round(t0, E.LOOKUPS9, 9, t0[E.MULT9], alpha)], axis=0)
 
 
 def test_every_constraint_vanishes_on_the_reference_trace(nlx, orc, tiled_case):
     E = nlx.ed25519_air
     slots, t0 = tiled_case
-    air, rc = E.ed25519_air()
-    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 3729 and len(E.LOOKUPS) == 1780
+    air, _ = E.ed25519_air()
+    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 3074 and (len(E.LOOKUPS), len(E.LOOKUPS9)) == (1120, 330)
     words = air.compile()
     alpha = (0x1234567890abcdef, 0x0fedcba987654321)
-    full = np.concatenate([t0, orc.logup_round(t0, E.LOOKUPS, 16, t0[E.MULT], alpha)], axis=0)
+    full = np.concatenate([t0, oracle_round1(orc, E, t0, alpha)], axis=0)
     n = full.shape[1]
     per = air._periodic
 
@@ -118,8 +124,7 @@ def test_gpu_trace_and_proof_equal_reference_and_oracle(nlx, ctx, orc, tiled_cas
         pytest.fail("GPU trace differs from the reference at column %d row %d" % (bad[0], bad[1]))
     proof = pr.prove(slots * 128)
     assert orc.stark_verify(pr.stark.desc, proof) == 1
-    want = orc.stark_prove_rounds(pr.stark.desc, lambda rnd, chal: t0 if rnd == 0 else
-                                  orc.logup_round(t0, E.LOOKUPS, 16, t0[E.MULT], chal[:2]), [])
+    want = orc.stark_prove_rounds(pr.stark.desc, lambda rnd, chal: t0 if rnd == 0 else oracle_round1(orc, E, t0, chal[:2]), [])
     assert proof == want
     pr.close()
 
@@ -150,8 +155,8 @@ def test_gpu_real_near_approvals_and_a_forgery(nlx, ctx, orc):
     forged[7] = (ax, ay, rx, ry, s ^ (1 << 100), h)
     with pytest.raises(nlx.NlxError, match="slot 7"):
         pr.generate_trace(forged)
-    rc = pr.es.range_check
-    rc.multiplicities(ctx, pr._t0)
-    bad_proof = pr.prover.prove_rounds(lambda rnd, chal: pr._t0 if rnd == 0 else rc.round1(ctx, pr._t0, chal[:2], pr._t1), [])
+    for rc in pr.es.range_checks:
+        rc.multiplicities(ctx, pr._t0)
+    bad_proof = pr.prover.prove_rounds(lambda rnd, chal: pr._t0 if rnd == 0 else pr.round1(chal[:2]), [])
     assert orc.stark_verify(pr.stark.desc, bad_proof) != 1
     pr.close()

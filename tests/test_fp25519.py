@@ -27,7 +27,7 @@ def test_unit_witness_matches_big_integers(nlx):
         a, b = rnd.getrandbits(256), rnd.getrandbits(256)
         cl, ql, carries = F.mul_unit_witness([(a, b)])
         assert F.from_limbs(cl) == a * b % F.P25519 and (F.from_limbs(ql) - F.Q0) * F.P25519 + F.from_limbs(cl) == a * b
-        assert all(0 <= lo < 65536 and 0 <= hi < 512 and his == hi << 7 for lo, hi, his in carries)
+        assert all(0 <= lo < 65536 and 0 <= hi < 512 for lo, hi in carries)
     # two products into one reduction, and a non-canonical result
     a, b, c, d = (rnd.getrandbits(256) for _ in range(4))
     cl, ql, _ = F.mul_unit_witness([(a, b), (c, d)])
@@ -69,7 +69,7 @@ def test_device_witness_code_on_the_host(nlx, tmp_path):
         f = line.split()
         cl, ql, carries = F.mul_unit_witness(prods, c=c)
         assert int(f[0], 16) == F.from_limbs(cl) and int(f[1], 16) == F.from_limbs(ql), prods
-        assert [int(x) for x in f[2:]] == [lo + (hi << 16) for lo, hi, _ in carries], prods
+        assert [int(x) for x in f[2:]] == [lo + (hi << 16) for lo, hi in carries], prods
 
 
 @pytest.fixture(scope="module")
@@ -78,21 +78,29 @@ def chip_case(nlx, orc):
     chip = F.FpMulChip(16, nlx.StarkConfig(fri_num_queries=20))
     a, b = _operands(1 << 16)
     t0 = chip.reference_trace(a, b)
-    t0[chip.MULT] = orc.logup_multiplicities(t0, range(chip.MULT), 16)
+    _fill_multiplicities(orc, chip, t0)
     return chip, t0, a, b
+
+
+def _fill_multiplicities(orc, chip, t):
+    t[chip.MULT16] = orc.logup_multiplicities(t, chip.lookups16, 16)
+    t[chip.MULT9] = orc.logup_multiplicities(t, chip.lookups9, 9)
 
 
 def _rounds(orc, chip, t0):
     def fn(rnd, chal):
-        return t0 if rnd == 0 else orc.logup_round(t0, range(chip.MULT), 16, t0[chip.MULT], chal[:2])
+        if rnd == 0:
+            return t0
+        return np.concatenate([orc.logup_round(t0, chip.lookups16, 16, t0[chip.MULT16], chal[:2]),
+                               orc.logup_round(t0, chip.lookups9, 9, t0[chip.MULT9], chal[:2])], axis=0)
     return fn
 
 
 def test_chip_oracle_accepts_and_rejects(nlx, orc, chip_case):
     chip, t0, a, b = chip_case
     F = nlx.fp25519
-    assert chip.air.constraint_degree == 3 and chip.stark.desc.n_cols == 225 and chip.stark.desc.period_bits == 16
-    assert int(t0[chip.MULT].sum()) == chip.MULT << 16
+    assert chip.air.constraint_degree == 3 and chip.stark.desc.n_cols == 97 + 84 + 20 and chip.stark.desc.period_bits == 16
+    assert int(t0[chip.MULT16].sum()) == 80 << 16 and int(t0[chip.MULT9].sum()) == 15 << 16
     for i in (0, 1, 4, 77):
         assert F.from_limbs(t0[chip.C:chip.C + 16, i]) == a[i] * b[i] % F.P25519
     proof = orc.stark_prove_rounds(chip.stark.desc, _rounds(orc, chip, t0), [])
@@ -101,12 +109,12 @@ def test_chip_oracle_accepts_and_rejects(nlx, orc, chip_case):
     def rejected(t):
         t = t.copy()
         try:
-            t[chip.MULT] = orc.logup_multiplicities(t, range(chip.MULT), 16)
+            _fill_multiplicities(orc, chip, t)
         except ValueError:
-            pass            # outside the table: keep the old multiplicities, the sums cannot agree
+            pass            # outside a table: keep the old multiplicities, the sums cannot agree
         return orc.stark_verify(chip.stark.desc, orc.stark_prove_rounds(chip.stark.desc, _rounds(orc, chip, t), [])) != 1
     # a wrong product limb (still 16 bits), a wrong carry
-    for col, row in ((chip.C + 3, 9), (chip.R + 3 * 7 + 1, 12)):
+    for col, row in ((chip.C + 3, 9), (chip.RHI + 7, 12)):
         bad = t0.copy()
         bad[col, row] = int(bad[col, row]) ^ 1
         assert rejected(bad), (col, row)
@@ -134,7 +142,7 @@ def test_gpu_chip_trace_and_proof_equal_oracle(nlx, ctx, orc, chip_case):
         pytest.fail("GPU chip trace differs from the reference at column %d row %d" % (bad[0], bad[1]))
     pr = chip.stark.build(ctx)
     out = torch.empty((chip.n_cols1, 1 << 16), dtype=torch.int64, device=dev.device)
-    proof = pr.prove_rounds(lambda rnd, chal: dev if rnd == 0 else chip.range_check.round1(ctx, dev, chal[:2], out), [])
+    proof = pr.prove_rounds(lambda rnd, chal: dev if rnd == 0 else chip.round1(ctx, dev, chal[:2], out), [])
     assert proof == orc.stark_prove_rounds(chip.stark.desc, _rounds(orc, chip, t0), [])
     assert orc.stark_verify(chip.stark.desc, proof) == 1
     pr.close()
