@@ -4,6 +4,7 @@
 // (fp25519.hpp) plus the auxiliary unit's step of the per-slot program.  Plain C++ / device code: the same function
 // runs in the sequential per-slot scan (no output), in the row-parallel emitter, and on the host in the tests.
 #pragma once
+#include "fe25519_fast.hpp"
 #include "fp25519.hpp"
 
 namespace nlx {
@@ -235,6 +236,58 @@ FP_HD inline bool row_aux(int r, const Slot& s, const Point& out, const uint32_t
 struct NoSink {
     FP_HD void unit(int, const fp::Unit&) {}
 };
+
+// The same row on values only (fe25519_fast.hpp): what the sequential scan needs - the canonical point after the row.
+struct FastSlot {
+    fe::Fe a_ymx, a_ypx, a_t2d;  // the triple of -A: (y + x, y - x, -2dxy)
+    fe::Fe b_ymx, b_ypx, b_t2d;
+};
+FP_HD inline void fast_slot(const Slot& s, FastSlot& f) {
+    const fe::Fe x = fe::from_limbs16(s.ax), y = fe::from_limbs16(s.ay), nt = fe::from_limbs16(s.nt);
+    f.a_ymx = fe::add(y, x);
+    f.a_ypx = fe::sub(y, x);
+    f.a_t2d = fe::neg(nt);
+    uint32_t k[16];
+    for (int i = 0; i < 16; i++) k[i] = K_LIMBS[K_B_YMX][i];
+    f.b_ymx = fe::from_limbs16(k);
+    for (int i = 0; i < 16; i++) k[i] = K_LIMBS[K_B_YPX][i];
+    f.b_ypx = fe::from_limbs16(k);
+    for (int i = 0; i < 16; i++) k[i] = K_LIMBS[K_B_T2D][i];
+    f.b_t2d = fe::from_limbs16(k);
+}
+struct FastPoint { fe::Fe x, y, z; };
+FP_HD inline void fast_madd(fe::Fe& x, fe::Fe& y, fe::Fe& z, fe::Fe& t, bool bit, const fe::Fe& ymx, const fe::Fe& ypx, const fe::Fe& t2d,
+                            bool want_t) {
+    // a zero bit adds the neutral triple (1, 1, 0): A = y - x, B = y + x, C = 0
+    const fe::Fe ymx_in = fe::sub(y, x), ypx_in = fe::add(y, x);
+    const fe::Fe aa = bit ? fe::mul(ymx_in, ymx) : ymx_in, bb = bit ? fe::mul(ypx_in, ypx) : ypx_in;
+    fe::Fe cc;
+    if (bit) cc = fe::mul(t, t2d);
+    else for (int i = 0; i < 10; i++) cc.l[i] = 0;
+    const fe::Fe dd = fe::dbl(z);
+    const fe::Fe e = fe::sub(bb, aa), f = fe::sub(dd, cc), g = fe::add(dd, cc), h = fe::add(bb, aa);
+    x = fe::mul(e, f);
+    y = fe::mul(g, h);
+    if (want_t) t = fe::mul(e, h);
+    z = fe::mul(f, g);
+}
+FP_HD inline void fast_row(FastPoint& q, bool sbit, bool hbit, const FastSlot& s) {
+    const fe::Fe a = fe::mul(q.x, q.x), b = fe::mul(q.y, q.y), zz = fe::mul(q.z, q.z);
+    const fe::Fe xy = fe::add(q.x, q.y);
+    const fe::Fe e1 = fe::mul(xy, xy);
+    const fe::Fe e = fe::sub(fe::sub(e1, a), b), g = fe::sub(b, a), f = fe::sub(g, fe::dbl(zz)), h = fe::neg(fe::add(a, b));
+    fe::Fe x = fe::mul(e, f), y = fe::mul(g, h), t = fe::mul(e, h), z = fe::mul(f, g);
+    fast_madd(x, y, z, t, sbit, s.b_ymx, s.b_ypx, s.b_t2d, true);
+    fast_madd(x, y, z, t, hbit, s.a_ymx, s.a_ypx, s.a_t2d, false);
+    q.x = x;
+    q.y = y;
+    q.z = z;
+}
+FP_HD inline void fast_store(const FastPoint& q, Point& p) {
+    fe::freeze(q.x, p.x);
+    fe::freeze(q.y, p.y);
+    fe::freeze(q.z, p.z);
+}
 
 // All round-0 cells of row r of a slot (multiplicity column zero) through put(column, value).  `in` is the row's input
 // point; the row's result is returned in `out`.  Returns false if the row's auxiliary check (curve equation of A or R,

@@ -2,7 +2,8 @@
 // §8f.1: curta_eddsa_verify_sigs_conditional, nearx/src/builder.rs:152).  Two kernels over the row code of
 // ed25519_rows.hpp:
 //   k_ed_scan  one lane per slot walks its 256 rows (the point after each row depends on the one before) and
-//              records the input point of every row - the only sequential part;
+//              records the input point of every row - the only sequential part, on values only (fe25519_fast.hpp:
+//              26-bit limbs, no witness cells; canonical results, so identical to what the row emitter recomputes);
 //   k_ed_rows  one lane per row recomputes its 22 units from that input point (results are canonical, so the
 //              recomputation is bit-identical) and writes its 1 945 cells; a wave's 64 lanes are 64 consecutive rows,
 //              so every column store is 512 contiguous bytes.
@@ -21,17 +22,25 @@ __global__ __launch_bounds__(64) void k_ed_scan(const uint64_t* __restrict__ wor
     ed::Slot s;
     ed::slot_from_words(words + (size_t)k * 24, s);
     slots[k] = s;
+    ed::FastSlot fs;
+    ed::fast_slot(s, fs);
+    ed::FastPoint fq;
+    {
+        uint32_t zero[16], one[16];
+        for (int i = 0; i < 16; i++) { zero[i] = 0; one[i] = i == 0; }
+        fq.x = fe::from_limbs16(zero);
+        fq.y = fe::from_limbs16(one);
+        fq.z = fe::from_limbs16(one);
+    }
     ed::Point q;
-    for (int i = 0; i < 16; i++) { q.x[i] = 0; q.y[i] = q.z[i] = i == 0; }
-    ed::NoSink none;
 #pragma unroll 1
     for (int r = 0; r < ed::ROWS; r++) {
+        ed::fast_store(fq, q);
         in[(size_t)k * ed::ROWS + r] = q;
         const int bit = ed::ROWS - 1 - r;
-        ed::Point o;
-        ed::row_main(none, q, (int)((s.sw[bit >> 4] >> (bit & 15)) & 1), (int)((s.hw[bit >> 4] >> (bit & 15)) & 1), s, o);
-        q = o;
+        ed::fast_row(fq, ((s.sw[bit >> 4] >> (bit & 15)) & 1) != 0, ((s.hw[bit >> 4] >> (bit & 15)) & 1) != 0, fs);
     }
+    ed::fast_store(fq, q);
     fin[k] = q;
 }
 

@@ -26,20 +26,37 @@ int main(int argc, char** argv) {
     }
     const size_t ns = slots.size(), n = ns * ed::ROWS;
     std::vector<uint64_t> trace((size_t)ed::N_COLS0 * n);
-    // pass 1: the input point of every row, and every slot's final point
+    // pass 1: the input point of every row, and every slot's final point - on values only (fe25519_fast.hpp), checked
+    // against the witness code's row
     std::vector<ed::Point> in(n), fin(ns);
     for (size_t k = 0; k < ns; k++) {
-        ed::Point q;
-        for (int i = 0; i < 16; i++) { q.x[i] = 0; q.y[i] = q.z[i] = i == 0; }
+        ed::FastSlot fs;
+        ed::fast_slot(slots[k], fs);
+        ed::FastPoint fq;
+        {
+            uint32_t zero[16] = {0}, one[16] = {1};
+            fq.x = fe::from_limbs16(zero);
+            fq.y = fe::from_limbs16(one);
+            fq.z = fe::from_limbs16(one);
+        }
         ed::NoSink none;
         for (int r = 0; r < ed::ROWS; r++) {
+            ed::Point q;
+            ed::fast_store(fq, q);
             in[k * ed::ROWS + r] = q;
             const int bit = ed::ROWS - 1 - r;
-            ed::Point o;
-            ed::row_main(none, q, (slots[k].sw[bit >> 4] >> (bit & 15)) & 1, (slots[k].hw[bit >> 4] >> (bit & 15)) & 1, slots[k], o);
-            q = o;
+            const int sbit = (slots[k].sw[bit >> 4] >> (bit & 15)) & 1, hbit = (slots[k].hw[bit >> 4] >> (bit & 15)) & 1;
+            ed::Point o, o2;
+            ed::row_main(none, q, sbit, hbit, slots[k], o);
+            ed::fast_row(fq, sbit, hbit, fs);
+            ed::fast_store(fq, o2);
+            for (int i = 0; i < 16; i++)
+                if (o.x[i] != o2.x[i] || o.y[i] != o2.y[i] || o.z[i] != o2.z[i]) {
+                    fprintf(stderr, "fast row differs from the witness row: slot %zu row %d\n", k, r);
+                    return 4;
+                }
         }
-        fin[k] = q;
+        ed::fast_store(fq, fin[k]);
     }
     // pass 2: every row on its own
     for (size_t k = 0; k < ns; k++)
