@@ -356,6 +356,7 @@ int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint6
  * v1 = local[a], v2 = local[dst] (dst = 0xFFFF: a single lookup, h (alpha + v1) = 1), h = local[b] + local[b+1] X,
  * alpha = challenge k + challenge k+1 X with k in word bits 56..61.  Emits the X^0 then the X^1 coefficient. */
 #define NLX_AIR_EMIT_LOGUP 20
+#define NLX_AIR_MAC 21             /* r[dst] = r[c] + r[a] * r[b], c in word bits 56..61: the inner step of every limb convolution */
 #define NLX_AIR_MAX_SEGMENTS 256
 #define NLX_AIR_NUM_REGS 64
 #define NLX_AIR_MAX_PERIODIC 64

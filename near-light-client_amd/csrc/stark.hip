@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void k_air_quotient(AirParams p) {
             case NLX_AIR_ADD: my[dst * bd] = gl::add(my[a * bd], mul_pow2(my[b * bd], sh)); continue;
             case NLX_AIR_SUB: my[dst * bd] = gl::sub(my[a * bd], mul_pow2(my[b * bd], sh)); continue;
             case NLX_AIR_MUL: my[dst * bd] = gl::mul(my[a * bd], my[b * bd]); continue;
+            case NLX_AIR_MAC: my[dst * bd] = gl::add(my[sh * bd], gl::mul(my[a * bd], my[b * bd])); continue;
             case NLX_AIR_XOR3:
             case NLX_AIR_CH:
             case NLX_AIR_MAJ: {
@@ -334,7 +335,7 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
             const uint64_t w = prog[pc];
             const uint32_t op = (uint32_t)(w & 0xFF), dst = (uint32_t)((w >> 8) & 0xFFFF);
             const uint32_t a = (uint32_t)((w >> 24) & 0xFFFF), b = (uint32_t)((w >> 40) & 0xFFFF);
-            if (op > NLX_AIR_EMIT_LOGUP) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
+            if (op > NLX_AIR_MAC) return ctx->fail(NLX_E_INVAL, "AIR word %u: unknown opcode %u", pc, op);
             if (op == NLX_AIR_EMIT_LOGUP) {
                 const uint32_t k = (uint32_t)(w >> 56) & 0x3F;
                 if ((w >> 62) != 0 || a >= d.n_cols || b + 1 >= d.n_cols || (dst != 0xFFFF && dst >= d.n_cols) || k + 1 >= n_round_challenges)
@@ -367,7 +368,7 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
                 }
                 continue;
             }
-            const bool three = op >= NLX_AIR_XOR3 && op <= NLX_AIR_MAJ;
+            const bool three = (op >= NLX_AIR_XOR3 && op <= NLX_AIR_MAJ) || op == NLX_AIR_MAC;
             const bool writes = op <= NLX_AIR_MUL || (op >= NLX_AIR_PERIODIC && op <= NLX_AIR_PACK_NEXT) || three;
             if (three) {
                 const uint32_t c3 = (uint32_t)(w >> 56) & 0x3F;

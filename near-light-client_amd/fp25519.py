@@ -57,26 +57,29 @@ def mul_unit_constraints(air, products, c, q, carries):
     assert sum(16 * bound for _, _, _, bound in products) < (1 << 40), "operand limbs too large for the carry range"
     d = []
     for k in range(2 * LIMBS):
-        terms, const = [], 0
+        # positive products first: a chain of multiply-adds (NLX_AIR_MAC); everything else is shift-adds
+        pos, neg, const = [], [], 0
         for a, b, sign, _ in products:
-            for i in range(max(0, k - LIMBS + 1), min(LIMBS, k + 1)):
-                t = a[i] * b[k - i]
-                terms.append(t if sign > 0 else t * (-1))
+            (pos if sign > 0 else neg).extend(a[i] * b[k - i] for i in range(max(0, k - LIMBS + 1), min(LIMBS, k + 1)))
+        acc = None
+        for t in pos:
+            acc = t if acc is None else acc + t
+        for t in neg:
+            acc = t * (-1) if acc is None else acc - t
         if k < LIMBS:
             if isinstance(c[k], int):
                 const -= c[k]
             else:
-                terms.append(c[k] * (-1))
-        # - (q - Q0) p  with  p = -19 + 2^15 X^15
+                acc = c[k] * (-1) if acc is None else acc - c[k]
+        # - (q - Q0) p  with  p = -19 + 2^15 X^15:  + 19 q[k] (= 16 q + 2 q + q)  - 2^15 q[k - 15]
         if k < Q_LIMBS:
-            terms.append(q[k] * 19)
+            for w in (16, 2, 1):
+                acc = q[k] * w if acc is None else acc + q[k] * w
             const -= 19 * Q0_LIMBS[k]
         if 0 <= k - 15 < Q_LIMBS:
-            terms.append(q[k - 15] * (-(1 << 15)))
+            t = q[k - 15] * (1 << 15)
+            acc = t * (-1) if acc is None else acc - t
             const += (1 << 15) * Q0_LIMBS[k - 15]
-        acc = terms[0]
-        for t in terms[1:]:
-            acc = acc + t
         if const:
             acc = acc + const
         d.append(acc)

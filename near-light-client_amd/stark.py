@@ -20,9 +20,9 @@ from ._lib import dll, ptr, NlxError
 P = 0xFFFFFFFF00000001
 (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_CONST, AIR_ADD, AIR_SUB, AIR_MUL, AIR_EMIT_TRANSITION, AIR_EMIT_FIRST,
  AIR_EMIT_LAST, AIR_EMIT, AIR_PERIODIC, AIR_PACK_LOCAL, AIR_PACK_NEXT, AIR_EMIT_BOOL, AIR_LOADV, AIR_XOR3, AIR_CH,
- AIR_MAJ, AIR_SEGMENT, AIR_EMIT_LOGUP) = range(21)
+ AIR_MAJ, AIR_SEGMENT, AIR_EMIT_LOGUP, AIR_MAC) = range(22)
 _AIR_BINARY = (AIR_ADD, AIR_SUB, AIR_MUL)
-_AIR_TERNARY = (AIR_XOR3, AIR_CH, AIR_MAJ)
+_AIR_TERNARY = (AIR_XOR3, AIR_CH, AIR_MAJ, AIR_MAC)
 _AIR_FUSED_EMITS = (AIR_EMIT_BOOL, AIR_EMIT_LOGUP)   # constraints that are one instruction over columns, no expression
 AIR_NUM_REGS = 64
 AIR_MAX_RESIDENT_LEAVES = 12   # loads kept in registers (LRU) before they are re-loaded
@@ -98,6 +98,11 @@ class _Expr:
         f = _pow2_factor(self)
         if f:
             return _Expr(self.air, AIR_ADD, o, f[0], deg, f[1])
+        # sum + product: one multiply-add instruction (r[dst] = r[c] + r[a] * r[b])
+        if o.op == AIR_MUL:
+            return _Expr(self.air, AIR_MAC, o.a, o.b, deg, c=self)
+        if self.op == AIR_MUL:
+            return _Expr(self.air, AIR_MAC, self.a, self.b, deg, c=o)
         return _Expr(self.air, AIR_ADD, self, o, deg)
 
     __radd__ = __add__

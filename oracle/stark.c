@@ -323,6 +323,7 @@ static void air_eval_base(const orc_stark_desc* d, const uint64_t* local, const 
             case ORC_AIR_ADD: reg[dst] = gl_add(reg[a % AIR_REGS], gl_mul(reg[b % AIR_REGS], 1ULL << AIR_SH(w))); break;
             case ORC_AIR_SUB: reg[dst] = gl_sub(reg[a % AIR_REGS], gl_mul(reg[b % AIR_REGS], 1ULL << AIR_SH(w))); break;
             case ORC_AIR_MUL: reg[dst] = gl_mul(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
+            case ORC_AIR_MAC: reg[dst] = gl_add(reg[AIR_SH(w)], gl_mul(reg[a % AIR_REGS], reg[b % AIR_REGS])); break;
             case ORC_AIR_PACK_LOCAL: case ORC_AIR_PACK_NEXT: {
                 const uint64_t* rowv = AIR_OP(w) == ORC_AIR_PACK_LOCAL ? local : next;
                 uint64_t acc = 0;
@@ -405,6 +406,7 @@ static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* n
             case ORC_AIR_ADD: reg[dst] = gl2_add(reg[a % AIR_REGS], gl2_scale(reg[b % AIR_REGS], 1ULL << AIR_SH(w))); break;
             case ORC_AIR_SUB: reg[dst] = gl2_sub(reg[a % AIR_REGS], gl2_scale(reg[b % AIR_REGS], 1ULL << AIR_SH(w))); break;
             case ORC_AIR_MUL: reg[dst] = gl2_mul(reg[a % AIR_REGS], reg[b % AIR_REGS]); break;
+            case ORC_AIR_MAC: reg[dst] = gl2_add(reg[AIR_SH(w)], gl2_mul(reg[a % AIR_REGS], reg[b % AIR_REGS])); break;
             case ORC_AIR_PACK_LOCAL: case ORC_AIR_PACK_NEXT: {
                 const gl2* rowv = AIR_OP(w) == ORC_AIR_PACK_LOCAL ? local : next;
                 gl2 acc = gl2_from(0);
@@ -522,7 +524,7 @@ static int desc_ok(const orc_stark_desc* d) {
                     AIR_SH(w) + 1 >= total_round_challenges(d))
                     return 0;
                 break;
-            default: if (AIR_OP(w) > ORC_AIR_EMIT_LOGUP) return 0;
+            default: if (AIR_OP(w) > ORC_AIR_MAC) return 0;
         }
     }
     return 1;

@@ -61,8 +61,9 @@ enum {
     ORC_AIR_CH = 17,             /* dst = c + a (b - c)            (choose: a ? b : c) */
     ORC_AIR_MAJ = 18,            /* dst = ab + c (a + b - 2ab)     (majority) */
     ORC_AIR_SEGMENT = 19,        /* no register is carried across this word (registers are cleared here) */
-    ORC_AIR_EMIT_LOGUP = 20      /* the two constraints of a LogUp helper: v2 col in dst (0xFFFF: none), v1 col in a,
+    ORC_AIR_EMIT_LOGUP = 20,     /* the two constraints of a LogUp helper: v2 col in dst (0xFFFF: none), v1 col in a,
                                     h cols b, b+1, challenge index in bits 56..61 */
+    ORC_AIR_MAC = 21             /* dst = r[c] + r[a] * r[b], c in bits 56..61 */
 };
 /* ADD / SUB carry a shift in bits 56..61 of the word: dst = r[a] +- r[b] * 2^shift. */
 

@@ -34,6 +34,7 @@ def run_program(words, local, nxt, pis, periodic=(), n_public=None):
                 out.append((10, int(local[a + i]) * (int(local[a + i]) - 1) % P))
         elif op == 15: pass  # LOADV: scheduling hint
         elif op == 19: reg = {}  # SEGMENT: nothing is carried across
+        elif op == 21: reg[dst] = (reg[sh] + reg[a] * reg[b]) % P   # MAC
         elif op == 20:           # EMIT_LOGUP: v2 col in dst, v1 col in a, h cols b / b+1, challenge index in sh
             n_pis = len(pis) - 2 if n_public is None else n_public
             a0, a1 = int(pis[n_pis + sh]), int(pis[n_pis + sh + 1])
@@ -76,7 +77,8 @@ def test_air_compile_semantics(nlx):
     assert air.quotient_degree_factor() == 4
     words = air.compile()
     n_mul = sum(1 for w in words if int(w) & 0xFF == 6)
-    assert n_mul == 5                      # l0*l1 once, *l2, l5*l5, two in the last product
+    n_mac = sum(1 for w in words if int(w) & 0xFF == 21)
+    assert (n_mul, n_mac) == (4, 1)        # l0*l1 + 7 once (a multiply-add), *l2, l5*l5, two in the last product
     lo = [int(x) for x in rng.integers(0, P, 6, dtype=np.uint64)]
     ne = [int(x) for x in rng.integers(0, P, 6, dtype=np.uint64)]
     pi = [int(x) for x in rng.integers(0, P, 2, dtype=np.uint64)]
@@ -96,7 +98,7 @@ def test_air_register_pressure(nlx):
         acc = acc * air.local(i) + air.next(i)
     air.constraint(acc)
     words = air.compile()
-    assert max((int(w) >> 8) & 0xFFFF for w in words if int(w) & 0xFF <= 6) < S.AIR_MAX_RESIDENT_LEAVES + 4
+    assert max((int(w) >> 8) & 0xFFFF for w in words if int(w) & 0xFF <= 6 or int(w) & 0xFF == 21) < S.AIR_MAX_RESIDENT_LEAVES + 4
     # 70 squares summed left to right: post-order evaluation frees operands as it goes
     wide = S.Air(200, 0)
     tot = wide.local(0) * wide.local(0)
@@ -106,7 +108,7 @@ def test_air_register_pressure(nlx):
     assert max((int(w) >> 8) & 0xFFFF for w in wide.compile() if int(w) & 0xFF <= 6) < S.AIR_MAX_RESIDENT_LEAVES + 4
     # 70 values that are all still needed later do not fit 64 registers: refused, not miscompiled
     over = S.Air(200, 0)
-    sq = [over.local(i) * over.local(i) for i in range(70)]
+    sq = [over.local(i) - over.local(i + 70) for i in range(70)]   # shared by both constraints below
     s1 = sq[0]
     for q in sq[1:]:
         s1 = s1 + q
@@ -268,7 +270,7 @@ def test_air_ternary_forms(nlx):
     assert air.constraint_degree == 4   # xor3 of a degree-3 node with a column and a constant
     words = air.compile()
     ops = [int(v) & 0xFF for v in words]
-    assert ops.count(16) == 3 and ops.count(17) == 1 and ops.count(18) == 1 and ops.count(6) == 1  # the "* 5"
+    assert ops.count(16) == 3 and ops.count(17) == 1 and ops.count(18) == 1 and ops.count(6) + ops.count(21) == 1  # the "* 5" (a multiply-add)
     for bits in ((0, 0, 0, 0), (1, 0, 1, 1), (1, 1, 1, 0), (0, 1, 0, 1)):
         got = run_program(words, bits, bits, [])
         bx, by, bz, bw = bits
