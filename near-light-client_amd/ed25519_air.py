@@ -118,8 +118,10 @@ def _const_vec(value):
     return _Vec(fp.to_limbs(value % P), 1 << 16)
 
 
-def ed25519_air():
+def ed25519_air(max_resident_leaves=None):
     air = Air(N_COLS0 + N_COLS1, 0, rounds=[(N_COLS0, 2), (N_COLS1, 0)])
+    if max_resident_leaves is not None:
+        air.max_resident_leaves = max_resident_leaves
     L, N = air.local, air.next  # noqa: N806
 
     def cells(base, nxt=False):
@@ -436,11 +438,11 @@ def slots_to_words(slots):
 class Ed25519Stark:
     """The AIR compiled for 2^log_slots signature slots (256 rows each)."""
 
-    def __init__(self, log_slots, config=None):
+    def __init__(self, log_slots, config=None, max_resident_leaves=None):
         if log_slots < 8:
             raise ValueError("at least 2^8 slots per proof (the 2^16-entry range table needs 2^16 rows)")
         self.log_slots = log_slots
-        self.air, self.range_checks = ed25519_air()
+        self.air, self.range_checks = ed25519_air(max_resident_leaves)
         self.stark = Stark(self.air, log_slots + 8, config)
 
 
@@ -448,9 +450,9 @@ class Ed25519Prover:
     """Proves 2^log_slots Ed25519 verifications on one GPU: trace generation (nlx_ed25519_trace), multiplicities and
     lookup columns (nlx_logup_*), two-round STARK (nlx_stark_prove_rounds) - nothing of the trace touches the host."""
 
-    def __init__(self, ctx, log_slots, config=None):
+    def __init__(self, ctx, log_slots, config=None, max_resident_leaves=None):
         self.ctx = ctx
-        self.es = Ed25519Stark(log_slots, config)
+        self.es = Ed25519Stark(log_slots, config, max_resident_leaves)
         self.stark = self.es.stark
         self.prover = self.stark.build(ctx)
         self._t0 = self._t1 = None

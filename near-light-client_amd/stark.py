@@ -140,6 +140,7 @@ class Air:
                 raise ValueError("rounds must split the columns into 1..3 non-empty groups")
         self._emits = []  # (op, expr)
         self.segment_nodes = AIR_SEGMENT_NODES
+        self.max_resident_leaves = AIR_MAX_RESIDENT_LEAVES   # more: fewer re-loads, a larger register file (LDS) per wave
         self._leaf_cache = {}
         self.period_bits = 0
         self._periodic = []  # value arrays, each of length 2^period_bits
@@ -374,7 +375,7 @@ class Air:
             """A free register, or the one of the resident load whose next use is farthest away (Belady).
             With `needed_at` (prefetch) the eviction is refused - returns None - when every candidate is needed
             sooner than the load being prefetched."""
-            if free and not (for_leaf and len(resident) >= AIR_MAX_RESIDENT_LEAVES):
+            if free and not (for_leaf and len(resident) >= self.max_resident_leaves):
                 return take_free()
             best, best_use = None, -1
             for y in resident:
