@@ -99,19 +99,26 @@ AUX_STEPS = {"ycmp": 0, "a_u": 1, "a_nt": 2, "a_u2": 3, "a_v": 4, "a_chk": 5, "r
 
 
 class _Vec:
-    """16 limb expressions (or integers) with a bound on their magnitude."""
+    """16 limb expressions (or integers) with a bound on their magnitude.  Lazy: `limbs` builds the expressions
+    afresh at every use, so two units reading the same linear combination (E, F, G, H of an addition) do not share
+    expression nodes - shared nodes would stay in VM registers from their first use to their last, 64 of them across
+    the four products of an addition, and the register file is what limits the quotient kernel's occupancy."""
 
-    def __init__(self, limbs, bound):
-        self.limbs, self.bound = list(limbs), bound
+    def __init__(self, make, bound):
+        self._make, self.bound = (make if callable(make) else (lambda v=list(make): list(v))), bound
+
+    @property
+    def limbs(self):
+        return self._make()
 
     def __add__(self, o):
-        return _Vec([a + b for a, b in zip(self.limbs, o.limbs)], self.bound + o.bound)
+        return _Vec(lambda: [a + b for a, b in zip(self.limbs, o.limbs)], self.bound + o.bound)
 
     def __sub__(self, o):
-        return _Vec([a - b for a, b in zip(self.limbs, o.limbs)], self.bound + o.bound)
+        return _Vec(lambda: [a - b for a, b in zip(self.limbs, o.limbs)], self.bound + o.bound)
 
     def scale(self, k):
-        return _Vec([a * k for a in self.limbs], self.bound * abs(k))
+        return _Vec(lambda: [a * k for a in self.limbs], self.bound * abs(k))
 
 
 def _const_vec(value):
