@@ -142,3 +142,38 @@ def test_gpu_logup_round_equals_oracle(nlx, ctx, orc, n_values, bits, db):
     assert proof == orc.stark_prove_rounds(st.desc, rounds_fn(orc, t0, n_values, bits), [])
     assert orc.stark_verify(st.desc, proof) == 1
     pr.close()
+
+
+@pytest.mark.gpu
+def test_gpu_witness_calls_reject_bad_arguments(nlx, ctx):
+    """The lookup / trace-generation entry points return an error code (never abort) for out-of-range arguments."""
+    import ctypes
+    import torch
+    dll = nlx.lib.dll
+    t = torch.zeros((4, 64), dtype=torch.int64, device="cuda:%d" % ctx.device)
+    cols = np.array([0, 1], dtype=np.uint32)
+    al = np.array([1, 2], dtype=np.uint64)
+    out = torch.zeros((6, 64), dtype=torch.int64, device=t.device)
+
+    def mult(**kw):
+        a = dict(trace=t.data_ptr(), n_cols=4, log_n=6, cols=cols.ctypes.data, n=2, bits=4, mcol=3)
+        a.update(kw)
+        return dll.nlx_logup_multiplicities(ctx.handle, a["trace"], a["n_cols"], a["log_n"], a["cols"], a["n"], a["bits"], a["mcol"])
+    assert mult() == 0
+    assert mult(bits=7) < 0 and mult(bits=0) < 0 and mult(bits=17) < 0          # table larger than the trace / out of range
+    assert mult(mcol=4) < 0 and mult(mcol=1) < 0                                # multiplicity column out of range / looked up
+    assert mult(trace=None) < 0 and mult(n=0) < 0
+    bad_cols = np.array([0, 9], dtype=np.uint32)
+    assert mult(cols=bad_cols.ctypes.data) < 0
+    assert b"out of range" in dll.nlx_last_error(ctx.handle)
+    assert dll.nlx_logup_round(ctx.handle, t.data_ptr(), 4, 6, cols.ctypes.data, 2, 4, 3, al.ctypes.data, out.data_ptr()) == 0
+    assert dll.nlx_logup_round(ctx.handle, t.data_ptr(), 4, 6, cols.ctypes.data, 2, 4, 3, None, out.data_ptr()) < 0
+    assert dll.nlx_logup_round(ctx.handle, t.data_ptr(), 4, 6, cols.ctypes.data, 2, 4, 3, al.ctypes.data, None) < 0
+    assert dll.nlx_logup_round_cols(2) == 6 and dll.nlx_logup_round_cols(3) == 8
+    words = np.zeros((256, 24), dtype=np.uint64)
+    assert dll.nlx_ed25519_trace(ctx.handle, words.ctypes.data, 17, t.data_ptr()) < 0
+    assert dll.nlx_ed25519_trace(ctx.handle, None, 8, t.data_ptr()) < 0
+    assert dll.nlx_fp25519_chip_trace(ctx.handle, None, words.ctypes.data, 16, t.data_ptr()) < 0
+    assert dll.nlx_fp25519_chip_trace(ctx.handle, words.ctypes.data, words.ctypes.data, 3, t.data_ptr()) < 0
+    assert dll.nlx_sha512_trace(ctx.handle, words.ctypes.data, words.ctypes.data, 19, t.data_ptr(), None) < 0
+    _ = ctypes
