@@ -13,7 +13,7 @@ namespace ed {
 constexpr int ROWS = 256, N_MAIN = 21, UNIT_CELLS = fp::UNIT_CELLS;
 // round-0 column map (ed25519_air.py)
 constexpr uint32_t cSIN = 0, cSB = 48, cHB = 49, cSA = 50, cHA = 51, cAX = 52, cAY = 68, cRX = 84, cRY = 100, cNT = 116,
-                   cSW = 132, cHW = 148, cMAIN = 164, cAUX_A = cMAIN + N_MAIN * UNIT_CELLS, cAUX_B = cAUX_A + 16,
+                   cSW = 132, cHW = 148, cCHK = 164, cMAIN = 168, cAUX_A = cMAIN + N_MAIN * UNIT_CELLS, cAUX_B = cAUX_A + 16,
                    cAUX_E = cAUX_B + 16, cAUX_F = cAUX_E + 16, cAUX = cAUX_F + 16, cMULT = cAUX + UNIT_CELLS,
                    cMULT9 = cMULT + 1, N_COLS0 = cMULT9 + 1;
 enum { U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2, U_BA, U_BB, U_BC, U_X3, U_Y3, U_T3, U_Z3, U_AA, U_AB, U_AC, U_X4, U_Y4, U_Z4 };
@@ -322,6 +322,15 @@ FP_HD inline bool emit_row(int r, const Slot& s, const Point& in, const uint32_t
         put(cNT + i, s.nt[i]);
         put(cSW + i, s.sw[i]);
         put(cHW + i, s.hw[i]);
+    }
+    {
+        // the row that closes block j carries limb j of A and R through the looked-up cells (their range check)
+        const bool close = (r & 15) == 15;
+        const int j = 15 - (r >> 4);
+        put(cCHK, close ? s.ax[j] : 0u);
+        put(cCHK + 1, close ? s.ay[j] : 0u);
+        put(cCHK + 2, close ? s.rx[j] : 0u);
+        put(cCHK + 3, close ? s.ry[j] : 0u);
     }
     EmitSink<Put> sink{put};
     row_main(sink, in, sbit, hbit, s, out);

@@ -15,7 +15,7 @@ A and R checked to be on the curve.  Row r of a slot handles bit 255 - r of both
 21 multiplication units per row plus one auxiliary unit that runs a small per-slot program in otherwise idle rows:
 2d*x*y of A (the addend's third coordinate), the curve equation of A and of R, and the final comparison
 RX * Z = X, RY * Z = Y.  Everything a unit reads is either a range-checked cell, a constant, or a cell tied by a
-degree <= 3 constraint to one of those; all unit results, quotients and carries (and the limbs of A and R) go through
+degree <= 3 constraint to one of those; all unit results, quotients and carries (and, once per slot, the limbs of A and R) go through
 the 2^16-table lookup (the carries' high parts through a 2^9 table).  Constraint degree 3, two commitment rounds
 (the second is logup.py's columns for the two tables).
 
@@ -81,8 +81,9 @@ class _Layout:
 LAY = _Layout()
 SIN = LAY.take(48)                               # the row's input point X, Y, Z
 SB, HB, SA, HA = (LAY.take(1) for _ in range(4))  # scalar bits and their 16-bit limb accumulators
-AX, AY, RX, RY = (LAY.take(16, True) for _ in range(4))
+AX, AY, RX, RY = (LAY.take(16) for _ in range(4))
 NT, SW, HW = (LAY.take(16) for _ in range(3))     # 2d x y of A; limbs of S and h
+CHK = LAY.take(4, True)                          # on the last row of limb j's block: limb j of AX, AY, RX, RY (range check)
 MAIN = [LAY.take_unit() for _ in range(N_MAIN)]
 AUX_A, AUX_B, AUX_E, AUX_F = (LAY.take(16) for _ in range(4))
 AUX = LAY.take_unit()
@@ -164,6 +165,13 @@ def ed25519_air(max_resident_leaves=None):
         for j in range(1, 16):
             cur = cur + block[j] * L(words + j)
         air.constraint(limb_end * (L(acc) - cur))
+    # ---- the limbs of A and R are range-checked once per slot: limb j shows up in a looked-up cell on the row that
+    # closes block j (the other rows of those four cells are free in-range values) ----
+    for k, base in enumerate((AX, AY, RX, RY)):
+        cur = block[0] * L(base)
+        for j in range(1, 16):
+            cur = cur + block[j] * L(base + j)
+        air.constraint(limb_end * (L(CHK + k) - cur))
     # ---- per-slot columns stay constant inside a slot ----
     for base in (AX, AY, RX, RY, NT, SW, HW):
         for i in range(16):
@@ -314,6 +322,9 @@ def reference_slot(ax, ay, rx, ry, s, h):
         t[SB, r], t[HB, r], t[SA, r], t[HA, r] = sbit, hbit, sa, ha
         for base, limbs in ((AX, axl), (AY, ayl), (RX, rxl), (RY, ryl), (NT, ntl), (SW, fp.to_limbs(s)), (HW, fp.to_limbs(h))):
             put_vec(base, r, limbs)
+        if r % 16 == 15:
+            j = 15 - r // 16
+            t[CHK:CHK + 4, r] = [axl[j], ayl[j], rxl[j], ryl[j]]
         x1, y1, z1 = q
         put_vec(SIN, r, x1)
         put_vec(SIN + 16, r, y1)

@@ -85,7 +85,7 @@ def test_every_constraint_vanishes_on_the_reference_trace(nlx, orc, tiled_case):
     E = nlx.ed25519_air
     slots, t0 = tiled_case
     air, _ = E.ed25519_air()
-    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 3074 and (len(E.LOOKUPS), len(E.LOOKUPS9)) == (1120, 330)
+    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 3018 and (len(E.LOOKUPS), len(E.LOOKUPS9)) == (1060, 330)
     words = air.compile()
     alpha = (0x1234567890abcdef, 0x0fedcba987654321)
     full = np.concatenate([t0, oracle_round1(orc, E, t0, alpha)], axis=0)
