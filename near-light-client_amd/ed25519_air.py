@@ -122,10 +122,6 @@ class _Vec:
         return _Vec(lambda: [a * k for a in self.limbs], self.bound * abs(k))
 
 
-def _const_vec(value):
-    return _Vec(fp.to_limbs(value % P), 1 << 16)
-
-
 def ed25519_air(max_resident_leaves=None):
     air = Air(N_COLS0 + N_COLS1, 0, rounds=[(N_COLS0, 2), (N_COLS1, 0)])
     if max_resident_leaves is not None:
@@ -275,10 +271,6 @@ def ed25519_air(max_resident_leaves=None):
 # ---------------------------------------------------------------------------------------------
 # plain-Python witness (tests only; the product path generates the trace on the GPU)
 # ---------------------------------------------------------------------------------------------
-def _signed(vals):
-    return [int(v) for v in vals]
-
-
 def _vadd(a, b):
     return [x + y for x, y in zip(a, b)]
 
