@@ -1,6 +1,6 @@
 // Witness generation for the Ed25519 verification AIR (near-light-client_amd/ed25519_air.py; SURVEY.md §8a row a12,
 // curta_eddsa_verify_sigs_conditional at nearx/src/builder.rs:152).  One trace row = one bit of both scalars: a point
-// doubling, a conditional addition of the base point and one of -A, as 21 multiplication units mod 2^255 - 19
+// doubling and the addition of 0, B, -A or B - A (Shamir's trick), as 15 multiplication units mod 2^255 - 19
 // (fp25519.hpp) plus the auxiliary unit's step of the per-slot program.  Plain C++ / device code: the same function
 // runs in the sequential per-slot scan (no output), in the row-parallel emitter, and on the host in the tests.
 #pragma once
@@ -10,33 +10,35 @@
 namespace nlx {
 namespace ed {
 
-constexpr int ROWS = 256, N_MAIN = 21, UNIT_CELLS = fp::UNIT_CELLS;
+constexpr int ROWS = 256, N_MAIN = 15, UNIT_CELLS = fp::UNIT_CELLS;
 // round-0 column map (ed25519_air.py)
 constexpr uint32_t cSIN = 0, cSB = 48, cHB = 49, cSA = 50, cHA = 51, cAX = 52, cAY = 68, cRX = 84, cRY = 100, cNT = 116,
-                   cSW = 132, cHW = 148, cCHK = 164, cMAIN = 168, cAUX_A = cMAIN + N_MAIN * UNIT_CELLS, cAUX_B = cAUX_A + 16,
+                   cSW = 132, cHW = 148, cCHK = 164, cSAA = 168, cSBB = 184, cSCC = 200, cSX3 = 216, cSY3 = 232, cSZ3 = 248,
+                   cSPT = 264, cP2 = 280, cMAIN = 344, cAUX_A = cMAIN + N_MAIN * UNIT_CELLS, cAUX_B = cAUX_A + 16,
                    cAUX_E = cAUX_B + 16, cAUX_F = cAUX_E + 16, cAUX = cAUX_F + 16, cMULT = cAUX + UNIT_CELLS,
                    cMULT9 = cMULT + 1, N_COLS0 = cMULT9 + 1;
-enum { U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2, U_BA, U_BB, U_BC, U_X3, U_Y3, U_T3, U_Z3, U_AA, U_AB, U_AC, U_X4, U_Y4, U_Z4 };
+enum { U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2, U_PA, U_PB, U_PC, U_PD, U_X4, U_Y4, U_Z4 };
 enum { STEP_YCMP = 0, STEP_A_U = 1, STEP_A_NT = 2, STEP_A_U2 = 3, STEP_A_V = 4, STEP_A_CHK = 5, STEP_R_U = 6, STEP_R_V = 7,
-       STEP_R_CHK = 8, STEP_XCMP = 255 };
+       STEP_R_CHK = 8, STEP_S_AA = 9, STEP_S_BB = 10, STEP_S_CC = 11, STEP_S_X = 12, STEP_S_Y = 13, STEP_S_Z = 14, STEP_S_T = 15,
+       STEP_S_PT = 16, STEP_XCMP = 255 };
 
 typedef int32_t limbs_t[16];
 
-// curve constants as 16-bit limbs, little-endian: d, 2d, the base point's triple (y - x, y + x, 2 d x y), p - 1
-static constexpr uint16_t K_LIMBS[6][16] = {
+// curve constants as 16-bit limbs, little-endian: d, 2d, the base point's triple (y - x, y + x, 2 d x y), p - 1, x_B y_B
+static constexpr uint16_t K_LIMBS[7][16] = {
     {0x78a3, 0x1359, 0x4dca, 0x75eb, 0xd8ab, 0x4141, 0x0a4d, 0x0070, 0xe898, 0x7779, 0x4079, 0x8cc7, 0xfe73, 0x2b6f, 0x6cee, 0x5203},
     {0xf159, 0x26b2, 0x9b94, 0xebd6, 0xb156, 0x8283, 0x149a, 0x00e0, 0xd130, 0xeef3, 0x80f2, 0x198e, 0xfce7, 0x56df, 0xd9dc, 0x2406},
     {0x913e, 0xd740, 0x3905, 0x9d10, 0xbeb3, 0xd140, 0x9f05, 0xfd39, 0x8a09, 0x688f, 0x8434, 0xa5c1, 0x1267, 0x98f8, 0x2f92, 0x44fd},
     {0x3b85, 0xf58c, 0x93c6, 0x2fbc, 0x0e19, 0xfb8c, 0x2dc6, 0xcf93, 0x42c2, 0x643d, 0x4898, 0x270b, 0xba65, 0x33d4, 0x9d3a, 0x07cf},
     {0xaa68, 0x877a, 0x1205, 0xabc9, 0xc49e, 0xccaa, 0xe823, 0x26d9, 0x598c, 0xdd43, 0x7dcb, 0x5a1b, 0x65a8, 0x9f0c, 0x7b68, 0x6f11},
-    {0xffec, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0x7fff}};
+    {0xffec, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0xffff, 0x7fff},
+    {0xdda3, 0xa5b7, 0x8ab3, 0x6dde, 0x52f5, 0x7751, 0x9f80, 0x20f0, 0xe37d, 0x64ab, 0x4e8e, 0x66ea, 0x7665, 0xd78b, 0x5f0f, 0x6787}};
 FP_HD inline void const_limbs(int which, limbs_t out) {
     for (int i = 0; i < 16; i++) out[i] = K_LIMBS[which][i];
 }
+enum { K_D = 0, K_D2 = 1, K_B_YMX = 2, K_B_YPX = 3, K_B_T2D = 4, K_M1 = 5, K_B_T = 6 };
 
-enum { K_D = 0, K_D2 = 1, K_B_YMX = 2, K_B_YPX = 3, K_B_T2D = 4, K_M1 = 5 };
-
-// one product unit: c = a b (canonical), quotient, carries.  Not inlined on the device: a row calls it 22 times, and one
+// one product unit: c = a b (canonical), quotient, carries.  Not inlined on the device: a row calls it 16 times, and one
 // copy with fully unrolled loops (every array in registers) is what keeps the generator out of scratch memory.
 FP_HD FP_NOINLINE inline void mul1(const limbs_t a, const limbs_t b, fp::Unit& u, const uint32_t* c_fixed = nullptr) {
     int64_t prod[32];
@@ -51,10 +53,23 @@ FP_HD inline void vcopy(const uint32_t* a, limbs_t o) { for (int i = 0; i < 16; 
 
 struct Point { uint32_t x[16], y[16], z[16]; };  // reduced limbs
 
-// The slot's constant data: limbs of A, R, 2dxy of A, the scalars.
+// The slot's constant data: limbs of A, R, the scalars, and what the auxiliary program derives from A: 2dxy and the
+// point B - A with the three products of its addition (all canonical).
 struct Slot {
     uint32_t ax[16], ay[16], rx[16], ry[16], nt[16], sw[16], hw[16];
+    uint32_t saa[16], sbb[16], scc[16], sx3[16], sy3[16], sz3[16], st3[16], spt[16];
 };
+
+// the linear combinations the B - A addition multiplies: E = BB - AA, H = BB + AA, F = CC' + 2, G = 2 - CC'
+FP_HD inline void sum_operands(const Slot& s, limbs_t e, limbs_t f, limbs_t g, limbs_t h) {
+    for (int i = 0; i < 16; i++) {
+        const int32_t two = i == 0 ? 2 : 0;
+        e[i] = (int32_t)s.sbb[i] - (int32_t)s.saa[i];
+        h[i] = (int32_t)s.sbb[i] + (int32_t)s.saa[i];
+        f[i] = (int32_t)s.scc[i] + two;
+        g[i] = two - (int32_t)s.scc[i];
+    }
+}
 
 FP_HD inline void slot_from_words(const uint64_t* w /* ax ay rx ry s h: 6 x 4 words */, Slot& s) {
     uint32_t* dst[6] = {s.ax, s.ay, s.rx, s.ry, s.sw, s.hw};
@@ -62,57 +77,70 @@ FP_HD inline void slot_from_words(const uint64_t* w /* ax ay rx ry s h: 6 x 4 wo
         for (int i = 0; i < 16; i++) dst[v][i] = (uint32_t)((w[4 * v + (i >> 2)] >> (16 * (i & 3))) & 0xFFFF);
     limbs_t a, b, k;
     fp::Unit u;
+    auto store = [&](uint32_t* out) { for (int i = 0; i < 16; i++) out[i] = u.c[i]; };
     vcopy(s.ax, a);
     vcopy(s.ay, b);
     mul1(a, b, u);
     const_limbs(K_D2, k);
     vcopy(u.c, a);
     mul1(k, a, u);
-    for (int i = 0; i < 16; i++) s.nt[i] = u.c[i];
-}
-
-// Madd with the precomputed triple (ymx, ypx, t2d) of the addend (signed limbs).  Sink::unit(index, Unit) receives
-// the seven (six without T) units in the order of the column map.
-template <class Sink>
-FP_HD inline void madd(Sink& sink, int first_unit, const uint32_t* x, const uint32_t* y, const uint32_t* z, const uint32_t* t,
-                       const limbs_t ymx, const limbs_t ypx, const limbs_t t2d, bool want_t, Point& out, uint32_t* t_out) {
-    fp::Unit aa, bb, cc, u;
-    limbs_t l0;
-    vsub(y, x, l0);
-    mul1(l0, ymx, aa);
-    sink.unit(first_unit, aa);
-    vadd(y, x, l0);
-    mul1(l0, ypx, bb);
-    sink.unit(first_unit + 1, bb);
-    vcopy(t, l0);
-    mul1(l0, t2d, cc);
-    sink.unit(first_unit + 2, cc);
+    store(s.nt);
+    vadd(s.ay, s.ax, a);
+    const_limbs(K_B_YMX, k);
+    mul1(a, k, u);
+    store(s.saa);
+    vsub(s.ay, s.ax, a);
+    const_limbs(K_B_YPX, k);
+    mul1(a, k, u);
+    store(s.sbb);
+    vcopy(s.nt, a);
+    const_limbs(K_B_T, k);
+    mul1(a, k, u);
+    store(s.scc);
     limbs_t e, f, g, h;
-    for (int i = 0; i < 16; i++) {
-        const int32_t dd = 2 * (int32_t)z[i];
-        e[i] = (int32_t)bb.c[i] - (int32_t)aa.c[i];
-        f[i] = dd - (int32_t)cc.c[i];
-        g[i] = dd + (int32_t)cc.c[i];
-        h[i] = (int32_t)bb.c[i] + (int32_t)aa.c[i];
-    }
+    sum_operands(s, e, f, g, h);
     mul1(e, f, u);
-    sink.unit(first_unit + 3, u);
-    for (int i = 0; i < 16; i++) out.x[i] = u.c[i];
+    store(s.sx3);
     mul1(g, h, u);
-    sink.unit(first_unit + 4, u);
-    for (int i = 0; i < 16; i++) out.y[i] = u.c[i];
-    int nxt = first_unit + 5;
-    if (want_t) {
-        mul1(e, h, u);
-        sink.unit(nxt++, u);
-        for (int i = 0; i < 16; i++) t_out[i] = u.c[i];
-    }
+    store(s.sy3);
     mul1(f, g, u);
-    sink.unit(nxt, u);
-    for (int i = 0; i < 16; i++) out.z[i] = u.c[i];
+    store(s.sz3);
+    mul1(e, h, u);
+    store(s.st3);
+    const_limbs(K_D2, k);
+    vcopy(s.st3, a);
+    mul1(k, a, u);
+    store(s.spt);
 }
 
-// One row: in -> 2 in + sbit B + hbit (-A).
+// the row's addend (y - x, y + x, 2dt, 2z): neutral, B, -A or B - A by the two bits (signed limbs)
+FP_HD inline void addend(const Slot& s, int sbit, int hbit, limbs_t ymx, limbs_t ypx, limbs_t t2d, limbs_t z2) {
+    for (int i = 0; i < 16; i++) {
+        const int32_t one = i == 0, two = i == 0 ? 2 : 0;
+        if (sbit && hbit) {
+            ymx[i] = (int32_t)s.sy3[i] - (int32_t)s.sx3[i];
+            ypx[i] = (int32_t)s.sy3[i] + (int32_t)s.sx3[i];
+            t2d[i] = (int32_t)s.spt[i];
+            z2[i] = 2 * (int32_t)s.sz3[i];
+        } else if (hbit) {  // -A = (-x, y)
+            ymx[i] = (int32_t)s.ay[i] + (int32_t)s.ax[i];
+            ypx[i] = (int32_t)s.ay[i] - (int32_t)s.ax[i];
+            t2d[i] = -(int32_t)s.nt[i];
+            z2[i] = two;
+        } else if (sbit) {
+            ymx[i] = K_LIMBS[K_B_YMX][i];
+            ypx[i] = K_LIMBS[K_B_YPX][i];
+            t2d[i] = K_LIMBS[K_B_T2D][i];
+            z2[i] = two;
+        } else {
+            ymx[i] = ypx[i] = one;
+            t2d[i] = 0;
+            z2[i] = two;
+        }
+    }
+}
+
+// One row: in -> 2 in + (0 | B | -A | B - A).  Sink::unit(index, Unit) receives the fifteen units in column order.
 template <class Sink>
 FP_HD inline void row_main(Sink& sink, const Point& in, int sbit, int hbit, const Slot& s, Point& out) {
     fp::Unit a_, b_, zz, e1, u;
@@ -137,39 +165,49 @@ FP_HD inline void row_main(Sink& sink, const Point& in, int sbit, int hbit, cons
         f[i] = g[i] - 2 * (int32_t)zz.c[i];
         h[i] = -(av + bv);
     }
-    Point p2, p3;
-    uint32_t t2[16], t3[16];
+    uint32_t x2[16], y2[16], t2[16], z2[16];
     mul1(e, f, u);
     sink.unit(U_X2, u);
-    for (int i = 0; i < 16; i++) p2.x[i] = u.c[i];
+    for (int i = 0; i < 16; i++) x2[i] = u.c[i];
     mul1(g, h, u);
     sink.unit(U_Y2, u);
-    for (int i = 0; i < 16; i++) p2.y[i] = u.c[i];
+    for (int i = 0; i < 16; i++) y2[i] = u.c[i];
     mul1(e, h, u);
     sink.unit(U_T2, u);
     for (int i = 0; i < 16; i++) t2[i] = u.c[i];
     mul1(f, g, u);
     sink.unit(U_Z2, u);
-    for (int i = 0; i < 16; i++) p2.z[i] = u.c[i];
-    limbs_t ymx, ypx, t2d;
-    if (sbit) {
-        const_limbs(K_B_YMX, ymx);
-        const_limbs(K_B_YPX, ypx);
-        const_limbs(K_B_T2D, t2d);
-    } else {
-        for (int i = 0; i < 16; i++) { ymx[i] = ypx[i] = i == 0; t2d[i] = 0; }
+    for (int i = 0; i < 16; i++) z2[i] = u.c[i];
+    limbs_t ymx, ypx, t2d, pz2;
+    addend(s, sbit, hbit, ymx, ypx, t2d, pz2);
+    fp::Unit pa, pb, pc, pd;
+    vsub(y2, x2, l0);
+    mul1(l0, ymx, pa);
+    sink.unit(U_PA, pa);
+    vadd(y2, x2, l0);
+    mul1(l0, ypx, pb);
+    sink.unit(U_PB, pb);
+    vcopy(t2, l0);
+    mul1(l0, t2d, pc);
+    sink.unit(U_PC, pc);
+    vcopy(z2, l0);
+    mul1(l0, pz2, pd);
+    sink.unit(U_PD, pd);
+    for (int i = 0; i < 16; i++) {
+        e[i] = (int32_t)pb.c[i] - (int32_t)pa.c[i];
+        f[i] = (int32_t)pd.c[i] - (int32_t)pc.c[i];
+        g[i] = (int32_t)pd.c[i] + (int32_t)pc.c[i];
+        h[i] = (int32_t)pb.c[i] + (int32_t)pa.c[i];
     }
-    madd(sink, U_BA, p2.x, p2.y, p2.z, t2, ymx, ypx, t2d, true, p3, t3);
-    if (hbit) {  // -A = (-x, y): (y + x, y - x, -2dxy)
-        for (int i = 0; i < 16; i++) {
-            ymx[i] = (int32_t)s.ay[i] + (int32_t)s.ax[i];
-            ypx[i] = (int32_t)s.ay[i] - (int32_t)s.ax[i];
-            t2d[i] = -(int32_t)s.nt[i];
-        }
-    } else {
-        for (int i = 0; i < 16; i++) { ymx[i] = ypx[i] = i == 0; t2d[i] = 0; }
-    }
-    madd(sink, U_AA, p3.x, p3.y, p3.z, t3, ymx, ypx, t2d, false, out, nullptr);
+    mul1(e, f, u);
+    sink.unit(U_X4, u);
+    for (int i = 0; i < 16; i++) out.x[i] = u.c[i];
+    mul1(g, h, u);
+    sink.unit(U_Y4, u);
+    for (int i = 0; i < 16; i++) out.y[i] = u.c[i];
+    mul1(f, g, u);
+    sink.unit(U_Z4, u);
+    for (int i = 0; i < 16; i++) out.z[i] = u.c[i];
 }
 
 // The auxiliary unit of row r (0..255) of a slot: operands (a, b, e, f) and the unit a b + e e - f f = c.
@@ -183,11 +221,14 @@ FP_HD inline bool row_aux(int r, const Slot& s, const Point& out, const uint32_t
     const uint32_t* fixed = nullptr;
     uint32_t cfix[16];
     fp::Unit t;
-    limbs_t l0, l1;
+    limbs_t l0, l1, se, sf, sg, sh;
     auto xy_of = [&](const uint32_t* px, const uint32_t* py, fp::Unit& o) {
         vcopy(px, l0);
         vcopy(py, l1);
         mul1(l0, l1, o);
+    };
+    auto set2 = [&](const limbs_t a, const limbs_t b) {
+        for (int i = 0; i < 16; i++) { x.a[i] = a[i]; x.b[i] = b[i]; }
     };
     switch (r) {
         case STEP_YCMP:
@@ -217,6 +258,14 @@ FP_HD inline bool row_aux(int r, const Slot& s, const Point& out, const uint32_t
             fixed = cfix;
             break;
         }
+        case STEP_S_AA: vadd(s.ay, s.ax, x.a); const_limbs(K_B_YMX, x.b); break;
+        case STEP_S_BB: vsub(s.ay, s.ax, x.a); const_limbs(K_B_YPX, x.b); break;
+        case STEP_S_CC: vcopy(s.nt, x.a); const_limbs(K_B_T, x.b); break;
+        case STEP_S_X: sum_operands(s, se, sf, sg, sh); set2(se, sf); break;
+        case STEP_S_Y: sum_operands(s, se, sf, sg, sh); set2(sg, sh); break;
+        case STEP_S_Z: sum_operands(s, se, sf, sg, sh); set2(sf, sg); break;
+        case STEP_S_T: sum_operands(s, se, sf, sg, sh); set2(se, sh); break;
+        case STEP_S_PT: const_limbs(K_D2, x.a); vcopy(s.st3, x.b); break;
         case STEP_XCMP:
             vcopy(s.rx, x.a);
             vcopy(out.z, x.b);
@@ -239,49 +288,53 @@ struct NoSink {
 
 // The same row on values only (fe25519_fast.hpp): what the sequential scan needs - the canonical point after the row.
 struct FastSlot {
-    fe::Fe a_ymx, a_ypx, a_t2d;  // the triple of -A: (y + x, y - x, -2dxy)
-    fe::Fe b_ymx, b_ypx, b_t2d;
+    fe::Fe ymx[4], ypx[4], t2d[4], z2[4];  // the addend for (s_bit + 2 h_bit)
 };
 FP_HD inline void fast_slot(const Slot& s, FastSlot& f) {
-    const fe::Fe x = fe::from_limbs16(s.ax), y = fe::from_limbs16(s.ay), nt = fe::from_limbs16(s.nt);
-    f.a_ymx = fe::add(y, x);
-    f.a_ypx = fe::sub(y, x);
-    f.a_t2d = fe::neg(nt);
-    uint32_t k[16];
-    for (int i = 0; i < 16; i++) k[i] = K_LIMBS[K_B_YMX][i];
-    f.b_ymx = fe::from_limbs16(k);
-    for (int i = 0; i < 16; i++) k[i] = K_LIMBS[K_B_YPX][i];
-    f.b_ypx = fe::from_limbs16(k);
-    for (int i = 0; i < 16; i++) k[i] = K_LIMBS[K_B_T2D][i];
-    f.b_t2d = fe::from_limbs16(k);
+    for (int sel = 0; sel < 4; sel++) {
+        limbs_t ymx, ypx, t2d, z2;
+        addend(s, sel & 1, sel >> 1, ymx, ypx, t2d, z2);
+        for (int v = 0; v < 4; v++) {
+            const int32_t* src = v == 0 ? ymx : (v == 1 ? ypx : (v == 2 ? t2d : z2));
+            // signed limbs -> a non-negative representative: add p limb-wise where needed is not necessary, fe::Fe limbs
+            // are signed; regroup 16-bit signed limbs into 26-bit signed limbs through the value's two's-complement-free sum
+            fe::Fe r;
+            for (int i = 0; i < 10; i++) r.l[i] = 0;
+            for (int i = 0; i < 16; i++) {
+                // limb i sits at bit 16 i = 26 q + o
+                const int q = (16 * i) / 26, o = (16 * i) % 26;
+                r.l[q] += (int64_t)src[i] * ((int64_t)1 << o);
+            }
+            fe::carry10(r.l);
+            (v == 0 ? f.ymx : (v == 1 ? f.ypx : (v == 2 ? f.t2d : f.z2)))[sel] = r;
+        }
+    }
 }
 struct FastPoint { fe::Fe x, y, z; };
-FP_HD inline void fast_madd(fe::Fe& x, fe::Fe& y, fe::Fe& z, fe::Fe& t, bool bit, const fe::Fe& ymx, const fe::Fe& ypx, const fe::Fe& t2d,
-                            bool want_t) {
-    // a zero bit adds the neutral triple (1, 1, 0): A = y - x, B = y + x, C = 0
-    const fe::Fe ymx_in = fe::sub(y, x), ypx_in = fe::add(y, x);
-    const fe::Fe aa = bit ? fe::mul(ymx_in, ymx) : ymx_in, bb = bit ? fe::mul(ypx_in, ypx) : ypx_in;
-    fe::Fe cc;
-    if (bit) cc = fe::mul(t, t2d);
-    else for (int i = 0; i < 10; i++) cc.l[i] = 0;
-    const fe::Fe dd = fe::dbl(z);
-    const fe::Fe e = fe::sub(bb, aa), f = fe::sub(dd, cc), g = fe::add(dd, cc), h = fe::add(bb, aa);
-    x = fe::mul(e, f);
-    y = fe::mul(g, h);
-    if (want_t) t = fe::mul(e, h);
-    z = fe::mul(f, g);
-}
 FP_HD inline void fast_row(FastPoint& q, bool sbit, bool hbit, const FastSlot& s) {
     const fe::Fe a = fe::mul(q.x, q.x), b = fe::mul(q.y, q.y), zz = fe::mul(q.z, q.z);
     const fe::Fe xy = fe::add(q.x, q.y);
     const fe::Fe e1 = fe::mul(xy, xy);
     const fe::Fe e = fe::sub(fe::sub(e1, a), b), g = fe::sub(b, a), f = fe::sub(g, fe::dbl(zz)), h = fe::neg(fe::add(a, b));
-    fe::Fe x = fe::mul(e, f), y = fe::mul(g, h), t = fe::mul(e, h), z = fe::mul(f, g);
-    fast_madd(x, y, z, t, sbit, s.b_ymx, s.b_ypx, s.b_t2d, true);
-    fast_madd(x, y, z, t, hbit, s.a_ymx, s.a_ypx, s.a_t2d, false);
-    q.x = x;
-    q.y = y;
-    q.z = z;
+    const fe::Fe x2 = fe::mul(e, f), y2 = fe::mul(g, h), t2 = fe::mul(e, h), z2 = fe::mul(f, g);
+    const int sel = (sbit ? 1 : 0) + (hbit ? 2 : 0);
+    const fe::Fe ymx_in = fe::sub(y2, x2), ypx_in = fe::add(y2, x2);
+    fe::Fe pa, pb, pc, pd;
+    if (sel == 0) {  // the neutral addend (1, 1, 0, 2)
+        pa = ymx_in;
+        pb = ypx_in;
+        for (int i = 0; i < 10; i++) pc.l[i] = 0;
+        pd = fe::dbl(z2);
+    } else {
+        pa = fe::mul(ymx_in, s.ymx[sel]);
+        pb = fe::mul(ypx_in, s.ypx[sel]);
+        pc = fe::mul(t2, s.t2d[sel]);
+        pd = fe::mul(z2, s.z2[sel]);
+    }
+    const fe::Fe e_ = fe::sub(pb, pa), f_ = fe::sub(pd, pc), g_ = fe::add(pd, pc), h_ = fe::add(pb, pa);
+    q.x = fe::mul(e_, f_);
+    q.y = fe::mul(g_, h_);
+    q.z = fe::mul(f_, g_);
 }
 FP_HD inline void fast_store(const FastPoint& q, Point& p) {
     fe::freeze(q.x, p.x);
@@ -289,9 +342,9 @@ FP_HD inline void fast_store(const FastPoint& q, Point& p) {
     fe::freeze(q.z, p.z);
 }
 
-// All round-0 cells of row r of a slot (multiplicity column zero) through put(column, value).  `in` is the row's input
-// point; the row's result is returned in `out`.  Returns false if the row's auxiliary check (curve equation of A or R,
-// final comparison) is not satisfied by the slot's data - the signature does not verify.
+// All round-0 cells of row r of a slot (multiplicity columns zero) through put(column, value).  `in` is the row's
+// input point; the row's result is returned in `out`.  Returns false if the row's auxiliary check (curve equation of
+// A or R, final comparison) is not satisfied by the slot's data - the signature does not verify.
 template <class Put>
 struct EmitSink {
     Put& put;
@@ -322,6 +375,13 @@ FP_HD inline bool emit_row(int r, const Slot& s, const Point& in, const uint32_t
         put(cNT + i, s.nt[i]);
         put(cSW + i, s.sw[i]);
         put(cHW + i, s.hw[i]);
+        put(cSAA + i, s.saa[i]);
+        put(cSBB + i, s.sbb[i]);
+        put(cSCC + i, s.scc[i]);
+        put(cSX3 + i, s.sx3[i]);
+        put(cSY3 + i, s.sy3[i]);
+        put(cSZ3 + i, s.sz3[i]);
+        put(cSPT + i, s.spt[i]);
     }
     {
         // the row that closes block j carries limb j of A and R through the looked-up cells (their range check)
@@ -331,6 +391,16 @@ FP_HD inline bool emit_row(int r, const Slot& s, const Point& in, const uint32_t
         put(cCHK + 1, close ? s.ay[j] : 0u);
         put(cCHK + 2, close ? s.rx[j] : 0u);
         put(cCHK + 3, close ? s.ry[j] : 0u);
+    }
+    {
+        limbs_t ymx, ypx, t2d, z2;
+        addend(s, sbit, hbit, ymx, ypx, t2d, z2);
+        for (int i = 0; i < 16; i++) {
+            put(cP2 + i, gl_signed(ymx[i]));
+            put(cP2 + 16 + i, gl_signed(ypx[i]));
+            put(cP2 + 32 + i, gl_signed(t2d[i]));
+            put(cP2 + 48 + i, gl_signed(z2[i]));
+        }
     }
     EmitSink<Put> sink{put};
     row_main(sink, in, sbit, hbit, s, out);

@@ -4,8 +4,8 @@
 //   k_ed_scan  one lane per slot walks its 256 rows (the point after each row depends on the one before) and
 //              records the input point of every row - the only sequential part, on values only (fe25519_fast.hpp:
 //              26-bit limbs, no witness cells; canonical results, so identical to what the row emitter recomputes);
-//   k_ed_rows  one lane per row recomputes its 22 units from that input point (results are canonical, so the
-//              recomputation is bit-identical) and writes its 1 945 cells; a wave's 64 lanes are 64 consecutive rows,
+//   k_ed_rows  one lane per row recomputes its 16 units from that input point (results are canonical, so the
+//              recomputation is bit-identical) and writes its 1 418 cells; a wave's 64 lanes are 64 consecutive rows,
 //              so every column store is 512 contiguous bytes.
 #include "ctx.hpp"
 #include "ed25519_rows.hpp"

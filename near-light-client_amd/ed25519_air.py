@@ -6,18 +6,19 @@ checks, the multi-round prover).
 Statement per signature slot (256 consecutive rows):  [S] B + [h] (-A) = R  on the twisted Edwards curve
 -x^2 + y^2 = 1 + d x^2 y^2 over F_p, p = 2^255 - 19, for the slot's A = (AX, AY), R = (RX, RY) (affine, 16-bit limbs),
 S and h (16 limbs each; h is the SHA-512 digest already reduced mod L - sha512_air.py proves the digest itself), with
-A and R checked to be on the curve.  Row r of a slot handles bit 255 - r of both scalars:
+A and R checked to be on the curve.  Row r of a slot handles bit 255 - r of both scalars (Shamir's trick):
 
-    Q <- 2 Q                  8 units   (dbl-2008-hwcd, a = -1)
-    Q <- Q + s_bit * B        7 units   (madd-2008-hwcd-3 with the precomputed affine triple (y-x, y+x, 2dxy); a zero bit
-    Q <- Q + h_bit * (-A)     6 units    adds the neutral triple (1, 1, 0); the last T is not needed)
+    Q <- 2 Q                                      8 units   (dbl-2008-hwcd, a = -1)
+    Q <- Q + (0 | B | -A | B - A)                 7 units   (add-2008-hwcd-3 with the addend in the precomputed form
+                                                             (y-x, y+x, 2dt, 2z), selected by the two bits into
+                                                             64 operand cells; the result's T is not needed)
 
-21 multiplication units per row plus one auxiliary unit that runs a small per-slot program in otherwise idle rows:
-2d*x*y of A (the addend's third coordinate), the curve equation of A and of R, and the final comparison
-RX * Z = X, RY * Z = Y.  Everything a unit reads is either a range-checked cell, a constant, or a cell tied by a
-degree <= 3 constraint to one of those; all unit results, quotients and carries (and, once per slot, the limbs of A and R) go through
-the 2^16-table lookup (the carries' high parts through a 2^9 table).  Constraint degree 3, two commitment rounds
-(the second is logup.py's columns for the two tables).
+15 multiplication units per row plus one auxiliary unit that runs a per-slot program in otherwise idle rows:
+2d*x*y of A, the point B - A (one addition, its intermediate and final values kept in per-slot columns), the curve
+equation of A and of R, and the final comparison RX * Z = X, RY * Z = Y.  Everything a unit reads is either a
+range-checked cell, a constant, or a cell tied by a degree <= 3 constraint to one of those; all unit results, quotients
+and carries (and, once per slot, the limbs of A and R) go through the 2^16-table lookup (the carries' high parts through
+a 2^9 table).  Constraint degree 3, two commitment rounds (the second is logup.py's columns for the two tables).
 
 Scope of this version: the slot's (A, R, S, h) are witness columns constant over the slot - binding them to data
 outside the proof (curta does that with its bus; here it would be one more running accumulator over a challenge) and
@@ -51,7 +52,6 @@ def _recover_x(y, sign):
 
 BX = _recover_x(BY, 0)
 ROWS = 256                       # rows per signature slot
-N_MAIN = 21
 UNIT = fp.UNIT_CELLS             # 63 range-checked cells per unit
 
 
@@ -84,6 +84,10 @@ SB, HB, SA, HA = (LAY.take(1) for _ in range(4))  # scalar bits and their 16-bit
 AX, AY, RX, RY = (LAY.take(16) for _ in range(4))
 NT, SW, HW = (LAY.take(16) for _ in range(3))     # 2d x y of A; limbs of S and h
 CHK = LAY.take(4, True)                          # on the last row of limb j's block: limb j of AX, AY, RX, RY (range check)
+# B - A: the three products of its addition, then its X, Y, Z and 2d T (per-slot columns tied to auxiliary results)
+SAA, SBB, SCC, SX3, SY3, SZ3, SPT = (LAY.take(16) for _ in range(7))
+P2 = LAY.take(64)                                # the row's addend (y-x, y+x, 2dt, 2z), selected by the two bits
+N_MAIN = 15
 MAIN = [LAY.take_unit() for _ in range(N_MAIN)]
 AUX_A, AUX_B, AUX_E, AUX_F = (LAY.take(16) for _ in range(4))
 AUX = LAY.take_unit()
@@ -93,10 +97,10 @@ LOOKUPS, LOOKUPS9 = list(LAY.lookups16), list(LAY.lookups9)
 N_COLS1A, N_COLS1B = logup.round_cols(len(LOOKUPS)), logup.round_cols(len(LOOKUPS9))
 N_COLS1 = N_COLS1A + N_COLS1B
 # main unit indices
-(U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2,
- U_BA, U_BB, U_BC, U_X3, U_Y3, U_T3, U_Z3,
- U_AA, U_AB, U_AC, U_X4, U_Y4, U_Z4) = range(N_MAIN)
-AUX_STEPS = {"ycmp": 0, "a_u": 1, "a_nt": 2, "a_u2": 3, "a_v": 4, "a_chk": 5, "r_u": 6, "r_v": 7, "r_chk": 8, "xcmp": 255}
+(U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2, U_PA, U_PB, U_PC, U_PD, U_X4, U_Y4, U_Z4) = range(N_MAIN)
+AUX_STEPS = {"ycmp": 0, "a_u": 1, "a_nt": 2, "a_u2": 3, "a_v": 4, "a_chk": 5, "r_u": 6, "r_v": 7, "r_chk": 8,
+             "s_aa": 9, "s_bb": 10, "s_cc": 11, "s_x": 12, "s_y": 13, "s_z": 14, "s_t": 15, "s_pt": 16, "xcmp": 255}
+B_YMX, B_YPX, B_T2D, B_T = (BY - BX) % P, (BY + BX) % P, D2 * BX * BY % P, BX * BY % P
 
 
 class _Vec:
@@ -169,7 +173,7 @@ def ed25519_air(max_resident_leaves=None):
             cur = cur + block[j] * L(base + j)
         air.constraint(limb_end * (L(CHK + k) - cur))
     # ---- per-slot columns stay constant inside a slot ----
-    for base in (AX, AY, RX, RY, NT, SW, HW):
+    for base in (AX, AY, RX, RY, NT, SW, HW, SAA, SBB, SCC, SX3, SY3, SZ3, SPT):
         for i in range(16):
             air.constraint((1 - is_last) * (N(base + i) - L(base + i)))
 
@@ -189,36 +193,33 @@ def ed25519_air(max_resident_leaves=None):
     t2 = unit(MAIN[U_T2], [(e, h, 1)])
     z2 = unit(MAIN[U_Z2], [(f, g, 1)])
 
-    def madd(units, x, y, z, t, ymx, ypx, t2d, want_t):
-        aa = unit(MAIN[units[0]], [(y - x, ymx, 1)])
-        bb = unit(MAIN[units[1]], [(y + x, ypx, 1)])
-        cc = unit(MAIN[units[2]], [(t, t2d, 1)])
-        dd = z.scale(2)
-        e_, f_, g_, h_ = bb - aa, dd - cc, dd + cc, bb + aa
-        x3 = unit(MAIN[units[3]], [(e_, f_, 1)])
-        y3 = unit(MAIN[units[4]], [(g_, h_, 1)])
-        t3 = unit(MAIN[units[5]], [(e_, h_, 1)]) if want_t else None
-        z3 = unit(MAIN[units[6 if want_t else 5]], [(f_, g_, 1)])
-        return x3, y3, z3, t3
-
-    def select(bit, vec_limbs, neutral_first, bound):
-        """bit * v + (1 - bit) * neutral, neutral = (neutral_first, 0, .., 0)"""
-        out = []
-        for i, v in enumerate(vec_limbs):
-            n0 = neutral_first if i == 0 else 0
-            out.append(bit * (v - n0) + n0 if n0 else bit * v)
-        return _Vec(out, bound)
-
-    # ---- + s_bit * B (constants) ----
-    b_ymx, b_ypx, b_t2d = (BY - BX) % P, (BY + BX) % P, D2 * BX * BY % P
-    x3, y3, z3, t3 = madd((U_BA, U_BB, U_BC, U_X3, U_Y3, U_T3, U_Z3), x2, y2, z2, t2,
-                          select(sb, fp.to_limbs(b_ymx), 1, 1 << 16), select(sb, fp.to_limbs(b_ypx), 1, 1 << 16),
-                          select(sb, fp.to_limbs(b_t2d), 0, 1 << 16), True)
-    # ---- + h_bit * (-A): the triple of (-x, y) is (y + x, y - x, -2dxy) ----
+    # ---- the addend: 0, B, -A or B - A by the two bits, in the form (y - x, y + x, 2 d t, 2 z) ----
     ax, ay, nt = cells(AX), cells(AY), cells(NT)
-    x4, y4, z4, _ = madd((U_AA, U_AB, U_AC, U_X4, U_Y4, U_Z4), x3, y3, z3, t3,
-                         select(hb, (ay + ax).limbs, 1, 1 << 17), select(hb, (ay - ax).limbs, 1, 1 << 16),
-                         select(hb, nt.scale(-1).limbs, 0, 1 << 16), False)
+    sx3, sy3, sz3, spt = cells(SX3), cells(SY3), cells(SZ3), cells(SPT)
+    w_ = sb * hb
+    c_o, c_b, c_n = 1 - sb - hb + w_, sb - w_, hb - w_
+    forms = (  # (neutral, B, -A = (-x, y), B - A) for each of the four coordinates
+        (fp.to_limbs(1), fp.to_limbs(B_YMX), (ay + ax).limbs, (sy3 - sx3).limbs),
+        (fp.to_limbs(1), fp.to_limbs(B_YPX), (ay - ax).limbs, (sy3 + sx3).limbs),
+        (fp.to_limbs(0), fp.to_limbs(B_T2D), nt.scale(-1).limbs, spt.limbs),
+        (fp.to_limbs(2), fp.to_limbs(2), fp.to_limbs(2), sz3.scale(2).limbs))
+    for v, (o_l, b_l, n_l, s_l) in enumerate(forms):
+        for i in range(16):
+            sel = w_ * s_l[i] + c_n * n_l[i]
+            if b_l[i]:
+                sel = sel + c_b * b_l[i]
+            if o_l[i]:
+                sel = sel + c_o * o_l[i]
+            air.constraint(L(P2 + 16 * v + i) - sel)
+    p_ymx, p_ypx, p_t2d, p_z2 = (_Vec([L(P2 + 16 * v + i) for i in range(16)], 1 << 17) for v in range(4))
+    pa = unit(MAIN[U_PA], [(y2 - x2, p_ymx, 1)])
+    pb = unit(MAIN[U_PB], [(y2 + x2, p_ypx, 1)])
+    pc = unit(MAIN[U_PC], [(t2, p_t2d, 1)])
+    pd = unit(MAIN[U_PD], [(z2, p_z2, 1)])
+    e_, f_, g_, h_ = pb - pa, pd - pc, pd + pc, pb + pa
+    x4 = unit(MAIN[U_X4], [(e_, f_, 1)])
+    y4 = unit(MAIN[U_Y4], [(g_, h_, 1)])
+    z4 = unit(MAIN[U_Z4], [(f_, g_, 1)])
     # ---- the next row starts from this row's result, a new slot from the neutral element (0, 1, 1) ----
     for k, vec in enumerate((x4, y4, z4)):
         for i in range(16):
@@ -252,6 +253,23 @@ def ed25519_air(max_resident_leaves=None):
     tie(step["a_u"], nxt_b, uc)
     tie(step["a_nt"], ua, d2_l)
     tie(step["a_nt"], nt, uc)
+    # B - A = B + (-A) by the mixed addition with B's constants, -A = (-x, y, 1, -xy):
+    #   AA = (y + x) B_ymx, BB = (y - x) B_ypx, CC = -(2dxy)(x_B y_B) = -NT * T_B, D = 2; E = BB - AA, F = 2 - CC,
+    #   G = 2 + CC, H = BB + AA; X = E F, Y = G H, Z = F G, T = E H, and the addend's third coordinate 2d T
+    saa, sbb, scc = cells(SAA), cells(SBB), cells(SCC)
+    two = _Vec(fp.to_limbs(2), 2)
+    e_s, h_s = sbb - saa, sbb + saa
+    f_s, g_s = scc + two, two - scc                # SCC holds NT * T_B = -CC
+    for name, a_src, b_src, dst in (("s_aa", ay + ax, fp.to_limbs(B_YMX), saa), ("s_bb", ay - ax, fp.to_limbs(B_YPX), sbb),
+                                    ("s_cc", nt, fp.to_limbs(B_T), scc), ("s_x", e_s, f_s, sx3), ("s_y", g_s, h_s, sy3),
+                                    ("s_z", f_s, g_s, sz3), ("s_t", e_s, h_s, None)):
+        tie(step[name], ua, a_src)
+        tie(step[name], ub, b_src)
+        if dst is not None:
+            tie(step[name], dst, uc)
+    tie(step["s_t"], nxt_b, uc)                   # 2d T: the next row multiplies this row's result by 2d
+    tie(step["s_pt"], ua, d2_l)
+    tie(step["s_pt"], spt, uc)
     tie(step["xcmp"], ua, rx)                     # RX * Z = X on the slot's last row ...
     tie(step["xcmp"], ub, z4)
     tie(step["xcmp"], uc, x4)
@@ -283,8 +301,27 @@ def _vscale(a, k):
     return [x * k for x in a]
 
 
+def _canon_mul(a, b):
+    """canonical limbs of a * b for limb vectors (signed limbs allowed)"""
+    return fp.to_limbs(fp.from_limbs(a) * fp.from_limbs(b) % P)
+
+
+def slot_constants(ax, ay):
+    """The per-slot values the auxiliary program computes: 2dxy, and B - A with its intermediate products."""
+    axl, ayl = fp.to_limbs(ax), fp.to_limbs(ay)
+    nt = fp.to_limbs(D2 * ax * ay % P)
+    saa = _canon_mul(_vadd(ayl, axl), fp.to_limbs(B_YMX))
+    sbb = _canon_mul(_vsub(ayl, axl), fp.to_limbs(B_YPX))
+    scc = _canon_mul(nt, fp.to_limbs(B_T))
+    two = fp.to_limbs(2)
+    e_s, h_s, f_s, g_s = _vsub(sbb, saa), _vadd(sbb, saa), _vadd(scc, two), _vsub(two, scc)
+    sx3, sy3, sz3, st3 = _canon_mul(e_s, f_s), _canon_mul(g_s, h_s), _canon_mul(f_s, g_s), _canon_mul(e_s, h_s)
+    spt = _canon_mul(fp.to_limbs(D2), st3)
+    return dict(nt=nt, saa=saa, sbb=sbb, scc=scc, sx3=sx3, sy3=sy3, sz3=sz3, st3=st3, spt=spt, e=e_s, f=f_s, g=g_s, h=h_s)
+
+
 def reference_slot(ax, ay, rx, ry, s, h):
-    """The 256 round-0 rows of one slot (multiplicity column zero): (N_COLS0, 256) uint64 in the Goldilocks field.
+    """The 256 round-0 rows of one slot (multiplicity columns zero): (N_COLS0, 256) uint64 in the Goldilocks field.
     Raises AssertionError if the statement is false (a unit has no witness)."""
     gl = 0xFFFFFFFF00000001
     t = np.zeros((N_COLS0, ROWS), dtype=np.uint64)
@@ -298,11 +335,15 @@ def reference_slot(ax, ay, rx, ry, s, h):
         t[base:base + 16, row] = [v % gl for v in limbs]
 
     axl, ayl, rxl, ryl = (fp.to_limbs(v) for v in (ax, ay, rx, ry))
-    ntv = D2 * ax * ay % P
-    ntl = fp.to_limbs(ntv)
-    one = fp.to_limbs(1)
-    b_ymx, b_ypx, b_t2d = fp.to_limbs((BY - BX) % P), fp.to_limbs((BY + BX) % P), fp.to_limbs(D2 * BX * BY % P)
-    zero = [0] * 16
+    k = slot_constants(ax, ay)
+    one, two, zero = fp.to_limbs(1), fp.to_limbs(2), [0] * 16
+    addends = {  # (s_bit, h_bit) -> (y - x, y + x, 2 d t, 2 z)
+        (0, 0): (one, one, zero, two),
+        (1, 0): (fp.to_limbs(B_YMX), fp.to_limbs(B_YPX), fp.to_limbs(B_T2D), two),
+        (0, 1): (_vadd(ayl, axl), _vsub(ayl, axl), _vscale(k["nt"], -1), two),
+        (1, 1): (_vsub(k["sy3"], k["sx3"]), _vadd(k["sy3"], k["sx3"]), k["spt"], _vscale(k["sz3"], 2))}
+    carried = ((AX, axl), (AY, ayl), (RX, rxl), (RY, ryl), (NT, k["nt"]), (SW, fp.to_limbs(s)), (HW, fp.to_limbs(h)),
+               (SAA, k["saa"]), (SBB, k["sbb"]), (SCC, k["scc"]), (SX3, k["sx3"]), (SY3, k["sy3"]), (SZ3, k["sz3"]), (SPT, k["spt"]))
     q = (zero, one, one)                                   # X, Y, Z limbs
     sa = ha = 0
     aux_prev_c = None
@@ -312,7 +353,7 @@ def reference_slot(ax, ay, rx, ry, s, h):
         sa = (0 if r % 16 == 0 else 2 * sa) + sbit
         ha = (0 if r % 16 == 0 else 2 * ha) + hbit
         t[SB, r], t[HB, r], t[SA, r], t[HA, r] = sbit, hbit, sa, ha
-        for base, limbs in ((AX, axl), (AY, ayl), (RX, rxl), (RY, ryl), (NT, ntl), (SW, fp.to_limbs(s)), (HW, fp.to_limbs(h))):
+        for base, limbs in carried:
             put_vec(base, r, limbs)
         if r % 16 == 15:
             j = 15 - r // 16
@@ -334,44 +375,54 @@ def reference_slot(ax, ay, rx, ry, s, h):
         y2 = put_unit(MAIN[U_Y2], r, [(g, hh)])
         t2 = put_unit(MAIN[U_T2], r, [(e, hh)])
         z2 = put_unit(MAIN[U_Z2], r, [(f, g)])
-
-        def madd(units, x, y, z, tt, ymx, ypx, t2d, want_t):
-            aa = put_unit(MAIN[units[0]], r, [(_vsub(y, x), ymx)])
-            bb = put_unit(MAIN[units[1]], r, [(_vadd(y, x), ypx)])
-            cc = put_unit(MAIN[units[2]], r, [(tt, t2d)])
-            dd = _vscale(z, 2)
-            e_, f_, g_, h_ = _vsub(bb, aa), _vsub(dd, cc), _vadd(dd, cc), _vadd(bb, aa)
-            x3 = put_unit(MAIN[units[3]], r, [(e_, f_)])
-            y3 = put_unit(MAIN[units[4]], r, [(g_, h_)])
-            t3 = put_unit(MAIN[units[5]], r, [(e_, h_)]) if want_t else None
-            z3 = put_unit(MAIN[units[6 if want_t else 5]], r, [(f_, g_)])
-            return x3, y3, z3, t3
-
-        x3, y3, z3, t3 = madd((U_BA, U_BB, U_BC, U_X3, U_Y3, U_T3, U_Z3), x2, y2, z2, t2,
-                              b_ymx if sbit else one, b_ypx if sbit else one, b_t2d if sbit else zero, True)
-        x4, y4, z4, _ = madd((U_AA, U_AB, U_AC, U_X4, U_Y4, U_Z4), x3, y3, z3, t3,
-                             _vadd(ayl, axl) if hbit else one, _vsub(ayl, axl) if hbit else one,
-                             _vscale(ntl, -1) if hbit else zero, False)
+        p2 = addends[(sbit, hbit)]
+        for v in range(4):
+            put_vec(P2 + 16 * v, r, p2[v])
+        pa = put_unit(MAIN[U_PA], r, [(_vsub(y2, x2), p2[0])])
+        pb = put_unit(MAIN[U_PB], r, [(_vadd(y2, x2), p2[1])])
+        pc = put_unit(MAIN[U_PC], r, [(t2, p2[2])])
+        pd = put_unit(MAIN[U_PD], r, [(z2, p2[3])])
+        e_, f_, g_, h_ = _vsub(pb, pa), _vsub(pd, pc), _vadd(pd, pc), _vadd(pb, pa)
+        x4 = put_unit(MAIN[U_X4], r, [(e_, f_)])
+        y4 = put_unit(MAIN[U_Y4], r, [(g_, h_)])
+        z4 = put_unit(MAIN[U_Z4], r, [(f_, g_)])
         # auxiliary program
         ua = ub = ue = uf = zero
         c_fixed = None
-        if r == AUX_STEPS["a_u"] or r == AUX_STEPS["a_u2"]:
+        st = {v: n for n, v in AUX_STEPS.items()}.get(r)
+        if st in ("a_u", "a_u2"):
             ua, ub = axl, ayl
-        elif r == AUX_STEPS["a_nt"]:
+        elif st == "a_nt":
             ua, ub = fp.to_limbs(D2), aux_prev_c
-        elif r in (AUX_STEPS["a_v"], AUX_STEPS["r_v"]):
+        elif st in ("a_v", "r_v"):
             ua = ub = aux_prev_c
-        elif r == AUX_STEPS["a_chk"]:
+        elif st == "a_chk":
             ua, ub, ue, uf, c_fixed = fp.to_limbs(D), aux_prev_c, axl, ayl, P - 1
-        elif r == AUX_STEPS["r_u"]:
+        elif st == "r_u":
             ua, ub = rxl, ryl
-        elif r == AUX_STEPS["r_chk"]:
+        elif st == "r_chk":
             ua, ub, ue, uf, c_fixed = fp.to_limbs(D), aux_prev_c, rxl, ryl, P - 1
-        elif r == AUX_STEPS["xcmp"]:
+        elif st == "s_aa":
+            ua, ub = _vadd(ayl, axl), fp.to_limbs(B_YMX)
+        elif st == "s_bb":
+            ua, ub = _vsub(ayl, axl), fp.to_limbs(B_YPX)
+        elif st == "s_cc":
+            ua, ub = k["nt"], fp.to_limbs(B_T)
+        elif st == "s_x":
+            ua, ub = k["e"], k["f"]
+        elif st == "s_y":
+            ua, ub = k["g"], k["h"]
+        elif st == "s_z":
+            ua, ub = k["f"], k["g"]
+        elif st == "s_t":
+            ua, ub = k["e"], k["h"]
+        elif st == "s_pt":
+            ua, ub = fp.to_limbs(D2), aux_prev_c
+        elif st == "xcmp":
             ua, ub, c_fixed = rxl, z4, fp.from_limbs(x4)
         for base, limbs in ((AUX_A, ua), (AUX_B, ub), (AUX_E, ue), (AUX_F, uf)):
             put_vec(base, r, limbs)
-        if r != AUX_STEPS["ycmp"]:
+        if st != "ycmp":
             aux_prev_c = put_unit(AUX, r, [(ua, ub, 1), (ue, ue, 1), (uf, uf, -1)], c=c_fixed)
         q = (x4, y4, z4)
     return t, q

@@ -85,7 +85,7 @@ def test_every_constraint_vanishes_on_the_reference_trace(nlx, orc, tiled_case):
     E = nlx.ed25519_air
     slots, t0 = tiled_case
     air, _ = E.ed25519_air()
-    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 3018 and (len(E.LOOKUPS), len(E.LOOKUPS9)) == (1060, 330)
+    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 2438 and (len(E.LOOKUPS), len(E.LOOKUPS9)) == (772, 240)
     words = air.compile()
     alpha = (0x1234567890abcdef, 0x0fedcba987654321)
     full = np.concatenate([t0, oracle_round1(orc, E, t0, alpha)], axis=0)
@@ -107,7 +107,7 @@ def test_every_constraint_vanishes_on_the_reference_trace(nlx, orc, tiled_case):
     for i in list(range(0, 10)) + [15, 16, 17, 254, 255, 256, 257, 260, 511, 512, n - 1]:
         assert violations(i) == [], i
     # tampering with a cell breaks a constraint on that row or the one before it
-    for col, row in ((E.SB, 40), (E.SIN + 3, 100), (E.MAIN[E.U_X4] + 2, 77), (E.MAIN[E.U_Y2] + 20, 5), (E.AUX + 1, 255), (E.AX + 1, 300),
+    for col, row in ((E.SB, 40), (E.SIN + 3, 100), (E.MAIN[E.U_X4] + 2, 77), (E.MAIN[E.U_Y2] + 20, 5), (E.P2 + 17, 60), (E.SX3 + 1, 12), (E.SPT + 3, 16), (E.AUX + 1, 255), (E.AX + 1, 300),
                      (E.SW + 2, 9), (E.NT, 2), (E.AUX_E + 4, 30), (E.HA, 31)):
         assert violations(row, (col, row, 1)) or violations(row - 1, (col, row, 1)), (col, row)
 
