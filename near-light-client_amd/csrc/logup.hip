@@ -5,7 +5,7 @@
 // Witness side, all on the device: multiplicities of the looked-up cells (LDS histograms per block, then one
 // global add per non-zero bin), then for a challenge alpha the round-1 columns: one helper h = 1/(alpha+v1) + 1/(alpha+v2) per pair of
 // lookups, g = m/(alpha+t) and the running sum phi (a two-level additive scan).  One extension inversion per
-// looked-up cell (a base-field inversion of the norm): ~130 multiplications, nothing next to hashing the columns.
+// eight looked-up cells (Montgomery's trick over a lane's helpers; the inversion is a base-field inversion of the norm).
 #include "ctx.hpp"
 #include "gl.hpp"
 #include "transcript.hpp"
@@ -56,16 +56,47 @@ struct LogupParams {
     uint32_t log_n, n_lookups, table_bits, mult_col;
 };
 
-// one lane per (row, helper)
+// One lane per (row, group of HELPERS_PER_LANE helpers).  h = 1/d1 + 1/d2 = (d1 + d2) / (d1 d2), and the denominators
+// of a lane's helpers are inverted together (Montgomery's trick): one extension inversion - a base-field inversion
+// of the norm, ~75 multiplications - per eight lookups instead of one per lookup.
+constexpr uint32_t HELPERS_PER_LANE = 4;
+
 __global__ __launch_bounds__(256) void k_logup_helpers(LogupParams p) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> p.log_n) return;
-    const uint32_t j = blockIdx.y;
+    const uint32_t H = (p.n_lookups + 1) / 2, j0 = blockIdx.y * HELPERS_PER_LANE;
     const gl::Ext al{p.alpha[0], p.alpha[1]};
-    gl::Ext h = gl::inv(gl::add(al, gl::ext(p.trace[((size_t)p.cols[2 * j] << p.log_n) + i])));
-    if (2 * j + 1 < p.n_lookups) h = gl::add(h, gl::inv(gl::add(al, gl::ext(p.trace[((size_t)p.cols[2 * j + 1] << p.log_n) + i]))));
-    p.out[((size_t)(2 * j) << p.log_n) + i] = h.a;
-    p.out[((size_t)(2 * j + 1) << p.log_n) + i] = h.b;
+    gl::Ext num[HELPERS_PER_LANE], den[HELPERS_PER_LANE], pre[HELPERS_PER_LANE];
+    gl::Ext run{1, 0};
+#pragma unroll
+    for (uint32_t t = 0; t < HELPERS_PER_LANE; t++) {
+        const uint32_t j = j0 + t;
+        num[t] = gl::Ext{1, 0};
+        den[t] = gl::Ext{1, 0};
+        if (j < H) {
+            const gl::Ext d1 = gl::add(al, gl::ext(p.trace[((size_t)p.cols[2 * j] << p.log_n) + i]));
+            if (2 * j + 1 < p.n_lookups) {
+                const gl::Ext d2 = gl::add(al, gl::ext(p.trace[((size_t)p.cols[2 * j + 1] << p.log_n) + i]));
+                num[t] = gl::add(d1, d2);
+                den[t] = gl::mul(d1, d2);
+            } else {
+                den[t] = d1;
+            }
+        }
+        pre[t] = run;  // product of the denominators before t
+        run = gl::mul(run, den[t]);
+    }
+    gl::Ext inv = gl::inv(run);
+#pragma unroll
+    for (int t = HELPERS_PER_LANE - 1; t >= 0; t--) {
+        const uint32_t j = j0 + t;
+        const gl::Ext h = gl::mul(num[t], gl::mul(inv, pre[t]));  // num / den
+        inv = gl::mul(inv, den[t]);
+        if (j < H) {
+            p.out[((size_t)(2 * j) << p.log_n) + i] = h.a;
+            p.out[((size_t)(2 * j + 1) << p.log_n) + i] = h.b;
+        }
+    }
 }
 
 // one lane per row: g = m / (alpha + t), and the row's contribution sum h - g into the phi columns (scanned next)
@@ -237,7 +268,7 @@ extern "C" int32_t nlx_logup_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t
         p.alpha[0] = alpha[0] % gl::P; p.alpha[1] = alpha[1] % gl::P;
         p.log_n = log_n; p.n_lookups = n_lookups; p.table_bits = table_bits; p.mult_col = mult_col;
         const unsigned blocks = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(k_logup_helpers, dim3(blocks, H), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(k_logup_helpers, dim3(blocks, (H + HELPERS_PER_LANE - 1) / HELPERS_PER_LANE), dim3(256), 0, st, p);
         hipLaunchKernelGGL(k_logup_rowsum, dim3(blocks), dim3(256), 0, st, p);
         launch_add_scan(st, p.out + (size_t)(2 * H + 2) * n, n, n, 2, d_scratch);
         rc = so.finish();
