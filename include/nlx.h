@@ -391,6 +391,14 @@ typedef struct {
     uint32_t round_cols[3];
     uint32_t round_challenges[3];
     uint32_t reserved;
+    /* Round values: round_values[r] (<= 64) field elements the prover sends with round r - totals of bus / accumulator
+     * columns that depend on earlier challenges.  They enter the transcript after the round's cap and before its
+     * challenges are drawn, travel after the public inputs at the end of the proof, and the program reads them as
+     * NLX_AIR_PUBLIC: the values array is  public inputs | values of round 0 | challenges of round 0 | values of round 1 |
+     * challenges of round 1 | ...  The proof only shows that the constraints hold for the values it carries; whoever
+     * relies on the proof compares them with what they should be (e.g. the fingerprint of the claimed data). */
+    uint32_t round_values[3];
+    uint32_t reserved2;
 } nlx_stark_desc;
 typedef struct nlx_stark nlx_stark;
 
@@ -402,11 +410,12 @@ size_t nlx_stark_proof_max_bytes(const nlx_stark* s);
  * trace: n_cols x n column-major (host or device), every value canonical. */
 int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* public_inputs, uint8_t* proof_out,
                         size_t proof_cap, size_t* proof_len);
-/* Multi-round proving: round_fn(user, r, challenges, n) returns round r's columns (round_cols[r] x n, column-major,
- * host or device pointer, valid until the next callback or the end of the call) given the challenges drawn after the
- * earlier rounds.  Proof bytes: one cap per round, the quotient cap, local / next values of every column in round
- * order, quotient values, FriProof (one oracle per round + the quotient oracle), public inputs. */
-typedef const uint64_t* (*nlx_round_fn)(void* user, uint32_t round, const uint64_t* challenges, uint32_t n_challenges);
+/* Multi-round proving: round_fn(user, r, known, n_known, values_out) returns round r's columns (round_cols[r] x n,
+ * column-major, host or device pointer, valid until the next callback or the end of the call) given `known` - the
+ * round values and challenges of the earlier rounds, in values-array order - and writes the round's round_values[r]
+ * values to values_out (NULL when the round sends none).  Proof bytes: one cap per round, the quotient cap, local / next values of every column in round
+ * order, quotient values, FriProof (one oracle per round + the quotient oracle), public inputs, round values. */
+typedef const uint64_t* (*nlx_round_fn)(void* user, uint32_t round, const uint64_t* known, uint32_t n_known, uint64_t* values_out);
 int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, const uint64_t* public_inputs,
                                uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
 int32_t nlx_stark_stage_times(const nlx_stark* s, uint32_t* n_stages, const char** names_out, float* ms_out);

@@ -264,7 +264,8 @@ struct nlx_stark {
     nlx_stark_desc d{};
     std::vector<uint64_t> program;  // canonicalised copy
     uint32_t qdb = 0, nq = 0, n_regs = 0, n_fri_rounds = 0;
-    uint32_t n_rounds = 1, round_cols[3] = {0, 0, 0}, round_challenges[3] = {0, 0, 0}, n_round_challenges = 0;
+    uint32_t n_rounds = 1, round_cols[3] = {0, 0, 0}, round_challenges[3] = {0, 0, 0}, round_values[3] = {0, 0, 0},
+             n_round_challenges = 0;  // n_round_challenges: round values + challenges, i.e. the values array minus public inputs
     uint64_t* d_program = nullptr;
     std::vector<uint32_t> seg;        // {first word, end word} per program segment
     std::vector<uint32_t> seg_after;  // constraints emitted after each segment
@@ -290,6 +291,7 @@ static size_t stark_proof_max_bytes(const nlx_stark_desc& d, uint32_t n_rounds) 
     size_t per_query = (size_t)(d.n_cols + nq) * 8 + n_oracles * (1 + 32 * (size_t)log_L) +
                        n_rounds * (((size_t)16 << d.fri_arity_bits) + 1 + 32 * (size_t)log_L);
     bytes += per_query * d.fri_num_queries + ((size_t)16 << d.degree_bits) + 8 + 4 + 8 * (size_t)d.num_public_inputs;
+    for (uint32_t r = 0; r < d.n_rounds && r < 3; r++) bytes += 8 * (size_t)d.round_values[r];
     return bytes + 64;
 }
 
@@ -319,9 +321,10 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
     if (d.n_rounds) {
         uint32_t tot = 0;
         for (uint32_t r = 0; r < d.n_rounds; r++) {
-            if (d.round_cols[r] == 0 || d.round_challenges[r] > 16) return ctx->fail(NLX_E_RANGE, "round %u: columns / challenges out of range", r);
+            if (d.round_cols[r] == 0 || d.round_challenges[r] > 16 || d.round_values[r] > 64)
+                return ctx->fail(NLX_E_RANGE, "round %u: columns / challenges / values out of range", r);
             tot += d.round_cols[r];
-            n_round_challenges += d.round_challenges[r];
+            n_round_challenges += d.round_challenges[r] + d.round_values[r];  // everything after the public inputs
         }
         if (tot != d.n_cols) return ctx->fail(NLX_E_INVAL, "round_cols must add up to n_cols");
     }
@@ -426,6 +429,7 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
     for (uint32_t r = 0; r < s->n_rounds; r++) {
         s->round_cols[r] = d.n_rounds ? d.round_cols[r] : d.n_cols;
         s->round_challenges[r] = d.n_rounds ? d.round_challenges[r] : 0;
+        s->round_values[r] = d.n_rounds ? d.round_values[r] : 0;
     }
     s->n_round_challenges = n_round_challenges;
     s->nq = d.num_challenges * q;
@@ -575,6 +579,7 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
     std::vector<uint64_t> cap(capw);
     // values readable by NLX_AIR_PUBLIC: the public inputs, then the verifier challenges in the order drawn
     std::vector<uint64_t> values(public_inputs, public_inputs + d.num_public_inputs);
+    std::vector<uint64_t> round_vals;
     std::vector<const uint64_t*> h_cols(ncols);
 #define CHECK(x) do { rc = (x); if (rc) goto done; } while (0)
 #define HIPCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { rc = ctx->hip_fail(e__, #call); goto done; } } while (0)
@@ -585,14 +590,23 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
         stage("commit_trace");
         for (uint32_t r = 0; r < NRD; r++) {
             const uint32_t rcols = s->round_cols[r];
-            const uint64_t* tr_ptr = round_fn(user, r, values.data() + d.num_public_inputs, (uint32_t)(values.size() - d.num_public_inputs));
+            const uint32_t n_rv = s->round_values[r];
+            uint64_t rv[64];
+            const uint64_t* tr_ptr = round_fn(user, r, values.data() + d.num_public_inputs, (uint32_t)(values.size() - d.num_public_inputs),
+                                              n_rv ? rv : nullptr);
             if (!tr_ptr) { rc = ctx->fail(NLX_E_INVAL, "round %u: the round callback returned NULL", r); goto done; }
+            for (uint32_t k = 0; k < n_rv; k++) rv[k] %= gl::P;
             Staged tr(ctx, tr_ptr, (size_t)rcols * n * 8, true, false);
             CHECK(tr.status);
             CHECK(commit_build(ctx, tr.as<uint64_t>(), n, CommitInput::ValuesNatural, rcols, log_n, d.rate_bits, cap_h, &cr[r]));
             CHECK(fetch(ctx, cap.data(), cr[r]->cap, capw * 8));
             w.u64s(cap.data(), capw);
             ch.observe(cap.data(), capw);
+            if (n_rv) {  // the round's values: into the transcript before its challenges, into the proof's tail later
+                ch.observe(rv, n_rv);
+                values.insert(values.end(), rv, rv + n_rv);
+                round_vals.insert(round_vals.end(), rv, rv + n_rv);
+            }
             for (uint32_t k = 0; k < s->round_challenges[r]; k++) values.push_back(ch.challenge());
             for (uint32_t c = 0; c < rcols; c++) h_cols[col0[r] + c] = cr[r]->lde + (size_t)c * L;
             col0[r + 1] = col0[r] + rcols;
@@ -714,6 +728,7 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
         }
         w.u32(d.num_public_inputs);
         w.u64s(public_inputs, d.num_public_inputs);
+        w.u64s(round_vals.data(), round_vals.size());
         stage("end");
         s->n_stages--;
         s->timed = true;
@@ -737,7 +752,7 @@ done:
     return rc;
 }
 
-static const uint64_t* single_round_fn(void* user, uint32_t round, const uint64_t*, uint32_t) {
+static const uint64_t* single_round_fn(void* user, uint32_t round, const uint64_t*, uint32_t, uint64_t*) {
     return round == 0 ? (const uint64_t*)user : nullptr;
 }
 

@@ -39,7 +39,8 @@ class StarkDesc(ctypes.Structure):
         "n_words")] + [("program", ctypes.POINTER(ctypes.c_uint64)), ("n_periodic", ctypes.c_uint32),
                        ("period_bits", ctypes.c_uint32), ("periodic", ctypes.POINTER(ctypes.c_uint64)),
                        ("n_rounds", ctypes.c_uint32), ("round_cols", ctypes.c_uint32 * 3),
-                       ("round_challenges", ctypes.c_uint32 * 3), ("reserved", ctypes.c_uint32)]
+                       ("round_challenges", ctypes.c_uint32 * 3), ("reserved", ctypes.c_uint32),
+                       ("round_values", ctypes.c_uint32 * 3), ("reserved2", ctypes.c_uint32)]
 
 
 class StarkConfig:
@@ -128,13 +129,17 @@ class _Expr:
 class Air:
     """An AIR over `n_cols` trace columns and `num_public_inputs` public inputs."""
 
-    def __init__(self, n_cols, num_public_inputs=0, rounds=None):
+    def __init__(self, n_cols, num_public_inputs=0, rounds=None, round_values=None):
         """rounds: None for a classic single-round AIR, or [(columns, verifier_challenges), ...] - round r commits
         that many columns (column indices run through the rounds in order) and, once its Merkle cap is in the
         transcript, that many base-field challenges are drawn; `challenge(k)` reads them in the order drawn."""
         self.n_cols = n_cols
         self.num_public_inputs = num_public_inputs
         self.rounds = rounds
+        # round_values[r]: field elements the prover sends with round r (totals of accumulator columns); readable through
+        # round_value(r, i).  The values array is public inputs | values r0 | challenges r0 | values r1 | challenges r1 ..
+        self.round_values = list(round_values) if round_values is not None else ([0] * len(rounds) if rounds else [])
+        assert len(self.round_values) == (len(rounds) if rounds else 0) and all(0 <= v <= 64 for v in self.round_values)
         if rounds is not None:
             if not 1 <= len(rounds) <= 3 or sum(c for c, _ in rounds) != n_cols or any(c < 1 for c, _ in rounds):
                 raise ValueError("rounds must split the columns into 1..3 non-empty groups")
@@ -191,7 +196,24 @@ class Air:
     def challenge(self, k):
         """The k-th verifier challenge of a multi-round AIR (a constant for the constraint degree)."""
         assert self.rounds is not None and 0 <= k < sum(n for _, n in self.rounds)
-        return self._leaf(AIR_PUBLIC, self.num_public_inputs + k, 0)
+        return self._leaf(AIR_PUBLIC, self.num_public_inputs + self.challenge_offset(k), 0)
+
+    def challenge_offset(self, k):
+        """position of the k-th challenge among everything after the public inputs (round values come in between)"""
+        off = 0
+        for r, (_, n_ch) in enumerate(self.rounds):
+            off += self.round_values[r]
+            if k < n_ch:
+                return off + k
+            k -= n_ch
+            off += n_ch
+        raise IndexError(k)
+
+    def round_value(self, r, i):
+        """The i-th value the prover sends with round r (a constant for the constraint degree)."""
+        assert self.rounds is not None and 0 <= r < len(self.rounds) and 0 <= i < self.round_values[r]
+        off = sum(self.round_values[q] + self.rounds[q][1] for q in range(r))
+        return self._leaf(AIR_PUBLIC, self.num_public_inputs + off + i, 0)
 
     def const(self, v):
         return self._leaf(AIR_CONST, int(v) % P, 0)
@@ -233,7 +255,10 @@ class Air:
         extension (logup.py), as ONE VM instruction: v1, v2 (None: a single-lookup helper) and (h, h + 1) are local
         columns, alpha = challenge(k) + challenge(k + 1) X.  Same constraint values as writing them out with the
         DSL, a thirtieth of the program words."""
-        assert self.rounds is not None and 0 <= challenge and challenge + 1 < sum(n for _, n in self.rounds) and challenge < 63
+        assert self.rounds is not None and 0 <= challenge and challenge + 1 < sum(n for _, n in self.rounds)
+        assert self.challenge_offset(challenge + 1) == self.challenge_offset(challenge) + 1   # drawn in the same round
+        challenge = self.challenge_offset(challenge)       # the instruction indexes the values array after the public inputs
+        assert challenge < 63
         for c in (v1_col, h_col, h_col + 1) + (() if v2_col is None else (v2_col,)):
             assert 0 <= c < self.n_cols
         self._emits.append((AIR_EMIT_LOGUP, (v1_col, 0xFFFF if v2_col is None else v2_col, h_col, challenge), 2))
@@ -512,13 +537,15 @@ class Stark:
             for r, (c, k) in enumerate(air.rounds):
                 self.desc.round_cols[r] = c
                 self.desc.round_challenges[r] = k
+                self.desc.round_values[r] = air.round_values[r]
         self.degree_bits = degree_bits
 
     def build(self, ctx):
         return StarkProver(ctx, self)
 
 
-_ROUND_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32)
+_ROUND_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32,
+                             ctypes.POINTER(ctypes.c_uint64))
 
 
 class StarkProver:
@@ -548,18 +575,26 @@ class StarkProver:
         return self._buf[:ln.value].tobytes()
 
     def prove_rounds(self, round_fn, public_inputs=()):
-        """Multi-round proving (nlx_stark_prove_rounds).  round_fn(round, challenges: list[int]) returns round r's
-        columns - a (round_cols[r], n) uint64 host array or a device tensor - computed from the challenges drawn
-        after the earlier rounds."""
+        """Multi-round proving (nlx_stark_prove_rounds).  round_fn(round, known: list[int]) returns round r's
+        columns - a (round_cols[r], n) uint64 host array or a device tensor - computed from `known`, everything after
+        the public inputs in the values array so far (round values and challenges of the earlier rounds); a round
+        with round values returns (columns, values)."""
         pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         if pis.size != self.stark.air.num_public_inputs:
             raise ValueError("expected %d public inputs" % self.stark.air.num_public_inputs)
         desc = self.stark.desc
         keep, errors = [], []
 
-        def cb(_user, rnd, ch_ptr, n_ch):
+        def cb(_user, rnd, ch_ptr, n_ch, values_out):
             try:
                 arr = round_fn(rnd, [int(ch_ptr[i]) for i in range(n_ch)])
+                n_rv = desc.round_values[rnd] if desc.n_rounds else 0
+                if n_rv:                      # a round with values returns (columns, values)
+                    arr, vals = arr
+                    if len(vals) != n_rv:
+                        raise ValueError("round %d: expected %d round values" % (rnd, n_rv))
+                    for i, v in enumerate(vals):
+                        values_out[i] = int(v) % P
                 want = (desc.round_cols[rnd] if desc.n_rounds else desc.n_cols, 1 << desc.degree_bits)
                 if tuple(arr.shape) != want:
                     raise ValueError("round %d: expected columns of shape %r" % (rnd, want))

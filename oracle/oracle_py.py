@@ -276,12 +276,14 @@ def stark_verify(desc, proof):
     return int(d.orc_stark_verify(ctypes.addressof(desc), buf.ctypes.data, buf.size))
 
 
-ROUND_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32)
+ROUND_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32,
+                            ctypes.POINTER(ctypes.c_uint64))
 
 
 def stark_prove_rounds(desc, round_fn, public_inputs):
-    """Multi-round STARK (orc_stark_prove_rounds).  round_fn(round, challenges: list[int]) -> (round_cols, n) uint64
-    array: round r's columns, computed from the challenges drawn after the earlier rounds."""
+    """Multi-round STARK (orc_stark_prove_rounds).  round_fn(round, known: list[int]) -> (round_cols, n) uint64
+    array: round r's columns, computed from the round values and challenges of the earlier rounds; a round that has
+    round values returns (columns, values)."""
     d = _stark_sigs()
     d.orc_stark_prove_rounds.restype = ctypes.c_size_t
     d.orc_stark_prove_rounds.argtypes = [ctypes.c_void_p, ROUND_FN, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -289,9 +291,16 @@ def stark_prove_rounds(desc, round_fn, public_inputs):
     pis = _u64(public_inputs)
     keep = []
 
-    def cb(_user, rnd, ch_ptr, n_ch):
+    def cb(_user, rnd, ch_ptr, n_ch, values_out):
         chal = [int(ch_ptr[i]) for i in range(n_ch)]
-        arr = _u64(round_fn(rnd, chal))
+        res = round_fn(rnd, chal)
+        n_rv = desc.round_values[rnd] if desc.n_rounds else 0
+        if n_rv:                              # a round with round values returns (columns, values)
+            res, vals = res
+            assert len(vals) == n_rv
+            for i, v in enumerate(vals):
+                values_out[i] = int(v) % P
+        arr = _u64(res)
         assert arr.shape == (desc.round_cols[rnd] if desc.n_rounds else desc.n_cols, 1 << desc.degree_bits)
         keep.append(arr)
         return arr.ctypes.data
@@ -302,6 +311,19 @@ def stark_prove_rounds(desc, round_fn, public_inputs):
     if n == 0:
         raise RuntimeError("orc_stark_prove_rounds failed (bad descriptor, callback or buffer overflow)")
     return out[:n].tobytes()
+
+
+def stark_values(desc, proof):
+    """orc_stark_values: [public inputs | round values and challenges, round by round] as the verifier derives them."""
+    d = dll()
+    d.orc_stark_values.restype = ctypes.c_uint32
+    d.orc_stark_values.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    buf = np.frombuffer(proof, dtype=np.uint8)
+    out = np.zeros(desc.num_public_inputs + 3 * (64 + 16) + 1, dtype=np.uint64)
+    n = d.orc_stark_values(ctypes.addressof(desc), buf.ctypes.data, buf.size, out.ctypes.data)
+    if n == 0 and desc.num_public_inputs:
+        raise ValueError("malformed proof")
+    return [int(v) for v in out[:n]]
 
 
 def logup_multiplicities(trace, cols, table_bits):

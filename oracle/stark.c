@@ -486,9 +486,15 @@ static uint64_t* periodic_coeffs(const orc_stark_desc* d) {
 /* rounds of commitment: classic starky = one round, no verifier challenges before the alphas */
 static uint32_t n_rounds_of(const orc_stark_desc* d) { return d->n_rounds ? d->n_rounds : 1; }
 static uint32_t round_cols_of(const orc_stark_desc* d, uint32_t r) { return d->n_rounds ? d->round_cols[r] : d->n_cols; }
+/* everything after the public inputs in the values array: round values and challenges of all rounds */
 static uint32_t total_round_challenges(const orc_stark_desc* d) {
     uint32_t t = 0;
-    for (uint32_t r = 0; r < d->n_rounds; r++) t += d->round_challenges[r];
+    for (uint32_t r = 0; r < d->n_rounds; r++) t += d->round_challenges[r] + d->round_values[r];
+    return t;
+}
+static uint32_t total_round_values(const orc_stark_desc* d) {
+    uint32_t t = 0;
+    for (uint32_t r = 0; r < d->n_rounds; r++) t += d->round_values[r];
     return t;
 }
 
@@ -502,7 +508,7 @@ static int desc_ok(const orc_stark_desc* d) {
     if (d->n_rounds) {
         uint32_t tot = 0;
         for (uint32_t r = 0; r < d->n_rounds; r++) {
-            if (!d->round_cols[r] || d->round_challenges[r] > 16) return 0;
+            if (!d->round_cols[r] || d->round_challenges[r] > 16 || d->round_values[r] > 64) return 0;
             tot += d->round_cols[r];
         }
         if (tot != d->n_cols) return 0;
@@ -538,7 +544,8 @@ size_t orc_stark_proof_max_bytes(const orc_stark_desc* d) {
     uint32_t R = fri_num_rounds(&fp);
     size_t bytes = (NRD + 1) * capb + 16 * (size_t)(2 * d->n_cols + nq) + R * capb;
     size_t per_query = (d->n_cols + nq) * 8 + (NRD + 1) * (1 + 32 * (size_t)log_L) + R * (((size_t)16 << d->fri_arity_bits) + 1 + 32 * (size_t)log_L);
-    bytes += per_query * d->fri_num_queries + ((size_t)16 << d->degree_bits) + 8 + 4 + 8 * (size_t)d->num_public_inputs;
+    bytes += per_query * d->fri_num_queries + ((size_t)16 << d->degree_bits) + 8 + 4 + 8 * (size_t)d->num_public_inputs +
+             8 * (size_t)total_round_values(d);
     return bytes + 64;
 }
 
@@ -566,14 +573,19 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
     int ok = 1;
     for (uint32_t r = 0; r < NRD && ok; r++) {
         const uint32_t rc = round_cols_of(d, r);
-        const uint64_t* tr = fn(user, r, values + d->num_public_inputs, n_drawn);
+        uint64_t* rv = values + d->num_public_inputs + n_drawn;  /* this round's values go here */
+        const uint32_t n_rv = d->n_rounds ? d->round_values[r] : 0;
+        const uint64_t* tr = fn(user, r, values + d->num_public_inputs, n_drawn, n_rv ? rv : NULL);
         if (!tr) { ok = 0; break; }
+        for (uint32_t k = 0; k < n_rv; k++) rv[k] %= GL_P;
         r_coeffs[r] = (uint64_t*)malloc(8 * n * rc);
         r_leaves[r] = (uint64_t*)malloc(8 * L * rc);
         r_dig[r] = (uint64_t*)malloc(8 * orc_merkle_digest_words(L, cap_h));
         orc_commit_from_values(tr, rc, log_n, d->rate_bits, cap_h, r_coeffs[r], r_leaves[r], r_dig[r], r_cap[r]);
         w_u64s(&w, r_cap[r], capw);
         observe_cap(&ch, r_cap[r], cap_h);
+        if (n_rv) orc_ch_observe_many(&ch, rv, n_rv);
+        n_drawn += n_rv;
         if (d->n_rounds)
             for (uint32_t k = 0; k < d->round_challenges[r]; k++) values[d->num_public_inputs + n_drawn++] = orc_ch_challenge(&ch);
         col0[r + 1] = col0[r] + rc;
@@ -688,13 +700,21 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
     fri_prove(&fp, oracles, NRD + 1, batches, 2, &ch, &w);
     w_u32(&w, d->num_public_inputs);
     w_u64s(&w, public_inputs, d->num_public_inputs);
+    {   /* the round values, in round order, after the public inputs */
+        uint32_t off = d->num_public_inputs;
+        for (uint32_t r = 0; r < d->n_rounds; r++) {
+            w_u64s(&w, values + off, d->round_values[r]);
+            off += d->round_values[r] + d->round_challenges[r];
+        }
+    }
     free(idx_o); free(o_local); free(q_coeffs); free(q_leaves); free(q_dig); free(values);
     for (uint32_t r = 0; r < NRD; r++) { free(r_coeffs[r]); free(r_leaves[r]); free(r_dig[r]); }
     return w.overflow ? 0 : w.len;
 }
 
-static const uint64_t* single_round_fn(void* user, uint32_t round, const uint64_t* challenges, uint32_t n_challenges) {
-    (void)challenges; (void)n_challenges;
+static const uint64_t* single_round_fn(void* user, uint32_t round, const uint64_t* challenges, uint32_t n_challenges,
+                                       uint64_t* values_out) {
+    (void)challenges; (void)n_challenges; (void)values_out;
     return round == 0 ? (const uint64_t*)user : NULL;
 }
 
@@ -702,6 +722,35 @@ size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uin
                        uint8_t* proof_out, size_t cap_bytes) {
     if (d->n_rounds > 1) return 0;
     return orc_stark_prove_rounds(d, single_round_fn, (void*)trace, public_inputs, proof_out, cap_bytes);
+}
+
+/* The values array of a proof - public inputs, then per round its round values and the challenges drawn after it - as the
+ * verifier derives it from the proof's caps and tail (no checks beyond sizes): what a caller needs to compare a round
+ * value with the fingerprint it is supposed to be.  Returns the number of values, 0 on a malformed proof. */
+uint32_t orc_stark_values(const orc_stark_desc* d, const uint8_t* proof, size_t len, uint64_t* out) {
+    if (!desc_ok(d)) return 0;
+    const size_t capw = (size_t)4 << d->cap_height;
+    const uint32_t NRD = n_rounds_of(d), n_rv_total = total_round_values(d);
+    if (len < 8 * (NRD + 1) * capw + 4 + 8 * (size_t)(d->num_public_inputs + n_rv_total)) return 0;
+    const size_t tail = len - 4 - 8 * (size_t)(d->num_public_inputs + n_rv_total);
+    const uint64_t* caps = (const uint64_t*)proof;
+    uint64_t rv[3 * 64];
+    memcpy(out, proof + tail + 4, 8 * (size_t)d->num_public_inputs);
+    memcpy(rv, proof + tail + 4 + 8 * (size_t)d->num_public_inputs, 8 * (size_t)n_rv_total);
+    orc_challenger ch;
+    orc_ch_init(&ch);
+    uint32_t n = d->num_public_inputs, off = 0;
+    for (uint32_t rd = 0; rd < NRD; rd++) {
+        uint64_t cap[4 * 64];
+        memcpy(cap, caps + rd * capw, 8 * capw);
+        orc_ch_observe_many(&ch, cap, capw);
+        if (!d->n_rounds) continue;
+        for (uint32_t k = 0; k < d->round_values[rd]; k++) out[n++] = rv[off + k];
+        if (d->round_values[rd]) orc_ch_observe_many(&ch, rv + off, d->round_values[rd]);
+        off += d->round_values[rd];
+        for (uint32_t k = 0; k < d->round_challenges[rd]; k++) out[n++] = orc_ch_challenge(&ch);
+    }
+    return n;
 }
 
 int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) {
@@ -720,25 +769,33 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
     r_u64s(&r, (uint64_t*)o_local, 2 * (2 * ncols + nq));
     /* public inputs are at the very end; the verifier challenges follow them in the values array */
     uint64_t* pis = (uint64_t*)calloc(d->num_public_inputs + n_rch + 1, 8);
-    if (len < 4 + 8 * (size_t)d->num_public_inputs) { rc = -1; goto done; }
+    const uint32_t n_rv_total = total_round_values(d);
+    uint64_t round_vals[3 * 64];
+    if (len < 4 + 8 * (size_t)(d->num_public_inputs + n_rv_total)) { rc = -1; goto done; }
     {
-        size_t tail = len - 4 - 8 * (size_t)d->num_public_inputs;
+        size_t tail = len - 4 - 8 * (size_t)(d->num_public_inputs + n_rv_total);
         uint32_t n_pi;
         memcpy(&n_pi, proof + tail, 4);
         if (n_pi != d->num_public_inputs) { rc = -1; goto done; }
         memcpy(pis, proof + tail + 4, 8 * (size_t)n_pi);
+        memcpy(round_vals, proof + tail + 4 + 8 * (size_t)n_pi, 8 * (size_t)n_rv_total);
         for (uint32_t i = 0; i < n_pi; i++) if (pis[i] >= GL_P) { rc = -1; goto done; }
+        for (uint32_t i = 0; i < n_rv_total; i++) if (round_vals[i] >= GL_P) { rc = -1; goto done; }
         r.len = tail; /* the FRI reader must consume exactly up to here */
     }
     if (r.bad) { rc = -1; goto done; }
     {
         orc_challenger ch;
         orc_ch_init(&ch);
-        uint32_t n_drawn = 0;
+        uint32_t n_drawn = 0, rv_off = 0;
         for (uint32_t rd = 0; rd < NRD; rd++) {
             orc_ch_observe_many(&ch, caps + rd * capw, capw);
-            if (d->n_rounds)
+            if (d->n_rounds) {
+                for (uint32_t k = 0; k < d->round_values[rd]; k++) pis[d->num_public_inputs + n_drawn++] = round_vals[rv_off + k];
+                if (d->round_values[rd]) orc_ch_observe_many(&ch, round_vals + rv_off, d->round_values[rd]);
+                rv_off += d->round_values[rd];
                 for (uint32_t k = 0; k < d->round_challenges[rd]; k++) pis[d->num_public_inputs + n_drawn++] = orc_ch_challenge(&ch);
+            }
         }
         uint64_t alphas[4];
         for (uint32_t j = 0; j < nc; j++) alphas[j] = orc_ch_challenge(&ch);

@@ -93,16 +93,25 @@ typedef struct {
     uint32_t n_rounds;
     uint32_t round_cols[3];
     uint32_t round_challenges[3];
+    uint32_t reserved;
+    /* round values: round_values[r] field elements the prover sends with round r (bus / accumulator totals that depend on
+     * earlier challenges).  They are observed after the round's cap and before its challenges are drawn, are written
+     * after the public inputs at the end of the proof, and the program reads them as PUBLIC: the values array is
+     * public inputs | values of round 0 | challenges of round 0 | values of round 1 | challenges of round 1 | ... */
+    uint32_t round_values[3];
+    uint32_t reserved2;
 } orc_stark_desc;
 
-/* returns round `round`'s columns (round_cols[round] x n, column-major) given the challenges drawn so far */
-typedef const uint64_t* (*orc_round_fn)(void* user, uint32_t round, const uint64_t* challenges, uint32_t n_challenges);
+/* returns round `round`'s columns (round_cols[round] x n, column-major) given everything after the public inputs in the
+ * values array so far (`n_known` elements), and writes the round's round_values[round] values to values_out */
+typedef const uint64_t* (*orc_round_fn)(void* user, uint32_t round, const uint64_t* known, uint32_t n_known, uint64_t* values_out);
 size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* user, const uint64_t* public_inputs,
                               uint8_t* proof_out, size_t cap_bytes);
 size_t orc_stark_proof_max_bytes(const orc_stark_desc* d);
 /* trace: n_cols x n column-major.  Returns bytes written (0 on overflow). */
 size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uint64_t* public_inputs,
                        uint8_t* proof_out, size_t cap_bytes);
+uint32_t orc_stark_values(const orc_stark_desc* d, const uint8_t* proof, size_t len, uint64_t* out);
 int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len);
 
 #ifdef __cplusplus

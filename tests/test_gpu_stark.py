@@ -274,3 +274,25 @@ def test_multi_round_logup_bytes_equal_oracle(nlx, ctx, orc):
     vb, tb, mb = logup_case(7, bad=True)
     assert orc.stark_verify(st.desc, pr.prove_rounds(logup_rounds(vb, tb, mb))) != 1
     pr.close()
+
+
+def test_round_values_bytes_equal_oracle(nlx, ctx, orc):
+    """A round that sends values (the total of a challenge-dependent accumulator): same proof bytes as the oracle, and
+    the value the proof carries is the fingerprint of the committed column."""
+    from test_stark_cpu import fingerprint_air, fingerprint_rounds
+    S = nlx.stark
+    for db in (6, 11):
+        st = S.Stark(fingerprint_air(S), db, S.StarkConfig(fri_num_queries=20))
+        v = np.random.default_rng(db).integers(0, P, 1 << db, dtype=np.uint64)
+        pr = st.build(ctx)
+        proof = pr.prove_rounds(fingerprint_rounds(v), [])
+        assert proof == orc.stark_prove_rounds(st.desc, fingerprint_rounds(v), [])
+        assert orc.stark_verify(st.desc, proof) == 1
+        gamma, total = orc.stark_values(st.desc, proof)
+        acc = 0
+        for x in v:
+            acc = (acc * gamma + int(x)) % P
+        assert total == acc
+        with pytest.raises(ValueError):
+            pr.prove_rounds(lambda rnd, known: fingerprint_rounds(v)(rnd, known)[0] if rnd else np.array([v], dtype=np.uint64), [])
+        pr.close()

@@ -370,3 +370,55 @@ def test_program_segments_do_not_change_the_proof(nlx, orc):
             row = run_program(st.program, t[:, 3], t[:, 4], pis, periodic=[int(c[3 % len(c)]) for c in air._periodic])
             assert len(row) == air.num_constraints
         assert all(p == proofs[0] for p in proofs) and sizes[1] > sizes[0]
+
+
+def fingerprint_air(S):
+    """Round 0: a column v; challenge gamma; round 1: the Horner accumulator acc(i) = acc(i-1) gamma + v(i), whose last
+    value is a ROUND VALUE - sent by the prover, bound by a last-row constraint, compared by whoever relies on the proof
+    with the fingerprint of the data they believe v to be."""
+    air = S.Air(2, 0, rounds=[(1, 1), (1, 0)], round_values=[0, 1])
+    v, acc = air.local(0), air.local(1)
+    gamma, total = air.challenge(0), air.round_value(1, 0)
+    air.constraint_first_row(acc - v)
+    air.constraint_transition(air.next(1) - (acc * gamma + air.next(0)))
+    air.constraint_last_row(acc - total)
+    return air
+
+
+def fingerprint_rounds(v, lie=0):
+    def fn(rnd, known):
+        if rnd == 0:
+            return np.array([v], dtype=np.uint64)
+        gamma, acc, out = known[0], 0, []
+        for x in v:
+            acc = (acc * gamma + int(x)) % P
+            out.append(acc)
+        return np.array([out], dtype=np.uint64), [(acc + lie) % P]
+    return fn
+
+
+def test_round_values_oracle(nlx, orc):
+    S = nlx.stark
+    air = fingerprint_air(S)
+    st = S.Stark(air, 6, S.StarkConfig(fri_num_queries=20))
+    assert list(st.desc.round_values) == [0, 1, 0] and ctypes_sizeof(st.desc) == 120
+    rng = np.random.default_rng(5)
+    v = rng.integers(0, P, 64, dtype=np.uint64)
+    proof = orc.stark_prove_rounds(st.desc, fingerprint_rounds(v), [])
+    assert orc.stark_verify(st.desc, proof) == 1
+    gamma, total = orc.stark_values(st.desc, proof)       # (challenge of round 0, value of round 1) in values-array order
+    acc = 0
+    for x in v:
+        acc = (acc * gamma + int(x)) % P
+    assert total == acc                                    # the relying party's check: the value IS the fingerprint of v
+    # a prover that sends another value cannot satisfy the last-row constraint
+    assert orc.stark_verify(st.desc, orc.stark_prove_rounds(st.desc, fingerprint_rounds(v, lie=1), [])) != 1
+    # the value is part of the transcript: changing it in the proof changes every later challenge
+    bad = bytearray(proof)
+    bad[-3] ^= 1
+    assert orc.stark_verify(st.desc, bytes(bad)) != 1
+
+
+def ctypes_sizeof(x):
+    import ctypes
+    return ctypes.sizeof(x)
