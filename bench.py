@@ -495,7 +495,7 @@ def run_ed25519(args, nlx, torch, rank, world, local, dist):
         t1 = time.perf_counter()
         pr.generate_trace(words)
         t_trace += time.perf_counter() - t1
-        proof = pr.prover.prove_rounds(lambda rnd, chal: pr._t0 if rnd == 0 else pr.round1(chal[:2]), [])
+        proof = pr.prover.prove_rounds(lambda rnd, known: pr._t0 if rnd == 0 else pr.round1(known), [])
     barrier(dist, torch)
     dt = time.perf_counter() - t0
     dt = reduce_max(dist, torch, dt)
@@ -536,9 +536,11 @@ def run_ed25519(args, nlx, torch, rank, world, local, dist):
             pr2 = pr if args.log_slots == 8 else E.Ed25519Prover(ctx, 8)
             host = pr2.generate_trace(words[:256]).cpu().numpy().view(np.uint64)
             tc = time.time()
-            p2 = oracle_py.stark_prove_rounds(pr2.stark.desc, lambda rnd, chal: host if rnd == 0 else np.concatenate(
-                [oracle_py.logup_round(host, E.LOOKUPS, 16, host[E.MULT], chal[:2]),
-                 oracle_py.logup_round(host, E.LOOKUPS9, 9, host[E.MULT9], chal[:2])], axis=0), [])
+            def cpu_round1(known):
+                acc, total = E.binding_columns(host, known[2:4])
+                return np.concatenate([oracle_py.logup_round(host, E.LOOKUPS, 16, host[E.MULT], known[:2]),
+                                       oracle_py.logup_round(host, E.LOOKUPS9, 9, host[E.MULT9], known[:2]), acc], axis=0), list(total)
+            p2 = oracle_py.stark_prove_rounds(pr2.stark.desc, lambda rnd, known: host if rnd == 0 else cpu_round1(known), [])
             dtc = time.time() - tc
             out["cpu_baseline"] = {"value": 256 / dtc, "unit": "signatures/s", "cores": cores, "kind": "port",
                                    "sample": "oracle two-round STARK prover (incl. its lookup columns) on 2^8 slots in %.1f s (trace "
@@ -662,6 +664,9 @@ def run_sync_starks(args, nlx, torch, rank, world, local, dist):
             out["oracle_verifier_accepts"] = {"sha256": oracle_py.stark_verify(p256.stark.desc, a[0]) == 1,
                                               "sha512": oracle_py.stark_verify(p512.stark.desc, b[0]) == 1,
                                               "ed25519": oracle_py.stark_verify(ped.stark.desc, c) == 1}
+            vals = oracle_py.stark_values(ped.stark.desc, c)           # [alpha0, alpha1, gamma0, gamma1, total0, total1]
+            bound = (slots * ((1 << log_slots) // n_sigs + 1))[: 1 << log_slots]
+            out["ed25519_round_value_is_the_fingerprint_of_the_signatures"] = tuple(vals[4:6]) == E.fingerprint(bound, vals[2:4])
     for pr in (p256, p512, ped):
         pr.close()
     for c_ in ctxs:

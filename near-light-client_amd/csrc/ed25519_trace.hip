@@ -9,7 +9,9 @@
 //              so every column store is 512 contiguous bytes.
 #include "ctx.hpp"
 #include "ed25519_rows.hpp"
+#include "gl.hpp"
 #include "transcript.hpp"
+#include <vector>
 
 namespace nlx {
 
@@ -72,9 +74,92 @@ __global__ __launch_bounds__(64) void k_ed_rows(const ed::Slot* __restrict__ slo
     if (!ed::emit_row(r, s, p, prev_ry, &prev_fin, put, o)) atomicMin(bad_slot, r == ed::STEP_YCMP ? prev : k);
 }
 
+// ---- binding accumulator (round 1): Horner fingerprint in F_p^2 of every slot's limbs, limb 15 first, in the order
+// A.x, A.y, R.x, R.y, S, h ----
+__device__ __forceinline__ gl::Ext absorb_limb(gl::Ext acc, gl::Ext gamma, const uint64_t* __restrict__ trace, size_t n, size_t row, int j) {
+    const uint32_t base[6] = {ed::cAX, ed::cAY, ed::cRX, ed::cRY, ed::cSW, ed::cHW};
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        acc = gl::mul(acc, gamma);
+        acc.a = gl::add(acc.a, trace[(size_t)(base[k] + j) * n + row]);
+    }
+    return acc;
+}
+
+// one lane per slot: the slot's own fingerprint (starting from 0)
+__global__ __launch_bounds__(64) void k_ed_bind_slot(const uint64_t* __restrict__ trace, uint32_t n_slots, gl::Ext gamma,
+                                                     gl::Ext* __restrict__ slot_fp) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_slots) return;
+    const size_t n = (size_t)n_slots * ed::ROWS, row = (size_t)k * ed::ROWS;
+    gl::Ext acc{0, 0};
+    for (int j = 15; j >= 0; j--) acc = absorb_limb(acc, gamma, trace, n, row, j);
+    slot_fp[k] = acc;
+}
+
+// one lane per slot: the accumulator column from the slot's start value (exclusive: a row holds what was absorbed before it)
+__global__ __launch_bounds__(64) void k_ed_bind_rows(const uint64_t* __restrict__ trace, uint32_t n_slots, gl::Ext gamma,
+                                                     const gl::Ext* __restrict__ start, uint64_t* __restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_slots) return;
+    const size_t n = (size_t)n_slots * ed::ROWS, row0 = (size_t)k * ed::ROWS;
+    gl::Ext acc = start[k];
+    for (int r = 0; r < ed::ROWS; r++) {
+        out[row0 + r] = acc.a;
+        out[n + row0 + r] = acc.b;
+        if ((r & 15) == 15) acc = absorb_limb(acc, gamma, trace, n, row0 + r, 15 - (r >> 4));
+    }
+}
+
 }  // namespace nlx
 
 using namespace nlx;
+
+extern "C" int32_t nlx_ed25519_bind_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t log_slots, const uint64_t gamma[2],
+                                          uint64_t* acc_out, uint64_t total_out[2]) {
+    if (!ctx) return NLX_E_INVAL;
+    if (!trace || !gamma || !acc_out || !total_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
+    if (log_slots > 16) return ctx->fail(NLX_E_RANGE, "log_slots must be <= 16");
+    (void)hipSetDevice(ctx->device);
+    const uint32_t n_slots = 1u << log_slots;
+    const size_t n = (size_t)n_slots * ed::ROWS;
+    Staged tr(ctx, trace, (size_t)ed::N_COLS0 * n * 8, true, false);
+    if (tr.status) return tr.status;
+    Staged so(ctx, acc_out, 2 * n * 8, false, true);
+    if (so.status) return so.status;
+    gl::Ext* d_fp = (gl::Ext*)ctx->alloc((size_t)n_slots * sizeof(gl::Ext));
+    if (!d_fp) return NLX_E_NOMEM;
+    const gl::Ext g{gamma[0] % gl::P, gamma[1] % gl::P};
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_ed_bind_slot, dim3((n_slots + 63) / 64), dim3(64), 0, st, tr.as<uint64_t>(), n_slots, g, d_fp);
+    std::vector<gl::Ext> fp_h(n_slots), start(n_slots);
+    int32_t rc = fetch(ctx, fp_h.data(), d_fp, (size_t)n_slots * sizeof(gl::Ext));
+    if (!rc) {
+        // the slots' start values: acc_(s+1) = acc_s gamma^96 + fp_s (a few thousand extension multiplications, on the host)
+        const gl::Ext g96 = gl::pow(g, 96);
+        gl::Ext acc{0, 0};
+        for (uint32_t k = 0; k < n_slots; k++) {
+            start[k] = acc;
+            acc = gl::add(gl::mul(acc, g96), fp_h[k]);
+        }
+        total_out[0] = acc.a;
+        total_out[1] = acc.b;
+        hipError_t e = hipMemcpyAsync(d_fp, start.data(), (size_t)n_slots * sizeof(gl::Ext), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) rc = ctx->hip_fail(e, "hipMemcpyAsync");
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(k_ed_bind_rows, dim3((n_slots + 63) / 64), dim3(64), 0, st, tr.as<uint64_t>(), n_slots, g, d_fp,
+                           so.as<uint64_t>());
+        rc = so.finish();
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    ctx->release(d_fp);
+    if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
+    hipError_t le = hipGetLastError();
+    if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
+    return rc;
+}
+
 
 extern "C" int32_t nlx_ed25519_trace(nlx_ctx* ctx, const uint64_t* slots, uint32_t log_slots, uint64_t* trace_out) {
     if (!ctx) return NLX_E_INVAL;

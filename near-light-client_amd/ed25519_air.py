@@ -20,9 +20,11 @@ range-checked cell, a constant, or a cell tied by a degree <= 3 constraint to on
 and carries (and, once per slot, the limbs of A and R) go through the 2^16-table lookup (the carries' high parts through
 a 2^9 table).  Constraint degree 3, two commitment rounds (the second is logup.py's columns for the two tables).
 
-Scope of this version: the slot's (A, R, S, h) are witness columns constant over the slot - binding them to data
-outside the proof (curta does that with its bus; here it would be one more running accumulator over a challenge) and
-the reduction of the 512-bit digest mod L are left to the caller.  The check is the cofactorless one
+Binding to public data: a fifth and sixth challenge gamma (drawn with the lookup challenge, after round 0) and a
+round-1 accumulator column fold every slot's 96 limbs (A, R, S, h) into one Horner fingerprint in the quadratic
+extension; its total is a ROUND VALUE of the proof (stark.py).  Whoever relies on the proof recomputes
+`fingerprint(slots, gamma)` from the tuples it believes were verified and compares.  The reduction of the 512-bit
+SHA-512 digest mod L is left to the caller.  The check is the cofactorless one
 (ed25519-dalek's `verify`: [S]B - [h]A == R).
 """
 import numpy as np
@@ -95,7 +97,9 @@ MULT, MULT9 = LAY.take(1), LAY.take(1)     # multiplicities of the 2^16 table an
 N_COLS0 = LAY.n
 LOOKUPS, LOOKUPS9 = list(LAY.lookups16), list(LAY.lookups9)
 N_COLS1A, N_COLS1B = logup.round_cols(len(LOOKUPS)), logup.round_cols(len(LOOKUPS9))
-N_COLS1 = N_COLS1A + N_COLS1B
+ACC = N_COLS0 + N_COLS1A + N_COLS1B       # round 1: after the lookup columns, the fingerprint accumulator (2 base columns)
+N_COLS1 = N_COLS1A + N_COLS1B + 2
+BOUND = (AX, AY, RX, RY, SW, HW)           # the per-slot limb vectors the fingerprint absorbs, limb 15 first
 # main unit indices
 (U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2, U_PA, U_PB, U_PC, U_PD, U_X4, U_Y4, U_Z4) = range(N_MAIN)
 AUX_STEPS = {"ycmp": 0, "a_u": 1, "a_nt": 2, "a_u2": 3, "a_v": 4, "a_chk": 5, "r_u": 6, "r_v": 7, "r_chk": 8,
@@ -127,7 +131,7 @@ class _Vec:
 
 
 def ed25519_air(max_resident_leaves=None):
-    air = Air(N_COLS0 + N_COLS1, 0, rounds=[(N_COLS0, 2), (N_COLS1, 0)])
+    air = Air(N_COLS0 + N_COLS1, 0, rounds=[(N_COLS0, 4), (N_COLS1, 0)], round_values=[0, 2])
     if max_resident_leaves is not None:
         air.max_resident_leaves = max_resident_leaves
     L, N = air.local, air.next  # noqa: N806
@@ -281,6 +285,40 @@ def ed25519_air(max_resident_leaves=None):
         air.constraint(no_sq * L(AUX_E + i))
         air.constraint(no_sq * L(AUX_F + i))
 
+    # ---- fingerprint of the slots' data: acc' = acc gamma^6 + sum_k gamma^(5-k) limb_k on the row that closes block j
+    # (limb j of AX, AY, RX, RY, S, h), unchanged elsewhere; starts at 0, and the total after the last row is the
+    # proof's round value ----
+    def ext_mul(x, y):
+        return x[0] * y[0] + x[1] * y[1] * logup.W, x[0] * y[1] + x[1] * y[0]
+    gam = [(air.challenge(2), air.challenge(3))]
+    for _ in range(5):
+        gam.append(ext_mul(gam[-1], gam[0]))                  # gam[k] = gamma^(k+1)
+    closing = [periodic_rows({16 * (15 - j) + 15}) for j in range(16)]
+    acc = (L(ACC), L(ACC + 1))
+
+    def word(j):
+        """sum_k gamma^(5-k) limb_(k,j) as an extension element: limb j of AX, AY, RX, RY, S with weights gamma^5 .. gamma,
+        limb j of h with weight 1"""
+        w0, w1 = L(BOUND[5] + j), None
+        for k in range(5):
+            g0, g1 = gam[4 - k]
+            limb = L(BOUND[k] + j)
+            w0 = w0 + g0 * limb
+            w1 = g1 * limb if w1 is None else w1 + g1 * limb
+        return w0, w1
+
+    absorbed = [None, None]                                    # sum_j closing_j word(j): degree 2
+    for j in range(16):
+        for c, wc in enumerate(word(j)):
+            term = closing[j] * wc
+            absorbed[c] = term if absorbed[c] is None else absorbed[c] + term
+    grown = ext_mul(acc, (gam[5][0] - 1, gam[5][1]))           # acc (gamma^6 - 1)
+    total = ext_mul(acc, gam[5])
+    last_word = word(0)                                        # the last row of the trace closes block 0 of the last slot
+    for c in range(2):
+        air.constraint_first_row(acc[c])
+        air.constraint_transition(N(ACC + c) - (acc[c] + limb_end * grown[c] + absorbed[c]))
+        air.constraint_last_row(total[c] + last_word[c] - air.round_value(1, c))
     rc = logup.RangeCheck(air, LOOKUPS, 16, MULT, N_COLS0)
     rc9 = logup.RangeCheck(air, LOOKUPS9, fp.CARRY_HI_BITS, MULT9, N_COLS0 + N_COLS1A)
     return air, (rc, rc9)
@@ -486,6 +524,43 @@ def synthetic_slots(count, seed=1):
     return out
 
 
+def _ext_mul(x, y):
+    gl = 0xFFFFFFFF00000001
+    return (x[0] * y[0] + logup.W * x[1] * y[1]) % gl, (x[0] * y[1] + x[1] * y[0]) % gl
+
+
+def fingerprint(slots, gamma):
+    """What the proof's round value must be for these slots: Horner in F_p^2 over, slot by slot, limb 15 down to limb 0
+    of (A.x, A.y, R.x, R.y, S, h) - the relying party's side of the binding."""
+    acc = (0, 0)
+    for sl in slots:
+        limbs = [fp.to_limbs(v) for v in sl]
+        for j in range(15, -1, -1):
+            for k in range(6):
+                acc = _ext_mul(acc, gamma)
+                acc = ((acc[0] + limbs[k][j]) % 0xFFFFFFFF00000001, acc[1])
+    return acc
+
+
+def binding_columns(t0, gamma):
+    """Round-1 accumulator columns (2, n) and the total, from a round-0 trace (plain Python; tests and the oracle path)."""
+    gl = 0xFFFFFFFF00000001
+    n = t0.shape[1]
+    out = np.zeros((2, n), dtype=np.uint64)
+    g6 = (1, 0)
+    for _ in range(6):
+        g6 = _ext_mul(g6, gamma)
+    acc = (0, 0)
+    for r in range(n):
+        out[0, r], out[1, r] = acc
+        if r % 16 == 15:
+            j = 15 - (r % ROWS) // 16
+            for k in range(6):
+                acc = _ext_mul(acc, gamma)
+                acc = ((acc[0] + int(t0[BOUND[k] + j, r])) % gl, acc[1])
+    return out, acc
+
+
 def slots_to_words(slots):
     """[(ax, ay, rx, ry, s, h)] -> (n, 24) uint64: the input format of nlx_ed25519_trace"""
     out = np.zeros((len(slots), 24), dtype=np.uint64)
@@ -538,16 +613,23 @@ class Ed25519Prover:
             rc.multiplicities(self.ctx, self._t0)
         return self._t0
 
-    def round1(self, alpha):
-        """the lookup columns of both tables for challenge alpha, into the device round-1 buffer"""
+    def round1(self, known):
+        """Round 1 for the challenges known = [alpha0, alpha1, gamma0, gamma1]: the lookup columns of both tables and the
+        binding accumulator into the device round-1 buffer; returns (columns, [total0, total1])."""
+        from ._lib import dll
+        alpha, gamma = known[:2], np.array([int(known[2]), int(known[3])], dtype=np.uint64)
         rc16, rc9 = self.es.range_checks
         rc16.round1(self.ctx, self._t0, alpha, self._t1[:N_COLS1A])
-        rc9.round1(self.ctx, self._t0, alpha, self._t1[N_COLS1A:])
-        return self._t1
+        rc9.round1(self.ctx, self._t0, alpha, self._t1[N_COLS1A:N_COLS1A + N_COLS1B])
+        total = np.zeros(2, dtype=np.uint64)
+        self.ctx.check(dll.nlx_ed25519_bind_round(self.ctx.handle, self._t0.data_ptr(), self.es.log_slots, gamma.ctypes.data,
+                                                  self._t1[N_COLS1A + N_COLS1B:].data_ptr(), total.ctypes.data))
+        self.last_total = (int(total[0]), int(total[1]))
+        return self._t1, [int(total[0]), int(total[1])]
 
     def prove(self, slots):
         t0 = self.generate_trace(slots)
-        return self.prover.prove_rounds(lambda rnd, chal: t0 if rnd == 0 else self.round1(chal[:2]), [])
+        return self.prover.prove_rounds(lambda rnd, known: t0 if rnd == 0 else self.round1(known), [])
 
     def close(self):
         self.prover.close()

@@ -76,19 +76,25 @@ def tiled_case(nlx, orc):
     return slots, t0
 
 
-def oracle_round1(orc, E, t0, alpha):
-    return np.concatenate([orc.logup_round(t0, E.LOOKUPS, 16, t0[E.MULT], alpha),
-                           orc.logup_round(t0, E.LOOKUPS9, 9, t0[E.MULT9], alpha)], axis=0)
+def oracle_round1(orc, E, t0, known):
+    """round 1 on the CPU for known = [alpha0, alpha1, gamma0, gamma1]: (columns, round values)"""
+    acc, total = E.binding_columns(t0, known[2:4])
+    cols = np.concatenate([orc.logup_round(t0, E.LOOKUPS, 16, t0[E.MULT], known[:2]),
+                           orc.logup_round(t0, E.LOOKUPS9, 9, t0[E.MULT9], known[:2]), acc], axis=0)
+    return cols, list(total)
 
 
 def test_every_constraint_vanishes_on_the_reference_trace(nlx, orc, tiled_case):
     E = nlx.ed25519_air
     slots, t0 = tiled_case
     air, _ = E.ed25519_air()
-    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 2438 and (len(E.LOOKUPS), len(E.LOOKUPS9)) == (772, 240)
+    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 2440 and (len(E.LOOKUPS), len(E.LOOKUPS9)) == (772, 240)
     words = air.compile()
-    alpha = (0x1234567890abcdef, 0x0fedcba987654321)
-    full = np.concatenate([t0, oracle_round1(orc, E, t0, alpha)], axis=0)
+    known = [0x1234567890abcdef, 0x0fedcba987654321, 0x0123456789abcdef, 0x0edcba9876543210]     # alpha, gamma
+    r1, total = oracle_round1(orc, E, t0, known)
+    assert tuple(total) == E.fingerprint(slots * 128, known[2:4])
+    full = np.concatenate([t0, r1], axis=0)
+    alpha = known + total                                          # the values array after the (zero) public inputs
     n = full.shape[1]
     per = air._periodic
 
@@ -101,14 +107,15 @@ def test_every_constraint_vanishes_on_the_reference_trace(nlx, orc, tiled_case):
                 loc[col] = (int(loc[col]) + delta) % P
             if row == (i + 1) % n:
                 nxt[col] = (int(nxt[col]) + delta) % P
-        vals = run_program(words, loc, nxt, list(alpha), periodic=[int(c[i % len(c)]) for c in per])
+        vals = run_program(words, loc, nxt, list(alpha), periodic=[int(c[i % len(c)]) for c in per], n_public=0)
         assert len(vals) == air.num_constraints
-        return [k for k, (_, v) in enumerate(vals) if v != 0]
+        return [k for k, (op, v) in enumerate(vals) if v != 0 and not (op == 7 and i == n - 1) and not (op == 8 and i != 0)
+                and not (op == 9 and i != n - 1)]
     for i in list(range(0, 10)) + [15, 16, 17, 254, 255, 256, 257, 260, 511, 512, n - 1]:
         assert violations(i) == [], i
     # tampering with a cell breaks a constraint on that row or the one before it
     for col, row in ((E.SB, 40), (E.SIN + 3, 100), (E.MAIN[E.U_X4] + 2, 77), (E.MAIN[E.U_Y2] + 20, 5), (E.P2 + 17, 60), (E.SX3 + 1, 12), (E.SPT + 3, 16), (E.AUX + 1, 255), (E.AX + 1, 300),
-                     (E.SW + 2, 9), (E.NT, 2), (E.AUX_E + 4, 30), (E.HA, 31)):
+                     (E.SW + 2, 9), (E.NT, 2), (E.AUX_E + 4, 30), (E.HA, 31), (E.ACC, 100), (E.ACC + 1, 16)):
         assert violations(row, (col, row, 1)) or violations(row - 1, (col, row, 1)), (col, row)
 
 
@@ -124,8 +131,14 @@ def test_gpu_trace_and_proof_equal_reference_and_oracle(nlx, ctx, orc, tiled_cas
         pytest.fail("GPU trace differs from the reference at column %d row %d" % (bad[0], bad[1]))
     proof = pr.prove(slots * 128)
     assert orc.stark_verify(pr.stark.desc, proof) == 1
-    want = orc.stark_prove_rounds(pr.stark.desc, lambda rnd, chal: t0 if rnd == 0 else oracle_round1(orc, E, t0, chal[:2]), [])
+    want = orc.stark_prove_rounds(pr.stark.desc, lambda rnd, known: t0 if rnd == 0 else oracle_round1(orc, E, t0, known), [])
     assert proof == want
+    # the binding: the round value the proof carries is the fingerprint of exactly these slots under the proof's gamma
+    vals = orc.stark_values(pr.stark.desc, proof)
+    assert len(vals) == 6 and tuple(vals[4:6]) == E.fingerprint(slots * 128, vals[2:4]) == pr.last_total
+    other = list(slots * 128)
+    other[3] = other[2]
+    assert tuple(vals[4:6]) != E.fingerprint(other, vals[2:4])
     pr.close()
 
 
@@ -157,6 +170,6 @@ def test_gpu_real_near_approvals_and_a_forgery(nlx, ctx, orc):
         pr.generate_trace(forged)
     for rc in pr.es.range_checks:
         rc.multiplicities(ctx, pr._t0)
-    bad_proof = pr.prover.prove_rounds(lambda rnd, chal: pr._t0 if rnd == 0 else pr.round1(chal[:2]), [])
+    bad_proof = pr.prover.prove_rounds(lambda rnd, known: pr._t0 if rnd == 0 else pr.round1(known), [])
     assert orc.stark_verify(pr.stark.desc, bad_proof) != 1
     pr.close()
