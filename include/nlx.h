@@ -470,6 +470,13 @@ int32_t nlx_ed25519_bind_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t log
 #define NLX_SHA256_COLS 1953
 int32_t nlx_sha256_trace(nlx_ctx* ctx, const uint32_t* blocks, const uint8_t* is_first, uint32_t log_blocks,
                          uint64_t* trace_out, uint64_t digest_out[8]);
+/* The SHA-256 AIR's binding accumulator (round 1, one column over F_p^2 = two base columns) for the challenge gamma:
+ * the running Horner fingerprint of every block's (message-start flag, 16 message words) - absorbed on the block's first
+ * row - and 8 output chaining words - on its last row -, each row holding what was absorbed before it.  trace: the
+ * round-0 trace; acc_out: 2 x (4 << log_blocks); total_out: the round value the proof sends
+ * (near-light-client_amd/sha256_air.py::fingerprint is the relying party's side). */
+int32_t nlx_sha256_bind_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t log_blocks, const uint64_t gamma[2],
+                              uint64_t* acc_out, uint64_t total_out[2]);
 /* The SHA-512 sibling (column layout and constraints: near-light-client_amd/sha512_air.py; caller in the reference:
  * the SHA-512 of R || A || M inside curta_eddsa_verify_sigs_conditional, nearx/src/builder.rs:152).  blocks:
  * 2^log_blocks padded 1024-bit blocks as 16 big-endian-decoded 64-bit words each.  Writes the NLX_SHA512_COLS x

@@ -48,7 +48,8 @@ PE = PA + 128                   # 1808
 HIN = PE + 128                  # 1936
 CY = HIN + 8                    # 1944
 IS_FIRST = CY + 8               # 1952
-N_COLS = IS_FIRST + 1           # 1953
+N_COLS = IS_FIRST + 1           # 1953 (round 0)
+ACC = N_COLS                    # round 1: the binding accumulator, one element of F_p^2 = two base columns
 ROWS_PER_BLOCK = 4
 
 IV = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
@@ -81,7 +82,7 @@ assert K[0] == 0x428a2f98 and K[63] == 0xc67178f2
 
 
 def sha256_air():
-    air = Air(N_COLS, 8)
+    air = Air(N_COLS + 2, 8, rounds=[(N_COLS, 2), (2, 0)], round_values=[0, 2])
     L, N = air.local, air.next  # noqa: N806
     two32 = 1 << 32
     k_slot = [air.periodic([K[16 * q + j] for q in range(4)]) for j in range(16)]
@@ -171,6 +172,29 @@ def sha256_air():
         air.constraint_first_row(cur[k] - IV[k])
     for k in range(8):
         air.constraint_last_row(ho[k] - air.public(k))
+
+    # 8. binding: a challenge gamma in F_p^2 (drawn once the trace is committed) and a round-1 accumulator fold every
+    # block's (message-start flag, 16 message words) - on its first row - and 8 output chaining words - on its last row -
+    # into one Horner fingerprint; the total is a round value of the proof, which the relying party recomputes from the
+    # messages it believes were hashed (fingerprint() below).  Each row holds what was absorbed before it.
+    def ext_mul(x, y):
+        return x[0] * y[0] + x[1] * y[1] * 7, x[0] * y[1] + x[1] * y[0]
+    gamma = (air.challenge(0), air.challenge(1))
+
+    def horner(start, elems):
+        """((start gamma + e_0) gamma + e_1) .. gamma + e_last: a chain, so that few values are live at a time"""
+        c0, c1 = start
+        for e in elems:
+            c0, c1 = ext_mul((c0, c1), gamma)
+            c0 = c0 + e
+        return c0, c1
+    acc = (L(ACC), L(ACC + 1))
+    after_head = horner(acc, [L(IS_FIRST)] + [air.pack(j * SLOT + oW, 32) for j in range(16)])   # 17 elements, rows q = 0
+    after_tail = horner(acc, ho)                                                                  # 8 elements, rows q = 3
+    for c in range(2):
+        air.constraint_first_row(acc[c])
+        air.constraint_transition(N(ACC + c) - (acc[c] + is_q0 * (after_head[c] - acc[c]) + is_q3 * (after_tail[c] - acc[c])))
+        air.constraint_last_row(after_tail[c] - air.round_value(1, c))
     return air
 
 
@@ -293,9 +317,71 @@ def reference_trace(blocks, is_first):
     return t, np.array(h, dtype=np.uint64)
 
 
+def _ext_mul(x, y):
+    gl = 0xFFFFFFFF00000001
+    return (x[0] * y[0] + 7 * x[1] * y[1]) % gl, (x[0] * y[1] + x[1] * y[0]) % gl
+
+
+def block_outputs(blocks, is_first):
+    """output chaining value of every block (the eight words the AIR absorbs on a block's last row)"""
+    outs, h = [], list(IV)
+    for bi, blk in enumerate(blocks):
+        if is_first[bi] or bi == 0:
+            h = list(IV)
+        w = _schedule(blk)
+        a, b, c, d, e, f, g, hh = h
+        for r in range(64):
+            t1 = (hh + (_rotr(e, 6) ^ _rotr(e, 11) ^ _rotr(e, 25)) + ((e & f) ^ (~e & g & 0xFFFFFFFF)) + K[r] + w[r]) & 0xFFFFFFFF
+            t2 = ((_rotr(a, 2) ^ _rotr(a, 13) ^ _rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c))) & 0xFFFFFFFF
+            hh, g, f, e, d, c, b, a = g, f, e, (d + t1) & 0xFFFFFFFF, c, b, a, (t1 + t2) & 0xFFFFFFFF
+        h = [(x + y) & 0xFFFFFFFF for x, y in zip(h, (a, b, c, d, e, f, g, hh))]
+        outs.append(list(h))
+    return outs
+
+
+def fingerprint(blocks, is_first, gamma):
+    """What the proof's round value must be for these padded blocks (blocks_for_messages): Horner in F_p^2 over, block by
+    block, (message-start flag, 16 message words, 8 output chaining words) - the relying party's side of the binding."""
+    gl = 0xFFFFFFFF00000001
+    acc = (0, 0)
+    for bi, (blk, out) in enumerate(zip(blocks, block_outputs(blocks, is_first))):
+        for v in [1 if (is_first[bi] or bi == 0) else 0] + [int(x) for x in blk] + out:
+            acc = _ext_mul(acc, gamma)
+            acc = ((acc[0] + v) % gl, acc[1])
+    return acc
+
+
+def binding_columns(blocks, is_first, gamma):
+    """Round-1 accumulator columns (2, 4 n_blocks) and the total, plain Python (tests and the oracle path)."""
+    gl = 0xFFFFFFFF00000001
+    n = ROWS_PER_BLOCK * len(blocks)
+    out = np.zeros((2, n), dtype=np.uint64)
+    acc = (0, 0)
+    for bi, (blk, ho) in enumerate(zip(blocks, block_outputs(blocks, is_first))):
+        for q in range(4):
+            out[0, 4 * bi + q], out[1, 4 * bi + q] = acc
+            elems = ([1 if (is_first[bi] or bi == 0) else 0] + [int(x) for x in blk]) if q == 0 else (ho if q == 3 else [])
+            for v in elems:
+                acc = _ext_mul(acc, gamma)
+                acc = ((acc[0] + v) % gl, acc[1])
+    return out, acc
+
+
+def cpu_rounds(blocks, is_first, trace):
+    """round function for a CPU prover of this AIR (tests, the bench's cpu_baseline): round 0 = the given trace, round 1 = the
+    binding accumulator and its total for the gamma the prover drew"""
+    def fn(rnd, known):
+        if rnd == 0:
+            return trace
+        cols, total = binding_columns(blocks, is_first, known[:2])
+        return cols, list(total)
+    return fn
+
+
 class Sha256Prover:
-    """Proves SHA-256 of a batch of messages on one GPU: trace generation (nlx_sha256_trace) straight into
-    HBM, then nlx_stark_prove on the device-resident trace.  2^log_blocks compression blocks per proof."""
+    """Proves SHA-256 of a batch of messages on one GPU: trace generation (nlx_sha256_trace) straight into HBM, the
+    binding accumulator (nlx_sha256_bind_round) once the prover has drawn gamma, and the two-round STARK
+    (nlx_stark_prove_rounds) on the device-resident columns.  2^log_blocks compression blocks per proof."""
 
     def __init__(self, ctx, log_blocks, config=None, segment_nodes=None):
         from .stark import Stark
@@ -308,10 +394,11 @@ class Sha256Prover:
             air.segment_nodes = segment_nodes
         self.stark = Stark(air, log_blocks + 2, config)
         self.prover = self.stark.build(ctx)
-        self._trace = None
+        self._trace = self._acc = None
+        self.last_total = None
 
     def generate_trace(self, blocks, is_first):
-        """Returns (device trace tensor [N_COLS, n] int64, digest words uint64[8])."""
+        """Returns (device round-0 trace tensor [N_COLS, n] int64, digest words uint64[8])."""
         import torch
         from ._lib import dll
         blocks = np.ascontiguousarray(blocks, dtype=np.uint32)
@@ -321,18 +408,33 @@ class Sha256Prover:
         n = ROWS_PER_BLOCK << self.log_blocks
         if self._trace is None:
             self._trace = torch.empty((N_COLS, n), dtype=torch.int64, device="cuda:%d" % self.ctx.device)
+            self._acc = torch.empty((2, n), dtype=torch.int64, device=self._trace.device)
         digest = np.zeros(8, dtype=np.uint64)
         self.ctx.check(dll.nlx_sha256_trace(self.ctx.handle, blocks.ctypes.data, is_first.ctypes.data, self.log_blocks,
                                             self._trace.data_ptr(), digest.ctypes.data))
         return self._trace, digest
 
+    def round1(self, known):
+        """The binding accumulator for gamma = known[0:2] (device columns) and its total, the proof's round value."""
+        from ._lib import dll
+        gamma = np.array([int(known[0]), int(known[1])], dtype=np.uint64)
+        total = np.zeros(2, dtype=np.uint64)
+        self.ctx.check(dll.nlx_sha256_bind_round(self.ctx.handle, self._trace.data_ptr(), self.log_blocks, gamma.ctypes.data,
+                                                 self._acc.data_ptr(), total.ctypes.data))
+        self.last_total = (int(total[0]), int(total[1]))
+        return self._acc, [int(total[0]), int(total[1])]
+
+    def prove_trace(self, digest):
+        """The proof for the trace generate_trace() left on the device (public inputs: the last digest)."""
+        return self.prover.prove_rounds(lambda rnd, known: self._trace if rnd == 0 else self.round1(known), digest)
+
     def prove(self, messages):
         """Returns (proof bytes, digest words of the last message in the batch)."""
         blocks, first, want = blocks_for_messages(messages, self.log_blocks)
-        trace, digest = self.generate_trace(blocks, first)
+        _, digest = self.generate_trace(blocks, first)
         assert np.array_equal(digest, want)  # the GPU's chaining value is the real SHA-256 digest
-        return self.prover.prove(trace, digest), digest
+        return self.prove_trace(digest), digest
 
     def close(self):
         self.prover.close()
-        self._trace = None
+        self._trace = self._acc = None

@@ -41,7 +41,7 @@ def cases():
     blocks, first, digest = SA.blocks_for_messages([b"abc", b"near light client" * 4], 2)
     t, _ = SA.reference_trace(blocks, first)
     st = S.Stark(SA.sha256_air(), 4)
-    proof = orc.stark_prove(st.desc, t, digest)
+    proof = orc.stark_prove_rounds(st.desc, SA.cpu_rounds(blocks, first, t), digest)
     assert orc.stark_verify(st.desc, proof) == 1
     out["stark_sha256_4_blocks"] = {"bytes": len(proof), "sha256": hashlib.sha256(proof).hexdigest(),
                                     "program_words": int(st.desc.n_words)}

@@ -59,13 +59,24 @@ def test_reference_trace_is_sha256_and_satisfies_air(nlx):
     air = SA.sha256_air()
     words = air.compile()
     n = t.shape[1]
+    gamma = (0x0123456789abcdef, 0x0fedcba987654321)
+    acc, total = SA.binding_columns(blocks, first, gamma)
+    assert tuple(total) == SA.fingerprint(blocks, first, gamma)
+    full = np.concatenate([t, acc], axis=0)
+    values = [int(x) for x in digest] + list(gamma) + list(total)          # public inputs | challenges of round 0 | values of round 1
     for i in list(range(0, 9)) + [27, 28, 35, 36, 39, 40, n - 2, n - 1]:
-        vals = run_program(words, t[:, i], t[:, (i + 1) % n], digest, periodic=_periodic_values(SA, i))
-        assert len(vals) == 2042
+        vals = run_program(words, full[:, i], full[:, (i + 1) % n], values, periodic=_periodic_values(SA, i), n_public=8)
+        assert len(vals) == 2048
         for op, v in vals:
-            if (op == 8 and i != 0) or (op == 9 and i != n - 1):
+            if (op == 8 and i != 0) or (op == 9 and i != n - 1) or (op == 7 and i == n - 1):
                 continue
             assert v == 0, (i, op)
+    # the accumulator is bound: another value in a row, or another total, breaks a constraint
+    bad = full.copy()
+    bad[SA.ACC, 9] = (int(bad[SA.ACC, 9]) + 1) % P
+    assert any(v != 0 for _, v in run_program(words, bad[:, 8], bad[:, 9], values, periodic=_periodic_values(SA, 8), n_public=8))
+    vals = run_program(words, full[:, n - 1], full[:, 0], values[:10] + [(total[0] + 1) % P, total[1]], periodic=_periodic_values(SA, n - 1), n_public=8)
+    assert any(v != 0 for op, v in vals if op == 9)
 
 
 def test_header_hash_through_the_air(nlx):
@@ -90,9 +101,17 @@ def test_oracle_stark_on_sha256(nlx, orc):
     assert first.tolist() == [1, 1, 0, 1]
     t, _ = SA.reference_trace(blocks, first)
     st = S.Stark(SA.sha256_air(), 4)
-    assert st.desc.quotient_degree_factor == 2 and st.desc.n_periodic == 18 and st.desc.period_bits == 2
-    proof = orc.stark_prove(st.desc, t, digest)
+    assert st.desc.quotient_degree_factor == 2 and st.desc.n_periodic == 18 and st.desc.period_bits == 2 and st.desc.n_rounds == 2
+
+    def prove(trace, pis):
+        return orc.stark_prove_rounds(st.desc, SA.cpu_rounds(blocks, first, trace), pis)
+    proof = prove(t, digest)
     assert orc.stark_verify(st.desc, proof) == 1
+    vals = orc.stark_values(st.desc, proof)                      # digest | gamma | the fingerprint the proof carries
+    assert tuple(vals[10:12]) == SA.fingerprint(blocks, first, vals[8:10])
+    other = blocks.copy()
+    other[0, 0] ^= 1
+    assert tuple(vals[10:12]) != SA.fingerprint(other, first, vals[8:10])
     slot = SA.SLOT
     tampered = [(3 * slot + SA.oE + 3, 5), (SA.oA + 31, 0), (9 * slot + SA.oCA, 6), (2 * slot + SA.oCE + 1, 9), (4 * slot + SA.oW + 4, 5),
                 (4 * slot + SA.oSW, 6), (slot + SA.oCW, 13), (SA.PA + 40, 2), (SA.PE + 127, 15), (SA.IS_FIRST, 8), (SA.IS_FIRST, 4),
@@ -100,13 +119,13 @@ def test_oracle_stark_on_sha256(nlx, orc):
     for col, row in tampered:
         t2 = t.copy()
         t2[col, row] = (int(t2[col, row]) + 1) % P
-        assert orc.stark_verify(st.desc, orc.stark_prove(st.desc, t2, digest)) != 1, (col, row)
+        assert orc.stark_verify(st.desc, prove(t2, digest)) != 1, (col, row)
     d2 = digest.copy()
     d2[7] ^= np.uint64(1)
-    assert orc.stark_verify(st.desc, orc.stark_prove(st.desc, t, d2)) != 1
+    assert orc.stark_verify(st.desc, prove(t, d2)) != 1
     # a different message in row 0 of a block (free columns) is a different statement: the digest no longer matches
     t3, _ = SA.reference_trace(SA.blocks_for_messages([b"abd", bytes(range(100)), b"x"], 2)[0], first)
-    assert orc.stark_verify(st.desc, orc.stark_prove(st.desc, t3, digest)) != 1
+    assert orc.stark_verify(st.desc, prove(t3, digest)) != 1
 
 
 @pytest.mark.gpu
@@ -138,7 +157,7 @@ def test_gpu_sha256_proof_bytes_equal_oracle(nlx, ctx, orc, log_blocks):
     blocks, first, want_digest = SA.blocks_for_messages(msgs, log_blocks)
     assert np.array_equal(digest, want_digest)
     t, _ = SA.reference_trace(blocks, first)
-    want = orc.stark_prove(sp.stark.desc, t, digest)
+    want = orc.stark_prove_rounds(sp.stark.desc, SA.cpu_rounds(blocks, first, t), digest)
     assert len(proof) == len(want)
     if proof != want:
         a, b = np.frombuffer(proof, np.uint8), np.frombuffer(want, np.uint8)
