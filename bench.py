@@ -398,9 +398,7 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
     sp = make_prover(ctx, args.log_blocks, segment_nodes=args.segment_nodes)
 
     def prove_current(pis):
-        """prove the trace generate_trace() left on the device (SHA-256: two rounds, the second is the binding accumulator)"""
-        if wide:
-            return sp.prover.prove_into(sp._trace, pis.ctypes.data)
+        """prove the trace generate_trace() left on the device (two rounds: the second is the binding accumulator)"""
         return sp.prove_trace(pis)
     digest = None
     for _ in range(args.warmup):
@@ -429,7 +427,7 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
         assert np.array_equal(digest, want), "GPU chaining value is not the real digest"
         calls, ms, alg = kstats["hash_lde_leaves"]
         achieved = (alg / calls) / (ms / calls * 1e-3) / 1e9 if calls else 0.0
-        proof = sp.prover.prove(trace, pis_of(digest)) if wide else sp.prove_trace(pis_of(digest))
+        proof = sp.prove_trace(pis_of(digest))
         n_rows = SA.ROWS_PER_BLOCK << args.log_blocks
         out = {
             "metric": "%s STARK: compression blocks proved per second (secondary workload)" % ("SHA-512" if wide else "SHA-256"),
@@ -464,8 +462,7 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
             tr2, dg2 = sp2.generate_trace(b2, f2)
             host_trace = tr2.cpu().numpy().view(np.uint64)
             tc = time.time()
-            pr2 = (oracle_py.stark_prove(sp2.stark.desc, host_trace, pis_of(dg2)) if wide else
-                   oracle_py.stark_prove_rounds(sp2.stark.desc, SA.cpu_rounds(b2, f2, host_trace), dg2))
+            pr2 = oracle_py.stark_prove_rounds(sp2.stark.desc, SA.cpu_rounds(b2, f2, host_trace), pis_of(dg2))
             dtc = time.time() - tc
             ok = oracle_py.stark_verify(sp2.stark.desc, pr2) == 1
             sp2.close()

@@ -485,6 +485,10 @@ int32_t nlx_sha256_bind_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t log_
 #define NLX_SHA512_COLS 4745
 int32_t nlx_sha512_trace(nlx_ctx* ctx, const uint64_t* blocks, const uint8_t* is_first, uint32_t log_blocks,
                          uint64_t* trace_out, uint64_t digest_out[8]);
+/* Round 1 of the SHA-512 AIR: the binding accumulator for gamma (as nlx_sha256_bind_round; 64-bit words are absorbed as
+ * (low, high) halves: 33 elements on a block's first row, 16 on its last). */
+int32_t nlx_sha512_bind_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t log_blocks, const uint64_t gamma[2],
+                              uint64_t* acc_out, uint64_t total_out[2]);
 /* Synthetic wide-AIR witness (inputs only): n_cols (multiple of 4) x n column-major host buffer, k1 = the
  * n_cols/4 per-group constants of the AIR, public_inputs[2] = first-row values of columns 0 and 1. */
 int32_t nlx_synth_stark_trace(uint32_t n_cols, uint32_t log_n, uint64_t seed, const uint64_t* k1, uint64_t* trace,

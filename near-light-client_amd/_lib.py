@@ -114,6 +114,8 @@ SIGNATURES = {
                                                ctypes.c_void_p]),
     "nlx_sha256_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                           ctypes.c_void_p, ctypes.c_void_p]),
+    "nlx_sha512_bind_round": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p]),
     "nlx_sha512_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                           ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_synth_stark_trace": (ctypes.c_int32, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p,

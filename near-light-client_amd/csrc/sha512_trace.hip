@@ -6,7 +6,9 @@
 // Two kernels, as for SHA-256.  k_sha512_chain: one lane per message start walks that message's blocks and records
 // every block's input chaining value.  k_sha512_trace: one lane per trace row.
 #include "ctx.hpp"
+#include "gl.hpp"
 #include "transcript.hpp"
+#include <vector>
 
 namespace nlx {
 
@@ -180,9 +182,107 @@ __global__ __launch_bounds__(256) void k_sha512_trace(const uint64_t* __restrict
     put(cIS_FIRST, (q == 0 && (is_first[blk] || blk == 0)) ? 1u : 0u);
 }
 
+// ---- binding accumulator (round 1 of the AIR): Horner fingerprint in F_p^2 of every block's message-start flag, 16
+// message words and 8 output chaining words, 64-bit words as (low, high) halves, read back from the trace ----
+__device__ __forceinline__ uint64_t packed_half(const uint64_t* __restrict__ trace, size_t n, size_t row, uint32_t base) {
+    uint64_t v = 0;
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) v |= trace[(size_t)(base + i) * n + row] << i;
+    return v;
+}
+__device__ __forceinline__ gl::Ext absorb1(gl::Ext acc, gl::Ext gamma, uint64_t v) {
+    acc = gl::mul(acc, gamma);
+    acc.a = gl::add(acc.a, v);
+    return acc;
+}
+__device__ __forceinline__ gl::Ext sha512_absorb_head(gl::Ext acc, gl::Ext gamma, const uint64_t* __restrict__ trace, size_t n, size_t row0) {
+    acc = absorb1(acc, gamma, trace[(size_t)cIS_FIRST * n + row0]);
+    for (uint32_t j = 0; j < 16; j++) {
+        acc = absorb1(acc, gamma, packed_half(trace, n, row0, j * kSLOT + oW));
+        acc = absorb1(acc, gamma, packed_half(trace, n, row0, j * kSLOT + oW + 32));
+    }
+    return acc;
+}
+__device__ __forceinline__ gl::Ext sha512_absorb_tail(gl::Ext acc, gl::Ext gamma, const uint64_t* __restrict__ trace, size_t n, size_t row3) {
+    for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t base = (kSLOTS - 1 - (k & 3)) * kSLOT + (k < 4 ? oA : oE);
+        const uint64_t lo = trace[(size_t)(cHIN + 2 * k) * n + row3] + packed_half(trace, n, row3, base);
+        const uint64_t hi = trace[(size_t)(cHIN + 2 * k + 1) * n + row3] + packed_half(trace, n, row3, base + 32) + (lo >> 32);
+        acc = absorb1(acc, gamma, lo & 0xFFFFFFFFull);
+        acc = absorb1(acc, gamma, hi & 0xFFFFFFFFull);
+    }
+    return acc;
+}
+__global__ __launch_bounds__(64) void k_sha512_bind_block(const uint64_t* __restrict__ trace, uint32_t n_blocks, gl::Ext gamma,
+                                                          gl::Ext* __restrict__ block_fp) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const size_t n = (size_t)n_blocks << 2;
+    gl::Ext acc = sha512_absorb_head(gl::Ext{0, 0}, gamma, trace, n, (size_t)b * 4);
+    block_fp[b] = sha512_absorb_tail(acc, gamma, trace, n, (size_t)b * 4 + 3);
+}
+__global__ __launch_bounds__(64) void k_sha512_bind_rows(const uint64_t* __restrict__ trace, uint32_t n_blocks, gl::Ext gamma,
+                                                         const gl::Ext* __restrict__ start, uint64_t* __restrict__ out) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const size_t n = (size_t)n_blocks << 2, row0 = (size_t)b * 4;
+    const gl::Ext s0 = start[b], s1 = sha512_absorb_head(s0, gamma, trace, n, row0);
+    out[row0] = s0.a;
+    out[n + row0] = s0.b;
+    for (int q = 1; q < 4; q++) {
+        out[row0 + q] = s1.a;
+        out[n + row0 + q] = s1.b;
+    }
+}
+
 }  // namespace nlx
 
 using namespace nlx;
+
+extern "C" int32_t nlx_sha512_bind_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t log_blocks, const uint64_t gamma[2],
+                                         uint64_t* acc_out, uint64_t total_out[2]) {
+    if (!ctx) return NLX_E_INVAL;
+    if (!trace || !gamma || !acc_out || !total_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
+    if (log_blocks > 18) return ctx->fail(NLX_E_RANGE, "log_blocks must be <= 18");
+    (void)hipSetDevice(ctx->device);
+    const uint32_t n_blocks = 1u << log_blocks;
+    const size_t n = (size_t)n_blocks << 2;
+    Staged tr(ctx, trace, (size_t)NLX_SHA512_COLS * n * 8, true, false);
+    if (tr.status) return tr.status;
+    Staged so(ctx, acc_out, 2 * n * 8, false, true);
+    if (so.status) return so.status;
+    gl::Ext* d_fp = (gl::Ext*)ctx->alloc((size_t)n_blocks * sizeof(gl::Ext));
+    if (!d_fp) return NLX_E_NOMEM;
+    const gl::Ext g{gamma[0] % gl::P, gamma[1] % gl::P};
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_sha512_bind_block, dim3((n_blocks + 63) / 64), dim3(64), 0, st, tr.as<uint64_t>(), n_blocks, g, d_fp);
+    std::vector<gl::Ext> fp_h(n_blocks), start(n_blocks);
+    int32_t rc = fetch(ctx, fp_h.data(), d_fp, (size_t)n_blocks * sizeof(gl::Ext));
+    if (!rc) {
+        const gl::Ext g49 = gl::pow(g, 49);  // a block absorbs 33 + 16 elements
+        gl::Ext acc{0, 0};
+        for (uint32_t b = 0; b < n_blocks; b++) {
+            start[b] = acc;
+            acc = gl::add(gl::mul(acc, g49), fp_h[b]);
+        }
+        total_out[0] = acc.a;
+        total_out[1] = acc.b;
+        hipError_t e = hipMemcpyAsync(d_fp, start.data(), (size_t)n_blocks * sizeof(gl::Ext), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) rc = ctx->hip_fail(e, "hipMemcpyAsync");
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(k_sha512_bind_rows, dim3((n_blocks + 63) / 64), dim3(64), 0, st, tr.as<uint64_t>(), n_blocks, g, d_fp,
+                           so.as<uint64_t>());
+        rc = so.finish();
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    ctx->release(d_fp);
+    if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
+    hipError_t le = hipGetLastError();
+    if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
+    return rc;
+}
+
 
 extern "C" int32_t nlx_sha512_trace(nlx_ctx* ctx, const uint64_t* blocks, const uint8_t* is_first, uint32_t log_blocks,
                                     uint64_t* trace_out, uint64_t digest_out[8]) {

@@ -46,7 +46,8 @@ PE = PA + 256                   # 4456
 HIN = PE + 256                  # 4712
 CY = HIN + 16                   # 4728
 IS_FIRST = CY + 16              # 4744
-N_COLS = IS_FIRST + 1           # 4745
+N_COLS = IS_FIRST + 1           # 4745 (round 0)
+ACC = N_COLS                    # round 1: the binding accumulator, one element of F_p^2 = two base columns
 M64 = (1 << 64) - 1
 
 
@@ -81,7 +82,7 @@ def _halves(x):
 
 
 def sha512_air():
-    air = Air(N_COLS, 16)
+    air = Air(N_COLS + 2, 16, rounds=[(N_COLS, 2), (2, 0)], round_values=[0, 2])
     L, N = air.local, air.next  # noqa: N806
     two32 = 1 << 32
     k_slot = [[air.periodic([_halves(K[SLOTS * q + j])[h] for q in range(4)]) for h in range(2)] for j in range(SLOTS)]
@@ -165,12 +166,14 @@ def sha512_air():
     # Written word by word so that each word's packed halves are used while they are in registers.
     nb = 1 - is_q3
     air.constraint_first_row(L(IS_FIRST) - 1)
+    out_halves = []                                             # the block's output chaining value, (low, high) per word
     for k in range(8):
         base_out = a_base(SLOTS - 1 - k) if k < 4 else e_base(SLOTS - 1 - (k - 4))
         base_start = a_base(-k - 1) if k < 4 else e_base(-(k - 4) - 1)
         out, nxt, cur = word(base_out), word(base_start, True), word(base_start)
         lo = L(HIN + 2 * k) + out[0] - L(CY + 2 * k) * two32
         hi = L(HIN + 2 * k + 1) + out[1] + L(CY + 2 * k) - L(CY + 2 * k + 1) * two32
+        out_halves += [lo, hi]
         for h, ho in enumerate((lo, hi)):
             iv = _halves(IV[k])[h]
             air.constraint(nb * (nxt[h] - out[h]))
@@ -179,6 +182,29 @@ def sha512_air():
             air.constraint(is_q3 * (N(HIN + 2 * k + h) - nxt[h]))
             air.constraint_first_row(cur[h] - iv)
             air.constraint_last_row(ho - air.public(2 * k + h))
+
+    # 8. binding (as in sha256_air.py): a challenge gamma in F_p^2 and a round-1 accumulator fold every block's
+    # (message-start flag, 16 message words as (low, high) halves) - on its first row - and 8 output chaining words as
+    # halves - on its last row - into one Horner fingerprint; the total is a round value of the proof.
+    def ext_mul(x, y):
+        return x[0] * y[0] + x[1] * y[1] * 7, x[0] * y[1] + x[1] * y[0]
+    gamma = (air.challenge(0), air.challenge(1))
+
+    def horner(start, elems):
+        c0, c1 = start
+        for e in elems:
+            c0, c1 = ext_mul((c0, c1), gamma)
+            c0 = c0 + e
+        return c0, c1
+    acc = (L(ACC), L(ACC + 1))
+    msg = [L(IS_FIRST)]
+    for j in range(16):
+        msg += list(word(j * SLOT + oW))
+    after_head, after_tail = horner(acc, msg), horner(acc, out_halves)      # 33 elements on rows q = 0, 16 on rows q = 3
+    for c in range(2):
+        air.constraint_first_row(acc[c])
+        air.constraint_transition(N(ACC + c) - (acc[c] + is_q0 * (after_head[c] - acc[c]) + is_q3 * (after_tail[c] - acc[c])))
+        air.constraint_last_row(after_tail[c] - air.round_value(1, c))
     return air
 
 
@@ -313,6 +339,76 @@ def reference_trace(blocks, is_first):
     return t, np.array(h, dtype=np.uint64)
 
 
+def _ext_mul(x, y):
+    gl = 0xFFFFFFFF00000001
+    return (x[0] * y[0] + 7 * x[1] * y[1]) % gl, (x[0] * y[1] + x[1] * y[0]) % gl
+
+
+def block_outputs(blocks, is_first):
+    """output chaining value (eight 64-bit words) of every block"""
+    outs, h = [], list(IV)
+    for bi, blk in enumerate(blocks):
+        if is_first[bi] or bi == 0:
+            h = list(IV)
+        w = _schedule(blk)
+        a, b, c, d, e, f, g, hh = h
+        for r in range(ROUNDS):
+            t1 = (hh + (_rotr(e, 14) ^ _rotr(e, 18) ^ _rotr(e, 41)) + ((e & f) ^ (~e & g & M64)) + K[r] + w[r]) & M64
+            t2 = ((_rotr(a, 28) ^ _rotr(a, 34) ^ _rotr(a, 39)) + ((a & b) ^ (a & c) ^ (b & c))) & M64
+            hh, g, f, e, d, c, b, a = g, f, e, (d + t1) & M64, c, b, a, (t1 + t2) & M64
+        h = [(x + y) & M64 for x, y in zip(h, (a, b, c, d, e, f, g, hh))]
+        outs.append(list(h))
+    return outs
+
+
+def _block_elements(blk, first, out):
+    head = [1 if first else 0]
+    for wv in blk:
+        head += list(_halves(int(wv)))
+    tail = []
+    for wv in out:
+        tail += list(_halves(int(wv)))
+    return head, tail
+
+
+def fingerprint(blocks, is_first, gamma):
+    """What the proof's round value must be for these padded blocks: Horner in F_p^2 over, block by block, the message-start
+    flag, the 16 message words and the 8 output chaining words as (low, high) halves."""
+    gl = 0xFFFFFFFF00000001
+    acc = (0, 0)
+    for bi, (blk, out) in enumerate(zip(blocks, block_outputs(blocks, is_first))):
+        head, tail = _block_elements(blk, is_first[bi] or bi == 0, out)
+        for v in head + tail:
+            acc = _ext_mul(acc, gamma)
+            acc = ((acc[0] + v) % gl, acc[1])
+    return acc
+
+
+def binding_columns(blocks, is_first, gamma):
+    """Round-1 accumulator columns (2, 4 n_blocks) and the total, plain Python (tests and the oracle path)."""
+    gl = 0xFFFFFFFF00000001
+    out = np.zeros((2, ROWS_PER_BLOCK * len(blocks)), dtype=np.uint64)
+    acc = (0, 0)
+    for bi, (blk, ho) in enumerate(zip(blocks, block_outputs(blocks, is_first))):
+        head, tail = _block_elements(blk, is_first[bi] or bi == 0, ho)
+        for q in range(4):
+            out[0, 4 * bi + q], out[1, 4 * bi + q] = acc
+            for v in (head if q == 0 else (tail if q == 3 else [])):
+                acc = _ext_mul(acc, gamma)
+                acc = ((acc[0] + v) % gl, acc[1])
+    return out, acc
+
+
+def cpu_rounds(blocks, is_first, trace):
+    """round function for a CPU prover of this AIR: round 0 = the given trace, round 1 = the binding accumulator"""
+    def fn(rnd, known):
+        if rnd == 0:
+            return trace
+        cols, total = binding_columns(blocks, is_first, known[:2])
+        return cols, list(total)
+    return fn
+
+
 class Sha512Prover:
     """Proves SHA-512 of a batch of messages on one GPU: trace generation (nlx_sha512_trace) straight into HBM,
     then nlx_stark_prove on the device-resident trace.  2^log_blocks compression blocks per proof."""
@@ -328,7 +424,8 @@ class Sha512Prover:
             air.segment_nodes = segment_nodes
         self.stark = Stark(air, log_blocks + 2, config)
         self.prover = self.stark.build(ctx)
-        self._trace = None
+        self._trace = self._acc = None
+        self.last_total = None
 
     def generate_trace(self, blocks, is_first):
         """Returns (device trace tensor [N_COLS, n] int64, digest words uint64[8])."""
@@ -341,6 +438,7 @@ class Sha512Prover:
         n = ROWS_PER_BLOCK << self.log_blocks
         if self._trace is None:
             self._trace = torch.empty((N_COLS, n), dtype=torch.int64, device="cuda:%d" % self.ctx.device)
+            self._acc = torch.empty((2, n), dtype=torch.int64, device=self._trace.device)
         digest = np.zeros(8, dtype=np.uint64)
         self.ctx.check(dll.nlx_sha512_trace(self.ctx.handle, blocks.ctypes.data, is_first.ctypes.data, self.log_blocks,
                                             self._trace.data_ptr(), digest.ctypes.data))
@@ -351,8 +449,22 @@ class Sha512Prover:
         blocks, first, want = blocks_for_messages(messages, self.log_blocks)
         trace, digest = self.generate_trace(blocks, first)
         assert np.array_equal(digest, want)  # the GPU's chaining value is the real SHA-512 digest
-        return self.prover.prove(trace, digest_halves(digest)), digest
+        return self.prove_trace(digest_halves(digest)), digest
+
+    def round1(self, known):
+        """The binding accumulator for gamma = known[0:2] (device columns) and its total, the proof's round value."""
+        from ._lib import dll
+        gamma = np.array([int(known[0]), int(known[1])], dtype=np.uint64)
+        total = np.zeros(2, dtype=np.uint64)
+        self.ctx.check(dll.nlx_sha512_bind_round(self.ctx.handle, self._trace.data_ptr(), self.log_blocks, gamma.ctypes.data,
+                                                 self._acc.data_ptr(), total.ctypes.data))
+        self.last_total = (int(total[0]), int(total[1]))
+        return self._acc, [int(total[0]), int(total[1])]
+
+    def prove_trace(self, public_inputs):
+        """The proof for the trace generate_trace() left on the device (public inputs: the last digest's sixteen halves)."""
+        return self.prover.prove_rounds(lambda rnd, known: self._trace if rnd == 0 else self.round1(known), public_inputs)
 
     def close(self):
         self.prover.close()
-        self._trace = None
+        self._trace = self._acc = None

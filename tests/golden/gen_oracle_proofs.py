@@ -49,7 +49,7 @@ def cases():
     blocks, first, digest = SB.blocks_for_messages([b"abc", b"near light client" * 9], 2)
     t, _ = SB.reference_trace(blocks, first)
     st = S.Stark(SB.sha512_air(), 4)
-    proof = orc.stark_prove(st.desc, t, SB.digest_halves(digest))
+    proof = orc.stark_prove_rounds(st.desc, SB.cpu_rounds(blocks, first, t), SB.digest_halves(digest))
     assert orc.stark_verify(st.desc, proof) == 1
     out["stark_sha512_4_blocks"] = {"bytes": len(proof), "sha256": hashlib.sha256(proof).hexdigest(),
                                     "program_words": int(st.desc.n_words)}

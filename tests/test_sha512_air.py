@@ -63,11 +63,16 @@ def test_reference_trace_is_sha512_and_satisfies_air(nlx):
     words = air.compile()
     pis = SB.digest_halves(digest)
     n = t.shape[1]
+    gamma = (0x0123456789abcdef, 0x0fedcba987654321)
+    acc, total = SB.binding_columns(blocks, first, gamma)
+    assert tuple(total) == SB.fingerprint(blocks, first, gamma)
+    full = np.concatenate([t, acc], axis=0)
+    values = [int(x) for x in pis] + list(gamma) + list(total)
     for i in [0, 1, 2, 3, 4, 27, 28, 35, 36, 39, 40, n - 2, n - 1]:
-        vals = run_program(words, t[:, i], t[:, (i + 1) % n], pis, periodic=_periodic_values(SB, i))
-        assert len(vals) == air.num_constraints == 4946
+        vals = run_program(words, full[:, i], full[:, (i + 1) % n], values, periodic=_periodic_values(SB, i), n_public=16)
+        assert len(vals) == air.num_constraints == 4952
         for op, v in vals:
-            if (op == 8 and i != 0) or (op == 9 and i != n - 1):
+            if (op == 8 and i != 0) or (op == 9 and i != n - 1) or (op == 7 and i == n - 1):
                 continue
             assert v == 0, (i, op)
 
@@ -80,8 +85,13 @@ def test_oracle_stark_on_sha512(nlx, orc):
     st = S.Stark(SB.sha512_air(), 4)
     assert st.desc.quotient_degree_factor == 2 and st.desc.n_periodic == 42 and st.desc.period_bits == 2
     pis = SB.digest_halves(digest)
-    proof = orc.stark_prove(st.desc, t, pis)
+
+    def prove(trace, p_):
+        return orc.stark_prove_rounds(st.desc, SB.cpu_rounds(blocks, first, trace), p_)
+    proof = prove(t, pis)
     assert orc.stark_verify(st.desc, proof) == 1
+    vals = orc.stark_values(st.desc, proof)                      # digest halves | gamma | the fingerprint the proof carries
+    assert tuple(vals[18:20]) == SB.fingerprint(blocks, first, vals[16:18])
     slot = SB.SLOT
     tampered = [(3 * slot + SB.oE + 40, 5), (SB.oA + 63, 0), (9 * slot + SB.oCA, 6), (9 * slot + SB.oCA + 3, 6), (2 * slot + SB.oCE + 4, 9),
                 (4 * slot + SB.oW + 33, 5), (4 * slot + SB.oSW + 1, 6), (slot + SB.oCW + 2, 13), (SB.PA + 70, 2), (SB.PE + 255, 15),
@@ -89,10 +99,10 @@ def test_oracle_stark_on_sha512(nlx, orc):
     for col, row in tampered:
         t2 = t.copy()
         t2[col, row] = (int(t2[col, row]) + 1) % P
-        assert orc.stark_verify(st.desc, orc.stark_prove(st.desc, t2, pis)) != 1, (col, row)
+        assert orc.stark_verify(st.desc, prove(t2, pis)) != 1, (col, row)
     p2 = pis.copy()
     p2[9] ^= np.uint64(1)
-    assert orc.stark_verify(st.desc, orc.stark_prove(st.desc, t, p2)) != 1
+    assert orc.stark_verify(st.desc, prove(t, p2)) != 1
 
 
 @pytest.mark.gpu
@@ -124,7 +134,7 @@ def test_gpu_sha512_proof_bytes_equal_oracle(nlx, ctx, orc, log_blocks):
     blocks, first, want_digest = SB.blocks_for_messages(msgs, log_blocks)
     assert np.array_equal(digest, want_digest)
     t, _ = SB.reference_trace(blocks, first)
-    want = orc.stark_prove(sp.stark.desc, t, SB.digest_halves(digest))
+    want = orc.stark_prove_rounds(sp.stark.desc, SB.cpu_rounds(blocks, first, t), SB.digest_halves(digest))
     assert len(proof) == len(want)
     if proof != want:
         a, b = np.frombuffer(proof, np.uint8), np.frombuffer(want, np.uint8)
