@@ -13,6 +13,7 @@
 //    trace LDE is read in place - no second low-degree extension as in the reference flow;
 //  * quotient chunks come from per-coset inverse transforms + a 2^qdb-point DFT across cosets, as in the
 //    plonky2 path; commitments, openings and FRI are the same device code as nlx_prove.
+#include <algorithm>
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -269,6 +270,8 @@ struct nlx_stark {
     uint64_t* d_program = nullptr;
     std::vector<uint32_t> seg;        // {first word, end word} per program segment
     std::vector<uint32_t> seg_after;  // constraints emitted after each segment
+    std::vector<uint32_t> seg_regs;   // registers each segment uses (table sorted by this)
+    std::vector<uint32_t> seg_group;  // first segment of each launch group
     uint32_t* d_seg = nullptr;
     uint64_t* d_small = nullptr;  // FRI coset tables (rate_bits) | quotient coset tables (qdb) | w_A^-i
     uint64_t *d_coset_base = nullptr, *d_q_coset_base = nullptr, *d_q_zh_inv = nullptr, *d_q_wR_inv = nullptr,
@@ -330,8 +333,8 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
     }
     // program validation: opcodes, operand ranges, no register read before it is written
     std::vector<uint64_t> prog(d.program, d.program + d.n_words);
-    uint32_t n_regs = 1, n_emits = 0;
-    std::vector<uint32_t> seg_bounds, seg_emits;  // word index of each boundary, constraints emitted before it
+    uint32_t n_regs = 1, n_emits = 0, cur_regs = 1;
+    std::vector<uint32_t> seg_bounds, seg_emits, seg_regs;  // per boundary: word index, constraints emitted before it, registers of the segment it closes
     {
         bool written[NLX_AIR_NUM_REGS] = {false};
         for (uint32_t pc = 0; pc < d.n_words; pc++) {
@@ -351,6 +354,8 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
                 if (seg_bounds.size() + 2 > NLX_AIR_MAX_SEGMENTS) return ctx->fail(NLX_E_RANGE, "AIR: too many segments");
                 seg_bounds.push_back(pc);
                 seg_emits.push_back(n_emits);
+                seg_regs.push_back(cur_regs);
+                cur_regs = 1;
                 for (bool& wr : written) wr = false;
                 continue;
             }
@@ -401,6 +406,7 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
             if (writes) {
                 written[dst] = true;
                 if (dst + 1 > n_regs) n_regs = dst + 1;
+                if (dst + 1 > cur_regs) cur_regs = dst + 1;
             }
         }
     }
@@ -413,17 +419,30 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
     s->d.program = s->program.data();
     s->n_regs = n_regs;
     {
-        uint32_t lo = 0, before = 0;
+        // Segment table, sorted by register need: the quotient kernel is launched once per group of segments with a
+        // similar register file, because the LDS a launch reserves per wave is that of its hungriest segment (one
+        // 64-register segment among 17-register ones tripled the whole kernel's time before this).  The order of the
+        // table is free: every segment carries its own alpha power.
         seg_bounds.push_back(d.n_words);
         seg_emits.push_back(n_emits);
+        seg_regs.push_back(cur_regs);
+        struct SegRow { uint32_t lo, hi, after, regs; };
+        std::vector<SegRow> rows;
+        uint32_t lo = 0;
         for (size_t i = 0; i < seg_bounds.size(); i++) {
-            s->seg.push_back(lo);
-            s->seg.push_back(seg_bounds[i]);
-            s->seg_after.push_back(n_emits - seg_emits[i]);
+            rows.push_back(SegRow{lo, seg_bounds[i], n_emits - seg_emits[i], seg_regs[i]});
             lo = seg_bounds[i] + 1;
-            before = seg_emits[i];
         }
-        (void)before;
+        std::stable_sort(rows.begin(), rows.end(), [](const SegRow& a, const SegRow& b) { return a.regs < b.regs; });
+        for (const SegRow& r : rows) {
+            s->seg.push_back(r.lo);
+            s->seg.push_back(r.hi);
+            s->seg_after.push_back(r.after);
+            s->seg_regs.push_back(r.regs);
+        }
+        // groups: a new launch where the register need grows by more than a quarter over the group's first segment
+        for (uint32_t i = 0; i < rows.size(); i++)
+            if (i == 0 || rows[i].regs > s->seg_regs[s->seg_group.back()] + s->seg_regs[s->seg_group.back()] / 4 + 2) s->seg_group.push_back(i);
     }
     s->n_rounds = d.n_rounds ? d.n_rounds : 1;
     for (uint32_t r = 0; r < s->n_rounds; r++) {
@@ -646,9 +665,16 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
             // single-wave blocks pack the 160 KB of a CU at the finest granularity
             unsigned bs = 64;
             while (bs > n) bs >>= 1;
-            const size_t lds = (size_t)bs * s->n_regs * 8;
             ctx->begin_kernel("air_quotient", 8.0 * Q * (2.0 * ncols + nc));
-            hipLaunchKernelGGL(k_air_quotient, dim3((unsigned)(Q / bs), n_seg), dim3(bs), lds, st, ap);
+            for (size_t gi = 0; gi < s->seg_group.size(); gi++) {
+                const uint32_t first = s->seg_group[gi], last = gi + 1 < s->seg_group.size() ? s->seg_group[gi + 1] : n_seg;
+                AirParams gp = ap;
+                gp.seg = ap.seg + 2 * first;
+                gp.seg_mul = ap.seg_mul + 2 * first;
+                gp.part = n_seg > 1 ? ap.part + (size_t)first * nc * Q : nullptr;
+                const size_t lds = (size_t)bs * s->seg_regs[last - 1] * 8;  // the group's largest register file
+                hipLaunchKernelGGL(k_air_quotient, dim3((unsigned)(Q / bs), last - first), dim3(bs), lds, st, gp);
+            }
             if (n_seg > 1)
                 hipLaunchKernelGGL(k_air_combine, dim3((unsigned)((nc * Q + 255) / 256)), dim3(256), 0, st, d_part, s->d_q_zh_inv,
                                    d_qvals, n_seg, nc, log_n, log_n + qdb);
