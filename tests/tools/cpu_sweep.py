@@ -1,12 +1,12 @@
 """CPU side of BASELINE.json configs[0] (plumbing, no GPU): the oracle prover (C port, OpenMP) on the default
 nineteen-gate workload at several sizes.  Needs libnlx.so only for the workload generator (host code).
-    python tools/cpu_sweep.py [max_log_n]   ->  one JSON object per line"""
+    python tests/tools/cpu_sweep.py [max_log_n]   ->  one JSON object per line"""
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 cores = min(len(os.sched_getaffinity(0)), 16)

@@ -1,7 +1,10 @@
 """Differential fuzz (run on the GPU box): random gate mixes / sizes / public-input counts; GPU proof bytes must
-equal the oracle prover and the oracle verifier must accept.  `python tools/fuzz_plonk.py`."""
+equal the oracle prover and the oracle verifier must accept.  `python tests/tools/fuzz_plonk.py`."""
 import sys, time
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/oracle'); sys.path.insert(0,'/root/repo/tests')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for _p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, _p)
 import nlxpkg; nlx=nlxpkg.load()
 import oracle_py as orc
 import numpy as np
