@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark", "sha256", "sha512", "ed25519", "sync_starks"])
     ap.add_argument("--log-blocks", type=int, default=14, help="sha256 workload: 2^k compression blocks per proof")
-    ap.add_argument("--log-slots", type=int, default=10, help="ed25519 workload: 2^k signature slots per proof (>= 8)")
+    ap.add_argument("--log-slots", type=int, default=10, help="ed25519 workload: 2^k signature slots per proof (>= 4)")
     ap.add_argument("--segment-nodes", type=int, default=None, help="sha256 workload: AIR program segment size (0 = one segment)")
     ap.add_argument("--stark-cols", type=int, default=256)
     ap.add_argument("--log-n", type=int, default=16)
@@ -538,7 +538,7 @@ def run_ed25519(args, nlx, torch, rank, world, local, dist):
             cores = min(len(os.sched_getaffinity(0)), 16)
             os.environ["OMP_NUM_THREADS"] = str(cores)
             pr2 = pr if args.log_slots == 8 else E.Ed25519Prover(ctx, 8)
-            host = pr2.generate_trace(words[:256]).cpu().numpy().view(np.uint64)
+            host = pr2.generate_trace(np.tile(words, (4, 1))[:256]).cpu().numpy().view(np.uint64)
             tc = time.time()
             def cpu_round1(known):
                 acc, total = E.binding_columns(host, known[2:4])
@@ -588,7 +588,7 @@ def run_sync_starks(args, nlx, torch, rank, world, local, dist):
     n_sigs = len(slots)
     lb256 = max(2, (sum(len(SA.pad_message(m)) for m in sha_msgs) - 1).bit_length())
     lb512 = max(2, (n_sigs - 1).bit_length())
-    log_slots = max(8, (n_sigs - 1).bit_length())
+    log_slots = max(4, (n_sigs - 1).bit_length())           # below 2^8 slots the range table is spread over several columns
     slot_words = E.slots_to_words((slots * ((1 << log_slots) // n_sigs + 1))[: 1 << log_slots])
     # the four proofs are independent: each gets its own context (HIP stream + scratch) and, in the
     # concurrent mode, its own host thread - the small latency-bound STARKs then run under the Ed25519 one

@@ -431,12 +431,17 @@ int32_t nlx_stark_batch_prove(nlx_stark* const* workers, uint32_t n_workers, nlx
  *   nlx_logup_round: for alpha = alpha[0] + alpha[1] X writes the nlx_logup_round_cols(n_lookups) round-1 columns into
  *     out: helpers h_j = 1/(alpha+v_2j) + 1/(alpha+v_2j+1) (two base columns each), g = m/(alpha+t) with t(i) = i mod
  *     2^table_bits, and the running sum phi(0) = 0, phi(i+1) = phi(i) + sum_j h_j(i) - g(i).
+ * table_cols (a power of two, normally 1): the table may be spread over that many periodic columns of period
+ * P = 2^table_bits / table_cols, column c holding c P + (i mod P), so that a trace shorter than the table can carry it;
+ * mult_col is then the first of table_cols consecutive multiplicity columns (value v counts in column v / P, row v mod P)
+ * and the round has one g per table column: helpers | g_0 .. g_(table_cols-1) | phi.
  * Both may be called from inside an nlx_round_fn callback on the same context. */
 int32_t nlx_logup_multiplicities(nlx_ctx* ctx, uint64_t* trace, uint32_t n_cols, uint32_t log_n, const uint32_t* cols,
-                                 uint32_t n_lookups, uint32_t table_bits, uint32_t mult_col);
-uint32_t nlx_logup_round_cols(uint32_t n_lookups);
+                                 uint32_t n_lookups, uint32_t table_bits, uint32_t table_cols, uint32_t mult_col);
+uint32_t nlx_logup_round_cols(uint32_t n_lookups, uint32_t table_cols);
 int32_t nlx_logup_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t n_cols, uint32_t log_n, const uint32_t* cols,
-                        uint32_t n_lookups, uint32_t table_bits, uint32_t mult_col, const uint64_t alpha[2], uint64_t* out);
+                        uint32_t n_lookups, uint32_t table_bits, uint32_t table_cols, uint32_t mult_col, const uint64_t alpha[2],
+                        uint64_t* out);
 /* a12: the multiplication unit mod 2^255 - 19 (the field under the Ed25519 verifications of
  * curta_eddsa_verify_sigs_conditional, nearx/src/builder.rs:152) as a stand-alone chip: one a * b = c (mod p) per row.
  * Constraints: near-light-client_amd/fp25519.py::FpMulChip.  a, b: 2^log_rows operands of four little-endian 64-bit
@@ -449,8 +454,9 @@ int32_t nlx_fp25519_chip_trace(nlx_ctx* ctx, const uint64_t* a, const uint64_t* 
  * near-light-client_amd/ed25519_air.py; caller in the reference: curta_eddsa_verify_sigs_conditional,
  * nearx/src/builder.rs:152).  slots: 2^log_slots signatures, each six 256-bit little-endian numbers of four 64-bit
  * words: A.x, A.y, R.x, R.y (affine, reduced), S, h (the SHA-512 digest reduced mod L).  Writes the NLX_ED25519_COLS0 x
- * (256 << log_slots) round-0 trace (host or device), the two multiplicity columns (2^16 table, 2^9 table of the
- * carries' high parts) zeroed (nlx_logup_multiplicities fills them).  Returns NLX_E_INVAL naming the first slot whose statement is false (the signature does not verify, or a point
+ * (256 << log_slots) round-0 trace (host or device), the two multiplicity columns (2^9 table of the carries' high parts,
+ * then the 2^16 table - last, so that a proof of fewer than 2^8 slots can append the further multiplicity columns of a
+ * table spread over several columns) zeroed (nlx_logup_multiplicities fills them).  Returns NLX_E_INVAL naming the first slot whose statement is false (the signature does not verify, or a point
  * is off the curve): no trace satisfies the AIR for it. */
 #define NLX_ED25519_COLS0 1418
 int32_t nlx_ed25519_trace(nlx_ctx* ctx, const uint64_t* slots, uint32_t log_slots, uint64_t* trace_out);

@@ -102,10 +102,11 @@ SIGNATURES = {
                                                ctypes.c_void_p]),
     "nlx_stark_batch_prove": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t]),
     "nlx_logup_multiplicities": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
-                                                  ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
-    "nlx_logup_round_cols": (ctypes.c_uint32, [ctypes.c_uint32]),
+                                                  ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
+    "nlx_logup_round_cols": (ctypes.c_uint32, [ctypes.c_uint32, ctypes.c_uint32]),
     "nlx_logup_round": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
-                                         ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),
+                                         ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                         ctypes.c_void_p]),
     "nlx_fp25519_chip_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "nlx_ed25519_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "nlx_ed25519_bind_round": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,

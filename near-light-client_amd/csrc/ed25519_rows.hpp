@@ -15,8 +15,8 @@ constexpr int ROWS = 256, N_MAIN = 15, UNIT_CELLS = fp::UNIT_CELLS;
 constexpr uint32_t cSIN = 0, cSB = 48, cHB = 49, cSA = 50, cHA = 51, cAX = 52, cAY = 68, cRX = 84, cRY = 100, cNT = 116,
                    cSW = 132, cHW = 148, cCHK = 164, cSAA = 168, cSBB = 184, cSCC = 200, cSX3 = 216, cSY3 = 232, cSZ3 = 248,
                    cSPT = 264, cP2 = 280, cMAIN = 344, cAUX_A = cMAIN + N_MAIN * UNIT_CELLS, cAUX_B = cAUX_A + 16,
-                   cAUX_E = cAUX_B + 16, cAUX_F = cAUX_E + 16, cAUX = cAUX_F + 16, cMULT = cAUX + UNIT_CELLS,
-                   cMULT9 = cMULT + 1, N_COLS0 = cMULT9 + 1;
+                   cAUX_E = cAUX_B + 16, cAUX_F = cAUX_E + 16, cAUX = cAUX_F + 16, cMULT9 = cAUX + UNIT_CELLS,
+                   cMULT = cMULT9 + 1, N_COLS0 = cMULT + 1;  // further multiplicity columns of a spread table follow (caller's)
 enum { U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2, U_PA, U_PB, U_PC, U_PD, U_X4, U_Y4, U_Z4 };
 enum { STEP_YCMP = 0, STEP_A_U = 1, STEP_A_NT = 2, STEP_A_U2 = 3, STEP_A_V = 4, STEP_A_CHK = 5, STEP_R_U = 6, STEP_R_V = 7,
        STEP_R_CHK = 8, STEP_S_AA = 9, STEP_S_BB = 10, STEP_S_CC = 11, STEP_S_X = 12, STEP_S_Y = 13, STEP_S_Z = 14, STEP_S_T = 15,

@@ -20,7 +20,7 @@ constexpr uint32_t COUNT_BINS = 1u << 14;
 constexpr uint32_t COUNT_THREADS = 1024;
 
 __global__ __launch_bounds__(COUNT_THREADS) void k_logup_count(const uint64_t* __restrict__ trace, const uint32_t* __restrict__ cols,
-                                                               uint32_t log_n, uint32_t n_lookups, uint32_t table_bits,
+                                                               uint32_t log_n, uint32_t n_lookups, uint32_t table_bits, uint32_t period_bits,
                                                                unsigned long long* __restrict__ mult, uint32_t* __restrict__ err) {
     __shared__ uint32_t bins[COUNT_BINS];
     const size_t total = (size_t)n_lookups << log_n;
@@ -42,7 +42,11 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_logup_count(const uint64_t* _
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < COUNT_BINS; i += COUNT_THREADS) {
             const uint32_t c = bins[i];
-            if (c) atomicAdd(mult + ((size_t)pass << 14) + i, (unsigned long long)c);
+            if (c) {
+                // value v = pass 2^14 + i lives in table column v >> period_bits, row v mod 2^period_bits
+                const uint32_t v = (pass << 14) + i;
+                atomicAdd(mult + ((size_t)(v >> period_bits) << log_n) + (v & ((1u << period_bits) - 1)), (unsigned long long)c);
+            }
         }
         __syncthreads();
     }
@@ -53,7 +57,7 @@ struct LogupParams {
     const uint32_t* cols;
     uint64_t* out;  // [2 H + 4][n]
     uint64_t alpha[2];
-    uint32_t log_n, n_lookups, table_bits, mult_col;
+    uint32_t log_n, n_lookups, table_bits, mult_col, table_cols, period_bits;
 };
 
 // One lane per (row, group of HELPERS_PER_LANE helpers).  h = 1/d1 + 1/d2 = (d1 + d2) / (d1 d2), and the denominators
@@ -99,7 +103,8 @@ __global__ __launch_bounds__(256) void k_logup_helpers(LogupParams p) {
     }
 }
 
-// one lane per row: g = m / (alpha + t), and the row's contribution sum h - g into the phi columns (scanned next)
+// one lane per row: g_c = m_c / (alpha + t_c) for every table column c, and the row's contribution sum h - sum g into the
+// phi columns (scanned next)
 __global__ __launch_bounds__(256) void k_logup_rowsum(LogupParams p) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> p.log_n) return;
@@ -107,15 +112,17 @@ __global__ __launch_bounds__(256) void k_logup_rowsum(LogupParams p) {
     gl::Ext acc{0, 0};
     for (uint32_t j = 0; j < H; j++)
         acc = gl::add(acc, gl::Ext{p.out[((size_t)(2 * j) << p.log_n) + i], p.out[((size_t)(2 * j + 1) << p.log_n) + i]});
-    const uint64_t t = (uint64_t)(i & (((size_t)1 << p.table_bits) - 1));
-    const uint64_t m = p.trace[((size_t)p.mult_col << p.log_n) + i];
-    const gl::Ext g = gl::mul(gl::inv(gl::add(gl::Ext{p.alpha[0], p.alpha[1]}, gl::ext(t))), m);
     uint64_t* gcol = p.out + ((size_t)(2 * H) << p.log_n);
-    gcol[i] = g.a;
-    gcol[((size_t)1 << p.log_n) + i] = g.b;
-    const gl::Ext d = gl::sub(acc, g);
-    gcol[((size_t)2 << p.log_n) + i] = d.a;
-    gcol[((size_t)3 << p.log_n) + i] = d.b;
+    for (uint32_t c = 0; c < p.table_cols; c++) {
+        const uint64_t t = ((uint64_t)c << p.period_bits) + (uint64_t)(i & (((size_t)1 << p.period_bits) - 1));
+        const uint64_t m = p.trace[((size_t)(p.mult_col + c) << p.log_n) + i];
+        const gl::Ext g = gl::mul(gl::inv(gl::add(gl::Ext{p.alpha[0], p.alpha[1]}, gl::ext(t))), m);
+        gcol[((size_t)(2 * c) << p.log_n) + i] = g.a;
+        gcol[((size_t)(2 * c + 1) << p.log_n) + i] = g.b;
+        acc = gl::sub(acc, g);
+    }
+    gcol[((size_t)(2 * p.table_cols) << p.log_n) + i] = acc.a;
+    gcol[((size_t)(2 * p.table_cols + 1) << p.log_n) + i] = acc.b;
 }
 
 // ---- additive exclusive scan in F_p (blockIdx.y = column) ----
@@ -196,21 +203,27 @@ static size_t add_scan_scratch_words(size_t count, uint32_t ncol) {
 using namespace nlx;
 
 static int32_t logup_check(nlx_ctx* ctx, const void* trace, uint32_t n_cols, uint32_t log_n, const uint32_t* cols,
-                           uint32_t n_lookups, uint32_t table_bits, uint32_t mult_col) {
+                           uint32_t n_lookups, uint32_t table_bits, uint32_t table_cols, uint32_t mult_col, uint32_t* period_bits) {
     if (!trace || !cols) return ctx->fail(NLX_E_INVAL, "NULL argument");
-    if (log_n < 1 || log_n > 26 || table_bits < 1 || table_bits > 16 || table_bits > log_n)
-        return ctx->fail(NLX_E_RANGE, "need 1 <= table_bits <= min(16, log_n) and log_n <= 26");
-    if (n_lookups == 0 || n_lookups > 8192 || n_cols > 8192 || mult_col >= n_cols)
+    uint32_t lk = 0;
+    while ((1u << lk) < table_cols) lk++;
+    if (table_cols == 0 || (1u << lk) != table_cols || lk > 8) return ctx->fail(NLX_E_RANGE, "table_cols must be a power of two <= 256");
+    if (log_n < 1 || log_n > 26 || table_bits < 1 || table_bits > 16 || lk > table_bits || table_bits - lk > log_n)
+        return ctx->fail(NLX_E_RANGE, "need 1 <= table_bits <= 16, 2^table_bits / table_cols <= 2^log_n and log_n <= 26");
+    if (n_lookups == 0 || n_lookups > 8192 || n_cols > 8192 || mult_col + table_cols > n_cols)
         return ctx->fail(NLX_E_RANGE, "lookup count / column index out of range");
     for (uint32_t l = 0; l < n_lookups; l++)
-        if (cols[l] >= n_cols || cols[l] == mult_col) return ctx->fail(NLX_E_RANGE, "lookup %u: column out of range", l);
+        if (cols[l] >= n_cols || (cols[l] >= mult_col && cols[l] < mult_col + table_cols))
+            return ctx->fail(NLX_E_RANGE, "lookup %u: column out of range", l);
+    *period_bits = table_bits - lk;
     return NLX_OK;
 }
 
 extern "C" int32_t nlx_logup_multiplicities(nlx_ctx* ctx, uint64_t* trace, uint32_t n_cols, uint32_t log_n, const uint32_t* cols,
-                                            uint32_t n_lookups, uint32_t table_bits, uint32_t mult_col) {
+                                            uint32_t n_lookups, uint32_t table_bits, uint32_t table_cols, uint32_t mult_col) {
     if (!ctx) return NLX_E_INVAL;
-    int32_t rc = logup_check(ctx, trace, n_cols, log_n, cols, n_lookups, table_bits, mult_col);
+    uint32_t pb = 0;
+    int32_t rc = logup_check(ctx, trace, n_cols, log_n, cols, n_lookups, table_bits, table_cols, mult_col, &pb);
     if (rc) return rc;
     (void)hipSetDevice(ctx->device);
     const size_t n = (size_t)1 << log_n;
@@ -223,13 +236,13 @@ extern "C" int32_t nlx_logup_multiplicities(nlx_ctx* ctx, uint64_t* trace, uint3
     uint64_t* mult = tr.as<uint64_t>() + (size_t)mult_col * n;
     hipError_t e = hipMemcpyAsync(d_cols, cols, (size_t)n_lookups * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(mult, 0, n * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(mult, 0, n * 8 * table_cols, st);
     uint32_t err = 0;
     if (e == hipSuccess) {
         const size_t total = (size_t)n_lookups << log_n;
         const unsigned blocks = (unsigned)(total < ((size_t)512 << 12) ? (total + 4095) / 4096 : 512);  // >= 4096 cells per block
         hipLaunchKernelGGL(k_logup_count, dim3(blocks), dim3(COUNT_THREADS), 0, st, tr.as<uint64_t>(), d_cols, log_n, n_lookups,
-                           table_bits, (unsigned long long*)mult, d_err);
+                           table_bits, pb, (unsigned long long*)mult, d_err);
         e = hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) rc = tr.finish();
@@ -240,18 +253,19 @@ extern "C" int32_t nlx_logup_multiplicities(nlx_ctx* ctx, uint64_t* trace, uint3
     return rc;
 }
 
-extern "C" uint32_t nlx_logup_round_cols(uint32_t n_lookups) { return 2 * ((n_lookups + 1) / 2) + 4; }
+extern "C" uint32_t nlx_logup_round_cols(uint32_t n_lookups, uint32_t table_cols) { return 2 * ((n_lookups + 1) / 2) + 2 * table_cols + 2; }
 
 extern "C" int32_t nlx_logup_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t n_cols, uint32_t log_n, const uint32_t* cols,
-                                   uint32_t n_lookups, uint32_t table_bits, uint32_t mult_col, const uint64_t alpha[2],
-                                   uint64_t* out) {
+                                   uint32_t n_lookups, uint32_t table_bits, uint32_t table_cols, uint32_t mult_col,
+                                   const uint64_t alpha[2], uint64_t* out) {
     if (!ctx) return NLX_E_INVAL;
-    int32_t rc = logup_check(ctx, trace, n_cols, log_n, cols, n_lookups, table_bits, mult_col);
+    uint32_t pb = 0;
+    int32_t rc = logup_check(ctx, trace, n_cols, log_n, cols, n_lookups, table_bits, table_cols, mult_col, &pb);
     if (rc) return rc;
     if (!alpha || !out) return ctx->fail(NLX_E_INVAL, "NULL argument");
     (void)hipSetDevice(ctx->device);
     const size_t n = (size_t)1 << log_n;
-    const uint32_t H = (n_lookups + 1) / 2, n_out = 2 * H + 4;
+    const uint32_t H = (n_lookups + 1) / 2, n_out = 2 * H + 2 * table_cols + 2;
     Staged tr(ctx, trace, (size_t)n_cols * n * 8, true, false);
     if (tr.status) return tr.status;
     Staged so(ctx, out, (size_t)n_out * n * 8, false, true);
@@ -267,10 +281,11 @@ extern "C" int32_t nlx_logup_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t
         p.trace = tr.as<uint64_t>(); p.cols = d_cols; p.out = so.as<uint64_t>();
         p.alpha[0] = alpha[0] % gl::P; p.alpha[1] = alpha[1] % gl::P;
         p.log_n = log_n; p.n_lookups = n_lookups; p.table_bits = table_bits; p.mult_col = mult_col;
+        p.table_cols = table_cols; p.period_bits = pb;
         const unsigned blocks = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_logup_helpers, dim3(blocks, (H + HELPERS_PER_LANE - 1) / HELPERS_PER_LANE), dim3(256), 0, st, p);
         hipLaunchKernelGGL(k_logup_rowsum, dim3(blocks), dim3(256), 0, st, p);
-        launch_add_scan(st, p.out + (size_t)(2 * H + 2) * n, n, n, 2, d_scratch);
+        launch_add_scan(st, p.out + (size_t)(2 * H + 2 * table_cols) * n, n, n, 2, d_scratch);
         rc = so.finish();
         e = hipStreamSynchronize(st);
     }

@@ -93,12 +93,20 @@ N_MAIN = 15
 MAIN = [LAY.take_unit() for _ in range(N_MAIN)]
 AUX_A, AUX_B, AUX_E, AUX_F = (LAY.take(16) for _ in range(4))
 AUX = LAY.take_unit()
-MULT, MULT9 = LAY.take(1), LAY.take(1)     # multiplicities of the 2^16 table and of the 2^9 table
-N_COLS0 = LAY.n
+MULT9, MULT = LAY.take(1), LAY.take(1)     # multiplicities of the 2^9 table, then (last: it may grow) of the 2^16 table
 LOOKUPS, LOOKUPS9 = list(LAY.lookups16), list(LAY.lookups9)
-N_COLS1A, N_COLS1B = logup.round_cols(len(LOOKUPS)), logup.round_cols(len(LOOKUPS9))
-ACC = N_COLS0 + N_COLS1A + N_COLS1B       # round 1: after the lookup columns, the fingerprint accumulator (2 base columns)
-N_COLS1 = N_COLS1A + N_COLS1B + 2
+
+
+def layout(table_cols=1):
+    """Column counts when the 2^16 table is spread over `table_cols` columns (proofs of fewer than 2^8 slots: a trace of
+    2^15 rows carries the table in two columns of 2^15, and so on): the multiplicity columns MULT .. MULT + table_cols - 1
+    close round 0; round 1 = lookup columns of the 2^16 table, of the 2^9 table, the fingerprint accumulator."""
+    n0 = LAY.n + table_cols - 1
+    n1a, n1b = logup.round_cols(len(LOOKUPS), table_cols), logup.round_cols(len(LOOKUPS9))
+    return dict(n_cols0=n0, n_cols1a=n1a, n_cols1b=n1b, acc=n0 + n1a + n1b, n_cols1=n1a + n1b + 2)
+
+
+N_COLS0, N_COLS1A, N_COLS1B, ACC, N_COLS1 = (layout()[k] for k in ("n_cols0", "n_cols1a", "n_cols1b", "acc", "n_cols1"))
 BOUND = (AX, AY, RX, RY, SW, HW)           # the per-slot limb vectors the fingerprint absorbs, limb 15 first
 # main unit indices
 (U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2, U_PA, U_PB, U_PC, U_PD, U_X4, U_Y4, U_Z4) = range(N_MAIN)
@@ -130,8 +138,10 @@ class _Vec:
         return _Vec(lambda: [a * k for a in self.limbs], self.bound * abs(k))
 
 
-def ed25519_air(max_resident_leaves=None):
-    air = Air(N_COLS0 + N_COLS1, 0, rounds=[(N_COLS0, 4), (N_COLS1, 0)], round_values=[0, 2])
+def ed25519_air(max_resident_leaves=None, table_cols=1):
+    lay = layout(table_cols)
+    ACC = lay["acc"]  # noqa: N806  (shadows the module constant, which is the table_cols = 1 value)
+    air = Air(lay["n_cols0"] + lay["n_cols1"], 0, rounds=[(lay["n_cols0"], 4), (lay["n_cols1"], 0)], round_values=[0, 2])
     if max_resident_leaves is not None:
         air.max_resident_leaves = max_resident_leaves
     L, N = air.local, air.next  # noqa: N806
@@ -319,8 +329,8 @@ def ed25519_air(max_resident_leaves=None):
         air.constraint_first_row(acc[c])
         air.constraint_transition(N(ACC + c) - (acc[c] + limb_end * grown[c] + absorbed[c]))
         air.constraint_last_row(total[c] + last_word[c] - air.round_value(1, c))
-    rc = logup.RangeCheck(air, LOOKUPS, 16, MULT, N_COLS0)
-    rc9 = logup.RangeCheck(air, LOOKUPS9, fp.CARRY_HI_BITS, MULT9, N_COLS0 + N_COLS1A)
+    rc = logup.RangeCheck(air, LOOKUPS, 16, MULT, lay["n_cols0"], table_cols=table_cols)
+    rc9 = logup.RangeCheck(air, LOOKUPS9, fp.CARRY_HI_BITS, MULT9, lay["n_cols0"] + lay["n_cols1a"])
     return air, (rc, rc9)
 
 
@@ -575,10 +585,13 @@ class Ed25519Stark:
     """The AIR compiled for 2^log_slots signature slots (256 rows each)."""
 
     def __init__(self, log_slots, config=None, max_resident_leaves=None):
-        if log_slots < 8:
-            raise ValueError("at least 2^8 slots per proof (the 2^16-entry range table needs 2^16 rows)")
+        if log_slots < 4:
+            raise ValueError("at least 2^4 slots per proof")
         self.log_slots = log_slots
-        self.air, self.range_checks = ed25519_air(max_resident_leaves)
+        # below 2^8 slots the trace is shorter than the 2^16-entry range table: spread the table over several columns
+        self.table_cols = 1 << max(0, 8 - log_slots)
+        self.layout = layout(self.table_cols)
+        self.air, self.range_checks = ed25519_air(max_resident_leaves, self.table_cols)
         self.stark = Stark(self.air, log_slots + 8, config)
 
 
@@ -605,8 +618,8 @@ class Ed25519Prover:
         n = n_slots * ROWS
         if self._t0 is None:
             dev = "cuda:%d" % self.ctx.device
-            self._t0 = torch.empty((N_COLS0, n), dtype=torch.int64, device=dev)
-            self._t1 = torch.empty((N_COLS1, n), dtype=torch.int64, device=dev)
+            self._t0 = torch.empty((self.es.layout["n_cols0"], n), dtype=torch.int64, device=dev)
+            self._t1 = torch.empty((self.es.layout["n_cols1"], n), dtype=torch.int64, device=dev)
         words = np.ascontiguousarray(words, dtype=np.uint64)
         self.ctx.check(dll.nlx_ed25519_trace(self.ctx.handle, words.ctypes.data, self.es.log_slots, self._t0.data_ptr()))
         for rc in self.es.range_checks:
@@ -619,11 +632,12 @@ class Ed25519Prover:
         from ._lib import dll
         alpha, gamma = known[:2], np.array([int(known[2]), int(known[3])], dtype=np.uint64)
         rc16, rc9 = self.es.range_checks
-        rc16.round1(self.ctx, self._t0, alpha, self._t1[:N_COLS1A])
-        rc9.round1(self.ctx, self._t0, alpha, self._t1[N_COLS1A:N_COLS1A + N_COLS1B])
+        n1a, n1b = self.es.layout["n_cols1a"], self.es.layout["n_cols1b"]
+        rc16.round1(self.ctx, self._t0, alpha, self._t1[:n1a])
+        rc9.round1(self.ctx, self._t0, alpha, self._t1[n1a:n1a + n1b])
         total = np.zeros(2, dtype=np.uint64)
         self.ctx.check(dll.nlx_ed25519_bind_round(self.ctx.handle, self._t0.data_ptr(), self.es.log_slots, gamma.ctypes.data,
-                                                  self._t1[N_COLS1A + N_COLS1B:].data_ptr(), total.ctypes.data))
+                                                  self._t1[n1a + n1b:].data_ptr(), total.ctypes.data))
         self.last_total = (int(total[0]), int(total[1]))
         return self._t1, [int(total[0]), int(total[1])]
 

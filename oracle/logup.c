@@ -13,32 +13,41 @@
 #include <stdlib.h>
 #include <string.h>
 
-/* multiplicities: the count of value v goes to row v.  Returns 1, or 0 if a looked-up cell is outside the table. */
+/* The table {0 .. 2^bits - 1} may be spread over `table_cols` (a power of two) periodic columns of period
+ * P = 2^bits / table_cols, column j holding j P + (i mod P): a short trace can then carry a table longer than itself.
+ * multiplicities: `mult` is table_cols consecutive columns; the count of value v goes to column v / P, row v mod P.
+ * Returns 1, or 0 if a looked-up cell is outside the table. */
 int orc_logup_multiplicities(const uint64_t* trace, uint32_t log_n, const uint32_t* cols, uint32_t n_lookups,
-                             uint32_t table_bits, uint64_t* mult) {
+                             uint32_t table_bits, uint32_t table_cols, uint64_t* mult) {
     const size_t n = (size_t)1 << log_n;
-    if (table_bits > log_n) return 0;
-    memset(mult, 0, 8 * n);
+    uint32_t lk = 0;
+    while ((1u << lk) < table_cols) lk++;
+    if ((1u << lk) != table_cols || lk > table_bits || table_bits - lk > log_n) return 0;
+    const uint32_t pb = table_bits - lk;
+    memset(mult, 0, 8 * n * table_cols);
     for (uint32_t l = 0; l < n_lookups; l++) {
         const uint64_t* col = trace + (size_t)cols[l] * n;
         for (size_t i = 0; i < n; i++) {
             if (col[i] >> table_bits) return 0;
-            mult[col[i]]++;
+            mult[(size_t)(col[i] >> pb) * n + (col[i] & (((uint64_t)1 << pb) - 1))]++;
         }
     }
     return 1;
 }
 
-uint32_t orc_logup_round_cols(uint32_t n_lookups) { return 2 * ((n_lookups + 1) / 2) + 4; }
+uint32_t orc_logup_round_cols(uint32_t n_lookups, uint32_t table_cols) { return 2 * ((n_lookups + 1) / 2) + 2 * table_cols + 2; }
 
+/* out: helpers (2 H columns), g_0 .. g_(table_cols-1) (two columns each), phi (two columns) */
 void orc_logup_round(const uint64_t* trace, uint32_t log_n, const uint32_t* cols, uint32_t n_lookups, uint32_t table_bits,
-                     const uint64_t* mult, const uint64_t alpha[2], uint64_t* out) {
+                     uint32_t table_cols, const uint64_t* mult, const uint64_t alpha[2], uint64_t* out) {
     const size_t n = (size_t)1 << log_n;
     const uint32_t H = (n_lookups + 1) / 2;
+    uint32_t lk = 0;
+    while ((1u << lk) < table_cols) lk++;
+    const uint32_t pb = table_bits - lk;
     const gl2 al = gl2_make(alpha[0] % GL_P, alpha[1] % GL_P);
-    uint64_t* g0 = out + (size_t)(2 * H) * n;
-    uint64_t* g1 = g0 + n;
-    uint64_t* phi0 = g1 + n;
+    uint64_t* gcols = out + (size_t)(2 * H) * n;
+    uint64_t* phi0 = gcols + (size_t)(2 * table_cols) * n;
     uint64_t* phi1 = phi0 + n;
     gl2* rowsum = (gl2*)malloc(sizeof(gl2) * n);
 #pragma omp parallel for schedule(static)
@@ -51,11 +60,14 @@ void orc_logup_round(const uint64_t* trace, uint32_t log_n, const uint32_t* cols
             out[(size_t)(2 * j + 1) * n + i] = h.b;
             acc = gl2_add(acc, h);
         }
-        const uint64_t t = (uint64_t)(i & (((size_t)1 << table_bits) - 1));
-        const gl2 g = gl2_scale(gl2_inv(gl2_add(al, gl2_from(t))), mult[i] % GL_P);
-        g0[i] = g.a;
-        g1[i] = g.b;
-        rowsum[i] = gl2_sub(acc, g);
+        for (uint32_t c = 0; c < table_cols; c++) {
+            const uint64_t t = ((uint64_t)c << pb) + (uint64_t)(i & (((size_t)1 << pb) - 1));
+            const gl2 g = gl2_scale(gl2_inv(gl2_add(al, gl2_from(t))), mult[(size_t)c * n + i] % GL_P);
+            gcols[(size_t)(2 * c) * n + i] = g.a;
+            gcols[(size_t)(2 * c + 1) * n + i] = g.b;
+            acc = gl2_sub(acc, g);
+        }
+        rowsum[i] = acc;
     }
     gl2 run = gl2_from(0);
     for (size_t i = 0; i < n; i++) {

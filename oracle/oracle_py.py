@@ -326,33 +326,34 @@ def stark_values(desc, proof):
     return [int(v) for v in out[:n]]
 
 
-def logup_multiplicities(trace, cols, table_bits):
-    """orc_logup_multiplicities: trace (n_cols, n) uint64, cols = the looked-up columns.  Returns m (n,) or raises."""
+def logup_multiplicities(trace, cols, table_bits, table_cols=1):
+    """orc_logup_multiplicities: trace (n_cols, n) uint64, cols = the looked-up columns.  Returns m: (n,) for one table
+    column, (table_cols, n) when the table is spread over several; raises if a cell is outside the table."""
     d = dll()
     t = _u64(trace)
     c = np.ascontiguousarray(cols, dtype=np.uint32)
     n = t.shape[1]
-    m = np.zeros(n, dtype=np.uint64)
+    m = np.zeros((table_cols, n), dtype=np.uint64)
     d.orc_logup_multiplicities.restype = ctypes.c_int
     d.orc_logup_multiplicities.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
-                                             ctypes.c_void_p]
-    if not d.orc_logup_multiplicities(t.ctypes.data, n.bit_length() - 1, c.ctypes.data, c.size, table_bits, m.ctypes.data):
+                                           ctypes.c_uint32, ctypes.c_void_p]
+    if not d.orc_logup_multiplicities(t.ctypes.data, n.bit_length() - 1, c.ctypes.data, c.size, table_bits, table_cols, m.ctypes.data):
         raise ValueError("a looked-up cell is outside the table")
-    return m
+    return m[0] if table_cols == 1 else m
 
 
-def logup_round(trace, cols, table_bits, mult, alpha):
-    """orc_logup_round: the round-1 columns (helpers, g, phi) as a (2 * ceil(k / 2) + 4, n) array."""
+def logup_round(trace, cols, table_bits, mult, alpha, table_cols=1):
+    """orc_logup_round: the round-1 columns (helpers, g per table column, phi) as a (2 ceil(k / 2) + 2 table_cols + 2, n) array."""
     d = dll()
     t = _u64(trace)
     c = np.ascontiguousarray(cols, dtype=np.uint32)
-    m = _u64(mult)
+    m = np.ascontiguousarray(_u64(mult).reshape(table_cols, -1))
     n = t.shape[1]
     al = np.array([int(alpha[0]), int(alpha[1])], dtype=np.uint64)
-    out = np.zeros((2 * ((c.size + 1) // 2) + 4, n), dtype=np.uint64)
+    out = np.zeros((2 * ((c.size + 1) // 2) + 2 * table_cols + 2, n), dtype=np.uint64)
     d.orc_logup_round.restype = None
-    d.orc_logup_round.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
-                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    d.orc_logup_round(t.ctypes.data, n.bit_length() - 1, c.ctypes.data, c.size, table_bits, m.ctypes.data, al.ctypes.data,
-                        out.ctypes.data)
+    d.orc_logup_round.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    d.orc_logup_round(t.ctypes.data, n.bit_length() - 1, c.ctypes.data, c.size, table_bits, table_cols, m.ctypes.data, al.ctypes.data,
+                      out.ctypes.data)
     return out

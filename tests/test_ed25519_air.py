@@ -76,10 +76,10 @@ def tiled_case(nlx, orc):
     return slots, t0
 
 
-def oracle_round1(orc, E, t0, known):
+def oracle_round1(orc, E, t0, known, table_cols=1):
     """round 1 on the CPU for known = [alpha0, alpha1, gamma0, gamma1]: (columns, round values)"""
     acc, total = E.binding_columns(t0, known[2:4])
-    cols = np.concatenate([orc.logup_round(t0, E.LOOKUPS, 16, t0[E.MULT], known[:2]),
+    cols = np.concatenate([orc.logup_round(t0, E.LOOKUPS, 16, t0[E.MULT:E.MULT + table_cols], known[:2], table_cols),
                            orc.logup_round(t0, E.LOOKUPS9, 9, t0[E.MULT9], known[:2]), acc], axis=0)
     return cols, list(total)
 
@@ -143,6 +143,31 @@ def test_gpu_trace_and_proof_equal_reference_and_oracle(nlx, ctx, orc, tiled_cas
 
 
 @pytest.mark.gpu
+def test_gpu_small_batch_with_the_table_spread_over_two_columns(nlx, ctx, orc):
+    """2^7 slots = 2^15 rows: shorter than the 2^16-entry range table, which then sits in two periodic columns of 2^15 rows
+    with two multiplicity columns.  Device trace == reference, proof bytes == the oracle prover's."""
+    E = nlx.ed25519_air
+    slots = rfc_slots(nlx)[:2]
+    pr = E.Ed25519Prover(ctx, 7, nlx.StarkConfig(fri_num_queries=20))
+    assert pr.es.table_cols == 2 and pr.es.layout["n_cols0"] == E.N_COLS0 + 1 and pr.stark.desc.period_bits == 15
+    t0 = np.zeros((pr.es.layout["n_cols0"], 1 << 15), dtype=np.uint64)
+    t0[:E.N_COLS0] = np.tile(E.reference_trace(slots), (1, 64))
+    t0[E.MULT:E.MULT + 2] = orc.logup_multiplicities(t0, E.LOOKUPS, 16, 2)
+    t0[E.MULT9] = orc.logup_multiplicities(t0, E.LOOKUPS9, 9)
+    dev = pr.generate_trace(slots * 64)
+    got = dev.cpu().numpy().view(np.uint64)
+    if not np.array_equal(got, t0):
+        bad = np.argwhere(got != t0)[0]
+        pytest.fail("GPU trace differs from the reference at column %d row %d" % (bad[0], bad[1]))
+    proof = pr.prove(slots * 64)
+    assert orc.stark_verify(pr.stark.desc, proof) == 1
+    assert proof == orc.stark_prove_rounds(pr.stark.desc, lambda rnd, known: t0 if rnd == 0 else oracle_round1(orc, E, t0, known, 2), [])
+    vals = orc.stark_values(pr.stark.desc, proof)
+    assert tuple(vals[4:6]) == E.fingerprint(slots * 64, vals[2:4])
+    pr.close()
+
+
+@pytest.mark.gpu
 def test_gpu_real_near_approvals_and_a_forgery(nlx, ctx, orc):
     """The Ed25519 checks of a real Sync step (mainnet main_1.json: every signed approval) in one proof; flipping one
     bit of one signature is reported by the trace generator (and the trace it leaves does not prove)."""
@@ -159,8 +184,9 @@ def test_gpu_real_near_approvals_and_a_forgery(nlx, ctx, orc):
             assert sl is not None
             slots.append(sl)
     assert len(slots) > 32
-    slots = (slots * (256 // len(slots) + 1))[:256]
-    pr = E.Ed25519Prover(ctx, 8, nlx.StarkConfig(fri_num_queries=20))
+    log_slots = (len(slots) - 1).bit_length()            # 66 approvals -> 2^7 slots: the range table in two columns
+    slots = (slots * 2)[: 1 << log_slots]
+    pr = E.Ed25519Prover(ctx, log_slots, nlx.StarkConfig(fri_num_queries=20))
     proof = pr.prove(slots)
     assert orc.stark_verify(pr.stark.desc, proof) == 1
     ax, ay, rx, ry, s, h = slots[7]

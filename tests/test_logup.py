@@ -7,27 +7,28 @@ import pytest
 from conftest import P
 
 
-def range_air(nlx, n_values, bits, fused=True):
-    """n_values looked-up columns, then the multiplicity column; round 1 = the lookup columns."""
+def range_air(nlx, n_values, bits, fused=True, table_cols=1):
+    """n_values looked-up columns, then the multiplicity column(s); round 1 = the lookup columns."""
     S, LU = nlx.stark, nlx.logup
-    air = S.Air(n_values + 1 + LU.round_cols(n_values), 0, rounds=[(n_values + 1, 2), (LU.round_cols(n_values), 0)])
-    rc = LU.RangeCheck(air, range(n_values), bits, n_values, n_values + 1, fused=fused)
+    n0, n1 = n_values + table_cols, LU.round_cols(n_values, table_cols)
+    air = S.Air(n0 + n1, 0, rounds=[(n0, 2), (n1, 0)])
+    rc = LU.RangeCheck(air, range(n_values), bits, n_values, n0, fused=fused, table_cols=table_cols)
     return air, rc
 
 
-def make_trace(orc, n_values, bits, db, seed=1):
+def make_trace(orc, n_values, bits, db, seed=1, table_cols=1):
     rng = np.random.default_rng(seed)
-    t0 = np.zeros((n_values + 1, 1 << db), dtype=np.uint64)
+    t0 = np.zeros((n_values + table_cols, 1 << db), dtype=np.uint64)
     t0[:n_values] = rng.integers(0, 1 << bits, (n_values, 1 << db), dtype=np.uint64)
-    t0[n_values] = orc.logup_multiplicities(t0, range(n_values), bits)
+    t0[n_values:] = orc.logup_multiplicities(t0, range(n_values), bits, table_cols)
     return t0
 
 
-def rounds_fn(orc, t0, n_values, bits):
+def rounds_fn(orc, t0, n_values, bits, table_cols=1):
     def fn(rnd, chal):
         if rnd == 0:
             return t0
-        return orc.logup_round(t0, range(n_values), bits, t0[n_values], chal[:2])
+        return orc.logup_round(t0, range(n_values), bits, t0[n_values:], chal[:2], table_cols)
     return fn
 
 
@@ -93,6 +94,28 @@ def test_fused_instruction_equals_written_out_constraints(nlx, orc, n_values):
     assert proofs[0] == proofs[1] and sizes[0] < sizes[1]
 
 
+@pytest.mark.parametrize("bits,db,table_cols", [(8, 7, 2), (8, 6, 4), (10, 8, 4)])
+def test_table_spread_over_several_columns_oracle(nlx, orc, bits, db, table_cols):
+    """A table longer than the trace: 2^bits entries in table_cols periodic columns of 2^bits / table_cols rows each."""
+    S = nlx.stark
+    n_values = 3
+    air, rc = range_air(nlx, n_values, bits, table_cols=table_cols)
+    st = S.Stark(air, db, S.StarkConfig(fri_num_queries=20))
+    assert st.desc.period_bits == bits - table_cols.bit_length() + 1 and rc.n_round_cols == 4 + 2 * table_cols + 2
+    t0 = make_trace(orc, n_values, bits, db, seed=3, table_cols=table_cols)
+    assert int(t0[n_values:].sum()) == n_values << db and int(t0[:n_values].max()) >= (1 << db)     # values beyond the trace length
+    proof = orc.stark_prove_rounds(st.desc, rounds_fn(orc, t0, n_values, bits, table_cols), [])
+    assert orc.stark_verify(st.desc, proof) == 1
+    bad = t0.copy()
+    bad[1, 5] = 1 << bits
+    assert orc.stark_verify(st.desc, orc.stark_prove_rounds(st.desc, rounds_fn(orc, bad, n_values, bits, table_cols), [])) != 1
+    bad = t0.copy()                                      # a count moved to the same row of another table column
+    c = int(np.argmax(t0[n_values:, 2] > 0))
+    bad[n_values + c, 2] -= 1
+    bad[n_values + (c + 1) % table_cols, 2] += 1
+    assert orc.stark_verify(st.desc, orc.stark_prove_rounds(st.desc, rounds_fn(orc, bad, n_values, bits, table_cols), [])) != 1
+
+
 def test_mixed_periods_tile(nlx):
     S = nlx.stark
     air = S.Air(1, 0)
@@ -106,18 +129,19 @@ def test_mixed_periods_tile(nlx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_values,bits,db", [(5, 6, 7), (4, 8, 10), (7, 16, 16), (1, 4, 5)])
-def test_gpu_logup_round_equals_oracle(nlx, ctx, orc, n_values, bits, db):
+@pytest.mark.parametrize("n_values,bits,db,table_cols", [(5, 6, 7, 1), (4, 8, 10, 1), (7, 16, 16, 1), (1, 4, 5, 1), (3, 8, 6, 4),
+                                                         (6, 16, 14, 4)])
+def test_gpu_logup_round_equals_oracle(nlx, ctx, orc, n_values, bits, db, table_cols):
     import torch
     S = nlx.stark
-    air, rc = range_air(nlx, n_values, bits)
-    t0 = make_trace(orc, n_values, bits, db, seed=db)
+    air, rc = range_air(nlx, n_values, bits, table_cols=table_cols)
+    t0 = make_trace(orc, n_values, bits, db, seed=db, table_cols=table_cols)
     dev = torch.from_numpy(t0.view(np.int64)).to("cuda:%d" % ctx.device)
-    dev[n_values].zero_()
+    dev[n_values:].zero_()
     rc.multiplicities(ctx, dev)
     assert np.array_equal(dev.cpu().numpy().view(np.uint64), t0)
     alpha = (0x123456789abcdef1 % P, 0xfedcba9876543210 % P)
-    want = orc.logup_round(t0, range(n_values), bits, t0[n_values], alpha)
+    want = orc.logup_round(t0, range(n_values), bits, t0[n_values:], alpha, table_cols)
     out = torch.empty((rc.n_round_cols, 1 << db), dtype=torch.int64, device=dev.device)
     rc.round1(ctx, dev, alpha, out)
     got = out.cpu().numpy().view(np.uint64)
@@ -139,7 +163,7 @@ def test_gpu_logup_round_equals_oracle(nlx, ctx, orc, n_values, bits, db):
             return dev
         return rc.round1(ctx, dev, chal[:2], out)
     proof = pr.prove_rounds(gpu_rounds, [])
-    assert proof == orc.stark_prove_rounds(st.desc, rounds_fn(orc, t0, n_values, bits), [])
+    assert proof == orc.stark_prove_rounds(st.desc, rounds_fn(orc, t0, n_values, bits, table_cols), [])
     assert orc.stark_verify(st.desc, proof) == 1
     pr.close()
 
@@ -156,20 +180,22 @@ def test_gpu_witness_calls_reject_bad_arguments(nlx, ctx):
     out = torch.zeros((6, 64), dtype=torch.int64, device=t.device)
 
     def mult(**kw):
-        a = dict(trace=t.data_ptr(), n_cols=4, log_n=6, cols=cols.ctypes.data, n=2, bits=4, mcol=3)
+        a = dict(trace=t.data_ptr(), n_cols=4, log_n=6, cols=cols.ctypes.data, n=2, bits=4, tcols=1, mcol=3)
         a.update(kw)
-        return dll.nlx_logup_multiplicities(ctx.handle, a["trace"], a["n_cols"], a["log_n"], a["cols"], a["n"], a["bits"], a["mcol"])
+        return dll.nlx_logup_multiplicities(ctx.handle, a["trace"], a["n_cols"], a["log_n"], a["cols"], a["n"], a["bits"], a["tcols"],
+                                            a["mcol"])
     assert mult() == 0
     assert mult(bits=7) < 0 and mult(bits=0) < 0 and mult(bits=17) < 0          # table larger than the trace / out of range
+    assert mult(tcols=3) < 0 and mult(tcols=0) < 0 and mult(tcols=2) < 0         # not a power of two / columns run past the trace
     assert mult(mcol=4) < 0 and mult(mcol=1) < 0                                # multiplicity column out of range / looked up
     assert mult(trace=None) < 0 and mult(n=0) < 0
     bad_cols = np.array([0, 9], dtype=np.uint32)
     assert mult(cols=bad_cols.ctypes.data) < 0
     assert b"out of range" in dll.nlx_last_error(ctx.handle)
-    assert dll.nlx_logup_round(ctx.handle, t.data_ptr(), 4, 6, cols.ctypes.data, 2, 4, 3, al.ctypes.data, out.data_ptr()) == 0
-    assert dll.nlx_logup_round(ctx.handle, t.data_ptr(), 4, 6, cols.ctypes.data, 2, 4, 3, None, out.data_ptr()) < 0
-    assert dll.nlx_logup_round(ctx.handle, t.data_ptr(), 4, 6, cols.ctypes.data, 2, 4, 3, al.ctypes.data, None) < 0
-    assert dll.nlx_logup_round_cols(2) == 6 and dll.nlx_logup_round_cols(3) == 8
+    assert dll.nlx_logup_round(ctx.handle, t.data_ptr(), 4, 6, cols.ctypes.data, 2, 4, 1, 3, al.ctypes.data, out.data_ptr()) == 0
+    assert dll.nlx_logup_round(ctx.handle, t.data_ptr(), 4, 6, cols.ctypes.data, 2, 4, 1, 3, None, out.data_ptr()) < 0
+    assert dll.nlx_logup_round(ctx.handle, t.data_ptr(), 4, 6, cols.ctypes.data, 2, 4, 1, 3, al.ctypes.data, None) < 0
+    assert dll.nlx_logup_round_cols(2, 1) == 6 and dll.nlx_logup_round_cols(3, 1) == 8 and dll.nlx_logup_round_cols(3, 4) == 14
     words = np.zeros((256, 24), dtype=np.uint64)
     assert dll.nlx_ed25519_trace(ctx.handle, words.ctypes.data, 17, t.data_ptr()) < 0
     assert dll.nlx_ed25519_trace(ctx.handle, None, 8, t.data_ptr()) < 0
