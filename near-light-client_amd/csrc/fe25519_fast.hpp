@@ -50,10 +50,17 @@ FP_HD inline Fe mul(const Fe& a, const Fe& b) {  // inputs |l_i| < 2^28
     int64_t t[20];
     FP_UNROLL
     for (int k = 0; k < 20; k++) t[k] = 0;
+    // the limbs fit 32 bits (|l_i| < 2^28): 32 x 32 -> 64-bit multiply-adds, one instruction each on the device
+    int32_t a32[10], b32[10];
+    FP_UNROLL
+    for (int i = 0; i < 10; i++) {
+        a32[i] = (int32_t)a.l[i];
+        b32[i] = (int32_t)b.l[i];
+    }
     FP_UNROLL
     for (int i = 0; i < 10; i++) {
         FP_UNROLL
-        for (int j = 0; j < 10; j++) t[i + j] += a.l[i] * b.l[j];
+        for (int j = 0; j < 10; j++) t[i + j] += (int64_t)a32[i] * b32[j];
     }
     // carry the 19 columns to 26-bit limbs (t[19] collects the last carry)
     FP_UNROLL
