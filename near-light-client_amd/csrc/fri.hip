@@ -75,8 +75,13 @@ int32_t fri_prove(nlx_ctx* ctx, const FriProveArgs& a, Challenger& ch, Writer& w
         fp.alpha_nz[0] = ap.a; fp.alpha_nz[1] = ap.b;  // alpha^nz
         fp.out = d_fri_a;
         fp.log_n = log_n; fp.rate_bits = a.rate_bits;
+        uint64_t* d_comb = nullptr;
+        if (const size_t words = fri_combine_scratch_words(fp)) {
+            d_comb = dalloc(words * 8);
+            FRI_ALLOC(d_comb);
+        }
         ctx->begin_kernel("fri_combine", 8.0 * L * n_open + 16.0 * L);
-        launch_fri_combine(st, fp);
+        launch_fri_combine(st, fp, d_comb);
         ctx->end_kernel();
     }
     // commit phase: layer values ping-pong between d_fri_a / d_fri_b; digests kept per layer

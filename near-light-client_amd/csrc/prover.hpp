@@ -58,7 +58,10 @@ struct FriCombineParams {
     uint32_t nz[4];             // the g*zeta batch = first nz[o] columns of every table o, in table order
     uint32_t nz_off[4];         // index of table o's first g*zeta polynomial in that batch
 };
-void launch_fri_combine(hipStream_t st, const FriCombineParams& p);
+// scratch: fri_combine_scratch_words(p) words when that is non-zero (small domains of many columns are combined in column
+// slices), else may be null
+size_t fri_combine_scratch_words(const FriCombineParams& p);
+void launch_fri_combine(hipStream_t st, const FriCombineParams& p, uint64_t* scratch);
 void launch_fri_leaves(hipStream_t st, const uint64_t* d_values, unsigned log_n, unsigned rate_bits,
                        unsigned arity_bits, uint64_t* d_digests);
 void launch_fri_leaves_wide(hipStream_t st, const uint64_t* d_values, unsigned log_n, unsigned rate_bits,

@@ -816,9 +816,86 @@ __global__ __launch_bounds__(256) void k_fri_combine(FriCombineParams p) {
     const gl::Ext res = gl::add(q0, q1);
     reinterpret_cast<ulonglong2*>(p.out)[pos] = make_ulonglong2(res.a, res.b);
 }
-void launch_fri_combine(hipStream_t st, const FriCombineParams& p) {
+// Small domains (a wide STARK trace of a few hundred rows: 4 745 columns x 1 024 points): one lane per point walks
+// thousands of columns alone while most of the chip idles.  The columns are then cut into `slices` ranges
+// (blockIdx.y), each lane sums its range into a partial (s0, s1), and a second kernel adds the partials and divides.
+__global__ __launch_bounds__(256) void k_fri_combine_partial(FriCombineParams p, uint32_t per_slice, uint64_t* __restrict__ part) {
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned log_L = p.log_n + p.rate_bits;
+    if (pos >> log_L) return;
+    const size_t L = (size_t)1 << log_L;
+    const uint32_t lo = blockIdx.y * per_slice, hi = lo + per_slice;
+    gl::Ext s0{0, 0}, s1{0, 0};
+    uint32_t first = 0;  // global index of the table's first column
+    for (int o = 0; o < 4; o++) {
+        const uint64_t* tab = p.tables[o];
+        const uint32_t nco = p.n_cols[o];
+        const uint32_t c_lo = lo > first ? lo - first : 0, c_hi = hi > first ? (hi - first < nco ? hi - first : nco) : 0;
+        for (uint32_t c = c_lo; c < c_hi; c++) {
+            const uint32_t idx = first + c;
+            const uint64_t v = tab[(size_t)c * L + pos];
+            s0 = gl::add(s0, gl::mul(gl::Ext{p.alpha_pows[2 * idx], p.alpha_pows[2 * idx + 1]}, v));
+            if (c < p.nz[o]) {
+                const uint32_t zi = p.nz_off[o] + c;
+                s1 = gl::add(s1, gl::mul(gl::Ext{p.alpha_pows[2 * zi], p.alpha_pows[2 * zi + 1]}, v));
+            }
+        }
+        first += nco;
+    }
+    uint64_t* dst = part + (((size_t)blockIdx.y << log_L) + pos) * 4;
+    dst[0] = s0.a; dst[1] = s0.b; dst[2] = s1.a; dst[3] = s1.b;
+}
+__global__ __launch_bounds__(256) void k_fri_combine_finish(FriCombineParams p, uint32_t slices, const uint64_t* __restrict__ part) {
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned log_L = p.log_n + p.rate_bits;
+    if (pos >> log_L) return;
+    const size_t n = (size_t)1 << p.log_n;
+    gl::Ext s0{0, 0}, s1{0, 0};
+    for (uint32_t sl = 0; sl < slices; sl++) {
+        const uint64_t* src = part + (((size_t)sl << log_L) + pos) * 4;
+        s0 = gl::add(s0, gl::Ext{src[0], src[1]});
+        s1 = gl::add(s1, gl::Ext{src[2], src[3]});
+    }
+    const uint32_t r = (uint32_t)(pos >> p.log_n), k = (uint32_t)(pos & (n - 1));
+    const uint64_t x = gl::mul(p.coset_base[r], root_pow(p.w_n_table, k, (uint32_t)(n >> 1)));
+    const gl::Ext zeta{p.zeta[0], p.zeta[1]}, gzeta{p.gzeta[0], p.gzeta[1]};
+    const gl::Ext d0 = gl::sub(gl::ext(x), zeta), d1 = gl::sub(gl::ext(x), gzeta);
+    const gl::Ext inv01 = gl::inv(gl::mul(d0, d1));
+    const gl::Ext i0 = gl::mul(inv01, d1), i1 = gl::mul(inv01, d0);
+    gl::Ext q0 = gl::mul(gl::sub(s0, gl::Ext{p.c0[0], p.c0[1]}), i0);
+    q0 = gl::mul(q0, gl::Ext{p.alpha_nz[0], p.alpha_nz[1]});
+    const gl::Ext q1 = gl::mul(gl::sub(s1, gl::Ext{p.c1[0], p.c1[1]}), i1);
+    const gl::Ext res = gl::add(q0, q1);
+    reinterpret_cast<ulonglong2*>(p.out)[pos] = make_ulonglong2(res.a, res.b);
+}
+
+// number of column slices for this shape (1 = the single-kernel path) and the scratch it needs
+uint32_t fri_combine_slices(const FriCombineParams& p) {
     const size_t L = (size_t)1 << (p.log_n + p.rate_bits);
-    hipLaunchKernelGGL(k_fri_combine, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, p);
+    uint32_t cols = 0;
+    for (int o = 0; o < 4; o++) cols += p.n_cols[o];
+    if (L >= ((size_t)1 << 15) || cols < 256) return 1;
+    uint32_t want = (uint32_t)((((size_t)1 << 17) + L - 1) / L);  // aim for ~2^17 lanes
+    const uint32_t max_slices = cols / 64 ? cols / 64 : 1;        // at least 64 columns per slice
+    if (want > max_slices) want = max_slices;
+    return want > 64 ? 64 : want;
+}
+size_t fri_combine_scratch_words(const FriCombineParams& p) {
+    const uint32_t s = fri_combine_slices(p);
+    return s > 1 ? ((size_t)s << (p.log_n + p.rate_bits)) * 4 : 0;
+}
+void launch_fri_combine(hipStream_t st, const FriCombineParams& p, uint64_t* scratch) {
+    const size_t L = (size_t)1 << (p.log_n + p.rate_bits);
+    const uint32_t slices = scratch ? fri_combine_slices(p) : 1;
+    if (slices <= 1) {
+        hipLaunchKernelGGL(k_fri_combine, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, p);
+        return;
+    }
+    uint32_t cols = 0;
+    for (int o = 0; o < 4; o++) cols += p.n_cols[o];
+    const uint32_t per_slice = (cols + slices - 1) / slices;
+    hipLaunchKernelGGL(k_fri_combine_partial, dim3((unsigned)((L + 255) / 256), slices), dim3(256), 0, st, p, per_slice, scratch);
+    hipLaunchKernelGGL(k_fri_combine_finish, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, p, slices, scratch);
 }
 
 // Layer leaf digests.  values: ext (2 words), coset-major with sub-domain size n = 2^log_n
