@@ -15,7 +15,8 @@ OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(HERE, "libnlx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
+# -Xarch_host -mavx2: the host side of the library (transcript hashing, FRI bookkeeping) runs on the GPU node's x86-64 CPU
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Xarch_host", "-mavx2", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(HERE, "..", "include")]
 
 
