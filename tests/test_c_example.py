@@ -57,3 +57,39 @@ def test_c_stark_caller_matches_python_path(nlx, ctx, tmp_path):
     # different instruction schedules, same constraint order and values -> same proof bytes
     assert ("proof %d bytes, fold %016x" % (len(proof), fold)) in r.stdout, r.stdout
     pr.close()
+
+
+def test_c_rounds_caller_builds(nlx, tmp_path):
+    _build(tmp_path, "rounds_example")
+
+
+@pytest.mark.gpu
+def test_c_rounds_caller_matches_python_path(nlx, ctx, orc, tmp_path):
+    """examples/rounds_example.c (multi-round proof with a round value through the C callback) produces the same proof as
+    the Python assembler + prover for the same AIR and column, and its round value is the column's fingerprint."""
+    import numpy as np
+    from conftest import P
+    from test_stark_cpu import fingerprint_air, fingerprint_rounds
+    exe = _build(tmp_path, "rounds_example")
+    r = subprocess.run([exe, "9"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    S = nlx.stark
+    v, x = [], 88172645463325252
+    for _ in range(1 << 9):
+        x ^= (x << 13) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 7
+        x ^= (x << 17) & 0xFFFFFFFFFFFFFFFF
+        v.append(x % P)
+    v = np.array(v, dtype=np.uint64)
+    pr = S.Stark(fingerprint_air(S), 9).build(ctx)
+    proof = pr.prove_rounds(fingerprint_rounds(v), [])
+    fold = 0
+    for i in range(0, len(proof) - 7, 8):
+        fold = ((fold * 0x100000001B3) ^ int.from_bytes(proof[i:i + 8], "little")) & 0xFFFFFFFFFFFFFFFF
+    gamma, total = orc.stark_values(pr.stark.desc, proof)
+    assert ("proof %d bytes, fold %016x, round value %d" % (len(proof), fold, total)) in r.stdout, r.stdout
+    acc = 0
+    for e in v:
+        acc = (acc * gamma + int(e)) % P
+    assert acc == total
+    pr.close()
