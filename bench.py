@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--map-log-n", type=int, default=18,
                     help="rows of a map proof; SURVEY.md §8d: 18-20 = Sync / map sized (estimate), 12-14 = reduce sized")
     ap.add_argument("--reduce-log-n", type=int, default=13)
+    ap.add_argument("--map-starks", action="store_true", help="verify128 workload: also prove the map jobs' SHA-256 work (1 444 "
+                    "compression blocks of 4 inclusion proofs -> 2^11 blocks per job), one STARK per rank over the jobs it owns")
     return ap.parse_args()
 
 

@@ -184,12 +184,41 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+    # Optionally the curta sub-proofs of the map jobs as well: a map job verifies 4 transaction / receipt inclusion proofs =
+    # 1 444 SHA-256 compression blocks, padded to 2^11.  Each rank proves the blocks of ALL the map
+    # jobs it owns in ONE SHA-256 STARK before the tree (one 2^16-block proof on one GPU, 2^13 blocks per GPU on eight):
+    # a proof per job would leave the chip mostly idle (2^11 blocks is 2^14 LDE rows; measured 18.6 ms per job against 142 ms
+    # for all 32 together), and the binding fingerprint covers every block either way.  Blocks: synthetic 64-byte Merkle nodes.
+    stark_ms = 0.0
+    sha = None
+    if getattr(args, "map_starks", False):
+        sa = nlx.sha256_air
+        owned = sum(1 for j in range(plan.n_map) if owner(j, world) == rank)
+        lb = 11 + max(0, (owned - 1).bit_length())
+        sha = sa.Sha256Prover(ctx, lb)
+        rng = np.random.default_rng(17 + rank)
+        n_msgs = 1 << (lb - 1)
+        raw = rng.integers(0, 256, (n_msgs, 64), dtype=np.uint8)
+        pad = np.zeros((n_msgs, 64), dtype=np.uint8)
+        pad[:, 0], pad[:, 62] = 0x80, 0x02
+        sha_blocks = np.concatenate([raw, pad], axis=1).reshape(2 * n_msgs, 64).view(">u4").astype(np.uint32)
+        sha_first = np.tile(np.array([1, 0], dtype=np.uint8), n_msgs)
+
+    def map_starks():
+        t1 = time.perf_counter()
+        _, digest = sha.generate_trace(sha_blocks, sha_first)
+        sha.prove_trace(digest)
+        return (time.perf_counter() - t1) * 1e3
     root = None
     for _ in range(args.warmup):
+        if sha is not None:
+            map_starks()
         root, _ = run_tree(plan, prover, rank, world, dist, device)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if sha is not None:
+            stark_ms += map_starks()
         root, stats = run_tree(plan, prover, rank, world, dist, device)
     sync()
     dt = time.perf_counter() - t0
@@ -206,7 +235,9 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist):
         "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
         "config": {"workload": "VerifyCircuit 128x4-shaped map-reduce job: 32 map proofs (2^%d rows) + 31 reduce "
                                "proofs + 1 outer proof (2^%d rows), sharded round-robin, one RCCL all-gather of "
-                               "digests per level" % (args.map_log_n, args.reduce_log_n),
+                               "digests per level" % (args.map_log_n, args.reduce_log_n) +
+                               ("; plus, per rank, one SHA-256 STARK of the 2^11 blocks of every map job it owns" if sha is not None else ""),
+                   "map_starks_ms_per_step_rank0": round(stark_ms / args.steps, 2) if sha is not None else None,
                    "jobs": plan.n_jobs, "proofs_in_flight_per_gpu": args.inflight,
                    "level_ms_last_step": [[k, n, round(ms, 3)] for k, n, ms in stats["level_ms"]], "root_digest": [int(x) for x in root], "parallelism": "mapreduce x%d" % world},
         "roofline": None, "cpu_baseline": None,
