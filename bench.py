@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark", "sha256", "sha512", "ed25519", "sync_starks"])
     ap.add_argument("--log-blocks", type=int, default=14, help="sha256 workload: 2^k compression blocks per proof")
     ap.add_argument("--log-slots", type=int, default=10, help="ed25519 workload: 2^k signature slots per proof (>= 4)")
-    ap.add_argument("--segment-nodes", type=int, default=None, help="sha256 workload: AIR program segment size (0 = one segment)")
+    ap.add_argument("--segment-nodes", type=int, default=None, help="sha256 / sha512 / ed25519 workloads: AIR program segment size in arithmetic nodes (0 = one segment)")
     ap.add_argument("--stark-cols", type=int, default=256)
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--gate-mix", default="nearx", choices=["nearx", "basic"])
@@ -490,7 +490,7 @@ def run_ed25519(args, nlx, torch, rank, world, local, dist):
     distinct = E.synthetic_slots(64, seed=9 + rank)
     words = np.tile(E.slots_to_words(distinct), (n_slots // 64, 1))
     ctx = nlx.Context(local)
-    pr = E.Ed25519Prover(ctx, args.log_slots)
+    pr = E.Ed25519Prover(ctx, args.log_slots, segment_nodes=args.segment_nodes)
     for _ in range(args.warmup):
         pr.prove(words)
     ctx.kernel_timing(True)
@@ -519,7 +519,7 @@ def run_ed25519(args, nlx, torch, rank, world, local, dist):
             "value": world * args.steps * n_slots / dt, "unit": "signatures/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
-            "config": {"workload": "two-round STARK of 2^%d Ed25519 verifications (%d rows x %d + %d columns, degree-3 AIR, 22 "
+            "config": {"workload": "two-round STARK of 2^%d Ed25519 verifications (%d rows x %d + %d columns, degree-3 AIR, 16 "
                                    "multiplication units mod 2^255-19 per row, %d + %d range-check lookups per row (2^16 / 2^9 tables); standard_fast_config: "
                                    "rate 2, 84 queries, 16 PoW bits); trace, multiplicities and lookup columns generated on the "
                                    "GPU inside the timed region; replicas only"

@@ -27,7 +27,7 @@ _AIR_FUSED_EMITS = (AIR_EMIT_BOOL, AIR_EMIT_LOGUP)   # constraints that are one 
 AIR_NUM_REGS = 64
 AIR_MAX_RESIDENT_LEAVES = 12   # loads kept in registers (LRU) before they are re-loaded
 AIR_LOAD_BATCH = 8             # loads issued together (NLX_AIR_LOADV): memory-level parallelism of the VM
-AIR_SEGMENT_NODES = 1024       # arithmetic nodes per program segment (NLX_AIR_SEGMENT): the GPU runs segments in parallel
+AIR_SEGMENT_NODES = 400        # arithmetic nodes per program segment (NLX_AIR_SEGMENT): the GPU runs segments in parallel
 AIR_MAX_SEGMENTS = 256
 
 
