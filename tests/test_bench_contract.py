@@ -49,3 +49,25 @@ def test_secondary_workload_lines(args):
     for k in REQUIRED:
         assert k in d, k
     assert d["value"] > 0 and d["cpu_baseline"] is None and "workload" in d["config"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [("--log-n", "12"), ("--workload", "verify128", "--log-n", "10", "--map-log-n", "11")])
+def test_driver_launch_line_two_ranks(args):
+    """The driver's N > 1 command (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`) with N = 2 on the one-GPU box: NLX_BENCH_REHEARSAL=1 puts both ranks on
+    GPU 0 over gloo (RCCL refuses two ranks on one device), everything else is the code path of a real two-GPU run:
+    rank / world from the environment, barrier, MAX over ranks, one JSON line from rank 0."""
+    env = dict(os.environ, NLX_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", *args]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and "rehearsal" in d["config"]
+    assert d["scaling"] == ("strong" if "verify128" in args else "weak")
