@@ -10,7 +10,7 @@
 typedef struct { uint8_t* p; size_t len, cap; int overflow; } wbuf;
 static inline void w_bytes(wbuf* w, const void* src, size_t n) {
     if (w->len + n > w->cap) { w->overflow = 1; return; }
-    memcpy(w->p + w->len, src, n);
+    if (n) memcpy(w->p + w->len, src, n);
     w->len += n;
 }
 static inline void w_u64s(wbuf* w, const uint64_t* v, size_t n) { w_bytes(w, v, n * 8); } /* little-endian host */

@@ -85,7 +85,7 @@ void orc_hash_pad(const uint64_t* in, size_t len, uint64_t out[4]) {
     while ((padded + 1) % 12 != 0) padded++;
     padded++;
     uint64_t* buf = (uint64_t*)calloc(padded, 8);
-    memcpy(buf, in, len * 8);
+    if (len) memcpy(buf, in, len * 8);
     buf[len] = 1;
     buf[padded - 1] = 1;
     orc_hash_no_pad(buf, padded, out);

@@ -565,7 +565,7 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
     orc_ch_init(&ch);
     /* values readable by PUBLIC: public inputs, then the verifier challenges in the order they are drawn */
     uint64_t* values = (uint64_t*)calloc(d->num_public_inputs + n_rch + 1, 8);
-    memcpy(values, public_inputs, 8 * (size_t)d->num_public_inputs);
+    if (d->num_public_inputs) memcpy(values, public_inputs, 8 * (size_t)d->num_public_inputs);
     uint32_t n_drawn = 0;
     uint64_t *r_coeffs[3] = {0}, *r_leaves[3] = {0}, *r_dig[3] = {0};
     uint64_t r_cap[3][4 * 64];
