@@ -52,7 +52,7 @@ def test_row_code_built_for_the_host_equals_reference(nlx, tmp_path):
     """csrc/ed25519_rows.hpp (what the GPU kernels run), compiled with g++, writes the same trace as the reference."""
     E = nlx.ed25519_air
     exe, out = str(tmp_path / "edcheck"), str(tmp_path / "trace.bin")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "near-light-client_amd", "csrc"),
+    subprocess.run(["g++", "-O2", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "near-light-client_amd", "csrc"),
                     os.path.join(ROOT, "tests", "native", "ed25519_host_check.cpp"), "-o", exe], check=True, capture_output=True)
     slots = rfc_slots(nlx)
     want = E.reference_trace(slots)

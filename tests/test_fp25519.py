@@ -49,7 +49,7 @@ def test_device_witness_code_on_the_host(nlx, tmp_path):
     from conftest import ROOT
     F = nlx.fp25519
     exe = str(tmp_path / "fpcheck")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "near-light-client_amd", "csrc"),
+    subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "near-light-client_amd", "csrc"),
                     os.path.join(ROOT, "tests", "native", "fp25519_host_check.cpp"), "-o", exe], check=True, capture_output=True)
     rnd = random.Random(3)
     m, p = (1 << 256) - 1, F.P25519
