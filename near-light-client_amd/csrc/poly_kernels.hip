@@ -108,6 +108,111 @@ __global__ __launch_bounds__(256) void k_eval_fold(const uint64_t* __restrict__ 
     }
 }
 
+// Stage 1 for columns longer than one chunk, as a weighted sum instead of a tree: inside a chunk the element at
+// local offset j carries the weight prod_{l : bit l of j} Y(l) - the same 2^11 extension weights for every chunk and
+// every column.  A lane owns the elements j = i * 256 + tid (coalesced 8-byte loads), so its weights factor as
+// A[i] * B[tid] and stay in registers while the block walks `cols_per_block` columns: per coefficient two 64 x 64
+// multiply-accumulates into unreduced column sums (as GateAcc, prover_kernels.hip) instead of the tree's extension
+// multiplication, one reduction per lane and column, the 256 partial sums added through wave shuffles and LDS.
+// Field arithmetic is exact, so the partials equal k_eval_fold<false>'s.
+struct DotAcc {
+    uint64_t a[4];
+    uint32_t k[4];
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[i] = 0; k[i] = 0; }
+    }
+    __device__ __forceinline__ void mac(uint64_t c, uint64_t w) {
+        const uint32_t c0 = (uint32_t)c, c1 = (uint32_t)(c >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+        asm("v_mad_u64_u32 %[a0], vcc, %[c0], %[w0], %[a0]\n\t"
+            "v_addc_co_u32 %[k0], vcc, 0, %[k0], vcc\n\t"
+            "v_mad_u64_u32 %[a1], vcc, %[c0], %[w1], %[a1]\n\t"
+            "v_addc_co_u32 %[k1], vcc, 0, %[k1], vcc\n\t"
+            "v_mad_u64_u32 %[a2], vcc, %[c1], %[w0], %[a2]\n\t"
+            "v_addc_co_u32 %[k2], vcc, 0, %[k2], vcc\n\t"
+            "v_mad_u64_u32 %[a3], vcc, %[c1], %[w1], %[a3]\n\t"
+            "v_addc_co_u32 %[k3], vcc, 0, %[k3], vcc"
+            : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [k0] "+v"(k[0]), [k1] "+v"(k[1]),
+              [k2] "+v"(k[2]), [k3] "+v"(k[3])
+            : [c0] "v"(c0), [c1] "v"(c1), [w0] "v"(w0), [w1] "v"(w1)
+            : "vcc");
+    }
+    // A0 + (A1 + A2) 2^32 + (A3 + K0) 2^64 + (K1 + K2) 2^96 + K3 2^128 (mod p): 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32
+    __device__ __forceinline__ uint64_t finish() const {
+        const uint64_t m1 = gl::canon(a[1]), m2 = gl::canon(a[2]);
+        uint64_t r = gl::canon(a[0]);
+        r = gl::add(r, gl::reduce128(m1 << 32, m1 >> 32));
+        r = gl::add(r, gl::reduce128(m2 << 32, m2 >> 32));
+        r = gl::add(r, gl::mul(gl::canon(a[3]), gl::EPS));
+        r = gl::add(r, gl::mul((uint64_t)k[0], gl::EPS));
+        r = gl::sub(r, (uint64_t)k[1] + k[2]);
+        r = gl::sub(r, (uint64_t)k[3] << 32);
+        return r;
+    }
+};
+
+constexpr uint32_t EVAL_DOT_MAX_COLS = 64;  // columns per block (LDS for their wave partials)
+
+__global__ __launch_bounds__(256) void k_eval_dot(const uint64_t* __restrict__ in, size_t in_stride, uint32_t n_cols,
+                                                  uint32_t cols_per_block, unsigned log_n, const uint64_t* __restrict__ zpow,
+                                                  uint64_t* __restrict__ out, size_t out_stride) {
+    __shared__ uint64_t wave_part[EVAL_DOT_MAX_COLS * 4 * 2];
+    const unsigned tid = threadIdx.x;
+    const size_t elem0 = (size_t)blockIdx.x << EVAL_CHUNK_LOG;
+    auto Y = [&](unsigned l) {
+        const unsigned k = log_n - 1 - l;
+        return gl::Ext{zpow[2 * k], zpow[2 * k + 1]};
+    };
+    gl::Ext w[8];
+    {
+        gl::Ext b{1, 0};
+        for (unsigned l = 0; l < 8; l++)
+            if ((tid >> l) & 1) b = gl::mul(b, Y(l));
+        const gl::Ext y8 = Y(8), y9 = Y(9), y10 = Y(10);
+        const gl::Ext y89 = gl::mul(y8, y9);
+        w[0] = b;
+        w[1] = gl::mul(b, y8);
+        w[2] = gl::mul(b, y9);
+        w[3] = gl::mul(b, y89);
+        w[4] = gl::mul(b, y10);
+        w[5] = gl::mul(w[1], y10);
+        w[6] = gl::mul(w[2], y10);
+        w[7] = gl::mul(w[3], y10);
+    }
+    const uint32_t col0 = blockIdx.y * cols_per_block;
+    const uint32_t col1 = col0 + cols_per_block < n_cols ? col0 + cols_per_block : n_cols;
+    for (uint32_t col = col0; col < col1; col++) {
+        const uint64_t* src = in + (size_t)col * in_stride + elem0 + tid;
+        uint64_t c[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) c[i] = src[i * 256];
+        DotAcc A, B;
+        A.reset();
+        B.reset();
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            A.mac(c[i], w[i].a);
+            B.mac(c[i], w[i].b);
+        }
+        gl::Ext s{A.finish(), B.finish()};
+        for (int d = 32; d >= 1; d >>= 1) s = gl::add(s, shfl_down_ext(s, d));
+        if ((tid & 63) == 0) {
+            uint64_t* wp = wave_part + ((size_t)(col - col0) * 4 + (tid >> 6)) * 2;
+            wp[0] = s.a;
+            wp[1] = s.b;
+        }
+    }
+    __syncthreads();
+    if (tid < col1 - col0) {
+        const uint64_t* wp = wave_part + (size_t)tid * 8;
+        gl::Ext s{wp[0], wp[1]};
+        for (int i = 1; i < 4; i++) s = gl::add(s, gl::Ext{wp[2 * i], wp[2 * i + 1]});
+        uint64_t* o = out + (size_t)(col0 + tid) * out_stride + 2 * (size_t)blockIdx.x;
+        o[0] = s.a;
+        o[1] = s.b;
+    }
+}
+
 // zpow[k] = z^(2^k), k in [0, count)
 __global__ void k_zpow(const uint64_t* __restrict__ z, unsigned count, uint64_t* __restrict__ zpow) {
     if (threadIdx.x | blockIdx.x) return;
@@ -142,8 +247,13 @@ void launch_eval_br(hipStream_t st, const uint64_t* d_coeffs_br, size_t stride, 
         return;
     }
     unsigned log_count = log_n - EVAL_CHUNK_LOG;  // partials per column after stage 1
-    hipLaunchKernelGGL(k_eval_fold<false>, dim3(1u << log_count, n_cols), dim3(256), 0, st, d_coeffs_br, stride, log_n,
-                       0u, log_n, zpow, bufA, (size_t)2 << log_count);
+    {
+        // enough blocks to fill the chip, as many columns per block as that leaves (the weights are computed per block)
+        uint32_t cpb = EVAL_DOT_MAX_COLS;
+        while (cpb > 4 && ((size_t)((n_cols + cpb - 1) / cpb) << log_count) < 2048) cpb >>= 1;
+        hipLaunchKernelGGL(k_eval_dot, dim3(1u << log_count, (n_cols + cpb - 1) / cpb), dim3(256), 0, st, d_coeffs_br, stride,
+                           n_cols, cpb, log_n, zpow, bufA, (size_t)2 << log_count);
+    }
     unsigned level = EVAL_CHUNK_LOG;
     uint64_t* src = bufA;
     uint64_t* dst = bufB;
