@@ -46,6 +46,11 @@ typedef struct nlx_commit nlx_commit;
 /* library / ABI version (major << 16 | minor) */
 uint32_t nlx_version(void);
 const char* nlx_strerror(int32_t code);
+/* The Goldilocks generator pair this library was built with (include/nlx_field.h):
+ * out[0] = MULTIPLICATIVE_GROUP_GENERATOR (coset shift, k_i base), out[1] = POWER_OF_TWO_GENERATOR (order 2^32).
+ * plonky2_field::goldilocks_field::GoldilocksField::{MULTIPLICATIVE_GROUP_GENERATOR, POWER_OF_TWO_GENERATOR}
+ * (crate pinned at /root/reference/Cargo.lock:4912-4914); a caller checks it against its own constants once. */
+void nlx_field_generators(uint64_t out[2]);
 
 /* ---- context ---- */
 int32_t nlx_ctx_create(int device, nlx_ctx** out);
@@ -303,7 +308,7 @@ typedef struct {
     uint32_t pct_extension;   /* rows split evenly over ArithmeticExtension / MulExtension / Reducing / ReducingExtension */
     uint32_t pct_misc;        /* rows split evenly over PoseidonMds / Exponentiation / CosetInterpolation / RandomAccess */
     uint32_t pct_u32;         /* rows split evenly over U32AddMany / U32Arithmetic / U32Subtraction / U32RangeCheck / Comparison */
-    uint32_t reserved;
+    uint32_t wide_comparison; /* 1: ComparisonGate { num_bits 25, num_chunks 25 } (132 constraints, the widest gate) instead of { 32, 16 } */
 } nlx_synth_params;
 /* number of gates / selector polynomials the generator will emit for these parameters */
 void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_selectors);

@@ -6,7 +6,9 @@ import numpy as np
 
 GOLDILOCKS_P = 0xFFFFFFFF00000001
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnlx.so")
+# NLX_GL_GENERATOR_SET=2021 selects the library built with the other candidate generator pair (include/nlx_field.h)
+_GEN_SET = os.environ.get("NLX_GL_GENERATOR_SET", "7")
+LIB_PATH = os.path.join(_HERE, "libnlx.so" if _GEN_SET == "7" else "libnlx_gen%s.so" % _GEN_SET)
 
 # If torch is going to be used in this process (bench.py, multi-GPU dispatch) it must load its
 # bundled HIP runtime first; libnlx.so then binds to the same libamdhip64.so.7 instance so
@@ -31,6 +33,7 @@ c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 SIGNATURES = {
     "nlx_version": (ctypes.c_uint32, []),
     "nlx_strerror": (ctypes.c_char_p, [ctypes.c_int32]),
+    "nlx_field_generators": (None, [ctypes.POINTER(ctypes.c_uint64)]),
     "nlx_ctx_create": (ctypes.c_int32, [ctypes.c_int, c_void_pp]),
     "nlx_ctx_destroy": (None, [ctypes.c_void_p]),
     "nlx_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),

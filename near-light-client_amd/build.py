@@ -11,13 +11,19 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, ".obj")
-LIB = os.path.join(HERE, "libnlx.so")
+# Generator pair (include/nlx_field.h): default set 7; NLX_GL_GENERATOR_SET=2021 builds the other candidate pair
+# into libnlx_gen2021.so (own object cache) so the parity suites can be run under both.
+GEN_SET = os.environ.get("NLX_GL_GENERATOR_SET", "7")
+if GEN_SET not in ("7", "2021"):
+    raise RuntimeError("NLX_GL_GENERATOR_SET must be 7 or 2021")
+_SUFFIX = "" if GEN_SET == "7" else "_gen" + GEN_SET
+OBJ = os.path.join(CSRC, ".obj" + _SUFFIX)
+LIB = os.path.join(HERE, "libnlx%s.so" % _SUFFIX)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 # -Xarch_host -mavx2: the host side of the library (transcript hashing, FRI bookkeeping) runs on the GPU node's x86-64 CPU
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Xarch_host", "-mavx2", "-Wall", "-Wno-unused-function",
-         "-I", os.path.join(HERE, "..", "include")]
+         "-I", os.path.join(HERE, "..", "include"), "-DNLX_GL_GENERATOR_SET=" + GEN_SET]
 
 
 def _sources():

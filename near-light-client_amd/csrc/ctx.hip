@@ -170,7 +170,12 @@ Staged::~Staged() {
 
 extern "C" {
 
-uint32_t nlx_version(void) { return (0u << 16) | 1u; }
+uint32_t nlx_version(void) { return (0u << 16) | 2u; }
+
+void nlx_field_generators(uint64_t out[2]) {
+    out[0] = gl::GEN;
+    out[1] = gl::POW2_GEN;
+}
 
 const char* nlx_strerror(int32_t code) {
     switch (code) {

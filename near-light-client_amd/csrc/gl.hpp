@@ -11,6 +11,7 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include "nlx_field.h"
 
 #if defined(__HIP__)
 #include <hip/hip_runtime.h>
@@ -23,8 +24,9 @@ namespace gl {
 
 constexpr uint64_t P = 0xFFFFFFFF00000001ULL;
 constexpr uint64_t EPS = 0xFFFFFFFFULL;  // 2^64 mod p
-constexpr uint64_t GEN = 14293326489335486720ULL;       // multiplicative generator = coset shift
-constexpr uint64_t POW2_GEN = 7277203076849721926ULL;   // order 2^32
+// the generator pair comes from include/nlx_field.h (one definition for product, oracle and golden model)
+constexpr uint64_t GEN = NLX_GL_MULTIPLICATIVE_GROUP_GENERATOR;  // multiplicative generator = coset shift
+constexpr uint64_t POW2_GEN = NLX_GL_POWER_OF_TWO_GENERATOR;     // order 2^32
 constexpr unsigned TWO_ADICITY = 32;
 constexpr uint64_t W = 7;  // X^2 = W in the quadratic extension
 

@@ -10,6 +10,7 @@
 // over a few KB and runs on the host, as it does in the reference - only
 // Merkle caps (512 B), openings (~4.5 KB), the final polynomial and the query answers cross
 // PCIe.  It is not a fallback for any device stage.
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <functional>
@@ -29,6 +30,30 @@ namespace {
 uint32_t fri_num_rounds(const nlx_circuit_desc& d) {
     return nlx::fri_num_rounds(d.degree_bits, d.rate_bits, d.cap_height, d.fri_arity_bits, d.fri_final_poly_bits);
 }
+
+// plonky2 Gate::num_constraints() of every gate kind k_quotient evaluates: the alpha-power table of the quotient stage
+// must hold one power per constraint of the widest gate (the circuit's `num_gate_constraints`).
+uint32_t gate_num_constraints(const nlx_gate_desc& g) {
+    const uint32_t p0 = g.param0, p1 = g.param1;
+    switch (g.kind) {
+        case NLX_GATE_CONSTANT: case NLX_GATE_ARITHMETIC: return p0;
+        case NLX_GATE_PUBLIC_INPUT: return 4;
+        case NLX_GATE_BASE_SUM: return 1 + p1;                      // the sum + one range product per limb
+        case NLX_GATE_POSEIDON: return 123;                         // 1 swap bit + 4 deltas + 3*12 + 22 + 4*12 + 12 outputs
+        case NLX_GATE_ARITHMETIC_EXT: case NLX_GATE_MUL_EXT: case NLX_GATE_REDUCING: case NLX_GATE_REDUCING_EXT:
+            return 2 * p0;                                          // D = 2 base constraints per extension constraint
+        case NLX_GATE_POSEIDON_MDS: return 24;
+        case NLX_GATE_EXPONENTIATION: return p0 + 1;
+        case NLX_GATE_RANDOM_ACCESS: return (p1 & 0xFFFF) * (p0 + 2) + (p1 >> 16);
+        case NLX_GATE_COSET_INTERPOLATION: return 2 * (2 + 2 * (((1u << p0) - 2) / (p1 - 1)));
+        case NLX_GATE_U32_ADD_MANY: return p1 * (3 + 18);
+        case NLX_GATE_U32_ARITHMETIC: return p0 * (4 + 32);
+        case NLX_GATE_U32_SUBTRACTION: return p0 * (3 + 16);
+        case NLX_GATE_U32_RANGE_CHECK: return p0 * 17;
+        case NLX_GATE_COMPARISON: return 6 + 5 * p1 + (p0 + p1 - 1) / p1;
+        default: return 0;
+    }
+}
 }  // namespace
 
 struct nlx_circuit {
@@ -36,7 +61,7 @@ struct nlx_circuit {
     nlx_circuit_desc d{};
     std::vector<nlx_gate_desc> gates;
     std::vector<uint64_t> k_is;
-    uint32_t n_consts_all = 0, n_cs = 0, n_zs = 0, n_q = 0, n_fri_rounds = 0, n_terms = 0;
+    uint32_t n_consts_all = 0, n_cs = 0, n_zs = 0, n_q = 0, n_fri_rounds = 0, n_terms = 0, max_gate_constraints = 0;
     nlx_commit* cs = nullptr;           // constants + sigmas commitment
     std::vector<uint64_t> cs_cap;       // host copy
     uint64_t* d_sigma_values = nullptr; // [routed][n]
@@ -118,6 +143,7 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
     c->ctx = ctx;
     c->d = d;
     c->gates.assign(d.gates, d.gates + d.num_gates);
+    for (const nlx_gate_desc& gt : c->gates) c->max_gate_constraints = std::max(c->max_gate_constraints, gate_num_constraints(gt));
     c->k_is.assign(d.k_is, d.k_is + d.num_routed_wires);
     c->d.gates = c->gates.data();
     c->d.k_is = c->k_is.data();
@@ -249,7 +275,7 @@ size_t nlx_proof_max_bytes(const nlx_circuit* c) {
     for (int o = 0; o < 4; o++) per_query += cols[o] * 8 + 1 + 32 * (size_t)(log_L - d.cap_height);
     per_query += c->n_fri_rounds * ((size_t)16 << d.fri_arity_bits) + c->n_fri_rounds * (1 + 32 * (size_t)log_L);
     bytes += per_query * d.fri_num_queries;
-    bytes += ((size_t)16 << (d.degree_bits - c->n_fri_rounds * d.fri_arity_bits)) + 8 + 4 + 8 * (size_t)d.num_public_inputs;
+    bytes += ((size_t)16 << (d.degree_bits - c->n_fri_rounds * d.fri_arity_bits)) + 8 + 8 + 8 * (size_t)d.num_public_inputs;
     return bytes + 64;
 }
 
@@ -343,7 +369,7 @@ int32_t quotient_stage(nlx_circuit* c, const nlx_commit* cw, const nlx_commit* c
     const unsigned log_n = d.degree_bits;
     const size_t n = c->n(), L = c->L();
     const uint32_t nc = d.num_challenges, npp = d.num_partial_products;
-    c->n_terms = nc + nc * (npp + 1) + 128;
+    c->n_terms = nc + nc * (npp + 1) + c->max_gate_constraints;  // one alpha power per vanishing term (GateAcc reads ap[T0 + k])
     uint64_t* d_alpha_pows = (uint64_t*)ctx->alloc((size_t)2 * c->n_terms * 8);
     uint64_t* d_qvals = (uint64_t*)ctx->alloc((size_t)nc * L * 8);
     uint64_t* d_qchunks = (uint64_t*)ctx->alloc((size_t)nc * L * 8);
@@ -531,7 +557,7 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
             fa.d_wA_inv = c->d_wA_inv;
             CHECK(fri_prove(ctx, fa, ch, w, scratch, stage));
         }
-        w.u32(d.num_public_inputs);
+        w.usize(d.num_public_inputs);  // write_proof_with_public_inputs: write_usize(len), then the field vec
         w.u64s(h_pis.data(), h_pis.size());
         stage("end");
         c->n_stages--;  // "end" only closes the last interval

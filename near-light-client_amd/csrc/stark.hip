@@ -267,6 +267,7 @@ struct nlx_stark {
     uint32_t qdb = 0, nq = 0, n_regs = 0, n_fri_rounds = 0;
     uint32_t n_rounds = 1, round_cols[3] = {0, 0, 0}, round_challenges[3] = {0, 0, 0}, round_values[3] = {0, 0, 0},
              n_round_challenges = 0;  // n_round_challenges: round values + challenges, i.e. the values array minus public inputs
+    uint64_t air_digest[4] = {0, 0, 0, 0};  // the statement digest the transcript opens with (air_digest_host)
     uint64_t* d_program = nullptr;
     std::vector<uint32_t> seg;        // {first word, end word} per program segment
     std::vector<uint32_t> seg_after;  // constraints emitted after each segment
@@ -293,9 +294,30 @@ static size_t stark_proof_max_bytes(const nlx_stark_desc& d, uint32_t n_rounds) 
     size_t bytes = n_oracles * capb + 16 * (size_t)(2 * d.n_cols + nq) + n_rounds * capb;
     size_t per_query = (size_t)(d.n_cols + nq) * 8 + n_oracles * (1 + 32 * (size_t)log_L) +
                        n_rounds * (((size_t)16 << d.fri_arity_bits) + 1 + 32 * (size_t)log_L);
-    bytes += per_query * d.fri_num_queries + ((size_t)16 << d.degree_bits) + 8 + 4 + 8 * (size_t)d.num_public_inputs;
+    bytes += per_query * d.fri_num_queries + ((size_t)16 << d.degree_bits) + 8 + 8 + 8 * (size_t)d.num_public_inputs;
     for (uint32_t r = 0; r < d.n_rounds && r < 3; r++) bytes += 8 * (size_t)d.round_values[r];
     return bytes + 64;
+}
+
+// What circuit_digest is to a plonky2 circuit: the whole description (config, program, periodic columns, round
+// structure) hashed into four field elements.  hash_no_pad over 32-bit halves (each a canonical field element): 24 shape
+// words, then every program word as (lo, hi) - the stored program already has its CONST immediates reduced -, then every
+// periodic value (reduced) as (lo, hi).
+static void air_digest_host(const nlx_stark_desc& d, const std::vector<uint64_t>& prog, const std::vector<uint64_t>& periodic,
+                            uint64_t out[4]) {
+    std::vector<uint64_t> v;
+    v.reserve(24 + 2 * prog.size() + 2 * periodic.size());
+    const uint32_t shape[14] = {d.degree_bits, d.n_cols, d.num_challenges, d.rate_bits, d.cap_height, d.quotient_degree_factor,
+                                d.fri_pow_bits, d.fri_num_queries, d.fri_arity_bits, d.fri_final_poly_bits,
+                                d.num_public_inputs, d.n_words, d.n_periodic, d.n_periodic ? d.period_bits : 0u};
+    for (uint32_t x : shape) v.push_back(x);
+    v.push_back(d.n_rounds);
+    for (uint32_t r = 0; r < 3; r++) v.push_back(r < d.n_rounds ? d.round_cols[r] : 0);
+    for (uint32_t r = 0; r < 3; r++) v.push_back(r < d.n_rounds ? d.round_challenges[r] : 0);
+    for (uint32_t r = 0; r < 3; r++) v.push_back(r < d.n_rounds ? d.round_values[r] : 0);
+    for (uint64_t w : prog) { v.push_back(w & 0xFFFFFFFFu); v.push_back(w >> 32); }
+    for (uint64_t w : periodic) { v.push_back(w & 0xFFFFFFFFu); v.push_back(w >> 32); }
+    hash_no_pad_host(v.data(), v.size(), out);
 }
 
 extern "C" {
@@ -516,6 +538,7 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
             if (e2 != hipSuccess) return fail(ctx->hip_fail(e2, "hipMemcpy(periodic)"));
         }
     }
+    air_digest_host(s->d, s->program, s->periodic, s->air_digest);
     for (int i = 0; i <= NLX_MAX_STAGES; i++)
         if (hipEventCreate(&s->ev[i]) != hipSuccess) return fail(ctx->fail(NLX_E_HIP, "hipEventCreate failed"));
     {
@@ -595,6 +618,12 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
     };
     Writer w{proof_out, 0, proof_cap};
     Challenger ch;
+    // The transcript opens with the statement - the AIR digest, then the public inputs - before any commitment: the
+    // public inputs enter the AIR linearly, so a transcript without them would let a prover choose them after alpha and
+    // zeta are known (the starky of the pinned era had that gap; plonky2's own prover observes circuit_digest and the
+    // public-input hash first, and so does this one).
+    ch.observe(s->air_digest, 4);
+    ch.observe(public_inputs, d.num_public_inputs);
     std::vector<uint64_t> cap(capw);
     // values readable by NLX_AIR_PUBLIC: the public inputs, then the verifier challenges in the order drawn
     std::vector<uint64_t> values(public_inputs, public_inputs + d.num_public_inputs);
@@ -752,7 +781,7 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
             fa.d_wA_inv = s->d_wA_inv;
             CHECK(fri_prove(ctx, fa, ch, w, scratch, stage));
         }
-        w.u32(d.num_public_inputs);
+        w.usize(d.num_public_inputs);
         w.u64s(public_inputs, d.num_public_inputs);
         w.u64s(round_vals.data(), round_vals.size());
         stage("end");

@@ -104,7 +104,7 @@ void poseidon_gate_row(const uint64_t in[12], uint64_t swap, uint64_t* w /*135*/
     for (int i = 0; i < 12; i++) w[12 + i] = st[i];
 }
 
-uint32_t gate_degree(uint32_t kind, uint32_t p0) {
+uint32_t gate_degree(uint32_t kind, uint32_t p0, uint32_t p1 = 0) {
     switch (kind) {
         case NLX_GATE_NOOP: return 0;
         case NLX_GATE_CONSTANT: return 1;
@@ -123,8 +123,8 @@ uint32_t gate_degree(uint32_t kind, uint32_t p0) {
         case NLX_GATE_U32_ADD_MANY:
         case NLX_GATE_U32_ARITHMETIC:
         case NLX_GATE_U32_SUBTRACTION:
-        case NLX_GATE_U32_RANGE_CHECK:
-        case NLX_GATE_COMPARISON: return 4;  // 1 << limb_bits / 1 << chunk_bits
+        case NLX_GATE_U32_RANGE_CHECK: return 4;  // 1 << limb_bits
+        case NLX_GATE_COMPARISON: return p1 ? 1u << ((p0 + p1 - 1) / p1) : 4;  // 1 << chunk_bits
     }
     return 0;
 }
@@ -154,13 +154,14 @@ static uint32_t build_gate_list(const nlx_synth_params* sp, uint32_t* kinds, uin
     add(NLX_GATE_CONSTANT, 2, 0);                                // degree 1: "ConstantGate" < "PoseidonMdsGate" < "PublicInputGate"
     if (sp->pct_misc) add(NLX_GATE_POSEIDON_MDS, 0, 0);
     add(NLX_GATE_PUBLIC_INPUT, 0, 0);
-    if (sp->pct_base_sum) add(NLX_GATE_BASE_SUM, 2, 63);         // degree 2: "BaseSum" < "ReducingExtension" < "Reducing"
+    if (sp->pct_base_sum) add(NLX_GATE_BASE_SUM, 2, 63);         // degree 2: "BaseSum" < "Comparison" (1-bit chunks) < "ReducingExtension" < "Reducing"
+    if (sp->pct_u32 && sp->wide_comparison) add(NLX_GATE_COMPARISON, 25, 25);  // 132 constraints: more than any other gate
     if (sp->pct_extension) add(NLX_GATE_REDUCING_EXT, 32, 0);
     if (sp->pct_extension) add(NLX_GATE_REDUCING, 43, 0);
     if (sp->pct_extension) add(NLX_GATE_ARITHMETIC_EXT, 10, 0);  // degree 3: "ArithmeticExtension" < "ArithmeticGate" < "Mul..."
     if (sp->pct_arithmetic) add(NLX_GATE_ARITHMETIC, 20, 0);
     if (sp->pct_extension) add(NLX_GATE_MUL_EXT, 13, 0);
-    if (sp->pct_u32) add(NLX_GATE_COMPARISON, 32, 16);           // degree 4: "ComparisonGate" < "ExponentiationGate" < "U32..."
+    if (sp->pct_u32 && !sp->wide_comparison) add(NLX_GATE_COMPARISON, 32, 16);           // degree 4: "ComparisonGate" < "ExponentiationGate" < "U32..."
     if (sp->pct_misc) add(NLX_GATE_EXPONENTIATION, 66, 0);
     if (sp->pct_u32) add(NLX_GATE_U32_ADD_MANY, 2, 5);           // num_ops as plonky2x derives them for 135 / 80 wires
     if (sp->pct_u32) add(NLX_GATE_U32_ARITHMETIC, 3, 0);
@@ -177,12 +178,12 @@ void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_
     const uint32_t g = build_gate_list(sp, kinds, p0, p1);
     *n_gates = g;
     // greedy selector groups with max_degree = 8 (gates::selectors::selector_polynomials)
-    uint32_t max_deg = gate_degree(kinds[g - 1], p0[g - 1]);
+    uint32_t max_deg = gate_degree(kinds[g - 1], p0[g - 1], p1[g - 1]);
     if (max_deg + g - 1 <= 8) { *n_selectors = 1; return; }
     uint32_t sel = 0, start = 0;
     while (start < g) {
         uint32_t size = 0;
-        while (start + size < g && size + gate_degree(kinds[start + size], p0[start + size]) < 8) size++;
+        while (start + size < g && size + gate_degree(kinds[start + size], p0[start + size], p1[start + size]) < 8) size++;
         start += size;
         sel++;
     }
@@ -279,7 +280,7 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
         uint32_t start = 0, sel = 0;
         while (start < n_gates) {
             uint32_t size = 0;
-            while (start + size < n_gates && size + gate_degree(gates[start + size].kind, gates[start + size].param0) < 8) size++;
+            while (start + size < n_gates && size + gate_degree(gates[start + size].kind, gates[start + size].param0, gates[start + size].param1) < 8) size++;
             for (uint32_t g = start; g < start + size; g++) { gates[g].selector_index = sel; gates[g].group_start = start; gates[g].group_end = start + size; }
             start += size;
             sel++;
@@ -603,19 +604,23 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
                 break;
             }
             case NLX_GATE_COMPARISON: {
-                // result = (first <= second) on 32-bit inputs, 16 chunks of 2 bits
-                const uint32_t nch = 16, cb = 2;
-                uint64_t a = rng.next() & 0xFFFFFFFFULL, b = rng.next() & 0xFFFFFFFFULL;
+                // result = (first <= second) on num_bits-bit inputs in num_chunks chunks (32 bits as 16 chunks of 2 by
+                // default; 25 chunks of 1 bit - 132 constraints, the widest gate - with sp->wide_comparison)
+                const uint32_t nch = gates[g_cmp].param1, cb = (gates[g_cmp].param0 + nch - 1) / nch;
+                const uint64_t in_mask = (1ULL << gates[g_cmp].param0) - 1, ch_mask = (1ULL << cb) - 1;
+                uint64_t a = rng.next() & in_mask, b = rng.next() & in_mask;
                 if ((rng.next() & 7) == 0) b = a;  // exercise the all-chunks-equal path
                 if (!pool32.empty() && (rng.next() & 1)) {
                     const uint32_t src = pool32[rng.below((uint32_t)pool32.size())];
-                    a = wires[src];
-                    dsu.unite(slot(0, row), src);
+                    if (wires[src] <= in_mask) {
+                        a = wires[src];
+                        dsu.unite(slot(0, row), src);
+                    }
                 }
                 W_at(0, row) = a; W_at(1, row) = b;
                 uint64_t msd = 0;
                 for (uint32_t i = 0; i < nch; i++) {
-                    const uint64_t f = (a >> (cb * i)) & 3, s2 = (b >> (cb * i)) & 3;
+                    const uint64_t f = (a >> (cb * i)) & ch_mask, s2 = (b >> (cb * i)) & ch_mask;
                     const uint64_t diff = gl::sub(s2, f);
                     const uint64_t eq = f == s2 ? 1 : 0;
                     W_at(4 + i, row) = f;

@@ -64,7 +64,7 @@ struct Writer {
     }
     void u64s(const uint64_t* v, size_t n) { bytes(v, n * 8); }
     void u8(uint8_t v) { bytes(&v, 1); }
-    void u32(uint32_t v) { bytes(&v, 4); }
+    void usize(uint64_t v) { bytes(&v, 8); }  // Write::write_usize: 8 little-endian bytes
 };
 
 // plonky2::fri::reduction_strategies::FriReductionStrategy::ConstantArityBits(arity_bits, final_poly_bits)

@@ -36,7 +36,7 @@ class SynthParams(ctypes.Structure):
                 ("pct_poseidon", ctypes.c_uint32), ("pct_arithmetic", ctypes.c_uint32),
                 ("pct_base_sum", ctypes.c_uint32), ("pct_constant", ctypes.c_uint32), ("seed", ctypes.c_uint64),
                 ("pct_extension", ctypes.c_uint32), ("pct_misc", ctypes.c_uint32), ("pct_u32", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32)]
+                ("wide_comparison", ctypes.c_uint32)]
 
 
 class CircuitConfig:
@@ -68,11 +68,11 @@ class SyntheticCircuit:
     """A satisfiable nearx-shaped circuit + witness (see csrc/synth.cpp)."""
 
     def __init__(self, log_n, seed=1, num_public_inputs=4, pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5,
-                 pct_constant=5, pct_extension=0, pct_misc=0, pct_u32=0, config=None):
+                 pct_constant=5, pct_extension=0, pct_misc=0, pct_u32=0, config=None, wide_comparison=False):
         self.config = config or CircuitConfig()
         self.log_n = log_n
         sp = SynthParams(log_n, num_public_inputs, pct_poseidon, pct_arithmetic, pct_base_sum, pct_constant, seed,
-                         pct_extension, pct_misc, pct_u32, 0)
+                         pct_extension, pct_misc, pct_u32, 1 if wide_comparison else 0)
         ng, ns = ctypes.c_uint32(), ctypes.c_uint32()
         dll.nlx_synth_shape(ctypes.byref(sp), ctypes.byref(ng), ctypes.byref(ns))
         n = 1 << log_n

@@ -15,7 +15,8 @@ static inline void w_bytes(wbuf* w, const void* src, size_t n) {
 }
 static inline void w_u64s(wbuf* w, const uint64_t* v, size_t n) { w_bytes(w, v, n * 8); } /* little-endian host */
 static inline void w_u8(wbuf* w, uint8_t v) { w_bytes(w, &v, 1); }
-static inline void w_u32(wbuf* w, uint32_t v) { w_bytes(w, &v, 4); }
+/* plonky2 util::serialization Write::write_usize: a usize travels as 8 little-endian bytes */
+static inline void w_usize(wbuf* w, uint64_t v) { w_bytes(w, &v, 8); }
 typedef struct { const uint8_t* p; size_t len, pos; int bad; } rbuf;
 static inline void r_bytes(rbuf* r, void* dst, size_t n) {
     if (r->pos + n > r->len) { r->bad = 1; memset(dst, 0, n); return; }

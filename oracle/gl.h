@@ -5,8 +5,9 @@
  * /root/reference/Cargo.lock:4912-4914; source NOT vendored in /root/reference, so this
  * follows the published algorithm: goldilocks_field.rs / extension/quadratic.rs).
  *
- *   p  = 2^64 - 2^32 + 1,   MULTIPLICATIVE_GROUP_GENERATOR = 14293326489335486720 (= coset shift),
- *   POWER_OF_TWO_GENERATOR  = 7277203076849721926 (order 2^32),  ext2 = F_p[X]/(X^2 - 7).
+ *   p  = 2^64 - 2^32 + 1,  ext2 = F_p[X]/(X^2 - 7).  MULTIPLICATIVE_GROUP_GENERATOR (= coset shift) and
+ *   POWER_OF_TWO_GENERATOR (order 2^32) are parameters: include/nlx_field.h holds the one definition
+ *   (default 7 / 1753635133440165772; the evidence for each candidate pair is written there).
  *
  * Parity status: "parity unpinned" against Rust-produced proof bytes (none exist in the
  * reference); the Poseidon permutation is pinned by upstream's known-answer
@@ -18,11 +19,12 @@
 #define NLX_ORACLE_GL_H
 #include <stdint.h>
 #include <stddef.h>
+#include "../include/nlx_field.h"
 
 #define GL_P 0xFFFFFFFF00000001ULL
 #define GL_EPS 0xFFFFFFFFULL
-#define GL_GEN 14293326489335486720ULL
-#define GL_POW2_GEN 7277203076849721926ULL
+#define GL_GEN NLX_GL_MULTIPLICATIVE_GROUP_GENERATOR
+#define GL_POW2_GEN NLX_GL_POWER_OF_TWO_GENERATOR
 #define GL_TWO_ADICITY 32
 #define GL_W 7ULL /* ext2 non-residue */
 

@@ -9,6 +9,9 @@
 extern "C" {
 #endif
 
+/* the generator pair the oracle was built with (include/nlx_field.h): {MULTIPLICATIVE_GROUP_GENERATOR, POWER_OF_TWO_GENERATOR} */
+void orc_field_generators(uint64_t out[2]);
+
 /* ---- plonky2::hash::poseidon (Poseidon::poseidon_naive schedule), hashing.rs ---- */
 void orc_poseidon_permute(uint64_t state[12]);
 void orc_hash_no_pad(const uint64_t* in, size_t len, uint64_t out[4]);

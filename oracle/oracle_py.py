@@ -10,15 +10,26 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liboracle.so")
+# generator pair: include/nlx_field.h; NLX_GL_GENERATOR_SET=2021 builds / loads the other candidate pair
+GEN_SET = os.environ.get("NLX_GL_GENERATOR_SET", "7")
+_LIBNAME = "liboracle.so" if GEN_SET == "7" else "liboracle_gen%s.so" % GEN_SET
+_LIB = os.path.join(_HERE, _LIBNAME)
 P = 0xFFFFFFFF00000001
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".inc"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "nlx_field.h"))
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", _HERE, "-B", _LIBNAME, "GEN_SET=" + GEN_SET], check=True, capture_output=True)
     return _LIB
+
+
+def generators():
+    """(MULTIPLICATIVE_GROUP_GENERATOR, POWER_OF_TWO_GENERATOR) the oracle was built with"""
+    out = (ctypes.c_uint64 * 2)()
+    dll().orc_field_generators(out)
+    return int(out[0]), int(out[1])
 
 
 _dll = None
@@ -253,6 +264,8 @@ def _stark_sigs():
     d.orc_stark_prove.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     d.orc_stark_verify.restype = ctypes.c_int
     d.orc_stark_verify.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    d.orc_stark_air_digest.restype = None
+    d.orc_stark_air_digest.argtypes = [ctypes.c_void_p, u64p]
     return d
 
 
@@ -274,6 +287,14 @@ def stark_verify(desc, proof):
     d = _stark_sigs()
     buf = np.frombuffer(proof, dtype=np.uint8)
     return int(d.orc_stark_verify(ctypes.addressof(desc), buf.ctypes.data, buf.size))
+
+
+def stark_air_digest(desc):
+    """the statement digest the STARK transcript opens with (orc_stark_air_digest)"""
+    d = _stark_sigs()
+    out = np.zeros(4, dtype=np.uint64)
+    d.orc_stark_air_digest(ctypes.addressof(desc), _p(out))
+    return [int(x) for x in out]
 
 
 ROUND_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32,

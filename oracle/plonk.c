@@ -215,7 +215,7 @@ size_t orc_proof_max_bytes(const orc_circuit* c) {
     for (int o = 0; o < 4; o++) per_query += cols[o] * 8 + 1 + 32 * (c->log_L - d->cap_height);
     for (uint32_t r = 0; r < c->n_fri_rounds; r++) per_query += ((size_t)16 << d->fri_arity_bits) + 1 + 32 * c->log_L;
     bytes += per_query * d->fri_num_queries;
-    bytes += 16 * ((size_t)1 << d->degree_bits) /* final poly upper bound */ + 8 + 4 + 8 * d->num_public_inputs;
+    bytes += 16 * ((size_t)1 << d->degree_bits) /* final poly upper bound */ + 8 + 8 + 8 * d->num_public_inputs;
     return bytes + 64;
 }
 
@@ -616,7 +616,7 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
     }
     w_u64s(&w, (uint64_t*)coeffs, 2 * final_len);
     w_u64s(&w, &pow_witness, 1);
-    w_u32(&w, d->num_public_inputs);
+    w_usize(&w, d->num_public_inputs); /* write_proof_with_public_inputs: write_usize(len) then the field vec */
     w_u64s(&w, public_inputs, d->num_public_inputs);
 
     if (tr) {
@@ -694,8 +694,8 @@ int orc_verify(const orc_circuit* c, const uint8_t* proof, size_t len) {
     uint64_t pow_witness;
     r_u64s(&r, (uint64_t*)final_poly, 2 * final_len);
     r_u64s(&r, &pow_witness, 1);
-    uint32_t n_pi = 0;
-    r_bytes(&r, &n_pi, 4);
+    uint64_t n_pi = 0;
+    r_bytes(&r, &n_pi, 8);
     uint64_t* pis = (uint64_t*)malloc(8 * (n_pi + 1));
     if (n_pi != d->num_public_inputs) r.bad = 1;
     else r_u64s(&r, pis, n_pi);

@@ -12,6 +12,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+void orc_field_generators(uint64_t out[2]) {
+    out[0] = GL_GEN;
+    out[1] = GL_POW2_GEN;
+}
+
 void orc_fft(uint64_t* a, unsigned log_n) {
     size_t n = (size_t)1 << log_n;
     for (size_t i = 0; i < n; i++) {

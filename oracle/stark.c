@@ -483,6 +483,48 @@ static uint64_t* periodic_coeffs(const orc_stark_desc* d) {
     return c;
 }
 
+/* The AIR digest: what circuit_digest is to a plonky2 circuit - the whole description (config, program, periodic
+ * columns, round structure) hashed into four field elements, so that a proof is bound to the statement's constraint set.
+ * hash_no_pad over 32-bit halves (every half is a canonical field element): the 24 shape words below, then every
+ * program word as (lo, hi) with CONST immediates reduced mod p first, then every periodic value (reduced) as (lo, hi). */
+void orc_stark_air_digest(const orc_stark_desc* d, uint64_t out[4]) {
+    const size_t n_per = d->n_periodic ? ((size_t)d->n_periodic << d->period_bits) : 0;
+    const size_t len = 24 + 2 * (size_t)d->n_words + 2 * n_per;
+    uint64_t* v = (uint64_t*)malloc(8 * len);
+    size_t k = 0;
+    const uint32_t shape[14] = {d->degree_bits, d->n_cols, d->num_challenges, d->rate_bits, d->cap_height,
+                                d->quotient_degree_factor, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits,
+                                d->fri_final_poly_bits, d->num_public_inputs, d->n_words, d->n_periodic,
+                                d->n_periodic ? d->period_bits : 0};
+    for (int i = 0; i < 14; i++) v[k++] = shape[i];
+    v[k++] = d->n_rounds;
+    for (int r = 0; r < 3; r++) v[k++] = (uint32_t)r < d->n_rounds ? d->round_cols[r] : 0;
+    for (int r = 0; r < 3; r++) v[k++] = (uint32_t)r < d->n_rounds ? d->round_challenges[r] : 0;
+    for (int r = 0; r < 3; r++) v[k++] = (uint32_t)r < d->n_rounds ? d->round_values[r] : 0;
+    for (uint32_t pc = 0; pc < d->n_words; pc++) {
+        uint64_t w = d->program[pc];
+        v[k++] = w & 0xFFFFFFFFu; v[k++] = w >> 32;
+        if (AIR_OP(w) == ORC_AIR_CONST && pc + 1 < d->n_words) {
+            w = d->program[++pc] % GL_P;
+            v[k++] = w & 0xFFFFFFFFu; v[k++] = w >> 32;
+        }
+    }
+    for (size_t i = 0; i < n_per; i++) { uint64_t w = d->periodic[i] % GL_P; v[k++] = w & 0xFFFFFFFFu; v[k++] = w >> 32; }
+    orc_hash_no_pad(v, k, out);
+    free(v);
+}
+
+/* The transcript opens with the statement: the AIR digest, then the public inputs, before any commitment.  (plonky2's
+ * starky of the pinned era observed only the trace cap first - a Fiat-Shamir gap: the public inputs enter the AIR
+ * linearly, so a prover could fix them AFTER alpha and zeta were known.  plonky2's own prover observes circuit_digest and
+ * the public-input hash first; the STARK side does the same here.) */
+static void transcript_start(orc_challenger* ch, const orc_stark_desc* d, const uint64_t* public_inputs) {
+    uint64_t dig[4];
+    orc_stark_air_digest(d, dig);
+    orc_ch_observe_many(ch, dig, 4);
+    if (d->num_public_inputs) orc_ch_observe_many(ch, public_inputs, d->num_public_inputs);
+}
+
 /* rounds of commitment: classic starky = one round, no verifier challenges before the alphas */
 static uint32_t n_rounds_of(const orc_stark_desc* d) { return d->n_rounds ? d->n_rounds : 1; }
 static uint32_t round_cols_of(const orc_stark_desc* d, uint32_t r) { return d->n_rounds ? d->round_cols[r] : d->n_cols; }
@@ -544,7 +586,7 @@ size_t orc_stark_proof_max_bytes(const orc_stark_desc* d) {
     uint32_t R = fri_num_rounds(&fp);
     size_t bytes = (NRD + 1) * capb + 16 * (size_t)(2 * d->n_cols + nq) + R * capb;
     size_t per_query = (d->n_cols + nq) * 8 + (NRD + 1) * (1 + 32 * (size_t)log_L) + R * (((size_t)16 << d->fri_arity_bits) + 1 + 32 * (size_t)log_L);
-    bytes += per_query * d->fri_num_queries + ((size_t)16 << d->degree_bits) + 8 + 4 + 8 * (size_t)d->num_public_inputs +
+    bytes += per_query * d->fri_num_queries + ((size_t)16 << d->degree_bits) + 8 + 8 + 8 * (size_t)d->num_public_inputs +
              8 * (size_t)total_round_values(d);
     return bytes + 64;
 }
@@ -566,6 +608,7 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
     /* values readable by PUBLIC: public inputs, then the verifier challenges in the order they are drawn */
     uint64_t* values = (uint64_t*)calloc(d->num_public_inputs + n_rch + 1, 8);
     if (d->num_public_inputs) memcpy(values, public_inputs, 8 * (size_t)d->num_public_inputs);
+    transcript_start(&ch, d, values);
     uint32_t n_drawn = 0;
     uint64_t *r_coeffs[3] = {0}, *r_leaves[3] = {0}, *r_dig[3] = {0};
     uint64_t r_cap[3][4 * 64];
@@ -698,7 +741,7 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
     orc_fri_batch batches[2] = {{zeta, ncols + nq, idx_o, idx_p}, {g_zeta, ncols, idx_o, idx_p}};
     orc_fri_params fp = {d->degree_bits, d->rate_bits, cap_h, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits};
     fri_prove(&fp, oracles, NRD + 1, batches, 2, &ch, &w);
-    w_u32(&w, d->num_public_inputs);
+    w_usize(&w, d->num_public_inputs);
     w_u64s(&w, public_inputs, d->num_public_inputs);
     {   /* the round values, in round order, after the public inputs */
         uint32_t off = d->num_public_inputs;
@@ -731,14 +774,15 @@ uint32_t orc_stark_values(const orc_stark_desc* d, const uint8_t* proof, size_t 
     if (!desc_ok(d)) return 0;
     const size_t capw = (size_t)4 << d->cap_height;
     const uint32_t NRD = n_rounds_of(d), n_rv_total = total_round_values(d);
-    if (len < 8 * (NRD + 1) * capw + 4 + 8 * (size_t)(d->num_public_inputs + n_rv_total)) return 0;
-    const size_t tail = len - 4 - 8 * (size_t)(d->num_public_inputs + n_rv_total);
+    if (len < 8 * (NRD + 1) * capw + 8 + 8 * (size_t)(d->num_public_inputs + n_rv_total)) return 0;
+    const size_t tail = len - 8 - 8 * (size_t)(d->num_public_inputs + n_rv_total);
     const uint64_t* caps = (const uint64_t*)proof;
     uint64_t rv[3 * 64];
-    memcpy(out, proof + tail + 4, 8 * (size_t)d->num_public_inputs);
-    memcpy(rv, proof + tail + 4 + 8 * (size_t)d->num_public_inputs, 8 * (size_t)n_rv_total);
+    memcpy(out, proof + tail + 8, 8 * (size_t)d->num_public_inputs);
+    memcpy(rv, proof + tail + 8 + 8 * (size_t)d->num_public_inputs, 8 * (size_t)n_rv_total);
     orc_challenger ch;
     orc_ch_init(&ch);
+    transcript_start(&ch, d, out);
     uint32_t n = d->num_public_inputs, off = 0;
     for (uint32_t rd = 0; rd < NRD; rd++) {
         uint64_t cap[4 * 64];
@@ -771,14 +815,14 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
     uint64_t* pis = (uint64_t*)calloc(d->num_public_inputs + n_rch + 1, 8);
     const uint32_t n_rv_total = total_round_values(d);
     uint64_t round_vals[3 * 64];
-    if (len < 4 + 8 * (size_t)(d->num_public_inputs + n_rv_total)) { rc = -1; goto done; }
+    if (len < 8 + 8 * (size_t)(d->num_public_inputs + n_rv_total)) { rc = -1; goto done; }
     {
-        size_t tail = len - 4 - 8 * (size_t)(d->num_public_inputs + n_rv_total);
-        uint32_t n_pi;
-        memcpy(&n_pi, proof + tail, 4);
+        size_t tail = len - 8 - 8 * (size_t)(d->num_public_inputs + n_rv_total);
+        uint64_t n_pi;
+        memcpy(&n_pi, proof + tail, 8);
         if (n_pi != d->num_public_inputs) { rc = -1; goto done; }
-        memcpy(pis, proof + tail + 4, 8 * (size_t)n_pi);
-        memcpy(round_vals, proof + tail + 4 + 8 * (size_t)n_pi, 8 * (size_t)n_rv_total);
+        memcpy(pis, proof + tail + 8, 8 * (size_t)n_pi);
+        memcpy(round_vals, proof + tail + 8 + 8 * (size_t)n_pi, 8 * (size_t)n_rv_total);
         for (uint32_t i = 0; i < n_pi; i++) if (pis[i] >= GL_P) { rc = -1; goto done; }
         for (uint32_t i = 0; i < n_rv_total; i++) if (round_vals[i] >= GL_P) { rc = -1; goto done; }
         r.len = tail; /* the FRI reader must consume exactly up to here */
@@ -787,6 +831,7 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
     {
         orc_challenger ch;
         orc_ch_init(&ch);
+        transcript_start(&ch, d, pis);
         uint32_t n_drawn = 0, rv_off = 0;
         for (uint32_t rd = 0; rd < NRD; rd++) {
             orc_ch_observe_many(&ch, caps + rd * capw, capw);

@@ -111,6 +111,8 @@ size_t orc_stark_proof_max_bytes(const orc_stark_desc* d);
 /* trace: n_cols x n column-major.  Returns bytes written (0 on overflow). */
 size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uint64_t* public_inputs,
                        uint8_t* proof_out, size_t cap_bytes);
+/* the statement digest observed first in the transcript (config, program, periodic columns, round structure) */
+void orc_stark_air_digest(const orc_stark_desc* d, uint64_t out[4]);
 uint32_t orc_stark_values(const orc_stark_desc* d, const uint8_t* proof, size_t len, uint64_t* out);
 int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len);
 

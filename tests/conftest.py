@@ -11,6 +11,23 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 P = 0xFFFFFFFF00000001
 
 
+def field_generators(gen_set=None):
+    """(set, MULTIPLICATIVE_GROUP_GENERATOR, POWER_OF_TWO_GENERATOR) read from include/nlx_field.h - the one definition;
+    NLX_GL_GENERATOR_SET picks the set, exactly as the two library builds do."""
+    import re
+    gen_set = gen_set or os.environ.get("NLX_GL_GENERATOR_SET", "7")
+    with open(os.path.join(ROOT, "include", "nlx_field.h")) as f:
+        text = f.read()
+    m = re.search(r"NLX_GL_GENERATOR_SET == %s\s*\n#define NLX_GL_MULTIPLICATIVE_GROUP_GENERATOR (\d+)ULL\s*\n"
+                  r"#define NLX_GL_POWER_OF_TWO_GENERATOR (\d+)ULL" % gen_set, text)
+    assert m, "generator set %s is not defined in include/nlx_field.h" % gen_set
+    return gen_set, int(m.group(1)), int(m.group(2))
+
+
+GEN_SET, GEN, POW2_GEN = field_generators()
+GOLDEN_SUFFIX = "" if GEN_SET == "7" else "_gen" + GEN_SET
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
@@ -18,7 +35,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden():
     import json
-    with open(os.path.join(ROOT, "tests", "golden", "primitives.json")) as f:
+    with open(os.path.join(ROOT, "tests", "golden", "primitives%s.json" % GOLDEN_SUFFIX)) as f:
         return json.load(f)
 
 

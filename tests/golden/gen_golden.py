@@ -8,6 +8,8 @@ vectors are upstream's own known-answer tests (plonky2 poseidon_goldilocks.rs te
 quoted in SURVEY.md §8c); the third is SURVEY's [V] vector.
 
 Run:  python tests/golden/gen_golden.py   (rewrites primitives.json; deterministic)
+      NLX_GL_GENERATOR_SET=2021 python tests/golden/gen_golden.py   (primitives_gen2021.json: the other
+      candidate generator pair of include/nlx_field.h; only the LDE / commit / field sections differ)
 """
 import json
 import os
@@ -17,8 +19,21 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from gen_poseidon_constants import round_constants  # constants generator (ChaCha8 recipe)
 
 P = 0xFFFFFFFF00000001
-GEN = 14293326489335486720
-POW2_GEN = 7277203076849721926
+
+
+def field_generators(gen_set):
+    """the pair of include/nlx_field.h for the given set (the model shares only this definition with the C code)"""
+    import re
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "..", "..", "include", "nlx_field.h")) as f:
+        text = f.read()
+    m = re.search(r"NLX_GL_GENERATOR_SET == %s\s*\n#define NLX_GL_MULTIPLICATIVE_GROUP_GENERATOR (\d+)ULL\s*\n"
+                  r"#define NLX_GL_POWER_OF_TWO_GENERATOR (\d+)ULL" % gen_set, text)
+    return int(m.group(1)), int(m.group(2))
+
+
+GEN_SET = os.environ.get("NLX_GL_GENERATOR_SET", "7")
+GEN, POW2_GEN = field_generators(GEN_SET)
 RC = round_constants()
 CIRC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
 DIAG = [8] + [0] * 11
@@ -199,7 +214,10 @@ def main():
     g["field"] = {"p": P, "generator": GEN, "pow2_generator": POW2_GEN,
                   "gen_order_check": pow(GEN, (P - 1) >> 32, P), "root_2_8": root_of_unity(8)}
     assert g["field"]["gen_order_check"] == POW2_GEN
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "primitives.json")
+    assert all(pow(GEN, (P - 1) // q, P) != 1 for q in (2, 3, 5, 17, 257, 65537)), "not a generator of F_p^*"
+    g["field"]["generator_set"] = GEN_SET
+    name = "primitives.json" if GEN_SET == "7" else "primitives_gen%s.json" % GEN_SET
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
     with open(path, "w") as f:
         json.dump(g, f, indent=0, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -56,8 +56,14 @@ def cases():
     return out
 
 
+def golden_path():
+    """one file per generator pair of include/nlx_field.h (NLX_GL_GENERATOR_SET picks the build, as everywhere)"""
+    gen_set = os.environ.get("NLX_GL_GENERATOR_SET", "7")
+    return os.path.join(ROOT, "tests", "golden", "oracle_proofs.json" if gen_set == "7" else "oracle_proofs_gen%s.json" % gen_set)
+
+
 if __name__ == "__main__":
-    path = os.path.join(ROOT, "tests", "golden", "oracle_proofs.json")
+    path = golden_path()
     with open(path, "w") as f:
         json.dump(cases(), f, indent=1, sort_keys=True)
     print("wrote", path)

@@ -3,10 +3,9 @@ HIP path vs the CPU oracle on seeded inputs, and vs the committed golden fixture
 import numpy as np
 import pytest
 
-from conftest import P, rand_field
+from conftest import GEN, POW2_GEN, P, rand_field
 
 pytestmark = pytest.mark.gpu
-GEN = 14293326489335486720
 
 
 def test_poseidon_kats_gpu(nlx, ctx, golden):
@@ -140,7 +139,7 @@ def test_commit_large_roundtrip_properties(nlx, ctx, orc):
     L = 1 << (log_n + rate_bits)
     idx = np.array([0, 1, L // 2 + 3, L - 1, 12345], dtype=np.uint64)
     rows, paths = pb.open_rows(idx)
-    w = pow(7277203076849721926, 1 << (32 - log_n - rate_bits), P)
+    w = pow(POW2_GEN, 1 << (32 - log_n - rate_bits), P)
     for j, i in enumerate(idx):
         br = int(format(int(i), "0%db" % (log_n + rate_bits))[::-1], 2)
         x = GEN * pow(w, br, P) % P

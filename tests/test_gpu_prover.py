@@ -48,6 +48,45 @@ def test_proof_bytes_equal_oracle(nlx, ctx, orc, log_n, kw):
     ref.close()
 
 
+def _assert_same_bytes(got, want, what):
+    assert len(got) == len(want)
+    if got != want:
+        a, b = np.frombuffer(got, np.uint8), np.frombuffer(want, np.uint8)
+        first = int(np.nonzero(a != b)[0][0])
+        pytest.fail("%s: proof bytes differ from the oracle, first at byte %d of %d" % (what, first, len(want)))
+
+
+def test_bench_shape_bytes_equal_oracle(nlx, ctx, orc):
+    """The shape bench.py times by default until round 2 (2^16 rows, the nineteen-gate "nearx" mix,
+    standard_recursion_config): whole-proof BYTES equal the oracle prover's (about 10 s of oracle time on 16 cores)."""
+    import bench
+    syn = nlx.SyntheticCircuit(16, seed=0x6E6C78, **bench.GATE_MIXES["nearx"])
+    ref = orc.Circuit.from_synthetic(syn)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    want = ref.prove(syn.wires, syn.public_inputs)
+    got = cd.prove(syn.wires, syn.public_inputs)
+    _assert_same_bytes(got, want, "2^16 nineteen-gate circuit")
+    assert ref.verify(got) == 1
+    cd.close()
+    ref.close()
+
+
+def test_widest_gate_bytes_equal_oracle(nlx, ctx, orc):
+    """ComparisonGate { num_bits 25, num_chunks 25 } emits 132 constraints - more than PoseidonGate's 123 and more than
+    the 128 alpha powers the quotient stage reserved for gate constraints until round 2 (it now sizes the table from the
+    widest gate of the circuit, as the oracle always did)."""
+    syn = nlx.SyntheticCircuit(9, seed=25, pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_u32=50,
+                               wide_comparison=True)
+    assert any(g.kind == 18 and g.param0 == 25 and g.param1 == 25 for g in syn.gates)
+    ref = orc.Circuit.from_synthetic(syn)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    want = ref.prove(syn.wires, syn.public_inputs)
+    assert ref.verify(want) == 1
+    _assert_same_bytes(cd.prove(syn.wires, syn.public_inputs), want, "ComparisonGate(25, 25)")
+    cd.close()
+    ref.close()
+
+
 def test_stagewise_against_oracle_trace(nlx, ctx, orc):
     """Localises a mismatch: challenges and intermediate polynomials of the oracle trace vs what the
     GPU commits (Z / partial products and quotient chunks recovered from the proof's openings)."""

@@ -5,7 +5,7 @@ nlx_prove (and therefore as the oracle)."""
 import numpy as np
 import pytest
 
-from conftest import P
+from conftest import POW2_GEN, P
 
 pytestmark = pytest.mark.gpu
 
@@ -47,7 +47,7 @@ def test_stagewise_proof_equals_whole_proof(nlx, ctx, orc, log_n, kw):
     out += cq.cap.tobytes()
     ch.observe(cq.cap)
     zeta = ch.challenges(2)
-    g = pow(7277203076849721926, 1 << (32 - log_n), P)   # primitive 2^log_n-th root of unity
+    g = pow(POW2_GEN, 1 << (32 - log_n), P)   # primitive 2^log_n-th root of unity
     gzeta = np.array([int(zeta[0]) * g % P, int(zeta[1]) * g % P], dtype=np.uint64)
     # 4. openings
     cs = cd.constants_sigmas_batch()

@@ -24,6 +24,7 @@ CASES = [
     ("periodic", 6, {}),
     ("periodic", 9, dict(rate_bits=2)),
     ("periodic", 12, {}),
+    ("wide64", 14, {}),                               # 2^14 rows x 64 columns: the largest whole-STARK byte comparison
 ]
 
 

@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import P
+from conftest import POW2_GEN, P
 
 
 @pytest.mark.parametrize("log_n,kw", [
@@ -76,7 +76,7 @@ def test_selector_groups_follow_plonky2(nlx):
 def test_sigma_is_a_permutation_respecting_copies(nlx):
     syn = nlx.SyntheticCircuit(7, seed=9)
     n = 1 << 7
-    w = pow(7277203076849721926, 1 << (32 - 7), P)
+    w = pow(POW2_GEN, 1 << (32 - 7), P)
     sub = [pow(w, i, P) for i in range(n)]
     ids = {}
     for j in range(80):

@@ -356,11 +356,12 @@ def test_multi_round_logup_oracle(nlx, orc):
 
 def test_program_segments_do_not_change_the_proof(nlx, orc):
     """NLX_AIR_SEGMENT boundaries (no register carried across; shared sub-expressions recomputed per segment) leave
-    every constraint value, and so the proof bytes, unchanged."""
+    every constraint value unchanged.  (The proof bytes were equal too until the transcript began with the AIR digest,
+    which covers the program words: now only the trace cap - everything before the first challenge - is.)"""
     S = nlx.stark
     for kind, db in (("wide24", 6), ("wide96", 7), ("fib", 5), ("periodic", 6)):
         air, t, pis = make_case(S, kind, db)
-        proofs, sizes = [], []
+        proofs, sizes, rows = [], [], []
         for seg in (0, 1, 16, 1024):
             air.segment_nodes = seg
             st = S.Stark(air, db)
@@ -369,7 +370,10 @@ def test_program_segments_do_not_change_the_proof(nlx, orc):
             assert orc.stark_verify(st.desc, proofs[-1]) == 1
             row = run_program(st.program, t[:, 3], t[:, 4], pis, periodic=[int(c[3 % len(c)]) for c in air._periodic])
             assert len(row) == air.num_constraints
-        assert all(p == proofs[0] for p in proofs) and sizes[1] > sizes[0]
+            # a row pair that is NOT consecutive: non-zero constraint values, equal for every segmentation
+            rows.append(run_program(st.program, t[:, 3], t[:, 7], pis, periodic=[int(c[3 % len(c)]) for c in air._periodic]))
+        assert all(r == rows[0] for r in rows) and any(v != 0 for _, v in rows[0])
+        assert all(p[:512] == proofs[0][:512] for p in proofs) and sizes[1] > sizes[0]
 
 
 def fingerprint_air(S):
@@ -422,3 +426,39 @@ def test_round_values_oracle(nlx, orc):
 def ctypes_sizeof(x):
     import ctypes
     return ctypes.sizeof(x)
+
+
+def test_transcript_binds_public_inputs_and_air(nlx, orc):
+    """The transcript opens with the AIR digest and the public inputs (round 1 observed only caps and round values, so
+    a public input could be chosen after alpha and zeta were known).  Sharpest case: a public input NO constraint reads -
+    the constraint check cannot notice a change, only the transcript can."""
+    S = nlx.stark
+    air = S.Air(2, 4)  # FibonacciStark + a fourth public input that the program never loads
+    air.constraint_first_row(air.local(0) - air.public(0))
+    air.constraint_first_row(air.local(1) - air.public(1))
+    air.constraint_last_row(air.local(1) - air.public(2))
+    air.constraint_transition(air.next(0) - air.local(1))
+    air.constraint_transition(air.next(1) - air.local(0) - air.local(1))
+    t, pis3 = S.fibonacci_trace(6, 3, 5)
+    pis = np.concatenate([pis3, np.array([77], dtype=np.uint64)])
+    st = S.Stark(air, 6)
+    proof = orc.stark_prove(st.desc, t, pis)
+    assert orc.stark_verify(st.desc, proof) == 1
+    # tail = u64 count | public inputs: rewrite the unread one after the fact
+    assert int.from_bytes(proof[-40:-32], "little") == 4 and int.from_bytes(proof[-8:], "little") == 77
+    forged = proof[:-8] + (78).to_bytes(8, "little")
+    assert orc.stark_verify(st.desc, forged) != 1
+    # the same trace proved for the other value is a different transcript from the first cap's challenges on
+    other = orc.stark_prove(st.desc, t, np.concatenate([pis3, np.array([78], dtype=np.uint64)]))
+    assert orc.stark_verify(st.desc, other) == 1 and other[:512] == proof[:512] and other[512:1024] != proof[512:1024]
+    # and the statement digest covers the program: an AIR differing in one constant rejects the proof of the other
+    air2 = S.Air(2, 4)
+    air2.constraint_first_row(air2.local(0) - air2.public(0))
+    air2.constraint_first_row(air2.local(1) - air2.public(1))
+    air2.constraint_last_row(air2.local(1) - air2.public(2))
+    air2.constraint_transition(air2.next(0) - air2.local(1))
+    air2.constraint_transition((air2.next(1) - air2.local(0) - air2.local(1)) * 2)
+    st2 = S.Stark(air2, 6)
+    assert orc.stark_air_digest(st.desc) != orc.stark_air_digest(st2.desc)
+    assert orc.stark_verify(st2.desc, proof) != 1
+    assert orc.stark_verify(st2.desc, orc.stark_prove(st2.desc, t, pis)) == 1
