@@ -33,6 +33,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# Integer-VALU issue roofline of the Poseidon permutation kernel: per wave 11.2 k v_mad_u64_u32 at 4.7
+# cycles + 10.5 k other VALU at 2.9 cycles (measured issue costs, profiles/r02_valu_ubench.txt) = 83.1 k cycles per 64
+# permutations; 1 024 SIMDs at the 2.1 GHz the chip holds under this load.
+VALU_CYCLES_PER_WAVE_PERM = 11.2e3 * 4.7 + 10.5e3 * 2.9
+VALU_PEAK_GPERM = 1024 * 64 / VALU_CYCLES_PER_WAVE_PERM * 2.1
+VALU_PEAK_NOTE = ("1 024 SIMDs x 64 lanes / (11.2 k MAC x 4.7 cyc + 10.5 k other VALU x 2.9 cyc per wave) x 2.1 GHz; issue costs "
+                  "measured by tools/ubench/poseidon_ubench.hip (profiles/r02_valu_ubench.txt)")
+
+
+def stored_traffic(key, alg_bytes):
+    """HBM bytes per launch from the committed PMC pass (profiles/r02_pmc_traffic.json: FETCH_SIZE x 2 per the microarch
+    guide, a separate rocprofv3 --pmc run of this command): measured ratio traffic / algorithmic bytes x this run's
+    algorithmic bytes.  Not measured in this process (counters need their own run) - labelled "stored"."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        prof = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(prof):
+            try:
+                ratio = json.load(open(prof)).get(key)
+                if ratio:
+                    return ratio * alg_bytes, "stored: profiles/%s (%s = %.3f)" % (name, key, ratio)
+            except Exception:
+                pass
+    return None, None
 
 # Row shares (percent) of the synthetic SyncCircuit-shaped workload; the rest are NoopGate rows.  "nearx" (default)
 # contains all nineteen gate kinds the library implements - Poseidon hashing, base-field and extension arithmetic,
@@ -50,14 +73,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sync", choices=["sync", "verify128", "stark", "sha256", "sha512", "ed25519", "sync_starks"])
+    ap.add_argument("--workload", default="sync", choices=["sync", "outer", "verify128", "stark", "sha256", "sha512", "ed25519", "ntt24"])
     ap.add_argument("--log-blocks", type=int, default=14, help="sha256 workload: 2^k compression blocks per proof")
     ap.add_argument("--log-slots", type=int, default=10, help="ed25519 workload: 2^k signature slots per proof (>= 4)")
     ap.add_argument("--segment-nodes", type=int, default=None, help="sha256 / sha512 / ed25519 workloads: AIR program segment size in arithmetic nodes (0 = one segment)")
     ap.add_argument("--stark-cols", type=int, default=256)
-    ap.add_argument("--log-n", type=int, default=16)
+    ap.add_argument("--log-n", type=int, default=None,
+                    help="rows of the (outer) plonky2 proof: default 18 for --workload sync (DESIGN.md §6 derives >= 2^17 from the "
+                         "in-circuit cost of verifying the three STARK proofs), 16 for the others")
     ap.add_argument("--gate-mix", default="nearx", choices=["nearx", "basic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="sync workload: skip the plonky2-only 2^16 figures")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent proofs in flight per GPU (one context + stream + host thread each); the K "
                          "timed steps are shared between them")
@@ -145,7 +171,8 @@ def cpu_baseline(nlx, log_n, gate_mix):
                       "in rows; oracle verifier accepted: %s" % (sample_log_n, int(scale), dt, ok)}
 
 
-def run_sync(args, nlx, torch, rank, world, local, dist):
+def run_outer(args, nlx, torch, rank, world, local, dist):
+    """--workload outer: the outer plonky2 proof alone (round 1's default job; --log-n sweeps its size)."""
     import numpy as np
     gate_mix = GATE_MIXES[args.gate_mix]
     syn = nlx.SyntheticCircuit(args.log_n, seed=1000 + rank, num_public_inputs=64, **gate_mix)
@@ -563,20 +590,19 @@ def run_ed25519(args, nlx, torch, rank, world, local, dist):
     return out
 
 
-def run_sync_starks(args, nlx, torch, rank, world, local, dist):
-    """Secondary workload: every STARK sub-proof of ONE real Sync step (mainnet fixtures main_0 -> main_1, the step the
-    reference's tests walk, crates/protocol/src/lib.rs:364-405): the SHA-256 of its header / next_bps hashing
-    (curta_sha256), the SHA-512 of every signed approval and the Ed25519 verification of every signed approval
-    (curta_eddsa_verify_sigs_conditional, nearx/src/builder.rs:152) - plus the outer plonky2 proof of the bench's
-    default shape.  A step = all four proofs, traces generated on the GPU; they are independent, so the timed pass runs
-    them concurrently (one context, stream and host thread each); the per-proof times come from a sequential pass."""
+def sync_step_setup(args, nlx, torch, rank, local):
+    """Everything one real Sync step needs, resident on GPU `local`: the step main_1 -> main_2 of the reference's mainnet
+    fixtures (BASELINE.json configs[0]/[1] name fixtures/main_2.json; crates/protocol/src/lib.rs:364-405 walks the same
+    chain).  What nearx proves for it (nearx/src/builder.rs:265-308 `sync`): header / next_bps hashing = curta_sha256
+    (builder.rs:220,316; variables.rs:71-72), one SHA-512 + one Ed25519 verification per signed approval =
+    curta_eddsa_verify_sigs_conditional (builder.rs:116-164), and the outer plonky2 circuit that verifies those STARKs."""
     import json
     import numpy as np
     NP, SA, SB, E = nlx.near_protocol, nlx.sha256_air, nlx.sha512_air, nlx.ed25519_air
     near = os.path.join(ROOT, "tests", "golden", "near")
-    with open(os.path.join(near, "main_0.json")) as f:
-        bps = json.load(f)["body"]["next_bps"]
     with open(os.path.join(near, "main_1.json")) as f:
+        bps = json.load(f)["body"]["next_bps"]
+    with open(os.path.join(near, "main_2.json")) as f:
         nxt = json.load(f)["body"]
     msg = NP.reconstruct_approval_message(nxt)
     sha_msgs = NP.sync_sha256_messages(nxt)
@@ -588,96 +614,315 @@ def run_sync_starks(args, nlx, torch, rank, world, local, dist):
         sig_msgs.append(raw[:32] + pk + msg)
         slots.append(E.slot_from_signature(pk, msg, raw))
     n_sigs = len(slots)
-    lb256 = max(2, (sum(len(SA.pad_message(m)) for m in sha_msgs) - 1).bit_length())
-    lb512 = max(2, (n_sigs - 1).bit_length())
-    log_slots = max(4, (n_sigs - 1).bit_length())           # below 2^8 slots the range table is spread over several columns
-    slot_words = E.slots_to_words((slots * ((1 << log_slots) // n_sigs + 1))[: 1 << log_slots])
-    # the four proofs are independent: each gets its own context (HIP stream + scratch) and, in the
-    # concurrent mode, its own host thread - the small latency-bound STARKs then run under the Ed25519 one
+    st = {"n_sigs": n_sigs, "sha_msgs": sha_msgs, "sig_msgs": sig_msgs, "slots": slots, "nxt": nxt}
+    st["lb256"] = max(2, (sum(len(SA.pad_message(m)) for m in sha_msgs) - 1).bit_length())
+    st["lb512"] = max(2, (n_sigs - 1).bit_length())
+    st["log_slots"] = max(4, (n_sigs - 1).bit_length())   # below 2^8 slots the range table is spread over several columns
+    st["bound_slots"] = (slots * ((1 << st["log_slots"]) // n_sigs + 1))[: 1 << st["log_slots"]]
+    st["slot_words"] = E.slots_to_words(st["bound_slots"])
+    # the four proofs get a context (HIP stream + scratch) each
     ctxs = [nlx.Context(local) for _ in range(4)]
-    p256, p512, ped = SA.Sha256Prover(ctxs[0], lb256), SB.Sha512Prover(ctxs[1], lb512), E.Ed25519Prover(ctxs[2], log_slots)
+    st["ctxs"] = ctxs
+    st["p256"], st["p512"] = SA.Sha256Prover(ctxs[0], st["lb256"]), SB.Sha512Prover(ctxs[1], st["lb512"])
+    st["ped"] = E.Ed25519Prover(ctxs[2], st["log_slots"])
     syn = nlx.SyntheticCircuit(args.log_n, seed=1000 + rank, num_public_inputs=64, **GATE_MIXES[args.gate_mix])
     io = nlx.nearx_io
-    sync_in, sync_out = io.sync_io(io.load_fixture(os.path.join(near, "main_1.json")))
+    sync_in, sync_out = io.sync_io(io.load_fixture(os.path.join(near, "main_2.json")))
     syn.set_public_inputs(io.bytes_to_field_elements(sync_in + sync_out))
-    cd = nlx.CircuitData.from_synthetic(ctxs[3], syn)
-    wires = torch.from_numpy(syn.wires.view(np.int64)).cuda()
-    pis = np.ascontiguousarray(syn.public_inputs)
-    jobs = [lambda: p256.prove(sha_msgs), lambda: p512.prove(sig_msgs), lambda: ped.prove(slot_words),
-            lambda: cd.prove_into(wires, pis.ctypes.data)]
+    st["syn"], st["sync_out"] = syn, sync_out
+    st["cd"] = nlx.CircuitData.from_synthetic(ctxs[3], syn)
+    st["wires"] = torch.from_numpy(syn.wires.view(np.int64)).to("cuda:%d" % local)   # witness resident in HBM
+    st["pis"] = np.ascontiguousarray(syn.public_inputs)
+    return st
 
-    def step(concurrent):
-        res, ms = [None] * 4, [0.0] * 4
 
-        def run(i):
-            t1 = time.perf_counter()
-            res[i] = jobs[i]()
-            ms[i] = 1e3 * (time.perf_counter() - t1)
-        if concurrent:
-            import threading
-            th = [threading.Thread(target=run, args=(i,)) for i in range(4)]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-        else:
-            for i in range(4):
-                run(i)
-        return res[0], res[1], res[2], ms
-    for _ in range(args.warmup):
-        step(False)
-        step(True)
-    # sequential pass (per-proof times), then the timed concurrent pass
-    parts = np.zeros(4)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        a, b, c, ms = step(False)
-        parts += ms
-    dt_seq = time.perf_counter() - t0
+def stark_verifier_rows(st):
+    """Lower bound on the rows of the outer circuit, from what it must do: verify the three STARK proofs.  One
+    PoseidonGate row per permutation (plonky2 hashes in-circuit with one gate per permutation): per FRI query and per
+    committed oracle, ceil(cols / 8) permutations for the opened leaf and one per Merkle sibling; per FRI reduction round a
+    2^arity-point leaf of extension values (2 * 2^arity / 8 permutations) and its path; plus the transcript (every opened
+    value is observed: 2 * (2 * cols + quotient) elements / 8).  Arithmetic rows (FRI folding, the AIR's constraints at zeta)
+    come on top and are not counted, so this is a floor.  DESIGN.md §6 works the numbers."""
+    rows = {}
+    for name, pr in (("sha256", st["p256"]), ("sha512", st["p512"]), ("ed25519", st["ped"])):
+        d = pr.stark.desc
+        log_l = d.degree_bits + d.rate_bits
+        n_rounds = d.n_rounds if d.n_rounds else 1
+        oracles = [d.round_cols[r] for r in range(n_rounds)] if d.n_rounds else [d.n_cols]
+        oracles.append(d.num_challenges * d.quotient_degree_factor)
+        per_query = sum((c + 7) // 8 if c > 4 else 0 for c in oracles) + len(oracles) * (log_l - d.cap_height)
+        bits, fri_rounds = d.degree_bits, 0
+        while bits > d.fri_final_poly_bits and bits + d.rate_bits >= d.cap_height + d.fri_arity_bits and bits >= d.fri_arity_bits:
+            bits -= d.fri_arity_bits
+            fri_rounds += 1
+        ll = log_l
+        for _ in range(fri_rounds):
+            ll -= d.fri_arity_bits
+            per_query += (2 << d.fri_arity_bits) // 8 + max(ll - d.cap_height, 0)
+        transcript = (2 * (2 * d.n_cols + oracles[-1]) + 7) // 8
+        rows[name] = per_query * d.fri_num_queries + transcript
+    rows["total"] = sum(rows.values())
+    return rows
+
+
+def run_sync(args, nlx, torch, rank, world, local, dist):
+    """Default workload (BASELINE.json configs[1]): ONE FULL SYNC PROOF per step = the SHA-256 STARK, the SHA-512 STARK
+    and the Ed25519 STARK of a real mainnet step (traces generated on the GPU inside the timed region) + the outer plonky2
+    proof (2^--log-n rows, default 2^18).  Within a step the outer proof consumes the STARK proofs, so it starts only after
+    all three are done (they run concurrently: own context, stream and host thread each); successive Sync requests are
+    independent ("replicas only"), so step i+1's STARKs overlap step i's outer proof."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    st = sync_step_setup(args, nlx, torch, rank, local)
+    p256, p512, ped, cd, wires, pis = st["p256"], st["p512"], st["ped"], st["cd"], st["wires"], st["pis"]
+    ctxs = st["ctxs"]
+    outer_buf = cd._buf   # nlx_prove writes the proof here (prove_into returns its length)
+    stark_jobs = [lambda: p256.prove(st["sha_msgs"]), lambda: p512.prove(st["sig_msgs"]), lambda: ped.prove(st["slot_words"])]
+    pool = ThreadPoolExecutor(max_workers=4)
+
+    def outer_job():
+        return cd.prove_into(wires, pis.ctypes.data)
+
+    def timed(fn, slot, acc):
+        t1 = time.perf_counter()
+        r = fn()
+        acc[slot] += 1e3 * (time.perf_counter() - t1)
+        return r
+
+    def run_steps(k, pipelined, acc):
+        """k Sync proofs; returns the last step's (sha256, sha512, ed25519) results and outer proof length"""
+        res, prev_outer, outer_len = None, None, 0
+        for _ in range(k):
+            if pipelined:
+                futs = [pool.submit(timed, j, i, acc) for i, j in enumerate(stark_jobs)]
+                res = [f.result() for f in futs]            # this step's STARKs (the previous step's outer proof runs meanwhile)
+                if prev_outer is not None:
+                    outer_len = prev_outer.result()
+                prev_outer = pool.submit(timed, outer_job, 3, acc)
+            else:
+                res = [timed(j, i, acc) for i, j in enumerate(stark_jobs)]
+                outer_len = timed(outer_job, 3, acc)
+        if prev_outer is not None:
+            outer_len = prev_outer.result()
+        return res, outer_len
+    scratch = [0.0] * 4
+    if args.warmup:
+        run_steps(args.warmup, True, scratch)
+    for c in ctxs:
+        c.kernel_timing(True)
     barrier(dist, torch)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        a, b, c, _ = step(True)
+    (a, b, c_proof), outer_len = run_steps(args.steps, True, [0.0] * 4)
     barrier(dist, torch)
     dt = reduce_max(dist, torch, time.perf_counter() - t0)
+    names = ("intt", "lde", "hash_lde_leaves", "merkle_levels", "quotient", "air_quotient", "fri_combine")
+
+    def collect():
+        ks = {k: [0, 0.0, 0.0, 0.0] for k in names}
+        for c in ctxs:
+            for k in names:
+                n_, ms_, b_ = c.kernel_stats(k)
+                ks[k][0] += n_
+                ks[k][1] += ms_
+                ks[k][2] += b_
+                ks[k][3] += c.kernel_units(k)
+        return ks
+    kstats = collect()
+    for c in ctxs:
+        c.kernel_timing(False)
     out = None
     if rank == 0:
         import hashlib
         import struct
-        assert b"".join(struct.pack(">I", int(x)) for x in a[1]) == io.b58decode32(nxt["inner_lite"]["next_bp_hash"])
-        assert [int(x) for x in b[1]] == list(struct.unpack(">8Q", hashlib.sha512(sig_msgs[-1]).digest()))
-        parts /= args.steps
+        io = nlx.nearx_io
+        outer_proof = outer_buf[:outer_len].tobytes()
+        # the public digests are the real ones: next_bp_hash of the header, hashlib's SHA-512 of the last approval
+        assert b"".join(struct.pack(">I", int(x)) for x in a[1]) == io.b58decode32(st["nxt"]["inner_lite"]["next_bp_hash"])
+        assert [int(x) for x in b[1]] == list(struct.unpack(">8Q", hashlib.sha512(st["sig_msgs"][-1]).digest()))
+        # one step with one proof at a time, kernel events on: per-proof times and the kernels' own durations
+        for c in ctxs:
+            c.kernel_timing(True)
+        parts = [0.0] * 4
+        t1 = time.perf_counter()
+        run_steps(2, False, parts)
+        seq_ms = (time.perf_counter() - t1) / 2 * 1e3
+        ks1 = collect()
+        for c in ctxs:
+            c.kernel_timing(False)
+        parts = [p / 2 for p in parts]
+
+        def roofs(ks):
+            calls, ms, alg, perms = ks["hash_lde_leaves"]
+            if not calls:
+                return None, None
+            ach = alg / (ms * 1e-3) / 1e9
+            gperm = perms / (ms * 1e-3) / 1e9
+            hbm = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                   "traffic": None, "kernel": "k_hash_lde_leaves", "launches": calls, "avg_launch_ms": ms / calls,
+                   "alg_bytes_per_launch": alg / calls}
+            valu = {"bound": "integer VALU issue", "achieved": gperm, "peak": VALU_PEAK_GPERM, "unit": "Gperm/s",
+                    "frac": gperm / VALU_PEAK_GPERM, "kernel": "k_hash_lde_leaves", "permutations_per_launch": perms / calls,
+                    "peak_model": VALU_PEAK_NOTE}
+            return hbm, valu
+        hbm, valu = roofs(kstats)
+        hbm1, valu1 = roofs(ks1)
+        if hbm is not None:
+            hbm["traffic"], hbm["traffic_source"] = stored_traffic("hash_lde_leaves_fetch_over_algorithmic", hbm["alg_bytes_per_launch"])
+            hbm["note"] = ("Poseidon leaf hashing of every LDE table of the four proofs (8cL + 32L bytes per launch, SURVEY.md §8d); "
+                           "integer-VALU bound, so the HBM fraction is low by construction - see roofline_valu; with several "
+                           "proofs in flight the event-timed duration includes time shared with the other streams' kernels "
+                           "(roofline_single_stream: one proof at a time)")
+        rows = stark_verifier_rows(st)
         out = {
-            "metric": "Sync step: all STARK sub-proofs (SHA-256, SHA-512, Ed25519) + the outer proof, per second (secondary workload)",
-            "value": world * args.steps / dt, "unit": "sync steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 (Goldilocks field, integer)", "data": "real mainnet Sync step (fixtures main_0 -> main_1) for the STARKs; synthetic outer circuit",
-            "config": {"workload": "one real Sync step: SHA-256 STARK of %d messages (2^%d blocks), SHA-512 STARK of %d approval "
-                                   "hashes (2^%d blocks), Ed25519 STARK of %d approval signatures (2^%d slots), outer plonky2 proof "
-                                   "(2^%d rows, synthetic nearx-shaped); the four proofs run concurrently on one GPU (own context, "
-                                   "stream and host thread each); replicas only"
-                                   % (len(sha_msgs), lb256, n_sigs, lb512, n_sigs, log_slots, args.log_n),
-                       "ms_one_after_the_other": {"sha256": round(parts[0], 2), "sha512": round(parts[1], 2), "ed25519": round(parts[2], 2),
-                                                  "outer_plonky2": round(parts[3], 2), "step": round(dt_seq / args.steps * 1e3, 2)},
-                       "proof_bytes": {"sha256": len(a[0]), "sha512": len(b[0]), "ed25519": len(c)},
-                       "public_digest": "SHA-256 STARK output = the header's next_bp_hash; SHA-512 STARK output = hashlib's digest of the last approval"},
-            "roofline": None,
+            "metric": "Sync/Verify proofs/sec at 1/2/4/8 MI355X + achieved HBM GB/s vs roofline",
+            "value": world * args.steps / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer)",
+            "data": "real mainnet Sync step (fixtures main_1 -> main_2) for the three STARKs, traces generated on the GPU; synthetic outer circuit of SyncCircuit's static shape",
+            "config": {"workload": "one full Sync proof = SHA-256 STARK of %d header / next_bps messages (2^%d blocks, 2^%d x %d trace) + "
+                                   "SHA-512 STARK of %d approval hashes (2^%d blocks) + Ed25519 STARK of %d approval signatures (2^%d "
+                                   "slots, 2^%d rows) + outer plonky2 proof (standard_recursion_config, 2^%d rows, 135 wires, %d gate "
+                                   "kinds); the outer proof of a step starts when its three STARKs are done, the next step's "
+                                   "STARKs overlap it; replicas only"
+                                   % (len(st["sha_msgs"]), st["lb256"], st["lb256"] + 2, p256.stark.desc.n_cols, st["n_sigs"], st["lb512"],
+                                      st["n_sigs"], st["log_slots"], ped.stark.desc.degree_bits, args.log_n, st["syn"].num_gates),
+                       "log_n_outer": args.log_n, "gate_mix_pct": GATE_MIXES[args.gate_mix],
+                       "outer_rows_floor_from_stark_verification": rows,
+                       "public_inputs": "64 bytes of real Sync I/O (fixtures/main_2.json): new head hash 0x%s" % st["sync_out"].hex(),
+                       "proof_bytes": {"sha256": len(a[0]), "sha512": len(b[0]), "ed25519": len(c_proof), "outer": outer_len},
+                       "parallelism": "replicas x%d" % world},
+            "roofline": hbm, "roofline_valu": valu,
+            "roofline_single_stream": {"hbm_frac": hbm1["frac"] if hbm1 else None, "hbm_achieved": hbm1["achieved"] if hbm1 else None,
+                                       "valu_frac": valu1["frac"] if valu1 else None, "valu_achieved": valu1["achieved"] if valu1 else None,
+                                       "avg_launch_ms": hbm1["avg_launch_ms"] if hbm1 else None, "launches": hbm1["launches"] if hbm1 else None,
+                                       "note": "2 steps, one proof at a time, after the timed region"},
+            "ms_one_proof_at_a_time": {"sha256": round(parts[0], 2), "sha512": round(parts[1], 2), "ed25519": round(parts[2], 2),
+                                       "outer_plonky2": round(parts[3], 2), "step": round(seq_ms, 2)},
+            "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kstats.items()},
+            "outer_stage_ms_last_proof": {k: round(v, 3) for k, v in cd.stage_times()},
         }
+        # the plonky2 proof alone at 2^16 rows (round 1's headline shape), same code, one proof at a time and three in flight
+        out["plonky2_only"] = {"log_n_%d_ms_single_stream" % args.log_n: round(parts[3], 2)}
+        if not args.no_extra:
+            out["plonky2_only"].update(outer_only_figures(nlx, ctxs, local, torch, rank, 16, args.gate_mix))
         if not args.no_cpu_baseline and world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import oracle_py
+            out["cpu_baseline"], out["parity_checked"] = cpu_baseline_sync(args, nlx, st, a, b, seq_ms)
+        else:
             out["cpu_baseline"] = None
-            out["oracle_verifier_accepts"] = {"sha256": oracle_py.stark_verify(p256.stark.desc, a[0]) == 1,
-                                              "sha512": oracle_py.stark_verify(p512.stark.desc, b[0]) == 1,
-                                              "ed25519": oracle_py.stark_verify(ped.stark.desc, c) == 1}
-            vals = oracle_py.stark_values(ped.stark.desc, c)           # [alpha0, alpha1, gamma0, gamma1, total0, total1]
-            bound = (slots * ((1 << log_slots) // n_sigs + 1))[: 1 << log_slots]
-            out["ed25519_round_value_is_the_fingerprint_of_the_signatures"] = tuple(vals[4:6]) == E.fingerprint(bound, vals[2:4])
+        out["outer_proof_sha256"] = hashlib.sha256(outer_proof).hexdigest()
+    pool.shutdown()
     for pr in (p256, p512, ped):
         pr.close()
     for c_ in ctxs:
         c_.close()
     return out
+
+
+def outer_only_figures(nlx, ctxs, local, torch, rank, log_n, gate_mix):
+    """ms per plonky2 proof at 2^log_n rows: one at a time on one context, and three in flight (nlx_batch_prove)"""
+    import ctypes
+    import numpy as np
+    syn = nlx.SyntheticCircuit(log_n, seed=1000 + rank, num_public_inputs=64, **GATE_MIXES[gate_mix])
+    cds = [nlx.CircuitData.from_synthetic(c, syn) for c in ctxs[:3]]
+    wires = torch.from_numpy(syn.wires.view(np.int64)).to("cuda:%d" % local)
+    pis = np.ascontiguousarray(syn.public_inputs)
+    for cd in cds:
+        cd.prove_into(wires, pis.ctypes.data)
+    t0 = time.perf_counter()
+    for _ in range(4):
+        cds[0].prove_into(wires, pis.ctypes.data)
+    single = (time.perf_counter() - t0) / 4 * 1e3
+    k = 12
+    cap = nlx.lib.dll.nlx_proof_max_bytes(cds[0].handle)
+    bufs = [np.zeros(cap, dtype=np.uint8) for _ in range(k)]
+    jobs = (nlx.ProveJob * k)()
+    for i in range(k):
+        jobs[i].wires, jobs[i].public_inputs, jobs[i].proof_out, jobs[i].proof_cap = wires.data_ptr(), pis.ctypes.data, bufs[i].ctypes.data, cap
+    handles = (ctypes.c_void_p * 3)(*[cd.handle for cd in cds])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc = nlx.lib.dll.nlx_batch_prove(handles, 3, jobs, k)
+    torch.cuda.synchronize()
+    three = (time.perf_counter() - t0) / k * 1e3
+    for cd in cds:
+        cd.close()
+    if rc != 0:
+        raise RuntimeError("nlx_batch_prove failed with %d" % rc)
+    return {"log_n_%d_ms_single_stream" % log_n: round(single, 2), "log_n_%d_ms_three_in_flight" % log_n: round(three, 2),
+            "log_n_%d_proofs_per_s_three_in_flight" % log_n: round(1e3 / three, 1)}
+
+
+def cpu_baseline_sync(args, nlx, st, sha256_result, sha512_result, gpu_seq_ms):
+    """The oracle (C port, OpenMP) on a bounded sample of the same Sync step, on the GPU box's host cores:
+    outer proof at 2^15 rows (scaled linearly to 2^log_n), the SHA-256 and SHA-512 STARKs at full size, the Ed25519 STARK
+    at 2^5 slots (scaled linearly to the step's slots).  The same inputs are proved on the GPU and the BYTES compared."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    SA, SB, E = nlx.sha256_air, nlx.sha512_air, nlx.ed25519_air
+    cores = min(len(os.sched_getaffinity(0)), 16)  # a one-GPU box grants 16 host cores
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    gate_mix = GATE_MIXES[args.gate_mix]
+    ctx = st["ctxs"][3]
+    parity = {}
+    # outer: warm-up (spins up the OpenMP team, faults in the arenas), then the timed sample
+    s_log = min(15, args.log_n)
+    warm = nlx.SyntheticCircuit(max(s_log - 3, 6), seed=98, **gate_mix)
+    wc = oracle_py.Circuit.from_synthetic(warm)
+    wc.prove(warm.wires, warm.public_inputs)
+    wc.close()
+    syn = nlx.SyntheticCircuit(s_log, seed=99, **gate_mix)
+    circ = oracle_py.Circuit.from_synthetic(syn)
+    t = time.time()
+    want = circ.prove(syn.wires, syn.public_inputs)
+    t_outer = time.time() - t
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    got = cd.prove(syn.wires, syn.public_inputs)
+    cd.close()
+    parity["outer"] = {"log_n": s_log, "bytes_equal": got == want, "oracle_verifier_accepts": circ.verify(got) == 1}
+    circ.close()
+    scale_outer = 2.0 ** (args.log_n - s_log)
+    # SHA-256 / SHA-512 STARKs of the step, full size: the oracle proves the reference trace of the same messages
+    blocks, first, digest = SA.blocks_for_messages(st["sha_msgs"], st["lb256"])
+    tr, _ = SA.reference_trace(blocks, first)
+    t = time.time()
+    want = oracle_py.stark_prove_rounds(st["p256"].stark.desc, SA.cpu_rounds(blocks, first, tr), digest)
+    t256 = time.time() - t
+    parity["sha256"] = {"log_blocks": st["lb256"], "bytes_equal": want == sha256_result[0]}
+    blocks, first, digest = SB.blocks_for_messages(st["sig_msgs"], st["lb512"])
+    tr, _ = SB.reference_trace(blocks, first)
+    t = time.time()
+    want = oracle_py.stark_prove_rounds(st["p512"].stark.desc, SB.cpu_rounds(blocks, first, tr), SB.digest_halves(digest))
+    t512 = time.time() - t
+    parity["sha512"] = {"log_blocks": st["lb512"], "bytes_equal": want == sha512_result[0]}
+    # Ed25519: 2^5 slots of the step's signatures
+    s_slots = min(5, st["log_slots"])
+    pr2 = E.Ed25519Prover(ctx, s_slots)
+    words = E.slots_to_words(st["bound_slots"][: 1 << s_slots])
+    got = pr2.prove(words)
+    host = pr2.generate_trace(words).cpu().numpy().view(np.uint64)
+    tc = pr2.es.table_cols   # below 2^8 slots the 2^16-entry range table is spread over several periodic columns
+
+    def cpu_round1(known):   # known = [alpha0, alpha1, gamma0, gamma1]
+        acc, total_ = E.binding_columns(host, known[2:4])
+        cols = np.concatenate([oracle_py.logup_round(host, E.LOOKUPS, 16, host[E.MULT:E.MULT + tc], known[:2], tc),
+                               oracle_py.logup_round(host, E.LOOKUPS9, 9, host[E.MULT9], known[:2]), acc], axis=0)
+        return cols, list(total_)
+    t = time.time()
+    want = oracle_py.stark_prove_rounds(pr2.stark.desc, lambda rnd, known: host if rnd == 0 else cpu_round1(known), [])
+    t_ed = time.time() - t
+    parity["ed25519"] = {"log_slots": s_slots, "bytes_equal": got == want}
+    pr2.close()
+    scale_ed = 2.0 ** (st["log_slots"] - s_slots)
+    total = t_outer * scale_outer + t256 + t512 + t_ed * scale_ed
+    base = {"value": 1.0 / total, "unit": "proofs/s", "cores": cores, "kind": "port",
+            "sample": "oracle on one Sync step: outer proof at 2^%d rows in %.2f s (x%d, linear in rows), SHA-256 STARK 2^%d blocks "
+                      "%.2f s, SHA-512 STARK 2^%d blocks %.2f s, Ed25519 STARK 2^%d slots %.2f s (x%d, linear in slots) -> %.1f s per "
+                      "Sync proof; scalar C port, several times slower than plonky2's AVX2 prover would be: a baseline, not a target"
+                      % (s_log, t_outer, int(scale_outer), st["lb256"], t256, st["lb512"], t512, s_slots, t_ed, int(scale_ed), total),
+            "cpu_seconds_sampled": round(t_outer + t256 + t512 + t_ed, 2)}
+    parity["all_bytes_equal"] = all(v["bytes_equal"] for v in parity.values())
+    return base, parity
 
 
 def main():
@@ -688,12 +933,14 @@ def main():
     rank, world, local, dist = dist_setup(args.gpus)
     import nlxpkg
     nlx = nlxpkg.load()
+    if args.log_n is None:
+        args.log_n = 18 if args.workload == "sync" else 16
     if args.workload == "sync":
         out = run_sync(args, nlx, torch, rank, world, local, dist)
+    elif args.workload == "outer":
+        out = run_outer(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "stark":
         out = run_stark(args, nlx, torch, rank, world, local, dist)
-    elif args.workload == "sync_starks":
-        out = run_sync_starks(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "ed25519":
         out = run_ed25519(args, nlx, torch, rank, world, local, dist)
     elif args.workload in ("sha256", "sha512"):

@@ -86,6 +86,9 @@ int main(int argc, char** argv) {
         memcpy(&w, proof + i, 8);
         fold = (fold * 0x100000001B3ULL) ^ w;
     }
+    printf("program:");  /* part of the statement (the transcript opens with its digest): a second prover needs these words */
+    for (uint32_t i = 0; i < d.n_words; i++) printf(" %llx", (unsigned long long)prog[i]);
+    printf("\n");
     printf("ok: 2^%u rows, proof %zu bytes, fold %016llx, round value %llu\n", log_n, len, (unsigned long long)fold,
            (unsigned long long)r.total);
     nlx_stark_destroy(stark);

@@ -73,7 +73,9 @@ int main(int argc, char** argv) {
         memcpy(&w, proof + i, 8);
         fold = fold * 0x100000001B3ULL ^ w;
     }
-    printf("ok: fibonacci stark 2^%u rows, proof %zu bytes, fold %016llx\n", log_n, len, (unsigned long long)fold);
+    printf("program:");  /* the program is part of the statement (the transcript opens with its digest): a second prover needs these words */
+    for (uint32_t i = 0; i < d.n_words; i++) printf(" %llx", (unsigned long long)prog[i]);
+    printf("\nok: fibonacci stark 2^%u rows, proof %zu bytes, fold %016llx\n", log_n, len, (unsigned long long)fold);
     nlx_buf_destroy(buf);
     nlx_stark_destroy(stark);
     nlx_ctx_destroy(ctx);

@@ -80,6 +80,9 @@ int32_t nlx_ctx_trim(nlx_ctx* ctx);
  * with HIP events on the context's stream.  nlx_ctx_kernel_timing(ctx, x) also clears the samples. */
 int32_t nlx_ctx_kernel_timing(nlx_ctx* ctx, int enable);
 int32_t nlx_ctx_kernel_stats(nlx_ctx* ctx, const char* name, uint64_t* calls, double* total_ms, double* alg_bytes);
+/* work units of the same samples that are not bytes: Poseidon permutations for "hash_lde_leaves" and "merkle_levels"
+ * (the kernels whose bound is the integer-VALU issue rate, not HBM); 0 for the others */
+int32_t nlx_ctx_kernel_units(nlx_ctx* ctx, const char* name, double* units);
 
 /* ---- a1: GoldilocksField arithmetic, element-wise (device self-test of the field core) ----
  * a, b: n arbitrary u64 (values >= p are reduced first, except for row 4).  out: 5 x n:

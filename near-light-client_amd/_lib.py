@@ -50,6 +50,7 @@ SIGNATURES = {
     "nlx_ctx_kernel_timing": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int]),
     "nlx_ctx_kernel_stats": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
                                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "nlx_ctx_kernel_units": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]),
     "nlx_field_ops": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "nlx_poseidon_permute_batch": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "nlx_hash_rows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
@@ -251,6 +252,12 @@ class Context:
         n, ms, b = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
         self.check(dll.nlx_ctx_kernel_stats(self.handle, name.encode(), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(b)))
         return n.value, ms.value, b.value
+
+    def kernel_units(self, name):
+        """work units other than bytes of the named kernel's samples (Poseidon permutations for the hashing kernels)"""
+        u = ctypes.c_double()
+        self.check(dll.nlx_ctx_kernel_units(self.handle, name.encode(), ctypes.byref(u)))
+        return u.value
 
     def close(self):
         if self.handle:

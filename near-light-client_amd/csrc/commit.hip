@@ -80,10 +80,11 @@ int32_t commit_build(nlx_ctx* ctx, const uint64_t* d_in, size_t in_stride, Commi
     ctx->begin_kernel("lde", (8.0 * n + 8.0 * L) * n_cols);
     launch_lde_dit(st, ctx->tables, c->coeffs_br, n, c->lde, L, n_cols, log_n, rate_bits, scale);
     ctx->end_kernel();
-    ctx->begin_kernel("hash_lde_leaves", 8.0 * n_cols * L + 32.0 * L);
+    // units: Poseidon permutations (hash_or_noop: none for rows of <= 4 elements, else one per 8 absorbed)
+    ctx->begin_kernel("hash_lde_leaves", 8.0 * n_cols * L + 32.0 * L, n_cols <= 4 ? 0.0 : (double)L * ((n_cols + 7) / 8));
     launch_hash_lde_leaves(st, c->lde, L, n_cols, log_n, rate_bits, c->digests);
     ctx->end_kernel();
-    ctx->begin_kernel("merkle_levels", 64.0 * L);
+    ctx->begin_kernel("merkle_levels", 64.0 * L, (double)L - (double)((size_t)1 << cap_height));
     c->cap = launch_merkle_levels(st, c->digests, L, cap_height);
     ctx->end_kernel();
     hipError_t e = hipGetLastError();

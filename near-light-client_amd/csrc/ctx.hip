@@ -104,9 +104,9 @@ hipEvent_t nlx_ctx::get_event() {
     (void)hipEventCreate(&e);
     return e;
 }
-void nlx_ctx::begin_kernel(const char* name, double alg_bytes) {
+void nlx_ctx::begin_kernel(const char* name, double alg_bytes, double units) {
     if (!kernel_timing) return;
-    KernelSample ks{name, alg_bytes, get_event(), get_event()};
+    KernelSample ks{name, alg_bytes, units, get_event(), get_event()};
     (void)hipEventRecord(ks.e0, stream);
     samples.push_back(ks);
 }
@@ -268,6 +268,15 @@ int32_t nlx_ctx_kernel_stats(nlx_ctx* c, const char* name, uint64_t* calls, doub
     if (calls) *calls = n;
     if (total_ms) *total_ms = ms;
     if (alg_bytes) *alg_bytes = bytes;
+    return NLX_OK;
+}
+
+int32_t nlx_ctx_kernel_units(nlx_ctx* c, const char* name, double* units) {
+    if (!c || !name || !units) return NLX_E_INVAL;
+    double u = 0;
+    for (auto& ks : c->samples)
+        if (strcmp(ks.name, name) == 0) u += ks.units;
+    *units = u;
     return NLX_OK;
 }
 

@@ -31,12 +31,12 @@ struct nlx_ctx {
 
     // Optional per-kernel device timing (HIP events on `stream` around selected launches); used by
     // bench.py to report the dominant kernel's average duration from inside the timed region.
-    struct KernelSample { const char* name; double alg_bytes; hipEvent_t e0, e1; };
+    struct KernelSample { const char* name; double alg_bytes; double units; hipEvent_t e0, e1; };
     bool kernel_timing = false;
     std::vector<KernelSample> samples;
     std::vector<hipEvent_t> event_pool;
     hipEvent_t get_event();
-    void begin_kernel(const char* name, double alg_bytes);
+    void begin_kernel(const char* name, double alg_bytes, double units = 0.0);  // units: work items other than bytes (Poseidon permutations)
     void end_kernel();
 
     // pinned staging buffer for small device->host reads

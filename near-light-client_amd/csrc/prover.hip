@@ -54,6 +54,32 @@ uint32_t gate_num_constraints(const nlx_gate_desc& g) {
         default: return 0;
     }
 }
+
+// Rough cost of one gate's evaluation at one point in VALU instructions (a field multiplication ~ 27, an alpha-power
+// multiply-accumulate ~ 16, a wire read + add ~ 10): only the RATIOS matter - they balance k_quotient's work split.
+uint32_t gate_eval_cost(const nlx_gate_desc& g) {
+    const uint32_t p0 = g.param0, p1 = g.param1, emits = gate_num_constraints(g);
+    uint32_t muls = 0;
+    switch (g.kind) {
+        case NLX_GATE_ARITHMETIC: muls = 3 * p0; break;
+        case NLX_GATE_BASE_SUM: muls = p1 * (1 + p0); break;
+        case NLX_GATE_POSEIDON: muls = 8 * 48 + 22 * 26 + 121 + 8 * 12; break;  // S-boxes, fast partial rounds, 11 x 11 matrix, MDS layers
+        case NLX_GATE_ARITHMETIC_EXT: muls = 9 * p0; break;
+        case NLX_GATE_MUL_EXT: muls = 7 * p0; break;
+        case NLX_GATE_REDUCING: case NLX_GATE_REDUCING_EXT: muls = 5 * p0; break;
+        case NLX_GATE_POSEIDON_MDS: muls = 2 * 12; break;
+        case NLX_GATE_EXPONENTIATION: muls = 3 * p0; break;
+        case NLX_GATE_RANDOM_ACCESS: muls = (p1 & 0xFFFF) * ((1u << p0) + p0); break;
+        case NLX_GATE_COSET_INTERPOLATION: muls = 14u << p0; break;
+        case NLX_GATE_U32_ADD_MANY: muls = p1 * (2 * 18 + 1); break;
+        case NLX_GATE_U32_ARITHMETIC: muls = p0 * (2 * 32 + 4); break;
+        case NLX_GATE_U32_SUBTRACTION: muls = p0 * (2 * 16 + 2); break;
+        case NLX_GATE_U32_RANGE_CHECK: muls = p0 * 2 * 16; break;
+        case NLX_GATE_COMPARISON: muls = p1 * 9; break;
+        default: break;
+    }
+    return 60 + 27 * muls + 16 * emits;
+}
 }  // namespace
 
 struct nlx_circuit {
@@ -66,6 +92,8 @@ struct nlx_circuit {
     std::vector<uint64_t> cs_cap;       // host copy
     uint64_t* d_sigma_values = nullptr; // [routed][n]
     GateDev* d_gates = nullptr;
+    uint32_t* d_work = nullptr;         // k_quotient's work split: [quotient_waves()][work_stride]
+    uint32_t work_stride = 0;
     uint64_t* d_small = nullptr;        // k_is | coset_base | zh_inv | w_R_inv_pows | chunk_scale | w_A_inv_pows
     uint64_t *d_k_is = nullptr, *d_coset_base = nullptr, *d_zh_inv = nullptr, *d_wR_inv = nullptr,
              *d_chunk_scale = nullptr, *d_wA_inv = nullptr;
@@ -217,6 +245,39 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
         c->d_wA_inv = c->d_chunk_scale + R;
         launch_l0_table(ctx->stream, c->d_l0_scaled, log_n, d.rate_bits, c->d_coset_base, ctx->tables.fwd[log_n]);
     }
+    {
+        // k_quotient's work split: items = every gate + the permutation argument of each challenge; longest item first into
+        // the least loaded wave.  Wave w and wave w + QW/2 of a block share a SIMD, so the bins are then paired heavy with
+        // light: what has to balance is the load per SIMD (the same split runs on every tile).
+        const uint32_t QWv = quotient_waves(), n_items = d.num_gates + d.num_challenges;
+        std::vector<std::pair<uint32_t, uint32_t>> items;  // (cost, id)
+        for (uint32_t g = 0; g < d.num_gates; g++) items.push_back({gate_eval_cost(c->gates[g]), g});
+        for (uint32_t ch = 0; ch < d.num_challenges; ch++) items.push_back({200 + 130 * d.num_routed_wires, d.num_gates + ch});
+        std::sort(items.begin(), items.end(), [](const auto& a, const auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+        std::vector<std::vector<uint32_t>> bins(QWv);
+        std::vector<uint64_t> load(QWv, 0);
+        for (const auto& it : items) {
+            const uint32_t b = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+            bins[b].push_back(it.second);
+            load[b] += it.first;
+        }
+        std::vector<uint32_t> order(QWv);
+        for (uint32_t i = 0; i < QWv; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return load[a] != load[b] ? load[a] > load[b] : a < b; });
+        c->work_stride = n_items + 1;
+        std::vector<uint32_t> work((size_t)QWv * c->work_stride, 0xFFFFFFFFu);
+        for (uint32_t i = 0; i < QWv; i++) {
+            // heaviest bins on waves 0 .. QW/2-1, lightest first on waves QW/2 .. QW-1: SIMD s gets bins order[s] and order[QW-1-s]
+            const uint32_t wave = i < QWv / 2 ? i : QWv / 2 + (QWv - 1 - i);
+            std::copy(bins[order[i]].begin(), bins[order[i]].end(), work.begin() + (size_t)wave * c->work_stride);
+        }
+        c->d_work = (uint32_t*)ctx->alloc(work.size() * 4);
+        if (!c->d_work) return fail(NLX_E_NOMEM);
+        hipError_t e = hipMemcpy(c->d_work, work.data(), work.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(ctx->hip_fail(e, "hipMemcpy(work split)"));
+        if (quotient_lds_bytes(d.num_wires, c->n_consts_all) > 160 * 1024)
+            return fail(ctx->fail(NLX_E_UNSUPPORTED, "num_wires %u: the quotient kernel's wire tile does not fit the 160 KB of LDS", d.num_wires));
+    }
     c->cs_cap.resize((size_t)4 << d.cap_height);
     rc = fetch(ctx, c->cs_cap.data(), c->cs->cap, c->cs_cap.size() * 8);
     if (rc) return fail(rc);
@@ -245,6 +306,7 @@ void nlx_circuit_destroy(nlx_circuit* c) {
     if (c->cs) nlx_commit_destroy(c->cs);
     ctx->release(c->d_sigma_values);
     ctx->release(c->d_gates);
+    ctx->release(c->d_work);
     ctx->release(c->d_small);
     ctx->release(c->d_l0_scaled);
     for (int i = 0; i <= NLX_MAX_STAGES; i++)
@@ -386,6 +448,7 @@ int32_t quotient_stage(nlx_circuit* c, const nlx_commit* cw, const nlx_commit* c
         for (int i = 0; i < 2; i++) { qp.betas[i] = betas[i]; qp.gammas[i] = gammas[i]; }
         for (int i = 0; i < 4; i++) qp.pih[i] = pih[i];
         qp.alpha_stride = c->n_terms;
+        qp.num_wires = d.num_wires; qp.work = c->d_work; qp.work_stride = c->work_stride;
         qp.log_n = log_n; qp.rate_bits = d.rate_bits; qp.n_gates = d.num_gates; qp.n_selectors = d.num_selectors;
         qp.n_consts_all = c->n_consts_all; qp.routed = d.num_routed_wires; qp.chunk = d.quotient_degree_factor; qp.nc = nc; qp.npp = npp;
         ctx->begin_kernel("quotient", 8.0 * L * (c->n_cs + d.num_wires + c->n_zs + nc) + 8.0 * L * nc);

@@ -39,8 +39,15 @@ struct QuotientParams {
     uint64_t betas[2], gammas[2], pih[4];
     uint32_t alpha_stride;
     uint32_t log_n, rate_bits, n_gates, n_selectors, n_consts_all, routed, chunk, nc, npp;
+    uint32_t num_wires;
+    // work split of one tile of 64 points over the kernel's quotient_waves() waves: row w lists wave w's items, terminated by
+    // 0xFFFFFFFF; item g < n_gates = gate g, item n_gates + c = the permutation argument of challenge c (device, host-built)
+    const uint32_t* work;
+    uint32_t work_stride;
 };
 void launch_quotient(hipStream_t st, const QuotientParams& p);
+size_t quotient_lds_bytes(uint32_t num_wires, uint32_t n_consts_all);
+uint32_t quotient_waves();
 void launch_l0_table(hipStream_t st, uint64_t* d_out, unsigned log_n, unsigned rate_bits, const uint64_t* d_coset_base,
                      const uint64_t* d_w_n_table);
 void launch_quotient_chunks(hipStream_t st, const uint64_t* d_in, uint64_t* d_out, unsigned log_n, unsigned rate_bits,

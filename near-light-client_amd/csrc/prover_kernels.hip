@@ -359,376 +359,428 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc) {
     for (int i = 0; i < 12; i++) acc.emit(gl::sub(st[i], W(12 + i)));
 }
 
-// One lane per LDE point.  All gates are evaluated at every point (the selector filter zeroes
-// the inactive ones), so control flow is wave-uniform.
-__global__ __launch_bounds__(256, 4) void k_quotient(QuotientParams p) {
-    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned log_L = p.log_n + p.rate_bits;
-    if (pos >> log_L) return;
-    const size_t n = (size_t)1 << p.log_n, L = (size_t)1 << log_L;
-    const uint32_t r = (uint32_t)(pos >> p.log_n), k = (uint32_t)(pos & (n - 1));
-    const size_t pos_next = ((size_t)r << p.log_n) + ((k + 1) & (n - 1));
-    const uint64_t x = gl::mul(p.coset_base[r], root_pow(p.w_n_table, k, (uint32_t)(n >> 1)));
+// One gate's unfiltered constraints at this lane's point, folded into `acc` with the alpha powers (Gate::eval_unfiltered_base).
+// W(c): wire c of the point; CC(c): constants column c (selectors first) of the point; n = 2^log_n.
+template <class WireFn, class ConstFn>
+__device__ __forceinline__ void eval_gate(const GateDev& gd, const QuotientParams& p, WireFn W, ConstFn CC, GateAcc& acc, size_t n) {
+    switch (gd.kind) {
+        case NLX_GATE_CONSTANT:
+            for (uint32_t i = 0; i < gd.param0; i++) acc.emit(gl::sub(CC(p.n_selectors + i), W(i)));
+            break;
+        case NLX_GATE_PUBLIC_INPUT:
+            for (uint32_t i = 0; i < 4; i++) acc.emit(gl::sub(W(i), p.pih[i]));
+            break;
+        case NLX_GATE_ARITHMETIC: {
+            const uint64_t c0 = CC(p.n_selectors), c1 = CC(p.n_selectors + 1);
+            for (uint32_t i = 0; i < gd.param0; i++) {
+                const uint64_t m0 = W(4 * i), m1 = W(4 * i + 1), ad = W(4 * i + 2), o = W(4 * i + 3);
+                acc.emit(gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1))));
+            }
+            break;
+        }
+        case NLX_GATE_BASE_SUM: {
+            const uint32_t B = gd.param0, nl = gd.param1;
+            uint64_t sum = 0;
+            for (uint32_t i = nl; i-- > 0;) sum = gl::add(gl::mul(sum, (uint64_t)B), W(1 + i));
+            acc.emit(gl::sub(sum, W(0)));
+            for (uint32_t i = 0; i < nl; i++) {
+                const uint64_t limb = W(1 + i);
+                uint64_t prod = 1;
+                for (uint32_t t = 0; t < B; t++) prod = gl::mul(prod, gl::sub(limb, (uint64_t)t));
+                acc.emit(prod);
+            }
+            break;
+        }
+        case NLX_GATE_POSEIDON:
+            gate_poseidon(W, acc);
+            break;
+        case NLX_GATE_ARITHMETIC_EXT: {
+            const uint64_t c0 = CC(p.n_selectors), c1 = CC(p.n_selectors + 1);
+            for (uint32_t i = 0; i < gd.param0; i++) {
+                const gl::Ext m0{W(8 * i), W(8 * i + 1)}, m1{W(8 * i + 2), W(8 * i + 3)};
+                const gl::Ext pr = gl::mul(m0, m1);
+                acc.emit(gl::sub(W(8 * i + 6), gl::add(gl::mul(pr.a, c0), gl::mul(W(8 * i + 4), c1))));
+                acc.emit(gl::sub(W(8 * i + 7), gl::add(gl::mul(pr.b, c0), gl::mul(W(8 * i + 5), c1))));
+            }
+            break;
+        }
+        case NLX_GATE_MUL_EXT: {
+            const uint64_t c0 = CC(p.n_selectors);
+            for (uint32_t i = 0; i < gd.param0; i++) {
+                const gl::Ext m0{W(6 * i), W(6 * i + 1)}, m1{W(6 * i + 2), W(6 * i + 3)};
+                const gl::Ext pr = gl::mul(m0, m1);
+                acc.emit(gl::sub(W(6 * i + 4), gl::mul(pr.a, c0)));
+                acc.emit(gl::sub(W(6 * i + 5), gl::mul(pr.b, c0)));
+            }
+            break;
+        }
+        case NLX_GATE_REDUCING:
+        case NLX_GATE_REDUCING_EXT: {
+            const uint32_t nco = gd.param0;
+            const bool ext = gd.kind == NLX_GATE_REDUCING_EXT;
+            const uint32_t start_coeffs = 6, start_accs = start_coeffs + (ext ? 2 * nco : nco);
+            const gl::Ext alpha{W(2), W(3)};
+            gl::Ext a{W(4), W(5)};
+            for (uint32_t i = 0; i < nco; i++) {
+                const uint32_t aw = (i == nco - 1) ? 0 : start_accs + 2 * i;  // last accumulator = output wires
+                const gl::Ext nxt{W(aw), W(aw + 1)};
+                const gl::Ext pr = gl::mul(a, alpha);
+                if (ext) {
+                    acc.emit(gl::sub(gl::add(pr.a, W(start_coeffs + 2 * i)), nxt.a));
+                    acc.emit(gl::sub(gl::add(pr.b, W(start_coeffs + 2 * i + 1)), nxt.b));
+                } else {
+                    acc.emit(gl::sub(gl::add(pr.a, W(start_coeffs + i)), nxt.a));
+                    acc.emit(gl::sub(pr.b, nxt.b));
+                }
+                a = nxt;
+            }
+            break;
+        }
+        case NLX_GATE_POSEIDON_MDS: {
+            // outputs = MDS * inputs on both components of the extension algebra: the linear layer of the
+            // permutation itself (32-bit halves, multiply-accumulate, one reduction per output)
+            for (uint32_t comp = 0; comp < 2; comp++) {
+                uint64_t st[12];
+#pragma unroll
+                for (int i = 0; i < 12; i++) st[i] = W(2 * i + comp);
+                mds_canon(st);
+#pragma unroll
+                for (int rr = 0; rr < 12; rr++) acc.emit_at(2 * rr + comp, gl::sub(W(24 + 2 * rr + comp), st[rr]));
+            }
+            acc.k += 24;
+            break;
+        }
+        case NLX_GATE_EXPONENTIATION: {
+            const uint32_t nb = gd.param0;
+            const uint64_t base = W(0);
+            uint64_t prev_iv = 1;
+            for (uint32_t i = 0; i < nb; i++) {
+                const uint64_t prev = i ? gl::mul(prev_iv, prev_iv) : 1;
+                const uint64_t bit = W(1 + (nb - 1 - i));
+                const uint64_t sel = gl::add(gl::mul(bit, base), gl::sub(1, bit));
+                const uint64_t iv = W(2 + nb + i);
+                acc.emit(gl::sub(gl::mul(prev, sel), iv));
+                prev_iv = iv;
+            }
+            acc.emit(gl::sub(W(1 + nb), prev_iv));
+            break;
+        }
+        case NLX_GATE_U32_ADD_MANY: {
+            const uint32_t na = gd.param0, nops = gd.param1, nl = 18, nrl = 16;
+            for (uint32_t i = 0; i < nops; i++) {
+                const uint32_t b0 = (na + 3) * i, lb = (na + 3) * nops + nl * i;
+                uint64_t computed = W(b0 + na);
+                for (uint32_t j = 0; j < na; j++) computed = gl::add(computed, W(b0 + j));
+                const uint64_t res = W(b0 + na + 1), cy = W(b0 + na + 2);
+                acc.emit(gl::sub(gl::add(gl::mul(cy, 1ULL << 32), res), computed));
+                Sum128 cr, cc;
+                for (uint32_t j = nl; j-- > 0;) {
+                    const uint64_t l = W(lb + j);
+                    acc.emit(limb4(l));
+                    if (j < nrl) cr.add(l, 2 * j);
+                    else cc.add(l, 2 * (j - nrl));
+                }
+                acc.emit(gl::sub(cr.value(), res));
+                acc.emit(gl::sub(cc.value(), cy));
+            }
+            break;
+        }
+        case NLX_GATE_U32_ARITHMETIC: {
+            const uint32_t nops = gd.param0;
+            for (uint32_t i = 0; i < nops; i++) {
+                const uint32_t b0 = 6 * i, lb = 6 * nops + 32 * i;
+                const uint64_t computed = gl::add(gl::mul(W(b0), W(b0 + 1)), W(b0 + 2));
+                const uint64_t lo = W(b0 + 3), hi = W(b0 + 4), inv = W(b0 + 5);
+                const uint64_t hi_not_max = gl::sub(gl::mul(inv, gl::sub(0xFFFFFFFFULL, hi)), 1);
+                acc.emit(gl::mul(hi_not_max, lo));
+                acc.emit(gl::sub(gl::add(gl::mul(hi, 1ULL << 32), lo), computed));
+                Sum128 cl, ch;
+                for (uint32_t j = 32; j-- > 0;) {
+                    const uint64_t l = W(lb + j);
+                    acc.emit(limb4(l));
+                    if (j < 16) cl.add(l, 2 * j);
+                    else ch.add(l, 2 * (j - 16));
+                }
+                acc.emit(gl::sub(cl.value(), lo));
+                acc.emit(gl::sub(ch.value(), hi));
+            }
+            break;
+        }
+        case NLX_GATE_U32_SUBTRACTION: {
+            const uint32_t nops = gd.param0;
+            for (uint32_t i = 0; i < nops; i++) {
+                const uint32_t b0 = 5 * i, lb = 5 * nops + 16 * i;
+                const uint64_t initial = gl::sub(gl::sub(W(b0), W(b0 + 1)), W(b0 + 2));
+                const uint64_t res = W(b0 + 3), bo = W(b0 + 4);
+                acc.emit(gl::sub(res, gl::add(initial, gl::mul(bo, 1ULL << 32))));
+                Sum128 c;
+                for (uint32_t j = 16; j-- > 0;) {
+                    const uint64_t l = W(lb + j);
+                    acc.emit(limb4(l));
+                    c.add(l, 2 * j);
+                }
+                acc.emit(gl::sub(c.value(), res));
+                acc.emit(gl::mul(bo, gl::sub(1, bo)));
+            }
+            break;
+        }
+        case NLX_GATE_U32_RANGE_CHECK: {
+            const uint32_t nin = gd.param0;
+            for (uint32_t i = 0; i < nin; i++) {
+                const uint32_t ab = nin + 16 * i;
+                Sum128 sum;
+                for (uint32_t j = 0; j < 16; j++) sum.add(W(ab + j), 2 * j);
+                acc.emit(gl::sub(sum.value(), W(i)));
+                for (uint32_t j = 0; j < 16; j++) acc.emit(limb4(W(ab + j)));
+            }
+            break;
+        }
+        case NLX_GATE_COMPARISON: {
+            const uint32_t nbits = gd.param0, nch = gd.param1, cb = (nbits + nch - 1) / nch;
+            const uint32_t fc = 4, sc = 4 + nch, eqd = 4 + 2 * nch, ceq = 4 + 3 * nch, iv = 4 + 4 * nch, msb = 4 + 5 * nch;
+            Sum128 fcomb, scomb;  // nch * cb = num_bits <= 62 (checked at circuit build)
+            for (uint32_t i = 0; i < nch; i++) {
+                fcomb.add(W(fc + i), cb * i);
+                scomb.add(W(sc + i), cb * i);
+            }
+            acc.emit(gl::sub(fcomb.value(), W(0)));
+            acc.emit(gl::sub(scomb.value(), W(1)));
+            uint64_t msd = 0;
+            for (uint32_t i = 0; i < nch; i++) {
+                const uint64_t f = W(fc + i), s2 = W(sc + i);
+                uint64_t p1, p2;
+                if (cb == 2) {
+                    p1 = limb4(f);
+                    p2 = limb4(s2);
+                } else {
+                    p1 = f;
+                    p2 = s2;
+                    for (uint32_t x2 = 1; x2 < (1u << cb); x2++) {
+                        p1 = gl::mul(p1, gl::sub(f, (uint64_t)x2));
+                        p2 = gl::mul(p2, gl::sub(s2, (uint64_t)x2));
+                    }
+                }
+                acc.emit(p1);
+                acc.emit(p2);
+                const uint64_t diff = gl::sub(s2, f), e = W(ceq + i), ivv = W(iv + i);
+                acc.emit(gl::sub(gl::mul(diff, W(eqd + i)), gl::sub(1, e)));
+                acc.emit(gl::mul(e, diff));
+                acc.emit(gl::sub(ivv, gl::mul(e, msd)));
+                msd = gl::add(ivv, gl::mul(gl::sub(1, e), diff));
+            }
+            acc.emit(gl::sub(W(3), msd));
+            uint64_t bc = 0;
+            for (uint32_t b = 0; b <= cb; b++) {
+                const uint64_t bit = W(msb + b);
+                acc.emit(gl::mul(bit, gl::sub(1, bit)));
+            }
+            for (uint32_t b = cb + 1; b-- > 0;) bc = gl::add(gl::add(bc, bc), W(msb + b));
+            acc.emit(gl::sub(gl::add(1ULL << cb, W(3)), bc));
+            acc.emit(gl::sub(W(2), W(msb + cb)));
+            break;
+        }
+        case NLX_GATE_COSET_INTERPOLATION: {
+            const uint32_t bits = gd.param0, deg = gd.param1, np = 1u << bits;
+            const uint32_t sep = 1 + 2 * np, sev = sep + 2, si = sev + 2, ni = (np - 2) / (deg - 1), ssh = si + 4 * ni;
+            const uint64_t shift = W(0);
+            const gl::Ext pt{W(ssh), W(ssh + 1)};
+            acc.emit(gl::sub(W(sep), gl::mul(pt.a, shift)));
+            acc.emit(gl::sub(W(sep + 1), gl::mul(pt.b, shift)));
+            // domain x_j = w_np^j comes from the w_n table; on a multiplicative subgroup the barycentric
+            // weight 1 / prod_{i != j} (x_j - x_i) is x_j / np
+            uint64_t np_inv = 1;
+            for (uint32_t i = 0; i < bits; i++) np_inv = gl::mul(np_inv, 0x7FFFFFFF80000001ULL);  // 2^-1
+            const uint32_t stride = (uint32_t)(n >> bits), half = (uint32_t)(n >> 1);
+            gl::Ext ev{0, 0}, pr{1, 0};
+            for (uint32_t c = 0; c <= ni; c++) {
+                const uint32_t start = c == 0 ? 0 : 1 + (deg - 1) * c;
+                uint32_t end = c == 0 ? deg : start + deg - 1;
+                end = end > np ? np : end;
+                for (uint32_t j = start; j < end; j++) {
+                    const uint64_t xj = root_pow(p.w_n_table, j * stride, half);
+                    const gl::Ext term{gl::sub(pt.a, xj), pt.b};
+                    const gl::Ext vp = gl::mul(gl::Ext{W(1 + 2 * j), W(2 + 2 * j)}, pr);
+                    ev = gl::add(gl::mul(ev, term), gl::mul(vp, gl::mul(xj, np_inv)));
+                    pr = gl::mul(pr, term);
+                }
+                if (c < ni) {
+                    const gl::Ext ie{W(si + 2 * c), W(si + 2 * c + 1)}, ip{W(si + 2 * (ni + c)), W(si + 2 * (ni + c) + 1)};
+                    acc.emit(gl::sub(ie.a, ev.a));
+                    acc.emit(gl::sub(ie.b, ev.b));
+                    acc.emit(gl::sub(ip.a, pr.a));
+                    acc.emit(gl::sub(ip.b, pr.b));
+                    ev = ie;
+                    pr = ip;
+                }
+            }
+            acc.emit(gl::sub(W(sev), ev.a));
+            acc.emit(gl::sub(W(sev + 1), ev.b));
+            break;
+        }
+        case NLX_GATE_RANDOM_ACCESS: {
+            const uint32_t bits = gd.param0, copies = gd.param1 & 0xFFFF, extra = gd.param1 >> 16;
+            const uint32_t vec = 1u << bits, rt = (2 + vec) * copies + extra;
+            for (uint32_t cpy = 0; cpy < copies; cpy++) {
+                const uint32_t b0 = (2 + vec) * cpy, bw = rt + cpy * bits;
+                for (uint32_t i = 0; i < bits; i++) {
+                    const uint64_t b = W(bw + i);
+                    acc.emit(gl::mul(b, gl::sub(b, 1)));
+                }
+                uint64_t rec = 0;
+                for (uint32_t i = bits; i-- > 0;) rec = gl::add(gl::add(rec, rec), W(bw + i));
+                acc.emit(gl::sub(rec, W(b0)));
+                // fold the list by the index bits; level i consumes bit i.  The selected element is
+                // computed by a recursive descent so that no list array lives in registers:
+                // value(level, j) = value(level-1, 2j) + bit * (value(level-1, 2j+1) - value(level-1, 2j))
+                // evaluated iteratively over the 2^bits leaves with a small stack.
+                uint64_t stack[7];
+                uint32_t depth_of[7];
+                int sp = 0;
+                for (uint32_t leaf = 0; leaf < vec; leaf++) {
+                    uint64_t v = W(b0 + 2 + leaf);
+                    uint32_t lvl = 0;
+                    while (sp > 0 && depth_of[sp - 1] == lvl) {
+                        const uint64_t left = stack[--sp];
+                        const uint64_t b = W(bw + lvl);
+                        v = gl::add(left, gl::mul(b, gl::sub(v, left)));
+                        lvl++;
+                    }
+                    stack[sp] = v;
+                    depth_of[sp] = lvl;
+                    sp++;
+                }
+                acc.emit(gl::sub(stack[0], W(b0 + 1)));
+            }
+            for (uint32_t i = 0; i < extra; i++) acc.emit(gl::sub(CC(p.n_selectors + i), W((2 + vec) * copies + i)));
+            break;
+        }
+        default: break;  // NoopGate
+    }
+}
 
-    auto CS = [&](uint32_t c) { return p.cs[(size_t)c * L + pos]; };
-    auto W = [&](uint32_t c) { return p.wires[(size_t)c * L + pos]; };
+// k_quotient: compute_quotient_polys' inner loop (eval_vanishing_poly_base_batch) on the LDE domain.
+//
+// A block is QW waves that share ONE tile of 64 consecutive LDE points (same coset).  The tile's wire row and constants row
+// are staged ONCE in LDS ([column][64 points], 512 contiguous bytes per column, conflict-free) - in round 1 every gate re-read
+// its wires from global memory: 2 310 loads per point, 10 GB of traffic per launch against 1 GB of distinct columns (PMC).
+// The work of a point - every gate of the circuit plus the permutation argument of each challenge - is split over the waves
+// by a host-built, cost-balanced item list (QuotientParams::work): all gates are evaluated at every point whatever their
+// selector says, so the split is the same for every tile and control flow stays wave-uniform.  The waves' partial sums meet
+// in LDS.  Sigma and Z columns are used once per point and are read straight from global memory.
+constexpr int QW = 8;  // waves per tile: 2 tiles x 8 waves per CU = 4 waves per SIMD
+
+__global__ __launch_bounds__(64 * QW, 4) void k_quotient(QuotientParams p) {
+    extern __shared__ uint64_t q_lds[];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned log_L = p.log_n + p.rate_bits;
+    const size_t n = (size_t)1 << p.log_n, L = (size_t)1 << log_L;
+    const size_t pos_raw = (size_t)blockIdx.x * 64 + lane;
+    const bool live = pos_raw < L;                 // a domain of fewer than 64 points: the spare lanes redo the last point
+    const size_t pos = live ? pos_raw : L - 1;
+    const uint32_t r = (uint32_t)(pos >> p.log_n), k = (uint32_t)(pos & (n - 1));
+    uint64_t* lw = q_lds;                                  // [num_wires][64]
+    uint64_t* lc = q_lds + (size_t)p.num_wires * 64;       // [n_consts_all][64]
+    for (uint32_t c = wv; c < p.num_wires; c += QW) lw[c * 64 + lane] = p.wires[(size_t)c * L + pos];
+    for (uint32_t c = wv; c < p.n_consts_all; c += QW) lc[c * 64 + lane] = p.cs[(size_t)c * L + pos];
+    __syncthreads();
+    auto W = [&](uint32_t c) { return lw[c * 64 + lane]; };
+    auto CC = [&](uint32_t c) { return lc[c * 64 + lane]; };
     auto ZS = [&](uint32_t c) { return p.zs[(size_t)c * L + pos]; };
 
     const uint32_t nc = p.nc, npp = p.npp;
     const uint32_t T0 = nc + nc * (npp + 1);
     const uint64_t* ap0 = p.alpha_pows;
     const uint64_t* ap1 = p.alpha_pows + p.alpha_stride;
-
-    uint64_t tot0 = 0, tot1 = 0;  // sum over all terms EXCEPT the L_0 term (divided by Z_H later)
+    uint64_t tot0 = 0, tot1 = 0;  // sum over all terms EXCEPT the L_0 terms (divided by Z_H later)
+    uint64_t l0a = 0, l0b = 0;    // sum_i (Z_i - 1) alpha_c^i, multiplied by L_0(x)/Z_H(x) below
     GateAcc acc;
     acc.ap0 = ap0 + T0;
     acc.ap1 = ap1 + T0;
-    // ---- gate constraints ----
-    for (uint32_t g = 0; g < p.n_gates; g++) {
-        const GateDev gd = p.gates[g];
-        // filter
-        const uint64_t s = CS(gd.selector_index);
-        uint64_t f = 1;
-        for (uint32_t i = gd.group_start; i < gd.group_end; i++)
-            if (i != gd.index) f = gl::mul(f, gl::sub((uint64_t)i, s));
-        if (p.n_selectors > 1) f = gl::mul(f, gl::sub(0xFFFFFFFFULL, s));
-        acc.reset();
-        switch (gd.kind) {
-            case NLX_GATE_CONSTANT:
-                for (uint32_t i = 0; i < gd.param0; i++) acc.emit(gl::sub(CS(p.n_selectors + i), W(i)));
-                break;
-            case NLX_GATE_PUBLIC_INPUT:
-                for (uint32_t i = 0; i < 4; i++) acc.emit(gl::sub(W(i), p.pih[i]));
-                break;
-            case NLX_GATE_ARITHMETIC: {
-                const uint64_t c0 = CS(p.n_selectors), c1 = CS(p.n_selectors + 1);
-                for (uint32_t i = 0; i < gd.param0; i++) {
-                    const uint64_t m0 = W(4 * i), m1 = W(4 * i + 1), ad = W(4 * i + 2), o = W(4 * i + 3);
-                    acc.emit(gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1))));
-                }
-                break;
-            }
-            case NLX_GATE_BASE_SUM: {
-                const uint32_t B = gd.param0, nl = gd.param1;
-                uint64_t sum = 0;
-                for (uint32_t i = nl; i-- > 0;) sum = gl::add(gl::mul(sum, (uint64_t)B), W(1 + i));
-                acc.emit(gl::sub(sum, W(0)));
-                for (uint32_t i = 0; i < nl; i++) {
-                    const uint64_t limb = W(1 + i);
-                    uint64_t prod = 1;
-                    for (uint32_t t = 0; t < B; t++) prod = gl::mul(prod, gl::sub(limb, (uint64_t)t));
-                    acc.emit(prod);
-                }
-                break;
-            }
-            case NLX_GATE_POSEIDON:
-                gate_poseidon(W, acc);
-                break;
-            case NLX_GATE_ARITHMETIC_EXT: {
-                const uint64_t c0 = CS(p.n_selectors), c1 = CS(p.n_selectors + 1);
-                for (uint32_t i = 0; i < gd.param0; i++) {
-                    const gl::Ext m0{W(8 * i), W(8 * i + 1)}, m1{W(8 * i + 2), W(8 * i + 3)};
-                    const gl::Ext pr = gl::mul(m0, m1);
-                    acc.emit(gl::sub(W(8 * i + 6), gl::add(gl::mul(pr.a, c0), gl::mul(W(8 * i + 4), c1))));
-                    acc.emit(gl::sub(W(8 * i + 7), gl::add(gl::mul(pr.b, c0), gl::mul(W(8 * i + 5), c1))));
-                }
-                break;
-            }
-            case NLX_GATE_MUL_EXT: {
-                const uint64_t c0 = CS(p.n_selectors);
-                for (uint32_t i = 0; i < gd.param0; i++) {
-                    const gl::Ext m0{W(6 * i), W(6 * i + 1)}, m1{W(6 * i + 2), W(6 * i + 3)};
-                    const gl::Ext pr = gl::mul(m0, m1);
-                    acc.emit(gl::sub(W(6 * i + 4), gl::mul(pr.a, c0)));
-                    acc.emit(gl::sub(W(6 * i + 5), gl::mul(pr.b, c0)));
-                }
-                break;
-            }
-            case NLX_GATE_REDUCING:
-            case NLX_GATE_REDUCING_EXT: {
-                const uint32_t nco = gd.param0;
-                const bool ext = gd.kind == NLX_GATE_REDUCING_EXT;
-                const uint32_t start_coeffs = 6, start_accs = start_coeffs + (ext ? 2 * nco : nco);
-                const gl::Ext alpha{W(2), W(3)};
-                gl::Ext a{W(4), W(5)};
-                for (uint32_t i = 0; i < nco; i++) {
-                    const uint32_t aw = (i == nco - 1) ? 0 : start_accs + 2 * i;  // last accumulator = output wires
-                    const gl::Ext nxt{W(aw), W(aw + 1)};
-                    const gl::Ext pr = gl::mul(a, alpha);
-                    if (ext) {
-                        acc.emit(gl::sub(gl::add(pr.a, W(start_coeffs + 2 * i)), nxt.a));
-                        acc.emit(gl::sub(gl::add(pr.b, W(start_coeffs + 2 * i + 1)), nxt.b));
-                    } else {
-                        acc.emit(gl::sub(gl::add(pr.a, W(start_coeffs + i)), nxt.a));
-                        acc.emit(gl::sub(pr.b, nxt.b));
-                    }
-                    a = nxt;
-                }
-                break;
-            }
-            case NLX_GATE_POSEIDON_MDS: {
-                // outputs = MDS * inputs on both components of the extension algebra: the linear layer of the
-                // permutation itself (32-bit halves, multiply-accumulate, one reduction per output)
-                for (uint32_t comp = 0; comp < 2; comp++) {
-                    uint64_t st[12];
-#pragma unroll
-                    for (int i = 0; i < 12; i++) st[i] = W(2 * i + comp);
-                    mds_canon(st);
-#pragma unroll
-                    for (int rr = 0; rr < 12; rr++) acc.emit_at(2 * rr + comp, gl::sub(W(24 + 2 * rr + comp), st[rr]));
-                }
-                acc.k += 24;
-                break;
-            }
-            case NLX_GATE_EXPONENTIATION: {
-                const uint32_t nb = gd.param0;
-                const uint64_t base = W(0);
-                uint64_t prev_iv = 1;
-                for (uint32_t i = 0; i < nb; i++) {
-                    const uint64_t prev = i ? gl::mul(prev_iv, prev_iv) : 1;
-                    const uint64_t bit = W(1 + (nb - 1 - i));
-                    const uint64_t sel = gl::add(gl::mul(bit, base), gl::sub(1, bit));
-                    const uint64_t iv = W(2 + nb + i);
-                    acc.emit(gl::sub(gl::mul(prev, sel), iv));
-                    prev_iv = iv;
-                }
-                acc.emit(gl::sub(W(1 + nb), prev_iv));
-                break;
-            }
-            case NLX_GATE_U32_ADD_MANY: {
-                const uint32_t na = gd.param0, nops = gd.param1, nl = 18, nrl = 16;
-                for (uint32_t i = 0; i < nops; i++) {
-                    const uint32_t b0 = (na + 3) * i, lb = (na + 3) * nops + nl * i;
-                    uint64_t computed = W(b0 + na);
-                    for (uint32_t j = 0; j < na; j++) computed = gl::add(computed, W(b0 + j));
-                    const uint64_t res = W(b0 + na + 1), cy = W(b0 + na + 2);
-                    acc.emit(gl::sub(gl::add(gl::mul(cy, 1ULL << 32), res), computed));
-                    Sum128 cr, cc;
-                    for (uint32_t j = nl; j-- > 0;) {
-                        const uint64_t l = W(lb + j);
-                        acc.emit(limb4(l));
-                        if (j < nrl) cr.add(l, 2 * j);
-                        else cc.add(l, 2 * (j - nrl));
-                    }
-                    acc.emit(gl::sub(cr.value(), res));
-                    acc.emit(gl::sub(cc.value(), cy));
-                }
-                break;
-            }
-            case NLX_GATE_U32_ARITHMETIC: {
-                const uint32_t nops = gd.param0;
-                for (uint32_t i = 0; i < nops; i++) {
-                    const uint32_t b0 = 6 * i, lb = 6 * nops + 32 * i;
-                    const uint64_t computed = gl::add(gl::mul(W(b0), W(b0 + 1)), W(b0 + 2));
-                    const uint64_t lo = W(b0 + 3), hi = W(b0 + 4), inv = W(b0 + 5);
-                    const uint64_t hi_not_max = gl::sub(gl::mul(inv, gl::sub(0xFFFFFFFFULL, hi)), 1);
-                    acc.emit(gl::mul(hi_not_max, lo));
-                    acc.emit(gl::sub(gl::add(gl::mul(hi, 1ULL << 32), lo), computed));
-                    Sum128 cl, ch;
-                    for (uint32_t j = 32; j-- > 0;) {
-                        const uint64_t l = W(lb + j);
-                        acc.emit(limb4(l));
-                        if (j < 16) cl.add(l, 2 * j);
-                        else ch.add(l, 2 * (j - 16));
-                    }
-                    acc.emit(gl::sub(cl.value(), lo));
-                    acc.emit(gl::sub(ch.value(), hi));
-                }
-                break;
-            }
-            case NLX_GATE_U32_SUBTRACTION: {
-                const uint32_t nops = gd.param0;
-                for (uint32_t i = 0; i < nops; i++) {
-                    const uint32_t b0 = 5 * i, lb = 5 * nops + 16 * i;
-                    const uint64_t initial = gl::sub(gl::sub(W(b0), W(b0 + 1)), W(b0 + 2));
-                    const uint64_t res = W(b0 + 3), bo = W(b0 + 4);
-                    acc.emit(gl::sub(res, gl::add(initial, gl::mul(bo, 1ULL << 32))));
-                    Sum128 c;
-                    for (uint32_t j = 16; j-- > 0;) {
-                        const uint64_t l = W(lb + j);
-                        acc.emit(limb4(l));
-                        c.add(l, 2 * j);
-                    }
-                    acc.emit(gl::sub(c.value(), res));
-                    acc.emit(gl::mul(bo, gl::sub(1, bo)));
-                }
-                break;
-            }
-            case NLX_GATE_U32_RANGE_CHECK: {
-                const uint32_t nin = gd.param0;
-                for (uint32_t i = 0; i < nin; i++) {
-                    const uint32_t ab = nin + 16 * i;
-                    Sum128 sum;
-                    for (uint32_t j = 0; j < 16; j++) sum.add(W(ab + j), 2 * j);
-                    acc.emit(gl::sub(sum.value(), W(i)));
-                    for (uint32_t j = 0; j < 16; j++) acc.emit(limb4(W(ab + j)));
-                }
-                break;
-            }
-            case NLX_GATE_COMPARISON: {
-                const uint32_t nbits = gd.param0, nch = gd.param1, cb = (nbits + nch - 1) / nch;
-                const uint32_t fc = 4, sc = 4 + nch, eqd = 4 + 2 * nch, ceq = 4 + 3 * nch, iv = 4 + 4 * nch, msb = 4 + 5 * nch;
-                Sum128 fcomb, scomb;  // nch * cb = num_bits <= 62 (checked at circuit build)
-                for (uint32_t i = 0; i < nch; i++) {
-                    fcomb.add(W(fc + i), cb * i);
-                    scomb.add(W(sc + i), cb * i);
-                }
-                acc.emit(gl::sub(fcomb.value(), W(0)));
-                acc.emit(gl::sub(scomb.value(), W(1)));
-                uint64_t msd = 0;
-                for (uint32_t i = 0; i < nch; i++) {
-                    const uint64_t f = W(fc + i), s2 = W(sc + i);
-                    uint64_t p1, p2;
-                    if (cb == 2) {
-                        p1 = limb4(f);
-                        p2 = limb4(s2);
-                    } else {
-                        p1 = f;
-                        p2 = s2;
-                        for (uint32_t x2 = 1; x2 < (1u << cb); x2++) {
-                            p1 = gl::mul(p1, gl::sub(f, (uint64_t)x2));
-                            p2 = gl::mul(p2, gl::sub(s2, (uint64_t)x2));
-                        }
-                    }
-                    acc.emit(p1);
-                    acc.emit(p2);
-                    const uint64_t diff = gl::sub(s2, f), e = W(ceq + i), ivv = W(iv + i);
-                    acc.emit(gl::sub(gl::mul(diff, W(eqd + i)), gl::sub(1, e)));
-                    acc.emit(gl::mul(e, diff));
-                    acc.emit(gl::sub(ivv, gl::mul(e, msd)));
-                    msd = gl::add(ivv, gl::mul(gl::sub(1, e), diff));
-                }
-                acc.emit(gl::sub(W(3), msd));
-                uint64_t bc = 0;
-                for (uint32_t b = 0; b <= cb; b++) {
-                    const uint64_t bit = W(msb + b);
-                    acc.emit(gl::mul(bit, gl::sub(1, bit)));
-                }
-                for (uint32_t b = cb + 1; b-- > 0;) bc = gl::add(gl::add(bc, bc), W(msb + b));
-                acc.emit(gl::sub(gl::add(1ULL << cb, W(3)), bc));
-                acc.emit(gl::sub(W(2), W(msb + cb)));
-                break;
-            }
-            case NLX_GATE_COSET_INTERPOLATION: {
-                const uint32_t bits = gd.param0, deg = gd.param1, np = 1u << bits;
-                const uint32_t sep = 1 + 2 * np, sev = sep + 2, si = sev + 2, ni = (np - 2) / (deg - 1), ssh = si + 4 * ni;
-                const uint64_t shift = W(0);
-                const gl::Ext pt{W(ssh), W(ssh + 1)};
-                acc.emit(gl::sub(W(sep), gl::mul(pt.a, shift)));
-                acc.emit(gl::sub(W(sep + 1), gl::mul(pt.b, shift)));
-                // domain x_j = w_np^j comes from the w_n table; on a multiplicative subgroup the barycentric
-                // weight 1 / prod_{i != j} (x_j - x_i) is x_j / np
-                uint64_t np_inv = 1;
-                for (uint32_t i = 0; i < bits; i++) np_inv = gl::mul(np_inv, 0x7FFFFFFF80000001ULL);  // 2^-1
-                const uint32_t stride = (uint32_t)(n >> bits), half = (uint32_t)(n >> 1);
-                gl::Ext ev{0, 0}, pr{1, 0};
-                for (uint32_t c = 0; c <= ni; c++) {
-                    const uint32_t start = c == 0 ? 0 : 1 + (deg - 1) * c;
-                    uint32_t end = c == 0 ? deg : start + deg - 1;
-                    end = end > np ? np : end;
-                    for (uint32_t j = start; j < end; j++) {
-                        const uint64_t xj = root_pow(p.w_n_table, j * stride, half);
-                        const gl::Ext term{gl::sub(pt.a, xj), pt.b};
-                        const gl::Ext vp = gl::mul(gl::Ext{W(1 + 2 * j), W(2 + 2 * j)}, pr);
-                        ev = gl::add(gl::mul(ev, term), gl::mul(vp, gl::mul(xj, np_inv)));
-                        pr = gl::mul(pr, term);
-                    }
-                    if (c < ni) {
-                        const gl::Ext ie{W(si + 2 * c), W(si + 2 * c + 1)}, ip{W(si + 2 * (ni + c)), W(si + 2 * (ni + c) + 1)};
-                        acc.emit(gl::sub(ie.a, ev.a));
-                        acc.emit(gl::sub(ie.b, ev.b));
-                        acc.emit(gl::sub(ip.a, pr.a));
-                        acc.emit(gl::sub(ip.b, pr.b));
-                        ev = ie;
-                        pr = ip;
-                    }
-                }
-                acc.emit(gl::sub(W(sev), ev.a));
-                acc.emit(gl::sub(W(sev + 1), ev.b));
-                break;
-            }
-            case NLX_GATE_RANDOM_ACCESS: {
-                const uint32_t bits = gd.param0, copies = gd.param1 & 0xFFFF, extra = gd.param1 >> 16;
-                const uint32_t vec = 1u << bits, rt = (2 + vec) * copies + extra;
-                for (uint32_t cpy = 0; cpy < copies; cpy++) {
-                    const uint32_t b0 = (2 + vec) * cpy, bw = rt + cpy * bits;
-                    for (uint32_t i = 0; i < bits; i++) {
-                        const uint64_t b = W(bw + i);
-                        acc.emit(gl::mul(b, gl::sub(b, 1)));
-                    }
-                    uint64_t rec = 0;
-                    for (uint32_t i = bits; i-- > 0;) rec = gl::add(gl::add(rec, rec), W(bw + i));
-                    acc.emit(gl::sub(rec, W(b0)));
-                    // fold the list by the index bits; level i consumes bit i.  The selected element is
-                    // computed by a recursive descent so that no list array lives in registers:
-                    // value(level, j) = value(level-1, 2j) + bit * (value(level-1, 2j+1) - value(level-1, 2j))
-                    // evaluated iteratively over the 2^bits leaves with a small stack.
-                    uint64_t stack[7];
-                    uint32_t depth_of[7];
-                    int sp = 0;
-                    for (uint32_t leaf = 0; leaf < vec; leaf++) {
-                        uint64_t v = W(b0 + 2 + leaf);
-                        uint32_t lvl = 0;
-                        while (sp > 0 && depth_of[sp - 1] == lvl) {
-                            const uint64_t left = stack[--sp];
-                            const uint64_t b = W(bw + lvl);
-                            v = gl::add(left, gl::mul(b, gl::sub(v, left)));
-                            lvl++;
-                        }
-                        stack[sp] = v;
-                        depth_of[sp] = lvl;
-                        sp++;
-                    }
-                    acc.emit(gl::sub(stack[0], W(b0 + 1)));
-                }
-                for (uint32_t i = 0; i < extra; i++) acc.emit(gl::sub(CS(p.n_selectors + i), W((2 + vec) * copies + i)));
-                break;
-            }
-            default: break;  // NoopGate
-        }
-        tot0 = gl::add(tot0, gl::mul(f, acc.finish(0)));
-        tot1 = gl::add(tot1, gl::mul(f, acc.finish(1)));
-    }
-    // ---- permutation argument ----
-    // vanishing_terms = [L_0 (Z_i - 1)]_i ++ [partial-product checks]_i ++ gate constraints, and EVERY
-    // alpha_c reduces the whole list, so each term feeds both sums.
-    const uint32_t n_chunks = (p.routed + p.chunk - 1) / p.chunk;
-    uint64_t l0a = 0, l0b = 0;  // sum_i (Z_i - 1) alpha_c^i, multiplied by L_0(x)/Z_H(x) below
-    for (uint32_t c = 0; c < nc; c++) {
-        const uint64_t beta = p.betas[c], gamma = p.gammas[c];
-        const uint64_t bx = gl::mul(beta, x);
-        const uint64_t z_x = ZS(c);
-        const uint64_t z_gx = p.zs[(size_t)c * L + pos_next];
-        const uint64_t zm1 = gl::sub(z_x, 1);
-        l0a = gl::add(l0a, gl::mul(zm1, ap0[c]));
-        l0b = gl::add(l0b, gl::mul(zm1, ap1[c]));
-        uint64_t accv = z_x;
+    const uint32_t* work = p.work + (size_t)wv * p.work_stride;
+    for (uint32_t wi = 0;; wi++) {
+        const uint32_t item = work[wi];  // wave-uniform
+        if (item == 0xFFFFFFFFu) break;
+        if (item < p.n_gates) {
+            // ---- one gate: filter x sum_k alpha^k c_k ----
+            const GateDev gd = p.gates[item];
+            const uint64_t s = CC(gd.selector_index);
+            uint64_t f = 1;
+            for (uint32_t i = gd.group_start; i < gd.group_end; i++)
+                if (i != gd.index) f = gl::mul(f, gl::sub((uint64_t)i, s));
+            if (p.n_selectors > 1) f = gl::mul(f, gl::sub(0xFFFFFFFFULL, s));
+            acc.reset();
+            eval_gate(gd, p, W, CC, acc, n);
+            tot0 = gl::add(tot0, gl::mul(f, acc.finish(0)));
+            tot1 = gl::add(tot1, gl::mul(f, acc.finish(1)));
+        } else {
+            // ---- the permutation argument of challenge c ----
+            // vanishing_terms = [L_0 (Z_i - 1)]_i ++ [partial-product checks]_i ++ gate constraints, and EVERY
+            // alpha reduces the whole list, so each term feeds both sums.
+            const uint32_t c = item - p.n_gates;
+            const uint32_t n_chunks = (p.routed + p.chunk - 1) / p.chunk;
+            const size_t pos_next = ((size_t)r << p.log_n) + ((k + 1) & (n - 1));
+            const uint64_t x = gl::mul(p.coset_base[r], root_pow(p.w_n_table, k, (uint32_t)(n >> 1)));
+            const uint64_t beta = p.betas[c], gamma = p.gammas[c];
+            const uint64_t bx = gl::mul(beta, x);
+            const uint64_t z_x = ZS(c);
+            const uint64_t z_gx = p.zs[(size_t)c * L + pos_next];
+            const uint64_t zm1 = gl::sub(z_x, 1);
+            l0a = gl::add(l0a, gl::mul(zm1, ap0[c]));
+            l0b = gl::add(l0b, gl::mul(zm1, ap1[c]));
+            uint64_t accv = z_x;
 #pragma unroll 1
-        for (uint32_t q = 0; q < n_chunks; q++) {
-            uint64_t nm = 1, dn = 1;
-            for (uint32_t j = q * p.chunk; j < (q + 1) * p.chunk && j < p.routed; j++) {
-                const uint64_t w = W(j);
-                nm = gl::mul(nm, gl::add(gl::add(w, gl::mul(bx, p.k_is[j])), gamma));
-                dn = gl::mul(dn, gl::add(gl::add(w, gl::mul(beta, CS(p.n_consts_all + j))), gamma));
+            for (uint32_t q = 0; q < n_chunks; q++) {
+                uint64_t nm = 1, dn = 1;
+                for (uint32_t j = q * p.chunk; j < (q + 1) * p.chunk && j < p.routed; j++) {
+                    const uint64_t w = W(j);
+                    const uint64_t sg = p.cs[(size_t)(p.n_consts_all + j) * L + pos];
+                    nm = gl::mul(nm, gl::add(gl::add(w, gl::mul(bx, p.k_is[j])), gamma));
+                    dn = gl::mul(dn, gl::add(gl::add(w, gl::mul(beta, sg)), gamma));
+                }
+                const uint64_t new_acc = (q + 1 < n_chunks) ? ZS(nc + c * npp + q) : z_gx;
+                const uint64_t term = gl::sub(gl::mul(accv, nm), gl::mul(new_acc, dn));
+                const uint32_t t = nc + c * (npp + 1) + q;
+                tot0 = gl::add(tot0, gl::mul(term, ap0[t]));
+                tot1 = gl::add(tot1, gl::mul(term, ap1[t]));
+                accv = new_acc;
             }
-            const uint64_t new_acc = (q + 1 < n_chunks) ? ZS(nc + c * npp + q) : z_gx;
-            const uint64_t term = gl::sub(gl::mul(accv, nm), gl::mul(new_acc, dn));
-            const uint32_t t = nc + c * (npp + 1) + q;
-            tot0 = gl::add(tot0, gl::mul(term, ap0[t]));
-            tot1 = gl::add(tot1, gl::mul(term, ap1[t]));
-            accv = new_acc;
         }
+    }
+    // ---- the waves' partial sums meet in LDS (the tile is dead once every wave is past its last item) ----
+    __syncthreads();
+    uint64_t* red = q_lds;  // [QW][4][64]
+    red[(wv * 4 + 0) * 64 + lane] = tot0;
+    red[(wv * 4 + 1) * 64 + lane] = tot1;
+    red[(wv * 4 + 2) * 64 + lane] = l0a;
+    red[(wv * 4 + 3) * 64 + lane] = l0b;
+    __syncthreads();
+    if (wv != 0) return;
+    for (uint32_t w2 = 1; w2 < QW; w2++) {
+        tot0 = gl::add(tot0, red[(w2 * 4 + 0) * 64 + lane]);
+        tot1 = gl::add(tot1, red[(w2 * 4 + 1) * 64 + lane]);
+        l0a = gl::add(l0a, red[(w2 * 4 + 2) * 64 + lane]);
+        l0b = gl::add(l0b, red[(w2 * 4 + 3) * 64 + lane]);
     }
     // quotient = (L_0 terms + rest) / Z_H(x);  L_0(x)/Z_H(x) = 1 / (n (x - 1)) = l0_scaled[pos]
     const uint64_t zh_inv = p.zh_inv[r];
     const uint64_t l0s = p.l0_scaled[pos];
+    if (!live) return;
     p.out[pos] = gl::add(gl::mul(tot0, zh_inv), gl::mul(l0a, l0s));
     if (nc > 1) p.out[L + pos] = gl::add(gl::mul(tot1, zh_inv), gl::mul(l0b, l0s));
 }
 
+size_t quotient_lds_bytes(uint32_t num_wires, uint32_t n_consts_all) {
+    const size_t tile = (size_t)(num_wires + n_consts_all) * 64 * 8, red = (size_t)QW * 4 * 64 * 8;
+    return tile > red ? tile : red;
+}
+uint32_t quotient_waves() { return QW; }
+
 void launch_quotient(hipStream_t st, const QuotientParams& p) {
     const size_t L = (size_t)1 << (p.log_n + p.rate_bits);
-    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, p);
+    const size_t lds = quotient_lds_bytes(p.num_wires, p.n_consts_all);
+    // more than the default 64 KB of dynamic LDS: the attribute is per function and device, setting it again is free
+    (void)hipFuncSetAttribute((const void*)k_quotient, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_quotient, dim3((unsigned)((L + 63) / 64)), dim3(64 * QW), lds, st, p);
 }
 
 // l0_scaled[pos] = 1 / (n * (x_pos - 1)), batch-inverted 8 per thread

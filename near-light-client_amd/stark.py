@@ -516,10 +516,13 @@ class Stark:
     """A compiled AIR + config at a fixed trace length: what starky's `prove(stark, config, trace, pis)`
     takes.  `desc` is the C-ABI descriptor (nlx_stark_desc); `build(ctx)` makes it resident on a GPU."""
 
-    def __init__(self, air, degree_bits, config=None):
+    def __init__(self, air, degree_bits, config=None, program=None):
+        """program: a caller-assembled register program for the same constraints (default: air.compile()).  The program is
+        part of the statement - the transcript opens with a digest of it - so two provers agree on proof bytes only if they
+        run the same words."""
         self.air = air
         self.config = config or StarkConfig()
-        self.program = air.compile()
+        self.program = air.compile() if program is None else np.ascontiguousarray(program, dtype=np.uint64)
         cfg = self.config
         qdf = air.quotient_degree_factor()
         if qdf > (1 << cfg.rate_bits):

@@ -9,10 +9,11 @@ from conftest import ROOT
 
 
 def _build(tmp_path, name="prove_example"):
+    from conftest import GOLDEN_SUFFIX
     exe = str(tmp_path / name)
     lib_dir = os.path.join(ROOT, "near-light-client_amd")
     cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", name + ".c"), "-L", lib_dir, "-lnlx", "-Wl,-rpath," + lib_dir, "-o", exe]
+           os.path.join(ROOT, "examples", name + ".c"), "-L", lib_dir, "-lnlx" + GOLDEN_SUFFIX, "-Wl,-rpath," + lib_dir, "-o", exe]
     subprocess.run(cmd, check=True, capture_output=True)
     return exe
 
@@ -47,14 +48,15 @@ def test_c_stark_caller_matches_python_path(nlx, ctx, tmp_path):
     assert r.returncode == 0, r.stderr
     S = nlx.stark
     t, pis = S.fibonacci_trace(9, 3, 5)
-    st = S.Stark(S.fibonacci_air(), 9)
-    # the C example lays its program out by hand; compile the same constraints with the assembler and compare proofs
+    # the C example lays its program out by hand and prints it: the program is part of the statement (the transcript opens
+    # with its digest), so the Python prover is given the same words for the same AIR
+    words = [int(w, 16) for w in r.stdout.split("program:")[1].splitlines()[0].split()]
+    st = S.Stark(S.fibonacci_air(), 9, program=words)
     pr = st.build(ctx)
     proof = pr.prove(t, pis)
     fold = 0
     for i in range(0, len(proof) - 7, 8):
         fold = ((fold * 0x100000001B3) ^ int.from_bytes(proof[i:i + 8], "little")) & 0xFFFFFFFFFFFFFFFF
-    # different instruction schedules, same constraint order and values -> same proof bytes
     assert ("proof %d bytes, fold %016x" % (len(proof), fold)) in r.stdout, r.stdout
     pr.close()
 
@@ -81,7 +83,8 @@ def test_c_rounds_caller_matches_python_path(nlx, ctx, orc, tmp_path):
         x ^= (x << 17) & 0xFFFFFFFFFFFFFFFF
         v.append(x % P)
     v = np.array(v, dtype=np.uint64)
-    pr = S.Stark(fingerprint_air(S), 9).build(ctx)
+    words = [int(w, 16) for w in r.stdout.split("program:")[1].splitlines()[0].split()]
+    pr = S.Stark(fingerprint_air(S), 9, program=words).build(ctx)
     proof = pr.prove_rounds(fingerprint_rounds(v), [])
     fold = 0
     for i in range(0, len(proof) - 7, 8):

@@ -62,7 +62,7 @@ def test_stagewise_proof_equals_whole_proof(nlx, ctx, orc, log_n, kw):
     # 5. FRI
     fp = pk.FriParams(cfg.fri_arity_bits, cfg.fri_final_poly_bits, cfg.fri_pow_bits, cfg.fri_num_queries)
     out += pk.fri_prove(ctx, [cs, cw, cz, cq], [0, 0, nc, 0], zeta, openings_zeta, o_next, fp, ch)
-    out += np.uint32(syn.public_inputs.size).tobytes() + syn.public_inputs.tobytes()
+    out += np.uint64(syn.public_inputs.size).tobytes() + syn.public_inputs.tobytes()   # write_usize(len), then the field vec
     assert len(out) == len(want)
     if bytes(out) != want:
         a, b = np.frombuffer(bytes(out), np.uint8), np.frombuffer(want, np.uint8)
