@@ -778,7 +778,7 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
             "value": world * args.steps / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer)",
-            "data": "real mainnet Sync step (fixtures main_1 -> main_2) for the three STARKs, traces generated on the GPU; synthetic outer circuit of SyncCircuit's static shape",
+            "data": "synthetic outer circuit of SyncCircuit's static shape; the three STARK statements are the real mainnet Sync step main_1 -> main_2 (the reference's fixtures), traces generated on the GPU",
             "config": {"workload": "one full Sync proof = SHA-256 STARK of %d header / next_bps messages (2^%d blocks, 2^%d x %d trace) + "
                                    "SHA-512 STARK of %d approval hashes (2^%d blocks) + Ed25519 STARK of %d approval signatures (2^%d "
                                    "slots, 2^%d rows) + outer plonky2 proof (standard_recursion_config, 2^%d rows, 135 wires, %d gate "

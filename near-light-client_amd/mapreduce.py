@@ -5,33 +5,72 @@ Mirrors plonky2x `frontend::mapreduce::generator::MapReduceDynamicGenerator` +
 registration at `:112-122`): N/B independent MAP proofs, then a binary tree of REDUCE proofs, then the
 outer proof.  The reference runs them one after another on CPU ("No parallelisation", README.md:123);
 here the jobs of every level are dealt round-robin over the ranks (one process per GPU) and the only
-exchange is ONE all-gather per level of the children's digests (RCCL over xGMI on GPUs, gloo in the
-CPU tests).  Results do not depend on the number of ranks.
+exchange is ONE all-gather per level (RCCL over xGMI on GPUs, gloo in the CPU tests) of what a parent job
+consumes from its children: each child's **blob = public output ‖ serialized proof**.
 
-The prover behind a job is injected (`prove_fn`) so the sharding logic is testable without a GPU.
+* A map job proves VERIFY_BATCH ids and outputs a `[ProofVerificationResult; VERIFY_AMT]` array (its own results,
+  then defaults - nearx/src/verify.rs:69-86), N x 33 bytes.
+* A reduce job takes its two children's proofs and outputs, and outputs their merge (`MergeProofHint`,
+  verify.rs:151-183; `succinct_io.merge_verify_outputs`).  In the reference the reduce circuit verifies the two child
+  proofs in-circuit; the synthetic reduce circuits here carry the children as public inputs instead: the 2 x 4 field
+  elements of `blob_digest(child)` = SHA-256(output ‖ proof), so a reduce proof is bound to exactly those children.
+* The outer proof binds the root blob the same way and its output is the job's output (verify.rs:94-98).
+
+Results (root digest, output bytes) do not depend on the number of ranks or on how many jobs are in flight per GPU.
+Job counts need not be powers of two (the reference asserts they are, nearx/src/main.rs:19; here an unpaired node of a
+level is carried to the next level unchanged).  The prover behind a job is injected (`prove_fn`) so the sharding logic
+is testable without a GPU.
 """
+import hashlib
+
 import numpy as np
+
+from . import succinct_io
 
 P = 0xFFFFFFFF00000001
 
 
-def proof_digest(proof_bytes):
-    """4 field elements identifying a child proof: its first Merkle-cap entry (wires cap[0])."""
-    return np.frombuffer(proof_bytes[:32], dtype=np.uint64).copy()
+def blob_digest(output, proof):
+    """4 field elements identifying a child: SHA-256(public output ‖ proof bytes), four little-endian words mod p"""
+    h = hashlib.sha256(bytes(output) + bytes(proof)).digest()
+    return np.array([int.from_bytes(h[8 * i: 8 * i + 8], "little") % P for i in range(4)], dtype=np.uint64)
+
+
+class Blob:
+    """what travels from a job to its parent: the job's public output and its serialized proof"""
+    __slots__ = ("output", "proof")
+
+    def __init__(self, output, proof):
+        self.output, self.proof = bytes(output), bytes(proof)
+
+    def digest(self):
+        return blob_digest(self.output, self.proof)
+
+    def pack(self):
+        return len(self.output).to_bytes(8, "little") + len(self.proof).to_bytes(8, "little") + self.output + self.proof
+
+    @classmethod
+    def unpack(cls, raw):
+        lo, lp = int.from_bytes(raw[:8], "little"), int.from_bytes(raw[8:16], "little")
+        if 16 + lo + lp > len(raw):
+            raise ValueError("truncated blob")
+        return cls(raw[16:16 + lo], raw[16 + lo:16 + lo + lp])
 
 
 class TreePlan:
-    """Static job list for `n_map` map proofs reduced pairwise to one (n_map a power of two)."""
+    """Static job list for `n_map` map proofs reduced pairwise to one.  levels[l] = reduce jobs at reduce level l; when
+    a level has an odd number of nodes the last one moves up unchanged (carried[l] is True)."""
 
     def __init__(self, n_map):
-        if n_map < 1 or n_map & (n_map - 1):
-            raise ValueError("n_map must be a power of two")
+        if n_map < 1:
+            raise ValueError("at least one map job")
         self.n_map = n_map
-        self.levels = []  # levels[l] = number of reduce jobs at reduce level l
+        self.levels, self.carried = [], []
         k = n_map
         while k > 1:
-            k //= 2
-            self.levels.append(k)
+            self.levels.append(k // 2)
+            self.carried.append(bool(k & 1))
+            k = k // 2 + (k & 1)
 
     @property
     def n_jobs(self):
@@ -42,86 +81,130 @@ def owner(job_index, world):
     return job_index % world
 
 
-def all_gather_digests(local, n_jobs, rank, world, dist, device=None):
-    """local: dict job_index -> (4,) uint64.  Returns (n_jobs, 4) uint64 with every job's digest.
-    One collective per level; payload is n_jobs * 32 bytes."""
-    per = (n_jobs + world - 1) // world
+def all_gather_blobs(local, n_jobs, rank, world, dist, device=None):
+    """local: dict job_index -> Blob.  Returns the list of all n_jobs blobs on every rank.  One collective for the
+    lengths and one for the payload (padded to the longest blob of the level): O(100 KB) per job, latency-bound."""
     if dist is None or world == 1:
-        out = np.zeros((n_jobs, 4), dtype=np.uint64)
-        for j, d in local.items():
-            out[j] = d
-        return out
+        return [local[j] for j in range(n_jobs)]
     import torch
-    send = torch.zeros((per, 4), dtype=torch.int64, device=device)
-    for j, d in local.items():
-        send[j // world] = torch.from_numpy(np.asarray(d, dtype=np.uint64).view(np.int64)).to(send.device)
+    per = (n_jobs + world - 1) // world
+    packed = {j: b.pack() for j, b in local.items()}
+    lens = torch.zeros(per, dtype=torch.int64, device=device)
+    for j, raw in packed.items():
+        lens[j // world] = len(raw)
+    all_lens = [torch.zeros_like(lens) for _ in range(world)]
+    dist.all_gather(all_lens, lens)
+    width = max(int(t.max().item()) for t in all_lens)
+    send = torch.zeros((per, width), dtype=torch.uint8)
+    for j, raw in packed.items():
+        send[j // world, :len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    send = send.to(lens.device)
     recv = [torch.zeros_like(send) for _ in range(world)]
     dist.all_gather(recv, send)
-    out = np.zeros((n_jobs, 4), dtype=np.uint64)
-    for r in range(world):
-        got = recv[r].cpu().numpy().view(np.uint64)
-        for slot in range(per):
-            j = slot * world + r
-            if j < n_jobs:
-                out[j] = got[slot]
+    out = []
+    for j in range(n_jobs):
+        r, slot = j % world, j // world
+        ln = int(all_lens[r][slot].item())
+        out.append(Blob.unpack(recv[r][slot, :ln].cpu().numpy().tobytes()))
     return out
 
 
-def run_tree(plan, prove_fn, rank=0, world=1, dist=None, device=None):
-    """Executes the whole tree.  prove_fn(kind, level, index, public_inputs) -> proof bytes, where kind
-    is "map" | "reduce" | "outer"; map jobs get no children (public_inputs=None -> the job's own).
-    Returns (root_digest, stats) on every rank; stats counts the proofs this rank produced."""
-    import time
-    done = 0
-    level_ms = []
+def default_request(n_map, batch=4):
+    """A synthetic Verify request of n_map * batch ids: (trusted header hash, [id hash]) - the shape of
+    nearx/src/verify.rs:47-55 without the account strings, which do not reach the proof tree."""
+    header = hashlib.sha256(b"nlx verify request").digest()
+    ids = [hashlib.sha256(b"nlx id %d" % i).digest() for i in range(n_map * batch)]
+    return header, ids, batch
 
-    def run_level(jobs):
-        """jobs: list of (kind, level, index, public_inputs) owned by this rank -> {index: digest}.
+
+def run_tree(plan, prove_fn, rank=0, world=1, dist=None, device=None, request=None):
+    """Executes the whole tree.  prove_fn(kind, level, index, public_inputs) -> proof bytes, kind "map" | "reduce" |
+    "outer", public_inputs = 8 field elements: for a map job a digest of the request slice it proves, for a reduce job
+    its children's blob digests, for the outer job the root blob's digest twice.
+    Returns (root_digest, stats) on every rank; stats carries the job's output bytes (VERIFY_AMT x 33) and the proofs
+    this rank produced."""
+    import time
+    header, ids, batch = request if request is not None else default_request(plan.n_map)
+    n_amt = len(ids)
+    if n_amt != plan.n_map * batch:
+        raise ValueError("the request must hold n_map * batch ids")
+    done = 0
+    level_ms, bytes_gathered = [], 0
+
+    def run_level(jobs, outputs):
+        """jobs: list of (kind, level, index, public_inputs) owned by this rank; outputs[i]: job i's public output.
         A prover may offer prove_many() to keep several independent jobs of a level in flight."""
         if hasattr(prove_fn, "prove_many"):
             proofs = prove_fn.prove_many(jobs)
         else:
             proofs = [prove_fn(*job) for job in jobs]
-        return {job[2]: proof_digest(pr) for job, pr in zip(jobs, proofs)}
+        return {job[2]: Blob(out, pr) for job, out, pr in zip(jobs, outputs, proofs)}
 
-    # ---- map level ----
+    # ---- map level: job j proves ids[j * batch : (j + 1) * batch] ----
     t0 = time.perf_counter()
-    jobs = [("map", 0, j, None) for j in range(plan.n_map) if owner(j, world) == rank]
-    local = run_level(jobs)
+    jobs, outs = [], []
+    for j in range(plan.n_map):
+        if owner(j, world) != rank:
+            continue
+        mine = ids[j * batch:(j + 1) * batch]
+        pis = blob_digest(header + b"".join(mine), j.to_bytes(8, "little"))
+        jobs.append(("map", 0, j, np.concatenate([pis, pis])))
+        results = [(i, True) for i in mine] + succinct_io.default_verify_output(n_amt - len(mine))
+        outs.append(succinct_io.encode_verify_output(results))
+    local = run_level(jobs, outs)
     done += len(jobs)
-    digests = all_gather_digests(local, plan.n_map, rank, world, dist, device)
+    nodes = all_gather_blobs(local, plan.n_map, rank, world, dist, device)
+    bytes_gathered += sum(len(b.proof) + len(b.output) for b in nodes)
     level_ms.append(("map", plan.n_map, (time.perf_counter() - t0) * 1e3))
     # ---- reduce levels ----
     for lvl, n_jobs in enumerate(plan.levels):
-        jobs = [("reduce", lvl, j, np.concatenate([digests[2 * j], digests[2 * j + 1]]))
-                for j in range(n_jobs) if owner(j, world) == rank]
         t0 = time.perf_counter()
-        local = run_level(jobs)
+        jobs, outs = [], []
+        for j in range(n_jobs):
+            if owner(j, world) != rank:
+                continue
+            left, right = nodes[2 * j], nodes[2 * j + 1]
+            jobs.append(("reduce", lvl, j, np.concatenate([left.digest(), right.digest()])))
+            merged = succinct_io.merge_verify_outputs(succinct_io.decode_verify_output(left.output),
+                                                      succinct_io.decode_verify_output(right.output))
+            outs.append(succinct_io.encode_verify_output(merged))
+        local = run_level(jobs, outs)
         done += len(jobs)
-        digests = all_gather_digests(local, n_jobs, rank, world, dist, device)
+        nxt = all_gather_blobs(local, n_jobs, rank, world, dist, device)
+        bytes_gathered += sum(len(b.proof) + len(b.output) for b in nxt)
+        if plan.carried[lvl]:
+            nxt.append(nodes[-1])   # the unpaired node moves up unchanged
+        nodes = nxt
         level_ms.append(("reduce%d" % lvl, n_jobs, (time.perf_counter() - t0) * 1e3))
-    # ---- outer proof (rank 0), digest broadcast through the same collective ----
+    # ---- outer proof (rank 0), broadcast through the same collective ----
     t0 = time.perf_counter()
     local = {}
+    root_child = nodes[0]
     if rank == 0:
-        pis = np.concatenate([digests[0], digests[0]])
-        local[0] = proof_digest(prove_fn("outer", 0, 0, pis))
+        d = root_child.digest()
+        proof = prove_fn("outer", 0, 0, np.concatenate([d, d]))
+        local[0] = Blob(root_child.output, proof)
         done += 1
-    root = all_gather_digests(local, 1, rank, world, dist, device)[0]
+    if dist is None or world == 1:
+        outer = local[0]
+    else:
+        outer = all_gather_blobs(local, 1, rank, world, dist, device)[0]
     level_ms.append(("outer", 1, (time.perf_counter() - t0) * 1e3))
-    return root, {"proofs_by_this_rank": done, "level_ms": level_ms}
+    return outer.digest(), {"proofs_by_this_rank": done, "level_ms": level_ms, "output": outer.output,
+                            "outer_proof": outer.proof, "bytes_gathered": bytes_gathered}
 
 
 class GpuTreeProver:
     """prove_fn backed by nlx_prove: one map circuit, one reduce circuit per level, one outer circuit,
     all resident on this rank's GPU.  `workers` independent contexts (stream + host thread each) keep
-    several jobs of a level in flight.  Witness tables live in HBM; a job only re-targets the
-    PublicInputGate row (4 words) to its public inputs - map jobs to a per-job seed, reduce / outer jobs
-    to their children's digests."""
+    several jobs of a level in flight.  Witness tables live in HBM (an nlx_buf of the worker's context); a job only
+    re-targets the PublicInputGate row (4 words) to its public inputs, through nlx_buf_upload - i.e. on the context's own
+    stream, ordered before the proof that reads it (round 1 patched a torch tensor on torch's current stream of whatever
+    device the calling thread had current, which nothing ordered against the context's stream)."""
 
     def __init__(self, nlx, ctx, plan, map_log_n, reduce_log_n, gate_mix=None, torch=None, workers=1):
         import queue
-        self.nlx, self.plan, self.torch = nlx, plan, torch
+        self.nlx, self.plan = nlx, plan
         mix = gate_mix or dict(pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)
         self.workers = []
         self.free = queue.Queue()
@@ -133,26 +216,18 @@ class GpuTreeProver:
             for kind, lvl, log_n, seed in specs:
                 syn = nlx.SyntheticCircuit(log_n, seed=seed, num_public_inputs=8, **mix)
                 cd = nlx.CircuitData.from_synthetic(c, syn)
-                dev = None
-                if torch is not None:
-                    dev = torch.from_numpy(syn.wires.view(np.int64)).to(torch.device("cuda", ctx.device))
+                dev = nlx.DeviceBuffer.from_array(c, syn.wires)
                 wk["circ"][(kind, lvl)] = (syn, cd, dev)
             self.workers.append(wk)
             self.free.put(wk)
 
     def _prove(self, wk, kind, level, index, public_inputs):
         syn, cd, dev = wk["circ"][(kind, level if kind == "reduce" else 0)]
-        if kind == "map":
-            pis = np.array([(index * 0x9E3779B97F4A7C15 + k) % P for k in range(8)], dtype=np.uint64)
-        else:
-            pis = public_inputs
-        syn.set_public_inputs(pis)
-        if dev is None:
-            return cd.prove(syn.wires, syn.public_inputs)
-        # patch the 4 words of the PublicInputGate row in the HBM-resident witness
-        dev[0:4, 0] = self.torch.from_numpy(syn.wires[0:4, 0].copy().view(np.int64)).to(dev.device)
-        self.torch.cuda.current_stream().synchronize()
-        return cd.prove(dev, syn.public_inputs)
+        syn.set_public_inputs(public_inputs)
+        n = 1 << syn.log_n
+        for col in range(4):   # the PublicInputGate row: wires 0..3 of row 0 hold the public-input hash
+            dev.upload(syn.wires[col, 0:1], offset=col * n * 8)
+        return cd.prove(dev.ptr, syn.public_inputs)
 
     def __call__(self, kind, level, index, public_inputs):
         wk = self.free.get()
@@ -228,17 +303,32 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist):
         dt = float(tt.item())
     if rank != 0:
         return None
+    # what the job returned is checked before it is reported: the output lists every requested id as verified, in order,
+    # and (unless --no-cpu-baseline) the oracle verifier accepts the outer proof for the public inputs that bind the root
+    header, ids, _ = default_request(plan.n_map)
+    output_ok = succinct_io.decode_verify_output(stats["output"]) == [(i, True) for i in ids]
+    outer_ok = None
+    if not getattr(args, "no_cpu_baseline", False):
+        import os
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        import oracle_py
+        oc = oracle_py.Circuit.from_synthetic(prover.workers[0]["circ"][("outer", 0)][0])
+        outer_ok = oc.verify(stats["outer_proof"]) == 1
+        oc.close()
     return {
         "metric": "Sync/Verify proofs/sec at 1/2/4/8 MI355X + achieved HBM GB/s vs roofline",
         "value": args.steps / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
         "config": {"workload": "VerifyCircuit 128x4-shaped map-reduce job: 32 map proofs (2^%d rows) + 31 reduce "
-                               "proofs + 1 outer proof (2^%d rows), sharded round-robin, one RCCL all-gather of "
-                               "digests per level" % (args.map_log_n, args.reduce_log_n) +
+                               "proofs + 1 outer proof (2^%d rows), sharded round-robin, one RCCL all-gather per level of the children's "
+                               "(public output || serialized proof) blobs" % (args.map_log_n, args.reduce_log_n) +
                                ("; plus, per rank, one SHA-256 STARK of the 2^11 blocks of every map job it owns" if sha is not None else ""),
                    "map_starks_ms_per_step_rank0": round(stark_ms / args.steps, 2) if sha is not None else None,
                    "jobs": plan.n_jobs, "proofs_in_flight_per_gpu": args.inflight,
-                   "level_ms_last_step": [[k, n, round(ms, 3)] for k, n, ms in stats["level_ms"]], "root_digest": [int(x) for x in root], "parallelism": "mapreduce x%d" % world},
+                   "level_ms_last_step": [[k, n, round(ms, 3)] for k, n, ms in stats["level_ms"]], "root_digest": [int(x) for x in root], "bytes_gathered_last_step": stats["bytes_gathered"],
+                   "output_bytes": len(stats["output"]), "output_lists_every_id_as_verified": output_ok,
+                   "oracle_verifier_accepts_outer_proof": outer_ok, "parallelism": "mapreduce x%d" % world},
         "roofline": None, "cpu_baseline": None,
     }

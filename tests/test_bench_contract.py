@@ -28,17 +28,35 @@ def test_bench_parses_its_flags():
 
 @pytest.mark.gpu
 def test_default_workload_line():
-    d = run_bench("--gpus", "1", "--steps", "3", "--warmup", "1", "--log-n", "12")
+    """the default job = one full Sync proof (three STARKs of the mainnet step + the outer plonky2 proof, here at 2^12 rows)"""
+    d = run_bench("--gpus", "1", "--steps", "3", "--warmup", "1", "--log-n", "12", timeout=600)
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["data"].startswith("synthetic") and "workload" in d["config"]
+    for part in ("SHA-256 STARK", "SHA-512 STARK", "Ed25519 STARK", "outer plonky2 proof"):
+        assert part in d["config"]["workload"], part
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-6          # proofs/s x s/proof = 1 at N = 1
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf
+    rv = d["roofline_valu"]
+    assert rv["unit"] == "Gperm/s" and 0 < rv["frac"] < 1.2 and abs(rv["frac"] - rv["achieved"] / rv["peak"]) < 1e-12
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
+    # the cpu_baseline leg proves the same inputs on both sides and compares the BYTES
+    pc = d["parity_checked"]
+    assert pc["all_bytes_equal"] is True and pc["outer"]["bytes_equal"] and pc["sha256"]["bytes_equal"] and pc["sha512"]["bytes_equal"]
+    assert pc["ed25519"]["bytes_equal"] and pc["outer"]["oracle_verifier_accepts"]
+    assert d["config"]["outer_rows_floor_from_stark_verification"]["total"] > 1 << 16
+
+
+@pytest.mark.gpu
+def test_outer_only_workload_line():
+    d = run_bench("--workload", "outer", "--steps", "3", "--warmup", "1", "--log-n", "12")
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["roofline"]["kernel"] == "k_hash_lde_leaves" and d["cpu_baseline"]["value"] > 0
 
 
 @pytest.mark.gpu
@@ -51,23 +69,50 @@ def test_secondary_workload_lines(args):
     assert d["value"] > 0 and d["cpu_baseline"] is None and "workload" in d["config"]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("args", [("--log-n", "12"), ("--workload", "verify128", "--log-n", "10", "--map-log-n", "11")])
-def test_driver_launch_line_two_ranks(args):
-    """The driver's N > 1 command (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
-    --master-port P bench.py --gpus N ...`) with N = 2 on the one-GPU box: NLX_BENCH_REHEARSAL=1 puts both ranks on
-    GPU 0 over gloo (RCCL refuses two ranks on one device), everything else is the code path of a real two-GPU run:
-    rank / world from the environment, barrier, MAX over ranks, one JSON line from rank 0."""
-    env = dict(os.environ, NLX_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _launch_two_ranks(args, env_extra, port):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", *args]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     for k in REQUIRED:
         assert k in d, k
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and "rehearsal" in d["config"]
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    return d
+
+
+VERIFY_ARGS = ("--workload", "verify128", "--reduce-log-n", "10", "--map-log-n", "11")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [("--log-n", "12", "--no-extra"), VERIFY_ARGS])
+def test_driver_launch_line_two_ranks(args):
+    """The driver's N > 1 command (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`) with N = 2 on the one-GPU box: NLX_BENCH_REHEARSAL=1 puts both ranks on
+    GPU 0 over gloo (RCCL refuses two ranks on one device), everything else is the code path of a real two-GPU run:
+    rank / world from the environment, barrier, MAX over ranks, one JSON line from rank 0.  The Verify job's root digest
+    and output must equal the one-rank run's."""
+    d = _launch_two_ranks(args, {"NLX_BENCH_REHEARSAL": "1"}, 29641)
+    assert "rehearsal" in d["config"]
     assert d["scaling"] == ("strong" if "verify128" in args else "weak")
+    if "verify128" in args:
+        one = run_bench(*args, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", timeout=600)
+        assert one["config"]["root_digest"] == d["config"]["root_digest"], "root(ws=2) != root(ws=1)"
+        assert d["config"]["output_lists_every_id_as_verified"] is True and one["config"]["output_lists_every_id_as_verified"] is True
+        assert d["config"]["bytes_gathered_last_step"] == one["config"]["bytes_gathered_last_step"] > 64 * 50_000
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_rccl():
+    """the real N = 2 path (backend nccl = RCCL, one rank per GPU): runs where two GPUs are visible, skipped on a one-GPU box"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    d = _launch_two_ranks(VERIFY_ARGS, {}, 29642)
+    assert "rehearsal" not in d["config"] and d["scaling"] == "strong"
+    one = run_bench(*VERIFY_ARGS, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", timeout=600)
+    assert one["config"]["root_digest"] == d["config"]["root_digest"]

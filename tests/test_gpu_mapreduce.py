@@ -23,7 +23,7 @@ class _Recording:
         return pr
 
 
-@pytest.mark.parametrize("n_map", [1, 2, 4])
+@pytest.mark.parametrize("n_map", [1, 2, 4, 3])
 def test_tree_proofs_verify_and_root_is_stable(nlx, ctx, orc, n_map):
     import torch
     mr = importlib.import_module("nlx_amd.mapreduce")
@@ -39,13 +39,18 @@ def test_tree_proofs_verify_and_root_is_stable(nlx, ctx, orc, n_map):
         oc = orc.Circuit.from_synthetic(syn)
         assert oc.verify(pr) == 1, (kind, lvl)
         oc.close()
-    # the outer proof's public inputs are the digest of the last reduce (or the only map) proof, twice
+    # the outer proof's public inputs are the digest of the root child's blob (output || proof), twice: the u64 count, then 8 words
     outer = rec.proofs[-1][2]
+    assert int.from_bytes(outer[-72:-64], "little") == 8
     pis = np.frombuffer(outer[-64:], dtype=np.uint64)
-    child = mr.proof_digest(rec.proofs[-2][2])
+    sio = importlib.import_module("nlx_amd.succinct_io")
+    _, ids, batch = mr.default_request(n_map)
+    want_out = sio.encode_verify_output([(i, True) for i in ids])
+    assert stats["output"] == want_out and stats["outer_proof"] == outer
+    child = mr.blob_digest(want_out, rec.proofs[-2][2])
     assert np.array_equal(pis[:4], child) and np.array_equal(pis[4:], child)
-    assert np.array_equal(root, mr.proof_digest(outer))
+    assert np.array_equal(root, mr.blob_digest(want_out, outer))
     # same tree with three proofs in flight per level
     prover3 = mr.GpuTreeProver(nlx, ctx, plan, 10, 9, torch=torch, workers=3)
-    root3, _ = mr.run_tree(plan, prover3)
-    assert np.array_equal(root, root3)
+    root3, stats3 = mr.run_tree(plan, prover3)
+    assert np.array_equal(root, root3) and stats3["output"] == want_out

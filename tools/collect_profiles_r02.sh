@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-2 profile collection on an MI355X box (run from the repo root through gpurun:
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles_r02.sh v1').
+# Kernel stats and PMC counters come from SEPARATE rocprofv3 runs (never --pmc together with trace domains other than
+# --kernel-trace); the program follows "--" directly as `python3 script`.  Results land in gpurun_out/profiles_r02_<tag>/;
+# the summaries to be judged are copied into profiles/ by hand (tracked).
+set -e
+TAG=${1:-vX}
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out/profiles_r02_$TAG
+mkdir -p "$OUT"
+cd "$ROOT"
+echo "== ubench"; ./tools/ubench/pub > "$OUT/r02_valu_ubench_$TAG.txt" 2>&1 || true
+echo "== bench sync"; python bench.py --steps 10 --warmup 2 > "$OUT/r02_bench_sync_$TAG.json"
+echo "== bench outer 2^16"; python bench.py --workload outer --steps 24 --warmup 3 --no-cpu-baseline > "$OUT/r02_bench_outer_2p16_$TAG.json"
+python bench.py --workload outer --steps 12 --warmup 3 --inflight 1 --no-cpu-baseline > "$OUT/r02_bench_outer_2p16_single_stream_$TAG.json"
+cd /tmp && export TMPDIR=/tmp
+echo "== rocprof sync"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_sync" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 6 --warmup 1 --no-cpu-baseline --no-extra > /dev/null
+echo "== rocprof outer single"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_outer_single" -o s --output-format csv -- python3 "$ROOT/bench.py" --workload outer --steps 8 --warmup 2 --inflight 1 --no-cpu-baseline > /dev/null
+echo "== pmc"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o p --output-format csv -- python3 "$ROOT/bench.py" --workload outer --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline > /dev/null
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o p --output-format csv -- python3 "$ROOT/bench.py" --workload outer --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline > /dev/null
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVES --kernel-trace -d "$OUT/pmc_insts" -o p --output-format csv -- python3 "$ROOT/bench.py" --workload outer --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline > /dev/null
+cp "$OUT/stats_sync/s_kernel_stats.csv" "$OUT/r02_bench_sync_kernel_stats_$TAG.csv"
+cp "$OUT/stats_outer_single/s_kernel_stats.csv" "$OUT/r02_bench_outer_2p16_single_stream_kernel_stats_$TAG.csv"
+python3 "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/r02_pmc_traffic_$TAG.json" || true
+ls "$OUT"

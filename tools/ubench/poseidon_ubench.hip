@@ -60,6 +60,70 @@ __global__ void k_rate(uint32_t* out, uint32_t a, uint32_t b, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7 ^ (uint32_t)(y0 ^ y1 ^ y2 ^ y3 ^ y4 ^ y5 ^ y6 ^ y7);
 }
 
+// ---- the same probes counted in SHADER CYCLES (s_memtime) instead of wall time: cycles per wave-instruction per SIMD at
+// 1, 2, 4 and 8 waves per SIMD, so that the issue cost is separated from the clock the chip holds under the load ----
+template <int OP>
+__global__ void k_cycles(uint32_t* out, unsigned long long* cyc, uint32_t a, uint32_t b, int iters) {
+    uint32_t x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    uint64_t y0 = x0, y1 = x1, y2 = x2, y3 = x3, y4 = x4, y5 = x5, y6 = x6, y7 = x7;
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; i++) {
+        if (OP == 4) {
+            asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                         "v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+        } else if (OP == 3) {
+            asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+                         "v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n"
+                         : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7) : "v"(a), "v"(b) : "vcc");
+        } else if (OP == 10) {  // the carry-chain glue of the field code: v_add_co_u32 feeding v_addc_co_u32 through VCC
+            asm volatile("v_add_co_u32 %0, vcc, %0, %8\n v_addc_co_u32 %1, vcc, 0, %1, vcc\n v_add_co_u32 %2, vcc, %2, %8\n v_addc_co_u32 %3, vcc, 0, %3, vcc\n"
+                         "v_add_co_u32 %4, vcc, %4, %8\n v_addc_co_u32 %5, vcc, 0, %5, vcc\n v_add_co_u32 %6, vcc, %6, %8\n v_addc_co_u32 %7, vcc, 0, %7, vcc\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a) : "vcc");
+        } else if (OP == 11) {  // the multiply-accumulate + carry-count pair of the unreduced sums (GateAcc::mac)
+            asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_addc_co_u32 %4, vcc, 0, %4, vcc\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_addc_co_u32 %5, vcc, 0, %5, vcc\n"
+                         "v_mad_u64_u32 %2, vcc, %8, %9, %2\n v_addc_co_u32 %6, vcc, 0, %6, vcc\n v_mad_u64_u32 %3, vcc, %8, %9, %3\n v_addc_co_u32 %7, vcc, 0, %7, vcc\n"
+                         : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b) : "vcc");
+        } else if (OP == 12) {  // v_cndmask / v_cmp pair of a canonicalising add
+            asm volatile("v_cmp_lt_u32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_u32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                         "v_cmp_lt_u32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %8, vcc\n v_cmp_lt_u32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a) : "vcc");
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7 ^ c0 ^ c1 ^ c2 ^ c3 ^ (uint32_t)(y0 ^ y1 ^ y2 ^ y3 ^ y4 ^ y5 ^ y6 ^ y7);
+}
+
+template <int OP>
+int cycles(const char* name, uint32_t* d_out, unsigned long long* d_cyc) {
+    const int iters = 4096, threads = 256;  // one block of 4 waves = one wave per SIMD of a CU
+    for (int waves_per_simd = 1; waves_per_simd <= 8; waves_per_simd *= 2) {
+        const int blocks = 256 * waves_per_simd;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_cycles<OP>, dim3(blocks), dim3(threads), 0, 0, d_out, d_cyc, 12345u, 678u, 16);
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_cycles<OP>, dim3(blocks), dim3(threads), 0, 0, d_out, d_cyc, 12345u, 678u, iters);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> h(blocks * 4);
+        CK(hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost));
+        double sum = 0;
+        for (auto v : h) sum += (double)v;
+        const double per_wave = sum / h.size() / (iters * 8.0);       // s_memtime ticks per instruction of one wave
+        const double per_simd = per_wave / waves_per_simd;            // waves of a SIMD interleave
+        const double ns = ms * 1e6 / ((double)blocks * 4 * iters * 8 / 1024.0);
+        // an s_memtime tick is one shader cycle (MI355X_MICROARCH.md, cycle-constants table): ticks per instruction per SIMD
+        // slot = the issue cost in cycles; ns / ticks = the clock period the chip held during the launch
+        printf("%-34s %d wave(s)/SIMD: %.3f ms, %.2f ns per wave-instruction per SIMD; s_memtime %.4f ticks per instruction per wave (%.4f per SIMD slot -> %.2f GHz)\n",
+               name, waves_per_simd, ms, ns, per_wave, per_simd, per_simd / ns);
+    }
+    return 0;
+}
+
 template <int OP>
 int rate(const char* name, uint32_t* d_out) {
     const int iters = 4096, blocks = 256 * 8, threads = 256;  // 8 waves per SIMD
@@ -249,6 +313,13 @@ int main() {
     rate<3>("v_mad_u64_u32", d_out);
     rate<5>("v_lshl_add_u64", d_out);
     rate<6>("v_fma_f64", d_out);
+    unsigned long long* d_cyc;
+    CK(hipMalloc(&d_cyc, 256 * 8 * 4 * 8));
+    cycles<4>("v_add_u32", d_out, d_cyc);
+    cycles<10>("v_add_co_u32 + v_addc_co_u32", d_out, d_cyc);
+    cycles<12>("v_cmp_lt_u32 + v_cndmask_b32", d_out, d_cyc);
+    cycles<3>("v_mad_u64_u32", d_out, d_cyc);
+    cycles<11>("v_mad_u64_u32 + v_addc_co_u32", d_out, d_cyc);
     size_t n = 1 << 21;
     uint64_t* d_states;
     CK(hipMalloc(&d_states, 12 * n * 8));
