@@ -33,13 +33,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-# Integer-VALU issue roofline of the Poseidon permutation kernel: per wave 11.2 k v_mad_u64_u32 at 4.7
-# cycles + 10.5 k other VALU at 2.9 cycles (measured issue costs, profiles/r02_valu_ubench.txt) = 83.1 k cycles per 64
-# permutations; 1 024 SIMDs at the 2.1 GHz the chip holds under this load.
-VALU_CYCLES_PER_WAVE_PERM = 11.2e3 * 4.7 + 10.5e3 * 2.9
-VALU_PEAK_GPERM = 1024 * 64 / VALU_CYCLES_PER_WAVE_PERM * 2.1
-VALU_PEAK_NOTE = ("1 024 SIMDs x 64 lanes / (11.2 k MAC x 4.7 cyc + 10.5 k other VALU x 2.9 cyc per wave) x 2.1 GHz; issue costs "
-                  "measured by tools/ubench/poseidon_ubench.hip (profiles/r02_valu_ubench.txt)")
+# Integer-VALU issue roofline of the Poseidon permutation kernels (profiles/r02_valu_ubench_v1.txt).  Measured
+# on MI355X at full occupancy: every 32 x 32-bit multiply form issues at 1.99 ns per wave-instruction per SIMD (and so does
+# every VCC-chained add).  The multiplies a permutation cannot do without: 4 per field multiplication (118 S-boxes x 4) and
+# 24 per MDS output (12 state elements x 2 halves; 12 outputs x 30 rounds) = 10 528 per permutation.  Peak = what the chip
+# would do if every other instruction were free: 1 024 SIMDs x 64 lanes / (10 528 x 1.99 ns).  The kernel issues ~17 k
+# instructions per permutation (reductions, carry chains, loads), all at about the same 2 ns.
+VALU_MULS_PER_PERM = 118 * 4 * 4 + 12 * 30 * 24
+VALU_NS_PER_MUL = 1.99
+VALU_PEAK_GPERM = 1024 * 64 / (VALU_MULS_PER_PERM * VALU_NS_PER_MUL)
+VALU_PEAK_NOTE = ("1 024 SIMDs x 64 lanes / (10 528 irreducible 32x32 multiply-adds per permutation x 1.99 ns measured issue cost per "
+                  "wave-instruction per SIMD at full occupancy, tools/ubench/poseidon_ubench.hip -> profiles/r02_valu_ubench_v1.txt); "
+                  "a bound on the multiplies alone - the permutation micro-benchmark itself reaches 1.73 Gperm/s")
 
 
 def stored_traffic(key, alg_bytes):

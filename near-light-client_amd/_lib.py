@@ -9,6 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NLX_GL_GENERATOR_SET=2021 selects the library built with the other candidate generator pair (include/nlx_field.h)
 _GEN_SET = os.environ.get("NLX_GL_GENERATOR_SET", "7")
 LIB_PATH = os.path.join(_HERE, "libnlx.so" if _GEN_SET == "7" else "libnlx_gen%s.so" % _GEN_SET)
+if os.environ.get("NLX_BUILD_VARIANT"):  # a kernel-tuning build made by build.py with the same variable (experiments only)
+    LIB_PATH = LIB_PATH[:-3] + "_" + os.environ["NLX_BUILD_VARIANT"] + ".so"
 
 # If torch is going to be used in this process (bench.py, multi-GPU dispatch) it must load its
 # bundled HIP runtime first; libnlx.so then binds to the same libamdhip64.so.7 instance so

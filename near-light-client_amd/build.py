@@ -17,13 +17,18 @@ GEN_SET = os.environ.get("NLX_GL_GENERATOR_SET", "7")
 if GEN_SET not in ("7", "2021"):
     raise RuntimeError("NLX_GL_GENERATOR_SET must be 7 or 2021")
 _SUFFIX = "" if GEN_SET == "7" else "_gen" + GEN_SET
+# kernel-tuning experiments: NLX_BUILD_VARIANT=name NLX_EXTRA_FLAGS="-DNLX_QW=4 ..." builds libnlx_name.so beside the real one
+# (own object cache); near-light-client_amd/_lib.py loads it when NLX_BUILD_VARIANT is set.  Never used by tests or the bench.
+VARIANT = os.environ.get("NLX_BUILD_VARIANT", "")
+if VARIANT:
+    _SUFFIX += "_" + VARIANT
 OBJ = os.path.join(CSRC, ".obj" + _SUFFIX)
 LIB = os.path.join(HERE, "libnlx%s.so" % _SUFFIX)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 # -Xarch_host -mavx2: the host side of the library (transcript hashing, FRI bookkeeping) runs on the GPU node's x86-64 CPU
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Xarch_host", "-mavx2", "-Wall", "-Wno-unused-function",
-         "-I", os.path.join(HERE, "..", "include"), "-DNLX_GL_GENERATOR_SET=" + GEN_SET]
+         "-I", os.path.join(HERE, "..", "include"), "-DNLX_GL_GENERATOR_SET=" + GEN_SET] + os.environ.get("NLX_EXTRA_FLAGS", "").split()
 
 
 def _sources():

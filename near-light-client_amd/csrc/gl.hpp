@@ -72,7 +72,7 @@ GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) { return canon(reduce128_loos
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // 64x64 -> 128 product and Goldilocks reduction as two asm blocks with VCC carry chains
-// (20 instructions; hipcc's u64 code needs 29).  See gl32.hpp for the measurements behind this.
+// (16 instructions; hipcc's u64 code needs 29).  See gl32.hpp for the measurements behind this.
 __device__ __forceinline__ uint64_t mul_loose_asm(uint64_t a, uint64_t b) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
     const uint64_t t = (uint64_t)a0 * b0, m = (uint64_t)a0 * b1, x = (uint64_t)a1 * b1;
@@ -83,7 +83,8 @@ __device__ __forceinline__ uint64_t mul_loose_asm(uint64_t a, uint64_t b) {
         : [mid] "=&v"(mid), [x1] "=v"(x1)
         : [ah] "v"(a1), [bl] "v"(b0), [m] "v"(m), [xh] "v"((uint32_t)(x >> 32))
         : "vcc");
-    uint32_t r0, r1, w1, w2, w3, t0, t1;
+    // limbs w1..w3, then r = (w1:w0) - w3 [borrow -> -EPS]
+    uint32_t r0, r1, w1, w2, w3, t0;
     asm("v_add_co_u32 %[w1], vcc, %[th], %[m0]\n\t"
         "v_addc_co_u32 %[w2], vcc, %[x0], %[m1], vcc\n\t"
         "v_addc_co_u32 %[w3], vcc, 0, %[x1], vcc\n\t"
@@ -91,19 +92,23 @@ __device__ __forceinline__ uint64_t mul_loose_asm(uint64_t a, uint64_t b) {
         "v_subbrev_co_u32 %[r1], vcc, 0, %[w1], vcc\n\t"
         "v_cndmask_b32_e64 %[t0], 0, -1, vcc\n\t"
         "v_sub_co_u32 %[r0], vcc, %[r0], %[t0]\n\t"
-        "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc\n\t"
-        "v_sub_co_u32 %[t0], vcc, 0, %[w2]\n\t"
-        "v_subbrev_co_u32 %[t1], vcc, 0, %[w2], vcc\n\t"
-        "v_add_co_u32 %[r0], vcc, %[r0], %[t0]\n\t"
-        "v_addc_co_u32 %[r1], vcc, %[r1], %[t1], vcc\n\t"
-        "v_cndmask_b32_e64 %[t0], 0, -1, vcc\n\t"
-        "v_add_co_u32 %[r0], vcc, %[r0], %[t0]\n\t"
-        "v_addc_co_u32 %[r1], vcc, 0, %[r1], vcc"
-        : [r0] "=&v"(r0), [r1] "=&v"(r1), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [t0] "=&v"(t0)
         : [w0] "v"((uint32_t)t), [th] "v"((uint32_t)(t >> 32)), [m0] "v"((uint32_t)mid), [x0] "v"((uint32_t)x),
           [m1] "v"((uint32_t)(mid >> 32)), [x1] "v"(x1)
         : "vcc");
-    return ((uint64_t)r1 << 32) | r0;
+    // + w2 * EPS [carry -> +EPS]: ONE multiply-add (carry-out in VCC), carry -> mask, mask * 1 + r.  On gfx950 every
+    // VCC-chained add issues as slowly as a multiply (profiles/r02_valu_ubench.txt), so these three replace seven.
+    const uint64_t base = ((uint64_t)r1 << 32) | r0;
+    uint64_t r;
+    uint32_t tm;
+    asm("v_mad_u64_u32 %[r], vcc, %[w2], -1, %[base]\n\t"
+        "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
+        "v_mad_u64_u32 %[r], vcc, %[t], 1, %[r]"
+        : [r] "=&v"(r), [t] "=&v"(tm)
+        : [w2] "v"(w2), [base] "v"(base)
+        : "vcc");
+    return r;
 }
 #endif
 

@@ -1,11 +1,13 @@
 // Goldilocks arithmetic on 32-bit limb pairs with hand-placed carry chains (gfx950 inline asm).
 //
-// Measured on MI355X (tools/ubench): v_mad_u64_u32 issues at the same rate as every other
-// integer multiply (~4.7 cycles per wave-instruction) and plain 32-bit adds at ~2.9, so a field
-// multiply is bounded by its four 32x32->64 products plus the carry/borrow glue around them.
-// hipcc's u64 code spends ~25 glue instructions per multiply (zero-extending moves, 64-bit
-// compares, cndmask pairs); keeping elements as {lo, hi} u32 pairs and chaining carries through
-// VCC brings the whole multiply + reduction to 20 instructions.
+// Measured on MI355X (tools/ubench, profiles/r02_valu_ubench.txt): at full occupancy v_mad_u64_u32 issues at ~2.0 ns per
+// wave-instruction per SIMD like every other integer multiply - and so does every VCC-chained add / subtract / compare
+// (v_add_co_u32 + v_addc_co_u32: 1.99 ns each, v_cmp + v_cndmask: 1.82 ns); only carry-free ALU ops reach 1.17 ns.  A
+// field multiply therefore costs its INSTRUCTION COUNT x 2 ns, whatever the instructions are, and a multiply-add that
+// replaces several carry-chain instructions is a straight win: `r = base + w2 * (2^32 - 1)` is ONE v_mad_u64_u32 (its
+// carry-out lands in VCC) instead of four add / subtract-with-carry instructions, and `r += carry ? 2^32 - 1 : 0` is a
+// v_cndmask + one more v_mad_u64_u32 (mask * 1 + r) instead of three.  Multiply + reduction: 16 instructions (20 in
+// round 1, ~29 from hipcc's u64 code); the fold of an MDS accumulator pair: 5 (9 in round 1).
 #pragma once
 #include "gl.hpp"
 
@@ -18,27 +20,33 @@ struct F {
 __device__ __forceinline__ F from_u64(uint64_t x) { return F{(uint32_t)x, (uint32_t)(x >> 32)}; }
 __device__ __forceinline__ uint64_t to_u64(F x) { return ((uint64_t)x.hi << 32) | x.lo; }
 
+// base + w2 * EPS (mod p) -> loose.  2^64 = EPS (mod p): the multiply-add's carry out of 2^64 is worth EPS, and adding it
+// cannot carry again (base + w2 * EPS - 2^64 <= 2^64 - 2^33).  Three instructions: multiply-add, carry -> mask, mask * 1 + r.
+__device__ __forceinline__ F add_w2_eps(uint64_t base, uint32_t w2) {
+    uint64_t r;
+    uint32_t t;
+    asm("v_mad_u64_u32 %[r], vcc, %[w2], -1, %[base]\n\t"
+        "v_cndmask_b32_e64 %[t], 0, -1, vcc\n\t"
+        "v_mad_u64_u32 %[r], vcc, %[t], 1, %[r]"
+        : [r] "=&v"(r), [t] "=&v"(t)
+        : [w2] "v"(w2), [base] "v"(base)
+        : "vcc");
+    return from_u64(r);
+}
+
 // (w3:w2:w1:w0) mod p -> loose
 //   r = (w1:w0) - w3 [borrow -> -EPS] + (w2 * EPS) [carry -> +EPS]
 __device__ __forceinline__ F reduce128(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
-    F r;
-    uint32_t t0, t1;
+    uint32_t r0, r1, t0;
     asm("v_sub_co_u32 %[r0], vcc, %[w0], %[w3]\n\t"
         "v_subbrev_co_u32 %[r1], vcc, 0, %[w1], vcc\n\t"
         "v_cndmask_b32_e64 %[t0], 0, -1, vcc\n\t"
         "v_sub_co_u32 %[r0], vcc, %[r0], %[t0]\n\t"
-        "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc\n\t"
-        "v_sub_co_u32 %[t0], vcc, 0, %[w2]\n\t"
-        "v_subbrev_co_u32 %[t1], vcc, 0, %[w2], vcc\n\t"
-        "v_add_co_u32 %[r0], vcc, %[r0], %[t0]\n\t"
-        "v_addc_co_u32 %[r1], vcc, %[r1], %[t1], vcc\n\t"
-        "v_cndmask_b32_e64 %[t0], 0, -1, vcc\n\t"
-        "v_add_co_u32 %[r0], vcc, %[r0], %[t0]\n\t"
-        "v_addc_co_u32 %[r1], vcc, 0, %[r1], vcc"
-        : [r0] "=&v"(r.lo), [r1] "=&v"(r.hi), [t0] "=&v"(t0), [t1] "=&v"(t1)
-        : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3)
+        "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [t0] "=&v"(t0)
+        : [w0] "v"(w0), [w1] "v"(w1), [w3] "v"(w3)
         : "vcc");
-    return r;
+    return add_w2_eps(((uint64_t)r1 << 32) | r0, w2);
 }
 
 // loose * loose -> loose
@@ -54,10 +62,8 @@ __device__ __forceinline__ F mul(F a, F b) {
         : [mid] "=&v"(mid), [x1] "=v"(x1)
         : [ah] "v"(a.hi), [bl] "v"(b.lo), [m] "v"(m), [xh] "v"((uint32_t)(x >> 32))
         : "vcc");
-    // limbs w1..w3 and the reduction r = (w1:w0) - w3 [borrow -> -EPS] + w2*EPS [carry -> +EPS] in ONE
-    // block (the compiler pads every asm boundary with an s_nop)
-    F r;
-    uint32_t w1, w2, w3, t0, t1;
+    // limbs w1..w3, then (w1:w0) - w3 [borrow -> -EPS]; the + w2 * EPS [carry -> +EPS] half is add_w2_eps
+    uint32_t r0, r1, w1, w2, w3, t0;
     asm("v_add_co_u32 %[w1], vcc, %[th], %[m0]\n\t"
         "v_addc_co_u32 %[w2], vcc, %[x0], %[m1], vcc\n\t"
         "v_addc_co_u32 %[w3], vcc, 0, %[x1], vcc\n\t"
@@ -65,19 +71,12 @@ __device__ __forceinline__ F mul(F a, F b) {
         "v_subbrev_co_u32 %[r1], vcc, 0, %[w1], vcc\n\t"
         "v_cndmask_b32_e64 %[t0], 0, -1, vcc\n\t"
         "v_sub_co_u32 %[r0], vcc, %[r0], %[t0]\n\t"
-        "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc\n\t"
-        "v_sub_co_u32 %[t0], vcc, 0, %[w2]\n\t"
-        "v_subbrev_co_u32 %[t1], vcc, 0, %[w2], vcc\n\t"
-        "v_add_co_u32 %[r0], vcc, %[r0], %[t0]\n\t"
-        "v_addc_co_u32 %[r1], vcc, %[r1], %[t1], vcc\n\t"
-        "v_cndmask_b32_e64 %[t0], 0, -1, vcc\n\t"
-        "v_add_co_u32 %[r0], vcc, %[r0], %[t0]\n\t"
-        "v_addc_co_u32 %[r1], vcc, 0, %[r1], vcc"
-        : [r0] "=&v"(r.lo), [r1] "=&v"(r.hi), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [t0] "=&v"(t0)
         : [w0] "v"((uint32_t)t), [th] "v"((uint32_t)(t >> 32)), [m0] "v"((uint32_t)mid), [x0] "v"((uint32_t)x),
           [m1] "v"((uint32_t)(mid >> 32)), [x1] "v"(x1)
         : "vcc");
-    return r;
+    return add_w2_eps(((uint64_t)r1 << 32) | r0, w2);
 }
 
 // loose + canonical constant -> loose
@@ -127,19 +126,7 @@ __device__ __forceinline__ F fold_acc(uint64_t al, uint64_t ah) {
         : [al1] "v"((uint32_t)(al >> 32)), [ah0] "v"((uint32_t)ah), [ah1] "v"((uint32_t)(ah >> 32))
         : "vcc");
     // r = (w1:w0) + w2 * EPS, carry -> + EPS
-    F r;
-    uint32_t t0, t1;
-    asm("v_sub_co_u32 %[t0], vcc, 0, %[w2]\n\t"
-        "v_subbrev_co_u32 %[t1], vcc, 0, %[w2], vcc\n\t"
-        "v_add_co_u32 %[r0], vcc, %[w0], %[t0]\n\t"
-        "v_addc_co_u32 %[r1], vcc, %[w1], %[t1], vcc\n\t"
-        "v_cndmask_b32_e64 %[t0], 0, -1, vcc\n\t"
-        "v_add_co_u32 %[r0], vcc, %[r0], %[t0]\n\t"
-        "v_addc_co_u32 %[r1], vcc, 0, %[r1], vcc"
-        : [r0] "=&v"(r.lo), [r1] "=&v"(r.hi), [t0] "=&v"(t0), [t1] "=&v"(t1)
-        : [w0] "v"((uint32_t)al), [w1] "v"(w1), [w2] "v"(w2)
-        : "vcc");
-    return r;
+    return add_w2_eps(((uint64_t)w1 << 32) | (uint32_t)al, w2);
 }
 
 // Linear layer; `rc_next` (12 canonical constants, wave-uniform, or nullptr) is the NEXT round's

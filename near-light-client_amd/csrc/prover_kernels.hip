@@ -667,9 +667,15 @@ __device__ __forceinline__ void eval_gate(const GateDev& gd, const QuotientParam
 // by a host-built, cost-balanced item list (QuotientParams::work): all gates are evaluated at every point whatever their
 // selector says, so the split is the same for every tile and control flow stays wave-uniform.  The waves' partial sums meet
 // in LDS.  Sigma and Z columns are used once per point and are read straight from global memory.
-constexpr int QW = 8;  // waves per tile: 2 tiles x 8 waves per CU = 4 waves per SIMD
+#ifndef NLX_QW
+#define NLX_QW 8        // waves per tile: 2 tiles x 8 waves per CU = 4 waves per SIMD
+#endif
+#ifndef NLX_QMINW
+#define NLX_QMINW 4     // minimum waves per SIMD the register allocation must allow
+#endif
+constexpr int QW = NLX_QW;
 
-__global__ __launch_bounds__(64 * QW, 4) void k_quotient(QuotientParams p) {
+__global__ __launch_bounds__(64 * QW, NLX_QMINW) void k_quotient(QuotientParams p) {
     extern __shared__ uint64_t q_lds[];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned log_L = p.log_n + p.rate_bits;
