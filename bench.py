@@ -88,6 +88,8 @@ def parse():
                          "in-circuit cost of verifying the three STARK proofs), 16 for the others")
     ap.add_argument("--gate-mix", default="nearx", choices=["nearx", "basic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ntt-log-n", type=int, default=24)
+    ap.add_argument("--ntt-cols", type=int, default=16)
     ap.add_argument("--no-extra", action="store_true", help="sync workload: skip the plonky2-only 2^16 figures")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent proofs in flight per GPU (one context + stream + host thread each); the K "
@@ -930,6 +932,74 @@ def cpu_baseline_sync(args, nlx, st, sha256_result, sha512_result, gpu_seq_ms):
     return base, parity
 
 
+def run_ntt24(args, nlx, torch, rank, world, local, dist):
+    """BASELINE.json configs[4]'s transform (the 2^24-point NTT behind the recursive wrap, here over Goldilocks): a batch of
+    --ntt-cols columns x 2^--ntt-log-n points, resident in HBM, one forward NTT of the whole batch per step through
+    nlx_ntt_batch (natural order in and out).  With N ranks the columns are split over the ranks - independent
+    transforms, no collective (strong scaling); splitting ONE transform across GPUs (row-block four-step with an
+    all-to-all) is out of scope."""
+    import numpy as np
+    log_n, cols = args.ntt_log_n, args.ntt_cols
+    mine = [c for c in range(cols) if c % world == rank]
+    n = 1 << log_n
+    ctx = nlx.Context(local)
+    g = torch.Generator(device="cpu").manual_seed(0x6E6C78 + rank)
+    host = torch.randint(0, 2 ** 62, (max(len(mine), 1), n), generator=g, dtype=torch.int64)
+    data = host.to("cuda:%d" % local)
+    dll = nlx.lib.dll
+
+    def step():
+        if mine:
+            ctx.check(dll.nlx_ntt_batch(ctx.handle, data.data_ptr(), len(mine), log_n, 0, 1))
+    for _ in range(args.warmup):
+        step()
+    ctx.kernel_timing(True)
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(dist, torch)
+    dt = reduce_max(dist, torch, time.perf_counter() - t0)
+    kt, kr = ctx.kernel_stats("ntt_transform"), ctx.kernel_stats("ntt_reorder")
+    ctx.kernel_timing(False)
+    out = None
+    if rank == 0:
+        alg = 16.0 * n * cols          # SURVEY.md §8d: one read + one write of every element
+        ach = (kt[2] / kt[0]) / (kt[1] / kt[0] * 1e-3) / 1e9 if kt[0] else 0.0
+        out = {
+            "metric": "NTT 2^%d x %d columns: transforms of the whole batch per second (BASELINE config 5's transform size)" % (log_n, cols),
+            "value": args.steps / dt, "unit": "batch NTTs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
+            "config": {"workload": "forward NTT of %d columns x 2^%d points (natural order in and out), columns resident in HBM, "
+                                   "split over the ranks (no collective)" % (cols, log_n),
+                       "columns_per_rank": len(mine), "whole_call_GBps_algorithmic": alg / (dt / args.steps) / 1e9,
+                       "transform_ms_rank0": kt[1] / kt[0] if kt[0] else None, "reorder_ms_rank0": kr[1] / kr[0] if kr[0] else None,
+                       "parallelism": "columns x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_ntt_pass<DIF> x passes (ntt_transform)", "launches": kt[0],
+                         "avg_launch_ms": kt[1] / kt[0] if kt[0] else None, "alg_bytes_per_launch": kt[2] / kt[0] if kt[0] else None,
+                         "note": "a 2^24-point transform is three LDS passes (2^8 points per pass per workgroup): actual traffic is 3 x "
+                                 "the algorithmic 16 n bytes per column; the butterflies are integer-VALU work (DESIGN.md §4)"},
+            "cpu_baseline": None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle_py
+            cores = min(len(os.sched_getaffinity(0)), 16)
+            s_log = min(log_n, 20)
+            col = host[0, : 1 << s_log].numpy().view(np.uint64) % np.uint64(0xFFFFFFFF00000001)
+            tc = time.time()
+            ref = oracle_py.fft(col)
+            dtc = time.time() - tc
+            got = nlx.ntt(ctx, col.reshape(1, -1))[0]
+            out["cpu_baseline"] = {"value": 1.0 / (dtc * cols * 2.0 ** (log_n - s_log) * (log_n / s_log)), "unit": "batch NTTs/s", "cores": 1,
+                                   "kind": "port", "sample": "oracle radix-2 NTT of one 2^%d-point column in %.2f s on one core, scaled by "
+                                   "n log n and the %d columns; GPU output of the same column equal: %s" % (s_log, dtc, cols, bool(np.array_equal(ref, got)))}
+    ctx.close()
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -944,6 +1014,8 @@ def main():
         out = run_sync(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "outer":
         out = run_outer(args, nlx, torch, rank, world, local, dist)
+    elif args.workload == "ntt24":
+        out = run_ntt24(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "stark":
         out = run_stark(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "ed25519":

@@ -76,7 +76,8 @@ int32_t nlx_buf_download(nlx_buf* buf, size_t offset, void* dst, size_t bytes);
 int32_t nlx_ctx_memory(const nlx_ctx* ctx, size_t* reserved_bytes, size_t* in_use_bytes);
 int32_t nlx_ctx_trim(nlx_ctx* ctx);
 /* Per-kernel device timing for measurement (bench.py's roofline): when enabled, the library brackets
- * its main kernels ("intt", "lde", "hash_lde_leaves", "merkle_levels", "quotient", "fri_combine")
+ * its main kernels ("intt", "lde", "hash_lde_leaves", "merkle_levels", "quotient", "air_quotient", "fri_combine"; nlx_ntt_batch:
+ * "ntt_transform", "ntt_reorder")
  * with HIP events on the context's stream.  nlx_ctx_kernel_timing(ctx, x) also clears the samples. */
 int32_t nlx_ctx_kernel_timing(nlx_ctx* ctx, int enable);
 int32_t nlx_ctx_kernel_stats(nlx_ctx* ctx, const char* name, uint64_t* calls, double* total_ms, double* alg_bytes);

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void k_merkle_level(const uint64_t* __restrict
 }
 
 constexpr size_t MERKLE_WIDE_MAX_PARENTS = (size_t)1 << 14;
-void launch_merkle_level_wide(hipStream_t st, const uint64_t* children, uint64_t* parents, size_t n_parents);
+constexpr unsigned MERKLE_FUSED_MAX_LEVELS = 6;  // 2^6 children per block: 32 sixteen-lane groups on the first fused level
+void launch_merkle_fused(hipStream_t st, const uint64_t* children, size_t n_children, unsigned levels);
 
 // ---- host launchers (stream-ordered, no synchronisation) ----
 void launch_permute_batch(hipStream_t st, uint64_t* d_states, size_t n) {
@@ -112,10 +113,21 @@ const uint64_t* launch_merkle_levels(hipStream_t st, uint64_t* d_digests, size_t
     while (lvl > cap) {
         uint64_t* nxt = cur + lvl * 4;
         size_t half = lvl >> 1;
-        // below ~2^14 parents a level no longer fills the chip with one lane per permutation:
-        // switch to the 16-lanes-per-permutation kernel (latency ~1/5)
-        if (half <= MERKLE_WIDE_MAX_PARENTS) launch_merkle_level_wide(st, cur, nxt, half);
-        else hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, cur, nxt, half);
+        // below ~2^14 parents a level no longer fills the chip with one lane per permutation: switch to sixteen lanes per
+        // permutation (latency ~1/5), and - every such level being latency-bound - run up to six consecutive levels in
+        // ONE launch: a block owns a subtree of 2^K children and walks it up in LDS (round 1 launched every level
+        // separately: 11 launches of ~29 us for the top of a 2^19-leaf tree, now 2)
+        if (half <= MERKLE_WIDE_MAX_PARENTS) {
+            unsigned K = 0;
+            while (K < MERKLE_FUSED_MAX_LEVELS && (lvl >> K) > cap) K++;
+            launch_merkle_fused(st, cur, lvl, K);
+            for (unsigned s = 0; s < K; s++) {
+                cur += lvl * 4;
+                lvl >>= 1;
+            }
+            continue;
+        }
+        hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, cur, nxt, half);
         cur = nxt;
         lvl = half;
     }
@@ -235,17 +247,39 @@ __device__ __forceinline__ gl32::F permute_wide(gl32::F x, uint32_t j, volatile 
     return x;
 }
 
-// parents[i] = two_to_one(children[2i], children[2i+1]), one parent per 16 lanes
-__global__ __launch_bounds__(256) void k_merkle_level_wide(const uint64_t* __restrict__ children,
-                                                           uint64_t* __restrict__ parents, size_t n_parents) {
-    __shared__ uint64_t lds[WIDE_GROUPS_PER_BLOCK * 24];
+// K consecutive tree levels in one launch: block b owns the subtree over children [b 2^K, (b + 1) 2^K) of the level at
+// `children` (n_children digests, level-major array: the parent levels follow it back to back) and walks it up in LDS,
+// one parent per sixteen-lane group and level; every level is also written to its place in the digest array (Merkle
+// paths are read from it later).  2^K <= 2 * FUSED_GROUPS.
+constexpr unsigned FUSED_GROUPS = 32;  // 512 threads: two waves per SIMD on the first level, one from the second on
+
+__global__ __launch_bounds__(FUSED_GROUPS * 16) void k_merkle_fused(const uint64_t* __restrict__ children, uint64_t* __restrict__ parents0,
+                                                                   size_t n_children, unsigned K) {
+    __shared__ uint64_t slots[FUSED_GROUPS * 24];
+    __shared__ uint64_t lv[2][FUSED_GROUPS * 2 * 4];
     const uint32_t j = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const size_t i = (size_t)blockIdx.x * WIDE_GROUPS_PER_BLOCK + g;
-    const bool live = i < n_parents;
-    uint64_t v = 0;
-    if (live && j < 8) v = children[i * 8 + j];
-    gl32::F x = permute_wide(gl32::from_u64(v), j, lds + g * 24);
-    if (live && j < 4) parents[i * 4 + j] = gl::canon(gl32::to_u64(x));
+    const uint32_t n_own = 1u << K;
+    for (uint32_t i = threadIdx.x; i < n_own * 4; i += FUSED_GROUPS * 16) lv[0][i] = children[((size_t)blockIdx.x << K) * 4 + i];
+    __syncthreads();
+    uint64_t* outp = parents0;
+    size_t level_total = n_children;
+    for (unsigned s = 1; s <= K; s++) {
+        const uint32_t own = n_own >> s;  // this block's parents on the level
+        level_total >>= 1;
+        const uint64_t* src = lv[(s - 1) & 1];
+        uint64_t* dst = lv[s & 1];
+        if (g < own) {
+            const uint64_t v = j < 8 ? src[g * 8 + j] : 0;
+            const gl32::F x = permute_wide(gl32::from_u64(v), j, slots + g * 24);
+            if (j < 4) {
+                const uint64_t w = gl::canon(gl32::to_u64(x));
+                dst[g * 4 + j] = w;
+                outp[((size_t)blockIdx.x * own + g) * 4 + j] = w;
+            }
+        }
+        __syncthreads();
+        outp += level_total * 4;
+    }
 }
 
 // FRI layer leaves, one leaf per 16 lanes (see k_fri_leaves for the index maps)
@@ -317,9 +351,10 @@ void launch_fri_leaves_wide(hipStream_t st, const uint64_t* d_values, unsigned l
     else if (arity_bits == 2) hipLaunchKernelGGL(k_fri_leaves_wide<2>, dim3(blocks), dim3(256), 0, st, d_values, log_n, rate_bits, d_digests);
 }
 
-void launch_merkle_level_wide(hipStream_t st, const uint64_t* children, uint64_t* parents, size_t n_parents) {
-    hipLaunchKernelGGL(k_merkle_level_wide, dim3((unsigned)((n_parents + WIDE_GROUPS_PER_BLOCK - 1) / WIDE_GROUPS_PER_BLOCK)),
-                       dim3(256), 0, st, children, parents, n_parents);
+void launch_merkle_fused(hipStream_t st, const uint64_t* children, size_t n_children, unsigned levels) {
+    // children level at `children`, its parents right behind it (level-major digest array)
+    hipLaunchKernelGGL(k_merkle_fused, dim3((unsigned)(n_children >> levels)), dim3(FUSED_GROUPS * 16), 0, st, children,
+                       const_cast<uint64_t*>(children) + n_children * 4, n_children, levels);
 }
 
 }  // namespace nlx

@@ -19,6 +19,7 @@ void orc_hash_or_noop(const uint64_t* in, size_t len, uint64_t out[4]);
 void orc_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]);
 
 /* ---- plonky2_field::fft ---- values[i] = sum_j coeffs[j] w^(ij), natural order both sides */
+uint64_t orc_eval_poly_base(const uint64_t* coeffs, size_t n, uint64_t x);
 void orc_fft(uint64_t* a, unsigned log_n);
 void orc_ifft(uint64_t* a, unsigned log_n);
 void orc_coset_fft(uint64_t* a, unsigned log_n, uint64_t shift);

@@ -146,6 +146,15 @@ class Challenger:
         return int(dll().orc_ch_challenge(ctypes.byref(self.s)))
 
 
+def eval_poly(coeffs, x):
+    """Horner evaluation of base-field coefficients at a base-field point, in C (long polynomials)"""
+    c = _u64(coeffs)
+    d = dll()
+    d.orc_eval_poly_base.restype = ctypes.c_uint64
+    d.orc_eval_poly_base.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64]
+    return int(d.orc_eval_poly_base(c.ctypes.data, c.size, int(x) % P))
+
+
 def eval_poly_ext(coeffs, z):
     """Horner evaluation of base-field coefficients at z = (a, b) in F_p[X]/(X^2-7) (python ints)."""
     a, b = 0, 0

@@ -17,6 +17,13 @@ void orc_field_generators(uint64_t out[2]) {
     out[1] = GL_POW2_GEN;
 }
 
+/* PolynomialCoeffs::eval in the base field: Horner, coefficients in natural order */
+uint64_t orc_eval_poly_base(const uint64_t* coeffs, size_t n, uint64_t x) {
+    uint64_t acc = 0;
+    for (size_t i = n; i-- > 0;) acc = gl_add(gl_mul(acc, x), coeffs[i]);
+    return acc;
+}
+
 void orc_fft(uint64_t* a, unsigned log_n) {
     size_t n = (size_t)1 << log_n;
     for (size_t i = 0; i < n; i++) {

@@ -179,6 +179,24 @@ def test_ntt_2p24_three_passes(nlx, ctx):
     assert (f < np.uint64(P)).all()
 
 
+def test_ntt_2p24_sampled_against_horner(nlx, ctx, orc):
+    """BASELINE config 5 (2^24-point NTT, a batch of columns): a random sample of outputs of every column equals the
+    polynomial evaluated at w^k by the oracle's Horner loop (2^24 multiplications per sample), forward and coset."""
+    rng = np.random.default_rng(2424)
+    log_n, n_cols = 24, 4
+    a = rand_field(rng, (n_cols, 1 << log_n))
+    w = pow(POW2_GEN, 1 << (32 - log_n), P)
+    f = nlx.ntt(ctx, a)
+    fc = nlx.ntt(ctx, a[:2], coset_shift=GEN)
+    ks = [0, 1, (1 << log_n) - 1, 1 << 23] + [int(k) for k in rng.integers(0, 1 << log_n, 4)]
+    for c in range(n_cols):
+        for k in ks[c::2] if c else ks:                      # every sample on column 0, half of them on the others
+            assert int(f[c, k]) == orc.eval_poly(a[c], pow(w, k, P)), (c, k)
+    for k in ks[:5]:
+        assert int(fc[1, k]) == orc.eval_poly(a[1], GEN * pow(w, k, P) % P), k
+    assert np.array_equal(nlx.ntt(ctx, fc, inverse=True, coset_shift=GEN), a[:2])
+
+
 def test_field_core_edge_values(nlx, ctx):
     """GoldilocksField core (incl. the hand-written carry-chain multiply) on every pair of edge values:
     0, 1, 2^32 +-1, p +-1, 2^64-1, ... plus random pairs, against Python big integers."""
