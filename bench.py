@@ -1025,7 +1025,16 @@ def main():
     else:
         from importlib import import_module
         mr = import_module("nlx_amd.mapreduce")
-        out = mr.bench_verify128(args, nlx, torch, rank, world, local, dist)
+        verify_outer = None
+        if not args.no_cpu_baseline:
+            def verify_outer(syn, proof):   # the checker (test oracle's plonky2 verifier) on the job's outer proof
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle_py
+                oc = oracle_py.Circuit.from_synthetic(syn)
+                ok = oc.verify(proof) == 1
+                oc.close()
+                return ok
+        out = mr.bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer)
     if rank == 0:
         if os.environ.get("NLX_BENCH_REHEARSAL") == "1":
             out["config"]["rehearsal"] = "all ranks share GPU 0, gloo backend: NOT a scaling measurement"

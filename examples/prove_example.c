@@ -2,7 +2,7 @@
  * GPU 0, prove it again and check the two proofs are byte-identical.  This is what a cgo / Rust FFI
  * caller does, minus the language binding.
  *
- *   gcc -O2 -I include examples/prove_example.c -L near-light-client_amd -lnlx \
+ *   gcc -O2 -I include examples/prove_example.c -L near-light-client_amd -lnlx -lnlx_synth \
  *       -Wl,-rpath,$PWD/near-light-client_amd -o /tmp/prove_example && /tmp/prove_example 12
  */
 #include <stdint.h>
@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "nlx.h"
+#include "nlx_synth.h"
 
 #define CHECK(call)                                                                        \
     do {                                                                                   \

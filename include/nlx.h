@@ -60,6 +60,15 @@ const char* nlx_last_error(const nlx_ctx* ctx);
  * NULL restores the context's own stream.  The caller keeps ownership of the stream. */
 int32_t nlx_ctx_set_stream(nlx_ctx* ctx, void* hip_stream);
 int32_t nlx_ctx_synchronize(nlx_ctx* ctx);
+/* Scheduling priority of the context's own stream: high = 1 puts its kernels ahead of other streams' when workgroup slots
+ * free up.  For small latency-bound proofs (the curta STARKs of a Sync step) sharing a GPU with a large throughput-bound one
+ * (the outer proof): the short kernels no longer queue behind the long ones.  Call it before queuing work. */
+int32_t nlx_ctx_set_priority(nlx_ctx* ctx, int high);
+/* Restrict the context's own stream to a subset of the device's compute units (bit i of the mask = CU i; MI355X has 256).
+ * Two contexts with disjoint masks partition the chip: a chain of short latency-bound kernels (a small STARK) then runs
+ * beside a long throughput-bound proof instead of queueing behind its millisecond-long workgroups.  Call it before queuing
+ * work; a later nlx_ctx_set_priority undoes it. */
+int32_t nlx_ctx_set_cu_mask(nlx_ctx* ctx, const uint32_t* mask, uint32_t n_words);
 /* Device buffers for callers without HIP bindings of their own (SURVEY.md §8b `nlx_buf`): every entry point that
  * takes a "host or device" pointer accepts nlx_buf_device_ptr(buf) (+ an offset).  A buffer belongs to its context
  * and must be destroyed before it; upload / download are synchronous. */
@@ -300,31 +309,6 @@ int32_t nlx_prove_stage_times(const nlx_circuit* c, uint32_t* n_stages, const ch
  * at `pos` has at least `bits` leading zero bits in output word 7. */
 int32_t nlx_pow_grind(nlx_ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t* nonce_out);
 
-/* ---- synthetic nearx-shaped workload (inputs only) ---- */
-typedef struct {
-    uint32_t log_n;
-    uint32_t num_public_inputs;
-    uint32_t pct_poseidon;    /* share of rows (percent) that are PoseidonGate rows */
-    uint32_t pct_arithmetic;
-    uint32_t pct_base_sum;
-    uint32_t pct_constant;    /* remaining rows are NoopGate */
-    uint64_t seed;
-    uint32_t pct_extension;   /* rows split evenly over ArithmeticExtension / MulExtension / Reducing / ReducingExtension */
-    uint32_t pct_misc;        /* rows split evenly over PoseidonMds / Exponentiation / CosetInterpolation / RandomAccess */
-    uint32_t pct_u32;         /* rows split evenly over U32AddMany / U32Arithmetic / U32Subtraction / U32RangeCheck / Comparison */
-    uint32_t wide_comparison; /* 1: ComparisonGate { num_bits 25, num_chunks 25 } (132 constraints, the widest gate) instead of { 32, 16 } */
-} nlx_synth_params;
-/* number of gates / selector polynomials the generator will emit for these parameters */
-void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_selectors);
-/* Fills host buffers: gates[n_gates], k_is[80], constants[(n_selectors+2) x n], sigmas[80 x n],
- * wires[135 x n], public_inputs[num_public_inputs].  The witness satisfies every constraint. */
-int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint64_t* k_is, uint64_t* constants,
-                          uint64_t* sigmas, uint64_t* wires, uint64_t* public_inputs);
-/* Re-target a generated witness (host buffer, 135 x n column-major) to other public inputs: rewrites the
- * PublicInputGate row so the witness stays satisfying.  Used by the map-reduce workload, where a reduce
- * job's public inputs are its children's digests. */
-int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint64_t* public_inputs, uint32_t count);
-
 /* ---- a12: starky-style STARK prover ----
  * Replaces starky::prover::prove / compute_quotient_polys / StarkOpeningSet::new / Stark::fri_instance -
  * the public ancestor of the un-vendored starkyx (curta) prover that plonky2x runs for nearx's
@@ -504,11 +488,6 @@ int32_t nlx_sha512_trace(nlx_ctx* ctx, const uint64_t* blocks, const uint8_t* is
  * (low, high) halves: 33 elements on a block's first row, 16 on its last). */
 int32_t nlx_sha512_bind_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t log_blocks, const uint64_t gamma[2],
                               uint64_t* acc_out, uint64_t total_out[2]);
-/* Synthetic wide-AIR witness (inputs only): n_cols (multiple of 4) x n column-major host buffer, k1 = the
- * n_cols/4 per-group constants of the AIR, public_inputs[2] = first-row values of columns 0 and 1. */
-int32_t nlx_synth_stark_trace(uint32_t n_cols, uint32_t log_n, uint64_t seed, const uint64_t* k1, uint64_t* trace,
-                              uint64_t* public_inputs);
-
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,11 @@ if not os.path.exists(LIB_PATH):
         "(or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
 
 _dll = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+# the workload generator (synthetic circuits / witnesses - inputs only, include/nlx_synth.h) lives in its own library
+SYNTH_LIB_PATH = os.path.join(_HERE, os.path.basename(LIB_PATH).replace("libnlx", "libnlx_synth", 1))
+if not os.path.exists(SYNTH_LIB_PATH):
+    raise ImportError("nlx_amd: %s not found. Build it with `python near-light-client_amd/build.py`." % SYNTH_LIB_PATH)
+_synth_dll = ctypes.CDLL(SYNTH_LIB_PATH)
 
 u64p = ctypes.POINTER(ctypes.c_uint64)
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)
@@ -41,6 +46,8 @@ SIGNATURES = {
     "nlx_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "nlx_ctx_set_stream": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_ctx_synchronize": (ctypes.c_int32, [ctypes.c_void_p]),
+    "nlx_ctx_set_priority": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int]),
+    "nlx_ctx_set_cu_mask": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32]),
     "nlx_buf_create": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_size_t, c_void_pp]),
     "nlx_buf_destroy": (None, [ctypes.c_void_p]),
     "nlx_buf_device_ptr": (ctypes.c_void_p, [ctypes.c_void_p]),
@@ -125,6 +132,10 @@ SIGNATURES = {
                                                ctypes.c_void_p]),
     "nlx_sha512_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
                                           ctypes.c_void_p, ctypes.c_void_p]),
+}
+
+# include/nlx_synth.h (libnlx_synth.so)
+SYNTH_SIGNATURES = {
     "nlx_synth_stark_trace": (ctypes.c_int32, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_synth_shape": (None, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
@@ -132,12 +143,14 @@ SIGNATURES = {
     "nlx_synth_set_public_inputs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]),
 }
 
-for _name, (_res, _args) in SIGNATURES.items():
-    _fn = getattr(_dll, _name)  # AttributeError here = ABI mismatch: fail at import
-    _fn.restype = _res
-    _fn.argtypes = _args
+for _lib, _sigs in ((_dll, SIGNATURES), (_synth_dll, SYNTH_SIGNATURES)):
+    for _name, (_res, _args) in _sigs.items():
+        _fn = getattr(_lib, _name)  # AttributeError here = ABI mismatch: fail at import
+        _fn.restype = _res
+        _fn.argtypes = _args
 
 dll = _dll
+synth_dll = _synth_dll
 
 
 class NlxError(RuntimeError):
@@ -242,6 +255,18 @@ class Context:
 
     def synchronize(self):
         self.check(dll.nlx_ctx_synchronize(self.handle))
+
+    def set_cu_mask(self, cus):
+        """run this context's stream on the given compute units only (iterable of CU indices; nlx_ctx_set_cu_mask)"""
+        words = [0] * 8
+        for i in cus:
+            words[i // 32] |= 1 << (i % 32)
+        arr = (ctypes.c_uint32 * 8)(*words)
+        self.check(dll.nlx_ctx_set_cu_mask(self.handle, arr, 8))
+
+    def set_priority(self, high=True):
+        """scheduling priority of the context's stream (nlx_ctx_set_priority); call before queuing work"""
+        self.check(dll.nlx_ctx_set_priority(self.handle, 1 if high else 0))
 
     def set_stream(self, hip_stream):
         self.check(dll.nlx_ctx_set_stream(self.handle, hip_stream))

@@ -24,6 +24,10 @@ if VARIANT:
     _SUFFIX += "_" + VARIANT
 OBJ = os.path.join(CSRC, ".obj" + _SUFFIX)
 LIB = os.path.join(HERE, "libnlx%s.so" % _SUFFIX)
+# workload generation (synthetic circuits / witnesses: inputs for tests, examples and bench.py) is NOT part of the product
+# library: csrc/synth.cpp -> libnlx_synth.so (host C++ only; include/nlx_synth.h)
+SYNTH_SOURCES = ("synth.cpp",)
+SYNTH_LIB = os.path.join(HERE, "libnlx_synth%s.so" % _SUFFIX)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 # -Xarch_host -mavx2: the host side of the library (transcript hashing, FRI bookkeeping) runs on the GPU node's x86-64 CPU
@@ -60,23 +64,24 @@ def _compile(src, verbose):
 def build_lib(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hm = _headers_mtime()
-    todo, objs = [], []
+    todo, objs, synth_objs = [], [], []
     for src in _sources():
         obj = os.path.join(OBJ, src + ".o")
-        objs.append(obj)
+        (synth_objs if src in SYNTH_SOURCES else objs).append(obj)
         sm = max(os.path.getmtime(os.path.join(CSRC, src)), hm)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < sm:
             todo.append(src)
     if todo:
         with ThreadPoolExecutor(max_workers=min(6, len(todo))) as ex:
             list(ex.map(lambda s: _compile(s, verbose), todo))
-    if todo or not os.path.exists(LIB):
-        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    for lib, members in ((LIB, objs), (SYNTH_LIB, synth_objs)):
+        if todo or not os.path.exists(lib):
+            cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + members
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     return LIB
 
 

@@ -215,6 +215,36 @@ int32_t nlx_ctx_create(int device, nlx_ctx** out) {
     return NLX_OK;
 }
 
+int32_t nlx_ctx_set_priority(nlx_ctx* c, int high) {
+    if (!c) return NLX_E_INVAL;
+    (void)hipSetDevice(c->device);
+    if (c->stream != c->own_stream) return c->fail(NLX_E_INVAL, "the context runs on a caller-provided stream (nlx_ctx_set_stream)");
+    NLX_HIP(c, hipStreamSynchronize(c->own_stream));
+    int least = 0, greatest = 0;
+    NLX_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t s = nullptr;
+    NLX_HIP(c, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high ? greatest : least));
+    (void)hipStreamDestroy(c->own_stream);
+    c->own_stream = c->stream = s;
+    return NLX_OK;
+}
+
+int32_t nlx_ctx_set_cu_mask(nlx_ctx* c, const uint32_t* mask, uint32_t n_words) {
+    if (!c) return NLX_E_INVAL;
+    if (!mask || n_words == 0 || n_words > 32) return c->fail(NLX_E_INVAL, "CU mask: 1..32 words");
+    uint32_t any = 0;
+    for (uint32_t i = 0; i < n_words; i++) any |= mask[i];
+    if (!any) return c->fail(NLX_E_INVAL, "CU mask selects no compute unit");
+    (void)hipSetDevice(c->device);
+    if (c->stream != c->own_stream) return c->fail(NLX_E_INVAL, "the context runs on a caller-provided stream (nlx_ctx_set_stream)");
+    NLX_HIP(c, hipStreamSynchronize(c->own_stream));
+    hipStream_t s = nullptr;
+    NLX_HIP(c, hipExtStreamCreateWithCUMask(&s, n_words, mask));
+    (void)hipStreamDestroy(c->own_stream);
+    c->own_stream = c->stream = s;
+    return NLX_OK;
+}
+
 void nlx_ctx_destroy(nlx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);

@@ -13,7 +13,7 @@
 #include <cstring>
 #include <numeric>
 #include <vector>
-#include "../../include/nlx.h"
+#include "../../include/nlx_synth.h"
 #include "gl.hpp"
 #include "poseidon.hpp"
 #include "poseidon_fast_constants.inc"

@@ -9,7 +9,7 @@ import ctypes
 
 import numpy as np
 
-from ._lib import dll, ptr, NlxError
+from ._lib import dll, synth_dll, ptr, NlxError
 
 (GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_BASE_SUM, GATE_POSEIDON, GATE_ARITHMETIC_EXT,
  GATE_MUL_EXT, GATE_REDUCING, GATE_REDUCING_EXT, GATE_POSEIDON_MDS, GATE_EXPONENTIATION, GATE_RANDOM_ACCESS,
@@ -74,7 +74,7 @@ class SyntheticCircuit:
         sp = SynthParams(log_n, num_public_inputs, pct_poseidon, pct_arithmetic, pct_base_sum, pct_constant, seed,
                          pct_extension, pct_misc, pct_u32, 1 if wide_comparison else 0)
         ng, ns = ctypes.c_uint32(), ctypes.c_uint32()
-        dll.nlx_synth_shape(ctypes.byref(sp), ctypes.byref(ng), ctypes.byref(ns))
+        synth_dll.nlx_synth_shape(ctypes.byref(sp), ctypes.byref(ng), ctypes.byref(ns))
         n = 1 << log_n
         self.num_selectors, self.num_gates = ns.value, ng.value
         self.gates = (GateDesc * ng.value)()
@@ -83,7 +83,7 @@ class SyntheticCircuit:
         self.sigmas = np.zeros((80, n), dtype=np.uint64)
         self.wires = np.zeros((135, n), dtype=np.uint64)
         self.public_inputs = np.zeros(max(num_public_inputs, 1), dtype=np.uint64)[:num_public_inputs]
-        rc = dll.nlx_synth_circuit(ctypes.byref(sp), self.gates, ptr(self.k_is), ptr(self.constants),
+        rc = synth_dll.nlx_synth_circuit(ctypes.byref(sp), self.gates, ptr(self.k_is), ptr(self.constants),
                                    ptr(self.sigmas), ptr(self.wires), ptr(self.public_inputs) if num_public_inputs else None)
         if rc != 0:
             raise NlxError(rc, "nlx_synth_circuit failed")
@@ -93,7 +93,7 @@ class SyntheticCircuit:
         pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         if pis.size != self.public_inputs.size:
             raise ValueError("the number of public inputs is fixed by the circuit")
-        rc = dll.nlx_synth_set_public_inputs(ptr(self.wires), self.log_n, ptr(pis), pis.size)
+        rc = synth_dll.nlx_synth_set_public_inputs(ptr(self.wires), self.log_n, ptr(pis), pis.size)
         if rc != 0:
             raise NlxError(rc, "nlx_synth_set_public_inputs failed")
         self.public_inputs = pis.copy()

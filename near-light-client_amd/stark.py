@@ -15,7 +15,7 @@ import ctypes
 
 import numpy as np
 
-from ._lib import dll, ptr, NlxError
+from ._lib import dll, synth_dll, ptr, NlxError
 
 P = 0xFFFFFFFF00000001
 (AIR_LOCAL, AIR_NEXT, AIR_PUBLIC, AIR_CONST, AIR_ADD, AIR_SUB, AIR_MUL, AIR_EMIT_TRANSITION, AIR_EMIT_FIRST,
@@ -693,7 +693,7 @@ def wide_trace(air, degree_bits, seed=1):
     """Satisfying witness of wide_air (generated by the native workload generator, nlx_synth_stark_trace)."""
     t = np.zeros((air.n_cols, 1 << degree_bits), dtype=np.uint64)
     pis = np.zeros(2, dtype=np.uint64)
-    rc = dll.nlx_synth_stark_trace(air.n_cols, degree_bits, seed, ptr(air.k1), ptr(t), ptr(pis))
+    rc = synth_dll.nlx_synth_stark_trace(air.n_cols, degree_bits, seed, ptr(air.k1), ptr(t), ptr(pis))
     if rc != 0:
         raise NlxError(rc, "nlx_synth_stark_trace")
     return t, pis

@@ -8,22 +8,30 @@ import pytest
 from conftest import ROOT
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "nlx.h")).read()
+def _declared_symbols(header="nlx.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(nlx_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_symbols_exported(nlx):
+    """include/nlx.h <-> libnlx.so (the product), include/nlx_synth.h <-> libnlx_synth.so (workload generation only)"""
     dll = ctypes.CDLL(os.path.join(ROOT, "near-light-client_amd", "libnlx.so"))
     names = _declared_symbols()
-    assert len(names) >= 20
+    assert len(names) >= 60
     for name in names:
         assert hasattr(dll, name), "libnlx.so does not export %s" % name
+    synth = ctypes.CDLL(os.path.join(ROOT, "near-light-client_amd", "libnlx_synth.so"))
+    synth_names = _declared_symbols("nlx_synth.h")
+    assert len(synth_names) == 4 and all(n.startswith("nlx_synth_") for n in synth_names)
+    for name in synth_names:
+        assert hasattr(synth, name), "libnlx_synth.so does not export %s" % name
+        assert not hasattr(dll, name), "the product library still carries the workload generator (%s)" % name
 
 
 def test_python_binding_covers_header(nlx):
     assert sorted(nlx.lib.SIGNATURES) == _declared_symbols()
+    assert sorted(nlx.lib.SYNTH_SIGNATURES) == _declared_symbols("nlx_synth.h")
 
 
 def test_version_and_strerror(nlx):

@@ -13,7 +13,8 @@ def _build(tmp_path, name="prove_example"):
     exe = str(tmp_path / name)
     lib_dir = os.path.join(ROOT, "near-light-client_amd")
     cmd = ["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", name + ".c"), "-L", lib_dir, "-lnlx" + GOLDEN_SUFFIX, "-Wl,-rpath," + lib_dir, "-o", exe]
+           os.path.join(ROOT, "examples", name + ".c"), "-L", lib_dir, "-lnlx" + GOLDEN_SUFFIX, "-lnlx_synth" + GOLDEN_SUFFIX,
+           "-Wl,-rpath," + lib_dir, "-o", exe]
     subprocess.run(cmd, check=True, capture_output=True)
     return exe
 

@@ -230,8 +230,8 @@ def test_stark_abi_rejects_null(nlx):
     k1 = np.ones(1, dtype=np.uint64)
     t = np.zeros((4, 8), dtype=np.uint64)
     pis = np.zeros(2, dtype=np.uint64)
-    assert d.nlx_synth_stark_trace(3, 3, 1, k1.ctypes.data, t.ctypes.data, pis.ctypes.data) != 0  # n_cols % 4
-    assert d.nlx_synth_stark_trace(4, 3, 1, k1.ctypes.data, t.ctypes.data, pis.ctypes.data) == 0
+    assert nlx.lib.synth_dll.nlx_synth_stark_trace(3, 3, 1, k1.ctypes.data, t.ctypes.data, pis.ctypes.data) != 0  # n_cols % 4
+    assert nlx.lib.synth_dll.nlx_synth_stark_trace(4, 3, 1, k1.ctypes.data, t.ctypes.data, pis.ctypes.data) == 0
 
 
 def test_air_fused_forms(nlx):
