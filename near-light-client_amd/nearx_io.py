@@ -168,3 +168,34 @@ def inclusion_proof_verify(head_block_root, proof):
     outcome_verified = outcome_root == b58decode32(proof["block_header_lite"]["inner_lite"]["outcome_root"])
     block_verified = compute_root_from_path(proof["block_proof"], block_hash) == head_block_root
     return block_hash_matches and outcome_verified and block_verified
+
+
+def inclusion_proof_sha256_messages(proof):
+    """Every SHA-256 preimage `Verify::verify` hashes for ONE transaction / receipt inclusion proof, in evaluation order
+    (nearx/src/builder.rs:344-363 -> nearx/src/merkle.rs:17-51 `NearMerkleTree::get_root` + `HeaderVariable::hash`,
+    each through `curta_sha256`): the proven block's header hash (3), the outcome's hashes, the outcome-root chain and -
+    last, so that its digest is the SHA-256 STARK's public output - the block-proof chain, whose final digest must be the
+    trusted head's `block_merkle_root`.  Returns (messages, dict(block_hash, outcome_root, block_root)) with the values
+    the circuit compares (what `inclusion_proof_verify` checks)."""
+    msgs = []
+
+    def sha(b):
+        msgs.append(bytes(b))
+        return _sha(b)
+
+    def root_from_path(path, item_hash):
+        h = item_hash
+        for uncle in path:
+            u = b58decode32(uncle["hash"])
+            h = sha(u + h) if uncle["direction"] == "Left" else sha(h + u)
+        return h
+    for m in header_hash_preimages(proof["block_header_lite"]):
+        block_hash = sha(m)
+    op = proof["outcome_proof"]
+    hs = [b58decode32(op["id"]), sha(_borsh_partial_outcome(op["outcome"]))]
+    hs += [sha(log.encode()) for log in op["outcome"]["logs"]]
+    outcome_hash = sha(len(hs).to_bytes(4, "little") + b"".join(hs))
+    shard_root = root_from_path(op["proof"], outcome_hash)
+    outcome_root = root_from_path(proof["outcome_root_proof"], sha(shard_root))
+    block_root = root_from_path(proof["block_proof"], block_hash)
+    return msgs, {"block_hash": block_hash, "outcome_root": outcome_root, "block_root": block_root}

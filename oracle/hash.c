@@ -11,6 +11,7 @@
  */
 #include "oracle.h"
 #include "poseidon_constants.h"
+#include "poseidon_fast_constants.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -46,7 +47,67 @@ static void mds_layer(uint64_t s[12]) {
     for (int r = 0; r < 12; r++) s[r] = gl_reduce128((u128)al[r] + ((u128)ah[r] << 32));
 }
 
+static const uint64_t FAST_FIRST[12] = NLX_POSEIDON_FAST_FIRST_RC_INIT;
+static const uint64_t FAST_RC[22] = NLX_POSEIDON_FAST_RC_INIT;
+static const uint64_t FAST_VS[22][11] = NLX_POSEIDON_FAST_VS_INIT;
+static const uint64_t FAST_W[22][11] = NLX_POSEIDON_FAST_W_HATS_INIT;
+static const uint64_t FAST_INIT[11][11] = NLX_POSEIDON_FAST_INITIAL_MATRIX_INIT;
+
+/* sum of <= 12 products of canonical elements, reduced once (each product < 2^128 / 16 is not guaranteed, so the sum is
+ * kept as two 128-bit halves: low 64 bits and the rest) */
+static inline uint64_t dot_reduce(const uint64_t* a, const uint64_t* b, int n, uint64_t acc0) {
+    u128 lo = acc0, hi = 0;
+    for (int i = 0; i < n; i++) {
+        u128 p = (u128)a[i] * b[i];
+        lo += (uint64_t)p;
+        hi += (uint64_t)(p >> 64);
+    }
+    /* value = lo + hi * 2^64 with lo < 2^68, hi < 2^68: fold hi through 2^64 = 2^32 - 1 (mod p) */
+    uint64_t r = gl_reduce128(lo);
+    uint64_t h = gl_reduce128(hi);
+    return gl_add(r, gl_mul(h, GL_EPS));
+}
+
+/* plonky2::hash::poseidon::Poseidon::poseidon - the schedule the Rust prover actually runs: 4 full rounds, the 22 partial
+ * rounds in their "fast" form (partial_first_constant_layer, mds_partial_layer_init, then per round one S-box, one constant
+ * and mds_partial_layer_fast: a 12-term dot product and a rank-one update), 4 full rounds.  Same function as
+ * poseidon_naive (tests/test_oracle_golden.py checks fast == naive on the known-answer vectors and random states).
+ * Measured here (orc_poseidon_chain, one 2.1 GHz Xeon core): 8.1 us per permutation against 7.7 us for the naive
+ * schedule - in scalar C the fast form's 23 full 64 x 64 products per partial round cost what the naive layer's 144
+ * small-constant products (which the compiler vectorises) cost; upstream's advantage comes from its AVX2 / NEON kernels. */
 void orc_poseidon_permute(uint64_t s[12]) {
+    int rc = 0;
+    for (int round = 0; round < 4; round++) {
+        for (int i = 0; i < 12; i++) s[i] = sbox7(gl_add(s[i], RC[rc++]));
+        mds_layer(s);
+    }
+    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], FAST_FIRST[i]);
+    {
+        uint64_t res[12];
+        res[0] = s[0];
+        for (int c = 1; c < 12; c++) {
+            uint64_t col[11];
+            for (int r = 1; r < 12; r++) col[r - 1] = FAST_INIT[r - 1][c - 1];
+            res[c] = dot_reduce(s + 1, col, 11, 0);
+        }
+        memcpy(s, res, sizeof res);
+    }
+    for (int r = 0; r < 22; r++) {
+        uint64_t s0 = sbox7(s[0]);
+        if (r < 21) s0 = gl_add(s0, FAST_RC[r]);
+        const uint64_t d = dot_reduce(s + 1, FAST_W[r], 11, 0);
+        for (int i = 1; i < 12; i++) s[i] = gl_add(s[i], gl_mul(s0, FAST_VS[r][i - 1]));
+        s[0] = gl_add(d, gl_mul(s0, MDS_CIRC[0] + MDS_DIAG[0]));
+    }
+    rc = 26 * 12;
+    for (int round = 0; round < 4; round++) {
+        for (int i = 0; i < 12; i++) s[i] = sbox7(gl_add(s[i], RC[rc++]));
+        mds_layer(s);
+    }
+}
+
+/* Poseidon::poseidon_naive: add all 12 constants, S-box on all lanes (full rounds) or lane 0 (partial rounds), full MDS */
+void orc_poseidon_permute_naive(uint64_t s[12]) {
     int rc = 0;
     for (int round = 0; round < 30; round++) {
         for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], RC[rc++]);
@@ -57,6 +118,16 @@ void orc_poseidon_permute(uint64_t s[12]) {
         }
         mds_layer(s);
     }
+}
+
+/* n chained permutations of one state (timing aid for the cpu_baseline notes; returns a checksum) */
+uint64_t orc_poseidon_chain(uint64_t n, int naive) {
+    uint64_t s[12] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
+    for (uint64_t i = 0; i < n; i++) {
+        if (naive) orc_poseidon_permute_naive(s);
+        else orc_poseidon_permute(s);
+    }
+    return s[0] ^ s[7];
 }
 
 /* hashing.rs hash_n_to_m_no_pad with m = 4: overwrite-mode absorb, rate 8, no padding. */

@@ -13,7 +13,9 @@ extern "C" {
 void orc_field_generators(uint64_t out[2]);
 
 /* ---- plonky2::hash::poseidon (Poseidon::poseidon_naive schedule), hashing.rs ---- */
-void orc_poseidon_permute(uint64_t state[12]);
+void orc_poseidon_permute(uint64_t state[12]);        /* Poseidon::poseidon (fast partial rounds) */
+void orc_poseidon_permute_naive(uint64_t state[12]);  /* Poseidon::poseidon_naive */
+uint64_t orc_poseidon_chain(uint64_t n, int naive);
 void orc_hash_no_pad(const uint64_t* in, size_t len, uint64_t out[4]);
 void orc_hash_or_noop(const uint64_t* in, size_t len, uint64_t out[4]);
 void orc_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]);

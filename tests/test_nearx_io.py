@@ -5,6 +5,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 
@@ -90,3 +91,49 @@ def test_inclusion_proof_blackbox_fixture(nlx):
     assert io.inclusion_proof_verify(b"\x00" * 32, proof) is False
     # the header of the proven block hashes to the block hash the outcome proof names
     assert io.header_hash(proof["block_header_lite"]) == io.b58decode32(proof["outcome_proof"]["block_hash"])
+
+
+def test_inclusion_proof_sha256_messages_reproduce_the_check(nlx):
+    """the SHA-256 work list of one inclusion proof (what a Verify map job hands to curta_sha256): hashing the messages
+    in order reproduces every value `inclusion_proof_verify` compares, for both of the reference's proof fixtures"""
+    import hashlib
+    io = _io(nlx)
+    for name, root in (("old.json", _b58_any(io, BLOCK_MERKLE_ROOT)), ("new.json", None)):
+        proof = json.load(open(os.path.join(NEAR, name)))
+        msgs, vals = io.inclusion_proof_sha256_messages(proof)
+        assert len(msgs) == 3 + 1 + len(proof["outcome_proof"]["outcome"]["logs"]) + 1 + len(proof["outcome_proof"]["proof"]) \
+            + 1 + len(proof["outcome_root_proof"]) + len(proof["block_proof"])
+        assert hashlib.sha256(msgs[2]).digest() == vals["block_hash"] == io.b58decode32(proof["outcome_proof"]["block_hash"])
+        assert vals["outcome_root"] == io.b58decode32(proof["block_header_lite"]["inner_lite"]["outcome_root"])
+        assert hashlib.sha256(msgs[-1]).digest() == vals["block_root"]
+        if root is not None:
+            assert vals["block_root"] == root and io.inclusion_proof_verify(root, proof)
+        else:
+            assert io.inclusion_proof_verify(vals["block_root"], proof)
+        # a chain: every path message contains the digest of the message that produced its child
+        assert hashlib.sha256(msgs[0]).digest() == msgs[1][:32]
+
+
+@pytest.mark.gpu
+def test_verify_side_sha256_stark_from_the_proof_fixtures(nlx, ctx, orc):
+    """Row f.2: the SHA-256 work of a Verify map job on REAL inputs - the two inclusion proofs of the reference's fixtures
+    (fixtures/old.json, new.json) - proved in one GPU STARK whose public digest is the block Merkle root the last proof
+    climbs to (old.json: the literal the reference's own test pins, nearx/src/builder.rs:642); the oracle verifier accepts
+    it and the round value is the fingerprint of exactly these messages and digests."""
+    import struct
+    io = _io(nlx)
+    SA = nlx.sha256_air
+    msgs = []
+    for name in ("new.json", "old.json"):
+        m, vals = io.inclusion_proof_sha256_messages(json.load(open(os.path.join(NEAR, name))))
+        msgs += m
+    n_blocks = sum(len(SA.pad_message(m)) for m in msgs)
+    lb = max(2, (n_blocks - 1).bit_length())
+    pr = SA.Sha256Prover(ctx, lb)
+    proof, digest = pr.prove(msgs)
+    assert b"".join(struct.pack(">I", int(x)) for x in digest) == _b58_any(io, BLOCK_MERKLE_ROOT)
+    assert orc.stark_verify(pr.stark.desc, proof) == 1
+    vals = orc.stark_values(pr.stark.desc, proof)     # digest (8) | gamma (2) | the fingerprint the proof carries (2)
+    blocks, first, _ = SA.blocks_for_messages(msgs, lb)
+    assert tuple(vals[10:12]) == SA.fingerprint(blocks, first, vals[8:10])
+    pr.close()

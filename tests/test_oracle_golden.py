@@ -10,6 +10,20 @@ def test_poseidon_kats(orc, golden):
         assert [int(x) for x in out] == kat["out"], kat["source"]
 
 
+def test_poseidon_fast_schedule_equals_naive(orc, golden):
+    """Poseidon::poseidon (fast partial rounds - what the oracle and the Rust prover run) == Poseidon::poseidon_naive (the
+    schedule the known-answer vectors are stated for), on the KATs, on carry-edge states and on random states."""
+    rng = np.random.default_rng(77)
+    E = 0xFFFFFFFF
+    edge = [0, 1, E, E + 1, P - 1, P - 2, (1 << 63), P - E, 2 * E, (1 << 32) + 1, P >> 1, 7]
+    states = [k["in"] for k in golden["poseidon_kat"]] + [edge, edge[::-1]] + [list(rand_field(rng, 12)) for _ in range(200)]
+    arr = np.array(states, dtype=np.uint64)
+    fast, naive = orc.poseidon_permute(arr), orc.poseidon_permute_naive(arr)
+    assert np.array_equal(fast, naive)
+    for kat, out in zip(golden["poseidon_kat"], naive):
+        assert [int(x) for x in out] == kat["out"]
+
+
 def test_hash_or_noop_lengths(orc, golden):
     for case in golden["hash_or_noop"]:
         out = orc.hash_or_noop(np.array(case["in"], dtype=np.uint64))

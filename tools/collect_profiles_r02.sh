@@ -14,6 +14,13 @@ echo "== ubench"; ./tools/ubench/pub > "$OUT/r02_valu_ubench_$TAG.txt" 2>&1 || t
 echo "== bench sync"; python bench.py --steps 10 --warmup 2 > "$OUT/r02_bench_sync_$TAG.json"
 echo "== bench outer 2^16"; python bench.py --workload outer --steps 24 --warmup 3 --no-cpu-baseline > "$OUT/r02_bench_outer_2p16_$TAG.json"
 python bench.py --workload outer --steps 12 --warmup 3 --inflight 1 --no-cpu-baseline > "$OUT/r02_bench_outer_2p16_single_stream_$TAG.json"
+for ln in 13 18 20; do python bench.py --workload outer --log-n $ln --steps 8 --warmup 2 --inflight 1 --no-cpu-baseline > "$OUT/r02_bench_outer_2p${ln}_single_stream_$TAG.json"; done
+echo "== verify128"; python bench.py --workload verify128 --steps 2 --warmup 1 > "$OUT/r02_verify128_1gpu_$TAG.json"
+python bench.py --workload verify128 --map-log-n 15 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/r02_verify128_1gpu_map2p15_$TAG.json"
+echo "== ntt24"; python bench.py --workload ntt24 --steps 5 --warmup 1 > "$OUT/r02_ntt24_$TAG.json"
+echo "== starks"; python bench.py --workload ed25519 --log-slots 10 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/r02_ed25519_2p10_slots_$TAG.json"
+python bench.py --workload sha256 --log-blocks 14 --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/r02_sha256_2p14_blocks_$TAG.json"
+python bench.py --workload sha512 --log-blocks 14 --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/r02_sha512_2p14_blocks_$TAG.json"
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprof sync"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats_sync" -o s --output-format csv -- python3 "$ROOT/bench.py" --steps 6 --warmup 1 --no-cpu-baseline --no-extra > /dev/null
