@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ntt-log-n", type=int, default=24)
     ap.add_argument("--ntt-cols", type=int, default=16)
+    ap.add_argument("--ntt-field", default="goldilocks", choices=["goldilocks", "bn254"],
+                    help="ntt24 workload: goldilocks (the prover's field) or bn254 (the scalar field of the recursive wrap, row f.4)")
     ap.add_argument("--no-extra", action="store_true", help="sync workload: skip the plonky2-only 2^16 figures")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent proofs in flight per GPU (one context + stream + host thread each); the K "
@@ -944,6 +946,8 @@ def run_ntt24(args, nlx, torch, rank, world, local, dist):
     transforms, no collective (strong scaling); splitting ONE transform across GPUs (row-block four-step with an
     all-to-all) is out of scope."""
     import numpy as np
+    if args.ntt_field == "bn254":
+        return run_ntt24_bn254(args, nlx, torch, rank, world, local, dist)
     log_n, cols = args.ntt_log_n, args.ntt_cols
     mine = [c for c in range(cols) if c % world == rank]
     n = 1 << log_n
@@ -1001,6 +1005,73 @@ def run_ntt24(args, nlx, torch, rank, world, local, dist):
             out["cpu_baseline"] = {"value": 1.0 / (dtc * cols * 2.0 ** (log_n - s_log) * (log_n / s_log)), "unit": "batch NTTs/s", "cores": 1,
                                    "kind": "port", "sample": "oracle radix-2 NTT of one 2^%d-point column in %.2f s on one core, scaled by "
                                    "n log n and the %d columns; GPU output of the same column equal: %s" % (s_log, dtc, cols, bool(np.array_equal(ref, got)))}
+    ctx.close()
+    return out
+
+
+def run_ntt24_bn254(args, nlx, torch, rank, world, local, dist):
+    """--workload ntt24 --ntt-field bn254: the transform of BASELINE.json configs[4] in its own field - a batch of columns
+    x 2^--ntt-log-n points over BN254's scalar field (gnark-crypto fr.Element words, Montgomery form), resident in HBM,
+    one forward NTT of the batch per step through nlx_bn254_ntt_batch; columns split over the ranks."""
+    log_n, cols = args.ntt_log_n, args.ntt_cols
+    mine = [c for c in range(cols) if c % world == rank]
+    n = 1 << log_n
+    ctx = nlx.Context(local)
+    g = torch.Generator(device="cpu").manual_seed(0x626E + rank)
+    host = torch.randint(0, 2 ** 60, (max(len(mine), 1), n, 4), generator=g, dtype=torch.int64)   # top word < 2^60: values < r
+    data = host.to("cuda:%d" % local)
+    dll = nlx.lib.dll
+
+    def step():
+        if mine:
+            ctx.check(dll.nlx_bn254_ntt_batch(ctx.handle, data.data_ptr(), len(mine), log_n, 0, 1))
+    for _ in range(args.warmup):
+        step()
+    ctx.kernel_timing(True)
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(dist, torch)
+    dt = reduce_max(dist, torch, time.perf_counter() - t0)
+    kt, kr = ctx.kernel_stats("bn254_ntt_transform"), ctx.kernel_stats("bn254_ntt_reorder")
+    ctx.kernel_timing(False)
+    out = None
+    if rank == 0:
+        ach = (kt[2] / kt[0]) / (kt[1] / kt[0] * 1e-3) / 1e9 if kt[0] else 0.0
+        muls = n / 2 * log_n * len(mine)
+        out = {
+            "metric": "BN254 Fr NTT 2^%d x %d columns: transforms of the whole batch per second (the recursive wrap's transform, row f.4)" % (log_n, cols),
+            "value": args.steps / dt, "unit": "batch NTTs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u256 (BN254 scalar field, Montgomery form, integer)", "data": "synthetic",
+            "config": {"workload": "forward NTT of %d columns x 2^%d points over BN254 Fr (fr.Element words in and out, natural order), "
+                                   "resident in HBM, columns split over the ranks (no collective)" % (cols, log_n),
+                       "columns_per_rank": len(mine), "transform_ms_rank0": kt[1] / kt[0] if kt[0] else None,
+                       "reorder_ms_rank0": kr[1] / kr[0] if kr[0] else None,
+                       "montgomery_multiplications_per_second_rank0": muls / (kt[1] / kt[0] * 1e-3) if kt[0] else None,
+                       "parallelism": "columns x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_bn_dif<3> x passes (bn254_ntt_transform)", "launches": kt[0],
+                         "avg_launch_ms": kt[1] / kt[0] if kt[0] else None, "alg_bytes_per_launch": kt[2] / kt[0] if kt[0] else None,
+                         "note": "64 bytes per element algorithmic (one read, one write); the transform makes log_n / 3 trips through "
+                                 "HBM and is bound by the integer-VALU issue rate of the 256-bit Montgomery products"},
+            "cpu_baseline": None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import bn254_py
+            s_log = min(log_n, 12)
+            col = nlx.bn254_unpack(host[:1, : 1 << s_log].numpy().view("uint64"))[0]
+            tc = time.time()
+            ref = bn254_py.ntt([bn254_py.from_montgomery(x) for x in col])
+            dtc = time.time() - tc
+            got = nlx.bn254_unpack(nlx.bn254_ntt(ctx, host[:1, : 1 << s_log].numpy().view("uint64"), montgomery=True))[0]
+            ok = [bn254_py.from_montgomery(x) for x in got] == ref
+            out["cpu_baseline"] = {"value": 1.0 / (dtc * cols * 2.0 ** (log_n - s_log) * (log_n / s_log)), "unit": "batch NTTs/s", "cores": 1,
+                                   "kind": "port", "sample": "pure-Python big-integer model, one 2^%d-point column in %.2f s, scaled by n log n and "
+                                   "the %d columns (a model for parity, not a competitive CPU implementation); GPU output of the same column "
+                                   "equal: %s" % (s_log, dtc, cols, ok)}
     ctx.close()
     return out
 

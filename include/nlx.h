@@ -124,6 +124,15 @@ int32_t nlx_merkle_build(nlx_ctx* ctx, const uint64_t* leaves, size_t n_leaves, 
 int32_t nlx_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse,
                       uint64_t coset_shift);
 
+/* ---- f.4 (first piece): the BN254 scalar-field NTT of the recursive wrap (gnark-crypto ecc/bn254/fr/fft Domain.FFT /
+ * FFTInverse; the wrap itself is not in /root/reference - succinct.json:7-8 names the entry point that can run it).
+ * cols: n_cols x 2^log_n elements, column-major, transformed in place, natural order in and out; an element is 32 bytes =
+ * four little-endian 64-bit words.  flags = NLX_BN254_MONTGOMERY: elements are in Montgomery form (R = 2^256), i.e.
+ * gnark-crypto's fr.Element exactly as it lies in memory; flags = 0: canonical integers < r.  log_n <= 28 (Fr's 2-adicity);
+ * the root of unity is gnark-crypto's (5^((r-1)/2^28)).  inverse = 1 also multiplies by 1/n. */
+#define NLX_BN254_MONTGOMERY 1u
+int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags);
+
 /* ---- a3: plonky2::fri::oracle::PolynomialBatch::{from_values, from_coeffs} ----
  * values / coeffs: n_cols x 2^log_n column-major, natural order.  The coset shift is the
  * field's multiplicative generator (plonky2 F::coset_shift()).  blinding / salting is not

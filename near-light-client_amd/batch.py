@@ -159,3 +159,41 @@ class PolynomialBatch:
             self.close()
         except Exception:
             pass
+
+
+# ---- row f.4, first piece: the BN254 scalar-field NTT (csrc/bn254.hip, nlx_bn254_ntt_batch) ----
+BN254_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def bn254_pack(values):
+    """nested lists of Python ints < r, shape (n_cols, n) -> (n_cols, n, 4) uint64, little-endian words"""
+    v = [[int(x) for x in col] for col in values]
+    out = np.zeros((len(v), len(v[0]), 4), dtype=np.uint64)
+    for c, col in enumerate(v):
+        for i, x in enumerate(col):
+            for w in range(4):
+                out[c, i, w] = (x >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def bn254_unpack(arr):
+    a = np.asarray(arr, dtype=np.uint64)
+    return [[sum(int(a[c, i, w]) << (64 * w) for w in range(4)) for i in range(a.shape[1])] for c in range(a.shape[0])]
+
+
+def bn254_ntt(ctx, cols, inverse=False, montgomery=False):
+    """gnark-crypto fft.Domain.FFT / FFTInverse over BN254's scalar field, natural order in and out.  cols: (n_cols, n, 4)
+    uint64 (bn254_pack), canonical integers < r, or fr.Element Montgomery words with montgomery=True; or a device tensor of
+    that shape (transformed in place and returned)."""
+    if hasattr(cols, "data_ptr"):
+        n_cols, n = cols.shape[0], cols.shape[1]
+        c = cols
+    else:
+        c = np.ascontiguousarray(cols, dtype=np.uint64).copy()
+        n_cols, n = c.shape[0], c.shape[1]
+    log_n = n.bit_length() - 1
+    if 1 << log_n != n or c.shape[2] != 4:
+        raise ValueError("shape must be (n_cols, 2^k, 4)")
+    p = c.data_ptr() if hasattr(c, "data_ptr") else c.ctypes.data
+    ctx.check(dll.nlx_bn254_ntt_batch(ctx.handle, p, n_cols, log_n, 1 if inverse else 0, 1 if montgomery else 0))
+    return c

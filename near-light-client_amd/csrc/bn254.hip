@@ -1,0 +1,341 @@
+// BN254 scalar field (Fr) arithmetic and NTT for gfx950 - the first piece of SURVEY.md §8 row f.4 (the recursive wrap:
+// plonky2x's BN128-Poseidon wrapper -> gnark Groth16 / PLONK over BN254; BASELINE.json configs[4] names its 2^24-point NTT).
+// The wrap is not in /root/reference (succinct.json:7-8 only names the platform entry point that can run it; gnark is
+// Go, un-vendored), so this follows the published definitions:
+//   r = 21888242871839275222246405745257275088548364400416034343698204186575808495617 (2-adicity 28),
+//   the 2^28-th root of unity gnark-crypto's ecc/bn254/fr/fft uses
+//   (19103219067921713944291392827692070036145651957329286315305642004821462161904 = 5^((r-1)/2^28)),
+//   elements in Montgomery form (R = 2^256) as four little-endian 64-bit words - gnark-crypto's fr.Element layout -
+//   so a Go caller's []fr.Element can be handed over as it lies in memory (nlx.h: nlx_bn254_ntt_batch).
+// Replaces gnark-crypto fft.Domain.FFT / FFTInverse (DIF, natural order out after the bit-reversal the caller would do).
+//
+// Multiplication: CIOS Montgomery on eight 32-bit limbs; every step is a v_mad_u64_u32 (32 x 32 + 64).  A 256-bit
+// multiplication is ~170 multiply-adds against Goldilocks' 4, so unlike the Goldilocks transforms this one is bound by
+// the integer-VALU issue rate outright; the passes below fuse three butterfly levels per trip through HBM (radix 8 in
+// registers) to keep the memory traffic behind it.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+#include <vector>
+#include "ctx.hpp"
+#include "../../include/nlx.h"
+
+namespace nlx {
+namespace bn {
+
+struct Fr {
+    uint32_t v[8];
+};
+
+#define BN_HD __host__ __device__ __forceinline__
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__ static const uint32_t D_MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                                         0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+#endif
+static const uint32_t H_MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+static const uint32_t H_ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};  // R mod r
+static const uint32_t H_R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};   // R^2 mod r
+static const uint32_t H_ROOT28[8] = {0x80d13d9cu, 0x636e7355u, 0x2445ffd6u, 0xa22bf374u, 0x1eb203d8u, 0x56452ac0u, 0x2963f9e7u, 0x1860ef94u};  // w_{2^28} R mod r
+constexpr uint32_t N0INV = 0xefffffffu;  // -r^-1 mod 2^32
+
+BN_HD const uint32_t* modulus() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return D_MOD;
+#else
+    return H_MOD;
+#endif
+}
+
+// a >= b as 256-bit integers
+BN_HD bool geq(const Fr& a, const uint32_t* b) {
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        if (a.v[i] != b[i]) return a.v[i] > b[i];
+    }
+    return true;
+}
+BN_HD void sub_mod_raw(Fr& a, const uint32_t* b) {  // a -= b (no borrow out expected)
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint64_t d = (uint64_t)a.v[i] - b[i] - borrow;
+        a.v[i] = (uint32_t)d;
+        borrow = (d >> 32) & 1;
+    }
+}
+BN_HD Fr add(const Fr& a, const Fr& b) {
+    Fr r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)a.v[i] + b.v[i];
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    // r < 2 * modulus < 2^255: no carry out of 256 bits
+    if (geq(r, modulus())) sub_mod_raw(r, modulus());
+    return r;
+}
+BN_HD Fr sub(const Fr& a, const Fr& b) {
+    Fr r;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint64_t d = (uint64_t)a.v[i] - b.v[i] - borrow;
+        r.v[i] = (uint32_t)d;
+        borrow = (d >> 32) & 1;
+    }
+    if (borrow) {
+        uint64_t c = 0;
+        const uint32_t* m = modulus();
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            c += (uint64_t)r.v[i] + m[i];
+            r.v[i] = (uint32_t)c;
+            c >>= 32;
+        }
+    }
+    return r;
+}
+
+// Montgomery product a b R^-1 mod r (CIOS, 32-bit limbs): t has nine limbs; every inner step is one 32 x 32 + 64 multiply-add
+BN_HD Fr mul(const Fr& a, const Fr& b) {
+    const uint32_t* m = modulus();
+    uint32_t t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (uint64_t)a.v[j] * b.v[i] + t[j];
+            t[j] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[8] = (uint32_t)c;
+        t[9] = (uint32_t)(c >> 32);
+        const uint32_t q = t[0] * N0INV;
+        c = (uint64_t)q * m[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            c += (uint64_t)q * m[j] + t[j];
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[7] = (uint32_t)c;
+        t[8] = t[9] + (uint32_t)(c >> 32);
+    }
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    if (t[8] || geq(r, m)) sub_mod_raw(r, m);
+    return r;
+}
+
+inline Fr from_limbs(const uint32_t* l) {
+    Fr r;
+    memcpy(r.v, l, 32);
+    return r;
+}
+inline Fr h_pow(Fr b, uint64_t e) {  // host: Montgomery-form power
+    Fr r = from_limbs(H_ONE);
+    while (e) {
+        if (e & 1) r = mul(r, b);
+        b = mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+inline Fr h_inv(const Fr& a) {  // a^(r-2), exponent as 256-bit
+    Fr e = from_limbs(H_MOD);
+    e.v[0] -= 2;  // r - 2 (the low limb 0xf0000001 does not borrow)
+    Fr r = from_limbs(H_ONE), b = a;
+    for (int i = 0; i < 256; i++) {
+        if ((e.v[i / 32] >> (i % 32)) & 1) r = mul(r, b);
+        b = mul(b, b);
+    }
+    return r;
+}
+
+// ---- kernels ----
+// data layout: column-major, element = 8 little-endian 32-bit limbs = gnark-crypto's [4]uint64; 128-bit loads / stores
+__device__ __forceinline__ Fr load(const Fr* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1];
+    Fr r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void store(Fr* p, const Fr& r) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+// out[i] = in[i] * k  (to / from Montgomery form, the 1/n of the inverse transform)
+__global__ __launch_bounds__(256) void k_bn_scale(Fr* __restrict__ data, size_t count, Fr k) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    store(data + i, mul(load(data + i), k));
+}
+
+// w^e from the two-level table: lo[e & 4095] * hi[e >> 12]
+__device__ __forceinline__ Fr twiddle(const Fr* __restrict__ lo, const Fr* __restrict__ hi, uint32_t e) {
+    const Fr a = load(lo + (e & 4095u));
+    if (e < 4096u) return a;
+    return mul(a, load(hi + (e >> 12)));
+}
+
+// LEVELS (1..3) consecutive DIF levels per trip through HBM.  Level with half-size h pairs (i, i + h): a' = a + b,
+// b' = (a - b) w_{2h}^(i mod h), w_{2h} = w_n^(n / 2h).  A thread owns the 2^LEVELS elements base + k * h_last
+// (h_last = the half-size of the last fused level), i.e. one butterfly network of the fused levels.
+template <int LEVELS>
+__global__ __launch_bounds__(256) void k_bn_dif(Fr* __restrict__ data, unsigned log_n, unsigned log_h_first,
+                                                const Fr* __restrict__ tw_lo, const Fr* __restrict__ tw_hi, uint32_t n_cols) {
+    constexpr int R = 1 << LEVELS;
+    const size_t n = (size_t)1 << log_n;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // butterfly-network index within a column
+    const size_t per_col = n >> LEVELS;
+    if (t >= per_col * n_cols) return;
+    const size_t col = t / per_col, u = t % per_col;
+    const unsigned log_h_last = log_h_first - (LEVELS - 1);
+    const size_t h_last = (size_t)1 << log_h_last;
+    // u = (block index among groups of 2 h_first) * h_last + offset below h_last
+    const size_t off = u & (h_last - 1), grp = u >> log_h_last;
+    Fr* base = data + col * n + (grp << (log_h_first + 1)) + off;
+    Fr x[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) x[k] = load(base + (size_t)k * h_last);
+#pragma unroll
+    for (int l = 0; l < LEVELS; l++) {
+        const int half = R >> (l + 1);                 // distance between partners in units of h_last
+        const unsigned log_h = log_h_first - l;        // this level's half-size
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            if ((k & half) == 0) {
+                // position of x[k] inside its 2h block: (k mod 2 half) * h_last + off, with k mod 2 half < half here
+                const uint32_t idx = (uint32_t)((size_t)(k & (half - 1)) * h_last + off);
+                const uint32_t e = idx << (log_n - 1 - log_h);   // w_{2h}^idx = w_n^(idx n / 2h)
+                const Fr a = x[k], b = x[k + half];
+                x[k] = add(a, b);
+                const Fr d = sub(a, b);
+                x[k + half] = e ? mul(d, twiddle(tw_lo, tw_hi, e)) : d;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) store(base + (size_t)k * h_last, x[k]);
+}
+
+// out[bitrev(i)] = in[i] * k  (the bit-reversal back to natural order, fused with the last scaling)
+__global__ __launch_bounds__(256) void k_bn_bitrev(const Fr* __restrict__ in, Fr* __restrict__ out, unsigned log_n, uint32_t n_cols,
+                                                   Fr k, int scale) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n_cols) return;
+    const size_t col = t >> log_n, i = t & (n - 1);
+    const size_t j = log_n ? (__brevll(i) >> (64 - log_n)) : 0;
+    Fr v = load(in + col * n + i);
+    if (scale) v = mul(v, k);
+    store(out + col * n + j, v);
+}
+
+}  // namespace bn
+}  // namespace nlx
+
+using namespace nlx;
+using nlx::bn::Fr;
+
+extern "C" {
+
+int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags) {
+    if (!ctx) return NLX_E_INVAL;
+    if (n_cols == 0) return NLX_OK;
+    if (!cols) return ctx->fail(NLX_E_INVAL, "cols is NULL");
+    if (log_n > 28) return ctx->fail(NLX_E_RANGE, "BN254 Fr has 2-adicity 28");
+    if (n_cols > 65535 || (flags & ~1u)) return ctx->fail(NLX_E_RANGE, "n_cols > 65535 or unknown flag");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)1 << log_n, count = n * n_cols;
+    const bool mont_io = flags & NLX_BN254_MONTGOMERY;
+    // twiddle tables for w = w_n (or its inverse): lo[i] = w^i, hi[i] = w^(4096 i), Montgomery form
+    // (the tables live in the context, like the Goldilocks ones, and go with it)
+    struct { Fr* d_lo; Fr* d_hi; } tb;
+    std::pair<void*, void*>& slot = ctx->bn254_tables[log_n * 2 + (inverse ? 1 : 0)];
+    tb.d_lo = (Fr*)slot.first;
+    tb.d_hi = (Fr*)slot.second;
+    if (!tb.d_lo) {
+        Fr w = bn::h_pow(bn::from_limbs(bn::H_ROOT28), (uint64_t)1 << (28 - log_n));
+        if (inverse) w = bn::h_inv(w);
+        const size_t half = n >> 1, n_hi = std::max<size_t>((half + 4095) >> 12, 1);
+        std::vector<Fr> lo(4096), hi(n_hi);
+        lo[0] = bn::from_limbs(bn::H_ONE);
+        for (size_t i = 1; i < 4096; i++) lo[i] = bn::mul(lo[i - 1], w);
+        const Fr w4096 = bn::mul(lo[4095], w);
+        hi[0] = lo[0];
+        for (size_t i = 1; i < n_hi; i++) hi[i] = bn::mul(hi[i - 1], w4096);
+        tb.d_lo = (Fr*)ctx->alloc(4096 * sizeof(Fr));
+        tb.d_hi = (Fr*)ctx->alloc(n_hi * sizeof(Fr));
+        if (!tb.d_lo || !tb.d_hi) return NLX_E_NOMEM;
+        NLX_HIP(ctx, hipMemcpyAsync(tb.d_lo, lo.data(), 4096 * sizeof(Fr), hipMemcpyHostToDevice, st));
+        NLX_HIP(ctx, hipMemcpyAsync(tb.d_hi, hi.data(), n_hi * sizeof(Fr), hipMemcpyHostToDevice, st));
+        NLX_HIP(ctx, hipStreamSynchronize(st));
+        slot = {tb.d_lo, tb.d_hi};
+    }
+    nlx::Staged s(ctx, cols, count * 32, true, true);
+    if (s.status) return s.status;
+    Fr* d = s.as<Fr>();
+    Fr* tmp = (Fr*)ctx->alloc(count * 32);
+    if (!tmp) return NLX_E_NOMEM;
+    const unsigned blocks1 = (unsigned)((count + 255) / 256);
+    if (!mont_io) hipLaunchKernelGGL(bn::k_bn_scale, dim3(blocks1), dim3(256), 0, st, d, count, bn::from_limbs(bn::H_R2));
+    // DIF: natural order in, bit-reversed out; three levels per pass while they last
+    ctx->begin_kernel("bn254_ntt_transform", 64.0 * count);  // algorithmic bytes: 32 B read + 32 B written per element
+    int lvl = (int)log_n - 1;  // log2 of the current level's half-size
+    while (lvl >= 0) {
+        const int take = lvl >= 2 ? 3 : lvl + 1;
+        const size_t nets = (n >> take) * n_cols;
+        const unsigned blocks = (unsigned)((nets + 255) / 256);
+        if (take == 3) hipLaunchKernelGGL(bn::k_bn_dif<3>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols);
+        else if (take == 2) hipLaunchKernelGGL(bn::k_bn_dif<2>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols);
+        else hipLaunchKernelGGL(bn::k_bn_dif<1>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols);
+        lvl -= take;
+    }
+    ctx->end_kernel();
+    // back to natural order, fused with the scalings still owed: 1/n (inverse) and R^-1 (standard-form output)
+    Fr k = bn::from_limbs(bn::H_ONE);
+    int scale = 0;
+    if (inverse) {
+        Fr nn{};
+        nn.v[0] = (uint32_t)n; nn.v[1] = (uint32_t)((uint64_t)n >> 32);
+        k = bn::h_inv(bn::mul(nn, bn::from_limbs(bn::H_R2)));  // (n R)^-1 R = n^-1 in Montgomery form
+        scale = 1;
+    }
+    if (!mont_io) {
+        // multiplying by the standard-form value of k (= k R^-1 in Montgomery terms) leaves the product in standard form
+        Fr one{};
+        one.v[0] = 1;
+        k = bn::mul(k, one);
+        scale = 1;
+    }
+    ctx->begin_kernel("bn254_ntt_reorder", 64.0 * count);
+    hipLaunchKernelGGL(bn::k_bn_bitrev, dim3(blocks1), dim3(256), 0, st, d, tmp, log_n, (uint32_t)n_cols, k, scale);
+    hipError_t e = hipMemcpyAsync(d, tmp, count * 32, hipMemcpyDeviceToDevice, st);
+    ctx->end_kernel();
+    ctx->release(tmp);
+    if (e != hipSuccess) return ctx->hip_fail(e, "hipMemcpyAsync");
+    int32_t rc = s.finish();
+    if (rc) return rc;
+    NLX_HIP(ctx, hipStreamSynchronize(st));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return ctx->hip_fail(le, "kernel launch");
+    return NLX_OK;
+}
+
+}  // extern "C"
