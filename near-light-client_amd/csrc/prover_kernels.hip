@@ -264,14 +264,17 @@ struct Sum128 {
 
 // prod_{x < 4} (l - x): the 2-bit limb range check of the u32 gates, as u (u + 2) with u = l (l - 3)
 // (l (l - 3) = l^2 - 3l and (l - 1)(l - 2) = l^2 - 3l + 2): two multiplications instead of three
+// (canonical l in, LOOSE result out - any u64 congruent to the product: GateAcc::emit and gl::mul_loose take loose values,
+// so the canonicalising compare / select after each multiplication is skipped)
 __device__ __forceinline__ uint64_t limb4(uint64_t l) {
-    const uint64_t u = gl::mul(l, gl::sub(l, 3));
-    return gl::mul(u, gl::add(u, 2));
+    const uint64_t u = gl::mul_loose(l, gl::sub(l, 3));
+    return gl::mul_loose(u, gl::add_loose(u, 2));
 }
 
+// x^7, any u64 in, LOOSE out (consumers: poseidon::mds_layer, which splits any u64 into halves, and gl::add_loose)
 __device__ __forceinline__ uint64_t sbox7c(uint64_t x) {
-    uint64_t x2 = gl::mul(x, x), x4 = gl::mul(x2, x2), x3 = gl::mul(x, x2);
-    return gl::mul(x3, x4);
+    uint64_t x2 = gl::mul_loose(x, x), x4 = gl::mul_loose(x2, x2), x3 = gl::mul_loose(x, x2);
+    return gl::mul_loose(x3, x4);
 }
 __device__ __forceinline__ void mds_canon(uint64_t (&s)[12]) {
     poseidon::mds_layer(s);
@@ -335,7 +338,7 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc) {
         const uint64_t in = W(65 + r);
         acc.emit(gl::sub(st[0], in));
         uint64_t s0 = sbox7c(in);
-        if (r < 21) s0 = gl::add(s0, FAST_RC[r]);
+        if (r < 21) s0 = gl::add_loose(s0, FAST_RC[r]);
         uint64_t d = gl::mul(s0, 25);
 #pragma unroll
         for (int i = 1; i < 12; i++) {
