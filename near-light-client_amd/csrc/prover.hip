@@ -12,6 +12,7 @@
 // PCIe.  It is not a fallback for any device stage.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <thread>
@@ -55,31 +56,33 @@ uint32_t gate_num_constraints(const nlx_gate_desc& g) {
     }
 }
 
-// Rough cost of one gate's evaluation at one point in VALU instructions (a field multiplication ~ 27, an alpha-power
-// multiply-accumulate ~ 16, a wire read + add ~ 10): only the RATIOS matter - they balance k_quotient's work split.
+// Cost of one gate's evaluation at one point, in microseconds of k_quotient's stage time per 2^19 points when every wave of a
+// tile evaluates that item alone (measured on MI355X with the calibration build, tools/quotient_calibrate.sh, standard
+// parameters; scaled linearly in the parameter that multiplies the work).  Only the RATIOS matter: they balance the work split.
 uint32_t gate_eval_cost(const nlx_gate_desc& g) {
-    const uint32_t p0 = g.param0, p1 = g.param1, emits = gate_num_constraints(g);
-    uint32_t muls = 0;
+    const uint32_t p0 = g.param0, p1 = g.param1;
     switch (g.kind) {
-        case NLX_GATE_ARITHMETIC: muls = 3 * p0; break;
-        case NLX_GATE_BASE_SUM: muls = p1 * (1 + p0); break;
-        case NLX_GATE_POSEIDON: muls = 8 * 48 + 22 * 26 + 121 + 8 * 12; break;  // S-boxes, fast partial rounds, 11 x 11 matrix, MDS layers
-        case NLX_GATE_ARITHMETIC_EXT: muls = 9 * p0; break;
-        case NLX_GATE_MUL_EXT: muls = 7 * p0; break;
-        case NLX_GATE_REDUCING: case NLX_GATE_REDUCING_EXT: muls = 5 * p0; break;
-        case NLX_GATE_POSEIDON_MDS: muls = 2 * 12; break;
-        case NLX_GATE_EXPONENTIATION: muls = 3 * p0; break;
-        case NLX_GATE_RANDOM_ACCESS: muls = (p1 & 0xFFFF) * ((1u << p0) + p0); break;
-        case NLX_GATE_COSET_INTERPOLATION: muls = 14u << p0; break;
-        case NLX_GATE_U32_ADD_MANY: muls = p1 * (2 * 18 + 1); break;
-        case NLX_GATE_U32_ARITHMETIC: muls = p0 * (2 * 32 + 4); break;
-        case NLX_GATE_U32_SUBTRACTION: muls = p0 * (2 * 16 + 2); break;
-        case NLX_GATE_U32_RANGE_CHECK: muls = p0 * 2 * 16; break;
-        case NLX_GATE_COMPARISON: muls = p1 * 9; break;
-        default: break;
+        case NLX_GATE_ARITHMETIC: return 10 + 9 * p0 / 2;
+        case NLX_GATE_BASE_SUM: return 10 + 84 * p1 * (1 + p0) / 30;      // 530 for 63 limbs in base 2
+        case NLX_GATE_POSEIDON: return 3170;                                // evaluated in three parts, see POSEIDON_PART_SHARE
+        case NLX_GATE_ARITHMETIC_EXT: return 10 + 12 * p0;
+        case NLX_GATE_MUL_EXT: return 10 + 10 * p0;
+        case NLX_GATE_REDUCING: return 10 + 114 * p0 / 10;
+        case NLX_GATE_REDUCING_EXT: return 10 + 103 * p0 / 10;
+        case NLX_GATE_POSEIDON_MDS: return 90;
+        case NLX_GATE_EXPONENTIATION: return 10 + 67 * p0 / 10;
+        case NLX_GATE_RANDOM_ACCESS: return 10 + 185 * (p1 & 0xFFFF) * (1u << p0) / 16;
+        case NLX_GATE_COSET_INTERPOLATION: return 10 + (34u << p0);
+        case NLX_GATE_U32_ADD_MANY: return 10 + 106 * p1;
+        case NLX_GATE_U32_ARITHMETIC: return 10 + 193 * p0;
+        case NLX_GATE_U32_SUBTRACTION: return 10 + 105 * p0;
+        case NLX_GATE_U32_RANGE_CHECK: return 10 + 84 * p0;
+        case NLX_GATE_COMPARISON: return 10 + 21 * p1;
+        default: return 10;
     }
-    return 60 + 27 * muls + 16 * emits;
 }
+// PoseidonGate's three parts (prover_kernels.hip gate_poseidon): part mask, share of the gate's cost in percent
+constexpr uint32_t POSEIDON_PARTS[3][2] = {{1, 15}, {2, 68}, {4, 17}};
 }  // namespace
 
 struct nlx_circuit {
@@ -249,10 +252,20 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
         // k_quotient's work split: items = every gate + the permutation argument of each challenge; longest item first into
         // the least loaded wave.  Wave w and wave w + QW/2 of a block share a SIMD, so the bins are then paired heavy with
         // light: what has to balance is the load per SIMD (the same split runs on every tile).
-        const uint32_t QWv = quotient_waves(), n_items = d.num_gates + d.num_challenges;
+        const uint32_t QWv = quotient_waves();
+        if (d.num_gates + d.num_challenges > 0xFFFFu) return fail(ctx->fail(NLX_E_RANGE, "too many gates"));
         std::vector<std::pair<uint32_t, uint32_t>> items;  // (cost, id)
-        for (uint32_t g = 0; g < d.num_gates; g++) items.push_back({gate_eval_cost(c->gates[g]), g});
-        for (uint32_t ch = 0; ch < d.num_challenges; ch++) items.push_back({200 + 130 * d.num_routed_wires, d.num_gates + ch});
+        uint32_t n_words = 0;
+        for (uint32_t g = 0; g < d.num_gates; g++) {
+            const uint32_t cost = gate_eval_cost(c->gates[g]);
+            if (c->gates[g].kind == NLX_GATE_POSEIDON) {
+                for (const auto& part : POSEIDON_PARTS) items.push_back({cost * part[1] / 100, g | (part[0] << 16)});
+            } else {
+                items.push_back({cost, g});
+            }
+        }
+        for (uint32_t ch = 0; ch < d.num_challenges; ch++) items.push_back({10 + 51 * d.num_routed_wires / 4, d.num_gates + ch});  // 1 020 for 80 routed wires
+        n_words = (uint32_t)items.size();
         std::sort(items.begin(), items.end(), [](const auto& a, const auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
         std::vector<std::vector<uint32_t>> bins(QWv);
         std::vector<uint64_t> load(QWv, 0);
@@ -264,13 +277,21 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
         std::vector<uint32_t> order(QWv);
         for (uint32_t i = 0; i < QWv; i++) order[i] = i;
         std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return load[a] != load[b] ? load[a] > load[b] : a < b; });
-        c->work_stride = n_items + 1;
+        c->work_stride = n_words + 1;
         std::vector<uint32_t> work((size_t)QWv * c->work_stride, 0xFFFFFFFFu);
         for (uint32_t i = 0; i < QWv; i++) {
             // heaviest bins on waves 0 .. QW/2-1, lightest first on waves QW/2 .. QW-1: SIMD s gets bins order[s] and order[QW-1-s]
             const uint32_t wave = i < QWv / 2 ? i : QWv / 2 + (QWv - 1 - i);
             std::copy(bins[order[i]].begin(), bins[order[i]].end(), work.begin() + (size_t)wave * c->work_stride);
         }
+#ifdef NLX_QUOTIENT_CALIBRATE
+        // kernel-tuning build only (build.py, NLX_BUILD_VARIANT): every wave evaluates the ONE item named by NLX_Q_ONLY, so
+        // that the stage time ranks the items' real costs (tools/quotient_calibrate.sh); the proof is wrong by design
+        if (const char* only = getenv("NLX_Q_ONLY")) {
+            std::fill(work.begin(), work.end(), 0xFFFFFFFFu);
+            for (uint32_t w = 0; w < QWv; w++) work[(size_t)w * c->work_stride] = (uint32_t)atoi(only);
+        }
+#endif
         c->d_work = (uint32_t*)ctx->alloc(work.size() * 4);
         if (!c->d_work) return fail(NLX_E_NOMEM);
         hipError_t e = hipMemcpy(c->d_work, work.data(), work.size() * 4, hipMemcpyHostToDevice);

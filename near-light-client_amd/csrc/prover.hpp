@@ -41,7 +41,8 @@ struct QuotientParams {
     uint32_t log_n, rate_bits, n_gates, n_selectors, n_consts_all, routed, chunk, nc, npp;
     uint32_t num_wires;
     // work split of one tile of 64 points over the kernel's quotient_waves() waves: row w lists wave w's items, terminated by
-    // 0xFFFFFFFF; item g < n_gates = gate g, item n_gates + c = the permutation argument of challenge c (device, host-built)
+    // 0xFFFFFFFF; low 16 bits g < n_gates = gate g (bits 16.. = part mask for a gate evaluated in parts: PoseidonGate),
+    // n_gates + c = the permutation argument of challenge c (device, host-built)
     const uint32_t* work;
     uint32_t work_stride;
 };

@@ -282,90 +282,110 @@ __device__ __forceinline__ void mds_canon(uint64_t (&s)[12]) {
     for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
 }
 
-// PoseidonGate::eval_unfiltered_base (fast partial-round formulation, as upstream)
+// PoseidonGate::eval_unfiltered_base (fast partial-round formulation, as upstream), in three independent parts (bit mask):
+// every round of the gate restarts from WIRES (the round's S-box inputs are wires, the constraint ties them to the state
+// computed from the previous round's wires), so the 123 constraints split wherever the state is reloaded:
+//   1: swap bit, deltas, full rounds 0-2 and the check of round 3's inputs            constraints 0 .. 40
+//   2: full round 3 from its input wires, the 22 partial rounds, the check of round 26's inputs      41 .. 74
+//   4: full rounds 26-29 and the output wires                                                        75 .. 122
+// Each part is its own work item of k_quotient (part 2 alone is two thirds of the gate and a fifth of the whole kernel);
+// constraint k always meets alpha^k (GateAcc::emit_at).
 template <class WireFn>
-__device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc) {
+__device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t parts) {
     const uint64_t* RC = poseidon::RC_DEV;
-    const uint64_t swap = W(24);
-    acc.emit(gl::mul(swap, gl::sub(swap, 1)));
     uint64_t st[12];
+    if (parts & 1u) {
+        const uint64_t swap = W(24);
+        acc.emit_at(0, gl::mul(swap, gl::sub(swap, 1)));
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint64_t lhs = W(i), rhs = W(i + 4), delta = W(25 + i);
-        acc.emit(gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
-        st[i] = gl::add(lhs, delta);
-        st[i + 4] = gl::sub(rhs, delta);
-    }
+        for (int i = 0; i < 4; i++) {
+            const uint64_t lhs = W(i), rhs = W(i + 4), delta = W(25 + i);
+            acc.emit_at(1 + i, gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
+            st[i] = gl::add(lhs, delta);
+            st[i + 4] = gl::sub(rhs, delta);
+        }
 #pragma unroll
-    for (int i = 8; i < 12; i++) st[i] = W(i);
+        for (int i = 8; i < 12; i++) st[i] = W(i);
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], RC[r * 12 + i]);
-        if (r != 0) {
+            for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], RC[r * 12 + i]);
+            if (r != 0) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    const uint64_t in = W(29 + 12 * (r - 1) + i);
+                    acc.emit_at(5 + 12 * (r - 1) + i, gl::sub(st[i], in));
+                    st[i] = in;
+                }
+            }
+            if (r == 3) break;  // round 3 itself belongs to part 2
+#pragma unroll
+            for (int i = 0; i < 12; i++) st[i] = sbox7c(st[i]);
+            mds_canon(st);
+        }
+    }
+    if (parts & 2u) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = sbox7c(W(29 + 24 + i));   // round 3's S-box inputs are wires
+        mds_canon(st);
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], FAST_FIRST[i]);
+        {
+            uint64_t res[12];
+            res[0] = st[0];
+#pragma unroll
+            for (int c = 1; c < 12; c++) res[c] = 0;
+#pragma unroll 1
+            for (int r = 1; r < 12; r++) {
+                // dynamic r: select st[r] without indexing registers dynamically
+                uint64_t sr = 0;
+#pragma unroll
+                for (int t = 1; t < 12; t++) sr = (t == r) ? st[t] : sr;
+#pragma unroll
+                for (int c = 1; c < 12; c++) res[c] = gl::add(res[c], gl::mul(sr, FAST_INIT[r - 1][c - 1]));
+            }
+#pragma unroll
+            for (int i = 0; i < 12; i++) st[i] = res[i];
+        }
+#pragma unroll 1
+        for (int r = 0; r < 22; r++) {
+            const uint64_t in = W(65 + r);
+            acc.emit_at(41 + r, gl::sub(st[0], in));
+            uint64_t s0 = sbox7c(in);
+            if (r < 21) s0 = gl::add_loose(s0, FAST_RC[r]);
+            uint64_t d = gl::mul(s0, 25);
+#pragma unroll
+            for (int i = 1; i < 12; i++) {
+                d = gl::add(d, gl::mul(st[i], FAST_W[r][i - 1]));
+                st[i] = gl::add(st[i], gl::mul(s0, FAST_VS[r][i - 1]));
+            }
+            st[0] = d;
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++)
+            acc.emit_at(63 + i, gl::sub(gl::add(st[i], RC[26 * 12 + i]), W(87 + i)));
+    }
+    if (parts & 4u) {
+#pragma unroll 1
+        for (int r = 0; r < 4; r++) {
 #pragma unroll
             for (int i = 0; i < 12; i++) {
-                const uint64_t in = W(29 + 12 * (r - 1) + i);
-                acc.emit(gl::sub(st[i], in));
-                st[i] = in;
+                const uint64_t in = W(87 + 12 * r + i);
+                if (r != 0) acc.emit_at(63 + 12 * r + i, gl::sub(gl::add(st[i], RC[(26 + r) * 12 + i]), in));
+                st[i] = sbox7c(in);
             }
+            mds_canon(st);
         }
 #pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = sbox7c(st[i]);
-        mds_canon(st);
+        for (int i = 0; i < 12; i++) acc.emit_at(111 + i, gl::sub(st[i], W(12 + i)));
     }
-#pragma unroll
-    for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], FAST_FIRST[i]);
-    {
-        uint64_t res[12];
-        res[0] = st[0];
-#pragma unroll
-        for (int c = 1; c < 12; c++) res[c] = 0;
-#pragma unroll 1
-        for (int r = 1; r < 12; r++) {
-            // dynamic r: select st[r] without indexing registers dynamically
-            uint64_t sr = 0;
-#pragma unroll
-            for (int t = 1; t < 12; t++) sr = (t == r) ? st[t] : sr;
-#pragma unroll
-            for (int c = 1; c < 12; c++) res[c] = gl::add(res[c], gl::mul(sr, FAST_INIT[r - 1][c - 1]));
-        }
-#pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = res[i];
-    }
-#pragma unroll 1
-    for (int r = 0; r < 22; r++) {
-        const uint64_t in = W(65 + r);
-        acc.emit(gl::sub(st[0], in));
-        uint64_t s0 = sbox7c(in);
-        if (r < 21) s0 = gl::add_loose(s0, FAST_RC[r]);
-        uint64_t d = gl::mul(s0, 25);
-#pragma unroll
-        for (int i = 1; i < 12; i++) {
-            d = gl::add(d, gl::mul(st[i], FAST_W[r][i - 1]));
-            st[i] = gl::add(st[i], gl::mul(s0, FAST_VS[r][i - 1]));
-        }
-        st[0] = d;
-    }
-#pragma unroll 1
-    for (int r = 0; r < 4; r++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            const uint64_t v = gl::add(st[i], RC[(26 + r) * 12 + i]);
-            const uint64_t in = W(87 + 12 * r + i);
-            acc.emit(gl::sub(v, in));
-            st[i] = sbox7c(in);
-        }
-        mds_canon(st);
-    }
-#pragma unroll
-    for (int i = 0; i < 12; i++) acc.emit(gl::sub(st[i], W(12 + i)));
 }
 
 // One gate's unfiltered constraints at this lane's point, folded into `acc` with the alpha powers (Gate::eval_unfiltered_base).
 // W(c): wire c of the point; CC(c): constants column c (selectors first) of the point; n = 2^log_n.
 template <class WireFn, class ConstFn>
-__device__ __forceinline__ void eval_gate(const GateDev& gd, const QuotientParams& p, WireFn W, ConstFn CC, GateAcc& acc, size_t n) {
+__device__ __forceinline__ void eval_gate(const GateDev& gd, const QuotientParams& p, WireFn W, ConstFn CC, GateAcc& acc, size_t n,
+                                          uint32_t parts) {
     switch (gd.kind) {
         case NLX_GATE_CONSTANT:
             for (uint32_t i = 0; i < gd.param0; i++) acc.emit(gl::sub(CC(p.n_selectors + i), W(i)));
@@ -395,7 +415,7 @@ __device__ __forceinline__ void eval_gate(const GateDev& gd, const QuotientParam
             break;
         }
         case NLX_GATE_POSEIDON:
-            gate_poseidon(W, acc);
+            gate_poseidon(W, acc, parts);
             break;
         case NLX_GATE_ARITHMETIC_EXT: {
             const uint64_t c0 = CC(p.n_selectors), c1 = CC(p.n_selectors + 1);
@@ -707,10 +727,11 @@ __global__ __launch_bounds__(64 * QW, NLX_QMINW) void k_quotient(QuotientParams 
     acc.ap1 = ap1 + T0;
     const uint32_t* work = p.work + (size_t)wv * p.work_stride;
     for (uint32_t wi = 0;; wi++) {
-        const uint32_t item = work[wi];  // wave-uniform
-        if (item == 0xFFFFFFFFu) break;
+        const uint32_t word = work[wi];  // wave-uniform: item in the low half, for a gate evaluated in parts the part mask above it
+        if (word == 0xFFFFFFFFu) break;
+        const uint32_t item = word & 0xFFFFu, parts = (word >> 16) ? (word >> 16) : 7u;
         if (item < p.n_gates) {
-            // ---- one gate: filter x sum_k alpha^k c_k ----
+            // ---- one gate (or one part of it): filter x sum_k alpha^k c_k ----
             const GateDev gd = p.gates[item];
             const uint64_t s = CC(gd.selector_index);
             uint64_t f = 1;
@@ -718,7 +739,7 @@ __global__ __launch_bounds__(64 * QW, NLX_QMINW) void k_quotient(QuotientParams 
                 if (i != gd.index) f = gl::mul(f, gl::sub((uint64_t)i, s));
             if (p.n_selectors > 1) f = gl::mul(f, gl::sub(0xFFFFFFFFULL, s));
             acc.reset();
-            eval_gate(gd, p, W, CC, acc, n);
+            eval_gate(gd, p, W, CC, acc, n, parts);
             tot0 = gl::add(tot0, gl::mul(f, acc.finish(0)));
             tot1 = gl::add(tot1, gl::mul(f, acc.finish(1)));
         } else {
