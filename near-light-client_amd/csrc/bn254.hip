@@ -185,11 +185,37 @@ __global__ __launch_bounds__(256) void k_bn_scale(Fr* __restrict__ data, size_t 
     store(data + i, mul(load(data + i), k));
 }
 
-// w^e from the two-level table: lo[e & 4095] * hi[e >> 12]
-__device__ __forceinline__ Fr twiddle(const Fr* __restrict__ lo, const Fr* __restrict__ hi, uint32_t e) {
+// T[e] = lo[e & 4095] * hi[e >> 12]: the full table w_n^e, e < n/2, built once per (size, direction) on the device from
+// two small host-made tables.  A two-level table read inside the butterflies would cost a second 256-bit product per
+// butterfly - as much as the butterfly itself (measured: 97 ms against this version's time at 16 x 2^24).
+__global__ __launch_bounds__(256) void k_bn_fill_twiddles(Fr* __restrict__ out, size_t count, const Fr* __restrict__ lo,
+                                                          const Fr* __restrict__ hi) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
     const Fr a = load(lo + (e & 4095u));
-    if (e < 4096u) return a;
-    return mul(a, load(hi + (e >> 12)));
+    store(out + e, e < 4096u ? a : mul(a, load(hi + (e >> 12))));
+}
+
+__device__ __forceinline__ Fr twiddle(const Fr* __restrict__ table, const Fr* __restrict__, uint32_t e) { return load(table + e); }
+
+// One DIF level on a thread's register tile: partners are HALF apart (in units of h_last); HALF is a template parameter so
+// that every x[] index is static and the tile stays in registers (a runtime `half` put the whole tile into scratch memory:
+// the first version ran at a third of this one's speed).
+template <int R, int HALF>
+__device__ __forceinline__ void dif_level(Fr (&x)[R], size_t h_last, size_t off, unsigned shift, const Fr* __restrict__ tw_lo,
+                                          const Fr* __restrict__ tw_hi) {
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        if ((k & HALF) == 0) {
+            // position of x[k] inside its 2h block: (k mod 2 HALF) * h_last + off, and k mod 2 HALF < HALF here
+            const uint32_t idx = (uint32_t)((size_t)(k & (HALF - 1)) * h_last + off);
+            const uint32_t e = idx << shift;   // w_{2h}^idx = w_n^(idx n / 2h)
+            const Fr a = x[k], b = x[k + HALF];
+            x[k] = add(a, b);
+            const Fr d = sub(a, b);
+            x[k + HALF] = e ? mul(d, twiddle(tw_lo, tw_hi, e)) : d;
+        }
+    }
 }
 
 // LEVELS (1..3) consecutive DIF levels per trip through HBM.  Level with half-size h pairs (i, i + h): a' = a + b,
@@ -212,26 +238,54 @@ __global__ __launch_bounds__(256) void k_bn_dif(Fr* __restrict__ data, unsigned 
     Fr x[R];
 #pragma unroll
     for (int k = 0; k < R; k++) x[k] = load(base + (size_t)k * h_last);
-#pragma unroll
-    for (int l = 0; l < LEVELS; l++) {
-        const int half = R >> (l + 1);                 // distance between partners in units of h_last
-        const unsigned log_h = log_h_first - l;        // this level's half-size
-#pragma unroll
-        for (int k = 0; k < R; k++) {
-            if ((k & half) == 0) {
-                // position of x[k] inside its 2h block: (k mod 2 half) * h_last + off, with k mod 2 half < half here
-                const uint32_t idx = (uint32_t)((size_t)(k & (half - 1)) * h_last + off);
-                const uint32_t e = idx << (log_n - 1 - log_h);   // w_{2h}^idx = w_n^(idx n / 2h)
-                const Fr a = x[k], b = x[k + half];
-                x[k] = add(a, b);
-                const Fr d = sub(a, b);
-                x[k + half] = e ? mul(d, twiddle(tw_lo, tw_hi, e)) : d;
-            }
-        }
+    // level l has half-size 2^(log_h_first - l): twiddle exponent shift = log_n - 1 - (log_h_first - l)
+    const unsigned sh0 = log_n - 1 - log_h_first;
+    if constexpr (LEVELS == 3) {
+        // (unreachable: three levels run in k_bn_dif3, whose tile is eight named registers - the compiler kept this
+        // array form in scratch memory even with static indices)
+        dif_level<R, 4>(x, h_last, off, sh0, tw_lo, tw_hi);
+        dif_level<R, 2>(x, h_last, off, sh0 + 1, tw_lo, tw_hi);
+        dif_level<R, 1>(x, h_last, off, sh0 + 2, tw_lo, tw_hi);
+    } else if constexpr (LEVELS == 2) {
+        dif_level<R, 2>(x, h_last, off, sh0, tw_lo, tw_hi);
+        dif_level<R, 1>(x, h_last, off, sh0 + 1, tw_lo, tw_hi);
+    } else {
+        dif_level<R, 1>(x, h_last, off, sh0, tw_lo, tw_hi);
     }
 #pragma unroll
     for (int k = 0; k < R; k++) store(base + (size_t)k * h_last, x[k]);
 }
+
+// Three fused levels with the tile in eight NAMED registers (radix 8).
+#define BN_BF(A, B, IDX, SH)                                              \
+    {                                                                     \
+        const uint32_t e_ = (uint32_t)(IDX) << (SH);                      \
+        const Fr a_ = A, b_ = B;                                          \
+        A = add(a_, b_);                                                  \
+        const Fr d_ = sub(a_, b_);                                        \
+        B = e_ ? mul(d_, twiddle(tw_lo, tw_hi, e_)) : d_;                 \
+    }
+__global__ __launch_bounds__(256) void k_bn_dif3(Fr* __restrict__ data, unsigned log_n, unsigned log_h_first,
+                                                 const Fr* __restrict__ tw_lo, const Fr* __restrict__ tw_hi, uint32_t n_cols) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per_col = n >> 3;
+    if (t >= per_col * n_cols) return;
+    const size_t col = t / per_col, u = t % per_col;
+    const unsigned log_h_last = log_h_first - 2;
+    const size_t h = (size_t)1 << log_h_last;
+    const size_t off = u & (h - 1), grp = u >> log_h_last;
+    Fr* base = data + col * n + (grp << (log_h_first + 1)) + off;
+    Fr x0 = load(base), x1 = load(base + h), x2 = load(base + 2 * h), x3 = load(base + 3 * h), x4 = load(base + 4 * h),
+       x5 = load(base + 5 * h), x6 = load(base + 6 * h), x7 = load(base + 7 * h);
+    const unsigned s0 = log_n - 1 - log_h_first;
+    BN_BF(x0, x4, off, s0) BN_BF(x1, x5, h + off, s0) BN_BF(x2, x6, 2 * h + off, s0) BN_BF(x3, x7, 3 * h + off, s0)
+    BN_BF(x0, x2, off, s0 + 1) BN_BF(x1, x3, h + off, s0 + 1) BN_BF(x4, x6, off, s0 + 1) BN_BF(x5, x7, h + off, s0 + 1)
+    BN_BF(x0, x1, off, s0 + 2) BN_BF(x2, x3, off, s0 + 2) BN_BF(x4, x5, off, s0 + 2) BN_BF(x6, x7, off, s0 + 2)
+    store(base, x0); store(base + h, x1); store(base + 2 * h, x2); store(base + 3 * h, x3);
+    store(base + 4 * h, x4); store(base + 5 * h, x5); store(base + 6 * h, x6); store(base + 7 * h, x7);
+}
+#undef BN_BF
 
 // out[bitrev(i)] = in[i] * k  (the bit-reversal back to natural order, fused with the last scaling)
 __global__ __launch_bounds__(256) void k_bn_bitrev(const Fr* __restrict__ in, Fr* __restrict__ out, unsigned log_n, uint32_t n_cols,
@@ -265,28 +319,32 @@ int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_
     const size_t n = (size_t)1 << log_n, count = n * n_cols;
     const bool mont_io = flags & NLX_BN254_MONTGOMERY;
     // twiddle tables for w = w_n (or its inverse): lo[i] = w^i, hi[i] = w^(4096 i), Montgomery form
-    // (the tables live in the context, like the Goldilocks ones, and go with it)
+    // (the table lives in the context, like the Goldilocks ones, and goes with it: 32 n / 2 bytes, 268 MB at n = 2^24)
     struct { Fr* d_lo; Fr* d_hi; } tb;
-    std::pair<void*, void*>& slot = ctx->bn254_tables[log_n * 2 + (inverse ? 1 : 0)];
-    tb.d_lo = (Fr*)slot.first;
-    tb.d_hi = (Fr*)slot.second;
+    void*& slot = ctx->bn254_tables[log_n * 2 + (inverse ? 1 : 0)];
+    tb.d_lo = (Fr*)slot;
+    tb.d_hi = nullptr;
     if (!tb.d_lo) {
         Fr w = bn::h_pow(bn::from_limbs(bn::H_ROOT28), (uint64_t)1 << (28 - log_n));
         if (inverse) w = bn::h_inv(w);
-        const size_t half = n >> 1, n_hi = std::max<size_t>((half + 4095) >> 12, 1);
+        const size_t half = std::max<size_t>(n >> 1, 1), n_hi = std::max<size_t>((half + 4095) >> 12, 1);
         std::vector<Fr> lo(4096), hi(n_hi);
         lo[0] = bn::from_limbs(bn::H_ONE);
         for (size_t i = 1; i < 4096; i++) lo[i] = bn::mul(lo[i - 1], w);
         const Fr w4096 = bn::mul(lo[4095], w);
         hi[0] = lo[0];
         for (size_t i = 1; i < n_hi; i++) hi[i] = bn::mul(hi[i - 1], w4096);
-        tb.d_lo = (Fr*)ctx->alloc(4096 * sizeof(Fr));
-        tb.d_hi = (Fr*)ctx->alloc(n_hi * sizeof(Fr));
-        if (!tb.d_lo || !tb.d_hi) return NLX_E_NOMEM;
-        NLX_HIP(ctx, hipMemcpyAsync(tb.d_lo, lo.data(), 4096 * sizeof(Fr), hipMemcpyHostToDevice, st));
-        NLX_HIP(ctx, hipMemcpyAsync(tb.d_hi, hi.data(), n_hi * sizeof(Fr), hipMemcpyHostToDevice, st));
+        Fr* d_lo = (Fr*)ctx->alloc(4096 * sizeof(Fr));
+        Fr* d_hi = (Fr*)ctx->alloc(n_hi * sizeof(Fr));
+        tb.d_lo = (Fr*)ctx->alloc(half * sizeof(Fr));
+        if (!d_lo || !d_hi || !tb.d_lo) return NLX_E_NOMEM;
+        NLX_HIP(ctx, hipMemcpyAsync(d_lo, lo.data(), 4096 * sizeof(Fr), hipMemcpyHostToDevice, st));
+        NLX_HIP(ctx, hipMemcpyAsync(d_hi, hi.data(), n_hi * sizeof(Fr), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(bn::k_bn_fill_twiddles, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, tb.d_lo, half, d_lo, d_hi);
         NLX_HIP(ctx, hipStreamSynchronize(st));
-        slot = {tb.d_lo, tb.d_hi};
+        ctx->release(d_lo);
+        ctx->release(d_hi);
+        slot = tb.d_lo;
     }
     nlx::Staged s(ctx, cols, count * 32, true, true);
     if (s.status) return s.status;
@@ -302,7 +360,7 @@ int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_
         const int take = lvl >= 2 ? 3 : lvl + 1;
         const size_t nets = (n >> take) * n_cols;
         const unsigned blocks = (unsigned)((nets + 255) / 256);
-        if (take == 3) hipLaunchKernelGGL(bn::k_bn_dif<3>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols);
+        if (take == 3) hipLaunchKernelGGL(bn::k_bn_dif3, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols);
         else if (take == 2) hipLaunchKernelGGL(bn::k_bn_dif<2>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols);
         else hipLaunchKernelGGL(bn::k_bn_dif<1>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols);
         lvl -= take;

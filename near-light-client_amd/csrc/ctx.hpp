@@ -28,8 +28,8 @@ struct nlx_ctx {
     std::map<uint32_t, uint64_t*> coset_scale;
     // shift^i (natural order) tables for nlx_ntt_batch keyed by (log_n, shift)
     std::map<std::pair<uint32_t, uint64_t>, uint64_t*> nat_scale;
-    // BN254 Fr twiddle tables (csrc/bn254.hip) keyed by 2 log_n + inverse: {w^i : i < 4096}, {w^(4096 i)}
-    std::map<uint32_t, std::pair<void*, void*>> bn254_tables;
+    // BN254 Fr twiddle table (csrc/bn254.hip) keyed by 2 log_n + inverse: w_n^e for e < n/2
+    std::map<uint32_t, void*> bn254_tables;
 
     // Optional per-kernel device timing (HIP events on `stream` around selected launches); used by
     // bench.py to report the dominant kernel's average duration from inside the timed region.
