@@ -262,3 +262,20 @@ def test_device_buffer_roundtrip_and_use(nlx, ctx):
     assert cd.prove(w.ptr, syn.public_inputs) == cd.prove(syn.wires, syn.public_inputs)
     w.close()
     cd.close()
+
+
+def test_stream_priority_and_cu_mask_keep_results(nlx, orc):
+    """nlx_ctx_set_priority / nlx_ctx_set_cu_mask replace the context's stream: scheduling knobs, results unchanged"""
+    rng = np.random.default_rng(5)
+    vals = rand_field(rng, (9, 1 << 8))
+    want = orc.commit(vals, 3, 2)["cap"]
+    c = nlx.Context(0)
+    c.set_priority(True)
+    assert np.array_equal(nlx.PolynomialBatch.from_values(c, vals, 3, 2).cap, want)
+    c.set_cu_mask(range(0, 256, 4))          # a quarter of the chip
+    assert np.array_equal(nlx.PolynomialBatch.from_values(c, vals, 3, 2).cap, want)
+    c.set_priority(False)                    # back to an unrestricted, normal-priority stream
+    assert np.array_equal(nlx.PolynomialBatch.from_values(c, vals, 3, 2).cap, want)
+    with pytest.raises(nlx.NlxError):
+        c.set_cu_mask([])                    # a mask that selects no compute unit
+    c.close()
