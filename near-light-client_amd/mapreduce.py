@@ -117,6 +117,22 @@ def default_request(n_map, batch=4):
     return header, ids, batch
 
 
+def reference_request():
+    """The Verify request of the reference's own platform record (fixtures/verify_proof.json, kept as
+    tests/golden/near/succinct_requests.json): the trusted header hash and the 128 transaction / receipt ids, VERIFY_BATCH = 4
+    (nearx/src/config.rs:36-37) - BASELINE.json configs[3]'s input.  None if the fixture is not there."""
+    import json
+    import os
+    from . import nearx_io
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "near", "succinct_requests.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        raw = bytes.fromhex(json.load(f)["verify"]["input"][2:])
+    header, ids = nearx_io.decode_verify_input(raw)
+    return header, [h for _, h, _ in ids], 4
+
+
 def run_tree(plan, prove_fn, rank=0, world=1, dist=None, device=None, request=None):
     """Executes the whole tree.  prove_fn(kind, level, index, public_inputs) -> proof bytes, kind "map" | "reduce" |
     "outer", public_inputs = 8 field elements: for a map job a digest of the request slice it proves, for a reduce job
@@ -248,6 +264,8 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer=Non
     """bench.py --workload verify128: whole VerifyCircuit-128x4-shaped job per step, strong scaling."""
     import time
     plan = TreePlan(32)
+    # the request: the reference's own 128-id Verify request when its fixture is present (every rank reads the same file)
+    request = reference_request() or default_request(plan.n_map)
     ctx = nlx.Context(local)
     prover = GpuTreeProver(nlx, ctx, plan, args.map_log_n, args.reduce_log_n, torch=torch, workers=args.inflight)
     device = torch.device("cuda", local)
@@ -288,13 +306,13 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer=Non
     for _ in range(args.warmup):
         if sha is not None:
             map_starks()
-        root, _ = run_tree(plan, prover, rank, world, dist, device)
+        root, _ = run_tree(plan, prover, rank, world, dist, device, request)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if sha is not None:
             stark_ms += map_starks()
-        root, stats = run_tree(plan, prover, rank, world, dist, device)
+        root, stats = run_tree(plan, prover, rank, world, dist, device, request)
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -305,7 +323,7 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer=Non
         return None
     # what the job returned is checked before it is reported: the output lists every requested id as verified, in order
     # (bench.py, which may use the test oracle, additionally runs the oracle verifier on the outer proof)
-    header, ids, _ = default_request(plan.n_map)
+    header, ids, _ = request
     output_ok = succinct_io.decode_verify_output(stats["output"]) == [(i, True) for i in ids]
     outer_ok = None
     if verify_outer is not None:
@@ -321,7 +339,8 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer=Non
                                ("; plus, per rank, one SHA-256 STARK of the 2^11 blocks of every map job it owns" if sha is not None else ""),
                    "map_starks_ms_per_step_rank0": round(stark_ms / args.steps, 2) if sha is not None else None,
                    "jobs": plan.n_jobs, "proofs_in_flight_per_gpu": args.inflight,
-                   "level_ms_last_step": [[k, n, round(ms, 3)] for k, n, ms in stats["level_ms"]], "root_digest": [int(x) for x in root], "bytes_gathered_last_step": stats["bytes_gathered"],
+                   "level_ms_last_step": [[k, n, round(ms, 3)] for k, n, ms in stats["level_ms"]], "request": "fixtures/verify_proof.json: 128 real ids under header 0x%s" % request[0].hex() if reference_request() else "synthetic ids",
+                   "root_digest": [int(x) for x in root], "bytes_gathered_last_step": stats["bytes_gathered"],
                    "output_bytes": len(stats["output"]), "output_lists_every_id_as_verified": output_ok,
                    "oracle_verifier_accepts_outer_proof": outer_ok, "parallelism": "mapreduce x%d" % world},
         "roofline": None, "cpu_baseline": None,
