@@ -13,7 +13,9 @@
  *             root of p ("Sage: GF(p).multiplicative_generator()", the comment upstream carries), and
  *             upstream's quadratic-extension constant EXT_POWER_OF_TWO_GENERATOR = [0, 15659105665374529263]
  *             (order 2^33) squares to 7 * 15659105665374529263^2 = 1753635133440165772 - i.e. to THIS
- *             set's g_{2^32}, not to the other one's (tests/test_field_params.py checks the arithmetic).
+ *             set's g_{2^32}, not to the other one's; upstream's EXT_MULTIPLICATIVE_GROUP_GENERATOR
+ *             [18081566051660590251, 16121475356294670766] generates F_{p^2}^* under X^2 = 7 and its (p^2-1)/2^33-th power
+ *             is exactly that [0, 15659105665374529263] (tests/test_field_params.py checks the arithmetic).
  *   set 2021  g = 14293326489335486720, g_{2^32} = 7277203076849721926: self-consistent, carried by
  *             early-2021 plonky2, and the pair round 1 of this repository was built with.
  * Default: set 7.  Build the other one with -DNLX_GL_GENERATOR_SET=2021 (build.py and oracle_py.py do

@@ -35,6 +35,39 @@ def test_default_matches_upstream_extension_generator():
     assert pow(sq, 1 << 31, P) == P - 1
 
 
+def test_upstream_extension_generators_fit_set_7_only():
+    """Two more constants of plonky2_field's quadratic extension, recalled independently of each other:
+    EXT_MULTIPLICATIVE_GROUP_GENERATOR = [18081566051660590251, 16121475356294670766] and
+    EXT_POWER_OF_TWO_GENERATOR = [0, 15659105665374529263].  Under X^2 = 7 the first one generates all of F_{p^2}^*
+    (order p^2 - 1 = 2^33 * 3 * 5 * 7 * 17 * 179 * 257 * 65537 * 7361031152998637: no proper divisor kills it) and its
+    (p^2 - 1) / 2^33-th power is EXACTLY the second one - so the three recollections (W = 7 and the two generators) agree
+    with each other, and the second one's square is set 7's base-field POWER_OF_TWO_GENERATOR (previous test)."""
+    w = 7
+
+    def mul(a, b):
+        return ((a[0] * b[0] + w * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+    def power(a, e):
+        r = (1, 0)
+        while e:
+            if e & 1:
+                r = mul(r, a)
+            a = mul(a, a)
+            e >>= 1
+        return r
+    factors = (2, 3, 5, 7, 17, 179, 257, 65537, 7361031152998637)
+    order = P * P - 1
+    rest = order
+    for q in factors:
+        while rest % q == 0:
+            rest //= q
+    assert rest == 1                                            # the factorisation of p^2 - 1 is complete
+    g = (18081566051660590251, 16121475356294670766)
+    assert power(g, order) == (1, 0) and all(power(g, order // q) != (1, 0) for q in factors)
+    assert power(g, order >> 33) == (0, 15659105665374529263)
+    assert pow(7, (P - 1) // 2, P) == P - 1                     # 7 is a non-residue: X^2 - 7 is irreducible
+
+
 def test_oracle_and_golden_use_the_header_pair(orc, golden):
     assert orc.generators() == (GEN, POW2_GEN)
     assert golden["field"]["generator"] == GEN and golden["field"]["pow2_generator"] == POW2_GEN
