@@ -613,21 +613,17 @@ def sync_step_setup(args, nlx, torch, rank, local):
         bps = json.load(f)["body"]["next_bps"]
     with open(os.path.join(near, "main_2.json")) as f:
         nxt = json.load(f)["body"]
-    msg = NP.reconstruct_approval_message(nxt)
     sha_msgs = NP.sync_sha256_messages(nxt)
-    sig_msgs, slots = [], []
-    for sig, bp in zip(nxt["approvals_after_next"], bps):
-        if sig is None:
-            continue
-        pk, raw = NP._key_bytes(bp["public_key"], 32), NP._key_bytes(sig, 64)
-        sig_msgs.append(raw[:32] + pk + msg)
-        slots.append(E.slot_from_signature(pk, msg, raw))
-    n_sigs = len(slots)
-    st = {"n_sigs": n_sigs, "sha_msgs": sha_msgs, "sig_msgs": sig_msgs, "slots": slots, "nxt": nxt}
+    # one Ed25519 slot per validator of the epoch (validate_signatures<LEN>): active where the block carries its approval
+    stmt = NP.approval_statement(bps, nxt)
+    sig_msgs, slots = stmt["sig_msgs"], stmt["slots"]
+    n_sigs = len(sig_msgs)
+    st = {"n_sigs": n_sigs, "n_validators": len(slots), "sha_msgs": sha_msgs, "sig_msgs": sig_msgs, "slots": slots, "nxt": nxt,
+          "statement": stmt}
     st["lb256"] = max(2, (sum(len(SA.pad_message(m)) for m in sha_msgs) - 1).bit_length())
     st["lb512"] = max(2, (n_sigs - 1).bit_length())
-    st["log_slots"] = max(4, (n_sigs - 1).bit_length())   # below 2^8 slots the range table is spread over several columns
-    st["bound_slots"] = (slots * ((1 << st["log_slots"]) // n_sigs + 1))[: 1 << st["log_slots"]]
+    st["log_slots"] = max(4, (len(slots) - 1).bit_length())   # below 2^8 slots the range table is spread over several columns
+    st["bound_slots"] = slots + [E.inactive_slot()] * ((1 << st["log_slots"]) - len(slots))
     st["slot_words"] = E.slots_to_words(st["bound_slots"])
     # the four proofs get a context (HIP stream + scratch) each
     ctxs = [nlx.Context(local) for _ in range(4)]
@@ -791,12 +787,12 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
             "scaling": "weak", "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer)",
             "data": "synthetic outer circuit of SyncCircuit's static shape; the three STARK statements are the real mainnet Sync step main_1 -> main_2 (the reference's fixtures), traces generated on the GPU",
             "config": {"workload": "one full Sync proof = SHA-256 STARK of %d header / next_bps messages (2^%d blocks, 2^%d x %d trace) + "
-                                   "SHA-512 STARK of %d approval hashes (2^%d blocks) + Ed25519 STARK of %d approval signatures (2^%d "
-                                   "slots, 2^%d rows) + outer plonky2 proof (standard_recursion_config, 2^%d rows, 135 wires, %d gate "
+                                   "SHA-512 STARK of %d approval hashes (2^%d blocks) + Ed25519 STARK of %d validator slots, %d of them active = "
+                                   "signed approvals, D mod L reduced in the AIR (2^%d slots, 2^%d rows) + outer plonky2 proof (standard_recursion_config, 2^%d rows, 135 wires, %d gate "
                                    "kinds); the outer proof of a step starts when its three STARKs are done, the next step's "
                                    "STARKs overlap it; replicas only"
                                    % (len(st["sha_msgs"]), st["lb256"], st["lb256"] + 2, p256.stark.desc.n_cols, st["n_sigs"], st["lb512"],
-                                      st["n_sigs"], st["log_slots"], ped.stark.desc.degree_bits, args.log_n, st["syn"].num_gates),
+                                      st["n_validators"], st["n_sigs"], st["log_slots"], ped.stark.desc.degree_bits, args.log_n, st["syn"].num_gates),
                        "log_n_outer": args.log_n, "gate_mix_pct": GATE_MIXES[args.gate_mix],
                        "outer_rows_floor_from_stark_verification": rows,
                        "public_inputs": "64 bytes of real Sync I/O (fixtures/main_2.json): new head hash 0x%s" % st["sync_out"].hex(),
@@ -820,7 +816,7 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
         if not args.no_extra:
             out["plonky2_only"].update(outer_only_figures(nlx, ctxs, local, torch, rank, 16, args.gate_mix))
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"], out["parity_checked"] = cpu_baseline_sync(args, nlx, st, a, b, seq_ms)
+            out["cpu_baseline"], out["parity_checked"] = cpu_baseline_sync(args, nlx, st, a, b, c_proof, seq_ms)
         else:
             out["cpu_baseline"] = None
         out["outer_proof_sha256"] = hashlib.sha256(outer_proof).hexdigest()
@@ -866,7 +862,7 @@ def outer_only_figures(nlx, ctxs, local, torch, rank, log_n, gate_mix):
             "log_n_%d_proofs_per_s_three_in_flight" % log_n: round(1e3 / three, 1)}
 
 
-def cpu_baseline_sync(args, nlx, st, sha256_result, sha512_result, gpu_seq_ms):
+def cpu_baseline_sync(args, nlx, st, sha256_result, sha512_result, ed25519_proof, gpu_seq_ms):
     """The oracle (C port, OpenMP) on a bounded sample of the same Sync step, on the GPU box's host cores:
     outer proof at 2^15 rows (scaled linearly to 2^log_n), the SHA-256 and SHA-512 STARKs at full size, the Ed25519 STARK
     at 2^5 slots (scaled linearly to the step's slots).  The same inputs are proved on the GPU and the BYTES compared."""
@@ -909,6 +905,20 @@ def cpu_baseline_sync(args, nlx, st, sha256_result, sha512_result, gpu_seq_ms):
     want = oracle_py.stark_prove_rounds(st["p512"].stark.desc, SB.cpu_rounds(blocks, first, tr), SB.digest_halves(digest))
     t512 = time.time() - t
     parity["sha512"] = {"log_blocks": st["lb512"], "bytes_equal": want == sha512_result[0]}
+    # the relying party's side of the two bindings (post-timing; the oracle only parses the proofs' round values): the
+    # SHA-512 proof's fingerprint covers every block and chaining value of the approvals' hashes, the Ed25519 proof's
+    # covers (A, R, S, D, active) of every validator slot - with D taken from the SAME chaining values, so the digests
+    # the curve equation used are the ones the SHA-512 proof is about
+    v512 = oracle_py.stark_values(st["p512"].stark.desc, sha512_result[0])
+    ved = oracle_py.stark_values(st["ped"].stark.desc, ed25519_proof)
+    outs = SB.block_outputs(blocks, first)
+    ends = [i for i in range(len(blocks)) if i + 1 == len(blocks) or first[i + 1]][-st["n_sigs"]:]   # filler messages come first
+    tied = nlx.near_protocol.slots_with_digests(st["statement"], [outs[i] for i in ends])
+    tied += [E.inactive_slot()] * ((1 << st["log_slots"]) - len(tied))
+    parity["bindings"] = {"bytes_equal": tuple(v512[18:20]) == SB.fingerprint(blocks, first, v512[16:18])
+                          and tuple(ved[4:6]) == E.fingerprint(tied, ved[2:4]),
+                          "note": "SHA-512 and Ed25519 round values recomputed from the step's public data; the Ed25519 slots' D = the "
+                                  "SHA-512 proof's digests"}
     # Ed25519: 2^5 slots of the step's signatures
     s_slots = min(5, st["log_slots"])
     pr2 = E.Ed25519Prover(ctx, s_slots)

@@ -170,7 +170,7 @@ Staged::~Staged() {
 
 extern "C" {
 
-uint32_t nlx_version(void) { return (0u << 16) | 2u; }
+uint32_t nlx_version(void) { return (0u << 16) | 3u; }
 
 void nlx_field_generators(uint64_t out[2]) {
     out[0] = gl::GEN;

@@ -15,8 +15,11 @@ constexpr int ROWS = 256, N_MAIN = 15, UNIT_CELLS = fp::UNIT_CELLS;
 constexpr uint32_t cSIN = 0, cSB = 48, cHB = 49, cSA = 50, cHA = 51, cAX = 52, cAY = 68, cRX = 84, cRY = 100, cNT = 116,
                    cSW = 132, cHW = 148, cCHK = 164, cSAA = 168, cSBB = 184, cSCC = 200, cSX3 = 216, cSY3 = 232, cSZ3 = 248,
                    cSPT = 264, cP2 = 280, cMAIN = 344, cAUX_A = cMAIN + N_MAIN * UNIT_CELLS, cAUX_B = cAUX_A + 16,
-                   cAUX_E = cAUX_B + 16, cAUX_F = cAUX_E + 16, cAUX = cAUX_F + 16, cMULT9 = cAUX + UNIT_CELLS,
+                   cAUX_E = cAUX_B + 16, cAUX_F = cAUX_E + 16, cAUX = cAUX_F + 16, cACT = cAUX + UNIT_CELLS, cDW = cACT + 1,
+                   cQW = cDW + 32, cCHKQ = cQW + 17, cCLO = cCHKQ + 2, cDH = cCLO + 1, cDS = cDH + 1, cCHI = cDS + 1,
+                   cBH = cCHI + 1, cBS = cBH + 1, cMULT9 = cBS + 1,
                    cMULT = cMULT9 + 1, N_COLS0 = cMULT + 1;  // further multiplicity columns of a spread table follow (caller's)
+constexpr int SLOT_WORDS = 32, MODL_ROWS = 32;
 enum { U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2, U_PA, U_PB, U_PC, U_PD, U_X4, U_Y4, U_Z4 };
 enum { STEP_YCMP = 0, STEP_A_U = 1, STEP_A_NT = 2, STEP_A_U2 = 3, STEP_A_V = 4, STEP_A_CHK = 5, STEP_R_U = 6, STEP_R_V = 7,
        STEP_R_CHK = 8, STEP_S_AA = 9, STEP_S_BB = 10, STEP_S_CC = 11, STEP_S_X = 12, STEP_S_Y = 13, STEP_S_Z = 14, STEP_S_T = 15,
@@ -58,7 +61,75 @@ struct Point { uint32_t x[16], y[16], z[16]; };  // reduced limbs
 struct Slot {
     uint32_t ax[16], ay[16], rx[16], ry[16], nt[16], sw[16], hw[16];
     uint32_t saa[16], sbb[16], scc[16], sx3[16], sy3[16], sz3[16], st3[16], spt[16];
+    // the reduction h = D mod L and the two comparisons (ed25519_air.py modl_witness)
+    uint32_t dw[32], qw[17], carry[MODL_ROWS + 1], dh[16], ds[16];
+    uint32_t bh, bs;      // bit j: the carry into limb j of h + (L - 1 - h) / S + (L - 1 - S)
+    uint32_t active;      // 1: the slot's three checks are on
+    uint32_t s_in_range;  // 0: S >= L (no witness for the comparison)
 };
+
+// the group order L = 2^252 + 27742317777372353535851937790883648493, 16-bit limbs
+static constexpr uint16_t L_LIMBS[16] = {0xd3ed, 0x5cf5, 0x631a, 0x5812, 0x9cd6, 0xa2f7, 0xf9de, 0x14de, 0, 0, 0, 0, 0, 0, 0, 0x1000};
+
+// h = D mod L, q = D div L and the carries of q L + h = D position by position; L - 1 - h, L - 1 - S with their carry bits.
+// Long division by 16-bit digits: L = 2^252 + c with c < 2^125, so floor(R / 2^252) is the quotient digit or one more.
+FP_HD inline void modl_witness(Slot& s) {
+    uint32_t rem[18];
+    for (int i = 0; i < 18; i++) rem[i] = 0;
+    for (int i = 0; i < 17; i++) s.qw[i] = 0;
+    for (int k = 31; k >= 0; k--) {
+        for (int i = 17; i > 0; i--) rem[i] = rem[i - 1];   // rem = rem * 2^16 + D_k  (rem < L, so 17 limbs + the new one)
+        rem[0] = s.dw[k];
+        uint32_t digit = ((rem[16] << 16) | rem[15]) >> 12;   // floor(rem / 2^252); rem < 2^269
+        // rem -= digit * L
+        int64_t borrow = 0;
+        for (int i = 0; i < 18; i++) {
+            const int64_t v = (int64_t)rem[i] - (i < 16 ? (int64_t)digit * L_LIMBS[i] : 0) + borrow;
+            rem[i] = (uint32_t)(v & 0xFFFF);
+            borrow = v >> 16;   // arithmetic shift: floor
+        }
+        if (borrow < 0) {       // one too many: add L back
+            digit--;
+            uint32_t c = 0;
+            for (int i = 0; i < 18; i++) {
+                const uint32_t v = rem[i] + (i < 16 ? L_LIMBS[i] : 0u) + c;
+                rem[i] = v & 0xFFFF;
+                c = v >> 16;
+            }
+        }
+        if (k < 17) s.qw[k] = digit;   // D < 2^512 and L > 2^252: the digits above position 16 are zero
+    }
+    for (int i = 0; i < 16; i++) s.hw[i] = rem[i];
+    uint64_t c = 0;
+    s.carry[0] = 0;
+    for (int k = 0; k < MODL_ROWS; k++) {
+        uint64_t tot = c + (k < 16 ? s.hw[k] : 0u);
+        for (int i = 0; i < 17; i++)
+            if (k - i >= 0 && k - i < 16) tot += (uint64_t)s.qw[i] * L_LIMBS[k - i];
+        c = (tot - s.dw[k]) >> 16;   // tot = D_k (mod 2^16) and tot >= D_k
+        s.carry[k + 1] = (uint32_t)c;
+    }
+    // complements: x + (L - 1 - x) = L - 1 limb by limb
+    s.s_in_range = 1;
+    for (int which = 0; which < 2; which++) {
+        const uint32_t* x = which ? s.sw : s.hw;
+        uint32_t* comp = which ? s.ds : s.dh;
+        int32_t borrow = 0;
+        for (int i = 0; i < 16; i++) {   // comp = L - 1 - x
+            const int32_t v = (int32_t)L_LIMBS[i] - (i == 0 ? 1 : 0) - (int32_t)x[i] + borrow;
+            comp[i] = (uint32_t)(v & 0xFFFF);
+            borrow = v >> 16;
+        }
+        if (borrow < 0 && which) s.s_in_range = 0;
+        uint32_t bits = 0, cb = 0;
+        for (int i = 0; i < 16; i++) {
+            const uint32_t lm1 = (uint32_t)L_LIMBS[i] - (i == 0 ? 1u : 0u);
+            cb = (x[i] + comp[i] + cb - lm1) >> 16 & 1u;
+            if (i < 15) bits |= cb << (i + 1);
+        }
+        (which ? s.bs : s.bh) = bits;
+    }
+}
 
 // the linear combinations the B - A addition multiplies: E = BB - AA, H = BB + AA, F = CC' + 2, G = 2 - CC'
 FP_HD inline void sum_operands(const Slot& s, limbs_t e, limbs_t f, limbs_t g, limbs_t h) {
@@ -71,10 +142,13 @@ FP_HD inline void sum_operands(const Slot& s, limbs_t e, limbs_t f, limbs_t g, l
     }
 }
 
-FP_HD inline void slot_from_words(const uint64_t* w /* ax ay rx ry s h: 6 x 4 words */, Slot& s) {
-    uint32_t* dst[6] = {s.ax, s.ay, s.rx, s.ry, s.sw, s.hw};
-    for (int v = 0; v < 6; v++)
+FP_HD inline void slot_from_words(const uint64_t* w /* ax ay rx ry s: 5 x 4 words, D: 8 words, active, 3 spare */, Slot& s) {
+    uint32_t* dst[5] = {s.ax, s.ay, s.rx, s.ry, s.sw};
+    for (int v = 0; v < 5; v++)
         for (int i = 0; i < 16; i++) dst[v][i] = (uint32_t)((w[4 * v + (i >> 2)] >> (16 * (i & 3))) & 0xFFFF);
+    for (int i = 0; i < 32; i++) s.dw[i] = (uint32_t)((w[20 + (i >> 2)] >> (16 * (i & 3))) & 0xFFFF);
+    s.active = (uint32_t)(w[28] & 1);
+    modl_witness(s);
     limbs_t a, b, k;
     fp::Unit u;
     auto store = [&](uint32_t* out) { for (int i = 0; i < 16; i++) out[i] = u.c[i]; };
@@ -216,7 +290,10 @@ struct AuxRow {
     limbs_t a, b, e, f;
     fp::Unit u;
 };
-FP_HD inline bool row_aux(int r, const Slot& s, const Point& out, const uint32_t* prev_ry, const Point* prev_final, AuxRow& x) {
+// prev_active: the previous slot's flag (row 0 holds ITS Y comparison).  The three checks of an inactive slot run with a
+// free result (the canonical product) instead of the value the check demands.
+FP_HD inline bool row_aux(int r, const Slot& s, const Point& out, const uint32_t* prev_ry, const Point* prev_final, bool prev_active,
+                          AuxRow& x) {
     for (int i = 0; i < 16; i++) x.a[i] = x.b[i] = x.e[i] = x.f[i] = 0;
     const uint32_t* fixed = nullptr;
     uint32_t cfix[16];
@@ -235,7 +312,7 @@ FP_HD inline bool row_aux(int r, const Slot& s, const Point& out, const uint32_t
             vcopy(prev_ry, x.a);
             vcopy(prev_final->z, x.b);
             for (int i = 0; i < 16; i++) cfix[i] = prev_final->y[i];
-            fixed = cfix;
+            if (prev_active) fixed = cfix;
             break;
         case STEP_A_U: case STEP_A_U2: vcopy(s.ax, x.a); vcopy(s.ay, x.b); break;
         case STEP_A_NT: xy_of(s.ax, s.ay, t); const_limbs(K_D2, x.a); vcopy(t.c, x.b); break;
@@ -255,7 +332,7 @@ FP_HD inline bool row_aux(int r, const Slot& s, const Point& out, const uint32_t
             limbs_t m1;
             const_limbs(K_M1, m1);
             for (int i = 0; i < 16; i++) cfix[i] = (uint32_t)m1[i];
-            fixed = cfix;
+            if (s.active) fixed = cfix;
             break;
         }
         case STEP_S_AA: vadd(s.ay, s.ax, x.a); const_limbs(K_B_YMX, x.b); break;
@@ -270,7 +347,7 @@ FP_HD inline bool row_aux(int r, const Slot& s, const Point& out, const uint32_t
             vcopy(s.rx, x.a);
             vcopy(out.z, x.b);
             for (int i = 0; i < 16; i++) cfix[i] = out.x[i];
-            fixed = cfix;
+            if (s.active) fixed = cfix;
             break;
         default: break;
     }
@@ -354,8 +431,8 @@ struct EmitSink {
 FP_HD inline uint64_t gl_signed(int32_t v) { return v >= 0 ? (uint64_t)v : 0xFFFFFFFF00000001ull - (uint64_t)(-(int64_t)v); }
 
 template <class Put>
-FP_HD inline bool emit_row(int r, const Slot& s, const Point& in, const uint32_t* prev_ry, const Point* prev_final, Put& put,
-                           Point& out) {
+FP_HD inline bool emit_row(int r, const Slot& s, const Point& in, const uint32_t* prev_ry, const Point* prev_final, bool prev_active,
+                           Put& put, Point& out) {
     const int bit = ROWS - 1 - r;
     const int sbit = (int)((s.sw[bit >> 4] >> (bit & 15)) & 1), hbit = (int)((s.hw[bit >> 4] >> (bit & 15)) & 1);
     // limb accumulators: the bits of this limb seen so far, MSB first
@@ -391,6 +468,21 @@ FP_HD inline bool emit_row(int r, const Slot& s, const Point& in, const uint32_t
         put(cCHK + 1, close ? s.ay[j] : 0u);
         put(cCHK + 2, close ? s.rx[j] : 0u);
         put(cCHK + 3, close ? s.ry[j] : 0u);
+        put(cCHKQ, close ? s.qw[j] : 0u);
+        put(cCHKQ + 1, r == ROWS - 1 ? s.qw[16] : 0u);
+    }
+    {
+        // the reduction mod L: per-slot D and q, the carry into position r, the complements' limb r and carry bits
+        put(cACT, s.active);
+        for (int i = 0; i < 32; i++) put(cDW + i, s.dw[i]);
+        for (int i = 0; i < 17; i++) put(cQW + i, s.qw[i]);
+        const uint32_t c = r <= MODL_ROWS ? s.carry[r] : 0u;
+        put(cCLO, c & 0xFFFF);
+        put(cCHI, c >> 16);
+        put(cDH, r < 16 ? s.dh[r] : 0u);
+        put(cDS, r < 16 ? s.ds[r] : 0u);
+        put(cBH, r < 16 ? (s.bh >> r) & 1u : 0u);
+        put(cBS, r < 16 ? (s.bs >> r) & 1u : 0u);
     }
     {
         limbs_t ymx, ypx, t2d, z2;
@@ -405,7 +497,7 @@ FP_HD inline bool emit_row(int r, const Slot& s, const Point& in, const uint32_t
     EmitSink<Put> sink{put};
     row_main(sink, in, sbit, hbit, s, out);
     AuxRow ax;
-    const bool ok = row_aux(r, s, out, prev_ry, prev_final, ax);
+    const bool ok = row_aux(r, s, out, prev_ry, prev_final, prev_active, ax);   // S >= L (s.s_in_range == 0) is the caller's to report
     for (int i = 0; i < 16; i++) {
         put(cAUX_A + i, gl_signed(ax.a[i]));
         put(cAUX_B + i, gl_signed(ax.b[i]));

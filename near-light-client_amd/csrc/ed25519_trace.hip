@@ -5,7 +5,7 @@
 //              records the input point of every row - the only sequential part, on values only (fe25519_fast.hpp:
 //              26-bit limbs, no witness cells; canonical results, so identical to what the row emitter recomputes);
 //   k_ed_rows  one lane per row recomputes its 16 units from that input point (results are canonical, so the
-//              recomputation is bit-identical) and writes its 1 418 cells; a wave's 64 lanes are 64 consecutive rows,
+//              recomputation is bit-identical) and writes its 1 476 cells; a wave's 64 lanes are 64 consecutive rows,
 //              so every column store is 512 contiguous bytes.
 #include "ctx.hpp"
 #include "ed25519_rows.hpp"
@@ -22,7 +22,7 @@ __global__ __launch_bounds__(64) void k_ed_scan(const uint64_t* __restrict__ wor
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_slots) return;
     ed::Slot s;
-    ed::slot_from_words(words + (size_t)k * 24, s);
+    ed::slot_from_words(words + (size_t)k * ed::SLOT_WORDS, s);
     slots[k] = s;
     ed::FastSlot fs;
     ed::fast_slot(s, fs);
@@ -64,25 +64,31 @@ __global__ __launch_bounds__(64) void k_ed_rows(const ed::Slot* __restrict__ slo
     const ed::Point p = in[row];
     ed::Point prev_fin;
     uint32_t prev_ry[16];
+    bool prev_active = true;
     if (r == ed::STEP_YCMP) {
         prev_fin = fin[prev];
         for (int i = 0; i < 16; i++) prev_ry[i] = slots[prev].ry[i];
+        prev_active = slots[prev].active != 0;
     }
     TracePut put{trace, n, row};
     ed::Point o;
     // row 0 checks the previous slot's Y comparison
-    if (!ed::emit_row(r, s, p, prev_ry, &prev_fin, put, o)) atomicMin(bad_slot, r == ed::STEP_YCMP ? prev : k);
+    if (!ed::emit_row(r, s, p, prev_ry, &prev_fin, prev_active, put, o)) atomicMin(bad_slot, r == ed::STEP_YCMP ? prev : k);
+    if (r == 1 && !s.s_in_range) atomicMin(bad_slot, k);   // S >= L: the comparison rows have no witness
 }
 
 // ---- binding accumulator (round 1): Horner fingerprint in F_p^2 of every slot's limbs, limb 15 first, in the order
-// A.x, A.y, R.x, R.y, S, h ----
+// A.x, A.y, R.x, R.y, S, D low half, D high half, active (a one-limb value: zero above limb 0) ----
+constexpr int ED_BOUND = 8;   // values absorbed per limb index
 __device__ __forceinline__ gl::Ext absorb_limb(gl::Ext acc, gl::Ext gamma, const uint64_t* __restrict__ trace, size_t n, size_t row, int j) {
-    const uint32_t base[6] = {ed::cAX, ed::cAY, ed::cRX, ed::cRY, ed::cSW, ed::cHW};
+    const uint32_t base[ED_BOUND - 1] = {ed::cAX, ed::cAY, ed::cRX, ed::cRY, ed::cSW, ed::cDW, ed::cDW + 16};
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
+    for (int k = 0; k < ED_BOUND - 1; k++) {
         acc = gl::mul(acc, gamma);
         acc.a = gl::add(acc.a, trace[(size_t)(base[k] + j) * n + row]);
     }
+    acc = gl::mul(acc, gamma);
+    if (j == 0) acc.a = gl::add(acc.a, trace[(size_t)ed::cACT * n + row]);
     return acc;
 }
 
@@ -135,12 +141,12 @@ extern "C" int32_t nlx_ed25519_bind_round(nlx_ctx* ctx, const uint64_t* trace, u
     std::vector<gl::Ext> fp_h(n_slots), start(n_slots);
     int32_t rc = fetch(ctx, fp_h.data(), d_fp, (size_t)n_slots * sizeof(gl::Ext));
     if (!rc) {
-        // the slots' start values: acc_(s+1) = acc_s gamma^96 + fp_s (a few thousand extension multiplications, on the host)
-        const gl::Ext g96 = gl::pow(g, 96);
+        // the slots' start values: acc_(s+1) = acc_s gamma^128 + fp_s (a few thousand extension multiplications, on the host)
+        const gl::Ext g_slot = gl::pow(g, 16 * ED_BOUND);
         gl::Ext acc{0, 0};
         for (uint32_t k = 0; k < n_slots; k++) {
             start[k] = acc;
-            acc = gl::add(gl::mul(acc, g96), fp_h[k]);
+            acc = gl::add(gl::mul(acc, g_slot), fp_h[k]);
         }
         total_out[0] = acc.a;
         total_out[1] = acc.b;
@@ -168,7 +174,7 @@ extern "C" int32_t nlx_ed25519_trace(nlx_ctx* ctx, const uint64_t* slots, uint32
     (void)hipSetDevice(ctx->device);
     const uint32_t n_slots = 1u << log_slots;
     const size_t n = (size_t)n_slots * ed::ROWS;
-    Staged sw(ctx, slots, (size_t)n_slots * 24 * 8, true, false);
+    Staged sw(ctx, slots, (size_t)n_slots * ed::SLOT_WORDS * 8, true, false);
     if (sw.status) return sw.status;
     Staged st(ctx, trace_out, (size_t)ed::N_COLS0 * n * 8, false, true);
     if (st.status) return st.status;
@@ -195,7 +201,7 @@ extern "C" int32_t nlx_ed25519_trace(nlx_ctx* ctx, const uint64_t* slots, uint32
     if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
     if (!rc && e0 != hipSuccess) rc = ctx->hip_fail(e0, "hipMemcpyAsync");
     if (!rc && bad != 0xFFFFFFFFu)
-        rc = ctx->fail(NLX_E_INVAL, "slot %u: the statement is false (the signature does not verify, or A / R is not on the curve); "
-                                    "the trace was written but cannot satisfy the AIR", bad);
+        rc = ctx->fail(NLX_E_INVAL, "slot %u: the statement is false (the signature does not verify, A / R is not on the curve, or "
+                                    "S >= L); the trace was written but cannot satisfy the AIR", bad);
     return rc;
 }

@@ -3,10 +3,16 @@ nearx/src/builder.rs:152 - the largest share of a Sync proof; curta's own tables
 Cargo.lock:6515, so this is an independent construction on the pieces of this package: fp25519 units, logup range
 checks, the multi-round prover).
 
-Statement per signature slot (256 consecutive rows):  [S] B + [h] (-A) = R  on the twisted Edwards curve
--x^2 + y^2 = 1 + d x^2 y^2 over F_p, p = 2^255 - 19, for the slot's A = (AX, AY), R = (RX, RY) (affine, 16-bit limbs),
-S and h (16 limbs each; h is the SHA-512 digest already reduced mod L - sha512_air.py proves the digest itself), with
-A and R checked to be on the curve.  Row r of a slot handles bit 255 - r of both scalars (Shamir's trick):
+Statement per signature slot (256 consecutive rows), for the slot's A = (AX, AY), R = (RX, RY) (affine, 16-bit limbs),
+S (16 limbs), D (32 limbs: the 512-bit SHA-512 digest of R || A || M read as a little-endian integer - sha512_air.py
+proves the digest itself) and the flag `active`:
+
+    h = D mod L   (0 <= h < L, D = q L + h limb by limb with range-checked q and carries),   S < L,   and, IF active:
+    A and R are on the twisted Edwards curve -x^2 + y^2 = 1 + d x^2 y^2 over F_p, p = 2^255 - 19, and [S] B + [h] (-A) = R.
+
+An inactive slot (`curta_eddsa_verify_sigs_conditional`'s is_active = false, nearx/src/builder.rs:137-158: a validator that
+did not sign, or the dummy key) runs the same rows with its three checks switched off.  Row r of a slot handles bit
+255 - r of both scalars (Shamir's trick):
 
     Q <- 2 Q                                      8 units   (dbl-2008-hwcd, a = -1)
     Q <- Q + (0 | B | -A | B - A)                 7 units   (add-2008-hwcd-3 with the addend in the precomputed form
@@ -20,12 +26,16 @@ range-checked cell, a constant, or a cell tied by a degree <= 3 constraint to on
 and carries (and, once per slot, the limbs of A and R) go through the 2^16-table lookup (the carries' high parts through
 a 2^9 table).  Constraint degree 3, two commitment rounds (the second is logup.py's columns for the two tables).
 
+The reduction mod L (rows 0 .. 31 of a slot, one 16-bit position of D = q L + h per row; rows 0 .. 15 also carry the two
+comparisons h <= L - 1 and S <= L - 1 as additions h + d = L - 1 with range-checked d): q sits in 17 per-slot columns, the
+carries in two looked-up cells per row, everything of degree 2.
+
 Binding to public data: a fifth and sixth challenge gamma (drawn with the lookup challenge, after round 0) and a
-round-1 accumulator column fold every slot's 96 limbs (A, R, S, h) into one Horner fingerprint in the quadratic
-extension; its total is a ROUND VALUE of the proof (stark.py).  Whoever relies on the proof recomputes
-`fingerprint(slots, gamma)` from the tuples it believes were verified and compares.  The reduction of the 512-bit
-SHA-512 digest mod L is left to the caller.  The check is the cofactorless one
-(ed25519-dalek's `verify`: [S]B - [h]A == R).
+round-1 accumulator column fold every slot's 128 limbs (A, R, S, D low half, D high half, active) into one Horner
+fingerprint in the quadratic extension; its total is a ROUND VALUE of the proof (stark.py).  Whoever relies on the proof
+recomputes `fingerprint(slots, gamma)` from the tuples it believes were verified - public keys, signatures, SHA-512
+digests, activity flags - and compares; h never leaves the proof.  The check is the cofactorless one (ed25519-dalek's
+`verify`: [S]B - [h]A == R).
 """
 import numpy as np
 
@@ -93,6 +103,15 @@ N_MAIN = 15
 MAIN = [LAY.take_unit() for _ in range(N_MAIN)]
 AUX_A, AUX_B, AUX_E, AUX_F = (LAY.take(16) for _ in range(4))
 AUX = LAY.take_unit()
+ACT = LAY.take(1)                                # per slot: 1 = the signature is checked, 0 = the three checks are off
+DW = LAY.take(32)                                # per slot: the 512-bit digest D, 16-bit limbs
+QW = LAY.take(17)                                # per slot: q = D div L
+CHKQ = LAY.take(2, True)                         # range check of q: limb j on the row that closes block j; limb 16 on the slot's last row
+CLO = LAY.take(1, True)                          # row k < 32: carry into position k of q L + h = D (low 16 bits) ...
+DH, DS = LAY.take(1, True), LAY.take(1, True)    # row j < 16: limb j of L - 1 - h and of L - 1 - S
+CHI = LAY.take(1)                                # ... and its high part (2^9 table)
+LAY.lookups9.append(CHI)
+BH, BS = LAY.take(1), LAY.take(1)                # row j <= 16: carry bit into limb j of h + (L - 1 - h) and S + (L - 1 - S)
 MULT9, MULT = LAY.take(1), LAY.take(1)     # multiplicities of the 2^9 table, then (last: it may grow) of the 2^16 table
 LOOKUPS, LOOKUPS9 = list(LAY.lookups16), list(LAY.lookups9)
 
@@ -107,7 +126,11 @@ def layout(table_cols=1):
 
 
 N_COLS0, N_COLS1A, N_COLS1B, ACC, N_COLS1 = (layout()[k] for k in ("n_cols0", "n_cols1a", "n_cols1b", "acc", "n_cols1"))
-BOUND = (AX, AY, RX, RY, SW, HW)           # the per-slot limb vectors the fingerprint absorbs, limb 15 first
+BOUND = (AX, AY, RX, RY, SW, DW, DW + 16)  # the per-slot limb vectors the fingerprint absorbs, limb 15 first; then `active` (limb 0 only)
+N_BOUND = len(BOUND) + 1                   # values per limb index
+L_LIMBS = [(L_ORDER >> (16 * i)) & 0xFFFF for i in range(16)]
+LM1_LIMBS = [((L_ORDER - 1) >> (16 * i)) & 0xFFFF for i in range(16)]
+MODL_ROWS = 32                             # positions of D = q L + h, one per row from the slot's first row
 # main unit indices
 (U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2, U_PA, U_PB, U_PC, U_PD, U_X4, U_Y4, U_Z4) = range(N_MAIN)
 AUX_STEPS = {"ycmp": 0, "a_u": 1, "a_nt": 2, "a_u2": 3, "a_v": 4, "a_chk": 5, "r_u": 6, "r_v": 7, "r_chk": 8,
@@ -193,6 +216,43 @@ def ed25519_air(max_resident_leaves=None, table_cols=1, segment_nodes=None):
     for base in (AX, AY, RX, RY, NT, SW, HW, SAA, SBB, SCC, SX3, SY3, SZ3, SPT):
         for i in range(16):
             air.constraint((1 - is_last) * (N(base + i) - L(base + i)))
+    for col in [ACT] + list(range(DW, DW + 32)) + list(range(QW, QW + 17)):
+        air.constraint((1 - is_last) * (N(col) - L(col)))
+    act = L(ACT)
+    air.constraint(act * (act - 1))
+
+    # ---- h = D mod L: position k of  q L + h = D  on row k of the slot (k < 32), carries through two looked-up cells;
+    # h <= L - 1 and S <= L - 1 as additions with a range-checked complement on rows 0 .. 15 ----
+    e_row = [periodic_rows({k}) for k in range(MODL_ROWS)]
+    m32, m16 = periodic_rows(set(range(MODL_ROWS))), periodic_rows(set(range(16)))
+    lm1 = air.periodic([LM1_LIMBS[r] if r < 16 else 0 for r in range(ROWS)])
+    conv = None
+    for i in range(17):
+        coeff = air.periodic([L_LIMBS[r - i] if (r < MODL_ROWS and 0 <= r - i < 16) else 0 for r in range(ROWS)])
+        term = L(QW + i) * coeff
+        conv = term if conv is None else conv + term
+    hsel, ssel, dsel = e_row[0] * L(HW), e_row[0] * L(SW), e_row[0] * L(DW)
+    for k in range(1, MODL_ROWS):
+        if k < 16:
+            hsel, ssel = hsel + e_row[k] * L(HW + k), ssel + e_row[k] * L(SW + k)
+        dsel = dsel + e_row[k] * L(DW + k)
+    carry_in, carry_out = L(CLO) + L(CHI) * 65536, N(CLO) + N(CHI) * 65536
+    air.constraint(conv + hsel - dsel + m32 * (carry_in - carry_out * 65536))
+    for cell in (CLO, CHI):
+        air.constraint(e_row[0] * L(cell))                 # nothing is carried into position 0 ...
+        air.constraint(e_row[MODL_ROWS - 1] * N(cell))     # ... or out of position 31 (q L + h = D exactly, D < 2^512)
+    for sel, comp, bit in ((hsel, DH, BH), (ssel, DS, BS)):
+        b = L(bit)
+        air.constraint(b * (b - 1))
+        air.constraint(sel - lm1 + m16 * (L(comp) + b - N(bit) * 65536))
+        air.constraint(e_row[0] * b)
+        air.constraint(e_row[15] * N(bit))
+    # q's limbs pass through looked-up cells once per slot, like the limbs of A and R
+    cur = block[0] * L(QW)
+    for j in range(1, 16):
+        cur = cur + block[j] * L(QW + j)
+    air.constraint(limb_end * (L(CHKQ) - cur))
+    air.constraint(is_last * (L(CHKQ + 1) - L(QW + 16)))
 
     # ---- doubling of the input point ----
     x1, y1, z1 = cells(SIN), cells(SIN + 16), cells(SIN + 32)
@@ -249,10 +309,11 @@ def ed25519_air(max_resident_leaves=None, table_cols=1, segment_nodes=None):
     rx, ry = cells(RX), cells(RY)
     d_l, d2_l, m1_l = fp.to_limbs(D), fp.to_limbs(D2), fp.to_limbs(P - 1)
 
-    def tie(sel, lhs, rhs):
+    def tie(sel, lhs, rhs, gated=False):
+        """sel * (lhs - rhs) = 0 limb by limb; gated: only in an active slot (the three checks of the statement)"""
         for i in range(16):
             r = rhs[i] if isinstance(rhs, list) else rhs.limbs[i]
-            air.constraint(sel * (lhs.limbs[i] - r))
+            air.constraint((sel * act if gated else sel) * (lhs.limbs[i] - r))
 
     nxt_a, nxt_b, nxt_c = cells(AUX_A, True), cells(AUX_B, True), cells(AUX, True)
     for pre, u_, v_, chk, px, py in (("a", "a_u2", "a_v", "a_chk", ax, ay), ("r", "r_u", "r_v", "r_chk", rx, ry)):
@@ -264,7 +325,7 @@ def ed25519_air(max_resident_leaves=None, table_cols=1, segment_nodes=None):
         tie(step[chk], ua, d_l)
         tie(step[chk], ue, px)
         tie(step[chk], uf, py)
-        tie(step[chk], uc, m1_l)
+        tie(step[chk], uc, m1_l, gated=True)
     tie(step["a_u"], ua, ax)                      # u = x y, then NT = 2d u
     tie(step["a_u"], ub, ay)
     tie(step["a_u"], nxt_b, uc)
@@ -289,34 +350,34 @@ def ed25519_air(max_resident_leaves=None, table_cols=1, segment_nodes=None):
     tie(step["s_pt"], spt, uc)
     tie(step["xcmp"], ua, rx)                     # RX * Z = X on the slot's last row ...
     tie(step["xcmp"], ub, z4)
-    tie(step["xcmp"], uc, x4)
+    tie(step["xcmp"], uc, x4, gated=True)
     tie(step["xcmp"], nxt_a, ry)                  # ... RY * Z = Y on the row after it
     tie(step["xcmp"], nxt_b, z4)
-    tie(step["xcmp"], nxt_c, y4)
+    tie(step["xcmp"], nxt_c, y4, gated=True)
     no_sq = 1 - step["a_chk"] - step["r_chk"]
     for i in range(16):
         air.constraint(no_sq * L(AUX_E + i))
         air.constraint(no_sq * L(AUX_F + i))
 
-    # ---- fingerprint of the slots' data: acc' = acc gamma^6 + sum_k gamma^(5-k) limb_k on the row that closes block j
-    # (limb j of AX, AY, RX, RY, S, h), unchanged elsewhere; starts at 0, and the total after the last row is the
-    # proof's round value ----
+    # ---- fingerprint of the slots' data: acc' = acc gamma^8 + sum_k gamma^(7-k) limb_k on the row that closes block j
+    # (limb j of AX, AY, RX, RY, S, D low, D high; then `active` for j = 0 and nothing for the other j), unchanged
+    # elsewhere; starts at 0, and the total after the last row is the proof's round value ----
     def ext_mul(x, y):
         return x[0] * y[0] + x[1] * y[1] * logup.W, x[0] * y[1] + x[1] * y[0]
     gam = [(air.challenge(2), air.challenge(3))]
-    for _ in range(5):
+    for _ in range(N_BOUND - 1):
         gam.append(ext_mul(gam[-1], gam[0]))                  # gam[k] = gamma^(k+1)
     closing = [periodic_rows({16 * (15 - j) + 15}) for j in range(16)]
     acc = (L(ACC), L(ACC + 1))
 
     def word(j):
-        """sum_k gamma^(5-k) limb_(k,j) as an extension element: limb j of AX, AY, RX, RY, S with weights gamma^5 .. gamma,
-        limb j of h with weight 1"""
-        w0, w1 = L(BOUND[5] + j), None
-        for k in range(5):
-            g0, g1 = gam[4 - k]
+        """sum_k gamma^(7-k) value_(k,j) as an extension element: limb j of the seven vectors with weights gamma^7 .. gamma,
+        the flag (limb 0 only) with weight 1"""
+        w0, w1 = (act if j == 0 else None), None
+        for k in range(len(BOUND)):
+            g0, g1 = gam[len(BOUND) - 1 - k]
             limb = L(BOUND[k] + j)
-            w0 = w0 + g0 * limb
+            w0 = g0 * limb if w0 is None else w0 + g0 * limb
             w1 = g1 * limb if w1 is None else w1 + g1 * limb
         return w0, w1
 
@@ -325,8 +386,9 @@ def ed25519_air(max_resident_leaves=None, table_cols=1, segment_nodes=None):
         for c, wc in enumerate(word(j)):
             term = closing[j] * wc
             absorbed[c] = term if absorbed[c] is None else absorbed[c] + term
-    grown = ext_mul(acc, (gam[5][0] - 1, gam[5][1]))           # acc (gamma^6 - 1)
-    total = ext_mul(acc, gam[5])
+    g_all = gam[N_BOUND - 1]                                   # gamma^8
+    grown = ext_mul(acc, (g_all[0] - 1, g_all[1]))             # acc (gamma^8 - 1)
+    total = ext_mul(acc, g_all)
     last_word = word(0)                                        # the last row of the trace closes block 0 of the last slot
     for c in range(2):
         air.constraint_first_row(acc[c])
@@ -371,11 +433,52 @@ def slot_constants(ax, ay):
     return dict(nt=nt, saa=saa, sbb=sbb, scc=scc, sx3=sx3, sy3=sy3, sz3=sz3, st3=st3, spt=spt, e=e_s, f=f_s, g=g_s, h=h_s)
 
 
-def reference_slot(ax, ay, rx, ry, s, h):
+def modl_witness(s, d):
+    """What the mod-L rows hold for the scalar S and the digest D: h = D mod L, the limbs of q = D div L, the carry into
+    every position of q L + h = D (33 values, first and last 0), and for x in (h, S) the limbs of L - 1 - x with the carry
+    bits of x + (L - 1 - x) (17 values, first and last 0).  Raises AssertionError if S >= L or D >= 2^512."""
+    assert 0 <= d < (1 << 512) and 0 <= s < L_ORDER
+    q, h = divmod(d, L_ORDER)
+    qw = [(q >> (16 * i)) & 0xFFFF for i in range(17)]
+    hw, dw = fp.to_limbs(h), [(d >> (16 * k)) & 0xFFFF for k in range(32)]
+    carries = [0]
+    for k in range(MODL_ROWS):
+        tot = sum(qw[i] * L_LIMBS[k - i] for i in range(17) if 0 <= k - i < 16) + (hw[k] if k < 16 else 0) + carries[-1] - dw[k]
+        assert tot % 65536 == 0 and tot >= 0
+        carries.append(tot >> 16)
+    assert carries[-1] == 0 and max(carries) < (1 << 25)
+    comps = []
+    for x in (h, s):
+        xl, cl, bits = fp.to_limbs(x), fp.to_limbs(L_ORDER - 1 - x), [0]
+        for j in range(16):
+            tot = xl[j] + cl[j] + bits[-1] - LM1_LIMBS[j]
+            assert tot in (0, 65536)
+            bits.append(tot >> 16)
+        assert bits[-1] == 0
+        comps.append((cl, bits))
+    return dict(h=h, qw=qw, dw=dw, carries=carries, dh=comps[0][0], bh=comps[0][1], ds=comps[1][0], bs=comps[1][1])
+
+
+def reference_slot(ax, ay, rx, ry, s, d, active=1):
     """The 256 round-0 rows of one slot (multiplicity columns zero): (N_COLS0, 256) uint64 in the Goldilocks field.
     Raises AssertionError if the statement is false (a unit has no witness)."""
     gl = 0xFFFFFFFF00000001
     t = np.zeros((N_COLS0, ROWS), dtype=np.uint64)
+    ml = modl_witness(s, d)
+    h = ml["h"]
+    t[ACT, :] = 1 if active else 0
+    for k in range(32):
+        t[DW + k, :] = ml["dw"][k]
+    for i in range(17):
+        t[QW + i, :] = ml["qw"][i]
+    for k in range(MODL_ROWS + 1):
+        t[CLO, k], t[CHI, k] = ml["carries"][k] & 0xFFFF, ml["carries"][k] >> 16
+    for j in range(17):
+        t[BH, j], t[BS, j] = ml["bh"][j], ml["bs"][j]
+        if j < 16:
+            t[DH, j], t[DS, j] = ml["dh"][j], ml["ds"][j]
+            t[CHKQ, 16 * (15 - j) + 15] = ml["qw"][j]
+    t[CHKQ + 1, ROWS - 1] = ml["qw"][16]
 
     def put_unit(base, row, products, c=None):
         cl, ql, carries = fp.mul_unit_witness(products, c=c)
@@ -448,11 +551,11 @@ def reference_slot(ax, ay, rx, ry, s, h):
         elif st in ("a_v", "r_v"):
             ua = ub = aux_prev_c
         elif st == "a_chk":
-            ua, ub, ue, uf, c_fixed = fp.to_limbs(D), aux_prev_c, axl, ayl, P - 1
+            ua, ub, ue, uf, c_fixed = fp.to_limbs(D), aux_prev_c, axl, ayl, (P - 1 if active else None)
         elif st == "r_u":
             ua, ub = rxl, ryl
         elif st == "r_chk":
-            ua, ub, ue, uf, c_fixed = fp.to_limbs(D), aux_prev_c, rxl, ryl, P - 1
+            ua, ub, ue, uf, c_fixed = fp.to_limbs(D), aux_prev_c, rxl, ryl, (P - 1 if active else None)
         elif st == "s_aa":
             ua, ub = _vadd(ayl, axl), fp.to_limbs(B_YMX)
         elif st == "s_bb":
@@ -470,7 +573,7 @@ def reference_slot(ax, ay, rx, ry, s, h):
         elif st == "s_pt":
             ua, ub = fp.to_limbs(D2), aux_prev_c
         elif st == "xcmp":
-            ua, ub, c_fixed = rxl, z4, fp.from_limbs(x4)
+            ua, ub, c_fixed = rxl, z4, (fp.from_limbs(x4) if active else None)
         for base, limbs in ((AUX_A, ua), (AUX_B, ub), (AUX_E, ue), (AUX_F, uf)):
             put_vec(base, r, limbs)
         if st != "ycmp":
@@ -480,8 +583,8 @@ def reference_slot(ax, ay, rx, ry, s, h):
 
 
 def reference_trace(slots):
-    """Round-0 trace of a list of slots (ax, ay, rx, ry, s, h): the Y comparison of slot k sits in row 0 of slot k + 1
-    (cyclically)."""
+    """Round-0 trace of a list of slots (ax, ay, rx, ry, s, d[, active]): the Y comparison of slot k sits in row 0 of
+    slot k + 1 (cyclically)."""
     parts, finals = [], []
     for sl in slots:
         tr, q = reference_slot(*sl)
@@ -493,12 +596,14 @@ def reference_trace(slots):
         tr = parts[k]
         tr[AUX_A:AUX_A + 16, 0] = ry
         tr[AUX_B:AUX_B + 16, 0] = z4
-        tr[AUX:AUX + fp.UNIT_CELLS, 0] = fp.unit_cell_values(*fp.mul_unit_witness([(ry, z4, 1)], c=fp.from_limbs(y4)))
+        prev_active = len(slots[prev]) < 7 or slots[prev][6]
+        tr[AUX:AUX + fp.UNIT_CELLS, 0] = fp.unit_cell_values(*fp.mul_unit_witness([(ry, z4, 1)], c=fp.from_limbs(y4) if prev_active else None))
     return np.concatenate(parts, axis=1)
 
 
-def slot_from_signature(public_key, message, signature):
-    """(ax, ay, rx, ry, s, h) for an RFC 8032 signature, or None if the encodings are invalid."""
+def slot_from_signature(public_key, message, signature, active=1):
+    """(ax, ay, rx, ry, s, d, active) for an RFC 8032 signature - d = SHA-512(R || A || M) as a little-endian integer -
+    or None if the encodings are invalid."""
     import hashlib
     if len(public_key) != 32 or len(signature) != 64:
         return None
@@ -515,13 +620,18 @@ def slot_from_signature(public_key, message, signature):
     s = int.from_bytes(signature[32:], "little")
     if a is None or r is None or s >= L_ORDER:
         return None
-    h = int.from_bytes(hashlib.sha512(signature[:32] + public_key + message).digest(), "little") % L_ORDER
-    return a[0], a[1], r[0], r[1], s, h
+    d = int.from_bytes(hashlib.sha512(signature[:32] + public_key + message).digest(), "little")
+    return a[0], a[1], r[0], r[1], s, d, active
+
+
+def inactive_slot():
+    """A slot whose checks are switched off (a validator that did not sign): the neutral point, zero scalars."""
+    return 0, 1, 0, 1, 0, 0, 0
 
 
 def synthetic_slots(count, seed=1):
-    """`count` true statements [S]B = R + [h]A with random keys, nonces and h (the AIR does not tie h to a hash, so any
-    h with S = r + h a mod L makes a valid slot): the bench's workload."""
+    """`count` true statements [S]B = R + [D mod L]A with random keys, nonces and 512-bit D (the AIR does not tie D to a
+    hash - sha512_air.py does - so any D with S = r + D a mod L makes a valid slot): the bench's workload."""
     import random
     from .near_protocol import _G, _mul
     rnd = random.Random(seed)
@@ -531,9 +641,10 @@ def synthetic_slots(count, seed=1):
         return pt[0] * zi % P, pt[1] * zi % P
     out = []
     for _ in range(count):
-        a, r, h = (rnd.randrange(1, L_ORDER) for _ in range(3))
+        a, r = (rnd.randrange(1, L_ORDER) for _ in range(2))
+        d = rnd.randrange(1 << 512)
         (ax, ay), (rx, ry) = affine(_mul(a, _G)), affine(_mul(r, _G))
-        out.append((ax, ay, rx, ry, (r + h * a) % L_ORDER, h))
+        out.append((ax, ay, rx, ry, (r + d * a) % L_ORDER, d, 1))
     return out
 
 
@@ -542,14 +653,20 @@ def _ext_mul(x, y):
     return (x[0] * y[0] + logup.W * x[1] * y[1]) % gl, (x[0] * y[1] + x[1] * y[0]) % gl
 
 
+def bound_values(slot):
+    """The eight 256-bit values of a slot the fingerprint absorbs: A.x, A.y, R.x, R.y, S, D mod 2^256, D div 2^256, active."""
+    ax, ay, rx, ry, s, d = slot[:6]
+    return ax, ay, rx, ry, s, d & ((1 << 256) - 1), d >> 256, (1 if len(slot) < 7 or slot[6] else 0)
+
+
 def fingerprint(slots, gamma):
     """What the proof's round value must be for these slots: Horner in F_p^2 over, slot by slot, limb 15 down to limb 0
-    of (A.x, A.y, R.x, R.y, S, h) - the relying party's side of the binding."""
+    of (A.x, A.y, R.x, R.y, S, D low, D high, active) - the relying party's side of the binding."""
     acc = (0, 0)
     for sl in slots:
-        limbs = [fp.to_limbs(v) for v in sl]
+        limbs = [fp.to_limbs(v) for v in bound_values(sl)]
         for j in range(15, -1, -1):
-            for k in range(6):
+            for k in range(N_BOUND):
                 acc = _ext_mul(acc, gamma)
                 acc = ((acc[0] + limbs[k][j]) % 0xFFFFFFFF00000001, acc[1])
     return acc
@@ -560,27 +677,30 @@ def binding_columns(t0, gamma):
     gl = 0xFFFFFFFF00000001
     n = t0.shape[1]
     out = np.zeros((2, n), dtype=np.uint64)
-    g6 = (1, 0)
-    for _ in range(6):
-        g6 = _ext_mul(g6, gamma)
     acc = (0, 0)
     for r in range(n):
         out[0, r], out[1, r] = acc
         if r % 16 == 15:
             j = 15 - (r % ROWS) // 16
-            for k in range(6):
+            for k in range(N_BOUND):
                 acc = _ext_mul(acc, gamma)
-                acc = ((acc[0] + int(t0[BOUND[k] + j, r])) % gl, acc[1])
+                v = int(t0[BOUND[k] + j, r]) if k < len(BOUND) else (int(t0[ACT, r]) if j == 0 else 0)
+                acc = ((acc[0] + v) % gl, acc[1])
     return out, acc
 
 
+SLOT_WORDS = 32
+
+
 def slots_to_words(slots):
-    """[(ax, ay, rx, ry, s, h)] -> (n, 24) uint64: the input format of nlx_ed25519_trace"""
-    out = np.zeros((len(slots), 24), dtype=np.uint64)
+    """[(ax, ay, rx, ry, s, d[, active])] -> (n, 32) uint64: the input format of nlx_ed25519_trace (five 256-bit values,
+    the 512-bit digest, the flag, three spare words)"""
+    out = np.zeros((len(slots), SLOT_WORDS), dtype=np.uint64)
     for k, sl in enumerate(slots):
-        for v, x in enumerate(sl):
+        for v, x in enumerate(bound_values(sl)[:7]):
             for w in range(4):
                 out[k, 4 * v + w] = (int(x) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+        out[k, 28] = bound_values(sl)[7]
     return out
 
 
@@ -610,13 +730,14 @@ class Ed25519Prover:
         self._t0 = self._t1 = None
 
     def generate_trace(self, slots):
-        """slots: list of 2^log_slots (ax, ay, rx, ry, s, h).  Returns the device round-0 trace with multiplicities;
-        raises NlxError if a statement is false (its comparison unit has no in-range witness)."""
+        """slots: list of 2^log_slots (ax, ay, rx, ry, s, d[, active]) or their words.  Returns the device round-0 trace
+        with multiplicities; raises NlxError if an active slot's statement is false (its comparison unit has no in-range
+        witness) or any S >= L."""
         import torch
         from ._lib import dll
         n_slots = 1 << self.es.log_slots
         words = slots if isinstance(slots, np.ndarray) else slots_to_words(slots)
-        if words.shape != (n_slots, 24):
+        if words.shape != (n_slots, SLOT_WORDS):
             raise ValueError("expected 2^%d slots" % self.es.log_slots)
         n = n_slots * ROWS
         if self._t0 is None:

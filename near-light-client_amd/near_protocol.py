@@ -191,3 +191,39 @@ def sync_sha256_messages(next_block):
     if nb is not None:
         msgs.append(len(nb).to_bytes(4, "little") + b"".join(validator_stake_borsh(v) for v in nb))
     return msgs
+
+
+def approval_statement(epoch_bps, next_block):
+    """The Ed25519 side of one Sync step as nearx lays it out (nearx/src/builder.rs:116-164 `validate_signatures<LEN>`): ONE
+    SLOT PER VALIDATOR of the epoch, in order - active with its signature over the approval message where the block carries
+    one, inactive (`is_active` false, checks off) where it does not - plus the SHA-512 preimages R || A || M of the signed
+    ones (what curta_eddsa hashes).  Returns dict(message, slots, signed (validator indices), sig_msgs)."""
+    from . import ed25519_air as E
+    msg = reconstruct_approval_message(next_block)
+    slots, signed, sig_msgs = [], [], []
+    for i, (sig, bp) in enumerate(zip(next_block["approvals_after_next"], epoch_bps)):
+        if sig is None:
+            slots.append(E.inactive_slot())
+            continue
+        pk, raw = _key_bytes(bp["public_key"], 32), _key_bytes(sig, 64)
+        sl = E.slot_from_signature(pk, msg, raw)
+        if sl is None:
+            raise ValueError("validator %d: malformed key or signature" % i)
+        slots.append(sl)
+        signed.append(i)
+        sig_msgs.append(raw[:32] + pk + msg)
+    return dict(message=msg, slots=slots, signed=signed, sig_msgs=sig_msgs)
+
+
+def slots_with_digests(statement, digest_words):
+    """The relying party's view of the Ed25519 slots when the SHA-512 digests come from the SHA-512 STARK's side: signed
+    validator k's D is the little-endian integer of digest k's 64 bytes (eight big-endian 64-bit words, as sha512_air's
+    block outputs).  With these slots `ed25519_air.fingerprint` must reproduce the Ed25519 proof's round value - the tie
+    between the two proofs: the same numbers are absorbed by both fingerprints."""
+    slots = list(statement["slots"])
+    if len(digest_words) != len(statement["signed"]):
+        raise ValueError("one digest per signed validator")
+    for i, words in zip(statement["signed"], digest_words):
+        d = int.from_bytes(b"".join(int(w).to_bytes(8, "big") for w in words), "little")
+        slots[i] = slots[i][:5] + (d,) + slots[i][6:]
+    return slots

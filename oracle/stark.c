@@ -472,7 +472,7 @@ static void air_eval_ext(const orc_stark_desc* d, const gl2* local, const gl2* n
     }
 }
 
-#define ORC_MAX_PERIODIC 64
+#define ORC_MAX_PERIODIC 128
 /* interpolation of each periodic column over the period-th roots of unity (coefficients, natural order) */
 static uint64_t* periodic_coeffs(const orc_stark_desc* d) {
     if (!d->n_periodic) return NULL;

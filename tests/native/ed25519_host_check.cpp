@@ -1,5 +1,6 @@
-// Host build of the Ed25519 trace generator's row code (csrc/ed25519_rows.hpp): reads slots as six 64-hex-digit numbers
-// (ax ay rx ry s h) per line and writes the round-0 trace of all slots, column-major u64, to the file named in argv[1].
+// Host build of the Ed25519 trace generator's row code (csrc/ed25519_rows.hpp): reads slots as five 64-hex-digit numbers,
+// one of 128 digits and a flag (ax ay rx ry s d active) per line and writes the round-0 trace of all slots, column-major
+// u64, to the file named in argv[1]; exit code 5 if the row code reports a false statement.
 // tests/test_ed25519_air.py compares it with the Python reference trace.
 #include <cstdio>
 #include <cstdlib>
@@ -11,15 +12,22 @@ using namespace nlx;
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::vector<ed::Slot> slots;
-    char buf[6][80];
-    while (scanf("%64s %64s %64s %64s %64s %64s", buf[0], buf[1], buf[2], buf[3], buf[4], buf[5]) == 6) {
-        uint64_t w[24];
-        for (int v = 0; v < 6; v++)
+    char buf[5][80], dbuf[160];
+    unsigned active = 1;
+    while (scanf("%64s %64s %64s %64s %64s %128s %u", buf[0], buf[1], buf[2], buf[3], buf[4], dbuf, &active) == 7) {
+        uint64_t w[ed::SLOT_WORDS] = {0};
+        for (int v = 0; v < 5; v++)
             for (int k = 0; k < 4; k++) {
                 unsigned long long x = 0;
                 sscanf(buf[v] + 16 * (3 - k), "%16llx", &x);
                 w[4 * v + k] = x;
             }
+        for (int k = 0; k < 8; k++) {
+            unsigned long long x = 0;
+            sscanf(dbuf + 16 * (7 - k), "%16llx", &x);
+            w[20 + k] = x;
+        }
+        w[28] = active;
         ed::Slot s;
         ed::slot_from_words(w, s);
         slots.push_back(s);
@@ -59,16 +67,17 @@ int main(int argc, char** argv) {
         ed::fast_store(fq, fin[k]);
     }
     // pass 2: every row on its own
+    bool all_ok = true;
     for (size_t k = 0; k < ns; k++)
         for (int r = 0; r < ed::ROWS; r++) {
             const size_t row = k * ed::ROWS + r, prev = (k + ns - 1) % ns;
             auto put = [&](uint32_t col, uint64_t v) { trace[(size_t)col * n + row] = v; };
             ed::Point o;
-            ed::emit_row(r, slots[k], in[row], slots[prev].ry, &fin[prev], put, o);
+            all_ok &= ed::emit_row(r, slots[k], in[row], slots[prev].ry, &fin[prev], slots[prev].active != 0, put, o) && slots[k].s_in_range;
         }
     FILE* f = fopen(argv[1], "wb");
     if (!f) return 3;
     fwrite(trace.data(), 8, trace.size(), f);
     fclose(f);
-    return 0;
+    return all_ok ? 0 : 5;
 }

@@ -3,6 +3,7 @@ generator reproduces RFC 8032 signatures and refuses false statements; every con
 trace (row-by-row interpreter, lookup columns from the oracle's restatement); the C++ row code the GPU runs, built for
 the host, equals the Python reference.  GPU part: device trace == reference, proof bytes == oracle prover's, real NEAR
 approval signatures verify, a forged signature does not."""
+import hashlib
 import json
 import os
 import subprocess
@@ -23,6 +24,11 @@ RFC8032 = [  # (public key, message, signature): RFC 8032 §7.1 TEST 1, 2, 3
 ]
 
 
+def slot_line(sl):
+    """a slot in the text format of tests/native/ed25519_host_check.cpp"""
+    return " ".join("%064x" % v for v in sl[:5]) + " %0128x %d" % (sl[5], sl[6] if len(sl) > 6 else 1)
+
+
 def rfc_slots(nlx):
     E = nlx.ed25519_air
     return [E.slot_from_signature(bytes.fromhex(pk), bytes.fromhex(m), bytes.fromhex(sig)) for pk, m, sig in RFC8032]
@@ -32,18 +38,27 @@ def test_witness_generator_verifies_rfc8032(nlx):
     E, F = nlx.ed25519_air, nlx.fp25519
     assert (E.BX, E.BY) == (15112221349535400772501151409588531511454012693041857206046113283949847762202,
                             46316835694926478169428394003475163141307993866256225615783033603165251855960)
-    for sl in rfc_slots(nlx):
-        ax, ay, rx, ry, s, h = sl
+    for (pk, m, sig), sl in zip(RFC8032, rfc_slots(nlx)):
+        ax, ay, rx, ry, s, d, active = sl
+        assert active == 1 and d == int.from_bytes(hashlib.sha512(bytes.fromhex(sig)[:32] + bytes.fromhex(pk) + bytes.fromhex(m)).digest(), "little")
         assert (-ax * ax + ay * ay - 1 - E.D * ax * ax * ay * ay) % E.P == 0
         t, q = E.reference_slot(*sl)
         x4, y4, z4 = (F.from_limbs(v) for v in q)
         zi = pow(z4, E.P - 2, E.P)
         assert (x4 * zi % E.P, y4 * zi % E.P) == (rx, ry)            # [S]B + [h](-A) == R
         assert t.shape == (E.N_COLS0, 256) and int(t.max()) < P
-    ax, ay, rx, ry, s, h = rfc_slots(nlx)[1]
-    for bad in ((ax, ay, rx, ry, s ^ 1, h), (ax, ay, rx, ry, s, h ^ 4), (ax, ay, ry, rx, s, h), (ax + 1, ay, rx, ry, s, h)):
+    ax, ay, rx, ry, s, d, _ = rfc_slots(nlx)[1]
+    for bad in ((ax, ay, rx, ry, s ^ 1, d), (ax, ay, rx, ry, s, d ^ 4), (ax, ay, rx, ry, s, d ^ (1 << 400)), (ax, ay, ry, rx, s, d), (ax + 1, ay, rx, ry, s, d),
+                (ax, ay, rx, ry, s + E.L_ORDER, d)):
         with pytest.raises(AssertionError):                          # a false statement has no witness
             E.reference_slot(*bad)
+        if bad[4] < E.L_ORDER:
+            E.reference_slot(*bad, active=0)                         # ... unless the slot's checks are off
+    # the reduction mod L at its edges: D = 0, L - 1, L, 2^512 - 1, a multiple of L; S = L - 1
+    for dd in (0, E.L_ORDER - 1, E.L_ORDER, (1 << 512) - 1, E.L_ORDER * ((1 << 259) + 12345), (1 << 256) - 1, 1 << 256):
+        w = E.modl_witness(E.L_ORDER - 1, dd)
+        assert w["h"] == dd % E.L_ORDER and sum(v << (16 * i) for i, v in enumerate(w["qw"])) == dd // E.L_ORDER
+        assert max(w["qw"] + w["dh"] + w["ds"]) < 65536 and max(w["carries"]) < (1 << 25) and set(w["bh"] + w["bs"]) <= {0, 1}
     assert E.slot_from_signature(b"\x00" * 32, b"", b"\x00" * 64) is not None or True
     assert E.slot_from_signature(bytes.fromhex(RFC8032[0][0]), b"", bytes.fromhex(RFC8032[0][2])[:32] + b"\xff" * 32) is None   # S >= L
 
@@ -54,10 +69,14 @@ def test_row_code_built_for_the_host_equals_reference(nlx, tmp_path):
     exe, out = str(tmp_path / "edcheck"), str(tmp_path / "trace.bin")
     subprocess.run(["g++", "-O2", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "near-light-client_amd", "csrc"),
                     os.path.join(ROOT, "tests", "native", "ed25519_host_check.cpp"), "-o", exe], check=True, capture_output=True)
-    slots = rfc_slots(nlx)
+    ax, ay, rx, ry, s, d, _ = rfc_slots(nlx)[2]
+    # three RFC 8032 signatures, a forged one in an inactive slot, an empty inactive slot, D = 2^512 - 1 in an inactive slot
+    slots = rfc_slots(nlx) + [(ax, ay, rx, ry, s ^ 2, d, 0), E.inactive_slot(), (ax, ay, rx, ry, E.L_ORDER - 1, (1 << 512) - 1, 0)]
     want = E.reference_trace(slots)
-    text = "\n".join(" ".join("%064x" % v for v in s) for s in slots) + "\n"
+    text = "\n".join(slot_line(s) for s in slots) + "\n"
     subprocess.run([exe, out], input=text, text=True, check=True)
+    for bad in ((ax, ay, rx, ry, s ^ 2, d, 1), (ax, ay, rx, ry, s + E.L_ORDER, d, 0)):        # forged and active; S >= L
+        assert subprocess.run([exe, out + ".bad"], input=slot_line(bad) + "\n", text=True).returncode == 5
     got = np.fromfile(out, dtype=np.uint64).reshape(E.N_COLS0, -1)
     assert got.shape == want.shape
     if not np.array_equal(got, want):
@@ -67,9 +86,12 @@ def test_row_code_built_for_the_host_equals_reference(nlx, tmp_path):
 
 @pytest.fixture(scope="module")
 def tiled_case(nlx, orc):
-    """2^16 rows: the reference trace of two slots tiled 128 times (cyclically consistent), with multiplicities."""
+    """2^16 rows: the reference trace of two slots tiled 128 times (cyclically consistent), with multiplicities.  The
+    second slot is a FORGED signature in an inactive slot: it proves only because its checks are off."""
     E = nlx.ed25519_air
     slots = rfc_slots(nlx)[:2]
+    ax, ay, rx, ry, s, d, _ = slots[1]
+    slots[1] = (ax, ay, rx, ry, s ^ 2, d, 0)
     t0 = np.tile(E.reference_trace(slots), (1, 128))
     t0[E.MULT] = orc.logup_multiplicities(t0, E.LOOKUPS, 16)
     t0[E.MULT9] = orc.logup_multiplicities(t0, E.LOOKUPS9, 9)
@@ -88,7 +110,7 @@ def test_every_constraint_vanishes_on_the_reference_trace(nlx, orc, tiled_case):
     E = nlx.ed25519_air
     slots, t0 = tiled_case
     air, _ = E.ed25519_air()
-    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 2440 and (len(E.LOOKUPS), len(E.LOOKUPS9)) == (772, 240)
+    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 2506 and (len(E.LOOKUPS), len(E.LOOKUPS9)) == (777, 241)
     words = air.compile()
     known = [0x1234567890abcdef, 0x0fedcba987654321, 0x0123456789abcdef, 0x0edcba9876543210]     # alpha, gamma
     r1, total = oracle_round1(orc, E, t0, known)
@@ -111,12 +133,18 @@ def test_every_constraint_vanishes_on_the_reference_trace(nlx, orc, tiled_case):
         assert len(vals) == air.num_constraints
         return [k for k, (op, v) in enumerate(vals) if v != 0 and not (op == 7 and i == n - 1) and not (op == 8 and i != 0)
                 and not (op == 9 and i != n - 1)]
-    for i in list(range(0, 10)) + [15, 16, 17, 254, 255, 256, 257, 260, 511, 512, n - 1]:
+    for i in list(range(0, 10)) + [15, 16, 17, 30, 31, 32, 33, 254, 255, 256, 257, 260, 271, 272, 287, 288, 511, 512, n - 1]:
         assert violations(i) == [], i
     # tampering with a cell breaks a constraint on that row or the one before it
     for col, row in ((E.SB, 40), (E.SIN + 3, 100), (E.MAIN[E.U_X4] + 2, 77), (E.MAIN[E.U_Y2] + 20, 5), (E.P2 + 17, 60), (E.SX3 + 1, 12), (E.SPT + 3, 16), (E.AUX + 1, 255), (E.AX + 1, 300),
-                     (E.SW + 2, 9), (E.NT, 2), (E.AUX_E + 4, 30), (E.HA, 31), (E.ACC, 100), (E.ACC + 1, 16)):
+                     (E.SW + 2, 9), (E.NT, 2), (E.AUX_E + 4, 30), (E.HA, 31), (E.ACC, 100), (E.ACC + 1, 16),
+                     (E.ACT, 70), (E.DW + 3, 3), (E.DW + 20, 20), (E.DW + 31, 400), (E.QW + 2, 9), (E.QW + 16, 31), (E.CLO, 5), (E.CHI, 7), (E.CLO, 32),
+                     (E.DH, 3), (E.DS, 15), (E.BH, 4), (E.BS, 16), (E.CHKQ, 15), (E.CHKQ + 1, 255), (E.HW + 1, 1), (E.SW + 15, 15)):
         assert violations(row, (col, row, 1)) or violations(row - 1, (col, row, 1)), (col, row)
+    # the forged slot (rows 256 .. 511) is held together by its flag alone: with the flag on, its last row violates the
+    # X comparison's sixteen limb equations (and the next row's Y comparison)
+    assert len(violations(511, (E.ACT, 511, 1))) >= 16 and violations(511) == []
+    assert violations(255, (E.ACT, 255, P - 1))              # and the flag is a bit
 
 
 @pytest.mark.gpu
@@ -169,33 +197,51 @@ def test_gpu_small_batch_with_the_table_spread_over_two_columns(nlx, ctx, orc):
 
 @pytest.mark.gpu
 def test_gpu_real_near_approvals_and_a_forgery(nlx, ctx, orc):
-    """The Ed25519 checks of a real Sync step (mainnet main_1.json: every signed approval) in one proof; flipping one
-    bit of one signature is reported by the trace generator (and the trace it leaves does not prove)."""
+    """The Ed25519 statement of a real Sync step (mainnet main_0 -> main_1) as validate_signatures<LEN> lays it out: one
+    slot per validator, active where the block carries its approval; D reduced mod L inside the proof; tied to the
+    SHA-512 side through the digests; forged / unsigned slots."""
     E, NP = nlx.ed25519_air, nlx.near_protocol
     with open(os.path.join(ROOT, "tests", "golden", "near", "main_0.json")) as f:
         bps = json.load(f)["body"]["next_bps"]
     with open(os.path.join(ROOT, "tests", "golden", "near", "main_1.json")) as f:
         nxt = json.load(f)["body"]
-    msg = NP.reconstruct_approval_message(nxt)
-    slots = []
-    for sig, bp in zip(nxt["approvals_after_next"], bps):
-        if sig is not None:
-            sl = E.slot_from_signature(NP._key_bytes(bp["public_key"], 32), msg, NP._key_bytes(sig, 64))
-            assert sl is not None
-            slots.append(sl)
-    assert len(slots) > 32
-    log_slots = (len(slots) - 1).bit_length()            # 66 approvals -> 2^7 slots: the range table in two columns
-    slots = (slots * 2)[: 1 << log_slots]
+    stmt = NP.approval_statement(bps, nxt)
+    n_val, n_signed = len(stmt["slots"]), len(stmt["signed"])
+    assert n_val == len(bps) > n_signed > 32 and sum(sl[6] for sl in stmt["slots"]) == n_signed
+    log_slots = (n_val - 1).bit_length()                 # one slot per validator; the rest of the power of two is inactive
+    slots = stmt["slots"] + [E.inactive_slot()] * ((1 << log_slots) - n_val)
     pr = E.Ed25519Prover(ctx, log_slots, nlx.StarkConfig(fri_num_queries=20))
     proof = pr.prove(slots)
     assert orc.stark_verify(pr.stark.desc, proof) == 1
-    ax, ay, rx, ry, s, h = slots[7]
+    # the tie to the SHA-512 side: the same digests, taken from sha512_air's block outputs (what the SHA-512 STARK's
+    # fingerprint absorbs), reproduce this proof's round value; a digest changed in one bit does not
+    SB = nlx.sha512_air
+    blocks, first, _ = SB.blocks_for_messages(stmt["sig_msgs"])
+    outs = SB.block_outputs(blocks, first)[-n_signed:]   # one block per message; filler messages come first
+    vals = orc.stark_values(pr.stark.desc, proof)
+    tied = NP.slots_with_digests(stmt, outs) + [E.inactive_slot()] * ((1 << log_slots) - n_val)
+    assert tied == slots and tuple(vals[4:6]) == E.fingerprint(tied, vals[2:4])
+    outs[5] = [outs[5][0] ^ 1] + list(outs[5][1:])
+    assert tuple(vals[4:6]) != E.fingerprint(NP.slots_with_digests(stmt, outs) + slots[n_val:], vals[2:4])
+    # a validator that did not sign cannot be passed off as active ...
+    k_in = next(i for i, sl in enumerate(stmt["slots"]) if not sl[6])
+    flipped = list(slots)
+    flipped[k_in] = slots[k_in][:6] + (1,)
+    assert tuple(vals[4:6]) != E.fingerprint(flipped, vals[2:4])
+    # ... a forged signature is reported by the trace generator (and the trace it leaves does not prove) unless its slot is off
+    k_sig = stmt["signed"][7]
+    ax, ay, rx, ry, s, d, _ = slots[k_sig]
     forged = list(slots)
-    forged[7] = (ax, ay, rx, ry, s ^ (1 << 100), h)
-    with pytest.raises(nlx.NlxError, match="slot 7"):
+    forged[k_sig] = (ax, ay, rx, ry, s ^ (1 << 100), d, 1)
+    with pytest.raises(nlx.NlxError, match="slot %d" % k_sig):
         pr.generate_trace(forged)
     for rc in pr.es.range_checks:
         rc.multiplicities(ctx, pr._t0)
     bad_proof = pr.prover.prove_rounds(lambda rnd, known: pr._t0 if rnd == 0 else pr.round1(known), [])
     assert orc.stark_verify(pr.stark.desc, bad_proof) != 1
+    forged[k_sig] = (ax, ay, rx, ry, s ^ (1 << 100), d, 0)
+    assert orc.stark_verify(pr.stark.desc, pr.prove(forged)) == 1
+    with pytest.raises(nlx.NlxError, match="slot %d" % k_sig):      # S >= L has no witness, active or not
+        forged[k_sig] = (ax, ay, rx, ry, s + E.L_ORDER, d, 0)
+        pr.generate_trace(forged)
     pr.close()

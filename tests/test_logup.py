@@ -200,7 +200,7 @@ def test_gpu_witness_calls_reject_bad_arguments(nlx, ctx):
     assert dll.nlx_logup_round(ctx.handle, t.data_ptr(), 4, 6, cols.ctypes.data, 2, 4, 1, 3, None, out.data_ptr()) < 0
     assert dll.nlx_logup_round(ctx.handle, t.data_ptr(), 4, 6, cols.ctypes.data, 2, 4, 1, 3, al.ctypes.data, None) < 0
     assert dll.nlx_logup_round_cols(2, 1) == 6 and dll.nlx_logup_round_cols(3, 1) == 8 and dll.nlx_logup_round_cols(3, 4) == 14
-    words = np.zeros((256, 24), dtype=np.uint64)
+    words = np.zeros((256, 32), dtype=np.uint64)
     assert dll.nlx_ed25519_trace(ctx.handle, words.ctypes.data, 17, t.data_ptr()) < 0
     assert dll.nlx_ed25519_trace(ctx.handle, None, 8, t.data_ptr()) < 0
     assert dll.nlx_fp25519_chip_trace(ctx.handle, None, words.ctypes.data, 16, t.data_ptr()) < 0
