@@ -462,13 +462,13 @@ int32_t nlx_fp25519_chip_trace(nlx_ctx* ctx, const uint64_t* a, const uint64_t* 
  * then the 2^16 table - last, so that a proof of fewer than 2^8 slots can append the further multiplicity columns of a
  * table spread over several columns) zeroed (nlx_logup_multiplicities fills them).  Returns NLX_E_INVAL naming the first
  * slot whose statement is false (an active slot whose signature does not verify or whose A / R is off the curve; any slot
- * with S >= L): no trace satisfies the AIR for it. */
+ * with S >= L or a coordinate >= p): no trace satisfies the AIR for it. */
 #define NLX_ED25519_SLOT_WORDS 32
-#define NLX_ED25519_COLS0 1476
+#define NLX_ED25519_COLS0 1488
 int32_t nlx_ed25519_trace(nlx_ctx* ctx, const uint64_t* slots, uint32_t log_slots, uint64_t* trace_out);
 /* The AIR's binding accumulator (round 1, two base columns = one column over F_p^2) for the challenge gamma = gamma[0] +
- * gamma[1] X: the running Horner fingerprint of every slot's 128 limbs (limb 15 first; A.x, A.y, R.x, R.y, S, D mod 2^256,
- * D div 2^256, active), each row
+ * gamma[1] X: the running Horner fingerprint of every slot's 96 limbs (limb 15 first; the 32-byte encodings of A and R - y with the
+ * parity of x in bit 255 -, S, D mod 2^256, D div 2^256, active), each row
  * holding what was absorbed before it.  trace: the round-0 trace (host or device); acc_out: 2 x (256 << log_slots);
  * total_out: the fingerprint of all slots - the round value the proof sends, which the relying party recomputes from
  * the tuples it believes were verified (near-light-client_amd/ed25519_air.py::fingerprint). */

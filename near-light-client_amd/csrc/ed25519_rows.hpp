@@ -17,7 +17,8 @@ constexpr uint32_t cSIN = 0, cSB = 48, cHB = 49, cSA = 50, cHA = 51, cAX = 52, c
                    cSPT = 264, cP2 = 280, cMAIN = 344, cAUX_A = cMAIN + N_MAIN * UNIT_CELLS, cAUX_B = cAUX_A + 16,
                    cAUX_E = cAUX_B + 16, cAUX_F = cAUX_E + 16, cAUX = cAUX_F + 16, cACT = cAUX + UNIT_CELLS, cDW = cACT + 1,
                    cQW = cDW + 32, cCHKQ = cQW + 17, cCLO = cCHKQ + 2, cDH = cCLO + 1, cDS = cDH + 1, cCHI = cDS + 1,
-                   cBH = cCHI + 1, cBS = cBH + 1, cMULT9 = cBS + 1,
+                   cBH = cCHI + 1, cBS = cBH + 1, cSGA = cBS + 1, cSGR = cSGA + 1, cCXY = cSGR + 1, cKXA = cCXY + 4, cKXR = cKXA + 1,
+                   cBXY = cKXR + 1, cMULT9 = cBXY + 4,
                    cMULT = cMULT9 + 1, N_COLS0 = cMULT + 1;  // further multiplicity columns of a spread table follow (caller's)
 constexpr int SLOT_WORDS = 32, MODL_ROWS = 32;
 enum { U_A, U_B, U_ZZ, U_E, U_X2, U_Y2, U_T2, U_Z2, U_PA, U_PB, U_PC, U_PD, U_X4, U_Y4, U_Z4 };
@@ -65,7 +66,9 @@ struct Slot {
     uint32_t dw[32], qw[17], carry[MODL_ROWS + 1], dh[16], ds[16];
     uint32_t bh, bs;      // bit j: the carry into limb j of h + (L - 1 - h) / S + (L - 1 - S)
     uint32_t active;      // 1: the slot's three checks are on
-    uint32_t s_in_range;  // 0: S >= L (no witness for the comparison)
+    uint32_t s_in_range;  // 0: S >= L or a coordinate >= p (no witness for the comparisons)
+    uint32_t cxy[4][16];  // p - 1 - v for v = A.x, A.y, R.x, R.y
+    uint32_t bxy[4];      // bit j: the carry into limb j of v + (p - 1 - v)
 };
 
 // the group order L = 2^252 + 27742317777372353535851937790883648493, 16-bit limbs
@@ -128,6 +131,23 @@ FP_HD inline void modl_witness(Slot& s) {
             if (i < 15) bits |= cb << (i + 1);
         }
         (which ? s.bs : s.bh) = bits;
+    }
+    // canonical coordinates: v + (p - 1 - v) = p - 1, p - 1 = 2^255 - 20
+    for (int v = 0; v < 4; v++) {
+        const uint32_t* x = v == 0 ? s.ax : (v == 1 ? s.ay : (v == 2 ? s.rx : s.ry));
+        int32_t borrow = 0;
+        for (int i = 0; i < 16; i++) {
+            const int32_t t = (int32_t)K_LIMBS[K_M1][i] - (int32_t)x[i] + borrow;
+            s.cxy[v][i] = (uint32_t)(t & 0xFFFF);
+            borrow = t >> 16;
+        }
+        if (borrow < 0) s.s_in_range = 0;
+        uint32_t bits = 0, cb = 0;
+        for (int i = 0; i < 16; i++) {
+            cb = (x[i] + s.cxy[v][i] + cb - (uint32_t)K_LIMBS[K_M1][i]) >> 16 & 1u;
+            if (i < 15) bits |= cb << (i + 1);
+        }
+        s.bxy[v] = bits;
     }
 }
 
@@ -483,6 +503,15 @@ FP_HD inline bool emit_row(int r, const Slot& s, const Point& in, const uint32_t
         put(cDS, r < 16 ? s.ds[r] : 0u);
         put(cBH, r < 16 ? (s.bh >> r) & 1u : 0u);
         put(cBS, r < 16 ? (s.bs >> r) & 1u : 0u);
+        // the encodings' sign bits, the coordinates' complements to p - 1, limb 0 of x halved (parity)
+        put(cSGA, s.ax[0] & 1u);
+        put(cSGR, s.rx[0] & 1u);
+        for (int v = 0; v < 4; v++) {
+            put(cCXY + v, r < 16 ? s.cxy[v][r] : 0u);
+            put(cBXY + v, r < 16 ? (s.bxy[v] >> r) & 1u : 0u);
+        }
+        put(cKXA, r == 0 ? s.ax[0] >> 1 : 0u);
+        put(cKXR, r == 0 ? s.rx[0] >> 1 : 0u);
     }
     {
         limbs_t ymx, ypx, t2d, z2;

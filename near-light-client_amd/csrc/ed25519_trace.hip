@@ -5,7 +5,7 @@
 //              records the input point of every row - the only sequential part, on values only (fe25519_fast.hpp:
 //              26-bit limbs, no witness cells; canonical results, so identical to what the row emitter recomputes);
 //   k_ed_rows  one lane per row recomputes its 16 units from that input point (results are canonical, so the
-//              recomputation is bit-identical) and writes its 1 476 cells; a wave's 64 lanes are 64 consecutive rows,
+//              recomputation is bit-identical) and writes its 1 488 cells; a wave's 64 lanes are 64 consecutive rows,
 //              so every column store is 512 contiguous bytes.
 #include "ctx.hpp"
 #include "ed25519_rows.hpp"
@@ -78,14 +78,17 @@ __global__ __launch_bounds__(64) void k_ed_rows(const ed::Slot* __restrict__ slo
 }
 
 // ---- binding accumulator (round 1): Horner fingerprint in F_p^2 of every slot's limbs, limb 15 first, in the order
-// A.x, A.y, R.x, R.y, S, D low half, D high half, active (a one-limb value: zero above limb 0) ----
-constexpr int ED_BOUND = 8;   // values absorbed per limb index
+// enc(A), enc(R) (y with the sign bit of x on top of limb 15), S, D low half, D high half, active (a one-limb value) ----
+constexpr int ED_BOUND = 6;   // values absorbed per limb index
 __device__ __forceinline__ gl::Ext absorb_limb(gl::Ext acc, gl::Ext gamma, const uint64_t* __restrict__ trace, size_t n, size_t row, int j) {
-    const uint32_t base[ED_BOUND - 1] = {ed::cAX, ed::cAY, ed::cRX, ed::cRY, ed::cSW, ed::cDW, ed::cDW + 16};
+    const uint32_t base[ED_BOUND - 1] = {ed::cAY, ed::cRY, ed::cSW, ed::cDW, ed::cDW + 16};
+    const uint32_t sign[2] = {ed::cSGA, ed::cSGR};
 #pragma unroll
     for (int k = 0; k < ED_BOUND - 1; k++) {
         acc = gl::mul(acc, gamma);
-        acc.a = gl::add(acc.a, trace[(size_t)(base[k] + j) * n + row]);
+        uint64_t v = trace[(size_t)(base[k] + j) * n + row];
+        if (k < 2 && j == 15) v += trace[(size_t)sign[k] * n + row] << 15;   // both small: no reduction needed before the add
+        acc.a = gl::add(acc.a, v);
     }
     acc = gl::mul(acc, gamma);
     if (j == 0) acc.a = gl::add(acc.a, trace[(size_t)ed::cACT * n + row]);
@@ -141,7 +144,7 @@ extern "C" int32_t nlx_ed25519_bind_round(nlx_ctx* ctx, const uint64_t* trace, u
     std::vector<gl::Ext> fp_h(n_slots), start(n_slots);
     int32_t rc = fetch(ctx, fp_h.data(), d_fp, (size_t)n_slots * sizeof(gl::Ext));
     if (!rc) {
-        // the slots' start values: acc_(s+1) = acc_s gamma^128 + fp_s (a few thousand extension multiplications, on the host)
+        // the slots' start values: acc_(s+1) = acc_s gamma^96 + fp_s (a few thousand extension multiplications, on the host)
         const gl::Ext g_slot = gl::pow(g, 16 * ED_BOUND);
         gl::Ext acc{0, 0};
         for (uint32_t k = 0; k < n_slots; k++) {
@@ -201,7 +204,7 @@ extern "C" int32_t nlx_ed25519_trace(nlx_ctx* ctx, const uint64_t* slots, uint32
     if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
     if (!rc && e0 != hipSuccess) rc = ctx->hip_fail(e0, "hipMemcpyAsync");
     if (!rc && bad != 0xFFFFFFFFu)
-        rc = ctx->fail(NLX_E_INVAL, "slot %u: the statement is false (the signature does not verify, A / R is not on the curve, or "
-                                    "S >= L); the trace was written but cannot satisfy the AIR", bad);
+        rc = ctx->fail(NLX_E_INVAL, "slot %u: the statement is false (the signature does not verify, A / R is not on the curve, "
+                                    "S >= L or a coordinate >= p); the trace was written but cannot satisfy the AIR", bad);
     return rc;
 }

@@ -31,8 +31,9 @@ comparisons h <= L - 1 and S <= L - 1 as additions h + d = L - 1 with range-chec
 carries in two looked-up cells per row, everything of degree 2.
 
 Binding to public data: a fifth and sixth challenge gamma (drawn with the lookup challenge, after round 0) and a
-round-1 accumulator column fold every slot's 128 limbs (A, R, S, D low half, D high half, active) into one Horner
-fingerprint in the quadratic extension; its total is a ROUND VALUE of the proof (stark.py).  Whoever relies on the proof
+round-1 accumulator column fold every slot's 96 limbs (the 32-byte encodings of A and R - y with the parity of x on top,
+both coordinates proved canonical, so decompression is part of the statement -, S, D low half, D high half, active) into
+one Horner fingerprint in the quadratic extension; its total is a ROUND VALUE of the proof (stark.py).  Whoever relies on the proof
 recomputes `fingerprint(slots, gamma)` from the tuples it believes were verified - public keys, signatures, SHA-512
 digests, activity flags - and compares; h never leaves the proof.  The check is the cofactorless one (ed25519-dalek's
 `verify`: [S]B - [h]A == R).
@@ -112,6 +113,10 @@ DH, DS = LAY.take(1, True), LAY.take(1, True)    # row j < 16: limb j of L - 1 -
 CHI = LAY.take(1)                                # ... and its high part (2^9 table)
 LAY.lookups9.append(CHI)
 BH, BS = LAY.take(1), LAY.take(1)                # row j <= 16: carry bit into limb j of h + (L - 1 - h) and S + (L - 1 - S)
+SGA, SGR = LAY.take(1), LAY.take(1)              # per slot: the sign bits of the encodings of A and R = the parity of A.x, R.x
+CXY = LAY.take(4, True)                          # row j < 16: limb j of p - 1 - v for v = A.x, A.y, R.x, R.y (canonical coordinates)
+KXA, KXR = LAY.take(1, True), LAY.take(1, True)  # row 0: (limb 0 of A.x, R.x) div 2
+BXY = LAY.take(4)                                # row j <= 16: the carry bits of those four additions
 MULT9, MULT = LAY.take(1), LAY.take(1)     # multiplicities of the 2^9 table, then (last: it may grow) of the 2^16 table
 LOOKUPS, LOOKUPS9 = list(LAY.lookups16), list(LAY.lookups9)
 
@@ -126,8 +131,11 @@ def layout(table_cols=1):
 
 
 N_COLS0, N_COLS1A, N_COLS1B, ACC, N_COLS1 = (layout()[k] for k in ("n_cols0", "n_cols1a", "n_cols1b", "acc", "n_cols1"))
-BOUND = (AX, AY, RX, RY, SW, DW, DW + 16)  # the per-slot limb vectors the fingerprint absorbs, limb 15 first; then `active` (limb 0 only)
+# what the fingerprint absorbs per limb index j, limb 15 first: the 32-byte ENCODINGS of A and R (y with the sign of x in
+# bit 255: (y column base, sign column)), S, the two halves of D, then `active` (limb 0 only)
+BOUND = ((AY, SGA), (RY, SGR), (SW, None), (DW, None), (DW + 16, None))
 N_BOUND = len(BOUND) + 1                   # values per limb index
+PM1_LIMBS = [((P - 1) >> (16 * i)) & 0xFFFF for i in range(16)]
 L_LIMBS = [(L_ORDER >> (16 * i)) & 0xFFFF for i in range(16)]
 LM1_LIMBS = [((L_ORDER - 1) >> (16 * i)) & 0xFFFF for i in range(16)]
 MODL_ROWS = 32                             # positions of D = q L + h, one per row from the slot's first row
@@ -247,6 +255,23 @@ def ed25519_air(max_resident_leaves=None, table_cols=1, segment_nodes=None):
         air.constraint(sel - lm1 + m16 * (L(comp) + b - N(bit) * 65536))
         air.constraint(e_row[0] * b)
         air.constraint(e_row[15] * N(bit))
+    # canonical coordinates (v <= p - 1, the same complement addition) and the encodings' sign bits (parity of x): what the
+    # fingerprint binds is the 32-byte encoding of A and of R, so "decompression" is part of the statement
+    pm1 = air.periodic([PM1_LIMBS[r] if r < 16 else 0 for r in range(ROWS)])
+    for v, base in enumerate((AX, AY, RX, RY)):
+        vsel = e_row[0] * L(base)
+        for k in range(1, 16):
+            vsel = vsel + e_row[k] * L(base + k)
+        b = L(BXY + v)
+        air.constraint(b * (b - 1))
+        air.constraint(vsel - pm1 + m16 * (L(CXY + v) + b - N(BXY + v) * 65536))
+        air.constraint(e_row[0] * b)
+        air.constraint(e_row[15] * N(BXY + v))
+    for sign, half, base in ((SGA, KXA, AX), (SGR, KXR, RX)):
+        sg = L(sign)
+        air.constraint(sg * (sg - 1))
+        air.constraint((1 - is_last) * (N(sign) - sg))
+        air.constraint(e_row[0] * (L(base) - L(half) * 2 - sg))
     # q's limbs pass through looked-up cells once per slot, like the limbs of A and R
     cur = block[0] * L(QW)
     for j in range(1, 16):
@@ -359,8 +384,8 @@ def ed25519_air(max_resident_leaves=None, table_cols=1, segment_nodes=None):
         air.constraint(no_sq * L(AUX_E + i))
         air.constraint(no_sq * L(AUX_F + i))
 
-    # ---- fingerprint of the slots' data: acc' = acc gamma^8 + sum_k gamma^(7-k) limb_k on the row that closes block j
-    # (limb j of AX, AY, RX, RY, S, D low, D high; then `active` for j = 0 and nothing for the other j), unchanged
+    # ---- fingerprint of the slots' data: acc' = acc gamma^6 + sum_k gamma^(5-k) limb_k on the row that closes block j
+    # (limb j of enc(A), enc(R), S, D low, D high; then `active` for j = 0 and nothing for the other j), unchanged
     # elsewhere; starts at 0, and the total after the last row is the proof's round value ----
     def ext_mul(x, y):
         return x[0] * y[0] + x[1] * y[1] * logup.W, x[0] * y[1] + x[1] * y[0]
@@ -371,12 +396,14 @@ def ed25519_air(max_resident_leaves=None, table_cols=1, segment_nodes=None):
     acc = (L(ACC), L(ACC + 1))
 
     def word(j):
-        """sum_k gamma^(7-k) value_(k,j) as an extension element: limb j of the seven vectors with weights gamma^7 .. gamma,
+        """sum_k gamma^(5-k) value_(k,j) as an extension element: limb j of the five vectors with weights gamma^5 .. gamma,
         the flag (limb 0 only) with weight 1"""
         w0, w1 = (act if j == 0 else None), None
-        for k in range(len(BOUND)):
+        for k, (base, sign) in enumerate(BOUND):
             g0, g1 = gam[len(BOUND) - 1 - k]
-            limb = L(BOUND[k] + j)
+            limb = L(base + j)
+            if sign is not None and j == 15:
+                limb = limb + L(sign) * 32768
             w0 = g0 * limb if w0 is None else w0 + g0 * limb
             w1 = g1 * limb if w1 is None else w1 + g1 * limb
         return w0, w1
@@ -386,8 +413,8 @@ def ed25519_air(max_resident_leaves=None, table_cols=1, segment_nodes=None):
         for c, wc in enumerate(word(j)):
             term = closing[j] * wc
             absorbed[c] = term if absorbed[c] is None else absorbed[c] + term
-    g_all = gam[N_BOUND - 1]                                   # gamma^8
-    grown = ext_mul(acc, (g_all[0] - 1, g_all[1]))             # acc (gamma^8 - 1)
+    g_all = gam[N_BOUND - 1]                                   # gamma^6
+    grown = ext_mul(acc, (g_all[0] - 1, g_all[1]))             # acc (gamma^6 - 1)
     total = ext_mul(acc, g_all)
     last_word = word(0)                                        # the last row of the trace closes block 0 of the last slot
     for c in range(2):
@@ -479,6 +506,15 @@ def reference_slot(ax, ay, rx, ry, s, d, active=1):
             t[DH, j], t[DS, j] = ml["dh"][j], ml["ds"][j]
             t[CHKQ, 16 * (15 - j) + 15] = ml["qw"][j]
     t[CHKQ + 1, ROWS - 1] = ml["qw"][16]
+    for v, x in enumerate((ax, ay, rx, ry)):
+        assert 0 <= x < P                                      # canonical coordinates only
+        xl, cl, carry = fp.to_limbs(x), fp.to_limbs(P - 1 - x), 0
+        for j in range(16):
+            t[CXY + v, j], t[BXY + v, j] = cl[j], carry
+            carry = (xl[j] + cl[j] + carry - PM1_LIMBS[j]) >> 16
+        assert carry == 0
+    t[SGA, :], t[SGR, :] = ax & 1, rx & 1
+    t[KXA, 0], t[KXR, 0] = (ax & 0xFFFF) >> 1, (rx & 0xFFFF) >> 1
 
     def put_unit(base, row, products, c=None):
         cl, ql, carries = fp.mul_unit_witness(products, c=c)
@@ -654,17 +690,32 @@ def _ext_mul(x, y):
 
 
 def bound_values(slot):
-    """The eight 256-bit values of a slot the fingerprint absorbs: A.x, A.y, R.x, R.y, S, D mod 2^256, D div 2^256, active."""
+    """The six 256-bit values of a slot the fingerprint absorbs: the RFC 8032 encodings of A and R (y with the parity of x in
+    bit 255 - the public key and the first half of the signature as little-endian integers), S, D mod 2^256, D div 2^256,
+    active."""
     ax, ay, rx, ry, s, d = slot[:6]
-    return ax, ay, rx, ry, s, d & ((1 << 256) - 1), d >> 256, (1 if len(slot) < 7 or slot[6] else 0)
+    return (ay | ((ax & 1) << 255), ry | ((rx & 1) << 255), s, d & ((1 << 256) - 1), d >> 256,
+            (1 if len(slot) < 7 or slot[6] else 0))
+
+
+def public_slot(public_key, signature, digest, active=1):
+    """The same six values from what a relying party holds - 32-byte key, 64-byte signature, 64-byte SHA-512 digest - with
+    no curve arithmetic: `fingerprint` accepts these tuples as well as full slots."""
+    return PublicSlot((int.from_bytes(public_key, "little"), int.from_bytes(signature[:32], "little"),
+                       int.from_bytes(signature[32:], "little"), int.from_bytes(digest[:32], "little"),
+                       int.from_bytes(digest[32:], "little"), 1 if active else 0))
+
+
+class PublicSlot(tuple):
+    """six bound values, already in the fingerprint's form"""
 
 
 def fingerprint(slots, gamma):
     """What the proof's round value must be for these slots: Horner in F_p^2 over, slot by slot, limb 15 down to limb 0
-    of (A.x, A.y, R.x, R.y, S, D low, D high, active) - the relying party's side of the binding."""
+    of (enc A, enc R, S, D low, D high, active) - the relying party's side of the binding."""
     acc = (0, 0)
     for sl in slots:
-        limbs = [fp.to_limbs(v) for v in bound_values(sl)]
+        limbs = [fp.to_limbs(v) for v in (sl if isinstance(sl, PublicSlot) else bound_values(sl))]
         for j in range(15, -1, -1):
             for k in range(N_BOUND):
                 acc = _ext_mul(acc, gamma)
@@ -684,7 +735,11 @@ def binding_columns(t0, gamma):
             j = 15 - (r % ROWS) // 16
             for k in range(N_BOUND):
                 acc = _ext_mul(acc, gamma)
-                v = int(t0[BOUND[k] + j, r]) if k < len(BOUND) else (int(t0[ACT, r]) if j == 0 else 0)
+                if k < len(BOUND):
+                    base, sign = BOUND[k]
+                    v = int(t0[base + j, r]) + (int(t0[sign, r]) << 15 if sign is not None and j == 15 else 0)
+                else:
+                    v = int(t0[ACT, r]) if j == 0 else 0
                 acc = ((acc[0] + v) % gl, acc[1])
     return out, acc
 
@@ -697,10 +752,11 @@ def slots_to_words(slots):
     the 512-bit digest, the flag, three spare words)"""
     out = np.zeros((len(slots), SLOT_WORDS), dtype=np.uint64)
     for k, sl in enumerate(slots):
-        for v, x in enumerate(bound_values(sl)[:7]):
+        ax, ay, rx, ry, s, d = sl[:6]
+        for v, x in enumerate((ax, ay, rx, ry, s, d & ((1 << 256) - 1), d >> 256)):
             for w in range(4):
                 out[k, 4 * v + w] = (int(x) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
-        out[k, 28] = bound_values(sl)[7]
+        out[k, 28] = 1 if len(sl) < 7 or sl[6] else 0
     return out
 
 

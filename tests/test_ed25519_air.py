@@ -42,6 +42,9 @@ def test_witness_generator_verifies_rfc8032(nlx):
         ax, ay, rx, ry, s, d, active = sl
         assert active == 1 and d == int.from_bytes(hashlib.sha512(bytes.fromhex(sig)[:32] + bytes.fromhex(pk) + bytes.fromhex(m)).digest(), "little")
         assert (-ax * ax + ay * ay - 1 - E.D * ax * ax * ay * ay) % E.P == 0
+        # what the fingerprint binds is what the verifier holds: key, signature, digest - no curve arithmetic needed
+        digest = hashlib.sha512(bytes.fromhex(sig)[:32] + bytes.fromhex(pk) + bytes.fromhex(m)).digest()
+        assert tuple(E.public_slot(bytes.fromhex(pk), bytes.fromhex(sig), digest)) == E.bound_values(sl)
         t, q = E.reference_slot(*sl)
         x4, y4, z4 = (F.from_limbs(v) for v in q)
         zi = pow(z4, E.P - 2, E.P)
@@ -49,10 +52,10 @@ def test_witness_generator_verifies_rfc8032(nlx):
         assert t.shape == (E.N_COLS0, 256) and int(t.max()) < P
     ax, ay, rx, ry, s, d, _ = rfc_slots(nlx)[1]
     for bad in ((ax, ay, rx, ry, s ^ 1, d), (ax, ay, rx, ry, s, d ^ 4), (ax, ay, rx, ry, s, d ^ (1 << 400)), (ax, ay, ry, rx, s, d), (ax + 1, ay, rx, ry, s, d),
-                (ax, ay, rx, ry, s + E.L_ORDER, d)):
+                (ax, ay, rx, ry, s + E.L_ORDER, d), (ax + E.P, ay, rx, ry, s, d), (ax, ay, rx, ry + E.P, s, d)):
         with pytest.raises(AssertionError):                          # a false statement has no witness
             E.reference_slot(*bad)
-        if bad[4] < E.L_ORDER:
+        if bad[4] < E.L_ORDER and max(bad[:4]) < E.P:
             E.reference_slot(*bad, active=0)                         # ... unless the slot's checks are off
     # the reduction mod L at its edges: D = 0, L - 1, L, 2^512 - 1, a multiple of L; S = L - 1
     for dd in (0, E.L_ORDER - 1, E.L_ORDER, (1 << 512) - 1, E.L_ORDER * ((1 << 259) + 12345), (1 << 256) - 1, 1 << 256):
@@ -75,7 +78,7 @@ def test_row_code_built_for_the_host_equals_reference(nlx, tmp_path):
     want = E.reference_trace(slots)
     text = "\n".join(slot_line(s) for s in slots) + "\n"
     subprocess.run([exe, out], input=text, text=True, check=True)
-    for bad in ((ax, ay, rx, ry, s ^ 2, d, 1), (ax, ay, rx, ry, s + E.L_ORDER, d, 0)):        # forged and active; S >= L
+    for bad in ((ax, ay, rx, ry, s ^ 2, d, 1), (ax, ay, rx, ry, s + E.L_ORDER, d, 0), (ax, ay + E.P, rx, ry, s, d, 0)):   # forged and active; S >= L; y >= p
         assert subprocess.run([exe, out + ".bad"], input=slot_line(bad) + "\n", text=True).returncode == 5
     got = np.fromfile(out, dtype=np.uint64).reshape(E.N_COLS0, -1)
     assert got.shape == want.shape
@@ -110,7 +113,7 @@ def test_every_constraint_vanishes_on_the_reference_trace(nlx, orc, tiled_case):
     E = nlx.ed25519_air
     slots, t0 = tiled_case
     air, _ = E.ed25519_air()
-    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 2506 and (len(E.LOOKUPS), len(E.LOOKUPS9)) == (777, 241)
+    assert air.constraint_degree == 3 and air.n_cols == E.N_COLS0 + E.N_COLS1 == 2524 and (len(E.LOOKUPS), len(E.LOOKUPS9)) == (783, 241)
     words = air.compile()
     known = [0x1234567890abcdef, 0x0fedcba987654321, 0x0123456789abcdef, 0x0edcba9876543210]     # alpha, gamma
     r1, total = oracle_round1(orc, E, t0, known)
@@ -139,7 +142,8 @@ def test_every_constraint_vanishes_on_the_reference_trace(nlx, orc, tiled_case):
     for col, row in ((E.SB, 40), (E.SIN + 3, 100), (E.MAIN[E.U_X4] + 2, 77), (E.MAIN[E.U_Y2] + 20, 5), (E.P2 + 17, 60), (E.SX3 + 1, 12), (E.SPT + 3, 16), (E.AUX + 1, 255), (E.AX + 1, 300),
                      (E.SW + 2, 9), (E.NT, 2), (E.AUX_E + 4, 30), (E.HA, 31), (E.ACC, 100), (E.ACC + 1, 16),
                      (E.ACT, 70), (E.DW + 3, 3), (E.DW + 20, 20), (E.DW + 31, 400), (E.QW + 2, 9), (E.QW + 16, 31), (E.CLO, 5), (E.CHI, 7), (E.CLO, 32),
-                     (E.DH, 3), (E.DS, 15), (E.BH, 4), (E.BS, 16), (E.CHKQ, 15), (E.CHKQ + 1, 255), (E.HW + 1, 1), (E.SW + 15, 15)):
+                     (E.DH, 3), (E.DS, 15), (E.BH, 4), (E.BS, 16), (E.CHKQ, 15), (E.CHKQ + 1, 255), (E.HW + 1, 1), (E.SW + 15, 15),
+                     (E.SGA, 30), (E.SGR, 255), (E.CXY, 0), (E.CXY + 3, 15), (E.BXY + 1, 7), (E.BXY + 2, 16), (E.KXA, 0), (E.KXR, 0), (E.AY + 15, 15)):
         assert violations(row, (col, row, 1)) or violations(row - 1, (col, row, 1)), (col, row)
     # the forged slot (rows 256 .. 511) is held together by its flag alone: with the flag on, its last row violates the
     # X comparison's sixteen limb equations (and the next row's Y comparison)
@@ -221,6 +225,12 @@ def test_gpu_real_near_approvals_and_a_forgery(nlx, ctx, orc):
     vals = orc.stark_values(pr.stark.desc, proof)
     tied = NP.slots_with_digests(stmt, outs) + [E.inactive_slot()] * ((1 << log_slots) - n_val)
     assert tied == slots and tuple(vals[4:6]) == E.fingerprint(tied, vals[2:4])
+    # and so do the raw bytes a verifier holds - keys, signatures, digests, flags - with no curve arithmetic at all
+    idle = E.PublicSlot(E.bound_values(E.inactive_slot()))
+    pubs = [idle if sig is None else E.public_slot(NP._key_bytes(bp["public_key"], 32), NP._key_bytes(sig, 64),
+                                                   hashlib.sha512(NP._key_bytes(sig, 64)[:32] + NP._key_bytes(bp["public_key"], 32) + stmt["message"]).digest())
+            for sig, bp in zip(nxt["approvals_after_next"], bps)]
+    assert tuple(vals[4:6]) == E.fingerprint(pubs + [idle] * ((1 << log_slots) - n_val), vals[2:4])
     outs[5] = [outs[5][0] ^ 1] + list(outs[5][1:])
     assert tuple(vals[4:6]) != E.fingerprint(NP.slots_with_digests(stmt, outs) + slots[n_val:], vals[2:4])
     # a validator that did not sign cannot be passed off as active ...
