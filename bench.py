@@ -625,14 +625,17 @@ def sync_step_setup(args, nlx, torch, rank, local):
     st["log_slots"] = max(4, (len(slots) - 1).bit_length())   # below 2^8 slots the range table is spread over several columns
     st["bound_slots"] = slots + [E.inactive_slot()] * ((1 << st["log_slots"]) - len(slots))
     st["slot_words"] = E.slots_to_words(st["bound_slots"])
-    # the four proofs get a context (HIP stream + scratch) each
-    ctxs = [nlx.Context(local) for _ in range(4)]
-    st["ctxs"] = ctxs
-    st["p256"], st["p512"] = SA.Sha256Prover(ctxs[0], st["lb256"]), SB.Sha512Prover(ctxs[1], st["lb512"])
-    st["ped"] = E.Ed25519Prover(ctxs[2], st["log_slots"])
-    syn = nlx.SyntheticCircuit(args.log_n, seed=1000 + rank, num_public_inputs=64, **GATE_MIXES[args.gate_mix])
+    # the four proofs get a context (HIP stream + scratch) each; the three STARK transcripts open with the step's tag
+    # (a hash of the step's 64 public I/O bytes - the outer proof's public inputs)
     io = nlx.nearx_io
     sync_in, sync_out = io.sync_io(io.load_fixture(os.path.join(near, "main_2.json")))
+    st["step_tag"] = nlx.stark.step_tag(sync_in + sync_out)
+    ctxs = [nlx.Context(local) for _ in range(4)]
+    st["ctxs"] = ctxs
+    st["p256"] = SA.Sha256Prover(ctxs[0], st["lb256"], step_tag=st["step_tag"])
+    st["p512"] = SB.Sha512Prover(ctxs[1], st["lb512"], step_tag=st["step_tag"])
+    st["ped"] = E.Ed25519Prover(ctxs[2], st["log_slots"], step_tag=st["step_tag"])
+    syn = nlx.SyntheticCircuit(args.log_n, seed=1000 + rank, num_public_inputs=64, **GATE_MIXES[args.gate_mix])
     syn.set_public_inputs(io.bytes_to_field_elements(sync_in + sync_out))
     st["syn"], st["sync_out"] = syn, sync_out
     st["cd"] = nlx.CircuitData.from_synthetic(ctxs[3], syn)
@@ -896,13 +899,14 @@ def cpu_baseline_sync(args, nlx, st, sha256_result, sha512_result, ed25519_proof
     blocks, first, digest = SA.blocks_for_messages(st["sha_msgs"], st["lb256"])
     tr, _ = SA.reference_trace(blocks, first)
     t = time.time()
-    want = oracle_py.stark_prove_rounds(st["p256"].stark.desc, SA.cpu_rounds(blocks, first, tr), digest)
+    tag = st["step_tag"]
+    want = oracle_py.stark_prove_rounds(st["p256"].stark.desc, SA.cpu_rounds(blocks, first, tr), [int(v) for v in digest] + tag)
     t256 = time.time() - t
     parity["sha256"] = {"log_blocks": st["lb256"], "bytes_equal": want == sha256_result[0]}
     blocks, first, digest = SB.blocks_for_messages(st["sig_msgs"], st["lb512"])
     tr, _ = SB.reference_trace(blocks, first)
     t = time.time()
-    want = oracle_py.stark_prove_rounds(st["p512"].stark.desc, SB.cpu_rounds(blocks, first, tr), SB.digest_halves(digest))
+    want = oracle_py.stark_prove_rounds(st["p512"].stark.desc, SB.cpu_rounds(blocks, first, tr), [int(v) for v in SB.digest_halves(digest)] + tag)
     t512 = time.time() - t
     parity["sha512"] = {"log_blocks": st["lb512"], "bytes_equal": want == sha512_result[0]}
     # the relying party's side of the two bindings (post-timing; the oracle only parses the proofs' round values): the
@@ -915,10 +919,13 @@ def cpu_baseline_sync(args, nlx, st, sha256_result, sha512_result, ed25519_proof
     ends = [i for i in range(len(blocks)) if i + 1 == len(blocks) or first[i + 1]][-st["n_sigs"]:]   # filler messages come first
     tied = nlx.near_protocol.slots_with_digests(st["statement"], [outs[i] for i in ends])
     tied += [E.inactive_slot()] * ((1 << st["log_slots"]) - len(tied))
-    parity["bindings"] = {"bytes_equal": tuple(v512[18:20]) == SB.fingerprint(blocks, first, v512[16:18])
-                          and tuple(ved[4:6]) == E.fingerprint(tied, ved[2:4]),
+    v256 = oracle_py.stark_values(st["p256"].stark.desc, sha256_result[0])
+    # values = public inputs (the AIR's own, then the 4-element step tag) | challenges | the fingerprint total
+    parity["bindings"] = {"bytes_equal": tuple(v512[22:24]) == SB.fingerprint(blocks, first, v512[20:22])
+                          and tuple(ved[8:10]) == E.fingerprint(tied, ved[6:8])
+                          and list(v256[8:12]) == list(v512[16:20]) == list(ved[0:4]) == tag,
                           "note": "SHA-512 and Ed25519 round values recomputed from the step's public data; the Ed25519 slots' D = the "
-                                  "SHA-512 proof's digests"}
+                                  "SHA-512 proof's digests; the three transcripts open with the same step tag (hash of the 64 I/O bytes)"}
     # Ed25519: 2^5 slots of the step's signatures
     s_slots = min(5, st["log_slots"])
     pr2 = E.Ed25519Prover(ctx, s_slots)

@@ -42,7 +42,7 @@ import numpy as np
 
 from . import fp25519 as fp
 from . import logup
-from .stark import Air, Stark
+from .stark import STEP_TAG_LEN, Air, Stark
 
 P = fp.P25519
 D = (-121665 * pow(121666, P - 2, P)) % P
@@ -169,10 +169,10 @@ class _Vec:
         return _Vec(lambda: [a * k for a in self.limbs], self.bound * abs(k))
 
 
-def ed25519_air(max_resident_leaves=None, table_cols=1, segment_nodes=None):
+def ed25519_air(max_resident_leaves=None, table_cols=1, segment_nodes=None, tagged=False):
     lay = layout(table_cols)
     ACC = lay["acc"]  # noqa: N806  (shadows the module constant, which is the table_cols = 1 value)
-    air = Air(lay["n_cols0"] + lay["n_cols1"], 0, rounds=[(lay["n_cols0"], 4), (lay["n_cols1"], 0)], round_values=[0, 2])
+    air = Air(lay["n_cols0"] + lay["n_cols1"], STEP_TAG_LEN if tagged else 0, rounds=[(lay["n_cols0"], 4), (lay["n_cols1"], 0)], round_values=[0, 2])
     if max_resident_leaves is not None:
         air.max_resident_leaves = max_resident_leaves
     # 400-node segments put the units whose operands are plain cells into their own low-register launch groups
@@ -763,14 +763,14 @@ def slots_to_words(slots):
 class Ed25519Stark:
     """The AIR compiled for 2^log_slots signature slots (256 rows each)."""
 
-    def __init__(self, log_slots, config=None, max_resident_leaves=None, segment_nodes=None):
+    def __init__(self, log_slots, config=None, max_resident_leaves=None, segment_nodes=None, tagged=False):
         if log_slots < 4:
             raise ValueError("at least 2^4 slots per proof")
         self.log_slots = log_slots
         # below 2^8 slots the trace is shorter than the 2^16-entry range table: spread the table over several columns
         self.table_cols = 1 << max(0, 8 - log_slots)
         self.layout = layout(self.table_cols)
-        self.air, self.range_checks = ed25519_air(max_resident_leaves, self.table_cols, segment_nodes)
+        self.air, self.range_checks = ed25519_air(max_resident_leaves, self.table_cols, segment_nodes, tagged)
         self.stark = Stark(self.air, log_slots + 8, config)
 
 
@@ -778,9 +778,10 @@ class Ed25519Prover:
     """Proves 2^log_slots Ed25519 verifications on one GPU: trace generation (nlx_ed25519_trace), multiplicities and
     lookup columns (nlx_logup_*), two-round STARK (nlx_stark_prove_rounds) - nothing of the trace touches the host."""
 
-    def __init__(self, ctx, log_slots, config=None, max_resident_leaves=None, segment_nodes=None):
+    def __init__(self, ctx, log_slots, config=None, max_resident_leaves=None, segment_nodes=None, step_tag=None):
         self.ctx = ctx
-        self.es = Ed25519Stark(log_slots, config, max_resident_leaves, segment_nodes)
+        self.step_tag = None if step_tag is None else [int(v) for v in step_tag]   # see stark.step_tag: public inputs 0..3
+        self.es = Ed25519Stark(log_slots, config, max_resident_leaves, segment_nodes, tagged=self.step_tag is not None)
         self.stark = self.es.stark
         self.prover = self.stark.build(ctx)
         self._t0 = self._t1 = None
@@ -823,7 +824,7 @@ class Ed25519Prover:
 
     def prove(self, slots):
         t0 = self.generate_trace(slots)
-        return self.prover.prove_rounds(lambda rnd, known: t0 if rnd == 0 else self.round1(known), [])
+        return self.prover.prove_rounds(lambda rnd, known: t0 if rnd == 0 else self.round1(known), self.step_tag or [])
 
     def close(self):
         self.prover.close()

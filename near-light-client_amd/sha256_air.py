@@ -39,7 +39,7 @@ import struct
 
 import numpy as np
 
-from .stark import Air
+from .stark import STEP_TAG_LEN, Air
 
 SLOT = 105                      # columns per round slot
 oA, oE, oW, oCA, oCE, oCW, oSW = 0, 32, 64, 96, 99, 102, 104
@@ -81,8 +81,8 @@ K = _round_constants()
 assert K[0] == 0x428a2f98 and K[63] == 0xc67178f2
 
 
-def sha256_air():
-    air = Air(N_COLS + 2, 8, rounds=[(N_COLS, 2), (2, 0)], round_values=[0, 2])
+def sha256_air(tagged=False):
+    air = Air(N_COLS + 2, 8 + (STEP_TAG_LEN if tagged else 0), rounds=[(N_COLS, 2), (2, 0)], round_values=[0, 2])   # tagged: public inputs 8..11 = the step tag
     L, N = air.local, air.next  # noqa: N806
     two32 = 1 << 32
     k_slot = [air.periodic([K[16 * q + j] for q in range(4)]) for j in range(16)]
@@ -383,13 +383,14 @@ class Sha256Prover:
     binding accumulator (nlx_sha256_bind_round) once the prover has drawn gamma, and the two-round STARK
     (nlx_stark_prove_rounds) on the device-resident columns.  2^log_blocks compression blocks per proof."""
 
-    def __init__(self, ctx, log_blocks, config=None, segment_nodes=None):
+    def __init__(self, ctx, log_blocks, config=None, segment_nodes=None, step_tag=None):
         from .stark import Stark
         self.ctx = ctx
+        self.step_tag = None if step_tag is None else [int(v) for v in step_tag]   # see stark.step_tag
         self.log_blocks = log_blocks
         if log_blocks < 2:
             raise ValueError("at least four blocks per proof (a block is four trace rows, a STARK at least sixteen)")
-        air = sha256_air()
+        air = sha256_air(tagged=self.step_tag is not None)
         if segment_nodes is not None:
             air.segment_nodes = segment_nodes
         self.stark = Stark(air, log_blocks + 2, config)
@@ -426,7 +427,8 @@ class Sha256Prover:
 
     def prove_trace(self, digest):
         """The proof for the trace generate_trace() left on the device (public inputs: the last digest)."""
-        return self.prover.prove_rounds(lambda rnd, known: self._trace if rnd == 0 else self.round1(known), digest)
+        pis = [int(v) for v in digest] + (self.step_tag or [])
+        return self.prover.prove_rounds(lambda rnd, known: self._trace if rnd == 0 else self.round1(known), pis)
 
     def prove(self, messages):
         """Returns (proof bytes, digest words of the last message in the batch)."""

@@ -34,7 +34,7 @@ import struct
 
 import numpy as np
 
-from .stark import Air
+from .stark import STEP_TAG_LEN, Air
 
 ROUNDS = 80
 SLOTS = 20                      # rounds per row
@@ -81,8 +81,8 @@ def _halves(x):
     return x & 0xFFFFFFFF, x >> 32
 
 
-def sha512_air():
-    air = Air(N_COLS + 2, 16, rounds=[(N_COLS, 2), (2, 0)], round_values=[0, 2])
+def sha512_air(tagged=False):
+    air = Air(N_COLS + 2, 16 + (STEP_TAG_LEN if tagged else 0), rounds=[(N_COLS, 2), (2, 0)], round_values=[0, 2])   # tagged: public inputs 16..19 = the step tag
     L, N = air.local, air.next  # noqa: N806
     two32 = 1 << 32
     k_slot = [[air.periodic([_halves(K[SLOTS * q + j])[h] for q in range(4)]) for h in range(2)] for j in range(SLOTS)]
@@ -413,13 +413,14 @@ class Sha512Prover:
     """Proves SHA-512 of a batch of messages on one GPU: trace generation (nlx_sha512_trace) straight into HBM,
     then nlx_stark_prove on the device-resident trace.  2^log_blocks compression blocks per proof."""
 
-    def __init__(self, ctx, log_blocks, config=None, segment_nodes=None):
+    def __init__(self, ctx, log_blocks, config=None, segment_nodes=None, step_tag=None):
         from .stark import Stark
         self.ctx = ctx
         self.log_blocks = log_blocks
         if log_blocks < 2:
             raise ValueError("at least four blocks per proof (a block is four trace rows, a STARK at least sixteen)")
-        air = sha512_air()
+        self.step_tag = None if step_tag is None else [int(v) for v in step_tag]   # see stark.step_tag
+        air = sha512_air(tagged=self.step_tag is not None)
         if segment_nodes is not None:
             air.segment_nodes = segment_nodes
         self.stark = Stark(air, log_blocks + 2, config)
@@ -463,7 +464,8 @@ class Sha512Prover:
 
     def prove_trace(self, public_inputs):
         """The proof for the trace generate_trace() left on the device (public inputs: the last digest's sixteen halves)."""
-        return self.prover.prove_rounds(lambda rnd, known: self._trace if rnd == 0 else self.round1(known), public_inputs)
+        pis = [int(v) for v in public_inputs] + (self.step_tag or [])
+        return self.prover.prove_rounds(lambda rnd, known: self._trace if rnd == 0 else self.round1(known), pis)
 
     def close(self):
         self.prover.close()

@@ -126,6 +126,18 @@ class _Expr:
     __rmul__ = __mul__
 
 
+STEP_TAG_LEN = 4   # field elements of a step tag: extra public inputs that no constraint reads but every transcript absorbs
+
+
+def step_tag(data):
+    """Four field elements naming a job (e.g. one Sync step: SHA-256 of its public input and output bytes, 56 bits per
+    element).  The AIRs of one job declare STEP_TAG_LEN extra public inputs and all take the same tag, so the transcripts of
+    its proofs open with the same values and a proof made for one step cannot be presented with another's."""
+    import hashlib
+    h = hashlib.sha256(bytes(data)).digest()
+    return [int.from_bytes(h[7 * i:7 * i + 7], "little") for i in range(STEP_TAG_LEN)]
+
+
 class Air:
     """An AIR over `n_cols` trace columns and `num_public_inputs` public inputs."""
 

@@ -169,3 +169,30 @@ def test_gpu_sha512_of_real_approval_signatures(nlx, ctx, orc):
     assert [int(x) for x in digest] == list(struct.unpack(">8Q", hashlib.sha512(msgs[-1]).digest()))
     assert orc.stark_verify(sp.stark.desc, proof) == 1
     sp.close()
+
+
+@pytest.mark.gpu
+def test_gpu_step_tag_opens_the_transcripts(nlx, ctx, orc):
+    """A tagged prover's AIR declares four extra public inputs that no constraint reads; the transcript absorbs them, so
+    proofs of one job (same tag) are told apart from another job's: bytes equal the oracle's with the tag, differ between
+    tags, and the verifier rejects a proof whose tag was edited afterwards."""
+    SB, S = nlx.sha512_air, nlx.stark
+    msgs = [b"abc", b"step tag"]
+    tag_a, tag_b = S.step_tag(b"step A"), S.step_tag(b"step B")
+    assert len(tag_a) == 4 and tag_a != tag_b and max(tag_a) < (1 << 56) and S.step_tag(b"step A") == tag_a
+    pa, pb, plain = (SB.Sha512Prover(ctx, 2, nlx.StarkConfig(fri_num_queries=10), step_tag=t) for t in (tag_a, tag_b, None))
+    assert pa.stark.desc.num_public_inputs == 20 and plain.stark.desc.num_public_inputs == 16
+    proof_a, digest = pa.prove(msgs)
+    proof_b, _ = pb.prove(msgs)
+    assert proof_a != proof_b and orc.stark_verify(pa.stark.desc, proof_a) == 1 and orc.stark_verify(pb.stark.desc, proof_b) == 1
+    blocks, first, _ = SB.blocks_for_messages(msgs, 2)
+    tr, _ = SB.reference_trace(blocks, first)
+    assert proof_a == orc.stark_prove_rounds(pa.stark.desc, SB.cpu_rounds(blocks, first, tr), [int(v) for v in SB.digest_halves(digest)] + tag_a)
+    vals = orc.stark_values(pa.stark.desc, proof_a)
+    assert list(vals[16:20]) == tag_a and tuple(vals[22:24]) == SB.fingerprint(blocks, first, vals[20:22])
+    # the tag travels in the proof (public inputs): swapping it for the other job's breaks the transcript
+    k = proof_a.find(int(tag_a[0]).to_bytes(8, "little"))
+    assert k >= 0
+    assert orc.stark_verify(pa.stark.desc, proof_a[:k] + int(tag_b[0]).to_bytes(8, "little") + proof_a[k + 8:]) != 1
+    for p_ in (pa, pb, plain):
+        p_.close()
