@@ -132,6 +132,13 @@ int32_t nlx_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_
  * the root of unity is gnark-crypto's (5^((r-1)/2^28)).  inverse = 1 also multiplies by 1/n. */
 #define NLX_BN254_MONTGOMERY 1u
 int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags);
+/* ---- f.4 (second piece): the G1 multi-scalar multiplication of the wrap's KZG commitments (gnark-crypto ecc/bn254
+ * G1Affine.MultiExp(points, scalars, config)).  points: n x 8 little-endian 64-bit words = gnark-crypto's G1Affine as it lies in
+ * memory (X then Y, each an fp.Element in Montgomery form, R = 2^256; the point at infinity is (0, 0)); scalars: n x 4 words,
+ * fr.Element in Montgomery form with flags = NLX_BN254_MONTGOMERY, canonical integers < r with flags = 0.  out: sum_i
+ * scalars[i] * points[i] as a G1Affine (8 words, Montgomery; (0, 0) for the point at infinity).  points / scalars may be host
+ * or device pointers; n <= 2^27.  Points are taken to be on the curve (as MultiExp does). */
+int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t flags, uint64_t out[8]);
 
 /* ---- a3: plonky2::fri::oracle::PolynomialBatch::{from_values, from_coeffs} ----
  * values / coeffs: n_cols x 2^log_n column-major, natural order.  The coset shift is the

@@ -197,3 +197,54 @@ def bn254_ntt(ctx, cols, inverse=False, montgomery=False):
     p = c.data_ptr() if hasattr(c, "data_ptr") else c.ctypes.data
     ctx.check(dll.nlx_bn254_ntt_batch(ctx.handle, p, n_cols, log_n, 1 if inverse else 0, 1 if montgomery else 0))
     return c
+
+
+# ---- row f.4, second piece: the BN254 G1 multi-scalar multiplication (csrc/bn254_msm.hip, nlx_bn254_msm_g1) ----
+BN254_Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+_MONT_Q = (1 << 256) % BN254_Q
+
+
+def bn254_g1_pack(points):
+    """[(x, y) | None] (affine integers < q; None = the point at infinity) -> (n, 8) uint64: gnark-crypto's G1Affine layout
+    (X, Y in Montgomery form, four little-endian words each; infinity = all zero)"""
+    out = np.zeros((len(points), 8), dtype=np.uint64)
+    for i, pt in enumerate(points):
+        if pt is None:
+            continue
+        for c, v in enumerate(pt):
+            m = int(v) * _MONT_Q % BN254_Q
+            for w in range(4):
+                out[i, 4 * c + w] = (m >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def bn254_g1_unpack(words):
+    """8 uint64 words (G1Affine, Montgomery) -> (x, y) integers, or None for the point at infinity"""
+    w = [int(v) for v in np.asarray(words, dtype=np.uint64).reshape(8)]
+    x, y = (sum(w[4 * c + k] << (64 * k) for k in range(4)) for c in range(2))
+    if x == 0 and y == 0:
+        return None
+    rinv = pow(_MONT_Q, BN254_Q - 2, BN254_Q)
+    return x * rinv % BN254_Q, y * rinv % BN254_Q
+
+
+def bn254_msm_g1(ctx, points, scalars, montgomery=False):
+    """gnark-crypto G1Affine.MultiExp: sum_i scalars[i] * points[i].  points: (n, 8) uint64 (bn254_g1_pack) or a device tensor
+    of that shape; scalars: (n, 4) uint64 - canonical integers < r, or fr.Element Montgomery words with montgomery=True - or
+    a device tensor.  Returns the 8 words of the result (G1Affine, Montgomery; all zero = infinity)."""
+    def ptr(a, width):
+        if hasattr(a, "data_ptr"):
+            if tuple(a.shape)[1:] != (width,) or not a.is_contiguous():
+                raise ValueError("expected a contiguous (n, %d) tensor" % width)
+            return a, a.data_ptr(), a.shape[0]
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        if a.ndim != 2 or a.shape[1] != width:
+            raise ValueError("expected shape (n, %d)" % width)
+        return a, a.ctypes.data, a.shape[0]
+    p_keep, p_ptr, n = ptr(points, 8)
+    s_keep, s_ptr, n2 = ptr(scalars, 4)
+    if n != n2:
+        raise ValueError("points and scalars differ in length")
+    out = np.zeros(8, dtype=np.uint64)
+    ctx.check(dll.nlx_bn254_msm_g1(ctx.handle, p_ptr if n else None, s_ptr if n else None, n, 1 if montgomery else 0, out.ctypes.data))
+    return out

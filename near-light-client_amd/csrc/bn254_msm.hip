@@ -1,0 +1,253 @@
+// Multi-scalar multiplication over BN254 G1 for gfx950 - the second piece of SURVEY.md §8 row f.4 (the recursive wrap: a
+// gnark PLONK / Groth16 prover over BN254 commits to its polynomials with KZG, i.e. one G1 MSM of the circuit's size per
+// polynomial; BASELINE.json configs[4] puts that size at 2^24).  The wrap is not in /root/reference (succinct.json:7-8 only
+// names the platform entry point; gnark-crypto is Go, un-vendored): this follows the published definitions - the curve
+// y^2 = x^3 + 3 over Fq, its group order r - and gnark-crypto's memory layout (G1Affine = X, Y as fp.Element: four
+// little-endian 64-bit words each, Montgomery form, the point at infinity as (0, 0); scalars as fr.Element), so that
+// ecc/bn254 G1Affine.MultiExp(points, scalars) can be replaced by one call on the caller's slices.
+//
+// Bucket method (Pippenger) with 16-bit unsigned windows, laid out for the GPU:
+//   k_msm_digits   one lane per scalar: out of Montgomery form, sixteen 16-bit digits -> one (digit, index) pair per window
+//                  and a histogram of the digits (global atomics, 2^20 counters);
+//   hipcub         exclusive scan of the histogram = where every bucket starts in the sorted order; radix sort of each
+//                  window's pairs by digit (16-bit keys);
+//   k_msm_buckets  one lane per bucket (16 x 65 535 of them): the sum of its points by mixed Jacobian additions, points
+//                  fetched through the sorted indices - at 2^24 points a bucket holds ~256, so neighbouring lanes run
+//                  loops of similar length;
+//   k_msm_reduce   per window sum_b b * B_b: 256 lanes x 256 buckets each by running sums, the chunk offsets by a 16-bit
+//                  double-and-add, the 256 partial results through LDS;
+//   host           sum_w 2^(16 w) W_w (240 doublings) and the one inversion for the affine result.
+// Bound: integer VALU - a mixed addition is 11 field multiplications of ~170 multiply-adds each.
+#include <hipcub/hipcub.hpp>
+#include <vector>
+#include "bn254_fp.hpp"
+#include "ctx.hpp"
+#include "transcript.hpp"
+#include "../../include/nlx.h"
+
+namespace nlx {
+namespace msm {
+
+using namespace bnf;
+typedef Fp<QP> Fq;
+typedef Fp<RP> Fr;
+
+constexpr int WINDOW_BITS = 16, N_WINDOWS = 16, N_BUCKETS = 1 << WINDOW_BITS;
+
+struct Affine { Fq x, y; };       // (0, 0) = the point at infinity (gnark-crypto's convention; not on the curve)
+struct Jac { Fq x, y, z; };       // z = 0: the point at infinity
+
+BNF_HD bool is_inf(const Affine& p) { return is_zero(p.x) && is_zero(p.y); }
+BNF_HD Jac jac_inf() { return Jac{one<QP>(), one<QP>(), zero<QP>()}; }
+BNF_HD Jac from_affine(const Affine& p) { return is_inf(p) ? jac_inf() : Jac{p.x, p.y, one<QP>()}; }
+
+// dbl-2009-l (a = 0): 2M + 5S
+BNF_HD Jac jdbl(const Jac& p) {
+    if (is_zero(p.z)) return p;
+    const Fq a = sqr(p.x), b = sqr(p.y), c = sqr(b);
+    Fq d = sub(sub(sqr(add(p.x, b)), a), c);
+    d = dbl(d);
+    const Fq e = add(dbl(a), a), f = sqr(e);
+    Jac r;
+    r.x = sub(f, dbl(d));
+    r.y = sub(mul(e, sub(d, r.x)), dbl(dbl(dbl(c))));
+    r.z = dbl(mul(p.y, p.z));
+    return r;
+}
+// madd-2007-bl: Jacobian + affine, 7M + 4S; the exceptional cases (infinity on either side, equal or opposite points) are
+// real here: a bucket may well receive the same point twice
+BNF_HD Jac jmadd(const Jac& p, const Affine& q) {
+    if (is_inf(q)) return p;
+    if (is_zero(p.z)) return Jac{q.x, q.y, one<QP>()};
+    const Fq z1z1 = sqr(p.z), u2 = mul(q.x, z1z1), s2 = mul(mul(q.y, p.z), z1z1);
+    const Fq h = sub(u2, p.x);
+    Fq r = sub(s2, p.y);
+    if (is_zero(h)) {
+        if (is_zero(r)) return jdbl(Jac{q.x, q.y, one<QP>()});
+        return jac_inf();
+    }
+    r = dbl(r);
+    const Fq hh = sqr(h), i = dbl(dbl(hh)), j = mul(h, i), v = mul(p.x, i);
+    Jac o;
+    o.x = sub(sub(sqr(r), j), dbl(v));
+    o.y = sub(mul(r, sub(v, o.x)), dbl(mul(p.y, j)));
+    o.z = sub(sub(sqr(add(p.z, h)), z1z1), hh);
+    return o;
+}
+// add-2007-bl: 11M + 5S
+BNF_HD Jac jadd(const Jac& p, const Jac& q) {
+    if (is_zero(p.z)) return q;
+    if (is_zero(q.z)) return p;
+    const Fq z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+    const Fq u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
+    const Fq s1 = mul(mul(p.y, q.z), z2z2), s2 = mul(mul(q.y, p.z), z1z1);
+    const Fq h = sub(u2, u1);
+    Fq r = sub(s2, s1);
+    if (is_zero(h)) {
+        if (is_zero(r)) return jdbl(p);
+        return jac_inf();
+    }
+    r = dbl(r);
+    const Fq i = sqr(dbl(h)), j = mul(h, i), v = mul(u1, i);
+    Jac o;
+    o.x = sub(sub(sqr(r), j), dbl(v));
+    o.y = sub(mul(r, sub(v, o.x)), dbl(mul(s1, j)));
+    o.z = mul(sub(sub(sqr(add(p.z, q.z)), z1z1), z2z2), h);
+    return o;
+}
+BNF_HD Jac jneg(const Jac& p) { return Jac{p.x, neg(p.y), p.z}; }
+
+// ---- digits ----
+__global__ __launch_bounds__(256) void k_msm_digits(const uint64_t* __restrict__ scalars, size_t n, int montgomery,
+                                                    uint16_t* __restrict__ keys /* [window][n] */, uint32_t* __restrict__ hist /* [window][65536] */) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = load_words<RP>(scalars + 4 * i);
+    if (montgomery) s = from_mont(s);
+    else if (geq_mod(s)) sub_mod_raw(s);   // a non-reduced word string: fold once (callers hand reduced values)
+#pragma unroll
+    for (int w = 0; w < N_WINDOWS; w++) {
+        const uint32_t d = (s.v[w >> 1] >> (16 * (w & 1))) & 0xFFFFu;
+        keys[(size_t)w * n + i] = (uint16_t)d;
+        atomicAdd(hist + (size_t)w * N_BUCKETS + d, 1u);   // digit 0 too: its pairs sort first and the scan must step over them
+    }
+}
+__global__ __launch_bounds__(256) void k_msm_iota(uint32_t* __restrict__ v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+
+// ---- bucket sums: lane (w, b) adds the points whose window-w digit is b ----
+__global__ __launch_bounds__(64) void k_msm_buckets(const Affine* __restrict__ points, const uint32_t* __restrict__ sorted /* [window][n] */,
+                                                    const uint32_t* __restrict__ starts /* [window * 65536 + 1]: exclusive scan */,
+                                                    Jac* __restrict__ buckets /* [window][65536] */) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // = w * 65536 + b
+    if (t >= (uint32_t)N_WINDOWS * N_BUCKETS) return;
+    Jac acc = jac_inf();
+    if ((t & (N_BUCKETS - 1)) != 0) {   // bucket 0 weighs nothing
+        const uint32_t lo = starts[t], hi = starts[t + 1];   // positions in the window-major sorted array
+#pragma unroll 1
+        for (uint32_t p = lo; p < hi; p++) acc = jmadd(acc, points[sorted[p]]);
+    }
+    buckets[t] = acc;
+}
+
+// ---- window sums: W_w = sum_b b B_b.  Lane c of block w owns buckets 256 c .. 256 c + 255 ----
+constexpr int RED_LANES = 256, RED_CHUNK = N_BUCKETS / RED_LANES;
+__global__ __launch_bounds__(RED_LANES) void k_msm_reduce(const Jac* __restrict__ buckets, Jac* __restrict__ window_sums) {
+    __shared__ Jac part[RED_LANES];
+    const uint32_t w = blockIdx.x, c = threadIdx.x, base = c * RED_CHUNK;
+    const Jac* b = buckets + (size_t)w * N_BUCKETS + base;
+    Jac running = jac_inf(), local = jac_inf();
+#pragma unroll 1
+    for (int j = RED_CHUNK - 1; j >= 0; j--) {   // running = sum_{j' >= j} B, local = sum_j (j + 1) B_(base + j)
+        running = jadd(running, b[j]);
+        local = jadd(local, running);
+    }
+    // sum_j (base + j) B = local + (base - 1) * running; for the first chunk that is local - running
+    Jac shifted = jac_inf();
+    if (c == 0) {
+        shifted = jneg(running);
+    } else {
+        const uint32_t k = base - 1;
+#pragma unroll 1
+        for (int bit = 15; bit >= 0; bit--) {
+            shifted = jdbl(shifted);
+            if ((k >> bit) & 1) shifted = jadd(shifted, running);
+        }
+    }
+    part[c] = jadd(local, shifted);
+    __syncthreads();
+#pragma unroll 1
+    for (int stride = RED_LANES / 2; stride > 0; stride >>= 1) {
+        if (c < (uint32_t)stride) part[c] = jadd(part[c], part[c + stride]);
+        __syncthreads();
+    }
+    if (c == 0) window_sums[w] = part[0];
+}
+
+}  // namespace msm
+}  // namespace nlx
+
+using namespace nlx;
+
+extern "C" int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t flags,
+                                    uint64_t out[8]) {
+    using namespace nlx::msm;
+    if (!ctx) return NLX_E_INVAL;
+    if (!out || (n && (!points || !scalars))) return ctx->fail(NLX_E_INVAL, "NULL argument");
+    if (flags & ~(uint32_t)NLX_BN254_MONTGOMERY) return ctx->fail(NLX_E_RANGE, "unknown flag");
+    if (n > ((uint64_t)1 << 27)) return ctx->fail(NLX_E_RANGE, "at most 2^27 points per call (32-bit positions of 16 n pairs)");
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    if (n == 0) return NLX_OK;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    Staged sp(ctx, points, (size_t)n * 64, true, false);
+    if (sp.status) return sp.status;
+    Staged ss(ctx, scalars, (size_t)n * 32, true, false);
+    if (ss.status) return ss.status;
+    const size_t pairs = (size_t)n * N_WINDOWS, n_hist = (size_t)N_WINDOWS * N_BUCKETS;
+    uint16_t* d_keys = (uint16_t*)ctx->alloc(pairs * 2);
+    uint16_t* d_keys_sorted = (uint16_t*)ctx->alloc((size_t)n * 2);
+    uint32_t* d_iota = (uint32_t*)ctx->alloc((size_t)n * 4);
+    uint32_t* d_sorted = (uint32_t*)ctx->alloc(pairs * 4);
+    uint32_t* d_hist = (uint32_t*)ctx->alloc((n_hist + 1) * 4);
+    uint32_t* d_starts = (uint32_t*)ctx->alloc((n_hist + 1) * 4);
+    Jac* d_buckets = (Jac*)ctx->alloc(n_hist * sizeof(Jac));
+    Jac* d_wsum = (Jac*)ctx->alloc(N_WINDOWS * sizeof(Jac));
+    size_t tmp_sort = 0, tmp_scan = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, d_keys, d_keys_sorted, d_iota, d_sorted, (int)n, 0, WINDOW_BITS, st);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, d_hist, d_starts, (int)(n_hist + 1), st);
+    const size_t tmp_bytes = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+    void* d_tmp = ctx->alloc(tmp_bytes ? tmp_bytes : 16);
+    auto release_all = [&]() {
+        for (void* p : {(void*)d_keys, (void*)d_keys_sorted, (void*)d_iota, (void*)d_sorted, (void*)d_hist, (void*)d_starts,
+                        (void*)d_buckets, (void*)d_wsum, d_tmp})
+            if (p) ctx->release(p);
+    };
+    if (!d_keys || !d_keys_sorted || !d_iota || !d_sorted || !d_hist || !d_starts || !d_buckets || !d_wsum || !d_tmp) {
+        release_all();
+        return NLX_E_NOMEM;
+    }
+    int32_t rc = NLX_OK;
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && !rc) rc = ctx->hip_fail(e, what);
+        return e == hipSuccess;
+    };
+    const unsigned blocks_n = (unsigned)((n + 255) / 256);
+    hip_ok(hipMemsetAsync(d_hist, 0, (n_hist + 1) * 4, st), "hipMemsetAsync");
+    // algorithmic bytes of the whole job: every point and scalar once
+    ctx->begin_kernel("bn254_msm_g1", 96.0 * (double)n, n);
+    hipLaunchKernelGGL(k_msm_digits, dim3(blocks_n), dim3(256), 0, st, ss.as<uint64_t>(), (size_t)n,
+                       (flags & NLX_BN254_MONTGOMERY) ? 1 : 0, d_keys, d_hist);
+    hipLaunchKernelGGL(k_msm_iota, dim3(blocks_n), dim3(256), 0, st, d_iota, (size_t)n);
+    size_t tb = tmp_bytes;
+    hip_ok(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_hist, d_starts, (int)(n_hist + 1), st), "hipcub::ExclusiveSum");
+    for (int w = 0; w < N_WINDOWS && !rc; w++) {
+        tb = tmp_bytes;
+        hip_ok(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys + (size_t)w * n, d_keys_sorted, d_iota, d_sorted + (size_t)w * n,
+                                                  (int)n, 0, WINDOW_BITS, st), "hipcub::SortPairs");
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)(n_hist / 64)), dim3(64), 0, st, sp.as<Affine>(), d_sorted, d_starts, d_buckets);
+        hipLaunchKernelGGL(k_msm_reduce, dim3(N_WINDOWS), dim3(RED_LANES), 0, st, d_buckets, d_wsum);
+    }
+    ctx->end_kernel();
+    Jac wsum[N_WINDOWS];
+    if (!rc) rc = fetch(ctx, wsum, d_wsum, sizeof(wsum));
+    hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
+    hip_ok(hipGetLastError(), "kernel launch");
+    release_all();
+    if (rc) return rc;
+    // sum_w 2^(16 w) W_w, then to affine
+    Jac acc = wsum[N_WINDOWS - 1];
+    for (int w = N_WINDOWS - 2; w >= 0; w--) {
+        for (int k = 0; k < WINDOW_BITS; k++) acc = jdbl(acc);
+        acc = jadd(acc, wsum[w]);
+    }
+    if (is_zero(acc.z)) return NLX_OK;   // infinity: (0, 0)
+    const Fq zi = inv_host(acc.z), zi2 = sqr(zi);
+    store_words(mul(acc.x, zi2), out);
+    store_words(mul(acc.y, mul(zi2, zi)), out + 4);
+    return NLX_OK;
+}

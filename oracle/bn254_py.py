@@ -52,3 +52,85 @@ def to_montgomery(x):
 
 def from_montgomery(x):
     return int(x) * pow(MONT_R, R - 2, R) % R
+
+
+# ---- G1: y^2 = x^3 + 3 over Fq, generator (1, 2), group order R (EIP-196's alt_bn128) ----
+Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+G1 = (1, 2)
+
+
+def g1_add(p, q):
+    """affine addition; None = the point at infinity"""
+    if p is None:
+        return q
+    if q is None:
+        return p
+    x1, y1 = p
+    x2, y2 = q
+    if x1 == x2:
+        if (y1 + y2) % Q == 0:
+            return None
+        lam = 3 * x1 * x1 * pow(2 * y1, Q - 2, Q) % Q
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, Q - 2, Q) % Q
+    x3 = (lam * lam - x1 - x2) % Q
+    return x3, (lam * (x1 - x3) - y1) % Q
+
+
+def g1_neg(p):
+    return None if p is None else (p[0], (-p[1]) % Q)
+
+
+def _jac_dbl(p):
+    x, y, z = p
+    if z == 0:
+        return p
+    a, b = x * x % Q, y * y % Q
+    c = b * b % Q
+    d = 2 * ((x + b) * (x + b) - a - c) % Q
+    e = 3 * a % Q
+    x3 = (e * e - 2 * d) % Q
+    return x3, (e * (d - x3) - 8 * c) % Q, 2 * y * z % Q
+
+
+def _jac_add_affine(p, q):
+    x1, y1, z1 = p
+    if z1 == 0:
+        return q[0], q[1], 1
+    z1z1 = z1 * z1 % Q
+    u2, s2 = q[0] * z1z1 % Q, q[1] * z1 * z1z1 % Q
+    h, r = (u2 - x1) % Q, (s2 - y1) % Q
+    if h == 0:
+        return _jac_dbl((q[0], q[1], 1)) if r == 0 else (1, 1, 0)
+    hh = h * h % Q
+    hhh, v = h * hh % Q, x1 * hh % Q
+    x3 = (r * r - hhh - 2 * v) % Q
+    return x3, (r * (v - x3) - y1 * hhh) % Q, z1 * h % Q
+
+
+def g1_mul(k, p):
+    """k * p by double-and-add in Jacobian coordinates (one inversion at the end)"""
+    k %= R
+    if p is None or k == 0:
+        return None
+    acc = (1, 1, 0)
+    for bit in range(k.bit_length() - 1, -1, -1):
+        acc = _jac_dbl(acc)
+        if (k >> bit) & 1:
+            acc = _jac_add_affine(acc, p)
+    if acc[2] == 0:
+        return None
+    zi = pow(acc[2], Q - 2, Q)
+    return acc[0] * zi * zi % Q, acc[1] * zi * zi * zi % Q
+
+
+def msm_g1(scalars, points):
+    """sum_i scalars[i] * points[i], term by term"""
+    acc = None
+    for k, p in zip(scalars, points):
+        acc = g1_add(acc, g1_mul(int(k), p))
+    return acc
+
+
+assert g1_add(G1, G1) == (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+                          9918110051302171585080402603319702774565515993150576347155970296011118125764)   # EIP-196's 2 G

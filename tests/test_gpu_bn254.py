@@ -59,3 +59,79 @@ def test_bn254_ntt_argument_checks(nlx, ctx):
     with pytest.raises(nlx.NlxError):
         a = np.zeros((1, 2, 4), dtype=np.uint64)
         ctx.check(nlx.lib.dll.nlx_bn254_ntt_batch(ctx.handle, a.ctypes.data, 1, 29, 0, 0))   # 2-adicity 28
+
+
+# ---- the G1 multi-scalar multiplication (row f.4's second piece, nlx_bn254_msm_g1) ----
+def _points(bn, count, seed):
+    rng = random.Random(seed)
+    return [bn.g1_mul(rng.randrange(1, bn.R), bn.G1) for _ in range(count)]
+
+
+def _scalar_words(ks):
+    out = np.zeros((len(ks), 4), dtype=np.uint64)
+    for i, k in enumerate(ks):
+        for w in range(4):
+            out[i, w] = (int(k) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 300, 2048])
+def test_bn254_msm_vs_model(nlx, ctx, bn, n):
+    """sum_i k_i P_i equals the model's term-by-term sum, for canonical and for Montgomery (fr.Element) scalars"""
+    rng = random.Random(1000 + n)
+    pts = _points(bn, n, n)
+    ks = [rng.randrange(bn.R) for _ in range(n)]
+    want = bn.msm_g1(ks, pts)
+    got = nlx.bn254_g1_unpack(nlx.bn254_msm_g1(ctx, nlx.bn254_g1_pack(pts), _scalar_words(ks)))
+    assert got == want
+    mont = _scalar_words([bn.to_montgomery(k) for k in ks])
+    assert nlx.bn254_g1_unpack(nlx.bn254_msm_g1(ctx, nlx.bn254_g1_pack(pts), mont, montgomery=True)) == want
+
+
+def test_bn254_msm_edge_cases(nlx, ctx, bn):
+    """zero / one / r - 1 scalars, all-ones digits, the point at infinity, the same point many times (the buckets' doubling
+    branch), a point and its negative (the cancelling branch), an empty input, a sum that is the point at infinity"""
+    g = bn.G1
+    pts = _points(bn, 6, 77)
+    p0 = pts[0]
+    cases = [
+        ([0, 1, bn.R - 1, (1 << 253) - 1, 0xFFFF, 0xFFFF0000], pts),
+        ([5, 7, 9, 11], [p0, None, p0, bn.g1_neg(p0)]),                      # infinity in the input; P, P, -P in different buckets
+        ([0x1234] * 40, [p0] * 40),                                          # one bucket receives the same point 40 times
+        ([0x1234] * 2 + [3], [p0, bn.g1_neg(p0), g]),                        # P + (-P) inside a bucket, then more
+        ([0xABCD, 0xABCD], [p0, bn.g1_neg(p0)]),                             # the whole sum is the point at infinity
+        ([0, 0, 0], pts[:3]),
+        ([bn.R - 1] * 3, [g, g, g]),
+    ]
+    for ks, ps in cases:
+        got = nlx.bn254_g1_unpack(nlx.bn254_msm_g1(ctx, nlx.bn254_g1_pack(ps), _scalar_words(ks)))
+        assert got == bn.msm_g1(ks, ps), (ks, ps)
+    assert nlx.bn254_g1_unpack(nlx.bn254_msm_g1(ctx, np.zeros((0, 8), dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64))) is None
+    assert nlx.lib.dll.nlx_bn254_msm_g1(ctx.handle, None, None, 4, 0, np.zeros(8, dtype=np.uint64).ctypes.data) < 0   # NULL inputs
+
+
+def test_bn254_msm_2p20_structured(nlx, ctx, bn):
+    """2^20 points drawn from 64 distinct ones with random scalars: sum_i k_i P_(i mod 64) = sum_j (sum_(i = j mod 64) k_i) P_j -
+    64 scalar multiplications in the model pin a full-size run (and every bucket's doubling branch: its points repeat);
+    linearity in the scalars: msm(k) + msm(k') = msm(k + k')"""
+    import torch
+    n, m = 1 << 20, 64
+    base = _points(bn, m, 5)
+    packed = np.tile(nlx.bn254_g1_pack(base), (n // m, 1))
+    rs = np.random.RandomState(7)
+    words = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.int64).astype(np.uint64)   # 254-bit canonical scalars
+    words[:, 3] &= np.uint64((1 << 60) - 1)
+    ks = [sum(int(words[i, w]) << (64 * w) for w in range(4)) for i in range(n)]
+    sums = [sum(ks[j::m]) % bn.R for j in range(m)]
+    want = bn.msm_g1(sums, base)
+    d_pts = torch.from_numpy(packed.view(np.int64)).to("cuda:%d" % ctx.device)
+    d_ks = torch.from_numpy(words.view(np.int64)).to(d_pts.device)
+    got = nlx.bn254_g1_unpack(nlx.bn254_msm_g1(ctx, d_pts, d_ks))
+    assert got == want
+    words2 = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    words2[:, 3] &= np.uint64((1 << 60) - 1)
+    ks2 = [sum(int(words2[i, w]) << (64 * w) for w in range(4)) for i in range(n)]
+    both = _scalar_words([(a + b) % bn.R for a, b in zip(ks, ks2)])
+    g2 = nlx.bn254_g1_unpack(nlx.bn254_msm_g1(ctx, d_pts, words2))
+    g12 = nlx.bn254_g1_unpack(nlx.bn254_msm_g1(ctx, d_pts, both))
+    assert bn.g1_add(got, g2) == g12
