@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sync", choices=["sync", "outer", "verify128", "stark", "sha256", "sha512", "ed25519", "ntt24"])
+    ap.add_argument("--workload", default="sync", choices=["sync", "outer", "verify128", "stark", "sha256", "sha512", "ed25519", "ntt24", "msm24"])
     ap.add_argument("--log-blocks", type=int, default=14, help="sha256 workload: 2^k compression blocks per proof")
     ap.add_argument("--log-slots", type=int, default=10, help="ed25519 workload: 2^k signature slots per proof (>= 4)")
     ap.add_argument("--segment-nodes", type=int, default=None, help="sha256 / sha512 / ed25519 workloads: AIR program segment size in arithmetic nodes (0 = one segment)")
@@ -1093,6 +1093,83 @@ def run_ntt24_bn254(args, nlx, torch, rank, world, local, dist):
     return out
 
 
+def run_msm24(args, nlx, torch, rank, world, local, dist):
+    """--workload msm24: the KZG commitment of the recursive wrap (BASELINE.json configs[4]'s size): one
+    BN254 G1 multi-scalar multiplication of 2^--ntt-log-n points per step through nlx_bn254_msm_g1, points and scalars
+    resident in HBM in gnark-crypto's layouts.  The points are 4 096 distinct curve points tiled (generated by the
+    big-integer model; 2^24 of them would take hours), the scalars random 254-bit values.  With N ranks every rank owns a
+    slice of the points (the partial sums add on the host: one G1 addition per rank, no collective)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bn254_py   # input generation (points on the curve) and the post-timing check only
+    log_n = args.ntt_log_n
+    n = (1 << log_n) // world
+    m = min(4096, n)
+    rng = __import__("random").Random(99)
+    acc, base = bn254_py.g1_mul(rng.randrange(1, bn254_py.R), bn254_py.G1), []
+    step_pt = bn254_py.g1_mul(rng.randrange(1, bn254_py.R), bn254_py.G1)
+    for _ in range(m):                       # m distinct points by repeated addition
+        base.append(acc)
+        acc = bn254_py.g1_add(acc, step_pt)
+    ctx = nlx.Context(local)
+    dev = "cuda:%d" % local
+    pts = torch.from_numpy(nlx.bn254_g1_pack(base).view(np.int64)).to(dev).repeat((n + m - 1) // m, 1)[:n].contiguous()
+    g = torch.Generator(device="cpu").manual_seed(0x6D736D + rank)
+    ks = torch.randint(0, 2 ** 60, (n, 4), generator=g, dtype=torch.int64)   # top word < 2^60: values < r, canonical form
+    d_ks = ks.to(dev)
+
+    def step():
+        return nlx.bn254_msm_g1(ctx, pts, d_ks)
+    for _ in range(args.warmup):
+        step()
+    ctx.kernel_timing(True)
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier(dist, torch)
+    dt = reduce_max(dist, torch, time.perf_counter() - t0)
+    kt = ctx.kernel_stats("bn254_msm_g1")
+    ctx.kernel_timing(False)
+    out = None
+    if rank == 0:
+        ms = kt[1] / kt[0] if kt[0] else None
+        adds_per_s = 16.0 * n / (ms * 1e-3) if ms else None       # one mixed addition per (point, window) pair
+        out = {
+            "metric": "BN254 G1 MSM of 2^%d points: multi-scalar multiplications per second (the recursive wrap's KZG commitment, row f.4)" % log_n,
+            "value": args.steps / dt, "unit": "MSMs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u256 (BN254 base field, Montgomery form, integer)", "data": "synthetic",
+            "config": {"workload": "one G1 MSM of 2^%d points x 254-bit scalars (gnark-crypto G1Affine / fr.Element words), resident "
+                                   "in HBM, points split over the ranks" % log_n,
+                       "points_per_rank": n, "distinct_points": m, "device_ms_rank0": ms,
+                       "points_per_second": world * n * args.steps / dt,
+                       "bucket_additions_per_second_rank0": adds_per_s, "parallelism": "points x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": (96.0 * n / (ms * 1e-3) / 1e9) if ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (96.0 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms else None, "traffic": None,
+                         "kernel": "bn254_msm_g1 (digits, scan, 16 radix sorts, bucket sums, window reduction)", "launches": kt[0],
+                         "avg_launch_ms": ms, "alg_bytes_per_launch": 96.0 * n,
+                         "note": "96 bytes per point algorithmic (point + scalar once); the job is bound by the integer-VALU issue rate: "
+                                 "16 mixed Jacobian additions per point, 11 Montgomery products of ~170 multiply-adds each"},
+            "cpu_baseline": None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            # the model on the same input: sum_i k_i P_(i mod m) = sum_j (sum_(i = j mod m) k_i) P_j - m scalar multiplications
+            tc = time.time()
+            kw = ks.numpy().view(np.uint64)
+            ints = (kw[:, 0].astype(object) + (kw[:, 1].astype(object) << 64) + (kw[:, 2].astype(object) << 128) + (kw[:, 3].astype(object) << 192))
+            sums = [int(sum(ints[j::m])) % bn254_py.R for j in range(m)]
+            want = bn254_py.msm_g1(sums, base)
+            dtc = time.time() - tc
+            per_mul = dtc / m
+            out["cpu_baseline"] = {"value": 1.0 / (per_mul * n), "unit": "MSMs/s", "cores": 1, "kind": "port",
+                                   "sample": "pure-Python big-integer model: %d scalar multiplications in %.1f s; a term-by-term MSM of all "
+                                             "2^%d points would take %.0f s (a model for parity, not a competitive CPU implementation); GPU "
+                                             "result equal to the model's: %s" % (m, dtc, log_n, per_mul * n, nlx.bn254_g1_unpack(res) == want)}
+    ctx.close()
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -1109,6 +1186,8 @@ def main():
         out = run_outer(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "ntt24":
         out = run_ntt24(args, nlx, torch, rank, world, local, dist)
+    elif args.workload == "msm24":
+        out = run_msm24(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "stark":
         out = run_stark(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "ed25519":
