@@ -7,16 +7,15 @@
 // ecc/bn254 G1Affine.MultiExp(points, scalars) can be replaced by one call on the caller's slices.
 //
 // Bucket method (Pippenger) with 16-bit unsigned windows, laid out for the GPU:
-//   k_msm_digits   one lane per scalar: out of Montgomery form, sixteen 16-bit digits -> one (digit, index) pair per window
-//                  and a histogram of the digits (global atomics, 2^20 counters);
-//   hipcub         exclusive scan of the histogram = where every bucket starts in the sorted order; radix sort of each
-//                  window's pairs by digit (16-bit keys);
+//   k_msm_digits   one lane per scalar: out of Montgomery form, sixteen 16-bit digits -> one (digit, index) pair per window;
+//   hipcub         radix sort of each window's pairs by digit (16-bit keys); k_msm_ranges reads every bucket's first and
+//                  last position off the sorted keys;
 //   k_msm_buckets  one lane per bucket (16 x 65 535 of them): the sum of its points by mixed Jacobian additions, points
 //                  fetched through the sorted indices - at 2^24 points a bucket holds ~256, so neighbouring lanes run
 //                  loops of similar length;
-//   k_msm_reduce   per window sum_b b * B_b: 256 lanes x 256 buckets each by running sums, the chunk offsets by a 16-bit
-//                  double-and-add, the 256 partial results through LDS;
-//   host           sum_w 2^(16 w) W_w (240 doublings) and the one inversion for the affine result.
+//   k_msm_reduce   per window sum_b b * B_b: 2 048 lanes x 32 buckets each by running sums, the chunk offsets by a 16-bit
+//                  double-and-add, 256 partial results at a time through LDS;
+//   host           the blocks' partial sums, sum_w 2^(16 w) W_w (240 doublings) and the one inversion for the affine result.
 // Bound: integer VALU - a mixed addition is 11 field multiplications of ~170 multiply-adds each.
 #include <hipcub/hipcub.hpp>
 #include <vector>
@@ -99,7 +98,7 @@ BNF_HD Jac jneg(const Jac& p) { return Jac{p.x, neg(p.y), p.z}; }
 
 // ---- digits ----
 __global__ __launch_bounds__(256) void k_msm_digits(const uint64_t* __restrict__ scalars, size_t n, int montgomery,
-                                                    uint16_t* __restrict__ keys /* [window][n] */, uint32_t* __restrict__ hist /* [window][65536] */) {
+                                                    uint16_t* __restrict__ keys /* [window][n] */) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Fr s = load_words<RP>(scalars + 4 * i);
@@ -109,7 +108,6 @@ __global__ __launch_bounds__(256) void k_msm_digits(const uint64_t* __restrict__
     for (int w = 0; w < N_WINDOWS; w++) {
         const uint32_t d = (s.v[w >> 1] >> (16 * (w & 1))) & 0xFFFFu;
         keys[(size_t)w * n + i] = (uint16_t)d;
-        atomicAdd(hist + (size_t)w * N_BUCKETS + d, 1u);   // digit 0 too: its pairs sort first and the scan must step over them
     }
 }
 __global__ __launch_bounds__(256) void k_msm_iota(uint32_t* __restrict__ v, size_t n) {
@@ -117,26 +115,43 @@ __global__ __launch_bounds__(256) void k_msm_iota(uint32_t* __restrict__ v, size
     if (i < n) v[i] = (uint32_t)i;
 }
 
+// where every bucket of one window starts and ends in its sorted pairs: position p opens bucket key[p] if it differs from
+// its left neighbour and closes it if it differs from its right one (empty buckets keep lo = hi = 0) - no atomics: a
+// histogram of 2^28 digits on 2^20 counters (the top window's digits have 12 bits) cost 12 ms of contention
+__global__ __launch_bounds__(256) void k_msm_ranges(const uint16_t* __restrict__ sorted_keys, size_t n, uint32_t base /* w * n */,
+                                                    uint32_t* __restrict__ lo, uint32_t* __restrict__ hi /* this window's 65536 */) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint16_t k = sorted_keys[p];
+    if (p == 0 || sorted_keys[p - 1] != k) lo[k] = base + (uint32_t)p;
+    if (p + 1 == n || sorted_keys[p + 1] != k) hi[k] = base + (uint32_t)p + 1;
+}
+
 // ---- bucket sums: lane (w, b) adds the points whose window-w digit is b ----
-__global__ __launch_bounds__(64) void k_msm_buckets(const Affine* __restrict__ points, const uint32_t* __restrict__ sorted /* [window][n] */,
-                                                    const uint32_t* __restrict__ starts /* [window * 65536 + 1]: exclusive scan */,
+#ifndef NLX_MSM_MINW
+#define NLX_MSM_MINW 3   // waves per SIMD the register allocation must allow (tuning builds: build.py NLX_EXTRA_FLAGS)
+#endif
+__global__ __launch_bounds__(64, NLX_MSM_MINW) void k_msm_buckets(const Affine* __restrict__ points, const uint32_t* __restrict__ sorted /* [window][n] */,
+                                                    const uint32_t* __restrict__ range_lo, const uint32_t* __restrict__ range_hi /* [window][65536] */,
                                                     Jac* __restrict__ buckets /* [window][65536] */) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // = w * 65536 + b
     if (t >= (uint32_t)N_WINDOWS * N_BUCKETS) return;
     Jac acc = jac_inf();
     if ((t & (N_BUCKETS - 1)) != 0) {   // bucket 0 weighs nothing
-        const uint32_t lo = starts[t], hi = starts[t + 1];   // positions in the window-major sorted array
+        const uint32_t lo = range_lo[t], hi = range_hi[t];   // positions in the window-major sorted array
 #pragma unroll 1
         for (uint32_t p = lo; p < hi; p++) acc = jmadd(acc, points[sorted[p]]);
     }
     buckets[t] = acc;
 }
 
-// ---- window sums: W_w = sum_b b B_b.  Lane c of block w owns buckets 256 c .. 256 c + 255 ----
-constexpr int RED_LANES = 256, RED_CHUNK = N_BUCKETS / RED_LANES;
-__global__ __launch_bounds__(RED_LANES) void k_msm_reduce(const Jac* __restrict__ buckets, Jac* __restrict__ window_sums) {
+// ---- window sums: W_w = sum_b b B_b.  Lane c of window w owns buckets 32 c .. 32 c + 31; a block is 256 such lanes, a
+// window RED_BLOCKS blocks whose partial sums the host adds.  The running-sum chain per lane is 64 additions + 16
+// double-and-add steps + 8 tree levels: with 256 buckets per lane (one block per window) this kernel took 14 ms ----
+constexpr int RED_LANES = 256, RED_CHUNK = 32, RED_BLOCKS = N_BUCKETS / (RED_LANES * RED_CHUNK);
+__global__ __launch_bounds__(RED_LANES) void k_msm_reduce(const Jac* __restrict__ buckets, Jac* __restrict__ window_sums /* [window][RED_BLOCKS] */) {
     __shared__ Jac part[RED_LANES];
-    const uint32_t w = blockIdx.x, c = threadIdx.x, base = c * RED_CHUNK;
+    const uint32_t w = blockIdx.x / RED_BLOCKS, c = (blockIdx.x % RED_BLOCKS) * RED_LANES + threadIdx.x, base = c * RED_CHUNK;
     const Jac* b = buckets + (size_t)w * N_BUCKETS + base;
     Jac running = jac_inf(), local = jac_inf();
 #pragma unroll 1
@@ -156,14 +171,15 @@ __global__ __launch_bounds__(RED_LANES) void k_msm_reduce(const Jac* __restrict_
             if ((k >> bit) & 1) shifted = jadd(shifted, running);
         }
     }
-    part[c] = jadd(local, shifted);
+    const uint32_t l = threadIdx.x;
+    part[l] = jadd(local, shifted);
     __syncthreads();
 #pragma unroll 1
     for (int stride = RED_LANES / 2; stride > 0; stride >>= 1) {
-        if (c < (uint32_t)stride) part[c] = jadd(part[c], part[c + stride]);
+        if (l < (uint32_t)stride) part[l] = jadd(part[l], part[l + stride]);
         __syncthreads();
     }
-    if (c == 0) window_sums[w] = part[0];
+    if (l == 0) window_sums[blockIdx.x] = part[0];
 }
 
 }  // namespace msm
@@ -191,21 +207,19 @@ extern "C" int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const 
     uint16_t* d_keys_sorted = (uint16_t*)ctx->alloc((size_t)n * 2);
     uint32_t* d_iota = (uint32_t*)ctx->alloc((size_t)n * 4);
     uint32_t* d_sorted = (uint32_t*)ctx->alloc(pairs * 4);
-    uint32_t* d_hist = (uint32_t*)ctx->alloc((n_hist + 1) * 4);
-    uint32_t* d_starts = (uint32_t*)ctx->alloc((n_hist + 1) * 4);
+    uint32_t* d_lo = (uint32_t*)ctx->alloc(n_hist * 2 * 4);   // range_lo | range_hi
+    uint32_t* d_hi = d_lo ? d_lo + n_hist : nullptr;
     Jac* d_buckets = (Jac*)ctx->alloc(n_hist * sizeof(Jac));
-    Jac* d_wsum = (Jac*)ctx->alloc(N_WINDOWS * sizeof(Jac));
-    size_t tmp_sort = 0, tmp_scan = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, d_keys, d_keys_sorted, d_iota, d_sorted, (int)n, 0, WINDOW_BITS, st);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, d_hist, d_starts, (int)(n_hist + 1), st);
-    const size_t tmp_bytes = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+    constexpr int N_WSUM = N_WINDOWS * RED_BLOCKS;
+    Jac* d_wsum = (Jac*)ctx->alloc(N_WSUM * sizeof(Jac));
+    size_t tmp_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_iota, d_sorted, (int)n, 0, WINDOW_BITS, st);
     void* d_tmp = ctx->alloc(tmp_bytes ? tmp_bytes : 16);
     auto release_all = [&]() {
-        for (void* p : {(void*)d_keys, (void*)d_keys_sorted, (void*)d_iota, (void*)d_sorted, (void*)d_hist, (void*)d_starts,
-                        (void*)d_buckets, (void*)d_wsum, d_tmp})
+        for (void* p : {(void*)d_keys, (void*)d_keys_sorted, (void*)d_iota, (void*)d_sorted, (void*)d_lo, (void*)d_buckets, (void*)d_wsum, d_tmp})
             if (p) ctx->release(p);
     };
-    if (!d_keys || !d_keys_sorted || !d_iota || !d_sorted || !d_hist || !d_starts || !d_buckets || !d_wsum || !d_tmp) {
+    if (!d_keys || !d_keys_sorted || !d_iota || !d_sorted || !d_lo || !d_buckets || !d_wsum || !d_tmp) {
         release_all();
         return NLX_E_NOMEM;
     }
@@ -215,31 +229,35 @@ extern "C" int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const 
         return e == hipSuccess;
     };
     const unsigned blocks_n = (unsigned)((n + 255) / 256);
-    hip_ok(hipMemsetAsync(d_hist, 0, (n_hist + 1) * 4, st), "hipMemsetAsync");
+    hip_ok(hipMemsetAsync(d_lo, 0, n_hist * 2 * 4, st), "hipMemsetAsync");
     // algorithmic bytes of the whole job: every point and scalar once
     ctx->begin_kernel("bn254_msm_g1", 96.0 * (double)n, n);
     hipLaunchKernelGGL(k_msm_digits, dim3(blocks_n), dim3(256), 0, st, ss.as<uint64_t>(), (size_t)n,
-                       (flags & NLX_BN254_MONTGOMERY) ? 1 : 0, d_keys, d_hist);
+                       (flags & NLX_BN254_MONTGOMERY) ? 1 : 0, d_keys);
     hipLaunchKernelGGL(k_msm_iota, dim3(blocks_n), dim3(256), 0, st, d_iota, (size_t)n);
-    size_t tb = tmp_bytes;
-    hip_ok(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_hist, d_starts, (int)(n_hist + 1), st), "hipcub::ExclusiveSum");
     for (int w = 0; w < N_WINDOWS && !rc; w++) {
-        tb = tmp_bytes;
+        size_t tb = tmp_bytes;
         hip_ok(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys + (size_t)w * n, d_keys_sorted, d_iota, d_sorted + (size_t)w * n,
                                                   (int)n, 0, WINDOW_BITS, st), "hipcub::SortPairs");
+        hipLaunchKernelGGL(k_msm_ranges, dim3(blocks_n), dim3(256), 0, st, d_keys_sorted, (size_t)n, (uint32_t)((size_t)w * n),
+                           d_lo + (size_t)w * N_BUCKETS, d_hi + (size_t)w * N_BUCKETS);
     }
     if (!rc) {
-        hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)(n_hist / 64)), dim3(64), 0, st, sp.as<Affine>(), d_sorted, d_starts, d_buckets);
-        hipLaunchKernelGGL(k_msm_reduce, dim3(N_WINDOWS), dim3(RED_LANES), 0, st, d_buckets, d_wsum);
+        hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)(n_hist / 64)), dim3(64), 0, st, sp.as<Affine>(), d_sorted, d_lo, d_hi, d_buckets);
+        hipLaunchKernelGGL(k_msm_reduce, dim3(N_WSUM), dim3(RED_LANES), 0, st, d_buckets, d_wsum);
     }
     ctx->end_kernel();
-    Jac wsum[N_WINDOWS];
-    if (!rc) rc = fetch(ctx, wsum, d_wsum, sizeof(wsum));
+    Jac part[N_WSUM], wsum[N_WINDOWS];
+    if (!rc) rc = fetch(ctx, part, d_wsum, sizeof(part));
     hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
     hip_ok(hipGetLastError(), "kernel launch");
     release_all();
     if (rc) return rc;
-    // sum_w 2^(16 w) W_w, then to affine
+    // the blocks' partial sums per window, sum_w 2^(16 w) W_w, then to affine
+    for (int w = 0; w < N_WINDOWS; w++) {
+        wsum[w] = part[w * RED_BLOCKS];
+        for (int k = 1; k < RED_BLOCKS; k++) wsum[w] = jadd(wsum[w], part[w * RED_BLOCKS + k]);
+    }
     Jac acc = wsum[N_WINDOWS - 1];
     for (int w = N_WINDOWS - 2; w >= 0; w--) {
         for (int k = 0; k < WINDOW_BITS; k++) acc = jdbl(acc);
