@@ -1,0 +1,194 @@
+// BN254 base field on nine 29-bit limbs - the arithmetic of the MSM's device kernels (bn254_msm.hip).
+//
+// Why not eight 32-bit limbs (bn254_fp.hpp): gfx950 wants the 64-bit operands of v_mad_u64_u32 in even-aligned register
+// pairs, and a CIOS Montgomery product on saturated limbs shifts its accumulator by one 32-bit limb per row - the compiler
+// pays for that with register moves (7 294 v_mov_b32 against 2 305 multiply-adds in the first bucket kernel, ~880
+// instructions per field product).  With 29-bit limbs a product is < 2^58, eighteen of them fit a 64-bit column, so the
+// schoolbook product and the Montgomery reduction are plain `col[i + j] += a[i] * b[j]` into FIXED columns: one multiply-add
+// per partial product, no carry handling inside the loops, no shifting (~250 instructions per product).
+//
+// Representation: value = sum v[i] 2^(29 i), limbs 0..7 < 2^29, limb 8 takes what is left; Montgomery form with R' = 2^261.
+// Values are kept loose (no canonical reduction on the fast path).  Bounds, checked by the host test
+// (tests/native/bn254_f29_check.cpp) on random and extreme inputs:
+//   mul / sqr      inputs < 2^257.5 each (product < 2^515 = 2^254 R')      -> result < 2^254 + q < 2^255   ("tight")
+//   add            any two values whose sum is < 2^258                      -> the plain sum, limbs normalised
+//   sub<K>(a, b)   a + K q - b for K q >= the bound of b (K = 4: b < 2^255, K = 8: b < 3 * 2^255)
+//   tighten        any value < 2^258                                        -> the same residue, < 1.1 q
+// The point formulas in bn254_msm.hip state the bound of every intermediate.
+#pragma once
+#include <cstdint>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define F29_HD __host__ __device__ __forceinline__
+#else
+#define F29_HD inline   // plain g++ build of the host test
+#endif
+
+namespace nlx {
+namespace f29 {
+
+constexpr int NL = 9, LB = 29;
+constexpr uint32_t MASK = (1u << LB) - 1;
+constexpr uint32_t NINV = 0x4866389u;   // -q^-1 mod 2^29
+
+struct Fe {
+    uint32_t v[NL];
+};
+
+F29_HD uint32_t q_limb(int i) {
+    constexpr uint32_t Q[NL] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u, 0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    return Q[i];
+}
+template <int K>
+F29_HD uint32_t kq_limb(int i) {   // limbs of K q, K = 4 or 8
+    static_assert(K == 4 || K == 8, "K q is tabulated for K = 4 and 8");
+    constexpr uint32_t Q4[NL] = {0x01f3f51cu, 0x041182dbu, 0x11ca8d3cu, 0x0b548b43u, 0x161765e0u, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u};
+    constexpr uint32_t Q8[NL] = {0x03e7ea38u, 0x082305b6u, 0x03951a78u, 0x16a91687u, 0x0c2ecbc0u, 0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u};
+    return K == 4 ? Q4[i] : Q8[i];
+}
+F29_HD Fe zero() {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = 0;
+    return r;
+}
+F29_HD Fe one() {   // R' mod q: the Montgomery form of 1
+    constexpr uint32_t O[NL] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u, 0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = O[i];
+    return r;
+}
+F29_HD bool is_zero_exact(const Fe& a) {   // the integer 0 (how the point at infinity is marked), not "0 mod q"
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) o |= a.v[i];
+    return o == 0;
+}
+
+// Montgomery product a b / 2^261 mod q, operand bounds in the header comment
+F29_HD Fe mul(const Fe& a, const Fe& b) {
+    uint64_t col[2 * NL];
+#pragma unroll
+    for (int k = 0; k < 2 * NL; k++) col[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+#pragma unroll
+        for (int j = 0; j < NL; j++) col[i + j] += (uint64_t)a.v[i] * b.v[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const uint32_t m = ((uint32_t)col[i] * NINV) & MASK;
+#pragma unroll
+        for (int j = 0; j < NL; j++) col[i + j] += (uint64_t)m * q_limb(j);
+        col[i + 1] += col[i] >> LB;   // the low 29 bits of col[i] are now zero
+    }
+    Fe r;
+#pragma unroll
+    for (int i = NL; i < 2 * NL - 1; i++) {
+        r.v[i - NL] = (uint32_t)col[i] & MASK;
+        col[i + 1] += col[i] >> LB;
+    }
+    r.v[NL - 1] = (uint32_t)col[2 * NL - 1];
+    return r;
+}
+F29_HD Fe sqr(const Fe& a) { return mul(a, a); }
+
+F29_HD Fe add(const Fe& a, const Fe& b) {
+    Fe r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+        const uint32_t s = a.v[i] + b.v[i] + c;
+        r.v[i] = s & MASK;
+        c = s >> LB;
+    }
+    r.v[NL - 1] = a.v[NL - 1] + b.v[NL - 1] + c;
+    return r;
+}
+F29_HD Fe dbl(const Fe& a) { return add(a, a); }
+
+// a + K q - b, non-negative as long as b <= K q
+template <int K>
+F29_HD Fe sub(const Fe& a, const Fe& b) {
+    Fe r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+        const int32_t s = (int32_t)a.v[i] + (int32_t)kq_limb<K>(i) - (int32_t)b.v[i] + c;
+        r.v[i] = (uint32_t)s & MASK;
+        c = s >> LB;   // arithmetic shift: floor
+    }
+    r.v[NL - 1] = (uint32_t)((int32_t)a.v[NL - 1] + (int32_t)kq_limb<K>(NL - 1) - (int32_t)b.v[NL - 1] + c);
+    return r;
+}
+
+// the same residue below 1.1 q, for any value < 2^258: subtract floor(V / 2^248 * (2^248 / q)) q, the factor rounded down
+F29_HD Fe tighten(const Fe& a) {
+    const uint32_t t = ((a.v[NL - 1] >> 16) * 21668u) >> 20;   // <= V / q, short of it by less than 0.03
+    Fe r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+        const int64_t s = (int64_t)a.v[i] - (int64_t)((uint64_t)t * q_limb(i)) + c;
+        r.v[i] = (uint32_t)s & MASK;
+        c = s >> LB;
+    }
+    r.v[NL - 1] = (uint32_t)((int64_t)a.v[NL - 1] - (int64_t)((uint64_t)t * q_limb(NL - 1)) + c);
+    return r;
+}
+
+// a = 0 mod q, for any value < 2^258
+F29_HD bool is_zero_mod(const Fe& a) {
+    const Fe t = tighten(a);   // in [0, 1.1 q): zero mod q means 0 or q
+    uint32_t z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        z |= t.v[i];
+        e |= t.v[i] ^ q_limb(i);
+    }
+    return z == 0 || e == 0;
+}
+
+// ---- in and out of the form: 2^256-Montgomery words (gnark-crypto's fp.Element) <-> this ----
+F29_HD Fe from_words256(const uint32_t* w /* eight 32-bit limbs of an integer */) {   // plain re-slicing, no arithmetic
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int bit = LB * i, k = bit >> 5, o = bit & 31;
+        uint64_t x = (uint64_t)w[k] >> o;
+        if (k + 1 < 8) x |= (uint64_t)w[k + 1] << (32 - o);
+        r.v[i] = (uint32_t)x & MASK;
+    }
+    return r;
+}
+// x 2^256 mod q (an fp.Element read as an integer) -> x 2^261 mod q: one product with 2^266 mod q
+F29_HD Fe from_mont256(const uint32_t* w) {
+    constexpr uint32_t C[NL] = {0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
+    Fe c;
+#pragma unroll
+    for (int i = 0; i < NL; i++) c.v[i] = C[i];
+    return mul(from_words256(w), c);
+}
+// the canonical integer x < q of a value in this form, as eight 32-bit limbs
+F29_HD void to_canonical256(const Fe& a, uint32_t* w) {
+    Fe o = zero();
+    o.v[0] = 1;
+    Fe t = mul(a, o);   // (A + M q) / R' with M < R': at most q, and q only for A = 0 mod q
+    uint32_t e = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) e |= t.v[i] ^ q_limb(i);
+    if (e == 0) t = zero();
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int bit = LB * i, k = bit >> 5, o2 = bit & 31;
+        const uint64_t x = (uint64_t)t.v[i] << o2;
+        w[k] |= (uint32_t)x;
+        if (k + 1 < 8) w[k + 1] |= (uint32_t)(x >> 32);
+    }
+}
+
+}  // namespace f29
+}  // namespace nlx

@@ -16,9 +16,13 @@
 //   k_msm_reduce   per window sum_b b * B_b: 2 048 lanes x 32 buckets each by running sums, the chunk offsets by a 16-bit
 //                  double-and-add, 256 partial results at a time through LDS;
 //   host           the blocks' partial sums, sum_w 2^(16 w) W_w (240 doublings) and the one inversion for the affine result.
-// Bound: integer VALU - a mixed addition is 11 field multiplications of ~170 multiply-adds each.
+// Bound: integer VALU - a mixed addition is 11 field products.  The kernels compute on nine 29-bit limbs (bn254_f29.hpp:
+// fixed 64-bit columns, one multiply-add per partial product, ~250 instructions per product against ~880 for the CIOS
+// product on 32-bit limbs, whose shifting accumulator costs gfx950 a register move per multiply-add); the points are
+// converted once per call, the host's short tail stays on 32-bit limbs (bn254_fp.hpp).
 #include <hipcub/hipcub.hpp>
 #include <vector>
+#include "bn254_f29.hpp"
 #include "bn254_fp.hpp"
 #include "ctx.hpp"
 #include "transcript.hpp"
@@ -96,6 +100,88 @@ BNF_HD Jac jadd(const Jac& p, const Jac& q) {
 }
 BNF_HD Jac jneg(const Jac& p) { return Jac{p.x, neg(p.y), p.z}; }
 
+// ---- the same group law on the device's field representation (bn254_f29.hpp).  Coordinates of stored points are "tight"
+// (< 2^255); the bound of every intermediate is noted where it is not a product (products are < 2^255 whenever the two
+// operands multiply to less than 2^515) ----
+using f29::Fe;
+struct Aff29 { Fe x, y; };        // both exactly zero: the point at infinity
+struct Jac29 { Fe x, y, z; };     // z exactly zero: the point at infinity
+struct JacWords { uint32_t x[8], y[8], z[8]; };   // canonical integers, for the host's tail
+
+__device__ __forceinline__ bool is_inf(const Aff29& p) { return f29::is_zero_exact(p.x) && f29::is_zero_exact(p.y); }
+__device__ __forceinline__ Jac29 inf29() { return Jac29{f29::one(), f29::one(), f29::zero()}; }
+
+__device__ __noinline__ Jac29 jdbl29(const Jac29& p) {   // rare in the bucket kernel (a bucket receiving its own sum): kept out of line
+    using namespace f29;
+    if (is_zero_exact(p.z)) return p;
+    const Fe a = sqr(p.x), b = sqr(p.y), c = sqr(b);
+    const Fe d = dbl(tighten(sub<8>(sqr(add(p.x, b)), add(a, c))));   // (x + b)^2 - a - c: the subtrahend < 2^256; d < 2.2 q
+    const Fe e = add(dbl(a), a);                                      // 3 a < 3 * 2^255
+    Jac29 r;
+    r.x = tighten(sub<8>(sqr(e), dbl(d)));                            // 2 d < 2^256
+    const Fe t = mul(e, sub<4>(d, r.x));                              // d - x3 + 4 q < 2^256.3, times e < 2^256.6
+    const Fe c4 = dbl(dbl(tighten(c)));                               // 4 c < 4.4 q: subtracted twice (8 c would pass 8 q)
+    r.y = tighten(sub<8>(tighten(sub<8>(t, c4)), c4));
+    r.z = tighten(dbl(mul(p.y, p.z)));
+    return r;
+}
+__device__ __forceinline__ Jac29 jmadd29(const Jac29& p, const Aff29& q) {
+    using namespace f29;
+    if (is_inf(q)) return p;
+    if (is_zero_exact(p.z)) return Jac29{q.x, q.y, one()};
+    const Fe z1z1 = sqr(p.z), u2 = mul(q.x, z1z1), s2 = mul(mul(q.y, p.z), z1z1);
+    const Fe h = sub<4>(u2, p.x), r0 = sub<4>(s2, p.y);               // < 2^255 + 4 q = 2^256.3
+    if (is_zero_mod(h)) {
+        if (is_zero_mod(r0)) return jdbl29(Jac29{q.x, q.y, one()});
+        return inf29();
+    }
+    const Fe r = dbl(r0);                                             // < 2^257.3
+    const Fe hh = sqr(h), i = dbl(dbl(hh)), j = mul(h, i), v = mul(p.x, i);   // i < 2^257
+    Jac29 o;
+    o.x = tighten(sub<8>(sqr(r), add(j, dbl(v))));                    // j + 2 v < 3 * 2^255 <= 8 q
+    o.y = tighten(sub<8>(mul(r, sub<4>(v, o.x)), dbl(mul(p.y, j))));
+    o.z = tighten(sub<8>(sqr(add(p.z, h)), add(z1z1, hh)));           // z + h < 2^256.8
+    return o;
+}
+__device__ __forceinline__ Jac29 jadd29(const Jac29& p, const Jac29& q) {
+    using namespace f29;
+    if (is_zero_exact(p.z)) return q;
+    if (is_zero_exact(q.z)) return p;
+    const Fe z1z1 = sqr(p.z), z2z2 = sqr(q.z);
+    const Fe u1 = mul(p.x, z2z2), u2 = mul(q.x, z1z1);
+    const Fe s1 = mul(mul(p.y, q.z), z2z2), s2 = mul(mul(q.y, p.z), z1z1);
+    const Fe h = sub<4>(u2, u1), r0 = sub<4>(s2, s1);
+    if (is_zero_mod(h)) {
+        if (is_zero_mod(r0)) return jdbl29(p);
+        return inf29();
+    }
+    const Fe r = dbl(r0);
+    const Fe i = sqr(dbl(h)), j = mul(h, i), v = mul(u1, i);          // 2 h < 2^257.3
+    Jac29 o;
+    o.x = tighten(sub<8>(sqr(r), add(j, dbl(v))));
+    o.y = tighten(sub<8>(mul(r, sub<4>(v, o.x)), dbl(mul(s1, j))));
+    o.z = mul(sub<8>(sqr(add(p.z, q.z)), add(z1z1, z2z2)), h);        // (< 2^257.1) (< 2^256.3)
+    return o;
+}
+__device__ __forceinline__ Jac29 jneg29(const Jac29& p) { return Jac29{p.x, f29::tighten(f29::sub<4>(f29::zero(), p.y)), p.z}; }
+
+// gnark-crypto G1Affine words -> the device form, once per point
+__global__ __launch_bounds__(256) void k_msm_convert(const uint64_t* __restrict__ points, size_t n, Aff29* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint64_t x = points[8 * i + k];
+        w[2 * k] = (uint32_t)x;
+        w[2 * k + 1] = (uint32_t)(x >> 32);
+    }
+    Aff29 p;
+    p.x = f29::from_mont256(w);       // (0, 0) stays exactly (0, 0)
+    p.y = f29::from_mont256(w + 8);
+    out[i] = p;
+}
+
 // ---- digits ----
 __global__ __launch_bounds__(256) void k_msm_digits(const uint64_t* __restrict__ scalars, size_t n, int montgomery,
                                                     uint16_t* __restrict__ keys /* [window][n] */) {
@@ -131,16 +217,16 @@ __global__ __launch_bounds__(256) void k_msm_ranges(const uint16_t* __restrict__
 #ifndef NLX_MSM_MINW
 #define NLX_MSM_MINW 3   // waves per SIMD the register allocation must allow (tuning builds: build.py NLX_EXTRA_FLAGS)
 #endif
-__global__ __launch_bounds__(64, NLX_MSM_MINW) void k_msm_buckets(const Affine* __restrict__ points, const uint32_t* __restrict__ sorted /* [window][n] */,
+__global__ __launch_bounds__(64, NLX_MSM_MINW) void k_msm_buckets(const Aff29* __restrict__ points, const uint32_t* __restrict__ sorted /* [window][n] */,
                                                     const uint32_t* __restrict__ range_lo, const uint32_t* __restrict__ range_hi /* [window][65536] */,
-                                                    Jac* __restrict__ buckets /* [window][65536] */) {
+                                                    Jac29* __restrict__ buckets /* [window][65536] */) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // = w * 65536 + b
     if (t >= (uint32_t)N_WINDOWS * N_BUCKETS) return;
-    Jac acc = jac_inf();
+    Jac29 acc = inf29();
     if ((t & (N_BUCKETS - 1)) != 0) {   // bucket 0 weighs nothing
         const uint32_t lo = range_lo[t], hi = range_hi[t];   // positions in the window-major sorted array
 #pragma unroll 1
-        for (uint32_t p = lo; p < hi; p++) acc = jmadd(acc, points[sorted[p]]);
+        for (uint32_t p = lo; p < hi; p++) acc = jmadd29(acc, points[sorted[p]]);
     }
     buckets[t] = acc;
 }
@@ -149,37 +235,47 @@ __global__ __launch_bounds__(64, NLX_MSM_MINW) void k_msm_buckets(const Affine* 
 // window RED_BLOCKS blocks whose partial sums the host adds.  The running-sum chain per lane is 64 additions + 16
 // double-and-add steps + 8 tree levels: with 256 buckets per lane (one block per window) this kernel took 14 ms ----
 constexpr int RED_LANES = 256, RED_CHUNK = 32, RED_BLOCKS = N_BUCKETS / (RED_LANES * RED_CHUNK);
-__global__ __launch_bounds__(RED_LANES) void k_msm_reduce(const Jac* __restrict__ buckets, Jac* __restrict__ window_sums /* [window][RED_BLOCKS] */) {
-    __shared__ Jac part[RED_LANES];
+__global__ __launch_bounds__(RED_LANES) void k_msm_reduce(const Jac29* __restrict__ buckets, JacWords* __restrict__ window_sums /* [window][RED_BLOCKS] */) {
+    __shared__ Jac29 part[RED_LANES];
     const uint32_t w = blockIdx.x / RED_BLOCKS, c = (blockIdx.x % RED_BLOCKS) * RED_LANES + threadIdx.x, base = c * RED_CHUNK;
-    const Jac* b = buckets + (size_t)w * N_BUCKETS + base;
-    Jac running = jac_inf(), local = jac_inf();
+    const Jac29* b = buckets + (size_t)w * N_BUCKETS + base;
+    Jac29 running = inf29(), local = inf29();
 #pragma unroll 1
     for (int j = RED_CHUNK - 1; j >= 0; j--) {   // running = sum_{j' >= j} B, local = sum_j (j + 1) B_(base + j)
-        running = jadd(running, b[j]);
-        local = jadd(local, running);
+        running = jadd29(running, b[j]);
+        local = jadd29(local, running);
     }
     // sum_j (base + j) B = local + (base - 1) * running; for the first chunk that is local - running
-    Jac shifted = jac_inf();
+    Jac29 shifted = inf29();
     if (c == 0) {
-        shifted = jneg(running);
+        shifted = jneg29(running);
     } else {
         const uint32_t k = base - 1;
 #pragma unroll 1
         for (int bit = 15; bit >= 0; bit--) {
-            shifted = jdbl(shifted);
-            if ((k >> bit) & 1) shifted = jadd(shifted, running);
+            shifted = jdbl29(shifted);
+            if ((k >> bit) & 1) shifted = jadd29(shifted, running);
         }
     }
     const uint32_t l = threadIdx.x;
-    part[l] = jadd(local, shifted);
+    part[l] = jadd29(local, shifted);
     __syncthreads();
 #pragma unroll 1
     for (int stride = RED_LANES / 2; stride > 0; stride >>= 1) {
-        if (l < (uint32_t)stride) part[l] = jadd(part[l], part[l + stride]);
+        if (l < (uint32_t)stride) part[l] = jadd29(part[l], part[l + stride]);
         __syncthreads();
     }
-    if (l == 0) window_sums[blockIdx.x] = part[0];
+    if (l == 0) {   // canonical integers for the host (which works on 32-bit limbs, bn254_fp.hpp)
+        JacWords o;
+        f29::to_canonical256(part[0].x, o.x);
+        f29::to_canonical256(part[0].y, o.y);
+        if (f29::is_zero_exact(part[0].z)) {
+            for (int k = 0; k < 8; k++) o.z[k] = 0;
+        } else {
+            f29::to_canonical256(part[0].z, o.z);
+        }
+        window_sums[blockIdx.x] = o;
+    }
 }
 
 }  // namespace msm
@@ -209,17 +305,19 @@ extern "C" int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const 
     uint32_t* d_sorted = (uint32_t*)ctx->alloc(pairs * 4);
     uint32_t* d_lo = (uint32_t*)ctx->alloc(n_hist * 2 * 4);   // range_lo | range_hi
     uint32_t* d_hi = d_lo ? d_lo + n_hist : nullptr;
-    Jac* d_buckets = (Jac*)ctx->alloc(n_hist * sizeof(Jac));
+    Jac29* d_buckets = (Jac29*)ctx->alloc(n_hist * sizeof(Jac29));
+    Aff29* d_pts = (Aff29*)ctx->alloc((size_t)n * sizeof(Aff29));   // the points in the kernels' field representation
     constexpr int N_WSUM = N_WINDOWS * RED_BLOCKS;
-    Jac* d_wsum = (Jac*)ctx->alloc(N_WSUM * sizeof(Jac));
+    JacWords* d_wsum = (JacWords*)ctx->alloc(N_WSUM * sizeof(JacWords));
     size_t tmp_bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys, d_keys_sorted, d_iota, d_sorted, (int)n, 0, WINDOW_BITS, st);
     void* d_tmp = ctx->alloc(tmp_bytes ? tmp_bytes : 16);
     auto release_all = [&]() {
-        for (void* p : {(void*)d_keys, (void*)d_keys_sorted, (void*)d_iota, (void*)d_sorted, (void*)d_lo, (void*)d_buckets, (void*)d_wsum, d_tmp})
+        for (void* p : {(void*)d_keys, (void*)d_keys_sorted, (void*)d_iota, (void*)d_sorted, (void*)d_lo, (void*)d_buckets, (void*)d_pts,
+                        (void*)d_wsum, d_tmp})
             if (p) ctx->release(p);
     };
-    if (!d_keys || !d_keys_sorted || !d_iota || !d_sorted || !d_lo || !d_buckets || !d_wsum || !d_tmp) {
+    if (!d_keys || !d_keys_sorted || !d_iota || !d_sorted || !d_lo || !d_buckets || !d_pts || !d_wsum || !d_tmp) {
         release_all();
         return NLX_E_NOMEM;
     }
@@ -235,6 +333,7 @@ extern "C" int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const 
     hipLaunchKernelGGL(k_msm_digits, dim3(blocks_n), dim3(256), 0, st, ss.as<uint64_t>(), (size_t)n,
                        (flags & NLX_BN254_MONTGOMERY) ? 1 : 0, d_keys);
     hipLaunchKernelGGL(k_msm_iota, dim3(blocks_n), dim3(256), 0, st, d_iota, (size_t)n);
+    hipLaunchKernelGGL(k_msm_convert, dim3(blocks_n), dim3(256), 0, st, sp.as<uint64_t>(), (size_t)n, d_pts);
     for (int w = 0; w < N_WINDOWS && !rc; w++) {
         size_t tb = tmp_bytes;
         hip_ok(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_keys + (size_t)w * n, d_keys_sorted, d_iota, d_sorted + (size_t)w * n,
@@ -243,17 +342,23 @@ extern "C" int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const 
                            d_lo + (size_t)w * N_BUCKETS, d_hi + (size_t)w * N_BUCKETS);
     }
     if (!rc) {
-        hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)(n_hist / 64)), dim3(64), 0, st, sp.as<Affine>(), d_sorted, d_lo, d_hi, d_buckets);
+        hipLaunchKernelGGL(k_msm_buckets, dim3((unsigned)(n_hist / 64)), dim3(64), 0, st, d_pts, d_sorted, d_lo, d_hi, d_buckets);
         hipLaunchKernelGGL(k_msm_reduce, dim3(N_WSUM), dim3(RED_LANES), 0, st, d_buckets, d_wsum);
     }
     ctx->end_kernel();
+    JacWords words[N_WSUM];
     Jac part[N_WSUM], wsum[N_WINDOWS];
-    if (!rc) rc = fetch(ctx, part, d_wsum, sizeof(part));
+    if (!rc) rc = fetch(ctx, words, d_wsum, sizeof(words));
     hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
     hip_ok(hipGetLastError(), "kernel launch");
     release_all();
     if (rc) return rc;
     // the blocks' partial sums per window, sum_w 2^(16 w) W_w, then to affine
+    for (int k = 0; k < N_WSUM; k++) {
+        Fq x, y, z;
+        for (int l = 0; l < 8; l++) { x.v[l] = words[k].x[l]; y.v[l] = words[k].y[l]; z.v[l] = words[k].z[l]; }
+        part[k] = Jac{to_mont(x), to_mont(y), to_mont(z)};   // z = 0 stays 0: the point at infinity
+    }
     for (int w = 0; w < N_WINDOWS; w++) {
         wsum[w] = part[w * RED_BLOCKS];
         for (int k = 1; k < RED_BLOCKS; k++) wsum[w] = jadd(wsum[w], part[w * RED_BLOCKS + k]);

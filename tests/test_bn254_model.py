@@ -33,3 +33,53 @@ def test_g1_model():
     assert bn.msm_g1(ks, pts) == bn.g1_add(bn.msm_g1(ks[:2], pts[:2]), bn.msm_g1(ks[2:], pts[2:]))
     logs = [rng.randrange(bn.R) for _ in range(4)]
     assert bn.msm_g1(ks[:4], [bn.g1_mul(a, g) for a in logs]) == bn.g1_mul(sum(k * a for k, a in zip(ks, logs)) % bn.R, g)
+
+
+def test_f29_field_code_built_for_the_host(tmp_path):
+    """csrc/bn254_f29.hpp (the MSM kernels' arithmetic on nine 29-bit limbs), compiled with g++: every operation equals the
+    big-integer computation and stays inside the bounds its header states - on random operands and on the extremes of the
+    allowed ranges"""
+    import os
+    import subprocess
+    import bn254_py as bn
+    from conftest import ROOT
+    exe = str(tmp_path / "f29check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-Wno-unknown-pragmas", "-fsanitize=undefined", "-fno-sanitize-recover=all",
+                    "-I", os.path.join(ROOT, "near-light-client_amd", "csrc"), os.path.join(ROOT, "tests", "native", "bn254_f29_check.cpp"), "-o", exe],
+                   check=True, capture_output=True)
+    q, rp = bn.Q, 1 << 261
+    rng = random.Random(29)
+    tight = lambda: rng.randrange(1 << 255)                              # noqa: E731
+    mul_in = lambda: rng.choice([rng.randrange(int(2 ** 257.5)), int(2 ** 257.5) - 1, 0, 1, q, q - 1, 2 * q])   # noqa: E731
+    cases = []
+    for _ in range(300):
+        cases.append(("mul", mul_in(), mul_in()))
+        cases.append(("add", rng.randrange(1 << 257), rng.randrange(1 << 257)))
+        cases.append(("sub4", rng.randrange(1 << 257), rng.choice([tight(), (1 << 255) - 1, 0])))
+        cases.append(("sub8", rng.randrange(1 << 257), rng.choice([rng.randrange(3 << 255), (3 << 255) - 1, 0])))
+        cases.append(("tighten", rng.choice([rng.randrange(1 << 258), (1 << 258) - 1, 0, q, 21 * q, q - 1, 7 * q + 5]), 0))
+        cases.append(("iszero", rng.choice([rng.randrange(1 << 258), 0, q, 5 * q, 21 * q, q + 1, 13 * q - 1]), 0))
+        cases.append(("frommont", rng.choice([rng.randrange(q), 0, q - 1, (1 << 256) % q]), 0))
+        cases.append(("tocanon", rng.choice([tight(), 0, q, 2 * q, rp % q]), 0))
+    text = "".join("%s %x %x\n" % c for c in cases)
+    out = subprocess.run([exe], input=text, text=True, capture_output=True, check=True).stdout.split("\n")
+    for (op, a, b), line in zip(cases, out):
+        val, normalised = line.split()
+        got = int(val, 16)
+        assert normalised == "1", (op, a, b)
+        if op == "mul":
+            assert got % q == a * b * pow(rp, -1, q) % q and got < (1 << 254) + q, (op, hex(a), hex(b))
+        elif op == "add":
+            assert got == a + b
+        elif op == "sub4":
+            assert got == a + 4 * q - b
+        elif op == "sub8":
+            assert got == a + 8 * q - b
+        elif op == "tighten":
+            assert got % q == a % q and got < 1.1 * q
+        elif op == "iszero":
+            assert got == (1 if a % q == 0 else 0)
+        elif op == "frommont":
+            assert got % q == a * 32 % q and got < (1 << 255)            # x 2^256 -> x 2^261
+        elif op == "tocanon":
+            assert got == a * pow(rp, -1, q) % q
