@@ -1115,7 +1115,8 @@ def run_msm24(args, nlx, torch, rank, world, local, dist):
     dev = "cuda:%d" % local
     pts = torch.from_numpy(nlx.bn254_g1_pack(base).view(np.int64)).to(dev).repeat((n + m - 1) // m, 1)[:n].contiguous()
     g = torch.Generator(device="cpu").manual_seed(0x6D736D + rank)
-    ks = torch.randint(0, 2 ** 60, (n, 4), generator=g, dtype=torch.int64)   # top word < 2^60: values < r, canonical form
+    ks = torch.randint(0, 2 ** 62, (n, 4), generator=g, dtype=torch.int64) * 4 + torch.randint(0, 4, (n, 4), generator=g, dtype=torch.int64)
+    ks[:, 3] = torch.randint(0, 0x30644e72e131a029, (n,), generator=g, dtype=torch.int64)   # top word below r's: uniform scalars < r, canonical form
     d_ks = ks.to(dev)
 
     def step():

@@ -36,6 +36,11 @@ typedef Fp<QP> Fq;
 typedef Fp<RP> Fr;
 
 constexpr int WINDOW_BITS = 16, N_WINDOWS = 16, N_BUCKETS = 1 << WINDOW_BITS;
+// The top window's digit has only 14 bits (scalars are below r < 2^254): its 12 388 buckets would hold five times the
+// points of any other and their lanes would run on alone at the end of the bucket kernel (63 ms, against 28 ms of issue
+// time).  Its sort key is therefore digit * 4 + (point index mod 4): four sub-buckets per digit, which the window
+// reduction adds up before weighing them.
+constexpr int TOP_SUB_BITS = 2;
 
 struct Affine { Fq x, y; };       // (0, 0) = the point at infinity (gnark-crypto's convention; not on the curve)
 struct Jac { Fq x, y, z; };       // z = 0: the point at infinity
@@ -192,7 +197,8 @@ __global__ __launch_bounds__(256) void k_msm_digits(const uint64_t* __restrict__
     else if (geq_mod(s)) sub_mod_raw(s);   // a non-reduced word string: fold once (callers hand reduced values)
 #pragma unroll
     for (int w = 0; w < N_WINDOWS; w++) {
-        const uint32_t d = (s.v[w >> 1] >> (16 * (w & 1))) & 0xFFFFu;
+        uint32_t d = (s.v[w >> 1] >> (16 * (w & 1))) & 0xFFFFu;
+        if (w == N_WINDOWS - 1) d = (d << TOP_SUB_BITS) | ((uint32_t)i & ((1u << TOP_SUB_BITS) - 1));   // d < 2^14 there
         keys[(size_t)w * n + i] = (uint16_t)d;
     }
 }
@@ -223,7 +229,8 @@ __global__ __launch_bounds__(64, NLX_MSM_MINW) void k_msm_buckets(const Aff29* _
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // = w * 65536 + b
     if (t >= (uint32_t)N_WINDOWS * N_BUCKETS) return;
     Jac29 acc = inf29();
-    if ((t & (N_BUCKETS - 1)) != 0) {   // bucket 0 weighs nothing
+    const uint32_t digit = (t >> WINDOW_BITS) == N_WINDOWS - 1 ? (t & (N_BUCKETS - 1)) >> TOP_SUB_BITS : t & (N_BUCKETS - 1);
+    if (digit != 0) {   // digit 0 weighs nothing
         const uint32_t lo = range_lo[t], hi = range_hi[t];   // positions in the window-major sorted array
 #pragma unroll 1
         for (uint32_t p = lo; p < hi; p++) acc = jmadd29(acc, points[sorted[p]]);
@@ -240,17 +247,18 @@ __global__ __launch_bounds__(RED_LANES) void k_msm_reduce(const Jac29* __restric
     const uint32_t w = blockIdx.x / RED_BLOCKS, c = (blockIdx.x % RED_BLOCKS) * RED_LANES + threadIdx.x, base = c * RED_CHUNK;
     const Jac29* b = buckets + (size_t)w * N_BUCKETS + base;
     Jac29 running = inf29(), local = inf29();
+    const int sub = w == N_WINDOWS - 1 ? TOP_SUB_BITS : 0;   // buckets per digit = 2^sub (a chunk holds whole digits)
 #pragma unroll 1
-    for (int j = RED_CHUNK - 1; j >= 0; j--) {   // running = sum_{j' >= j} B, local = sum_j (j + 1) B_(base + j)
+    for (int j = RED_CHUNK - 1; j >= 0; j--) {   // running = sum_{j' >= j} B, local = sum_d (d + 1) (digit (base >> sub) + d's buckets)
         running = jadd29(running, b[j]);
-        local = jadd29(local, running);
+        if ((j & ((1 << sub) - 1)) == 0) local = jadd29(local, running);
     }
-    // sum_j (base + j) B = local + (base - 1) * running; for the first chunk that is local - running
+    // sum_d ((base >> sub) + d) B_d = local + ((base >> sub) - 1) * running; for the first chunk that is local - running
     Jac29 shifted = inf29();
     if (c == 0) {
         shifted = jneg29(running);
     } else {
-        const uint32_t k = base - 1;
+        const uint32_t k = (base >> sub) - 1;
 #pragma unroll 1
         for (int bit = 15; bit >= 0; bit--) {
             shifted = jdbl29(shifted);
