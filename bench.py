@@ -51,7 +51,7 @@ def stored_traffic(key, alg_bytes):
     """HBM bytes per launch from the committed PMC pass (profiles/r02_pmc_traffic.json: FETCH_SIZE x 2 per the microarch
     guide, a separate rocprofv3 --pmc run of this command): measured ratio traffic / algorithmic bytes x this run's
     algorithmic bytes.  Not measured in this process (counters need their own run) - labelled "stored"."""
-    for name in ("r02_pmc_traffic_v2.json",):
+    for name in ("r02_pmc_traffic_v5.json", "r02_pmc_traffic_v2.json"):
         prof = os.path.join(ROOT, "profiles", name)
         if os.path.exists(prof):
             try:

@@ -41,7 +41,8 @@ def main(root):
     if f and w:
         alg = 8 * L * (N_CS + N_W + N_ZS + NC) + 8 * L * NC   # every column once + z(gx) + the two outputs
         traffic = (2 * f[0][1] + w[0][1]) * 1024
-        d = {"FETCH_SIZE_KB": f[0][1], "WRITE_SIZE_KB": w[0][1], "traffic_bytes": traffic, "algorithmic_bytes": alg, "ratio": traffic / alg}
+        d = {"FETCH_SIZE_KB": f[0][1], "WRITE_SIZE_KB": w[0][1], "traffic_bytes": traffic, "algorithmic_bytes": alg, "ratio": traffic / alg,
+             "fetched_bytes": 2 * f[0][1] * 1024, "fetched_over_algorithmic": 2 * f[0][1] * 1024 / alg}
         for c in ("SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_WAVES"):
             v = last(insts, q, c, 1)
             if v:
@@ -50,7 +51,8 @@ def main(root):
             d["valu_wave_instructions_per_tile_of_64_points"] = d["SQ_INSTS_VALU"] / (L / 64)
             d["vmem_rd_wave_instructions_per_tile_of_64_points"] = d.get("SQ_INSTS_VMEM_RD", 0) / (L / 64)
         out["quotient_19_gates"] = d
-        out["quotient_fetch_over_algorithmic"] = traffic / alg
+        out["quotient_traffic_over_algorithmic"] = traffic / alg            # reads + writes (the writes include spilled registers)
+        out["quotient_fetch_over_algorithmic"] = 2 * f[0][1] * 1024 / alg   # reads alone
     # k_hash_lde_leaves: three launches per proof (wires 135, zs 20, quotient 16 columns)
     h = "nlx::k_hash_lde_leaves"
     f, w = last(fetch, h, "FETCH_SIZE", 3), last(write, h, "WRITE_SIZE", 3)
