@@ -1099,6 +1099,7 @@ def run_msm24(args, nlx, torch, rank, world, local, dist):
     resident in HBM in gnark-crypto's layouts.  The points are 4 096 distinct curve points tiled (generated by the
     big-integer model; 2^24 of them would take hours), the scalars random 254-bit values.  With N ranks every rank owns a
     slice of the points (the partial sums add on the host: one G1 addition per rank, no collective)."""
+    import hashlib
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import bn254_py   # input generation (points on the curve) and the post-timing check only
@@ -1114,9 +1115,12 @@ def run_msm24(args, nlx, torch, rank, world, local, dist):
     ctx = nlx.Context(local)
     dev = "cuda:%d" % local
     pts = torch.from_numpy(nlx.bn254_g1_pack(base).view(np.int64)).to(dev).repeat((n + m - 1) // m, 1)[:n].contiguous()
-    g = torch.Generator(device="cpu").manual_seed(0x6D736D + rank)
-    ks = torch.randint(0, 2 ** 62, (n, 4), generator=g, dtype=torch.int64) * 4 + torch.randint(0, 4, (n, 4), generator=g, dtype=torch.int64)
-    ks[:, 3] = torch.randint(0, 0x30644e72e131a029, (n,), generator=g, dtype=torch.int64)   # top word below r's: uniform scalars < r, canonical form
+    # the job's scalars are the same for every world size (each rank takes its slice), so that the joined result can be compared
+    g = torch.Generator(device="cpu").manual_seed(0x6D736D)
+    n_all = n * world
+    ks = torch.randint(0, 2 ** 62, (n_all, 4), generator=g, dtype=torch.int64) * 4 + torch.randint(0, 4, (n_all, 4), generator=g, dtype=torch.int64)
+    ks[:, 3] = torch.randint(0, 0x30644e72e131a029, (n_all,), generator=g, dtype=torch.int64)   # top word below r's: uniform scalars < r, canonical form
+    ks = ks[rank * n:(rank + 1) * n].contiguous()   # n is a multiple of the tile of distinct points: point i of the job = base[i mod m]
     d_ks = ks.to(dev)
 
     def step():
@@ -1132,6 +1136,11 @@ def run_msm24(args, nlx, torch, rank, world, local, dist):
     dt = reduce_max(dist, torch, time.perf_counter() - t0)
     kt = ctx.kernel_stats("bn254_msm_g1")
     ctx.kernel_timing(False)
+    if world > 1:   # the ranks' partial results meet on rank 0: 64 bytes each, one G1 addition per rank
+        mine_t = torch.from_numpy(res.view(np.int64).copy()).to("cpu" if dist.get_backend() == "gloo" else dev)
+        parts = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(parts, mine_t)
+        res = nlx.bn254_g1_sum(np.stack([p.cpu().numpy().view(np.uint64) for p in parts]))
     out = None
     if rank == 0:
         ms = kt[1] / kt[0] if kt[0] else None
@@ -1144,6 +1153,7 @@ def run_msm24(args, nlx, torch, rank, world, local, dist):
             "config": {"workload": "one G1 MSM of 2^%d points x 254-bit scalars (gnark-crypto G1Affine / fr.Element words), resident "
                                    "in HBM, points split over the ranks" % log_n,
                        "points_per_rank": n, "distinct_points": m, "device_ms_rank0": ms,
+                       "result_sha256": hashlib.sha256(np.ascontiguousarray(res, dtype=np.uint64).tobytes()).hexdigest(),
                        "points_per_second": world * n * args.steps / dt,
                        "bucket_additions_per_second_rank0": adds_per_s, "parallelism": "points x%d" % world},
             "roofline": {"bound": "hbm", "achieved": (96.0 * n / (ms * 1e-3) / 1e9) if ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -139,6 +139,9 @@ int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_
  * scalars[i] * points[i] as a G1Affine (8 words, Montgomery; (0, 0) for the point at infinity).  points / scalars may be host
  * or device pointers; n <= 2^27.  Points are taken to be on the curve (as MultiExp does). */
 int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t flags, uint64_t out[8]);
+/* The sum of n G1Affine points (same layout; host pointers, computed on the host): joins the partial results of an MSM whose
+ * points were split over several GPUs - one addition per rank. */
+int32_t nlx_bn254_g1_sum(const uint64_t* points, uint64_t n, uint64_t out[8]);
 
 /* ---- a3: plonky2::fri::oracle::PolynomialBatch::{from_values, from_coeffs} ----
  * values / coeffs: n_cols x 2^log_n column-major, natural order.  The coset shift is the

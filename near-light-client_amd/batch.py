@@ -248,3 +248,12 @@ def bn254_msm_g1(ctx, points, scalars, montgomery=False):
     out = np.zeros(8, dtype=np.uint64)
     ctx.check(dll.nlx_bn254_msm_g1(ctx.handle, p_ptr if n else None, s_ptr if n else None, n, 1 if montgomery else 0, out.ctypes.data))
     return out
+
+
+def bn254_g1_sum(points):
+    """The sum of G1Affine points, (n, 8) uint64 words each (host): joins the partial MSMs of several GPUs."""
+    a = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    out = np.zeros(8, dtype=np.uint64)
+    if dll.nlx_bn254_g1_sum(a.ctypes.data if len(a) else None, len(a), out.ctypes.data) != 0:
+        raise ValueError("nlx_bn254_g1_sum failed")
+    return out

@@ -382,3 +382,21 @@ extern "C" int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const 
     store_words(mul(acc.y, mul(zi2, zi)), out + 4);
     return NLX_OK;
 }
+
+// Sum of n G1Affine points on the host (gnark-crypto layouts as above): what joins the partial results of an MSM whose points
+// were split over several GPUs - one addition per rank.
+extern "C" int32_t nlx_bn254_g1_sum(const uint64_t* points, uint64_t n, uint64_t out[8]) {
+    using namespace nlx::msm;
+    if (!out || (n && !points)) return NLX_E_INVAL;
+    Jac acc = jac_inf();
+    for (uint64_t i = 0; i < n; i++) {
+        Affine p{load_words<QP>(points + 8 * i), load_words<QP>(points + 8 * i + 4)};
+        acc = jmadd(acc, p);
+    }
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    if (is_zero(acc.z)) return NLX_OK;
+    const Fq zi = inv_host(acc.z), zi2 = sqr(zi);
+    store_words(mul(acc.x, zi2), out);
+    store_words(mul(acc.y, mul(zi2, zi)), out + 4);
+    return NLX_OK;
+}

@@ -62,7 +62,7 @@ def test_outer_only_workload_line():
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [("--workload", "stark", "--log-n", "10"), ("--workload", "sha256", "--log-blocks", "4"),
                                   ("--workload", "sha512", "--log-blocks", "3"), ("--workload", "ed25519", "--log-slots", "8"),
-                                  ("--workload", "ntt24", "--ntt-log-n", "18", "--ntt-cols", "4")])
+                                  ("--workload", "ntt24", "--ntt-log-n", "18", "--ntt-cols", "4"), ("--workload", "msm24", "--ntt-log-n", "14")])
 def test_secondary_workload_lines(args):
     d = run_bench(*args, "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
     for k in REQUIRED:
@@ -105,6 +105,17 @@ def test_driver_launch_line_two_ranks(args):
         assert one["config"]["root_digest"] == d["config"]["root_digest"], "root(ws=2) != root(ws=1)"
         assert d["config"]["output_lists_every_id_as_verified"] is True and one["config"]["output_lists_every_id_as_verified"] is True
         assert d["config"]["bytes_gathered_last_step"] == one["config"]["bytes_gathered_last_step"] > 64 * 50_000
+
+
+@pytest.mark.gpu
+def test_msm_split_over_two_ranks_joins_to_the_one_rank_result():
+    """--workload msm24 with the points split over two ranks (rehearsal: both on GPU 0 over gloo): the partial results, joined
+    by nlx_bn254_g1_sum on rank 0, are the one-rank result"""
+    args = ("--workload", "msm24", "--ntt-log-n", "14")
+    two = _launch_two_ranks(args, {"NLX_BENCH_REHEARSAL": "1"}, 29643)
+    one = run_bench(*args, "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert two["config"]["points_per_rank"] * 2 == one["config"]["points_per_rank"] == 1 << 14
+    assert two["config"]["result_sha256"] == one["config"]["result_sha256"]
 
 
 @pytest.mark.gpu

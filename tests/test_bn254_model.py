@@ -83,3 +83,15 @@ def test_f29_field_code_built_for_the_host(tmp_path):
             assert got % q == a * 32 % q and got < (1 << 255)            # x 2^256 -> x 2^261
         elif op == "tocanon":
             assert got == a * pow(rp, -1, q) % q
+
+
+def test_g1_sum_on_the_host(nlx):
+    """nlx_bn254_g1_sum (host code of the MSM's tail, no GPU): sums of G1Affine words equal the model's, infinity included"""
+    import bn254_py as bn
+    rng = random.Random(3)
+    pts = [bn.g1_mul(rng.randrange(1, bn.R), bn.G1) for _ in range(6)]
+    for chosen in (pts, pts[:1], [], [pts[0], bn.g1_neg(pts[0])], [pts[1], pts[1], None, pts[2]]):
+        want = None
+        for p in chosen:
+            want = bn.g1_add(want, p)
+        assert nlx.bn254_g1_unpack(nlx.bn254_g1_sum(nlx.bn254_g1_pack(chosen))) == want
