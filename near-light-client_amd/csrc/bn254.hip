@@ -9,14 +9,20 @@
 //   so a Go caller's []fr.Element can be handed over as it lies in memory (nlx.h: nlx_bn254_ntt_batch).
 // Replaces gnark-crypto fft.Domain.FFT / FFTInverse (DIF, natural order out after the bit-reversal the caller would do).
 //
-// Multiplication: CIOS Montgomery on eight 32-bit limbs; every step is a v_mad_u64_u32 (32 x 32 + 64).  A 256-bit
-// multiplication is ~170 multiply-adds against Goldilocks' 4, so unlike the Goldilocks transforms this one is bound by
-// the integer-VALU issue rate outright; the passes below fuse three butterfly levels per trip through HBM (radix 8 in
-// registers) to keep the memory traffic behind it.
+// Multiplication: the butterflies compute on nine 29-bit limbs (bn254_f29.hpp, modulus r: Montgomery form with R' = 2^261,
+// one v_mad_u64_u32 per partial product into fixed 64-bit columns, loose values with stated bounds) - the CIOS product on
+// eight 32-bit limbs of the first version cost ~800 instructions, most of them register moves (gfx950 wants the 64-bit
+// operands of the multiply-add in even-aligned pairs and a CIOS accumulator shifts by one limb per row).  Elements rest
+// in memory as 32 bytes in every pass (values below 2^256, re-sliced on load and store); the first pass multiplies by the
+// constant that takes the caller's form (fr.Element or canonical) into the kernels' form, the reordering pass by the one
+// that takes it back (with the 1/n).  The eight-limb code below remains for the host (twiddle tables, constants).  A
+// 256-bit product is ~160 multiply-adds against Goldilocks' 4, so unlike the Goldilocks transforms this one is bound by
+// the integer-VALU issue rate outright; the passes fuse three butterfly levels per trip through HBM (radix 8 in registers).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
 #include <vector>
+#include "bn254_f29.hpp"
 #include "ctx.hpp"
 #include "../../include/nlx.h"
 
@@ -178,31 +184,47 @@ __device__ __forceinline__ void store(Fr* p, const Fr& r) {
     q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
 }
 
-// out[i] = in[i] * k  (to / from Montgomery form, the 1/n of the inverse transform)
-__global__ __launch_bounds__(256) void k_bn_scale(Fr* __restrict__ data, size_t count, Fr k) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    store(data + i, mul(load(data + i), k));
+// ---- the kernels' element: nine 29-bit limbs, modulus r (bn254_f29.hpp) ----
+using f29::Fe;
+typedef f29::RMod RM;
+static const uint32_t H_K261[8] = {0x8fffff57u, 0x2fd4e156u, 0xa494b01au, 0x75bba827u, 0x819caa80u, 0x5301fa84u, 0x563d4475u, 0x0dc83629u};  // 2^261 mod r (plain)
+static const uint32_t H_C522[f29::NL] = {0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu, 0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au};  // 2^522 mod r
+__device__ __forceinline__ Fe load29(const Fr* p) {
+    const Fr r = load(p);
+    return f29::from_words256(r.v);
 }
+__device__ __forceinline__ void store29(Fr* p, const Fe& a) {   // a < 2^256
+    Fr r;
+    f29::to_words256(a, r.v);
+    store(p, r);
+}
+struct InScale {   // what the first pass multiplies every element by (takes the caller's form into the kernels')
+    Fe k;
+    int on;
+};
 
 // T[e] = lo[e & 4095] * hi[e >> 12]: the full table w_n^e, e < n/2, built once per (size, direction) on the device from
 // two small host-made tables.  A two-level table read inside the butterflies would cost a second 256-bit product per
 // butterfly - as much as the butterfly itself (measured: 97 ms against this version's time at 16 x 2^24).
+// The table holds the canonical integers w^e 2^261 mod r (the kernels' Montgomery form) as 32-byte words.
 __global__ __launch_bounds__(256) void k_bn_fill_twiddles(Fr* __restrict__ out, size_t count, const Fr* __restrict__ lo,
-                                                          const Fr* __restrict__ hi) {
+                                                          const Fr* __restrict__ hi, Fr k261) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= count) return;
     const Fr a = load(lo + (e & 4095u));
-    store(out + e, e < 4096u ? a : mul(a, load(hi + (e >> 12))));
+    const Fr w = e < 4096u ? a : mul(a, load(hi + (e >> 12)));   // w^e 2^256 (eight-limb Montgomery form)
+    store(out + e, mul(w, k261));                                  // (w^e 2^256) (2^261) / 2^256
 }
 
-__device__ __forceinline__ Fr twiddle(const Fr* __restrict__ table, const Fr* __restrict__, uint32_t e) { return load(table + e); }
+__device__ __forceinline__ Fe twiddle(const Fr* __restrict__ table, const Fr* __restrict__, uint32_t e) { return load29(table + e); }
 
 // One DIF level on a thread's register tile: partners are HALF apart (in units of h_last); HALF is a template parameter so
 // that every x[] index is static and the tile stays in registers (a runtime `half` put the whole tile into scratch memory:
 // the first version ran at a third of this one's speed).
-template <int R, int HALF>
-__device__ __forceinline__ void dif_level(Fr (&x)[R], size_t h_last, size_t off, unsigned shift, const Fr* __restrict__ tw_lo,
+// Bounds: values enter a pass below 2^255; a sum is tightened (< 1.1 r) except on the first fused level (< 2^256 there, which
+// a - b + 8 r still accepts as b); differences go through a product (< 2^255) or are tightened.
+template <int R, int HALF, bool TIGHT>
+__device__ __forceinline__ void dif_level(Fe (&x)[R], size_t h_last, size_t off, unsigned shift, const Fr* __restrict__ tw_lo,
                                           const Fr* __restrict__ tw_hi) {
 #pragma unroll
     for (int k = 0; k < R; k++) {
@@ -210,10 +232,10 @@ __device__ __forceinline__ void dif_level(Fr (&x)[R], size_t h_last, size_t off,
             // position of x[k] inside its 2h block: (k mod 2 HALF) * h_last + off, and k mod 2 HALF < HALF here
             const uint32_t idx = (uint32_t)((size_t)(k & (HALF - 1)) * h_last + off);
             const uint32_t e = idx << shift;   // w_{2h}^idx = w_n^(idx n / 2h)
-            const Fr a = x[k], b = x[k + HALF];
-            x[k] = add(a, b);
-            const Fr d = sub(a, b);
-            x[k + HALF] = e ? mul(d, twiddle(tw_lo, tw_hi, e)) : d;
+            const Fe a = x[k], b = x[k + HALF];
+            x[k] = TIGHT ? f29::tighten<RM>(f29::add(a, b)) : f29::add(a, b);
+            const Fe d = f29::sub<8, RM>(a, b);
+            x[k + HALF] = e ? f29::mul<RM>(d, twiddle(tw_lo, tw_hi, e)) : f29::tighten<RM>(d);
         }
     }
 }
@@ -223,7 +245,7 @@ __device__ __forceinline__ void dif_level(Fr (&x)[R], size_t h_last, size_t off,
 // (h_last = the half-size of the last fused level), i.e. one butterfly network of the fused levels.
 template <int LEVELS>
 __global__ __launch_bounds__(256) void k_bn_dif(Fr* __restrict__ data, unsigned log_n, unsigned log_h_first,
-                                                const Fr* __restrict__ tw_lo, const Fr* __restrict__ tw_hi, uint32_t n_cols) {
+                                                const Fr* __restrict__ tw_lo, const Fr* __restrict__ tw_hi, uint32_t n_cols, InScale in) {
     constexpr int R = 1 << LEVELS;
     const size_t n = (size_t)1 << log_n;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // butterfly-network index within a column
@@ -235,38 +257,41 @@ __global__ __launch_bounds__(256) void k_bn_dif(Fr* __restrict__ data, unsigned 
     // u = (block index among groups of 2 h_first) * h_last + offset below h_last
     const size_t off = u & (h_last - 1), grp = u >> log_h_last;
     Fr* base = data + col * n + (grp << (log_h_first + 1)) + off;
-    Fr x[R];
+    Fe x[R];
 #pragma unroll
-    for (int k = 0; k < R; k++) x[k] = load(base + (size_t)k * h_last);
+    for (int k = 0; k < R; k++) {
+        x[k] = load29(base + (size_t)k * h_last);
+        if (in.on) x[k] = f29::mul<RM>(x[k], in.k);
+    }
     // level l has half-size 2^(log_h_first - l): twiddle exponent shift = log_n - 1 - (log_h_first - l)
     const unsigned sh0 = log_n - 1 - log_h_first;
     if constexpr (LEVELS == 3) {
         // (unreachable: three levels run in k_bn_dif3, whose tile is eight named registers - the compiler kept this
         // array form in scratch memory even with static indices)
-        dif_level<R, 4>(x, h_last, off, sh0, tw_lo, tw_hi);
-        dif_level<R, 2>(x, h_last, off, sh0 + 1, tw_lo, tw_hi);
-        dif_level<R, 1>(x, h_last, off, sh0 + 2, tw_lo, tw_hi);
+        dif_level<R, 4, false>(x, h_last, off, sh0, tw_lo, tw_hi);
+        dif_level<R, 2, true>(x, h_last, off, sh0 + 1, tw_lo, tw_hi);
+        dif_level<R, 1, true>(x, h_last, off, sh0 + 2, tw_lo, tw_hi);
     } else if constexpr (LEVELS == 2) {
-        dif_level<R, 2>(x, h_last, off, sh0, tw_lo, tw_hi);
-        dif_level<R, 1>(x, h_last, off, sh0 + 1, tw_lo, tw_hi);
+        dif_level<R, 2, false>(x, h_last, off, sh0, tw_lo, tw_hi);
+        dif_level<R, 1, true>(x, h_last, off, sh0 + 1, tw_lo, tw_hi);
     } else {
-        dif_level<R, 1>(x, h_last, off, sh0, tw_lo, tw_hi);
+        dif_level<R, 1, true>(x, h_last, off, sh0, tw_lo, tw_hi);
     }
 #pragma unroll
-    for (int k = 0; k < R; k++) store(base + (size_t)k * h_last, x[k]);
+    for (int k = 0; k < R; k++) store29(base + (size_t)k * h_last, x[k]);
 }
 
 // Three fused levels with the tile in eight NAMED registers (radix 8).
-#define BN_BF(A, B, IDX, SH)                                              \
-    {                                                                     \
-        const uint32_t e_ = (uint32_t)(IDX) << (SH);                      \
-        const Fr a_ = A, b_ = B;                                          \
-        A = add(a_, b_);                                                  \
-        const Fr d_ = sub(a_, b_);                                        \
-        B = e_ ? mul(d_, twiddle(tw_lo, tw_hi, e_)) : d_;                 \
+#define BN_BF(A, B, IDX, SH, TIGHT)                                                       \
+    {                                                                                     \
+        const uint32_t e_ = (uint32_t)(IDX) << (SH);                                      \
+        const Fe a_ = A, b_ = B;                                                          \
+        A = TIGHT ? f29::tighten<RM>(f29::add(a_, b_)) : f29::add(a_, b_);                \
+        const Fe d_ = f29::sub<8, RM>(a_, b_);                                            \
+        B = e_ ? f29::mul<RM>(d_, twiddle(tw_lo, tw_hi, e_)) : f29::tighten<RM>(d_);      \
     }
 __global__ __launch_bounds__(256) void k_bn_dif3(Fr* __restrict__ data, unsigned log_n, unsigned log_h_first,
-                                                 const Fr* __restrict__ tw_lo, const Fr* __restrict__ tw_hi, uint32_t n_cols) {
+                                                 const Fr* __restrict__ tw_lo, const Fr* __restrict__ tw_hi, uint32_t n_cols, InScale in) {
     const size_t n = (size_t)1 << log_n;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per_col = n >> 3;
@@ -276,28 +301,41 @@ __global__ __launch_bounds__(256) void k_bn_dif3(Fr* __restrict__ data, unsigned
     const size_t h = (size_t)1 << log_h_last;
     const size_t off = u & (h - 1), grp = u >> log_h_last;
     Fr* base = data + col * n + (grp << (log_h_first + 1)) + off;
-    Fr x0 = load(base), x1 = load(base + h), x2 = load(base + 2 * h), x3 = load(base + 3 * h), x4 = load(base + 4 * h),
-       x5 = load(base + 5 * h), x6 = load(base + 6 * h), x7 = load(base + 7 * h);
+    Fe x0 = load29(base), x1 = load29(base + h), x2 = load29(base + 2 * h), x3 = load29(base + 3 * h), x4 = load29(base + 4 * h),
+       x5 = load29(base + 5 * h), x6 = load29(base + 6 * h), x7 = load29(base + 7 * h);
+    if (in.on) {
+        x0 = f29::mul<RM>(x0, in.k); x1 = f29::mul<RM>(x1, in.k); x2 = f29::mul<RM>(x2, in.k); x3 = f29::mul<RM>(x3, in.k);
+        x4 = f29::mul<RM>(x4, in.k); x5 = f29::mul<RM>(x5, in.k); x6 = f29::mul<RM>(x6, in.k); x7 = f29::mul<RM>(x7, in.k);
+    }
     const unsigned s0 = log_n - 1 - log_h_first;
-    BN_BF(x0, x4, off, s0) BN_BF(x1, x5, h + off, s0) BN_BF(x2, x6, 2 * h + off, s0) BN_BF(x3, x7, 3 * h + off, s0)
-    BN_BF(x0, x2, off, s0 + 1) BN_BF(x1, x3, h + off, s0 + 1) BN_BF(x4, x6, off, s0 + 1) BN_BF(x5, x7, h + off, s0 + 1)
-    BN_BF(x0, x1, off, s0 + 2) BN_BF(x2, x3, off, s0 + 2) BN_BF(x4, x5, off, s0 + 2) BN_BF(x6, x7, off, s0 + 2)
-    store(base, x0); store(base + h, x1); store(base + 2 * h, x2); store(base + 3 * h, x3);
-    store(base + 4 * h, x4); store(base + 5 * h, x5); store(base + 6 * h, x6); store(base + 7 * h, x7);
+    BN_BF(x0, x4, off, s0, false) BN_BF(x1, x5, h + off, s0, false) BN_BF(x2, x6, 2 * h + off, s0, false) BN_BF(x3, x7, 3 * h + off, s0, false)
+    BN_BF(x0, x2, off, s0 + 1, true) BN_BF(x1, x3, h + off, s0 + 1, true) BN_BF(x4, x6, off, s0 + 1, true) BN_BF(x5, x7, h + off, s0 + 1, true)
+    BN_BF(x0, x1, off, s0 + 2, true) BN_BF(x2, x3, off, s0 + 2, true) BN_BF(x4, x5, off, s0 + 2, true) BN_BF(x6, x7, off, s0 + 2, true)
+    store29(base, x0); store29(base + h, x1); store29(base + 2 * h, x2); store29(base + 3 * h, x3);
+    store29(base + 4 * h, x4); store29(base + 5 * h, x5); store29(base + 6 * h, x6); store29(base + 7 * h, x7);
 }
 #undef BN_BF
 
-// out[bitrev(i)] = in[i] * k  (the bit-reversal back to natural order, fused with the last scaling)
-__global__ __launch_bounds__(256) void k_bn_bitrev(const Fr* __restrict__ in, Fr* __restrict__ out, unsigned log_n, uint32_t n_cols,
-                                                   Fr k, int scale) {
+// data[bitrev(i)] <- data[i] * k, canonical, IN PLACE: the thread of the smaller index of each pair (i, bitrev(i)) swaps the
+// two (the bit-reversal back to natural order, fused with the product that takes the kernels' form back to the caller's -
+// and carries the 1/n of the inverse transform).  The first version wrote a second buffer and copied it back: twice the
+// traffic and 8.6 GB of scratch at 16 x 2^24.
+__global__ __launch_bounds__(256) void k_bn_bitrev(Fr* __restrict__ data, unsigned log_n, uint32_t n_cols, Fe k) {
     const size_t n = (size_t)1 << log_n;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * n_cols) return;
     const size_t col = t >> log_n, i = t & (n - 1);
     const size_t j = log_n ? (__brevll(i) >> (64 - log_n)) : 0;
-    Fr v = load(in + col * n + i);
-    if (scale) v = mul(v, k);
-    store(out + col * n + j, v);
+    if (j < i) return;
+    Fr* base = data + col * n;
+    const Fe a = f29::canonical<RM>(f29::mul<RM>(load29(base + i), k));
+    if (j == i) {
+        store29(base + i, a);
+        return;
+    }
+    const Fe b = f29::canonical<RM>(f29::mul<RM>(load29(base + j), k));
+    store29(base + j, a);
+    store29(base + i, b);
 }
 
 }  // namespace bn
@@ -313,6 +351,7 @@ int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_
     if (n_cols == 0) return NLX_OK;
     if (!cols) return ctx->fail(NLX_E_INVAL, "cols is NULL");
     if (log_n > 28) return ctx->fail(NLX_E_RANGE, "BN254 Fr has 2-adicity 28");
+    if (log_n == 0) return NLX_OK;   // the transform of one point is that point
     if (n_cols > 65535 || (flags & ~1u)) return ctx->fail(NLX_E_RANGE, "n_cols > 65535 or unknown flag");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
@@ -340,7 +379,8 @@ int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_
         if (!d_lo || !d_hi || !tb.d_lo) return NLX_E_NOMEM;
         NLX_HIP(ctx, hipMemcpyAsync(d_lo, lo.data(), 4096 * sizeof(Fr), hipMemcpyHostToDevice, st));
         NLX_HIP(ctx, hipMemcpyAsync(d_hi, hi.data(), n_hi * sizeof(Fr), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(bn::k_bn_fill_twiddles, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, tb.d_lo, half, d_lo, d_hi);
+        hipLaunchKernelGGL(bn::k_bn_fill_twiddles, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, tb.d_lo, half, d_lo, d_hi,
+                           bn::from_limbs(bn::H_K261));
         NLX_HIP(ctx, hipStreamSynchronize(st));
         ctx->release(d_lo);
         ctx->release(d_hi);
@@ -349,45 +389,47 @@ int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_
     nlx::Staged s(ctx, cols, count * 32, true, true);
     if (s.status) return s.status;
     Fr* d = s.as<Fr>();
-    Fr* tmp = (Fr*)ctx->alloc(count * 32);
-    if (!tmp) return NLX_E_NOMEM;
     const unsigned blocks1 = (unsigned)((count + 255) / 256);
-    if (!mont_io) hipLaunchKernelGGL(bn::k_bn_scale, dim3(blocks1), dim3(256), 0, st, d, count, bn::from_limbs(bn::H_R2));
     // DIF: natural order in, bit-reversed out; three levels per pass while they last
     ctx->begin_kernel("bn254_ntt_transform", 64.0 * count);  // algorithmic bytes: 32 B read + 32 B written per element
+    // the first pass also takes the caller's form into the kernels' (x 2^261 mod r): fr.Element words (x 2^256) times 2^266 /
+    // 2^261, canonical integers times 2^522 / 2^261
+    bn::InScale first{};
+    first.on = 1;
+    for (int i = 0; i < f29::NL; i++) first.k.v[i] = mont_io ? f29::RMod::c266(i) : bn::H_C522[i];
+    bn::InScale none{};
     int lvl = (int)log_n - 1;  // log2 of the current level's half-size
+    bool is_first = true;
     while (lvl >= 0) {
         const int take = lvl >= 2 ? 3 : lvl + 1;
         const size_t nets = (n >> take) * n_cols;
         const unsigned blocks = (unsigned)((nets + 255) / 256);
-        if (take == 3) hipLaunchKernelGGL(bn::k_bn_dif3, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols);
-        else if (take == 2) hipLaunchKernelGGL(bn::k_bn_dif<2>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols);
-        else hipLaunchKernelGGL(bn::k_bn_dif<1>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols);
+        const bn::InScale in = is_first ? first : none;
+        if (take == 3) hipLaunchKernelGGL(bn::k_bn_dif3, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols, in);
+        else if (take == 2) hipLaunchKernelGGL(bn::k_bn_dif<2>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols, in);
+        else hipLaunchKernelGGL(bn::k_bn_dif<1>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols, in);
+        is_first = false;
         lvl -= take;
     }
     ctx->end_kernel();
-    // back to natural order, fused with the scalings still owed: 1/n (inverse) and R^-1 (standard-form output)
-    Fr k = bn::from_limbs(bn::H_ONE);
-    int scale = 0;
+    // back to natural order, fused with the product that leaves the kernels' form: an element is y 2^261, and y 2^261 c / 2^261
+    // = y c, so c is the PLAIN integer (2^256 if the caller wants fr.Element words) (1/n if inverse) mod r.  The eight-limb
+    // Montgomery form of z is the plain integer z 2^256 mod r, which the host code below produces directly.
+    Fr c = bn::from_limbs(bn::H_ONE);                        // plain 2^256 mod r
     if (inverse) {
         Fr nn{};
         nn.v[0] = (uint32_t)n; nn.v[1] = (uint32_t)((uint64_t)n >> 32);
-        k = bn::h_inv(bn::mul(nn, bn::from_limbs(bn::H_R2)));  // (n R)^-1 R = n^-1 in Montgomery form
-        scale = 1;
+        c = bn::h_inv(bn::mul(nn, bn::from_limbs(bn::H_R2)));   // Montgomery form of 1/n = plain 2^256 / n
     }
     if (!mont_io) {
-        // multiplying by the standard-form value of k (= k R^-1 in Montgomery terms) leaves the product in standard form
         Fr one{};
         one.v[0] = 1;
-        k = bn::mul(k, one);
-        scale = 1;
+        c = bn::mul(c, one);                                  // / 2^256: plain 1/n (or 1)
     }
+    const bn::Fe k = f29::from_words256(c.v);
     ctx->begin_kernel("bn254_ntt_reorder", 64.0 * count);
-    hipLaunchKernelGGL(bn::k_bn_bitrev, dim3(blocks1), dim3(256), 0, st, d, tmp, log_n, (uint32_t)n_cols, k, scale);
-    hipError_t e = hipMemcpyAsync(d, tmp, count * 32, hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(bn::k_bn_bitrev, dim3(blocks1), dim3(256), 0, st, d, log_n, (uint32_t)n_cols, k);
     ctx->end_kernel();
-    ctx->release(tmp);
-    if (e != hipSuccess) return ctx->hip_fail(e, "hipMemcpyAsync");
     int32_t rc = s.finish();
     if (rc) return rc;
     NLX_HIP(ctx, hipStreamSynchronize(st));

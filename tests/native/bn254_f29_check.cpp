@@ -1,5 +1,6 @@
-// Host build of the MSM's 29-bit-limb field arithmetic (csrc/bn254_f29.hpp): reads "op A [B]" lines (hexadecimal integers
-// below 2^261), prints the result as a hexadecimal integer and whether its limbs 0..7 are below 2^29.
+// Host build of the 29-bit-limb field arithmetic of the BN254 kernels (csrc/bn254_f29.hpp; base field q: the MSM, scalar field
+// r: the NTT): reads "modulus op A B" lines (hexadecimal integers below 2^261), prints the result as a hexadecimal integer
+// and whether its limbs 0..7 are below 2^29.
 // tests/test_bn254_model.py checks every answer, and the bounds the header states, with Python integers.
 #include <cstdio>
 #include <cstring>
@@ -44,31 +45,37 @@ static void print(const Fe& a) {   // sum v[i] 2^(29 i) as hex (limb 8 may carry
     printf("%s %u\n", s.c_str(), carry_check);
 }
 
-int main() {
-    char op[32], a[128], b[128];
-    while (scanf("%31s %127s %127s", op, a, b) == 3) {
+template <class M>
+static int run(const char* op, const Fe& x, const Fe& y) {
+    if (!strcmp(op, "mul")) print(mul<M>(x, y));
+    else if (!strcmp(op, "add")) print(add(x, y));
+    else if (!strcmp(op, "sub4")) print(sub<4, M>(x, y));
+    else if (!strcmp(op, "sub8")) print(sub<8, M>(x, y));
+    else if (!strcmp(op, "tighten")) print(tighten<M>(x));
+    else if (!strcmp(op, "canonical")) print(canonical<M>(x));
+    else if (!strcmp(op, "iszero")) printf("%d 1\n", is_zero_mod<M>(x) ? 1 : 0);
+    else if (!strcmp(op, "frommont") || !strcmp(op, "words")) {
+        uint32_t w[8];
+        to_words256(x, w);   // the operand is below 2^256
+        if (!strcmp(op, "words")) print(from_words256(w));   // slicing there and back
+        else print(from_mont256<M>(w));
+    } else if (!strcmp(op, "tocanon")) {
+        uint32_t w[8];
+        to_canonical256<M>(x, w);
+        std::string s;
+        char t[16];
+        for (int k = 7; k >= 0; k--) { snprintf(t, sizeof t, "%08x", w[k]); s += t; }
+        printf("%s 1\n", s.c_str());
+    } else return 2;
+    return 0;
+}
+
+int main() {   // lines: modulus ("q" | "r") op A B
+    char mod[8], op[32], a[128], b[128];
+    while (scanf("%7s %31s %127s %127s", mod, op, a, b) == 4) {
         const Fe x = parse(a), y = parse(b);
-        if (!strcmp(op, "mul")) print(mul(x, y));
-        else if (!strcmp(op, "add")) print(add(x, y));
-        else if (!strcmp(op, "sub4")) print(sub<4>(x, y));
-        else if (!strcmp(op, "sub8")) print(sub<8>(x, y));
-        else if (!strcmp(op, "tighten")) print(tighten(x));
-        else if (!strcmp(op, "iszero")) printf("%d 1\n", is_zero_mod(x) ? 1 : 0);
-        else if (!strcmp(op, "frommont")) {
-            uint32_t w[8];
-            for (int k = 0; k < 8; k++) w[k] = 0;
-            for (int i = 0; i < NL; i++)
-                for (int bit = 0; bit < 32; bit++)
-                    if ((x.v[i] >> bit) & 1) { const int pos = LB * i + bit; if (pos < 256) w[pos >> 5] |= 1u << (pos & 31); }
-            print(from_mont256(w));
-        } else if (!strcmp(op, "tocanon")) {
-            uint32_t w[8];
-            to_canonical256(x, w);
-            std::string s;
-            char t[16];
-            for (int k = 7; k >= 0; k--) { snprintf(t, sizeof t, "%08x", w[k]); s += t; }
-            printf("%s 1\n", s.c_str());
-        } else return 2;
+        const int rc = mod[0] == 'q' ? run<QMod>(op, x, y) : run<RMod>(op, x, y);
+        if (rc) return rc;
     }
     return 0;
 }

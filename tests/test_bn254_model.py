@@ -47,23 +47,28 @@ def test_f29_field_code_built_for_the_host(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-Wno-unknown-pragmas", "-fsanitize=undefined", "-fno-sanitize-recover=all",
                     "-I", os.path.join(ROOT, "near-light-client_amd", "csrc"), os.path.join(ROOT, "tests", "native", "bn254_f29_check.cpp"), "-o", exe],
                    check=True, capture_output=True)
-    q, rp = bn.Q, 1 << 261
+    rp = 1 << 261
     rng = random.Random(29)
-    tight = lambda: rng.randrange(1 << 255)                              # noqa: E731
-    mul_in = lambda: rng.choice([rng.randrange(int(2 ** 257.5)), int(2 ** 257.5) - 1, 0, 1, q, q - 1, 2 * q])   # noqa: E731
     cases = []
-    for _ in range(300):
-        cases.append(("mul", mul_in(), mul_in()))
-        cases.append(("add", rng.randrange(1 << 257), rng.randrange(1 << 257)))
-        cases.append(("sub4", rng.randrange(1 << 257), rng.choice([tight(), (1 << 255) - 1, 0])))
-        cases.append(("sub8", rng.randrange(1 << 257), rng.choice([rng.randrange(3 << 255), (3 << 255) - 1, 0])))
-        cases.append(("tighten", rng.choice([rng.randrange(1 << 258), (1 << 258) - 1, 0, q, 21 * q, q - 1, 7 * q + 5]), 0))
-        cases.append(("iszero", rng.choice([rng.randrange(1 << 258), 0, q, 5 * q, 21 * q, q + 1, 13 * q - 1]), 0))
-        cases.append(("frommont", rng.choice([rng.randrange(q), 0, q - 1, (1 << 256) % q]), 0))
-        cases.append(("tocanon", rng.choice([tight(), 0, q, 2 * q, rp % q]), 0))
-    text = "".join("%s %x %x\n" % c for c in cases)
+    for name, q in (("q", bn.Q), ("r", bn.R)):
+        tight = lambda: rng.randrange(1 << 255)                              # noqa: E731
+        mul_in = lambda: rng.choice([rng.randrange(int(2 ** 257.5)), int(2 ** 257.5) - 1, 0, 1, q, q - 1, 2 * q])   # noqa: E731,B023
+        for _ in range(200):
+            cases.append((name, "mul", mul_in(), mul_in()))
+            cases.append((name, "add", rng.randrange(1 << 257), rng.randrange(1 << 257)))
+            cases.append((name, "sub4", rng.randrange(1 << 257), rng.choice([tight(), (1 << 255) - 1, 0])))
+            cases.append((name, "sub8", rng.randrange(1 << 257), rng.choice([rng.randrange(3 << 255), (3 << 255) - 1, 0])))
+            cases.append((name, "tighten", rng.choice([rng.randrange(1 << 258), (1 << 258) - 1, 0, q, 21 * q, q - 1, 7 * q + 5]), 0))
+            cases.append((name, "canonical", rng.choice([rng.randrange(1 << 258), (1 << 258) - 1, 0, q, 21 * q, q - 1, 7 * q + 5, 2 * q - 1]), 0))
+            cases.append((name, "iszero", rng.choice([rng.randrange(1 << 258), 0, q, 5 * q, 21 * q, q + 1, 13 * q - 1]), 0))
+            cases.append((name, "frommont", rng.choice([rng.randrange(q), 0, q - 1, (1 << 256) % q]), 0))
+            cases.append((name, "words", rng.choice([rng.randrange(1 << 256), (1 << 256) - 1, 0]), 0))
+            cases.append((name, "tocanon", rng.choice([tight(), 0, q, 2 * q, rp % q]), 0))
+    text = "".join("%s %s %x %x\n" % c for c in cases)
     out = subprocess.run([exe], input=text, text=True, capture_output=True, check=True).stdout.split("\n")
-    for (op, a, b), line in zip(cases, out):
+    assert len(out) >= len(cases)
+    for (name, op, a, b), line in zip(cases, out):
+        q = bn.Q if name == "q" else bn.R
         val, normalised = line.split()
         got = int(val, 16)
         assert normalised == "1", (op, a, b)
@@ -77,10 +82,14 @@ def test_f29_field_code_built_for_the_host(tmp_path):
             assert got == a + 8 * q - b
         elif op == "tighten":
             assert got % q == a % q and got < 1.1 * q
+        elif op == "canonical":
+            assert got == a % q
         elif op == "iszero":
             assert got == (1 if a % q == 0 else 0)
         elif op == "frommont":
             assert got % q == a * 32 % q and got < (1 << 255)            # x 2^256 -> x 2^261
+        elif op == "words":
+            assert got == a
         elif op == "tocanon":
             assert got == a * pow(rp, -1, q) % q
 
