@@ -132,6 +132,14 @@ int32_t nlx_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_
  * the root of unity is gnark-crypto's (5^((r-1)/2^28)).  inverse = 1 also multiplies by 1/n. */
 #define NLX_BN254_MONTGOMERY 1u
 int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags);
+/* The same with gnark-crypto's two FFT options.  coset_shift != NULL (four words in the form of the data): the transform on
+ * the coset shift * <w> - fft.OnCoset() with the domain's FrMultiplicativeGen: forward evaluates on shift w^k (coefficient j
+ * is multiplied by shift^j first), inverse interpolates from there (coefficient j is multiplied by shift^-j last).
+ * NLX_BN254_BITREV_OUT: skip the reordering pass - natural order in, bit-reversed order out, what fft.DIF leaves (the
+ * caller pairs it with a transform that reads bit-reversed input, or reorders once at the end). */
+#define NLX_BN254_BITREV_OUT 2u
+int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags,
+                                  const uint64_t* coset_shift);
 /* ---- f.4 (second piece): the G1 multi-scalar multiplication of the wrap's KZG commitments (gnark-crypto ecc/bn254
  * G1Affine.MultiExp(points, scalars, config)).  points: n x 8 little-endian 64-bit words = gnark-crypto's G1Affine as it lies in
  * memory (X then Y, each an fp.Element in Montgomery form, R = 2^256; the point at infinity is (0, 0)); scalars: n x 4 words,

@@ -71,6 +71,8 @@ SIGNATURES = {
                                        ctypes.c_int, ctypes.c_uint64]),
     "nlx_bn254_ntt_batch": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int,
                                               ctypes.c_uint32]),
+    "nlx_bn254_ntt_batch_coset": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int,
+                                                    ctypes.c_uint32, ctypes.c_void_p]),
     "nlx_bn254_msm_g1": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32,
                                            ctypes.c_void_p]),
     "nlx_bn254_g1_sum": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),

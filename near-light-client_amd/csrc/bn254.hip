@@ -198,10 +198,23 @@ __device__ __forceinline__ void store29(Fr* p, const Fe& a) {   // a < 2^256
     f29::to_words256(a, r.v);
     store(p, r);
 }
-struct InScale {   // what the first pass multiplies every element by (takes the caller's form into the kernels')
+// What a pass multiplies element e of a column by: a constant (k), or - for a transform on a coset - the e-th power of the
+// shift times that constant, from a two-level table: lo[e & 4095] * hi[e >> 12] (32-byte words; hi[0] is the Montgomery
+// one, so entries below 4096 need no product).  The first pass uses it to take the caller's form into the kernels' (and
+// the coefficients onto the coset), the last one to take it back (with the 1/n and the inverse powers).
+struct Scale {
     Fe k;
+    const Fr* lo;
+    const Fr* hi;
     int on;
 };
+__device__ __forceinline__ Fe scaled(const Fe& x, const Scale& sc, size_t e) {
+    if (!sc.lo) return f29::mul<RM>(x, sc.k);
+    Fe f = load29(sc.lo + (e & 4095u));
+    if (e >> 12) f = f29::mul<RM>(f, load29(sc.hi + (e >> 12)));
+    return f29::mul<RM>(x, f);
+}
+typedef Scale InScale;
 
 // T[e] = lo[e & 4095] * hi[e >> 12]: the full table w_n^e, e < n/2, built once per (size, direction) on the device from
 // two small host-made tables.  A two-level table read inside the butterflies would cost a second 256-bit product per
@@ -258,10 +271,11 @@ __global__ __launch_bounds__(256) void k_bn_dif(Fr* __restrict__ data, unsigned 
     const size_t off = u & (h_last - 1), grp = u >> log_h_last;
     Fr* base = data + col * n + (grp << (log_h_first + 1)) + off;
     Fe x[R];
+    const size_t e0 = (grp << (log_h_first + 1)) + off;   // index of x[0] within its column
 #pragma unroll
     for (int k = 0; k < R; k++) {
         x[k] = load29(base + (size_t)k * h_last);
-        if (in.on) x[k] = f29::mul<RM>(x[k], in.k);
+        if (in.on) x[k] = scaled(x[k], in, e0 + (size_t)k * h_last);
     }
     // level l has half-size 2^(log_h_first - l): twiddle exponent shift = log_n - 1 - (log_h_first - l)
     const unsigned sh0 = log_n - 1 - log_h_first;
@@ -304,8 +318,9 @@ __global__ __launch_bounds__(256) void k_bn_dif3(Fr* __restrict__ data, unsigned
     Fe x0 = load29(base), x1 = load29(base + h), x2 = load29(base + 2 * h), x3 = load29(base + 3 * h), x4 = load29(base + 4 * h),
        x5 = load29(base + 5 * h), x6 = load29(base + 6 * h), x7 = load29(base + 7 * h);
     if (in.on) {
-        x0 = f29::mul<RM>(x0, in.k); x1 = f29::mul<RM>(x1, in.k); x2 = f29::mul<RM>(x2, in.k); x3 = f29::mul<RM>(x3, in.k);
-        x4 = f29::mul<RM>(x4, in.k); x5 = f29::mul<RM>(x5, in.k); x6 = f29::mul<RM>(x6, in.k); x7 = f29::mul<RM>(x7, in.k);
+        const size_t e0 = (grp << (log_h_first + 1)) + off;   // index of x0 within its column
+        x0 = scaled(x0, in, e0); x1 = scaled(x1, in, e0 + h); x2 = scaled(x2, in, e0 + 2 * h); x3 = scaled(x3, in, e0 + 3 * h);
+        x4 = scaled(x4, in, e0 + 4 * h); x5 = scaled(x5, in, e0 + 5 * h); x6 = scaled(x6, in, e0 + 6 * h); x7 = scaled(x7, in, e0 + 7 * h);
     }
     const unsigned s0 = log_n - 1 - log_h_first;
     BN_BF(x0, x4, off, s0, false) BN_BF(x1, x5, h + off, s0, false) BN_BF(x2, x6, 2 * h + off, s0, false) BN_BF(x3, x7, 3 * h + off, s0, false)
@@ -320,7 +335,7 @@ __global__ __launch_bounds__(256) void k_bn_dif3(Fr* __restrict__ data, unsigned
 // two (the bit-reversal back to natural order, fused with the product that takes the kernels' form back to the caller's -
 // and carries the 1/n of the inverse transform).  The first version wrote a second buffer and copied it back: twice the
 // traffic and 8.6 GB of scratch at 16 x 2^24.
-__global__ __launch_bounds__(256) void k_bn_bitrev(Fr* __restrict__ data, unsigned log_n, uint32_t n_cols, Fe k) {
+__global__ __launch_bounds__(256) void k_bn_bitrev(Fr* __restrict__ data, unsigned log_n, uint32_t n_cols, Scale k) {
     const size_t n = (size_t)1 << log_n;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * n_cols) return;
@@ -328,14 +343,25 @@ __global__ __launch_bounds__(256) void k_bn_bitrev(Fr* __restrict__ data, unsign
     const size_t j = log_n ? (__brevll(i) >> (64 - log_n)) : 0;
     if (j < i) return;
     Fr* base = data + col * n;
-    const Fe a = f29::canonical<RM>(f29::mul<RM>(load29(base + i), k));
+    const Fe a = f29::canonical<RM>(scaled(load29(base + i), k, j));   // position i holds natural index j = bitrev(i)
     if (j == i) {
         store29(base + i, a);
         return;
     }
-    const Fe b = f29::canonical<RM>(f29::mul<RM>(load29(base + j), k));
+    const Fe b = f29::canonical<RM>(scaled(load29(base + j), k, i));
     store29(base + j, a);
     store29(base + i, b);
+}
+
+// The same product without the reordering (flag NLX_BN254_BITREV_OUT: gnark-crypto's fft.DIF leaves its output like this):
+// position p keeps natural index bitrev(p).
+__global__ __launch_bounds__(256) void k_bn_scale_out(Fr* __restrict__ data, unsigned log_n, uint32_t n_cols, Scale k) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n_cols) return;
+    const size_t i = t & (n - 1);
+    const size_t j = log_n ? (__brevll(i) >> (64 - log_n)) : 0;
+    store29(data + t, f29::canonical<RM>(scaled(load29(data + t), k, j)));
 }
 
 }  // namespace bn
@@ -346,13 +372,14 @@ using nlx::bn::Fr;
 
 extern "C" {
 
-int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags) {
+int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags,
+                                  const uint64_t* coset_shift) {
     if (!ctx) return NLX_E_INVAL;
     if (n_cols == 0) return NLX_OK;
     if (!cols) return ctx->fail(NLX_E_INVAL, "cols is NULL");
     if (log_n > 28) return ctx->fail(NLX_E_RANGE, "BN254 Fr has 2-adicity 28");
-    if (log_n == 0) return NLX_OK;   // the transform of one point is that point
-    if (n_cols > 65535 || (flags & ~1u)) return ctx->fail(NLX_E_RANGE, "n_cols > 65535 or unknown flag");
+    if (n_cols > 65535 || (flags & ~(NLX_BN254_MONTGOMERY | NLX_BN254_BITREV_OUT))) return ctx->fail(NLX_E_RANGE, "n_cols > 65535 or unknown flag");
+    if (log_n == 0) return NLX_OK;   // the transform of one point is that point, on any coset
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     const size_t n = (size_t)1 << log_n, count = n * n_cols;
@@ -398,6 +425,47 @@ int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_
     first.on = 1;
     for (int i = 0; i < f29::NL; i++) first.k.v[i] = mont_io ? f29::RMod::c266(i) : bn::H_C522[i];
     bn::InScale none{};
+    // On a coset (forward: coefficient j times shift^j first; inverse: coefficient j times shift^-j last) the constant of
+    // that pass moves into a two-level power table, built on the host with the eight-limb code: lo[j] = plain(s^j C),
+    // hi[m] = plain(s^(4096 m) 2^261), so that the kernels' product lo hi / 2^261 is plain(s^(j + 4096 m) C).
+    Fr* d_pow = nullptr;
+    auto power_table = [&](Fr base_mont /* eight-limb Montgomery form of s */, const Fr& c_plain, bn::Scale& sc) -> int32_t {
+        const size_t n_hi = std::max<size_t>((n + 4095) >> 12, 1);
+        std::vector<Fr> t(4096 + n_hi);
+        Fr pw = bn::from_limbs(bn::H_ONE);                                   // s^0
+        for (size_t j = 0; j < 4096; j++) {
+            t[j] = bn::mul(pw, c_plain);                                     // s^j 2^256 C / 2^256
+            pw = bn::mul(pw, base_mont);
+        }
+        const Fr step = pw, k261 = bn::from_limbs(bn::H_K261);              // s^4096
+        pw = bn::from_limbs(bn::H_ONE);
+        for (size_t m = 0; m < n_hi; m++) {
+            t[4096 + m] = bn::mul(pw, k261);
+            pw = bn::mul(pw, step);
+        }
+        d_pow = (Fr*)ctx->alloc(t.size() * sizeof(Fr));
+        if (!d_pow) return NLX_E_NOMEM;
+        hipError_t e = hipMemcpyAsync(d_pow, t.data(), t.size() * sizeof(Fr), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);                    // t is a local
+        if (e != hipSuccess) return ctx->hip_fail(e, "hipMemcpyAsync(coset powers)");
+        sc.lo = d_pow;
+        sc.hi = d_pow + 4096;
+        return NLX_OK;
+    };
+    Fr shift_mont{};
+    if (coset_shift) {
+        for (int i = 0; i < 4; i++) { shift_mont.v[2 * i] = (uint32_t)coset_shift[i]; shift_mont.v[2 * i + 1] = (uint32_t)(coset_shift[i] >> 32); }
+        if (!mont_io) shift_mont = bn::mul(shift_mont, bn::from_limbs(bn::H_R2));
+        bool zero = true;
+        for (int i = 0; i < 8; i++) zero = zero && shift_mont.v[i] == 0;
+        if (zero) return ctx->fail(NLX_E_INVAL, "coset shift is zero");
+    }
+    if (coset_shift && !inverse) {
+        Fr c_in{};   // plain 2^266 or 2^522 mod r, from the kernels' limbs
+        f29::to_words256(first.k, c_in.v);
+        const int32_t prc = power_table(shift_mont, c_in, first);
+        if (prc) { if (d_pow) ctx->release(d_pow); return prc; }
+    }
     int lvl = (int)log_n - 1;  // log2 of the current level's half-size
     bool is_first = true;
     while (lvl >= 0) {
@@ -426,16 +494,29 @@ int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_
         one.v[0] = 1;
         c = bn::mul(c, one);                                  // / 2^256: plain 1/n (or 1)
     }
-    const bn::Fe k = f29::from_words256(c.v);
+    bn::Scale last{};
+    last.on = 1;
+    last.k = f29::from_words256(c.v);
+    if (coset_shift && inverse) {
+        const int32_t prc = power_table(bn::h_inv(shift_mont), c, last);
+        if (prc) { if (d_pow) ctx->release(d_pow); return prc; }
+    }
     ctx->begin_kernel("bn254_ntt_reorder", 64.0 * count);
-    hipLaunchKernelGGL(bn::k_bn_bitrev, dim3(blocks1), dim3(256), 0, st, d, log_n, (uint32_t)n_cols, k);
+    if (flags & NLX_BN254_BITREV_OUT) hipLaunchKernelGGL(bn::k_bn_scale_out, dim3(blocks1), dim3(256), 0, st, d, log_n, (uint32_t)n_cols, last);
+    else hipLaunchKernelGGL(bn::k_bn_bitrev, dim3(blocks1), dim3(256), 0, st, d, log_n, (uint32_t)n_cols, last);
     ctx->end_kernel();
     int32_t rc = s.finish();
+    hipError_t es = hipStreamSynchronize(st);
+    if (d_pow) ctx->release(d_pow);
     if (rc) return rc;
-    NLX_HIP(ctx, hipStreamSynchronize(st));
+    if (es != hipSuccess) return ctx->hip_fail(es, "hipStreamSynchronize");
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return ctx->hip_fail(le, "kernel launch");
     return NLX_OK;
+}
+
+int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags) {
+    return nlx_bn254_ntt_batch_coset(ctx, cols, n_cols, log_n, inverse, flags, nullptr);
 }
 
 }  // extern "C"

@@ -61,6 +61,32 @@ def test_bn254_ntt_argument_checks(nlx, ctx):
         ctx.check(nlx.lib.dll.nlx_bn254_ntt_batch(ctx.handle, a.ctypes.data, 1, 29, 0, 0))   # 2-adicity 28
 
 
+@pytest.mark.parametrize("log_n", [1, 3, 8, 12, 13])
+def test_bn254_ntt_on_a_coset_and_bit_reversed_output(nlx, ctx, bn, log_n):
+    """gnark-crypto's two FFT options: OnCoset (forward: evaluations on shift w^k, inverse: back) for the domain's generator 5
+    and for a random shift, in both element forms; fft.DIF's bit-reversed output"""
+    rng = random.Random(555 + log_n)
+    n = 1 << log_n
+    col = [rng.randrange(bn.R) for _ in range(n)]
+    rev = [int(format(i, "0%db" % log_n)[::-1], 2) for i in range(n)]
+    for shift in (5, rng.randrange(2, bn.R)):
+        want = bn.ntt([c * pow(shift, j, bn.R) % bn.R for j, c in enumerate(col)])
+        got = nlx.bn254_unpack(nlx.bn254_ntt(ctx, nlx.bn254_pack([col]), coset_shift=shift))[0]
+        assert got == want, (log_n, shift)
+        assert got == [bn.eval_poly(col, shift * pow(bn.root_of_unity(log_n), k, bn.R) % bn.R) for k in range(min(n, 3))] + got[3:]
+        back = nlx.bn254_unpack(nlx.bn254_ntt(ctx, nlx.bn254_pack([got]), inverse=True, coset_shift=shift))[0]
+        assert back == col
+        mont = [[bn.to_montgomery(x) for x in col]]
+        gm = nlx.bn254_unpack(nlx.bn254_ntt(ctx, nlx.bn254_pack(mont), montgomery=True, coset_shift=bn.to_montgomery(shift)))[0]
+        assert [bn.from_montgomery(x) for x in gm] == want
+        gb = nlx.bn254_unpack(nlx.bn254_ntt(ctx, nlx.bn254_pack([want]), inverse=True, coset_shift=shift, bitrev_out=True))[0]
+        assert [gb[rev[i]] for i in range(n)] == col
+    plain = bn.ntt(col)
+    gb = nlx.bn254_unpack(nlx.bn254_ntt(ctx, nlx.bn254_pack([col]), bitrev_out=True))[0]
+    assert [gb[rev[i]] for i in range(n)] == plain
+    assert nlx.lib.dll.nlx_bn254_ntt_batch_coset(ctx.handle, nlx.bn254_pack([col]).ctypes.data, 1, log_n, 0, 0, np.zeros(4, dtype=np.uint64).ctypes.data) < 0   # shift 0
+
+
 # ---- the G1 multi-scalar multiplication (row f.4's second piece, nlx_bn254_msm_g1) ----
 def _points(bn, count, seed):
     rng = random.Random(seed)
