@@ -215,8 +215,6 @@ int32_t nlx_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_
     }
     Staged s(ctx, cols, n_cols * n * 8, true, true);
     if (s.status) return s.status;
-    uint64_t* tmp = (uint64_t*)ctx->alloc(n_cols * n * 8);
-    if (!tmp) return NLX_E_NOMEM;
     // natural -> (DIF) -> bit-reversed -> permute back to natural.  Forward: pre-scale by
     // shift^i; inverse: post-scale by shift^-i (and 1/n inside the transform).
     // algorithmic bytes: 16 n per column for the transform (read + write once); the reordering back to
@@ -225,11 +223,16 @@ int32_t nlx_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_
     launch_ntt_dif_fwd(ctx->stream, ctx->tables, s.as<uint64_t>(), n, (uint32_t)n_cols, log_n, inverse != 0,
                        inverse ? nullptr : scale);
     ctx->end_kernel();
-    ctx->begin_kernel("ntt_reorder", 32.0 * n * n_cols);
-    launch_bitrev_permute(ctx->stream, s.as<uint64_t>(), tmp, n, (uint32_t)n_cols, log_n, inverse ? scale : nullptr);
-    hipError_t e = hipMemcpyAsync(s.dev, tmp, n_cols * n * 8, hipMemcpyDeviceToDevice, ctx->stream);
+    ctx->begin_kernel("ntt_reorder", 16.0 * n * n_cols);
+    hipError_t e = hipSuccess;
+    if (!launch_bitrev_inplace(ctx->stream, s.as<uint64_t>(), n, (uint32_t)n_cols, log_n, inverse ? scale : nullptr)) {
+        uint64_t* tmp = (uint64_t*)ctx->alloc(n_cols * n * 8);   // small transforms: gather into a second buffer, copy back
+        if (!tmp) { ctx->end_kernel(); return NLX_E_NOMEM; }
+        launch_bitrev_permute(ctx->stream, s.as<uint64_t>(), tmp, n, (uint32_t)n_cols, log_n, inverse ? scale : nullptr);
+        e = hipMemcpyAsync(s.dev, tmp, n_cols * n * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        ctx->release(tmp);
+    }
     ctx->end_kernel();
-    ctx->release(tmp);
     if (e != hipSuccess) return ctx->hip_fail(e, "hipMemcpyAsync");
     rc = s.finish();
     if (rc) return rc;

@@ -36,6 +36,8 @@ void launch_ntt_dif_fwd(hipStream_t st, const NttTables& tb, uint64_t* data, siz
                         unsigned log_n, bool inverse, const uint64_t* prescale_nat);
 void launch_bitrev_permute(hipStream_t st, const uint64_t* src, uint64_t* dst, size_t stride, uint32_t n_cols,
                            unsigned log_n, const uint64_t* postscale_nat);
+// in place and coalesced (tiles through LDS); false (nothing launched) below 2^12 points: use launch_bitrev_permute
+bool launch_bitrev_inplace(hipStream_t st, uint64_t* data, size_t stride, uint32_t n_cols, unsigned log_n, const uint64_t* postscale_nat);
 void launch_fill_coset_scale_br(hipStream_t st, uint64_t* d_table, unsigned log_n, unsigned rate_bits,
                                 uint64_t shift, bool inverse);
 void launch_intt_dif_cosets(hipStream_t st, const NttTables& tb, uint64_t* data, uint32_t n_y, unsigned log_n,
