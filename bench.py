@@ -1,27 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py - proofs/s of the MI355X-native prover on the SyncCircuit-shaped workload.
+"""bench.py - Sync proofs/s of the MI355X-native prover (and the secondary workloads of the same library).
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line from
 rank 0.  For N > 1 the driver launches it under torch.distributed.run (one rank per GPU, RCCL).
 
-Workload ("step" = one whole plonky2 proof through the C ABI, nlx_prove):
-  sync (default, BASELINE.json configs[1]): a synthetic circuit of SyncCircuit's static shape -
-    standard_recursion_config (135 wires / 80 routed, rate 8, cap height 4, 2 challenges,
-    28 FRI queries, 16 PoW bits), 2^16 rows, all nineteen gate kinds (GATE_MIXES below) with real copy
-    constraints and a satisfying witness
-    (the true row count of SyncCircuit is not recorded in the reference - SURVEY.md §7 - so
-    --log-n sweeps it).  Witness tables are resident in HBM before the timed region.
-  SyncCircuit does not shard: with N GPUs each rank proves its own independent
-  request ("replicas only"), scaling = weak, no data-path collective.
-  verify128 (--workload verify128): the VerifyCircuit 128x4 map-reduce job - 32 map proofs, a
-    binary reduce tree (16+8+4+2+1) and one outer proof, sharded over the ranks with an RCCL
-    all-gather of the children's digests between levels (scaling = strong).
+Workloads (--workload):
+  sync (default, BASELINE.json configs[1]): a "step" is ONE FULL SYNC PROOF - the SHA-256, SHA-512 and Ed25519 STARKs
+    of a real mainnet step (the reference's fixtures main_1 -> main_2; one Ed25519 slot per validator, active where the
+    block carries its approval; traces generated on the GPU inside the timed region) and the outer plonky2 proof that
+    verifies them: a synthetic circuit of SyncCircuit's static shape - standard_recursion_config (135 wires / 80 routed,
+    rate 8, cap height 4, 2 challenges, 28 FRI queries, 16 PoW bits), 2^18 rows (derived from the in-circuit cost of
+    verifying the three STARK proofs; --log-n), all nineteen gate kinds (GATE_MIXES below) with real copy
+    constraints, a satisfying witness resident in HBM, public inputs = the step's 64 real I/O bytes.
+    SyncCircuit does not shard: with N GPUs each rank proves its own independent request
+    ("replicas only"), scaling = weak, no data-path collective.
+  outer: the outer plonky2 proof alone (round 1's default), --log-n rows, --inflight proofs at a time.
+  verify128: the VerifyCircuit 128x4 map-reduce job - 32 map proofs, a binary reduce tree (16+8+4+2+1) and one outer
+    proof, sharded over the ranks with one all-gather of the children's (public output || proof) blobs per level
+    (scaling = strong).
+  stark / sha256 / sha512 / ed25519: one STARK proof per step (synthetic AIR; 2^k SHA-256 / SHA-512 blocks; 2^k Ed25519
+    slots), traces generated on the GPU.
+  ntt24 [--ntt-field bn254]: 16 columns x 2^24-point NTT (BASELINE.json configs[4]'s transform), over Goldilocks or BN254 Fr.
+  msm24: one BN254 G1 multi-scalar multiplication of 2^24 points (the recursive wrap's KZG commitment).
 
-roofline: the dominant kernel is the Poseidon leaf hashing of the LDE tables
-  (k_hash_lde_leaves); its algorithmic bytes per launch are 8*c*L + 32*L and its
-  average duration is measured live with HIP events on the launch stream.
-cpu_baseline: the CPU oracle (C port of the same algorithm, OpenMP over the host cores) timed
-  on a bounded sample (one proof at 2^(log_n-1) rows after a warm-up proof), scaled linearly in rows.
+roofline: the dominant kernel is the Poseidon leaf hashing of the LDE tables (k_hash_lde_leaves); its algorithmic bytes
+  per launch are 8*c*L + 32*L and its average duration is measured live with HIP events on the launch
+  stream; roofline_valu is the bound that binds (integer-VALU issue).
+cpu_baseline: the CPU oracle (C port of the same algorithm, OpenMP over the host cores) timed on a bounded sample of the
+  same step; the same leg proves the sampled inputs on the GPU and compares the bytes (parity_checked).
 """
 import argparse
 import json
