@@ -95,6 +95,8 @@ def parse():
     ap.add_argument("--gate-mix", default="nearx", choices=["nearx", "basic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ntt-log-n", type=int, default=24)
+    ap.add_argument("--ntt-order", default="natural", choices=["natural", "dif", "dit"],
+                    help="ntt24 --ntt-field bn254: natural order in and out (default), or gnark-crypto's fft.DIF (bit-reversed out) / fft.DIT (bit-reversed in) - no reordering pass")
     ap.add_argument("--ntt-cols", type=int, default=16)
     ap.add_argument("--ntt-field", default="goldilocks", choices=["goldilocks", "bn254"],
                     help="ntt24 workload: goldilocks (the prover's field) or bn254 (the scalar field of the recursive wrap, row f.4)")
@@ -1044,10 +1046,11 @@ def run_ntt24_bn254(args, nlx, torch, rank, world, local, dist):
     host = torch.randint(0, 2 ** 60, (max(len(mine), 1), n, 4), generator=g, dtype=torch.int64)   # top word < 2^60: values < r
     data = host.to("cuda:%d" % local)
     dll = nlx.lib.dll
+    order_flags = 1 | {"natural": 0, "dif": 2, "dit": 4}[args.ntt_order]   # fr.Element words; see nlx.h NLX_BN254_BITREV_*
 
     def step():
         if mine:
-            ctx.check(dll.nlx_bn254_ntt_batch(ctx.handle, data.data_ptr(), len(mine), log_n, 0, 1))
+            ctx.check(dll.nlx_bn254_ntt_batch_coset(ctx.handle, data.data_ptr(), len(mine), log_n, 0, order_flags, None))
     for _ in range(args.warmup):
         step()
     ctx.kernel_timing(True)
@@ -1070,7 +1073,7 @@ def run_ntt24_bn254(args, nlx, torch, rank, world, local, dist):
             "dtype": "u256 (BN254 scalar field, Montgomery form, integer)", "data": "synthetic",
             "config": {"workload": "forward NTT of %d columns x 2^%d points over BN254 Fr (fr.Element words in and out, natural order), "
                                    "resident in HBM, columns split over the ranks (no collective)" % (cols, log_n),
-                       "columns_per_rank": len(mine), "transform_ms_rank0": kt[1] / kt[0] if kt[0] else None,
+                       "columns_per_rank": len(mine), "order": args.ntt_order, "transform_ms_rank0": kt[1] / kt[0] if kt[0] else None,
                        "reorder_ms_rank0": kr[1] / kr[0] if kr[0] else None,
                        "montgomery_multiplications_per_second_rank0": muls / (kt[1] / kt[0] * 1e-3) if kt[0] else None,
                        "parallelism": "columns x%d" % world},

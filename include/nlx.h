@@ -135,9 +135,11 @@ int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_
 /* The same with gnark-crypto's two FFT options.  coset_shift != NULL (four words in the form of the data): the transform on
  * the coset shift * <w> - fft.OnCoset() with the domain's FrMultiplicativeGen: forward evaluates on shift w^k (coefficient j
  * is multiplied by shift^j first), inverse interpolates from there (coefficient j is multiplied by shift^-j last).
- * NLX_BN254_BITREV_OUT: skip the reordering pass - natural order in, bit-reversed order out, what fft.DIF leaves (the
- * caller pairs it with a transform that reads bit-reversed input, or reorders once at the end). */
+ * NLX_BN254_BITREV_OUT: natural order in, bit-reversed order out - what fft.DIF leaves; NLX_BN254_BITREV_IN: bit-reversed
+ * order in, natural order out - fft.DIT (decimation in time).  Neither has a reordering pass: a prover that alternates
+ * them (FFTInverse(DIF) -> pointwise work -> FFT(DIT, OnCoset)), as gnark's does, never reorders.  Not both at once. */
 #define NLX_BN254_BITREV_OUT 2u
+#define NLX_BN254_BITREV_IN 4u
 int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags,
                                   const uint64_t* coset_shift);
 /* ---- f.4 (second piece): the G1 multi-scalar multiplication of the wrap's KZG commitments (gnark-crypto ecc/bn254

@@ -181,11 +181,12 @@ def bn254_unpack(arr):
     return [[sum(int(a[c, i, w]) << (64 * w) for w in range(4)) for i in range(a.shape[1])] for c in range(a.shape[0])]
 
 
-def bn254_ntt(ctx, cols, inverse=False, montgomery=False, coset_shift=None, bitrev_out=False):
+def bn254_ntt(ctx, cols, inverse=False, montgomery=False, coset_shift=None, bitrev_out=False, bitrev_in=False):
     """gnark-crypto fft.Domain.FFT / FFTInverse over BN254's scalar field, natural order in and out.  cols: (n_cols, n, 4)
     uint64 (bn254_pack), canonical integers < r, or fr.Element Montgomery words with montgomery=True; or a device tensor of
     that shape (transformed in place and returned).  coset_shift (an integer < r in the form of the data): the transform on
-    the coset shift * <w> (fft.OnCoset()); bitrev_out: leave the output in bit-reversed order (fft.DIF)."""
+    the coset shift * <w> (fft.OnCoset()); bitrev_out: leave the output in bit-reversed order (fft.DIF); bitrev_in: the
+    input is in bit-reversed order (fft.DIT)."""
     if hasattr(cols, "data_ptr"):
         n_cols, n = cols.shape[0], cols.shape[1]
         c = cols
@@ -196,7 +197,7 @@ def bn254_ntt(ctx, cols, inverse=False, montgomery=False, coset_shift=None, bitr
     if 1 << log_n != n or c.shape[2] != 4:
         raise ValueError("shape must be (n_cols, 2^k, 4)")
     p = c.data_ptr() if hasattr(c, "data_ptr") else c.ctypes.data
-    flags = (1 if montgomery else 0) | (2 if bitrev_out else 0)
+    flags = (1 if montgomery else 0) | (2 if bitrev_out else 0) | (4 if bitrev_in else 0)
     shift = None
     if coset_shift is not None:
         shift = np.array([(int(coset_shift) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(4)], dtype=np.uint64)

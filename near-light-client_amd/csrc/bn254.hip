@@ -207,9 +207,11 @@ struct Scale {
     const Fr* lo;
     const Fr* hi;
     int on;
+    int rev_bits;   // > 0: the data is in bit-reversed order there - the power's exponent is the reversal of the position
 };
 __device__ __forceinline__ Fe scaled(const Fe& x, const Scale& sc, size_t e) {
     if (!sc.lo) return f29::mul<RM>(x, sc.k);
+    if (sc.rev_bits) e = __brevll(e) >> (64 - sc.rev_bits);
     Fe f = load29(sc.lo + (e & 4095u));
     if (e >> 12) f = f29::mul<RM>(f, load29(sc.hi + (e >> 12)));
     return f29::mul<RM>(x, f);
@@ -258,7 +260,8 @@ __device__ __forceinline__ void dif_level(Fe (&x)[R], size_t h_last, size_t off,
 // (h_last = the half-size of the last fused level), i.e. one butterfly network of the fused levels.
 template <int LEVELS>
 __global__ __launch_bounds__(256) void k_bn_dif(Fr* __restrict__ data, unsigned log_n, unsigned log_h_first,
-                                                const Fr* __restrict__ tw_lo, const Fr* __restrict__ tw_hi, uint32_t n_cols, InScale in) {
+                                                const Fr* __restrict__ tw_lo, const Fr* __restrict__ tw_hi, uint32_t n_cols, InScale in,
+                                                Scale out) {
     constexpr int R = 1 << LEVELS;
     const size_t n = (size_t)1 << log_n;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // butterfly-network index within a column
@@ -292,7 +295,10 @@ __global__ __launch_bounds__(256) void k_bn_dif(Fr* __restrict__ data, unsigned 
         dif_level<R, 1, true>(x, h_last, off, sh0, tw_lo, tw_hi);
     }
 #pragma unroll
-    for (int k = 0; k < R; k++) store29(base + (size_t)k * h_last, x[k]);
+    for (int k = 0; k < R; k++) {
+        if (out.on) x[k] = f29::canonical<RM>(scaled(x[k], out, e0 + (size_t)k * h_last));   // the last pass also leaves the kernels' form
+        store29(base + (size_t)k * h_last, x[k]);
+    }
 }
 
 // Three fused levels with the tile in eight NAMED registers (radix 8).
@@ -305,7 +311,8 @@ __global__ __launch_bounds__(256) void k_bn_dif(Fr* __restrict__ data, unsigned 
         B = e_ ? f29::mul<RM>(d_, twiddle(tw_lo, tw_hi, e_)) : f29::tighten<RM>(d_);      \
     }
 __global__ __launch_bounds__(256) void k_bn_dif3(Fr* __restrict__ data, unsigned log_n, unsigned log_h_first,
-                                                 const Fr* __restrict__ tw_lo, const Fr* __restrict__ tw_hi, uint32_t n_cols, InScale in) {
+                                                 const Fr* __restrict__ tw_lo, const Fr* __restrict__ tw_hi, uint32_t n_cols, InScale in,
+                                                 Scale out) {
     const size_t n = (size_t)1 << log_n;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per_col = n >> 3;
@@ -317,8 +324,8 @@ __global__ __launch_bounds__(256) void k_bn_dif3(Fr* __restrict__ data, unsigned
     Fr* base = data + col * n + (grp << (log_h_first + 1)) + off;
     Fe x0 = load29(base), x1 = load29(base + h), x2 = load29(base + 2 * h), x3 = load29(base + 3 * h), x4 = load29(base + 4 * h),
        x5 = load29(base + 5 * h), x6 = load29(base + 6 * h), x7 = load29(base + 7 * h);
+    const size_t e0 = (grp << (log_h_first + 1)) + off;   // index of x0 within its column
     if (in.on) {
-        const size_t e0 = (grp << (log_h_first + 1)) + off;   // index of x0 within its column
         x0 = scaled(x0, in, e0); x1 = scaled(x1, in, e0 + h); x2 = scaled(x2, in, e0 + 2 * h); x3 = scaled(x3, in, e0 + 3 * h);
         x4 = scaled(x4, in, e0 + 4 * h); x5 = scaled(x5, in, e0 + 5 * h); x6 = scaled(x6, in, e0 + 6 * h); x7 = scaled(x7, in, e0 + 7 * h);
     }
@@ -326,10 +333,71 @@ __global__ __launch_bounds__(256) void k_bn_dif3(Fr* __restrict__ data, unsigned
     BN_BF(x0, x4, off, s0, false) BN_BF(x1, x5, h + off, s0, false) BN_BF(x2, x6, 2 * h + off, s0, false) BN_BF(x3, x7, 3 * h + off, s0, false)
     BN_BF(x0, x2, off, s0 + 1, true) BN_BF(x1, x3, h + off, s0 + 1, true) BN_BF(x4, x6, off, s0 + 1, true) BN_BF(x5, x7, h + off, s0 + 1, true)
     BN_BF(x0, x1, off, s0 + 2, true) BN_BF(x2, x3, off, s0 + 2, true) BN_BF(x4, x5, off, s0 + 2, true) BN_BF(x6, x7, off, s0 + 2, true)
+    if (out.on) {   // the last pass also leaves the kernels' form
+        x0 = f29::canonical<RM>(scaled(x0, out, e0)); x1 = f29::canonical<RM>(scaled(x1, out, e0 + h));
+        x2 = f29::canonical<RM>(scaled(x2, out, e0 + 2 * h)); x3 = f29::canonical<RM>(scaled(x3, out, e0 + 3 * h));
+        x4 = f29::canonical<RM>(scaled(x4, out, e0 + 4 * h)); x5 = f29::canonical<RM>(scaled(x5, out, e0 + 5 * h));
+        x6 = f29::canonical<RM>(scaled(x6, out, e0 + 6 * h)); x7 = f29::canonical<RM>(scaled(x7, out, e0 + 7 * h));
+    }
     store29(base, x0); store29(base + h, x1); store29(base + 2 * h, x2); store29(base + 3 * h, x3);
     store29(base + 4 * h, x4); store29(base + 5 * h, x5); store29(base + 6 * h, x6); store29(base + 7 * h, x7);
 }
 #undef BN_BF
+
+// ---- decimation in time: bit-reversed order in, natural order out (gnark-crypto's fft.DIT).  Level with half-size h pairs
+// (i, i + h): a' = a + w b, b' = a - w b, w = w_{2h}^(i mod h); the half-sizes grow from 1 to n / 2, LEVELS per pass.  A
+// thread owns the 2^LEVELS elements base + k h0 (h0 = the half-size of the pass's first level).  Bounds: w b is a product
+// (< 2^255; for w = 1, b tightened), so with a + 4 r - w b a value grows by less than 2^255.6 per level: below 2^257.5
+// after three, inside what a product and `tighten` accept; every stored value is tightened. ----
+#define BN_BT(A, B, IDX, SH)                                                              \
+    {                                                                                     \
+        const uint32_t e_ = (uint32_t)(IDX) << (SH);                                      \
+        const Fe a_ = A;                                                                  \
+        const Fe t_ = e_ ? f29::mul<RM>(B, twiddle(tw_lo, tw_hi, e_)) : f29::tighten<RM>(B); \
+        A = f29::add(a_, t_);                                                             \
+        B = f29::sub<4, RM>(a_, t_);                                                      \
+    }
+template <int LEVELS>
+__global__ __launch_bounds__(256) void k_bn_dit(Fr* __restrict__ data, unsigned log_n, unsigned log_h0,
+                                                const Fr* __restrict__ tw_lo, const Fr* __restrict__ tw_hi, uint32_t n_cols, InScale in,
+                                                Scale out) {
+    const size_t n = (size_t)1 << log_n;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per_col = n >> LEVELS;
+    if (t >= per_col * n_cols) return;
+    const size_t col = t / per_col, u = t % per_col;
+    const size_t h = (size_t)1 << log_h0;
+    const size_t off = u & (h - 1), grp = u >> log_h0;
+    const size_t e0 = (grp << (log_h0 + LEVELS)) + off;   // index of x0 within its column
+    Fr* base = data + col * n + e0;
+    const unsigned s0 = log_n - 1 - log_h0;
+    Fe x0 = load29(base), x1 = load29(base + h), x2, x3, x4, x5, x6, x7;
+    if constexpr (LEVELS >= 2) { x2 = load29(base + 2 * h); x3 = load29(base + 3 * h); }
+    if constexpr (LEVELS >= 3) { x4 = load29(base + 4 * h); x5 = load29(base + 5 * h); x6 = load29(base + 6 * h); x7 = load29(base + 7 * h); }
+    if (in.on) {
+        x0 = scaled(x0, in, e0); x1 = scaled(x1, in, e0 + h);
+        if constexpr (LEVELS >= 2) { x2 = scaled(x2, in, e0 + 2 * h); x3 = scaled(x3, in, e0 + 3 * h); }
+        if constexpr (LEVELS >= 3) { x4 = scaled(x4, in, e0 + 4 * h); x5 = scaled(x5, in, e0 + 5 * h); x6 = scaled(x6, in, e0 + 6 * h); x7 = scaled(x7, in, e0 + 7 * h); }
+    }
+    BN_BT(x0, x1, off, s0)
+    if constexpr (LEVELS >= 2) {
+        BN_BT(x2, x3, off, s0)
+        BN_BT(x0, x2, off, s0 - 1) BN_BT(x1, x3, h + off, s0 - 1)
+    }
+    if constexpr (LEVELS >= 3) {
+        BN_BT(x4, x5, off, s0) BN_BT(x6, x7, off, s0)
+        BN_BT(x4, x6, off, s0 - 1) BN_BT(x5, x7, h + off, s0 - 1)
+        BN_BT(x0, x4, off, s0 - 2) BN_BT(x1, x5, h + off, s0 - 2) BN_BT(x2, x6, 2 * h + off, s0 - 2) BN_BT(x3, x7, 3 * h + off, s0 - 2)
+    }
+    auto fin = [&](const Fe& x, size_t e) { return out.on ? f29::canonical<RM>(scaled(x, out, e)) : f29::tighten<RM>(x); };
+    store29(base, fin(x0, e0)); store29(base + h, fin(x1, e0 + h));
+    if constexpr (LEVELS >= 2) { store29(base + 2 * h, fin(x2, e0 + 2 * h)); store29(base + 3 * h, fin(x3, e0 + 3 * h)); }
+    if constexpr (LEVELS >= 3) {
+        store29(base + 4 * h, fin(x4, e0 + 4 * h)); store29(base + 5 * h, fin(x5, e0 + 5 * h));
+        store29(base + 6 * h, fin(x6, e0 + 6 * h)); store29(base + 7 * h, fin(x7, e0 + 7 * h));
+    }
+}
+#undef BN_BT
 
 // data[bitrev(i)] <- data[i] * k, canonical, IN PLACE: the thread of the smaller index of each pair (i, bitrev(i)) swaps the
 // two (the bit-reversal back to natural order, fused with the product that takes the kernels' form back to the caller's -
@@ -384,17 +452,6 @@ __global__ __launch_bounds__(256) void k_bn_bitrev_tiled(Fr* __restrict__ data, 
     }
 }
 
-// The same product without the reordering (flag NLX_BN254_BITREV_OUT: gnark-crypto's fft.DIF leaves its output like this):
-// position p keeps natural index bitrev(p).
-__global__ __launch_bounds__(256) void k_bn_scale_out(Fr* __restrict__ data, unsigned log_n, uint32_t n_cols, Scale k) {
-    const size_t n = (size_t)1 << log_n;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * n_cols) return;
-    const size_t i = t & (n - 1);
-    const size_t j = log_n ? (__brevll(i) >> (64 - log_n)) : 0;
-    store29(data + t, f29::canonical<RM>(scaled(load29(data + t), k, j)));
-}
-
 }  // namespace bn
 }  // namespace nlx
 
@@ -409,7 +466,8 @@ int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, u
     if (n_cols == 0) return NLX_OK;
     if (!cols) return ctx->fail(NLX_E_INVAL, "cols is NULL");
     if (log_n > 28) return ctx->fail(NLX_E_RANGE, "BN254 Fr has 2-adicity 28");
-    if (n_cols > 65535 || (flags & ~(NLX_BN254_MONTGOMERY | NLX_BN254_BITREV_OUT))) return ctx->fail(NLX_E_RANGE, "n_cols > 65535 or unknown flag");
+    if (n_cols > 65535 || (flags & ~(NLX_BN254_MONTGOMERY | NLX_BN254_BITREV_OUT | NLX_BN254_BITREV_IN))) return ctx->fail(NLX_E_RANGE, "n_cols > 65535 or unknown flag");
+    if ((flags & NLX_BN254_BITREV_OUT) && (flags & NLX_BN254_BITREV_IN)) return ctx->fail(NLX_E_UNSUPPORTED, "bit-reversed order on both sides: no decimation produces it");
     if (log_n == 0) return NLX_OK;   // the transform of one point is that point, on any coset
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
@@ -497,23 +555,10 @@ int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, u
         const int32_t prc = power_table(shift_mont, c_in, first);
         if (prc) { if (d_pow) ctx->release(d_pow); return prc; }
     }
-    int lvl = (int)log_n - 1;  // log2 of the current level's half-size
-    bool is_first = true;
-    while (lvl >= 0) {
-        const int take = lvl >= 2 ? 3 : lvl + 1;
-        const size_t nets = (n >> take) * n_cols;
-        const unsigned blocks = (unsigned)((nets + 255) / 256);
-        const bn::InScale in = is_first ? first : none;
-        if (take == 3) hipLaunchKernelGGL(bn::k_bn_dif3, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols, in);
-        else if (take == 2) hipLaunchKernelGGL(bn::k_bn_dif<2>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols, in);
-        else hipLaunchKernelGGL(bn::k_bn_dif<1>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols, in);
-        is_first = false;
-        lvl -= take;
-    }
-    ctx->end_kernel();
-    // back to natural order, fused with the product that leaves the kernels' form: an element is y 2^261, and y 2^261 c / 2^261
-    // = y c, so c is the PLAIN integer (2^256 if the caller wants fr.Element words) (1/n if inverse) mod r.  The eight-limb
-    // Montgomery form of z is the plain integer z 2^256 mod r, which the host code below produces directly.
+    // the product that leaves the kernels' form: an element is y 2^261, and y 2^261 c / 2^261 = y c, so c is the PLAIN integer
+    // (2^256 if the caller wants fr.Element words) (1/n if inverse) mod r.  The eight-limb Montgomery form of z is the plain
+    // integer z 2^256 mod r, which the host code below produces directly.  It rides on the reordering pass, or - when there
+    // is none (bit-reversed output, or the decimation in time) - on the last transform pass.
     Fr c = bn::from_limbs(bn::H_ONE);                        // plain 2^256 mod r
     if (inverse) {
         Fr nn{};
@@ -532,11 +577,48 @@ int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, u
         const int32_t prc = power_table(bn::h_inv(shift_mont), c, last);
         if (prc) { if (d_pow) ctx->release(d_pow); return prc; }
     }
-    ctx->begin_kernel("bn254_ntt_reorder", 64.0 * count);
-    if (flags & NLX_BN254_BITREV_OUT) hipLaunchKernelGGL(bn::k_bn_scale_out, dim3(blocks1), dim3(256), 0, st, d, log_n, (uint32_t)n_cols, last);
-    else if (log_n >= 2 * bn::BR_K) hipLaunchKernelGGL(bn::k_bn_bitrev_tiled, dim3(1u << (log_n - 2 * bn::BR_K), (unsigned)n_cols), dim3(256), 0, st, d, log_n, last);
-    else hipLaunchKernelGGL(bn::k_bn_bitrev, dim3(blocks1), dim3(256), 0, st, d, log_n, (uint32_t)n_cols, last);
+    const bool dit = flags & NLX_BN254_BITREV_IN, rev_out = flags & NLX_BN254_BITREV_OUT;
+    first.rev_bits = dit ? (int)log_n : 0;    // where the input is bit-reversed, position p holds coefficient bitrev(p)
+    last.rev_bits = rev_out ? (int)log_n : 0;
+    const bool fused_out = dit || rev_out;
+    if (!dit) {
+        // decimation in frequency: half-sizes n/2 down to 1, three levels per pass while they last
+        int lvl = (int)log_n - 1;  // log2 of the current level's half-size
+        bool is_first = true;
+        while (lvl >= 0) {
+            const int take = lvl >= 2 ? 3 : lvl + 1;
+            const size_t nets = (n >> take) * n_cols;
+            const unsigned blocks = (unsigned)((nets + 255) / 256);
+            const bn::InScale in = is_first ? first : none;
+            const bn::Scale out = (fused_out && lvl - take < 0) ? last : none;
+            if (take == 3) hipLaunchKernelGGL(bn::k_bn_dif3, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols, in, out);
+            else if (take == 2) hipLaunchKernelGGL(bn::k_bn_dif<2>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols, in, out);
+            else hipLaunchKernelGGL(bn::k_bn_dif<1>, dim3(blocks), dim3(256), 0, st, d, log_n, (unsigned)lvl, tb.d_lo, tb.d_hi, (uint32_t)n_cols, in, out);
+            is_first = false;
+            lvl -= take;
+        }
+    } else {
+        // decimation in time: half-sizes 1 up to n/2; the short pass (log_n mod 3 levels) goes first
+        unsigned lh = 0;
+        while (lh < log_n) {
+            const unsigned take = (lh == 0 && log_n % 3) ? log_n % 3 : 3;
+            const size_t nets = (n >> take) * n_cols;
+            const unsigned blocks = (unsigned)((nets + 255) / 256);
+            const bn::InScale in = lh == 0 ? first : none;
+            const bn::Scale out = lh + take >= log_n ? last : none;
+            if (take == 3) hipLaunchKernelGGL(bn::k_bn_dit<3>, dim3(blocks), dim3(256), 0, st, d, log_n, lh, tb.d_lo, tb.d_hi, (uint32_t)n_cols, in, out);
+            else if (take == 2) hipLaunchKernelGGL(bn::k_bn_dit<2>, dim3(blocks), dim3(256), 0, st, d, log_n, lh, tb.d_lo, tb.d_hi, (uint32_t)n_cols, in, out);
+            else hipLaunchKernelGGL(bn::k_bn_dit<1>, dim3(blocks), dim3(256), 0, st, d, log_n, lh, tb.d_lo, tb.d_hi, (uint32_t)n_cols, in, out);
+            lh += take;
+        }
+    }
     ctx->end_kernel();
+    if (!fused_out) {   // back to natural order, with the product that leaves the kernels' form
+        ctx->begin_kernel("bn254_ntt_reorder", 64.0 * count);
+        if (log_n >= 2 * bn::BR_K) hipLaunchKernelGGL(bn::k_bn_bitrev_tiled, dim3(1u << (log_n - 2 * bn::BR_K), (unsigned)n_cols), dim3(256), 0, st, d, log_n, last);
+        else hipLaunchKernelGGL(bn::k_bn_bitrev, dim3(blocks1), dim3(256), 0, st, d, log_n, (uint32_t)n_cols, last);
+        ctx->end_kernel();
+    }
     int32_t rc = s.finish();
     hipError_t es = hipStreamSynchronize(st);
     if (d_pow) ctx->release(d_pow);

@@ -84,6 +84,22 @@ def test_bn254_ntt_on_a_coset_and_bit_reversed_output(nlx, ctx, bn, log_n):
     plain = bn.ntt(col)
     gb = nlx.bn254_unpack(nlx.bn254_ntt(ctx, nlx.bn254_pack([col]), bitrev_out=True))[0]
     assert [gb[rev[i]] for i in range(n)] == plain
+    # fft.DIT: bit-reversed order in, natural order out - forward, inverse, on a coset, Montgomery words; and gnark's prover
+    # pattern FFTInverse(DIF) -> FFT(DIT, OnCoset) without a reordering in between
+    col_br = [col[rev[i]] for i in range(n)]
+    assert nlx.bn254_unpack(nlx.bn254_ntt(ctx, nlx.bn254_pack([col_br]), bitrev_in=True))[0] == plain
+    plain_br = [plain[rev[i]] for i in range(n)]
+    assert nlx.bn254_unpack(nlx.bn254_ntt(ctx, nlx.bn254_pack([plain_br]), inverse=True, bitrev_in=True))[0] == col
+    on5 = bn.ntt([c * pow(5, j, bn.R) % bn.R for j, c in enumerate(col)])
+    assert nlx.bn254_unpack(nlx.bn254_ntt(ctx, nlx.bn254_pack([col_br]), bitrev_in=True, coset_shift=5))[0] == on5
+    on5_br = [on5[rev[i]] for i in range(n)]
+    assert nlx.bn254_unpack(nlx.bn254_ntt(ctx, nlx.bn254_pack([on5_br]), inverse=True, bitrev_in=True, coset_shift=5))[0] == col
+    mont_br = [[bn.to_montgomery(x) for x in col_br]]
+    gm = nlx.bn254_unpack(nlx.bn254_ntt(ctx, nlx.bn254_pack(mont_br), montgomery=True, bitrev_in=True, coset_shift=bn.to_montgomery(5)))[0]
+    assert [bn.from_montgomery(x) for x in gm] == on5
+    coeffs_br = nlx.bn254_ntt(ctx, nlx.bn254_pack([plain]), inverse=True, bitrev_out=True)     # values -> coefficients, bit-reversed
+    assert nlx.bn254_unpack(nlx.bn254_ntt(ctx, coeffs_br, bitrev_in=True, coset_shift=5))[0] == on5
+    assert nlx.lib.dll.nlx_bn254_ntt_batch_coset(ctx.handle, nlx.bn254_pack([col]).ctypes.data, 1, log_n, 0, 6, None) < 0      # both orders reversed
     assert nlx.lib.dll.nlx_bn254_ntt_batch_coset(ctx.handle, nlx.bn254_pack([col]).ctypes.data, 1, log_n, 0, 0, np.zeros(4, dtype=np.uint64).ctypes.data) < 0   # shift 0
 
 
