@@ -95,6 +95,8 @@ def parse():
     ap.add_argument("--gate-mix", default="nearx", choices=["nearx", "basic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ntt-log-n", type=int, default=24)
+    ap.add_argument("--ntt-split", action="store_true", help="ntt24 with N > 1 ranks: split every ONE transform over the ranks (contiguous slices, "
+                    "log2 N pairwise slice exchanges) instead of dealing whole columns out")
     ap.add_argument("--ntt-order", default="natural", choices=["natural", "dif", "dit"],
                     help="ntt24 --ntt-field bn254: natural order in and out (default), or gnark-crypto's fft.DIF (bit-reversed out) / fft.DIT (bit-reversed in) - no reordering pass")
     ap.add_argument("--ntt-cols", type=int, default=16)
@@ -974,6 +976,8 @@ def run_ntt24(args, nlx, torch, rank, world, local, dist):
     if args.ntt_field == "bn254":
         return run_ntt24_bn254(args, nlx, torch, rank, world, local, dist)
     log_n, cols = args.ntt_log_n, args.ntt_cols
+    if args.ntt_split and world > 1:
+        return run_ntt24_split(args, nlx, torch, rank, world, local, dist)
     mine = [c for c in range(cols) if c % world == rank]
     n = 1 << log_n
     ctx = nlx.Context(local)
@@ -996,6 +1000,12 @@ def run_ntt24(args, nlx, torch, rank, world, local, dist):
     dt = reduce_max(dist, torch, time.perf_counter() - t0)
     kt, kr = ctx.kernel_stats("ntt_transform"), ctx.kernel_stats("ntt_reorder")
     ctx.kernel_timing(False)
+    digest = None
+    if world == 1 and log_n <= 20:     # one transform of the untouched input, hashed: what --ntt-split's reassembled result must equal
+        import hashlib
+        once = host.to(data.device)
+        ctx.check(dll.nlx_ntt_batch(ctx.handle, once.data_ptr(), cols, log_n, 0, 1))
+        digest = hashlib.sha256(once.cpu().numpy().tobytes()).hexdigest()
     out = None
     if rank == 0:
         alg = 16.0 * n * cols          # one read + one write of every element
@@ -1005,7 +1015,8 @@ def run_ntt24(args, nlx, torch, rank, world, local, dist):
             "value": args.steps / dt, "unit": "batch NTTs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
-            "config": {"workload": "forward NTT of %d columns x 2^%d points (natural order in and out), columns resident in HBM, "
+            "config": {"result_sha256": digest,
+                       "workload": "forward NTT of %d columns x 2^%d points (natural order in and out), columns resident in HBM, "
                                    "split over the ranks (no collective)" % (cols, log_n),
                        "columns_per_rank": len(mine), "whole_call_GBps_algorithmic": alg / (dt / args.steps) / 1e9,
                        "transform_ms_rank0": kt[1] / kt[0] if kt[0] else None, "reorder_ms_rank0": kr[1] / kr[0] if kr[0] else None,
@@ -1032,6 +1043,56 @@ def run_ntt24(args, nlx, torch, rank, world, local, dist):
                                    "n log n and the %d columns; GPU output of the same column equal: %s" % (s_log, dtc, cols, bool(np.array_equal(ref, got)))}
     ctx.close()
     return out
+
+
+def run_ntt24_split(args, nlx, torch, rank, world, local, dist):
+    """--workload ntt24 --ntt-split with N > 1 ranks (BASELINE.json configs[4] "split over GPUs"): every column's
+    ONE 2^--ntt-log-n-point transform is split over the ranks - contiguous slices, log2 N pairwise exchanges of the slice over
+    RCCL send / recv, then an independent transform per rank (near-light-client_amd/split_ntt.py).  Strong scaling of one
+    transform; link-bound by construction.  At <= 2^20 points the reassembled result is hashed for comparison with the
+    one-rank run."""
+    import hashlib
+    import numpy as np
+    log_n, cols = args.ntt_log_n, args.ntt_cols
+    n, m = 1 << log_n, (1 << log_n) // world
+    ctx = nlx.Context(local)
+    g = torch.Generator(device="cpu").manual_seed(0x6E6C78)     # the whole batch is the same for every world size
+    host = torch.randint(0, 2 ** 62, (cols, n), generator=g, dtype=torch.int64)
+    start = host[:, rank * m:(rank + 1) * m].contiguous().to("cuda:%d" % local)
+    data = torch.empty_like(start)
+    S = nlx.split_ntt
+
+    def step():
+        data.copy_(start)
+        torch.cuda.synchronize()
+        return S.split_ntt(ctx, data, log_n, rank, world, dist)
+    for _ in range(args.warmup):
+        step()
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(dist, torch)
+    dt = reduce_max(dist, torch, time.perf_counter() - t0)
+    digest = None
+    if log_n <= 20:
+        full = S.gather_natural(data, rank, world, dist)
+        digest = hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest()
+    ctx.close()
+    if rank != 0:
+        return None
+    return {
+        "metric": "Goldilocks NTT 2^%d x %d columns, every transform split over the ranks: transforms of the whole batch per second" % (log_n, cols),
+        "value": args.steps / dt, "unit": "batch NTTs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64 (Goldilocks field, integer)", "data": "synthetic",
+        "config": {"workload": "forward NTT of %d columns x 2^%d points, each transform split over %d ranks (contiguous slices, %d pairwise "
+                               "slice exchanges, then 2^%d-point transforms per rank); output: rank r holds X[k], k = bitrev(r) mod %d"
+                               % (cols, log_n, world, world.bit_length() - 1, log_n - world.bit_length() + 1, world),
+                   "slice_bytes_per_rank": cols * m * 8, "bytes_sent_per_rank_per_step": cols * m * 8 * (world.bit_length() - 1),
+                   "result_sha256": digest, "parallelism": "one transform x%d" % world},
+        "roofline": None, "cpu_baseline": None,
+    }
 
 
 def run_ntt24_bn254(args, nlx, torch, rank, world, local, dist):

@@ -124,6 +124,16 @@ int32_t nlx_merkle_build(nlx_ctx* ctx, const uint64_t* leaves, size_t n_leaves, 
 int32_t nlx_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse,
                       uint64_t coset_shift);
 
+/* cfg5 / SURVEY 8e: ONE forward transform of 2^log_n points per column split over G = 2^world_log GPUs.  Rank r holds the
+ * contiguous slice [r m, (r + 1) m), m = 2^log_n / G, of every column (n_cols x m, column-major, device memory).  The first
+ * world_log levels of a decimation in frequency pair element j with j + n / 2^(level + 1) - on another rank: for level =
+ * 0 .. world_log - 1 the caller exchanges slices with rank r XOR (G >> (level + 1)) (RCCL send / recv) and this call computes
+ * the rank's half of the level in place on `mine` from the partner's slice `theirs`.  After the last cross level every slice
+ * is an independent transform of m points: nlx_ntt_batch(mine, n_cols, log_n - world_log, 0, 1) leaves rank r holding
+ * X[k] for k = bitrev_G(r) (mod G) at local index k div G.  (near-light-client_amd/split_ntt.py drives it.) */
+int32_t nlx_ntt_split_level(nlx_ctx* ctx, uint64_t* mine, const uint64_t* theirs, size_t n_cols, uint32_t log_n, uint32_t world_log,
+                            uint32_t rank, uint32_t level);
+
 /* ---- f.4 (first piece): the BN254 scalar-field NTT of the recursive wrap (gnark-crypto ecc/bn254/fr/fft Domain.FFT /
  * FFTInverse; the wrap itself is not in /root/reference - succinct.json:7-8 names the entry point that can run it).
  * cols: n_cols x 2^log_n elements, column-major, transformed in place, natural order in and out; an element is 32 bytes =

@@ -69,6 +69,8 @@ SIGNATURES = {
                                           ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_ntt_batch": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
                                        ctypes.c_int, ctypes.c_uint64]),
+    "nlx_ntt_split_level": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32,
+                                              ctypes.c_uint32, ctypes.c_uint32]),
     "nlx_bn254_ntt_batch": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int,
                                               ctypes.c_uint32]),
     "nlx_bn254_ntt_batch_coset": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int,

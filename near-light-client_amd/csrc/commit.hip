@@ -240,6 +240,28 @@ int32_t nlx_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_
     return NLX_OK;
 }
 
+int32_t nlx_ntt_split_level(nlx_ctx* ctx, uint64_t* mine, const uint64_t* theirs, size_t n_cols, uint32_t log_n, uint32_t world_log,
+                            uint32_t rank, uint32_t level) {
+    if (!ctx) return NLX_E_INVAL;
+    if (n_cols == 0) return NLX_OK;
+    if (!mine || !theirs) return ctx->fail(NLX_E_INVAL, "NULL slice");
+    if (log_n > 32 || world_log == 0 || world_log > 6 || world_log >= log_n || level >= world_log || (rank >> world_log) || n_cols > 65535)
+        return ctx->fail(NLX_E_RANGE, "log_n %u, 2^%u ranks, rank %u, level %u: out of range", log_n, world_log, rank, level);
+    if (!is_device_ptr(mine) || !is_device_ptr(theirs)) return ctx->fail(NLX_E_INVAL, "the slices must be device memory");
+    (void)hipSetDevice(ctx->device);
+    int32_t rc = ctx->ensure_tables(log_n);
+    if (rc) return rc;
+    const size_t m = (size_t)1 << (log_n - world_log);
+    const uint32_t bit = world_log - 1 - level;                 // the bit of the rank this level pairs over
+    const bool upper = (rank >> bit) & 1;
+    const size_t idx0 = (size_t)(rank & ((1u << bit) - 1)) * m;   // offset of the slice inside the half-block of n / 2^(level + 1)
+    launch_ntt_split_level(ctx->stream, mine, theirs, m, (uint32_t)n_cols, upper, ctx->tables.fwd[log_n], idx0, level);
+    NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return ctx->hip_fail(le, "kernel launch");
+    return NLX_OK;
+}
+
 static int32_t commit_api(nlx_ctx* ctx, const uint64_t* data, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
                           uint32_t cap_height, uint64_t* cap_out, nlx_commit** out, CommitInput kind) {
     if (!ctx) return NLX_E_INVAL;

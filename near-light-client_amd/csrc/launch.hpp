@@ -42,6 +42,8 @@ void launch_fill_coset_scale_br(hipStream_t st, uint64_t* d_table, unsigned log_
                                 uint64_t shift, bool inverse);
 void launch_intt_dif_cosets(hipStream_t st, const NttTables& tb, uint64_t* data, uint32_t n_y, unsigned log_n,
                             unsigned rate_bits, const uint64_t* post_scale_br);
+void launch_ntt_split_level(hipStream_t st, uint64_t* mine, const uint64_t* theirs, size_t m, uint32_t n_cols, bool upper,
+                            const uint64_t* w_n_table, size_t idx0, unsigned level);
 void launch_fill_powers(hipStream_t st, uint64_t* d_table, size_t count, uint64_t base, uint64_t first);
 
 }  // namespace nlx

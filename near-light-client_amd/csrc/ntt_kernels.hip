@@ -510,6 +510,25 @@ bool launch_bitrev_inplace(hipStream_t st, uint64_t* data, size_t stride, uint32
     return true;
 }
 
+// One cross-rank level of a decimation in frequency whose input is split over several GPUs (nlx_ntt_split_level): this
+// rank's slice against its partner's.  Lower partner: a' = a + b (a = mine, b = theirs).  Upper partner: b' = (a - b) w,
+// a = theirs, b = mine, w = w_n^(idx0 + q) 2^level read from the size-n table (idx0 = the slice's offset inside the level's
+// half-block).
+__global__ __launch_bounds__(256) void k_ntt_split_level(uint64_t* __restrict__ mine, const uint64_t* __restrict__ theirs, size_t m,
+                                                         int upper, const uint64_t* __restrict__ w_n_table, size_t idx0, unsigned level) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const size_t at = (size_t)blockIdx.y * m + q;
+    const uint64_t x = mine[at], y = theirs[at];
+    mine[at] = upper ? gl::mul(gl::sub(y, x), w_n_table[(idx0 + q) << level]) : gl::add(x, y);
+}
+void launch_ntt_split_level(hipStream_t st, uint64_t* mine, const uint64_t* theirs, size_t m, uint32_t n_cols, bool upper,
+                            const uint64_t* w_n_table, size_t idx0, unsigned level) {
+    if (!n_cols || !m) return;
+    hipLaunchKernelGGL(k_ntt_split_level, dim3((unsigned)((m + 255) / 256), n_cols), dim3(256), 0, st, mine, theirs, m, upper ? 1 : 0,
+                       w_n_table, idx0, level);
+}
+
 // table[e] = root^e for e in [0, 2^log_size)
 __global__ void k_fill_powers(uint64_t* __restrict__ table, size_t count, uint64_t base, uint64_t first) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

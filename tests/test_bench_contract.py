@@ -119,6 +119,18 @@ def test_msm_split_over_two_ranks_joins_to_the_one_rank_result():
 
 
 @pytest.mark.gpu
+def test_one_ntt_split_over_two_ranks_equals_the_one_rank_transform():
+    """--workload ntt24 --ntt-split (BASELINE.json configs[4] "split over GPUs"): every 2^16-point transform split over two ranks
+    (rehearsal: both on GPU 0, gloo) - one slice exchange, one cross-rank butterfly level, a 2^15-point transform per rank -
+    reassembles to the one-rank result"""
+    args = ("--workload", "ntt24", "--ntt-log-n", "16", "--ntt-cols", "3")
+    two = _launch_two_ranks(args + ("--ntt-split",), {"NLX_BENCH_REHEARSAL": "1"}, 29644)
+    one = run_bench(*args, "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert two["scaling"] == "strong" and two["config"]["bytes_sent_per_rank_per_step"] == 3 * (1 << 15) * 8
+    assert two["config"]["result_sha256"] == one["config"]["result_sha256"] and one["config"]["result_sha256"] is not None
+
+
+@pytest.mark.gpu
 def test_two_ranks_over_rccl():
     """the real N = 2 path (backend nccl = RCCL, one rank per GPU): runs where two GPUs are visible, skipped on a one-GPU box"""
     import torch

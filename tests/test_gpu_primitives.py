@@ -279,3 +279,19 @@ def test_stream_priority_and_cu_mask_keep_results(nlx, orc):
     with pytest.raises(nlx.NlxError):
         c.set_cu_mask([])                    # a mask that selects no compute unit
     c.close()
+
+
+@pytest.mark.parametrize("world,log_n", [(2, 13), (4, 14)])
+def test_one_ntt_split_over_ranks(world, log_n):
+    """cfg5 / SURVEY 8e: ONE transform split over 2 and 4 ranks (one and two cross-rank levels; all ranks on this GPU over
+    gloo - the send / recv pattern, the cross-level kernel and the cyclic output distribution are those of the RCCL run):
+    the reassembled result equals the transform done by a single context"""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29650 + world), os.path.join(ROOT, "tests", "tools", "split_ntt_ranks.py"), str(log_n), "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0 and "equals one transform: True" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
