@@ -25,28 +25,44 @@ def _exchange(dist, mine, partner):
     gloo = dist.get_backend() == "gloo"
     send = mine.cpu() if gloo else mine
     recv = torch.empty_like(send)
-    ops = [dist.P2POp(dist.isend, send, partner), dist.P2POp(dist.irecv, recv, partner)]
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
+    if gloo:   # plain send / recv, the lower rank sending first (gloo has no batched point-to-point)
+        if dist.get_rank() < partner:
+            dist.send(send, partner)
+            dist.recv(recv, partner)
+        else:
+            dist.recv(recv, partner)
+            dist.send(send, partner)
+    else:
+        ops = [dist.P2POp(dist.isend, send, partner), dist.P2POp(dist.irecv, recv, partner)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
     return recv.to(mine.device) if gloo else recv
 
 
-def split_ntt(ctx, mine, log_n, rank, world, dist):
+def split_ntt(ctx, mine, log_n, rank, world, dist, level_fn=None, local_fn=None):
     """mine: (n_cols, 2^log_n / world) int64 device tensor, this rank's slice of every column (overwritten).  Forward NTT of
-    the whole columns; returns `mine`: X[k] for k = bitrev_G(rank) (mod G), local index k div G."""
-    import torch
+    the whole columns; returns `mine`: X[k] for k = bitrev_G(rank) (mod G), local index k div G.
+    level_fn(mine, theirs, level) / local_fn(mine): the two compute steps, by default the library's kernels on `ctx`
+    (nlx_ntt_split_level, nlx_ntt_batch); the CPU tests of the exchange pattern pass their own."""
     world_log = world.bit_length() - 1
     if world != 1 << world_log:
         raise ValueError("the number of ranks must be a power of two")
     n_cols, m = mine.shape
     if m << world_log != 1 << log_n or not mine.is_contiguous():
         raise ValueError("slice shape")
+    if level_fn is None:
+        def level_fn(mine_, theirs_, level_):
+            import torch
+            torch.cuda.current_stream(mine_.device).synchronize()
+            ctx.check(dll.nlx_ntt_split_level(ctx.handle, mine_.data_ptr(), theirs_.data_ptr(), n_cols, log_n, world_log, rank, level_))
+    if local_fn is None:
+        def local_fn(mine_):
+            ctx.check(dll.nlx_ntt_batch(ctx.handle, mine_.data_ptr(), n_cols, log_n - world_log, 0, 1))
     for level in range(world_log):
         partner = rank ^ (world >> (level + 1))
         theirs = _exchange(dist, mine, partner)
-        torch.cuda.current_stream(mine.device).synchronize()
-        ctx.check(dll.nlx_ntt_split_level(ctx.handle, mine.data_ptr(), theirs.data_ptr(), n_cols, log_n, world_log, rank, level))
-    ctx.check(dll.nlx_ntt_batch(ctx.handle, mine.data_ptr(), n_cols, log_n - world_log, 0, 1))
+        level_fn(mine, theirs, level)
+    local_fn(mine)
     return mine
 
 
