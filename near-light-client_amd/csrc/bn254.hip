@@ -310,7 +310,10 @@ __global__ __launch_bounds__(256) void k_bn_dif(Fr* __restrict__ data, unsigned 
         const Fe d_ = f29::sub<8, RM>(a_, b_);                                            \
         B = e_ ? f29::mul<RM>(d_, twiddle(tw_lo, tw_hi, e_)) : f29::tighten<RM>(d_);      \
     }
-__global__ __launch_bounds__(256) void k_bn_dif3(Fr* __restrict__ data, unsigned log_n, unsigned log_h_first,
+#ifndef NLX_BN_MINW
+#define NLX_BN_MINW 2   // waves per SIMD the radix-8 kernels' register allocation must allow (tuning builds: NLX_EXTRA_FLAGS)
+#endif
+__global__ __launch_bounds__(256, NLX_BN_MINW) void k_bn_dif3(Fr* __restrict__ data, unsigned log_n, unsigned log_h_first,
                                                  const Fr* __restrict__ tw_lo, const Fr* __restrict__ tw_hi, uint32_t n_cols, InScale in,
                                                  Scale out) {
     const size_t n = (size_t)1 << log_n;
