@@ -175,6 +175,24 @@ def test_large_proof_2p17_verifies(nlx, ctx, orc):
     cd.close()
 
 
+def test_headline_size_2p18_nineteen_gates_verifies(nlx, ctx, orc):
+    """The default bench's outer proof - 2^18 rows, all nineteen gate kinds, 64 public inputs (BASELINE.json's metric is
+    quoted on this shape): the circuit's constants / sigmas cap equals the oracle's and the oracle's verifier accepts the GPU
+    proof; a proof with one opened value changed is rejected."""
+    import bench
+    syn = nlx.SyntheticCircuit(18, seed=1000, num_public_inputs=64, **bench.GATE_MIXES["nearx"])
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    proof = cd.prove(syn.wires, syn.public_inputs)
+    ref = orc.Circuit.from_synthetic(syn)
+    assert np.array_equal(cd.constants_sigmas_cap, ref.constants_sigmas_cap())
+    assert ref.verify(proof) == 1
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 1
+    assert ref.verify(bytes(bad)) != 1
+    ref.close()
+    cd.close()
+
+
 @pytest.mark.parametrize("cfg", [
     dict(num_challenges=1, cap_height=0, fri_num_queries=5, fri_pow_bits=4, fri_arity_bits=2, fri_final_poly_bits=2),
     dict(cap_height=5, fri_num_queries=40, fri_pow_bits=0),
