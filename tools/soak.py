@@ -21,8 +21,16 @@ cd = nlx.CircuitData.from_synthetic(ctx, syn)
 p256, p512, ped = nlx.sha256_air.Sha256Prover(ctx, 6), nlx.sha512_air.Sha512Prover(ctx, 5), E.Ed25519Prover(ctx, 8)
 msgs = [bytes([i]) * (i * 7 % 200) for i in range(20)]
 slots = E.slots_to_words((E.synthetic_slots(16, seed=4) * 16)[:256])
+import numpy as np  # noqa: E402
+rs = np.random.RandomState(11)
+bn_cols = rs.randint(0, 1 << 60, size=(2, 1 << 14, 4), dtype=np.int64).astype(np.uint64)           # values below r
+g1 = np.tile(nlx.bn254_g1_pack([(1, 2), (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+                                         9918110051302171585080402603319702774565515993150576347155970296011118125764)]), (1 << 13, 1))
+ks = rs.randint(0, 1 << 60, size=(1 << 14, 4), dtype=np.int64).astype(np.uint64)
 jobs = {"plonky2_2p13": lambda: cd.prove(syn.wires, syn.public_inputs), "sha256_2p6": lambda: p256.prove(msgs)[0],
-        "sha512_2p5": lambda: p512.prove(msgs)[0], "ed25519_2p8": lambda: ped.prove(slots)}
+        "sha512_2p5": lambda: p512.prove(msgs)[0], "ed25519_2p8": lambda: ped.prove(slots),
+        "bn254_ntt_2p14_coset_dit": lambda: nlx.bn254_ntt(ctx, bn_cols, coset_shift=5, bitrev_in=True).tobytes(),
+        "bn254_msm_2p14": lambda: nlx.bn254_msm_g1(ctx, g1, ks).tobytes()}
 first, mem0 = {}, None
 t0 = time.time()
 for it in range(iters):
