@@ -7,7 +7,7 @@
 // replaces several carry-chain instructions is a straight win: `r = base + w2 * (2^32 - 1)` is ONE v_mad_u64_u32 (its
 // carry-out lands in VCC) instead of four add / subtract-with-carry instructions, and `r += carry ? 2^32 - 1 : 0` is a
 // v_cndmask + one more v_mad_u64_u32 (mask * 1 + r) instead of three.  Multiply + reduction: 16 instructions (20 in
-// round 1, ~29 from hipcc's u64 code); the fold of an MDS accumulator pair: 5 (9 in round 1).
+// round 1, ~29 from hipcc's u64 code); the fold of an MDS accumulator pair: 4 (9 in round 1).
 #pragma once
 #include "gl.hpp"
 
@@ -116,17 +116,22 @@ __device__ __forceinline__ F sbox7(F x) {
     return mul(x3, x4);
 }
 
-// value = al + ah * 2^32 (al, ah u64 accumulators, ah < 2^42) -> loose
+// value = al + ah * 2^32 (al, ah u64 accumulators below 2^42: twelve products of a 32-bit limb and a constant < 2^6, plus a
+// round constant's limb) -> loose.  2^64 = EPS (mod p), so ah's high word folds in first, as a multiply-add that cannot
+// carry (al + ah1 * EPS < 2^42 + 2^42); ah's low word then lands on the high word of the sum, and only that addition can
+// carry - once, worth EPS, and adding it cannot carry again.  Four instructions (five when the limbs were summed first).
 __device__ __forceinline__ F fold_acc(uint64_t al, uint64_t ah) {
-    // limbs: w0 = al0, w1 = al1 + ah0, w2 = ah1 + carry  (w2 < 2^11), w3 = 0
-    uint32_t w1, w2;
-    asm("v_add_co_u32 %[w1], vcc, %[al1], %[ah0]\n\t"
-        "v_addc_co_u32 %[w2], vcc, 0, %[ah1], vcc"
-        : [w1] "=&v"(w1), [w2] "=v"(w2)
-        : [al1] "v"((uint32_t)(al >> 32)), [ah0] "v"((uint32_t)ah), [ah1] "v"((uint32_t)(ah >> 32))
+    uint64_t t;
+    asm("v_mad_u64_u32 %[t], vcc, %[ah1], -1, %[al]" : [t] "=&v"(t) : [ah1] "v"((uint32_t)(ah >> 32)), [al] "v"(al) : "vcc");
+    uint32_t r1, m;
+    asm("v_add_co_u32 %[r1], vcc, %[t1], %[ah0]\n\t"
+        "v_cndmask_b32_e64 %[m], 0, -1, vcc"
+        : [r1] "=&v"(r1), [m] "=&v"(m)
+        : [t1] "v"((uint32_t)(t >> 32)), [ah0] "v"((uint32_t)ah)
         : "vcc");
-    // r = (w1:w0) + w2 * EPS, carry -> + EPS
-    return add_w2_eps(((uint64_t)w1 << 32) | (uint32_t)al, w2);
+    uint64_t r;
+    asm("v_mad_u64_u32 %[r], vcc, %[m], 1, %[base]" : [r] "=&v"(r) : [m] "v"(m), [base] "v"(((uint64_t)r1 << 32) | (uint32_t)t) : "vcc");
+    return from_u64(r);
 }
 
 // Linear layer; `rc_next` (12 canonical constants, wave-uniform, or nullptr) is the NEXT round's
