@@ -50,7 +50,7 @@ VALU_NS_PER_MUL = 1.99
 VALU_PEAK_GPERM = 1024 * 64 / (VALU_MULS_PER_PERM * VALU_NS_PER_MUL)
 VALU_PEAK_NOTE = ("1 024 SIMDs x 64 lanes / (10 528 irreducible 32x32 multiply-adds per permutation x 1.99 ns measured issue cost per "
                   "wave-instruction per SIMD at full occupancy, tools/ubench/poseidon_ubench.hip -> profiles/r02_valu_ubench_v1.txt); "
-                  "a bound on the multiplies alone - the permutation micro-benchmark itself reaches 1.73 Gperm/s")
+                  "a bound on the multiplies alone - the permutation micro-benchmark itself reaches 1.74 Gperm/s")
 
 
 def stored_traffic(key, alg_bytes):
