@@ -110,6 +110,11 @@ BNF_HD Jac jneg(const Jac& p) { return Jac{p.x, neg(p.y), p.z}; }
 // operands multiply to less than 2^515) ----
 using f29::Fe;
 struct Aff29 { Fe x, y; };        // both exactly zero: the point at infinity
+// How the converted points rest in memory: both coordinates (tight, below 2^255) re-sliced into eight 32-bit words each -
+// 64 bytes, one aligned access per gathered point (as 72 bytes of limbs a point straddled two 128-byte lines: the bucket
+// kernel fetched 67 GB for 2^28 gathered points, PMC FETCH_SIZE).
+struct __attribute__((aligned(64))) AffPacked { uint32_t x[8], y[8]; };
+__device__ __forceinline__ Aff29 unpack(const AffPacked& p) { return Aff29{f29::from_words256(p.x), f29::from_words256(p.y)}; }
 struct Jac29 { Fe x, y, z; };     // z exactly zero: the point at infinity
 struct JacWords { uint32_t x[8], y[8], z[8]; };   // canonical integers, for the host's tail
 
@@ -130,22 +135,31 @@ __device__ __noinline__ Jac29 jdbl29(const Jac29& p) {   // rare in the bucket k
     r.z = tighten(dbl(mul(p.y, p.z)));
     return r;
 }
-__device__ __forceinline__ Jac29 jmadd29(const Jac29& p, const Aff29& q) {
+// The mixed addition in place, common case only: returns 0 and leaves acc + q in acc, or - touching nothing - 1 if q is
+// acc's own point (the sum is a doubling) or 2 if it is its negative (the sum is the point at infinity).  The rare cases
+// are the caller's, OUTSIDE this function: with the doubling called from in here the result struct of the whole addition
+// lived in scratch memory - 112 bytes written and read back per addition, 30 GB per 2^24-point MSM (PMC WRITE_SIZE).
+__device__ __forceinline__ int jmadd29_common(Jac29& acc, const Aff29& q) {
     using namespace f29;
-    if (is_inf(q)) return p;
-    if (is_zero_exact(p.z)) return Jac29{q.x, q.y, one()};
-    const Fe z1z1 = sqr(p.z), u2 = mul(q.x, z1z1), s2 = mul(mul(q.y, p.z), z1z1);
-    const Fe h = sub<4>(u2, p.x), r0 = sub<4>(s2, p.y);               // < 2^255 + 4 q = 2^256.3
-    if (is_zero_mod(h)) {
-        if (is_zero_mod(r0)) return jdbl29(Jac29{q.x, q.y, one()});
-        return inf29();
-    }
+    const Fe z1z1 = sqr(acc.z), u2 = mul(q.x, z1z1), s2 = mul(mul(q.y, acc.z), z1z1);
+    const Fe h = sub<4>(u2, acc.x), r0 = sub<4>(s2, acc.y);           // < 2^255 + 4 q = 2^256.3
+    if (is_zero_mod(h)) return is_zero_mod(r0) ? 1 : 2;
     const Fe r = dbl(r0);                                             // < 2^257.3
-    const Fe hh = sqr(h), i = dbl(dbl(hh)), j = mul(h, i), v = mul(p.x, i);   // i < 2^257
-    Jac29 o;
-    o.x = tighten(sub<8>(sqr(r), add(j, dbl(v))));                    // j + 2 v < 3 * 2^255 <= 8 q
-    o.y = tighten(sub<8>(mul(r, sub<4>(v, o.x)), dbl(mul(p.y, j))));
-    o.z = tighten(sub<8>(sqr(add(p.z, h)), add(z1z1, hh)));           // z + h < 2^256.8
+    const Fe hh = sqr(h), i = dbl(dbl(hh)), j = mul(h, i), v = mul(acc.x, i);   // i < 2^257
+    const Fe x3 = tighten(sub<8>(sqr(r), add(j, dbl(v))));            // j + 2 v < 3 * 2^255 <= 8 q
+    const Fe y3 = tighten(sub<8>(mul(r, sub<4>(v, x3)), dbl(mul(acc.y, j))));
+    acc.z = tighten(sub<8>(sqr(add(acc.z, h)), add(z1z1, hh)));       // z + h < 2^256.8
+    acc.x = x3;
+    acc.y = y3;
+    return 0;
+}
+__device__ __forceinline__ Jac29 jmadd29(const Jac29& p, const Aff29& q) {
+    if (is_inf(q)) return p;
+    if (f29::is_zero_exact(p.z)) return Jac29{q.x, q.y, f29::one()};
+    Jac29 o = p;
+    const int st = jmadd29_common(o, q);
+    if (st == 1) return jdbl29(Jac29{q.x, q.y, f29::one()});
+    if (st == 2) return inf29();
     return o;
 }
 __device__ __forceinline__ Jac29 jadd29(const Jac29& p, const Jac29& q) {
@@ -171,7 +185,7 @@ __device__ __forceinline__ Jac29 jadd29(const Jac29& p, const Jac29& q) {
 __device__ __forceinline__ Jac29 jneg29(const Jac29& p) { return Jac29{p.x, f29::tighten(f29::sub<4>(f29::zero(), p.y)), p.z}; }
 
 // gnark-crypto G1Affine words -> the device form, once per point
-__global__ __launch_bounds__(256) void k_msm_convert(const uint64_t* __restrict__ points, size_t n, Aff29* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_msm_convert(const uint64_t* __restrict__ points, size_t n, AffPacked* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t w[16];
@@ -181,9 +195,9 @@ __global__ __launch_bounds__(256) void k_msm_convert(const uint64_t* __restrict_
         w[2 * k] = (uint32_t)x;
         w[2 * k + 1] = (uint32_t)(x >> 32);
     }
-    Aff29 p;
-    p.x = f29::from_mont256(w);       // (0, 0) stays exactly (0, 0)
-    p.y = f29::from_mont256(w + 8);
+    AffPacked p;
+    f29::to_words256(f29::from_mont256(w), p.x);       // (0, 0) stays exactly (0, 0)
+    f29::to_words256(f29::from_mont256(w + 8), p.y);
     out[i] = p;
 }
 
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(256) void k_msm_ranges(const uint16_t* __restrict__
 #ifndef NLX_MSM_MINW
 #define NLX_MSM_MINW 3   // waves per SIMD the register allocation must allow (tuning builds: build.py NLX_EXTRA_FLAGS)
 #endif
-__global__ __launch_bounds__(64, NLX_MSM_MINW) void k_msm_buckets(const Aff29* __restrict__ points, const uint32_t* __restrict__ sorted /* [window][n] */,
+__global__ __launch_bounds__(64, NLX_MSM_MINW) void k_msm_buckets(const AffPacked* __restrict__ points, const uint32_t* __restrict__ sorted /* [window][n] */,
                                                     const uint32_t* __restrict__ range_lo, const uint32_t* __restrict__ range_hi /* [window][65536] */,
                                                     Jac29* __restrict__ buckets /* [window][65536] */) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // = w * 65536 + b
@@ -233,7 +247,17 @@ __global__ __launch_bounds__(64, NLX_MSM_MINW) void k_msm_buckets(const Aff29* _
     if (digit != 0) {   // digit 0 weighs nothing
         const uint32_t lo = range_lo[t], hi = range_hi[t];   // positions in the window-major sorted array
 #pragma unroll 1
-        for (uint32_t p = lo; p < hi; p++) acc = jmadd29(acc, points[sorted[p]]);
+        for (uint32_t p = lo; p < hi; p++) {
+            const Aff29 q = unpack(points[sorted[p]]);
+            if (is_inf(q)) continue;
+            if (f29::is_zero_exact(acc.z)) {
+                acc = Jac29{q.x, q.y, f29::one()};
+                continue;
+            }
+            const int st = jmadd29_common(acc, q);   // acc stays in registers on this path
+            if (st == 1) acc = jdbl29(Jac29{q.x, q.y, f29::one()});
+            else if (st == 2) acc = inf29();
+        }
     }
     buckets[t] = acc;
 }
@@ -314,7 +338,7 @@ extern "C" int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const 
     uint32_t* d_lo = (uint32_t*)ctx->alloc(n_hist * 2 * 4);   // range_lo | range_hi
     uint32_t* d_hi = d_lo ? d_lo + n_hist : nullptr;
     Jac29* d_buckets = (Jac29*)ctx->alloc(n_hist * sizeof(Jac29));
-    Aff29* d_pts = (Aff29*)ctx->alloc((size_t)n * sizeof(Aff29));   // the points in the kernels' field representation
+    AffPacked* d_pts = (AffPacked*)ctx->alloc((size_t)n * sizeof(AffPacked));   // the points in the kernels' field representation
     constexpr int N_WSUM = N_WINDOWS * RED_BLOCKS;
     JacWords* d_wsum = (JacWords*)ctx->alloc(N_WSUM * sizeof(JacWords));
     size_t tmp_bytes = 0;
