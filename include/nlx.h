@@ -162,6 +162,10 @@ int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const uint64_t* s
 /* The sum of n G1Affine points (same layout; host pointers, computed on the host): joins the partial results of an MSM whose
  * points were split over several GPUs - one addition per rank. */
 int32_t nlx_bn254_g1_sum(const uint64_t* points, uint64_t n, uint64_t out[8]);
+/* Test / bench data on the device: out[i] = (i + 1) * base for i < n as G1Affine words - n distinct curve points (an SRS's
+ * worth of gather targets for the MSM; a big-integer model makes a few thousand per second).  out: host or device, n x 8
+ * words; n <= 2^27; base must not be the point at infinity. */
+int32_t nlx_bn254_g1_multiples(nlx_ctx* ctx, const uint64_t base[8], uint64_t n, uint64_t* out);
 
 /* ---- a3: plonky2::fri::oracle::PolynomialBatch::{from_values, from_coeffs} ----
  * values / coeffs: n_cols x 2^log_n column-major, natural order.  The coset shift is the

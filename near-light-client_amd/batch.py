@@ -264,3 +264,17 @@ def bn254_g1_sum(points):
     if dll.nlx_bn254_g1_sum(a.ctypes.data if len(a) else None, len(a), out.ctypes.data) != 0:
         raise ValueError("nlx_bn254_g1_sum failed")
     return out
+
+
+def bn254_g1_multiples(ctx, base, n, device=None):
+    """[(i + 1) * base for i < n] as G1Affine words, computed on the GPU: (n, 8) uint64 on the host, or an int64 device
+    tensor with device="cuda:k" (test and bench data: n distinct curve points)."""
+    b = bn254_g1_pack([base])
+    if device is not None:
+        import torch
+        out = torch.empty((n, 8), dtype=torch.int64, device=device)
+        ctx.check(dll.nlx_bn254_g1_multiples(ctx.handle, b.ctypes.data, n, out.data_ptr()))
+        return out
+    out = np.zeros((n, 8), dtype=np.uint64)
+    ctx.check(dll.nlx_bn254_g1_multiples(ctx.handle, b.ctypes.data, n, out.ctypes.data))
+    return out

@@ -310,6 +310,66 @@ __global__ __launch_bounds__(RED_LANES) void k_msm_reduce(const Jac29* __restric
     }
 }
 
+// ---- test / bench data: out[i] = (i + 1) P for i < n as G1Affine words - n DISTINCT curve points (an SRS's worth of
+// gather targets; a big-integer model produces a few thousand per second).  One lane per chunk of GEN_CHUNK consecutive
+// multiples: the chunk's first point by double-and-add, the rest by mixed additions of P, kept in Jacobian form in a
+// scratch array; then ONE inversion per lane (Montgomery's trick over the chunk's Z coordinates) takes them to affine. ----
+constexpr uint32_t GEN_CHUNK = 256;
+__device__ __forceinline__ Fe inv29(const Fe& a) {   // a^(q - 2), a != 0 mod q
+    constexpr uint32_t E[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    Fe r = f29::one();
+#pragma unroll 1
+    for (int bit = 253; bit >= 0; bit--) {
+        r = f29::sqr(r);
+        if ((E[bit >> 5] >> (bit & 31)) & 1) r = f29::mul(r, a);
+    }
+    return r;
+}
+__global__ __launch_bounds__(64) void k_g1_multiples(AffPacked base_packed, uint64_t n, Jac29* __restrict__ jac /* [n] */,
+                                                     Fe* __restrict__ prefix /* [n] */, uint64_t* __restrict__ out /* [n][8] */) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t first = t * GEN_CHUNK;
+    if (first >= n) return;
+    const uint32_t count = (uint32_t)(n - first < GEN_CHUNK ? n - first : GEN_CHUNK);
+    const Aff29 base = unpack(base_packed);
+    // (first + 1) P
+    Jac29 acc = inf29();
+    const uint64_t k = first + 1;
+#pragma unroll 1
+    for (int bit = 63 - __clzll((long long)k); bit >= 0; bit--) {
+        acc = jdbl29(acc);
+        if ((k >> bit) & 1) acc = jmadd29(acc, base);
+    }
+    Fe run = f29::one();
+#pragma unroll 1
+    for (uint32_t j = 0; j < count; j++) {
+        if (j) acc = jmadd29(acc, base);
+        jac[first + j] = acc;
+        prefix[first + j] = run;                      // product of the Z's before this one
+        run = f29::mul(run, acc.z);                   // (no multiple below the group order is the point at infinity: Z != 0)
+    }
+    Fe inv = inv29(run);
+    Fe k256;                                          // 2^256 mod q (plain): takes x 2^261 to the caller's x 2^256
+    {
+        constexpr uint32_t K[f29::NL] = {0x058f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u, 0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
+#pragma unroll
+        for (int i = 0; i < f29::NL; i++) k256.v[i] = K[i];
+    }
+#pragma unroll 1
+    for (uint32_t j = count; j-- > 0;) {
+        const Jac29 p = jac[first + j];
+        const Fe zi = f29::mul(inv, prefix[first + j]);   // 1 / Z_j
+        inv = f29::mul(inv, p.z);
+        const Fe zi2 = f29::sqr(zi);
+        const Fe x = f29::canonical(f29::mul(f29::mul(p.x, zi2), k256)), y = f29::canonical(f29::mul(f29::mul(p.y, f29::mul(zi2, zi)), k256));
+        uint32_t w[16];
+        f29::to_words256(x, w);
+        f29::to_words256(y, w + 8);
+#pragma unroll
+        for (int i = 0; i < 8; i++) out[(first + j) * 8 + i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    }
+}
+
 }  // namespace msm
 }  // namespace nlx
 
@@ -423,4 +483,45 @@ extern "C" int32_t nlx_bn254_g1_sum(const uint64_t* points, uint64_t n, uint64_t
     store_words(mul(acc.x, zi2), out);
     store_words(mul(acc.y, mul(zi2, zi)), out + 4);
     return NLX_OK;
+}
+
+// out[i] = (i + 1) P, i < n, as G1Affine words (Montgomery), on the device: n distinct curve points for tests and benches.
+extern "C" int32_t nlx_bn254_g1_multiples(nlx_ctx* ctx, const uint64_t base[8], uint64_t n, uint64_t* out) {
+    using namespace nlx::msm;
+    if (!ctx) return NLX_E_INVAL;
+    if (!base || (n && !out)) return ctx->fail(NLX_E_INVAL, "NULL argument");
+    if (n > ((uint64_t)1 << 27)) return ctx->fail(NLX_E_RANGE, "at most 2^27 points");
+    if (n == 0) return NLX_OK;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    Staged so(ctx, out, (size_t)n * 64, false, true);
+    if (so.status) return so.status;
+    uint64_t* d_base = (uint64_t*)ctx->alloc(64 + sizeof(AffPacked));
+    Jac29* d_jac = (Jac29*)ctx->alloc((size_t)n * sizeof(Jac29));
+    Fe* d_prefix = (Fe*)ctx->alloc((size_t)n * sizeof(Fe));
+    int32_t rc = NLX_OK;
+    if (!d_base || !d_jac || !d_prefix) rc = NLX_E_NOMEM;
+    AffPacked packed{};
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(d_base, base, 64, hipMemcpyHostToDevice, st);
+        AffPacked* d_packed = (AffPacked*)(d_base + 8);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_msm_convert, dim3(1), dim3(256), 0, st, d_base, (size_t)1, d_packed);
+            e = hipMemcpyAsync(&packed, d_packed, sizeof(AffPacked), hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = ctx->hip_fail(e, "nlx_bn254_g1_multiples");
+    }
+    if (!rc) {
+        const uint64_t lanes = (n + GEN_CHUNK - 1) / GEN_CHUNK;
+        hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, packed, n, d_jac, d_prefix, so.as<uint64_t>());
+        rc = so.finish();
+        hipError_t e = hipStreamSynchronize(st);
+        if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
+        hipError_t le = hipGetLastError();
+        if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
+    }
+    for (void* p : {(void*)d_base, (void*)d_jac, (void*)d_prefix})
+        if (p) ctx->release(p);
+    return rc;
 }

@@ -177,3 +177,31 @@ def test_bn254_msm_2p20_structured(nlx, ctx, bn):
     g2 = nlx.bn254_g1_unpack(nlx.bn254_msm_g1(ctx, d_pts, words2))
     g12 = nlx.bn254_g1_unpack(nlx.bn254_msm_g1(ctx, d_pts, both))
     assert bn.g1_add(got, g2) == g12
+
+
+def test_bn254_g1_multiples_and_msm_over_distinct_points(nlx, ctx, bn):
+    """nlx_bn254_g1_multiples: out[i] = (i + 1) P equals the model's repeated addition (all of the first 700 - a chunk
+    boundary included - and samples up to 2^17); an MSM over 2^17 DISTINCT points with random scalars equals
+    (sum k_i (i + 1)) P - one scalar multiplication in the model pins the whole run"""
+    import torch
+    rng = random.Random(4242)
+    base = bn.g1_mul(rng.randrange(1, bn.R), bn.G1)
+    n = 1 << 17
+    dev = "cuda:%d" % ctx.device
+    pts = nlx.bn254_g1_multiples(ctx, base, n, device=dev)
+    host = pts.cpu().numpy().view(np.uint64)
+    acc = None
+    for i in range(700):
+        acc = bn.g1_add(acc, base)
+        assert nlx.bn254_g1_unpack(host[i]) == acc, i
+    for i in [rng.randrange(700, n) for _ in range(40)] + [n - 1, 255, 256, 257]:
+        assert nlx.bn254_g1_unpack(host[i]) == bn.g1_mul(i + 1, base), i
+    small = nlx.bn254_g1_multiples(ctx, base, 5)                       # host output, fewer points than one chunk
+    assert [nlx.bn254_g1_unpack(w) for w in small] == [bn.g1_mul(i + 1, base) for i in range(5)]
+    rs = np.random.RandomState(17)
+    words = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    words[:, 3] &= np.uint64((1 << 60) - 1)
+    ks = [sum(int(words[i, w]) << (64 * w) for w in range(4)) for i in range(n)]
+    total = sum(k * (i + 1) for i, k in enumerate(ks)) % bn.R
+    got = nlx.bn254_g1_unpack(nlx.bn254_msm_g1(ctx, pts, torch.from_numpy(words.view(np.int64)).to(dev)))
+    assert got == bn.g1_mul(total, base)
