@@ -95,6 +95,7 @@ def parse():
     ap.add_argument("--gate-mix", default="nearx", choices=["nearx", "basic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ntt-log-n", type=int, default=24)
+    ap.add_argument("--msm-group", default="g1", choices=["g1", "g2"], help="msm24: the group - G1 (KZG commitments) or G2 (Groth16's B query, coordinates in Fq2)")
     ap.add_argument("--ntt-split", action="store_true", help="ntt24 with N > 1 ranks: split every ONE transform over the ranks (contiguous slices, "
                     "log2 N pairwise slice exchanges) instead of dealing whole columns out")
     ap.add_argument("--ntt-order", default="natural", choices=["natural", "dif", "dit"],
@@ -1163,6 +1164,67 @@ def run_ntt24_bn254(args, nlx, torch, rank, world, local, dist):
     return out
 
 
+def run_msm24_g2(args, nlx, torch, rank, world, local, dist):
+    """--workload msm24 --msm-group g2: one BN254 G2 multi-scalar multiplication of 2^--ntt-log-n points per step (Groth16's B
+    query; nlx_bn254_msm_g2, gnark-crypto G2Affine words).  The points are 4 096 distinct curve points tiled (made by the
+    big-integer model: no device generator exists for G2), the scalars uniform below r; the result is checked against the
+    model through the regrouped sum.  One rank."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bn254_py   # input generation (points on the twist) and the post-timing check only
+    log_n = args.ntt_log_n
+    n, m = 1 << log_n, min(4096, 1 << log_n)
+    rng = __import__("random").Random(98)
+    acc, step_pt, base = bn254_py.g2_mul(rng.randrange(1, bn254_py.R), bn254_py.G2), bn254_py.g2_mul(rng.randrange(1, bn254_py.R), bn254_py.G2), []
+    for _ in range(m):
+        base.append(acc)
+        acc = bn254_py.g2_add(acc, step_pt)
+    ctx = nlx.Context(local)
+    dev = "cuda:%d" % local
+    pts = torch.from_numpy(nlx.bn254_g2_pack(base).view(np.int64)).to(dev).repeat(n // m, 1).contiguous()
+    g = torch.Generator(device="cpu").manual_seed(0x6D736E)
+    ks = torch.randint(0, 2 ** 62, (n, 4), generator=g, dtype=torch.int64) * 4 + torch.randint(0, 4, (n, 4), generator=g, dtype=torch.int64)
+    ks[:, 3] = torch.randint(0, 0x30644e72e131a029, (n,), generator=g, dtype=torch.int64)
+    d_ks = ks.to(dev)
+    for _ in range(args.warmup):
+        nlx.bn254_msm_g2(ctx, pts, d_ks)
+    ctx.kernel_timing(True)
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = nlx.bn254_msm_g2(ctx, pts, d_ks)
+    barrier(dist, torch)
+    dt = time.perf_counter() - t0
+    kt = ctx.kernel_stats("bn254_msm_g2")
+    ctx.kernel_timing(False)
+    ms = kt[1] / kt[0] if kt[0] else None
+    out = {
+        "metric": "BN254 G2 MSM of 2^%d points: multi-scalar multiplications per second (Groth16's B query, row f.4)" % log_n,
+        "value": args.steps / dt, "unit": "MSMs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u256 x 2 (BN254 base field's quadratic extension, integer)", "data": "synthetic",
+        "config": {"workload": "one G2 MSM of 2^%d points x 254-bit scalars (gnark-crypto G2Affine / fr.Element words), resident in HBM" % log_n,
+                   "distinct_points": m, "device_ms_rank0": ms, "parallelism": "x1"},
+        "roofline": {"bound": "hbm", "achieved": (160.0 * n / (ms * 1e-3) / 1e9) if ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (160.0 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms else None, "traffic": None, "kernel": "bn254_msm_g2",
+                     "launches": kt[0], "avg_launch_ms": ms, "alg_bytes_per_launch": 160.0 * n,
+                     "note": "160 bytes per point algorithmic; integer-VALU bound: three base-field products per Fq2 product"},
+        "cpu_baseline": None,
+    }
+    if not args.no_cpu_baseline:
+        kw = ks.numpy().view(np.uint64).astype(object)
+        ints = kw[:, 0] + (kw[:, 1] << 64) + (kw[:, 2] << 128) + (kw[:, 3] << 192)
+        tc = time.time()
+        want = bn254_py.msm_g2([int(sum(ints[j::m])) % bn254_py.R for j in range(m)], base)
+        per_mul = (time.time() - tc) / m
+        out["cpu_baseline"] = {"value": 1.0 / (per_mul * n), "unit": "MSMs/s", "cores": 1, "kind": "port",
+                               "sample": "pure-Python big-integer model: %d G2 scalar multiplications at %.1f ms each (a model for parity, not a "
+                                         "competitive CPU implementation); GPU result equal to the model's regrouped sum: %s"
+                                         % (m, per_mul * 1e3, nlx.bn254_g2_unpack(res) == want)}
+    ctx.close()
+    return out
+
+
 def run_msm24(args, nlx, torch, rank, world, local, dist):
     """--workload msm24: the KZG commitment of the recursive wrap (BASELINE.json configs[4]'s size): one
     BN254 G1 multi-scalar multiplication of 2^--ntt-log-n points per step through nlx_bn254_msm_g1, points and scalars
@@ -1268,7 +1330,7 @@ def main():
     elif args.workload == "ntt24":
         out = run_ntt24(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "msm24":
-        out = run_msm24(args, nlx, torch, rank, world, local, dist)
+        out = (run_msm24_g2 if args.msm_group == "g2" else run_msm24)(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "stark":
         out = run_stark(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "ed25519":

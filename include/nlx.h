@@ -159,9 +159,13 @@ int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, u
  * scalars[i] * points[i] as a G1Affine (8 words, Montgomery; (0, 0) for the point at infinity).  points / scalars may be host
  * or device pointers; n <= 2^27.  Points are taken to be on the curve (as MultiExp does). */
 int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t flags, uint64_t out[8]);
+/* The same over G2 (Groth16's B query): points n x 16 words = gnark-crypto's G2Affine (X then Y, each an E2{A0, A1} of two
+ * fp.Element, Montgomery; infinity = all zero), the coordinates in Fq2 = Fq[u] / (u^2 + 1); out: a G2Affine, 16 words. */
+int32_t nlx_bn254_msm_g2(nlx_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t flags, uint64_t out[16]);
 /* The sum of n G1Affine points (same layout; host pointers, computed on the host): joins the partial results of an MSM whose
  * points were split over several GPUs - one addition per rank. */
 int32_t nlx_bn254_g1_sum(const uint64_t* points, uint64_t n, uint64_t out[8]);
+int32_t nlx_bn254_g2_sum(const uint64_t* points, uint64_t n, uint64_t out[16]);   /* the same for G2Affine points */
 /* Test / bench data on the device: out[i] = (i + 1) * base for i < n as G1Affine words - n distinct curve points (an SRS's
  * worth of gather targets for the MSM; a big-integer model makes a few thousand per second).  out: host or device, n x 8
  * words; n <= 2^27; base must not be the point at infinity. */

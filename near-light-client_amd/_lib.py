@@ -78,6 +78,9 @@ SIGNATURES = {
     "nlx_bn254_msm_g1": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32,
                                            ctypes.c_void_p]),
     "nlx_bn254_g1_sum": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "nlx_bn254_g2_sum": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "nlx_bn254_msm_g2": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32,
+                                           ctypes.c_void_p]),
     "nlx_bn254_g1_multiples": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
     "nlx_commit_from_values": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
                                                 ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, c_void_pp]),

@@ -278,3 +278,57 @@ def bn254_g1_multiples(ctx, base, n, device=None):
     out = np.zeros((n, 8), dtype=np.uint64)
     ctx.check(dll.nlx_bn254_g1_multiples(ctx.handle, b.ctypes.data, n, out.ctypes.data))
     return out
+
+
+# ---- G2 (Groth16's B query): coordinates in Fq2 = Fq[u] / (u^2 + 1), gnark-crypto's G2Affine{X, Y E2{A0, A1}} ----
+def bn254_g2_pack(points):
+    """[((x0, x1), (y0, y1)) | None] -> (n, 16) uint64: X.A0, X.A1, Y.A0, Y.A1, each a Montgomery fp.Element"""
+    out = np.zeros((len(points), 16), dtype=np.uint64)
+    for i, pt in enumerate(points):
+        if pt is None:
+            continue
+        for c, v in enumerate((pt[0][0], pt[0][1], pt[1][0], pt[1][1])):
+            m = int(v) * _MONT_Q % BN254_Q
+            for w in range(4):
+                out[i, 4 * c + w] = (m >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def bn254_g2_unpack(words):
+    """16 uint64 words (G2Affine, Montgomery) -> ((x0, x1), (y0, y1)) integers, or None for the point at infinity"""
+    w = [int(v) for v in np.asarray(words, dtype=np.uint64).reshape(16)]
+    c = [sum(w[4 * k + j] << (64 * j) for j in range(4)) for k in range(4)]
+    if not any(c):
+        return None
+    rinv = pow(_MONT_Q, BN254_Q - 2, BN254_Q)
+    c = [v * rinv % BN254_Q for v in c]
+    return (c[0], c[1]), (c[2], c[3])
+
+
+def bn254_msm_g2(ctx, points, scalars, montgomery=False):
+    """gnark-crypto G2Affine.MultiExp: points (n, 16) uint64 (bn254_g2_pack) or a device tensor, scalars as bn254_msm_g1.
+    Returns the 16 words of the result."""
+    def ptr(a, width):
+        if hasattr(a, "data_ptr"):
+            if tuple(a.shape)[1:] != (width,) or not a.is_contiguous():
+                raise ValueError("expected a contiguous (n, %d) tensor" % width)
+            return a, a.data_ptr(), a.shape[0]
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        if a.ndim != 2 or a.shape[1] != width:
+            raise ValueError("expected shape (n, %d)" % width)
+        return a, a.ctypes.data, a.shape[0]
+    p_keep, p_ptr, n = ptr(points, 16)
+    s_keep, s_ptr, n2 = ptr(scalars, 4)
+    if n != n2:
+        raise ValueError("points and scalars differ in length")
+    out = np.zeros(16, dtype=np.uint64)
+    ctx.check(dll.nlx_bn254_msm_g2(ctx.handle, p_ptr if n else None, s_ptr if n else None, n, 1 if montgomery else 0, out.ctypes.data))
+    return out
+
+
+def bn254_g2_sum(points):
+    a = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 16)
+    out = np.zeros(16, dtype=np.uint64)
+    if dll.nlx_bn254_g2_sum(a.ctypes.data if len(a) else None, len(a), out.ctypes.data) != 0:
+        raise ValueError("nlx_bn254_g2_sum failed")
+    return out

@@ -259,5 +259,61 @@ F29_HD void to_canonical256(const Fe& a, uint32_t* w) {
     }
 }
 
+// ---- field policies for the curve code (bn254_msm.hip): the group law is written once over `F::T` ----
+// F1: the base field itself, loose values with the bounds stated at each formula.
+struct F1 {
+    typedef Fe T;
+    static constexpr int WORDS = 8;   // 32-bit words of an element in memory
+    F29_HD static T zero() { return f29::zero(); }
+    F29_HD static T one() { return f29::one<QMod>(); }
+    F29_HD static T mul(const T& a, const T& b) { return f29::mul<QMod>(a, b); }
+    F29_HD static T sqr(const T& a) { return f29::mul<QMod>(a, a); }
+    F29_HD static T add(const T& a, const T& b) { return f29::add(a, b); }
+    F29_HD static T dbl(const T& a) { return f29::add(a, a); }
+    template <int K>
+    F29_HD static T sub(const T& a, const T& b) { return f29::sub<K, QMod>(a, b); }
+    F29_HD static T tighten(const T& a) { return f29::tighten<QMod>(a); }
+    F29_HD static bool is_zero_mod(const T& a) { return f29::is_zero_mod<QMod>(a); }
+    F29_HD static bool is_zero_exact(const T& a) { return f29::is_zero_exact(a); }
+    F29_HD static T from_mont256(const uint32_t* w) { return f29::from_mont256<QMod>(w); }
+    F29_HD static void to_words(const T& a, uint32_t* w) { f29::to_words256(a, w); }            // a < 2^256
+    F29_HD static T from_words(const uint32_t* w) { return f29::from_words256(w); }
+    F29_HD static void to_canonical(const T& a, uint32_t* w) { f29::to_canonical256<QMod>(a, w); }
+};
+// F2: the quadratic extension Fq[u] / (u^2 + 1) of G2's coordinates.  Every result is tightened (both components below
+// 1.1 q), so no bound has to be tracked through the formulas: sums of two components stay below 2.2 q, products of such sums
+// far below 2^515, and a + 4 q - b is non-negative for any subtrahend.  Three base-field products per product (Karatsuba).
+struct Fe2 {
+    Fe c0, c1;
+};
+struct F2 {
+    typedef Fe2 T;
+    static constexpr int WORDS = 16;
+    F29_HD static Fe tt(const Fe& a) { return f29::tighten<QMod>(a); }
+    F29_HD static T zero() { return T{f29::zero(), f29::zero()}; }
+    F29_HD static T one() { return T{f29::one<QMod>(), f29::zero()}; }
+    F29_HD static T mul(const T& a, const T& b) {
+        const Fe t0 = f29::mul<QMod>(a.c0, b.c0), t1 = f29::mul<QMod>(a.c1, b.c1);
+        const Fe s = f29::mul<QMod>(f29::add(a.c0, a.c1), f29::add(b.c0, b.c1));
+        return T{tt(f29::sub<4, QMod>(t0, t1)), tt(f29::sub<8, QMod>(s, f29::add(t0, t1)))};
+    }
+    F29_HD static T sqr(const T& a) {   // (a0 + a1)(a0 - a1) + 2 a0 a1 u
+        const Fe p = f29::mul<QMod>(f29::add(a.c0, a.c1), f29::sub<4, QMod>(a.c0, a.c1));
+        const Fe m = f29::mul<QMod>(a.c0, a.c1);
+        return T{tt(p), tt(f29::add(m, m))};
+    }
+    F29_HD static T add(const T& a, const T& b) { return T{tt(f29::add(a.c0, b.c0)), tt(f29::add(a.c1, b.c1))}; }
+    F29_HD static T dbl(const T& a) { return add(a, a); }
+    template <int K>
+    F29_HD static T sub(const T& a, const T& b) { return T{tt(f29::sub<4, QMod>(a.c0, b.c0)), tt(f29::sub<4, QMod>(a.c1, b.c1))}; }
+    F29_HD static T tighten(const T& a) { return T{tt(a.c0), tt(a.c1)}; }
+    F29_HD static bool is_zero_mod(const T& a) { return f29::is_zero_mod<QMod>(a.c0) && f29::is_zero_mod<QMod>(a.c1); }
+    F29_HD static bool is_zero_exact(const T& a) { return f29::is_zero_exact(a.c0) && f29::is_zero_exact(a.c1); }
+    F29_HD static T from_mont256(const uint32_t* w) { return T{tt(f29::from_mont256<QMod>(w)), tt(f29::from_mont256<QMod>(w + 8))}; }
+    F29_HD static void to_words(const T& a, uint32_t* w) { f29::to_words256(a.c0, w); f29::to_words256(a.c1, w + 8); }
+    F29_HD static T from_words(const uint32_t* w) { return T{f29::from_words256(w), f29::from_words256(w + 8)}; }
+    F29_HD static void to_canonical(const T& a, uint32_t* w) { f29::to_canonical256<QMod>(a.c0, w); f29::to_canonical256<QMod>(a.c1, w + 8); }
+};
+
 }  // namespace f29
 }  // namespace nlx

@@ -134,3 +134,67 @@ def msm_g1(scalars, points):
 
 assert g1_add(G1, G1) == (1368015179489954701390400359078579693043519447331113978918064868415326638035,
                           9918110051302171585080402603319702774565515993150576347155970296011118125764)   # EIP-196's 2 G
+
+
+# ---- G2: y^2 = x^3 + 3 / (9 + u) over Fq2 = Fq[u] / (u^2 + 1), EIP-197's generator ----
+def f2_add(a, b):
+    return (a[0] + b[0]) % Q, (a[1] + b[1]) % Q
+
+
+def f2_sub(a, b):
+    return (a[0] - b[0]) % Q, (a[1] - b[1]) % Q
+
+
+def f2_mul(a, b):
+    return (a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q
+
+
+def f2_inv(a):
+    d = pow(a[0] * a[0] + a[1] * a[1], Q - 2, Q)
+    return a[0] * d % Q, (-a[1]) * d % Q
+
+
+B2 = f2_mul((3, 0), f2_inv((9, 1)))
+G2 = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+       11559732032986387107991004021392285783925812861821192530917403151452391805634),
+      (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+       4082367875863433681332203403145435568316851327593401208105741076214120093531))
+assert f2_mul(G2[1], G2[1]) == f2_add(f2_mul(f2_mul(G2[0], G2[0]), G2[0]), B2)     # the recalled generator is on the twist
+
+
+def g2_add(p, q):
+    """affine addition over Fq2; None = the point at infinity"""
+    if p is None:
+        return q
+    if q is None:
+        return p
+    (x1, y1), (x2, y2) = p, q
+    if x1 == x2:
+        if f2_add(y1, y2) == (0, 0):
+            return None
+        lam = f2_mul(f2_mul((3, 0), f2_mul(x1, x1)), f2_inv(f2_add(y1, y1)))
+    else:
+        lam = f2_mul(f2_sub(y2, y1), f2_inv(f2_sub(x2, x1)))
+    x3 = f2_sub(f2_sub(f2_mul(lam, lam), x1), x2)
+    return x3, f2_sub(f2_mul(lam, f2_sub(x1, x3)), y1)
+
+
+def g2_neg(p):
+    return None if p is None else (p[0], ((-p[1][0]) % Q, (-p[1][1]) % Q))
+
+
+def g2_mul(k, p):
+    k %= R
+    acc = None
+    for bit in range(k.bit_length() - 1, -1, -1):
+        acc = g2_add(acc, acc)
+        if (k >> bit) & 1:
+            acc = g2_add(acc, p)
+    return acc
+
+
+def msm_g2(scalars, points):
+    acc = None
+    for k, p in zip(scalars, points):
+        acc = g2_add(acc, g2_mul(int(k), p))
+    return acc

@@ -104,3 +104,18 @@ def test_g1_sum_on_the_host(nlx):
         for p in chosen:
             want = bn.g1_add(want, p)
         assert nlx.bn254_g1_unpack(nlx.bn254_g1_sum(nlx.bn254_g1_pack(chosen))) == want
+
+
+def test_g2_model_and_host_sum(nlx):
+    """the G2 half of the model (EIP-197's generator: on the twist, of order r) and nlx_bn254_g2_sum (host code, no GPU)"""
+    import bn254_py as bn
+    g = bn.G2
+    assert bn.g2_mul(bn.R, g) is None and bn.g2_mul(bn.R - 1, g) == bn.g2_neg(g) and bn.g2_add(g, bn.g2_neg(g)) is None
+    assert bn.g2_mul(7, g) == bn.g2_add(bn.g2_mul(3, g), bn.g2_mul(4, g))
+    rng = random.Random(4)
+    pts = [bn.g2_mul(rng.randrange(1, bn.R), g) for _ in range(4)]
+    for chosen in (pts, pts[:1], [], [pts[0], bn.g2_neg(pts[0])], [pts[1], pts[1], None, pts[2]]):
+        want = None
+        for p in chosen:
+            want = bn.g2_add(want, p)
+        assert nlx.bn254_g2_unpack(nlx.bn254_g2_sum(nlx.bn254_g2_pack(chosen))) == want

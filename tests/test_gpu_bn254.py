@@ -205,3 +205,38 @@ def test_bn254_g1_multiples_and_msm_over_distinct_points(nlx, ctx, bn):
     total = sum(k * (i + 1) for i, k in enumerate(ks)) % bn.R
     got = nlx.bn254_g1_unpack(nlx.bn254_msm_g1(ctx, pts, torch.from_numpy(words.view(np.int64)).to(dev)))
     assert got == bn.g1_mul(total, base)
+
+
+# ---- the G2 multi-scalar multiplication (Groth16's B query, nlx_bn254_msm_g2) ----
+def test_bn254_msm_g2_vs_model(nlx, ctx, bn):
+    """sum_i k_i P_i over G2 (coordinates in Fq2) equals the model's term-by-term sum - random inputs, Montgomery scalars,
+    the edge cases of the G1 test (infinity in the input, repeated and opposite points, extreme scalars, an infinite sum) -
+    and, at 2^14 points drawn from 16 distinct ones, the regrouped sum; linear in the scalars"""
+    import torch
+    rng = random.Random(2222)
+    g = bn.G2
+    pts = [bn.g2_mul(rng.randrange(1, bn.R), g) for _ in range(24)]
+    for n in (1, 2, 24):
+        ks = [rng.randrange(bn.R) for _ in range(n)]
+        want = bn.msm_g2(ks, pts[:n])
+        assert nlx.bn254_g2_unpack(nlx.bn254_msm_g2(ctx, nlx.bn254_g2_pack(pts[:n]), _scalar_words(ks))) == want
+        mont = _scalar_words([bn.to_montgomery(k) for k in ks])
+        assert nlx.bn254_g2_unpack(nlx.bn254_msm_g2(ctx, nlx.bn254_g2_pack(pts[:n]), mont, montgomery=True)) == want
+    p0 = pts[0]
+    for ks, ps in (([0, 1, bn.R - 1, (1 << 253) - 1, 0xFFFF, 0xFFFF0000], pts[:6]), ([5, 7, 9, 11], [p0, None, p0, bn.g2_neg(p0)]),
+                   ([0x1234] * 20, [p0] * 20), ([0x1234] * 2 + [3], [p0, bn.g2_neg(p0), g]), ([0xABCD, 0xABCD], [p0, bn.g2_neg(p0)]),
+                   ([0, 0], pts[:2])):
+        assert nlx.bn254_g2_unpack(nlx.bn254_msm_g2(ctx, nlx.bn254_g2_pack(ps), _scalar_words(ks))) == bn.msm_g2(ks, ps), ks
+    assert nlx.bn254_g2_unpack(nlx.bn254_msm_g2(ctx, np.zeros((0, 16), dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64))) is None
+    n, m = 1 << 14, 16
+    packed = np.tile(nlx.bn254_g2_pack(pts[:m]), (n // m, 1))
+    rs = np.random.RandomState(9)
+    words = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    words[:, 3] &= np.uint64((1 << 60) - 1)
+    ks = [sum(int(words[i, w]) << (64 * w) for w in range(4)) for i in range(n)]
+    want = bn.msm_g2([sum(ks[j::m]) % bn.R for j in range(m)], pts[:m])
+    d_pts = torch.from_numpy(packed.view(np.int64)).to("cuda:%d" % ctx.device)
+    got = nlx.bn254_g2_unpack(nlx.bn254_msm_g2(ctx, d_pts, words))
+    assert got == want
+    twice = _scalar_words([2 * k % bn.R for k in ks])
+    assert nlx.bn254_g2_unpack(nlx.bn254_msm_g2(ctx, d_pts, twice)) == bn.g2_add(got, got)
