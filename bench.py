@@ -1166,14 +1166,14 @@ def run_ntt24_bn254(args, nlx, torch, rank, world, local, dist):
 
 def run_msm24_g2(args, nlx, torch, rank, world, local, dist):
     """--workload msm24 --msm-group g2: one BN254 G2 multi-scalar multiplication of 2^--ntt-log-n points per step (Groth16's B
-    query; nlx_bn254_msm_g2, gnark-crypto G2Affine words).  The points are 4 096 distinct curve points tiled (made by the
+    query; nlx_bn254_msm_g2, gnark-crypto G2Affine words).  The points are 1 024 distinct curve points tiled (made by the
     big-integer model: no device generator exists for G2), the scalars uniform below r; the result is checked against the
     model through the regrouped sum.  One rank."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import bn254_py   # input generation (points on the twist) and the post-timing check only
     log_n = args.ntt_log_n
-    n, m = 1 << log_n, min(4096, 1 << log_n)
+    n, m = 1 << log_n, min(1024, 1 << log_n)     # the post-timing model check costs m G2 scalar multiplications (~30 ms each)
     rng = __import__("random").Random(98)
     acc, step_pt, base = bn254_py.g2_mul(rng.randrange(1, bn254_py.R), bn254_py.G2), bn254_py.g2_mul(rng.randrange(1, bn254_py.R), bn254_py.G2), []
     for _ in range(m):
