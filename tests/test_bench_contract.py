@@ -62,7 +62,9 @@ def test_outer_only_workload_line():
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [("--workload", "stark", "--log-n", "10"), ("--workload", "sha256", "--log-blocks", "4"),
                                   ("--workload", "sha512", "--log-blocks", "3"), ("--workload", "ed25519", "--log-slots", "8"),
-                                  ("--workload", "ntt24", "--ntt-log-n", "18", "--ntt-cols", "4"), ("--workload", "msm24", "--ntt-log-n", "14")])
+                                  ("--workload", "ntt24", "--ntt-log-n", "18", "--ntt-cols", "4"), ("--workload", "msm24", "--ntt-log-n", "14"),
+                                  ("--workload", "msm24", "--msm-group", "g2", "--ntt-log-n", "12"),
+                                  ("--workload", "ntt24", "--ntt-field", "bn254", "--ntt-order", "dit", "--ntt-log-n", "16", "--ntt-cols", "2")])
 def test_secondary_workload_lines(args):
     d = run_bench(*args, "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
     for k in REQUIRED:
