@@ -17,6 +17,7 @@
 //    levels there, and touches HBM once per pass with >=128-byte contiguous segments.
 #include <hip/hip_runtime.h>
 #include "gl.hpp"
+#include "gl32.hpp"
 #include "launch.hpp"
 
 namespace nlx {
@@ -36,7 +37,6 @@ struct PassParams {
     const uint64_t* tw;    // w_N^e, e in [0, N/2), N = 2^log_N = sub-problem size of this pass
     const uint64_t* scale; // optional per-element factor applied on load (indexed like src within a z slice)
     size_t scale_z_stride;
-    uint64_t r16[8];       // w_16^e (forward or inverse), constant twiddles of the register sub-transforms
     uint64_t final_scale;  // multiplied into every output (1 = none)
     const uint64_t* post_scale;  // optional per-element factor applied on store (indexed like dst within a z slice)
     size_t post_scale_z_stride;
@@ -45,6 +45,8 @@ struct PassParams {
     unsigned log_A;        // transform length inside the tile
     unsigned log_T;        // consecutive elements per tile row (strided pass) ; 0 for contiguous
     unsigned log_Q;        // sub-problems per tile (contiguous pass); 0 for strided
+    uint32_t n_cols;       // tile kernels: columns in the batch; a block walks cols_per_block of them at one tile position
+    uint32_t cols_per_block;
 };
 
 __device__ __forceinline__ uint64_t tw_full(const uint64_t* __restrict__ tw, uint32_t e, uint32_t half_N) {
@@ -52,11 +54,47 @@ __device__ __forceinline__ uint64_t tw_full(const uint64_t* __restrict__ tw, uin
     return e < half_N ? tw[e] : gl::P - tw[e - half_N];
 }
 
-// ---- in-register radix-2^g sub-transforms with constant twiddles (w_16 powers) ----
-// DIF: natural in, bit-reversed out.  DIT: bit-reversed in, natural out.  r16[e] = w_16^e (e < 8).
-template <int g>
-__device__ __forceinline__ void dft_dif(uint64_t (&x)[1 << g], const uint64_t (&r16)[8]) {
+// ---- in-register radix-2^g sub-transforms; the constant twiddles (powers of w_16) are powers of TWO ----
+// 2 has order 192 in F_p (2^96 = -1), so the subgroup of order 64 is <8> and every w_16^e is +-2^s: a multiplication by it
+// is a shift and a short reduction instead of a 64 x 64 product.  W16_LOG2 = log_2 of the library's w_16 (set 7:
+// POW2_GEN^(2^28) = 2^156; set 2021: 2^12), its inverse 2^(192 - that); run_passes checks the claim against
+// gl::root_of_unity on the host before the first launch.
+#if NLX_GL_GENERATOR_SET == 7
+constexpr int W16_LOG2 = 156;
+#else
+constexpr int W16_LOG2 = 12;
+#endif
+
+// One wave issues a vector instruction every four cycles whether or not it depends on the one before (MI355X_MICROARCH.md,
+// cycle constants), so interleaving independent butterflies buys nothing - but hipcc's scheduler does it, and the sixteen
+// products it keeps in flight cost the tile kernels ~100 spilled registers.  A fence after every butterfly / product keeps
+// the live set at the data plus one operation's temporaries.
+#define NLX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// x * 2^s mod p for canonical x, 0 <= s < 96 -> canonical
+__device__ __forceinline__ uint64_t mul_pow2(uint64_t x, int s) {
+    if (s == 0) return x;
+    if (s < 32) {  // (x2 : x1 : x0) = x << s, x2 < 2^s:  (x1:x0) + x2 * EPS
+        return gl::canon(gl32::to_u64(gl32::add_w2_eps(x << s, (uint32_t)(x >> (64 - s)))));
+    }
+    if (s == 32) return gl::canon(gl32::to_u64(gl32::add_w2_eps(x << 32, (uint32_t)(x >> 32))));
+    if (s < 64) {  // y = x << (s - 32) = (y2:y1:y0); y * 2^32 = the 128-bit limbs (y2 : y1 : y0 : 0)
+        const int t = s - 32;
+        const uint64_t y = x << t;
+        return gl::canon(gl32::to_u64(gl32::reduce128(0u, (uint32_t)y, (uint32_t)(y >> 32), (uint32_t)(x >> (64 - t)))));
+    }
+    // y = x << (s - 64) = (y2:y1:y0); y * 2^64 = y0 * EPS - y1 - y2 * 2^32  (2^96 = -1): both terms are canonical
+    const int t = s - 64;
+    const uint64_t y = t ? x << t : x;
+    const uint32_t y2 = t ? (uint32_t)(x >> (64 - t)) : 0u;
+    return gl::sub((uint64_t)(uint32_t)y * 0xFFFFFFFFull, ((uint64_t)y2 << 32) | (y >> 32));
+}
+
+// DIF: natural in, bit-reversed out.  DIT: bit-reversed in, natural out.  x points at 2^g canonical values.
+template <int g, bool INV>
+__device__ __forceinline__ void dft_dif(uint64_t* x) {
     constexpr int G = 1 << g;
+    constexpr int L = INV ? 192 - W16_LOG2 : W16_LOG2;
 #pragma unroll
     for (int t = 0; t < g; t++) {
         const int half = G >> (t + 1);
@@ -65,18 +103,19 @@ __device__ __forceinline__ void dft_dif(uint64_t (&x)[1 << g], const uint64_t (&
 #pragma unroll
             for (int u = 0; u < half; u++) {
                 const uint64_t a = x[b + u], c = x[b + u + half];
+                const int e = (u << t) * (16 / G);  // w_{2 half}^u = w_G^(u << t) = w_16^e = +-2^s
+                const int S = (e * L) % 192;
                 x[b + u] = gl::add(a, c);
-                uint64_t d = gl::sub(a, c);
-                const int e = (u << t) * (16 / G);  // w_{2 half}^u = w_G^(u << t) = w_16^(...)
-                if (e != 0) d = gl::mul(d, r16[e]);
-                x[b + u + half] = d;
+                x[b + u + half] = mul_pow2(S >= 96 ? gl::sub(c, a) : gl::sub(a, c), S % 96);
+                NLX_SCHED_FENCE();
             }
         }
     }
 }
-template <int g>
-__device__ __forceinline__ void dft_dit(uint64_t (&x)[1 << g], const uint64_t (&r16)[8]) {
+template <int g, bool INV>
+__device__ __forceinline__ void dft_dit(uint64_t* x) {
     constexpr int G = 1 << g;
+    constexpr int L = INV ? 192 - W16_LOG2 : W16_LOG2;
 #pragma unroll
     for (int t = 0; t < g; t++) {
         const int half = 1 << t;
@@ -85,11 +124,12 @@ __device__ __forceinline__ void dft_dit(uint64_t (&x)[1 << g], const uint64_t (&
 #pragma unroll
             for (int u = 0; u < half; u++) {
                 const uint64_t a = x[b + u];
-                uint64_t c = x[b + u + half];
                 const int e = (u << (g - 1 - t)) * (16 / G);
-                if (e != 0) c = gl::mul(c, r16[e]);
-                x[b + u] = gl::add(a, c);
-                x[b + u + half] = gl::sub(a, c);
+                const int S = (e * L) % 192;
+                const uint64_t c = mul_pow2(x[b + u + half], S % 96);
+                x[b + u] = S >= 96 ? gl::sub(a, c) : gl::add(a, c);
+                x[b + u + half] = S >= 96 ? gl::add(a, c) : gl::sub(a, c);
+                NLX_SCHED_FENCE();
             }
         }
     }
@@ -102,7 +142,7 @@ __device__ __forceinline__ uint32_t lds_pad(uint32_t i) { return i + (i >> 4); }
 // twl[e] = w_A^e (e < A/2) is the tile's root table in LDS: the 15 per-thread twiddle gathers of a
 // group hit LDS banks instead of L1 (measured: global gathers made the pass 2.5x slower than its
 // instruction count).
-template <bool DIT, int g>
+template <bool DIT, bool INV, int g>
 __device__ __forceinline__ void ntt_group(uint64_t* __restrict__ lds, const uint64_t* __restrict__ twl,
                                           const PassParams& p, unsigned log_P, unsigned log_T, uint32_t tile_elems) {
     constexpr int G = 1 << g;
@@ -130,9 +170,9 @@ __device__ __forceinline__ void ntt_group(uint64_t* __restrict__ lds, const uint
                     x[m] = gl::mul(x[m], tw_full(twl, e, half_A));
                 }
             }
-            dft_dit<g>(x, p.r16);
+            dft_dit<g, INV>(x);
         } else {
-            dft_dif<g>(x, p.r16);
+            dft_dif<g, INV>(x);
             if (log_P != 0) {
 #pragma unroll
                 for (int m = 1; m < G; m++) {
@@ -151,7 +191,7 @@ __device__ __forceinline__ void ntt_group(uint64_t* __restrict__ lds, const uint
 // transform over a tile held in LDS, log_A butterfly levels done as radix-16 register groups.
 //   strided pass   : element (j1, jt) of tile (q, t) lives at q*N + j1*M + t*T + jt
 //   contiguous pass: element (qq, j1) of tile `tile` lives at (tile*Q + qq)*A + j1   (M = T = 1)
-template <bool DIT>
+template <bool DIT, bool INV>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
     __shared__ uint64_t lds[TILE + TILE / 16];
     __shared__ uint64_t twl[TILE / 2];
@@ -226,10 +266,10 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
         // DIF: blocks shrink (B = A >> done); DIT: blocks grow (P = 1 << done)
         const unsigned log_P = DIT ? done : (log_A - done - g);
         switch (g) {
-            case 4: ntt_group<DIT, 4>(lds, twl, p, log_P, log_T, tile_elems); break;
-            case 3: ntt_group<DIT, 3>(lds, twl, p, log_P, log_T, tile_elems); break;
-            case 2: ntt_group<DIT, 2>(lds, twl, p, log_P, log_T, tile_elems); break;
-            default: ntt_group<DIT, 1>(lds, twl, p, log_P, log_T, tile_elems); break;
+            case 4: ntt_group<DIT, INV, 4>(lds, twl, p, log_P, log_T, tile_elems); break;
+            case 3: ntt_group<DIT, INV, 3>(lds, twl, p, log_P, log_T, tile_elems); break;
+            case 2: ntt_group<DIT, INV, 2>(lds, twl, p, log_P, log_T, tile_elems); break;
+            default: ntt_group<DIT, INV, 1>(lds, twl, p, log_P, log_T, tile_elems); break;
         }
         done += g;
         __syncthreads();
@@ -276,7 +316,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
 // column j0 of one sub-problem, loads its A elements with A wave-coalesced loads (lanes = consecutive
 // j0), forms the inter-pass twiddles w_N^(j0 * i) by repeated multiplication from ONE coalesced table
 // read (instead of A gathered reads), transforms in registers and stores back in place.
-template <bool DIT, int g>
+template <bool DIT, bool INV, int g>
 __global__ __launch_bounds__(256) void k_ntt_strided_reg(PassParams p) {
     constexpr int G = 1 << g;
     const unsigned log_M = p.log_N - g;
@@ -305,9 +345,9 @@ __global__ __launch_bounds__(256) void k_ntt_strided_reg(PassParams p) {
     if (DIT) {
 #pragma unroll
         for (int m = 1; m < G; m++) x[m] = gl::mul(x[m], pw[__brev((unsigned)m) >> (32 - g)]);
-        dft_dit<g>(x, p.r16);
+        dft_dit<g, INV>(x);
     } else {
-        dft_dif<g>(x, p.r16);
+        dft_dif<g, INV>(x);
 #pragma unroll
         for (int m = 1; m < G; m++) x[m] = gl::mul(x[m], pw[__brev((unsigned)m) >> (32 - g)]);
     }
@@ -319,6 +359,314 @@ __global__ __launch_bounds__(256) void k_ntt_strided_reg(PassParams p) {
         if (p.final_scale != 1) v = gl::mul(v, p.final_scale);
         if (ps) v = gl::mul(v, ps[gi]);
         dst[gi] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile kernels (column length >= 2^12): a block of 256 lanes owns ONE tile position of 4096 elements - sixteen per lane in
+// every radix round - and walks `cols_per_block` columns of the batch through it.  What depends on the position only is
+// made once per block and kept in registers / LDS across the columns: the inter-pass twiddles w_N^(k1 j0) (sixteen per
+// lane, a geometric sequence built from TWO table reads; the generic kernel gathers one value per element and pass from a
+// table of N/2 entries - 64 MB at 2^24), and the rounds' own twiddles.  The first round reads global memory and the last
+// one writes it wherever the round's lane order is the memory order, so an element makes one LDS round trip per exchange
+// between rounds instead of one per round plus a staging copy at either end.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t brev4(uint32_t m) { return __brev(m) >> 28; }
+__device__ __forceinline__ uint64_t mul_f(uint64_t a, uint64_t b) {
+    const uint64_t r = gl::mul(a, b);
+    NLX_SCHED_FENCE();
+    return r;
+}
+// Global memory of the tile kernels goes through buffer instructions: a wave-uniform descriptor per column (SGPRs), ONE
+// lane byte offset per round (a VGPR) and the row of the element as a scalar offset - sixteen accesses cost one address
+// register.  With 64-bit flat addresses hipcc hoists sixteen address pairs per round out of the column loop (64 VGPRs).
+// Columns of the tile kernels are at most 2^28 elements, so byte offsets fit 32 bits.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t buf_t;
+__device__ __forceinline__ buf_t make_buf(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ uint64_t buf_ld(buf_t r, uint32_t voff, uint32_t soff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return (uint64_t)v.x | ((uint64_t)v.y << 32);
+}
+__device__ __forceinline__ void buf_st(buf_t r, uint32_t voff, uint32_t soff, uint64_t x) {
+    u32x2 v;
+    v.x = (uint32_t)x;
+    v.y = (uint32_t)(x >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+__device__ __forceinline__ ulonglong2 buf_ld16(buf_t r, uint32_t voff, uint32_t soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_ulonglong2((uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32));
+}
+__device__ __forceinline__ void buf_st16(buf_t r, uint32_t voff, uint32_t soff, ulonglong2 x) {
+    u32x4 v;
+    v.x = (uint32_t)x.x;
+    v.y = (uint32_t)(x.x >> 32);
+    v.z = (uint32_t)x.y;
+    v.w = (uint32_t)(x.y >> 32);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+
+// Contiguous pass, 12 levels = three radix-16 rounds over the tile [base, base + 4096).  DIF (strides 256, 16, 1): direct
+// load, the store goes through LDS (round 3 leaves a lane with 16 consecutive elements).  DIT (strides 1, 16, 256): the
+// load goes through LDS, direct store.  p.tw = w_4096^e, e < 2048.  LDS positions are padded by one element per sixteen
+// (lds_pad), written out here as lane base + m x constant so that the sixteen accesses of a round share one address register.
+template <bool DIT, bool INV>
+__global__ __launch_bounds__(256, 4) void k_ntt_c12(PassParams p) {
+    __shared__ uint64_t lds[TILE + TILE / 16];
+    __shared__ uint64_t w2[256];   // w_256^(lo * brev4(m)) at [lo][m]
+    const uint32_t tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x << TILE_LOG;
+    const uint64_t* __restrict__ tw = p.tw;
+    // round of stride 256: lane `tid` multiplies element m by w_4096^(tid * brev4(m)) - the same for every column
+    uint64_t W1[16];
+#pragma unroll
+    for (int m = 1; m < 16; m++) W1[m] = tw_full(tw, tid * brev4(m), TILE / 2);
+    w2[tid] = tw_full(tw, 16u * (tid >> 4) * brev4(tid & 15), TILE / 2);
+    __syncthreads();
+    const uint64_t* __restrict__ w2l = w2 + (tid & 15) * 16;
+    uint64_t* __restrict__ l256 = lds + tid + (tid >> 4);                      // + 272 m : element 256 m + tid
+    uint64_t* __restrict__ l16 = lds + (tid >> 4) * 272 + (tid & 15);          // + 17 m  : element 256 c + 16 m + lo
+    uint64_t* __restrict__ l1 = lds + tid * 17;                                // + m     : element 16 tid + m
+    const bool has_scale = p.scale != nullptr, has_post = p.post_scale != nullptr;
+    const buf_t scale = make_buf(has_scale ? p.scale + (size_t)blockIdx.z * p.scale_z_stride + base : nullptr);
+    const buf_t post = make_buf(has_post ? p.post_scale + (size_t)blockIdx.z * p.post_scale_z_stride + base : nullptr);
+    const uint32_t col_end = min(p.n_cols, (blockIdx.y + 1) * p.cols_per_block);
+    for (uint32_t col = blockIdx.y * p.cols_per_block; col < col_end; col++) {
+        const buf_t src = make_buf(p.src + (size_t)col * p.src_stride + (size_t)blockIdx.z * p.src_z_stride + base);
+        const buf_t dst = make_buf(p.dst + (size_t)col * p.dst_stride + (size_t)blockIdx.z * p.dst_z_stride + base);
+        uint64_t x[16];
+        if (!DIT) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = buf_ld(src, tid * 8, m * 2048);
+            if (has_scale) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], buf_ld(scale, tid * 8, m * 2048));
+            }
+            dft_dif<4, INV>(x);
+#pragma unroll
+            for (int m = 1; m < 16; m++) x[m] = mul_f(x[m], W1[m]);
+#pragma unroll
+            for (int m = 0; m < 16; m++) l256[272 * m] = x[m];
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = l16[17 * m];
+            dft_dif<4, INV>(x);
+#pragma unroll
+            for (int m = 1; m < 16; m++) x[m] = mul_f(x[m], w2l[m]);
+#pragma unroll
+            for (int m = 0; m < 16; m++) l16[17 * m] = x[m];
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = l1[m];
+            dft_dif<4, INV>(x);
+            if (p.final_scale != 1) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], p.final_scale);
+            }
+#pragma unroll
+            for (int m = 0; m < 16; m++) l1[m] = x[m];
+            __syncthreads();
+            // pairs (2 i2, 2 i2 + 1), i2 = tid + 256 i: lds_pad(2 i2) = 2 tid + (tid >> 3) + 544 i
+            const uint64_t* __restrict__ lp = lds + 2 * tid + (tid >> 3);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                ulonglong2 v = make_ulonglong2(lp[544 * i], lp[544 * i + 1]);
+                if (has_post) {
+                    const ulonglong2 sc = buf_ld16(post, tid * 16, i * 4096);
+                    v.x = mul_f(v.x, sc.x);
+                    v.y = mul_f(v.y, sc.y);
+                }
+                buf_st16(dst, tid * 16, i * 4096, v);
+            }
+            __syncthreads();
+        } else {
+            uint64_t* __restrict__ lp = lds + 2 * tid + (tid >> 3);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                ulonglong2 v = buf_ld16(src, tid * 16, i * 4096);
+                if (has_scale) {
+                    const ulonglong2 sc = buf_ld16(scale, tid * 16, i * 4096);
+                    v.x = mul_f(v.x, sc.x);
+                    v.y = mul_f(v.y, sc.y);
+                }
+                lp[544 * i] = v.x;
+                lp[544 * i + 1] = v.y;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = l1[m];
+            dft_dit<4, INV>(x);
+#pragma unroll
+            for (int m = 0; m < 16; m++) l1[m] = x[m];
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = l16[17 * m];
+#pragma unroll
+            for (int m = 1; m < 16; m++) x[m] = mul_f(x[m], w2l[m]);
+            dft_dit<4, INV>(x);
+#pragma unroll
+            for (int m = 0; m < 16; m++) l16[17 * m] = x[m];
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = l256[272 * m];
+#pragma unroll
+            for (int m = 1; m < 16; m++) x[m] = mul_f(x[m], W1[m]);
+            dft_dit<4, INV>(x);
+            if (p.final_scale != 1) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], p.final_scale);
+            }
+            if (has_post) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], buf_ld(post, tid * 8, m * 2048));
+            }
+#pragma unroll
+            for (int m = 0; m < 16; m++) buf_st(dst, tid * 8, m * 2048, x[m]);
+            __syncthreads();
+        }
+    }
+}
+
+// Strided pass of 4 + REM levels (REM = 1 .. 4): element (j1, jt) of the tile lives at q N + j1 M + j0_base + jt with
+// A = 2^(4 + REM) values of j1 and T = 4096 / A consecutive jt (rows of >= 128 bytes).  Two rounds: a radix-2^REM round at
+// stride 16 and a radix-16 round at stride 1; the latter carries the inter-pass twiddle w_N^(bitrev_A(j1) (j0_base + jt))
+// - DIF: last, multiplied into the store; DIT: first, multiplied into the load - and every round's lanes are consecutive
+// jt, so both ends touch global memory directly: one LDS exchange per element and pass.
+template <bool DIT, bool INV, int REM>
+__global__ __launch_bounds__(256, 4) void k_ntt_s(PassParams p) {
+    constexpr unsigned LOG_A = 4 + REM, LOG_T = TILE_LOG - LOG_A, T = 1u << LOG_T, G1 = 1u << REM, ITEMS = 16 >> REM;
+    constexpr unsigned ROW = T + T / 16;   // LDS elements per padded row of T
+    __shared__ uint64_t lds[TILE + TILE / 16];
+    __shared__ uint64_t wa[16 << REM];   // w_A^(lo * bitrev_REM(m)) at [lo][m]
+    const uint32_t tid = threadIdx.x;
+    const unsigned log_M = p.log_N - LOG_A;
+    const uint32_t half_N = 1u << (p.log_N - 1);
+    const uint32_t q = blockIdx.x >> (log_M - LOG_T), t = blockIdx.x & ((1u << (log_M - LOG_T)) - 1);
+    const uint32_t j0_base = t << LOG_T;
+    const size_t base = ((size_t)q << p.log_N) + j0_base;
+    const uint64_t* __restrict__ tw = p.tw;
+    for (uint32_t i = tid; i < (16u << REM); i += 256)
+        wa[i] = tw_full(tw, ((i >> REM) * (__brev(i & (G1 - 1)) >> (32 - REM))) << log_M, half_N);
+    // radix-16 round: lane = (c, jt), elements j1 = 16 c + m; bitrev_A(j1) = brev4(m) 2^REM + bitrev_REM(c)
+    const uint32_t jt4 = tid & (T - 1), c4 = tid >> LOG_T;
+    uint64_t F[16];
+    {
+        const uint32_t j0 = j0_base + jt4;
+        const uint64_t p0 = tw[(size_t)j0 * (__brev(c4) >> (32 - REM))], p1 = tw[(size_t)j0 << REM];
+        uint64_t f = p0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            F[brev4(i)] = f;
+            if (i < 15) f = mul_f(f, p1);
+        }
+    }
+    __syncthreads();
+    // addresses: a wave-uniform row pointer (scalar arithmetic: + m rows) plus ONE lane byte offset per round; padded LDS
+    // positions as lane base + m x constant (an instruction's immediate offset)
+    const uint32_t mrow = 8u << log_M;                               // bytes between j1 and j1 + 1
+    const uint32_t g4 = (((c4 * 16) << log_M) + jt4) * 8;             // radix-16 round: row m
+    uint64_t* __restrict__ l4 = lds + c4 * 16 * ROW + jt4 + (jt4 >> 4);   // + m ROW
+    const bool has_scale = p.scale != nullptr, has_post = p.post_scale != nullptr;
+    const buf_t scale = make_buf(has_scale ? p.scale + (size_t)blockIdx.z * p.scale_z_stride + base : nullptr);
+    const buf_t post = make_buf(has_post ? p.post_scale + (size_t)blockIdx.z * p.post_scale_z_stride + base : nullptr);
+    const uint32_t col_end = min(p.n_cols, (blockIdx.y + 1) * p.cols_per_block);
+    for (uint32_t col = blockIdx.y * p.cols_per_block; col < col_end; col++) {
+        const buf_t src = make_buf(p.src + (size_t)col * p.src_stride + (size_t)blockIdx.z * p.src_z_stride + base);
+        const buf_t dst = make_buf(p.dst + (size_t)col * p.dst_stride + (size_t)blockIdx.z * p.dst_z_stride + base);
+        uint64_t x[16];
+        if (!DIT) {
+            // radix-2^REM round at stride 16: item w = (lo, jt), elements j1 = 16 m + lo
+#pragma unroll
+            for (unsigned it = 0; it < ITEMS; it++) {
+                const uint32_t w = tid + 256 * it, jt = w & (T - 1), lo = w >> LOG_T;
+                const uint32_t g1 = ((lo << log_M) + jt) * 8;
+#pragma unroll
+                for (unsigned m = 0; m < G1; m++) x[it * G1 + m] = buf_ld(src, g1, m * 16 * mrow);
+            }
+            if (has_scale) {
+#pragma unroll
+                for (unsigned it = 0; it < ITEMS; it++) {
+                    const uint32_t w = tid + 256 * it, jt = w & (T - 1), lo = w >> LOG_T;
+                    const uint32_t g1 = ((lo << log_M) + jt) * 8;
+#pragma unroll
+                    for (unsigned m = 0; m < G1; m++) x[it * G1 + m] = mul_f(x[it * G1 + m], buf_ld(scale, g1, m * 16 * mrow));
+                }
+            }
+#pragma unroll
+            for (unsigned it = 0; it < ITEMS; it++) {
+                const uint32_t w = tid + 256 * it, jt = w & (T - 1), lo = w >> LOG_T;
+                uint64_t* __restrict__ l1 = lds + lo * ROW + jt + (jt >> 4);   // + 16 m ROW
+                dft_dif<REM, INV>(x + it * G1);
+#pragma unroll
+                for (unsigned m = 1; m < G1; m++) x[it * G1 + m] = mul_f(x[it * G1 + m], wa[lo * G1 + m]);
+#pragma unroll
+                for (unsigned m = 0; m < G1; m++) l1[16 * ROW * m] = x[it * G1 + m];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = l4[ROW * m];
+            dft_dif<4, INV>(x);
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], F[m]);
+            if (p.final_scale != 1) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], p.final_scale);
+            }
+            if (has_post) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], buf_ld(post, g4, m * mrow));
+            }
+#pragma unroll
+            for (int m = 0; m < 16; m++) buf_st(dst, g4, m * mrow, x[m]);
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = buf_ld(src, g4, m * mrow);
+            if (has_scale) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], buf_ld(scale, g4, m * mrow));
+            }
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], F[m]);
+            dft_dit<4, INV>(x);
+#pragma unroll
+            for (int m = 0; m < 16; m++) l4[ROW * m] = x[m];
+            __syncthreads();
+#pragma unroll
+            for (unsigned it = 0; it < ITEMS; it++) {
+                const uint32_t w = tid + 256 * it, jt = w & (T - 1), lo = w >> LOG_T;
+                const uint64_t* __restrict__ l1 = lds + lo * ROW + jt + (jt >> 4);
+#pragma unroll
+                for (unsigned m = 0; m < G1; m++) x[it * G1 + m] = l1[16 * ROW * m];
+            }
+#pragma unroll
+            for (unsigned it = 0; it < ITEMS; it++) {
+                const uint32_t w = tid + 256 * it, lo = w >> LOG_T;
+#pragma unroll
+                for (unsigned m = 1; m < G1; m++) x[it * G1 + m] = mul_f(x[it * G1 + m], wa[lo * G1 + m]);
+                dft_dit<REM, INV>(x + it * G1);
+            }
+            if (p.final_scale != 1) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], p.final_scale);
+            }
+#pragma unroll
+            for (unsigned it = 0; it < ITEMS; it++) {
+                const uint32_t w = tid + 256 * it, jt = w & (T - 1), lo = w >> LOG_T;
+                const uint32_t g1 = ((lo << log_M) + jt) * 8;
+                if (has_post) {
+#pragma unroll
+                    for (unsigned m = 0; m < G1; m++) x[it * G1 + m] = mul_f(x[it * G1 + m], buf_ld(post, g1, m * 16 * mrow));
+                }
+#pragma unroll
+                for (unsigned m = 0; m < G1; m++) buf_st(dst, g1, m * 16 * mrow, x[it * G1 + m]);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -342,14 +690,30 @@ static Plan make_plan(unsigned log_n) {
     return pl;
 }
 
-template <bool DIT>
-static void run_passes(hipStream_t st, const NttTables& tb, bool inverse_roots, const uint64_t* src,
-                       size_t src_stride, size_t src_z_stride, uint64_t* dst, size_t dst_stride,
-                       size_t dst_z_stride, uint32_t n_cols, uint32_t n_z, unsigned log_n, const uint64_t* scale,
-                       size_t scale_z_stride, uint64_t final_scale, const uint64_t* post_scale = nullptr,
-                       size_t post_scale_z_stride = 0) {
+// the constant twiddles of the register sub-transforms are compiled in as powers of two: check them once per process
+static bool w16_is_the_compiled_power_of_two() {
+    static const bool ok = [] {
+        const uint64_t w16 = gl::root_of_unity(4);
+        return gl::pow(2, W16_LOG2) == w16 && gl::pow(2, 192 - W16_LOG2) == gl::inv(w16);
+    }();
+    return ok;
+}
+
+// columns a block walks at one tile position: as many as leave the grid a few blocks per CU slot (1024 resident blocks)
+static uint32_t pick_cols_per_block(size_t tiles_times_z, uint32_t n_cols) {
+    uint32_t cpb = 16;
+    while (cpb > 1 && tiles_times_z * ((n_cols + cpb - 1) / cpb) < 4096) cpb >>= 1;
+    return cpb < n_cols ? cpb : n_cols;
+}
+
+template <bool DIT, bool INV>
+static void run_passes_t(hipStream_t st, const NttTables& tb, const uint64_t* src, size_t src_stride, size_t src_z_stride,
+                         uint64_t* dst, size_t dst_stride, size_t dst_z_stride, uint32_t n_cols, uint32_t n_z, unsigned log_n,
+                         const uint64_t* scale, size_t scale_z_stride, uint64_t final_scale, const uint64_t* post_scale,
+                         size_t post_scale_z_stride) {
+    if (!w16_is_the_compiled_power_of_two()) abort();   // a build with the wrong NLX_GL_GENERATOR_SET table: never at run time
     Plan pl = make_plan(log_n);
-    const uint64_t* const* roots = inverse_roots ? tb.inv : tb.fwd;
+    const uint64_t* const* roots = INV ? tb.inv : tb.fwd;
     // DIF order: strided passes from the largest sub-problem down, contiguous pass last.
     // DIT order: contiguous pass first, strided passes with growing sub-problem.
     // Sub-problem sizes: contiguous N = 2^c; strided pass i (i = 1..) N_i = 2^(c + bits_1 + ... + bits_i).
@@ -374,17 +738,13 @@ static void run_passes(hipStream_t st, const NttTables& tb, bool inverse_roots, 
         p.log_N = logN_of[i];
         p.log_A = pl.log_A[i];
         p.tw = p.log_N >= 1 ? roots[p.log_N] : nullptr;
-        {
-            uint64_t w16 = gl::root_of_unity(4);
-            if (inverse_roots) w16 = gl::inv(w16);
-            uint64_t acc = 1;
-            for (int e = 0; e < 8; e++) { p.r16[e] = acc; acc = gl::mul(acc, w16); }
-        }
         p.scale = first ? scale : nullptr;
         p.scale_z_stride = scale_z_stride;
         p.final_scale = last ? final_scale : 1;
         p.post_scale = last ? post_scale : nullptr;
         p.post_scale_z_stride = post_scale_z_stride;
+        p.n_cols = n_cols;
+        p.cols_per_block = 1;
         unsigned tiles;
         if (i == 0) {  // contiguous
             p.log_T = 0;
@@ -405,15 +765,45 @@ static void run_passes(hipStream_t st, const NttTables& tb, bool inverse_roots, 
             const size_t threads = ((size_t)1 << log_n) >> p.log_A;
             const dim3 grid((unsigned)((threads + 255) / 256), n_cols, n_z);
             switch (p.log_A) {
-                case 4: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, 4>), grid, dim3(256), 0, st, p); break;
-                case 3: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, 3>), grid, dim3(256), 0, st, p); break;
-                case 2: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, 2>), grid, dim3(256), 0, st, p); break;
-                default: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, 1>), grid, dim3(256), 0, st, p); break;
+                case 4: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, INV, 4>), grid, dim3(256), 0, st, p); break;
+                case 3: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, INV, 3>), grid, dim3(256), 0, st, p); break;
+                case 2: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, INV, 2>), grid, dim3(256), 0, st, p); break;
+                default: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, INV, 1>), grid, dim3(256), 0, st, p); break;
             }
             continue;
         }
-        hipLaunchKernelGGL(k_ntt_pass<DIT>, dim3(tiles, n_cols, n_z), dim3(NTT_THREADS), 0, st, p);
+        if (log_n >= TILE_LOG && log_n <= 28) {
+            // tile kernels (32-bit byte offsets inside a column): the contiguous pass has 12 levels, a strided one 5 .. 8 over tiles of 2^(12 - log_A) columns
+            p.cols_per_block = pick_cols_per_block((size_t)tiles * n_z, n_cols);
+            const dim3 grid(tiles, (n_cols + p.cols_per_block - 1) / p.cols_per_block, n_z);
+            if (i == 0) {
+                hipLaunchKernelGGL((k_ntt_c12<DIT, INV>), grid, dim3(256), 0, st, p);
+            } else {
+                switch (p.log_A) {
+                    case 5: hipLaunchKernelGGL((k_ntt_s<DIT, INV, 1>), grid, dim3(256), 0, st, p); break;
+                    case 6: hipLaunchKernelGGL((k_ntt_s<DIT, INV, 2>), grid, dim3(256), 0, st, p); break;
+                    case 7: hipLaunchKernelGGL((k_ntt_s<DIT, INV, 3>), grid, dim3(256), 0, st, p); break;
+                    default: hipLaunchKernelGGL((k_ntt_s<DIT, INV, 4>), grid, dim3(256), 0, st, p); break;
+                }
+            }
+            continue;
+        }
+        hipLaunchKernelGGL((k_ntt_pass<DIT, INV>), dim3(tiles, n_cols, n_z), dim3(NTT_THREADS), 0, st, p);
     }
+}
+
+template <bool DIT>
+static void run_passes(hipStream_t st, const NttTables& tb, bool inverse_roots, const uint64_t* src,
+                       size_t src_stride, size_t src_z_stride, uint64_t* dst, size_t dst_stride,
+                       size_t dst_z_stride, uint32_t n_cols, uint32_t n_z, unsigned log_n, const uint64_t* scale,
+                       size_t scale_z_stride, uint64_t final_scale, const uint64_t* post_scale = nullptr,
+                       size_t post_scale_z_stride = 0) {
+    if (inverse_roots)
+        run_passes_t<DIT, true>(st, tb, src, src_stride, src_z_stride, dst, dst_stride, dst_z_stride, n_cols, n_z, log_n, scale,
+                                scale_z_stride, final_scale, post_scale, post_scale_z_stride);
+    else
+        run_passes_t<DIT, false>(st, tb, src, src_stride, src_z_stride, dst, dst_stride, dst_z_stride, n_cols, n_z, log_n, scale,
+                                 scale_z_stride, final_scale, post_scale, post_scale_z_stride);
 }
 
 void launch_intt_dif(hipStream_t st, const NttTables& tb, const uint64_t* src, size_t src_stride, uint64_t* dst,
