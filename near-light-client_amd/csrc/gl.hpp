@@ -38,15 +38,67 @@ GL_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
 #endif
 }
 
-GL_HD uint64_t canon(uint64_t a) { return a >= P ? a - P : a; }
+#if defined(__HIP__)
+// Device forms with hand-placed carries (overloads of the host forms below: clang resolves __host__ / __device__ per side).  Every vector instruction of this code issues at the same ~2 ns whatever it is
+// (gl32.hpp), so the forms below are chosen by COUNT: hipcc's u64 code for the three functions needs 4 / 6 / 6.
+// x + EPS carries out of 2^64 exactly when x >= P = 2^64 - EPS, and the sum is then x - P: one multiply-add (-1 * 1 + x,
+// carry into an SGPR pair) and two selects.
+__device__ __forceinline__ uint64_t canon(uint64_t a) {
+    uint64_t t, c;
+    asm("v_mad_u64_u32 %[t], %[c], -1, 1, %[a]" : [t] "=&v"(t), [c] "=s"(c) : [a] "v"(a));
+    uint32_t r0, r1;
+    asm("v_cndmask_b32_e64 %[r0], %[a0], %[t0], %[c]\n\t"
+        "v_cndmask_b32_e64 %[r1], %[a1], %[t1], %[c]"
+        : [r0] "=&v"(r0), [r1] "=v"(r1)
+        : [a0] "v"((uint32_t)a), [a1] "v"((uint32_t)(a >> 32)), [t0] "v"((uint32_t)t), [t1] "v"((uint32_t)(t >> 32)), [c] "s"(c));
+    return ((uint64_t)r1 << 32) | r0;
+}
+// canonical + canonical -> canonical: s = a + b, reduced when the addition carried or s >= P (5 vector instructions)
+__device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) {
+    uint32_t s0, s1;
+    uint64_t c1, c2, t;
+    asm("v_add_co_u32 %[s0], vcc, %[a0], %[b0]\n\t"
+        "v_addc_co_u32 %[s1], %[c1], %[a1], %[b1], vcc"
+        : [s0] "=&v"(s0), [s1] "=&v"(s1), [c1] "=s"(c1)
+        : [a0] "v"((uint32_t)a), [a1] "v"((uint32_t)(a >> 32)), [b0] "v"((uint32_t)b), [b1] "v"((uint32_t)(b >> 32))
+        : "vcc");
+    const uint64_t s = ((uint64_t)s1 << 32) | s0;
+    asm("v_mad_u64_u32 %[t], %[c], -1, 1, %[s]" : [t] "=&v"(t), [c] "=s"(c2) : [s] "v"(s));
+    const uint64_t c = c1 | c2;
+    uint32_t r0, r1;
+    asm("v_cndmask_b32_e64 %[r0], %[s0], %[t0], %[c]\n\t"
+        "v_cndmask_b32_e64 %[r1], %[s1], %[t1], %[c]"
+        : [r0] "=&v"(r0), [r1] "=v"(r1)
+        : [s0] "v"(s0), [s1] "v"(s1), [t0] "v"((uint32_t)t), [t1] "v"((uint32_t)(t >> 32)), [c] "s"(c));
+    return ((uint64_t)r1 << 32) | r0;
+}
+// (any u64) - canonical -> a value congruent to the difference, canonical when a is: a borrow is worth -EPS, and
+// a - b + 2^64 >= 2^64 - (P - 1) > EPS, so the correction cannot borrow again (5 vector instructions)
+__device__ __forceinline__ uint64_t sub(uint64_t a, uint64_t b) {
+    uint32_t d0, d1, m;
+    asm("v_sub_co_u32 %[d0], vcc, %[a0], %[b0]\n\t"
+        "v_subb_co_u32 %[d1], vcc, %[a1], %[b1], vcc\n\t"
+        "v_cndmask_b32_e64 %[m], 0, -1, vcc\n\t"
+        "v_sub_co_u32 %[d0], vcc, %[d0], %[m]\n\t"
+        "v_subbrev_co_u32 %[d1], vcc, 0, %[d1], vcc"
+        : [d0] "=&v"(d0), [d1] "=&v"(d1), [m] "=&v"(m)
+        : [a0] "v"((uint32_t)a), [a1] "v"((uint32_t)(a >> 32)), [b0] "v"((uint32_t)b), [b1] "v"((uint32_t)(b >> 32))
+        : "vcc");
+    return ((uint64_t)d1 << 32) | d0;
+}
+#define GL_H __host__ inline
+#else
+#define GL_H inline
+#endif
+GL_H uint64_t canon(uint64_t a) { return a >= P ? a - P : a; }
 
 // canonical + canonical -> canonical
-GL_HD uint64_t add(uint64_t a, uint64_t b) {
+GL_H uint64_t add(uint64_t a, uint64_t b) {
     uint64_t s = a + b;
     return (s < a || s >= P) ? s - P : s;
 }
 // canonical - canonical -> canonical
-GL_HD uint64_t sub(uint64_t a, uint64_t b) {
+GL_H uint64_t sub(uint64_t a, uint64_t b) {
     uint64_t d = a - b;
     return a < b ? d + P : d;
 }

@@ -700,7 +700,10 @@ constexpr int QW = NLX_QW;
 
 __global__ __launch_bounds__(64 * QW, NLX_QMINW) void k_quotient(QuotientParams p) {
     extern __shared__ uint64_t q_lds[];
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the wave index is the same in all 64 lanes, but hipcc cannot know that of threadIdx.x >> 6: without readfirstlane the item
+    // list is read with vector loads and EVERYTHING decoded from it - the gate switch, every gate's loops, every column index -
+    // is compiled as divergent control flow on vector registers (120 exec-masked branches, 111 spilled registers)
+    const uint32_t lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned log_L = p.log_n + p.rate_bits;
     const size_t n = (size_t)1 << p.log_n, L = (size_t)1 << log_L;
     const size_t pos_raw = (size_t)blockIdx.x * 64 + lane;
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(64 * QW, NLX_QMINW) void k_quotient(QuotientParams 
     acc.ap1 = ap1 + T0;
     const uint32_t* work = p.work + (size_t)wv * p.work_stride;
     for (uint32_t wi = 0;; wi++) {
-        const uint32_t word = work[wi];  // wave-uniform: item in the low half, for a gate evaluated in parts the part mask above it
+        const uint32_t word = __builtin_amdgcn_readfirstlane(work[wi]);  // wave-uniform: item in the low half, for a gate evaluated in parts the part mask above it
         if (word == 0xFFFFFFFFu) break;
         const uint32_t item = word & 0xFFFFu, parts = (word >> 16) ? (word >> 16) : 7u;
         if (item < p.n_gates) {
