@@ -16,8 +16,10 @@
 #if defined(__HIP__)
 #include <hip/hip_runtime.h>
 #define GL_HD __host__ __device__ __forceinline__
+#define GL_H __host__ inline   // host half of a function that has a hand-written __device__ overload
 #else
 #define GL_HD inline
+#define GL_H inline
 #endif
 
 namespace gl {
@@ -86,9 +88,6 @@ __device__ __forceinline__ uint64_t sub(uint64_t a, uint64_t b) {
         : "vcc");
     return ((uint64_t)d1 << 32) | d0;
 }
-#define GL_H __host__ inline
-#else
-#define GL_H inline
 #endif
 GL_H uint64_t canon(uint64_t a) { return a >= P ? a - P : a; }
 
@@ -105,7 +104,22 @@ GL_H uint64_t sub(uint64_t a, uint64_t b) {
 GL_HD uint64_t neg(uint64_t a) { return a ? P - a : 0; }
 
 // loose + canonical -> loose (single conditional fix-up; see plonky2 GoldilocksField::add)
-GL_HD uint64_t add_loose(uint64_t a, uint64_t c) {
+#if defined(__HIP__)
+// four vector instructions: the carry becomes a mask, and mask * 1 + s adds EPS where it is set
+__device__ __forceinline__ uint64_t add_loose(uint64_t a, uint64_t c) {
+    uint32_t s0, s1, m;
+    asm("v_add_co_u32 %[s0], vcc, %[a0], %[c0]\n\t"
+        "v_addc_co_u32 %[s1], vcc, %[a1], %[c1], vcc\n\t"
+        "v_cndmask_b32_e64 %[m], 0, -1, vcc"
+        : [s0] "=&v"(s0), [s1] "=&v"(s1), [m] "=v"(m)
+        : [a0] "v"((uint32_t)a), [a1] "v"((uint32_t)(a >> 32)), [c0] "v"((uint32_t)c), [c1] "v"((uint32_t)(c >> 32))
+        : "vcc");
+    uint64_t r;
+    asm("v_mad_u64_u32 %[r], vcc, %[m], 1, %[s]" : [r] "=&v"(r) : [m] "v"(m), [s] "v"(((uint64_t)s1 << 32) | s0) : "vcc");
+    return r;
+}
+#endif
+GL_H uint64_t add_loose(uint64_t a, uint64_t c) {
     uint64_t s = a + c;
     return s < a ? s + EPS : s;
 }

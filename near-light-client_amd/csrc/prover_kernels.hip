@@ -233,21 +233,60 @@ struct GateAcc {
             : "vcc");
     }
     __device__ __forceinline__ void emit(uint64_t c) { emit_at(k++, c); }
-    // sum for challenge ch: A0 + (A1 + A2) 2^32 + A3 2^64 + K0 2^64 + (K1 + K2) 2^96 + K3 2^128 (mod p), with
-    // 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32
-    __device__ __forceinline__ uint64_t finish(int ch) const {
-        const uint64_t* A = a + 4 * ch;
-        const uint32_t* K = kc + 4 * ch;
-        const uint64_t m1 = gl::canon(A[1]), m2 = gl::canon(A[2]);
-        uint64_t r = gl::canon(A[0]);
-        r = gl::add(r, gl::reduce128(m1 << 32, m1 >> 32));
-        r = gl::add(r, gl::reduce128(m2 << 32, m2 >> 32));
-        r = gl::add(r, gl::mul(gl::canon(A[3]), gl::EPS));
-        r = gl::add(r, gl::mul((uint64_t)K[0], gl::EPS));
-        r = gl::sub(r, (uint64_t)K[1] + K[2]);
-        r = gl::sub(r, (uint64_t)K[3] << 32);
-        return r;
+    // sum for challenge ch: A0 + (A1 + A2) 2^32 + A3 2^64 + K0 2^64 + (K1 + K2) 2^96 + K3 2^128 (mod p)
+    __device__ __forceinline__ uint64_t finish(int ch) const { return fold_columns(a + 4 * ch, kc + 4 * ch); }
+    // The four 64-bit columns and their carry counts as ONE 160-bit integer (t4 : t3 : t2 : t1 : t0), reduced with
+    // 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32: (t1:t0) + t2 EPS - t3 - t4 2^32.  ~35 instructions (the first version
+    // reduced every column on its own: ~110, twice per item of k_quotient).
+    static __device__ __forceinline__ uint64_t fold_columns(const uint64_t* A, const uint32_t* K) {
+        uint32_t t1, t2, t3, t4, m0, m1, cm;
+        asm("v_add_co_u32 %[m0], vcc, %[a1l], %[a2l]\n\t"
+            "v_addc_co_u32 %[m1], vcc, %[a1h], %[a2h], vcc\n\t"
+            "v_addc_co_u32 %[cm], vcc, 0, 0, vcc\n\t"
+            "v_add_co_u32 %[t1], vcc, %[a0h], %[m0]\n\t"
+            "v_addc_co_u32 %[t2], vcc, %[m1], %[a3l], vcc\n\t"
+            "v_addc_co_u32 %[t3], vcc, %[cm], %[a3h], vcc\n\t"
+            "v_addc_co_u32 %[t4], vcc, 0, %[k3], vcc\n\t"
+            "v_add_co_u32 %[t2], vcc, %[t2], %[k0]\n\t"
+            "v_addc_co_u32 %[t3], vcc, %[t3], %[k1], vcc\n\t"
+            "v_addc_co_u32 %[t4], vcc, 0, %[t4], vcc\n\t"
+            "v_add_co_u32 %[t3], vcc, %[t3], %[k2]\n\t"
+            "v_addc_co_u32 %[t4], vcc, 0, %[t4], vcc"
+            : [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [m0] "=&v"(m0), [m1] "=&v"(m1), [cm] "=&v"(cm)
+            : [a0h] "v"((uint32_t)(A[0] >> 32)), [a1l] "v"((uint32_t)A[1]), [a1h] "v"((uint32_t)(A[1] >> 32)), [a2l] "v"((uint32_t)A[2]),
+              [a2h] "v"((uint32_t)(A[2] >> 32)), [a3l] "v"((uint32_t)A[3]), [a3h] "v"((uint32_t)(A[3] >> 32)), [k0] "v"(K[0]),
+              [k1] "v"(K[1]), [k2] "v"(K[2]), [k3] "v"(K[3])
+            : "vcc");
+        const uint64_t r = gl::canon(gl32::to_u64(gl32::reduce128((uint32_t)A[0], t1, t2, t3)));
+        return gl::sub(r, (uint64_t)t4 << 32);
     }
+};
+
+// sum_i x_i c_i for wave-uniform constants c_i, as ONE running 160-bit sum (GateAcc's columns for a single sum): eight
+// instructions per product and one reduction, where a reduced multiply-add costs 24
+struct DotAcc {
+    uint64_t a[4];
+    uint32_t kc[4];
+    __device__ __forceinline__ void reset() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[i] = 0; kc[i] = 0; }
+    }
+    __device__ __forceinline__ void mac(uint64_t x, uint64_t c) {   // x: any u64, c: wave-uniform
+        const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
+        asm("v_mad_u64_u32 %[a0], vcc, %[x0], %[c0], %[a0]\n\t"
+            "v_addc_co_u32 %[k0], vcc, 0, %[k0], vcc\n\t"
+            "v_mad_u64_u32 %[a1], vcc, %[x0], %[c1], %[a1]\n\t"
+            "v_addc_co_u32 %[k1], vcc, 0, %[k1], vcc\n\t"
+            "v_mad_u64_u32 %[a2], vcc, %[x1], %[c0], %[a2]\n\t"
+            "v_addc_co_u32 %[k2], vcc, 0, %[k2], vcc\n\t"
+            "v_mad_u64_u32 %[a3], vcc, %[x1], %[c1], %[a3]\n\t"
+            "v_addc_co_u32 %[k3], vcc, 0, %[k3], vcc"
+            : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [k0] "+v"(kc[0]), [k1] "+v"(kc[1]),
+              [k2] "+v"(kc[2]), [k3] "+v"(kc[3])
+            : [x0] "v"(x0), [x1] "v"(x1), [c0] "s"((uint32_t)c), [c1] "s"((uint32_t)(c >> 32))
+            : "vcc");
+    }
+    __device__ __forceinline__ uint64_t value() const { return GateAcc::fold_columns(a, kc); }   // canonical
 };
 
 // sum_j x_j 2^(s_j) kept as a 128-bit integer and reduced once (Horner recombination of range-check limbs
@@ -331,18 +370,17 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t p
 #pragma unroll
         for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], FAST_FIRST[i]);
         {
+            // st[1..11] <- M^T st[1..11] (mds_partial_layer_init): each output column is ONE running 160-bit sum over the
+            // eleven products by wave-uniform constants, reduced once
             uint64_t res[12];
             res[0] = st[0];
 #pragma unroll
-            for (int c = 1; c < 12; c++) res[c] = 0;
-#pragma unroll 1
-            for (int r = 1; r < 12; r++) {
-                // dynamic r: select st[r] without indexing registers dynamically
-                uint64_t sr = 0;
+            for (int c = 1; c < 12; c++) {
+                DotAcc dot;
+                dot.reset();
 #pragma unroll
-                for (int t = 1; t < 12; t++) sr = (t == r) ? st[t] : sr;
-#pragma unroll
-                for (int c = 1; c < 12; c++) res[c] = gl::add(res[c], gl::mul(sr, FAST_INIT[r - 1][c - 1]));
+                for (int r = 1; r < 12; r++) dot.mac(st[r], FAST_INIT[r - 1][c - 1]);
+                res[c] = dot.value();
             }
 #pragma unroll
             for (int i = 0; i < 12; i++) st[i] = res[i];
@@ -353,13 +391,16 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t p
             acc.emit_at(41 + r, gl::sub(st[0], in));
             uint64_t s0 = sbox7c(in);
             if (r < 21) s0 = gl::add_loose(s0, FAST_RC[r]);
-            uint64_t d = gl::mul(s0, 25);
+            // new st[0] = 25 s0 + sum_i st[i] w_hat[i]: one running sum, one reduction; st[i] += s0 v[i]
+            DotAcc dot;
+            dot.reset();
+            dot.mac(s0, 25);
 #pragma unroll
             for (int i = 1; i < 12; i++) {
-                d = gl::add(d, gl::mul(st[i], FAST_W[r][i - 1]));
+                dot.mac(st[i], FAST_W[r][i - 1]);
                 st[i] = gl::add(st[i], gl::mul(s0, FAST_VS[r][i - 1]));
             }
-            st[0] = d;
+            st[0] = dot.value();
         }
 #pragma unroll
         for (int i = 0; i < 12; i++)
@@ -763,12 +804,14 @@ __global__ __launch_bounds__(64 * QW, NLX_QMINW) void k_quotient(QuotientParams 
             uint64_t accv = z_x;
 #pragma unroll 1
             for (uint32_t q = 0; q < n_chunks; q++) {
+                // numerator / denominator products in loose form (any u64 congruent to the value): w + gamma is shared and
+                // canonical, a product plus it needs ONE carry fix-up (gl::add_loose), and nothing here is compared
                 uint64_t nm = 1, dn = 1;
                 for (uint32_t j = q * p.chunk; j < (q + 1) * p.chunk && j < p.routed; j++) {
-                    const uint64_t w = W(j);
+                    const uint64_t wg = gl::add(W(j), gamma);
                     const uint64_t sg = p.cs[(size_t)(p.n_consts_all + j) * L + pos];
-                    nm = gl::mul(nm, gl::add(gl::add(w, gl::mul(bx, p.k_is[j])), gamma));
-                    dn = gl::mul(dn, gl::add(gl::add(w, gl::mul(beta, sg)), gamma));
+                    nm = gl::mul_loose(nm, gl::add_loose(gl::mul_loose(bx, p.k_is[j]), wg));
+                    dn = gl::mul_loose(dn, gl::add_loose(gl::mul_loose(beta, sg), wg));
                 }
                 const uint64_t new_acc = (q + 1 < n_chunks) ? ZS(nc + c * npp + q) : z_gx;
                 const uint64_t term = gl::sub(gl::mul(accv, nm), gl::mul(new_acc, dn));
