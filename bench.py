@@ -54,10 +54,10 @@ VALU_PEAK_NOTE = ("1 024 SIMDs x 64 lanes / (10 528 irreducible 32x32 multiply-a
 
 
 def stored_traffic(key, alg_bytes):
-    """HBM bytes per launch from the committed PMC pass (profiles/r02_pmc_traffic.json: FETCH_SIZE x 2 per the microarch
-    guide, a separate rocprofv3 --pmc run of this command): measured ratio traffic / algorithmic bytes x this run's
-    algorithmic bytes.  Not measured in this process (counters need their own run) - labelled "stored"."""
-    for name in ("r02_pmc_traffic_v5.json", "r02_pmc_traffic_v2.json"):
+    """HBM bytes per launch from the committed PMC pass (profiles/r03_pmc_traffic_outer_2p18.json: FETCH_SIZE x 2 + WRITE_SIZE
+    per the microarch guide, separate rocprofv3 --pmc runs of the outer proof at the headline's 2^18 rows, tools/pmc_ratio.py):
+    measured ratio traffic / algorithmic bytes x this run's algorithmic bytes.  Not measured in this process (counters need their own run) - labelled "stored"."""
+    for name in ("r03_pmc_traffic_outer_2p18.json", "r02_pmc_traffic_v5.json", "r02_pmc_traffic_v2.json"):
         prof = os.path.join(ROOT, "profiles", name)
         if os.path.exists(prof):
             try:
@@ -822,7 +822,11 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
                                        "note": "2 steps, one proof at a time, after the timed region"},
             "ms_one_proof_at_a_time": {"sha256": round(parts[0], 2), "sha512": round(parts[1], 2), "ed25519": round(parts[2], 2),
                                        "outer_plonky2": round(parts[3], 2), "step": round(seq_ms, 2)},
-            "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kstats.items()},
+            # additive per-step costs: the one-proof-at-a-time pass after the timed region (two steps, HIP events on each
+            # context's own stream).  The events of the TIMED region bracket kernels of four concurrent streams: those windows
+            # overlap and must not be read as shares of ms_per_step - kept under their own name.
+            "kernel_ms_per_step": {k: round(v[1] / 2, 3) for k, v in ks1.items()},
+            "kernel_event_ms_overlapping": {k: round(v[1] / args.steps, 3) for k, v in kstats.items()},
             "outer_stage_ms_last_proof": {k: round(v, 3) for k, v in cd.stage_times()},
         }
         # the plonky2 proof alone at 2^16 rows (round 1's headline shape), same code, one proof at a time and three in flight

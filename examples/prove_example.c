@@ -28,6 +28,23 @@ int main(int argc, char** argv) {
     nlx_ctx* ctx = NULL;
     CHECK(nlx_ctx_create(0, &ctx));
 
+    /* Failures are return codes, never aborts (include/nlx.h): a failed HOST allocation inside the library (a C++ exception
+     * there, stopped at the ABI), a device allocation and a commitment far beyond the GPU's memory all come back negative,
+     * and the context stays usable for the proof below. */
+    if (argc > 2 && strcmp(argv[2], "nomem") == 0) {
+        nlx_buf* big = NULL;
+        nlx_commit* cm = NULL;
+        uint64_t one_col[4] = {1, 2, 3, 4}, cap_out[4 * 16];
+        const int32_t r0 = nlx_abi_selftest(0);
+        const int32_t r1 = nlx_buf_create(ctx, (size_t)1 << 50, &big);
+        const int32_t r2 = nlx_commit_from_values(ctx, one_col, 65535, 27, 3, 4, cap_out, &cm);   /* 65 535 columns x 2^27 rows x 9 tables */
+        if (r0 != NLX_E_NOMEM || r1 >= 0 || r2 >= 0 || big != NULL || cm != NULL) {
+            fprintf(stderr, "expected negative return codes, got %d %d %d\n", r0, r1, r2);
+            return 3;
+        }
+        printf("refused: host allocation %d, device buffer %d (%s), commitment %d\n", r0, r1, nlx_strerror(r1), r2);
+    }
+
     nlx_synth_params sp;
     memset(&sp, 0, sizeof sp);
     sp.log_n = log_n;

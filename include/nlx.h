@@ -51,6 +51,14 @@ const char* nlx_strerror(int32_t code);
  * plonky2_field::goldilocks_field::GoldilocksField::{MULTIPLICATIVE_GROUP_GENERATOR, POWER_OF_TWO_GENERATOR}
  * (crate pinned at /root/reference/Cargo.lock:4912-4914); a caller checks it against its own constants once. */
 void nlx_field_generators(uint64_t out[2]);
+/* Self-test of the "never throws" rule on the caller's platform: raises a C++ exception INSIDE the library - kind 0: a
+ * real failed host allocation (a std::vector larger than the address space), 1: std::runtime_error, 2: a non-standard
+ * object - and returns what the entry points' guard makes of it: NLX_E_NOMEM for kind 0, NLX_E_INVAL otherwise
+ * (NLX_E_RANGE for an unknown kind).  Needs no context and no GPU.  Every extern "C" definition of the library is a
+ * function-try-block with this guard (csrc/ctx.hpp NLX_TRY / NLX_CATCH), so a std::bad_alloc in the host-side
+ * orchestration reaches a Rust / Go caller as a return code (crates/protocol/src/prelude.rs:1 maps
+ * such codes to anyhow::Error at the caller), never as an unwind through foreign frames. */
+int32_t nlx_abi_selftest(int32_t kind);
 
 /* ---- context ---- */
 int32_t nlx_ctx_create(int device, nlx_ctx** out);

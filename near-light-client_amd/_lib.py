@@ -40,6 +40,7 @@ c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 SIGNATURES = {
     "nlx_version": (ctypes.c_uint32, []),
     "nlx_strerror": (ctypes.c_char_p, [ctypes.c_int32]),
+    "nlx_abi_selftest": (ctypes.c_int32, [ctypes.c_int32]),
     "nlx_field_generators": (None, [ctypes.POINTER(ctypes.c_uint64)]),
     "nlx_ctx_create": (ctypes.c_int32, [ctypes.c_int, c_void_pp]),
     "nlx_ctx_destroy": (None, [ctypes.c_void_p]),

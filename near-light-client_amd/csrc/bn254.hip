@@ -464,7 +464,7 @@ using nlx::bn::Fr;
 extern "C" {
 
 int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags,
-                                  const uint64_t* coset_shift) {
+                                  const uint64_t* coset_shift) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (n_cols == 0) return NLX_OK;
     if (!cols) return ctx->fail(NLX_E_INVAL, "cols is NULL");
@@ -630,10 +630,10 @@ int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, u
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return ctx->hip_fail(le, "kernel launch");
     return NLX_OK;
-}
+} NLX_CATCH(ctx)
 
-int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags) {
+int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags) NLX_TRY {
     return nlx_bn254_ntt_batch_coset(ctx, cols, n_cols, log_n, inverse, flags, nullptr);
-}
+} NLX_CATCH(ctx)
 
 }  // extern "C"

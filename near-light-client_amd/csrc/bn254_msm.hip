@@ -540,21 +540,21 @@ int32_t affine_sum(const uint64_t* points, uint64_t n, uint64_t* out) {
 }  // namespace
 
 extern "C" int32_t nlx_bn254_msm_g1(nlx_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t flags,
-                                    uint64_t out[8]) {
+                                    uint64_t out[8]) NLX_TRY {
     return msm_run<f29::F1, msm::H1, 256>(ctx, points, scalars, n, flags, out, msm::k_msm_buckets, "bn254_msm_g1");
-}
+} NLX_CATCH(ctx)
 extern "C" int32_t nlx_bn254_msm_g2(nlx_ctx* ctx, const uint64_t* points, const uint64_t* scalars, uint64_t n, uint32_t flags,
-                                    uint64_t out[16]) {
+                                    uint64_t out[16]) NLX_TRY {
     return msm_run<f29::F2, msm::H2, 128>(ctx, points, scalars, n, flags, out, msm::k_msm_buckets_g2, "bn254_msm_g2");
-}
+} NLX_CATCH(ctx)
 
 // Sum of n affine points on the host (gnark-crypto layouts as above): what joins the partial results of an MSM whose points
 // were split over several GPUs - one addition per rank.
-extern "C" int32_t nlx_bn254_g1_sum(const uint64_t* points, uint64_t n, uint64_t out[8]) { return affine_sum<msm::H1>(points, n, out); }
-extern "C" int32_t nlx_bn254_g2_sum(const uint64_t* points, uint64_t n, uint64_t out[16]) { return affine_sum<msm::H2>(points, n, out); }
+extern "C" int32_t nlx_bn254_g1_sum(const uint64_t* points, uint64_t n, uint64_t out[8]) NLX_TRY { return affine_sum<msm::H1>(points, n, out); } NLX_CATCH(nullptr)
+extern "C" int32_t nlx_bn254_g2_sum(const uint64_t* points, uint64_t n, uint64_t out[16]) NLX_TRY { return affine_sum<msm::H2>(points, n, out); } NLX_CATCH(nullptr)
 
 // out[i] = (i + 1) P, i < n, as G1Affine words (Montgomery), on the device: n distinct curve points for tests and benches.
-extern "C" int32_t nlx_bn254_g1_multiples(nlx_ctx* ctx, const uint64_t base[8], uint64_t n, uint64_t* out) {
+extern "C" int32_t nlx_bn254_g1_multiples(nlx_ctx* ctx, const uint64_t base[8], uint64_t n, uint64_t* out) NLX_TRY {
     using namespace nlx::msm;
     if (!ctx) return NLX_E_INVAL;
     if (!base || (n && !out)) return ctx->fail(NLX_E_INVAL, "NULL argument");
@@ -592,4 +592,4 @@ extern "C" int32_t nlx_bn254_g1_multiples(nlx_ctx* ctx, const uint64_t base[8], 
     for (void* p : {(void*)d_base, (void*)d_jac, (void*)d_prefix})
         if (p) ctx->release(p);
     return rc;
-}
+} NLX_CATCH(ctx)

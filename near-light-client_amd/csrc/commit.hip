@@ -112,7 +112,7 @@ using namespace nlx;
 
 extern "C" {
 
-int32_t nlx_field_ops(nlx_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+int32_t nlx_field_ops(nlx_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (n == 0) return NLX_OK;
     if (!a || !b || !out) return ctx->fail(NLX_E_INVAL, "NULL buffer");
@@ -126,9 +126,9 @@ int32_t nlx_field_ops(nlx_ctx* ctx, const uint64_t* a, const uint64_t* b, size_t
     if (rc) return rc;
     NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NLX_OK;
-}
+} NLX_CATCH(ctx)
 
-int32_t nlx_poseidon_permute_batch(nlx_ctx* ctx, uint64_t* states, size_t n) {
+int32_t nlx_poseidon_permute_batch(nlx_ctx* ctx, uint64_t* states, size_t n) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (n == 0) return NLX_OK;
     if (!states) return ctx->fail(NLX_E_INVAL, "states is NULL");
@@ -140,9 +140,9 @@ int32_t nlx_poseidon_permute_batch(nlx_ctx* ctx, uint64_t* states, size_t n) {
     if (rc) return rc;
     NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NLX_OK;
-}
+} NLX_CATCH(ctx)
 
-int32_t nlx_hash_rows(nlx_ctx* ctx, const uint64_t* rows, size_t n_rows, size_t row_len, uint64_t* digests_out) {
+int32_t nlx_hash_rows(nlx_ctx* ctx, const uint64_t* rows, size_t n_rows, size_t row_len, uint64_t* digests_out) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (n_rows == 0) return NLX_OK;
     if (!digests_out || (!rows && row_len)) return ctx->fail(NLX_E_INVAL, "NULL buffer");
@@ -157,15 +157,15 @@ int32_t nlx_hash_rows(nlx_ctx* ctx, const uint64_t* rows, size_t n_rows, size_t 
     if (rc) return rc;
     NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NLX_OK;
-}
+} NLX_CATCH(ctx)
 
-size_t nlx_merkle_digest_words(size_t n_leaves, uint32_t cap_height) {
+size_t nlx_merkle_digest_words(size_t n_leaves, uint32_t cap_height) NLX_TRY {
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1)) || cap_height > 63) return 0;
     return merkle_digest_words(n_leaves, cap_height);
-}
+} NLX_CATCH_VALUE(nullptr, 0)
 
 int32_t nlx_merkle_build(nlx_ctx* ctx, const uint64_t* leaves, size_t n_leaves, size_t leaf_len, uint32_t cap_height,
-                         uint64_t* digests_out, uint64_t* cap_out) {
+                         uint64_t* digests_out, uint64_t* cap_out) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return ctx->fail(NLX_E_INVAL, "n_leaves must be a power of two");
     if (cap_height > 63 || ((size_t)1 << cap_height) > n_leaves)
@@ -194,9 +194,9 @@ int32_t nlx_merkle_build(nlx_ctx* ctx, const uint64_t* leaves, size_t n_leaves, 
     if (rc) return rc;
     if (e != hipSuccess) return ctx->hip_fail(e, "hipStreamSynchronize");
     return NLX_OK;
-}
+} NLX_CATCH(ctx)
 
-int32_t nlx_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint64_t coset_shift) {
+int32_t nlx_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint64_t coset_shift) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (n_cols == 0) return NLX_OK;
     if (!cols) return ctx->fail(NLX_E_INVAL, "cols is NULL");
@@ -238,10 +238,10 @@ int32_t nlx_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_
     if (rc) return rc;
     NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NLX_OK;
-}
+} NLX_CATCH(ctx)
 
 int32_t nlx_ntt_split_level(nlx_ctx* ctx, uint64_t* mine, const uint64_t* theirs, size_t n_cols, uint32_t log_n, uint32_t world_log,
-                            uint32_t rank, uint32_t level) {
+                            uint32_t rank, uint32_t level) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (n_cols == 0) return NLX_OK;
     if (!mine || !theirs) return ctx->fail(NLX_E_INVAL, "NULL slice");
@@ -260,7 +260,7 @@ int32_t nlx_ntt_split_level(nlx_ctx* ctx, uint64_t* mine, const uint64_t* theirs
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return ctx->hip_fail(le, "kernel launch");
     return NLX_OK;
-}
+} NLX_CATCH(ctx)
 
 static int32_t commit_api(nlx_ctx* ctx, const uint64_t* data, size_t n_cols, uint32_t log_n, uint32_t rate_bits,
                           uint32_t cap_height, uint64_t* cap_out, nlx_commit** out, CommitInput kind) {
@@ -289,24 +289,24 @@ static int32_t commit_api(nlx_ctx* ctx, const uint64_t* data, size_t n_cols, uin
 }
 
 int32_t nlx_commit_from_values(nlx_ctx* ctx, const uint64_t* values, size_t n_cols, uint32_t log_n,
-                               uint32_t rate_bits, uint32_t cap_height, uint64_t* cap_out, nlx_commit** out) {
+                               uint32_t rate_bits, uint32_t cap_height, uint64_t* cap_out, nlx_commit** out) NLX_TRY {
     return commit_api(ctx, values, n_cols, log_n, rate_bits, cap_height, cap_out, out, CommitInput::ValuesNatural);
-}
+} NLX_CATCH(ctx)
 
 int32_t nlx_commit_from_coeffs(nlx_ctx* ctx, const uint64_t* coeffs, size_t n_cols, uint32_t log_n,
-                               uint32_t rate_bits, uint32_t cap_height, uint64_t* cap_out, nlx_commit** out) {
+                               uint32_t rate_bits, uint32_t cap_height, uint64_t* cap_out, nlx_commit** out) NLX_TRY {
     return commit_api(ctx, coeffs, n_cols, log_n, rate_bits, cap_height, cap_out, out, CommitInput::CoeffsNatural);
-}
+} NLX_CATCH(ctx)
 
-void nlx_commit_destroy(nlx_commit* c) {
+void nlx_commit_destroy(nlx_commit* c) NLX_TRY {
     if (!c) return;
     c->ctx->release(c->coeffs_br);
     c->ctx->release(c->lde);
     c->ctx->release(c->digests);
     delete c;
-}
+} NLX_CATCH_VOID(nullptr)
 
-int32_t nlx_commit_get_coeffs(nlx_commit* c, uint64_t* coeffs_out) {
+int32_t nlx_commit_get_coeffs(nlx_commit* c, uint64_t* coeffs_out) NLX_TRY {
     if (!c || !coeffs_out) return NLX_E_INVAL;
     nlx_ctx* ctx = c->ctx;
     (void)hipSetDevice(ctx->device);
@@ -318,9 +318,9 @@ int32_t nlx_commit_get_coeffs(nlx_commit* c, uint64_t* coeffs_out) {
     if (rc) return rc;
     NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
-int32_t nlx_commit_get_cap(nlx_commit* c, uint64_t* cap_out) {
+int32_t nlx_commit_get_cap(nlx_commit* c, uint64_t* cap_out) NLX_TRY {
     if (!c || !cap_out) return NLX_E_INVAL;
     nlx_ctx* ctx = c->ctx;
     (void)hipSetDevice(ctx->device);
@@ -328,9 +328,9 @@ int32_t nlx_commit_get_cap(nlx_commit* c, uint64_t* cap_out) {
     if (rc) return rc;
     NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
-int32_t nlx_commit_open_rows(nlx_commit* c, const uint64_t* idx, size_t k, uint64_t* rows_out, uint64_t* paths_out) {
+int32_t nlx_commit_open_rows(nlx_commit* c, const uint64_t* idx, size_t k, uint64_t* rows_out, uint64_t* paths_out) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     nlx_ctx* ctx = c->ctx;
     if (k == 0) return NLX_OK;
@@ -358,9 +358,9 @@ int32_t nlx_commit_open_rows(nlx_commit* c, const uint64_t* idx, size_t k, uint6
     if (rc) return rc;
     NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
-int32_t nlx_commit_eval_at(nlx_commit* c, const uint64_t zeta[2], uint64_t* out_ext) {
+int32_t nlx_commit_eval_at(nlx_commit* c, const uint64_t zeta[2], uint64_t* out_ext) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     nlx_ctx* ctx = c->ctx;
     if (!zeta || !out_ext) return ctx->fail(NLX_E_INVAL, "NULL buffer");
@@ -377,9 +377,9 @@ int32_t nlx_commit_eval_at(nlx_commit* c, const uint64_t zeta[2], uint64_t* out_
     if (rc) return rc;
     NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
-int32_t nlx_commit_get_leaves(nlx_commit* c, uint64_t* leaves_out) {
+int32_t nlx_commit_get_leaves(nlx_commit* c, uint64_t* leaves_out) NLX_TRY {
     if (!c || !leaves_out) return NLX_E_INVAL;
     nlx_ctx* ctx = c->ctx;
     (void)hipSetDevice(ctx->device);
@@ -390,9 +390,9 @@ int32_t nlx_commit_get_leaves(nlx_commit* c, uint64_t* leaves_out) {
     if (rc) return rc;
     NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
-int32_t nlx_commit_get_digests(nlx_commit* c, uint64_t* digests_out) {
+int32_t nlx_commit_get_digests(nlx_commit* c, uint64_t* digests_out) NLX_TRY {
     if (!c || !digests_out) return NLX_E_INVAL;
     nlx_ctx* ctx = c->ctx;
     (void)hipSetDevice(ctx->device);
@@ -400,6 +400,6 @@ int32_t nlx_commit_get_digests(nlx_commit* c, uint64_t* digests_out) {
     if (rc) return rc;
     NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
 }  // extern "C"

@@ -1,6 +1,7 @@
 // Context implementation: device selection (gfx950 only, no CPU fallback), caching allocator,
 // lazily built twiddle / coset-scale tables.
 #include "ctx.hpp"
+#include <stdexcept>
 #include <cstring>
 #include <new>
 #include "gl.hpp"
@@ -56,8 +57,11 @@ int32_t nlx_ctx::ensure_tables(unsigned log_n) {
     for (unsigned k = tables.max_log + 1; k <= log_n; k++) {
         size_t half = (size_t)1 << (k - 1);
         uint64_t* f = (uint64_t*)alloc(half * 8);
-        uint64_t* i = (uint64_t*)alloc(half * 8);
-        if (!f || !i) return NLX_E_NOMEM;
+        uint64_t* i = f ? (uint64_t*)alloc(half * 8) : nullptr;
+        if (!f || !i) {
+            release(f);   // a half-built level is not kept: the table stays complete up to max_log
+            return NLX_E_NOMEM;
+        }
         uint64_t w = gl::root_of_unity(k);
         nlx::launch_fill_powers(stream, f, half, w, 1);
         nlx::launch_fill_powers(stream, i, half, gl::inv(w), 1);
@@ -82,13 +86,25 @@ int32_t nlx_ctx::get_coset_scale(unsigned log_n, unsigned rate_bits, const uint6
 }
 
 int32_t nlx_ctx::get_nat_scale(unsigned log_n, uint64_t shift, const uint64_t** out) {
+    // a bounded cache (the four most recently built tables): a caller that walks random coset shifts at 2^24 points would
+    // otherwise grow the context by 128 MB per call.  An evicted table goes back to the context's allocator; work already
+    // queued on the stream that reads it is ordered before any reuse of the block (one stream per context).
     auto key = std::make_pair((uint32_t)log_n, shift);
     auto it = nat_scale.find(key);
     if (it == nat_scale.end()) {
+        while (nat_scale_order.size() >= 4) {
+            auto old = nat_scale.find(nat_scale_order.front());
+            nat_scale_order.erase(nat_scale_order.begin());
+            if (old != nat_scale.end()) {
+                release(old->second);
+                nat_scale.erase(old);
+            }
+        }
         uint64_t* t = (uint64_t*)alloc((size_t)8 << log_n);
         if (!t) return NLX_E_NOMEM;
         nlx::launch_fill_powers(stream, t, (size_t)1 << log_n, shift, 1);
         it = nat_scale.emplace(key, t).first;
+        nat_scale_order.push_back(key);
     }
     *out = it->second;
     return NLX_OK;
@@ -170,14 +186,27 @@ Staged::~Staged() {
 
 extern "C" {
 
-uint32_t nlx_version(void) { return (0u << 16) | 3u; }
+uint32_t nlx_version(void) NLX_TRY { return (0u << 16) | 3u; } NLX_CATCH_VALUE(nullptr, 0)
 
-void nlx_field_generators(uint64_t out[2]) {
+void nlx_field_generators(uint64_t out[2]) NLX_TRY {
     out[0] = gl::GEN;
     out[1] = gl::POW2_GEN;
-}
+} NLX_CATCH_VOID(nullptr)
 
-const char* nlx_strerror(int32_t code) {
+int32_t nlx_abi_selftest(int32_t kind) NLX_TRY {
+    if (kind == 0) {
+        std::vector<uint64_t> v;
+        v.resize(v.max_size() / 2);   // std::bad_alloc (or std::length_error on a platform whose max_size is smaller)
+        return v[v.size() - 1] != 0 ? NLX_E_HIP : NLX_OK;   // not reached
+    }
+    if (kind == 1) throw std::runtime_error("nlx_abi_selftest");
+    if (kind == 2) throw 42;
+    return NLX_E_RANGE;
+} catch (const std::length_error&) {
+    return NLX_E_NOMEM;
+} NLX_CATCH(nullptr)
+
+const char* nlx_strerror(int32_t code) NLX_TRY {
     switch (code) {
         case NLX_OK: return "ok";
         case NLX_E_INVAL: return "invalid argument";
@@ -187,9 +216,9 @@ const char* nlx_strerror(int32_t code) {
         case NLX_E_UNSUPPORTED: return "unsupported";
         default: return "unknown error";
     }
-}
+} NLX_CATCH_VALUE(nullptr, "exception inside the library")
 
-int32_t nlx_ctx_create(int device, nlx_ctx** out) {
+int32_t nlx_ctx_create(int device, nlx_ctx** out) NLX_TRY {
     if (!out) return NLX_E_INVAL;
     *out = nullptr;
     int count = 0;
@@ -213,9 +242,9 @@ int32_t nlx_ctx_create(int device, nlx_ctx** out) {
     c->stream = c->own_stream;
     *out = c;
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
-int32_t nlx_ctx_set_priority(nlx_ctx* c, int high) {
+int32_t nlx_ctx_set_priority(nlx_ctx* c, int high) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     (void)hipSetDevice(c->device);
     if (c->stream != c->own_stream) return c->fail(NLX_E_INVAL, "the context runs on a caller-provided stream (nlx_ctx_set_stream)");
@@ -227,9 +256,9 @@ int32_t nlx_ctx_set_priority(nlx_ctx* c, int high) {
     (void)hipStreamDestroy(c->own_stream);
     c->own_stream = c->stream = s;
     return NLX_OK;
-}
+} NLX_CATCH(c)
 
-int32_t nlx_ctx_set_cu_mask(nlx_ctx* c, const uint32_t* mask, uint32_t n_words) {
+int32_t nlx_ctx_set_cu_mask(nlx_ctx* c, const uint32_t* mask, uint32_t n_words) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     if (!mask || n_words == 0 || n_words > 32) return c->fail(NLX_E_INVAL, "CU mask: 1..32 words");
     uint32_t any = 0;
@@ -243,9 +272,9 @@ int32_t nlx_ctx_set_cu_mask(nlx_ctx* c, const uint32_t* mask, uint32_t n_words) 
     (void)hipStreamDestroy(c->own_stream);
     c->own_stream = c->stream = s;
     return NLX_OK;
-}
+} NLX_CATCH(c)
 
-void nlx_ctx_destroy(nlx_ctx* c) {
+void nlx_ctx_destroy(nlx_ctx* c) NLX_TRY {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -256,19 +285,19 @@ void nlx_ctx_destroy(nlx_ctx* c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
-}
+} NLX_CATCH_VOID(nullptr)
 
-const char* nlx_last_error(const nlx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* nlx_last_error(const nlx_ctx* c) NLX_TRY { return c ? c->err.c_str() : "null context"; } NLX_CATCH_VALUE(nullptr, "exception inside the library")
 
-int32_t nlx_ctx_set_stream(nlx_ctx* c, void* hip_stream) {
+int32_t nlx_ctx_set_stream(nlx_ctx* c, void* hip_stream) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     (void)hipSetDevice(c->device);
     NLX_HIP(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return NLX_OK;
-}
+} NLX_CATCH(c)
 
-int32_t nlx_ctx_kernel_timing(nlx_ctx* c, int enable) {
+int32_t nlx_ctx_kernel_timing(nlx_ctx* c, int enable) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     (void)hipSetDevice(c->device);
     NLX_HIP(c, hipStreamSynchronize(c->stream));
@@ -279,9 +308,9 @@ int32_t nlx_ctx_kernel_timing(nlx_ctx* c, int enable) {
     c->samples.clear();
     c->kernel_timing = enable != 0;
     return NLX_OK;
-}
+} NLX_CATCH(c)
 
-int32_t nlx_ctx_kernel_stats(nlx_ctx* c, const char* name, uint64_t* calls, double* total_ms, double* alg_bytes) {
+int32_t nlx_ctx_kernel_stats(nlx_ctx* c, const char* name, uint64_t* calls, double* total_ms, double* alg_bytes) NLX_TRY {
     if (!c || !name) return NLX_E_INVAL;
     (void)hipSetDevice(c->device);
     NLX_HIP(c, hipStreamSynchronize(c->stream));
@@ -299,16 +328,16 @@ int32_t nlx_ctx_kernel_stats(nlx_ctx* c, const char* name, uint64_t* calls, doub
     if (total_ms) *total_ms = ms;
     if (alg_bytes) *alg_bytes = bytes;
     return NLX_OK;
-}
+} NLX_CATCH(c)
 
-int32_t nlx_ctx_kernel_units(nlx_ctx* c, const char* name, double* units) {
+int32_t nlx_ctx_kernel_units(nlx_ctx* c, const char* name, double* units) NLX_TRY {
     if (!c || !name || !units) return NLX_E_INVAL;
     double u = 0;
     for (auto& ks : c->samples)
         if (strcmp(ks.name, name) == 0) u += ks.units;
     *units = u;
     return NLX_OK;
-}
+} NLX_CATCH(c)
 
 // ---- nlx_buf: device buffers for callers without their own HIP bindings ----
 struct nlx_buf {
@@ -317,7 +346,7 @@ struct nlx_buf {
     size_t bytes;
 };
 
-int32_t nlx_buf_create(nlx_ctx* c, size_t bytes, nlx_buf** out) {
+int32_t nlx_buf_create(nlx_ctx* c, size_t bytes, nlx_buf** out) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     if (!out || bytes == 0) return c->fail(NLX_E_INVAL, "nlx_buf_create: NULL out or zero size");
     *out = nullptr;
@@ -328,20 +357,20 @@ int32_t nlx_buf_create(nlx_ctx* c, size_t bytes, nlx_buf** out) {
     if (!b) { c->release(p); return c->fail(NLX_E_NOMEM, "host allocation failed"); }
     *out = b;
     return NLX_OK;
-}
+} NLX_CATCH(c)
 
-void nlx_buf_destroy(nlx_buf* b) {
+void nlx_buf_destroy(nlx_buf* b) NLX_TRY {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     b->ctx->release(b->dev);
     delete b;
-}
+} NLX_CATCH_VOID(nullptr)
 
-void* nlx_buf_device_ptr(const nlx_buf* b) { return b ? b->dev : nullptr; }
-size_t nlx_buf_size(const nlx_buf* b) { return b ? b->bytes : 0; }
+void* nlx_buf_device_ptr(const nlx_buf* b) NLX_TRY { return b ? b->dev : nullptr; } NLX_CATCH_VALUE(nullptr, nullptr)
+size_t nlx_buf_size(const nlx_buf* b) NLX_TRY { return b ? b->bytes : 0; } NLX_CATCH_VALUE(nullptr, 0)
 
-int32_t nlx_buf_upload(nlx_buf* b, size_t offset, const void* src, size_t bytes) {
+int32_t nlx_buf_upload(nlx_buf* b, size_t offset, const void* src, size_t bytes) NLX_TRY {
     if (!b) return NLX_E_INVAL;
     nlx_ctx* c = b->ctx;
     if (!src && bytes) return c->fail(NLX_E_INVAL, "NULL source");
@@ -350,9 +379,9 @@ int32_t nlx_buf_upload(nlx_buf* b, size_t offset, const void* src, size_t bytes)
     NLX_HIP(c, hipMemcpyAsync((uint8_t*)b->dev + offset, src, bytes, hipMemcpyHostToDevice, c->stream));
     NLX_HIP(c, hipStreamSynchronize(c->stream));
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
-int32_t nlx_buf_download(nlx_buf* b, size_t offset, void* dst, size_t bytes) {
+int32_t nlx_buf_download(nlx_buf* b, size_t offset, void* dst, size_t bytes) NLX_TRY {
     if (!b) return NLX_E_INVAL;
     nlx_ctx* c = b->ctx;
     if (!dst && bytes) return c->fail(NLX_E_INVAL, "NULL destination");
@@ -361,28 +390,28 @@ int32_t nlx_buf_download(nlx_buf* b, size_t offset, void* dst, size_t bytes) {
     NLX_HIP(c, hipMemcpyAsync(dst, (const uint8_t*)b->dev + offset, bytes, hipMemcpyDeviceToHost, c->stream));
     NLX_HIP(c, hipStreamSynchronize(c->stream));
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
-int32_t nlx_ctx_trim(nlx_ctx* c) {
+int32_t nlx_ctx_trim(nlx_ctx* c) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     (void)hipSetDevice(c->device);
     c->trim();
     return NLX_OK;
-}
+} NLX_CATCH(c)
 
-int32_t nlx_ctx_memory(const nlx_ctx* c, size_t* reserved_bytes, size_t* in_use_bytes) {
+int32_t nlx_ctx_memory(const nlx_ctx* c, size_t* reserved_bytes, size_t* in_use_bytes) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     size_t used = 0;
     for (const auto& kv : c->live_blocks) used += kv.second;
     if (reserved_bytes) *reserved_bytes = c->bytes_reserved;
     if (in_use_bytes) *in_use_bytes = used;
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
-int32_t nlx_ctx_synchronize(nlx_ctx* c) {
+int32_t nlx_ctx_synchronize(nlx_ctx* c) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     NLX_HIP(c, hipStreamSynchronize(c->stream));
     return NLX_OK;
-}
+} NLX_CATCH(c)
 
 }  // extern "C"

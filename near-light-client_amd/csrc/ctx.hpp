@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <exception>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 #include "../../include/nlx.h"
@@ -28,6 +30,7 @@ struct nlx_ctx {
     std::map<uint32_t, uint64_t*> coset_scale;
     // shift^i (natural order) tables for nlx_ntt_batch keyed by (log_n, shift)
     std::map<std::pair<uint32_t, uint64_t>, uint64_t*> nat_scale;
+    std::vector<std::pair<uint32_t, uint64_t>> nat_scale_order;   // oldest first: at most four tables are kept
     // BN254 Fr twiddle table (csrc/bn254.hip) keyed by 2 log_n + inverse: w_n^e for e < n/2
     std::map<uint32_t, void*> bn254_tables;
 
@@ -66,6 +69,37 @@ struct nlx_ctx {
     int32_t get_nat_scale(unsigned log_n, uint64_t shift, const uint64_t** out);
 
 };
+
+// ---- the ABI never throws or aborts (include/nlx.h, SURVEY.md §8b: Rust / Go callers map return codes to their own errors) ----
+// Host code behind the entry points uses std::vector / map / string / thread; every extern "C" definition is therefore a
+// function-try-block:   int32_t nlx_foo(nlx_ctx* ctx, ...) NLX_TRY { ... } NLX_CATCH(ctx)
+// std::bad_alloc -> NLX_E_NOMEM, anything else -> NLX_E_INVAL, with nlx_last_error set when the call has a context.
+namespace nlx {
+inline void on_exception(nlx_ctx* ctx, const char* what) noexcept {
+    if (!ctx) return;
+    try {
+        ctx->err = what;
+    } catch (...) {
+    }
+}
+}  // namespace nlx
+#define NLX_TRY try
+#define NLX_CATCH_BODY(ctx, ret_nomem, ret_other)                                                          \
+    catch (const std::bad_alloc&) {                                                                       \
+        nlx::on_exception(ctx, "out of host memory (std::bad_alloc)");                                     \
+        return ret_nomem;                                                                                 \
+    }                                                                                                     \
+    catch (const std::exception& e__) {                                                                   \
+        nlx::on_exception(ctx, e__.what());                                                               \
+        return ret_other;                                                                                 \
+    }                                                                                                     \
+    catch (...) {                                                                                         \
+        nlx::on_exception(ctx, "unknown C++ exception");                                                  \
+        return ret_other;                                                                                 \
+    }
+#define NLX_CATCH(ctx) NLX_CATCH_BODY(ctx, NLX_E_NOMEM, NLX_E_INVAL)
+#define NLX_CATCH_VOID(ctx) NLX_CATCH_BODY(ctx, , )
+#define NLX_CATCH_VALUE(ctx, v) NLX_CATCH_BODY(ctx, v, v)
 
 #define NLX_HIP(ctx, call)                                   \
     do {                                                     \

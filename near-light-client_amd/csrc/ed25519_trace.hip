@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64) void k_ed_bind_rows(const uint64_t* __restrict_
 using namespace nlx;
 
 extern "C" int32_t nlx_ed25519_bind_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t log_slots, const uint64_t gamma[2],
-                                          uint64_t* acc_out, uint64_t total_out[2]) {
+                                          uint64_t* acc_out, uint64_t total_out[2]) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (!trace || !gamma || !acc_out || !total_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
     if (log_slots > 16) return ctx->fail(NLX_E_RANGE, "log_slots must be <= 16");
@@ -167,10 +167,10 @@ extern "C" int32_t nlx_ed25519_bind_round(nlx_ctx* ctx, const uint64_t* trace, u
     hipError_t le = hipGetLastError();
     if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
     return rc;
-}
+} NLX_CATCH(ctx)
 
 
-extern "C" int32_t nlx_ed25519_trace(nlx_ctx* ctx, const uint64_t* slots, uint32_t log_slots, uint64_t* trace_out) {
+extern "C" int32_t nlx_ed25519_trace(nlx_ctx* ctx, const uint64_t* slots, uint32_t log_slots, uint64_t* trace_out) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (!slots || !trace_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
     if (log_slots > 16) return ctx->fail(NLX_E_RANGE, "log_slots must be <= 16");
@@ -207,4 +207,4 @@ extern "C" int32_t nlx_ed25519_trace(nlx_ctx* ctx, const uint64_t* slots, uint32
         rc = ctx->fail(NLX_E_INVAL, "slot %u: the statement is false (the signature does not verify, A / R is not on the curve, "
                                     "S >= L or a coordinate >= p); the trace was written but cannot satisfy the AIR", bad);
     return rc;
-}
+} NLX_CATCH(ctx)

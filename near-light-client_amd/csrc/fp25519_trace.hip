@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_fp25519_chip_trace(const uint64_t* __re
 using namespace nlx;
 
 extern "C" int32_t nlx_fp25519_chip_trace(nlx_ctx* ctx, const uint64_t* a, const uint64_t* b, uint32_t log_rows,
-                                          uint64_t* trace_out) {
+                                          uint64_t* trace_out) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (!a || !b || !trace_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
     if (log_rows < 4 || log_rows > 24) return ctx->fail(NLX_E_RANGE, "log_rows must be in [4, 24]");
@@ -66,4 +66,4 @@ extern "C" int32_t nlx_fp25519_chip_trace(nlx_ctx* ctx, const uint64_t* a, const
     hipError_t le = hipGetLastError();
     if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
     return rc;
-}
+} NLX_CATCH(ctx)

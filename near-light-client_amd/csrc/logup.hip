@@ -220,7 +220,7 @@ static int32_t logup_check(nlx_ctx* ctx, const void* trace, uint32_t n_cols, uin
 }
 
 extern "C" int32_t nlx_logup_multiplicities(nlx_ctx* ctx, uint64_t* trace, uint32_t n_cols, uint32_t log_n, const uint32_t* cols,
-                                            uint32_t n_lookups, uint32_t table_bits, uint32_t table_cols, uint32_t mult_col) {
+                                            uint32_t n_lookups, uint32_t table_bits, uint32_t table_cols, uint32_t mult_col) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     uint32_t pb = 0;
     int32_t rc = logup_check(ctx, trace, n_cols, log_n, cols, n_lookups, table_bits, table_cols, mult_col, &pb);
@@ -251,13 +251,13 @@ extern "C" int32_t nlx_logup_multiplicities(nlx_ctx* ctx, uint64_t* trace, uint3
     if (e != hipSuccess) return ctx->hip_fail(e, "nlx_logup_multiplicities");
     if (!rc && err) rc = ctx->fail(NLX_E_RANGE, "a looked-up cell is outside the table [0, 2^%u)", table_bits);
     return rc;
-}
+} NLX_CATCH(ctx)
 
-extern "C" uint32_t nlx_logup_round_cols(uint32_t n_lookups, uint32_t table_cols) { return 2 * ((n_lookups + 1) / 2) + 2 * table_cols + 2; }
+extern "C" uint32_t nlx_logup_round_cols(uint32_t n_lookups, uint32_t table_cols) NLX_TRY { return 2 * ((n_lookups + 1) / 2) + 2 * table_cols + 2; } NLX_CATCH_VALUE(nullptr, 0)
 
 extern "C" int32_t nlx_logup_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t n_cols, uint32_t log_n, const uint32_t* cols,
                                    uint32_t n_lookups, uint32_t table_bits, uint32_t table_cols, uint32_t mult_col,
-                                   const uint64_t alpha[2], uint64_t* out) {
+                                   const uint64_t alpha[2], uint64_t* out) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     uint32_t pb = 0;
     int32_t rc = logup_check(ctx, trace, n_cols, log_n, cols, n_lookups, table_bits, table_cols, mult_col, &pb);
@@ -294,4 +294,4 @@ extern "C" int32_t nlx_logup_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t
     hipError_t le = hipGetLastError();
     if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
     return rc;
-}
+} NLX_CATCH(ctx)

@@ -114,7 +114,7 @@ struct nlx_circuit {
 extern "C" {
 
 int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint64_t* constants,
-                          const uint64_t* sigmas, nlx_circuit** out) {
+                          const uint64_t* sigmas, nlx_circuit** out) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (!desc || !constants || !sigmas || !out || !desc->gates || !desc->k_is)
         return ctx->fail(NLX_E_INVAL, "NULL argument");
@@ -317,9 +317,9 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
         if (hipEventCreate(&c->ev[i]) != hipSuccess) return fail(ctx->fail(NLX_E_HIP, "hipEventCreate failed"));
     *out = c;
     return NLX_OK;
-}
+} NLX_CATCH(ctx)
 
-void nlx_circuit_destroy(nlx_circuit* c) {
+void nlx_circuit_destroy(nlx_circuit* c) NLX_TRY {
     if (!c) return;
     nlx_ctx* ctx = c->ctx;
     (void)hipSetDevice(ctx->device);
@@ -333,21 +333,21 @@ void nlx_circuit_destroy(nlx_circuit* c) {
     for (int i = 0; i <= NLX_MAX_STAGES; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
-}
+} NLX_CATCH_VOID(nullptr)
 
-int32_t nlx_circuit_digest(const nlx_circuit* c, uint64_t out[4]) {
+int32_t nlx_circuit_digest(const nlx_circuit* c, uint64_t out[4]) NLX_TRY {
     if (!c || !out) return NLX_E_INVAL;
     memcpy(out, c->d.circuit_digest, 32);
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
-int32_t nlx_circuit_constants_sigmas_cap(const nlx_circuit* c, uint64_t* cap_out) {
+int32_t nlx_circuit_constants_sigmas_cap(const nlx_circuit* c, uint64_t* cap_out) NLX_TRY {
     if (!c || !cap_out) return NLX_E_INVAL;
     memcpy(cap_out, c->cs_cap.data(), c->cs_cap.size() * 8);
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
-size_t nlx_proof_max_bytes(const nlx_circuit* c) {
+size_t nlx_proof_max_bytes(const nlx_circuit* c) NLX_TRY {
     if (!c) return 0;
     const nlx_circuit_desc& d = c->d;
     const size_t capb = (size_t)32 << d.cap_height;
@@ -360,9 +360,9 @@ size_t nlx_proof_max_bytes(const nlx_circuit* c) {
     bytes += per_query * d.fri_num_queries;
     bytes += ((size_t)16 << (d.degree_bits - c->n_fri_rounds * d.fri_arity_bits)) + 8 + 8 + 8 * (size_t)d.num_public_inputs;
     return bytes + 64;
-}
+} NLX_CATCH_VALUE(nullptr, 0)
 
-int32_t nlx_pow_grind(nlx_ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t* nonce_out) {
+int32_t nlx_pow_grind(nlx_ctx* ctx, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t* nonce_out) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (!state || !nonce_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
     if (pos >= 8 || bits > 40) return ctx->fail(NLX_E_RANGE, "pos must be < 8 and bits <= 40");
@@ -382,9 +382,9 @@ int32_t nlx_pow_grind(nlx_ctx* ctx, const uint64_t state[12], uint32_t pos, uint
     if (best == ~0ull) return ctx->fail(NLX_E_RANGE, "proof of work: no witness found");
     *nonce_out = best;
     return NLX_OK;
-}
+} NLX_CATCH(ctx)
 
-int32_t nlx_prove_stage_times(const nlx_circuit* c, uint32_t* n_stages, const char** names_out, float* ms_out) {
+int32_t nlx_prove_stage_times(const nlx_circuit* c, uint32_t* n_stages, const char** names_out, float* ms_out) NLX_TRY {
     if (!c || !n_stages) return NLX_E_INVAL;
     if (!c->timed) { *n_stages = 0; return NLX_OK; }
     *n_stages = c->n_stages;
@@ -397,7 +397,7 @@ int32_t nlx_prove_stage_times(const nlx_circuit* c, uint32_t* n_stages, const ch
         }
     }
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
 }  // extern "C"
 
@@ -498,7 +498,7 @@ int32_t quotient_stage(nlx_circuit* c, const nlx_commit* cw, const nlx_commit* c
 extern "C" {
 
 int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_inputs, uint8_t* proof_out,
-                  size_t proof_cap, size_t* proof_len) {
+                  size_t proof_cap, size_t* proof_len) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     nlx_ctx* ctx = c->ctx;
     const nlx_circuit_desc& d = c->d;
@@ -664,9 +664,9 @@ done:
 #undef HIPCHK
 #undef CHECK_ALLOC
     return rc;
-}
+} NLX_CATCH(nullptr)
 
-int32_t nlx_batch_prove(nlx_circuit* const* workers, uint32_t n_workers, nlx_prove_job* jobs, size_t n_jobs) {
+int32_t nlx_batch_prove(nlx_circuit* const* workers, uint32_t n_workers, nlx_prove_job* jobs, size_t n_jobs) NLX_TRY {
     if (!workers || n_workers == 0 || (!jobs && n_jobs)) return NLX_E_INVAL;
     for (uint32_t w = 0; w < n_workers; w++) {
         if (!workers[w]) return NLX_E_INVAL;
@@ -695,15 +695,15 @@ int32_t nlx_batch_prove(nlx_circuit* const* workers, uint32_t n_workers, nlx_pro
     for (size_t j = 0; j < n_jobs; j++)
         if (jobs[j].status != NLX_OK) return jobs[j].status;
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
 
 // ---- stage-level entry points (the fine seam of INTEGRATION.md §3) ----
 
-const nlx_commit* nlx_circuit_constants_sigmas(const nlx_circuit* c) { return c ? c->cs : nullptr; }
+const nlx_commit* nlx_circuit_constants_sigmas(const nlx_circuit* c) NLX_TRY { return c ? c->cs : nullptr; } NLX_CATCH_VALUE(nullptr, nullptr)
 
 int32_t nlx_partial_products_and_zs(nlx_circuit* c, const uint64_t* wires, const uint64_t betas[2], const uint64_t gammas[2],
-                                    nlx_commit** zs_out) {
+                                    nlx_commit** zs_out) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     nlx_ctx* ctx = c->ctx;
     if (!wires || !betas || !gammas || !zs_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
@@ -715,11 +715,11 @@ int32_t nlx_partial_products_and_zs(nlx_circuit* c, const uint64_t* wires, const
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
     return rc;
-}
+} NLX_CATCH(nullptr)
 
 int32_t nlx_quotient_eval(nlx_circuit* c, const nlx_commit* wires, const nlx_commit* zs, const uint64_t betas[2],
                           const uint64_t gammas[2], const uint64_t alphas[2], const uint64_t public_inputs_hash[4],
-                          nlx_commit** quotient_out) {
+                          nlx_commit** quotient_out) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     nlx_ctx* ctx = c->ctx;
     if (!wires || !zs || !betas || !gammas || !alphas || !public_inputs_hash || !quotient_out)
@@ -737,12 +737,12 @@ int32_t nlx_quotient_eval(nlx_circuit* c, const nlx_commit* wires, const nlx_com
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
     return rc;
-}
+} NLX_CATCH(nullptr)
 
 int32_t nlx_fri_prove(nlx_ctx* ctx, const nlx_commit* const* oracles, uint32_t n_oracles, const uint32_t* n_next,
                       const uint64_t zeta[2], const uint64_t* openings_zeta, const uint64_t* openings_next,
                       const nlx_fri_params* params, nlx_challenger* challenger, uint8_t* proof_out, size_t proof_cap,
-                      size_t* proof_len) {
+                      size_t* proof_len) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (!oracles || !n_next || !zeta || !openings_zeta || !params || !challenger || !proof_out || !proof_len)
         return ctx->fail(NLX_E_INVAL, "NULL argument");
@@ -814,11 +814,11 @@ int32_t nlx_fri_prove(nlx_ctx* ctx, const nlx_commit* const* oracles, uint32_t n
     challenger->n_output = ch.n_out;
     *proof_len = w.len;
     return NLX_OK;
-}
+} NLX_CATCH(ctx)
 
 // plonky2::iop::challenger::Challenger on the host, for callers without their own (tests, the C example)
-void nlx_challenger_init(nlx_challenger* c) { if (c) memset(c, 0, sizeof *c); }
-int32_t nlx_challenger_observe(nlx_challenger* c, const uint64_t* elements, size_t n) {
+void nlx_challenger_init(nlx_challenger* c) NLX_TRY { if (c) memset(c, 0, sizeof *c); } NLX_CATCH_VOID(nullptr)
+int32_t nlx_challenger_observe(nlx_challenger* c, const uint64_t* elements, size_t n) NLX_TRY {
     if (!c || (!elements && n) || c->n_input > 8 || c->n_output > 8) return NLX_E_INVAL;
     Challenger ch;
     memcpy(ch.state, c->state, sizeof ch.state); memcpy(ch.in_buf, c->input, sizeof ch.in_buf);
@@ -830,8 +830,8 @@ int32_t nlx_challenger_observe(nlx_challenger* c, const uint64_t* elements, size
     memcpy(c->state, ch.state, sizeof ch.state); memcpy(c->input, ch.in_buf, sizeof ch.in_buf);
     memcpy(c->output, ch.out_buf, sizeof ch.out_buf); c->n_input = ch.n_in; c->n_output = ch.n_out;
     return NLX_OK;
-}
-int32_t nlx_challenger_challenge(nlx_challenger* c, uint64_t* out, size_t n) {
+} NLX_CATCH(nullptr)
+int32_t nlx_challenger_challenge(nlx_challenger* c, uint64_t* out, size_t n) NLX_TRY {
     if (!c || (!out && n) || c->n_input > 8 || c->n_output > 8) return NLX_E_INVAL;
     Challenger ch;
     memcpy(ch.state, c->state, sizeof ch.state); memcpy(ch.in_buf, c->input, sizeof ch.in_buf);
@@ -840,14 +840,14 @@ int32_t nlx_challenger_challenge(nlx_challenger* c, uint64_t* out, size_t n) {
     memcpy(c->state, ch.state, sizeof ch.state); memcpy(c->input, ch.in_buf, sizeof ch.in_buf);
     memcpy(c->output, ch.out_buf, sizeof ch.out_buf); c->n_input = ch.n_in; c->n_output = ch.n_out;
     return NLX_OK;
-}
-int32_t nlx_hash_no_pad(const uint64_t* elements, size_t n, uint64_t out[4]) {
+} NLX_CATCH(nullptr)
+int32_t nlx_hash_no_pad(const uint64_t* elements, size_t n, uint64_t out[4]) NLX_TRY {
     if ((!elements && n) || !out) return NLX_E_INVAL;
     for (size_t i = 0; i < n; i++)
         if (elements[i] >= gl::P) return NLX_E_RANGE;
     hash_no_pad_host(elements, n, out);
     for (int i = 0; i < 4; i++) out[i] = gl::canon(out[i]);
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
 }  // extern "C"

@@ -313,12 +313,34 @@ __device__ __forceinline__ uint64_t limb4(uint64_t l) {
 // x^7, any u64 in, LOOSE out (consumers: poseidon::mds_layer, which splits any u64 into halves, and gl::add_loose)
 __device__ __forceinline__ uint64_t sbox7c(uint64_t x) {
     uint64_t x2 = gl::mul_loose(x, x), x4 = gl::mul_loose(x2, x2), x3 = gl::mul_loose(x, x2);
-    return gl::mul_loose(x3, x4);
+    const uint64_t r = gl::mul_loose(x3, x4);
+    // one S-box at a time: a wave issues an instruction every four cycles whether or not it depends on the one before, so
+    // twelve interleaved S-boxes buy nothing and their temporaries were what k_quotient spilled (20 - 70 registers per part)
+    __builtin_amdgcn_sched_barrier(0);
+    return r;
 }
+// The permutation's linear layer on any-u64 inputs, canonical outputs: 32-bit halves, twelve multiply-accumulates per half
+// and output, the four-instruction fold of gl32.hpp - one output row at a time (a fence per row: see sbox7c)
 __device__ __forceinline__ void mds_canon(uint64_t (&s)[12]) {
-    poseidon::mds_layer(s);
+    constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    uint64_t o[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
+    for (int r = 0; r < 12; r++) {
+        uint64_t al = 0, ah = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            al += (uint64_t)(uint32_t)s[(i + r) % 12] * C[i];
+            ah += (uint64_t)(uint32_t)(s[(i + r) % 12] >> 32) * C[i];
+        }
+        if (r == 0) {
+            al += (uint64_t)(uint32_t)s[0] * 8u;
+            ah += (uint64_t)(uint32_t)(s[0] >> 32) * 8u;
+        }
+        o[r] = gl::canon(gl32::to_u64(gl32::fold_acc(al, ah)));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = o[i];
 }
 
 // PoseidonGate::eval_unfiltered_base (fast partial-round formulation, as upstream), in three independent parts (bit mask):
@@ -345,22 +367,23 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t p
         }
 #pragma unroll
         for (int i = 8; i < 12; i++) st[i] = W(i);
+        // rounds 0 .. 2 in full, each followed by the check of the next round's S-box inputs (wires), from which the next
+        // round restarts; round 3 itself belongs to part 2
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = gl::add_loose(st[i], RC[i]);
 #pragma unroll 1
-        for (int r = 0; r < 4; r++) {
-#pragma unroll
-            for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], RC[r * 12 + i]);
-            if (r != 0) {
-#pragma unroll
-                for (int i = 0; i < 12; i++) {
-                    const uint64_t in = W(29 + 12 * (r - 1) + i);
-                    acc.emit_at(5 + 12 * (r - 1) + i, gl::sub(st[i], in));
-                    st[i] = in;
-                }
-            }
-            if (r == 3) break;  // round 3 itself belongs to part 2
+        for (int r = 0; r < 3; r++) {
 #pragma unroll
             for (int i = 0; i < 12; i++) st[i] = sbox7c(st[i]);
             mds_canon(st);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const uint64_t in = W(29 + 12 * r + i);
+                acc.emit_at(5 + 12 * r + i, gl::sub(gl::add(st[i], RC[(r + 1) * 12 + i]), in));
+                st[i] = in;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     if (parts & 2u) {
@@ -381,6 +404,7 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t p
 #pragma unroll
                 for (int r = 1; r < 12; r++) dot.mac(st[r], FAST_INIT[r - 1][c - 1]);
                 res[c] = dot.value();
+                __builtin_amdgcn_sched_barrier(0);   // one column at a time (see sbox7c)
             }
 #pragma unroll
             for (int i = 0; i < 12; i++) st[i] = res[i];
@@ -399,6 +423,7 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t p
             for (int i = 1; i < 12; i++) {
                 dot.mac(st[i], FAST_W[r][i - 1]);
                 st[i] = gl::add(st[i], gl::mul(s0, FAST_VS[r][i - 1]));
+                __builtin_amdgcn_sched_barrier(0);
             }
             st[0] = dot.value();
         }
@@ -409,13 +434,19 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t p
     if (parts & 4u) {
 #pragma unroll 1
         for (int r = 0; r < 4; r++) {
+            // the check of this round's S-box inputs against the state the previous round left, THEN the round from its
+            // input wires (read a second time from LDS): the old state is dead before the new one is built
+            if (r != 0) {
 #pragma unroll
-            for (int i = 0; i < 12; i++) {
-                const uint64_t in = W(87 + 12 * r + i);
-                if (r != 0) acc.emit_at(63 + 12 * r + i, gl::sub(gl::add(st[i], RC[(26 + r) * 12 + i]), in));
-                st[i] = sbox7c(in);
+                for (int i = 0; i < 12; i++) {
+                    acc.emit_at(63 + 12 * r + i, gl::sub(gl::add(st[i], RC[(26 + r) * 12 + i]), W(87 + 12 * r + i)));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+#pragma unroll
+            for (int i = 0; i < 12; i++) st[i] = sbox7c(W(87 + 12 * r + i));
             mds_canon(st);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < 12; i++) acc.emit_at(111 + i, gl::sub(st[i], W(12 + i)));
@@ -503,13 +534,18 @@ __device__ __forceinline__ void eval_gate(const GateDev& gd, const QuotientParam
         case NLX_GATE_POSEIDON_MDS: {
             // outputs = MDS * inputs on both components of the extension algebra: the linear layer of the
             // permutation itself (32-bit halves, multiply-accumulate, one reduction per output)
-            for (uint32_t comp = 0; comp < 2; comp++) {
+#pragma unroll 1
+            for (uint32_t comp = 0; comp < 2; comp++) {   // one component at a time: both at once need 114 registers
                 uint64_t st[12];
 #pragma unroll
                 for (int i = 0; i < 12; i++) st[i] = W(2 * i + comp);
                 mds_canon(st);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int rr = 0; rr < 12; rr++) acc.emit_at(2 * rr + comp, gl::sub(W(24 + 2 * rr + comp), st[rr]));
+                for (int rr = 0; rr < 12; rr++) {
+                    acc.emit_at(2 * rr + comp, gl::sub(W(24 + 2 * rr + comp), st[rr]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             acc.k += 24;
             break;
@@ -747,10 +783,28 @@ __global__ __launch_bounds__(64 * QW, NLX_QMINW) void k_quotient(QuotientParams 
     const uint32_t lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned log_L = p.log_n + p.rate_bits;
     const size_t n = (size_t)1 << p.log_n, L = (size_t)1 << log_L;
-    const size_t pos_raw = (size_t)blockIdx.x * 64 + lane;
-    const bool live = pos_raw < L;                 // a domain of fewer than 64 points: the spare lanes redo the last point
-    const size_t pos = live ? pos_raw : L - 1;
-    const uint32_t r = (uint32_t)(pos >> p.log_n), k = (uint32_t)(pos & (n - 1));
+    // The lane's LDE point.  Its coordinates are needed by the tile load, by the two permutation-argument items and by the
+    // epilogue; kept in registers across the whole item loop they were what the kernel still spilled at entry (17 words per
+    // lane and tile = 1.2 GB per launch at 2^18 rows), so each of those places recomputes them from the lane index - made
+    // opaque to the compiler there, or it would merge the copies back into one long-lived value.
+    struct Point { size_t pos; uint32_t r, k; bool live; };
+    auto point_of = [&](uint32_t ln) {
+        const size_t pos_raw = (size_t)blockIdx.x * 64 + ln;
+        Point q;
+        q.live = pos_raw < L;                      // a domain of fewer than 64 points: the spare lanes redo the last point
+        q.pos = q.live ? pos_raw : L - 1;
+        q.r = (uint32_t)(q.pos >> p.log_n);
+        q.k = (uint32_t)(q.pos & (n - 1));
+        return q;
+    };
+    // NOT volatile: hipcc treats a volatile asm as a possible store, and every wave-uniform table read behind it (alpha
+    // powers, round constants) then goes through vector memory instead of the scalar cache (k_quotient 7.3 -> 9.3 ms).  The
+    // second operand ties the copy to the place it is made at (the item index), so it is neither hoisted nor merged.
+    auto opaque = [](uint32_t v, uint32_t where) {
+        asm("" : "+v"(v) : "s"(where));
+        return v;
+    };
+    const size_t pos = point_of(lane).pos;
     uint64_t* lw = q_lds;                                  // [num_wires][64]
     uint64_t* lc = q_lds + (size_t)p.num_wires * 64;       // [n_consts_all][64]
     for (uint32_t c = wv; c < p.num_wires; c += QW) lw[c * 64 + lane] = p.wires[(size_t)c * L + pos];
@@ -758,7 +812,6 @@ __global__ __launch_bounds__(64 * QW, NLX_QMINW) void k_quotient(QuotientParams 
     __syncthreads();
     auto W = [&](uint32_t c) { return lw[c * 64 + lane]; };
     auto CC = [&](uint32_t c) { return lc[c * 64 + lane]; };
-    auto ZS = [&](uint32_t c) { return p.zs[(size_t)c * L + pos]; };
 
     const uint32_t nc = p.nc, npp = p.npp;
     const uint32_t T0 = nc + nc * (npp + 1);
@@ -792,8 +845,11 @@ __global__ __launch_bounds__(64 * QW, NLX_QMINW) void k_quotient(QuotientParams 
             // alpha reduces the whole list, so each term feeds both sums.
             const uint32_t c = item - p.n_gates;
             const uint32_t n_chunks = (p.routed + p.chunk - 1) / p.chunk;
-            const size_t pos_next = ((size_t)r << p.log_n) + ((k + 1) & (n - 1));
-            const uint64_t x = gl::mul(p.coset_base[r], root_pow(p.w_n_table, k, (uint32_t)(n >> 1)));
+            const Point pt = point_of(opaque(lane, wi));
+            const size_t pos = pt.pos;
+            auto ZS = [&](uint32_t col) { return p.zs[(size_t)col * L + pos]; };
+            const size_t pos_next = ((size_t)pt.r << p.log_n) + ((pt.k + 1) & (n - 1));
+            const uint64_t x = gl::mul(p.coset_base[pt.r], root_pow(p.w_n_table, pt.k, (uint32_t)(n >> 1)));
             const uint64_t beta = p.betas[c], gamma = p.gammas[c];
             const uint64_t bx = gl::mul(beta, x);
             const uint64_t z_x = ZS(c);
@@ -838,11 +894,12 @@ __global__ __launch_bounds__(64 * QW, NLX_QMINW) void k_quotient(QuotientParams 
         l0b = gl::add(l0b, red[(w2 * 4 + 3) * 64 + lane]);
     }
     // quotient = (L_0 terms + rest) / Z_H(x);  L_0(x)/Z_H(x) = 1 / (n (x - 1)) = l0_scaled[pos]
-    const uint64_t zh_inv = p.zh_inv[r];
-    const uint64_t l0s = p.l0_scaled[pos];
-    if (!live) return;
-    p.out[pos] = gl::add(gl::mul(tot0, zh_inv), gl::mul(l0a, l0s));
-    if (nc > 1) p.out[L + pos] = gl::add(gl::mul(tot1, zh_inv), gl::mul(l0b, l0s));
+    const Point pe = point_of(opaque(lane, 0xFFFFFFFFu));
+    const uint64_t zh_inv = p.zh_inv[pe.r];
+    const uint64_t l0s = p.l0_scaled[pe.pos];
+    if (!pe.live) return;
+    p.out[pe.pos] = gl::add(gl::mul(tot0, zh_inv), gl::mul(l0a, l0s));
+    if (nc > 1) p.out[L + pe.pos] = gl::add(gl::mul(tot1, zh_inv), gl::mul(l0b, l0s));
 }
 
 size_t quotient_lds_bytes(uint32_t num_wires, uint32_t n_consts_all) {

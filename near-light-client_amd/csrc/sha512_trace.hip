@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void k_sha512_bind_rows(const uint64_t* __restr
 using namespace nlx;
 
 extern "C" int32_t nlx_sha512_bind_round(nlx_ctx* ctx, const uint64_t* trace, uint32_t log_blocks, const uint64_t gamma[2],
-                                         uint64_t* acc_out, uint64_t total_out[2]) {
+                                         uint64_t* acc_out, uint64_t total_out[2]) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (!trace || !gamma || !acc_out || !total_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
     if (log_blocks > 18) return ctx->fail(NLX_E_RANGE, "log_blocks must be <= 18");
@@ -281,11 +281,11 @@ extern "C" int32_t nlx_sha512_bind_round(nlx_ctx* ctx, const uint64_t* trace, ui
     hipError_t le = hipGetLastError();
     if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
     return rc;
-}
+} NLX_CATCH(ctx)
 
 
 extern "C" int32_t nlx_sha512_trace(nlx_ctx* ctx, const uint64_t* blocks, const uint8_t* is_first, uint32_t log_blocks,
-                                    uint64_t* trace_out, uint64_t digest_out[8]) {
+                                    uint64_t* trace_out, uint64_t digest_out[8]) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (!blocks || !is_first || !trace_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
     if (log_blocks > 18) return ctx->fail(NLX_E_RANGE, "log_blocks must be <= 18");
@@ -312,4 +312,4 @@ extern "C" int32_t nlx_sha512_trace(nlx_ctx* ctx, const uint64_t* blocks, const 
     hipError_t le = hipGetLastError();
     if (!rc && le != hipSuccess) rc = ctx->hip_fail(le, "kernel launch");
     return rc;
-}
+} NLX_CATCH(ctx)

@@ -322,7 +322,7 @@ static void air_digest_host(const nlx_stark_desc& d, const std::vector<uint64_t>
 
 extern "C" {
 
-int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** out) {
+int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** out) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (!desc || !out || (!desc->program && desc->n_words)) return ctx->fail(NLX_E_INVAL, "NULL argument");
     *out = nullptr;
@@ -547,9 +547,9 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
     }
     *out = s;
     return NLX_OK;
-}
+} NLX_CATCH(ctx)
 
-void nlx_stark_destroy(nlx_stark* s) {
+void nlx_stark_destroy(nlx_stark* s) NLX_TRY {
     if (!s) return;
     nlx_ctx* ctx = s->ctx;
     (void)hipSetDevice(ctx->device);
@@ -562,13 +562,13 @@ void nlx_stark_destroy(nlx_stark* s) {
     for (int i = 0; i <= NLX_MAX_STAGES; i++)
         if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
     delete s;
-}
+} NLX_CATCH_VOID(nullptr)
 
-size_t nlx_stark_proof_max_bytes(const nlx_stark* s) {
+size_t nlx_stark_proof_max_bytes(const nlx_stark* s) NLX_TRY {
     return s ? stark_proof_max_bytes(s->d, s->n_fri_rounds) : 0;
-}
+} NLX_CATCH_VALUE(nullptr, 0)
 
-int32_t nlx_stark_stage_times(const nlx_stark* s, uint32_t* n_stages, const char** names_out, float* ms_out) {
+int32_t nlx_stark_stage_times(const nlx_stark* s, uint32_t* n_stages, const char** names_out, float* ms_out) NLX_TRY {
     if (!s || !n_stages) return NLX_E_INVAL;
     if (!s->timed) { *n_stages = 0; return NLX_OK; }
     *n_stages = s->n_stages;
@@ -581,10 +581,10 @@ int32_t nlx_stark_stage_times(const nlx_stark* s, uint32_t* n_stages, const char
         }
     }
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
 int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, const uint64_t* public_inputs,
-                               uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+                               uint8_t* proof_out, size_t proof_cap, size_t* proof_len) NLX_TRY {
     if (!s) return NLX_E_INVAL;
     nlx_ctx* ctx = s->ctx;
     const nlx_stark_desc& d = s->d;
@@ -805,21 +805,21 @@ done:
 #undef HIPCHK
 #undef CHECK_ALLOC
     return rc;
-}
+} NLX_CATCH(nullptr)
 
 static const uint64_t* single_round_fn(void* user, uint32_t round, const uint64_t*, uint32_t, uint64_t*) {
     return round == 0 ? (const uint64_t*)user : nullptr;
 }
 
 int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* public_inputs, uint8_t* proof_out,
-                        size_t proof_cap, size_t* proof_len) {
+                        size_t proof_cap, size_t* proof_len) NLX_TRY {
     if (!s) return NLX_E_INVAL;
     if (!trace) return s->ctx->fail(NLX_E_INVAL, "NULL argument");
     if (s->n_rounds != 1) return s->ctx->fail(NLX_E_INVAL, "a multi-round STARK is proved with nlx_stark_prove_rounds");
     return nlx_stark_prove_rounds(s, single_round_fn, (void*)trace, public_inputs, proof_out, proof_cap, proof_len);
-}
+} NLX_CATCH(nullptr)
 
-int32_t nlx_stark_batch_prove(nlx_stark* const* workers, uint32_t n_workers, nlx_prove_job* jobs, size_t n_jobs) {
+int32_t nlx_stark_batch_prove(nlx_stark* const* workers, uint32_t n_workers, nlx_prove_job* jobs, size_t n_jobs) NLX_TRY {
     if (!workers || n_workers == 0 || (!jobs && n_jobs)) return NLX_E_INVAL;
     for (uint32_t w = 0; w < n_workers; w++) {
         if (!workers[w]) return NLX_E_INVAL;
@@ -849,6 +849,6 @@ int32_t nlx_stark_batch_prove(nlx_stark* const* workers, uint32_t n_workers, nlx
     for (size_t j = 0; j < n_jobs; j++)
         if (jobs[j].status != NLX_OK) return jobs[j].status;
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
 }  // extern "C"

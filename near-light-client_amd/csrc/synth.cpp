@@ -13,6 +13,8 @@
 #include <cstring>
 #include <numeric>
 #include <vector>
+#include <exception>
+#include <new>
 #include "../../include/nlx_synth.h"
 #include "gl.hpp"
 #include "poseidon.hpp"
@@ -144,6 +146,12 @@ struct Dsu {
 
 }  // namespace
 
+// the generator's entry points never throw either (same contract as include/nlx.h; this library has no context to report to)
+#define NLX_TRY try
+#define NLX_CATCH(ctx) catch (const std::bad_alloc&) { return -2; } catch (...) { return -1; }
+#define NLX_CATCH_VOID(ctx) catch (...) { return; }
+#define NLX_CATCH_VALUE(ctx, v) catch (...) { return v; }
+
 extern "C" {
 
 // gate list sorted by (degree, id) as plonky2's CircuitBuilder does; the set depends on the mix
@@ -173,7 +181,7 @@ static uint32_t build_gate_list(const nlx_synth_params* sp, uint32_t* kinds, uin
     return k;
 }
 
-void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_selectors) {
+void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_selectors) NLX_TRY {
     uint32_t kinds[24], p0[24], p1[24];
     const uint32_t g = build_gate_list(sp, kinds, p0, p1);
     *n_gates = g;
@@ -188,11 +196,11 @@ void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_
         sel++;
     }
     *n_selectors = sel;
-}
+} NLX_CATCH_VOID(nullptr)
 
 // Re-target a generated witness to new public inputs: only the PublicInputGate row (row 0, wires
 // 0..3 = hash_no_pad(public_inputs)) depends on them.
-int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint64_t* public_inputs, uint32_t count) {
+int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint64_t* public_inputs, uint32_t count) NLX_TRY {
     if (!wires || (!public_inputs && count)) return NLX_E_INVAL;
     const size_t n = (size_t)1 << log_n;
     uint64_t st[12] = {0};
@@ -206,12 +214,12 @@ int32_t nlx_synth_set_public_inputs(uint64_t* wires, uint32_t log_n, const uint6
     }
     for (int i = 0; i < 4; i++) wires[(size_t)i * n] = st[i];
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
 // Witness of the synthetic wide AIR (host mirror: stark.py wide_air): columns in groups of four (a, b, c, d),
 //   next.a = a*b + c,  next.b = b*c + k1[g],  next.c = (a + b + c) * d,  d boolean and constant down the trace.
 int32_t nlx_synth_stark_trace(uint32_t n_cols, uint32_t log_n, uint64_t seed, const uint64_t* k1, uint64_t* trace,
-                              uint64_t* public_inputs) {
+                              uint64_t* public_inputs) NLX_TRY {
     if (!k1 || !trace || !public_inputs || n_cols == 0 || (n_cols & 3)) return NLX_E_INVAL;
     if (log_n < 1 || log_n > 28) return NLX_E_RANGE;
     const size_t n = (size_t)1 << log_n;
@@ -231,10 +239,10 @@ int32_t nlx_synth_stark_trace(uint32_t n_cols, uint32_t log_n, uint64_t seed, co
     public_inputs[0] = trace[0];
     public_inputs[1] = trace[n];
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
 int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint64_t* k_is, uint64_t* constants,
-                          uint64_t* sigmas, uint64_t* wires, uint64_t* public_inputs) {
+                          uint64_t* sigmas, uint64_t* wires, uint64_t* public_inputs) NLX_TRY {
     const uint32_t W = 135, ROUTED = 80, NCONST = 2;
     const uint32_t log_n = sp->log_n;
     if (log_n < 3 || log_n > 26) return NLX_E_RANGE;
@@ -717,6 +725,6 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
         sigmas[s] = gl::mul(k_is[t / n], subgroup[t % n]);
     }
     return NLX_OK;
-}
+} NLX_CATCH(nullptr)
 
 }  // extern "C"

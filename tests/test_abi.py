@@ -40,6 +40,28 @@ def test_version_and_strerror(nlx):
     assert nlx.lib.dll.nlx_strerror(-5) == b"unsupported"
 
 
+def test_exceptions_do_not_cross_the_abi(nlx):
+    """include/nlx.h: "never throws or aborts".  A failed host allocation and two other exceptions raised inside the library
+    come back as return codes (every extern "C" definition is a function-try-block, csrc/ctx.hpp); no GPU needed."""
+    dll = nlx.lib.dll
+    assert dll.nlx_abi_selftest(0) == -2     # NLX_E_NOMEM: std::bad_alloc from a real oversized std::vector
+    assert dll.nlx_abi_selftest(1) == -1     # NLX_E_INVAL: std::runtime_error
+    assert dll.nlx_abi_selftest(2) == -1     # NLX_E_INVAL: a thrown int
+    assert dll.nlx_abi_selftest(9) == -4     # NLX_E_RANGE: unknown kind
+    # and every definition of an exported symbol carries the guard
+    import re
+    csrc = os.path.join(ROOT, "near-light-client_amd", "csrc")
+    unguarded = []
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith(".hip"):
+            continue
+        text = open(os.path.join(csrc, fn)).read()
+        for m in re.finditer(r'^(?:extern "C" )?(?:const )?\w+(?: ?\*)? (nlx_\w+)\(([^;{]*?)\)\s*(NLX_TRY )?\{', text, re.M | re.S):
+            if not m.group(3):
+                unguarded.append((fn, m.group(1)))
+    assert not unguarded, unguarded
+
+
 def test_no_cpu_fallback(nlx):
     """Without a gfx950 device context creation must fail loudly, never fall back to the CPU."""
     import torch

@@ -36,6 +36,17 @@ def test_c_caller_proves_on_gpu(nlx, tmp_path):
     assert r.stdout.startswith("ok: 2^11 rows")
 
 
+@pytest.mark.gpu
+def test_c_caller_sees_return_codes_for_failed_allocations(nlx, tmp_path):
+    """A host allocation that fails inside the library (C++ exception, stopped at the ABI), a 2^50-byte device buffer and
+    a 65 535-column x 2^27-row commitment: negative return codes, no abort, and the same context proves afterwards."""
+    exe = _build(tmp_path)
+    r = subprocess.run([exe, "9", "nomem"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    lines = r.stdout.splitlines()
+    assert lines[0].startswith("refused: host allocation -2") and lines[1].startswith("ok: 2^9 rows")
+
+
 def test_c_stark_caller_builds(nlx, tmp_path):
     _build(tmp_path, "stark_example")
 

@@ -2,14 +2,15 @@
 the given directory) for `bench.py --workload outer --steps 2 --warmup 1 --inflight 1` at 2^16 rows: per kernel of interest
 the LAST proof's launches, FETCH_SIZE / WRITE_SIZE in KB as reported, HBM traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950's
 FETCH_SIZE counts half of a coalesced streaming read: MI355X_MICROARCH.md, HBM section), and the algorithmic bytes of
-SURVEY.md §8(d) beside it.   python tools/pmc_summary.py gpurun_out/profiles_r02_<tag>"""
+SURVEY.md §8(d) beside it.   python tools/pmc_summary.py gpurun_out/profiles_r02_<tag> [log_n]   (log_n = the rows of the
+outer proof the passes ran on: 16 by default, 18 = the headline's size, tools/r03_pmc_outer18.sh)"""
 import collections
 import csv
 import json
 import os
 import sys
 
-LOG_N, RATE_BITS = 16, 3
+LOG_N, RATE_BITS = (int(sys.argv[2]) if len(sys.argv) > 2 else 16), 3
 L = 1 << (LOG_N + RATE_BITS)
 N_CS, N_W, N_ZS, NC = 85, 135, 20, 2  # constants+sigmas (3 selectors + 2 + 80), wires, Z + partial products, challenges
 
@@ -33,7 +34,7 @@ def main(root):
     write = load(os.path.join(root, "pmc_write", "p_counter_collection.csv"))
     insts = load(os.path.join(root, "pmc_insts", "p_counter_collection.csv"))
     out = {"log_n": LOG_N, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVES (separate passes), "
-                                     "bench.py --workload outer --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline, MI355X",
+                                     "bench.py --workload outer --log-n %d --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline, MI355X" % LOG_N,
            "units": "FETCH_SIZE / WRITE_SIZE are KB; traffic_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE counts 1/2 of coalesced streaming reads)"}
     # k_quotient: one launch per proof
     q = "nlx::k_quotient"
