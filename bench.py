@@ -103,7 +103,7 @@ def parse():
     ap.add_argument("--ntt-cols", type=int, default=16)
     ap.add_argument("--ntt-field", default="goldilocks", choices=["goldilocks", "bn254"],
                     help="ntt24 workload: goldilocks (the prover's field) or bn254 (the scalar field of the recursive wrap, row f.4)")
-    ap.add_argument("--no-extra", action="store_true", help="sync workload: skip the plonky2-only 2^16 figures")
+    ap.add_argument("--no-extra", action="store_true", help="sync workload: skip the plonky2-only 2^16 figures and the verify128 record")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent proofs in flight per GPU (one context + stream + host thread each); the K "
                          "timed steps are shared between them")
@@ -841,8 +841,26 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
     pool.shutdown()
     for pr in (p256, p512, ped):
         pr.close()
+    cd.close()
     for c_ in ctxs:
         c_.close()
+    # BASELINE.json configs[3] in the same line, so that the driver's N = 1, 2, 4, 8 runs of this command carry the STRONG-scaling
+    # figure north_star asks for next to the Sync replicas: the 128 x 4 Verify job (32 map + 31 reduce + 1 outer proofs, sharded
+    # round-robin, one RCCL all-gather of the children's blobs per level), 1 warm-up + 2 timed jobs.  Every rank takes part.
+    if not args.no_extra:
+        import copy
+        va = copy.copy(args)
+        va.steps, va.warmup, va.map_starks = 2, 1, False
+        v = run_verify128(va, nlx, torch, rank, world, local, dist)
+        if out is not None and v is not None:
+            out["verify128"] = {"proofs_per_s": v["value"], "ms_per_job": v["ms_per_step"], "n_gpus": world, "scaling": "strong",
+                                "level_ms": v["config"]["level_ms_last_step"], "bytes_gathered": v["config"]["bytes_gathered_last_step"],
+                                "root_digest": v["config"]["root_digest"], "output_ok": v["config"]["output_lists_every_id_as_verified"],
+                                "oracle_verifier_accepts_outer_proof": v["config"]["oracle_verifier_accepts_outer_proof"],
+                                "map_log_n": va.map_log_n, "reduce_log_n": va.reduce_log_n, "proofs_in_flight_per_gpu": va.inflight,
+                                "roofline": v["roofline"], "cpu_baseline": v["cpu_baseline"],
+                                "note": "the VerifyCircuit 128 x 4 map-reduce job of `--workload verify128`, 1 warm-up + 2 timed jobs after "
+                                        "the Sync measurement; strong scaling: the same 64 proofs whatever the number of GPUs"}
     return out
 
 
@@ -1317,6 +1335,53 @@ def run_msm24(args, nlx, torch, rank, world, local, dist):
     return out
 
 
+def run_verify128(args, nlx, torch, rank, world, local, dist, t_outer_2p15=None):
+    """BASELINE.json configs[3]: the VerifyCircuit 128 x 4 map-reduce job (nearx/src/verify.rs:69-90), sharded over the ranks -
+    the STRONG-scaling workload (README.md:123: "No parallelisation", 22 s per batch on the reference's CPU).  The CPU leg
+    times the test oracle on one reduce-sized proof and (unless the Sync leg already did) one 2^15-row proof and scales
+    linearly in rows: 32 map + 31 reduce + 1 outer proofs."""
+    from importlib import import_module
+    mr = import_module("nlx_amd.mapreduce")
+    verify_outer = cpu = None
+    if not args.no_cpu_baseline and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+        def verify_outer(syn, proof):   # the checker (test oracle's plonky2 verifier) on the job's outer proof
+            import oracle_py
+            oc = oracle_py.Circuit.from_synthetic(syn)
+            ok = oc.verify(proof) == 1
+            oc.close()
+            return ok
+
+        def cpu():
+            import oracle_py
+            cores = min(len(os.sched_getaffinity(0)), 16)
+            os.environ["OMP_NUM_THREADS"] = str(cores)
+            mix = dict(pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)   # GpuTreeProver's gate mix
+
+            def timed(log_n, seed):
+                syn = nlx.SyntheticCircuit(log_n, seed=seed, num_public_inputs=8, **mix)
+                oc = oracle_py.Circuit.from_synthetic(syn)
+                t = time.time()
+                oc.prove(syn.wires, syn.public_inputs)
+                dt_ = time.time() - t
+                oc.close()
+                return dt_
+            s_map = min(15, args.map_log_n)
+            timed(max(args.reduce_log_n - 3, 6), 97)     # spins up the OpenMP team
+            t_red = timed(args.reduce_log_n, 98)
+            t_map = t_outer_2p15 if (t_outer_2p15 is not None and s_map == 15) else timed(s_map, 99)
+            total = 32 * t_map * 2.0 ** (args.map_log_n - s_map) + 32 * t_red
+            return {"value": 1.0 / total, "unit": "proofs/s", "cores": cores, "kind": "port",
+                    "sample": "oracle prover: one reduce-sized proof (2^%d rows) %.2f s x 32, one 2^%d-row proof %.2f s x %d (linear in rows) "
+                              "x 32 map proofs -> %.0f s per 128 x 4 job" % (args.reduce_log_n, t_red, s_map, t_map,
+                                                                            int(2.0 ** (args.map_log_n - s_map)), total),
+                    "external_anchor": "the reference's README.md:123 quotes ~12 min per 128 x 4 job = 0.0014 proofs/s (22 s per "
+                                       "batch of 4, no parallelisation) on a Ryzen 9 7950X, witness generation and RPC included - "
+                                       "not like-for-like"}
+    return mr.bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer, cpu)
+
+
 def main():
     args = parse()
     import torch
@@ -1342,18 +1407,7 @@ def main():
     elif args.workload in ("sha256", "sha512"):
         out = run_sha256(args, nlx, torch, rank, world, local, dist)
     else:
-        from importlib import import_module
-        mr = import_module("nlx_amd.mapreduce")
-        verify_outer = None
-        if not args.no_cpu_baseline:
-            def verify_outer(syn, proof):   # the checker (test oracle's plonky2 verifier) on the job's outer proof
-                sys.path.insert(0, os.path.join(ROOT, "oracle"))
-                import oracle_py
-                oc = oracle_py.Circuit.from_synthetic(syn)
-                ok = oc.verify(proof) == 1
-                oc.close()
-                return ok
-        out = mr.bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer)
+        out = run_verify128(args, nlx, torch, rank, world, local, dist)
     if rank == 0:
         if os.environ.get("NLX_BENCH_REHEARSAL") == "1":
             out["config"]["rehearsal"] = "all ranks share GPU 0, gloo backend: NOT a scaling measurement"

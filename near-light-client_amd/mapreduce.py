@@ -87,6 +87,8 @@ def all_gather_blobs(local, n_jobs, rank, world, dist, device=None):
     if dist is None or world == 1:
         return [local[j] for j in range(n_jobs)]
     import torch
+    if device is None:   # RCCL moves device tensors only: this rank's own GPU; gloo (CPU tests, rehearsal) host tensors
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     per = (n_jobs + world - 1) // world
     packed = {j: b.pack() for j, b in local.items()}
     lens = torch.zeros(per, dtype=torch.int64, device=device)
@@ -98,7 +100,7 @@ def all_gather_blobs(local, n_jobs, rank, world, dist, device=None):
     send = torch.zeros((per, width), dtype=torch.uint8)
     for j, raw in packed.items():
         send[j // world, :len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
-    send = send.to(lens.device)
+    send = send.to(device)
     recv = [torch.zeros_like(send) for _ in range(world)]
     dist.all_gather(recv, send)
     out = []
@@ -260,8 +262,10 @@ class GpuTreeProver:
             return list(ex.map(lambda job: self(*job), jobs))
 
 
-def bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer=None):
-    """bench.py --workload verify128: whole VerifyCircuit-128x4-shaped job per step, strong scaling."""
+def bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer=None, cpu_baseline=None):
+    """bench.py --workload verify128 (and the `verify128` record of the default Sync line): whole VerifyCircuit-128x4-shaped
+    job per step, strong scaling.  cpu_baseline: a callable returning the line's cpu_baseline object (bench.py times the
+    test oracle there - this module never touches it) or None."""
     import time
     plan = TreePlan(32)
     # the request: the reference's own 128-id Verify request when its fixture is present (every rank reads the same file)
@@ -308,6 +312,8 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer=Non
             map_starks()
         root, _ = run_tree(plan, prover, rank, world, dist, device, request)
     sync()
+    for wk in prover.workers:
+        wk["ctx"].kernel_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if sha is not None:
@@ -315,6 +321,13 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer=Non
         root, stats = run_tree(plan, prover, rank, world, dist, device, request)
     sync()
     dt = time.perf_counter() - t0
+    # the dominant kernel of the job = Poseidon leaf hashing of the map proofs' LDE tables (8cL + 32L bytes per launch,
+    # SURVEY.md §8d), timed by HIP events on every worker context's own stream inside the timed region
+    calls, ms, alg = 0, 0.0, 0.0
+    for wk in prover.workers:
+        n_, ms_, b_ = wk["ctx"].kernel_stats("hash_lde_leaves")
+        calls, ms, alg = calls + n_, ms + ms_, alg + b_
+        wk["ctx"].kernel_timing(False)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -343,5 +356,12 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer=Non
                    "root_digest": [int(x) for x in root], "bytes_gathered_last_step": stats["bytes_gathered"],
                    "output_bytes": len(stats["output"]), "output_lists_every_id_as_verified": output_ok,
                    "oracle_verifier_accepts_outer_proof": outer_ok, "parallelism": "mapreduce x%d" % world},
-        "roofline": None, "cpu_baseline": None,
+        "roofline": None if not calls else {
+            "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / 8000.0,
+            "traffic": None, "kernel": "k_hash_lde_leaves", "launches": calls, "avg_launch_ms": ms / calls,
+            "alg_bytes_per_launch": alg / calls,
+            "note": "rank 0's launches of the last timed steps, every tree level together (map proofs at 2^%d rows dominate); "
+                    "integer-VALU bound like the Sync line's (DESIGN.md §4); with %d proofs in flight the event windows of "
+                    "concurrent streams overlap" % (args.map_log_n, args.inflight)},
+        "cpu_baseline": cpu_baseline() if cpu_baseline is not None else None,
     }

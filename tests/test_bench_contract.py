@@ -142,3 +142,29 @@ def test_two_ranks_over_rccl():
     assert "rehearsal" not in d["config"] and d["scaling"] == "strong"
     one = run_bench(*VERIFY_ARGS, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", timeout=600)
     assert one["config"]["root_digest"] == d["config"]["root_digest"]
+
+
+def _run_dist_units(backend, port, n=2):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "tools", "dist_units.py"), backend]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert r.stdout.count("dist_units ok") == n, r.stdout[-2000:]
+
+
+def test_exchange_primitives_two_and_three_ranks_gloo():
+    """mapreduce.all_gather_blobs (ragged blobs, job counts that are not multiples of the rank count, a rank that owns nothing)
+    and split_ntt._exchange under torch.distributed.run on host tensors - the same script the RCCL test below runs"""
+    _run_dist_units("gloo", 29651, 2)
+    _run_dist_units("gloo", 29652, 3)
+
+
+@pytest.mark.gpu
+def test_exchange_primitives_two_ranks_rccl():
+    """the same two primitives over backend nccl = RCCL with one rank per GPU and every tensor on the rank's own device: the
+    first thing to run on a multi-GPU node (skipped where fewer than two GPUs are visible - RCCL refuses two ranks on one)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_dist_units("nccl", 29653, 2)
