@@ -163,4 +163,98 @@ __device__ __forceinline__ void mds_layer(F (&s)[12], const uint64_t* __restrict
     for (int i = 0; i < 12; i++) s[i] = o[i];
 }
 
+
+// ---- the linear layer on the MATRIX cores ----------------------------------------------------------------------------
+// out[r] = sum_j M[r][j] s_j with M[r][j] = C[(j - r) mod 12] (+ 8 at [0][0]) and 64-bit s_j = sum_b 2^(8b) byte_b(s_j): eight
+// products of the constant 12 x 12 matrix with the state's byte planes - ONE v_mfma_i32_32x32x32_i8 each for all 64 states of
+// a wave (one state per lane, as everywhere in the hashing kernels).  No lane ever moves data: column n of B is supplied by
+// lane n (k < 16) and lane n + 32 (k >= 16), each its OWN state's twelve bytes of the plane, and A is placed so that output r
+// of the state in lane n + 32 h lands in row (r & 3) + 8 (r >> 2) + 4 h - which the 32 x 32 accumulator layout (col =
+// lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) hands back to that same lane as register r.  A lane's outputs
+// depend on its own inputs only, so lanes that have left the kernel do no harm.  The instruction's bytes are signed: the
+// planes are biased by 128 (xor 0x80) and 128 * rowsum * (1 + 2^8 + 2^16 + 2^24) rides in the table that seeds the
+// recombination (RCB, with the next round's constants).  Per layer: 24 xor + 48 v_perm + 8 MFMA + 96 v_mad_i64_i32 + the
+// 4-instruction folds = ~285 vector instructions where the multiply-accumulate form above needs ~430; the matrix pipe runs
+// beside the vector pipe.  Measured (tools/ubench, profiles/r03_poseidon_occupancy.txt): 1.74 -> 2.09 G permutations/s,
+// bit-identical outputs.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+
+// this lane's A operand: A[row = lane & 31][k = 16 (lane >> 5) + j], j = 0 .. 15 (the same k order as the B operand below,
+// whatever the hardware's order inside a lane's sixteen bytes is)
+__device__ __forceinline__ i32x4_t mds_a_fragment() {
+    constexpr int C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const uint32_t lane = threadIdx.x & 63, rho = lane & 31, h = lane >> 5;
+    const uint32_t g = (rho >> 2) & 1, r = (rho & 3) + 4 * (rho >> 3);
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (h == g && rho < 24) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int rr = 0; rr < 12; rr++)
+                if ((uint32_t)rr == r) m = (uint32_t)C[(j - rr + 12) % 12] + ((rr == 0 && j == 0) ? 8u : 0u);
+            w[j >> 2] |= m << (8 * (j & 3));
+        }
+    }
+    i32x4_t a;
+    a.x = (int)w[0]; a.y = (int)w[1]; a.z = (int)w[2]; a.w = (int)w[3];
+    return a;
+}
+// 4 x 4 byte transpose: p[b] = (x0.byte b, x1.byte b, x2.byte b, x3.byte b)
+__device__ __forceinline__ void transpose_bytes4(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t (&p)[4]) {
+    const uint32_t t01l = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t01h = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
+    const uint32_t t23l = __builtin_amdgcn_perm(x3, x2, 0x05010400u), t23h = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
+    p[0] = __builtin_amdgcn_perm(t23l, t01l, 0x05040100u);
+    p[1] = __builtin_amdgcn_perm(t23l, t01l, 0x07060302u);
+    p[2] = __builtin_amdgcn_perm(t23h, t01h, 0x05040100u);
+    p[3] = __builtin_amdgcn_perm(t23h, t01h, 0x07060302u);
+}
+__device__ __forceinline__ int opaque_sgpr(int v) {   // a wave-uniform constant the compiler must treat as a register, so
+    asm("" : "+s"(v));                                 // that d * 2^(8k) + acc stays ONE v_mad_i64_i32 (not shifts and adds)
+    return v;
+}
+// rcb: 24 wave-uniform words: [r] = bias + low half of the NEXT round's constant r, [12 + r] = bias + its high half
+__device__ __forceinline__ void mds_layer_mfma(F (&s)[12], const i32x4_t a, const uint64_t* __restrict__ rcb) {
+    const int m0 = opaque_sgpr(1), m8 = opaque_sgpr(1 << 8), m16 = opaque_sgpr(1 << 16), m24 = opaque_sgpr(1 << 24);
+    i32x16_t zero;
+#pragma unroll
+    for (int i = 0; i < 16; i++) zero[i] = 0;
+    uint64_t acc[2][12];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {   // planes 0 .. 3 come from the low words, 4 .. 7 from the high words
+        uint32_t pl[4][3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            uint32_t p[4];
+            if (half == 0)
+                transpose_bytes4(s[4 * q].lo ^ 0x80808080u, s[4 * q + 1].lo ^ 0x80808080u, s[4 * q + 2].lo ^ 0x80808080u,
+                                 s[4 * q + 3].lo ^ 0x80808080u, p);
+            else
+                transpose_bytes4(s[4 * q].hi ^ 0x80808080u, s[4 * q + 1].hi ^ 0x80808080u, s[4 * q + 2].hi ^ 0x80808080u,
+                                 s[4 * q + 3].hi ^ 0x80808080u, p);
+#pragma unroll
+            for (int b = 0; b < 4; b++) pl[b][q] = p[b];
+        }
+        i32x16_t d[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            i32x4_t bf;
+            bf.x = (int)pl[b][0]; bf.y = (int)pl[b][1]; bf.z = (int)pl[b][2]; bf.w = 0;
+            d[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf, zero, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 12; r++) {
+            int64_t t = (int64_t)d[0][r] * m0 + (int64_t)rcb[12 * half + r];
+            t = (int64_t)d[1][r] * m8 + t;
+            t = (int64_t)d[2][r] * m16 + t;
+            t = (int64_t)d[3][r] * m24 + t;
+            acc[half][r] = (uint64_t)t;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the low half's sixteen-register results are dead before the high half's exist
+    }
+#pragma unroll
+    for (int r = 0; r < 12; r++) s[r] = fold_acc(acc[0][r], acc[1][r]);
+}
+
 }  // namespace gl32

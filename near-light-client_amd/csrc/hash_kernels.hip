@@ -13,9 +13,12 @@
 
 namespace nlx {
 
-__global__ __launch_bounds__(256) void k_permute_batch(uint64_t* __restrict__ states, size_t n) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
+__global__ __launch_bounds__(256, 4) void k_permute_batch(uint64_t* __restrict__ states, size_t n) {
+    // every lane of a wave stays in the kernel through the permutation: its linear layer is a matrix-core product whose constant
+    // operand is spread over all 64 lanes (gl32::mds_layer_mfma); a lane beyond the end redoes the last state and stores nothing
+    const size_t t_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t_raw < n;
+    const size_t t = live ? t_raw : n - 1;
     uint64_t s[12];
     const ulonglong2* src = reinterpret_cast<const ulonglong2*>(states + t * 12);
 #pragma unroll
@@ -25,6 +28,7 @@ __global__ __launch_bounds__(256) void k_permute_batch(uint64_t* __restrict__ st
         s[2 * i + 1] = v.y;
     }
     poseidon::permute(s);
+    if (!live) return;
     ulonglong2* dst = reinterpret_cast<ulonglong2*>(states + t * 12);
 #pragma unroll
     for (int i = 0; i < 6; i++) dst[i] = make_ulonglong2(s[2 * i], s[2 * i + 1]);
@@ -37,10 +41,11 @@ __device__ __forceinline__ void store_digest(uint64_t* __restrict__ out, size_t 
 }
 
 // Leaf digests of row-major leaves (the MerkleTree::new(leaves, cap_height) calling convention).
-__global__ __launch_bounds__(256) void k_hash_leaves_rowmajor(const uint64_t* __restrict__ rows, uint32_t row_len,
+__global__ __launch_bounds__(256, 4) void k_hash_leaves_rowmajor(const uint64_t* __restrict__ rows, uint32_t row_len,
                                                               size_t n_rows, uint64_t* __restrict__ digests) {
-    size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
+    const size_t row_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = row_raw < n_rows;               // spare lanes redo the last row (see k_permute_batch) and store nothing
+    const size_t row = live ? row_raw : n_rows - 1;
     uint64_t s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256) void k_hash_leaves_rowmajor(const uint64_t* __
             uint64_t v = p[c];
             if (c == 0) s[0] = v; else if (c == 1) s[1] = v; else if (c == 2) s[2] = v; else s[3] = v;
         }
-        store_digest(digests, row, s);
+        if (live) store_digest(digests, row, s);
         return;
     }
     uint32_t c = 0;
@@ -66,14 +71,15 @@ __global__ __launch_bounds__(256) void k_hash_leaves_rowmajor(const uint64_t* __
             if ((uint32_t)j < rem) s[j] = p[c + j];
         poseidon::permute_loose(s);
     }
-    store_digest(digests, row, s);
+    if (live) store_digest(digests, row, s);
 }
 
 // One interior level: parent[i] = two_to_one(child[2i], child[2i+1]).
-__global__ __launch_bounds__(256) void k_merkle_level(const uint64_t* __restrict__ children,
+__global__ __launch_bounds__(256, 4) void k_merkle_level(const uint64_t* __restrict__ children,
                                                       uint64_t* __restrict__ parents, size_t n_parents) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_parents) return;
+    const size_t i_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i_raw < n_parents;              // spare lanes redo the last parent (see k_permute_batch) and store nothing
+    const size_t i = live ? i_raw : n_parents - 1;
     const ulonglong2* src = reinterpret_cast<const ulonglong2*>(children + i * 8);
     uint64_t s[12];
 #pragma unroll
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void k_merkle_level(const uint64_t* __restrict
     }
     s[8] = s[9] = s[10] = s[11] = 0;
     poseidon::permute_loose(s);
-    store_digest(parents, i, s);
+    if (live) store_digest(parents, i, s);
 }
 
 constexpr size_t MERKLE_WIDE_MAX_PARENTS = (size_t)1 << 14;
@@ -144,11 +150,12 @@ namespace nlx {
 // instead of a transposed copy of the whole table.
 constexpr size_t HASH_LEAVES_WIDE_MAX_ROWS = (size_t)1 << 13;  // measured crossover (4 745 columns): 2^13 rows 16 vs 24 ms, 2^14 rows 31 vs 26 ms
 
-__global__ __launch_bounds__(256) void k_hash_lde_leaves(const uint64_t* __restrict__ lde, size_t col_stride,
+__global__ __launch_bounds__(256, 4) void k_hash_lde_leaves(const uint64_t* __restrict__ lde, size_t col_stride,
                                                          uint32_t n_cols, unsigned log_n, unsigned rate_bits,
                                                          uint64_t* __restrict__ digests) {
-    size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >> (log_n + rate_bits)) return;
+    const size_t pos_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = (pos_raw >> (log_n + rate_bits)) == 0;   // spare lanes redo the last point (see k_permute_batch), store nothing
+    const size_t pos = live ? pos_raw : ((size_t)1 << (log_n + rate_bits)) - 1;
     uint64_t s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(256) void k_hash_lde_leaves(const uint64_t* __restr
             uint64_t v = p[(size_t)c * col_stride];
             if (c == 0) s[0] = v; else if (c == 1) s[1] = v; else if (c == 2) s[2] = v; else s[3] = v;
         }
-        store_digest(digests, leaf, s);
+        if (live) store_digest(digests, leaf, s);
         return;
     }
     uint32_t c = 0;
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(256) void k_hash_lde_leaves(const uint64_t* __restr
             if ((uint32_t)j < rem) s[j] = p[(size_t)(c + j) * col_stride];
         poseidon::permute_loose(s);
     }
-    store_digest(digests, leaf, s);
+    if (live) store_digest(digests, leaf, s);
 }
 
 void launch_hash_lde_leaves_wide(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols, unsigned log_n,

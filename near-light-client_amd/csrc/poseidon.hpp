@@ -23,6 +23,25 @@ constexpr int N_PARTIAL = 22;
 
 #if defined(__HIP__)
 __constant__ static const uint64_t RC_DEV[360] = NLX_POSEIDON_ROUND_CONSTANTS_INIT;
+// Seeds of the matrix-core linear layer's recombination (gl32::mds_layer_mfma): for layer l = 0 .. 30 and output r, the
+// byte-plane bias 128 * rowsum(r) * (1 + 2^8 + 2^16 + 2^24) plus the low ([r]) / high ([12 + r]) half of round l's constant
+// (l = 30: the bias alone - the last layer adds no constant).
+struct RcbTable {
+    uint64_t v[31 * 24];
+};
+constexpr RcbTable make_rcb_table() {
+    constexpr uint64_t rc[360] = NLX_POSEIDON_ROUND_CONSTANTS_INIT;
+    RcbTable t{};
+    for (int l = 0; l <= 30; l++)
+        for (int r = 0; r < 12; r++) {
+            const uint64_t bias = 128ull * (r == 0 ? 264ull : 256ull) * 0x01010101ull;
+            const uint64_t c = l < 30 ? rc[l * 12 + r] : 0ull;
+            t.v[l * 24 + r] = bias + (c & 0xFFFFFFFFull);
+            t.v[l * 24 + 12 + r] = bias + (c >> 32);
+        }
+    return t;
+}
+__constant__ static const RcbTable RCB_DEV = make_rcb_table();
 #endif
 static const uint64_t RC_HOST[360] = NLX_POSEIDON_ROUND_CONSTANTS_INIT;
 
@@ -78,8 +97,12 @@ GL_HD void mds_layer(uint64_t (&s)[12]) {
 GL_HD void permute_loose(uint64_t (&s)[12]) {
     const uint64_t* rc = rc_table();
 #if defined(__HIP_DEVICE_COMPILE__)
-    // device: {lo, hi} u32 pairs with hand-placed carry chains (gl32.hpp); every round's constants
-    // seed the accumulators of the PREVIOUS linear layer (only round 0 adds them explicitly)
+    // device: {lo, hi} u32 pairs with hand-placed carry chains (gl32.hpp); the linear layer runs on the matrix cores
+    // (gl32::mds_layer_mfma: one state per lane, all of a wave's lanes together) and every round's constants seed the
+    // recombination of the PREVIOUS layer (only round 0 adds them explicitly).  Callers keep the call in wave-uniform
+    // control flow (lanes may have LEFT the kernel - a lane's results depend on its own inputs only).
+    const uint64_t* rcb = RCB_DEV.v;
+    const gl32::i32x4_t a = gl32::mds_a_fragment();
     gl32::F t[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) t[i] = gl32::add_const(gl32::from_u64(s[i]), rc[i]);
@@ -87,22 +110,19 @@ GL_HD void permute_loose(uint64_t (&s)[12]) {
     for (int r = 0; r < HALF_FULL; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) t[i] = gl32::sbox7(t[i]);
-        gl32::mds_layer(t, rc + (r + 1) * 12);
+        gl32::mds_layer_mfma(t, a, rcb + (r + 1) * 24);
     }
 #pragma unroll 1
     for (int r = HALF_FULL; r < HALF_FULL + N_PARTIAL; r++) {
         t[0] = gl32::sbox7(t[0]);
-        gl32::mds_layer(t, rc + (r + 1) * 12);
+        gl32::mds_layer_mfma(t, a, rcb + (r + 1) * 24);
     }
 #pragma unroll 1
-    for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS - 1; r++) {
+    for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) t[i] = gl32::sbox7(t[i]);
-        gl32::mds_layer(t, rc + (r + 1) * 12);
+        gl32::mds_layer_mfma(t, a, rcb + (r + 1) * 24);   // r + 1 = 30: the bias alone
     }
-#pragma unroll
-    for (int i = 0; i < 12; i++) t[i] = gl32::sbox7(t[i]);
-    gl32::mds_layer(t);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl32::to_u64(t[i]);
 #else

@@ -1115,12 +1115,13 @@ void launch_fri_combine(hipStream_t st, const FriCombineParams& p, uint64_t* scr
 // (r, k' + mm * n/arity), in-leaf slot m = bitrev(mm); its tree position is
 // bitrev(r) * n' + bitrev(k').
 template <int ARITY_BITS>
-__global__ __launch_bounds__(256) void k_fri_leaves(const uint64_t* __restrict__ values, unsigned log_n,
+__global__ __launch_bounds__(256, 4) void k_fri_leaves(const uint64_t* __restrict__ values, unsigned log_n,
                                                     unsigned rate_bits, uint64_t* __restrict__ digests) {
     constexpr int ARITY = 1 << ARITY_BITS;
     const unsigned log_np = log_n - ARITY_BITS;
-    const size_t jp = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (jp >> (log_np + rate_bits)) return;
+    const size_t jp_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = (jp_raw >> (log_np + rate_bits)) == 0;   // every lane stays through the permutation (its linear layer is a
+    const size_t jp = live ? jp_raw : ((size_t)1 << (log_np + rate_bits)) - 1;   // wave-wide matrix product); spare lanes store nothing
     const size_t np = (size_t)1 << log_np, n = (size_t)1 << log_n;
     const uint32_t r = (uint32_t)(jp >> log_np), kp = (uint32_t)(jp & (np - 1));
     const ulonglong2* v = reinterpret_cast<const ulonglong2*>(values) + ((size_t)r * n + kp);
@@ -1140,6 +1141,7 @@ __global__ __launch_bounds__(256) void k_fri_leaves(const uint64_t* __restrict__
         }
         poseidon::permute_loose(s);
     }
+    if (!live) return;
     const size_t leaf = ((size_t)gl::bitrev32(r, rate_bits) << log_np) + gl::bitrev32(kp, log_np);
     ulonglong2* dst = reinterpret_cast<ulonglong2*>(digests + leaf * 4);
     dst[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));
@@ -1163,8 +1165,9 @@ __global__ __launch_bounds__(256) void k_fri_fold(const uint64_t* __restrict__ v
     constexpr int ARITY = 1 << ARITY_BITS;
     const unsigned log_np = log_n - ARITY_BITS;
     const unsigned log_L = log_n + rate_bits;
-    const size_t jp = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (jp >> (log_np + rate_bits)) return;
+    const size_t jp_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = (jp_raw >> (log_np + rate_bits)) == 0;   // every lane stays through the permutation (its linear layer is a
+    const size_t jp = live ? jp_raw : ((size_t)1 << (log_np + rate_bits)) - 1;   // wave-wide matrix product); spare lanes store nothing
     const size_t np = (size_t)1 << log_np, n = (size_t)1 << log_n;
     const uint32_t r = (uint32_t)(jp >> log_np), kp = (uint32_t)(jp & (np - 1));
     const ulonglong2* v = reinterpret_cast<const ulonglong2*>(values) + ((size_t)r * n + kp);
@@ -1236,16 +1239,18 @@ void launch_fri_final_coeffs(hipStream_t st, const uint64_t* d_values, unsigned 
 // 2^16 candidates per round: with 16 PoW bits a round succeeds with probability 1 - 1/e and costs one
 // permutation latency (a 2^18 round is throughput-bound and takes ~4x longer)
 constexpr uint32_t POW_GRID = 256, POW_BLOCK = 256;
-__global__ __launch_bounds__(POW_BLOCK) void k_pow_grind(PowParams p, unsigned long long* __restrict__ best) {
+__global__ __launch_bounds__(POW_BLOCK, 4) void k_pow_grind(PowParams p, unsigned long long* __restrict__ best) {
     const uint64_t stride = (uint64_t)POW_GRID * POW_BLOCK;
     const uint64_t gid = (uint64_t)blockIdx.x * POW_BLOCK + threadIdx.x;
     for (uint64_t round = 0; round < p.max_rounds; round++) {
         const uint64_t cand = round * stride + gid;
         // a smaller nonce found in an earlier round (or earlier in this one) ends the search:
         // every candidate below it has been or is being tested by a lane that cannot skip it.
+        // (a wave leaves only as a whole: the permutation's linear layer is a matrix-core product over all 64 lanes)
         const unsigned long long b = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (b < round * stride) return;
-        if (cand >= gl::P) return;
+        if (__builtin_amdgcn_readfirstlane((uint32_t)(b < round * stride))) return;   // any lane's view will do: best only falls
+        const bool valid = cand < gl::P;
+        if (!__any((int)valid)) return;
         uint64_t s[12];
 #pragma unroll
         for (int i = 0; i < 12; i++) s[i] = p.state[i];
@@ -1255,7 +1260,7 @@ __global__ __launch_bounds__(POW_BLOCK) void k_pow_grind(PowParams p, unsigned l
         poseidon::permute(s);
         const uint64_t resp = s[7];
         const unsigned lz = resp ? (unsigned)__clzll((long long)resp) : 64u;
-        if (lz >= p.bits) atomicMin(best, (unsigned long long)cand);
+        if (valid && lz >= p.bits) atomicMin(best, (unsigned long long)cand);
     }
 }
 void launch_pow_grind(hipStream_t st, const PowParams& p, unsigned long long* d_best) {

@@ -262,8 +262,126 @@ __device__ __forceinline__ void permute_loose(uint64_t (&st)[12]) {
 }
 }  // namespace v3
 
+
+namespace v4 {
+// The linear layer on the MATRIX cores.  out[r] = sum_j M[r][j] s_j with M[r][j] = C[(j - r) mod 12] (+ 8 at [0][0]) and
+// 64-bit s_j = sum_b 2^(8b) byte_b(s_j): eight products of the constant 12 x 12 matrix with the state's byte planes, one
+// v_mfma_i32_32x32x32_i8 each for all 64 states of a wave.  No lane ever moves data: B[k][col n] is supplied by lanes n
+// (k < 16) and n + 32 (k >= 16) - each its OWN state's twelve bytes of the plane - and A is block-placed so that output r of
+// the state in lane n + 32 h lands in row (r & 3) + 8 (r >> 2) + 4 h, which the 32 x 32 accumulator layout (col = lane & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) hands back to that same lane as register r.  Bytes are signed for the
+// instruction, so the planes are biased by 128 (xor 0x80) and the constant 128 * rowsum * (1 + 2^8 + 2^16 + 2^24) rides in
+// the round-constant table (RCB) that seeds the recombination.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ i32x4 a_fragment() {
+    constexpr int C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const uint32_t lane = threadIdx.x & 63, rho = lane & 31, h = lane >> 5;
+    const uint32_t g = (rho >> 2) & 1, r = (rho & 3) + 4 * (rho >> 3);
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (h == g && rho < 24) {
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int rr = 0; rr < 12; rr++)
+                if ((uint32_t)rr == r) m = (uint32_t)C[(j - rr + 12) % 12] + ((rr == 0 && j == 0) ? 8u : 0u);
+            w[j >> 2] |= m << (8 * (j & 3));
+        }
+    }
+    i32x4 a;
+    a.x = (int)w[0]; a.y = (int)w[1]; a.z = (int)w[2]; a.w = (int)w[3];
+    return a;
+}
+
+// 4 x 4 byte transpose: p[b] = (x0.byte b, x1.byte b, x2.byte b, x3.byte b)
+__device__ __forceinline__ void transpose4(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t (&p)[4]) {
+    const uint32_t t01l = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t01h = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
+    const uint32_t t23l = __builtin_amdgcn_perm(x3, x2, 0x05010400u), t23h = __builtin_amdgcn_perm(x3, x2, 0x07030602u);
+    p[0] = __builtin_amdgcn_perm(t23l, t01l, 0x05040100u);
+    p[1] = __builtin_amdgcn_perm(t23l, t01l, 0x07060302u);
+    p[2] = __builtin_amdgcn_perm(t23h, t01h, 0x05040100u);
+    p[3] = __builtin_amdgcn_perm(t23h, t01h, 0x07060302u);
+}
+
+__device__ __forceinline__ int opaque_s(int v) {   // a wave-uniform constant the compiler must treat as a register
+    asm("" : "+s"(v));                              // (so that d * 2^8k + acc stays ONE v_mad_i64_i32 instead of shifts and adds)
+    return v;
+}
+// rcb: 24 wave-uniform words for this layer: [r] = bias + low half of the next round's constant, [12 + r] = bias + high half
+__device__ __forceinline__ void mds_layer(gl32::F (&s)[12], const i32x4 a, const uint64_t* __restrict__ rcb) {
+    const int m0 = opaque_s(1), m8 = opaque_s(1 << 8), m16 = opaque_s(1 << 16), m24 = opaque_s(1 << 24);
+    i32x16 zero;
+#pragma unroll
+    for (int i = 0; i < 16; i++) zero[i] = 0;
+    uint64_t acc[2][12];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {   // planes 0 .. 3 come from the low words, 4 .. 7 from the high words
+        uint32_t pl[4][3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            uint32_t p[4];
+            if (half == 0)
+                transpose4(s[4 * q].lo ^ 0x80808080u, s[4 * q + 1].lo ^ 0x80808080u, s[4 * q + 2].lo ^ 0x80808080u, s[4 * q + 3].lo ^ 0x80808080u, p);
+            else
+                transpose4(s[4 * q].hi ^ 0x80808080u, s[4 * q + 1].hi ^ 0x80808080u, s[4 * q + 2].hi ^ 0x80808080u, s[4 * q + 3].hi ^ 0x80808080u, p);
+#pragma unroll
+            for (int b = 0; b < 4; b++) pl[b][q] = p[b];
+        }
+        i32x16 d[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            i32x4 bf;
+            bf.x = (int)pl[b][0]; bf.y = (int)pl[b][1]; bf.z = (int)pl[b][2]; bf.w = 0;
+            d[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf, zero, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 12; r++) {
+            int64_t t = (int64_t)d[0][r] * m0 + (int64_t)rcb[12 * half + r];
+            t = (int64_t)d[1][r] * m8 + t;
+            t = (int64_t)d[2][r] * m16 + t;
+            t = (int64_t)d[3][r] * m24 + t;
+            acc[half][r] = (uint64_t)t;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 12; r++) s[r] = gl32::fold_acc(acc[0][r], acc[1][r]);
+}
+
+__device__ __forceinline__ void permute_loose(uint64_t (&st)[12], const uint64_t* __restrict__ rcb) {
+    const uint64_t* rc = poseidon::RC_DEV;
+    const i32x4 a = a_fragment();
+    gl32::F s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl32::add_const(gl32::from_u64(st[i]), rc[i]);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl32::sbox7(s[i]);
+        mds_layer(s, a, rcb + (r + 1) * 24);
+    }
+#pragma unroll 1
+    for (int r = 4; r < 26; r++) {
+        s[0] = gl32::sbox7(s[0]);
+        mds_layer(s, a, rcb + (r + 1) * 24);
+    }
+#pragma unroll 1
+    for (int r = 26; r < 30; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl32::sbox7(s[i]);
+        mds_layer(s, a, rcb + (r + 1) * 24);   // entry 30: the bias alone
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = gl32::to_u64(s[i]);
+}
+}  // namespace v4
+
+__device__ uint64_t RCB_DEV[31 * 24];
+
 template <int V>
-__global__ __launch_bounds__(256) void k_perm(uint64_t* states, size_t n, int reps) {
+__global__ __launch_bounds__(256, 4) void k_perm(uint64_t* states, size_t n, int reps) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     uint64_t s[12];
@@ -273,7 +391,8 @@ __global__ __launch_bounds__(256) void k_perm(uint64_t* states, size_t n, int re
         if (V == 0) poseidon::permute_loose(s);
         else if (V == 1) v1::permute_loose(s);
         else if (V == 2) v2::permute_loose(s);
-        else v3::permute_loose(s);
+        else if (V == 3) v3::permute_loose(s);
+        else v4::permute_loose(s, RCB_DEV);
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) states[i * n + t] = gl::canon(s[i]);
@@ -333,5 +452,47 @@ int main() {
     std::vector<uint64_t> o3;
     bench_perm<3>("poseidon v3 (rc in accumulators)", d_states, n, o3);
     printf("v3 == v0: %s\n", o0 == o3 ? "yes" : "NO");
+    {   // v4's table: per layer l (the constants of round l, l = 30: none) the 12 low and 12 high accumulator seeds
+        std::vector<uint64_t> rcb(31 * 24);
+        const uint64_t spread = 1ull + (1ull << 8) + (1ull << 16) + (1ull << 24);
+        for (int l = 0; l <= 30; l++)
+            for (int r = 0; r < 12; r++) {
+                const uint64_t bias = 128ull * (r == 0 ? 264 : 256) * spread;
+                const uint64_t c = l < 30 ? poseidon::RC_HOST[l * 12 + r] : 0;
+                rcb[l * 24 + r] = bias + (uint32_t)c;
+                rcb[l * 24 + 12 + r] = bias + (c >> 32);
+            }
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(RCB_DEV), rcb.data(), rcb.size() * 8));
+    }
+    std::vector<uint64_t> o4;
+    bench_perm<4>("poseidon v4 (MDS on v_mfma_i32_32x32x32_i8)", d_states, n, o4);
+    printf("v4 == v0: %s\n", o0 == o4 ? "yes" : "NO");
+    if (o0 != o4) {
+        size_t bad = 0, first = (size_t)-1;
+        for (size_t i = 0; i < o0.size(); i++) if (o0[i] != o4[i]) { bad++; if (first == (size_t)-1) first = i; }
+        printf("   %zu of %zu words differ, first at %zu (state %zu word %zu): %016llx vs %016llx\n", bad, o0.size(), first, first % n, first / n,
+               (unsigned long long)o0[first], (unsigned long long)o4[first]);
+    }
+    // occupancy: dynamic LDS per 256-lane block caps the blocks per CU = waves per SIMD (160 KB of LDS per CU)
+    for (int V = 0; V <= 1; V++)
+        for (int w : {8, 6, 5, 4, 3, 2}) {
+            const size_t lds = w == 8 ? 0 : (size_t)(160 * 1024 / w) & ~(size_t)255;
+            std::vector<uint64_t> init(12 * n);
+            uint64_t x = 88172645463325252ull;
+            for (auto& v : init) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = x % gl::P; }
+            CK(hipMemcpy(d_states, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            auto kern = V == 0 ? k_perm<0> : k_perm<4>;
+            CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL(kern, dim3((unsigned)(n / 256)), dim3(256), lds, 0, d_states, n, 1);
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(kern, dim3((unsigned)(n / 256)), dim3(256), lds, 0, d_states, n, 4);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("occupancy sweep %s: at most %d wave(s) per SIMD (dynamic LDS %zu B per block): %.3f ms -> %.3f G permutations/s\n",
+                   V == 0 ? "v0 (VALU MDS)" : "v4 (MFMA MDS)", w, lds, ms, (double)n * 4 / (ms * 1e-3) / 1e9);
+        }
     return 0;
 }
