@@ -39,18 +39,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-# Integer-VALU issue roofline of the Poseidon permutation kernels (profiles/r02_valu_ubench_v1.txt).  Measured
-# on MI355X at full occupancy: every 32 x 32-bit multiply form issues at 1.99 ns per wave-instruction per SIMD (and so does
-# every VCC-chained add).  The multiplies a permutation cannot do without: 4 per field multiplication (118 S-boxes x 4) and
-# 24 per MDS output (12 state elements x 2 halves; 12 outputs x 30 rounds) = 10 528 per permutation.  Peak = what the chip
-# would do if every other instruction were free: 1 024 SIMDs x 64 lanes / (10 528 x 1.99 ns).  The kernel issues ~17 k
-# instructions per permutation (reductions, carry chains, loads), all at about the same 2 ns.
-VALU_MULS_PER_PERM = 118 * 4 * 4 + 12 * 30 * 24
+# Integer-VALU issue roofline of the Poseidon permutation kernels (profiles/r02_valu_ubench_v1.txt, r03_poseidon_occupancy.txt).
+# Measured on MI355X: every 32 x 32-bit multiply form issues at 1.99 ns per wave-instruction per SIMD (and so does every
+# VCC-chained add).  Since round 3 the linear layer's 8 640 multiply-adds run on the matrix cores (eight v_mfma_i32_32x32x32_i8
+# per layer over the state's byte planes, beside the vector pipe); what the VECTOR pipe cannot do without is 4 multiplies per
+# field multiplication (118 S-boxes x 4) and, per layer, the 96 multiply-adds that put the byte planes' 32-bit sums back
+# together (12 outputs x 8 planes): 1 888 + 30 x 96 = 4 768 per permutation.  Peak = what the chip would do if every other
+# instruction were free: 1 024 SIMDs x 64 lanes / (4 768 x 1.99 ns) = 6.9 G permutations/s (the matrix pipe's own bound, 240 MFMAs
+# of 32 cycles per 64 permutations and SIMD, is ~17 G/s).  The kernel issues ~16 k vector instructions per permutation
+# (reductions, carry chains, byte transposes), all at about the same 2 ns.  Round 2's model (all multiply-adds on the vector
+# pipe: 10 528 per permutation, 3.13 G/s) is kept in the note so that the fractions of the two rounds can be compared.
+VALU_MULS_PER_PERM = 118 * 4 * 4 + 30 * 96
 VALU_NS_PER_MUL = 1.99
 VALU_PEAK_GPERM = 1024 * 64 / (VALU_MULS_PER_PERM * VALU_NS_PER_MUL)
-VALU_PEAK_NOTE = ("1 024 SIMDs x 64 lanes / (10 528 irreducible 32x32 multiply-adds per permutation x 1.99 ns measured issue cost per "
-                  "wave-instruction per SIMD at full occupancy, tools/ubench/poseidon_ubench.hip -> profiles/r02_valu_ubench_v1.txt); "
-                  "a bound on the multiplies alone - the permutation micro-benchmark itself reaches 1.74 Gperm/s")
+VALU_PEAK_NOTE = ("1 024 SIMDs x 64 lanes / (4 768 irreducible vector multiply-adds per permutation - 1 888 in the S-boxes, 96 per layer "
+                  "recombining the matrix cores' byte-plane sums - x 1.99 ns measured issue cost per wave-instruction per SIMD, "
+                  "tools/ubench/poseidon_ubench.hip -> profiles/r03_poseidon_occupancy.txt); the permutation micro-benchmark itself "
+                  "reaches 2.09 Gperm/s (1.74 with the linear layer on the vector pipe, round 2, whose bound was 10 528 multiply-adds "
+                  "= 3.13 Gperm/s: this line's achieved / 3.13 compares with round 2's fractions)")
 
 
 def stored_traffic(key, alg_bytes):
@@ -1230,7 +1236,11 @@ def run_msm24_g2(args, nlx, torch, rank, world, local, dist):
         "roofline": {"bound": "hbm", "achieved": (160.0 * n / (ms * 1e-3) / 1e9) if ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (160.0 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms else None, "traffic": None, "kernel": "bn254_msm_g2",
                      "launches": kt[0], "avg_launch_ms": ms, "alg_bytes_per_launch": 160.0 * n,
-                     "note": "160 bytes per point algorithmic; integer-VALU bound: three base-field products per Fq2 product"},
+                     "note": "160 bytes per point algorithmic; integer-VALU bound (see roofline_valu): three base-field products per Fq2 product"},
+        "roofline_valu": {"bound": "integer VALU issue", "achieved": (16.0 * n / (ms * 1e-3) / 1e9) if ms else None,
+                          "peak": 1024 * 64 / (3.7 * 3400 * 1.99), "unit": "G bucket additions/s",
+                          "frac": (16.0 * n / (ms * 1e-3) / 1e9) / (1024 * 64 / (3.7 * 3400 * 1.99)) if ms else None,
+                          "peak_model": "the G1 model x 3.7 (Karatsuba Fq2 products, every result tightened: DESIGN.md §13)"},
         "cpu_baseline": None,
     }
     if not args.no_cpu_baseline:
@@ -1272,6 +1282,7 @@ def run_msm24(args, nlx, torch, rank, world, local, dist):
     n_all = n * world
     ks = torch.randint(0, 2 ** 62, (n_all, 4), generator=g, dtype=torch.int64) * 4 + torch.randint(0, 4, (n_all, 4), generator=g, dtype=torch.int64)
     ks[:, 3] = torch.randint(0, 0x30644e72e131a029, (n_all,), generator=g, dtype=torch.int64)   # top word below r's: uniform scalars < r, canonical form
+    ks_all = ks
     ks = ks[rank * n:(rank + 1) * n].contiguous()
     d_ks = ks.to(dev)
 
@@ -1312,10 +1323,23 @@ def run_msm24(args, nlx, torch, rank, world, local, dist):
                          "frac": (96.0 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms else None, "traffic": None,
                          "kernel": "bn254_msm_g1 (digits, scan, 16 radix sorts, bucket sums, window reduction)", "launches": kt[0],
                          "avg_launch_ms": ms, "alg_bytes_per_launch": 96.0 * n,
-                         "note": "96 bytes per point algorithmic (point + scalar once); the job is bound by the integer-VALU issue rate: "
-                                 "16 mixed Jacobian additions per point, 11 Montgomery products of ~170 multiply-adds each"},
+                         "note": "96 bytes per point algorithmic (point + scalar once); the job is bound by the integer-VALU issue rate - "
+                                 "see roofline_valu"},
+            # the bound that binds: one mixed Jacobian addition per (point, window) pair, ~3 400 vector instructions each
+            # (1 644 of them multiply-adds), every instruction at the measured 1.99 ns per wave-instruction per SIMD
+            "roofline_valu": {"bound": "integer VALU issue", "achieved": adds_per_s / 1e9 if adds_per_s else None,
+                              "peak": 1024 * 64 / (3400 * 1.99), "unit": "G bucket additions/s",
+                              "frac": (adds_per_s / 1e9) / (1024 * 64 / (3400 * 1.99)) if adds_per_s else None,
+                              "peak_model": "1 024 SIMDs x 64 lanes / (3 400 instructions per mixed addition x 1.99 ns, profiles/r02_valu_ubench_v5.txt); "
+                                            "sorting and the window reduction are inside the measured time"},
             "cpu_baseline": None,
         }
+        if world > 1:
+            # the joined result against the model: sum_i k_i (i + 1) base over ALL ranks' scalars, one scalar multiplication
+            kw = ks_all.numpy().view(np.uint64).astype(object)
+            ints = kw[:, 0] + (kw[:, 1] << 64) + (kw[:, 2] << 128) + (kw[:, 3] << 192)
+            total = int((ints * np.arange(1, n * world + 1, dtype=object)).sum()) % bn254_py.R
+            out["config"]["joined_result_equals_model"] = bool(nlx.bn254_g1_unpack(res) == bn254_py.g1_mul(total, base))
         if not args.no_cpu_baseline and world == 1:
             # the model on the same input: sum_i k_i (i + 1) base = (sum_i k_i (i + 1) mod r) base - one scalar multiplication
             # pins the whole result; its speed is measured on a sample of plain scalar multiplications

@@ -155,7 +155,8 @@ int32_t nlx_bn254_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_
  * is multiplied by shift^j first), inverse interpolates from there (coefficient j is multiplied by shift^-j last).
  * NLX_BN254_BITREV_OUT: natural order in, bit-reversed order out - what fft.DIF leaves; NLX_BN254_BITREV_IN: bit-reversed
  * order in, natural order out - fft.DIT (decimation in time).  Neither has a reordering pass: a prover that alternates
- * them (FFTInverse(DIF) -> pointwise work -> FFT(DIT, OnCoset)), as gnark's does, never reorders.  Not both at once. */
+ * them (FFTInverse(DIF) -> pointwise work -> FFT(DIT, OnCoset)), as gnark's does, never reorders.  Not both at once.
+ * coset_shift is read on the HOST (a device pointer is refused); with flags = 0 it must be a canonical integer below r. */
 #define NLX_BN254_BITREV_OUT 2u
 #define NLX_BN254_BITREV_IN 4u
 int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_n, int inverse, uint32_t flags,

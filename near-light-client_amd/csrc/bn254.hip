@@ -495,12 +495,28 @@ int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, u
         Fr* d_lo = (Fr*)ctx->alloc(4096 * sizeof(Fr));
         Fr* d_hi = (Fr*)ctx->alloc(n_hi * sizeof(Fr));
         tb.d_lo = (Fr*)ctx->alloc(half * sizeof(Fr));
-        if (!d_lo || !d_hi || !tb.d_lo) return NLX_E_NOMEM;
-        NLX_HIP(ctx, hipMemcpyAsync(d_lo, lo.data(), 4096 * sizeof(Fr), hipMemcpyHostToDevice, st));
-        NLX_HIP(ctx, hipMemcpyAsync(d_hi, hi.data(), n_hi * sizeof(Fr), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(bn::k_bn_fill_twiddles, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, tb.d_lo, half, d_lo, d_hi,
-                           bn::from_limbs(bn::H_K261));
-        NLX_HIP(ctx, hipStreamSynchronize(st));
+        // a table that could not be built completely is not kept: every block goes back to the context's allocator
+        auto drop = [&]() {
+            ctx->release(d_lo);
+            ctx->release(d_hi);
+            ctx->release(tb.d_lo);
+            tb.d_lo = nullptr;
+        };
+        if (!d_lo || !d_hi || !tb.d_lo) {
+            drop();
+            return ctx->fail(NLX_E_NOMEM, "BN254 twiddle table for 2^%u points (%zu bytes)", log_n, half * sizeof(Fr));
+        }
+        hipError_t te = hipMemcpyAsync(d_lo, lo.data(), 4096 * sizeof(Fr), hipMemcpyHostToDevice, st);
+        if (te == hipSuccess) te = hipMemcpyAsync(d_hi, hi.data(), n_hi * sizeof(Fr), hipMemcpyHostToDevice, st);
+        if (te == hipSuccess) {
+            hipLaunchKernelGGL(bn::k_bn_fill_twiddles, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, tb.d_lo, half, d_lo, d_hi,
+                               bn::from_limbs(bn::H_K261));
+            te = hipStreamSynchronize(st);
+        }
+        if (te != hipSuccess) {
+            drop();
+            return ctx->hip_fail(te, "BN254 twiddle table");
+        }
         ctx->release(d_lo);
         ctx->release(d_hi);
         slot = tb.d_lo;
@@ -536,7 +552,7 @@ int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, u
             pw = bn::mul(pw, step);
         }
         d_pow = (Fr*)ctx->alloc(t.size() * sizeof(Fr));
-        if (!d_pow) return NLX_E_NOMEM;
+        if (!d_pow) return ctx->fail(NLX_E_NOMEM, "BN254 coset power table");
         hipError_t e = hipMemcpyAsync(d_pow, t.data(), t.size() * sizeof(Fr), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);                    // t is a local
         if (e != hipSuccess) return ctx->hip_fail(e, "hipMemcpyAsync(coset powers)");
@@ -546,8 +562,17 @@ int32_t nlx_bn254_ntt_batch_coset(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, u
     };
     Fr shift_mont{};
     if (coset_shift) {
+        if (nlx::is_device_ptr(coset_shift)) return ctx->fail(NLX_E_INVAL, "coset_shift is read on the host: pass a host pointer");
         for (int i = 0; i < 4; i++) { shift_mont.v[2 * i] = (uint32_t)coset_shift[i]; shift_mont.v[2 * i + 1] = (uint32_t)(coset_shift[i] >> 32); }
-        if (!mont_io) shift_mont = bn::mul(shift_mont, bn::from_limbs(bn::H_R2));
+        if (!mont_io) {
+            // canonical integers must be below r (compare from the top limb down)
+            bool below = false;
+            for (int i = 7; i >= 0; i--) {
+                if (shift_mont.v[i] != bn::H_MOD[i]) { below = shift_mont.v[i] < bn::H_MOD[i]; break; }
+            }
+            if (!below) return ctx->fail(NLX_E_INVAL, "coset shift is not below the modulus");
+            shift_mont = bn::mul(shift_mont, bn::from_limbs(bn::H_R2));
+        }
         bool zero = true;
         for (int i = 0; i < 8; i++) zero = zero && shift_mont.v[i] == 0;
         if (zero) return ctx->fail(NLX_E_INVAL, "coset shift is zero");

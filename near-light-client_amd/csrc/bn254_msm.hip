@@ -252,7 +252,12 @@ __global__ __launch_bounds__(256) void k_msm_digits(const uint64_t* __restrict__
     if (i >= n) return;
     Fr s = load_words<RP>(scalars + 4 * i);
     if (montgomery) s = from_mont(s);
-    else if (geq_mod(s)) sub_mod_raw(s);   // a non-reduced word string: fold once (callers hand reduced values)
+    else {
+        // a non-reduced word string: 2^256 / r < 6, so at most five subtractions reduce it fully (one was not enough for
+        // s >= 2 r: the top window's digit then exceeded 14 bits and the key was truncated - a wrong point with NLX_OK)
+#pragma unroll 1
+        for (int k = 0; k < 5 && geq_mod(s); k++) sub_mod_raw(s);
+    }
 #pragma unroll
     for (int w = 0; w < N_WINDOWS; w++) {
         uint32_t d = (s.v[w >> 1] >> (16 * (w & 1))) & 0xFFFFu;
@@ -474,7 +479,7 @@ int32_t msm_run(nlx_ctx* ctx, const uint64_t* points, const uint64_t* scalars, u
     };
     if (!d_keys || !d_keys_sorted || !d_iota || !d_sorted || !d_lo || !d_buckets || !d_pts || !d_wsum || !d_tmp) {
         release_all();
-        return NLX_E_NOMEM;
+        return ctx->fail(NLX_E_NOMEM, "MSM of %llu points: device memory for the digit keys / sorted indices / buckets", (unsigned long long)n);
     }
     int32_t rc = NLX_OK;
     auto hip_ok = [&](hipError_t e, const char* what) {

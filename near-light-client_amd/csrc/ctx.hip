@@ -395,6 +395,10 @@ int32_t nlx_buf_download(nlx_buf* b, size_t offset, void* dst, size_t bytes) NLX
 int32_t nlx_ctx_trim(nlx_ctx* c) NLX_TRY {
     if (!c) return NLX_E_INVAL;
     (void)hipSetDevice(c->device);
+    // the BN254 twiddle tables (up to 268 MB each at 2^24 points) are rebuilt on demand: give them back as well
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->bn254_tables) c->release(kv.second);
+    c->bn254_tables.clear();
     c->trim();
     return NLX_OK;
 } NLX_CATCH(c)
