@@ -26,8 +26,8 @@ if not a.no_priority and not a.stark_cus:
     for c in st["ctxs"][:3]:
         c.set_priority(True)
 if a.stark_cus:
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count   # 256 on MI355X
     if a.pattern == "spread":
-        n_cu = torch.cuda.get_device_properties(0).multi_processor_count   # 256 on MI355X
         step = n_cu // a.stark_cus
         stark = [i for i in range(n_cu) if i % step == 0][: a.stark_cus]
     else:
