@@ -531,6 +531,176 @@ __global__ __launch_bounds__(256, 4) void k_ntt_c12(PassParams p) {
     }
 }
 
+// Short columns (2^8 .. 2^11 points: the wide STARK traces of a Sync step - thousands of columns of 2^9 .. 2^11 rows): the
+// same three rounds on a tile of 16 >> REM1 WHOLE COLUMNS of 2^(8 + REM1) points, the tile index being (column : 4 - REM1
+// bits)(point : 8 + REM1 bits).  The round of stride 256 is a radix-2^REM1 transform per column (none for 2^8 points), the
+// rounds of stride 16 and 1 are c12's.  The generic kernel gave such a column a block of its own with 15 of 16 lanes idle
+// (1.6 ms per launch on the SHA-512 trace, 11 ms per Sync step).  p.tw = w_N^e, e < N/2, N = 2^(8 + REM1).
+template <bool DIT, bool INV, int REM1>
+__global__ __launch_bounds__(256, 4) void k_ntt_cols(PassParams p) {
+    constexpr unsigned K = 8 + REM1, N = 1u << K, G = 1u << REM1, C = 16u >> REM1;
+    __shared__ uint64_t lds[TILE + TILE / 16];
+    __shared__ uint64_t w2[256];   // w_256^(lo * brev4(m)) at [lo][m]
+    const uint32_t tid = threadIdx.x;
+    const uint64_t* __restrict__ tw = p.tw;
+    uint64_t W1[G];                // w_N^(tid * bitrev_REM1(jt))
+#pragma unroll
+    for (unsigned jt = 1; jt < G; jt++) W1[jt] = tw_full(tw, tid * (__brev(jt) >> (32 - (REM1 ? REM1 : 1))), N / 2);
+    w2[tid] = tw_full(tw, G * (tid >> 4) * brev4(tid & 15), N / 2);   // w_256 = w_N^G
+    __syncthreads();
+    const uint64_t* __restrict__ w2l = w2 + (tid & 15) * 16;
+    uint64_t* __restrict__ l256 = lds + tid + (tid >> 4);                      // + 272 m : element 256 m + tid
+    uint64_t* __restrict__ l16 = lds + (tid >> 4) * 272 + (tid & 15);          // + 17 m  : element 256 c + 16 m + lo
+    uint64_t* __restrict__ l1 = lds + tid * 17;                                // + m     : element 16 tid + m
+    const bool has_scale = p.scale != nullptr, has_post = p.post_scale != nullptr;
+    const buf_t scale = make_buf(has_scale ? p.scale + (size_t)blockIdx.z * p.scale_z_stride : nullptr);
+    const buf_t post = make_buf(has_post ? p.post_scale + (size_t)blockIdx.z * p.post_scale_z_stride : nullptr);
+    const uint32_t src_cs = (uint32_t)p.src_stride * 8, dst_cs = (uint32_t)p.dst_stride * 8;   // bytes between columns
+    const uint32_t groups = (p.n_cols + C - 1) / C;
+    const uint32_t grp_end = min(groups, (blockIdx.x + 1) * p.cols_per_block);
+    for (uint32_t grp = blockIdx.x * p.cols_per_block; grp < grp_end; grp++) {
+        const uint32_t col0 = grp * C, n_valid = min(C, p.n_cols - col0);     // columns col0 .. col0 + n_valid - 1
+        const buf_t src = make_buf(p.src + (size_t)col0 * p.src_stride + (size_t)blockIdx.z * p.src_z_stride);
+        const buf_t dst = make_buf(p.dst + (size_t)col0 * p.dst_stride + (size_t)blockIdx.z * p.dst_z_stride);
+        uint64_t x[16];
+        // pairs of consecutive tile elements for the staged side: element 2 (tid + 256 i) = column cc, point jj
+        auto pair_col = [&](int i) { return (2 * (tid + 256 * i)) >> K; };
+        auto pair_pt = [&](int i) { return (2 * (tid + 256 * i)) & (N - 1); };
+        uint64_t* __restrict__ lp = lds + 2 * tid + (tid >> 3);                // + 544 i (lds_pad of the pair's first element)
+        if (!DIT) {
+            if (REM1 > 0) {
+                // round of stride 256: register m = (column c, jt), point jt 256 + tid
+#pragma unroll
+                for (unsigned c = 0; c < C; c++)
+#pragma unroll
+                    for (unsigned jt = 0; jt < G; jt++)
+                        x[c * G + jt] = c < n_valid ? buf_ld(src, tid * 8, c * src_cs + jt * 2048) : 0;
+                if (has_scale) {
+#pragma unroll
+                    for (unsigned c = 0; c < C; c++)
+#pragma unroll
+                        for (unsigned jt = 0; jt < G; jt++) x[c * G + jt] = mul_f(x[c * G + jt], buf_ld(scale, tid * 8, jt * 2048));
+                }
+#pragma unroll
+                for (unsigned c = 0; c < C; c++) {
+                    dft_dif<REM1, INV>(x + c * G);
+#pragma unroll
+                    for (unsigned jt = 1; jt < G; jt++) x[c * G + jt] = mul_f(x[c * G + jt], W1[jt]);
+                }
+#pragma unroll
+                for (int m = 0; m < 16; m++) l256[272 * m] = x[m];
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = l16[17 * m];
+            } else {
+                // 2^8 points: the round of stride 16 reads global memory itself: lane (column c = tid >> 4, lo), point 16 m + lo
+                const uint32_t c = tid >> 4, off = c * src_cs + (tid & 15) * 8;
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = c < n_valid ? buf_ld(src, off, m * 128) : 0;
+                if (has_scale) {
+#pragma unroll
+                    for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], buf_ld(scale, (tid & 15) * 8, m * 128));
+                }
+            }
+            dft_dif<4, INV>(x);
+#pragma unroll
+            for (int m = 1; m < 16; m++) x[m] = mul_f(x[m], w2l[m]);
+#pragma unroll
+            for (int m = 0; m < 16; m++) l16[17 * m] = x[m];
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = l1[m];
+            dft_dif<4, INV>(x);
+            if (p.final_scale != 1) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], p.final_scale);
+            }
+#pragma unroll
+            for (int m = 0; m < 16; m++) l1[m] = x[m];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t cc = pair_col(i), jj = pair_pt(i);
+                ulonglong2 v = make_ulonglong2(lp[544 * i], lp[544 * i + 1]);
+                if (has_post) {
+                    const ulonglong2 sc = buf_ld16(post, jj * 8, 0);
+                    v.x = mul_f(v.x, sc.x);
+                    v.y = mul_f(v.y, sc.y);
+                }
+                if (cc < n_valid) buf_st16(dst, cc * dst_cs + jj * 8, 0, v);
+            }
+            __syncthreads();
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t cc = pair_col(i), jj = pair_pt(i);
+                ulonglong2 v = make_ulonglong2(0, 0);
+                if (cc < n_valid) v = buf_ld16(src, cc * src_cs + jj * 8, 0);
+                if (has_scale) {
+                    const ulonglong2 sc = buf_ld16(scale, jj * 8, 0);
+                    v.x = mul_f(v.x, sc.x);
+                    v.y = mul_f(v.y, sc.y);
+                }
+                lp[544 * i] = v.x;
+                lp[544 * i + 1] = v.y;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = l1[m];
+            dft_dit<4, INV>(x);
+#pragma unroll
+            for (int m = 0; m < 16; m++) l1[m] = x[m];
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = l16[17 * m];
+#pragma unroll
+            for (int m = 1; m < 16; m++) x[m] = mul_f(x[m], w2l[m]);
+            dft_dit<4, INV>(x);
+            if (REM1 > 0) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) l16[17 * m] = x[m];
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = l256[272 * m];
+#pragma unroll
+                for (unsigned c = 0; c < C; c++) {
+#pragma unroll
+                    for (unsigned jt = 1; jt < G; jt++) x[c * G + jt] = mul_f(x[c * G + jt], W1[jt]);
+                    dft_dit<REM1, INV>(x + c * G);
+                }
+            }
+            if (p.final_scale != 1) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], p.final_scale);
+            }
+            if (REM1 > 0) {
+                if (has_post) {
+#pragma unroll
+                    for (unsigned c = 0; c < C; c++)
+#pragma unroll
+                        for (unsigned jt = 0; jt < G; jt++) x[c * G + jt] = mul_f(x[c * G + jt], buf_ld(post, tid * 8, jt * 2048));
+                }
+#pragma unroll
+                for (unsigned c = 0; c < C; c++)
+#pragma unroll
+                    for (unsigned jt = 0; jt < G; jt++)
+                        if (c < n_valid) buf_st(dst, tid * 8, c * dst_cs + jt * 2048, x[c * G + jt]);
+            } else {
+                const uint32_t c = tid >> 4, off = c * dst_cs + (tid & 15) * 8;
+                if (has_post) {
+#pragma unroll
+                    for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], buf_ld(post, (tid & 15) * 8, m * 128));
+                }
+                if (c < n_valid) {
+#pragma unroll
+                    for (int m = 0; m < 16; m++) buf_st(dst, off, m * 128, x[m]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Strided pass of 4 + REM levels (REM = 1 .. 4): element (j1, jt) of the tile lives at q N + j1 M + j0_base + jt with
 // A = 2^(4 + REM) values of j1 and T = 4096 / A consecutive jt (rows of >= 128 bytes).  Two rounds: a radix-2^REM round at
 // stride 16 and a radix-16 round at stride 1; the latter carries the inter-pass twiddle w_N^(bitrev_A(j1) (j0_base + jt))
@@ -769,6 +939,20 @@ static void run_passes_t(hipStream_t st, const NttTables& tb, const uint64_t* sr
                 case 3: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, INV, 3>), grid, dim3(256), 0, st, p); break;
                 case 2: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, INV, 2>), grid, dim3(256), 0, st, p); break;
                 default: hipLaunchKernelGGL((k_ntt_strided_reg<DIT, INV, 1>), grid, dim3(256), 0, st, p); break;
+            }
+            continue;
+        }
+        if (i == 0 && pl.n_pass == 1 && log_n >= 8 && log_n < TILE_LOG && src_stride < ((size_t)1 << 24) && dst_stride < ((size_t)1 << 24)) {
+            // short columns (one contiguous pass): tiles of 16 >> (log_n - 8) whole columns; a block walks cols_per_block tiles
+            const uint32_t C = 16u >> (log_n - 8), groups = (n_cols + C - 1) / C;
+            p.cols_per_block = 1;
+            while (p.cols_per_block < 8 && (size_t)((groups + 2 * p.cols_per_block - 1) / (2 * p.cols_per_block)) * n_z >= 2048) p.cols_per_block *= 2;
+            const dim3 grid((groups + p.cols_per_block - 1) / p.cols_per_block, 1, n_z);
+            switch (log_n) {
+                case 8: hipLaunchKernelGGL((k_ntt_cols<DIT, INV, 0>), grid, dim3(256), 0, st, p); break;
+                case 9: hipLaunchKernelGGL((k_ntt_cols<DIT, INV, 1>), grid, dim3(256), 0, st, p); break;
+                case 10: hipLaunchKernelGGL((k_ntt_cols<DIT, INV, 2>), grid, dim3(256), 0, st, p); break;
+                default: hipLaunchKernelGGL((k_ntt_cols<DIT, INV, 3>), grid, dim3(256), 0, st, p); break;
             }
             continue;
         }
