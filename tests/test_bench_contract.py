@@ -133,6 +133,20 @@ def test_one_ntt_split_over_two_ranks_equals_the_one_rank_transform():
 
 
 @pytest.mark.gpu
+def test_default_line_carries_the_verify_record_on_two_ranks():
+    """The driver's N > 1 command WITHOUT --no-extra (small sizes): after the Sync replicas every rank runs the 128 x 4 Verify job
+    and rank 0's line carries its record - the strong-scaling figure of BASELINE.json configs[3] (gloo rehearsal on one GPU)."""
+    d = _launch_two_ranks(("--log-n", "12", "--map-log-n", "11", "--reduce-log-n", "10"), {"NLX_BENCH_REHEARSAL": "1"}, 29644)
+    v = d["verify128"]
+    assert "error" not in v, v
+    assert v["n_gpus"] == 2 and v["scaling"] == "strong" and v["output_ok"] is True and v["proofs_per_s"] > 0
+    assert len(v["level_ms"]) == 7 and v["roofline"]["launches"] > 0
+    one = run_bench("--workload", "verify128", "--map-log-n", "11", "--reduce-log-n", "10", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                    timeout=600)
+    assert one["config"]["root_digest"] == v["root_digest"]
+
+
+@pytest.mark.gpu
 def test_two_ranks_over_rccl():
     """the real N = 2 path (backend nccl = RCCL, one rank per GPU): runs where two GPUs are visible, skipped on a one-GPU box"""
     import torch
