@@ -238,7 +238,13 @@ int32_t nlx_commit_get_digests(nlx_commit* c, uint64_t* digests_out);
 #define NLX_GATE_U32_SUBTRACTION 16 /* U32SubtractionGate { num_ops = param0 } */
 #define NLX_GATE_U32_RANGE_CHECK 17 /* U32RangeCheckGate { num_input_limbs = param0 } */
 #define NLX_GATE_COMPARISON 18      /* ComparisonGate { num_bits = param0, num_chunks = param1 } */
-#define NLX_GATE_KIND_MAX 18
+/* gates::lookup::LookupGate / gates::lookup_table::LookupTableGate of table param0: no gate constraints; their wires feed
+ * the lookup argument (vanishing_poly::check_lookup_constraints).  LookupGate slot i = wires (2i, 2i+1) = (input, output),
+ * num_routed_wires / 2 slots; LookupTableGate slot i = wires (3i, 3i+1, 3i+2) = (input, output, multiplicity),
+ * num_routed_wires / 3 slots. */
+#define NLX_GATE_LOOKUP 19
+#define NLX_GATE_LOOKUP_TABLE 20
+#define NLX_GATE_KIND_MAX 20
 
 typedef struct {
     uint32_t kind;
@@ -271,6 +277,25 @@ typedef struct {
     const nlx_gate_desc* gates;
     const uint64_t* k_is;            /* num_routed_wires coset shifts (host pointer) */
     uint64_t circuit_digest[4];      /* all zero: computed by nlx_circuit_build as plonky2 does */
+    /* ---- lookup tables (CommonCircuitData::luts, ProverOnlyCircuitData::{lookup_rows, lut_to_lookups}) ----
+     * num_luts == 0 (a zero-initialised tail): no lookup argument, the rest is ignored.  With tables:
+     *  - the constants matrix carries 4 + num_luts lookup selector columns between the gate selectors and the gate
+     *    constants (gates::selectors::selectors_lookup: TransSre, TransLdc, InitSre, LastLdc; selector_ends_lookups);
+     *  - nlx_prove first does prover::set_lookup_wires ON THE DEVICE WITNESS IT IS HANDED (multiplicity wires of the
+     *    LookupTableGate rows, padding slots of each table's last LookupGate row - the caller's buffer is written);
+     *  - 2 * num_challenges more challenges are drawn after the gammas, the Zs commitment carries the
+     *    num_challenges * (1 + S) lookup polynomials (RE, SLDC_0..S-1; S = ceil(num_routed_wires / 2 / (qdf - 1)))
+     *    after the partial products, they are opened at zeta and g * zeta, and the vanishing polynomial carries
+     *    check_lookup_constraints' 4 + num_luts + 2 S terms per challenge between the permutation and the gate terms.
+     * All four arrays are host pointers, copied by nlx_circuit_build. */
+    uint32_t num_luts;               /* 0 .. 16 */
+    uint32_t pad_;
+    const uint32_t* lut_sizes;       /* num_luts: entries per table (1 .. 65536) */
+    const uint16_t* lut_pairs;       /* the tables' (input, output) pairs, table after table, 2 x u16 per entry */
+    const uint32_t* lookup_rows;     /* 3 per table: last_lu_row, last_lut_row, first_lut_row (LookupWire); the LookupGate rows
+                                        are [last_lu_row, last_lut_row), the LookupTableGate rows [last_lut_row, first_lut_row],
+                                        row first_lut_row + 1 is a NoopGate row */
+    const uint32_t* lut_num_lookups; /* num_luts: lookups made into each table (lut_to_lookups[t].len()) */
 } nlx_circuit_desc;
 
 typedef struct nlx_circuit nlx_circuit;

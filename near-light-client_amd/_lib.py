@@ -154,6 +154,7 @@ SYNTH_SIGNATURES = {
                                                ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_synth_shape": (None, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     "nlx_synth_circuit": (ctypes.c_int32, [ctypes.c_void_p] * 7),
+    "nlx_synth_circuit_lookups": (ctypes.c_int32, [ctypes.c_void_p] * 9),
     "nlx_synth_set_public_inputs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]),
 }
 

@@ -109,6 +109,8 @@ void poseidon_gate_row(const uint64_t in[12], uint64_t swap, uint64_t* w /*135*/
 uint32_t gate_degree(uint32_t kind, uint32_t p0, uint32_t p1 = 0) {
     switch (kind) {
         case NLX_GATE_NOOP: return 0;
+        case NLX_GATE_LOOKUP: return 0;
+        case NLX_GATE_LOOKUP_TABLE: return 0;
         case NLX_GATE_CONSTANT: return 1;
         case NLX_GATE_PUBLIC_INPUT: return 1;
         case NLX_GATE_ARITHMETIC: return 3;
@@ -158,6 +160,9 @@ extern "C" {
 static uint32_t build_gate_list(const nlx_synth_params* sp, uint32_t* kinds, uint32_t* p0, uint32_t* p1) {
     uint32_t k = 0;
     auto add = [&](uint32_t kind, uint32_t a, uint32_t b) { kinds[k] = kind; p0[k] = a; p1[k] = b; k++; };
+    // degree 0, by id: "LookupGate {..lut_hash}" (one per table) < "LookupTableGate {..}" (one per table) < "NoopGate"
+    for (uint32_t t = 0; t < sp->num_luts; t++) add(NLX_GATE_LOOKUP, t, 0);
+    for (uint32_t t = 0; t < sp->num_luts; t++) add(NLX_GATE_LOOKUP_TABLE, t, 0);
     add(NLX_GATE_NOOP, 0, 0);                                    // degree 0
     add(NLX_GATE_CONSTANT, 2, 0);                                // degree 1: "ConstantGate" < "PoseidonMdsGate" < "PublicInputGate"
     if (sp->pct_misc) add(NLX_GATE_POSEIDON_MDS, 0, 0);
@@ -181,8 +186,28 @@ static uint32_t build_gate_list(const nlx_synth_params* sp, uint32_t* kinds, uin
     return k;
 }
 
+// synthetic table t: 2^lut_bits entries, inputs a permutation of the indices (so the input -> index map is exercised),
+// outputs a fixed 16-bit function
+static inline void lut_entry(uint32_t t, uint32_t i, uint16_t* inp, uint16_t* out) {
+    *inp = (uint16_t)(i ^ (t ? 0x00A5u + t : 0u));
+    *out = (uint16_t)((i * i + 7 * t + 3) & 0xFFFF);
+}
+struct LookupPlan {
+    uint32_t T = 0, len = 0, lookups = 0, lu_rows = 0, lut_rows = 0, block = 0;
+    explicit LookupPlan(const nlx_synth_params* sp) {
+        T = sp->num_luts;
+        if (!T) return;
+        len = 1u << sp->lut_bits;
+        lookups = sp->num_lookups;
+        lu_rows = (lookups + 39) / 40;
+        lut_rows = (len + 25) / 26;
+        block = lu_rows + lut_rows + 1;
+    }
+    uint32_t end_row() const { return 1 + T * block; }  // first row after the lookup blocks (they start at row 1)
+};
+
 void nlx_synth_shape(const nlx_synth_params* sp, uint32_t* n_gates, uint32_t* n_selectors) NLX_TRY {
-    uint32_t kinds[24], p0[24], p1[24];
+    uint32_t kinds[40], p0[40], p1[40];
     const uint32_t g = build_gate_list(sp, kinds, p0, p1);
     *n_gates = g;
     // greedy selector groups with max_degree = 8 (gates::selectors::selector_polynomials)
@@ -241,25 +266,41 @@ int32_t nlx_synth_stark_trace(uint32_t n_cols, uint32_t log_n, uint64_t seed, co
     return NLX_OK;
 } NLX_CATCH(nullptr)
 
-int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint64_t* k_is, uint64_t* constants,
-                          uint64_t* sigmas, uint64_t* wires, uint64_t* public_inputs) NLX_TRY {
+static int32_t synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint64_t* k_is, uint64_t* constants,
+                             uint64_t* sigmas, uint64_t* wires, uint64_t* public_inputs, uint16_t* lut_pairs,
+                             uint32_t* lookup_rows) {
     const uint32_t W = 135, ROUTED = 80, NCONST = 2;
     const uint32_t log_n = sp->log_n;
     if (log_n < 3 || log_n > 26) return NLX_E_RANGE;
     const size_t n = (size_t)1 << log_n;
     Rng rng(sp->seed ^ 0x6e6c78ULL);
+    const LookupPlan lp(sp);
+    if (lp.T) {
+        if (!lut_pairs || !lookup_rows) return NLX_E_INVAL;
+        if (lp.T > 8 || sp->lut_bits < 1 || sp->lut_bits > 16 || lp.lookups == 0) return NLX_E_RANGE;
+        if ((size_t)lp.end_row() + 2 >= n) return NLX_E_RANGE;
+        for (uint32_t t = 0; t < lp.T; t++) {
+            for (uint32_t i = 0; i < lp.len; i++) lut_entry(t, i, &lut_pairs[2 * ((size_t)t * lp.len + i)], &lut_pairs[2 * ((size_t)t * lp.len + i) + 1]);
+            lookup_rows[3 * t] = 1 + t * lp.block;                              // last_lu_row
+            lookup_rows[3 * t + 1] = lookup_rows[3 * t] + lp.lu_rows;           // last_lut_row
+            lookup_rows[3 * t + 2] = lookup_rows[3 * t + 1] + lp.lut_rows - 1;  // first_lut_row; the row after it is a NoopGate
+        }
+    }
+    const uint32_t n_lk_sel = lp.T ? 4 + lp.T : 0;  // lookup selector columns sit between the gate selectors and the gate constants
 
     // ---- gate table + selector groups ----
     uint32_t n_gates, n_sel;
     nlx_synth_shape(sp, &n_gates, &n_sel);
+    int g_noop = 0;
     int g_base = -1, g_arith = -1, g_pos = -1, g_aext = -1, g_mext = -1, g_red = -1, g_rext = -1, g_pmds = -1, g_exp = -1,
         g_ra = -1, g_ci = -1, g_cmp = -1, g_uadd = -1, g_uari = -1, g_usub = -1, g_urc = -1, g_const = 1, g_pi = 2;
     {
-        uint32_t kinds[24], p0[24], p1[24];
+        uint32_t kinds[40], p0[40], p1[40];
         const uint32_t k = build_gate_list(sp, kinds, p0, p1);
         for (uint32_t g = 0; g < k; g++) {
             gates[g].kind = kinds[g]; gates[g].param0 = p0[g]; gates[g].param1 = p1[g]; gates[g].index = g;
             switch (kinds[g]) {
+                case NLX_GATE_NOOP: g_noop = (int)g; break;
                 case NLX_GATE_BASE_SUM: g_base = (int)g; break;
                 case NLX_GATE_ARITHMETIC: g_arith = (int)g; break;
                 case NLX_GATE_POSEIDON: g_pos = (int)g; break;
@@ -302,7 +343,8 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
     std::vector<uint8_t> row_gate(n, 0);
     auto W_at = [&](uint32_t col, size_t row) -> uint64_t& { return wires[(size_t)col * n + row]; };
     auto C_at = [&](uint32_t col, size_t row) -> uint64_t& { return constants[(size_t)col * n + row]; };
-    memset(constants, 0, (size_t)(n_sel + NCONST) * n * 8);
+    const uint32_t cbase = n_sel + n_lk_sel;  // first gate-constant column
+    memset(constants, 0, (size_t)(cbase + NCONST) * n * 8);
     Dsu dsu((size_t)ROUTED * n);
     auto slot = [&](uint32_t col, size_t row) { return (uint32_t)((size_t)col * n + row); };
     std::vector<uint32_t> pool32;  // routed slots holding 32-bit values (inputs of the u32 gates)
@@ -327,11 +369,41 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
         // random fill first (unconstrained wires stay random)
         for (uint32_t c = 0; c < W; c++) W_at(c, row) = rng.field();
         uint32_t kind = NLX_GATE_NOOP;
-        int gidx = 0;
+        int gidx = g_noop;
         if (row == 0) {
             kind = NLX_GATE_PUBLIC_INPUT; gidx = g_pi;
         } else if (row + 2 >= n) {
-            kind = NLX_GATE_NOOP; gidx = 0;  // padding rows, as plonky2 pads with NoopGate
+            kind = NLX_GATE_NOOP; gidx = g_noop;  // padding rows, as plonky2 pads with NoopGate
+        } else if (row < lp.end_row()) {
+            // CircuitBuilder::add_all_lookups, one block per table: LookupGate rows, then the table upside down on
+            // LookupTableGate rows (first entries on the LAST row), then a NoopGate row
+            const uint32_t t = (uint32_t)(row - 1) / lp.block, r = (uint32_t)(row - 1) % lp.block;
+            if (r < lp.lu_rows) {
+                kind = NLX_GATE_LOOKUP; gidx = (int)t;
+                for (uint32_t sl = 0; sl < 40; sl++) {
+                    const uint32_t q = r * 40 + sl;
+                    uint16_t inp = 0, out = 0;  // slots past the last lookup stay unset (0): the PROVER pads them (set_lookup_wires)
+                    if (q < lp.lookups) {
+                        // skewed choice: a quarter of the table takes most lookups, some entries none
+                        uint32_t e = rng.below(4) ? rng.below((lp.len + 3) / 4) : rng.below(lp.len);
+                        lut_entry(t, e, &inp, &out);
+                        if ((sl & 7) == 0) pool.push_back(slot(2 * sl + 1, row));  // later rows copy looked-up outputs
+                    }
+                    W_at(2 * sl, row) = inp;
+                    W_at(2 * sl + 1, row) = out;
+                }
+            } else if (r < lp.lu_rows + lp.lut_rows) {
+                kind = NLX_GATE_LOOKUP_TABLE; gidx = (int)(lp.T + t);
+                const uint32_t first_lut = lookup_rows[3 * t + 2];
+                for (uint32_t sl = 0; sl < 26; sl++) {
+                    const uint32_t e = (first_lut - (uint32_t)row) * 26 + sl;
+                    uint16_t inp = 0, out = 0;
+                    if (e < lp.len) lut_entry(t, e, &inp, &out);
+                    W_at(3 * sl, row) = inp;
+                    W_at(3 * sl + 1, row) = out;
+                    W_at(3 * sl + 2, row) = 0;  // multiplicity: the prover's set_lookup_wires writes it
+                }
+            }
         } else {
             uint32_t r = rng.below(100);
             uint32_t t = sp->pct_poseidon;
@@ -373,15 +445,15 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
             case NLX_GATE_CONSTANT:
                 for (int i = 0; i < 2; i++) {
                     uint64_t v = rng.field();
-                    C_at(n_sel + i, row) = v;
+                    C_at(cbase + i, row) = v;
                     W_at(i, row) = v;
                     pool.push_back(slot(i, row));
                 }
                 break;
             case NLX_GATE_ARITHMETIC: {
                 uint64_t c0 = rng.field(), c1 = rng.field();
-                C_at(n_sel, row) = c0;
-                C_at(n_sel + 1, row) = c1;
+                C_at(cbase, row) = c0;
+                C_at(cbase + 1, row) = c1;
                 for (uint32_t op = 0; op < 20; op++) {
                     for (uint32_t q = 0; q < 3; q++) {
                         // half of the operands are copies of earlier routed values (copy constraints)
@@ -432,8 +504,8 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
             }
             case NLX_GATE_ARITHMETIC_EXT: {
                 const uint64_t c0 = rng.field(), c1 = rng.field();
-                C_at(n_sel, row) = c0;
-                C_at(n_sel + 1, row) = c1;
+                C_at(cbase, row) = c0;
+                C_at(cbase + 1, row) = c1;
                 for (uint32_t op = 0; op < 10; op++) {
                     const uint32_t b = 8 * op;
                     if (!pool.empty() && (rng.next() & 1)) {  // one operand limb copied from an earlier value
@@ -452,7 +524,7 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
             }
             case NLX_GATE_MUL_EXT: {
                 const uint64_t c0 = rng.field();
-                C_at(n_sel, row) = c0;
+                C_at(cbase, row) = c0;
                 for (uint32_t op = 0; op < 13; op++) {
                     const uint32_t b = 6 * op;
                     const gl::Ext m0{W_at(b, row), W_at(b + 1, row)}, m1{W_at(b + 2, row), W_at(b + 3, row)};
@@ -522,7 +594,7 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
                 }
                 for (uint32_t i = 0; i < extra; i++) {
                     const uint64_t v = rng.field();
-                    C_at(n_sel + i, row) = v;
+                    C_at(cbase + i, row) = v;
                     W_at((2 + vec) * copies + i, row) = v;
                 }
                 break;
@@ -702,6 +774,16 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
         for (uint32_t s = 0; s < n_sel; s++)
             C_at(s, row) = (gates[g].selector_index == s) ? gates[g].index : 0xFFFFFFFFULL;
     }
+    // lookup selectors (gates::selectors::selectors_lookup, selector_ends_lookups): TransSre on the table rows, TransLdc on
+    // the LookupGate rows, InitSre on the row after the table, LastLdc on the first LookupGate row, one end selector per table
+    for (uint32_t t = 0; t < lp.T; t++) {
+        const uint32_t last_lu = lookup_rows[3 * t], last_lut = lookup_rows[3 * t + 1], first_lut = lookup_rows[3 * t + 2];
+        for (uint32_t row = last_lut; row <= first_lut; row++) C_at(n_sel + 0, row) = 1;
+        for (uint32_t row = last_lu; row < last_lut; row++) C_at(n_sel + 1, row) = 1;
+        C_at(n_sel + 2, first_lut + 1) = 1;
+        C_at(n_sel + 3, last_lu) = 1;
+        C_at(n_sel + 4 + t, last_lut) = 1;
+    }
     // ---- sigma: each copy class becomes one cycle (next slot in increasing order, wrapping) ----
     const size_t total = (size_t)ROUTED * n;
     std::vector<uint32_t> next_in_class(total), last_seen(total, 0xFFFFFFFFu), first_seen(total, 0xFFFFFFFFu);
@@ -725,6 +807,18 @@ int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint
         sigmas[s] = gl::mul(k_is[t / n], subgroup[t % n]);
     }
     return NLX_OK;
+}
+
+int32_t nlx_synth_circuit(const nlx_synth_params* sp, nlx_gate_desc* gates, uint64_t* k_is, uint64_t* constants,
+                          uint64_t* sigmas, uint64_t* wires, uint64_t* public_inputs) NLX_TRY {
+    if (sp->num_luts) return NLX_E_INVAL;  // circuits with tables come from nlx_synth_circuit_lookups
+    return synth_circuit(sp, gates, k_is, constants, sigmas, wires, public_inputs, nullptr, nullptr);
+} NLX_CATCH(nullptr)
+
+int32_t nlx_synth_circuit_lookups(const nlx_synth_params* sp, nlx_gate_desc* gates, uint64_t* k_is, uint64_t* constants,
+                                  uint64_t* sigmas, uint64_t* wires, uint64_t* public_inputs, uint16_t* lut_pairs,
+                                  uint32_t* lookup_rows) NLX_TRY {
+    return synth_circuit(sp, gates, k_is, constants, sigmas, wires, public_inputs, lut_pairs, lookup_rows);
 } NLX_CATCH(nullptr)
 
 }  // extern "C"

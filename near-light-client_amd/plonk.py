@@ -14,7 +14,7 @@ from ._lib import dll, synth_dll, ptr, NlxError
 (GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_BASE_SUM, GATE_POSEIDON, GATE_ARITHMETIC_EXT,
  GATE_MUL_EXT, GATE_REDUCING, GATE_REDUCING_EXT, GATE_POSEIDON_MDS, GATE_EXPONENTIATION, GATE_RANDOM_ACCESS,
  GATE_COSET_INTERPOLATION, GATE_U32_ADD_MANY, GATE_U32_ARITHMETIC, GATE_U32_SUBTRACTION, GATE_U32_RANGE_CHECK,
- GATE_COMPARISON) = range(19)
+ GATE_COMPARISON, GATE_LOOKUP, GATE_LOOKUP_TABLE) = range(21)
 
 
 class GateDesc(ctypes.Structure):
@@ -28,7 +28,11 @@ class CircuitDesc(ctypes.Structure):
         "cap_height", "quotient_degree_factor", "num_partial_products", "fri_pow_bits", "fri_num_queries",
         "fri_arity_bits", "fri_final_poly_bits", "num_selectors", "num_gates", "num_public_inputs")] + [
         ("gates", ctypes.POINTER(GateDesc)), ("k_is", ctypes.POINTER(ctypes.c_uint64)),
-        ("circuit_digest", ctypes.c_uint64 * 4)]
+        ("circuit_digest", ctypes.c_uint64 * 4),
+        # lookup tables (include/nlx.h): a zero tail = none
+        ("num_luts", ctypes.c_uint32), ("pad_", ctypes.c_uint32), ("lut_sizes", ctypes.POINTER(ctypes.c_uint32)),
+        ("lut_pairs", ctypes.POINTER(ctypes.c_uint16)), ("lookup_rows", ctypes.POINTER(ctypes.c_uint32)),
+        ("lut_num_lookups", ctypes.POINTER(ctypes.c_uint32))]
 
 
 class SynthParams(ctypes.Structure):
@@ -36,7 +40,8 @@ class SynthParams(ctypes.Structure):
                 ("pct_poseidon", ctypes.c_uint32), ("pct_arithmetic", ctypes.c_uint32),
                 ("pct_base_sum", ctypes.c_uint32), ("pct_constant", ctypes.c_uint32), ("seed", ctypes.c_uint64),
                 ("pct_extension", ctypes.c_uint32), ("pct_misc", ctypes.c_uint32), ("pct_u32", ctypes.c_uint32),
-                ("wide_comparison", ctypes.c_uint32)]
+                ("wide_comparison", ctypes.c_uint32), ("num_luts", ctypes.c_uint32), ("lut_bits", ctypes.c_uint32),
+                ("num_lookups", ctypes.c_uint32), ("pad_", ctypes.c_uint32)]
 
 
 class CircuitConfig:
@@ -68,23 +73,38 @@ class SyntheticCircuit:
     """A satisfiable nearx-shaped circuit + witness (see csrc/synth.cpp)."""
 
     def __init__(self, log_n, seed=1, num_public_inputs=4, pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5,
-                 pct_constant=5, pct_extension=0, pct_misc=0, pct_u32=0, config=None, wide_comparison=False):
+                 pct_constant=5, pct_extension=0, pct_misc=0, pct_u32=0, config=None, wide_comparison=False,
+                 num_luts=0, lut_bits=8, num_lookups=0):
         self.config = config or CircuitConfig()
         self.log_n = log_n
         sp = SynthParams(log_n, num_public_inputs, pct_poseidon, pct_arithmetic, pct_base_sum, pct_constant, seed,
-                         pct_extension, pct_misc, pct_u32, 1 if wide_comparison else 0)
+                         pct_extension, pct_misc, pct_u32, 1 if wide_comparison else 0, num_luts,
+                         lut_bits if num_luts else 0, num_lookups if num_luts else 0, 0)
         ng, ns = ctypes.c_uint32(), ctypes.c_uint32()
         synth_dll.nlx_synth_shape(ctypes.byref(sp), ctypes.byref(ng), ctypes.byref(ns))
         n = 1 << log_n
         self.num_selectors, self.num_gates = ns.value, ng.value
         self.gates = (GateDesc * ng.value)()
         self.k_is = np.zeros(80, dtype=np.uint64)
-        self.constants = np.zeros((ns.value + 2, n), dtype=np.uint64)
+        self.num_luts = num_luts
+        self.num_lookup_selectors = 4 + num_luts if num_luts else 0
+        self.constants = np.zeros((ns.value + self.num_lookup_selectors + 2, n), dtype=np.uint64)
         self.sigmas = np.zeros((80, n), dtype=np.uint64)
         self.wires = np.zeros((135, n), dtype=np.uint64)
         self.public_inputs = np.zeros(max(num_public_inputs, 1), dtype=np.uint64)[:num_public_inputs]
-        rc = synth_dll.nlx_synth_circuit(ctypes.byref(sp), self.gates, ptr(self.k_is), ptr(self.constants),
-                                   ptr(self.sigmas), ptr(self.wires), ptr(self.public_inputs) if num_public_inputs else None)
+        pis = ptr(self.public_inputs) if num_public_inputs else None
+        if num_luts:
+            # the descriptor's table arrays (kept alive here): sizes, (input, output) pairs, LookupWire rows, lookups per table
+            self.lut_sizes = np.full(num_luts, 1 << lut_bits, dtype=np.uint32)
+            self.lut_pairs = np.zeros((num_luts << lut_bits, 2), dtype=np.uint16)
+            self.lookup_rows = np.zeros((num_luts, 3), dtype=np.uint32)
+            self.lut_num_lookups = np.full(num_luts, num_lookups, dtype=np.uint32)
+            rc = synth_dll.nlx_synth_circuit_lookups(ctypes.byref(sp), self.gates, ptr(self.k_is), ptr(self.constants),
+                                                     ptr(self.sigmas), ptr(self.wires), pis, self.lut_pairs.ctypes.data,
+                                                     self.lookup_rows.ctypes.data)
+        else:
+            rc = synth_dll.nlx_synth_circuit(ctypes.byref(sp), self.gates, ptr(self.k_is), ptr(self.constants),
+                                             ptr(self.sigmas), ptr(self.wires), pis)
         if rc != 0:
             raise NlxError(rc, "nlx_synth_circuit failed")
 
@@ -105,6 +125,12 @@ class SyntheticCircuit:
                         c.fri_num_queries, c.fri_arity_bits, c.fri_final_poly_bits, self.num_selectors,
                         self.num_gates, len(self.public_inputs), self.gates,
                         self.k_is.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+        if self.num_luts:
+            d.num_luts = self.num_luts
+            d.lut_sizes = self.lut_sizes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+            d.lut_pairs = self.lut_pairs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16))
+            d.lookup_rows = self.lookup_rows.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+            d.lut_num_lookups = self.lut_num_lookups.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
         return d
 
 

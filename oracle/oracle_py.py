@@ -184,14 +184,18 @@ class _Desc(ctypes.Structure):
         "degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_challenges", "rate_bits",
         "cap_height", "quotient_degree_factor", "num_partial_products", "fri_pow_bits", "fri_num_queries",
         "fri_arity_bits", "fri_final_poly_bits", "num_selectors", "num_gates", "num_public_inputs")] + [
-        ("gates", ctypes.POINTER(_Gate)), ("k_is", u64p), ("circuit_digest", ctypes.c_uint64 * 4)]
+        ("gates", ctypes.POINTER(_Gate)), ("k_is", u64p), ("circuit_digest", ctypes.c_uint64 * 4),
+        # lookup tables (plonk.h): all zero = none
+        ("num_luts", ctypes.c_uint32), ("pad_", ctypes.c_uint32), ("lut_sizes", ctypes.POINTER(ctypes.c_uint32)),
+        ("lut_pairs", ctypes.POINTER(ctypes.c_uint16)), ("lookup_rows", ctypes.POINTER(ctypes.c_uint32)),
+        ("lut_num_lookups", ctypes.POINTER(ctypes.c_uint32))]
 
 
 class _Trace(ctypes.Structure):
     _fields_ = [("betas", ctypes.c_uint64 * 4), ("gammas", ctypes.c_uint64 * 4), ("alphas", ctypes.c_uint64 * 4),
                 ("zeta", ctypes.c_uint64 * 2), ("fri_alpha", ctypes.c_uint64 * 2), ("fri_betas", ctypes.c_uint64 * 32),
                 ("pow_witness", ctypes.c_uint64), ("n_fri_rounds", ctypes.c_uint32),
-                ("query_indices", ctypes.c_uint64 * 128), ("zs_partial_values", u64p),
+                ("query_indices", ctypes.c_uint64 * 128), ("deltas", ctypes.c_uint64 * 16), ("zs_partial_values", u64p),
                 ("quotient_chunk_coeffs", u64p), ("fri_final_values", u64p)]
 
 
@@ -222,6 +226,10 @@ class Circuit:
             setattr(self.desc, f, getattr(desc_bytes_like, f))
         self.desc.gates = self._gates
         self.desc.k_is = _p(self._k)
+        if getattr(desc_bytes_like, "num_luts", 0):   # the arrays are copied by orc_circuit_build
+            self.desc.num_luts = desc_bytes_like.num_luts
+            for f in ("lut_sizes", "lut_pairs", "lookup_rows", "lut_num_lookups"):
+                setattr(self.desc, f, ctypes.cast(getattr(desc_bytes_like, f), dict(_Desc._fields_)[f]))
         self.h = d.orc_circuit_build(ctypes.byref(self.desc), _p(_u64(constants)), _p(_u64(sigmas)))
         self.max_bytes = d.orc_proof_max_bytes(self.h)
 
@@ -249,6 +257,8 @@ class Circuit:
         n = 1 << self.desc.degree_bits
         L = n << self.desc.rate_bits
         nzs = self.desc.num_challenges * (1 + self.desc.num_partial_products)
+        if self.desc.num_luts:   # + (RE, SLDC_0..S-1) per challenge
+            nzs += self.desc.num_challenges * (1 + -(-(self.desc.num_routed_wires // 2) // (self.desc.quotient_degree_factor - 1)))
         nq = self.desc.num_challenges * self.desc.quotient_degree_factor
         zs = np.zeros((nzs, n), dtype=np.uint64)
         qc = np.zeros((nq, n), dtype=np.uint64)
@@ -258,12 +268,21 @@ class Circuit:
         info = {"betas": list(tr.betas)[:2], "gammas": list(tr.gammas)[:2], "alphas": list(tr.alphas)[:2],
                 "zeta": list(tr.zeta), "fri_alpha": list(tr.fri_alpha), "pow_witness": tr.pow_witness,
                 "n_fri_rounds": tr.n_fri_rounds, "query_indices": list(tr.query_indices)[:self.desc.fri_num_queries],
-                "zs_partial_values": zs, "quotient_chunk_coeffs": qc, "fri_final_values": fv}
+                "zs_partial_values": zs, "quotient_chunk_coeffs": qc, "fri_final_values": fv,
+                "deltas": list(tr.deltas)[:4 * self.desc.num_challenges]}
         return buf[:ln].tobytes(), info
 
     def verify(self, proof):
         b = np.frombuffer(proof, dtype=np.uint8)
         return int(dll().orc_verify(self.h, b.ctypes.data, b.size))
+
+    def set_lookup_wires(self, wires):
+        """prover::set_lookup_wires on a copy of the witness (multiplicities, padding slots); returns the copy"""
+        w = _u64(wires).copy()
+        dll().orc_set_lookup_wires.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        if dll().orc_set_lookup_wires(self.h, w.ctypes.data) != 0:
+            raise ValueError("a looked-up input is not in its table")
+        return w
 
     def close(self):
         if self.h:

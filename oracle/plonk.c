@@ -23,6 +23,12 @@ const orc_poseidon_fast* orc_poseidon_fast_constants(void) { return &FAST; }
 
 #define UNUSED_SELECTOR 0xFFFFFFFFULL
 
+/* slot counts of the lookup argument (LookupGate::num_slots = routed / 2, LookupTableGate::num_slots = routed / 3;
+ * prover::compute_lookup_polys: S = ceil(lu slots / (max_quotient_degree_factor - 1)) partial sums per row) */
+typedef struct {
+    uint32_t num_luts, n_lu_slots, n_lut_slots, lu_degree, lut_degree, n_sldc;
+} orc_lookup_shape;
+
 /* ---- gate evaluators: base field ---- */
 #define FE uint64_t
 #define FE_ADD(a, b) gl_add(a, b)
@@ -100,7 +106,14 @@ struct orc_circuit {
     unsigned log_n, log_L;
     uint32_t n_cs;          /* constants + sigmas columns */
     uint32_t n_consts_all;  /* selectors + gate constants */
-    uint32_t n_zs;          /* num_challenges * (1 + num_partial_products) */
+    uint32_t n_zs;          /* num_challenges * (1 + num_partial_products) + n_lk_polys */
+    uint32_t n_zpp;         /* num_challenges * (1 + num_partial_products): the Zs and partial products alone */
+    uint32_t n_lk_sel;      /* lookup selector columns between the gate selectors and the gate constants: 4 + num_luts or 0 */
+    uint32_t n_lk_polys;    /* num_challenges * (1 + S) or 0 */
+    uint32_t n_lk_terms;    /* constraints per challenge round: 4 + num_luts + 2 S or 0 */
+    orc_lookup_shape lk;
+    uint32_t *lut_sizes, *lookup_rows, *lut_num_lookups, *lut_offsets; /* copies of the descriptor's arrays */
+    uint16_t* lut_pairs;
     uint32_t n_q;           /* num_challenges * quotient_degree_factor */
     uint32_t max_constraints;
     uint64_t* sigma_values; /* routed x n column-major (prover_data.sigmas) */
@@ -135,9 +148,35 @@ orc_circuit* orc_circuit_build(const orc_circuit_desc* desc, const uint64_t* con
     c->log_L = desc->degree_bits + desc->rate_bits;
     c->n = (size_t)1 << c->log_n;
     c->L = (size_t)1 << c->log_L;
-    c->n_consts_all = desc->num_selectors + desc->num_constants;
+    if (desc->num_luts) {
+        uint32_t T = desc->num_luts;
+        c->lk.num_luts = T;
+        c->lk.n_lu_slots = desc->num_routed_wires / 2;
+        c->lk.n_lut_slots = desc->num_routed_wires / 3;
+        c->lk.lu_degree = desc->quotient_degree_factor - 1;
+        c->lk.n_sldc = (c->lk.n_lu_slots + c->lk.lu_degree - 1) / c->lk.lu_degree;
+        c->lk.lut_degree = (c->lk.n_lut_slots + c->lk.n_sldc - 1) / c->lk.n_sldc;
+        c->n_lk_sel = 4 + T;
+        c->n_lk_polys = desc->num_challenges * (1 + c->lk.n_sldc);
+        c->n_lk_terms = 4 + T + 2 * c->lk.n_sldc;
+        c->lut_sizes = (uint32_t*)malloc(4 * T);
+        c->lut_num_lookups = (uint32_t*)malloc(4 * T);
+        c->lookup_rows = (uint32_t*)malloc(12 * T);
+        c->lut_offsets = (uint32_t*)malloc(4 * (T + 1));
+        memcpy(c->lut_sizes, desc->lut_sizes, 4 * T);
+        memcpy(c->lut_num_lookups, desc->lut_num_lookups, 4 * T);
+        memcpy(c->lookup_rows, desc->lookup_rows, 12 * T);
+        c->lut_offsets[0] = 0;
+        for (uint32_t t = 0; t < T; t++) c->lut_offsets[t + 1] = c->lut_offsets[t] + c->lut_sizes[t];
+        c->lut_pairs = (uint16_t*)malloc(4 * (size_t)c->lut_offsets[T]);
+        memcpy(c->lut_pairs, desc->lut_pairs, 4 * (size_t)c->lut_offsets[T]);
+        c->d.lut_sizes = c->lut_sizes; c->d.lut_num_lookups = c->lut_num_lookups;
+        c->d.lookup_rows = c->lookup_rows; c->d.lut_pairs = c->lut_pairs;
+    }
+    c->n_consts_all = desc->num_selectors + c->n_lk_sel + desc->num_constants;
     c->n_cs = c->n_consts_all + desc->num_routed_wires;
-    c->n_zs = desc->num_challenges * (1 + desc->num_partial_products);
+    c->n_zpp = desc->num_challenges * (1 + desc->num_partial_products);
+    c->n_zs = c->n_zpp + c->n_lk_polys;
     c->n_q = desc->num_challenges * desc->quotient_degree_factor;
     c->max_constraints = 0;
     for (uint32_t g = 0; g < desc->num_gates; g++) {
@@ -176,7 +215,9 @@ orc_circuit* orc_circuit_build(const orc_circuit_desc* desc, const uint64_t* con
 void orc_circuit_free(orc_circuit* c) {
     if (!c) return;
     free(c->gates); free(c->k_is); free(c->sigma_values); free(c->cs_coeffs); free(c->cs_leaves);
-    free(c->cs_digests); free(c->cs_cap); free(c);
+    free(c->cs_digests); free(c->cs_cap);
+    free(c->lut_sizes); free(c->lookup_rows); free(c->lut_num_lookups); free(c->lut_offsets); free(c->lut_pairs);
+    free(c);
 }
 void orc_circuit_digest(const orc_circuit* c, uint64_t out[4]) { memcpy(out, c->d.circuit_digest, 32); }
 void orc_circuit_constants_sigmas_cap(const orc_circuit* c, uint64_t* cap_out) {
@@ -204,11 +245,100 @@ static gl2 filter_ext(const orc_gate* g, gl2 s, int many) {
     return f;
 }
 
+/* ---------------- lookup argument ---------------- */
+/* vanishing_poly::get_lut_poly: the table's pairs (inp + B out) as the coefficients of a polynomial in delta, the FIRST entry
+ * at the highest power, padded with zero entries to `degree` = slots * rows (what RE reaches on the table's last row). */
+static uint64_t get_lut_poly(const orc_circuit* c, uint32_t t, const uint64_t deltas[4]) {
+    uint32_t len = c->lut_sizes[t], slots = c->lk.n_lut_slots;
+    uint32_t degree = slots * ((len + slots - 1) / slots);
+    const uint16_t* pr = c->lut_pairs + 2 * (size_t)c->lut_offsets[t];
+    uint64_t acc = 0;
+    for (uint32_t i = 0; i < degree; i++) {
+        uint64_t coeff = i < len ? gl_add(pr[2 * i], gl_mul(deltas[1], pr[2 * i + 1])) : 0;
+        acc = gl_add(gl_mul(acc, deltas[3]), coeff);
+    }
+    return acc;
+}
+
+/* prover::set_lookup_wires */
+int orc_set_lookup_wires(const orc_circuit* c, uint64_t* wires) {
+    const size_t n = c->n;
+    for (uint32_t t = 0; t < c->lk.num_luts; t++) {
+        uint32_t len = c->lut_sizes[t], n_lu = c->lk.n_lu_slots, n_lut = c->lk.n_lut_slots;
+        uint32_t last_lu = c->lookup_rows[3 * t], last_lut = c->lookup_rows[3 * t + 1], first_lut = c->lookup_rows[3 * t + 2];
+        const uint16_t* pr = c->lut_pairs + 2 * (size_t)c->lut_offsets[t];
+        int32_t* idx_of = (int32_t*)malloc(4 * 65536);
+        uint64_t* mult = (uint64_t*)calloc(len, 8);
+        memset(idx_of, 0xFF, 4 * 65536);
+        for (uint32_t i = 0; i < len; i++) idx_of[pr[2 * i]] = (int32_t)i; /* HashMap collect: the last entry with that input wins */
+        uint32_t lookups = c->lut_num_lookups[t];
+        int bad = 0;
+        /* lookups fill the LookupGate rows slot after slot from last_lu_row upwards (CircuitBuilder::find_slot) */
+        for (uint32_t q = 0; q < lookups; q++) {
+            uint32_t row = last_lu + q / n_lu, slot = q % n_lu;
+            uint64_t v = wires[(size_t)(2 * slot) * n + row];
+            if (row >= last_lut || v > 0xFFFF || idx_of[v] < 0) { bad = 1; break; }
+            mult[idx_of[v]]++;
+        }
+        if (!bad) {
+            uint32_t remaining = (n_lu - lookups % n_lu) % n_lu;
+            for (uint32_t slot = n_lu - remaining; slot < n_lu; slot++) {
+                wires[(size_t)(2 * slot) * n + (last_lut - 1)] = pr[0];
+                wires[(size_t)(2 * slot + 1) * n + (last_lut - 1)] = pr[1];
+                mult[0]++;
+            }
+            for (uint32_t e = 0; e < len; e++)
+                wires[(size_t)(3 * (e % n_lut) + 2) * n + (first_lut - e / n_lut)] = mult[e];
+        }
+        free(idx_of); free(mult);
+        if (bad) return -1;
+    }
+    return 0;
+}
+
+/* prover::compute_lookup_polys for one challenge round: cols = (1 + S) x n column-major, zeroed here.  RE and the Sum run
+ * down the LookupTableGate rows from first_lut_row to last_lut_row, the LDC continues down the LookupGate rows. */
+static void compute_lookup_polys(const orc_circuit* c, const uint64_t* wires, const uint64_t deltas[4], uint64_t* cols) {
+    const size_t n = c->n;
+    const uint32_t S = c->lk.n_sldc, n_lu = c->lk.n_lu_slots, n_lut = c->lk.n_lut_slots;
+    memset(cols, 0, 8 * n * (1 + S));
+#define WIRE(row, w) wires[(size_t)(w) * n + (row)]
+    for (uint32_t t = 0; t < c->lk.num_luts; t++) {
+        uint32_t last_lu = c->lookup_rows[3 * t], last_lut = c->lookup_rows[3 * t + 1], first_lut = c->lookup_rows[3 * t + 2];
+        for (uint32_t row = first_lut + 1; row-- > last_lut;) {
+            uint64_t re = cols[row + 1];
+            for (uint32_t i = 0; i < n_lut; i++)
+                re = gl_add(gl_mul(re, deltas[3]), gl_add(WIRE(row, 3 * i), gl_mul(deltas[1], WIRE(row, 3 * i + 1))));
+            cols[row] = re;
+            for (uint32_t p = 0; p < S; p++) {
+                uint64_t sum = p ? cols[(size_t)p * n + row] : cols[(size_t)S * n + row + 1];
+                for (uint32_t i = p * c->lk.lut_degree; i < (p + 1) * c->lk.lut_degree && i < n_lut; i++) {
+                    uint64_t combo = gl_add(WIRE(row, 3 * i), gl_mul(deltas[0], WIRE(row, 3 * i + 1)));
+                    sum = gl_add(sum, gl_mul(WIRE(row, 3 * i + 2), gl_inv(gl_sub(deltas[2], combo))));
+                }
+                cols[(size_t)(p + 1) * n + row] = sum;
+            }
+        }
+        for (uint32_t row = last_lut; row-- > last_lu;) {
+            for (uint32_t p = 0; p < S; p++) {
+                uint64_t prev = p ? cols[(size_t)p * n + row] : cols[(size_t)S * n + row + 1];
+                uint64_t sum = 0;
+                for (uint32_t i = p * c->lk.lu_degree; i < (p + 1) * c->lk.lu_degree && i < n_lu; i++) {
+                    uint64_t combo = gl_add(WIRE(row, 2 * i), gl_mul(deltas[0], WIRE(row, 2 * i + 1)));
+                    sum = gl_add(sum, gl_inv(gl_sub(deltas[2], combo)));
+                }
+                cols[(size_t)(p + 1) * n + row] = gl_sub(prev, sum);
+            }
+        }
+    }
+#undef WIRE
+}
+
 size_t orc_proof_max_bytes(const orc_circuit* c) {
     const orc_circuit_desc* d = &c->d;
     size_t capb = (size_t)32 << d->cap_height;
     size_t words = 0;
-    words += 2 * (c->n_cs + d->num_wires + c->n_zs + d->num_challenges + c->n_q);
+    words += 2 * (c->n_cs + d->num_wires + c->n_zs + d->num_challenges + c->n_lk_polys + c->n_q);
     size_t bytes = 3 * capb + words * 8 + c->n_fri_rounds * capb;
     size_t per_query = 0;
     uint32_t cols[4] = {c->n_cs, d->num_wires, c->n_zs, c->n_q};
@@ -252,7 +382,7 @@ static gl2 eval_base_poly_ext(const uint64_t* coeffs, size_t n, gl2 z) {
 static void vanishing_base(const orc_circuit* c, uint64_t x, size_t i, const uint64_t* cs_row,
                            const uint64_t* wires_row, const uint64_t* zs_row, const uint64_t* zs_next_row,
                            const uint64_t* betas, const uint64_t* gammas, const uint64_t* alphas,
-                           const uint64_t* pih, const uint64_t* z_h_evals, uint64_t* tmp_constraints,
+                           const uint64_t* deltas, const uint64_t* lut_polys, const uint64_t* pih, const uint64_t* z_h_evals, uint64_t* tmp_constraints,
                            uint64_t* out /* num_challenges */) {
     const orc_circuit_desc* d = &c->d;
     const uint32_t nc = d->num_challenges, npp = d->num_partial_products, routed = d->num_routed_wires;
@@ -267,15 +397,16 @@ static void vanishing_base(const orc_circuit* c, uint64_t x, size_t i, const uin
         uint32_t k = gate_num_constraints_base(gt);
         if (!k) continue;
         uint64_t f = filter_base(gt, cs_row[gt->selector_index], d->num_selectors > 1);
-        gate_eval_base(gt, cs_row + d->num_selectors, wires_row, pih, gout);
+        gate_eval_base(gt, cs_row + d->num_selectors + c->n_lk_sel, wires_row, pih, gout);
         for (uint32_t j = 0; j < k; j++) cons[j] = gl_add(cons[j], gl_mul(f, gout[j]));
     }
     /* L_0(x) = Z_H(x) / (n (x - 1))  (ZeroPolyOnCoset::eval_l_0) */
     uint64_t zh = z_h_evals[i & ((1u << d->rate_bits) - 1)];
     uint64_t l0 = gl_mul(zh, gl_inv(gl_mul((uint64_t)c->n % GL_P, gl_sub(x, 1))));
     const uint64_t* sig_row = cs_row + c->n_consts_all;
-    /* vanishing_terms = [z1 terms (nc)] ++ [partial product terms (nc * (npp+1))] ++ constraints */
-    uint32_t n_terms = nc + nc * (npp + 1) + nk;
+    /* vanishing_terms = [z1 terms (nc)] ++ [partial product terms (nc * (npp+1))] ++ [lookup terms (nc * n_lk_terms)] ++ constraints */
+    const uint32_t o_lk = nc + nc * (npp + 1), o_gate = o_lk + nc * c->n_lk_terms;
+    uint32_t n_terms = o_gate + nk;
     uint64_t* terms = gout + nk; /* scratch after gate outputs */
     for (uint32_t ci = 0; ci < nc; ci++) {
         uint64_t z_x = zs_row[ci], z_gx = zs_next_row[ci];
@@ -296,7 +427,11 @@ static void vanishing_base(const orc_circuit* c, uint64_t x, size_t i, const uin
             acc = new_acc;
         }
     }
-    for (uint32_t k = 0; k < nk; k++) terms[nc + nc * (npp + 1) + k] = cons[k];
+    for (uint32_t ci = 0; ci < nc && c->n_lk_terms; ci++)
+        lookup_constraints_base(&c->lk, cs_row + d->num_selectors, wires_row, zs_row + c->n_zpp + ci * (1 + c->lk.n_sldc),
+                                zs_next_row + c->n_zpp + ci * (1 + c->lk.n_sldc), deltas + 4 * ci,
+                                lut_polys + ci * c->lk.num_luts, terms + o_lk + ci * c->n_lk_terms);
+    for (uint32_t k = 0; k < nk; k++) terms[o_gate + k] = cons[k];
     uint64_t zh_inv = gl_inv(zh);
     for (uint32_t ci = 0; ci < nc; ci++) {
         uint64_t sum = 0;
@@ -327,6 +462,15 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
     wbuf w = {proof_out, 0, cap_bytes, 0};
     size_t ret = 0;
 
+    /* 0. set_lookup_wires: on a copy, the caller's witness stays as it was handed over */
+    uint64_t* wires_lk = NULL;
+    if (d->num_luts) {
+        wires_lk = (uint64_t*)malloc(8 * n * d->num_wires);
+        memcpy(wires_lk, wires, 8 * n * d->num_wires);
+        if (orc_set_lookup_wires(c, wires_lk)) { free(wires_lk); return 0; }
+        wires = wires_lk;
+    }
+
     /* 1. public inputs hash */
     uint64_t pih[4];
     orc_hash_no_pad(public_inputs, d->num_public_inputs, pih);
@@ -345,6 +489,15 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
     uint64_t betas[4], gammas[4], alphas[4];
     for (uint32_t i = 0; i < nc; i++) betas[i] = orc_ch_challenge(&ch);
     for (uint32_t i = 0; i < nc; i++) gammas[i] = orc_ch_challenge(&ch);
+    /* lookups: deltas = betas ++ gammas ++ 2 nc more challenges, NUM_COINS_LOOKUP = 4 per round (A, B, alpha, delta) */
+    uint64_t deltas[16] = {0}, lut_polys[4 * 16] = {0};
+    if (d->num_luts) {
+        if (nc > 4 || d->num_luts > 16) { free(wires_lk); batch_free(&bw); return 0; }
+        for (uint32_t i = 0; i < nc; i++) { deltas[i] = betas[i]; deltas[nc + i] = gammas[i]; }
+        for (uint32_t i = 0; i < 2 * nc; i++) deltas[2 * nc + i] = orc_ch_challenge(&ch);
+        for (uint32_t ci = 0; ci < nc; ci++)
+            for (uint32_t t = 0; t < d->num_luts; t++) lut_polys[ci * d->num_luts + t] = get_lut_poly(c, t, deltas + 4 * ci);
+    }
 
     /* 4. wires_permutation_partial_products_and_zs: column order [Z_0..Z_{nc-1}, pp(0,·), pp(1,·)..] */
     uint64_t* zs_values = (uint64_t*)malloc(8 * n * c->n_zs);
@@ -385,6 +538,9 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
                 }
         }
     }
+    /* compute_all_lookup_polys: the rounds' (RE, SLDC_0..S-1) after the partial products in the same commitment */
+    for (uint32_t ci = 0; ci < nc && c->n_lk_polys; ci++)
+        compute_lookup_polys(c, wires, deltas + 4 * ci, zs_values + (size_t)(c->n_zpp + ci * (1 + c->lk.n_sldc)) * n);
     if (tr && tr->zs_partial_values) memcpy(tr->zs_partial_values, zs_values, 8 * n * c->n_zs);
     batch_alloc(c, &bz, c->n_zs);
     orc_commit_from_values(zs_values, c->n_zs, c->log_n, d->rate_bits, cap_h, bz.coeffs, bz.leaves, bz.digests, bz.cap);
@@ -404,14 +560,15 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
         size_t next_step = (size_t)1 << d->rate_bits; /* quotient_degree_bits == rate_bits */
 #pragma omp parallel
         {
-            uint64_t* tmp = (uint64_t*)malloc(8 * (3 * c->max_constraints + 64 + nc * (npp + 2)));
+            uint64_t* tmp = (uint64_t*)malloc(8 * (3 * c->max_constraints + 64 + nc * (npp + 2 + c->n_lk_terms)));
 #pragma omp for schedule(static)
             for (size_t i = 0; i < L; i++) {
                 uint64_t x = gl_mul(GL_GEN, gl_pow(w_L, i));
                 size_t li = gl_bitrev(i, c->log_L), ln = gl_bitrev((i + next_step) % L, c->log_L);
                 uint64_t out[4];
                 vanishing_base(c, x, i, c->cs_leaves + li * c->n_cs, bw.leaves + li * d->num_wires,
-                               bz.leaves + li * c->n_zs, bz.leaves + ln * c->n_zs, betas, gammas, alphas, pih,
+                               bz.leaves + li * c->n_zs, bz.leaves + ln * c->n_zs, betas, gammas, alphas, deltas,
+                               lut_polys, pih,
                                z_h_evals, tmp, out);
                 for (uint32_t ci = 0; ci < nc; ci++) qvals[(size_t)ci * L + i] = out[ci];
             }
@@ -442,37 +599,47 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
     const batch* oracles[4];
     batch bcs = {c->cs_coeffs, c->cs_leaves, c->cs_digests, c->cs_cap, c->n_cs};
     oracles[0] = &bcs; oracles[1] = &bw; oracles[2] = &bz; oracles[3] = &bq;
+    /* CommonCircuitData::fri_all_polys: constants_sigmas, wires, Zs ++ partial products, quotient chunks, and LAST the
+     * lookup polynomials (columns n_zpp.. of the Zs commitment); fri_next_batch_polys: the Zs, then the lookup polynomials.
+     * views[] lists the zeta batch in that order as (coefficients, column count) */
+    struct { const uint64_t* coeffs; uint32_t n_cols; } views[5] = {
+        {bcs.coeffs, c->n_cs}, {bw.coeffs, d->num_wires}, {bz.coeffs, c->n_zpp}, {bq.coeffs, c->n_q},
+        {bz.coeffs + (size_t)c->n_zpp * n, c->n_lk_polys}};
     uint32_t n_open = c->n_cs + d->num_wires + c->n_zs + c->n_q;
+    uint32_t n_next = nc + c->n_lk_polys;
     gl2* open_zeta = (gl2*)malloc(sizeof(gl2) * n_open);
-    gl2* open_next = (gl2*)malloc(sizeof(gl2) * nc);
+    gl2* open_next = (gl2*)malloc(sizeof(gl2) * n_next);
     {
-        uint32_t base_k[5] = {0, 0, 0, 0, 0};
-        for (int o = 0; o < 4; o++) base_k[o + 1] = base_k[o] + oracles[o]->n_cols;
+        uint32_t base_k[6] = {0, 0, 0, 0, 0, 0};
+        for (int o = 0; o < 5; o++) base_k[o + 1] = base_k[o] + views[o].n_cols;
 #pragma omp parallel for schedule(dynamic)
         for (uint32_t k = 0; k < n_open; k++) {
             int o = 0;
             while (k >= base_k[o + 1]) o++;
-            open_zeta[k] = eval_base_poly_ext(oracles[o]->coeffs + (size_t)(k - base_k[o]) * n, n, zeta);
+            open_zeta[k] = eval_base_poly_ext(views[o].coeffs + (size_t)(k - base_k[o]) * n, n, zeta);
         }
-        for (uint32_t p = 0; p < nc; p++) open_next[p] = eval_base_poly_ext(bz.coeffs + (size_t)p * n, n, g_zeta);
+        for (uint32_t p = 0; p < n_next; p++)
+            open_next[p] = eval_base_poly_ext(bz.coeffs + (size_t)(p < nc ? p : c->n_zpp + (p - nc)) * n, n, g_zeta);
     }
     /* proof: caps + OpeningSet {constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys} */
     w_u64s(&w, bw.cap, (size_t)4 << cap_h);
     w_u64s(&w, bz.cap, (size_t)4 << cap_h);
     w_u64s(&w, bq.cap, (size_t)4 << cap_h);
     {
-        uint32_t o_wires = c->n_cs, o_zs = o_wires + d->num_wires, o_pp = o_zs + nc, o_q = o_zs + c->n_zs;
+        uint32_t o_wires = c->n_cs, o_zs = o_wires + d->num_wires, o_pp = o_zs + nc, o_q = o_zs + c->n_zpp, o_lk = o_q + c->n_q;
         w_u64s(&w, (uint64_t*)open_zeta, 2 * c->n_consts_all);                   /* constants */
         w_u64s(&w, (uint64_t*)(open_zeta + c->n_consts_all), 2 * routed);         /* plonk_sigmas */
         w_u64s(&w, (uint64_t*)(open_zeta + o_wires), 2 * d->num_wires);           /* wires */
         w_u64s(&w, (uint64_t*)(open_zeta + o_zs), 2 * nc);                        /* plonk_zs */
         w_u64s(&w, (uint64_t*)open_next, 2 * nc);                                 /* plonk_zs_next */
+        w_u64s(&w, (uint64_t*)(open_zeta + o_lk), 2 * c->n_lk_polys);             /* lookup_zs (read_opening_set order) */
+        w_u64s(&w, (uint64_t*)(open_next + nc), 2 * c->n_lk_polys);               /* lookup_zs_next */
         w_u64s(&w, (uint64_t*)(open_zeta + o_pp), 2 * nc * npp);                  /* partial_products */
         w_u64s(&w, (uint64_t*)(open_zeta + o_q), 2 * c->n_q);                     /* quotient_polys */
     }
     /* challenger.observe_openings(to_fri_openings): zeta batch in oracle order, then zeta_next batch */
     orc_ch_observe_many(&ch, (uint64_t*)open_zeta, 2 * n_open);
-    orc_ch_observe_many(&ch, (uint64_t*)open_next, 2 * nc);
+    orc_ch_observe_many(&ch, (uint64_t*)open_next, 2 * n_next);
 
     /* 7. PolynomialBatch::prove_openings */
     gl2 alpha = orc_ch_ext_challenge(&ch);
@@ -488,9 +655,9 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
         for (size_t i = 0; i < n; i++) {
             gl2 acc = gl2_from(0);
             uint32_t k = 0;
-            for (int o = 0; o < 4; o++)
-                for (uint32_t p = 0; p < oracles[o]->n_cols; p++, k++)
-                    acc = gl2_add(acc, gl2_scale(apows[k], oracles[o]->coeffs[(size_t)p * n + i]));
+            for (int o = 0; o < 5; o++)
+                for (uint32_t p = 0; p < views[o].n_cols; p++, k++)
+                    acc = gl2_add(acc, gl2_scale(apows[k], views[o].coeffs[(size_t)p * n + i]));
             comp[i] = acc;
         }
         free(apows);
@@ -500,8 +667,8 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
         /* batch 1: Zs at g*zeta; alpha.shift_poly(final_poly) multiplies by alpha^(count of batch 1) */
         memset(comp, 0, sizeof(gl2) * n);
         apow = gl2_from(1);
-        for (uint32_t p = 0; p < nc; p++) {
-            const uint64_t* co = bz.coeffs + (size_t)p * n;
+        for (uint32_t p = 0; p < n_next; p++) {
+            const uint64_t* co = bz.coeffs + (size_t)(p < nc ? p : c->n_zpp + (p - nc)) * n;
             for (size_t i = 0; i < n; i++) comp[i] = gl2_add(comp[i], gl2_scale(apow, co[i]));
             apow = gl2_mul(apow, alpha);
         }
@@ -629,6 +796,7 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
         tr->pow_witness = pow_witness;
         tr->n_fri_rounds = R;
         memcpy(tr->query_indices, qidx, 8 * d->fri_num_queries);
+        memcpy(tr->deltas, deltas, sizeof deltas);
     }
     ret = (w.overflow || !degree_ok) ? 0 : w.len;
 
@@ -636,6 +804,7 @@ size_t orc_prove_traced(const orc_circuit* c, const uint64_t* wires, const uint6
     free(tree_leaves); free(tree_digests); free(tree_nleaves);
     free(values); free(final_poly); free(open_zeta); free(open_next);
     batch_free(&bw); batch_free(&bz); batch_free(&bq);
+    free(wires_lk);
     return ret;
 }
 
@@ -665,14 +834,18 @@ int orc_verify(const orc_circuit* c, const uint8_t* proof, size_t len) {
     r_u64s(&r, caps, 3 * capw);
     const uint64_t *wires_cap = caps, *zs_cap = caps + capw, *q_cap = caps + 2 * capw;
     uint32_t n_open = c->n_cs + d->num_wires + c->n_zs + c->n_q;
-    gl2* o_consts = (gl2*)malloc(sizeof(gl2) * (n_open + nc));
+    /* read_opening_set: constants, sigmas, wires, zs, zs_next, lookup_zs, lookup_zs_next, partial products, quotient */
+    const uint32_t nlk = c->n_lk_polys;
+    gl2* o_consts = (gl2*)malloc(sizeof(gl2) * (n_open + nc + nlk));
     gl2* o_sigmas = o_consts + c->n_consts_all;
     gl2* o_wires = o_sigmas + routed;
     gl2* o_zs = o_wires + d->num_wires;
     gl2* o_zs_next = o_zs + nc;
-    gl2* o_pp = o_zs_next + nc;
+    gl2* o_lk = o_zs_next + nc;
+    gl2* o_lk_next = o_lk + nlk;
+    gl2* o_pp = o_lk_next + nlk;
     gl2* o_q = o_pp + nc * npp;
-    r_u64s(&r, (uint64_t*)o_consts, 2 * (n_open + nc));
+    r_u64s(&r, (uint64_t*)o_consts, 2 * (n_open + nc + nlk));
     uint64_t* fri_caps = caps + 3 * capw;
     r_u64s(&r, fri_caps, R * capw);
     /* query rounds are parsed later; find the tail (final poly, pow witness, public inputs) */
@@ -713,6 +886,14 @@ int orc_verify(const orc_circuit* c, const uint8_t* proof, size_t len) {
         uint64_t betas[4], gammas[4], alphas[4];
         for (uint32_t i = 0; i < nc; i++) betas[i] = orc_ch_challenge(&ch);
         for (uint32_t i = 0; i < nc; i++) gammas[i] = orc_ch_challenge(&ch);
+        uint64_t deltas[16] = {0}, lut_polys[4 * 16] = {0};
+        if (d->num_luts) {
+            if (nc > 4 || d->num_luts > 16) { rc = -1; goto done; }
+            for (uint32_t i = 0; i < nc; i++) { deltas[i] = betas[i]; deltas[nc + i] = gammas[i]; }
+            for (uint32_t i = 0; i < 2 * nc; i++) deltas[2 * nc + i] = orc_ch_challenge(&ch);
+            for (uint32_t ci = 0; ci < nc; ci++)
+                for (uint32_t t = 0; t < d->num_luts; t++) lut_polys[ci * d->num_luts + t] = get_lut_poly(c, t, deltas + 4 * ci);
+        }
         orc_ch_observe_many(&ch, zs_cap, capw);
         for (uint32_t i = 0; i < nc; i++) alphas[i] = orc_ch_challenge(&ch);
         orc_ch_observe_many(&ch, q_cap, capw);
@@ -720,7 +901,9 @@ int orc_verify(const orc_circuit* c, const uint8_t* proof, size_t len) {
         /* observe openings: zeta batch = constants, sigmas, wires, zs, partial products, quotient; then zs_next */
         orc_ch_observe_many(&ch, (uint64_t*)o_consts, 2 * (c->n_cs + d->num_wires + nc));
         orc_ch_observe_many(&ch, (uint64_t*)o_pp, 2 * (nc * npp + c->n_q));
+        orc_ch_observe_many(&ch, (uint64_t*)o_lk, 2 * nlk);
         orc_ch_observe_many(&ch, (uint64_t*)o_zs_next, 2 * nc);
+        orc_ch_observe_many(&ch, (uint64_t*)o_lk_next, 2 * nlk);
         gl2 fri_alpha = orc_ch_ext_challenge(&ch);
         gl2 fri_betas[16];
         for (uint32_t k = 0; k < R; k++) {
@@ -744,10 +927,11 @@ int orc_verify(const orc_circuit* c, const uint8_t* proof, size_t len) {
             uint32_t k = gate_num_constraints_ext(gt);
             if (!k) continue;
             gl2 f = filter_ext(gt, o_consts[gt->selector_index], d->num_selectors > 1);
-            gate_eval_ext(gt, o_consts + d->num_selectors, o_wires, pih_e, gout);
+            gate_eval_ext(gt, o_consts + d->num_selectors + c->n_lk_sel, o_wires, pih_e, gout);
             for (uint32_t j = 0; j < k; j++) cons[j] = gl2_add(cons[j], gl2_mul(f, gout[j]));
         }
-        uint32_t n_terms = nc + nc * (npp + 1) + nk;
+        const uint32_t t_lk = nc + nc * (npp + 1), t_gate = t_lk + nc * c->n_lk_terms;
+        uint32_t n_terms = t_gate + nk;
         gl2* terms = (gl2*)malloc(sizeof(gl2) * n_terms);
         gl2 zeta_n = zeta;
         for (uint32_t i = 0; i < d->degree_bits; i++) zeta_n = gl2_mul(zeta_n, zeta_n);
@@ -770,7 +954,11 @@ int orc_verify(const orc_circuit* c, const uint8_t* proof, size_t len) {
                 acc = new_acc;
             }
         }
-        for (uint32_t k = 0; k < nk; k++) terms[nc + nc * (npp + 1) + k] = cons[k];
+        for (uint32_t ci = 0; ci < nc && nlk; ci++)
+            lookup_constraints_ext(&c->lk, o_consts + d->num_selectors, o_wires, o_lk + ci * (1 + c->lk.n_sldc),
+                                   o_lk_next + ci * (1 + c->lk.n_sldc), deltas + 4 * ci, lut_polys + ci * d->num_luts,
+                                   terms + t_lk + ci * c->n_lk_terms);
+        for (uint32_t k = 0; k < nk; k++) terms[t_gate + k] = cons[k];
         for (uint32_t ci = 0; ci < nc && rc == 1; ci++) {
             gl2 lhs = reduce_with_powers_ext(terms, n_terms, gl2_from(alphas[ci]));
             gl2 rhs = gl2_mul(z_h, reduce_with_powers_ext(o_q + ci * chunk, chunk, zeta_n));
@@ -787,15 +975,19 @@ int orc_verify(const orc_circuit* c, const uint8_t* proof, size_t len) {
         {
             /* zeta batch order: constants_sigmas (oracle 0), wires, zs ++ partial products, quotient */
             gl2 apow = gl2_from(1);
-            const gl2* seqs[5] = {o_consts, o_wires, o_zs, o_pp, o_q};
-            uint32_t lens[5] = {c->n_cs, d->num_wires, nc, nc * npp, c->n_q};
-            for (int s = 0; s < 5; s++)
+            const gl2* seqs[6] = {o_consts, o_wires, o_zs, o_pp, o_q, o_lk};
+            uint32_t lens[6] = {c->n_cs, d->num_wires, nc, nc * npp, c->n_q, nlk};
+            for (int s = 0; s < 6; s++)
                 for (uint32_t i = 0; i < lens[s]; i++) { red0 = gl2_add(red0, gl2_mul(apow, seqs[s][i])); apow = gl2_mul(apow, fri_alpha); }
             apow = gl2_from(1);
             for (uint32_t i = 0; i < nc; i++) { red1 = gl2_add(red1, gl2_mul(apow, o_zs_next[i])); apow = gl2_mul(apow, fri_alpha); }
+            for (uint32_t i = 0; i < nlk; i++) { red1 = gl2_add(red1, gl2_mul(apow, o_lk_next[i])); apow = gl2_mul(apow, fri_alpha); }
         }
         gl2 g_zeta = gl2_scale(zeta, gl_root_of_unity(c->log_n));
-        gl2 alpha_pow_nc = gl2_pow(fri_alpha, nc);
+        gl2 alpha_pow_nc = gl2_pow(fri_alpha, nc + nlk);
+        /* fri_combine_initial walks the batch's polynomial list: Zs columns n_zpp.. (the lookup polynomials) come after the
+         * quotient chunks in the zeta batch and after the Zs in the zeta_next batch, so the Zs row is kept for later */
+        uint64_t* zrow = (uint64_t*)malloc(8 * (c->n_zs + 1));
         const uint64_t* init_caps[4] = {c->cs_cap, wires_cap, zs_cap, q_cap};
         uint64_t* row = (uint64_t*)malloc(8 * (d->num_wires + c->n_cs + c->n_zs + c->n_q + 8));
         rbuf qr = {proof, len, q_start, 0};
@@ -811,13 +1003,17 @@ int orc_verify(const orc_circuit* c, const uint8_t* proof, size_t len) {
                 if (plen != c->log_L - cap_h) { rc = -4; break; }
                 r_u64s(&qr, sib, 4 * plen);
                 if (!orc_merkle_verify(row, cols[o], x_index, sib, plen, init_caps[o], cap_h)) { rc = -5; break; }
-                for (uint32_t i = 0; i < cols[o]; i++) { sum0 = gl2_add(sum0, gl2_scale(apow, row[i])); apow = gl2_mul(apow, fri_alpha); }
+                uint32_t take = o == 2 ? c->n_zpp : cols[o];
+                for (uint32_t i = 0; i < take; i++) { sum0 = gl2_add(sum0, gl2_scale(apow, row[i])); apow = gl2_mul(apow, fri_alpha); }
                 if (o == 2) {
+                    memcpy(zrow, row, 8 * c->n_zs);
                     gl2 ap = gl2_from(1);
                     for (uint32_t i = 0; i < nc; i++) { sum1 = gl2_add(sum1, gl2_scale(ap, row[i])); ap = gl2_mul(ap, fri_alpha); }
+                    for (uint32_t i = 0; i < nlk; i++) { sum1 = gl2_add(sum1, gl2_scale(ap, row[c->n_zpp + i])); ap = gl2_mul(ap, fri_alpha); }
                 }
             }
             if (rc != 1) break;
+            for (uint32_t i = 0; i < nlk; i++) { sum0 = gl2_add(sum0, gl2_scale(apow, zrow[c->n_zpp + i])); apow = gl2_mul(apow, fri_alpha); }
             uint64_t subgroup_x = gl_mul(GL_GEN, gl_pow(gl_root_of_unity(c->log_L), gl_bitrev(x_index, c->log_L)));
             gl2 sx = gl2_from(subgroup_x);
             gl2 old_eval = gl2_mul(gl2_sub(sum0, red0), gl2_inv(gl2_sub(sx, zeta)));
@@ -867,7 +1063,7 @@ int orc_verify(const orc_circuit* c, const uint8_t* proof, size_t len) {
             if (!gl2_eq(fe, old_eval)) rc = -9;
         }
         if (qr.bad) rc = -10;
-        free(row);
+        free(row); free(zrow);
     }
 done:
     free(caps); free(o_consts); free(final_poly); free(pis);

@@ -39,7 +39,12 @@ enum {
     ORC_GATE_U32_ARITHMETIC = 15,  /* param0 = num_ops */
     ORC_GATE_U32_SUBTRACTION = 16, /* param0 = num_ops */
     ORC_GATE_U32_RANGE_CHECK = 17, /* param0 = num_input_limbs */
-    ORC_GATE_COMPARISON = 18       /* param0 = num_bits, param1 = num_chunks */
+    ORC_GATE_COMPARISON = 18,      /* param0 = num_bits, param1 = num_chunks */
+    /* plonky2::gates::{lookup, lookup_table}: no gate constraints of their own - their wires feed the lookup argument
+     * (vanishing_poly::check_lookup_constraints).  LookupGate: slot i = (looking_inp 2i, looking_out 2i+1), routed/2 slots;
+     * LookupTableGate: slot i = (looked_inp 3i, looked_out 3i+1, multiplicity 3i+2), routed/3 slots. */
+    ORC_GATE_LOOKUP = 19,
+    ORC_GATE_LOOKUP_TABLE = 20
 };
 
 typedef struct {
@@ -71,6 +76,19 @@ typedef struct {
     const orc_gate* gates;
     const uint64_t* k_is;          /* num_routed_wires coset shifts */
     uint64_t circuit_digest[4];
+    /* ---- lookup tables (CircuitBuilder::add_all_lookups; CommonCircuitData::luts, ProverOnlyCircuitData::lookup_rows) ----
+     * num_luts == 0: no lookup argument, everything below is ignored and the proof is what it was without these fields.
+     * With tables the constants matrix holds, between the gate selectors and the gate constants, the 4 + num_luts lookup
+     * selector columns (selectors::selectors_lookup: TransSre, TransLdc, InitSre, LastLdc; selector_ends_lookups: one per
+     * table), the Zs commitment carries num_challenges * (1 + S) more columns (RE and the S = ceil(routed/2 / (qdf-1))
+     * partial sums of every challenge) after the partial products, and 2 * num_challenges more challenges are drawn. */
+    uint32_t num_luts;
+    uint32_t pad_;
+    const uint32_t* lut_sizes;       /* num_luts: entries per table */
+    const uint16_t* lut_pairs;       /* the tables' (input, output) pairs, table after table, 2 u16 per entry */
+    const uint32_t* lookup_rows;     /* 3 per table: last_lu_row, last_lut_row, first_lut_row (LookupWire) */
+    const uint32_t* lut_num_lookups; /* num_luts: lookups made into each table (lut_to_lookups[i].len()); the rest of the
+                                        last LookupGate row is padded with the table's first entry by the prover */
 } orc_circuit_desc;
 
 typedef struct orc_circuit orc_circuit;
@@ -83,6 +101,12 @@ orc_circuit* orc_circuit_build(const orc_circuit_desc* desc, const uint64_t* con
 void orc_circuit_free(orc_circuit* c);
 void orc_circuit_digest(const orc_circuit* c, uint64_t out[4]);
 void orc_circuit_constants_sigmas_cap(const orc_circuit* c, uint64_t* cap_out);
+
+/* prover::set_lookup_wires on a host witness (num_wires x n column-major, in place): the multiplicity wires of every
+ * LookupTableGate row and the padding slots of each table's last LookupGate row.  orc_prove applies it to its own copy of
+ * the witness, as prove_with_partition_witness does to the PartitionWitness it is handed.  0 = ok, -1 = a looked-up input
+ * is not in its table. */
+int orc_set_lookup_wires(const orc_circuit* c, uint64_t* wires);
 
 /* upper bound of the serialized proof size in bytes */
 size_t orc_proof_max_bytes(const orc_circuit* c);
@@ -103,8 +127,9 @@ typedef struct {
     uint64_t pow_witness;
     uint32_t n_fri_rounds;
     uint64_t query_indices[128];
+    uint64_t deltas[16];           /* lookup challenges, 4 per challenge round (A, B, alpha, delta); zero without tables */
     /* optional dumps (caller-allocated or NULL) */
-    uint64_t* zs_partial_values;   /* (num_challenges*(1+num_partial_products)) x n column-major */
+    uint64_t* zs_partial_values;   /* (num_challenges*(1+num_partial_products) + num_challenges*(1+S) lookup columns) x n column-major */
     uint64_t* quotient_chunk_coeffs; /* (num_challenges*quotient_degree_factor) x n column-major */
     uint64_t* fri_final_values;    /* L ext values (2 words each), natural LDE order */
 } orc_trace;

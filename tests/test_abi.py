@@ -23,7 +23,7 @@ def test_header_symbols_exported(nlx):
         assert hasattr(dll, name), "libnlx.so does not export %s" % name
     synth = ctypes.CDLL(os.path.join(ROOT, "near-light-client_amd", "libnlx_synth.so"))
     synth_names = _declared_symbols("nlx_synth.h")
-    assert len(synth_names) == 4 and all(n.startswith("nlx_synth_") for n in synth_names)
+    assert len(synth_names) == 5 and all(n.startswith("nlx_synth_") for n in synth_names)
     for name in synth_names:
         assert hasattr(synth, name), "libnlx_synth.so does not export %s" % name
         assert not hasattr(dll, name), "the product library still carries the workload generator (%s)" % name
