@@ -58,7 +58,7 @@ int32_t fri_prove(nlx_ctx* ctx, const FriProveArgs& a, Challenger& ch, Writer& w
             ap = gl::mul(ap, al);
         }
         ap = gl::Ext{1, 0};
-        uint32_t nz_total = 0;
+        uint32_t nz_total = a.tail_cols;
         for (uint32_t o = 0; o < NO; o++) nz_total += a.nz[o];
         for (uint32_t i = 0; i < nz_total; i++) {
             c1 = gl::add(c1, gl::mul(ap, gl::Ext{a.open1[2 * (size_t)i], a.open1[2 * (size_t)i + 1]}));
@@ -66,7 +66,20 @@ int32_t fri_prove(nlx_ctx* ctx, const FriProveArgs& a, Challenger& ch, Writer& w
         }
         FriCombineParams fp{};
         for (uint32_t o = 0; o < NO; o++) { fp.tables[o] = oracles[o]->lde; fp.n_cols[o] = oracles[o]->n_cols; }
-        for (uint32_t o = 0, off = 0; o < NO; o++) { fp.nz[o] = a.nz[o]; fp.nz_off[o] = off; off += a.nz[o]; }
+        uint32_t nz_off = 0;
+        for (uint32_t o = 0; o < NO; o++) { fp.nz[o] = a.nz[o]; fp.nz_off[o] = nz_off; nz_off += a.nz[o]; }
+        if (a.tail_cols) {
+            // the trailing column group: cut off its oracle's view, listed last in both batches
+            if (a.tail_oracle >= NO) return ctx->fail(NLX_E_INVAL, "FRI: bad trailing column group");
+            const nlx_commit* to = oracles[a.tail_oracle];
+            if (a.tail_cols > to->n_cols || a.nz[a.tail_oracle] > to->n_cols - a.tail_cols)
+                return ctx->fail(NLX_E_INVAL, "FRI: bad trailing column group");
+            fp.n_cols[a.tail_oracle] = to->n_cols - a.tail_cols;
+            fp.tables[FRI_VIEWS - 1] = to->lde + (size_t)(to->n_cols - a.tail_cols) * L;
+            fp.n_cols[FRI_VIEWS - 1] = a.tail_cols;
+            fp.nz[FRI_VIEWS - 1] = a.tail_cols;
+            fp.nz_off[FRI_VIEWS - 1] = nz_off;
+        }
         fp.alpha_pows = d_fri_alpha_pows;
         fp.coset_base = a.d_coset_base;
         fp.w_n_table = ctx->tables.fwd[log_n];

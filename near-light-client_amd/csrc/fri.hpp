@@ -3,6 +3,7 @@
 // (DESIGN.md §FRI).  The FRI instance has the shape both callers need:
 //   batch 0: every column of every oracle, in oracle order, opened at zeta
 //   batch 1: the first nz[o] columns of every oracle o (in oracle order), opened at g * zeta
+// (+ an optional trailing column group of one oracle that closes both batches: FriProveArgs::tail_cols)
 #pragma once
 #include <functional>
 #include <vector>
@@ -15,6 +16,10 @@ struct FriProveArgs {
     const nlx_commit* oracles[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t n_oracles = 0;
     uint32_t nz[4] = {0, 0, 0, 0};  // columns of each oracle that are also opened at g * zeta
+    // plonky2 with lookup tables (CommonCircuitData::fri_all_polys / fri_next_batch_polys): the last tail_cols columns of
+    // oracle tail_oracle are listed AFTER every oracle in the zeta batch, and after the nz[] columns in the g * zeta batch
+    // (all of them are opened at both points).  open0 / open1 are in that order.
+    uint32_t tail_oracle = 0, tail_cols = 0;
     uint64_t zeta[2], gzeta[2];
     const uint64_t* open0 = nullptr;  // host: ext openings of batch 0 (2 words each), oracle order
     const uint64_t* open1 = nullptr;  // host: ext openings of batch 1

@@ -102,6 +102,20 @@ struct nlx_circuit {
              *d_chunk_scale = nullptr, *d_wA_inv = nullptr;
     uint64_t* d_l0_scaled = nullptr;
     const uint64_t* d_inv_scale_br = nullptr;  // ctx-owned
+    // lookup tables (all empty / zero without them)
+    uint32_t n_zpp = 0;        // Zs + partial products columns; n_zs = n_zpp + n_lk_polys
+    uint32_t n_lk_sel = 0;     // lookup selector columns (4 + tables), between the gate selectors and the gate constants
+    uint32_t n_lk_polys = 0;   // num_challenges * (1 + S)
+    uint32_t n_lk_terms = 0;   // 4 + tables + 2 S vanishing terms per challenge round
+    LookupShape lk{};
+    std::vector<uint32_t> lut_sizes, lut_offsets, lookup_rows, lut_num_lookups;
+    std::vector<uint16_t> lut_pairs;
+    std::vector<LookupTableDev> h_tabs;
+    LookupTableDev* d_tabs = nullptr;
+    uint32_t* d_lut_pairs = nullptr;  // all tables, input | output << 16
+    int32_t* d_idx_of = nullptr;      // [tables][65536]
+    uint32_t* d_mult = nullptr;       // multiplicity counters of all tables, then the error word
+    size_t mult_words = 0;
     // stage timing
     hipEvent_t ev[NLX_MAX_STAGES + 1]{};
     const char* stage_names[NLX_MAX_STAGES]{};
@@ -168,6 +182,22 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
         if (gt.kind == NLX_GATE_BASE_SUM && 1 + gt.param1 > d.num_wires) return ctx->fail(NLX_E_INVAL, "BaseSumGate too wide");
         if (gt.kind == NLX_GATE_CONSTANT && gt.param0 > d.num_constants) return ctx->fail(NLX_E_INVAL, "ConstantGate too wide");
     }
+    if (d.num_luts) {
+        // CommonCircuitData::luts + ProverOnlyCircuitData::lookup_rows: shapes as CircuitBuilder::add_all_lookups lays them out
+        if (d.num_luts > 16) return ctx->fail(NLX_E_RANGE, "at most 16 lookup tables");
+        if (!d.lut_sizes || !d.lut_pairs || !d.lookup_rows || !d.lut_num_lookups) return ctx->fail(NLX_E_INVAL, "NULL lookup table array");
+        const uint32_t n_lu = d.num_routed_wires / 2, n_lut = d.num_routed_wires / 3;
+        if (n_lut < 1 || d.quotient_degree_factor < 2) return ctx->fail(NLX_E_INVAL, "too few routed wires for the lookup gates");
+        for (uint32_t t = 0; t < d.num_luts; t++) {
+            const uint32_t len = d.lut_sizes[t], lookups = d.lut_num_lookups[t];
+            const uint32_t last_lu = d.lookup_rows[3 * t], last_lut = d.lookup_rows[3 * t + 1], first_lut = d.lookup_rows[3 * t + 2];
+            if (len < 1 || len > 65536 || lookups < 1) return ctx->fail(NLX_E_RANGE, "table %u: 1 .. 65536 entries and at least one lookup", t);
+            if (!(last_lu < last_lut && last_lut <= first_lut) || (uint64_t)first_lut + 1 >= ((uint64_t)1 << d.degree_bits))
+                return ctx->fail(NLX_E_INVAL, "table %u: lookup rows out of order or past the circuit", t);
+            if (last_lut - last_lu != (lookups + n_lu - 1) / n_lu || first_lut - last_lut + 1 != (len + n_lut - 1) / n_lut)
+                return ctx->fail(NLX_E_INVAL, "table %u: row counts do not match its lookups / entries", t);
+        }
+    }
     (void)hipSetDevice(ctx->device);
     nlx_circuit* c = new (std::nothrow) nlx_circuit();
     if (!c) return ctx->fail(NLX_E_NOMEM, "host allocation failed");
@@ -178,9 +208,30 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
     c->k_is.assign(d.k_is, d.k_is + d.num_routed_wires);
     c->d.gates = c->gates.data();
     c->d.k_is = c->k_is.data();
-    c->n_consts_all = d.num_selectors + d.num_constants;
+    if (d.num_luts) {
+        const uint32_t T = d.num_luts;
+        c->lk.num_luts = T;
+        c->lk.n_lu_slots = d.num_routed_wires / 2;
+        c->lk.n_lut_slots = d.num_routed_wires / 3;
+        c->lk.lu_degree = d.quotient_degree_factor - 1;
+        c->lk.n_sldc = (c->lk.n_lu_slots + c->lk.lu_degree - 1) / c->lk.lu_degree;
+        c->lk.lut_degree = (c->lk.n_lut_slots + c->lk.n_sldc - 1) / c->lk.n_sldc;
+        c->n_lk_sel = 4 + T;
+        c->n_lk_polys = d.num_challenges * (1 + c->lk.n_sldc);
+        c->n_lk_terms = 4 + T + 2 * c->lk.n_sldc;
+        c->lut_sizes.assign(d.lut_sizes, d.lut_sizes + T);
+        c->lut_num_lookups.assign(d.lut_num_lookups, d.lut_num_lookups + T);
+        c->lookup_rows.assign(d.lookup_rows, d.lookup_rows + 3 * T);
+        c->lut_offsets.assign(T + 1, 0);
+        for (uint32_t t = 0; t < T; t++) c->lut_offsets[t + 1] = c->lut_offsets[t] + c->lut_sizes[t];
+        c->lut_pairs.assign(d.lut_pairs, d.lut_pairs + 2 * (size_t)c->lut_offsets[T]);
+        c->d.lut_sizes = c->lut_sizes.data(); c->d.lut_num_lookups = c->lut_num_lookups.data();
+        c->d.lookup_rows = c->lookup_rows.data(); c->d.lut_pairs = c->lut_pairs.data();
+    }
+    c->n_consts_all = d.num_selectors + c->n_lk_sel + d.num_constants;
     c->n_cs = c->n_consts_all + d.num_routed_wires;
-    c->n_zs = d.num_challenges * (1 + d.num_partial_products);
+    c->n_zpp = d.num_challenges * (1 + d.num_partial_products);
+    c->n_zs = c->n_zpp + c->n_lk_polys;
     c->n_q = d.num_challenges * d.quotient_degree_factor;
     c->n_fri_rounds = fri_num_rounds(d);
     const size_t n = c->n(), L = c->L();
@@ -247,6 +298,39 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
         c->d_chunk_scale = c->d_wR_inv + R;
         c->d_wA_inv = c->d_chunk_scale + R;
         launch_l0_table(ctx->stream, c->d_l0_scaled, log_n, d.rate_bits, c->d_coset_base, ctx->tables.fwd[log_n]);
+    }
+    if (d.num_luts) {
+        // the tables on the device: packed pairs, the input -> index map of set_lookup_wires (HashMap collect: the last entry
+        // with an input wins), multiplicity counters
+        const uint32_t T = d.num_luts, total = c->lut_offsets[T];
+        std::vector<uint32_t> packed(total);
+        std::vector<int32_t> idx_of((size_t)T << 16, -1);
+        for (uint32_t t = 0; t < T; t++)
+            for (uint32_t i = 0; i < c->lut_sizes[t]; i++) {
+                const uint16_t* pr = &c->lut_pairs[2 * (size_t)(c->lut_offsets[t] + i)];
+                packed[c->lut_offsets[t] + i] = (uint32_t)pr[0] | ((uint32_t)pr[1] << 16);
+                idx_of[((size_t)t << 16) + pr[0]] = (int32_t)i;
+            }
+        c->mult_words = total;
+        c->d_lut_pairs = (uint32_t*)ctx->alloc((size_t)total * 4);
+        c->d_idx_of = (int32_t*)ctx->alloc(idx_of.size() * 4);
+        c->d_mult = (uint32_t*)ctx->alloc(((size_t)total + 1) * 4);
+        c->d_tabs = (LookupTableDev*)ctx->alloc(sizeof(LookupTableDev) * T);
+        if (!c->d_lut_pairs || !c->d_idx_of || !c->d_mult || !c->d_tabs) return fail(NLX_E_NOMEM);
+        c->h_tabs.resize(T);
+        for (uint32_t t = 0; t < T; t++) {
+            LookupTableDev& lt = c->h_tabs[t];
+            lt.len = c->lut_sizes[t]; lt.lookups = c->lut_num_lookups[t];
+            lt.last_lu = c->lookup_rows[3 * t]; lt.last_lut = c->lookup_rows[3 * t + 1]; lt.first_lut = c->lookup_rows[3 * t + 2];
+            lt.pad_ = 0;
+            lt.pairs = c->d_lut_pairs + c->lut_offsets[t];
+            lt.idx_of = c->d_idx_of + ((size_t)t << 16);
+            lt.mult = c->d_mult + c->lut_offsets[t];
+        }
+        hipError_t e = hipMemcpy(c->d_lut_pairs, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->d_idx_of, idx_of.data(), idx_of.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->d_tabs, c->h_tabs.data(), sizeof(LookupTableDev) * T, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(ctx->hip_fail(e, "hipMemcpy(lookup tables)"));
     }
     {
         // k_quotient's work split: items = every gate + the permutation argument of each challenge; longest item first into
@@ -330,6 +414,10 @@ void nlx_circuit_destroy(nlx_circuit* c) NLX_TRY {
     ctx->release(c->d_work);
     ctx->release(c->d_small);
     ctx->release(c->d_l0_scaled);
+    ctx->release(c->d_lut_pairs);
+    ctx->release(c->d_idx_of);
+    ctx->release(c->d_mult);
+    ctx->release(c->d_tabs);
     for (int i = 0; i <= NLX_MAX_STAGES; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     delete c;
@@ -352,7 +440,7 @@ size_t nlx_proof_max_bytes(const nlx_circuit* c) NLX_TRY {
     const nlx_circuit_desc& d = c->d;
     const size_t capb = (size_t)32 << d.cap_height;
     const unsigned log_L = d.degree_bits + d.rate_bits;
-    size_t bytes = 3 * capb + 16 * (size_t)(c->n_cs + d.num_wires + c->n_zs + d.num_challenges + c->n_q) + c->n_fri_rounds * capb;
+    size_t bytes = 3 * capb + 16 * (size_t)(c->n_cs + d.num_wires + c->n_zs + d.num_challenges + c->n_lk_polys + c->n_q) + c->n_fri_rounds * capb;
     size_t per_query = 0;
     const uint32_t cols[4] = {c->n_cs, d.num_wires, c->n_zs, c->n_q};
     for (int o = 0; o < 4; o++) per_query += cols[o] * 8 + 1 + 32 * (size_t)(log_L - d.cap_height);
@@ -406,8 +494,10 @@ namespace {
 // a8: Z and partial-product polynomials from the wires' subgroup values (device), committed.
 // Temporaries are handed to `defer` (released by the caller after it has synchronised) or, without one,
 // released here after a stream synchronisation.
+// With lookup tables the same commitment carries, after them, every challenge round's RE and partial-sum polynomials
+// (compute_all_lookup_polys); d_deltas = the rounds' (A, B, alpha, delta) on the device.
 int32_t zs_stage(nlx_circuit* c, const uint64_t* d_wire_values, const uint64_t betas[2], const uint64_t gammas[2],
-                 nlx_commit** cz, std::vector<void*>* defer) {
+                 const uint64_t* d_deltas, nlx_commit** cz, std::vector<void*>* defer) {
     nlx_ctx* ctx = c->ctx;
     const nlx_circuit_desc& d = c->d;
     const unsigned log_n = d.degree_bits;
@@ -428,6 +518,9 @@ int32_t zs_stage(nlx_circuit* c, const uint64_t* d_wire_values, const uint64_t b
         zp.log_n = log_n; zp.routed = d.num_routed_wires; zp.chunk = d.quotient_degree_factor; zp.nc = d.num_challenges;
         zp.npp = d.num_partial_products;
         launch_zs(ctx->stream, zp, d_zs_scratch);
+        if (c->n_lk_polys)
+            launch_lookup_polys(ctx->stream, c->lk, c->d_tabs, c->h_tabs.data(), d_wire_values, n, d.num_challenges, d_deltas,
+                                d_zs + (size_t)c->n_zpp * n);
         rc = commit_build(ctx, d_zs, n, CommitInput::ValuesNatural, c->n_zs, log_n, d.rate_bits, d.cap_height, cz);
     }
     // commit_build only enqueues: the inputs must outlive the stream work
@@ -444,7 +537,8 @@ int32_t zs_stage(nlx_circuit* c, const uint64_t* d_wire_values, const uint64_t b
 
 // a9: quotient polynomials (compute_quotient_polys) from the three LDE tables, committed from coefficients.
 int32_t quotient_stage(nlx_circuit* c, const nlx_commit* cw, const nlx_commit* cz, const uint64_t betas[2],
-                       const uint64_t gammas[2], const uint64_t alphas[2], const uint64_t pih[4], nlx_commit** cq,
+                       const uint64_t gammas[2], const uint64_t alphas[2], const uint64_t pih[4],
+                       const uint64_t* d_deltas, const uint64_t* d_lut_polys, nlx_commit** cq,
                        const std::function<void(const char*)>& stage, std::vector<void*>* defer) {
     nlx_ctx* ctx = c->ctx;
     const nlx_circuit_desc& d = c->d;
@@ -452,7 +546,8 @@ int32_t quotient_stage(nlx_circuit* c, const nlx_commit* cw, const nlx_commit* c
     const unsigned log_n = d.degree_bits;
     const size_t n = c->n(), L = c->L();
     const uint32_t nc = d.num_challenges, npp = d.num_partial_products;
-    c->n_terms = nc + nc * (npp + 1) + c->max_gate_constraints;  // one alpha power per vanishing term (GateAcc reads ap[T0 + k])
+    // one alpha power per vanishing term (GateAcc reads ap[T0 + k]): Z(1) terms, permutation terms, lookup terms, gate constraints
+    c->n_terms = nc + nc * (npp + 1) + nc * c->n_lk_terms + c->max_gate_constraints;
     uint64_t* d_alpha_pows = (uint64_t*)ctx->alloc((size_t)2 * c->n_terms * 8);
     uint64_t* d_qvals = (uint64_t*)ctx->alloc((size_t)nc * L * 8);
     uint64_t* d_qchunks = (uint64_t*)ctx->alloc((size_t)nc * L * 8);
@@ -472,6 +567,21 @@ int32_t quotient_stage(nlx_circuit* c, const nlx_commit* cw, const nlx_commit* c
         qp.num_wires = d.num_wires; qp.work = c->d_work; qp.work_stride = c->work_stride;
         qp.log_n = log_n; qp.rate_bits = d.rate_bits; qp.n_gates = d.num_gates; qp.n_selectors = d.num_selectors;
         qp.n_consts_all = c->n_consts_all; qp.routed = d.num_routed_wires; qp.chunk = d.quotient_degree_factor; qp.nc = nc; qp.npp = npp;
+        qp.gate_const0 = d.num_selectors + c->n_lk_sel;
+        qp.n_lk_terms = c->n_lk_terms;
+        if (c->n_lk_terms) {
+            // check_lookup_constraints_batch: the lookup terms' share of both alpha sums goes into d_qvals first, k_quotient adds it
+            LookupTermsParams lp{};
+            lp.cs = c->cs->lde; lp.wires = cw->lde; lp.zs = cz->lde;
+            lp.deltas = d_deltas; lp.lut_polys = d_lut_polys; lp.alpha_pows = d_alpha_pows; lp.out = d_qvals;
+            lp.alpha_stride = c->n_terms; lp.t_lk = nc + nc * (npp + 1);
+            lp.log_n = log_n; lp.rate_bits = d.rate_bits; lp.nc = nc; lp.sel0 = d.num_selectors; lp.lk0 = c->n_zpp;
+            lp.n_lk_terms = c->n_lk_terms; lp.s = c->lk;
+            ctx->begin_kernel("lookup_terms", 8.0 * L * (c->n_lk_sel + d.num_routed_wires + 2.0 * c->n_lk_polys + nc));
+            launch_lookup_terms(st, lp);
+            ctx->end_kernel();
+            qp.accumulate = 1;
+        }
         ctx->begin_kernel("quotient", 8.0 * L * (c->n_cs + d.num_wires + c->n_zs + nc) + 8.0 * L * nc);
         launch_quotient(st, qp);
         ctx->end_kernel();
@@ -545,8 +655,18 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
         stage("commit_wires");
         Staged sw(ctx, wires, (size_t)d.num_wires * n * 8, true, false);
         CHECK(sw.status);
+        // prover::set_lookup_wires, the first thing prove_with_partition_witness does to the witness it is handed: multiplicity
+        // wires and padding slots, on the device copy (a device witness is written in place, as upstream's PartitionWitness is)
+        if (d.num_luts)
+            launch_set_lookup_wires(st, c->lk, c->d_tabs, c->h_tabs.data(), sw.as<uint64_t>(), n, c->d_mult, c->mult_words,
+                                    c->d_mult + c->mult_words);
         CHECK(commit_build(ctx, sw.as<uint64_t>(), n, CommitInput::ValuesNatural, d.num_wires, log_n, d.rate_bits, cap_h, &cw));
         CHECK(fetch(ctx, cap.data(), cw->cap, capw * 8));
+        if (d.num_luts) {
+            uint32_t bad = 0;
+            CHECK(fetch(ctx, &bad, c->d_mult + c->mult_words, 4));
+            if (bad) { rc = ctx->fail(NLX_E_INVAL, "a looked-up input is not in its table (set_lookup_wires)"); goto done; }
+        }
         w.u64s(cap.data(), capw);
         ch.observe(d.circuit_digest, 4);
         ch.observe(pih, 4);
@@ -554,10 +674,37 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
         uint64_t betas[2] = {0, 0}, gammas[2] = {0, 0}, alphas[2] = {0, 0};
         for (uint32_t i = 0; i < nc; i++) betas[i] = ch.challenge();
         for (uint32_t i = 0; i < nc; i++) gammas[i] = ch.challenge();
+        // lookup challenges: deltas = betas ++ gammas ++ 2 nc more, NUM_COINS_LOOKUP = 4 per round (A, B, alpha, delta)
+        uint64_t deltas[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t* d_deltas = nullptr;   // deltas[4 nc] | lut_polys[nc tables]
+        if (d.num_luts) {
+            for (uint32_t i = 0; i < nc; i++) { deltas[i] = betas[i]; deltas[nc + i] = gammas[i]; }
+            for (uint32_t i = 0; i < 2 * nc; i++) deltas[2 * nc + i] = ch.challenge();
+            d_deltas = dalloc((size_t)(8 + 2 * 16) * 8);
+            CHECK_ALLOC(d_deltas);
+            HIPCHK(hipMemcpyAsync(d_deltas, deltas, sizeof deltas, hipMemcpyHostToDevice, st));
+        }
 
         // ---- 4. partial products and Z ----
         stage("zs_partial_products");
-        CHECK(zs_stage(c, sw.as<uint64_t>(), betas, gammas, &cz, &scratch));
+        CHECK(zs_stage(c, sw.as<uint64_t>(), betas, gammas, d_deltas, &cz, &scratch));
+        if (d.num_luts) {
+            // vanishing_poly::get_lut_poly per (round, table), on the host while the device builds the Zs commitment: the pairs
+            // (inp + B out) as coefficients in delta, first entry highest, zero-padded to whole table rows
+            uint64_t lut_polys[2 * 16];
+            for (uint32_t ci = 0; ci < nc; ci++)
+                for (uint32_t t = 0; t < d.num_luts; t++) {
+                    const uint32_t len = c->lut_sizes[t], slots = c->lk.n_lut_slots;
+                    const uint32_t degree = slots * ((len + slots - 1) / slots);
+                    const uint16_t* pr = &c->lut_pairs[2 * (size_t)c->lut_offsets[t]];
+                    const uint64_t B = deltas[4 * ci + 1], dl = deltas[4 * ci + 3];
+                    uint64_t acc = 0;
+                    for (uint32_t i = 0; i < len; i++) acc = gl::add(gl::mul(acc, dl), gl::add((uint64_t)pr[2 * i], gl::mul(B, (uint64_t)pr[2 * i + 1])));
+                    acc = gl::mul(acc, gl::pow(dl, degree - len));
+                    lut_polys[ci * d.num_luts + t] = acc;
+                }
+            HIPCHK(hipMemcpyAsync(d_deltas + 8, lut_polys, sizeof(uint64_t) * nc * d.num_luts, hipMemcpyHostToDevice, st));
+        }
         CHECK(fetch(ctx, cap.data(), cz->cap, capw * 8));
         w.u64s(cap.data(), capw);
         ch.observe(cap.data(), capw);
@@ -565,7 +712,7 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
 
         // ---- 5. quotient ----
         stage("quotient_eval");
-        CHECK(quotient_stage(c, cw, cz, betas, gammas, alphas, pih, &cq, stage, &scratch));
+        CHECK(quotient_stage(c, cw, cz, betas, gammas, alphas, pih, d_deltas, d_deltas ? d_deltas + 8 : nullptr, &cq, stage, &scratch));
         CHECK(fetch(ctx, cap.data(), cq->cap, capw * 8));
         w.u64s(cap.data(), capw);
         ch.observe(cap.data(), capw);
@@ -582,7 +729,8 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
         const nlx_commit* oracles[4] = {c->cs, cw, cz, cq};
         const uint32_t n_open = c->n_cs + d.num_wires + c->n_zs + c->n_q;
         uint64_t* d_points = dalloc(2048);
-        uint64_t* d_open = dalloc((size_t)(n_open + nc) * 16);
+        const uint32_t nlk = c->n_lk_polys, n_next = nc + nlk;
+        uint64_t* d_open = dalloc((size_t)(n_open + n_next) * 16);
         uint64_t* d_eval_scratch = dalloc(eval_scratch_words(d.num_wires > c->n_cs ? d.num_wires : c->n_cs, log_n) * 8);
         CHECK_ALLOC(d_points && d_open && d_eval_scratch);
         {
@@ -604,26 +752,40 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
             }
             launch_eval_br(st, cz->coeffs_br, n, nc, log_n, d_points + 2, d_open + 2 * (size_t)n_open, d_eval_scratch,
                            d_points + 4 + 64);
+            if (nlk)  // lookup_zs_next: the lookup polynomials (columns n_zpp.. of the Zs commitment) at g zeta
+                launch_eval_br(st, cz->coeffs_br + (size_t)c->n_zpp * n, n, nlk, log_n, d_points + 2,
+                               d_open + 2 * (size_t)(n_open + nc), d_eval_scratch, d_points + 4 + 64);
             HIPCHK(hipStreamSynchronize(st));
         }
-        std::vector<uint64_t> open((size_t)(n_open + nc) * 2);
+        std::vector<uint64_t> open((size_t)(n_open + n_next) * 2);
         CHECK(fetch(ctx, open.data(), d_open, open.size() * 8));
+        if (nlk) {
+            // CommonCircuitData::fri_all_polys lists the lookup polynomials LAST in the zeta batch (after the quotient chunks):
+            // move their openings from the middle (commitment order) to the end, then everything below reads FRI order
+            uint64_t* zs0 = open.data() + 2 * (size_t)(c->n_cs + d.num_wires);
+            std::vector<uint64_t> lkv(zs0 + 2 * (size_t)c->n_zpp, zs0 + 2 * (size_t)c->n_zs);
+            memmove(zs0 + 2 * (size_t)c->n_zpp, zs0 + 2 * (size_t)c->n_zs, 2 * (size_t)c->n_q * 8);
+            memcpy(zs0 + 2 * (size_t)(c->n_zpp + c->n_q), lkv.data(), lkv.size() * 8);
+        }
         {
             // OpeningSet wire order: constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys
             const uint64_t* o_cs = open.data();
             const uint64_t* o_w = o_cs + 2 * (size_t)c->n_cs;
             const uint64_t* o_zs = o_w + 2 * (size_t)d.num_wires;
             const uint64_t* o_pp = o_zs + 2 * (size_t)nc;
-            const uint64_t* o_q = o_zs + 2 * (size_t)c->n_zs;
+            const uint64_t* o_q = o_zs + 2 * (size_t)c->n_zpp;
+            const uint64_t* o_lk = o_q + 2 * (size_t)c->n_q;
             const uint64_t* o_next = open.data() + 2 * (size_t)n_open;
             w.u64s(o_cs, 2 * (size_t)c->n_cs);
             w.u64s(o_w, 2 * (size_t)d.num_wires);
             w.u64s(o_zs, 2 * (size_t)nc);
             w.u64s(o_next, 2 * (size_t)nc);
+            w.u64s(o_lk, 2 * (size_t)nlk);                    // lookup_zs, lookup_zs_next (read_opening_set order)
+            w.u64s(o_next + 2 * (size_t)nc, 2 * (size_t)nlk);
             w.u64s(o_pp, 2 * (size_t)nc * npp);
             w.u64s(o_q, 2 * (size_t)c->n_q);
             ch.observe(open.data(), 2 * (size_t)n_open);
-            ch.observe(o_next, 2 * (size_t)nc);
+            ch.observe(o_next, 2 * (size_t)n_next);
         }
 
         // ---- 7. FRI ----
@@ -632,6 +794,8 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
             for (int o = 0; o < 4; o++) fa.oracles[o] = oracles[o];
             fa.n_oracles = 4;
             fa.nz[2] = nc;  // plonk_zs_next: the first nc columns of the Zs / partial-products oracle
+            fa.tail_oracle = 2;  // the lookup polynomials: its last nlk columns, a group of their own at the end of both batches
+            fa.tail_cols = nlk;
             for (int i = 0; i < 2; i++) { fa.zeta[i] = zeta[i]; fa.gzeta[i] = gzeta[i]; }
             fa.open0 = open.data();
             fa.open1 = open.data() + 2 * (size_t)n_open;
@@ -709,9 +873,10 @@ int32_t nlx_partial_products_and_zs(nlx_circuit* c, const uint64_t* wires, const
     if (!wires || !betas || !gammas || !zs_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
     *zs_out = nullptr;
     (void)hipSetDevice(ctx->device);
+    if (c->d.num_luts) return ctx->fail(NLX_E_UNSUPPORTED, "circuits with lookup tables are proved through nlx_prove (the stage calls carry no lookup challenges)");
     Staged sw(ctx, wires, (size_t)c->d.num_wires * c->n() * 8, true, false);
     if (sw.status) return sw.status;
-    int32_t rc = zs_stage(c, sw.as<uint64_t>(), betas, gammas, zs_out, nullptr);
+    int32_t rc = zs_stage(c, sw.as<uint64_t>(), betas, gammas, nullptr, zs_out, nullptr);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
     return rc;
@@ -726,6 +891,7 @@ int32_t nlx_quotient_eval(nlx_circuit* c, const nlx_commit* wires, const nlx_com
         return ctx->fail(NLX_E_INVAL, "NULL argument");
     *quotient_out = nullptr;
     const nlx_circuit_desc& d = c->d;
+    if (d.num_luts) return ctx->fail(NLX_E_UNSUPPORTED, "circuits with lookup tables are proved through nlx_prove (the stage calls carry no lookup challenges)");
     if (wires->ctx != ctx || zs->ctx != ctx) return ctx->fail(NLX_E_INVAL, "commitments belong to another context");
     if (wires->n_cols != d.num_wires || zs->n_cols != c->n_zs || wires->log_n != d.degree_bits || zs->log_n != d.degree_bits ||
         wires->rate_bits != d.rate_bits || zs->rate_bits != d.rate_bits)
@@ -733,7 +899,7 @@ int32_t nlx_quotient_eval(nlx_circuit* c, const nlx_commit* wires, const nlx_com
     for (int i = 0; i < 4; i++)
         if (public_inputs_hash[i] >= gl::P) return ctx->fail(NLX_E_RANGE, "public inputs hash is not canonical");
     (void)hipSetDevice(ctx->device);
-    int32_t rc = quotient_stage(c, wires, zs, betas, gammas, alphas, public_inputs_hash, quotient_out, [](const char*) {}, nullptr);
+    int32_t rc = quotient_stage(c, wires, zs, betas, gammas, alphas, public_inputs_hash, nullptr, nullptr, quotient_out, [](const char*) {}, nullptr);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (!rc && e != hipSuccess) rc = ctx->hip_fail(e, "hipStreamSynchronize");
     return rc;

@@ -39,6 +39,10 @@ struct QuotientParams {
     uint64_t betas[2], gammas[2], pih[4];
     uint32_t alpha_stride;
     uint32_t log_n, rate_bits, n_gates, n_selectors, n_consts_all, routed, chunk, nc, npp;
+    uint32_t gate_const0;   // first gate-constant column of cs: n_selectors + the lookup selector columns
+    uint32_t n_lk_terms;    // lookup terms per challenge round (0 without tables): they sit between the permutation terms and
+                            // the gate constraints in the vanishing-term list, so the gates' alpha powers start that much later
+    uint32_t accumulate;    // 1: out[] already holds the lookup terms' share of both sums (launch_lookup_terms); it is added in
     uint32_t num_wires;
     // work split of one tile of 64 points over the kernel's quotient_waves() waves: row w lists wave w's items, terminated by
     // 0xFFFFFFFF; low 16 bits g < n_gates = gate g (bits 16.. = part mask for a gate evaluated in parts: PoseidonGate),
@@ -54,17 +58,53 @@ void launch_l0_table(hipStream_t st, uint64_t* d_out, unsigned log_n, unsigned r
 void launch_quotient_chunks(hipStream_t st, const uint64_t* d_in, uint64_t* d_out, unsigned log_n, unsigned rate_bits,
                             uint32_t nc, const uint64_t* d_w_R_inv_pows, const uint64_t* d_chunk_scale);
 
+// ---- the lookup argument (lookup_arg.hip; plonky2 prover::{set_lookup_wires, compute_lookup_polys},
+// vanishing_poly::check_lookup_constraints) ----
+struct LookupShape {
+    uint32_t num_luts, n_lu_slots, n_lut_slots, lu_degree, lut_degree, n_sldc;
+};
+struct LookupTableDev {       // one table, device-resident
+    uint32_t len, lookups, last_lu, last_lut, first_lut, pad_;
+    const uint32_t* pairs;    // len entries: input | output << 16
+    const int32_t* idx_of;    // 65 536 entries: table index of an input value, -1 = not in the table
+    uint32_t* mult;           // len counters (scratch of set_lookup_wires)
+};
+// set_lookup_wires on the device witness ([num_wires][n] subgroup values, written in place): multiplicity wires of the
+// LookupTableGate rows, padding slots of each table's last LookupGate row.  *d_err (device u32, zeroed here) becomes non-zero
+// when a looked-up input is not in its table.  h_tabs: host copy of d_tabs (launch geometry).
+void launch_set_lookup_wires(hipStream_t st, const LookupShape& s, const LookupTableDev* d_tabs, const LookupTableDev* h_tabs,
+                             uint64_t* d_wires, size_t n, uint32_t* d_mult_all, size_t mult_words, uint32_t* d_err);
+// compute_lookup_polys for every challenge round: d_cols = [nc * (1 + S)][n] (RE, SLDC_0..S-1 per round), zero-filled here;
+// deltas: 4 per round (A, B, alpha, delta)
+void launch_lookup_polys(hipStream_t st, const LookupShape& s, const LookupTableDev* d_tabs, const LookupTableDev* h_tabs,
+                         const uint64_t* d_wires, size_t n, uint32_t nc, const uint64_t* d_deltas, uint64_t* d_cols);
+struct LookupTermsParams {
+    const uint64_t* cs;        // constants+sigmas LDE [col][L]; the lookup selectors start at column sel0
+    const uint64_t* wires;     // [col][L]
+    const uint64_t* zs;        // [col][L]; round c's lookup polynomials start at column lk0 + c (1 + S)
+    const uint64_t* deltas;    // device: 4 per round
+    const uint64_t* lut_polys; // device: [nc][num_luts] get_lut_poly values
+    const uint64_t* alpha_pows;  // device: [2][alpha_stride]
+    uint64_t* out;             // [nc][L]: sum over BOTH rounds' lookup terms times alpha_c^(term index)
+    uint32_t alpha_stride, t_lk; // t_lk = index of the first lookup term in the vanishing-term list
+    uint32_t log_n, rate_bits, nc, sel0, lk0, n_lk_terms;
+    LookupShape s;
+};
+void launch_lookup_terms(hipStream_t st, const LookupTermsParams& p);
+
+constexpr int FRI_VIEWS = 5;
 struct FriCombineParams {
-    const uint64_t* tables[4];  // LDE tables in FRI oracle order
-    uint32_t n_cols[4];
+    const uint64_t* tables[FRI_VIEWS];  // LDE column groups in the zeta batch's order: the oracles, then (plonky2 with lookup
+                                        // tables) the trailing columns of one of them as a group of their own
+    uint32_t n_cols[FRI_VIEWS];
     const uint64_t* alpha_pows; // device ext table, sum(n_cols) entries
     const uint64_t* coset_base;
     const uint64_t* w_n_table;
     uint64_t zeta[2], gzeta[2], c0[2], c1[2], alpha_nz[2];
     uint64_t* out;              // L ext values
     uint32_t log_n, rate_bits;
-    uint32_t nz[4];             // the g*zeta batch = first nz[o] columns of every table o, in table order
-    uint32_t nz_off[4];         // index of table o's first g*zeta polynomial in that batch
+    uint32_t nz[FRI_VIEWS];     // the g*zeta batch = first nz[o] columns of every group o, in group order
+    uint32_t nz_off[FRI_VIEWS]; // index of group o's first g*zeta polynomial in that batch
 };
 // scratch: fri_combine_scratch_words(p) words when that is non-zero (small domains of many columns are combined in column
 // slices), else may be null

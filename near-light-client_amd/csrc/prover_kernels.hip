@@ -460,13 +460,13 @@ __device__ __forceinline__ void eval_gate(const GateDev& gd, const QuotientParam
                                           uint32_t parts) {
     switch (gd.kind) {
         case NLX_GATE_CONSTANT:
-            for (uint32_t i = 0; i < gd.param0; i++) acc.emit(gl::sub(CC(p.n_selectors + i), W(i)));
+            for (uint32_t i = 0; i < gd.param0; i++) acc.emit(gl::sub(CC(p.gate_const0 + i), W(i)));
             break;
         case NLX_GATE_PUBLIC_INPUT:
             for (uint32_t i = 0; i < 4; i++) acc.emit(gl::sub(W(i), p.pih[i]));
             break;
         case NLX_GATE_ARITHMETIC: {
-            const uint64_t c0 = CC(p.n_selectors), c1 = CC(p.n_selectors + 1);
+            const uint64_t c0 = CC(p.gate_const0), c1 = CC(p.gate_const0 + 1);
             for (uint32_t i = 0; i < gd.param0; i++) {
                 const uint64_t m0 = W(4 * i), m1 = W(4 * i + 1), ad = W(4 * i + 2), o = W(4 * i + 3);
                 acc.emit(gl::sub(o, gl::add(gl::mul(gl::mul(m0, m1), c0), gl::mul(ad, c1))));
@@ -490,7 +490,7 @@ __device__ __forceinline__ void eval_gate(const GateDev& gd, const QuotientParam
             gate_poseidon(W, acc, parts);
             break;
         case NLX_GATE_ARITHMETIC_EXT: {
-            const uint64_t c0 = CC(p.n_selectors), c1 = CC(p.n_selectors + 1);
+            const uint64_t c0 = CC(p.gate_const0), c1 = CC(p.gate_const0 + 1);
             for (uint32_t i = 0; i < gd.param0; i++) {
                 const gl::Ext m0{W(8 * i), W(8 * i + 1)}, m1{W(8 * i + 2), W(8 * i + 3)};
                 const gl::Ext pr = gl::mul(m0, m1);
@@ -500,7 +500,7 @@ __device__ __forceinline__ void eval_gate(const GateDev& gd, const QuotientParam
             break;
         }
         case NLX_GATE_MUL_EXT: {
-            const uint64_t c0 = CC(p.n_selectors);
+            const uint64_t c0 = CC(p.gate_const0);
             for (uint32_t i = 0; i < gd.param0; i++) {
                 const gl::Ext m0{W(6 * i), W(6 * i + 1)}, m1{W(6 * i + 2), W(6 * i + 3)};
                 const gl::Ext pr = gl::mul(m0, m1);
@@ -751,7 +751,7 @@ __device__ __forceinline__ void eval_gate(const GateDev& gd, const QuotientParam
                 }
                 acc.emit(gl::sub(stack[0], W(b0 + 1)));
             }
-            for (uint32_t i = 0; i < extra; i++) acc.emit(gl::sub(CC(p.n_selectors + i), W((2 + vec) * copies + i)));
+            for (uint32_t i = 0; i < extra; i++) acc.emit(gl::sub(CC(p.gate_const0 + i), W((2 + vec) * copies + i)));
             break;
         }
         default: break;  // NoopGate
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(64 * QW, NLX_QMINW) void k_quotient(QuotientParams 
     auto CC = [&](uint32_t c) { return lc[c * 64 + lane]; };
 
     const uint32_t nc = p.nc, npp = p.npp;
-    const uint32_t T0 = nc + nc * (npp + 1);
+    const uint32_t T0 = nc + nc * (npp + 1) + nc * p.n_lk_terms;  // first gate constraint's index in the vanishing-term list
     const uint64_t* ap0 = p.alpha_pows;
     const uint64_t* ap1 = p.alpha_pows + p.alpha_stride;
     uint64_t tot0 = 0, tot1 = 0;  // sum over all terms EXCEPT the L_0 terms (divided by Z_H later)
@@ -898,6 +898,10 @@ __global__ __launch_bounds__(64 * QW, NLX_QMINW) void k_quotient(QuotientParams 
     const uint64_t zh_inv = p.zh_inv[pe.r];
     const uint64_t l0s = p.l0_scaled[pe.pos];
     if (!pe.live) return;
+    if (p.accumulate) {  // circuits with lookup tables: k_lookup_terms left those terms' share of the sums here
+        tot0 = gl::add(tot0, p.out[pe.pos]);
+        if (nc > 1) tot1 = gl::add(tot1, p.out[L + pe.pos]);
+    }
     p.out[pe.pos] = gl::add(gl::mul(tot0, zh_inv), gl::mul(l0a, l0s));
     if (nc > 1) p.out[L + pe.pos] = gl::add(gl::mul(tot1, zh_inv), gl::mul(l0b, l0s));
 }
@@ -981,7 +985,7 @@ __device__ __forceinline__ void fri_column_sums(const FriCombineParams& p, size_
     only0.reset();
     only1.reset();
     uint32_t first = 0;  // global index of the table's first column
-    for (int o = 0; o < 4; o++) {
+    for (int o = 0; o < FRI_VIEWS; o++) {
         const uint64_t* tab = p.tables[o];
         const uint32_t nco = p.n_cols[o];
         const uint32_t c_lo = lo > first ? lo - first : 0, c_hi = hi > first ? (hi - first < nco ? hi - first : nco) : 0;
@@ -1085,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_fri_combine_finish(FriCombineParams p, 
 uint32_t fri_combine_slices(const FriCombineParams& p) {
     const size_t L = (size_t)1 << (p.log_n + p.rate_bits);
     uint32_t cols = 0;
-    for (int o = 0; o < 4; o++) cols += p.n_cols[o];
+    for (int o = 0; o < FRI_VIEWS; o++) cols += p.n_cols[o];
     if (L >= ((size_t)1 << 15) || cols < 256) return 1;
     uint32_t want = (uint32_t)((((size_t)1 << 17) + L - 1) / L);  // aim for ~2^17 lanes
     const uint32_t max_slices = cols / 64 ? cols / 64 : 1;        // at least 64 columns per slice
@@ -1104,7 +1108,7 @@ void launch_fri_combine(hipStream_t st, const FriCombineParams& p, uint64_t* scr
         return;
     }
     uint32_t cols = 0;
-    for (int o = 0; o < 4; o++) cols += p.n_cols[o];
+    for (int o = 0; o < FRI_VIEWS; o++) cols += p.n_cols[o];
     const uint32_t per_slice = (cols + slices - 1) / slices;
     hipLaunchKernelGGL(k_fri_combine_partial, dim3((unsigned)((L + 255) / 256), slices), dim3(256), 0, st, p, per_slice, scratch);
     hipLaunchKernelGGL(k_fri_combine_finish, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, p, slices, scratch);
