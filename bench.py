@@ -109,6 +109,9 @@ def parse():
     ap.add_argument("--ntt-cols", type=int, default=16)
     ap.add_argument("--ntt-field", default="goldilocks", choices=["goldilocks", "bn254"],
                     help="ntt24 workload: goldilocks (the prover's field) or bn254 (the scalar field of the recursive wrap, row f.4)")
+    ap.add_argument("--lookup-tables", type=int, default=0, help="outer workload: plonky2 lookup tables in the circuit (LookupGate / LookupTableGate rows, 0 = none)")
+    ap.add_argument("--lookup-bits", type=int, default=16, help="outer workload: 2^k (input, output) pairs per table")
+    ap.add_argument("--lookups", type=int, default=100000, help="outer workload: lookups into every table")
     ap.add_argument("--no-extra", action="store_true", help="sync workload: skip the plonky2-only 2^16 figures and the verify128 record")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent proofs in flight per GPU (one context + stream + host thread each); the K "
@@ -201,7 +204,8 @@ def run_outer(args, nlx, torch, rank, world, local, dist):
     """--workload outer: the outer plonky2 proof alone (round 1's default job; --log-n sweeps its size)."""
     import numpy as np
     gate_mix = GATE_MIXES[args.gate_mix]
-    syn = nlx.SyntheticCircuit(args.log_n, seed=1000 + rank, num_public_inputs=64, **gate_mix)
+    lk = dict(num_luts=args.lookup_tables, lut_bits=args.lookup_bits, num_lookups=args.lookups) if args.lookup_tables else {}
+    syn = nlx.SyntheticCircuit(args.log_n, seed=1000 + rank, num_public_inputs=64, **gate_mix, **lk)
     # public inputs = the real SyncCircuit I/O of the reference's fixture main_2.json (BASELINE.json configs[0]/[1]): 32-byte trusted
     # header hash in, 32-byte new head hash out (nearx/src/sync.rs:37,43), one field element per byte
     from importlib import import_module
@@ -248,7 +252,7 @@ def run_outer(args, nlx, torch, rank, world, local, dist):
         raise RuntimeError("nlx_batch_prove failed with %d" % rc)
     assert all(jobs[i].proof_len == jobs[0].proof_len for i in range(args.steps))
     dt = reduce_max(dist, torch, dt)
-    names = ("intt", "lde", "hash_lde_leaves", "merkle_levels", "quotient", "fri_combine")
+    names = ("intt", "lde", "hash_lde_leaves", "merkle_levels", "quotient", "fri_combine") + (("lookup_terms",) if lk else ())
     kstats = {k: [0, 0.0, 0.0] for k in names}
     for c in ctxs:
         for k in names:
@@ -295,6 +299,9 @@ def run_outer(args, nlx, torch, rank, world, local, dist):
                                    "135 wires, rate 8, 28 queries, 16 PoW bits, %d gate kinds), replicas only"
                                    % (args.log_n, syn.num_gates),
                        "log_n": args.log_n, "gate_mix_pct": gate_mix,
+                       "lookup_tables": ("%d table(s) of 2^%d pairs, %d lookups each (rows %s): set_lookup_wires, the lookup "
+                                         "polynomials and the lookup terms of the quotient inside the timed region"
+                                         % (args.lookup_tables, args.lookup_bits, args.lookups, syn.lookup_rows.tolist())) if lk else None,
                        "public_inputs": "64 bytes of real Sync I/O (fixtures/main_2.json): new head hash 0x%s" % sync_out.hex(), "proof_bytes": len(cds[0].prove(wires, pis)),
                        "proofs_in_flight_per_gpu": n_workers, "witness": args.host_witness or "resident in HBM", "parallelism": "replicas x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
