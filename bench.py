@@ -682,7 +682,16 @@ def stark_verifier_rows(st):
         n_rounds = d.n_rounds if d.n_rounds else 1
         oracles = [d.round_cols[r] for r in range(n_rounds)] if d.n_rounds else [d.n_cols]
         oracles.append(d.num_challenges * d.quotient_degree_factor)
-        per_query = sum((c + 7) // 8 if c > 4 else 0 for c in oracles) + len(oracles) * (log_l - d.cap_height)
+        G = d.leaf_group_cols
+
+        def leaf_perms(c):
+            """permutations to hash one opened row: whole-row hash_or_noop, or (grouped leaves) every run of G columns and
+            then the runs' digests"""
+            if G and c > G:
+                k = -(-c // G)
+                return (k - 1) * ((G + 7) // 8) + (c - (k - 1) * G + 7) // 8 + (4 * k + 7) // 8
+            return (c + 7) // 8 if c > 4 else 0
+        per_query = sum(leaf_perms(c) for c in oracles) + len(oracles) * (log_l - d.cap_height)
         bits, fri_rounds = d.degree_bits, 0
         while bits > d.fri_final_poly_bits and bits + d.rate_bits >= d.cap_height + d.fri_arity_bits and bits >= d.fri_arity_bits:
             bits -= d.fri_arity_bits

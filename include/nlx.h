@@ -464,7 +464,14 @@ typedef struct {
     uint32_t n_rounds;                /* 0..3 */
     uint32_t round_cols[3];
     uint32_t round_challenges[3];
-    uint32_t reserved;
+    /* Grouped Merkle leaves.  0 = every leaf is plonky2's hash_or_noop of the whole LDE row (starky's MerkleTree).  G > 0:
+     * a row of more than G columns is hashed as hash_no_pad(hash_no_pad(cols [0, G)) || hash_no_pad(cols [G, 2G)) || ...) -
+     * the tree's bottom level has arity ceil(n_cols / G) over column runs.  The proof's layout does not change (opened rows
+     * and sibling paths), the verifier spends ceil(K / 2) more permutations per opened row; for the prover the K runs of a
+     * leaf are independent work, which a trace of thousands of columns on a few thousand rows needs to fill the GPU
+     * (host rule: stark.py StarkConfig.leaf_group_cols).  Applies to every commitment of the proof
+     * (narrower ones are unaffected) and is part of the statement digest when non-zero.  8 <= G <= 4096. */
+    uint32_t leaf_group_cols;
     /* Round values: round_values[r] (<= 64) field elements the prover sends with round r - totals of bus / accumulator
      * columns that depend on earlier challenges.  They enter the transcript after the round's cap and before its
      * challenges are drawn, travel after the public inputs at the end of the proof, and the program reads them as

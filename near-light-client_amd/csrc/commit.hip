@@ -22,7 +22,7 @@ size_t merkle_digest_words(size_t n_leaves, uint32_t cap_height) {
 }
 
 int32_t commit_build(nlx_ctx* ctx, const uint64_t* d_in, size_t in_stride, CommitInput kind, uint32_t n_cols,
-                     uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, nlx_commit** out) {
+                     uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, nlx_commit** out, uint32_t leaf_group) {
     *out = nullptr;
     if (n_cols == 0 || n_cols > 65535) return ctx->fail(NLX_E_RANGE, "n_cols %u out of range [1, 65535]", n_cols);
     if (log_n + rate_bits > 32) return ctx->fail(NLX_E_RANGE, "log_n + rate_bits > 32");
@@ -44,10 +44,14 @@ int32_t commit_build(nlx_ctx* ctx, const uint64_t* d_in, size_t in_stride, Commi
     c->coeffs_br = (uint64_t*)ctx->alloc((size_t)n_cols * n * 8);
     c->lde = (uint64_t*)ctx->alloc((size_t)n_cols * L * 8);
     c->digests = (uint64_t*)ctx->alloc(merkle_digest_words(L, cap_height) * 8);
-    if (!c->coeffs_br || !c->lde || !c->digests) {
+    const bool grouped = leaf_group && n_cols > leaf_group;
+    const uint32_t n_groups = grouped ? (n_cols + leaf_group - 1) / leaf_group : 0;
+    if (grouped) c->group_digests = (uint64_t*)ctx->alloc((size_t)4 * n_groups * L * 8);
+    if (!c->coeffs_br || !c->lde || !c->digests || (grouped && !c->group_digests)) {
         ctx->release(c->coeffs_br);
         ctx->release(c->lde);
         ctx->release(c->digests);
+        ctx->release(c->group_digests);
         delete c;
         return NLX_E_NOMEM;
     }
@@ -81,9 +85,18 @@ int32_t commit_build(nlx_ctx* ctx, const uint64_t* d_in, size_t in_stride, Commi
     launch_lde_dit(st, ctx->tables, c->coeffs_br, n, c->lde, L, n_cols, log_n, rate_bits, scale);
     ctx->end_kernel();
     // units: Poseidon permutations (hash_or_noop: none for rows of <= 4 elements, else one per 8 absorbed)
-    ctx->begin_kernel("hash_lde_leaves", 8.0 * n_cols * L + 32.0 * L, n_cols <= 4 ? 0.0 : (double)L * ((n_cols + 7) / 8));
-    launch_hash_lde_leaves(st, c->lde, L, n_cols, log_n, rate_bits, c->digests);
-    ctx->end_kernel();
+    if (grouped) {
+        // permutations: every run's ceil(len / 8), then ceil(4 K / 8) per leaf over the runs' digests
+        const uint32_t last = n_cols - (n_groups - 1) * leaf_group;
+        const double perms = (double)L * ((double)(n_groups - 1) * ((leaf_group + 7) / 8) + (last + 7) / 8 + (4 * n_groups + 7) / 8);
+        ctx->begin_kernel("hash_lde_leaves", 8.0 * n_cols * L + 32.0 * L, perms);
+        launch_hash_lde_leaves_grouped(st, c->lde, L, n_cols, leaf_group, log_n, rate_bits, c->group_digests, c->digests);
+        ctx->end_kernel();
+    } else {
+        ctx->begin_kernel("hash_lde_leaves", 8.0 * n_cols * L + 32.0 * L, n_cols <= 4 ? 0.0 : (double)L * ((n_cols + 7) / 8));
+        launch_hash_lde_leaves(st, c->lde, L, n_cols, log_n, rate_bits, c->digests);
+        ctx->end_kernel();
+    }
     ctx->begin_kernel("merkle_levels", 64.0 * L, (double)L - (double)((size_t)1 << cap_height));
     c->cap = launch_merkle_levels(st, c->digests, L, cap_height);
     ctx->end_kernel();
@@ -92,6 +105,7 @@ int32_t commit_build(nlx_ctx* ctx, const uint64_t* d_in, size_t in_stride, Commi
         ctx->release(c->coeffs_br);
         ctx->release(c->lde);
         ctx->release(c->digests);
+        ctx->release(c->group_digests);
         delete c;
         return ctx->hip_fail(e, "commit_build launch");
     }
@@ -303,6 +317,7 @@ void nlx_commit_destroy(nlx_commit* c) NLX_TRY {
     c->ctx->release(c->coeffs_br);
     c->ctx->release(c->lde);
     c->ctx->release(c->digests);
+    c->ctx->release(c->group_digests);
     delete c;
 } NLX_CATCH_VOID(nullptr)
 

@@ -12,6 +12,7 @@ struct nlx_commit {
     uint64_t* lde = nullptr;        // [col][r][k] = p_col(g * w_L^(8k + r)), L = n << rate_bits
     uint64_t* digests = nullptr;    // level-major; level 0 in plonky2 leaf order
     const uint64_t* cap = nullptr;  // inside digests
+    uint64_t* group_digests = nullptr;  // grouped leaves only: the runs' digests, [4 K][L]
     size_t n() const { return (size_t)1 << log_n; }
     size_t L() const { return (size_t)1 << (log_n + rate_bits); }
     unsigned log_L() const { return log_n + rate_bits; }
@@ -23,6 +24,7 @@ size_t merkle_digest_words(size_t n_leaves, uint32_t cap_height);
 enum class CommitInput { ValuesNatural, CoeffsNatural, CoeffsBitrev };
 // d_in: device pointer, [col][n] with column stride in_stride.  Enqueues all work on ctx->stream;
 // no synchronisation.  On success *out owns coeffs_br / lde / digests.
+// leaf_group: 0 = plonky2 leaves (hash_or_noop of the whole LDE row); G > 0 and n_cols > G: grouped leaves (launch.hpp)
 int32_t commit_build(nlx_ctx* ctx, const uint64_t* d_in, size_t in_stride, CommitInput kind, uint32_t n_cols,
-                     uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, nlx_commit** out);
+                     uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, nlx_commit** out, uint32_t leaf_group = 0);
 }  // namespace nlx

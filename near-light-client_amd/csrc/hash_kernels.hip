@@ -189,6 +189,49 @@ __global__ __launch_bounds__(256, 4) void k_hash_lde_leaves(const uint64_t* __re
 void launch_hash_lde_leaves_wide(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols, unsigned log_n,
                                  unsigned rate_bits, uint64_t* d_digests);
 
+// Grouped leaves (STARK commitments of wide short traces, include/nlx.h leaf_group_cols): lane (pos, g = blockIdx.y) hashes
+// the run of columns [g group, (g + 1) group) of LDE row pos - hash_no_pad, whatever the run's length - and writes the
+// digest as four more COLUMNS of a small table laid out like the LDE itself ([4 g + j][pos]).  The leaf digest is then
+// the ordinary leaf hash of that table (launch_hash_lde_leaves: hash_no_pad of the 4 K words of a row, scattered to the
+// row's tree position).  A 4 745-column trace on 2^10 LDE rows is 594 permutations in sequence on each of 1 024 lanes as one
+// leaf per lane; as 38 runs of 128 columns it is 16 permutations on each of 38 912 lanes, then 19 on 1 024 leaves.
+__global__ __launch_bounds__(256, 4) void k_hash_lde_groups(const uint64_t* __restrict__ lde, size_t col_stride, uint32_t n_cols,
+                                                            uint32_t group, unsigned log_L, uint64_t* __restrict__ out) {
+    const size_t pos_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = (pos_raw >> log_L) == 0;   // spare lanes redo the last point (see k_permute_batch), store nothing
+    const size_t L = (size_t)1 << log_L, pos = live ? pos_raw : L - 1;
+    const uint32_t g = blockIdx.y, c0 = g * group, c1 = c0 + group < n_cols ? c0 + group : n_cols;
+    uint64_t s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    const uint64_t* p = lde + pos;
+    uint32_t c = c0;
+    for (; c + 8 <= c1; c += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] = p[(size_t)(c + j) * col_stride];
+        poseidon::permute_loose(s);
+    }
+    if (c < c1) {
+        const uint32_t rem = c1 - c;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if ((uint32_t)j < rem) s[j] = p[(size_t)(c + j) * col_stride];
+        poseidon::permute_loose(s);
+    }
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < 4; j++) out[((size_t)(4 * g + j) << log_L) + pos] = gl::canon(s[j]);
+}
+
+void launch_hash_lde_leaves_grouped(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols, uint32_t group,
+                                    unsigned log_n, unsigned rate_bits, uint64_t* d_group_digests, uint64_t* d_digests) {
+    const size_t rows = (size_t)1 << (log_n + rate_bits);
+    const uint32_t K = (n_cols + group - 1) / group;
+    hipLaunchKernelGGL(k_hash_lde_groups, dim3((unsigned)((rows + 255) / 256), K), dim3(256), 0, st, d_lde, col_stride, n_cols, group,
+                       log_n + rate_bits, d_group_digests);
+    launch_hash_lde_leaves(st, d_group_digests, rows, 4 * K, log_n, rate_bits, d_digests);
+}
+
 void launch_hash_lde_leaves(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols,
                             unsigned log_n, unsigned rate_bits, uint64_t* d_digests) {
     size_t rows = (size_t)1 << (log_n + rate_bits);

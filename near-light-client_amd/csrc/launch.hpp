@@ -15,6 +15,10 @@ const uint64_t* launch_merkle_levels(hipStream_t st, uint64_t* d_digests, size_t
 // the digest of point (r,k) is written at tree position bitrev3(r)*n + bitrev(k).
 void launch_hash_lde_leaves(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols,
                             unsigned log_n, unsigned rate_bits, uint64_t* d_digests);
+// grouped leaves (n_cols > group > 0): leaf = hash_no_pad of the digests of the row's runs of `group` columns;
+// d_group_digests: scratch of 4 * ceil(n_cols / group) columns x L words, alive until the stream has run this
+void launch_hash_lde_leaves_grouped(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols, uint32_t group,
+                                    unsigned log_n, unsigned rate_bits, uint64_t* d_group_digests, uint64_t* d_digests);
 
 // ---- ntt_kernels.hip ----
 struct NttTables {

@@ -315,6 +315,7 @@ static void air_digest_host(const nlx_stark_desc& d, const std::vector<uint64_t>
     for (uint32_t r = 0; r < 3; r++) v.push_back(r < d.n_rounds ? d.round_cols[r] : 0);
     for (uint32_t r = 0; r < 3; r++) v.push_back(r < d.n_rounds ? d.round_challenges[r] : 0);
     for (uint32_t r = 0; r < 3; r++) v.push_back(r < d.n_rounds ? d.round_values[r] : 0);
+    if (d.leaf_group_cols) v.push_back(d.leaf_group_cols);  // only when used: digests of whole-row statements stay what they were
     for (uint64_t w : prog) { v.push_back(w & 0xFFFFFFFFu); v.push_back(w >> 32); }
     for (uint64_t w : periodic) { v.push_back(w & 0xFFFFFFFFu); v.push_back(w >> 32); }
     hash_no_pad_host(v.data(), v.size(), out);
@@ -333,6 +334,7 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
     if (!q || (q & (q - 1)) || q > (1u << d.rate_bits))
         return ctx->fail(NLX_E_INVAL, "quotient_degree_factor must be a power of two <= 2^rate_bits");
     if (d.fri_arity_bits < 2 || d.fri_arity_bits > 4) return ctx->fail(NLX_E_UNSUPPORTED, "fri_arity_bits must be in [2, 4]");
+    if (d.leaf_group_cols && (d.leaf_group_cols < 8 || d.leaf_group_cols > 4096)) return ctx->fail(NLX_E_RANGE, "leaf_group_cols must be 0 or in [8, 4096]");
     if (d.degree_bits < 4 || d.degree_bits < d.fri_arity_bits || d.degree_bits + d.rate_bits > 30)
         return ctx->fail(NLX_E_RANGE, "degree_bits out of range");
     if (d.fri_num_queries > 128 || d.fri_num_queries == 0 || d.cap_height > 6 || d.cap_height > d.degree_bits + d.rate_bits)
@@ -646,7 +648,7 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
             for (uint32_t k = 0; k < n_rv; k++) rv[k] %= gl::P;
             Staged tr(ctx, tr_ptr, (size_t)rcols * n * 8, true, false);
             CHECK(tr.status);
-            CHECK(commit_build(ctx, tr.as<uint64_t>(), n, CommitInput::ValuesNatural, rcols, log_n, d.rate_bits, cap_h, &cr[r]));
+            CHECK(commit_build(ctx, tr.as<uint64_t>(), n, CommitInput::ValuesNatural, rcols, log_n, d.rate_bits, cap_h, &cr[r], d.leaf_group_cols));
             CHECK(fetch(ctx, cap.data(), cr[r]->cap, capw * 8));
             w.u64s(cap.data(), capw);
             ch.observe(cap.data(), capw);
@@ -713,7 +715,7 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
         launch_intt_dif_cosets(st, ctx->tables, d_qvals, nc, log_n, qdb, s->d_q_inv_scale_br);
         launch_quotient_chunks(st, d_qvals, d_qchunks, log_n, qdb, nc, s->d_q_wR_inv, s->d_q_chunk_scale);
         stage("commit_quotient");
-        CHECK(commit_build(ctx, d_qchunks, n, CommitInput::CoeffsBitrev, nq, log_n, d.rate_bits, cap_h, &cq));
+        CHECK(commit_build(ctx, d_qchunks, n, CommitInput::CoeffsBitrev, nq, log_n, d.rate_bits, cap_h, &cq, d.leaf_group_cols));
         CHECK(fetch(ctx, cap.data(), cq->cap, capw * 8));
         w.u64s(cap.data(), capw);
         ch.observe(cap.data(), capw);

@@ -39,7 +39,7 @@ class StarkDesc(ctypes.Structure):
         "n_words")] + [("program", ctypes.POINTER(ctypes.c_uint64)), ("n_periodic", ctypes.c_uint32),
                        ("period_bits", ctypes.c_uint32), ("periodic", ctypes.POINTER(ctypes.c_uint64)),
                        ("n_rounds", ctypes.c_uint32), ("round_cols", ctypes.c_uint32 * 3),
-                       ("round_challenges", ctypes.c_uint32 * 3), ("reserved", ctypes.c_uint32),
+                       ("round_challenges", ctypes.c_uint32 * 3), ("leaf_group_cols", ctypes.c_uint32),
                        ("round_values", ctypes.c_uint32 * 3), ("reserved2", ctypes.c_uint32)]
 
 
@@ -54,10 +54,22 @@ class StarkConfig:
         self.fri_num_queries = 84
         self.fri_arity_bits = 4
         self.fri_final_poly_bits = 5
+        # Merkle leaves over runs of this many columns (nlx_stark_desc.leaf_group_cols); None = by shape, see leaf_group_for
+        self.leaf_group_cols = None
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown config field %s" % k)
             setattr(self, k, v)
+
+    def leaf_group_for(self, degree_bits, widest_commitment):
+        """The statement's leaf_group_cols.  Whole-row leaves (0, starky's tree) unless the trace is WIDE AND SHORT: a
+        commitment of more than 256 columns on at most 2^14 LDE rows has fewer leaves than the GPU has lanes and hundreds of
+        sequential permutations per leaf (the Sync step's SHA-512 trace: 4 745 columns x 2^10 rows = 594 permutations on each
+        of 1 024 lanes); runs of 128 columns turn that into 16 permutations on each of 38 x 1 024 lanes.  The rule is part of
+        the statement (the verifier reads leaf_group_cols from the descriptor, and it is in the AIR digest)."""
+        if self.leaf_group_cols is not None:
+            return int(self.leaf_group_cols)
+        return 128 if widest_commitment > 256 and degree_bits + self.rate_bits <= 14 else 0
 
 
 def _pow2_factor(e):
@@ -547,6 +559,7 @@ class Stark:
                               cfg.fri_pow_bits, cfg.fri_num_queries, cfg.fri_arity_bits, cfg.fri_final_poly_bits,
                               air.num_public_inputs, len(self.program), self.program.ctypes.data_as(u64p),
                               len(air._periodic), air.period_bits, self.periodic.ctypes.data_as(u64p))
+        self.desc.leaf_group_cols = cfg.leaf_group_for(degree_bits, max(c for c, _ in air.rounds) if air.rounds is not None else air.n_cols)
         if air.rounds is not None:
             self.desc.n_rounds = len(air.rounds)
             for r, (c, k) in enumerate(air.rounds):

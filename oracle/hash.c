@@ -171,14 +171,35 @@ size_t orc_merkle_digest_words(size_t n_leaves, unsigned cap_height) {
     return w;
 }
 
+/* Grouped leaves (the STARK side's wide, short traces: stark.h leaf_group_cols): a leaf of more than `group` elements is
+ * hashed in two levels - hash_no_pad of every run of `group` elements (the last one may be shorter), then hash_no_pad of
+ * the run digests in order - so that the runs of one leaf are independent pieces of work.  group == 0 or a leaf that fits
+ * one run: plonky2's hash_or_noop of the whole leaf. */
+void orc_leaf_digest(const uint64_t* leaf, size_t leaf_len, size_t group, uint64_t out[4]) {
+    if (group == 0 || leaf_len <= group) { orc_hash_or_noop(leaf, leaf_len, out); return; }
+    size_t k = (leaf_len + group - 1) / group;
+    uint64_t* d = (uint64_t*)malloc(32 * k);
+    for (size_t g = 0; g < k; g++) {
+        size_t len = leaf_len - g * group < group ? leaf_len - g * group : group;
+        orc_hash_no_pad(leaf + g * group, len, d + 4 * g);
+    }
+    orc_hash_no_pad(d, 4 * k, out);
+    free(d);
+}
+
 void orc_merkle_build(const uint64_t* leaves, size_t n_leaves, size_t leaf_len, unsigned cap_height,
                       uint64_t* digests_out, uint64_t* cap_out) {
+    orc_merkle_build_g(leaves, n_leaves, leaf_len, 0, cap_height, digests_out, cap_out);
+}
+
+void orc_merkle_build_g(const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t group, unsigned cap_height,
+                        uint64_t* digests_out, uint64_t* cap_out) {
     size_t cap = (size_t)1 << cap_height;
     uint64_t* own = NULL;
     if (!digests_out) digests_out = own = (uint64_t*)malloc(orc_merkle_digest_words(n_leaves, cap_height) * 8);
     uint64_t* cur = digests_out;
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < n_leaves; i++) orc_hash_or_noop(leaves + i * leaf_len, leaf_len, cur + i * 4);
+    for (size_t i = 0; i < n_leaves; i++) orc_leaf_digest(leaves + i * leaf_len, leaf_len, group, cur + i * 4);
     size_t lvl = n_leaves;
     while (lvl > cap) {
         uint64_t* nxt = cur + lvl * 4;
@@ -208,9 +229,14 @@ void orc_merkle_prove(const uint64_t* digests, size_t n_leaves, unsigned cap_hei
 
 int orc_merkle_verify(const uint64_t* leaf, size_t leaf_len, size_t leaf_index, const uint64_t* siblings,
                       unsigned n_siblings, const uint64_t* cap, unsigned cap_height) {
+    return orc_merkle_verify_g(leaf, leaf_len, 0, leaf_index, siblings, n_siblings, cap, cap_height);
+}
+
+int orc_merkle_verify_g(const uint64_t* leaf, size_t leaf_len, size_t group, size_t leaf_index, const uint64_t* siblings,
+                        unsigned n_siblings, const uint64_t* cap, unsigned cap_height) {
     uint64_t cur[4];
     (void)cap_height;
-    orc_hash_or_noop(leaf, leaf_len, cur);
+    orc_leaf_digest(leaf, leaf_len, group, cur);
     size_t idx = leaf_index;
     for (unsigned k = 0; k < n_siblings; k++) {
         uint64_t nxt[4];

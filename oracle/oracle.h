@@ -31,6 +31,18 @@ void orc_coset_ifft(uint64_t* a, unsigned log_n, uint64_t shift);
  * leaves: row-major n_leaves x leaf_len.  digests_out (optional): level-major, level 0 =
  * leaf digests (n_leaves*4 words), then n_leaves/2, ... down to the cap level (inclusive).
  * cap_out: 2^cap_height digests. */
+/* leaves of more than `group` elements hashed in two levels (hash.c orc_leaf_digest); group 0 = plonky2's hash_or_noop */
+void orc_leaf_digest(const uint64_t* leaf, size_t leaf_len, size_t group, uint64_t out[4]);
+void orc_merkle_build_g(const uint64_t* leaves, size_t n_leaves, size_t leaf_len, size_t group, unsigned cap_height,
+                        uint64_t* digests_out, uint64_t* cap_out);
+int orc_merkle_verify_g(const uint64_t* leaf, size_t leaf_len, size_t group, size_t leaf_index, const uint64_t* siblings,
+                        unsigned n_siblings, const uint64_t* cap, unsigned cap_height);
+void orc_commit_from_values_g(const uint64_t* values, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                              unsigned cap_height, size_t leaf_group, uint64_t* coeffs_out, uint64_t* leaves_out,
+                              uint64_t* digests_out, uint64_t* cap_out);
+void orc_commit_from_coeffs_g(const uint64_t* coeffs, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                              unsigned cap_height, size_t leaf_group, uint64_t* leaves_out, uint64_t* digests_out,
+                              uint64_t* cap_out);
 void orc_merkle_build(const uint64_t* leaves, size_t n_leaves, size_t leaf_len, unsigned cap_height,
                       uint64_t* digests_out, uint64_t* cap_out);
 /* siblings bottom-up: (log2(n_leaves) - cap_height) digests */

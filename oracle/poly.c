@@ -78,6 +78,12 @@ void orc_coset_ifft(uint64_t* a, unsigned log_n, uint64_t shift) {
 void orc_commit_from_coeffs(const uint64_t* coeffs, size_t n_cols, unsigned log_n, unsigned rate_bits,
                             unsigned cap_height, uint64_t* leaves_out, uint64_t* digests_out,
                             uint64_t* cap_out) {
+    orc_commit_from_coeffs_g(coeffs, n_cols, log_n, rate_bits, cap_height, 0, leaves_out, digests_out, cap_out);
+}
+
+void orc_commit_from_coeffs_g(const uint64_t* coeffs, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                              unsigned cap_height, size_t leaf_group, uint64_t* leaves_out, uint64_t* digests_out,
+                              uint64_t* cap_out) {
     size_t n = (size_t)1 << log_n;
     unsigned log_l = log_n + rate_bits;
     size_t L = (size_t)1 << log_l;
@@ -96,19 +102,25 @@ void orc_commit_from_coeffs(const uint64_t* coeffs, size_t n_cols, unsigned log_
         }
         free(tmp);
     }
-    orc_merkle_build(leaves_out, L, n_cols, cap_height, digests_out, cap_out);
+    orc_merkle_build_g(leaves_out, L, n_cols, leaf_group, cap_height, digests_out, cap_out);
     free(own);
 }
 
 void orc_commit_from_values(const uint64_t* values, size_t n_cols, unsigned log_n, unsigned rate_bits,
                             unsigned cap_height, uint64_t* coeffs_out, uint64_t* leaves_out,
                             uint64_t* digests_out, uint64_t* cap_out) {
+    orc_commit_from_values_g(values, n_cols, log_n, rate_bits, cap_height, 0, coeffs_out, leaves_out, digests_out, cap_out);
+}
+
+void orc_commit_from_values_g(const uint64_t* values, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                              unsigned cap_height, size_t leaf_group, uint64_t* coeffs_out, uint64_t* leaves_out,
+                              uint64_t* digests_out, uint64_t* cap_out) {
     size_t n = (size_t)1 << log_n;
     uint64_t* own = NULL;
     if (!coeffs_out) coeffs_out = own = (uint64_t*)malloc(n * n_cols * 8);
     memcpy(coeffs_out, values, n * n_cols * 8);
 #pragma omp parallel for schedule(dynamic)
     for (size_t c = 0; c < n_cols; c++) orc_ifft(coeffs_out + c * n, log_n);
-    orc_commit_from_coeffs(coeffs_out, n_cols, log_n, rate_bits, cap_height, leaves_out, digests_out, cap_out);
+    orc_commit_from_coeffs_g(coeffs_out, n_cols, log_n, rate_bits, cap_height, leaf_group, leaves_out, digests_out, cap_out);
     free(own);
 }

@@ -226,7 +226,7 @@ static int fri_verify(const orc_fri_params* p, const uint64_t* const* caps, cons
                 uint64_t sib[64 * 4];
                 if (plen != log_L - cap_h) { rc = -4; break; }
                 r_u64s(&qr, sib, 4 * plen);
-                if (!orc_merkle_verify(rows[o], n_cols[o], x_index, sib, plen, caps[o], cap_h)) { rc = -5; break; }
+                if (!orc_merkle_verify_g(rows[o], n_cols[o], p->leaf_group, x_index, sib, plen, caps[o], cap_h)) { rc = -5; break; }
             }
             if (rc != 1) break;
             uint64_t subgroup_x = gl_mul(GL_GEN, gl_pow(gl_root_of_unity(log_L), gl_bitrev(x_index, log_L)));
@@ -489,7 +489,7 @@ static uint64_t* periodic_coeffs(const orc_stark_desc* d) {
  * program word as (lo, hi) with CONST immediates reduced mod p first, then every periodic value (reduced) as (lo, hi). */
 void orc_stark_air_digest(const orc_stark_desc* d, uint64_t out[4]) {
     const size_t n_per = d->n_periodic ? ((size_t)d->n_periodic << d->period_bits) : 0;
-    const size_t len = 24 + 2 * (size_t)d->n_words + 2 * n_per;
+    const size_t len = 24 + (d->leaf_group_cols ? 1 : 0) + 2 * (size_t)d->n_words + 2 * n_per;
     uint64_t* v = (uint64_t*)malloc(8 * len);
     size_t k = 0;
     const uint32_t shape[14] = {d->degree_bits, d->n_cols, d->num_challenges, d->rate_bits, d->cap_height,
@@ -501,6 +501,7 @@ void orc_stark_air_digest(const orc_stark_desc* d, uint64_t out[4]) {
     for (int r = 0; r < 3; r++) v[k++] = (uint32_t)r < d->n_rounds ? d->round_cols[r] : 0;
     for (int r = 0; r < 3; r++) v[k++] = (uint32_t)r < d->n_rounds ? d->round_challenges[r] : 0;
     for (int r = 0; r < 3; r++) v[k++] = (uint32_t)r < d->n_rounds ? d->round_values[r] : 0;
+    if (d->leaf_group_cols) v[k++] = d->leaf_group_cols;   /* only when used: digests of whole-row statements stay what they were */
     for (uint32_t pc = 0; pc < d->n_words; pc++) {
         uint64_t w = d->program[pc];
         v[k++] = w & 0xFFFFFFFFu; v[k++] = w >> 32;
@@ -582,7 +583,7 @@ size_t orc_stark_proof_max_bytes(const orc_stark_desc* d) {
     const size_t capb = (size_t)32 << d->cap_height;
     const unsigned log_L = d->degree_bits + d->rate_bits;
     const uint32_t nq = d->num_challenges * d->quotient_degree_factor, NRD = n_rounds_of(d);
-    orc_fri_params fp = {d->degree_bits, d->rate_bits, d->cap_height, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits};
+    orc_fri_params fp = {d->degree_bits, d->rate_bits, d->cap_height, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits, d->leaf_group_cols};
     uint32_t R = fri_num_rounds(&fp);
     size_t bytes = (NRD + 1) * capb + 16 * (size_t)(2 * d->n_cols + nq) + R * capb;
     size_t per_query = (d->n_cols + nq) * 8 + (NRD + 1) * (1 + 32 * (size_t)log_L) + R * (((size_t)16 << d->fri_arity_bits) + 1 + 32 * (size_t)log_L);
@@ -624,7 +625,7 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
         r_coeffs[r] = (uint64_t*)malloc(8 * n * rc);
         r_leaves[r] = (uint64_t*)malloc(8 * L * rc);
         r_dig[r] = (uint64_t*)malloc(8 * orc_merkle_digest_words(L, cap_h));
-        orc_commit_from_values(tr, rc, log_n, d->rate_bits, cap_h, r_coeffs[r], r_leaves[r], r_dig[r], r_cap[r]);
+        orc_commit_from_values_g(tr, rc, log_n, d->rate_bits, cap_h, d->leaf_group_cols, r_coeffs[r], r_leaves[r], r_dig[r], r_cap[r]);
         w_u64s(&w, r_cap[r], capw);
         observe_cap(&ch, r_cap[r], cap_h);
         if (n_rv) orc_ch_observe_many(&ch, rv, n_rv);
@@ -698,7 +699,7 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
     uint64_t* q_leaves = (uint64_t*)malloc(8 * L * nq);
     uint64_t* q_dig = (uint64_t*)malloc(8 * orc_merkle_digest_words(L, cap_h));
     uint64_t q_cap[4 * 64];
-    orc_commit_from_coeffs(q_coeffs, nq, log_n, d->rate_bits, cap_h, q_leaves, q_dig, q_cap);
+    orc_commit_from_coeffs_g(q_coeffs, nq, log_n, d->rate_bits, cap_h, d->leaf_group_cols, q_leaves, q_dig, q_cap);
     w_u64s(&w, q_cap, capw);
     observe_cap(&ch, q_cap, cap_h);
     gl2 zeta = orc_ch_ext_challenge(&ch);
@@ -739,7 +740,7 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
         for (uint32_t c = col0[r]; c < col0[r + 1]; c++) { idx_o[c] = r; idx_p[c] = c - col0[r]; }
     for (uint32_t c = 0; c < nq; c++) { idx_o[ncols + c] = NRD; idx_p[ncols + c] = c; }
     orc_fri_batch batches[2] = {{zeta, ncols + nq, idx_o, idx_p}, {g_zeta, ncols, idx_o, idx_p}};
-    orc_fri_params fp = {d->degree_bits, d->rate_bits, cap_h, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits};
+    orc_fri_params fp = {d->degree_bits, d->rate_bits, cap_h, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits, d->leaf_group_cols};
     fri_prove(&fp, oracles, NRD + 1, batches, 2, &ch, &w);
     w_usize(&w, d->num_public_inputs);
     w_u64s(&w, public_inputs, d->num_public_inputs);
@@ -894,7 +895,7 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
         for (uint32_t rd = 0; rd < NRD; rd++) { cap_ptrs[rd] = caps + rd * capw; n_cols[rd] = col0[rd + 1] - col0[rd]; }
         cap_ptrs[NRD] = caps + NRD * capw;
         n_cols[NRD] = nq;
-        orc_fri_params fp = {d->degree_bits, d->rate_bits, cap_h, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits};
+        orc_fri_params fp = {d->degree_bits, d->rate_bits, cap_h, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits, d->leaf_group_cols};
         rc = fri_verify(&fp, cap_ptrs, n_cols, NRD + 1, batches, 2, opened, &ch, &r);
         if (rc == 1 && r.pos != r.len) rc = -11;
         free(open0);

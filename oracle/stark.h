@@ -35,6 +35,7 @@ typedef struct {
 } orc_fri_batch;
 typedef struct {
     uint32_t degree_bits, rate_bits, cap_height, pow_bits, n_queries, arity_bits, final_poly_bits;
+    uint32_t leaf_group;   /* the oracles' leaves are hashed in runs of this many columns (0: whole rows; hash.c orc_leaf_digest) */
 } orc_fri_params;
 
 /* AIR program: 64-bit words, op | dst << 8 | a << 24 | b << 40 (16-bit fields); OP_CONST is followed by
@@ -93,7 +94,13 @@ typedef struct {
     uint32_t n_rounds;
     uint32_t round_cols[3];
     uint32_t round_challenges[3];
-    uint32_t reserved;
+    /* Grouped leaves: 0 = every Merkle leaf is plonky2's hash_or_noop of the whole LDE row.  G > 0: a row of more than G
+     * columns is hashed as hash_no_pad(hash_no_pad(cols [0, G)) || hash_no_pad(cols [G, 2G)) || ...) - a tree whose bottom
+     * level has arity ceil(n_cols / G) over column runs.  Same proof bytes layout (rows and sibling paths), same number of
+     * permutations + ceil(K / 2) for the verifier; for the prover the K runs of a leaf are independent work, which is what
+     * a trace of thousands of columns on a few thousand rows needs to fill a GPU.  Part of the
+     * statement digest when non-zero. */
+    uint32_t leaf_group_cols;
     /* round values: round_values[r] field elements the prover sends with round r (bus / accumulator totals that depend on
      * earlier challenges).  They are observed after the round's cap and before its challenges are drawn, are written
      * after the public inputs at the end of the proof, and the program reads them as PUBLIC: the values array is

@@ -25,6 +25,13 @@ CASES = [
     ("periodic", 9, dict(rate_bits=2)),
     ("periodic", 12, {}),
     ("wide64", 14, {}),                               # 2^14 rows x 64 columns: the largest whole-STARK byte comparison
+    # grouped Merkle leaves (nlx_stark_desc.leaf_group_cols): runs of G columns hashed on their own, then the runs' digests
+    ("wide64", 9, dict(leaf_group_cols=8)),           # 8 runs of 8: one permutation per run
+    ("wide64", 10, dict(leaf_group_cols=24)),         # runs 24 + 24 + 16: a short last run
+    ("wide16", 8, dict(leaf_group_cols=12)),          # runs 12 + 4: the last run no longer than a digest is still hashed
+    ("wide64", 11, dict(leaf_group_cols=64)),         # the row fits one run: whole-row leaves, but the digest names G
+    ("wide320", 7, {}),                               # the host rule: > 256 columns on <= 2^14 LDE rows -> runs of 128
+    ("wide320", 9, dict(leaf_group_cols=0)),          # ... switched off
 ]
 
 

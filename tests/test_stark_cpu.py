@@ -462,3 +462,40 @@ def test_transcript_binds_public_inputs_and_air(nlx, orc):
     assert orc.stark_air_digest(st.desc) != orc.stark_air_digest(st2.desc)
     assert orc.stark_verify(st2.desc, proof) != 1
     assert orc.stark_verify(st2.desc, orc.stark_prove(st2.desc, t, pis)) == 1
+
+
+def test_grouped_leaves_are_what_the_header_says(nlx, orc):
+    """leaf_group_cols: a row of more than G elements is hash_no_pad(hash_no_pad(run 0) || hash_no_pad(run 1) || ...), shorter rows
+    are plonky2's hash_or_noop; the STARK oracle proves and verifies with it, a verifier told another G rejects, and the
+    host rule switches it on only for wide short traces"""
+    import ctypes
+    d = orc.dll()
+    d.orc_leaf_digest.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+    d.orc_hash_no_pad.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+
+    def hash_no_pad(x):
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        h = np.zeros(4, dtype=np.uint64)
+        d.orc_hash_no_pad(x.ctypes.data, x.size, h.ctypes.data)
+        return h
+    rng = np.random.default_rng(5)
+    row = rng.integers(0, P, 37, dtype=np.uint64)
+    out = np.zeros(4, dtype=np.uint64)
+    for G in (8, 12, 36):
+        d.orc_leaf_digest(row.ctypes.data, row.size, G, out.ctypes.data)
+        runs = [hash_no_pad(row[i:i + G]) for i in range(0, row.size, G)]   # a run of ONE element (G = 12, 36) is hashed too
+        assert np.array_equal(out, hash_no_pad(np.concatenate(runs)))
+    for G in (0, 37, 64):
+        d.orc_leaf_digest(row.ctypes.data, row.size, G, out.ctypes.data)
+        assert np.array_equal(out, hash_no_pad(row))
+    S = nlx.stark
+    air, t, pis = make_case(S, "wide16", 6)
+    st = S.Stark(air, 6, S.StarkConfig(leaf_group_cols=8))
+    plain = S.Stark(air, 6)
+    assert st.desc.leaf_group_cols == 8 and plain.desc.leaf_group_cols == 0
+    proof = orc.stark_prove(st.desc, t, pis)
+    assert orc.stark_verify(st.desc, proof) == 1
+    assert orc.stark_verify(plain.desc, proof) != 1 and proof != orc.stark_prove(plain.desc, t, pis)
+    assert len(proof) == len(orc.stark_prove(plain.desc, t, pis))       # same layout: opened rows and sibling paths
+    cfg = S.StarkConfig()
+    assert cfg.leaf_group_for(9, 4745) == 128 and cfg.leaf_group_for(15, 1488) == 0 and cfg.leaf_group_for(9, 200) == 0

@@ -1,0 +1,21 @@
+#!/bin/bash
+# grouped Merkle leaves: parity of the STARK suites, then the Sync bench (one-at-a-time step and pipelined rate)
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+mkdir -p "$ROOT/gpurun_out/r03"
+cd "$ROOT"
+timeout -k 10 900 python -m pytest tests/test_gpu_stark.py tests/test_sha256_air.py tests/test_sha512_air.py tests/test_ed25519_air.py -m gpu -x -q > gpurun_out/r03/tests_leafgroups.txt 2>&1
+rc=$?
+echo "rc=$rc" >> gpurun_out/r03/tests_leafgroups.txt
+tail -6 gpurun_out/r03/tests_leafgroups.txt
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 600 python3 bench.py --no-extra > gpurun_out/r03/sync_leafgroups.json 2> gpurun_out/r03/sync_leafgroups.err
+echo "bench rc=$?"
+python3 - <<'PY'
+import json
+d = json.load(open("gpurun_out/r03/sync_leafgroups.json"))
+print("value", d["value"], "ms_per_step", d["ms_per_step"])
+print(d["ms_one_proof_at_a_time"])
+print(d["kernel_ms_per_step"])
+print(d["config"]["outer_rows_floor_from_stark_verification"], d["config"]["proof_bytes"])
+print(d.get("parity_checked"))
+PY
