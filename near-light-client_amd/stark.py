@@ -43,6 +43,11 @@ class StarkDesc(ctypes.Structure):
                        ("round_values", ctypes.c_uint32 * 3), ("reserved2", ctypes.c_uint32)]
 
 
+# grouped leaves are switched on up to this many LDE rows (2^k): at 2^16 rows one leaf per lane is one wave per SIMD, which
+# hashes at 1.6 G permutations/s where two or more waves reach 2.0 (profiles/r03_poseidon_occupancy_v2.txt)
+LEAF_GROUP_MAX_LOG_ROWS = 16
+
+
 class StarkConfig:
     """starky::config::StarkConfig::standard_fast_config()."""
 
@@ -63,13 +68,13 @@ class StarkConfig:
 
     def leaf_group_for(self, degree_bits, widest_commitment):
         """The statement's leaf_group_cols.  Whole-row leaves (0, starky's tree) unless the trace is WIDE AND SHORT: a
-        commitment of more than 256 columns on at most 2^14 LDE rows has fewer leaves than the GPU has lanes and hundreds of
+        commitment of more than 256 columns on at most 2^16 LDE rows has no more leaves than the GPU has lanes and hundreds of
         sequential permutations per leaf (the Sync step's SHA-512 trace: 4 745 columns x 2^10 rows = 594 permutations on each
         of 1 024 lanes); runs of 128 columns turn that into 16 permutations on each of 38 x 1 024 lanes.  The rule is part of
         the statement (the verifier reads leaf_group_cols from the descriptor, and it is in the AIR digest)."""
         if self.leaf_group_cols is not None:
             return int(self.leaf_group_cols)
-        return 128 if widest_commitment > 256 and degree_bits + self.rate_bits <= 14 else 0
+        return 128 if widest_commitment > 256 and degree_bits + self.rate_bits <= LEAF_GROUP_MAX_LOG_ROWS else 0
 
 
 def _pow2_factor(e):

@@ -498,4 +498,4 @@ def test_grouped_leaves_are_what_the_header_says(nlx, orc):
     assert orc.stark_verify(plain.desc, proof) != 1 and proof != orc.stark_prove(plain.desc, t, pis)
     assert len(proof) == len(orc.stark_prove(plain.desc, t, pis))       # same layout: opened rows and sibling paths
     cfg = S.StarkConfig()
-    assert cfg.leaf_group_for(9, 4745) == 128 and cfg.leaf_group_for(15, 1488) == 0 and cfg.leaf_group_for(9, 200) == 0
+    assert cfg.leaf_group_for(9, 4745) == 128 and cfg.leaf_group_for(15, 1488) == 128 and cfg.leaf_group_for(16, 1488) == 0 and cfg.leaf_group_for(9, 200) == 0
