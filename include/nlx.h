@@ -180,6 +180,42 @@ int32_t nlx_bn254_g2_sum(const uint64_t* points, uint64_t n, uint64_t out[16]); 
  * words; n <= 2^27; base must not be the point at infinity. */
 int32_t nlx_bn254_g1_multiples(nlx_ctx* ctx, const uint64_t base[8], uint64_t n, uint64_t* out);
 
+/* ---- f.4 (third piece): the PLONK prover's quotient chain and a KZG opening on those kernels.  What the wrap's prover
+ * (gnark backend/plonk/bn254 Prove; Go, not in /root/reference - succinct.json:7-8 names the entry point that runs it) does
+ * between its commitments, restated from the published protocol (three-wire PLONK as gnark arithmetises it), not from
+ * gnark's source: no blinding terms, no gnark byte format.  Every element is an fr.Element as it lies in memory (four words,
+ * Montgomery): flags must be NLX_BN254_MONTGOMERY.
+ *
+ * nlx_bn254_plonk_quotient: the thirteen polynomials given by their values on H = <w_n> (host or device pointers, n x 4 words
+ * each, natural order; pi may be NULL) -> coefficients (FFTInverse, DIF) -> values on the coset coset_shift * <w_4n> (FFT,
+ * DIT, OnCoset) -> there, pointwise,
+ *     t = [ ql l + qr r + qm l r + qo o + qk + pi
+ *           + alpha ( (l + beta x + gamma)(r + beta k1 x + gamma)(o + beta k2 x + gamma) z
+ *                     - (l + beta s1 + gamma)(r + beta s2 + gamma)(o + beta s3 + gamma) z(w_n x) )
+ *           + alpha^2 L1(x) (z - 1) ] / (x^n - 1),           L1(x) = (x^n - 1) / (n (x - 1))
+ * -> coefficients (FFTInverse, OnCoset).  t_out: the three chunks t_lo, t_mid, t_hi of n coefficients each (3 n x 4 words,
+ * natural order, host or device).  *high_chunk_is_zero (may be NULL): 1 if coefficients 3n .. 4n-1 all vanish - they do
+ * exactly when the witness satisfies gates and copy constraints, and a prover must not commit to t otherwise.
+ * coset_shift, k1, k2, alpha, beta, gamma: host, four words each, in the form of the data.  2 <= log_n <= 26. */
+typedef struct {
+    uint32_t log_n;
+    uint32_t flags;                       /* NLX_BN254_MONTGOMERY */
+    const uint64_t *ql, *qr, *qm, *qo, *qk;   /* selectors */
+    const uint64_t *s1, *s2, *s3;             /* the permutation, as polynomials: s_j(w^i) = the point of H, k1 H or k2 H that wire j of gate i maps to */
+    const uint64_t *l, *r, *o;                /* wires */
+    const uint64_t *z;                        /* the permutation's grand product, z(w^0) = 1 */
+    const uint64_t *pi;                       /* public-input polynomial (values on H) or NULL */
+    const uint64_t *coset_shift, *k1, *k2;    /* gnark: the domain's FrMultiplicativeGen u, then k1 = u, k2 = u^2 */
+    const uint64_t *alpha, *beta, *gamma;
+} nlx_bn254_plonk_quotient_args;
+int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_args* args, uint64_t* t_out, int32_t* high_chunk_is_zero);
+/* One KZG opening (gnark-crypto kzg.Open): coeffs = m coefficients (natural order, host or device), zeta = the point (host).
+ * y_out = p(zeta); quotient_out (may be NULL; host or device, m - 1 coefficients) = (p(X) - p(zeta)) / (X - zeta) - the
+ * running Horner values, computed as a parallel scan; proof_out (may be NULL) = its commitment sum_i q_i srs[i] over the first
+ * m - 1 points of the SRS (G1Affine words as for nlx_bn254_msm_g1; host or device).  2 <= m <= 2^28. */
+int32_t nlx_bn254_kzg_open(nlx_ctx* ctx, const uint64_t* coeffs, uint64_t m, const uint64_t zeta[4], const uint64_t* srs,
+                           uint64_t y_out[4], uint64_t* quotient_out, uint64_t proof_out[8]);
+
 /* ---- a3: plonky2::fri::oracle::PolynomialBatch::{from_values, from_coeffs} ----
  * values / coeffs: n_cols x 2^log_n column-major, natural order.  The coset shift is the
  * field's multiplicative generator (plonky2 F::coset_shift()).  blinding / salting is not

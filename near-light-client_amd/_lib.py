@@ -83,6 +83,9 @@ SIGNATURES = {
     "nlx_bn254_msm_g2": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32,
                                            ctypes.c_void_p]),
     "nlx_bn254_g1_multiples": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "nlx_bn254_plonk_quotient": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "nlx_bn254_kzg_open": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_commit_from_values": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
                                                 ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, c_void_pp]),
     "nlx_commit_from_coeffs": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,

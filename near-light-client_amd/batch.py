@@ -257,6 +257,78 @@ def bn254_msm_g1(ctx, points, scalars, montgomery=False):
     return out
 
 
+class _PlonkQuotientArgs(ctypes.Structure):
+    """nlx_bn254_plonk_quotient_args (include/nlx.h)"""
+    _fields_ = [("log_n", ctypes.c_uint32), ("flags", ctypes.c_uint32)] + [(k, ctypes.c_void_p) for k in (
+        "ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3", "l", "r", "o", "z", "pi", "coset_shift", "k1", "k2", "alpha", "beta", "gamma")]
+
+
+def _fr_words(x):
+    return np.array([(int(x) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(4)], dtype=np.uint64)
+
+
+def bn254_plonk_quotient(ctx, polys, coset_shift, k1, k2, alpha, beta, gamma):
+    """The PLONK prover's quotient chain over BN254's scalar field (nlx_bn254_plonk_quotient).  polys: dict with the values on
+    H of ql qr qm qo qk s1 s2 s3 l r o z and optionally pi, each an (n, 4) uint64 array of fr.Element words (Montgomery) or a
+    device tensor of that shape; the six scalars: integers in Montgomery form.  Returns (t, ok): t = (3, n, 4) uint64, the
+    chunks t_lo, t_mid, t_hi; ok = the fourth chunk vanished (the witness satisfies the circuit)."""
+    names = ("ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3", "l", "r", "o", "z")
+    keep, args = [], _PlonkQuotientArgs()
+    n = None
+    for k in names + ("pi",):
+        v = polys.get(k)
+        if v is None:
+            if k != "pi":
+                raise ValueError("missing polynomial %s" % k)
+            continue
+        if hasattr(v, "data_ptr"):
+            shape, ptr = tuple(v.shape), v.data_ptr()
+        else:
+            v = np.ascontiguousarray(v, dtype=np.uint64)
+            shape, ptr = v.shape, v.ctypes.data
+        if len(shape) != 2 or shape[1] != 4 or (n is not None and shape[0] != n):
+            raise ValueError("%s: expected shape (n, 4)" % k)
+        n = shape[0]
+        keep.append(v)
+        setattr(args, k, ptr)
+    args.log_n = n.bit_length() - 1
+    if 1 << args.log_n != n:
+        raise ValueError("n must be a power of two")
+    args.flags = 1
+    for k, x in (("coset_shift", coset_shift), ("k1", k1), ("k2", k2), ("alpha", alpha), ("beta", beta), ("gamma", gamma)):
+        w = _fr_words(x)
+        keep.append(w)
+        setattr(args, k, w.ctypes.data)
+    out = np.zeros((3, n, 4), dtype=np.uint64)
+    ok = ctypes.c_int32()
+    ctx.check(dll.nlx_bn254_plonk_quotient(ctx.handle, ctypes.byref(args), out.ctypes.data, ctypes.byref(ok)))
+    return out, bool(ok.value)
+
+
+def bn254_kzg_open(ctx, coeffs, zeta, srs=None, want_quotient=True):
+    """One KZG opening (nlx_bn254_kzg_open).  coeffs: (m, 4) uint64 fr.Element words (Montgomery) or a device tensor; zeta: an
+    integer in Montgomery form; srs: (>= m - 1, 8) G1Affine words (host array or device tensor) or None.  Returns (y words,
+    quotient (m - 1, 4) or None, proof words or None)."""
+    if hasattr(coeffs, "data_ptr"):
+        m, ptr = coeffs.shape[0], coeffs.data_ptr()
+    else:
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        m, ptr = coeffs.shape[0], coeffs.ctypes.data
+    z = _fr_words(zeta)
+    y = np.zeros(4, dtype=np.uint64)
+    q = np.zeros((m - 1, 4), dtype=np.uint64) if want_quotient else None
+    proof = np.zeros(8, dtype=np.uint64) if srs is not None else None
+    srs_ptr = None
+    if srs is not None:
+        srs_ptr = srs.data_ptr() if hasattr(srs, "data_ptr") else np.ascontiguousarray(srs, dtype=np.uint64).ctypes.data
+        if not hasattr(srs, "data_ptr"):
+            srs = np.ascontiguousarray(srs, dtype=np.uint64)
+            srs_ptr = srs.ctypes.data
+    ctx.check(dll.nlx_bn254_kzg_open(ctx.handle, ptr, m, z.ctypes.data, srs_ptr, y.ctypes.data,
+                                     q.ctypes.data if q is not None else None, proof.ctypes.data if proof is not None else None))
+    return y, q, proof
+
+
 def bn254_g1_sum(points):
     """The sum of G1Affine points, (n, 8) uint64 words each (host): joins the partial MSMs of several GPUs."""
     a = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)

@@ -19,6 +19,9 @@ if GEN_SET not in ("7", "2021"):
 _SUFFIX = "" if GEN_SET == "7" else "_gen" + GEN_SET
 # kernel-tuning experiments: NLX_BUILD_VARIANT=name NLX_EXTRA_FLAGS="-DNLX_QW=4 ..." builds libnlx_name.so beside the real one
 # (own object cache); near-light-client_amd/_lib.py loads it when NLX_BUILD_VARIANT is set.  Never used by tests or the bench.
+# Sanitizer build of the HOST side (the device side cannot be: no GPU ASan on the pool) - tools/asan_host.sh:
+#   NLX_BUILD_VARIANT=asan NLX_EXTRA_FLAGS="-Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer"
+#   NLX_EXTRA_LDFLAGS="-fsanitize=address,undefined -shared-libsan"  ->  libnlx_asan.so
 VARIANT = os.environ.get("NLX_BUILD_VARIANT", "")
 if VARIANT:
     _SUFFIX += "_" + VARIANT
@@ -76,7 +79,7 @@ def build_lib(force=False, verbose=False):
             list(ex.map(lambda s: _compile(s, verbose), todo))
     for lib, members in ((LIB, objs), (SYNTH_LIB, synth_objs)):
         if todo or not os.path.exists(lib):
-            cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + members
+            cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + members + os.environ.get("NLX_EXTRA_LDFLAGS", "").split()
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)

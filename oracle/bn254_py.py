@@ -198,3 +198,90 @@ def msm_g2(scalars, points):
     for k, p in zip(scalars, points):
         acc = g2_add(acc, g2_mul(int(k), p))
     return acc
+
+
+# ---- row f.4, third piece: the PLONK quotient chain and a KZG opening (published protocol, no blinding) ----
+def coset_evals(values_on_h, shift, blowup_log=2):
+    """values on H = <w_n> -> values on shift * <w_(n << blowup_log)> of the interpolating polynomial"""
+    c = ntt(values_on_h, inverse=True)
+    n4 = len(c) << blowup_log
+    s, out = 1, []
+    for j in range(n4):
+        out.append((c[j] * s % R) if j < len(c) else 0)
+        s = s * shift % R
+    return ntt(out)
+
+
+def plonk_quotient(p, shift, k1, k2, alpha, beta, gamma):
+    """p: dict of the thirteen polynomials' values on H (ql qr qm qo qk s1 s2 s3 l r o z, optional pi).  Returns the 4n
+    coefficients of t = (gate + alpha perm + alpha^2 L1 (z - 1)) / Z_H computed on the coset shift * <w_4n> (the top n are zero
+    exactly for a satisfying witness)."""
+    n = len(p["l"])
+    log_n = n.bit_length() - 1
+    n4 = 4 * n
+    ev = {k: coset_evals(v, shift) for k, v in p.items() if v is not None}
+    w4 = root_of_unity(log_n + 2)
+    ninv = pow(n, R - 2, R)
+    t, x = [], shift
+    for i in range(n4):
+        l, r, o, z, zn = ev["l"][i], ev["r"][i], ev["o"][i], ev["z"][i], ev["z"][(i + 4) % n4]
+        gate = (ev["ql"][i] * l + ev["qr"][i] * r + ev["qm"][i] * l * r + ev["qo"][i] * o + ev["qk"][i]) % R
+        if "pi" in ev:
+            gate = (gate + ev["pi"][i]) % R
+        f = (l + beta * x + gamma) * (r + beta * k1 * x + gamma) % R * (o + beta * k2 * x + gamma) % R * z % R
+        g = (l + beta * ev["s1"][i] + gamma) * (r + beta * ev["s2"][i] + gamma) % R * (o + beta * ev["s3"][i] + gamma) % R * zn % R
+        zh = (pow(x, n, R) - 1) % R
+        l1 = zh * pow(n * (x - 1) % R, R - 2, R) % R
+        num = (gate + alpha * (f - g) + alpha * alpha % R * l1 % R * (z - 1)) % R
+        t.append(num * pow(zh, R - 2, R) % R)
+        x = x * w4 % R
+    c = ntt(t, inverse=True)
+    sinv, s, out = pow(shift, R - 2, R), 1, []
+    for j in range(n4):
+        out.append(c[j] * s % R)
+        s = s * sinv % R
+    return out
+
+
+def kzg_open(coeffs, zeta):
+    """(p(zeta), coefficients of (p(X) - p(zeta)) / (X - zeta)) by synthetic division"""
+    h, q = 0, []
+    for c in reversed(coeffs):
+        h = (int(c) + zeta * h) % R
+        q.append(h)
+    y = q.pop()
+    return y, q[::-1]
+
+
+def plonk_witness(log_n, rng, k1, k2, beta, gamma, satisfied=True):
+    """A random satisfying three-wire PLONK instance on n = 2^log_n gates: selectors, wires with copy constraints among
+    equal values, the permutation as s1 s2 s3 (identity points w^i, k1 w^i, k2 w^i) and its grand product z."""
+    n = 1 << log_n
+    w = root_of_unity(log_n)
+    pool = [rng.randrange(R) for _ in range(max(2, n // 2))]
+    wires = [[pool[rng.randrange(len(pool))] for _ in range(n)] for _ in range(3)]
+    ql, qr, qm, qo = ([rng.randrange(R) for _ in range(n)] for _ in range(4))
+    qk = [(-(ql[i] * wires[0][i] + qr[i] * wires[1][i] + qm[i] * wires[0][i] * wires[1][i] + qo[i] * wires[2][i])) % R for i in range(n)]
+    ident = [[k * pow(w, i, R) % R for i in range(n)] for k in (1, k1, k2)]
+    # one cycle per value: every position of a value maps to the next position holding it
+    where = {}
+    for c in range(3):
+        for i in range(n):
+            where.setdefault(wires[c][i], []).append((c, i))
+    sigma = [[0] * n for _ in range(3)]
+    for pos in where.values():
+        for a, b in zip(pos, pos[1:] + pos[:1]):
+            sigma[a[0]][a[1]] = ident[b[0]][b[1]]
+    z, acc = [], 1
+    for i in range(n):
+        z.append(acc)
+        num = den = 1
+        for c in range(3):
+            num = num * (wires[c][i] + beta * ident[c][i] + gamma) % R
+            den = den * (wires[c][i] + beta * sigma[c][i] + gamma) % R
+        acc = acc * num % R * pow(den, R - 2, R) % R
+    assert acc == 1, "the grand product closes"
+    if not satisfied:
+        wires[2][rng.randrange(n)] += 1
+    return {"ql": ql, "qr": qr, "qm": qm, "qo": qo, "qk": qk, "s1": sigma[0], "s2": sigma[1], "s3": sigma[2],
+            "l": wires[0], "r": wires[1], "o": [x % R for x in wires[2]], "z": z}

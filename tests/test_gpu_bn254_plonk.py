@@ -1,0 +1,99 @@
+"""GPU parity tests of row f.4's third piece - the PLONK prover's quotient chain and a KZG opening over BN254's scalar field
+(nlx_bn254_plonk_quotient, nlx_bn254_kzg_open; csrc/bn254_plonk.hip) - against the pure-Python big-integer model
+(oracle/bn254_py.py: plonk_quotient, kzg_open, plonk_witness).  gnark is Go and not in /root/reference: the model restates
+the published protocol, parity unpinned as for the rest of row f.4."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bn():
+    import bn254_py
+    return bn254_py
+
+
+def _mont(bn, values):
+    return [bn.to_montgomery(v) for v in values]
+
+
+@pytest.mark.parametrize("log_n,with_pi", [(2, False), (3, True), (5, False), (8, True), (10, False)])
+def test_quotient_chain_equals_model(nlx, ctx, bn, log_n, with_pi):
+    rng = random.Random(100 + log_n)
+    u = 5                                                  # gnark's coset generator; k1 = u, k2 = u^2
+    k1, k2 = u, u * u % bn.R
+    alpha, beta, gamma = (rng.randrange(bn.R) for _ in range(3))
+    p = bn.plonk_witness(log_n, rng, k1, k2, beta, gamma)
+    n = 1 << log_n
+    if with_pi:
+        # a public-input polynomial that keeps the gates satisfied: move part of qk into it
+        p["pi"] = [rng.randrange(bn.R) if i < 3 else 0 for i in range(n)]
+        p["qk"] = [(a - b) % bn.R for a, b in zip(p["qk"], p["pi"])]
+    want = bn.plonk_quotient(p, u, k1, k2, alpha, beta, gamma)
+    assert not any(want[3 * n:]) and any(want[2 * n:3 * n])
+    packed = {k: nlx.bn254_pack([_mont(bn, v)])[0] for k, v in p.items()}
+    sc = [bn.to_montgomery(x) for x in (u, k1, k2, alpha, beta, gamma)]
+    t, ok = nlx.bn254_plonk_quotient(ctx, packed, *sc)
+    assert ok
+    got = [bn.from_montgomery(x) for chunk in nlx.bn254_unpack(t) for x in chunk]
+    assert got == want[:3 * n]
+    # the same from device-resident inputs
+    import torch
+    dev = {k: torch.from_numpy(v.view(np.int64)).cuda() for k, v in packed.items()}
+    t2, ok2 = nlx.bn254_plonk_quotient(ctx, dev, *sc)
+    assert ok2 and np.array_equal(t2, t)
+    # the identity the verifier checks, at a random point: (gate + alpha perm + alpha^2 L1 (z - 1))(zeta) = t(zeta) Z_H(zeta)
+    zeta = rng.randrange(bn.R)
+    co = {k: bn.ntt(v, inverse=True) for k, v in p.items()}
+    e = {k: bn.eval_poly(c, zeta) for k, c in co.items()}
+    zw = bn.eval_poly(co["z"], zeta * bn.root_of_unity(log_n) % bn.R)
+    R = bn.R
+    gate = (e["ql"] * e["l"] + e["qr"] * e["r"] + e["qm"] * e["l"] * e["r"] + e["qo"] * e["o"] + e["qk"] + e.get("pi", 0)) % R
+    f = (e["l"] + beta * zeta + gamma) * (e["r"] + beta * k1 * zeta + gamma) * (e["o"] + beta * k2 * zeta + gamma) * e["z"] % R
+    g = (e["l"] + beta * e["s1"] + gamma) * (e["r"] + beta * e["s2"] + gamma) * (e["o"] + beta * e["s3"] + gamma) * zw % R
+    zh = (pow(zeta, n, R) - 1) % R
+    l1 = zh * pow(n * (zeta - 1) % R, R - 2, R) % R
+    assert (gate + alpha * (f - g) + alpha * alpha * l1 * (e["z"] - 1)) % R == bn.eval_poly(got, zeta) * zh % R
+
+
+def test_a_witness_that_breaks_a_gate_is_reported(nlx, ctx, bn):
+    rng = random.Random(7)
+    alpha, beta, gamma = (rng.randrange(bn.R) for _ in range(3))
+    p = bn.plonk_witness(6, rng, 5, 25, beta, gamma, satisfied=False)
+    packed = {k: nlx.bn254_pack([_mont(bn, v)])[0] for k, v in p.items()}
+    t, ok = nlx.bn254_plonk_quotient(ctx, packed, *[bn.to_montgomery(x) for x in (5, 5, 25, alpha, beta, gamma)])
+    assert not ok
+    want = bn.plonk_quotient(p, 5, 5, 25, alpha, beta, gamma)
+    assert [bn.from_montgomery(x) for chunk in nlx.bn254_unpack(t) for x in chunk] == want[:3 * 64] and any(want[3 * 64:])
+    del packed["z"]
+    with pytest.raises(ValueError):
+        nlx.bn254_plonk_quotient(ctx, packed, 1, 1, 1, 1, 1, 1)
+
+
+@pytest.mark.parametrize("m", [2, 3, 63, 64, 65, 127, 4096, 4097, 64 * 64 * 2 + 5, (1 << 15) + 321])
+def test_kzg_open_equals_model(nlx, ctx, bn, m):
+    """the synthetic division as a three-phase scan: one run, exactly full runs, a short last run, two and three levels"""
+    rng = random.Random(m)
+    coeffs = [rng.randrange(bn.R) for _ in range(m)]
+    zeta = rng.randrange(bn.R)
+    y, q = bn.kzg_open(coeffs, zeta)
+    gy, gq, _ = nlx.bn254_kzg_open(ctx, nlx.bn254_pack([_mont(bn, coeffs)])[0], bn.to_montgomery(zeta))
+    assert bn.from_montgomery(nlx.bn254_unpack(gy[None, None, :])[0][0]) == y == bn.eval_poly(coeffs, zeta)
+    assert [bn.from_montgomery(x) for x in nlx.bn254_unpack(gq[None])[0]] == q
+
+
+def test_kzg_opening_proof_is_the_commitment_of_the_quotient(nlx, ctx, bn):
+    rng = random.Random(11)
+    m = 40
+    coeffs = [rng.randrange(bn.R) for _ in range(m)]
+    zeta = rng.randrange(bn.R)
+    srs = nlx.bn254_g1_multiples(ctx, bn.G1, m - 1)     # 1 G, 2 G, ...: any distinct points do
+    y, q, proof = nlx.bn254_kzg_open(ctx, nlx.bn254_pack([_mont(bn, coeffs)])[0], bn.to_montgomery(zeta), srs=srs)
+    _, want_q = bn.kzg_open(coeffs, zeta)
+    pts = [nlx.bn254_g1_unpack(w) for w in srs]
+    assert nlx.bn254_g1_unpack(proof) == bn.msm_g1(want_q, pts)
+    # and it is what the MSM entry point gives for the returned quotient
+    assert np.array_equal(proof, nlx.bn254_msm_g1(ctx, srs, q, montgomery=True))
