@@ -90,7 +90,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sync", choices=["sync", "outer", "verify128", "stark", "sha256", "sha512", "ed25519", "ntt24", "msm24"])
+    ap.add_argument("--workload", default="sync", choices=["sync", "outer", "verify128", "stark", "sha256", "sha512", "ed25519", "ntt24", "msm24", "plonk24"])
     ap.add_argument("--log-blocks", type=int, default=14, help="sha256 workload: 2^k compression blocks per proof")
     ap.add_argument("--log-slots", type=int, default=10, help="ed25519 workload: 2^k signature slots per proof (>= 4)")
     ap.add_argument("--segment-nodes", type=int, default=None, help="sha256 / sha512 / ed25519 workloads: AIR program segment size in arithmetic nodes (0 = one segment)")
@@ -1213,6 +1213,74 @@ def run_ntt24_bn254(args, nlx, torch, rank, world, local, dist):
     return out
 
 
+def run_plonk24(args, nlx, torch, rank, world, local, dist):
+    """--workload plonk24: the PLONK prover's quotient chain of the recursive wrap (row f.4's third piece) on a coset of
+    2^--ntt-log-n points (n = a quarter of that many gates): twelve FFTInverse(DIF) of n points, twelve FFT(DIT, OnCoset) of 4 n,
+    the pointwise pass, one FFTInverse(OnCoset) of 4 n - then one KZG opening of the 3 n-coefficient quotient (evaluation +
+    synthetic division as a scan; the MSM is msm24's job).  Inputs: uniform field elements resident in HBM (a random instance
+    does not satisfy a circuit; the arithmetic is the same - small satisfying instances are the parity tests').  One rank."""
+    import numpy as np
+    log4 = args.ntt_log_n
+    log_n = log4 - 2
+    n = 1 << log_n
+    ctx = nlx.Context(local)
+    dev = "cuda:%d" % local
+    g = torch.Generator(device="cpu").manual_seed(0x706C6B)
+
+    def rand_fr(count):
+        v = torch.randint(0, 2 ** 62, (count, 4), generator=g, dtype=torch.int64) * 4 + torch.randint(0, 4, (count, 4), generator=g, dtype=torch.int64)
+        v[:, 3] = torch.randint(0, 0x30644e72e131a029, (count,), generator=g, dtype=torch.int64)
+        return v.to(dev)
+    names = ("ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3", "l", "r", "o", "z")
+    polys = {k: rand_fr(n) for k in names}
+    out_t = torch.empty((3, n, 4), dtype=torch.int64, device=dev)
+    sc = [5, 5, 25, 0x1234567, 0x89abcdef, 0x1357]   # any words below r: Montgomery forms of some field elements
+
+    def step():
+        nlx.bn254_plonk_quotient(ctx, polys, *sc, out=out_t)
+    for _ in range(args.warmup):
+        step()
+    ctx.kernel_timing(True)
+    barrier(dist, torch)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(dist, torch)
+    dt = time.perf_counter() - t0
+    kq = ctx.kernel_stats("plonk_quotient")
+    ctx.kernel_timing(False)
+    # the opening of t (3 n coefficients) at a point: evaluation + quotient, no MSM
+    flat = out_t.reshape(3 * n, 4)
+    nlx.bn254_kzg_open(ctx, flat, 0x2468ace, want_quotient=False)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        nlx.bn254_kzg_open(ctx, flat, 0x2468ace, want_quotient=False)
+    torch.cuda.synchronize()
+    dt_open = (time.perf_counter() - t1) / args.steps
+    ms_q = kq[1] / kq[0] if kq[0] else None
+    alg = 32.0 * (4 * n) * (12 + 2 + 1)   # the pointwise pass: 12 evaluation columns + the two domain tables in, t out
+    out = {
+        "metric": "PLONK quotient chain over BN254 Fr on a coset of 2^%d points: chains per second (the recursive wrap's prover, row f.4)" % log4,
+        "value": args.steps / dt, "unit": "chains/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u256 (BN254 scalar field, Montgomery form, integer)", "data": "synthetic",
+        "config": {"workload": "n = 2^%d gates: 12 x FFTInverse(DIF, n) + 12 x FFT(DIT, OnCoset, 4n) + pointwise quotient on 4n points + "
+                               "FFTInverse(OnCoset, 4n), polynomials resident in HBM; domain tables (points, 1 / (n (x - 1)) by batch inversion) "
+                               "rebuilt every call" % log_n,
+                   "kzg_open_ms": dt_open * 1e3, "kzg_open_note": "evaluation + (p - p(zeta)) / (X - zeta) of the 3n-coefficient quotient as a "
+                   "three-level Horner scan, without the MSM (msm24 times that)", "pointwise_kernel_ms": ms_q, "parallelism": "x1"},
+        "roofline": {"bound": "hbm", "achieved": (alg / (ms_q * 1e-3) / 1e9) if ms_q else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (alg / (ms_q * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_q else None, "traffic": None, "kernel": "k_plonk_quotient",
+                     "launches": kq[0], "avg_launch_ms": ms_q, "alg_bytes_per_launch": alg,
+                     "note": "32-byte elements; 15 columns of 4n per launch; ~33 256-bit products per point (~250 vector instructions each) make "
+                             "it integer-VALU bound"},
+        "cpu_baseline": None,
+    }
+    ctx.close()
+    return out
+
+
 def run_msm24_g2(args, nlx, torch, rank, world, local, dist):
     """--workload msm24 --msm-group g2: one BN254 G2 multi-scalar multiplication of 2^--ntt-log-n points per step (Groth16's B
     query; nlx_bn254_msm_g2, gnark-crypto G2Affine words).  The points are 1 024 distinct curve points tiled (made by the
@@ -1445,6 +1513,8 @@ def main():
         out = run_ntt24(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "msm24":
         out = (run_msm24_g2 if args.msm_group == "g2" else run_msm24)(args, nlx, torch, rank, world, local, dist)
+    elif args.workload == "plonk24":
+        out = run_plonk24(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "stark":
         out = run_stark(args, nlx, torch, rank, world, local, dist)
     elif args.workload == "ed25519":

@@ -267,11 +267,12 @@ def _fr_words(x):
     return np.array([(int(x) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(4)], dtype=np.uint64)
 
 
-def bn254_plonk_quotient(ctx, polys, coset_shift, k1, k2, alpha, beta, gamma):
+def bn254_plonk_quotient(ctx, polys, coset_shift, k1, k2, alpha, beta, gamma, out=None):
     """The PLONK prover's quotient chain over BN254's scalar field (nlx_bn254_plonk_quotient).  polys: dict with the values on
     H of ql qr qm qo qk s1 s2 s3 l r o z and optionally pi, each an (n, 4) uint64 array of fr.Element words (Montgomery) or a
     device tensor of that shape; the six scalars: integers in Montgomery form.  Returns (t, ok): t = (3, n, 4) uint64, the
-    chunks t_lo, t_mid, t_hi; ok = the fourth chunk vanished (the witness satisfies the circuit)."""
+    chunks t_lo, t_mid, t_hi (or `out`, a device tensor of that shape, filled in place); ok = the fourth chunk vanished (the witness
+    satisfies the circuit)."""
     names = ("ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3", "l", "r", "o", "z")
     keep, args = [], _PlonkQuotientArgs()
     n = None
@@ -299,9 +300,11 @@ def bn254_plonk_quotient(ctx, polys, coset_shift, k1, k2, alpha, beta, gamma):
         w = _fr_words(x)
         keep.append(w)
         setattr(args, k, w.ctypes.data)
-    out = np.zeros((3, n, 4), dtype=np.uint64)
+    if out is None:
+        out = np.zeros((3, n, 4), dtype=np.uint64)
     ok = ctypes.c_int32()
-    ctx.check(dll.nlx_bn254_plonk_quotient(ctx.handle, ctypes.byref(args), out.ctypes.data, ctypes.byref(ok)))
+    ctx.check(dll.nlx_bn254_plonk_quotient(ctx.handle, ctypes.byref(args), out.data_ptr() if hasattr(out, "data_ptr") else out.ctypes.data,
+                                           ctypes.byref(ok)))
     return out, bool(ok.value)
 
 

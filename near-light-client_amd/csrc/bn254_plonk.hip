@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void k_plonk_quotient(QuotientParams p) {
 
 __global__ __launch_bounds__(256) void k_any_nonzero(const uint64_t* __restrict__ v, size_t words, uint32_t* __restrict__ flag) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < words && v[i]) atomicOr(flag, 1u);
+    const bool nz = i < words && v[i] != 0;
+    if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);   // one atomic per wave that saw anything
 }
 
 // ---- Horner scan: H_j = e_j + z H_{j-1} over a sequence in place (the synthetic division of a KZG opening) ----

@@ -119,3 +119,32 @@ def test_g2_model_and_host_sum(nlx):
         for p in chosen:
             want = bn.g2_add(want, p)
         assert nlx.bn254_g2_unpack(nlx.bn254_g2_sum(nlx.bn254_g2_pack(chosen))) == want
+
+
+def test_plonk_quotient_model_and_kzg_division():
+    """the big-integer model behind tests/test_gpu_bn254_plonk.py: a satisfying three-wire instance divides by Z_H (the quotient
+    has degree < 3n), a broken gate or a broken copy does not; synthetic division satisfies p = q (X - zeta) + p(zeta)"""
+    import random
+    import bn254_py as bn
+    rng = random.Random(21)
+    k1, k2 = 5, 25
+    alpha, beta, gamma = (rng.randrange(bn.R) for _ in range(3))
+    for log_n in (2, 4):
+        n = 1 << log_n
+        p = bn.plonk_witness(log_n, rng, k1, k2, beta, gamma)
+        t = bn.plonk_quotient(p, 5, k1, k2, alpha, beta, gamma)
+        assert not any(t[3 * n:]) and any(t[:3 * n])
+        bad = bn.plonk_witness(log_n, rng, k1, k2, beta, gamma, satisfied=False)
+        assert any(bn.plonk_quotient(bad, 5, k1, k2, alpha, beta, gamma)[3 * n:])
+        swapped = dict(p, s1=p["s2"], s2=p["s1"])             # a different permutation: z no longer matches it
+        assert any(bn.plonk_quotient(swapped, 5, k1, k2, alpha, beta, gamma)[3 * n:])
+    coeffs = [rng.randrange(bn.R) for _ in range(37)]
+    zeta = rng.randrange(bn.R)
+    y, q = bn.kzg_open(coeffs, zeta)
+    assert y == bn.eval_poly(coeffs, zeta) and len(q) == 36
+    back = [0] * 37
+    for i, qi in enumerate(q):
+        back[i + 1] = (back[i + 1] + qi) % bn.R
+        back[i] = (back[i] - zeta * qi) % bn.R
+    back[0] = (back[0] + y) % bn.R
+    assert back == coeffs
