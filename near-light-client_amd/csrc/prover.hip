@@ -56,33 +56,34 @@ uint32_t gate_num_constraints(const nlx_gate_desc& g) {
     }
 }
 
-// Cost of one gate's evaluation at one point, in microseconds of k_quotient's stage time per 2^19 points when every wave of a
-// tile evaluates that item alone (measured on MI355X with the calibration build, tools/quotient_calibrate.sh, standard
-// parameters; scaled linearly in the parameter that multiplies the work).  Only the RATIOS matter: they balance the work split.
+// Cost of one gate's evaluation at one point, in microseconds of k_quotient's time per 2^19 points when every wave of a
+// tile evaluates that item alone, less the 234 us an empty item list takes (measured on MI355X with the calibration build,
+// tools/quotient_calibrate.sh, standard parameters - round 3's kernel: profiles/r03_quotient_calibrate.txt; scaled linearly in
+// the parameter that multiplies the work).  Only the RATIOS matter: they balance the work split.
 uint32_t gate_eval_cost(const nlx_gate_desc& g) {
     const uint32_t p0 = g.param0, p1 = g.param1;
     switch (g.kind) {
-        case NLX_GATE_ARITHMETIC: return 10 + 9 * p0 / 2;
-        case NLX_GATE_BASE_SUM: return 10 + 84 * p1 * (1 + p0) / 30;      // 530 for 63 limbs in base 2
-        case NLX_GATE_POSEIDON: return 3170;                                // evaluated in three parts, see POSEIDON_PART_SHARE
-        case NLX_GATE_ARITHMETIC_EXT: return 10 + 12 * p0;
-        case NLX_GATE_MUL_EXT: return 10 + 10 * p0;
-        case NLX_GATE_REDUCING: return 10 + 114 * p0 / 10;
-        case NLX_GATE_REDUCING_EXT: return 10 + 103 * p0 / 10;
-        case NLX_GATE_POSEIDON_MDS: return 90;
-        case NLX_GATE_EXPONENTIATION: return 10 + 67 * p0 / 10;
-        case NLX_GATE_RANDOM_ACCESS: return 10 + 185 * (p1 & 0xFFFF) * (1u << p0) / 16;
-        case NLX_GATE_COSET_INTERPOLATION: return 10 + (34u << p0);
-        case NLX_GATE_U32_ADD_MANY: return 10 + 106 * p1;
-        case NLX_GATE_U32_ARITHMETIC: return 10 + 193 * p0;
-        case NLX_GATE_U32_SUBTRACTION: return 10 + 105 * p0;
-        case NLX_GATE_U32_RANGE_CHECK: return 10 + 84 * p0;
-        case NLX_GATE_COMPARISON: return 10 + 21 * p1;
+        case NLX_GATE_ARITHMETIC: return 10 + 6 * p0;                      // 130 for 20 operations
+        case NLX_GATE_BASE_SUM: return 10 + 95 * p1 * (1 + p0) / 30;      // 610 for 63 limbs in base 2
+        case NLX_GATE_POSEIDON: return 2540;                                // evaluated in three parts, see POSEIDON_PARTS
+        case NLX_GATE_ARITHMETIC_EXT: return 10 + 16 * p0;                 // 170
+        case NLX_GATE_MUL_EXT: return 10 + 13 * p0;                        // 180
+        case NLX_GATE_REDUCING: return 10 + 165 * p0 / 10;                 // 720
+        case NLX_GATE_REDUCING_EXT: return 10 + 160 * p0 / 10;             // 520
+        case NLX_GATE_POSEIDON_MDS: return 120;
+        case NLX_GATE_EXPONENTIATION: return 10 + 80 * p0 / 10;            // 540
+        case NLX_GATE_RANDOM_ACCESS: return 10 + 128 * (p1 & 0xFFFF) * (1u << p0) / 16;   // 520
+        case NLX_GATE_COSET_INTERPOLATION: return 10 + (34u << p0);        // 550
+        case NLX_GATE_U32_ADD_MANY: return 10 + 136 * p1;                  // 690
+        case NLX_GATE_U32_ARITHMETIC: return 10 + 250 * p0;                // 760
+        case NLX_GATE_U32_SUBTRACTION: return 10 + 132 * p0;               // 800
+        case NLX_GATE_U32_RANGE_CHECK: return 10 + 109 * p0;               // 770
+        case NLX_GATE_COMPARISON: return 10 + 27 * p1;                     // 440
         default: return 10;
     }
 }
 // PoseidonGate's three parts (prover_kernels.hip gate_poseidon): part mask, share of the gate's cost in percent
-constexpr uint32_t POSEIDON_PARTS[3][2] = {{1, 15}, {2, 68}, {4, 17}};
+constexpr uint32_t POSEIDON_PARTS[3][2] = {{1, 17}, {2, 59}, {4, 24}};   // measured 440 / 1 490 / 610
 }  // namespace
 
 struct nlx_circuit {
@@ -348,7 +349,7 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
                 items.push_back({cost, g});
             }
         }
-        for (uint32_t ch = 0; ch < d.num_challenges; ch++) items.push_back({10 + 51 * d.num_routed_wires / 4, d.num_gates + ch});  // 1 020 for 80 routed wires
+        for (uint32_t ch = 0; ch < d.num_challenges; ch++) items.push_back({10 + 45 * d.num_routed_wires / 4, d.num_gates + ch});  // 910 for 80 routed wires
         n_words = (uint32_t)items.size();
         std::sort(items.begin(), items.end(), [](const auto& a, const auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
         std::vector<std::vector<uint32_t>> bins(QWv);
