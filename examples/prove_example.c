@@ -4,6 +4,8 @@
  *
  *   gcc -O2 -I include examples/prove_example.c -L near-light-client_amd -lnlx -lnlx_synth \
  *       -Wl,-rpath,$PWD/near-light-client_amd -o /tmp/prove_example && /tmp/prove_example 12
+ *   /tmp/prove_example 12 lookups   the same circuit with two plonky2 lookup tables (LookupGate / LookupTableGate rows): the
+ *                                   descriptor's table arrays, a witness whose multiplicities the prover fills in
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -51,16 +53,22 @@ int main(int argc, char** argv) {
     sp.num_public_inputs = 4;
     sp.pct_poseidon = 20; sp.pct_arithmetic = 30; sp.pct_base_sum = 5; sp.pct_constant = 5; sp.pct_extension = 10;
     sp.seed = 42;
+    const int lookups = argc > 2 && strcmp(argv[2], "lookups") == 0;
+    if (lookups) { sp.num_luts = 2; sp.lut_bits = 8; sp.num_lookups = 300; }   /* two tables of 256 pairs, 300 lookups each */
+    const uint32_t n_lk_sel = lookups ? 4 + sp.num_luts : 0;   /* lookup selector columns between gate selectors and gate constants */
     uint32_t n_gates = 0, n_sel = 0;
     nlx_synth_shape(&sp, &n_gates, &n_sel);
 
     nlx_gate_desc* gates = calloc(n_gates, sizeof *gates);
     uint64_t* k_is = malloc(80 * 8);
-    uint64_t* constants = malloc((n_sel + 2) * n * 8);
+    uint64_t* constants = malloc((n_sel + n_lk_sel + 2) * n * 8);
     uint64_t* sigmas = malloc(80 * n * 8);
     uint64_t* wires = malloc(135 * n * 8);
     uint64_t pis[4];
-    CHECK(nlx_synth_circuit(&sp, gates, k_is, constants, sigmas, wires, pis));
+    uint32_t lut_sizes[2] = {256, 256}, lut_num_lookups[2] = {300, 300}, lookup_rows[2 * 3];
+    uint16_t* lut_pairs = malloc(2 * 256 * 2 * sizeof(uint16_t));
+    if (lookups) CHECK(nlx_synth_circuit_lookups(&sp, gates, k_is, constants, sigmas, wires, pis, lut_pairs, lookup_rows));
+    else CHECK(nlx_synth_circuit(&sp, gates, k_is, constants, sigmas, wires, pis));
 
     nlx_circuit_desc d;
     memset(&d, 0, sizeof d);
@@ -68,6 +76,10 @@ int main(int argc, char** argv) {
     d.rate_bits = 3; d.cap_height = 4; d.quotient_degree_factor = 8; d.num_partial_products = 9;
     d.fri_pow_bits = 16; d.fri_num_queries = 28; d.fri_arity_bits = 4; d.fri_final_poly_bits = 5;
     d.num_selectors = n_sel; d.num_gates = n_gates; d.num_public_inputs = 4; d.gates = gates; d.k_is = k_is;
+    if (lookups) {   /* CommonCircuitData::luts, ProverOnlyCircuitData::{lookup_rows, lut_to_lookups} - a zero tail means no tables */
+        d.num_luts = sp.num_luts; d.lut_sizes = lut_sizes; d.lut_pairs = lut_pairs; d.lookup_rows = lookup_rows;
+        d.lut_num_lookups = lut_num_lookups;
+    }
 
     nlx_circuit* circuit = NULL;
     CHECK(nlx_circuit_build(ctx, &d, constants, sigmas, &circuit));
@@ -83,10 +95,10 @@ int main(int argc, char** argv) {
     }
     uint64_t digest[4];
     CHECK(nlx_circuit_digest(circuit, digest));
-    printf("ok: 2^%u rows, %u gates, %u selectors, proof %zu bytes, circuit digest %016llx...\n", log_n, n_gates, n_sel, l1,
-           (unsigned long long)digest[0]);
+    printf("ok: 2^%u rows, %u gates, %u selectors, %u lookup tables, proof %zu bytes, circuit digest %016llx...\n", log_n, n_gates,
+           n_sel, d.num_luts, l1, (unsigned long long)digest[0]);
     nlx_circuit_destroy(circuit);
     nlx_ctx_destroy(ctx);
-    free(gates); free(k_is); free(constants); free(sigmas); free(wires); free(p1); free(p2);
+    free(gates); free(k_is); free(constants); free(sigmas); free(wires); free(p1); free(p2); free(lut_pairs);
     return 0;
 }

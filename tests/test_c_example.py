@@ -47,6 +47,25 @@ def test_c_caller_sees_return_codes_for_failed_allocations(nlx, tmp_path):
     assert lines[0].startswith("refused: host allocation -2") and lines[1].startswith("ok: 2^9 rows")
 
 
+@pytest.mark.gpu
+def test_c_caller_proves_a_circuit_with_lookup_tables(nlx, ctx, orc, tmp_path):
+    """the descriptor's table arrays from plain C; the proof has the size the Python path's (byte-equal to the oracle's,
+    tests/test_gpu_lookup.py) has for the same circuit"""
+    exe = _build(tmp_path)
+    r = subprocess.run([exe, "11", "lookups"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("ok: 2^11 rows") and "2 lookup tables" in r.stdout
+    syn = nlx.SyntheticCircuit(11, seed=42, num_public_inputs=4, pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5, pct_constant=5,
+                               pct_extension=10, num_luts=2, lut_bits=8, num_lookups=300)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    got = cd.prove(syn.wires, syn.public_inputs)
+    ref = orc.Circuit.from_synthetic(syn)
+    assert got == ref.prove(syn.wires, syn.public_inputs)
+    assert "proof %d bytes" % len(got) in r.stdout and "circuit digest %016x" % int(cd.circuit_digest[0]) in r.stdout
+    cd.close()
+    ref.close()
+
+
 def test_c_stark_caller_builds(nlx, tmp_path):
     _build(tmp_path, "stark_example")
 
