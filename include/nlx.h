@@ -209,6 +209,20 @@ typedef struct {
     const uint64_t *alpha, *beta, *gamma;
 } nlx_bn254_plonk_quotient_args;
 int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_args* args, uint64_t* t_out, int32_t* high_chunk_is_zero);
+/* The permutation's grand product (gnark computeZ / the paper's round 2): z(w^0) = 1,
+ * z(w^(i+1)) = z(w^i) prod_j (w_j(i) + beta id_j(i) + gamma) / (w_j(i) + beta s_j(i) + gamma), id = (w^i, k1 w^i, k2 w^i).
+ * One inversion per 64 rows (batch inversion), the running product as a multi-level scan.  All inputs n x 4 words on H in
+ * natural order, host or device; beta, gamma, k1, k2 host; z_out: n x 4 words, host or device.  *closes (may be NULL): 1 if
+ * the product returns to 1 after the last row - it does exactly when the wires respect the permutation. */
+int32_t nlx_bn254_plonk_grand_product(nlx_ctx* ctx, uint32_t log_n, const uint64_t* l, const uint64_t* r, const uint64_t* o,
+                                      const uint64_t* s1, const uint64_t* s2, const uint64_t* s3, const uint64_t beta[4],
+                                      const uint64_t gamma[4], const uint64_t k1[4], const uint64_t k2[4], uint64_t* z_out,
+                                      int32_t* closes);
+/* out[i] = sum_t scalars[t] * polys[t][i], i < m: the linearisation polynomial and the batched opening polynomial of the last
+ * round.  polys: host array of n_terms (<= 16) pointers, each to m x 4 words (host or device); scalars: host, n_terms x 4 words;
+ * out: m x 4 words, host or device (may alias one of the inputs). */
+int32_t nlx_bn254_fr_lincomb(nlx_ctx* ctx, uint64_t m, uint32_t n_terms, const uint64_t* const* polys, const uint64_t* scalars,
+                             uint64_t* out);
 /* One KZG opening (gnark-crypto kzg.Open): coeffs = m coefficients (natural order, host or device), zeta = the point (host).
  * y_out = p(zeta); quotient_out (may be NULL; host or device, m - 1 coefficients) = (p(X) - p(zeta)) / (X - zeta) - the
  * running Horner values, computed as a parallel scan; proof_out (may be NULL) = its commitment sum_i q_i srs[i] over the first

@@ -1,0 +1,181 @@
+"""Row f.4: a whole (unblinded) PLONK proof over BN254 on the GPU, assembled from the C-ABI pieces - the host-side mirror of
+what gnark's backend/plonk/bn254 `Prove` orchestrates for the recursive wrap (Go, not in /root/reference; succinct.json:7-8
+names the entry point that runs it).  The five rounds of the published protocol (Gabizon-Williamson-Ciobotaru), each round's
+heavy step one library call on device-resident polynomials:
+
+  1. [a] [b] [c]                      FFTInverse (nlx_bn254_ntt_batch) + three MSMs (nlx_bn254_msm_g1)
+  2. beta, gamma -> z, [z]            nlx_bn254_plonk_grand_product + FFTInverse + MSM
+  3. alpha -> t, [t_lo] [t_mid] [t_hi]  nlx_bn254_plonk_quotient + three MSMs
+  4. zeta -> six evaluations          nlx_bn254_kzg_open (value only)
+  5. v -> [W_zeta], [W_zeta_omega]    nlx_bn254_fr_lincomb (the linearisation polynomial and the batch in ONE combination of
+                                      fifteen polynomials), nlx_bn254_kzg_open twice (synthetic division + MSM)
+
+What this is not: gnark's byte format, blinding, its fiat-shamir labels (the transcript below is this repo's own SHA-256
+chain) or the wrapper circuit - a maintainer wires the same calls into gnark's rounds.  Parity: the
+proof's nine points and six scalars equal the big-integer model's (oracle/bn254_py.py plonk_prove_model) and the model's
+verifier accepts them (tests/test_gpu_bn254_plonk.py)."""
+import hashlib
+
+import numpy as np
+
+from . import batch as B
+
+R = B.BN254_R
+_MONT = (1 << 256) % R
+_MONT_INV = pow(_MONT, R - 2, R)
+
+
+def _to_mont(x):
+    return int(x) * _MONT % R
+
+
+def _from_words_mont(w):
+    return sum(int(w[k]) << (64 * k) for k in range(4)) * _MONT_INV % R
+
+
+def root_of_unity(log_n):
+    return pow(pow(5, (R - 1) >> 28, R), 1 << (28 - log_n), R)
+
+
+class Transcript:
+    """SHA-256 chain over 32-byte big-endian integers; a challenge is the chain value mod r (this repo's convention)."""
+
+    def __init__(self, label=b"nlx-plonk-bn254"):
+        self.state = hashlib.sha256(label).digest()
+
+    def absorb_int(self, x):
+        self.state = hashlib.sha256(self.state + int(x).to_bytes(32, "big")).digest()
+
+    def absorb_point(self, words):
+        pt = B.bn254_g1_unpack(words)
+        x, y = (0, 0) if pt is None else pt
+        self.absorb_int(x)
+        self.absorb_int(y)
+
+    def challenge(self, label):
+        self.state = hashlib.sha256(self.state + label).digest()
+        return int.from_bytes(self.state, "big") % R
+
+
+class ProvingKey:
+    """The preprocessed circuit on the device: the eight fixed polynomials by values on H and by coefficients, their
+    commitments, the SRS.  Everything is fr.Element / G1Affine words (Montgomery) in torch int64 tensors."""
+
+    NAMES = ("ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3")
+
+    def __init__(self, ctx, values, srs, k1, k2, device="cuda:0"):
+        """values: dict name -> n integers (canonical, values on H); srs: (>= n, 8) G1Affine words (array or device tensor)"""
+        import torch
+        self.ctx, self.device = ctx, device
+        self.n = len(values["ql"])
+        self.log_n = self.n.bit_length() - 1
+        self.k1, self.k2 = int(k1), int(k2)
+        self.srs = srs if hasattr(srs, "data_ptr") else torch.from_numpy(np.ascontiguousarray(srs, dtype=np.uint64).view(np.int64)).to(device)
+        packed = B.bn254_pack([[_to_mont(x) for x in values[k]] for k in self.NAMES])
+        self.values = torch.from_numpy(packed.view(np.int64)).to(device)                      # (8, n, 4)
+        self.coeffs = B.bn254_ntt(ctx, self.values.clone(), inverse=True, montgomery=True)     # in place on the clone
+        self.commitments = {k: B.bn254_msm_g1(ctx, self.srs[:self.n], self.coeffs[i], montgomery=True) for i, k in enumerate(self.NAMES)}
+
+    def value(self, name):
+        return self.values[self.NAMES.index(name)]
+
+    def coeff(self, name):
+        return self.coeffs[self.NAMES.index(name)]
+
+
+def prove(pk, l, r, o, public_inputs=()):
+    """l, r, o: the wire values on H (n canonical integers each).  Returns the proof: nine G1Affine word arrays and six
+    integers, under the keys of the model's proof dict."""
+    import torch
+    ctx, n, log_n = pk.ctx, pk.n, pk.log_n
+    w = root_of_unity(log_n)
+    commit = lambda c: B.bn254_msm_g1(ctx, pk.srs[:c.shape[0]], c, montgomery=True)
+    tr = Transcript()
+    tr.absorb_int(n)
+    for x in public_inputs:
+        tr.absorb_int(x)
+    for k in pk.NAMES:
+        tr.absorb_point(pk.commitments[k])
+    # round 1
+    wires = torch.from_numpy(B.bn254_pack([[_to_mont(x) for x in col] for col in (l, r, o)]).view(np.int64)).to(pk.device)   # (3, n, 4)
+    wire_coeffs = B.bn254_ntt(ctx, wires.clone(), inverse=True, montgomery=True)
+    proof = {"a": commit(wire_coeffs[0]), "b": commit(wire_coeffs[1]), "c": commit(wire_coeffs[2])}
+    for k in "abc":
+        tr.absorb_point(proof[k])
+    beta, gamma = tr.challenge(b"beta"), tr.challenge(b"gamma")
+    # round 2
+    z = torch.empty((n, 4), dtype=torch.int64, device=pk.device)
+    if not grand_product(ctx, log_n, wires[0], wires[1], wires[2], pk.value("s1"), pk.value("s2"), pk.value("s3"), beta, gamma, pk.k1, pk.k2, z):
+        raise ValueError("the wires do not respect the circuit's copy constraints (the grand product does not close)")
+    z_coeffs = B.bn254_ntt(ctx, z.clone().reshape(1, n, 4), inverse=True, montgomery=True)[0]
+    proof["z"] = commit(z_coeffs)
+    tr.absorb_point(proof["z"])
+    alpha = tr.challenge(b"alpha")
+    # round 3
+    polys = {k: pk.value(k) for k in pk.NAMES}
+    polys.update(l=wires[0], r=wires[1], o=wires[2], z=z)
+    t = torch.empty((3, n, 4), dtype=torch.int64, device=pk.device)
+    _, ok = B.bn254_plonk_quotient(ctx, polys, *[_to_mont(x) for x in (pk.k1, pk.k1, pk.k2, alpha, beta, gamma)], out=t)
+    if not ok:
+        raise ValueError("the witness does not satisfy the circuit (the quotient has a fourth chunk)")
+    for i, name in enumerate(("t_lo", "t_mid", "t_hi")):
+        proof[name] = commit(t[i])
+        tr.absorb_point(proof[name])
+    zeta = tr.challenge(b"zeta")
+    # round 4
+    at = lambda c, point: _from_words_mont(B.bn254_kzg_open(ctx, c, _to_mont(point), want_quotient=False)[0])
+    ev = {"a": at(wire_coeffs[0], zeta), "b": at(wire_coeffs[1], zeta), "c": at(wire_coeffs[2], zeta),
+          "s1": at(pk.coeff("s1"), zeta), "s2": at(pk.coeff("s2"), zeta), "zw": at(z_coeffs, zeta * w % R)}
+    for k in ("a", "b", "c", "s1", "s2", "zw"):
+        tr.absorb_int(ev[k])
+    v = tr.challenge(b"v")
+    # round 5: F = r + v a + v^2 b + v^3 c + v^4 s1 + v^5 s2 as ONE combination; its opening at zeta is W_zeta
+    sc = linearisation_scalars(ev, n, zeta, alpha, beta, gamma, pk.k1, pk.k2, v)
+    terms = {"qm": pk.coeff("qm"), "ql": pk.coeff("ql"), "qr": pk.coeff("qr"), "qo": pk.coeff("qo"), "qk": pk.coeff("qk"), "z": z_coeffs,
+             "s3": pk.coeff("s3"), "t_lo": t[0], "t_mid": t[1], "t_hi": t[2], "a": wire_coeffs[0], "b": wire_coeffs[1], "c": wire_coeffs[2],
+             "s1": pk.coeff("s1"), "s2": pk.coeff("s2")}
+    f = torch.empty((n, 4), dtype=torch.int64, device=pk.device)
+    lincomb(ctx, [terms[k] for k in sc], [sc[k] for k in sc], f)
+    proof["w_zeta"] = B.bn254_kzg_open(ctx, f, _to_mont(zeta), srs=pk.srs, want_quotient=False)[2]
+    proof["w_zeta_omega"] = B.bn254_kzg_open(ctx, z_coeffs, _to_mont(zeta * w % R), srs=pk.srs, want_quotient=False)[2]
+    proof["evals"] = ev
+    return proof
+
+
+def linearisation_scalars(ev, n, zeta, alpha, beta, gamma, k1, k2, v):
+    """coefficients of the fifteen polynomials in F(X) (the published round 5, constants dropped: they do not reach a quotient)"""
+    zh = (pow(zeta, n, R) - 1) % R
+    l1 = zh * pow(n * (zeta - 1) % R, R - 2, R) % R
+    a, b, c, s1, s2, zw = (ev[k] for k in ("a", "b", "c", "s1", "s2", "zw"))
+    zn = pow(zeta, n, R)
+    return {"qm": a * b % R, "ql": a, "qr": b, "qo": c, "qk": 1,
+            "z": (alpha * (a + beta * zeta + gamma) % R * (b + beta * k1 * zeta + gamma) % R * (c + beta * k2 * zeta + gamma) + alpha * alpha % R * l1) % R,
+            "s3": (-alpha * (a + beta * s1 + gamma) % R * (b + beta * s2 + gamma) % R * beta % R * zw) % R,
+            "t_lo": (-zh) % R, "t_mid": (-zh * zn) % R, "t_hi": (-zh * zn % R * zn) % R,
+            "a": v, "b": v * v % R, "c": pow(v, 3, R), "s1": pow(v, 4, R), "s2": pow(v, 5, R)}
+
+
+def grand_product(ctx, log_n, l, r, o, s1, s2, s3, beta, gamma, k1, k2, z_out):
+    """nlx_bn254_plonk_grand_product on device tensors / host arrays of fr.Element words; scalars: canonical integers.
+    Returns whether the product closes."""
+    import ctypes
+    from ._lib import dll
+    keep = [B._fr_words(_to_mont(x)) for x in (beta, gamma, k1, k2)]
+    ptr = lambda a: a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data
+    closes = ctypes.c_int32()
+    ctx.check(dll.nlx_bn254_plonk_grand_product(ctx.handle, log_n, ptr(l), ptr(r), ptr(o), ptr(s1), ptr(s2), ptr(s3),
+                                                keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, keep[3].ctypes.data,
+                                                ptr(z_out), ctypes.byref(closes)))
+    return bool(closes.value)
+
+
+def lincomb(ctx, polys, scalars, out):
+    """out = sum_t scalars[t] polys[t] (nlx_bn254_fr_lincomb): polys device tensors / host arrays (m, 4), scalars canonical integers"""
+    import ctypes
+    from ._lib import dll
+    ptr = lambda a: a.data_ptr() if hasattr(a, "data_ptr") else a.ctypes.data
+    m = polys[0].shape[0]
+    arr = (ctypes.c_void_p * len(polys))(*[ptr(p) for p in polys])
+    sc = np.stack([B._fr_words(_to_mont(s)) for s in scalars])
+    ctx.check(dll.nlx_bn254_fr_lincomb(ctx.handle, m, len(polys), arr, sc.ctypes.data, ptr(out)))
+    return out

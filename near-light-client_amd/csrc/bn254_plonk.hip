@@ -252,6 +252,107 @@ __global__ void k_horner_powers(const uint64_t* __restrict__ z_d, uint64_t* __re
     }
 }
 
+// ---- the permutation's grand product: z_0 = 1, z_{i+1} = z_i prod_j (w_j + beta id_j + gamma) / (w_j + beta sigma_j + gamma) ----
+// k_gp_ratios: one lane per run of GP_RUN rows - the rows' ratios with ONE inversion per run (Montgomery's trick: the
+// denominators' prefix products parked in the output), in I-form, written one place on (slot i + 1 = ratio_i, slot 0 = 1), so
+// that an inclusive product scan leaves z in place; the last row's ratio goes to `last` (z_{n-1} ratio_{n-1} must be 1).
+constexpr uint32_t GP_RUN = 64;
+struct GrandProductParams {
+    const uint64_t *l, *r, *o, *s1, *s2, *s3;
+    const uint64_t* sc;   // device: beta, gamma, k1, k2 (D-form words)
+    uint64_t* z;          // n elements
+    uint64_t* last;       // 1 element: ratio_{n-1}, I-form
+    uint32_t log_n;
+};
+__global__ __launch_bounds__(64) void k_gp_ratios(GrandProductParams p) {
+    const size_t n = (size_t)1 << p.log_n;
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * GP_RUN;
+    if (i0 >= n) return;
+    const size_t i1 = i0 + GP_RUN < n ? i0 + GP_RUN : n;
+    const Fe beta = ld(p.sc, 0), gamma = ld(p.sc, 1), beta_i = x32(beta);
+    const Fe bk1 = mul(beta, x32(ld(p.sc, 2))), bk2 = mul(beta, x32(ld(p.sc, 3)));   // D x I -> D
+    Fe w = root28_i();
+    for (uint32_t k = p.log_n; k < 28; k++) w = mul(w, w);
+    auto den_of = [&](size_t i) {   // I-form
+        Fe d = mul_dd(add(add(ld(p.l, i), mul(ld(p.s1, i), beta_i)), gamma), add(add(ld(p.r, i), mul(ld(p.s2, i), beta_i)), gamma));
+        return x32(mul_dd(d, add(add(ld(p.o, i), mul(ld(p.s3, i), beta_i)), gamma)));
+    };
+    Fe acc = one_i();
+#pragma unroll 1
+    for (size_t i = i0; i < i1; i++) {
+        acc = mul(acc, den_of(i));
+        if (i + 1 < i1) st(p.z, i + 1, acc);   // prefix product up to row i, parked where row i's ratio will go
+    }
+    Fe inv = inv_i(acc);
+    Fe x = pow_i(w, i1 - 1);                   // the run's last point, then downwards by w^-1 = w^(n-1)
+    const Fe winv = pow_i(w, n - 1);
+#pragma unroll 1
+    for (size_t i = i1; i-- > i0;) {
+        const Fe prev = i > i0 ? ld(p.z, i) : one_i();   // prefix product up to row i - 1
+        const Fe dinv = mul(inv, prev);
+        inv = mul(inv, den_of(i));
+        Fe num = mul_dd(add(add(ld(p.l, i), mul(beta, x)), gamma), add(add(ld(p.r, i), mul(bk1, x)), gamma));
+        num = mul_dd(num, add(add(ld(p.o, i), mul(bk2, x)), gamma));
+        const Fe ratio = mul(num, dinv);       // D x I -> D; the scan wants I-form
+        if (i + 1 < n) st(p.z, i + 1, x32(ratio));
+        else st(p.last, 0, x32(ratio));
+        x = mul(x, winv);
+    }
+    if (i0 == 0) st(p.z, 0, one_i());
+}
+// inclusive product scan in place (I-form), runs of SCAN_RUN per lane; to_d: the finished values leave in D-form
+__global__ __launch_bounds__(64) void k_mulscan_local(const uint64_t* __restrict__ seq, size_t len, uint64_t* __restrict__ runs) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, j0 = t * SCAN_RUN;
+    if (j0 >= len) return;
+    const size_t j1 = j0 + SCAN_RUN < len ? j0 + SCAN_RUN : len;
+    Fe h = one_i();
+#pragma unroll 1
+    for (size_t j = j0; j < j1; j++) h = mul(h, ld(seq, j));
+    st(runs, t, h);
+}
+__global__ __launch_bounds__(64) void k_mulscan_final(uint64_t* __restrict__ seq, size_t len, const uint64_t* __restrict__ runs_done, int to_d) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, j0 = t * SCAN_RUN;
+    if (j0 >= len) return;
+    const size_t j1 = j0 + SCAN_RUN < len ? j0 + SCAN_RUN : len;
+    Fe h = (t && runs_done) ? ld(runs_done, t - 1) : one_i();
+    const Fe c = one_d();   // the integer 2^256 mod r: I x plain -> D
+#pragma unroll 1
+    for (size_t j = j0; j < j1; j++) {
+        h = mul(h, ld(seq, j));
+        st(seq, j, to_d ? mul(h, c) : h);
+    }
+}
+// closes = (z_{n-1} ratio_{n-1} == 1): what a consistent permutation gives
+__global__ void k_gp_closes(const uint64_t* __restrict__ z_d, size_t n, const uint64_t* __restrict__ last_i, uint32_t* __restrict__ flag) {
+    if (threadIdx.x || blockIdx.x) return;
+    const Fe v = f29::canonical<RM>(mul(ld(z_d, n - 1), ld(last_i, 0)));   // D x I -> D
+    const Fe o = f29::canonical<RM>(one_d());
+    uint32_t diff = 0;
+    for (int i = 0; i < f29::NL; i++) diff |= v.v[i] ^ o.v[i];
+    *flag = diff ? 1u : 0u;
+}
+
+// out[i] = sum_t scalars[t] polys[t][i]: linearisation and batching polynomials of the last round
+__global__ void k_to_iform(uint64_t* __restrict__ sc, uint32_t count) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) st(sc, t, x32(ld(sc, t)));
+}
+constexpr uint32_t LINCOMB_MAX_TERMS = 16;
+struct LincombParams {
+    const uint64_t* polys[LINCOMB_MAX_TERMS];
+    const uint64_t* sc_i;   // device: the scalars, I-form
+    uint64_t* out;
+    size_t m;
+    uint32_t n_terms;
+};
+__global__ __launch_bounds__(256) void k_lincomb(LincombParams p) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.m) return;
+    Fe acc = f29::zero();
+    for (uint32_t t = 0; t < p.n_terms; t++) acc = add(acc, mul(ld(p.polys[t], i), ld(p.sc_i, t)));
+    st(p.out, i, acc);
+}
+
 }  // namespace bnp
 }  // namespace nlx
 
@@ -276,9 +377,124 @@ int32_t horner_scan(nlx_ctx* ctx, uint64_t* seq, size_t len, int rev, const uint
     hipLaunchKernelGGL(bnp::k_horner_final, dim3(blocks), dim3(64), 0, st, seq, len, rev, d_zpow + 4 * level, d_runs);
     return NLX_OK;
 }
+
+// inclusive product scan of seq (I-form) in place; to_d on the outermost level only
+int32_t mul_scan(nlx_ctx* ctx, uint64_t* seq, size_t len, int to_d, std::vector<void*>& tmp) {
+    hipStream_t st = ctx->stream;
+    const size_t runs = (len + bnp::SCAN_RUN - 1) / bnp::SCAN_RUN;
+    if (runs <= 1) {
+        hipLaunchKernelGGL(bnp::k_mulscan_final, dim3(1), dim3(64), 0, st, seq, len, (const uint64_t*)nullptr, to_d);
+        return NLX_OK;
+    }
+    uint64_t* d_runs = (uint64_t*)ctx->alloc(runs * 32);
+    if (!d_runs) return NLX_E_NOMEM;
+    tmp.push_back(d_runs);
+    const unsigned blocks = (unsigned)((runs + 63) / 64);
+    hipLaunchKernelGGL(bnp::k_mulscan_local, dim3(blocks), dim3(64), 0, st, seq, len, d_runs);
+    const int32_t rc = mul_scan(ctx, d_runs, runs, 0, tmp);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bnp::k_mulscan_final, dim3(blocks), dim3(64), 0, st, seq, len, d_runs, to_d);
+    return NLX_OK;
+}
 }  // namespace
 
 extern "C" {
+
+int32_t nlx_bn254_plonk_grand_product(nlx_ctx* ctx, uint32_t log_n, const uint64_t* l, const uint64_t* r, const uint64_t* o,
+                                      const uint64_t* s1, const uint64_t* s2, const uint64_t* s3, const uint64_t beta[4],
+                                      const uint64_t gamma[4], const uint64_t k1[4], const uint64_t k2[4], uint64_t* z_out,
+                                      int32_t* closes) NLX_TRY {
+    if (!ctx) return NLX_E_INVAL;
+    if (!l || !r || !o || !s1 || !s2 || !s3 || !beta || !gamma || !k1 || !k2 || !z_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
+    if (log_n < 1 || log_n > 28) return ctx->fail(NLX_E_RANGE, "log_n must be in [1, 28]");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)1 << log_n;
+    std::vector<void*> tmp;
+    auto done = [&](int32_t code) {
+        (void)hipStreamSynchronize(st);
+        for (void* p : tmp) ctx->release(p);
+        return code;
+    };
+    const uint64_t* in[6] = {l, r, o, s1, s2, s3};
+    const uint64_t* dev[6];
+    for (int i = 0; i < 6; i++) {
+        if (is_device_ptr(in[i])) { dev[i] = in[i]; continue; }
+        uint64_t* d = (uint64_t*)ctx->alloc(n * 32);
+        if (!d) return done(NLX_E_NOMEM);
+        tmp.push_back(d);
+        hipError_t e = hipMemcpyAsync(d, in[i], n * 32, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return done(ctx->hip_fail(e, "hipMemcpyAsync"));
+        dev[i] = d;
+    }
+    uint64_t* d_z = is_device_ptr(z_out) ? z_out : (uint64_t*)ctx->alloc(n * 32);
+    uint64_t* d_small = (uint64_t*)ctx->alloc(4 * 32 + 32 + 64);
+    if (d_z && d_z != z_out) tmp.push_back(d_z);
+    if (d_small) tmp.push_back(d_small);
+    if (!d_z || !d_small) return done(NLX_E_NOMEM);
+    uint64_t h[16];
+    memcpy(h, beta, 32); memcpy(h + 4, gamma, 32); memcpy(h + 8, k1, 32); memcpy(h + 12, k2, 32);
+    hipError_t e = hipMemcpyAsync(d_small, h, sizeof h, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return done(ctx->hip_fail(e, "hipMemcpyAsync"));
+    uint32_t* d_flag = (uint32_t*)(d_small + 20);
+    bnp::GrandProductParams gp{dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], d_small, d_z, d_small + 16, log_n};
+    hipLaunchKernelGGL(bnp::k_gp_ratios, dim3((unsigned)(((n + bnp::GP_RUN - 1) / bnp::GP_RUN + 63) / 64)), dim3(64), 0, st, gp);
+    int32_t rc = mul_scan(ctx, d_z, n, 1, tmp);
+    if (rc) return done(rc);
+    hipLaunchKernelGGL(bnp::k_gp_closes, dim3(1), dim3(1), 0, st, d_z, n, d_small + 16, d_flag);
+    uint32_t flag = 0;
+    e = hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && d_z != z_out) e = hipMemcpyAsync(z_out, d_z, n * 32, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return done(ctx->hip_fail(e, "copy out"));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return done(ctx->hip_fail(le, "kernel launch"));
+    if (closes) *closes = flag ? 0 : 1;
+    return done(NLX_OK);
+} NLX_CATCH(ctx)
+
+int32_t nlx_bn254_fr_lincomb(nlx_ctx* ctx, uint64_t m, uint32_t n_terms, const uint64_t* const* polys, const uint64_t* scalars,
+                             uint64_t* out) NLX_TRY {
+    if (!ctx) return NLX_E_INVAL;
+    if (!polys || !scalars || !out) return ctx->fail(NLX_E_INVAL, "NULL argument");
+    if (n_terms < 1 || n_terms > bnp::LINCOMB_MAX_TERMS || m < 1 || m > ((uint64_t)1 << 28)) return ctx->fail(NLX_E_RANGE, "1 .. 16 terms of 1 .. 2^28 elements");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    std::vector<void*> tmp;
+    auto done = [&](int32_t code) {
+        (void)hipStreamSynchronize(st);
+        for (void* p : tmp) ctx->release(p);
+        return code;
+    };
+    bnp::LincombParams lp{};
+    for (uint32_t t = 0; t < n_terms; t++) {
+        if (!polys[t]) return done(ctx->fail(NLX_E_INVAL, "NULL polynomial"));
+        if (is_device_ptr(polys[t])) { lp.polys[t] = polys[t]; continue; }
+        uint64_t* d = (uint64_t*)ctx->alloc(m * 32);
+        if (!d) return done(NLX_E_NOMEM);
+        tmp.push_back(d);
+        hipError_t e = hipMemcpyAsync(d, polys[t], m * 32, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return done(ctx->hip_fail(e, "hipMemcpyAsync"));
+        lp.polys[t] = d;
+    }
+    uint64_t* d_sc = (uint64_t*)ctx->alloc((size_t)n_terms * 32);
+    uint64_t* d_out = is_device_ptr(out) ? out : (uint64_t*)ctx->alloc(m * 32);
+    if (d_sc) tmp.push_back(d_sc);
+    if (d_out && d_out != out) tmp.push_back(d_out);
+    if (!d_sc || !d_out) return done(NLX_E_NOMEM);
+    hipError_t e = hipMemcpy(d_sc, scalars, (size_t)n_terms * 32, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return done(ctx->hip_fail(e, "hipMemcpy"));
+    hipLaunchKernelGGL(bnp::k_to_iform, dim3(1), dim3(64), 0, st, d_sc, n_terms);
+    lp.sc_i = d_sc; lp.out = d_out; lp.m = m; lp.n_terms = n_terms;
+    hipLaunchKernelGGL(bnp::k_lincomb, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, lp);
+    if (d_out != out) e = hipMemcpyAsync(out, d_out, m * 32, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return done(ctx->hip_fail(e, "copy out"));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return done(ctx->hip_fail(le, "kernel launch"));
+    return done(NLX_OK);
+} NLX_CATCH(ctx)
 
 int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_args* a, uint64_t* t_out, int32_t* high_chunk_is_zero) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;

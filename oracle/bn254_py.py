@@ -285,3 +285,143 @@ def plonk_witness(log_n, rng, k1, k2, beta, gamma, satisfied=True):
         wires[2][rng.randrange(n)] += 1
     return {"ql": ql, "qr": qr, "qm": qm, "qo": qo, "qk": qk, "s1": sigma[0], "s2": sigma[1], "s3": sigma[2],
             "l": wires[0], "r": wires[1], "o": [x % R for x in wires[2]], "z": z}
+
+
+# ---- a whole (unblinded) PLONK proof over the pieces above: model prover and a trapdoor verifier ----
+import hashlib as _hashlib
+
+
+class PlonkTranscript:
+    """SHA-256 chain: absorb 32-byte big-endian integers; a challenge is the chain value read as an integer mod r.  This
+    repo's own convention (gnark's fiat-shamir labels and encodings are not reproduced): model and device prover share it."""
+
+    def __init__(self, label=b"nlx-plonk-bn254"):
+        self.state = _hashlib.sha256(label).digest()
+
+    def absorb_int(self, x):
+        self.state = _hashlib.sha256(self.state + int(x).to_bytes(32, "big")).digest()
+
+    def absorb_point(self, p):
+        x, y = (0, 0) if p is None else p
+        self.absorb_int(x)
+        self.absorb_int(y)
+
+    def challenge(self, label):
+        self.state = _hashlib.sha256(self.state + label).digest()
+        return int.from_bytes(self.state, "big") % R
+
+
+def kzg_srs(tau, size):
+    """[tau^i] G1, i < size (a test SRS whose trapdoor the test keeps)"""
+    out, t = [], 1
+    for _ in range(size):
+        out.append(g1_mul(t, G1))
+        t = t * tau % R
+    return out
+
+
+def plonk_prove_model(p, srs, k1, k2, public_inputs=()):
+    """p: plonk_witness()-style dict WITHOUT z (values on H).  Returns the proof as a dict of points / integers."""
+    n = len(p["l"])
+    log_n = n.bit_length() - 1
+    w = root_of_unity(log_n)
+    co = {k: ntt(v, inverse=True) for k, v in p.items() if k != "z" and v is not None}
+    com = lambda c: msm_g1(c, srs[:len(c)])
+    tr = PlonkTranscript()
+    tr.absorb_int(n)
+    for x in public_inputs:
+        tr.absorb_int(x)
+    for k in ("ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3"):
+        tr.absorb_point(com(co[k]))
+    proof = {"a": com(co["l"]), "b": com(co["r"]), "c": com(co["o"])}
+    for k in "abc":
+        tr.absorb_point(proof[k])
+    beta, gamma = tr.challenge(b"beta"), tr.challenge(b"gamma")
+    z, acc = [], 1
+    for i in range(n):
+        z.append(acc)
+        x = pow(w, i, R)
+        num = (p["l"][i] + beta * x + gamma) * (p["r"][i] + beta * k1 * x + gamma) * (p["o"][i] + beta * k2 * x + gamma) % R
+        den = (p["l"][i] + beta * p["s1"][i] + gamma) * (p["r"][i] + beta * p["s2"][i] + gamma) * (p["o"][i] + beta * p["s3"][i] + gamma) % R
+        acc = acc * num % R * pow(den, R - 2, R) % R
+    co["z"] = ntt(z, inverse=True)
+    proof["z"] = com(co["z"])
+    tr.absorb_point(proof["z"])
+    alpha = tr.challenge(b"alpha")
+    t = plonk_quotient(dict(p, z=z), k1, k1, k2, alpha, beta, gamma)
+    assert not any(t[3 * n:]), "the witness does not satisfy the circuit"
+    chunks = [t[0:n], t[n:2 * n], t[2 * n:3 * n]]
+    for name, c in zip(("t_lo", "t_mid", "t_hi"), chunks):
+        proof[name] = com(c)
+        tr.absorb_point(proof[name])
+    zeta = tr.challenge(b"zeta")
+    ev = {"a": eval_poly(co["l"], zeta), "b": eval_poly(co["r"], zeta), "c": eval_poly(co["o"], zeta),
+          "s1": eval_poly(co["s1"], zeta), "s2": eval_poly(co["s2"], zeta), "zw": eval_poly(co["z"], zeta * w % R)}
+    for k in ("a", "b", "c", "s1", "s2", "zw"):
+        tr.absorb_int(ev[k])
+    v = tr.challenge(b"v")
+    terms = plonk_linearisation_scalars(ev, n, zeta, alpha, beta, gamma, k1, k2, v)
+    polys = {"qm": co["qm"], "ql": co["ql"], "qr": co["qr"], "qo": co["qo"], "qk": co["qk"], "z": co["z"], "s3": co["s3"],
+             "t_lo": chunks[0], "t_mid": chunks[1], "t_hi": chunks[2], "a": co["l"], "b": co["r"], "c": co["o"], "s1": co["s1"], "s2": co["s2"]}
+    f = [sum(terms[k] * polys[k][i] for k in terms) % R for i in range(n)]
+    _, wz = kzg_open(f, zeta)
+    _, wzw = kzg_open(co["z"], zeta * w % R)
+    proof["w_zeta"], proof["w_zeta_omega"] = com(wz), com(wzw)
+    proof["evals"] = ev
+    return proof
+
+
+def plonk_linearisation_scalars(ev, n, zeta, alpha, beta, gamma, k1, k2, v):
+    """coefficients of the polynomials in F(X) = r(X) + v a + v^2 b + v^3 c + v^4 s1 + v^5 s2 (the batched opening at zeta)"""
+    zh = (pow(zeta, n, R) - 1) % R
+    l1 = zh * pow(n * (zeta - 1) % R, R - 2, R) % R
+    a, b, c, s1, s2, zw = (ev[k] for k in ("a", "b", "c", "s1", "s2", "zw"))
+    zn = pow(zeta, n, R)
+    return {"qm": a * b % R, "ql": a, "qr": b, "qo": c, "qk": 1,
+            "z": (alpha * (a + beta * zeta + gamma) % R * (b + beta * k1 * zeta + gamma) % R * (c + beta * k2 * zeta + gamma) + alpha * alpha % R * l1) % R,
+            "s3": (-alpha * (a + beta * s1 + gamma) % R * (b + beta * s2 + gamma) % R * beta % R * zw) % R,
+            "t_lo": (-zh) % R, "t_mid": (-zh * zn) % R, "t_hi": (-zh * zn % R * zn) % R,
+            "a": v, "b": v * v % R, "c": pow(v, 3, R), "s1": pow(v, 4, R), "s2": pow(v, 5, R)}
+
+
+def plonk_verify_trapdoor(proof, vk, tau, k1, k2, public_inputs=(), pi_at=None):
+    """The PLONK verifier's equations with the pairing replaced by the SRS's trapdoor (a test SRS: tau is known):
+    [F] - E G = (tau - zeta) [W_zeta] and [z] - zw G = (tau - zeta w) [W_zeta_omega].  vk: commitments of the eight
+    preprocessed polynomials and n.  pi_at(zeta) = the public-input polynomial's value (0 without one)."""
+    n = vk["n"]
+    w = root_of_unity(n.bit_length() - 1)
+    tr = PlonkTranscript()
+    tr.absorb_int(n)
+    for x in public_inputs:
+        tr.absorb_int(x)
+    for k in ("ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3"):
+        tr.absorb_point(vk[k])
+    for k in "abc":
+        tr.absorb_point(proof[k])
+    beta, gamma = tr.challenge(b"beta"), tr.challenge(b"gamma")
+    tr.absorb_point(proof["z"])
+    alpha = tr.challenge(b"alpha")
+    for k in ("t_lo", "t_mid", "t_hi"):
+        tr.absorb_point(proof[k])
+    zeta = tr.challenge(b"zeta")
+    ev = proof["evals"]
+    for k in ("a", "b", "c", "s1", "s2", "zw"):
+        tr.absorb_int(ev[k])
+    v = tr.challenge(b"v")
+    sc = plonk_linearisation_scalars(ev, n, zeta, alpha, beta, gamma, k1, k2, v)
+    pts = {"qm": vk["qm"], "ql": vk["ql"], "qr": vk["qr"], "qo": vk["qo"], "qk": vk["qk"], "z": proof["z"], "s3": vk["s3"],
+           "t_lo": proof["t_lo"], "t_mid": proof["t_mid"], "t_hi": proof["t_hi"], "a": proof["a"], "b": proof["b"], "c": proof["c"],
+           "s1": vk["s1"], "s2": vk["s2"]}
+    keys = list(sc)
+    F = msm_g1([sc[k] for k in keys], [pts[k] for k in keys])
+    zh = (pow(zeta, n, R) - 1) % R
+    l1 = zh * pow(n * (zeta - 1) % R, R - 2, R) % R
+    a, b, c, s1, s2, zw = (ev[k] for k in ("a", "b", "c", "s1", "s2", "zw"))
+    pi = pi_at(zeta) if pi_at else 0
+    r0 = (pi - l1 * alpha * alpha - alpha * (a + beta * s1 + gamma) % R * (b + beta * s2 + gamma) % R * (c + gamma) % R * zw) % R
+    E = (-r0 + v * a + v * v * b + pow(v, 3, R) * c + pow(v, 4, R) * s1 + pow(v, 5, R) * s2) % R
+    lhs1 = g1_add(F, g1_neg(g1_mul(E, G1)))
+    rhs1 = g1_mul((tau - zeta) % R, proof["w_zeta"]) if proof["w_zeta"] is not None else None
+    lhs2 = g1_add(proof["z"], g1_neg(g1_mul(zw, G1)))
+    rhs2 = g1_mul((tau - zeta * w) % R, proof["w_zeta_omega"]) if proof["w_zeta_omega"] is not None else None
+    return lhs1 == rhs1 and lhs2 == rhs2

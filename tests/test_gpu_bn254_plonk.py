@@ -97,3 +97,63 @@ def test_kzg_opening_proof_is_the_commitment_of_the_quotient(nlx, ctx, bn):
     assert nlx.bn254_g1_unpack(proof) == bn.msm_g1(want_q, pts)
     # and it is what the MSM entry point gives for the returned quotient
     assert np.array_equal(proof, nlx.bn254_msm_g1(ctx, srs, q, montgomery=True))
+
+
+def _instance(bn, log_n, seed, k1=5, k2=25):
+    rng = random.Random(seed)
+    p = bn.plonk_witness(log_n, rng, k1, k2, 11, 13)
+    p.pop("z")
+    tau = rng.randrange(1, bn.R)
+    return p, tau
+
+
+@pytest.mark.parametrize("log_n", [3, 5, 7])
+def test_grand_product_and_lincomb_equal_model(nlx, ctx, bn, log_n):
+    import torch
+    rng = random.Random(log_n)
+    n, k1, k2 = 1 << log_n, 5, 25
+    beta, gamma = rng.randrange(bn.R), rng.randrange(bn.R)
+    p = bn.plonk_witness(log_n, rng, k1, k2, beta, gamma)       # its z is the model's grand product under these challenges
+    P = nlx.bn254_plonk
+    dev = {k: torch.from_numpy(nlx.bn254_pack([_mont(bn, p[k])])[0].view(np.int64)).cuda() for k in ("l", "r", "o", "s1", "s2", "s3")}
+    z = torch.empty((n, 4), dtype=torch.int64, device="cuda:0")
+    assert P.grand_product(ctx, log_n, dev["l"], dev["r"], dev["o"], dev["s1"], dev["s2"], dev["s3"], beta, gamma, k1, k2, z)
+    assert [bn.from_montgomery(x) for x in nlx.bn254_unpack(z.cpu().numpy().view(np.uint64)[None])[0]] == p["z"]
+    # host arrays in and out, and a permutation the wires do not respect
+    z_host = np.zeros((n, 4), dtype=np.uint64)
+    host = {k: v.cpu().numpy().view(np.uint64) for k, v in dev.items()}
+    assert not P.grand_product(ctx, log_n, host["l"], host["r"], host["o"], host["s2"], host["s1"], host["s3"], beta, gamma, k1, k2, z_host)
+    # lincomb
+    scal = [rng.randrange(bn.R) for _ in range(5)]
+    cols = [[rng.randrange(bn.R) for _ in range(n)] for _ in range(5)]
+    polys = [torch.from_numpy(nlx.bn254_pack([_mont(bn, c)])[0].view(np.int64)).cuda() for c in cols]
+    out = torch.empty((n, 4), dtype=torch.int64, device="cuda:0")
+    P.lincomb(ctx, polys, scal, out)
+    want = [sum(s * c[i] for s, c in zip(scal, cols)) % bn.R for i in range(n)]
+    assert [bn.from_montgomery(x) for x in nlx.bn254_unpack(out.cpu().numpy().view(np.uint64)[None])[0]] == want
+
+
+@pytest.mark.parametrize("log_n", [3, 6])
+def test_whole_plonk_proof_equals_model_and_verifies(nlx, ctx, bn, log_n):
+    """the five rounds on the device (near-light-client_amd/bn254_plonk.py) against the big-integer prover: nine commitments and
+    six evaluations equal, and the verifier's two opening equations hold (pairing replaced by the test SRS's trapdoor)"""
+    n, k1, k2 = 1 << log_n, 5, 25
+    p, tau = _instance(bn, log_n, 40 + log_n)
+    srs_pts = bn.kzg_srs(tau, n)
+    want = bn.plonk_prove_model(p, srs_pts, k1, k2)
+    P = nlx.bn254_plonk
+    pk = P.ProvingKey(ctx, p, nlx.bn254_g1_pack(srs_pts), k1, k2)
+    got = P.prove(pk, p["l"], p["r"], p["o"])
+    for k in ("a", "b", "c", "z", "t_lo", "t_mid", "t_hi", "w_zeta", "w_zeta_omega"):
+        assert nlx.bn254_g1_unpack(got[k]) == want[k], k
+    assert got["evals"] == want["evals"]
+    vk = {k: nlx.bn254_g1_unpack(pk.commitments[k]) for k in pk.NAMES}
+    vk["n"] = n
+    as_points = dict({k: nlx.bn254_g1_unpack(got[k]) for k in got if k != "evals"}, evals=got["evals"])
+    assert bn.plonk_verify_trapdoor(as_points, vk, tau, k1, k2)
+    assert not bn.plonk_verify_trapdoor(dict(as_points, evals=dict(got["evals"], zw=(got["evals"]["zw"] + 1) % bn.R)), vk, tau, k1, k2)
+    # a witness with a broken gate / a broken copy is refused before anything is committed to t
+    bad_o = list(p["o"])
+    bad_o[1] = (bad_o[1] + 1) % bn.R
+    with pytest.raises(ValueError):
+        P.prove(pk, p["l"], p["r"], bad_o)
