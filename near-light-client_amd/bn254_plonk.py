@@ -84,8 +84,8 @@ class ProvingKey:
 
 
 def prove(pk, l, r, o, public_inputs=()):
-    """l, r, o: the wire values on H (n canonical integers each).  Returns the proof: nine G1Affine word arrays and six
-    integers, under the keys of the model's proof dict."""
+    """l, r, o: the wire values on H - n canonical integers each, or (n, 4) device tensors of fr.Element words (Montgomery).
+    Returns the proof: nine G1Affine word arrays and six integers, under the keys of the model's proof dict."""
     import torch
     ctx, n, log_n = pk.ctx, pk.n, pk.log_n
     w = root_of_unity(log_n)
@@ -97,7 +97,10 @@ def prove(pk, l, r, o, public_inputs=()):
     for k in pk.NAMES:
         tr.absorb_point(pk.commitments[k])
     # round 1
-    wires = torch.from_numpy(B.bn254_pack([[_to_mont(x) for x in col] for col in (l, r, o)]).view(np.int64)).to(pk.device)   # (3, n, 4)
+    if hasattr(l, "data_ptr"):   # already fr.Element words on the device: (n, 4) tensors
+        wires = torch.stack([l, r, o])
+    else:
+        wires = torch.from_numpy(B.bn254_pack([[_to_mont(x) for x in col] for col in (l, r, o)]).view(np.int64)).to(pk.device)   # (3, n, 4)
     wire_coeffs = B.bn254_ntt(ctx, wires.clone(), inverse=True, montgomery=True)
     proof = {"a": commit(wire_coeffs[0]), "b": commit(wire_coeffs[1]), "c": commit(wire_coeffs[2])}
     for k in "abc":
