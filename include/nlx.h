@@ -223,6 +223,12 @@ int32_t nlx_bn254_plonk_grand_product(nlx_ctx* ctx, uint32_t log_n, const uint64
  * out: m x 4 words, host or device (may alias one of the inputs). */
 int32_t nlx_bn254_fr_lincomb(nlx_ctx* ctx, uint64_t m, uint32_t n_terms, const uint64_t* const* polys, const uint64_t* scalars,
                              uint64_t* out);
+/* Groth16's quotient (gnark backend/groth16/bn254 computeH): a, b, c = the values of A w, B w, C w on H (n x 4 words each,
+ * natural order, host or device) -> h = (a b - c) / (x^n - 1) as n coefficients (the top one is zero): three FFTInverse(DIF),
+ * three FFT(DIT, OnCoset) on the coset of the SAME size, one pointwise pass (the divisor is one constant there), one
+ * FFTInverse(OnCoset).  The proof's points are then nlx_bn254_msm_g1 / _g2 over the proving key's queries. */
+int32_t nlx_bn254_groth16_quotient(nlx_ctx* ctx, uint32_t log_n, const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                                   const uint64_t coset_shift[4], uint64_t* h_out);
 /* One KZG opening (gnark-crypto kzg.Open): coeffs = m coefficients (natural order, host or device), zeta = the point (host).
  * y_out = p(zeta); quotient_out (may be NULL; host or device, m - 1 coefficients) = (p(X) - p(zeta)) / (X - zeta) - the
  * running Horner values, computed as a parallel scan; proof_out (may be NULL) = its commitment sum_i q_i srs[i] over the first

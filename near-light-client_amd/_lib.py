@@ -86,6 +86,7 @@ SIGNATURES = {
     "nlx_bn254_plonk_quotient": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     "nlx_bn254_plonk_grand_product": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 11 + [ctypes.POINTER(ctypes.c_int32)]),
     "nlx_bn254_fr_lincomb": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "nlx_bn254_groth16_quotient": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 5),
     "nlx_bn254_kzg_open": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "nlx_commit_from_values": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,

@@ -182,3 +182,16 @@ def lincomb(ctx, polys, scalars, out):
     sc = np.stack([B._fr_words(_to_mont(s)) for s in scalars])
     ctx.check(dll.nlx_bn254_fr_lincomb(ctx.handle, m, len(polys), arr, sc.ctypes.data, ptr(out)))
     return out
+
+
+def groth16_quotient(ctx, a, b, c, coset_shift=5):
+    """nlx_bn254_groth16_quotient: a, b, c = values of A w, B w, C w on H ((n, 4) arrays or device tensors of fr.Element words);
+    returns h's n coefficients as a host array (n, 4)."""
+    from ._lib import dll
+    ptr = lambda x: x.data_ptr() if hasattr(x, "data_ptr") else np.ascontiguousarray(x, dtype=np.uint64).ctypes.data
+    n = a.shape[0]
+    keep = [x if hasattr(x, "data_ptr") else np.ascontiguousarray(x, dtype=np.uint64) for x in (a, b, c)]
+    sh = B._fr_words(_to_mont(coset_shift))
+    out = np.zeros((n, 4), dtype=np.uint64)
+    ctx.check(dll.nlx_bn254_groth16_quotient(ctx.handle, n.bit_length() - 1, ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), sh.ctypes.data, out.ctypes.data))
+    return out

@@ -332,6 +332,18 @@ __global__ void k_gp_closes(const uint64_t* __restrict__ z_d, size_t n, const ui
     *flag = diff ? 1u : 0u;
 }
 
+// Groth16's quotient on the coset of the SAME size: h = (a b - c) / (x^n - 1), the divisor one constant there
+__global__ __launch_bounds__(256) void k_g16_pointwise(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, const uint64_t* __restrict__ c,
+                                                       const uint64_t* __restrict__ zhinv_i, uint64_t* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st(out, i, mul(sub(mul_dd(ld(a, i), ld(b, i)), ld(c, i)), ld(zhinv_i, 0)));
+}
+__global__ void k_g16_const(const uint64_t* __restrict__ shift_d, uint32_t log_n, uint64_t* __restrict__ zhinv_i) {
+    if (threadIdx.x || blockIdx.x) return;
+    st(zhinv_i, 0, inv_i(sub(pow_i(x32(ld(shift_d, 0)), (uint64_t)1 << log_n), one_i())));
+}
+
 // out[i] = sum_t scalars[t] polys[t][i]: linearisation and batching polynomials of the last round
 __global__ void k_to_iform(uint64_t* __restrict__ sc, uint32_t count) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -451,6 +463,50 @@ int32_t nlx_bn254_plonk_grand_product(nlx_ctx* ctx, uint32_t log_n, const uint64
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return done(ctx->hip_fail(le, "kernel launch"));
     if (closes) *closes = flag ? 0 : 1;
+    return done(NLX_OK);
+} NLX_CATCH(ctx)
+
+int32_t nlx_bn254_groth16_quotient(nlx_ctx* ctx, uint32_t log_n, const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                                   const uint64_t coset_shift[4], uint64_t* h_out) NLX_TRY {
+    if (!ctx) return NLX_E_INVAL;
+    if (!a || !b || !c || !coset_shift || !h_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
+    if (log_n < 1 || log_n > 28) return ctx->fail(NLX_E_RANGE, "log_n must be in [1, 28]");
+    if (is_device_ptr(coset_shift)) return ctx->fail(NLX_E_INVAL, "the coset shift is a host value");
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)1 << log_n;
+    std::vector<void*> tmp;
+    auto done = [&](int32_t code) {
+        (void)hipStreamSynchronize(st);
+        for (void* p : tmp) ctx->release(p);
+        return code;
+    };
+    uint64_t* d_abc = (uint64_t*)ctx->alloc(3 * n * 32);
+    uint64_t* d_small = (uint64_t*)ctx->alloc(64);
+    if (d_abc) tmp.push_back(d_abc);
+    if (d_small) tmp.push_back(d_small);
+    if (!d_abc || !d_small) return done(NLX_E_NOMEM);
+    const uint64_t* in[3] = {a, b, c};
+    for (int i = 0; i < 3; i++) {
+        hipError_t e = hipMemcpyAsync(d_abc + (size_t)i * n * 4, in[i], n * 32, is_device_ptr(in[i]) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return done(ctx->hip_fail(e, "hipMemcpyAsync"));
+    }
+    hipError_t e = hipMemcpy(d_small, coset_shift, 32, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return done(ctx->hip_fail(e, "hipMemcpy"));
+    hipLaunchKernelGGL(bnp::k_g16_const, dim3(1), dim3(1), 0, st, d_small, log_n, d_small + 4);
+    // FFTInverse(DIF) -> FFT(DIT, OnCoset): no reordering pass; then a b - c over the coset's constant x^n - 1
+    int32_t rc = nlx_bn254_ntt_batch_coset(ctx, d_abc, 3, log_n, 1, NLX_BN254_MONTGOMERY | NLX_BN254_BITREV_OUT, nullptr);
+    if (!rc) rc = nlx_bn254_ntt_batch_coset(ctx, d_abc, 3, log_n, 0, NLX_BN254_MONTGOMERY | NLX_BN254_BITREV_IN, coset_shift);
+    if (rc) return done(rc);
+    hipLaunchKernelGGL(bnp::k_g16_pointwise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_abc, d_abc + n * 4, d_abc + 2 * n * 4,
+                       d_small + 4, d_abc, n);
+    rc = nlx_bn254_ntt_batch_coset(ctx, d_abc, 1, log_n, 1, NLX_BN254_MONTGOMERY, coset_shift);
+    if (rc) return done(rc);
+    e = hipMemcpyAsync(h_out, d_abc, n * 32, is_device_ptr(h_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return done(ctx->hip_fail(e, "copy out"));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return done(ctx->hip_fail(le, "kernel launch"));
     return done(NLX_OK);
 } NLX_CATCH(ctx)
 

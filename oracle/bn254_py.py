@@ -425,3 +425,17 @@ def plonk_verify_trapdoor(proof, vk, tau, k1, k2, public_inputs=(), pi_at=None):
     lhs2 = g1_add(proof["z"], g1_neg(g1_mul(zw, G1)))
     rhs2 = g1_mul((tau - zeta * w) % R, proof["w_zeta_omega"]) if proof["w_zeta_omega"] is not None else None
     return lhs1 == rhs1 and lhs2 == rhs2
+
+
+def groth16_quotient(a, b, c, shift=5):
+    """h = (A B - C) / Z_H from the three polynomials' values on H, on the coset shift * H of the same size (gnark computeH)"""
+    n = len(a)
+    ev = [coset_evals(v, shift, blowup_log=0) for v in (a, b, c)]
+    zhinv = pow((pow(shift, n, R) - 1) % R, R - 2, R)
+    t = [(x * y - z) % R * zhinv % R for x, y, z in zip(*ev)]
+    co = ntt(t, inverse=True)
+    sinv, s, out = pow(shift, R - 2, R), 1, []
+    for j in range(n):
+        out.append(co[j] * s % R)
+        s = s * sinv % R
+    return out

@@ -157,3 +157,20 @@ def test_whole_plonk_proof_equals_model_and_verifies(nlx, ctx, bn, log_n):
     bad_o[1] = (bad_o[1] + 1) % bn.R
     with pytest.raises(ValueError):
         P.prove(pk, p["l"], p["r"], bad_o)
+
+
+@pytest.mark.parametrize("log_n", [1, 4, 9, 12])
+def test_groth16_quotient_equals_model(nlx, ctx, bn, log_n):
+    """h = (a b - c) / Z_H for c = a b on H (an R1CS the witness satisfies): equal to the model's, a polynomial of degree < n - 1,
+    and a b - c = h Z_H at a random point"""
+    rng = random.Random(70 + log_n)
+    n = 1 << log_n
+    a = [rng.randrange(bn.R) for _ in range(n)]
+    b = [rng.randrange(bn.R) for _ in range(n)]
+    c = [x * y % bn.R for x, y in zip(a, b)]
+    pack = lambda v: nlx.bn254_pack([_mont(bn, v)])[0]
+    got = [bn.from_montgomery(x) for x in nlx.bn254_unpack(nlx.bn254_plonk.groth16_quotient(ctx, pack(a), pack(b), pack(c))[None])[0]]
+    assert got == bn.groth16_quotient(a, b, c) and got[-1] == 0
+    zeta = rng.randrange(bn.R)
+    A, Bp, C = (bn.eval_poly(bn.ntt(v, inverse=True), zeta) for v in (a, b, c))
+    assert (A * Bp - C) % bn.R == bn.eval_poly(got, zeta) * (pow(zeta, n, bn.R) - 1) % bn.R
