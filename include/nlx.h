@@ -535,7 +535,13 @@ typedef struct {
      * challenges of round 1 | ...  The proof only shows that the constraints hold for the values it carries; whoever
      * relies on the proof compares them with what they should be (e.g. the fingerprint of the claimed data). */
     uint32_t round_values[3];
-    uint32_t reserved2;
+    /* Openings digest.  0 = the transcript observes every opened value (starky's observe_openings: local ++ quotient at zeta,
+     * then the next values).  G > 0: it observes FOUR elements instead - that vector, zero-padded to a multiple of G, hashed
+     * in runs of G (hash_no_pad each) and the run digests hashed once more.  The binding is the same; the sequential absorption
+     * of 19 000 values on one host thread (2 400 permutations: 3 of the 8 ms of the Sync step's SHA-512 proof) becomes one
+     * small device launch and 150 host permutations.  Part of the statement digest when non-zero.
+     * 8 <= G <= 4096; a patch that must stay compatible with an unpatched starky verifier passes 0. */
+    uint32_t openings_group;
 } nlx_stark_desc;
 typedef struct nlx_stark nlx_stark;
 

@@ -315,7 +315,10 @@ static void air_digest_host(const nlx_stark_desc& d, const std::vector<uint64_t>
     for (uint32_t r = 0; r < 3; r++) v.push_back(r < d.n_rounds ? d.round_cols[r] : 0);
     for (uint32_t r = 0; r < 3; r++) v.push_back(r < d.n_rounds ? d.round_challenges[r] : 0);
     for (uint32_t r = 0; r < 3; r++) v.push_back(r < d.n_rounds ? d.round_values[r] : 0);
-    if (d.leaf_group_cols) v.push_back(d.leaf_group_cols);  // only when used: digests of whole-row statements stay what they were
+    if (d.leaf_group_cols || d.openings_group) {  // only when used: digests of plain-starky statements stay what they were
+        v.push_back(d.leaf_group_cols);
+        v.push_back(d.openings_group);
+    }
     for (uint64_t w : prog) { v.push_back(w & 0xFFFFFFFFu); v.push_back(w >> 32); }
     for (uint64_t w : periodic) { v.push_back(w & 0xFFFFFFFFu); v.push_back(w >> 32); }
     hash_no_pad_host(v.data(), v.size(), out);
@@ -335,6 +338,7 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
         return ctx->fail(NLX_E_INVAL, "quotient_degree_factor must be a power of two <= 2^rate_bits");
     if (d.fri_arity_bits < 2 || d.fri_arity_bits > 4) return ctx->fail(NLX_E_UNSUPPORTED, "fri_arity_bits must be in [2, 4]");
     if (d.leaf_group_cols && (d.leaf_group_cols < 8 || d.leaf_group_cols > 4096)) return ctx->fail(NLX_E_RANGE, "leaf_group_cols must be 0 or in [8, 4096]");
+    if (d.openings_group && (d.openings_group < 8 || d.openings_group > 4096)) return ctx->fail(NLX_E_RANGE, "openings_group must be 0 or in [8, 4096]");
     if (d.degree_bits < 4 || d.degree_bits < d.fri_arity_bits || d.degree_bits + d.rate_bits > 30)
         return ctx->fail(NLX_E_RANGE, "degree_bits out of range");
     if (d.fri_num_queries > 128 || d.fri_num_queries == 0 || d.cap_height > 6 || d.cap_height > d.degree_bits + d.rate_bits)
@@ -733,7 +737,10 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
         uint32_t widest = nq;
         for (uint32_t r = 0; r < NRD; r++) widest = s->round_cols[r] > widest ? s->round_cols[r] : widest;
         uint64_t* d_points = dalloc(2048);
-        uint64_t* d_open = dalloc((size_t)(n_open + ncols) * 16);
+        // with an openings digest the vector is zero-padded to whole runs and the runs' digests follow it
+        const size_t open_words = (size_t)(n_open + ncols) * 2;
+        const size_t og = d.openings_group, og_runs = og ? (open_words + og - 1) / og : 0;
+        uint64_t* d_open = dalloc((og ? og_runs * og + 4 * og_runs : open_words) * 8);
         uint64_t* d_eval_scratch = dalloc(eval_scratch_words(widest, log_n) * 8);
         CHECK_ALLOC(d_points && d_open && d_eval_scratch);
         {
@@ -752,8 +759,12 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
                                d_open + 2 * (size_t)(n_open + col0[r]), d_eval_scratch, d_points + 4 + 64);
             }
             launch_eval_br(st, cq->coeffs_br, n, nq, log_n, d_points, d_open + 2 * (size_t)ncols, d_eval_scratch, d_points + 4);
+            if (og) {
+                if (og_runs * og > open_words) HIPCHK(hipMemsetAsync(d_open + open_words, 0, (og_runs * og - open_words) * 8, st));
+                launch_hash_leaves_rowmajor(st, d_open, (uint32_t)og, og_runs, d_open + og_runs * og);
+            }
         }
-        std::vector<uint64_t> open((size_t)(n_open + ncols) * 2);
+        std::vector<uint64_t> open(og ? og_runs * og + 4 * og_runs : open_words);
         CHECK(fetch(ctx, open.data(), d_open, open.size() * 8));
         const uint64_t* o_local = open.data();
         const uint64_t* o_q = o_local + 2 * (size_t)ncols;
@@ -761,9 +772,16 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
         w.u64s(o_local, 2 * (size_t)ncols);
         w.u64s(o_next, 2 * (size_t)ncols);
         w.u64s(o_q, 2 * (size_t)nq);
-        // observe_openings(&openings.to_fri_openings()): zeta batch (local ++ quotient), then the g*zeta batch
-        ch.observe(open.data(), 2 * (size_t)n_open);
-        ch.observe(o_next, 2 * (size_t)ncols);
+        // observe_openings(&openings.to_fri_openings()): zeta batch (local ++ quotient), then the g*zeta batch - every value, or
+        // (openings_group) the digest of the runs' digests the device has just made
+        if (og) {
+            uint64_t dig[4];
+            hash_no_pad_host(open.data() + og_runs * og, 4 * og_runs, dig);
+            ch.observe(dig, 4);
+        } else {
+            ch.observe(open.data(), 2 * (size_t)n_open);
+            ch.observe(o_next, 2 * (size_t)ncols);
+        }
 
         // ---- FRI: Stark::fri_instance = [zeta: every round's columns ++ quotient], [g zeta: every round's columns] ----
         {

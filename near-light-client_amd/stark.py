@@ -40,7 +40,7 @@ class StarkDesc(ctypes.Structure):
                        ("period_bits", ctypes.c_uint32), ("periodic", ctypes.POINTER(ctypes.c_uint64)),
                        ("n_rounds", ctypes.c_uint32), ("round_cols", ctypes.c_uint32 * 3),
                        ("round_challenges", ctypes.c_uint32 * 3), ("leaf_group_cols", ctypes.c_uint32),
-                       ("round_values", ctypes.c_uint32 * 3), ("reserved2", ctypes.c_uint32)]
+                       ("round_values", ctypes.c_uint32 * 3), ("openings_group", ctypes.c_uint32)]
 
 
 # grouped leaves are switched on up to this many LDE rows (2^k): at 2^16 rows one leaf per lane is one wave per SIMD, which
@@ -61,6 +61,9 @@ class StarkConfig:
         self.fri_final_poly_bits = 5
         # Merkle leaves over runs of this many columns (nlx_stark_desc.leaf_group_cols); None = by shape, see leaf_group_for
         self.leaf_group_cols = None
+        # the transcript observes a digest of the openings (runs of this many values) instead of every value
+        # (nlx_stark_desc.openings_group); None = 64 when the trace has more than 256 columns, else 0 (starky's transcript)
+        self.openings_group = None
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown config field %s" % k)
@@ -565,6 +568,7 @@ class Stark:
                               air.num_public_inputs, len(self.program), self.program.ctypes.data_as(u64p),
                               len(air._periodic), air.period_bits, self.periodic.ctypes.data_as(u64p))
         self.desc.leaf_group_cols = cfg.leaf_group_for(degree_bits, max(c for c, _ in air.rounds) if air.rounds is not None else air.n_cols)
+        self.desc.openings_group = int(cfg.openings_group) if cfg.openings_group is not None else (64 if air.n_cols > 256 else 0)
         if air.rounds is not None:
             self.desc.n_rounds = len(air.rounds)
             for r, (c, k) in enumerate(air.rounds):

@@ -489,7 +489,7 @@ static uint64_t* periodic_coeffs(const orc_stark_desc* d) {
  * program word as (lo, hi) with CONST immediates reduced mod p first, then every periodic value (reduced) as (lo, hi). */
 void orc_stark_air_digest(const orc_stark_desc* d, uint64_t out[4]) {
     const size_t n_per = d->n_periodic ? ((size_t)d->n_periodic << d->period_bits) : 0;
-    const size_t len = 24 + (d->leaf_group_cols ? 1 : 0) + 2 * (size_t)d->n_words + 2 * n_per;
+    const size_t len = 24 + ((d->leaf_group_cols || d->openings_group) ? 2 : 0) + 2 * (size_t)d->n_words + 2 * n_per;
     uint64_t* v = (uint64_t*)malloc(8 * len);
     size_t k = 0;
     const uint32_t shape[14] = {d->degree_bits, d->n_cols, d->num_challenges, d->rate_bits, d->cap_height,
@@ -501,7 +501,10 @@ void orc_stark_air_digest(const orc_stark_desc* d, uint64_t out[4]) {
     for (int r = 0; r < 3; r++) v[k++] = (uint32_t)r < d->n_rounds ? d->round_cols[r] : 0;
     for (int r = 0; r < 3; r++) v[k++] = (uint32_t)r < d->n_rounds ? d->round_challenges[r] : 0;
     for (int r = 0; r < 3; r++) v[k++] = (uint32_t)r < d->n_rounds ? d->round_values[r] : 0;
-    if (d->leaf_group_cols) v[k++] = d->leaf_group_cols;   /* only when used: digests of whole-row statements stay what they were */
+    if (d->leaf_group_cols || d->openings_group) {   /* only when used: digests of plain-starky statements stay what they were */
+        v[k++] = d->leaf_group_cols;
+        v[k++] = d->openings_group;
+    }
     for (uint32_t pc = 0; pc < d->n_words; pc++) {
         uint64_t w = d->program[pc];
         v[k++] = w & 0xFFFFFFFFu; v[k++] = w >> 32;
@@ -524,6 +527,30 @@ static void transcript_start(orc_challenger* ch, const orc_stark_desc* d, const 
     orc_stark_air_digest(d, dig);
     orc_ch_observe_many(ch, dig, 4);
     if (d->num_public_inputs) orc_ch_observe_many(ch, public_inputs, d->num_public_inputs);
+}
+
+/* observe_openings(&openings.to_fri_openings()): the zeta batch (local ++ quotient), then the zeta_next batch - every value, or
+ * (openings_group = G) the four-element digest of that vector: zero-padded to a multiple of G, runs of G hashed, the run
+ * digests hashed */
+static void observe_openings(orc_challenger* ch, const orc_stark_desc* d, const gl2* o_local, const gl2* o_q, const gl2* o_next,
+                             uint32_t ncols, uint32_t nq) {
+    if (!d->openings_group) {
+        orc_ch_observe_many(ch, (const uint64_t*)o_local, 2 * ncols);
+        orc_ch_observe_many(ch, (const uint64_t*)o_q, 2 * nq);
+        orc_ch_observe_many(ch, (const uint64_t*)o_next, 2 * ncols);
+        return;
+    }
+    const size_t G = d->openings_group, len = 2 * (size_t)(2 * ncols + nq), K = (len + G - 1) / G;
+    uint64_t* v = (uint64_t*)calloc(K * G + 4 * K, 8);
+    uint64_t* dg = v + K * G;
+    memcpy(v, o_local, 16 * (size_t)ncols);
+    memcpy(v + 2 * (size_t)ncols, o_q, 16 * (size_t)nq);
+    memcpy(v + 2 * (size_t)(ncols + nq), o_next, 16 * (size_t)ncols);
+    for (size_t k = 0; k < K; k++) orc_hash_no_pad(v + k * G, G, dg + 4 * k);
+    uint64_t out[4];
+    orc_hash_no_pad(dg, 4 * K, out);
+    orc_ch_observe_many(ch, out, 4);
+    free(v);
 }
 
 /* rounds of commitment: classic starky = one round, no verifier challenges before the alphas */
@@ -721,9 +748,7 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
     w_u64s(&w, (uint64_t*)o_next, 2 * ncols);
     w_u64s(&w, (uint64_t*)o_q, 2 * nq);
     /* observe_openings: zeta batch (local ++ quotient), then zeta_next batch (next) */
-    orc_ch_observe_many(&ch, (uint64_t*)o_local, 2 * ncols);
-    orc_ch_observe_many(&ch, (uint64_t*)o_q, 2 * nq);
-    orc_ch_observe_many(&ch, (uint64_t*)o_next, 2 * ncols);
+    observe_openings(&ch, d, o_local, o_q, o_next, ncols, nq);
     /* fri_instance: batch 0 at zeta = every round's columns ++ quotient, batch 1 at g*zeta = every round's columns */
     orc_fri_oracle oracles[4];
     for (uint32_t r = 0; r < NRD; r++) {
@@ -847,9 +872,7 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
         for (uint32_t j = 0; j < nc; j++) alphas[j] = orc_ch_challenge(&ch);
         orc_ch_observe_many(&ch, caps + NRD * capw, capw);
         gl2 zeta = orc_ch_ext_challenge(&ch);
-        orc_ch_observe_many(&ch, (uint64_t*)o_local, 2 * ncols);
-        orc_ch_observe_many(&ch, (uint64_t*)o_q, 2 * nq);
-        orc_ch_observe_many(&ch, (uint64_t*)o_next, 2 * ncols);
+        observe_openings(&ch, d, o_local, o_q, o_next, ncols, nq);
         /* vanishing polynomial identity at zeta */
         const uint64_t g = gl_root_of_unity(log_n), last = gl_inv(g);
         gl2 zeta_n = zeta;

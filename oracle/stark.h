@@ -106,7 +106,12 @@ typedef struct {
      * after the public inputs at the end of the proof, and the program reads them as PUBLIC: the values array is
      * public inputs | values of round 0 | challenges of round 0 | values of round 1 | challenges of round 1 | ... */
     uint32_t round_values[3];
-    uint32_t reserved2;
+    /* Openings digest: 0 = the transcript observes every opened value (starky's observe_openings: local ++ quotient at zeta,
+     * then the next values).  G > 0: it observes FOUR elements instead - that vector, zero-padded to a multiple of G, hashed in
+     * runs of G (hash_no_pad each) and the run digests hashed once more.  Same binding, and the long sequential absorption (2 400
+     * permutations on one host thread for a 4 745-column trace: 3 of the proof's 8 ms) becomes parallel work.  In the statement
+     * digest when non-zero. */
+    uint32_t openings_group;
 } orc_stark_desc;
 
 /* returns round `round`'s columns (round_cols[round] x n, column-major) given everything after the public inputs in the

@@ -499,3 +499,21 @@ def test_grouped_leaves_are_what_the_header_says(nlx, orc):
     assert len(proof) == len(orc.stark_prove(plain.desc, t, pis))       # same layout: opened rows and sibling paths
     cfg = S.StarkConfig()
     assert cfg.leaf_group_for(9, 4745) == 128 and cfg.leaf_group_for(15, 1488) == 128 and cfg.leaf_group_for(16, 1488) == 0 and cfg.leaf_group_for(9, 200) == 0
+
+
+def test_openings_digest_is_what_the_header_says(nlx, orc):
+    """openings_group: the transcript observes hash_no_pad(run digests) of the opened values (local ++ quotient ++ next, zero-padded
+    to whole runs) instead of every value; the proof's bytes keep their layout, a verifier told another G (or none) rejects, and
+    the host rule switches it on above 256 columns"""
+    S = nlx.stark
+    air, t, pis = make_case(S, "wide16", 6)
+    plain, dig, other = S.Stark(air, 6), S.Stark(air, 6, S.StarkConfig(openings_group=8)), S.Stark(air, 6, S.StarkConfig(openings_group=16))
+    assert plain.desc.openings_group == 0 and dig.desc.openings_group == 8
+    proof = orc.stark_prove(dig.desc, t, pis)
+    assert orc.stark_verify(dig.desc, proof) == 1
+    assert orc.stark_verify(plain.desc, proof) != 1 and orc.stark_verify(other.desc, proof) != 1
+    base = orc.stark_prove(plain.desc, t, pis)
+    assert len(proof) == len(base) and proof != base
+    assert not np.array_equal(orc.stark_air_digest(plain.desc), orc.stark_air_digest(dig.desc))
+    wide = S.Stark(S.wide_air(320, seed=3), 5)
+    assert wide.desc.openings_group == 64 and wide.desc.leaf_group_cols == 128
