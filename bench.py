@@ -700,7 +700,11 @@ def stark_verifier_rows(st):
         for _ in range(fri_rounds):
             ll -= d.fri_arity_bits
             per_query += (2 << d.fri_arity_bits) // 8 + max(ll - d.cap_height, 0)
-        transcript = (2 * (2 * d.n_cols + oracles[-1]) + 7) // 8
+        n_observed = 2 * (2 * d.n_cols + oracles[-1])
+        transcript = (n_observed + 7) // 8
+        if d.openings_group:   # the runs' digests, then the digest of those
+            k = -(-n_observed // d.openings_group)
+            transcript = k * ((d.openings_group + 7) // 8) + (4 * k + 7) // 8
         rows[name] = per_query * d.fri_num_queries + transcript
     rows["total"] = sum(rows.values())
     return rows
