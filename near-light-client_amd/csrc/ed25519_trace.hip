@@ -46,6 +46,105 @@ __global__ __launch_bounds__(64) void k_ed_scan(const uint64_t* __restrict__ wor
     fin[k] = q;
 }
 
+// ---- the scan on FOUR lanes per slot ------------------------------------------------------------------------------------
+// A row of the double-and-add chain is fifteen field products in four dependent levels (4 squares; 4 products of the
+// doubling; 4 products with the addend; 3 products of the addition): k_ed_scan walks them one after the other on one lane per
+// slot - 128 lanes for the Sync step's 128 slots, 3.7 ms of latency.  Here a quad of lanes owns a slot: lane j computes
+// product j of every level (operands picked by lane-index selects, no divergent control flow), the four results travel by
+// DPP quad broadcasts (ten 26-bit limbs each), and lanes 0..2 canonicalise and store one coordinate of the row's input point
+// each.  The state is replicated in the quad; values are the same residues as k_ed_scan's (canonical after freeze), so the
+// trace is bit-identical.
+namespace quad {
+struct F10 { int32_t l[10]; };   // fe::Fe's limbs after a carry fit 32 bits (|l| <= 2^25 + small)
+
+template <int SRC>
+__device__ __forceinline__ F10 bcast(const F10& v) {   // lane SRC of the quad's value, in every lane of the quad
+    F10 r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.l[i] = __builtin_amdgcn_mov_dpp(v.l[i], SRC * 0x55, 0xF, 0xF, true);
+    return r;
+}
+__device__ __forceinline__ F10 pick(uint32_t j, const F10& a, const F10& b, const F10& c, const F10& d) {
+    F10 r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.l[i] = j == 0 ? a.l[i] : (j == 1 ? b.l[i] : (j == 2 ? c.l[i] : d.l[i]));
+    return r;
+}
+__device__ __forceinline__ F10 add(const F10& a, const F10& b) { F10 r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.l[i] = a.l[i] + b.l[i]; return r; }
+__device__ __forceinline__ F10 sub(const F10& a, const F10& b) { F10 r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.l[i] = a.l[i] - b.l[i]; return r; }
+__device__ __forceinline__ fe::Fe wide(const F10& a) { fe::Fe r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.l[i] = a.l[i]; return r; }
+__device__ __forceinline__ F10 narrow(const fe::Fe& a) { F10 r;
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.l[i] = (int32_t)a.l[i]; return r; }
+// operands: sums of at most four carried values (|l| < 2^28, fe::mul's bound); result carried
+__device__ __forceinline__ F10 mul(const F10& a, const F10& b) { return narrow(fe::mul(wide(a), wide(b))); }
+}  // namespace quad
+
+constexpr uint32_t SCAN4_SLOTS_PER_BLOCK = 16;   // 64 lanes
+__global__ __launch_bounds__(64) void k_ed_scan4(const uint64_t* __restrict__ words, uint32_t n_slots, ed::Slot* __restrict__ slots,
+                                                 ed::Point* __restrict__ in, ed::Point* __restrict__ fin) {
+    using quad::F10;
+    __shared__ int32_t tab[64][4][10];   // this lane's column of the slot's addend table: [sel][limb]
+    const uint32_t k_raw = blockIdx.x * SCAN4_SLOTS_PER_BLOCK + (threadIdx.x >> 2), j = threadIdx.x & 3;
+    const bool live = k_raw < n_slots;               // spare quads redo the last slot and store nothing (whole quads: DPP needs its lanes)
+    const uint32_t k = live ? k_raw : n_slots - 1;
+    ed::Slot s;
+    ed::slot_from_words(words + (size_t)k * ed::SLOT_WORDS, s);
+    if (live && j == 0) slots[k] = s;
+    {
+        ed::FastSlot fs;
+        ed::fast_slot(s, fs);
+        for (int sel = 0; sel < 4; sel++) {
+            const fe::Fe& v = j == 0 ? fs.ymx[sel] : (j == 1 ? fs.ypx[sel] : (j == 2 ? fs.t2d[sel] : fs.z2[sel]));
+            for (int i = 0; i < 10; i++) tab[threadIdx.x][sel][i] = (int32_t)v.l[i];
+        }
+    }
+    F10 x, y, z;
+#pragma unroll
+    for (int i = 0; i < 10; i++) { x.l[i] = 0; y.l[i] = i == 0; z.l[i] = i == 0; }
+    uint32_t* out_words = reinterpret_cast<uint32_t*>(in + (size_t)k * ed::ROWS) + 16 * j;   // coordinate j of the slot's first row
+#pragma unroll 1
+    for (int r = 0; r <= ed::ROWS; r++) {
+        // the row's input point (after the last row: the slot's final point): lanes 0..2 freeze and store one coordinate each
+        if (live && j < 3) {
+            uint32_t c16[16];
+            fe::freeze(quad::wide(quad::pick(j, x, y, z, z)), c16);
+            uint32_t* dst = r < ed::ROWS ? out_words + (size_t)r * 48 : reinterpret_cast<uint32_t*>(fin + k) + 16 * j;
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) *reinterpret_cast<uint4*>(dst + i) = make_uint4(c16[i], c16[i + 1], c16[i + 2], c16[i + 3]);
+        }
+        if (r == ed::ROWS) break;
+        const int bit = ed::ROWS - 1 - r;
+        const uint32_t sel = ((s.sw[bit >> 4] >> (bit & 15)) & 1) + 2 * ((s.hw[bit >> 4] >> (bit & 15)) & 1);
+        // level 1: a = x^2, b = y^2, zz = z^2, e1 = (x + y)^2
+        const F10 sq_in = quad::pick(j, x, y, z, quad::add(x, y));
+        const F10 sq = quad::mul(sq_in, sq_in);
+        const F10 a = quad::bcast<0>(sq), b = quad::bcast<1>(sq), zz = quad::bcast<2>(sq), e1 = quad::bcast<3>(sq);
+        const F10 e = quad::sub(quad::sub(e1, a), b), g = quad::sub(b, a), f = quad::sub(g, quad::add(zz, zz)), h = quad::sub(quad::sub(g, b), b);   // h = -(a + b)
+        // level 2: x2 = e f, y2 = g h, t2 = e h, z2 = f g
+        const F10 m2 = quad::mul(quad::pick(j, e, g, e, f), quad::pick(j, f, h, h, g));
+        const F10 x2 = quad::bcast<0>(m2), y2 = quad::bcast<1>(m2);
+        // level 3: the addend (its four products with the doubled point), sel = 0 being the neutral element's (1, 1, 0, 2)
+        F10 t;
+#pragma unroll
+        for (int i = 0; i < 10; i++) t.l[i] = tab[threadIdx.x][sel][i];
+        const F10 m3 = quad::mul(quad::pick(j, quad::sub(y2, x2), quad::add(y2, x2), m2, m2), t);
+        const F10 pa = quad::bcast<0>(m3), pb = quad::bcast<1>(m3), pc = quad::bcast<2>(m3), pd = quad::bcast<3>(m3);
+        const F10 e_ = quad::sub(pb, pa), f_ = quad::sub(pd, pc), g_ = quad::add(pd, pc), h_ = quad::add(pb, pa);
+        // level 4: x = e_ f_, y = g_ h_, z = f_ g_ (lane 3 repeats z)
+        const F10 m4 = quad::mul(quad::pick(j, e_, g_, f_, f_), quad::pick(j, f_, h_, g_, g_));
+        x = quad::bcast<0>(m4);
+        y = quad::bcast<1>(m4);
+        z = quad::bcast<2>(m4);
+    }
+}
+
 struct TracePut {
     uint64_t* trace;
     size_t n, row;
@@ -191,8 +290,10 @@ extern "C" int32_t nlx_ed25519_trace(nlx_ctx* ctx, const uint64_t* slots, uint32
     uint32_t bad = 0xFFFFFFFFu;
     hipError_t e0 = hipMemcpyAsync(d_bad, &bad, 4, hipMemcpyHostToDevice, ctx->stream);
     if (e0 != hipSuccess) { ctx->release(d); return ctx->hip_fail(e0, "hipMemcpyAsync"); }
-    hipLaunchKernelGGL(k_ed_scan, dim3((n_slots + 63) / 64), dim3(64), 0, ctx->stream, sw.as<uint64_t>(), n_slots, d_slots, d_in,
-                       d_fin);
+    // four lanes per slot (k_ed_scan4); k_ed_scan, one lane per slot, is the same walk written sequentially (kept: the reference
+    // the quad version is checked against in tests/native and the form the row emitter's recomputation mirrors)
+    hipLaunchKernelGGL(k_ed_scan4, dim3((n_slots + SCAN4_SLOTS_PER_BLOCK - 1) / SCAN4_SLOTS_PER_BLOCK), dim3(64), 0, ctx->stream,
+                       sw.as<uint64_t>(), n_slots, d_slots, d_in, d_fin);
     hipLaunchKernelGGL(k_ed_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_slots, d_in, d_fin, n_slots,
                        st.as<uint64_t>(), d_bad);
     e0 = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream);
