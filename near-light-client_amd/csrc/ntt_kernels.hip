@@ -1048,6 +1048,8 @@ void launch_bitrev_permute(hipStream_t st, const uint64_t* src, uint64_t* dst, s
 // where the other was: every global access is a 512-byte row.  The gather version above reads 8 bytes per 64-byte line and
 // needs a second buffer and a copy back: 6.0 ms of the 14.3 ms of a 16 x 2^24 batch.
 constexpr int BR_K = 6, BR_T = 1 << BR_K;
+// 16-byte accesses (a lane owns two adjacent elements of a row: 32 lanes per 512-byte row, eight rows per sweep) and every
+// load of both tiles in flight before the first LDS write: sixteen independent 16-byte loads per lane.
 __global__ __launch_bounds__(256) void k_bitrev_tiled(uint64_t* __restrict__ data, size_t stride, unsigned log_n,
                                                       const uint64_t* __restrict__ postscale) {
     __shared__ uint64_t ta[BR_T][BR_T + 1], tb[BR_T][BR_T + 1];
@@ -1055,26 +1057,37 @@ __global__ __launch_bounds__(256) void k_bitrev_tiled(uint64_t* __restrict__ dat
     const uint32_t mid = blockIdx.x, rmid = m ? gl::bitrev32(mid, m) : 0;
     if (rmid < mid) return;   // the pair's other block does the work
     uint64_t* d = data + (size_t)blockIdx.y * stride;
-    const uint32_t lo = threadIdx.x & (BR_T - 1), row0 = threadIdx.x >> BR_K;   // 4 rows per sweep
+    const uint32_t l2 = threadIdx.x & 31, row0 = threadIdx.x >> 5;   // elements 2 l2, 2 l2 + 1 of rows row0 + 8 k
     const bool self = rmid == mid;
-    for (uint32_t hi = row0; hi < BR_T; hi += 256 / BR_T) {
-        ta[hi][lo] = d[((size_t)hi << (m + BR_K)) | ((size_t)mid << BR_K) | lo];
-        if (!self) tb[hi][lo] = d[((size_t)hi << (m + BR_K)) | ((size_t)rmid << BR_K) | lo];
+    constexpr int SWEEPS = BR_T / 8;
+    ulonglong2 va[SWEEPS], vb[SWEEPS];
+#pragma unroll
+    for (int k = 0; k < SWEEPS; k++) {
+        const size_t hi = row0 + 8 * k;
+        va[k] = *reinterpret_cast<const ulonglong2*>(d + ((hi << (m + BR_K)) | ((size_t)mid << BR_K) | (2 * l2)));
+        if (!self) vb[k] = *reinterpret_cast<const ulonglong2*>(d + ((hi << (m + BR_K)) | ((size_t)rmid << BR_K) | (2 * l2)));
+    }
+#pragma unroll
+    for (int k = 0; k < SWEEPS; k++) {
+        const uint32_t hi = row0 + 8 * k;
+        ta[hi][2 * l2] = va[k].x; ta[hi][2 * l2 + 1] = va[k].y;
+        if (!self) { tb[hi][2 * l2] = vb[k].x; tb[hi][2 * l2 + 1] = vb[k].y; }
     }
     __syncthreads();
-    const uint32_t rlo = gl::bitrev32(lo, BR_K);
-    for (uint32_t hi = row0; hi < BR_T; hi += 256 / BR_T) {
-        const uint32_t rhi = gl::bitrev32(hi, BR_K);
+    const uint32_t r0 = gl::bitrev32(2 * l2, BR_K);   // rev(2 l2 + 1) = r0 + 32
+#pragma unroll
+    for (int k = 0; k < SWEEPS; k++) {
+        const uint32_t hi = row0 + 8 * k, rhi = gl::bitrev32(hi, BR_K);
         // destination (hi, rmid, lo) takes source (rev lo, mid, rev hi); destination (hi, mid, lo) the same from tile rmid
-        const size_t i1 = ((size_t)hi << (m + BR_K)) | ((size_t)rmid << BR_K) | lo;
-        uint64_t v = ta[rlo][rhi];
-        if (postscale) v = gl::mul(v, postscale[i1]);
-        d[i1] = v;
+        const size_t i1 = ((size_t)hi << (m + BR_K)) | ((size_t)rmid << BR_K) | (2 * l2);
+        ulonglong2 v = make_ulonglong2(ta[r0][rhi], ta[r0 + BR_T / 2][rhi]);
+        if (postscale) { v.x = gl::mul(v.x, postscale[i1]); v.y = gl::mul(v.y, postscale[i1 + 1]); }
+        *reinterpret_cast<ulonglong2*>(d + i1) = v;
         if (!self) {
-            const size_t i2 = ((size_t)hi << (m + BR_K)) | ((size_t)mid << BR_K) | lo;
-            uint64_t w = tb[rlo][rhi];
-            if (postscale) w = gl::mul(w, postscale[i2]);
-            d[i2] = w;
+            const size_t i2 = ((size_t)hi << (m + BR_K)) | ((size_t)mid << BR_K) | (2 * l2);
+            ulonglong2 w = make_ulonglong2(tb[r0][rhi], tb[r0 + BR_T / 2][rhi]);
+            if (postscale) { w.x = gl::mul(w.x, postscale[i2]); w.y = gl::mul(w.y, postscale[i2 + 1]); }
+            *reinterpret_cast<ulonglong2*>(d + i2) = w;
         }
     }
 }
