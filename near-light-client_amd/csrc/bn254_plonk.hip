@@ -419,6 +419,7 @@ int32_t nlx_bn254_plonk_grand_product(nlx_ctx* ctx, uint32_t log_n, const uint64
     if (!ctx) return NLX_E_INVAL;
     if (!l || !r || !o || !s1 || !s2 || !s3 || !beta || !gamma || !k1 || !k2 || !z_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
     if (log_n < 1 || log_n > 28) return ctx->fail(NLX_E_RANGE, "log_n must be in [1, 28]");
+    if (is_device_ptr(beta) || is_device_ptr(gamma) || is_device_ptr(k1) || is_device_ptr(k2)) return ctx->fail(NLX_E_INVAL, "the challenges and shifts are host values");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     const size_t n = (size_t)1 << log_n;
@@ -515,6 +516,7 @@ int32_t nlx_bn254_fr_lincomb(nlx_ctx* ctx, uint64_t m, uint32_t n_terms, const u
     if (!ctx) return NLX_E_INVAL;
     if (!polys || !scalars || !out) return ctx->fail(NLX_E_INVAL, "NULL argument");
     if (n_terms < 1 || n_terms > bnp::LINCOMB_MAX_TERMS || m < 1 || m > ((uint64_t)1 << 28)) return ctx->fail(NLX_E_RANGE, "1 .. 16 terms of 1 .. 2^28 elements");
+    if (is_device_ptr(polys) || is_device_ptr(scalars)) return ctx->fail(NLX_E_INVAL, "the pointer array and the scalars are host arrays");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     std::vector<void*> tmp;
@@ -560,7 +562,11 @@ int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_ar
         if (!polys[i]) return ctx->fail(NLX_E_INVAL, "NULL polynomial");
     if (a->log_n < 2 || a->log_n > 26) return ctx->fail(NLX_E_RANGE, "log_n must be in [2, 26] (the coset has four times the points)");
     if (a->flags != NLX_BN254_MONTGOMERY) return ctx->fail(NLX_E_UNSUPPORTED, "elements must be fr.Element words (flags = NLX_BN254_MONTGOMERY)");
-    if (is_device_ptr(a->coset_shift)) return ctx->fail(NLX_E_INVAL, "the challenges and shifts are host values");
+    {
+        const uint64_t* sc[6] = {a->coset_shift, a->k1, a->k2, a->alpha, a->beta, a->gamma};
+        for (const uint64_t* q : sc)
+            if (!q || is_device_ptr(q)) return ctx->fail(NLX_E_INVAL, "the challenges and shifts are host values (four words each)");
+    }
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     const uint32_t log_n = a->log_n, P = a->pi ? 13 : 12;
@@ -640,6 +646,7 @@ int32_t nlx_bn254_kzg_open(nlx_ctx* ctx, const uint64_t* coeffs, uint64_t m, con
     if (!coeffs || !zeta || !y_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
     if (m < 2 || m > ((uint64_t)1 << 28)) return ctx->fail(NLX_E_RANGE, "2 <= coefficients <= 2^28");
     if (proof_out && !srs) return ctx->fail(NLX_E_INVAL, "an opening proof needs the SRS");
+    if (is_device_ptr(zeta) || is_device_ptr(y_out)) return ctx->fail(NLX_E_INVAL, "the point and the value are host words");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     std::vector<void*> tmp;
