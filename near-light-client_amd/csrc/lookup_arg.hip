@@ -181,67 +181,104 @@ __global__ __launch_bounds__(256) void k_lookup_terms(LookupTermsParams p) {
     if (pos >> log_L) return;
     const size_t n = (size_t)1 << p.log_n, L = (size_t)1 << log_L;
     const size_t pos_next = (pos & ~(n - 1)) | ((pos + 1) & (n - 1));   // same coset, next subgroup element
-    const uint32_t S = p.s.n_sldc, T = p.s.num_luts;
+    const uint32_t S = p.s.n_sldc, T = p.s.num_luts, nc = p.nc;          // nc <= 2 (checked at nlx_circuit_build)
     const uint64_t* ap0 = p.alpha_pows + p.t_lk;
     const uint64_t* ap1 = p.alpha_pows + p.alpha_stride + p.t_lk;
-    auto Wl = [&](uint32_t c) { return p.wires[(size_t)c * L + pos]; };
     auto Sel = [&](uint32_t c) { return p.cs[(size_t)(p.sel0 + c) * L + pos]; };
+    auto Z = [&](uint32_t ci, uint32_t c) { return p.zs[(size_t)(p.lk0 + ci * (1 + S) + c) * L + pos]; };
+    auto Zn = [&](uint32_t ci, uint32_t c) { return p.zs[(size_t)(p.lk0 + ci * (1 + S) + c) * L + pos_next]; };
     uint64_t tot0 = 0, tot1 = 0;
-    uint32_t k = 0;
-    auto emit = [&](uint64_t term) {
-        tot0 = gl::add(tot0, gl::mul(term, ap0[k]));
-        tot1 = gl::add(tot1, gl::mul(term, ap1[k]));
-        k++;
+    auto emit_at = [&](uint32_t ci, uint32_t k, uint64_t term) {   // term index inside round ci's list (see the order above)
+        const uint32_t at = ci * p.n_lk_terms + k;
+        tot0 = gl::add(tot0, gl::mul(term, ap0[at]));
+        tot1 = gl::add(tot1, gl::mul(term, ap1[at]));
     };
     const uint64_t s_sre = Sel(0), s_ldc = Sel(1), s_init = Sel(2), s_last = Sel(3);
+    // the terms that need no wire
+    uint64_t dA[2], dB[2], alpha[2], delta[2], re[2], re_run[2];
+    for (uint32_t ci = 0; ci < nc; ci++) {
+        dA[ci] = p.deltas[4 * ci]; dB[ci] = p.deltas[4 * ci + 1]; alpha[ci] = p.deltas[4 * ci + 2]; delta[ci] = p.deltas[4 * ci + 3];
+        re[ci] = Z(ci, 0);
+        re_run[ci] = Zn(ci, 0);
+        emit_at(ci, 0, gl::mul(s_last, Z(ci, S)));
+        emit_at(ci, 1, gl::mul(s_init, Z(ci, 1)));
+        emit_at(ci, 2, gl::mul(s_init, re[ci]));
+        for (uint32_t t = 0; t < T; t++) emit_at(ci, 3 + t, gl::mul(Sel(4 + t), gl::sub(re[ci], p.lut_polys[ci * T + t])));
+    }
+    // ONE pass over the routed wires: wire w is element (w mod 3) of LookupTableGate slot w / 3 AND element (w mod 2) of
+    // LookupGate slot w / 2 - both gates' sums advance from the same load, for both challenge rounds.  (The first version
+    // walked the wires once per sum and round: 420 loads per point for 80 columns, 7.2 GB fetched per launch at 2^18 rows
+    // against 1.9 GB algorithmic - profiles/r03_pmc_new_kernels.txt.)
+    const uint32_t n_lut_w = 3 * p.s.n_lut_slots, n_lu_w = 2 * p.s.n_lu_slots, n_w = n_lut_w > n_lu_w ? n_lut_w : n_lu_w;
+    uint64_t inp3 = 0, inp2 = 0, combo[2] = {0, 0};
+    uint64_t lut_num[2] = {0, 0}, lut_den[2] = {1, 1}, lu_num[2] = {0, 0}, lu_den[2] = {1, 1};
+    uint32_t r3 = 0, slot3 = 0, in_group3 = 0, group3 = 0, slot2 = 0, in_group2 = 0, group2 = 0;
 #pragma unroll 1
-    for (uint32_t ci = 0; ci < p.nc; ci++) {
-        const uint64_t dA = p.deltas[4 * ci], dB = p.deltas[4 * ci + 1], alpha = p.deltas[4 * ci + 2], delta = p.deltas[4 * ci + 3];
-        const uint32_t c0 = p.lk0 + ci * (1 + S);
-        auto Z = [&](uint32_t c) { return p.zs[(size_t)(c0 + c) * L + pos]; };
-        auto Zn = [&](uint32_t c) { return p.zs[(size_t)(c0 + c) * L + pos_next]; };
-        const uint64_t re = Z(0);
-        emit(gl::mul(s_last, Z(S)));
-        emit(gl::mul(s_init, Z(1)));
-        emit(gl::mul(s_init, re));
-        for (uint32_t t = 0; t < T; t++) emit(gl::mul(Sel(4 + t), gl::sub(re, p.lut_polys[ci * T + t])));
-        {
-            uint64_t cur = Zn(0);
-#pragma unroll 2
-            for (uint32_t i = 0; i < p.s.n_lut_slots; i++)
-                cur = gl::add(gl::mul(cur, delta), gl::add(Wl(3 * i), gl::mul(dB, Wl(3 * i + 1))));
-            emit(gl::mul(s_sre, gl::sub(re, cur)));
+    for (uint32_t w = 0; w < n_w; w++) {
+        const uint64_t v = p.wires[(size_t)w * L + pos];
+        if (w < n_lut_w) {
+            if (r3 == 0) {
+                inp3 = v;
+            } else if (r3 == 1) {
+                for (uint32_t ci = 0; ci < nc; ci++) {
+                    combo[ci] = gl::add(inp3, gl::mul(dA[ci], v));
+                    re_run[ci] = gl::add(gl::mul(re_run[ci], delta[ci]), gl::add(inp3, gl::mul(dB[ci], v)));
+                }
+            } else {
+                for (uint32_t ci = 0; ci < nc; ci++) {   // (num, den) -> (num d + mult den, den d)
+                    const uint64_t d = gl::sub(alpha[ci], combo[ci]);
+                    lut_num[ci] = gl::add(gl::mul(lut_num[ci], d), gl::mul(v, lut_den[ci]));
+                    lut_den[ci] = gl::mul(lut_den[ci], d);
+                }
+                slot3++;
+                if (++in_group3 == p.s.lut_degree || slot3 == p.s.n_lut_slots) {   // the group's Sum transition
+                    for (uint32_t ci = 0; ci < nc; ci++) {
+                        const uint64_t prev = group3 ? Z(ci, group3) : Zn(ci, S);   // rows run upside down: row + 1 is "before"
+                        const uint64_t step = gl::sub(Z(ci, 1 + group3), prev);
+                        emit_at(ci, 4 + T + 2 * group3, gl::mul(s_sre, gl::sub(gl::mul(lut_den[ci], step), lut_num[ci])));
+                        lut_num[ci] = 0;
+                        lut_den[ci] = 1;
+                    }
+                    in_group3 = 0;
+                    group3++;
+                }
+            }
+            r3 = r3 == 2 ? 0 : r3 + 1;
         }
-        uint64_t prev = Zn(S);   // the last partial sum of the NEXT row (rows run upside down)
-#pragma unroll 1
-        for (uint32_t j = 0; j < S; j++) {
-            const uint64_t cur = Z(1 + j);
-            const uint64_t step = gl::sub(cur, prev);
-            {
-                uint64_t num = 0, den = 1;
-                const uint32_t hi = (j + 1) * p.s.lut_degree < p.s.n_lut_slots ? (j + 1) * p.s.lut_degree : p.s.n_lut_slots;
-                for (uint32_t i = j * p.s.lut_degree; i < hi; i++) {
-                    const uint64_t d = gl::sub(alpha, gl::add(Wl(3 * i), gl::mul(dA, Wl(3 * i + 1))));
-                    num = gl::add(gl::mul(num, d), gl::mul(Wl(3 * i + 2), den));
-                    den = gl::mul(den, d);
+        if (w < n_lu_w) {
+            if ((w & 1) == 0) {
+                inp2 = v;
+            } else {
+                for (uint32_t ci = 0; ci < nc; ci++) {   // (num, den) -> (num d + den, den d)
+                    const uint64_t d = gl::sub(alpha[ci], gl::add(inp2, gl::mul(dA[ci], v)));
+                    lu_num[ci] = gl::add(gl::mul(lu_num[ci], d), lu_den[ci]);
+                    lu_den[ci] = gl::mul(lu_den[ci], d);
                 }
-                emit(gl::mul(s_sre, gl::sub(gl::mul(den, step), num)));
-            }
-            {
-                uint64_t num = 0, den = 1;
-                const uint32_t hi = (j + 1) * p.s.lu_degree < p.s.n_lu_slots ? (j + 1) * p.s.lu_degree : p.s.n_lu_slots;
-                for (uint32_t i = j * p.s.lu_degree; i < hi; i++) {
-                    const uint64_t d = gl::sub(alpha, gl::add(Wl(2 * i), gl::mul(dA, Wl(2 * i + 1))));
-                    num = gl::add(gl::mul(num, d), den);
-                    den = gl::mul(den, d);
+                slot2++;
+                if (++in_group2 == p.s.lu_degree || slot2 == p.s.n_lu_slots) {     // the group's LDC transition
+                    for (uint32_t ci = 0; ci < nc; ci++) {
+                        const uint64_t prev = group2 ? Z(ci, group2) : Zn(ci, S);
+                        const uint64_t step = gl::sub(Z(ci, 1 + group2), prev);
+                        emit_at(ci, 5 + T + 2 * group2, gl::mul(s_ldc, gl::add(gl::mul(lu_den[ci], step), lu_num[ci])));
+                        lu_num[ci] = 0;
+                        lu_den[ci] = 1;
+                    }
+                    in_group2 = 0;
+                    group2++;
                 }
-                emit(gl::mul(s_ldc, gl::add(gl::mul(den, step), num)));
             }
-            prev = cur;
         }
     }
+    // groups past the last slot (shapes where S * degree overshoots the slots): empty products, SLDC_j = SLDC_{j-1}
+    for (; group3 < S; group3++)
+        for (uint32_t ci = 0; ci < nc; ci++)
+            emit_at(ci, 4 + T + 2 * group3, gl::mul(s_sre, gl::sub(Z(ci, 1 + group3), group3 ? Z(ci, group3) : Zn(ci, S))));
+    for (; group2 < S; group2++)
+        for (uint32_t ci = 0; ci < nc; ci++)
+            emit_at(ci, 5 + T + 2 * group2, gl::mul(s_ldc, gl::sub(Z(ci, 1 + group2), group2 ? Z(ci, group2) : Zn(ci, S))));
+    for (uint32_t ci = 0; ci < nc; ci++) emit_at(ci, 3 + T, gl::mul(s_sre, gl::sub(re[ci], re_run[ci])));   // RE's row transition
     p.out[pos] = tot0;
-    if (p.nc > 1) p.out[L + pos] = tot1;
+    if (nc > 1) p.out[L + pos] = tot1;
 }
 
 }  // namespace
