@@ -43,6 +43,22 @@ def test_proof_bytes_with_tables_equal_oracle(nlx, ctx, orc, log_n, T, bits, nl,
         ref.close()
 
 
+def test_one_challenge_round_with_tables(nlx, ctx, orc):
+    """num_challenges = 1: one round of lookup challenges (beta, gamma and two more), one RE / partial-sum set, one alpha sum"""
+    cfg = nlx.CircuitConfig(num_challenges=1)
+    syn = nlx.SyntheticCircuit(10, seed=77, num_luts=2, lut_bits=7, num_lookups=90, config=cfg)
+    ref = orc.Circuit.from_synthetic(syn)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    try:
+        want = ref.prove(syn.wires, syn.public_inputs)
+        got = cd.prove(syn.wires, syn.public_inputs)
+        _same(got, want, "one challenge round, two tables")
+        assert ref.verify(got) == 1
+    finally:
+        cd.close()
+        ref.close()
+
+
 def test_device_witness_gets_the_lookup_wires_in_place(nlx, ctx, orc):
     """a device-resident witness is written as prover::set_lookup_wires writes the PartitionWitness: multiplicities on the
     LookupTableGate rows, the table's first pair on the padding slots of the last LookupGate row - and nothing else"""
