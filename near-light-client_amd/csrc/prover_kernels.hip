@@ -42,47 +42,58 @@ __global__ __launch_bounds__(256) void k_zs_row_products(ZsParams p) {
     const size_t n = (size_t)1 << p.log_n;
     if (i >= n) return;
     const uint64_t x = root_pow(p.w_n_table, (uint32_t)i, (uint32_t)(n >> 1));
-    constexpr int MAXQ = 10;  // chunks per challenge (ceil(80 / 8))
-    uint64_t num[2 * MAXQ], den[2 * MAXQ];
+    constexpr int MAXQ = 10;  // chunks per challenge (ceil(80 / 8)); every array below is indexed by unrolled loop counters
+    uint64_t num[2 * MAXQ], den[2 * MAXQ];   // only: they stay in registers (runtime indices had put them in scratch, 496 bytes per lane)
     const uint32_t n_chunks = (p.routed + p.chunk - 1) / p.chunk;
-    for (uint32_t c = 0; c < p.nc; c++) {
-        const uint64_t beta = p.betas[c], gamma = p.gammas[c];
-        const uint64_t bx = gl::mul(beta, x);
-#pragma unroll 1
-        for (uint32_t q = 0; q < n_chunks; q++) {
-            uint64_t nm = 1, dn = 1;
+    // every wire / sigma value is loaded ONCE and feeds both challenges (the first version walked the 160 columns once per
+    // challenge: PMC 0.86 GB fetched per launch at 2^18 rows for 0.34 GB of columns)
+    const uint64_t bx0 = gl::mul(p.betas[0], x), bx1 = gl::mul(p.betas[1], x);
+#pragma unroll
+    for (int q = 0; q < MAXQ; q++) {
+        uint64_t nm0 = 1, dn0 = 1, nm1 = 1, dn1 = 1;
+        if ((uint32_t)q < n_chunks) {
             for (uint32_t j = q * p.chunk; j < (q + 1) * p.chunk && j < p.routed; j++) {
                 const uint64_t w = p.wires[(size_t)j * p.wires_stride + i];
                 const uint64_t sg = p.sigmas[(size_t)j * n + i];
-                nm = gl::mul(nm, gl::add(gl::add(w, gl::mul(bx, p.k_is[j])), gamma));
-                dn = gl::mul(dn, gl::add(gl::add(w, gl::mul(beta, sg)), gamma));
+                const uint64_t kj = p.k_is[j];
+                nm0 = gl::mul(nm0, gl::add(gl::add(w, gl::mul(bx0, kj)), p.gammas[0]));
+                dn0 = gl::mul(dn0, gl::add(gl::add(w, gl::mul(p.betas[0], sg)), p.gammas[0]));
+                if (p.nc > 1) {
+                    nm1 = gl::mul(nm1, gl::add(gl::add(w, gl::mul(bx1, kj)), p.gammas[1]));
+                    dn1 = gl::mul(dn1, gl::add(gl::add(w, gl::mul(p.betas[1], sg)), p.gammas[1]));
+                }
             }
-            num[c * MAXQ + q] = nm;
-            den[c * MAXQ + q] = dn;
         }
+        num[q] = nm0;
+        den[q] = dn0;
+        num[MAXQ + q] = nm1;
+        den[MAXQ + q] = dn1;   // unused chunks / the unused challenge hold 1: they pass through the batch inversion unchanged
     }
-    // batch inversion of all denominators of this row
-    const uint32_t total = p.nc * n_chunks;
+    // batch inversion of all denominators of this row: pref[t] = den[0] .. den[t-1], one inversion, then backwards
     uint64_t pref[2 * MAXQ];
     uint64_t acc = 1;
-    for (uint32_t t = 0; t < total; t++) {
-        const uint32_t idx = (t / n_chunks) * MAXQ + (t % n_chunks);
+#pragma unroll
+    for (int t = 0; t < 2 * MAXQ; t++) {
         pref[t] = acc;
-        acc = gl::mul(acc, den[idx]);
+        acc = gl::mul(acc, den[t]);
     }
     uint64_t inv = gl::inv(acc);
-    for (uint32_t t = total; t-- > 0;) {
-        const uint32_t idx = (t / n_chunks) * MAXQ + (t % n_chunks);
-        const uint64_t d = den[idx];
-        den[idx] = gl::mul(inv, pref[t]);  // 1 / den
+#pragma unroll
+    for (int t = 2 * MAXQ - 1; t >= 0; t--) {
+        const uint64_t d = den[t];
+        den[t] = gl::mul(inv, pref[t]);  // 1 / den
         inv = gl::mul(inv, d);
     }
-    for (uint32_t c = 0; c < p.nc; c++) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
         uint64_t cum = 1;
-        for (uint32_t q = 0; q < n_chunks; q++) {
-            cum = gl::mul(cum, gl::mul(num[c * MAXQ + q], den[c * MAXQ + q]));
-            if (q + 1 < n_chunks) p.out[(size_t)(p.nc + c * p.npp + q) * n + i] = cum;
-            else p.out[(size_t)c * n + i] = cum;  // row product, turned into Z by the scan
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) {
+            if ((uint32_t)c < p.nc && (uint32_t)q < n_chunks) {
+                cum = gl::mul(cum, gl::mul(num[c * MAXQ + q], den[c * MAXQ + q]));
+                if ((uint32_t)q + 1 < n_chunks) p.out[(size_t)(p.nc + c * p.npp + q) * n + i] = cum;
+                else p.out[(size_t)c * n + i] = cum;  // row product, turned into Z by the scan
+            }
         }
     }
 }
