@@ -15,4 +15,4 @@ def test_repeated_proofs_are_identical_and_memory_is_stable():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "5"], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-1500:] + r.stdout[-500:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["iterations"] == 5 and len(out["proofs"]) == 6 and out["in_use_bytes"] > 0   # four provers, the BN254 NTT and the MSM
+    assert out["iterations"] == 5 and len(out["proofs"]) == 9 and out["in_use_bytes"] > 0   # five provers (one with lookup tables), the BN254 NTT, MSM, PLONK quotient chain and KZG opening

@@ -27,7 +27,16 @@ bn_cols = rs.randint(0, 1 << 60, size=(2, 1 << 14, 4), dtype=np.int64).astype(np
 g1 = np.tile(nlx.bn254_g1_pack([(1, 2), (1368015179489954701390400359078579693043519447331113978918064868415326638035,
                                          9918110051302171585080402603319702774565515993150576347155970296011118125764)]), (1 << 13, 1))
 ks = rs.randint(0, 1 << 60, size=(1 << 14, 4), dtype=np.int64).astype(np.uint64)
+syn_lk = nlx.SyntheticCircuit(11, seed=8, num_luts=2, lut_bits=9, num_lookups=700)                   # two plonky2 lookup tables
+cd_lk = nlx.CircuitData.from_synthetic(ctx, syn_lk)
+fr = lambda rows: np.concatenate([rs.randint(0, 1 << 60, size=(rows, 3), dtype=np.int64), rs.randint(0, 1 << 58, size=(rows, 1), dtype=np.int64)],
+                                 axis=1).astype(np.uint64)                                           # fr.Element words below r
+plonk_polys = {k: fr(1 << 10) for k in ("ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3", "l", "r", "o", "z")}
+kzg_poly, kzg_srs = fr(3000), nlx.bn254_g1_multiples(ctx, (1, 2), 2999)
 jobs = {"plonky2_2p13": lambda: cd.prove(syn.wires, syn.public_inputs), "sha256_2p6": lambda: p256.prove(msgs)[0],
+        "plonky2_2p11_lookup_tables": lambda: cd_lk.prove(syn_lk.wires, syn_lk.public_inputs),
+        "bn254_plonk_quotient_2p10": lambda: nlx.bn254_plonk_quotient(ctx, plonk_polys, 5, 5, 25, 1234, 5678, 91011)[0].tobytes(),
+        "bn254_kzg_open_3000": lambda: b"".join(x.tobytes() for x in nlx.bn254_kzg_open(ctx, kzg_poly, 777, srs=kzg_srs)),
         "sha512_2p5": lambda: p512.prove(msgs)[0], "ed25519_2p8": lambda: ped.prove(slots),
         "bn254_ntt_2p14_coset_dit": lambda: nlx.bn254_ntt(ctx, bn_cols, coset_shift=5, bitrev_in=True).tobytes(),
         "bn254_msm_2p14": lambda: nlx.bn254_msm_g1(ctx, g1, ks).tobytes()}
