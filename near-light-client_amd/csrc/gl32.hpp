@@ -126,7 +126,7 @@ __device__ __forceinline__ F fold_acc(uint64_t al, uint64_t ah) {
     uint32_t r1, m;
     asm("v_add_co_u32 %[r1], vcc, %[t1], %[ah0]\n\t"
         "v_cndmask_b32_e64 %[m], 0, -1, vcc"
-        : [r1] "=&v"(r1), [m] "=&v"(m)
+        : [r1] "=v"(r1), [m] "=v"(m)   // no early clobber: r1 may take over t's dying high register (no v_mov to re-form the pair)
         : [t1] "v"((uint32_t)(t >> 32)), [ah0] "v"((uint32_t)ah)
         : "vcc");
     uint64_t r;
@@ -170,18 +170,27 @@ __device__ __forceinline__ void mds_layer(F (&s)[12], const uint64_t* __restrict
 // a wave (one state per lane, as everywhere in the hashing kernels).  No lane ever moves data: column n of B is supplied by
 // lane n (k < 16) and lane n + 32 (k >= 16), each its OWN state's twelve bytes of the plane, and A is placed so that output r
 // of the state in lane n + 32 h lands in row (r & 3) + 8 (r >> 2) + 4 h - which the 32 x 32 accumulator layout (col =
-// lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) hands back to that same lane as register r.  A lane's outputs
-// depend on its own inputs only, so lanes that have left the kernel do no harm.  The instruction's bytes are signed: the
-// planes are biased by 128 (xor 0x80) and 128 * rowsum * (1 + 2^8 + 2^16 + 2^24) rides in the table that seeds the
-// recombination (RCB, with the next round's constants).  Per layer: 24 xor + 48 v_perm + 8 MFMA + 96 v_mad_i64_i32 + the
-// 4-instruction folds = ~285 vector instructions where the multiply-accumulate form above needs ~430; the matrix pipe runs
-// beside the vector pipe.  Measured (tools/ubench, profiles/r03_poseidon_occupancy.txt): 1.74 -> 2.09 G permutations/s,
-// bit-identical outputs.
+// lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) hands back to that same lane as register r.
+//
+// CONTRACT: the constant operand A is spread over ALL 64 lanes of the wave (and must be zero in the lanes that hold no row),
+// and the matrix cores read every lane's registers whatever EXEC says: every lane of a wave must reach the permutation, with
+// EXEC all ones.  Callers clamp spare lanes to the last item and store nothing for them; no caller may return early.
+//
+// The instruction's bytes are signed: the planes are biased by 128 (xor 0x80), and the correction 128 * rowsum(r) is added BY
+// THE MATRIX CORES (round 4): a state uses twelve of its sixteen K slots, three of the spare ones hold the constant -128 in B
+// and -128, -128, (r == 0 ? -8 : 0) in A: 2 * 16384 + 1024 [r == 0] = 128 * 256 (+ 128 * 8).  Every D_b[r] is therefore the
+// exact unsigned sum  sum_j M[r][j] byte_b(s_j)  in [0, 67 320] and the recombination needs no sign handling:
+//   x = D_0 + 2^8 D_1, y = D_2 + 2^8 D_3 per 32-bit half (v_lshl_add_u32, full rate), then
+//   value = xL + 2^16 yL + 2^32 xH + 2^48 yH:  T = yL * 2^16 + (xH : xL) is ONE v_mad_u64_u32 on the register PAIR, and
+//   fold_pair adds 2^48 yH mod p (2^64 = EPS: five multiply / carry class instructions).
+// An output that also takes a round constant keeps the two-accumulator form (seeded from scalar registers) and fold_acc.
+// Per output 10 vector instructions of which 6 are multiply / carry class (12 and 8 with a constant); round 3 had 14 (8 + 2 + 4),
+// all of them multiply / carry class, plus 2 moves.  Per layer: 24 xor + 48 v_perm + 8 MFMA + ~130.
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
 
 // this lane's A operand: A[row = lane & 31][k = 16 (lane >> 5) + j], j = 0 .. 15 (the same k order as the B operand below,
-// whatever the hardware's order inside a lane's sixteen bytes is)
+// whatever the hardware's order inside a lane's sixteen bytes is); slots 12 .. 14 carry the bias correction (see above)
 __device__ __forceinline__ i32x4_t mds_a_fragment() {
     constexpr int C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     const uint32_t lane = threadIdx.x & 63, rho = lane & 31, h = lane >> 5;
@@ -196,11 +205,14 @@ __device__ __forceinline__ i32x4_t mds_a_fragment() {
                 if ((uint32_t)rr == r) m = (uint32_t)C[(j - rr + 12) % 12] + ((rr == 0 && j == 0) ? 8u : 0u);
             w[j >> 2] |= m << (8 * (j & 3));
         }
+        w[3] = r == 0 ? 0x00F88080u : 0x00008080u;
     }
     i32x4_t a;
     a.x = (int)w[0]; a.y = (int)w[1]; a.z = (int)w[2]; a.w = (int)w[3];
     return a;
 }
+constexpr uint32_t MDS_B_BIAS_SLOTS = 0x00808080u;   // the B operand's fourth dword: -128 in K slots 12 .. 14, slot 15 unused
+
 // 4 x 4 byte transpose: p[b] = (x0.byte b, x1.byte b, x2.byte b, x3.byte b)
 __device__ __forceinline__ void transpose_bytes4(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t (&p)[4]) {
     const uint32_t t01l = __builtin_amdgcn_perm(x1, x0, 0x05010400u), t01h = __builtin_amdgcn_perm(x1, x0, 0x07030602u);
@@ -210,17 +222,50 @@ __device__ __forceinline__ void transpose_bytes4(uint32_t x0, uint32_t x1, uint3
     p[2] = __builtin_amdgcn_perm(t23h, t01h, 0x05040100u);
     p[3] = __builtin_amdgcn_perm(t23h, t01h, 0x07060302u);
 }
-__device__ __forceinline__ int opaque_sgpr(int v) {   // a wave-uniform constant the compiler must treat as a register, so
-    asm("" : "+s"(v));                                 // that d * 2^(8k) + acc stays ONE v_mad_i64_i32 (not shifts and adds)
-    return v;
+// a * b + c as ONE v_mad_u64_u32 (the compiler would expand a power-of-two b into shifts and carry chains); the carry-out
+// goes to a scalar pair nobody reads, so VCC stays free for the neighbours
+__device__ __forceinline__ uint64_t mad_u64(uint32_t a, uint32_t b, uint64_t c) {
+    uint64_t r, sink;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sink) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
-// rcb: 24 wave-uniform words: [r] = bias + low half of the NEXT round's constant r, [12 + r] = bias + its high half
+__device__ __forceinline__ uint64_t mad_u64_sc(uint32_t a, uint32_t b, uint64_t c_uniform) {   // c from scalar registers
+    uint64_t r, sink;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sink) : "v"(a), "v"(b), "s"(c_uniform));
+    return r;
+}
+__device__ __forceinline__ uint64_t mad_u64_one(uint32_t a, uint64_t c) {   // a + c
+    uint64_t r, sink;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(r), "=s"(sink) : "v"(a), "v"(c));
+    return r;
+}
+// t + 2^48 yh (mod p) -> loose, for t < 2^59 and yh < 2^26.  z = yh * 2^16 = z0 + 2^32 z1 (one multiply, z1 < 2^10) and
+// 2^48 yh = 2^32 z0 + 2^64 z1; 2^64 = EPS, so z1 folds in by a multiply-add that cannot carry and z0 lands on the high word,
+// the only addition that can carry - once, worth EPS, and adding it cannot carry again.
+__device__ __forceinline__ F fold_pair(uint64_t t, uint32_t yh, uint32_t k16) {
+    uint64_t z, u, sink, sink2;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(z), "=s"(sink) : "v"(yh), "v"(k16));
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(u), "=s"(sink2) : "v"((uint32_t)(z >> 32)), "v"(t));
+    uint32_t r1, m;
+    asm("v_add_co_u32 %0, vcc, %2, %3\n\t"
+        "v_cndmask_b32_e64 %1, 0, -1, vcc"
+        : "=v"(r1), "=v"(m)
+        : "v"((uint32_t)(u >> 32)), "v"((uint32_t)z)
+        : "vcc");
+    return from_u64(mad_u64_one(m, ((uint64_t)r1 << 32) | (uint32_t)u));
+}
+
+// RC: 0 = no round constant follows this layer, 1 = a constant for output 0 only (the partial rounds, poseidon.hpp), 2 = twelve.
+// rcb: 24 wave-uniform words: [r] = low half of the NEXT round's constant r, [12 + r] = its high half (zero-extended)
+template <int RC>
 __device__ __forceinline__ void mds_layer_mfma(F (&s)[12], const i32x4_t a, const uint64_t* __restrict__ rcb) {
-    const int m0 = opaque_sgpr(1), m8 = opaque_sgpr(1 << 8), m16 = opaque_sgpr(1 << 16), m24 = opaque_sgpr(1 << 24);
+    uint32_t k16 = 65536u, bw = MDS_B_BIAS_SLOTS;
+    asm("" : "+v"(k16));   // a register the compiler cannot see through: yL * k16 + pair stays ONE v_mad_u64_u32
+    asm("" : "+v"(bw));    // likewise: a B operand assembled around a literal costs five moves per MFMA instead of one
     i32x16_t zero;
 #pragma unroll
     for (int i = 0; i < 16; i++) zero[i] = 0;
-    uint64_t acc[2][12];
+    uint32_t x[2][12], y[2][12];
 #pragma unroll
     for (int half = 0; half < 2; half++) {   // planes 0 .. 3 come from the low words, 4 .. 7 from the high words
         uint32_t pl[4][3];
@@ -240,21 +285,27 @@ __device__ __forceinline__ void mds_layer_mfma(F (&s)[12], const i32x4_t a, cons
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             i32x4_t bf;
-            bf.x = (int)pl[b][0]; bf.y = (int)pl[b][1]; bf.z = (int)pl[b][2]; bf.w = 0;
+            bf.x = (int)pl[b][0]; bf.y = (int)pl[b][1]; bf.z = (int)pl[b][2]; bf.w = (int)bw;
             d[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf, zero, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 12; r++) {
-            int64_t t = (int64_t)d[0][r] * m0 + (int64_t)rcb[12 * half + r];
-            t = (int64_t)d[1][r] * m8 + t;
-            t = (int64_t)d[2][r] * m16 + t;
-            t = (int64_t)d[3][r] * m24 + t;
-            acc[half][r] = (uint64_t)t;
+            x[half][r] = ((uint32_t)d[1][r] << 8) + (uint32_t)d[0][r];
+            y[half][r] = ((uint32_t)d[3][r] << 8) + (uint32_t)d[2][r];
         }
         __builtin_amdgcn_sched_barrier(0);   // the low half's sixteen-register results are dead before the high half's exist
     }
 #pragma unroll
-    for (int r = 0; r < 12; r++) s[r] = fold_acc(acc[0][r], acc[1][r]);
+    for (int r = 0; r < 12; r++) {
+        if (RC == 2 || (RC == 1 && r == 0)) {
+            const uint64_t al = mad_u64_one(x[0][r], mad_u64_sc(y[0][r], k16, rcb[r]));
+            const uint64_t ah = mad_u64_one(x[1][r], mad_u64_sc(y[1][r], k16, rcb[12 + r]));
+            s[r] = fold_acc(al, ah);
+        } else {
+            const uint64_t t = mad_u64(y[0][r], k16, ((uint64_t)x[1][r] << 32) | x[0][r]);
+            s[r] = fold_pair(t, y[1][r], k16);
+        }
+    }
 }
 
 }  // namespace gl32

@@ -23,22 +23,49 @@ constexpr int N_PARTIAL = 22;
 
 #if defined(__HIP__)
 __constant__ static const uint64_t RC_DEV[360] = NLX_POSEIDON_ROUND_CONSTANTS_INIT;
-// Seeds of the matrix-core linear layer's recombination (gl32::mds_layer_mfma): for layer l = 0 .. 30 and output r, the
-// byte-plane bias 128 * rowsum(r) * (1 + 2^8 + 2^16 + 2^24) plus the low ([r]) / high ([12 + r]) half of round l's constant
-// (l = 30: the bias alone - the last layer adds no constant).
+// Seeds of the matrix-core linear layer's recombination (gl32::mds_layer_mfma): for layer l = 1 .. 29 and output r the low
+// ([r]) and high ([12 + r]) half of the constant that round l adds, zero-extended to the 64-bit scalar operand of the seed.
+//
+// The partial rounds' constants are MOVED, not changed in effect (round 4): only element 0 passes through an S-box in rounds
+// 4 .. 25, so the eleven other constants of a partial round can ride along as a known offset delta_r (delta_r[0] = 0) of the
+// state and be settled once: with t_r the state before round r's S-boxes and tt_r = t_r - delta_r the state the kernel holds,
+//   delta_4 = 0,  v = c_{r+1} + M delta_r,  cc_{r+1} = (v[0], 0, ..., 0),  delta_{r+1} = (0, v[1], ..., v[11])   (r + 1 = 5 .. 25)
+//   cc_26 = c_26 + M delta_25   (twelve constants again: delta_26 = 0, the full rounds see the true state).
+// Rounds 5 .. 25 then add ONE constant (to element 0) instead of twelve: eleven outputs of those 21 layers take the cheaper
+// recombination without a seed.  The permutation's outputs are the same field elements (tests: upstream's known answers).
 struct RcbTable {
     uint64_t v[31 * 24];
 };
+constexpr uint64_t rcb_mulmod(uint64_t a, uint64_t b) { return (uint64_t)((unsigned __int128)a * b % gl::P); }
+constexpr uint64_t rcb_addmod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a + b) % gl::P); }
 constexpr RcbTable make_rcb_table() {
     constexpr uint64_t rc[360] = NLX_POSEIDON_ROUND_CONSTANTS_INIT;
+    constexpr uint64_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     RcbTable t{};
-    for (int l = 0; l <= 30; l++)
-        for (int r = 0; r < 12; r++) {
-            const uint64_t bias = 128ull * (r == 0 ? 264ull : 256ull) * 0x01010101ull;
-            const uint64_t c = l < 30 ? rc[l * 12 + r] : 0ull;
-            t.v[l * 24 + r] = bias + (c & 0xFFFFFFFFull);
-            t.v[l * 24 + 12 + r] = bias + (c >> 32);
+    uint64_t delta[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int l = 1; l <= 29; l++) {
+        uint64_t c[12] = {};
+        for (int r = 0; r < 12; r++) c[r] = rc[l * 12 + r];
+        if (l >= HALF_FULL + 1 && l <= HALF_FULL + N_PARTIAL) {   // rounds 5 .. 26: add M delta
+            for (int r = 0; r < 12; r++) {
+                uint64_t acc = c[r];
+                for (int i = 0; i < 12; i++) acc = rcb_addmod(acc, rcb_mulmod(C[i], delta[(i + r) % 12]));
+                if (r == 0) acc = rcb_addmod(acc, rcb_mulmod(8, delta[0]));
+                c[r] = acc;
+            }
+            if (l < HALF_FULL + N_PARTIAL) {   // rounds 5 .. 25: keep element 0's constant, carry the rest
+                delta[0] = 0;
+                for (int r = 1; r < 12; r++) {
+                    delta[r] = c[r];
+                    c[r] = 0;
+                }
+            }
         }
+        for (int r = 0; r < 12; r++) {
+            t.v[l * 24 + r] = c[r] & 0xFFFFFFFFull;
+            t.v[l * 24 + 12 + r] = c[r] >> 32;
+        }
+    }
     return t;
 }
 __constant__ static const RcbTable RCB_DEV = make_rcb_table();
@@ -99,8 +126,12 @@ GL_HD void permute_loose(uint64_t (&s)[12]) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // device: {lo, hi} u32 pairs with hand-placed carry chains (gl32.hpp); the linear layer runs on the matrix cores
     // (gl32::mds_layer_mfma: one state per lane, all of a wave's lanes together) and every round's constants seed the
-    // recombination of the PREVIOUS layer (only round 0 adds them explicitly).  Callers keep the call in wave-uniform
-    // control flow (lanes may have LEFT the kernel - a lane's results depend on its own inputs only).
+    // recombination of the PREVIOUS layer (only round 0 adds them explicitly; rounds 5 .. 25 have one constant each, see
+    // make_rcb_table).  CONTRACT: every lane of the wave reaches this call with EXEC all ones (gl32.hpp) - callers clamp
+    // spare lanes to the last item instead of returning.
+#if defined(NLX_DEBUG)
+    if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
+#endif
     const uint64_t* rcb = RCB_DEV.v;
     const gl32::i32x4_t a = gl32::mds_a_fragment();
     gl32::F t[12];
@@ -110,19 +141,24 @@ GL_HD void permute_loose(uint64_t (&s)[12]) {
     for (int r = 0; r < HALF_FULL; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) t[i] = gl32::sbox7(t[i]);
-        gl32::mds_layer_mfma(t, a, rcb + (r + 1) * 24);
+        gl32::mds_layer_mfma<2>(t, a, rcb + (r + 1) * 24);
     }
 #pragma unroll 1
-    for (int r = HALF_FULL; r < HALF_FULL + N_PARTIAL; r++) {
+    for (int r = HALF_FULL; r < HALF_FULL + N_PARTIAL - 1; r++) {
         t[0] = gl32::sbox7(t[0]);
-        gl32::mds_layer_mfma(t, a, rcb + (r + 1) * 24);
+        gl32::mds_layer_mfma<1>(t, a, rcb + (r + 1) * 24);
     }
+    t[0] = gl32::sbox7(t[0]);
+    gl32::mds_layer_mfma<2>(t, a, rcb + (HALF_FULL + N_PARTIAL) * 24);
 #pragma unroll 1
-    for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS; r++) {
+    for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS - 1; r++) {
 #pragma unroll
         for (int i = 0; i < 12; i++) t[i] = gl32::sbox7(t[i]);
-        gl32::mds_layer_mfma(t, a, rcb + (r + 1) * 24);   // r + 1 = 30: the bias alone
+        gl32::mds_layer_mfma<2>(t, a, rcb + (r + 1) * 24);
     }
+#pragma unroll
+    for (int i = 0; i < 12; i++) t[i] = gl32::sbox7(t[i]);
+    gl32::mds_layer_mfma<0>(t, a, rcb);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = gl32::to_u64(t[i]);
 #else
