@@ -112,6 +112,10 @@ def parse():
     ap.add_argument("--lookup-tables", type=int, default=0, help="outer workload: plonky2 lookup tables in the circuit (LookupGate / LookupTableGate rows, 0 = none)")
     ap.add_argument("--lookup-bits", type=int, default=16, help="outer workload: 2^k (input, output) pairs per table")
     ap.add_argument("--lookups", type=int, default=100000, help="outer workload: lookups into every table")
+    ap.add_argument("--stark-variant", default="starky", choices=["starky", "grouped-leaves"],
+                    help="starky (default, the headline): whole-row hash_or_noop Merkle leaves and every opening observed by the "
+                         "transcript - the reference's STARK protocol; grouped-leaves: round 3's protocol variant for wide, short traces "
+                         "(StarkConfig.grouped()), a labelled extra")
     ap.add_argument("--no-extra", action="store_true", help="sync workload: skip the plonky2-only 2^16 figures and the verify128 record")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent proofs in flight per GPU (one context + stream + host thread each); the K "
@@ -153,8 +157,7 @@ def dist_setup(n_gpus):
         dist = dist_mod
     else:
         torch.cuda.set_device(local)
-    if world != n_gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (n_gpus, world), file=sys.stderr)
+    assert world == n_gpus, "relaunch_under_torchrun() lets no other combination through"
     return rank, world, local, dist
 
 
@@ -656,9 +659,12 @@ def sync_step_setup(args, nlx, torch, rank, local):
     st["step_tag"] = nlx.stark.step_tag(sync_in + sync_out)
     ctxs = [nlx.Context(local) for _ in range(4)]
     st["ctxs"] = ctxs
-    st["p256"] = SA.Sha256Prover(ctxs[0], st["lb256"], step_tag=st["step_tag"])
-    st["p512"] = SB.Sha512Prover(ctxs[1], st["lb512"], step_tag=st["step_tag"])
-    st["ped"] = E.Ed25519Prover(ctxs[2], st["log_slots"], step_tag=st["step_tag"])
+    variant = getattr(args, "stark_variant", "starky")
+    mk_cfg = nlx.StarkConfig.grouped if variant == "grouped-leaves" else nlx.StarkConfig
+    st["stark_variant"] = variant
+    st["p256"] = SA.Sha256Prover(ctxs[0], st["lb256"], mk_cfg(), step_tag=st["step_tag"])
+    st["p512"] = SB.Sha512Prover(ctxs[1], st["lb512"], mk_cfg(), step_tag=st["step_tag"])
+    st["ped"] = E.Ed25519Prover(ctxs[2], st["log_slots"], mk_cfg(), step_tag=st["step_tag"])
     syn = nlx.SyntheticCircuit(args.log_n, seed=1000 + rank, num_public_inputs=64, **GATE_MIXES[args.gate_mix])
     syn.set_public_inputs(io.bytes_to_field_elements(sync_in + sync_out))
     st["syn"], st["sync_out"] = syn, sync_out
@@ -834,6 +840,11 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
                                    % (len(st["sha_msgs"]), st["lb256"], st["lb256"] + 2, p256.stark.desc.n_cols, st["n_sigs"], st["lb512"],
                                       st["n_validators"], st["n_sigs"], st["log_slots"], ped.stark.desc.degree_bits, args.log_n, st["syn"].num_gates),
                        "log_n_outer": args.log_n, "gate_mix_pct": GATE_MIXES[args.gate_mix],
+                       # the STARK protocol of the three sub-proofs: "starky" = the reference's (whole-row hash_or_noop leaves,
+                       # every opening observed); 0 / 0 below is the only setting an unpatched starky-style verifier accepts
+                       "stark_variant": st["stark_variant"],
+                       "leaf_group_cols": max(int(pr.stark.desc.leaf_group_cols) for pr in (p256, p512, ped)),
+                       "openings_group": max(int(pr.stark.desc.openings_group) for pr in (p256, p512, ped)),
                        "outer_rows_floor_from_stark_verification": rows,
                        "public_inputs": "64 bytes of real Sync I/O (fixtures/main_2.json): new head hash 0x%s" % st["sync_out"].hex(),
                        "proof_bytes": {"sha256": len(a[0]), "sha512": len(b[0]), "ed25519": len(c_proof), "outer": outer_len},
@@ -876,7 +887,7 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
     if not args.no_extra:
         import copy
         va = copy.copy(args)
-        va.steps, va.warmup, va.map_starks = 2, 1, False
+        va.steps, va.warmup, va.map_starks = 2, 1, True   # the map jobs' SHA-256 STARKs are part of the recorded job (builder.rs:344-363, merkle.rs:43-50)
         try:
             v = run_verify128(va, nlx, torch, rank, world, local, dist)
         except Exception as e:   # the Sync measurement stands whatever happens to the extra record (every rank runs the same code,
@@ -888,6 +899,7 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
                                 "level_ms": v["config"]["level_ms_last_step"], "bytes_gathered": v["config"]["bytes_gathered_last_step"],
                                 "root_digest": v["config"]["root_digest"], "output_ok": v["config"]["output_lists_every_id_as_verified"],
                                 "oracle_verifier_accepts_outer_proof": v["config"]["oracle_verifier_accepts_outer_proof"],
+                                "map_starks": v["config"]["map_starks"], "map_starks_ms_per_job": v["config"]["map_starks_ms_per_step_rank0"],
                                 "map_log_n": va.map_log_n, "reduce_log_n": va.reduce_log_n, "proofs_in_flight_per_gpu": va.inflight,
                                 "roofline": v["roofline"], "cpu_baseline": v["cpu_baseline"],
                                 "note": "the VerifyCircuit 128 x 4 map-reduce job of `--workload verify128`, 1 warm-up + 2 timed jobs after "
@@ -1499,8 +1511,36 @@ def run_verify128(args, nlx, torch, rank, world, local, dist, t_outer_2p15=None)
     return mr.bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer, cpu)
 
 
+def relaunch_under_torchrun(args):
+    """--gpus N > 1 without a launcher (WORLD_SIZE unset): start the N ranks ourselves, as CHILD processes of a process that
+    has not touched the GPU yet (no exec: the pool forbids replacing a process that initialised HIP, and this one has not even
+    imported torch), and leave with the launcher's exit code.  A WORLD_SIZE that disagrees with --gpus is an error, not a
+    warning: the line would otherwise report n_gpus = WORLD_SIZE for a run the caller believes to be on N GPUs."""
+    world = os.environ.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != args.gpus:
+            print("error: --gpus %d but WORLD_SIZE=%s; launch with python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                  "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, world, args.gpus, args.gpus), file=sys.stderr)
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher, starting %s" % (args.gpus, " ".join(cmd[1:9])), file=sys.stderr)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    relaunch_under_torchrun(args)   # before anything touches the GPU
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (there is no CPU fallback)")

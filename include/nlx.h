@@ -54,7 +54,9 @@ void nlx_field_generators(uint64_t out[2]);
 /* Self-test of the "never throws" rule on the caller's platform: raises a C++ exception INSIDE the library - kind 0: a
  * real failed host allocation (a std::vector larger than the address space), 1: std::runtime_error, 2: a non-standard
  * object - and returns what the entry points' guard makes of it: NLX_E_NOMEM for kind 0, NLX_E_INVAL otherwise
- * (NLX_E_RANGE for an unknown kind).  Needs no context and no GPU.  Every extern "C" definition of the library is a
+ * (NLX_E_RANGE for an unknown kind).  Kinds 3 / 4 / 5 arm / disarm a fault in nlx_batch_prove's start-up (3: starting the
+ * second worker thread fails, 4: the first, 5: off; they return NLX_OK): the batch must still return a code, with the
+ * workers that did start joined and every job proved (tests/test_gpu_mapreduce.py).  Needs no context and no GPU.  Every extern "C" definition of the library is a
  * function-try-block with this guard (csrc/ctx.hpp NLX_TRY / NLX_CATCH), so a std::bad_alloc in the host-side
  * orchestration reaches a Rust / Go caller as a return code (crates/protocol/src/prelude.rs:1 maps
  * such codes to anyhow::Error at the caller), never as an unwind through foreign frames. */

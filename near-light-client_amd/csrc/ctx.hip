@@ -132,6 +132,7 @@ void nlx_ctx::end_kernel() {
 }
 
 namespace nlx {
+std::atomic<int> batch_spawn_fault_after{-1};   // fault injection for nlx_batch_prove (prover.hip), armed by nlx_abi_selftest
 
 bool is_device_ptr(const void* p) {
     if (!p) return false;
@@ -201,6 +202,10 @@ int32_t nlx_abi_selftest(int32_t kind) NLX_TRY {
     }
     if (kind == 1) throw std::runtime_error("nlx_abi_selftest");
     if (kind == 2) throw 42;
+    if (kind >= 3 && kind <= 5) {   // fault injection for nlx_batch_prove's thread start-up: 3 = the second worker fails, 4 = the first, 5 = off
+        nlx::batch_spawn_fault_after = kind == 3 ? 1 : kind == 4 ? 0 : -1;
+        return NLX_OK;
+    }
     return NLX_E_RANGE;
 } catch (const std::length_error&) {
     return NLX_E_NOMEM;

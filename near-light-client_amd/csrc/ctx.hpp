@@ -1,6 +1,7 @@
 // Per-device context: stream, caching device allocator, twiddle / coset tables, error slot.
 // One context per HIP device and per host thread (SURVEY.md §8b threading contract).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
@@ -75,6 +76,7 @@ struct nlx_ctx {
 // function-try-block:   int32_t nlx_foo(nlx_ctx* ctx, ...) NLX_TRY { ... } NLX_CATCH(ctx)
 // std::bad_alloc -> NLX_E_NOMEM, anything else -> NLX_E_INVAL, with nlx_last_error set when the call has a context.
 namespace nlx {
+extern std::atomic<int> batch_spawn_fault_after;   // ctx.hip
 inline void on_exception(nlx_ctx* ctx, const char* what) noexcept {
     if (!ctx) return;
     try {

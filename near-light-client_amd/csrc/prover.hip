@@ -676,7 +676,11 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
         for (uint32_t i = 0; i < nc; i++) betas[i] = ch.challenge();
         for (uint32_t i = 0; i < nc; i++) gammas[i] = ch.challenge();
         // lookup challenges: deltas = betas ++ gammas ++ 2 nc more, NUM_COINS_LOOKUP = 4 per round (A, B, alpha, delta)
+        // deltas and lut_polys are the SOURCES of asynchronous host-to-device copies: both live until the function returns (the
+        // fetch() of the Zs cap below synchronises the stream after the second copy is enqueued; nothing here relies on the
+        // runtime staging a pageable source at call time)
         uint64_t deltas[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t lut_polys[2 * 16] = {};
         uint64_t* d_deltas = nullptr;   // deltas[4 nc] | lut_polys[nc tables]
         if (d.num_luts) {
             for (uint32_t i = 0; i < nc; i++) { deltas[i] = betas[i]; deltas[nc + i] = gammas[i]; }
@@ -692,7 +696,6 @@ int32_t nlx_prove(nlx_circuit* c, const uint64_t* wires, const uint64_t* public_
         if (d.num_luts) {
             // vanishing_poly::get_lut_poly per (round, table), on the host while the device builds the Zs commitment: the pairs
             // (inp + B out) as coefficients in delta, first entry highest, zero-padded to whole table rows
-            uint64_t lut_polys[2 * 16];
             for (uint32_t ci = 0; ci < nc; ci++)
                 for (uint32_t t = 0; t < d.num_luts; t++) {
                     const uint32_t len = c->lut_sizes[t], slots = c->lk.n_lut_slots;
@@ -831,6 +834,9 @@ done:
     return rc;
 } NLX_CATCH(nullptr)
 
+// test hook nlx::batch_spawn_fault_after (armed by nlx_abi_selftest kind 3 / 4, ctx.hip): pretend that starting worker thread
+// number >= this fails; -1 = off
+
 int32_t nlx_batch_prove(nlx_circuit* const* workers, uint32_t n_workers, nlx_prove_job* jobs, size_t n_jobs) NLX_TRY {
     if (!workers || n_workers == 0 || (!jobs && n_jobs)) return NLX_E_INVAL;
     for (uint32_t w = 0; w < n_workers; w++) {
@@ -852,10 +858,24 @@ int32_t nlx_batch_prove(nlx_circuit* const* workers, uint32_t n_workers, nlx_pro
     if (n_workers == 1) {
         run(workers[0]);
     } else {
+        // a std::thread that is still joinable when it is destroyed calls std::terminate: if creating worker w fails
+        // (std::system_error: no more threads), the workers already started are left to drain the queue and are JOINED before the
+        // error leaves this function as a return code (NLX_CATCH); the jobs they proved keep their status
         std::vector<std::thread> threads;
         threads.reserve(n_workers);
-        for (uint32_t w = 0; w < n_workers; w++) threads.emplace_back(run, workers[w]);
+        bool spawn_failed = false;
+        for (uint32_t w = 0; w < n_workers; w++) {
+            try {
+                if (batch_spawn_fault_after >= 0 && (int)w >= batch_spawn_fault_after) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+                threads.emplace_back(run, workers[w]);
+            } catch (...) {
+                spawn_failed = true;
+                break;
+            }
+        }
+        if (spawn_failed && threads.empty()) run(workers[0]);   // nobody started: the calling thread does the work
         for (auto& t : threads) t.join();
+        if (spawn_failed) workers[0]->ctx->fail(NLX_OK, "nlx_batch_prove: could not start every worker thread; the jobs were proved by the ones that started");
     }
     for (size_t j = 0; j < n_jobs; j++)
         if (jobs[j].status != NLX_OK) return jobs[j].status;

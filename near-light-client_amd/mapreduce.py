@@ -286,7 +286,7 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer=Non
     # jobs it owns in ONE SHA-256 STARK before the tree (one 2^16-block proof on one GPU, 2^13 blocks per GPU on eight):
     # a proof per job would leave the chip mostly idle (2^11 blocks is 2^14 LDE rows; measured 18.6 ms per job against 142 ms
     # for all 32 together), and the binding fingerprint covers every block either way.  Blocks: synthetic 64-byte Merkle nodes.
-    stark_ms = 0.0
+    stark_ms, last_stark_ms, owned = 0.0, 0.0, 0
     sha = None
     if getattr(args, "map_starks", False):
         sa = nlx.sha256_air
@@ -317,7 +317,8 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer=Non
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if sha is not None:
-            stark_ms += map_starks()
+            last_stark_ms = map_starks()
+            stark_ms += last_stark_ms
         root, stats = run_tree(plan, prover, rank, world, dist, device, request)
     sync()
     dt = time.perf_counter() - t0
@@ -352,7 +353,9 @@ def bench_verify128(args, nlx, torch, rank, world, local, dist, verify_outer=Non
                                ("; plus, per rank, one SHA-256 STARK of the 2^11 blocks of every map job it owns" if sha is not None else ""),
                    "map_starks_ms_per_step_rank0": round(stark_ms / args.steps, 2) if sha is not None else None,
                    "jobs": plan.n_jobs, "proofs_in_flight_per_gpu": args.inflight,
-                   "level_ms_last_step": [[k, n, round(ms, 3)] for k, n, ms in stats["level_ms"]], "request": "fixtures/verify_proof.json: 128 real ids under header 0x%s" % request[0].hex() if reference_request() else "synthetic ids",
+                   "map_starks": sha is not None,
+                   "level_ms_last_step": ([["map_starks_sha256 (rank 0's %d jobs, 2^%d blocks, one STARK)" % (owned, int(sha.log_blocks)), owned, round(last_stark_ms, 3)]] if sha is not None else []) +
+                                         [[k, n, round(ms, 3)] for k, n, ms in stats["level_ms"]], "request": "fixtures/verify_proof.json: 128 real ids under header 0x%s" % request[0].hex() if reference_request() else "synthetic ids",
                    "root_digest": [int(x) for x in root], "bytes_gathered_last_step": stats["bytes_gathered"],
                    "output_bytes": len(stats["output"]), "output_lists_every_id_as_verified": output_ok,
                    "oracle_verifier_accepts_outer_proof": outer_ok, "parallelism": "mapreduce x%d" % world},

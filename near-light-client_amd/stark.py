@@ -43,13 +43,21 @@ class StarkDesc(ctypes.Structure):
                        ("round_values", ctypes.c_uint32 * 3), ("openings_group", ctypes.c_uint32)]
 
 
-# grouped leaves are switched on up to this many LDE rows (2^k): at 2^16 rows one leaf per lane is one wave per SIMD, which
-# hashes at 1.6 G permutations/s where two or more waves reach 2.0 (profiles/r03_poseidon_occupancy_v2.txt)
+# the opt-in "grouped-leaves" variant (StarkConfig.grouped()) switches grouped leaves on up to this many LDE rows (2^k): at 2^16
+# rows one leaf per lane is one wave per SIMD, which hashes at 1.6 G permutations/s where two or more waves reach 2.0
+# (profiles/r03_poseidon_occupancy_v2.txt)
 LEAF_GROUP_MAX_LOG_ROWS = 16
+AUTO = "auto"
 
 
 class StarkConfig:
-    """starky::config::StarkConfig::standard_fast_config()."""
+    """starky::config::StarkConfig::standard_fast_config().
+
+    The DEFAULT is the reference's protocol: a Merkle leaf is hash_or_noop(row) over the whole row (leaf_group_cols = 0,
+    SURVEY 8a row a6) and the challenger observes every opened value (openings_group = 0, starky's observe_openings) - what
+    plonky2x's in-circuit STARK verifier re-hashes (/root/reference/nearx/src/builder.rs:152,220,316).  Round 3's protocol
+    variant (grouped leaves + an openings digest on wide, short traces) is opt-in: StarkConfig.grouped(), or explicit values;
+    bench.py reports it as "stark_variant": "grouped-leaves" and never as the headline."""
 
     def __init__(self, **kw):
         self.num_challenges = 2
@@ -59,25 +67,40 @@ class StarkConfig:
         self.fri_num_queries = 84
         self.fri_arity_bits = 4
         self.fri_final_poly_bits = 5
-        # Merkle leaves over runs of this many columns (nlx_stark_desc.leaf_group_cols); None = by shape, see leaf_group_for
-        self.leaf_group_cols = None
+        # Merkle leaves over runs of this many columns (nlx_stark_desc.leaf_group_cols); 0 = whole-row leaves (starky);
+        # AUTO = by shape, see leaf_group_for
+        self.leaf_group_cols = 0
         # the transcript observes a digest of the openings (runs of this many values) instead of every value
-        # (nlx_stark_desc.openings_group); None = 64 when the trace has more than 256 columns, else 0 (starky's transcript)
-        self.openings_group = None
+        # (nlx_stark_desc.openings_group); 0 = starky's transcript; AUTO = 64 when the trace has more than 256 columns, else 0
+        self.openings_group = 0
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown config field %s" % k)
             setattr(self, k, v)
 
+    @classmethod
+    def grouped(cls, **kw):
+        """round 3's variant: leaf_group_cols and openings_group chosen by the trace's shape"""
+        return cls(leaf_group_cols=AUTO, openings_group=AUTO, **kw)
+
+    @property
+    def variant(self):
+        return "starky" if self.leaf_group_cols == 0 and self.openings_group == 0 else "grouped-leaves"
+
     def leaf_group_for(self, degree_bits, widest_commitment):
-        """The statement's leaf_group_cols.  Whole-row leaves (0, starky's tree) unless the trace is WIDE AND SHORT: a
+        """The statement's leaf_group_cols.  AUTO: whole-row leaves (0, starky's tree) unless the trace is WIDE AND SHORT: a
         commitment of more than 256 columns on at most 2^16 LDE rows has no more leaves than the GPU has lanes and hundreds of
         sequential permutations per leaf (the Sync step's SHA-512 trace: 4 745 columns x 2^10 rows = 594 permutations on each
-        of 1 024 lanes); runs of 128 columns turn that into 16 permutations on each of 38 x 1 024 lanes.  The rule is part of
+        of 1 024 lanes); runs of 128 columns turn that into 16 permutations on each of 38 x 1 024 lanes.  The value is part of
         the statement (the verifier reads leaf_group_cols from the descriptor, and it is in the AIR digest)."""
-        if self.leaf_group_cols is not None:
+        if self.leaf_group_cols != AUTO:
             return int(self.leaf_group_cols)
         return 128 if widest_commitment > 256 and degree_bits + self.rate_bits <= LEAF_GROUP_MAX_LOG_ROWS else 0
+
+    def openings_group_for(self, n_cols):
+        if self.openings_group != AUTO:
+            return int(self.openings_group)
+        return 64 if n_cols > 256 else 0
 
 
 def _pow2_factor(e):
@@ -568,7 +591,7 @@ class Stark:
                               air.num_public_inputs, len(self.program), self.program.ctypes.data_as(u64p),
                               len(air._periodic), air.period_bits, self.periodic.ctypes.data_as(u64p))
         self.desc.leaf_group_cols = cfg.leaf_group_for(degree_bits, max(c for c, _ in air.rounds) if air.rounds is not None else air.n_cols)
-        self.desc.openings_group = int(cfg.openings_group) if cfg.openings_group is not None else (64 if air.n_cols > 256 else 0)
+        self.desc.openings_group = cfg.openings_group_for(air.n_cols)
         if air.rounds is not None:
             self.desc.n_rounds = len(air.rounds)
             for r, (c, k) in enumerate(air.rounds):

@@ -2,7 +2,13 @@
 not pin parity with the reference (nothing can); they pin this round's definition of the
 transcript / wire format so that a later change to oracle AND product together cannot drift unnoticed.
 Regenerate deliberately (python tests/golden/gen_oracle_proofs.py) when the workload generator or the proof format
-is changed on purpose, and say so in the commit."""
+is changed on purpose, and say so in the commit.
+
+FROZEN since round 4 for the reference's STARK protocol (StarkConfig's default: whole-row hash_or_noop leaves, every
+opening observed).  The two SHA entries moved twice in round 3 (commits d6dff16, 3d6f765) because the DEFAULT protocol was
+changed under them (grouped leaves, openings digest); with the default back on starky's protocol they are again, byte for
+byte, the values of commit 547a944 - the last state before that change.  New workloads get NEW keys; existing keys do not
+move again (protocol variants are opt-in configurations and have keys of their own)."""
 import hashlib
 import json
 import os

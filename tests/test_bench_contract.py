@@ -26,6 +26,26 @@ def test_bench_parses_its_flags():
     assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
 
 
+def test_gpus_flag_disagreeing_with_world_size_is_an_error():
+    """--gpus 4 under WORLD_SIZE=2 must not measure something else and call it a 4-GPU run: exit code 2, before any GPU call"""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and r.stdout.strip() == ""
+
+
+def test_gpus_flag_without_launcher_starts_the_ranks_itself():
+    """--gpus 2 with WORLD_SIZE unset: bench.py starts python -m torch.distributed.run ... itself (as a child, before any GPU
+    call).  On a box without two GPUs the ranks fail, and so does the parent - it never falls back to one GPU."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["NLX_BENCH_REHEARSAL"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--log-n", "10",
+                        "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert "without a launcher, starting -m torch.distributed.run --nnodes=1 --nproc-per-node 2" in r.stderr
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
 @pytest.mark.gpu
 def test_default_workload_line():
     """the default job = one full Sync proof (three STARKs of the mainnet step + the outer plonky2 proof, here at 2^12 rows)"""
@@ -49,6 +69,8 @@ def test_default_workload_line():
     assert pc["all_bytes_equal"] is True and pc["outer"]["bytes_equal"] and pc["sha256"]["bytes_equal"] and pc["sha512"]["bytes_equal"]
     assert pc["ed25519"]["bytes_equal"] and pc["outer"]["oracle_verifier_accepts"]
     assert d["config"]["outer_rows_floor_from_stark_verification"]["total"] > 1 << 16
+    # the headline runs the reference's STARK protocol: whole-row hash_or_noop leaves, every opening observed
+    assert d["config"]["stark_variant"] == "starky" and d["config"]["leaf_group_cols"] == 0 and d["config"]["openings_group"] == 0
 
 
 @pytest.mark.gpu
@@ -140,7 +162,9 @@ def test_default_line_carries_the_verify_record_on_two_ranks():
     v = d["verify128"]
     assert "error" not in v, v
     assert v["n_gpus"] == 2 and v["scaling"] == "strong" and v["output_ok"] is True and v["proofs_per_s"] > 0
-    assert len(v["level_ms"]) == 7 and v["roofline"]["launches"] > 0
+    # the recorded job includes the map jobs' SHA-256 STARKs (one per rank over the jobs it owns), first entry of level_ms
+    assert v["map_starks"] is True and v["map_starks_ms_per_job"] > 0 and v["level_ms"][0][0].startswith("map_starks_sha256")
+    assert len(v["level_ms"]) == 8 and v["roofline"]["launches"] > 0
     one = run_bench("--workload", "verify128", "--map-log-n", "11", "--reduce-log-n", "10", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
                     timeout=600)
     assert one["config"]["root_digest"] == v["root_digest"]

@@ -31,6 +31,9 @@ def test_headline_step_four_proofs_bytes_equal_oracle(nlx, orc):
     tag = st["step_tag"]
     try:
         assert st["n_validators"] == 100 and st["n_sigs"] == 72 and st["log_slots"] == 7 and st["lb256"] == 8 and st["lb512"] == 7
+        # the reference's STARK protocol (whole-row hash_or_noop leaves, every opening observed): the bench's default and the headline's
+        for k in ("p256", "p512", "ped"):
+            assert st[k].stark.desc.leaf_group_cols == 0 and st[k].stark.desc.openings_group == 0
         # ---- the three STARKs on the GPU (traces generated on the device), then the oracle on the reference traces ----
         got256 = st["p256"].prove(st["sha_msgs"])
         got512 = st["p512"].prove(st["sig_msgs"])

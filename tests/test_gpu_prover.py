@@ -253,6 +253,36 @@ def test_batch_prove_concurrent_workers(nlx, orc):
     assert len(set(proofs)) == 7
     with pytest.raises(nlx.NlxError):
         nlx.batch_prove([workers[0], workers[0]], jobs[:1])  # same context twice
+    # starting a worker thread fails (fault injected: nlx_abi_selftest 3 = the second worker, 4 = the first): the call still
+    # returns a code, the workers that did start are joined (a joinable std::thread destroyed during unwinding would be
+    # std::terminate) and every job is proved
+    try:
+        for kind in (3, 4):
+            assert nlx.lib.dll.nlx_abi_selftest(kind) == 0
+            assert nlx.batch_prove(workers, jobs) == expect
+    finally:
+        assert nlx.lib.dll.nlx_abi_selftest(5) == 0
+    assert nlx.batch_prove(workers, jobs) == expect
     ref.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_batch_prove_two_devices(nlx, orc):
+    """nlx_batch_prove with one worker per DEVICE (the in-process form of SURVEY 8e's partitioning): proofs equal the
+    single-context ones whatever device proved them.  Needs two GPUs (the driver's multi-GPU node; skipped on a one-GPU box)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ctxs = [nlx.Context(0), nlx.Context(1)]
+    syn = nlx.SyntheticCircuit(10, seed=33, num_public_inputs=8)
+    workers = [nlx.CircuitData.from_synthetic(c, syn) for c in ctxs]
+    jobs, expect = [], []
+    for j in range(6):
+        s = nlx.SyntheticCircuit(10, seed=33, num_public_inputs=8)
+        s.set_public_inputs(np.arange(8, dtype=np.uint64) + np.uint64(7 * j))
+        jobs.append((s.wires, s.public_inputs))
+        expect.append(workers[j % 2].prove(s.wires, s.public_inputs))
+    assert nlx.batch_prove(workers, jobs) == expect
     for c in ctxs:
         c.close()

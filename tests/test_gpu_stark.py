@@ -30,13 +30,13 @@ CASES = [
     ("wide64", 10, dict(leaf_group_cols=24)),         # runs 24 + 24 + 16: a short last run
     ("wide16", 8, dict(leaf_group_cols=12)),          # runs 12 + 4: the last run no longer than a digest is still hashed
     ("wide64", 11, dict(leaf_group_cols=64)),         # the row fits one run: whole-row leaves, but the digest names G
-    ("wide320", 7, {}),                               # the host rule: > 256 columns on <= 2^14 LDE rows -> runs of 128
-    ("wide320", 9, dict(leaf_group_cols=0)),          # ... switched off
+    ("wide320", 7, dict(leaf_group_cols="auto", openings_group="auto")),   # the opt-in variant's shape rule: > 256 columns on <= 2^16 LDE rows -> runs of 128, openings digest
+    ("wide320", 9, {}),                               # the default on the same wide trace: whole-row leaves, starky's transcript
     # openings digest (nlx_stark_desc.openings_group): the transcript observes the hash of the openings' run digests
     ("wide64", 9, dict(openings_group=8)),            # 2 (2 x 64 + 2) = 260 values: 32 full runs and a run of 4, zero-padded
     ("wide16", 8, dict(openings_group=24, leaf_group_cols=12)),
     ("fib", 8, dict(openings_group=4096)),            # everything in one padded run
-    ("wide320", 8, dict(openings_group=0)),           # the rule's default (64 above 256 columns) switched off: starky's transcript
+    ("wide320", 8, dict(leaf_group_cols="auto")),     # grouped leaves under starky's transcript (every opening observed)
 ]
 
 

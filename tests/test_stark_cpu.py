@@ -497,7 +497,11 @@ def test_grouped_leaves_are_what_the_header_says(nlx, orc):
     assert orc.stark_verify(st.desc, proof) == 1
     assert orc.stark_verify(plain.desc, proof) != 1 and proof != orc.stark_prove(plain.desc, t, pis)
     assert len(proof) == len(orc.stark_prove(plain.desc, t, pis))       # same layout: opened rows and sibling paths
+    # the DEFAULT is starky's tree whatever the shape; the shape rule is the opt-in variant's
     cfg = S.StarkConfig()
+    assert cfg.variant == "starky" and cfg.leaf_group_for(9, 4745) == 0 and cfg.openings_group_for(4745) == 0
+    cfg = S.StarkConfig.grouped()
+    assert cfg.variant == "grouped-leaves"
     assert cfg.leaf_group_for(9, 4745) == 128 and cfg.leaf_group_for(15, 1488) == 128 and cfg.leaf_group_for(16, 1488) == 0 and cfg.leaf_group_for(9, 200) == 0
 
 
@@ -516,4 +520,6 @@ def test_openings_digest_is_what_the_header_says(nlx, orc):
     assert len(proof) == len(base) and proof != base
     assert not np.array_equal(orc.stark_air_digest(plain.desc), orc.stark_air_digest(dig.desc))
     wide = S.Stark(S.wide_air(320, seed=3), 5)
+    assert wide.desc.openings_group == 0 and wide.desc.leaf_group_cols == 0        # the reference's protocol by default
+    wide = S.Stark(S.wide_air(320, seed=3), 5, S.StarkConfig.grouped())
     assert wide.desc.openings_group == 64 and wide.desc.leaf_group_cols == 128

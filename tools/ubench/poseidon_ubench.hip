@@ -55,6 +55,34 @@ __global__ void k_rate(uint32_t* out, uint32_t a, uint32_t b, int iters) {
             asm volatile("v_mul_hi_u32_u24 %0, %0, %8\n v_mul_hi_u32_u24 %1, %1, %8\n v_mul_hi_u32_u24 %2, %2, %8\n v_mul_hi_u32_u24 %3, %3, %8\n"
                          "v_mul_hi_u32_u24 %4, %4, %8\n v_mul_hi_u32_u24 %5, %5, %8\n v_mul_hi_u32_u24 %6, %6, %8\n v_mul_hi_u32_u24 %7, %7, %8\n"
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+        } else if (OP >= 20 && OP <= 39) {  // round 4: the glue instructions of the matrix-core linear layer
+#define NLX_R8(INS) asm volatile(INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) \
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc")
+#define I20(k) "v_xor_b32 %" #k ", 0x80808080, %" #k "\n"
+#define I21(k) "v_perm_b32 %" #k ", %" #k ", %8, %9\n"
+#define I22(k) "v_lshl_add_u32 %" #k ", %" #k ", 8, %8\n"
+#define I23(k) "v_lshlrev_b32 %" #k ", 16, %" #k "\n"
+#define I24(k) "v_cndmask_b32_e64 %" #k ", 0, -1, vcc\n"
+#define I25(k) "v_mov_b32 %" #k ", %8\n"
+#define I26(k) "v_add3_u32 %" #k ", %" #k ", %8, %9\n"
+#define I27(k) "v_and_or_b32 %" #k ", %" #k ", %8, %9\n"
+#define I28(k) "v_xor_b32 %" #k ", %8, %" #k "\n"
+#define I29(k) "v_bfe_u32 %" #k ", %" #k ", 3, 20\n"
+#define I30(k) "v_cndmask_b32_e32 %" #k ", 0, %8, vcc\n"
+#define I31(k) "v_add_co_u32 %" #k ", vcc, %" #k ", %8\n"
+#define I32(k) "v_and_b32 %" #k ", %8, %" #k "\n"
+#define I33(k) "v_sub_u32 %" #k ", %" #k ", %8\n"
+#define I34(k) "v_alignbit_b32 %" #k ", %" #k ", %8, 8\n"
+#define I35(k) "v_bitop3_b32 %" #k ", %" #k ", %8, %9 bitop3:0x96\n"
+#define I36(k) "v_mov_b32_dpp %" #k ", %" #k " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define I37(k) "v_add_u32_sdwa %" #k ", %" #k ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+#define I38(k) "v_lshlrev_b32_sdwa %" #k ", %9, %" #k " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n"
+#define I39(k) "v_or_b32_sdwa %" #k ", %" #k ", %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n"
+            if (OP == 20) NLX_R8(I20); else if (OP == 21) NLX_R8(I21); else if (OP == 22) NLX_R8(I22); else if (OP == 23) NLX_R8(I23);
+            else if (OP == 24) NLX_R8(I24); else if (OP == 25) NLX_R8(I25); else if (OP == 26) NLX_R8(I26); else if (OP == 27) NLX_R8(I27);
+            else if (OP == 28) NLX_R8(I28); else if (OP == 29) NLX_R8(I29); else if (OP == 30) NLX_R8(I30); else if (OP == 31) NLX_R8(I31);
+            else if (OP == 32) NLX_R8(I32); else if (OP == 33) NLX_R8(I33); else if (OP == 34) NLX_R8(I34); else if (OP == 35) NLX_R8(I35);
+            else if (OP == 36) NLX_R8(I36); else if (OP == 37) NLX_R8(I37); else if (OP == 38) NLX_R8(I38); else NLX_R8(I39);
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7 ^ (uint32_t)(y0 ^ y1 ^ y2 ^ y3 ^ y4 ^ y5 ^ y6 ^ y7);
@@ -432,6 +460,26 @@ int main() {
     rate<3>("v_mad_u64_u32", d_out);
     rate<5>("v_lshl_add_u64", d_out);
     rate<6>("v_fma_f64", d_out);
+    rate<20>("v_xor_b32 literal", d_out);
+    rate<28>("v_xor_b32 vgpr", d_out);
+    rate<21>("v_perm_b32", d_out);
+    rate<22>("v_lshl_add_u32", d_out);
+    rate<23>("v_lshlrev_b32", d_out);
+    rate<24>("v_cndmask_b32_e64", d_out);
+    rate<25>("v_mov_b32", d_out);
+    rate<26>("v_add3_u32", d_out);
+    rate<27>("v_and_or_b32", d_out);
+    rate<29>("v_bfe_u32", d_out);
+    rate<30>("v_cndmask_b32_e32", d_out);
+    rate<31>("v_add_co_u32 alone", d_out);
+    rate<32>("v_and_b32", d_out);
+    rate<33>("v_sub_u32", d_out);
+    rate<34>("v_alignbit_b32", d_out);
+    rate<35>("v_bitop3_b32", d_out);
+    rate<36>("v_mov_b32_dpp quad", d_out);
+    rate<37>("v_add_u32_sdwa", d_out);
+    rate<38>("v_lshlrev_b32_sdwa", d_out);
+    rate<39>("v_or_b32_sdwa preserve", d_out);
     unsigned long long* d_cyc;
     CK(hipMalloc(&d_cyc, 256 * 8 * 4 * 8));
     cycles<4>("v_add_u32", d_out, d_cyc);
