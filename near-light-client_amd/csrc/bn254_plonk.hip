@@ -119,7 +119,9 @@ struct QuotientParams {
     uint32_t log_n, has_pi;
 };
 
-__global__ void k_plonk_consts(Consts* out, uint32_t log_n, const uint64_t* in /* shift k1 k2 alpha beta gamma, D-form words */) {
+// bad: set to 1 when Z_H vanishes on the coset (the shift lies in the size-4n subgroup): inv_i(0) = 0 would otherwise give a
+// silently wrong quotient
+__global__ void k_plonk_consts(Consts* out, uint32_t log_n, const uint64_t* in /* shift k1 k2 alpha beta gamma, D-form words */, uint32_t* bad) {
     if (threadIdx.x || blockIdx.x) return;
     Consts k;
     Fe w = root28_i();
@@ -139,7 +141,9 @@ __global__ void k_plonk_consts(Consts* out, uint32_t log_n, const uint64_t* in /
     const Fe sn = pow_i(k.shift, (uint64_t)1 << log_n), j = pow_i(w, (uint64_t)1 << log_n);   // j: a primitive 4th root of unity
     Fe jk = one_i();
     for (int q = 0; q < 4; q++) {
-        k.zh_inv[q] = inv_i(sub(mul(sn, jk), one_i()));
+        const Fe den = sub(mul(sn, jk), one_i());
+        if (f29::is_zero_mod<RM>(den)) *bad = 1;
+        k.zh_inv[q] = inv_i(den);
         jk = mul(jk, j);
     }
     *out = k;
@@ -339,9 +343,11 @@ __global__ __launch_bounds__(256) void k_g16_pointwise(const uint64_t* __restric
     if (i >= n) return;
     st(out, i, mul(sub(mul_dd(ld(a, i), ld(b, i)), ld(c, i)), ld(zhinv_i, 0)));
 }
-__global__ void k_g16_const(const uint64_t* __restrict__ shift_d, uint32_t log_n, uint64_t* __restrict__ zhinv_i) {
+__global__ void k_g16_const(const uint64_t* __restrict__ shift_d, uint32_t log_n, uint64_t* __restrict__ zhinv_i, uint32_t* bad) {
     if (threadIdx.x || blockIdx.x) return;
-    st(zhinv_i, 0, inv_i(sub(pow_i(x32(ld(shift_d, 0)), (uint64_t)1 << log_n), one_i())));
+    const Fe den = sub(pow_i(x32(ld(shift_d, 0)), (uint64_t)1 << log_n), one_i());
+    *bad = f29::is_zero_mod<RM>(den) ? 1u : 0u;   // the shift lies in H: x^n - 1 vanishes on the whole coset
+    st(zhinv_i, 0, inv_i(den));
 }
 
 // out[i] = sum_t scalars[t] polys[t][i]: linearisation and batching polynomials of the last round
@@ -467,12 +473,24 @@ int32_t nlx_bn254_plonk_grand_product(nlx_ctx* ctx, uint32_t log_n, const uint64
     return done(NLX_OK);
 } NLX_CATCH(ctx)
 
+// a host scalar handed over as fr.Element words (Montgomery residue): any value below r is a residue, anything else is not an
+// fr.Element and the 29-bit-limb arithmetic's bounds would not hold for it
+static bool fr_words_below_r(const uint64_t* w) {
+    static const uint64_t R[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+    for (int i = 3; i >= 0; i--) {
+        if (w[i] < R[i]) return true;
+        if (w[i] > R[i]) return false;
+    }
+    return false;
+}
+
 int32_t nlx_bn254_groth16_quotient(nlx_ctx* ctx, uint32_t log_n, const uint64_t* a, const uint64_t* b, const uint64_t* c,
                                    const uint64_t coset_shift[4], uint64_t* h_out) NLX_TRY {
     if (!ctx) return NLX_E_INVAL;
     if (!a || !b || !c || !coset_shift || !h_out) return ctx->fail(NLX_E_INVAL, "NULL argument");
     if (log_n < 1 || log_n > 28) return ctx->fail(NLX_E_RANGE, "log_n must be in [1, 28]");
     if (is_device_ptr(coset_shift)) return ctx->fail(NLX_E_INVAL, "the coset shift is a host value");
+    if (!fr_words_below_r(coset_shift)) return ctx->fail(NLX_E_RANGE, "the coset shift is not below r");
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     const size_t n = (size_t)1 << log_n;
@@ -483,7 +501,7 @@ int32_t nlx_bn254_groth16_quotient(nlx_ctx* ctx, uint32_t log_n, const uint64_t*
         return code;
     };
     uint64_t* d_abc = (uint64_t*)ctx->alloc(3 * n * 32);
-    uint64_t* d_small = (uint64_t*)ctx->alloc(64);
+    uint64_t* d_small = (uint64_t*)ctx->alloc(96);   // shift | 1 / (shift^n - 1) | flag
     if (d_abc) tmp.push_back(d_abc);
     if (d_small) tmp.push_back(d_small);
     if (!d_abc || !d_small) return done(NLX_E_NOMEM);
@@ -494,7 +512,14 @@ int32_t nlx_bn254_groth16_quotient(nlx_ctx* ctx, uint32_t log_n, const uint64_t*
     }
     hipError_t e = hipMemcpy(d_small, coset_shift, 32, hipMemcpyHostToDevice);
     if (e != hipSuccess) return done(ctx->hip_fail(e, "hipMemcpy"));
-    hipLaunchKernelGGL(bnp::k_g16_const, dim3(1), dim3(1), 0, st, d_small, log_n, d_small + 4);
+    hipLaunchKernelGGL(bnp::k_g16_const, dim3(1), dim3(1), 0, st, d_small, log_n, d_small + 4, (uint32_t*)(d_small + 8));
+    {
+        uint32_t bad = 0;
+        e = hipMemcpyAsync(&bad, d_small + 8, 4, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return done(ctx->hip_fail(e, "hipMemcpyAsync"));
+        if (bad) return done(ctx->fail(NLX_E_INVAL, "coset shift lies in the evaluation subgroup (x^n - 1 vanishes on the coset)"));
+    }
     // FFTInverse(DIF) -> FFT(DIT, OnCoset): no reordering pass; then a b - c over the coset's constant x^n - 1
     int32_t rc = nlx_bn254_ntt_batch_coset(ctx, d_abc, 3, log_n, 1, NLX_BN254_MONTGOMERY | NLX_BN254_BITREV_OUT, nullptr);
     if (!rc) rc = nlx_bn254_ntt_batch_coset(ctx, d_abc, 3, log_n, 0, NLX_BN254_MONTGOMERY | NLX_BN254_BITREV_IN, coset_shift);
@@ -566,6 +591,8 @@ int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_ar
         const uint64_t* sc[6] = {a->coset_shift, a->k1, a->k2, a->alpha, a->beta, a->gamma};
         for (const uint64_t* q : sc)
             if (!q || is_device_ptr(q)) return ctx->fail(NLX_E_INVAL, "the challenges and shifts are host values (four words each)");
+        for (const uint64_t* q : sc)
+            if (!fr_words_below_r(q)) return ctx->fail(NLX_E_RANGE, "a challenge or shift is not below r (fr.Element words are residues)");
     }
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
@@ -597,7 +624,7 @@ int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_ar
         const uint64_t* src[6] = {a->coset_shift, a->k1, a->k2, a->alpha, a->beta, a->gamma};
         for (int i = 0; i < 6; i++) memcpy(h + 4 * i, src[i], 32);
         hipError_t e = hipMemcpyAsync(d_small, h, sizeof h, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 4, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 8, st);   // [0] high chunk non-zero, [1] Z_H vanishes on the coset
         if (e == hipSuccess) e = hipStreamSynchronize(st);   // h leaves scope
         if (e != hipSuccess) return done(ctx->hip_fail(e, "hipMemcpyAsync"));
     }
@@ -606,7 +633,7 @@ int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_ar
                                       is_device_ptr(polys[i]) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return done(ctx->hip_fail(e, "hipMemcpyAsync"));
     }
-    hipLaunchKernelGGL(bnp::k_plonk_consts, dim3(1), dim3(1), 0, st, d_k, log_n, d_small);
+    hipLaunchKernelGGL(bnp::k_plonk_consts, dim3(1), dim3(1), 0, st, d_k, log_n, d_small, d_flag + 1);
     hipLaunchKernelGGL(bnp::k_plonk_domain, dim3((unsigned)(((N4 + bnp::DOMAIN_RUN - 1) / bnp::DOMAIN_RUN + 63) / 64)), dim3(64), 0, st, d_k, log_n, d_x, d_linv);
     // 1. FFTInverse(DIF): values on H -> coefficients in bit-reversed order
     rc = nlx_bn254_ntt_batch_coset(ctx, d_in, P, log_n, 1, NLX_BN254_MONTGOMERY | NLX_BN254_BITREV_OUT, nullptr);
@@ -629,13 +656,17 @@ int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_ar
     rc = nlx_bn254_ntt_batch_coset(ctx, d_t, 1, log_n + 2, 1, NLX_BN254_MONTGOMERY, a->coset_shift);
     if (rc) return done(rc);
     hipLaunchKernelGGL(bnp::k_any_nonzero, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, st, d_t + 3 * n * 4, n * 4, d_flag);
-    uint32_t flag = 0;
-    hipError_t e = hipMemcpyAsync(t_out, d_t, 3 * n * 32, is_device_ptr(t_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st);
+    uint32_t flags[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(flags, d_flag, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return done(ctx->hip_fail(e, "copy out"));
+    if (flags[1]) return done(ctx->fail(NLX_E_INVAL, "coset shift lies in the evaluation subgroup (x^n - 1 vanishes on the coset)"));
+    e = hipMemcpyAsync(t_out, d_t, 3 * n * 32, is_device_ptr(t_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return done(ctx->hip_fail(e, "copy out"));
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return done(ctx->hip_fail(le, "kernel launch"));
+    const uint32_t flag = flags[0];
     if (high_chunk_is_zero) *high_chunk_is_zero = flag ? 0 : 1;
     return done(NLX_OK);
 } NLX_CATCH(ctx)

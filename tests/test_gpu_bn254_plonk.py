@@ -174,3 +174,37 @@ def test_groth16_quotient_equals_model(nlx, ctx, bn, log_n):
     zeta = rng.randrange(bn.R)
     A, Bp, C = (bn.eval_poly(bn.ntt(v, inverse=True), zeta) for v in (a, b, c))
     assert (A * Bp - C) % bn.R == bn.eval_poly(got, zeta) * (pow(zeta, n, bn.R) - 1) % bn.R
+
+
+def test_a_coset_shift_inside_the_subgroup_and_scalars_above_r_are_refused(nlx, ctx, bn):
+    """Z_H vanishes on a coset whose shift lies in the evaluation subgroup (size 4n for the PLONK chain, n for Groth16's H):
+    NLX_E_INVAL with a message instead of a quotient built on inv(0) = 0; a host scalar that is not below r is not an
+    fr.Element: NLX_E_RANGE"""
+    log_n = 3
+    rng = random.Random(5)
+    k1, k2 = 5, 25
+    alpha, beta, gamma = (rng.randrange(bn.R) for _ in range(3))
+    p = bn.plonk_witness(log_n, rng, k1, k2, beta, gamma)
+    packed = {k: nlx.bn254_pack([_mont(bn, v)])[0] for k, v in p.items()}
+    good = [bn.to_montgomery(x) for x in (5, k1, k2, alpha, beta, gamma)]
+    assert nlx.bn254_plonk_quotient(ctx, packed, *good)[1]
+    bad_shift = bn.root_of_unity(log_n + 2)                  # an element of the size-4n subgroup
+    with pytest.raises(nlx.NlxError) as ei:
+        nlx.bn254_plonk_quotient(ctx, packed, bn.to_montgomery(bad_shift), *good[1:])
+    assert ei.value.code == -1 and "evaluation subgroup" in str(ei.value)
+    for pos in range(6):
+        sc = list(good)
+        sc[pos] = bn.R + 3                                   # words of a number >= r
+        with pytest.raises(nlx.NlxError) as ei:
+            nlx.bn254_plonk_quotient(ctx, packed, *sc)
+        assert ei.value.code == -4
+    assert nlx.bn254_plonk_quotient(ctx, packed, *good)[1]   # the context still works
+    n = 1 << log_n
+    a = [rng.randrange(bn.R) for _ in range(n)]
+    b = [rng.randrange(bn.R) for _ in range(n)]
+    c = [x * y % bn.R for x, y in zip(a, b)]
+    pack = lambda v: nlx.bn254_pack([_mont(bn, v)])[0]
+    with pytest.raises(nlx.NlxError) as ei:
+        nlx.bn254_plonk.groth16_quotient(ctx, pack(a), pack(b), pack(c), coset_shift=bn.root_of_unity(log_n))
+    assert ei.value.code == -1 and "evaluation subgroup" in str(ei.value)
+    nlx.bn254_plonk.groth16_quotient(ctx, pack(a), pack(b), pack(c))

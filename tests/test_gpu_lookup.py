@@ -15,6 +15,7 @@ SHAPES = [
     (12, 1, 10, 80, dict(pct_extension=20, pct_misc=20, pct_u32=20, pct_poseidon=10, pct_arithmetic=10)),   # all 21 gate kinds
     (13, 1, 16, 5000, {}),                                       # a full 16-bit table: 2 521 table rows, 125 LookupGate rows
     (14, 3, 12, 20000, dict(pct_poseidon=20, pct_arithmetic=20, pct_u32=20)),
+    (16, 1, 16, 60000, {}),                                      # 2^16 rows with a full 2^16-pair table: the largest byte comparison with tables
 ]
 
 

@@ -1,7 +1,7 @@
 """GPU tests of the map-reduce dispatch with the real prover behind it (BASELINE.json configs[2]: the
 single-tx VerifyCircuit shape = one map proof + the outer proof; and the 2x1 / 4x1 shapes): every proof of
-the tree is accepted by the oracle verifier for its circuit, and the root digest does not depend on how many
-proofs are kept in flight."""
+the tree is accepted by the oracle verifier for its circuit AND byte-equal to what the oracle prover emits for the same
+job, and the root digest does not depend on how many proofs are kept in flight."""
 import importlib
 
 import numpy as np
@@ -50,6 +50,23 @@ def test_tree_proofs_verify_and_root_is_stable(nlx, ctx, orc, n_map):
     child = mr.blob_digest(want_out, rec.proofs[-2][2])
     assert np.array_equal(pis[:4], child) and np.array_equal(pis[4:], child)
     assert np.array_equal(root, mr.blob_digest(want_out, outer))
+    # the same tree proved by the ORACLE PROVER job by job (same circuits, same public inputs - a reduce job's inputs are the
+    # digests of its children's blobs, so one differing byte anywhere below would change every proof above it): every one
+    # of the tree's proofs is byte-equal, not only accepted
+    oc = {key: orc.Circuit.from_synthetic(v[0]) for key, v in circs.items()}
+
+    def oracle_prove(kind, level, index, public_inputs):
+        syn = circs[(kind, level if kind == "reduce" else 0)][0]
+        syn.set_public_inputs(public_inputs)
+        return oc[(kind, level if kind == "reduce" else 0)].prove(syn.wires, syn.public_inputs)
+    orec = _Recording(oracle_prove)
+    oroot, ostats = mr.run_tree(plan, orec)
+    assert [(k, l) for k, l, _ in orec.proofs] == [(k, l) for k, l, _ in rec.proofs]
+    for (kind, lvl, want), (_, _, got) in zip(orec.proofs, rec.proofs):
+        assert got == want, "tree proof (%s, level %d): GPU bytes differ from the oracle prover's" % (kind, lvl)
+    assert np.array_equal(oroot, root) and ostats["output"] == want_out
+    for c in oc.values():
+        c.close()
     # same tree with three proofs in flight per level
     prover3 = mr.GpuTreeProver(nlx, ctx, plan, 10, 9, torch=torch, workers=3)
     root3, stats3 = mr.run_tree(plan, prover3)

@@ -4,7 +4,7 @@ must accept them, and at BASELINE size the proof must verify (no full oracle pro
 import numpy as np
 import pytest
 
-from conftest import P
+from conftest import GEN, POW2_GEN, P
 
 pytestmark = pytest.mark.gpu
 
@@ -232,6 +232,42 @@ def test_repeated_proving_is_stable(nlx, orc):
     c.close()          # closes cd and pb first
     assert cd.handle is None and pb.handle is None
     cd.close()         # idempotent
+
+
+def test_2p20_row_proof_sampled_against_the_oracle(nlx, ctx, orc):
+    """2^20 rows (the largest proof the bench times; a full oracle prove would take minutes): the oracle VERIFIER accepts the
+    GPU proof (every constraint at zeta, every FRI query's Merkle paths and folds), the constants / sigmas cap equals the oracle's
+    own commitment, the proof's wires cap is the cap of the stage-level commitment of the same witness, and rows of that
+    commitment opened at sampled LDE positions equal the witness polynomials evaluated there by the oracle's Horner loop (the
+    coefficients checked by an oracle transform of the sampled columns) and verify against the cap."""
+    log_n = 20
+    syn = nlx.SyntheticCircuit(log_n, seed=2020, pct_poseidon=20, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)
+    cd = nlx.CircuitData.from_synthetic(ctx, syn)
+    proof = cd.prove(syn.wires, syn.public_inputs)
+    ref = orc.Circuit.from_synthetic(syn)
+    try:
+        assert np.array_equal(cd.constants_sigmas_cap, ref.constants_sigmas_cap())
+        assert ref.verify(proof) == 1
+    finally:
+        ref.close()
+        cd.close()
+    pb = nlx.PolynomialBatch.from_values(ctx, syn.wires, 3, 4)
+    assert pb.cap.tobytes() == proof[:512], "wires cap of the proof = cap of the stage-level commitment"
+    co = pb.coeffs()
+    cols = (0, 79, 134)
+    for c in cols:
+        assert np.array_equal(orc.fft(co[c]), syn.wires[c])
+    L = 1 << (log_n + 3)
+    idx = np.array([0, L // 2 + 7, L - 1, 1234567], dtype=np.uint64)
+    rows, paths = pb.open_rows(idx)
+    w = pow(POW2_GEN, 1 << (32 - log_n - 3), P)
+    for j, i in enumerate(idx):
+        br = int(format(int(i), "0%db" % (log_n + 3))[::-1], 2)
+        x = GEN * pow(w, br, P) % P
+        for c in cols:
+            assert orc.eval_poly_ext(co[c], (x, 0)) == (int(rows[j][c]), 0)
+        assert orc.merkle_verify(rows[j], int(i), paths[j], pb.cap, 4)
+    pb.close()
 
 
 def test_batch_prove_concurrent_workers(nlx, orc):
