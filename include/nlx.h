@@ -551,6 +551,12 @@ typedef struct nlx_stark nlx_stark;
 int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** out);
 void nlx_stark_destroy(nlx_stark* s);
 size_t nlx_stark_proof_max_bytes(const nlx_stark* s);
+/* Which kernel evaluates this STARK's constraints on the quotient coset (starky::prover::compute_quotient_polys ->
+ * Stark::eval_packed_generic; for the reference's circuits the curta AIRs behind /root/reference/nearx/src/builder.rs:152,220,316):
+ * 1 = a straight-line kernel generated at library build time from exactly this program (near-light-client_amd/airgen.py: the
+ * fixed AIRs of a Sync step and of the Verify job's map STARKs), 0 = the register-program interpreter (any program).  Same
+ * results either way; the environment variable NLX_AIR_VM=1, read when the STARK is built, keeps the interpreter. */
+int32_t nlx_stark_quotient_kernel(const nlx_stark* s);
 /* starky::prover::prove + StarkProofWithPublicInputs serialisation (wire format in DESIGN.md):
  * trace: n_cols x n column-major (host or device), every value canonical. */
 int32_t nlx_stark_prove(nlx_stark* s, const uint64_t* trace, const uint64_t* public_inputs, uint8_t* proof_out,

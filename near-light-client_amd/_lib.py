@@ -127,6 +127,7 @@ SIGNATURES = {
     "nlx_stark_build": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, c_void_pp]),
     "nlx_stark_destroy": (None, [ctypes.c_void_p]),
     "nlx_stark_proof_max_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "nlx_stark_quotient_kernel": (ctypes.c_int32, [ctypes.c_void_p]),
     "nlx_stark_prove": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                          ctypes.POINTER(ctypes.c_size_t)]),
     "nlx_stark_prove_rounds": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

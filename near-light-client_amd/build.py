@@ -38,8 +38,22 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Xarch_host", 
          "-I", os.path.join(HERE, "..", "include"), "-DNLX_GL_GENERATOR_SET=" + GEN_SET] + os.environ.get("NLX_EXTRA_FLAGS", "").split()
 
 
+AIRGEN = os.path.join(CSRC, "airgen")
+
+
+def _generate_air_kernels():
+    """csrc/airgen/*.hip: straight-line kernels for the fixed AIR programs (airgen.py), written by a child interpreter (the
+    generator stubs the package's ctypes layer - this must not leak into a process that goes on to load the library).  Files are
+    rewritten only when their text changes, so an unchanged AIR costs no recompilation."""
+    r = subprocess.run([sys.executable, os.path.join(HERE, "airgen.py")], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("airgen.py failed:\n%s\n%s" % (r.stdout, r.stderr))
+
+
 def _sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+    top = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+    gen = sorted(os.path.join("airgen", f) for f in os.listdir(AIRGEN) if f.endswith(".hip")) if os.path.isdir(AIRGEN) else []
+    return top + gen
 
 
 def _headers_mtime():
@@ -52,7 +66,7 @@ def _headers_mtime():
 
 
 def _compile(src, verbose):
-    obj = os.path.join(OBJ, src + ".o")
+    obj = os.path.join(OBJ, src.replace(os.sep, "_") + ".o")
     cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -66,16 +80,18 @@ def _compile(src, verbose):
 
 def build_lib(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
+    _generate_air_kernels()
     hm = _headers_mtime()
     todo, objs, synth_objs = [], [], []
     for src in _sources():
-        obj = os.path.join(OBJ, src + ".o")
+        obj = os.path.join(OBJ, src.replace(os.sep, "_") + ".o")
         (synth_objs if src in SYNTH_SOURCES else objs).append(obj)
         sm = max(os.path.getmtime(os.path.join(CSRC, src)), hm)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < sm:
             todo.append(src)
     if todo:
-        with ThreadPoolExecutor(max_workers=min(6, len(todo))) as ex:
+        todo.sort(key=lambda s_: -os.path.getsize(os.path.join(CSRC, s_)))   # the generated AIR kernels take ~a minute each: start them first
+        with ThreadPoolExecutor(max_workers=min(8, len(todo))) as ex:
             list(ex.map(lambda s: _compile(s, verbose), todo))
     for lib, members in ((LIB, objs), (SYNTH_LIB, synth_objs)):
         if todo or not os.path.exists(lib):

@@ -23,39 +23,11 @@
 #include "poly.hpp"
 #include "prover.hpp"
 #include "transcript.hpp"
+#include "air_vm.hpp"
 
 using namespace nlx;
 
 namespace nlx {
-
-struct AirParams {
-    const uint64_t* const* cols; // device: cols[c] = LDE column c ([r][k], L = n << rate_bits) of whichever committed oracle holds it
-    const uint64_t* program;    // device, n_words (constants canonical)
-    const uint64_t* pis;        // device
-    const uint64_t* coset_base; // device: g * w_{n q}^r', r' < q = 2^qdb
-    const uint64_t* zh_inv;     // device: 1 / Z_H on quotient coset r'
-    const uint64_t* l_inv;      // device: 1 / (n (x - 1)) on the quotient cosets, [r'][k]
-    const uint64_t* periodic;   // device: [column][r'][k mod period] = P_a((g w^r')^(n/period) * w_period^k)
-    const uint64_t* w_n_table;
-    uint64_t* out;              // [challenge][r'][k]
-    const uint32_t* seg;        // device: [segment] = {first word, end word} (n_seg > 1)
-    const uint64_t* seg_mul;    // device: [segment][challenge] = alpha^(constraints after the segment)
-    uint64_t* part;             // [segment][challenge][r'][k] partial sums (n_seg > 1)
-    uint32_t n_seg;
-    uint64_t alphas[2];
-    uint64_t g_inv;             // last = g^-1 (g generates the size-n subgroup)
-    uint32_t log_n, rate_bits, qdb, n_words, nc, n_regs, period_bits, n_pis;
-};
-
-// x * 2^sh (sh < 64): a 128-bit shift and one reduction instead of a general multiplication
-static __device__ __forceinline__ uint64_t mul_pow2(uint64_t x, uint32_t sh) {
-    if (sh == 0) return x;
-    return gl::reduce128(x << sh, x >> (64 - sh));
-}
-
-static __device__ __forceinline__ uint64_t root_pow_(const uint64_t* __restrict__ half_table, uint32_t e, uint32_t half) {
-    return e < half ? half_table[e] : gl::P - half_table[e - half];
-}
 
 // One lane per point (r', k) of the quotient domain.  Registers live in LDS as regs[reg * blockDim + lane]:
 // every access of a wave touches 64 consecutive 8-byte words (no bank conflicts); the program counter, the
@@ -269,6 +241,7 @@ struct nlx_stark {
              n_round_challenges = 0;  // n_round_challenges: round values + challenges, i.e. the values array minus public inputs
     uint64_t air_digest[4] = {0, 0, 0, 0};  // the statement digest the transcript opens with (air_digest_host)
     uint64_t* d_program = nullptr;
+    const AirGenEntry* gen = nullptr;   // a straight-line kernel generated from exactly this program (csrc/airgen/), or nullptr: the interpreter
     std::vector<uint32_t> seg;        // {first word, end word} per program segment
     std::vector<uint32_t> seg_after;  // constraints emitted after each segment
     std::vector<uint32_t> seg_regs;   // registers each segment uses (table sorted by this)
@@ -545,6 +518,13 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
         }
     }
     air_digest_host(s->d, s->program, s->periodic, s->air_digest);
+    // a kernel generated from these very words (same hash, same length)?  Two challenges and whole blocks of AIRGEN_BLOCK points
+    // only; NLX_AIR_VM=1 keeps the interpreter (the parity reference of the generated code, tests/test_gpu_airgen.py)
+    {
+        const char* force_vm = getenv("NLX_AIR_VM");
+        if (!(force_vm && force_vm[0] == '1') && s->d.num_challenges == 2 && ((size_t)1 << s->d.degree_bits) >= AIRGEN_BLOCK)
+            s->gen = airgen_find(airgen_program_hash(s->program.data(), s->program.size()), (uint32_t)s->program.size());
+    }
     for (int i = 0; i <= NLX_MAX_STAGES; i++)
         if (hipEventCreate(&s->ev[i]) != hipSuccess) return fail(ctx->fail(NLX_E_HIP, "hipEventCreate failed"));
     {
@@ -569,6 +549,8 @@ void nlx_stark_destroy(nlx_stark* s) NLX_TRY {
         if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
     delete s;
 } NLX_CATCH_VOID(nullptr)
+
+int32_t nlx_stark_quotient_kernel(const nlx_stark* s) NLX_TRY { return s && s->gen ? 1 : 0; } NLX_CATCH(nullptr)
 
 size_t nlx_stark_proof_max_bytes(const nlx_stark* s) NLX_TRY {
     return s ? stark_proof_max_bytes(s->d, s->n_fri_rounds) : 0;
@@ -701,7 +683,8 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
             unsigned bs = 64;
             while (bs > n) bs >>= 1;
             ctx->begin_kernel("air_quotient", 8.0 * Q * (2.0 * ncols + nc));
-            for (size_t gi = 0; gi < s->seg_group.size(); gi++) {
+            if (s->gen) s->gen->launch(st, (unsigned)(Q / AIRGEN_BLOCK), n_seg, ap);   // every segment of every point, straight-line code
+            for (size_t gi = 0; !s->gen && gi < s->seg_group.size(); gi++) {
                 const uint32_t first = s->seg_group[gi], last = gi + 1 < s->seg_group.size() ? s->seg_group[gi + 1] : n_seg;
                 AirParams gp = ap;
                 gp.seg = ap.seg + 2 * first;
