@@ -1088,10 +1088,11 @@ def run_ntt24(args, nlx, torch, rank, world, local, dist):
                        "transform_ms_rank0": kt[1] / kt[0] if kt[0] else None, "reorder_ms_rank0": kr[1] / kr[0] if kr[0] else None,
                        "parallelism": "columns x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_ntt_pass<DIF> x passes (ntt_transform)", "launches": kt[0],
+                         "traffic": None, "kernel": "k_ntt_s<4> x 2 + k_ntt_c8_nat (ntt_transform: natural order in and out, no reordering pass)", "launches": kt[0],
                          "avg_launch_ms": kt[1] / kt[0] if kt[0] else None, "alg_bytes_per_launch": kt[2] / kt[0] if kt[0] else None,
-                         "note": "a 2^24-point transform is three LDS passes (2^8 points per pass per workgroup): actual traffic is 3 x "
-                                 "the algorithmic 16 n bytes per column; the butterflies are integer-VALU work (DESIGN.md §4)"},
+                         "note": "a 2^24-point transform is three passes of eight levels (2^8 points per pass per workgroup), the last one writing "
+                                 "every value at its natural position: actual traffic is 3 x the algorithmic 16 n bytes per column; the "
+                                 "butterflies are integer-VALU work (DESIGN.md §4)"},
             "cpu_baseline": None,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -229,6 +229,27 @@ int32_t nlx_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_
     }
     Staged s(ctx, cols, n_cols * n * 8, true, true);
     if (s.status) return s.status;
+    // 2^18 .. 2^28 points: natural -> natural in three (four) passes, the last one writing every value at its natural position
+    // through a second buffer (launch_ntt_dif_natural, ntt_kernels.hip) - no reordering pass.  NLX_NTT_REORDER=1 keeps round
+    // 3's path (DIF + k_bitrev_tiled) for comparison.
+    hipError_t e = hipSuccess;
+    {
+        const char* keep = getenv("NLX_NTT_REORDER");
+        uint64_t* tmp = (log_n >= 18 && log_n <= 28 && !(keep && keep[0] == '1')) ? (uint64_t*)ctx->alloc(n_cols * n * 8) : nullptr;
+        if (tmp) {
+            ctx->begin_kernel("ntt_transform", 16.0 * n * n_cols);
+            const bool ok = launch_ntt_dif_natural(ctx->stream, ctx->tables, s.as<uint64_t>(), tmp, n, (uint32_t)n_cols, log_n, inverse != 0,
+                                                   inverse ? nullptr : scale, inverse ? scale : nullptr);
+            ctx->end_kernel();
+            ctx->release(tmp);   // stream-ordered: the block is handed out again only to work enqueued after these kernels
+            if (ok) {
+                rc = s.finish();
+                if (rc) return rc;
+                NLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                return NLX_OK;
+            }
+        }
+    }
     // natural -> (DIF) -> bit-reversed -> permute back to natural.  Forward: pre-scale by
     // shift^i; inverse: post-scale by shift^-i (and 1/n inside the transform).
     // algorithmic bytes: 16 n per column for the transform (read + write once); the reordering back to
@@ -238,7 +259,6 @@ int32_t nlx_ntt_batch(nlx_ctx* ctx, uint64_t* cols, size_t n_cols, uint32_t log_
                        inverse ? nullptr : scale);
     ctx->end_kernel();
     ctx->begin_kernel("ntt_reorder", 16.0 * n * n_cols);
-    hipError_t e = hipSuccess;
     if (!launch_bitrev_inplace(ctx->stream, s.as<uint64_t>(), n, (uint32_t)n_cols, log_n, inverse ? scale : nullptr)) {
         uint64_t* tmp = (uint64_t*)ctx->alloc(n_cols * n * 8);   // small transforms: gather into a second buffer, copy back
         if (!tmp) { ctx->end_kernel(); return NLX_E_NOMEM; }

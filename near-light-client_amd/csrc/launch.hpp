@@ -42,6 +42,9 @@ void launch_bitrev_permute(hipStream_t st, const uint64_t* src, uint64_t* dst, s
                            unsigned log_n, const uint64_t* postscale_nat);
 // in place and coalesced (tiles through LDS); false (nothing launched) below 2^12 points: use launch_bitrev_permute
 bool launch_bitrev_inplace(hipStream_t st, uint64_t* data, size_t stride, uint32_t n_cols, unsigned log_n, const uint64_t* postscale_nat);
+// natural -> natural, no reordering pass (2^18 .. 2^28 points; false = size out of range, nothing launched)
+bool launch_ntt_dif_natural(hipStream_t st, const NttTables& tb, uint64_t* data, uint64_t* tmp, size_t stride, uint32_t n_cols,
+                            unsigned log_n, bool inverse, const uint64_t* prescale_nat, const uint64_t* postscale_nat);
 void launch_fill_coset_scale_br(hipStream_t st, uint64_t* d_table, unsigned log_n, unsigned rate_bits,
                                 uint64_t shift, bool inverse);
 void launch_intt_dif_cosets(hipStream_t st, const NttTables& tb, uint64_t* data, uint32_t n_y, unsigned log_n,

@@ -1097,6 +1097,136 @@ bool launch_bitrev_inplace(hipStream_t st, uint64_t* data, size_t stride, uint32
     return true;
 }
 
+// ---- natural order in, natural order out, no reordering pass (round 4; nlx_ntt_batch, BASELINE.json configs[4]) ----------------
+// A decimation in frequency leaves X[k] at position bitrev(k); round 3 ran k_bitrev_tiled afterwards - a quarter of a 16 x 2^24
+// call, there only to un-permute what the last pass had just written.  Here the LAST pass writes every value at its natural
+// position.  That needs the pass's tile to hold runs of consecutive OUTPUT addresses, and an output address's low bits are the
+// reversed HIGH bits of the position: the contiguous pass is cut to 8 levels (rows of 256 elements) and a block takes the
+// sixteen rows whose positions differ in their top four bits - position (u : 4)(h' : log_n - 12)(c : 8) goes to address
+// (rev8 c)(rev h')(rev4 u), so for every c the sixteen u are one 128-byte line.  Reads: sixteen runs of 2 KB; writes: 256
+// lines of 128 bytes per tile; the strided passes above it take 8 levels each instead of 6 (k_ntt_s<4>), the last of them
+// writing into a second buffer so that this pass can scatter back into the caller's (no copy).
+template <bool INV>
+__global__ __launch_bounds__(256, 4) void k_ntt_c8_nat(PassParams p) {
+    constexpr unsigned ROW = 273;                         // 256 + one pad per sixteen + 1: rows start on different banks
+    __shared__ uint64_t lds[16 * ROW];
+    __shared__ uint64_t w2[256];                          // w_256^(lo * brev4(m)) at [lo][m]
+    const uint32_t tid = threadIdx.x;
+    const unsigned hb = p.log_n - 12, top = p.log_n - 8;
+    const uint32_t hp = blockIdx.x, rhp = hb ? gl::bitrev32(hp, hb) : 0;
+    w2[tid] = tw_full(p.tw, (tid >> 4) * brev4(tid & 15), 128);
+    __syncthreads();
+    // round of stride 16: lane (row ua, lo) holds c = 16 m + lo; round of stride 1: lane (chi, u' = rev4 u) holds c = 16 chi + m
+    const uint32_t ua = tid >> 4, lo = tid & 15, chi = tid >> 4, up = tid & 15, u2 = brev4(up);
+    const uint32_t g1 = (((((ua << hb) | hp) << 8) + lo)) * 8;                     // + 128 m bytes
+    const uint32_t g2 = (((brev4(chi) << top) | (rhp << 4) | up)) * 8;              // + (16 brev4(m) << top) * 8 bytes
+    uint64_t* __restrict__ l1 = lds + ua * ROW + lo;                              // + 17 m
+    const uint64_t* __restrict__ l2 = lds + u2 * ROW + 17 * chi;                   // + m
+    const uint64_t* __restrict__ w2l = w2 + lo * 16;
+    const bool has_scale = p.scale != nullptr, has_post = p.post_scale != nullptr;
+    const buf_t scale = make_buf(p.scale), post = make_buf(p.post_scale);
+    const uint32_t col_end = min(p.n_cols, (blockIdx.y + 1) * p.cols_per_block);
+    for (uint32_t col = blockIdx.y * p.cols_per_block; col < col_end; col++) {
+        const buf_t src = make_buf(p.src + (size_t)col * p.src_stride);
+        const buf_t dst = make_buf(p.dst + (size_t)col * p.dst_stride);
+        uint64_t x[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++) x[m] = buf_ld(src, g1, m * 128);
+        if (has_scale) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], buf_ld(scale, g1, m * 128));
+        }
+        dft_dif<4, INV>(x);
+#pragma unroll
+        for (int m = 1; m < 16; m++) x[m] = mul_f(x[m], w2l[m]);
+#pragma unroll
+        for (int m = 0; m < 16; m++) l1[17 * m] = x[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; m++) x[m] = l2[m];
+        dft_dif<4, INV>(x);
+        if (p.final_scale != 1) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) x[m] = mul_f(x[m], p.final_scale);
+        }
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const uint32_t so = ((16u * (__brev((uint32_t)m) >> 28)) << top) * 8;   // wave-uniform: the scalar offset
+            if (has_post) x[m] = mul_f(x[m], buf_ld(post, g2, so));
+            buf_st(dst, g2, so, x[m]);
+        }
+        __syncthreads();
+    }
+}
+
+// Natural -> natural transform of n_cols columns of 2^log_n points (18 <= log_n <= 28) through `tmp` (same shape as data).
+// Returns false when the size is outside that range (the caller then runs the DIF passes and the reordering kernel).
+bool launch_ntt_dif_natural(hipStream_t st, const NttTables& tb, uint64_t* data, uint64_t* tmp, size_t stride, uint32_t n_cols,
+                            unsigned log_n, bool inverse, const uint64_t* prescale_nat, const uint64_t* postscale_nat) {
+    if (log_n < 18 || log_n > 28 || !n_cols) return false;
+    if (!w16_is_the_compiled_power_of_two()) abort();
+    const uint64_t* const* roots = inverse ? tb.inv : tb.fwd;
+    const unsigned rem = log_n - 8, n_strided = (rem + STRIDED_BITS_MAX - 1) / STRIDED_BITS_MAX;
+    unsigned bits[4], logN[4], left = rem, acc = 8;
+    for (unsigned i = 0; i < n_strided; i++) {           // i = 0: the pass next to the contiguous one (smallest sub-problem)
+        bits[i] = (left + (n_strided - i) - 1) / (n_strided - i);
+        left -= bits[i];
+        acc += bits[i];
+        logN[i] = acc;
+    }
+    for (unsigned step = 0; step < n_strided; step++) {  // DIF: the largest sub-problem first
+        const unsigned i = n_strided - 1 - step;
+        const bool first = step == 0, last_strided = step + 1 == n_strided;
+        PassParams p{};
+        p.src = first ? data : data;
+        p.dst = last_strided ? tmp : data;
+        p.src_stride = stride;
+        p.dst_stride = stride;
+        p.log_n = log_n;
+        p.log_N = logN[i];
+        p.log_A = bits[i];
+        p.tw = roots[p.log_N];
+        p.scale = first ? prescale_nat : nullptr;
+        p.final_scale = 1;
+        p.n_cols = n_cols;
+        const unsigned log_M = p.log_N - p.log_A, t = TILE_LOG - p.log_A;
+        p.log_T = t < log_M ? t : log_M;
+        const unsigned tiles = 1u << (log_n - p.log_A - p.log_T);
+        p.cols_per_block = pick_cols_per_block(tiles, n_cols);
+        const dim3 grid(tiles, (n_cols + p.cols_per_block - 1) / p.cols_per_block, 1);
+#define NLX_NAT_S(REM)                                                                                                  \
+    do {                                                                                                                \
+        if (inverse) hipLaunchKernelGGL((k_ntt_s<false, true, REM>), grid, dim3(256), 0, st, p);                        \
+        else hipLaunchKernelGGL((k_ntt_s<false, false, REM>), grid, dim3(256), 0, st, p);                               \
+    } while (0)
+        switch (p.log_A) {
+            case 5: NLX_NAT_S(1); break;
+            case 6: NLX_NAT_S(2); break;
+            case 7: NLX_NAT_S(3); break;
+            default: NLX_NAT_S(4); break;
+        }
+#undef NLX_NAT_S
+    }
+    PassParams p{};
+    p.src = tmp;
+    p.dst = data;
+    p.src_stride = stride;
+    p.dst_stride = stride;
+    p.log_n = log_n;
+    p.log_N = 8;
+    p.log_A = 8;
+    p.tw = roots[8];
+    p.final_scale = inverse ? gl::inv((uint64_t)1 << log_n) : 1;
+    p.post_scale = postscale_nat;
+    p.n_cols = n_cols;
+    const unsigned tiles = 1u << (log_n - 12);
+    p.cols_per_block = pick_cols_per_block(tiles, n_cols);
+    const dim3 grid(tiles, (n_cols + p.cols_per_block - 1) / p.cols_per_block, 1);
+    if (inverse) hipLaunchKernelGGL((k_ntt_c8_nat<true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_ntt_c8_nat<false>), grid, dim3(256), 0, st, p);
+    return true;
+}
+
 // One cross-rank level of a decimation in frequency whose input is split over several GPUs (nlx_ntt_split_level): this
 // rank's slice against its partner's.  Lower partner: a' = a + b (a = mine, b = theirs).  Upper partner: b' = (a - b) w,
 // a = theirs, b = mine, w = w_n^(idx0 + q) 2^level read from the size-n table (idx0 = the slice's offset inside the level's

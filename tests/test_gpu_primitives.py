@@ -62,7 +62,7 @@ def test_merkle_tree(nlx, ctx, orc, golden):
         assert orc.merkle_verify(leaves[idx], idx, t.prove(idx), t.cap, cap_h)
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 3, 8, 12, 13, 14, 16, 17])
+@pytest.mark.parametrize("log_n", [0, 1, 3, 8, 12, 13, 14, 16, 17, 18, 19, 21])   # from 2^18 points: natural order out of the last pass itself (no reordering kernel)
 def test_ntt_vs_oracle(nlx, ctx, orc, log_n):
     rng = np.random.default_rng(100 + log_n)
     n_cols = 3
