@@ -116,6 +116,10 @@ def parse():
                     help="starky (default, the headline): whole-row hash_or_noop Merkle leaves and every opening observed by the "
                          "transcript - the reference's STARK protocol; grouped-leaves: round 3's protocol variant for wide, short traces "
                          "(StarkConfig.grouped()), a labelled extra")
+    ap.add_argument("--stark-batch-cols", type=int, default=512,
+                    help="starky variant: a commitment round of more than this many columns is committed as several PolynomialBatches of "
+                         "at most this many columns (plain plonky2 batches: hash_or_noop leaves over the batch's row, a cap and a FRI oracle "
+                         "each - nlx_stark_desc.batch_cols); 0 = one batch per round")
     ap.add_argument("--no-extra", action="store_true", help="sync workload: skip the plonky2-only 2^16 figures and the verify128 record")
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent proofs in flight per GPU (one context + stream + host thread each); the K "
@@ -660,8 +664,9 @@ def sync_step_setup(args, nlx, torch, rank, local):
     ctxs = [nlx.Context(local) for _ in range(4)]
     st["ctxs"] = ctxs
     variant = getattr(args, "stark_variant", "starky")
-    mk_cfg = nlx.StarkConfig.grouped if variant == "grouped-leaves" else nlx.StarkConfig
-    st["stark_variant"] = variant
+    batch_cols = 0 if variant == "grouped-leaves" else int(getattr(args, "stark_batch_cols", 512))
+    mk_cfg = nlx.StarkConfig.grouped if variant == "grouped-leaves" else (lambda: nlx.StarkConfig(batch_cols=batch_cols))
+    st["stark_variant"], st["stark_batch_cols"] = variant, batch_cols
     st["p256"] = SA.Sha256Prover(ctxs[0], st["lb256"], mk_cfg(), step_tag=st["step_tag"])
     st["p512"] = SB.Sha512Prover(ctxs[1], st["lb512"], mk_cfg(), step_tag=st["step_tag"])
     st["ped"] = E.Ed25519Prover(ctxs[2], st["log_slots"], mk_cfg(), step_tag=st["step_tag"])
@@ -687,6 +692,9 @@ def stark_verifier_rows(st):
         log_l = d.degree_bits + d.rate_bits
         n_rounds = d.n_rounds if d.n_rounds else 1
         oracles = [d.round_cols[r] for r in range(n_rounds)] if d.n_rounds else [d.n_cols]
+        if d.batch_cols:   # a round of more than batch_cols columns is several oracles: a leaf and a Merkle path each
+            B = d.batch_cols
+            oracles = [w for c in oracles for w in ([B] * (c // B) + ([c % B] if c % B else []) if c > B else [c])]
         oracles.append(d.num_challenges * d.quotient_degree_factor)
         G = d.leaf_group_cols
 
@@ -845,6 +853,9 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
                        "stark_variant": st["stark_variant"],
                        "leaf_group_cols": max(int(pr.stark.desc.leaf_group_cols) for pr in (p256, p512, ped)),
                        "openings_group": max(int(pr.stark.desc.openings_group) for pr in (p256, p512, ped)),
+                       # a commitment round of more columns than this is several PolynomialBatches (each with whole-row
+                       # hash_or_noop leaves, its own cap and FRI oracle): plonky2's own batching, more Merkle paths for the verifier
+                       "stark_batch_cols": st["stark_batch_cols"],
                        "outer_rows_floor_from_stark_verification": rows,
                        "public_inputs": "64 bytes of real Sync I/O (fixtures/main_2.json): new head hash 0x%s" % st["sync_out"].hex(),
                        "proof_bytes": {"sha256": len(a[0]), "sha512": len(b[0]), "ed25519": len(c_proof), "outer": outer_len},

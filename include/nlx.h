@@ -544,7 +544,18 @@ typedef struct {
      * small device launch and 150 host permutations.  Part of the statement digest when non-zero.
      * 8 <= G <= 4096; a patch that must stay compatible with an unpatched starky verifier passes 0. */
     uint32_t openings_group;
+    /* Batches.  0 = a round's columns are ONE PolynomialBatch (one Merkle tree, one cap).  B > 0: a round of more than B columns
+     * is committed as ceil(cols / B) PolynomialBatches of B columns (the last one what is left), in column order - each exactly
+     * plonky2's PolynomialBatch::from_values: leaf = hash_or_noop(that batch's row), its own 2^cap_height-entry cap, its own FRI
+     * oracle.  Nothing new for a verifier: the transcript observes the caps in order, the proof carries them in order, every
+     * query opens each batch's row with its own Merkle path, the openings and their order do not change.  Why: a leaf of a
+     * 4 745-column row is 594 permutations in SEQUENCE (a sponge), and a trace of 2^10 LDE rows has 1 024 of them - the GPU
+     * idles while every lane walks its chain; ten batches are ten independent sponges per row.  The cost is on the verifier's
+     * side: ceil(cols / B) - 1 more Merkle paths per query and round.  Part of the statement digest when non-zero.
+     * 8 <= B <= 65535; at most NLX_STARK_MAX_ORACLES batches + 1 (the quotient) in all. */
+    uint32_t batch_cols;
 } nlx_stark_desc;
+#define NLX_STARK_MAX_ORACLES 31
 typedef struct nlx_stark nlx_stark;
 
 /* Validates the program and keeps it and the coset tables resident on the device. */

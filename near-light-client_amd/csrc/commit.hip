@@ -21,8 +21,27 @@ size_t merkle_digest_words(size_t n_leaves, uint32_t cap_height) {
     return w;
 }
 
+nlx_commit commit_view(const nlx_commit* c, uint32_t k) {
+    nlx_commit v = *c;
+    v.owner = false;
+    v.n_trees = 1;
+    v.group_digests = nullptr;
+    if (c->n_trees > 1) {
+        const uint32_t c0 = k * c->batch_cols;
+        v.n_cols = c->n_cols - c0 < c->batch_cols ? c->n_cols - c0 : c->batch_cols;
+        v.coeffs_br = c->coeffs_br + (size_t)c0 * c->n();
+        v.lde = c->lde + (size_t)c0 * c->L();
+        v.digests = c->digests + (size_t)k * c->tree_words;
+        v.cap = c->cap + (size_t)k * c->tree_words;
+        v.batch_cols = 0;
+        v.tree_words = 0;
+    }
+    return v;
+}
+
 int32_t commit_build(nlx_ctx* ctx, const uint64_t* d_in, size_t in_stride, CommitInput kind, uint32_t n_cols,
-                     uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, nlx_commit** out, uint32_t leaf_group) {
+                     uint32_t log_n, uint32_t rate_bits, uint32_t cap_height, nlx_commit** out, uint32_t leaf_group,
+                     uint32_t batch_cols) {
     *out = nullptr;
     if (n_cols == 0 || n_cols > 65535) return ctx->fail(NLX_E_RANGE, "n_cols %u out of range [1, 65535]", n_cols);
     if (log_n + rate_bits > 32) return ctx->fail(NLX_E_RANGE, "log_n + rate_bits > 32");
@@ -43,7 +62,13 @@ int32_t commit_build(nlx_ctx* ctx, const uint64_t* d_in, size_t in_stride, Commi
     const size_t n = c->n(), L = c->L();
     c->coeffs_br = (uint64_t*)ctx->alloc((size_t)n_cols * n * 8);
     c->lde = (uint64_t*)ctx->alloc((size_t)n_cols * L * 8);
-    c->digests = (uint64_t*)ctx->alloc(merkle_digest_words(L, cap_height) * 8);
+    const bool batched = batch_cols && n_cols > batch_cols && !(leaf_group && n_cols > leaf_group);
+    if (batched) {
+        c->n_trees = (n_cols + batch_cols - 1) / batch_cols;
+        c->batch_cols = batch_cols;
+        c->tree_words = merkle_digest_words(L, cap_height);
+    }
+    c->digests = (uint64_t*)ctx->alloc(merkle_digest_words(L, cap_height) * 8 * c->n_trees);
     const bool grouped = leaf_group && n_cols > leaf_group;
     const uint32_t n_groups = grouped ? (n_cols + leaf_group - 1) / leaf_group : 0;
     if (grouped) c->group_digests = (uint64_t*)ctx->alloc((size_t)4 * n_groups * L * 8);
@@ -92,13 +117,19 @@ int32_t commit_build(nlx_ctx* ctx, const uint64_t* d_in, size_t in_stride, Commi
         ctx->begin_kernel("hash_lde_leaves", 8.0 * n_cols * L + 32.0 * L, perms);
         launch_hash_lde_leaves_grouped(st, c->lde, L, n_cols, leaf_group, log_n, rate_bits, c->group_digests, c->digests);
         ctx->end_kernel();
+    } else if (batched) {
+        const uint32_t last = n_cols - (c->n_trees - 1) * batch_cols;
+        const double perms = (double)L * ((double)(c->n_trees - 1) * ((batch_cols + 7) / 8) + (last <= 4 ? 0 : (last + 7) / 8));
+        ctx->begin_kernel("hash_lde_leaves", 8.0 * n_cols * L + 32.0 * L * c->n_trees, perms);
+        launch_hash_lde_leaves(st, c->lde, L, n_cols, log_n, rate_bits, c->digests, batch_cols, c->tree_words);
+        ctx->end_kernel();
     } else {
         ctx->begin_kernel("hash_lde_leaves", 8.0 * n_cols * L + 32.0 * L, n_cols <= 4 ? 0.0 : (double)L * ((n_cols + 7) / 8));
         launch_hash_lde_leaves(st, c->lde, L, n_cols, log_n, rate_bits, c->digests);
         ctx->end_kernel();
     }
-    ctx->begin_kernel("merkle_levels", 64.0 * L, (double)L - (double)((size_t)1 << cap_height));
-    c->cap = launch_merkle_levels(st, c->digests, L, cap_height);
+    ctx->begin_kernel("merkle_levels", 64.0 * L * c->n_trees, ((double)L - (double)((size_t)1 << cap_height)) * c->n_trees);
+    c->cap = launch_merkle_levels(st, c->digests, L, cap_height, c->n_trees, c->tree_words);
     ctx->end_kernel();
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -162,7 +162,7 @@ int32_t fri_prove(nlx_ctx* ctx, const FriProveArgs& a, Challenger& ch, Writer& w
         const unsigned plen0 = log_L - cap_h;
         // device layout of the answers (words)
         size_t off = 0;
-        size_t rows_off[4], paths_off[4];
+        size_t rows_off[FRI_MAX_ORACLES], paths_off[FRI_MAX_ORACLES];
         for (uint32_t o = 0; o < NO; o++) {
             rows_off[o] = off; off += (size_t)NQ * oracles[o]->n_cols;
             paths_off[o] = off; off += (size_t)NQ * plen0 * 4;

@@ -12,10 +12,12 @@
 
 namespace nlx {
 
+constexpr int FRI_MAX_ORACLES = 32;   // plonky2: 4; a STARK whose rounds are committed in batches (nlx_stark_desc.batch_cols): up to 31 + the quotient
+
 struct FriProveArgs {
-    const nlx_commit* oracles[4] = {nullptr, nullptr, nullptr, nullptr};
+    const nlx_commit* oracles[FRI_MAX_ORACLES] = {};
     uint32_t n_oracles = 0;
-    uint32_t nz[4] = {0, 0, 0, 0};  // columns of each oracle that are also opened at g * zeta
+    uint32_t nz[FRI_MAX_ORACLES] = {};  // columns of each oracle that are also opened at g * zeta
     // plonky2 with lookup tables (CommonCircuitData::fri_all_polys / fri_next_batch_polys): the last tail_cols columns of
     // oracle tail_oracle are listed AFTER every oracle in the zeta batch, and after the nz[] columns in the g * zeta batch
     // (all of them are opened at both points).  open0 / open1 are in that order.

@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256, 4) void k_hash_leaves_rowmajor(const uint64_t*
 
 // One interior level: parent[i] = two_to_one(child[2i], child[2i+1]).
 __global__ __launch_bounds__(256, 4) void k_merkle_level(const uint64_t* __restrict__ children,
-                                                      uint64_t* __restrict__ parents, size_t n_parents) {
+                                                      uint64_t* __restrict__ parents, size_t n_parents, size_t tree_words) {
+    children += (size_t)blockIdx.y * tree_words;   // several trees of one commitment (batches of columns), back to back
+    parents += (size_t)blockIdx.y * tree_words;
     const size_t i_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i_raw < n_parents;              // spare lanes redo the last parent (see k_permute_batch) and store nothing
     const size_t i = live ? i_raw : n_parents - 1;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256, 4) void k_merkle_level(const uint64_t* __restr
 
 constexpr size_t MERKLE_WIDE_MAX_PARENTS = (size_t)1 << 14;
 constexpr unsigned MERKLE_FUSED_MAX_LEVELS = 6;  // 2^6 children per block: 32 sixteen-lane groups on the first fused level
-void launch_merkle_fused(hipStream_t st, const uint64_t* children, size_t n_children, unsigned levels);
+void launch_merkle_fused(hipStream_t st, const uint64_t* children, size_t n_children, unsigned levels, uint32_t n_trees, size_t tree_words);
 
 // ---- host launchers (stream-ordered, no synchronisation) ----
 void launch_permute_batch(hipStream_t st, uint64_t* d_states, size_t n) {
@@ -112,7 +114,9 @@ void launch_hash_leaves_rowmajor(hipStream_t st, const uint64_t* d_rows, uint32_
 
 // digests: level-major, level 0 = n_leaves digests; builds levels down to the cap level.
 // Returns a device pointer to the cap level (2^cap_height digests) inside d_digests.
-const uint64_t* launch_merkle_levels(hipStream_t st, uint64_t* d_digests, size_t n_leaves, unsigned cap_height) {
+// n_trees > 1: that many trees of the same shape, `tree_words` words apart (the batches of one commitment round): every launch
+// covers all of them (blockIdx.y = tree), so ten trees cost the latency of one
+const uint64_t* launch_merkle_levels(hipStream_t st, uint64_t* d_digests, size_t n_leaves, unsigned cap_height, uint32_t n_trees, size_t tree_words) {
     size_t cap = (size_t)1 << cap_height;
     uint64_t* cur = d_digests;
     size_t lvl = n_leaves;
@@ -126,14 +130,14 @@ const uint64_t* launch_merkle_levels(hipStream_t st, uint64_t* d_digests, size_t
         if (half <= MERKLE_WIDE_MAX_PARENTS) {
             unsigned K = 0;
             while (K < MERKLE_FUSED_MAX_LEVELS && (lvl >> K) > cap) K++;
-            launch_merkle_fused(st, cur, lvl, K);
+            launch_merkle_fused(st, cur, lvl, K, n_trees, tree_words);
             for (unsigned s = 0; s < K; s++) {
                 cur += lvl * 4;
                 lvl >>= 1;
             }
             continue;
         }
-        hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, cur, nxt, half);
+        hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((half + 255) / 256), n_trees), dim3(256), 0, st, cur, nxt, half, tree_words);
         cur = nxt;
         lvl = half;
     }
@@ -150,9 +154,18 @@ namespace nlx {
 // instead of a transposed copy of the whole table.
 constexpr size_t HASH_LEAVES_WIDE_MAX_ROWS = (size_t)1 << 13;  // measured crossover (4 745 columns): 2^13 rows 16 vs 24 ms, 2^14 rows 31 vs 26 ms
 
+// batch_cols > 0: the table is committed as ceil(n_cols / batch_cols) PolynomialBatches of at most batch_cols columns each
+// (blockIdx.y = batch): a batch's leaf is hash_or_noop of ITS columns of the row, its digests go to tree blockIdx.y
+// (`tree_words` words apart).  batch_cols = 0: one batch, as always.
 __global__ __launch_bounds__(256, 4) void k_hash_lde_leaves(const uint64_t* __restrict__ lde, size_t col_stride,
                                                          uint32_t n_cols, unsigned log_n, unsigned rate_bits,
-                                                         uint64_t* __restrict__ digests) {
+                                                         uint64_t* __restrict__ digests, uint32_t batch_cols, size_t tree_words) {
+    if (batch_cols) {
+        const uint32_t c0 = blockIdx.y * batch_cols;
+        lde += (size_t)c0 * col_stride;
+        n_cols = n_cols - c0 < batch_cols ? n_cols - c0 : batch_cols;
+        digests += (size_t)blockIdx.y * tree_words;
+    }
     const size_t pos_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = (pos_raw >> (log_n + rate_bits)) == 0;   // spare lanes redo the last point (see k_permute_batch), store nothing
     const size_t pos = live ? pos_raw : ((size_t)1 << (log_n + rate_bits)) - 1;
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(256, 4) void k_hash_lde_leaves(const uint64_t* __re
 }
 
 void launch_hash_lde_leaves_wide(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols, unsigned log_n,
-                                 unsigned rate_bits, uint64_t* d_digests);
+                                 unsigned rate_bits, uint64_t* d_digests, uint32_t batch_cols, size_t tree_words);
 
 // Grouped leaves (STARK commitments of wide short traces, include/nlx.h leaf_group_cols): lane (pos, g = blockIdx.y) hashes
 // the run of columns [g group, (g + 1) group) of LDE row pos - hash_no_pad, whatever the run's length - and writes the
@@ -229,20 +242,23 @@ void launch_hash_lde_leaves_grouped(hipStream_t st, const uint64_t* d_lde, size_
     const uint32_t K = (n_cols + group - 1) / group;
     hipLaunchKernelGGL(k_hash_lde_groups, dim3((unsigned)((rows + 255) / 256), K), dim3(256), 0, st, d_lde, col_stride, n_cols, group,
                        log_n + rate_bits, d_group_digests);
-    launch_hash_lde_leaves(st, d_group_digests, rows, 4 * K, log_n, rate_bits, d_digests);
+    launch_hash_lde_leaves(st, d_group_digests, rows, 4 * K, log_n, rate_bits, d_digests, 0, 0);
 }
 
 void launch_hash_lde_leaves(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols,
-                            unsigned log_n, unsigned rate_bits, uint64_t* d_digests) {
+                            unsigned log_n, unsigned rate_bits, uint64_t* d_digests, uint32_t batch_cols, size_t tree_words) {
     size_t rows = (size_t)1 << (log_n + rate_bits);
+    const uint32_t n_batches = batch_cols ? (n_cols + batch_cols - 1) / batch_cols : 1;
+    const uint32_t widest = batch_cols && batch_cols < n_cols ? batch_cols : n_cols;
     // Few rows of many columns (a short wide STARK trace): one lane per leaf leaves most SIMDs idle while every lane
     // walks its ceil(c/8) permutations one after the other; sixteen lanes per leaf cut that chain's latency ~5x.
-    if (rows <= HASH_LEAVES_WIDE_MAX_ROWS && n_cols > 16) {
-        launch_hash_lde_leaves_wide(st, d_lde, col_stride, n_cols, log_n, rate_bits, d_digests);
+    // (leaves in flight = rows x batches: with batches a short trace fills the chip with one lane per leaf much sooner)
+    if (rows * n_batches <= HASH_LEAVES_WIDE_MAX_ROWS && widest > 16) {
+        launch_hash_lde_leaves_wide(st, d_lde, col_stride, n_cols, log_n, rate_bits, d_digests, batch_cols, tree_words);
         return;
     }
-    hipLaunchKernelGGL(k_hash_lde_leaves, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, d_lde, col_stride,
-                       n_cols, log_n, rate_bits, d_digests);
+    hipLaunchKernelGGL(k_hash_lde_leaves, dim3((unsigned)((rows + 255) / 256), n_batches), dim3(256), 0, st, d_lde, col_stride,
+                       n_cols, log_n, rate_bits, d_digests, batch_cols, tree_words);
 }
 
 }  // namespace nlx
@@ -304,7 +320,9 @@ __device__ __forceinline__ gl32::F permute_wide(gl32::F x, uint32_t j, volatile 
 constexpr unsigned FUSED_GROUPS = 32;  // 512 threads: two waves per SIMD on the first level, one from the second on
 
 __global__ __launch_bounds__(FUSED_GROUPS * 16) void k_merkle_fused(const uint64_t* __restrict__ children, uint64_t* __restrict__ parents0,
-                                                                   size_t n_children, unsigned K) {
+                                                                   size_t n_children, unsigned K, size_t tree_words) {
+    children += (size_t)blockIdx.y * tree_words;
+    parents0 += (size_t)blockIdx.y * tree_words;
     __shared__ uint64_t slots[FUSED_GROUPS * 24];
     __shared__ uint64_t lv[2][FUSED_GROUPS * 2 * 4];
     const uint32_t j = threadIdx.x & 15, g = threadIdx.x >> 4;
@@ -366,17 +384,28 @@ __global__ __launch_bounds__(256) void k_fri_leaves_wide(const uint64_t* __restr
 // LDE leaf digests, one leaf per 16 lanes (index maps as in k_hash_lde_leaves): lane j < 8 of a group owns the j-th
 // word of each 8-column chunk.
 __global__ __launch_bounds__(256) void k_hash_lde_leaves_wide(const uint64_t* __restrict__ lde, size_t col_stride, uint32_t n_cols,
-                                                              unsigned log_n, unsigned rate_bits, uint64_t* __restrict__ digests) {
+                                                              unsigned log_n, unsigned rate_bits, uint64_t* __restrict__ digests,
+                                                              uint32_t batch_cols, size_t tree_words) {
+    if (batch_cols) {   // see k_hash_lde_leaves
+        const uint32_t c0 = blockIdx.y * batch_cols;
+        lde += (size_t)c0 * col_stride;
+        n_cols = n_cols - c0 < batch_cols ? n_cols - c0 : batch_cols;
+        digests += (size_t)blockIdx.y * tree_words;
+    }
     __shared__ uint64_t lds[WIDE_GROUPS_PER_BLOCK * 24];
     const uint32_t j = threadIdx.x & 15, g = threadIdx.x >> 4;
     const size_t pos = (size_t)blockIdx.x * WIDE_GROUPS_PER_BLOCK + g;
     const bool live = (pos >> (log_n + rate_bits)) == 0;
     const uint64_t* p = lde + pos;
     gl32::F x = gl32::from_u64(0);
+    if (n_cols <= 4) {   // hash_or_noop: a row of at most four elements IS its digest, zero-padded (a short last batch)
+        if (j < n_cols) x = gl32::from_u64(live ? p[(size_t)j * col_stride] : 0);
+    } else {
 #pragma unroll 1
-    for (uint32_t c = 0; c < n_cols; c += 8) {
-        if (j < 8 && c + j < n_cols) x = gl32::from_u64(live ? p[(size_t)(c + j) * col_stride] : 0);  // overwrite-mode absorb
-        x = permute_wide(x, j, lds + g * 24);
+        for (uint32_t c = 0; c < n_cols; c += 8) {
+            if (j < 8 && c + j < n_cols) x = gl32::from_u64(live ? p[(size_t)(c + j) * col_stride] : 0);  // overwrite-mode absorb
+            x = permute_wide(x, j, lds + g * 24);
+        }
     }
     if (live && j < 4) {
         const uint32_t r = (uint32_t)(pos >> log_n), k = (uint32_t)(pos & (((size_t)1 << log_n) - 1));
@@ -386,10 +415,11 @@ __global__ __launch_bounds__(256) void k_hash_lde_leaves_wide(const uint64_t* __
 }
 
 void launch_hash_lde_leaves_wide(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols, unsigned log_n,
-                                 unsigned rate_bits, uint64_t* d_digests) {
+                                 unsigned rate_bits, uint64_t* d_digests, uint32_t batch_cols, size_t tree_words) {
     const size_t rows = (size_t)1 << (log_n + rate_bits);
-    hipLaunchKernelGGL(k_hash_lde_leaves_wide, dim3((unsigned)((rows + WIDE_GROUPS_PER_BLOCK - 1) / WIDE_GROUPS_PER_BLOCK)), dim3(256), 0,
-                       st, d_lde, col_stride, n_cols, log_n, rate_bits, d_digests);
+    const uint32_t n_batches = batch_cols ? (n_cols + batch_cols - 1) / batch_cols : 1;
+    hipLaunchKernelGGL(k_hash_lde_leaves_wide, dim3((unsigned)((rows + WIDE_GROUPS_PER_BLOCK - 1) / WIDE_GROUPS_PER_BLOCK), n_batches), dim3(256), 0,
+                       st, d_lde, col_stride, n_cols, log_n, rate_bits, d_digests, batch_cols, tree_words);
 }
 
 void launch_fri_leaves_wide(hipStream_t st, const uint64_t* d_values, unsigned log_n, unsigned rate_bits,
@@ -401,10 +431,10 @@ void launch_fri_leaves_wide(hipStream_t st, const uint64_t* d_values, unsigned l
     else if (arity_bits == 2) hipLaunchKernelGGL(k_fri_leaves_wide<2>, dim3(blocks), dim3(256), 0, st, d_values, log_n, rate_bits, d_digests);
 }
 
-void launch_merkle_fused(hipStream_t st, const uint64_t* children, size_t n_children, unsigned levels) {
+void launch_merkle_fused(hipStream_t st, const uint64_t* children, size_t n_children, unsigned levels, uint32_t n_trees, size_t tree_words) {
     // children level at `children`, its parents right behind it (level-major digest array)
-    hipLaunchKernelGGL(k_merkle_fused, dim3((unsigned)(n_children >> levels)), dim3(FUSED_GROUPS * 16), 0, st, children,
-                       const_cast<uint64_t*>(children) + n_children * 4, n_children, levels);
+    hipLaunchKernelGGL(k_merkle_fused, dim3((unsigned)(n_children >> levels), n_trees), dim3(FUSED_GROUPS * 16), 0, st, children,
+                       const_cast<uint64_t*>(children) + n_children * 4, n_children, levels, tree_words);
 }
 
 }  // namespace nlx

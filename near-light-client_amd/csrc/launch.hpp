@@ -10,11 +10,13 @@ namespace nlx {
 void launch_permute_batch(hipStream_t st, uint64_t* d_states, size_t n);
 void launch_hash_leaves_rowmajor(hipStream_t st, const uint64_t* d_rows, uint32_t row_len, size_t n_rows,
                                  uint64_t* d_digests);
-const uint64_t* launch_merkle_levels(hipStream_t st, uint64_t* d_digests, size_t n_leaves, unsigned cap_height);
+const uint64_t* launch_merkle_levels(hipStream_t st, uint64_t* d_digests, size_t n_leaves, unsigned cap_height, uint32_t n_trees = 1,
+                                     size_t tree_words = 0);   // n_trees trees of the same shape, tree_words apart: one set of launches
 // LDE-table leaf hashing: table is [col][coset r][k] (coset-major natural order);
 // the digest of point (r,k) is written at tree position bitrev3(r)*n + bitrev(k).
+// batch_cols > 0: ceil(n_cols / batch_cols) batches of columns, each with its own tree (tree_words apart in d_digests)
 void launch_hash_lde_leaves(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols,
-                            unsigned log_n, unsigned rate_bits, uint64_t* d_digests);
+                            unsigned log_n, unsigned rate_bits, uint64_t* d_digests, uint32_t batch_cols = 0, size_t tree_words = 0);
 // grouped leaves (n_cols > group > 0): leaf = hash_no_pad of the digests of the row's runs of `group` columns;
 // d_group_digests: scratch of 4 * ceil(n_cols / group) columns x L words, alive until the stream has run this
 void launch_hash_lde_leaves_grouped(hipStream_t st, const uint64_t* d_lde, size_t col_stride, uint32_t n_cols, uint32_t group,

@@ -92,7 +92,7 @@ struct LookupTermsParams {
 };
 void launch_lookup_terms(hipStream_t st, const LookupTermsParams& p);
 
-constexpr int FRI_VIEWS = 5;
+constexpr int FRI_VIEWS = 33;   // FRI_MAX_ORACLES (fri.hpp) + the trailing column group of plonky2's lookup argument
 struct FriCombineParams {
     const uint64_t* tables[FRI_VIEWS];  // LDE column groups in the zeta batch's order: the oracles, then (plonky2 with lookup
                                         // tables) the trailing columns of one of them as a group of their own

@@ -263,7 +263,12 @@ struct nlx_stark {
 static size_t stark_proof_max_bytes(const nlx_stark_desc& d, uint32_t n_rounds) {
     const size_t capb = (size_t)32 << d.cap_height;
     const unsigned log_L = d.degree_bits + d.rate_bits;
-    const uint32_t nq = d.num_challenges * d.quotient_degree_factor, n_oracles = (d.n_rounds ? d.n_rounds : 1) + 1;
+    uint32_t n_trace_oracles = 0;
+    for (uint32_t r = 0; r < (d.n_rounds ? d.n_rounds : 1u); r++) {
+        const uint32_t c = d.n_rounds ? d.round_cols[r] : d.n_cols;
+        n_trace_oracles += d.batch_cols && c > d.batch_cols ? (c + d.batch_cols - 1) / d.batch_cols : 1;
+    }
+    const uint32_t nq = d.num_challenges * d.quotient_degree_factor, n_oracles = n_trace_oracles + 1;
     size_t bytes = n_oracles * capb + 16 * (size_t)(2 * d.n_cols + nq) + n_rounds * capb;
     size_t per_query = (size_t)(d.n_cols + nq) * 8 + n_oracles * (1 + 32 * (size_t)log_L) +
                        n_rounds * (((size_t)16 << d.fri_arity_bits) + 1 + 32 * (size_t)log_L);
@@ -291,6 +296,10 @@ static void air_digest_host(const nlx_stark_desc& d, const std::vector<uint64_t>
     if (d.leaf_group_cols || d.openings_group) {  // only when used: digests of plain-starky statements stay what they were
         v.push_back(d.leaf_group_cols);
         v.push_back(d.openings_group);
+    }
+    if (d.batch_cols) {   // likewise: a statement without batches keeps its digest
+        v.push_back(0xB47C4u);
+        v.push_back(d.batch_cols);
     }
     for (uint64_t w : prog) { v.push_back(w & 0xFFFFFFFFu); v.push_back(w >> 32); }
     for (uint64_t w : periodic) { v.push_back(w & 0xFFFFFFFFu); v.push_back(w >> 32); }
@@ -321,6 +330,13 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
     if (d.n_periodic > NLX_AIR_MAX_PERIODIC || (d.n_periodic && (!d.periodic || d.period_bits > d.degree_bits || d.period_bits > 16)))
         return ctx->fail(NLX_E_RANGE, "periodic columns out of range");
     if (d.n_rounds > 3) return ctx->fail(NLX_E_RANGE, "at most three commitment rounds");
+    if (d.batch_cols) {
+        if (d.batch_cols < 8 || d.batch_cols > 65535) return ctx->fail(NLX_E_RANGE, "batch_cols must be 0 or 8 .. 65535");
+        if (d.leaf_group_cols) return ctx->fail(NLX_E_INVAL, "batch_cols and leaf_group_cols exclude each other");
+        uint32_t n_or = 0;
+        for (uint32_t r = 0; r < (d.n_rounds ? d.n_rounds : 1u); r++) n_or += ((d.n_rounds ? d.round_cols[r] : d.n_cols) + d.batch_cols - 1) / d.batch_cols;
+        if (n_or > NLX_STARK_MAX_ORACLES - 1) return ctx->fail(NLX_E_RANGE, "batch_cols %u makes %u batches (at most %u)", d.batch_cols, n_or, NLX_STARK_MAX_ORACLES - 1);
+    }
     uint32_t n_round_challenges = 0;
     if (d.n_rounds) {
         uint32_t tot = 0;
@@ -634,10 +650,15 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
             for (uint32_t k = 0; k < n_rv; k++) rv[k] %= gl::P;
             Staged tr(ctx, tr_ptr, (size_t)rcols * n * 8, true, false);
             CHECK(tr.status);
-            CHECK(commit_build(ctx, tr.as<uint64_t>(), n, CommitInput::ValuesNatural, rcols, log_n, d.rate_bits, cap_h, &cr[r], d.leaf_group_cols));
-            CHECK(fetch(ctx, cap.data(), cr[r]->cap, capw * 8));
-            w.u64s(cap.data(), capw);
-            ch.observe(cap.data(), capw);
+            // one PolynomialBatch, or (batch_cols) ceil(rcols / batch_cols) of them: transformed together, a tree and a cap each, the
+            // caps into the transcript and the proof in batch order
+            CHECK(commit_build(ctx, tr.as<uint64_t>(), n, CommitInput::ValuesNatural, rcols, log_n, d.rate_bits, cap_h, &cr[r], d.leaf_group_cols,
+                               d.batch_cols));
+            for (uint32_t k = 0; k < cr[r]->n_trees; k++) {
+                CHECK(fetch(ctx, cap.data(), cr[r]->cap + (size_t)k * cr[r]->tree_words, capw * 8));
+                w.u64s(cap.data(), capw);
+                ch.observe(cap.data(), capw);
+            }
             if (n_rv) {  // the round's values: into the transcript before its challenges, into the proof's tail later
                 ch.observe(rv, n_rv);
                 values.insert(values.end(), rv, rv + n_rv);
@@ -769,12 +790,17 @@ int32_t nlx_stark_prove_rounds(nlx_stark* s, nlx_round_fn round_fn, void* user, 
         // ---- FRI: Stark::fri_instance = [zeta: every round's columns ++ quotient], [g zeta: every round's columns] ----
         {
             FriProveArgs fa;
-            for (uint32_t r = 0; r < NRD; r++) {
-                fa.oracles[r] = cr[r];
-                fa.nz[r] = s->round_cols[r];
-            }
-            fa.oracles[NRD] = cq;
-            fa.n_oracles = NRD + 1;
+            nlx_commit views[NLX_STARK_MAX_ORACLES];   // a batch as a commitment of its own: its columns, its tree
+            uint32_t no = 0;
+            for (uint32_t r = 0; r < NRD; r++)
+                for (uint32_t k = 0; k < cr[r]->n_trees; k++) {
+                    views[no] = commit_view(cr[r], k);
+                    fa.oracles[no] = &views[no];
+                    fa.nz[no] = views[no].n_cols;
+                    no++;
+                }
+            fa.oracles[no] = cq;
+            fa.n_oracles = no + 1;
             for (int i = 0; i < 2; i++) { fa.zeta[i] = zeta[i]; fa.gzeta[i] = gzeta[i]; }
             fa.open0 = open.data();
             fa.open1 = o_next;

@@ -40,7 +40,7 @@ class StarkDesc(ctypes.Structure):
                        ("period_bits", ctypes.c_uint32), ("periodic", ctypes.POINTER(ctypes.c_uint64)),
                        ("n_rounds", ctypes.c_uint32), ("round_cols", ctypes.c_uint32 * 3),
                        ("round_challenges", ctypes.c_uint32 * 3), ("leaf_group_cols", ctypes.c_uint32),
-                       ("round_values", ctypes.c_uint32 * 3), ("openings_group", ctypes.c_uint32)]
+                       ("round_values", ctypes.c_uint32 * 3), ("openings_group", ctypes.c_uint32), ("batch_cols", ctypes.c_uint32)]
 
 
 # the opt-in "grouped-leaves" variant (StarkConfig.grouped()) switches grouped leaves on up to this many LDE rows (2^k): at 2^16
@@ -73,6 +73,10 @@ class StarkConfig:
         # the transcript observes a digest of the openings (runs of this many values) instead of every value
         # (nlx_stark_desc.openings_group); 0 = starky's transcript; AUTO = 64 when the trace has more than 256 columns, else 0
         self.openings_group = 0
+        # a commitment round of more than this many columns is committed as several PolynomialBatches of at most this many
+        # columns - plain plonky2 batches, each with whole-row hash_or_noop leaves, its own cap and FRI oracle
+        # (nlx_stark_desc.batch_cols); 0 = one batch per round
+        self.batch_cols = 0
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown config field %s" % k)
@@ -592,6 +596,7 @@ class Stark:
                               len(air._periodic), air.period_bits, self.periodic.ctypes.data_as(u64p))
         self.desc.leaf_group_cols = cfg.leaf_group_for(degree_bits, max(c for c, _ in air.rounds) if air.rounds is not None else air.n_cols)
         self.desc.openings_group = cfg.openings_group_for(air.n_cols)
+        self.desc.batch_cols = int(cfg.batch_cols)
         if air.rounds is not None:
             self.desc.n_rounds = len(air.rounds)
             for r, (c, k) in enumerate(air.rounds):

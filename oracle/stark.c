@@ -489,7 +489,7 @@ static uint64_t* periodic_coeffs(const orc_stark_desc* d) {
  * program word as (lo, hi) with CONST immediates reduced mod p first, then every periodic value (reduced) as (lo, hi). */
 void orc_stark_air_digest(const orc_stark_desc* d, uint64_t out[4]) {
     const size_t n_per = d->n_periodic ? ((size_t)d->n_periodic << d->period_bits) : 0;
-    const size_t len = 24 + ((d->leaf_group_cols || d->openings_group) ? 2 : 0) + 2 * (size_t)d->n_words + 2 * n_per;
+    const size_t len = 24 + ((d->leaf_group_cols || d->openings_group) ? 2 : 0) + (d->batch_cols ? 2 : 0) + 2 * (size_t)d->n_words + 2 * n_per;
     uint64_t* v = (uint64_t*)malloc(8 * len);
     size_t k = 0;
     const uint32_t shape[14] = {d->degree_bits, d->n_cols, d->num_challenges, d->rate_bits, d->cap_height,
@@ -504,6 +504,10 @@ void orc_stark_air_digest(const orc_stark_desc* d, uint64_t out[4]) {
     if (d->leaf_group_cols || d->openings_group) {   /* only when used: digests of plain-starky statements stay what they were */
         v[k++] = d->leaf_group_cols;
         v[k++] = d->openings_group;
+    }
+    if (d->batch_cols) {   /* likewise: a statement without batches keeps its digest */
+        v[k++] = 0xB47C4u;
+        v[k++] = d->batch_cols;
     }
     for (uint32_t pc = 0; pc < d->n_words; pc++) {
         uint64_t w = d->program[pc];
@@ -583,6 +587,15 @@ static int desc_ok(const orc_stark_desc* d) {
         }
         if (tot != d->n_cols) return 0;
     }
+    if (d->batch_cols) {
+        if (d->batch_cols < 8 || d->batch_cols > 65535 || d->leaf_group_cols) return 0;
+        uint32_t no = 0;
+        for (uint32_t r = 0; r < (d->n_rounds ? d->n_rounds : 1u); r++) {
+            const uint32_t rc = d->n_rounds ? d->round_cols[r] : d->n_cols;
+            no += (rc + d->batch_cols - 1) / d->batch_cols;
+        }
+        if (no > ORC_STARK_MAX_ORACLES - 1) return 0;
+    }
     const uint32_t n_values = d->num_public_inputs + total_round_challenges(d);
     for (uint32_t pc = 0; pc < d->n_words; pc++) {
         uint64_t w = d->program[pc];
@@ -606,14 +619,29 @@ static int desc_ok(const orc_stark_desc* d) {
     return 1;
 }
 
+/* batches of a round of rc columns (orc_stark_desc.batch_cols), and the trace oracles of the whole proof */
+static uint32_t batches_of(const orc_stark_desc* d, uint32_t rc) {
+    return d->batch_cols && rc > d->batch_cols ? (rc + d->batch_cols - 1) / d->batch_cols : 1;
+}
+static uint32_t batch_width(const orc_stark_desc* d, uint32_t rc, uint32_t k) {
+    if (batches_of(d, rc) == 1) return rc;
+    const uint32_t c0 = k * d->batch_cols;
+    return rc - c0 < d->batch_cols ? rc - c0 : d->batch_cols;
+}
+static uint32_t n_trace_oracles(const orc_stark_desc* d) {
+    uint32_t no = 0;
+    for (uint32_t r = 0; r < n_rounds_of(d); r++) no += batches_of(d, round_cols_of(d, r));
+    return no;
+}
+
 size_t orc_stark_proof_max_bytes(const orc_stark_desc* d) {
     const size_t capb = (size_t)32 << d->cap_height;
     const unsigned log_L = d->degree_bits + d->rate_bits;
-    const uint32_t nq = d->num_challenges * d->quotient_degree_factor, NRD = n_rounds_of(d);
+    const uint32_t nq = d->num_challenges * d->quotient_degree_factor, NO = n_trace_oracles(d);
     orc_fri_params fp = {d->degree_bits, d->rate_bits, d->cap_height, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits, d->leaf_group_cols};
     uint32_t R = fri_num_rounds(&fp);
-    size_t bytes = (NRD + 1) * capb + 16 * (size_t)(2 * d->n_cols + nq) + R * capb;
-    size_t per_query = (d->n_cols + nq) * 8 + (NRD + 1) * (1 + 32 * (size_t)log_L) + R * (((size_t)16 << d->fri_arity_bits) + 1 + 32 * (size_t)log_L);
+    size_t bytes = (NO + 1) * capb + 16 * (size_t)(2 * d->n_cols + nq) + R * capb;
+    size_t per_query = (d->n_cols + nq) * 8 + (NO + 1) * (1 + 32 * (size_t)log_L) + R * (((size_t)16 << d->fri_arity_bits) + 1 + 32 * (size_t)log_L);
     bytes += per_query * d->fri_num_queries + ((size_t)16 << d->degree_bits) + 8 + 8 + 8 * (size_t)d->num_public_inputs +
              8 * (size_t)total_round_values(d);
     return bytes + 64;
@@ -638,9 +666,11 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
     if (d->num_public_inputs) memcpy(values, public_inputs, 8 * (size_t)d->num_public_inputs);
     transcript_start(&ch, d, values);
     uint32_t n_drawn = 0;
-    uint64_t *r_coeffs[3] = {0}, *r_leaves[3] = {0}, *r_dig[3] = {0};
-    uint64_t r_cap[3][4 * 64];
-    uint32_t col0[4] = {0};
+    /* per TRACE ORACLE (a round, or one of its batches): coefficients, row-major leaves, tree, cap, first column and width */
+    uint64_t *r_coeffs[ORC_STARK_MAX_ORACLES] = {0}, *r_leaves[ORC_STARK_MAX_ORACLES] = {0}, *r_dig[ORC_STARK_MAX_ORACLES] = {0};
+    uint64_t (*r_cap)[4 * 64] = (uint64_t (*)[4 * 64])malloc(sizeof(uint64_t[4 * 64]) * ORC_STARK_MAX_ORACLES);
+    uint32_t col0[ORC_STARK_MAX_ORACLES + 1] = {0};
+    uint32_t NO = 0;   /* trace oracles so far */
     int ok = 1;
     for (uint32_t r = 0; r < NRD && ok; r++) {
         const uint32_t rc = round_cols_of(d, r);
@@ -649,20 +679,25 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
         const uint64_t* tr = fn(user, r, values + d->num_public_inputs, n_drawn, n_rv ? rv : NULL);
         if (!tr) { ok = 0; break; }
         for (uint32_t k = 0; k < n_rv; k++) rv[k] %= GL_P;
-        r_coeffs[r] = (uint64_t*)malloc(8 * n * rc);
-        r_leaves[r] = (uint64_t*)malloc(8 * L * rc);
-        r_dig[r] = (uint64_t*)malloc(8 * orc_merkle_digest_words(L, cap_h));
-        orc_commit_from_values_g(tr, rc, log_n, d->rate_bits, cap_h, d->leaf_group_cols, r_coeffs[r], r_leaves[r], r_dig[r], r_cap[r]);
-        w_u64s(&w, r_cap[r], capw);
-        observe_cap(&ch, r_cap[r], cap_h);
+        for (uint32_t k = 0; k < batches_of(d, rc); k++) {   /* one PolynomialBatch::from_values per batch, caps in batch order */
+            const uint32_t bw = batch_width(d, rc, k), o = NO++;
+            const uint64_t* btr = tr + (size_t)(col0[o] - (col0[o - k])) * n;   /* the batch's columns of this round (column-major) */
+            r_coeffs[o] = (uint64_t*)malloc(8 * n * bw);
+            r_leaves[o] = (uint64_t*)malloc(8 * L * bw);
+            r_dig[o] = (uint64_t*)malloc(8 * orc_merkle_digest_words(L, cap_h));
+            orc_commit_from_values_g(btr, bw, log_n, d->rate_bits, cap_h, d->leaf_group_cols, r_coeffs[o], r_leaves[o], r_dig[o], r_cap[o]);
+            w_u64s(&w, r_cap[o], capw);
+            observe_cap(&ch, r_cap[o], cap_h);
+            col0[o + 1] = col0[o] + bw;
+        }
         if (n_rv) orc_ch_observe_many(&ch, rv, n_rv);
         n_drawn += n_rv;
         if (d->n_rounds)
             for (uint32_t k = 0; k < d->round_challenges[r]; k++) values[d->num_public_inputs + n_drawn++] = orc_ch_challenge(&ch);
-        col0[r + 1] = col0[r] + rc;
     }
     if (!ok) {
-        for (uint32_t r = 0; r < NRD; r++) { free(r_coeffs[r]); free(r_leaves[r]); free(r_dig[r]); }
+        for (uint32_t o = 0; o < NO; o++) { free(r_coeffs[o]); free(r_leaves[o]); free(r_dig[o]); }
+        free(r_cap);
         free(values);
         return 0;
     }
@@ -702,7 +737,7 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
                 uint64_t l_first = gl_mul(zh, gl_inv(gl_mul(n_f, gl_sub(x, 1))));
                 uint64_t l_last = gl_mul(zh, gl_inv(gl_mul(n_f, gl_sub(gl_mul(g, x), 1))));
                 size_t li = gl_bitrev(i * step, log_L), ln = gl_bitrev(((i + next_step) % size) * step, log_L);
-                for (uint32_t r = 0; r < NRD; r++) {
+                for (uint32_t r = 0; r < NO; r++) {
                     const uint32_t rc = col0[r + 1] - col0[r];
                     memcpy(loc + col0[r], r_leaves[r] + li * rc, 8 * (size_t)rc);
                     memcpy(nxt + col0[r], r_leaves[r] + ln * rc, 8 * (size_t)rc);
@@ -735,7 +770,7 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
     gl2* o_local = (gl2*)malloc(sizeof(gl2) * (2 * ncols + nq));
     gl2* o_next = o_local + ncols;
     gl2* o_q = o_next + ncols;
-    for (uint32_t r = 0; r < NRD; r++) {
+    for (uint32_t r = 0; r < NO; r++) {
         const uint32_t rc = col0[r + 1] - col0[r];
 #pragma omp parallel for schedule(dynamic)
         for (uint32_t c = 0; c < rc; c++) {
@@ -750,23 +785,23 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
     /* observe_openings: zeta batch (local ++ quotient), then zeta_next batch (next) */
     observe_openings(&ch, d, o_local, o_q, o_next, ncols, nq);
     /* fri_instance: batch 0 at zeta = every round's columns ++ quotient, batch 1 at g*zeta = every round's columns */
-    orc_fri_oracle oracles[4];
-    for (uint32_t r = 0; r < NRD; r++) {
+    orc_fri_oracle oracles[ORC_STARK_MAX_ORACLES + 1];
+    for (uint32_t r = 0; r < NO; r++) {
         orc_fri_oracle o = {r_coeffs[r], r_leaves[r], r_dig[r], r_cap[r], col0[r + 1] - col0[r]};
         oracles[r] = o;
     }
     {
         orc_fri_oracle o = {q_coeffs, q_leaves, q_dig, q_cap, nq};
-        oracles[NRD] = o;
+        oracles[NO] = o;
     }
     uint32_t* idx_o = (uint32_t*)malloc(4 * 2 * (ncols + nq));
     uint32_t* idx_p = idx_o + ncols + nq;
-    for (uint32_t r = 0; r < NRD; r++)
+    for (uint32_t r = 0; r < NO; r++)
         for (uint32_t c = col0[r]; c < col0[r + 1]; c++) { idx_o[c] = r; idx_p[c] = c - col0[r]; }
-    for (uint32_t c = 0; c < nq; c++) { idx_o[ncols + c] = NRD; idx_p[ncols + c] = c; }
+    for (uint32_t c = 0; c < nq; c++) { idx_o[ncols + c] = NO; idx_p[ncols + c] = c; }
     orc_fri_batch batches[2] = {{zeta, ncols + nq, idx_o, idx_p}, {g_zeta, ncols, idx_o, idx_p}};
     orc_fri_params fp = {d->degree_bits, d->rate_bits, cap_h, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits, d->leaf_group_cols};
-    fri_prove(&fp, oracles, NRD + 1, batches, 2, &ch, &w);
+    fri_prove(&fp, oracles, NO + 1, batches, 2, &ch, &w);
     w_usize(&w, d->num_public_inputs);
     w_u64s(&w, public_inputs, d->num_public_inputs);
     {   /* the round values, in round order, after the public inputs */
@@ -777,7 +812,8 @@ size_t orc_stark_prove_rounds(const orc_stark_desc* d, orc_round_fn fn, void* us
         }
     }
     free(idx_o); free(o_local); free(q_coeffs); free(q_leaves); free(q_dig); free(values);
-    for (uint32_t r = 0; r < NRD; r++) { free(r_coeffs[r]); free(r_leaves[r]); free(r_dig[r]); }
+    for (uint32_t r = 0; r < NO; r++) { free(r_coeffs[r]); free(r_leaves[r]); free(r_dig[r]); }
+    free(r_cap);
     return w.overflow ? 0 : w.len;
 }
 
@@ -799,8 +835,8 @@ size_t orc_stark_prove(const orc_stark_desc* d, const uint64_t* trace, const uin
 uint32_t orc_stark_values(const orc_stark_desc* d, const uint8_t* proof, size_t len, uint64_t* out) {
     if (!desc_ok(d)) return 0;
     const size_t capw = (size_t)4 << d->cap_height;
-    const uint32_t NRD = n_rounds_of(d), n_rv_total = total_round_values(d);
-    if (len < 8 * (NRD + 1) * capw + 8 + 8 * (size_t)(d->num_public_inputs + n_rv_total)) return 0;
+    const uint32_t NRD = n_rounds_of(d), n_rv_total = total_round_values(d), NO = n_trace_oracles(d);
+    if (len < 8 * (NO + 1) * capw + 8 + 8 * (size_t)(d->num_public_inputs + n_rv_total)) return 0;
     const size_t tail = len - 8 - 8 * (size_t)(d->num_public_inputs + n_rv_total);
     const uint64_t* caps = (const uint64_t*)proof;
     uint64_t rv[3 * 64];
@@ -809,11 +845,13 @@ uint32_t orc_stark_values(const orc_stark_desc* d, const uint8_t* proof, size_t 
     orc_challenger ch;
     orc_ch_init(&ch);
     transcript_start(&ch, d, out);
-    uint32_t n = d->num_public_inputs, off = 0;
+    uint32_t n = d->num_public_inputs, off = 0, o = 0;
     for (uint32_t rd = 0; rd < NRD; rd++) {
-        uint64_t cap[4 * 64];
-        memcpy(cap, caps + rd * capw, 8 * capw);
-        orc_ch_observe_many(&ch, cap, capw);
+        for (uint32_t k = 0; k < batches_of(d, round_cols_of(d, rd)); k++, o++) {   /* the round's caps, batch by batch */
+            uint64_t cap[4 * 64];
+            memcpy(cap, caps + o * capw, 8 * capw);
+            orc_ch_observe_many(&ch, cap, capw);
+        }
         if (!d->n_rounds) continue;
         for (uint32_t k = 0; k < d->round_values[rd]; k++) out[n++] = rv[off + k];
         if (d->round_values[rd]) orc_ch_observe_many(&ch, rv + off, d->round_values[rd]);
@@ -828,11 +866,11 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
     const unsigned log_n = d->degree_bits, cap_h = d->cap_height;
     const size_t n = (size_t)1 << log_n, capw = (size_t)4 << cap_h;
     const uint32_t nc = d->num_challenges, qdf = d->quotient_degree_factor, ncols = d->n_cols, nq = nc * qdf;
-    const uint32_t NRD = n_rounds_of(d), n_rch = total_round_challenges(d);
+    const uint32_t NRD = n_rounds_of(d), n_rch = total_round_challenges(d), NO = n_trace_oracles(d);
     rbuf r = {proof, len, 0, 0};
     int rc = 1;
-    uint64_t* caps = (uint64_t*)malloc(8 * (NRD + 1) * capw);
-    r_u64s(&r, caps, (NRD + 1) * capw);
+    uint64_t* caps = (uint64_t*)malloc(8 * (NO + 1) * capw);
+    r_u64s(&r, caps, (NO + 1) * capw);
     gl2* o_local = (gl2*)malloc(sizeof(gl2) * (2 * ncols + nq));
     gl2* o_next = o_local + ncols;
     gl2* o_q = o_next + ncols;
@@ -858,9 +896,9 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
         orc_challenger ch;
         orc_ch_init(&ch);
         transcript_start(&ch, d, pis);
-        uint32_t n_drawn = 0, rv_off = 0;
+        uint32_t n_drawn = 0, rv_off = 0, oo = 0;
         for (uint32_t rd = 0; rd < NRD; rd++) {
-            orc_ch_observe_many(&ch, caps + rd * capw, capw);
+            for (uint32_t k = 0; k < batches_of(d, round_cols_of(d, rd)); k++, oo++) orc_ch_observe_many(&ch, caps + oo * capw, capw);
             if (d->n_rounds) {
                 for (uint32_t k = 0; k < d->round_values[rd]; k++) pis[d->num_public_inputs + n_drawn++] = round_vals[rv_off + k];
                 if (d->round_values[rd]) orc_ch_observe_many(&ch, round_vals + rv_off, d->round_values[rd]);
@@ -870,7 +908,7 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
         }
         uint64_t alphas[4];
         for (uint32_t j = 0; j < nc; j++) alphas[j] = orc_ch_challenge(&ch);
-        orc_ch_observe_many(&ch, caps + NRD * capw, capw);
+        orc_ch_observe_many(&ch, caps + NO * capw, capw);
         gl2 zeta = orc_ch_ext_challenge(&ch);
         observe_openings(&ch, d, o_local, o_q, o_next, ncols, nq);
         /* vanishing polynomial identity at zeta */
@@ -901,25 +939,29 @@ int orc_stark_verify(const orc_stark_desc* d, const uint8_t* proof, size_t len) 
         }
         if (rc != 1) goto done;
         gl2 g_zeta = gl2_scale(zeta, g);
-        uint32_t col0[4] = {0};
-        for (uint32_t rd = 0; rd < NRD; rd++) col0[rd + 1] = col0[rd] + round_cols_of(d, rd);
+        uint32_t col0[ORC_STARK_MAX_ORACLES + 1] = {0};   /* per trace oracle (a round or one of its batches) */
+        {
+            uint32_t o = 0;
+            for (uint32_t rd = 0; rd < NRD; rd++)
+                for (uint32_t k = 0; k < batches_of(d, round_cols_of(d, rd)); k++, o++) col0[o + 1] = col0[o] + batch_width(d, round_cols_of(d, rd), k);
+        }
         uint32_t* idx_o = (uint32_t*)malloc(4 * 2 * (ncols + nq));
         uint32_t* idx_p = idx_o + ncols + nq;
-        for (uint32_t rd = 0; rd < NRD; rd++)
+        for (uint32_t rd = 0; rd < NO; rd++)
             for (uint32_t c = col0[rd]; c < col0[rd + 1]; c++) { idx_o[c] = rd; idx_p[c] = c - col0[rd]; }
-        for (uint32_t c = 0; c < nq; c++) { idx_o[ncols + c] = NRD; idx_p[ncols + c] = c; }
+        for (uint32_t c = 0; c < nq; c++) { idx_o[ncols + c] = NO; idx_p[ncols + c] = c; }
         orc_fri_batch batches[2] = {{zeta, ncols + nq, idx_o, idx_p}, {g_zeta, ncols, idx_o, idx_p}};
         gl2* open0 = (gl2*)malloc(sizeof(gl2) * (ncols + nq));
         memcpy(open0, o_local, sizeof(gl2) * ncols);
         memcpy(open0 + ncols, o_q, sizeof(gl2) * nq);
         const gl2* opened[2] = {open0, o_next};
-        const uint64_t* cap_ptrs[4];
-        uint32_t n_cols[4];
-        for (uint32_t rd = 0; rd < NRD; rd++) { cap_ptrs[rd] = caps + rd * capw; n_cols[rd] = col0[rd + 1] - col0[rd]; }
-        cap_ptrs[NRD] = caps + NRD * capw;
-        n_cols[NRD] = nq;
+        const uint64_t* cap_ptrs[ORC_STARK_MAX_ORACLES + 1];
+        uint32_t n_cols[ORC_STARK_MAX_ORACLES + 1];
+        for (uint32_t rd = 0; rd < NO; rd++) { cap_ptrs[rd] = caps + rd * capw; n_cols[rd] = col0[rd + 1] - col0[rd]; }
+        cap_ptrs[NO] = caps + NO * capw;
+        n_cols[NO] = nq;
         orc_fri_params fp = {d->degree_bits, d->rate_bits, cap_h, d->fri_pow_bits, d->fri_num_queries, d->fri_arity_bits, d->fri_final_poly_bits, d->leaf_group_cols};
-        rc = fri_verify(&fp, cap_ptrs, n_cols, NRD + 1, batches, 2, opened, &ch, &r);
+        rc = fri_verify(&fp, cap_ptrs, n_cols, NO + 1, batches, 2, opened, &ch, &r);
         if (rc == 1 && r.pos != r.len) rc = -11;
         free(open0);
         free(idx_o);

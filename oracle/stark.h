@@ -112,7 +112,14 @@ typedef struct {
      * permutations on one host thread for a 4 745-column trace: 3 of the proof's 8 ms) becomes parallel work.  In the statement
      * digest when non-zero. */
     uint32_t openings_group;
+    /* Batches: 0 = a round's columns are one PolynomialBatch.  B > 0: a round of more than B columns is committed as
+     * ceil(cols / B) PolynomialBatches of B columns (the last one what is left), in column order - each exactly
+     * PolynomialBatch::from_values (hash_or_noop leaves over its own row, its own cap, its own FRI oracle); caps are observed and
+     * written in batch order, every query opens each batch's row with its own path; openings and their order do not change.
+     * In the statement digest when non-zero.  (include/nlx.h nlx_stark_desc.batch_cols) */
+    uint32_t batch_cols;
 } orc_stark_desc;
+#define ORC_STARK_MAX_ORACLES 31
 
 /* returns round `round`'s columns (round_cols[round] x n, column-major) given everything after the public inputs in the
  * values array so far (`n_known` elements), and writes the round's round_values[round] values to values_out */

@@ -37,6 +37,13 @@ CASES = [
     ("wide16", 8, dict(openings_group=24, leaf_group_cols=12)),
     ("fib", 8, dict(openings_group=4096)),            # everything in one padded run
     ("wide320", 8, dict(leaf_group_cols="auto")),     # grouped leaves under starky's transcript (every opening observed)
+    # batches (nlx_stark_desc.batch_cols): a round of more than B columns is committed as several PolynomialBatches - plain plonky2
+    # batches, each with hash_or_noop leaves over its own row, its own cap and its own FRI oracle
+    ("wide320", 8, dict(batch_cols=64)),              # five batches of 64
+    ("wide64", 9, dict(batch_cols=24)),               # 24 + 24 + 16
+    ("wide16", 8, dict(batch_cols=12)),               # 12 + 4: the last batch's row IS its digest (hash_or_noop)
+    ("wide320", 13, dict(batch_cols=128)),            # 128 + 128 + 64 on 2^14 LDE rows: one lane per leaf
+    ("wide64", 10, dict(batch_cols=64)),              # the round fits one batch: nothing changes but the statement digest
 ]
 
 

@@ -405,7 +405,7 @@ def test_round_values_oracle(nlx, orc):
     S = nlx.stark
     air = fingerprint_air(S)
     st = S.Stark(air, 6, S.StarkConfig(fri_num_queries=20))
-    assert list(st.desc.round_values) == [0, 1, 0] and ctypes_sizeof(st.desc) == 120
+    assert list(st.desc.round_values) == [0, 1, 0] and ctypes_sizeof(st.desc) == 128   # + batch_cols (round 4)
     rng = np.random.default_rng(5)
     v = rng.integers(0, P, 64, dtype=np.uint64)
     proof = orc.stark_prove_rounds(st.desc, fingerprint_rounds(v), [])
@@ -523,3 +523,40 @@ def test_openings_digest_is_what_the_header_says(nlx, orc):
     assert wide.desc.openings_group == 0 and wide.desc.leaf_group_cols == 0        # the reference's protocol by default
     wide = S.Stark(S.wide_air(320, seed=3), 5, S.StarkConfig.grouped())
     assert wide.desc.openings_group == 64 and wide.desc.leaf_group_cols == 128
+
+
+def test_batches_are_ordinary_polynomial_batches(nlx, orc):
+    """batch_cols: a commitment round of more than B columns is ceil(cols / B) PolynomialBatches - each one's cap is the cap of
+    orc.commit over ITS columns alone (hash_or_noop leaves, nothing new), the proof carries the caps in batch order where the
+    single cap was, every query opens one more row + path per extra batch, the oracle verifier accepts it and rejects it under
+    any other batching, and a statement without batches keeps its digest and its bytes"""
+    S = nlx.stark
+    air, t, pis = make_case(S, "wide16", 6)
+    plain, b12, b8 = S.Stark(air, 6), S.Stark(air, 6, S.StarkConfig(batch_cols=12)), S.Stark(air, 6, S.StarkConfig(batch_cols=8))
+    assert plain.desc.batch_cols == 0 and b12.desc.batch_cols == 12
+    base = orc.stark_prove(plain.desc, t, pis)
+    proof = orc.stark_prove(b12.desc, t, pis)
+    assert orc.stark_verify(b12.desc, proof) == 1
+    assert orc.stark_verify(plain.desc, proof) != 1 and orc.stark_verify(b8.desc, proof) != 1
+    assert not np.array_equal(orc.stark_air_digest(plain.desc), orc.stark_air_digest(b12.desc))
+    capb = 32 << 4
+    for k, (lo, hi) in enumerate(((0, 12), (12, 16))):          # 12 + 4 columns; the second batch's leaves are the rows themselves
+        want = orc.commit(t[lo:hi], 1, 4)["cap"]
+        got = np.frombuffer(proof[k * capb:(k + 1) * capb], dtype=np.uint64).reshape(16, 4)
+        assert np.array_equal(got, want), "cap of batch %d is PolynomialBatch::from_values of its columns" % k
+    log_l = 7
+    assert len(proof) == len(base) + capb + 84 * (1 + 32 * (log_l - 4))   # one more cap, one more path per query
+    tampered = bytearray(proof)
+    tampered[capb + 5] ^= 1                                                # the second batch's cap
+    assert orc.stark_verify(b12.desc, bytes(tampered)) != 1
+    # a two-round AIR (SHA-256's binding round): every round is batched on its own - round 0 in four batches, round 1 (two columns) in one
+    SA = nlx.sha256_air
+    blocks, first, digest = SA.blocks_for_messages([b"abc", b"batches"], 2)
+    tr, _ = SA.reference_trace(blocks, first)
+    st = S.Stark(SA.sha256_air(), 4, S.StarkConfig(batch_cols=512, fri_num_queries=10))
+    proof = orc.stark_prove_rounds(st.desc, SA.cpu_rounds(blocks, first, tr), digest)
+    assert orc.stark_verify(st.desc, proof) == 1
+    assert orc.stark_verify(S.Stark(SA.sha256_air(), 4, S.StarkConfig(fri_num_queries=10)).desc, proof) != 1
+    for k in range(4):
+        want = orc.commit(tr[512 * k:512 * (k + 1)], 1, 4)["cap"]
+        assert np.array_equal(np.frombuffer(proof[k * capb:(k + 1) * capb], dtype=np.uint64).reshape(16, 4), want)
