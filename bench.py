@@ -557,7 +557,7 @@ def run_ed25519(args, nlx, torch, rank, world, local, dist):
     distinct = E.synthetic_slots(64, seed=9 + rank)
     words = np.tile(E.slots_to_words(distinct), (n_slots // 64, 1))
     ctx = nlx.Context(local)
-    pr = E.Ed25519Prover(ctx, args.log_slots, segment_nodes=args.segment_nodes)
+    pr = E.Ed25519Prover(ctx, args.log_slots, nlx.StarkConfig(batch_cols=args.stark_batch_cols), segment_nodes=args.segment_nodes)
     for _ in range(args.warmup):
         pr.prove(words)
     ctx.kernel_timing(True)
