@@ -209,7 +209,15 @@ typedef struct {
     const uint64_t *pi;                       /* public-input polynomial (values on H) or NULL */
     const uint64_t *coset_shift, *k1, *k2;    /* gnark: the domain's FrMultiplicativeGen u, then k1 = u, k2 = u^2 */
     const uint64_t *alpha, *beta, *gamma;
+    /* Blinding (flags |= NLX_BN254_PLONK_BLINDED; gnark: getBlindedPolynomial, order 1 for l, r, o and order 2 for z): host, nine
+     * elements of four words in the form of the data - b[0], b[1] for l, b[2], b[3] for r, b[4], b[5] for o, b[6], b[7], b[8] for
+     * z: the polynomial that enters the quotient is l(X) + (b[0] + b[1] X)(X^n - 1) ... z(X) + (b[6] + b[7] X + b[8] X^2)(X^n - 1)
+     * (same values on H; the caller commits to and opens the blinded polynomials).  The quotient then has 3 n + 6 coefficients:
+     * t_out receives ALL 4 n of them (4 n x 4 words) and *high_chunk_is_zero tells whether coefficients 3 n + 6 .. 4 n - 1 vanish;
+     * gnark's h1, h2, h3 are t[0 : n + 2], t[n + 2 : 2 n + 4], t[2 n + 4 : 3 n + 6].  log_n >= 3.  NULL / flag clear: as before. */
+    const uint64_t *blinding;
 } nlx_bn254_plonk_quotient_args;
+#define NLX_BN254_PLONK_BLINDED 0x100u
 int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_args* args, uint64_t* t_out, int32_t* high_chunk_is_zero);
 /* The permutation's grand product (gnark computeZ / the paper's round 2): z(w^0) = 1,
  * z(w^(i+1)) = z(w^i) prod_j (w_j(i) + beta id_j(i) + gamma) / (w_j(i) + beta s_j(i) + gamma), id = (w^i, k1 w^i, k2 w^i).

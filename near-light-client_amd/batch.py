@@ -260,14 +260,14 @@ def bn254_msm_g1(ctx, points, scalars, montgomery=False):
 class _PlonkQuotientArgs(ctypes.Structure):
     """nlx_bn254_plonk_quotient_args (include/nlx.h)"""
     _fields_ = [("log_n", ctypes.c_uint32), ("flags", ctypes.c_uint32)] + [(k, ctypes.c_void_p) for k in (
-        "ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3", "l", "r", "o", "z", "pi", "coset_shift", "k1", "k2", "alpha", "beta", "gamma")]
+        "ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3", "l", "r", "o", "z", "pi", "coset_shift", "k1", "k2", "alpha", "beta", "gamma", "blinding")]
 
 
 def _fr_words(x):
     return np.array([(int(x) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(4)], dtype=np.uint64)
 
 
-def bn254_plonk_quotient(ctx, polys, coset_shift, k1, k2, alpha, beta, gamma, out=None):
+def bn254_plonk_quotient(ctx, polys, coset_shift, k1, k2, alpha, beta, gamma, out=None, blinding=None):
     """The PLONK prover's quotient chain over BN254's scalar field (nlx_bn254_plonk_quotient).  polys: dict with the values on
     H of ql qr qm qo qk s1 s2 s3 l r o z and optionally pi, each an (n, 4) uint64 array of fr.Element words (Montgomery) or a
     device tensor of that shape; the six scalars: integers in Montgomery form.  Returns (t, ok): t = (3, n, 4) uint64, the
@@ -296,12 +296,21 @@ def bn254_plonk_quotient(ctx, polys, coset_shift, k1, k2, alpha, beta, gamma, ou
     if 1 << args.log_n != n:
         raise ValueError("n must be a power of two")
     args.flags = 1
+    if blinding is not None:
+        # nine scalars (Montgomery integers): l += (b0 + b1 X) Z_H, r: b2 b3, o: b4 b5, z += (b6 + b7 X + b8 X^2) Z_H; the call then
+        # returns ALL 4 n coefficients of the quotient (3 n + 6 of them non-zero), shape (4 n, 4)
+        if len(blinding) != 9:
+            raise ValueError("nine blinding scalars")
+        bw = np.stack([_fr_words(x) for x in blinding])
+        keep.append(bw)
+        args.blinding = bw.ctypes.data
+        args.flags = 1 | 0x100
     for k, x in (("coset_shift", coset_shift), ("k1", k1), ("k2", k2), ("alpha", alpha), ("beta", beta), ("gamma", gamma)):
         w = _fr_words(x)
         keep.append(w)
         setattr(args, k, w.ctypes.data)
     if out is None:
-        out = np.zeros((3, n, 4), dtype=np.uint64)
+        out = np.zeros((3, n, 4) if blinding is None else (4 * n, 4), dtype=np.uint64)
     ok = ctypes.c_int32()
     ctx.check(dll.nlx_bn254_plonk_quotient(ctx.handle, ctypes.byref(args), out.data_ptr() if hasattr(out, "data_ptr") else out.ctypes.data,
                                            ctypes.byref(ok)))

@@ -177,6 +177,22 @@ __global__ __launch_bounds__(64) void k_plonk_domain(const Consts* __restrict__ 
     }
 }
 
+// Blinding in coefficient form: p(X) += (b_0 + b_1 X + ...)(X^n - 1), i.e. coefficient i loses b_i and coefficient n + i gains it.
+// The coefficients lie in the 4n-array in bit-reversed order (what the coset FFT (DIT) reads): one lane per touched coefficient.
+// ev: [poly][4n] elements; job t = (poly, i, sign) for the nine blinding scalars b (D-form words, in order l l r r o o z z z).
+__global__ void k_plonk_blind(uint64_t* __restrict__ ev, const uint64_t* __restrict__ b, uint32_t log_n) {
+    const uint32_t t = threadIdx.x;
+    if (t >= 18) return;
+    const uint32_t j = t >> 1, add_side = t & 1;                   // scalar j, the - b_i (0) or the + b_i (1) side
+    const uint32_t poly = j < 6 ? 8 + (j >> 1) : 11, i = j < 6 ? (j & 1) : j - 6;
+    const size_t N4 = (size_t)4 << log_n;
+    const uint32_t idx = (add_side ? ((uint32_t)1 << log_n) : 0u) + i;
+    const uint32_t pos = __brev(idx) >> (32 - (log_n + 2));
+    uint64_t* col = ev + (size_t)poly * N4 * 4;
+    const Fe cur = ld(col, pos), bj = ld(b, j);
+    st(col, pos, add_side ? add(cur, bj) : sub(cur, bj));
+}
+
 __global__ __launch_bounds__(256) void k_plonk_quotient(QuotientParams p) {
     const size_t N4 = (size_t)4 << p.log_n;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -586,7 +602,14 @@ int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_ar
     for (int i = 0; i < 12; i++)
         if (!polys[i]) return ctx->fail(NLX_E_INVAL, "NULL polynomial");
     if (a->log_n < 2 || a->log_n > 26) return ctx->fail(NLX_E_RANGE, "log_n must be in [2, 26] (the coset has four times the points)");
-    if (a->flags != NLX_BN254_MONTGOMERY) return ctx->fail(NLX_E_UNSUPPORTED, "elements must be fr.Element words (flags = NLX_BN254_MONTGOMERY)");
+    const bool blinded = (a->flags & NLX_BN254_PLONK_BLINDED) != 0;
+    if ((a->flags & ~NLX_BN254_PLONK_BLINDED) != NLX_BN254_MONTGOMERY) return ctx->fail(NLX_E_UNSUPPORTED, "elements must be fr.Element words (flags = NLX_BN254_MONTGOMERY)");
+    if (blinded) {
+        if (!a->blinding || is_device_ptr(a->blinding)) return ctx->fail(NLX_E_INVAL, "the blinding scalars are host values (nine elements of four words)");
+        if (a->log_n < 3) return ctx->fail(NLX_E_RANGE, "a blinded quotient needs log_n >= 3 (3 n + 6 coefficients on 4 n points)");
+        for (int i = 0; i < 9; i++)
+            if (!fr_words_below_r(a->blinding + 4 * i)) return ctx->fail(NLX_E_RANGE, "a blinding scalar is not below r");
+    }
     {
         const uint64_t* sc[6] = {a->coset_shift, a->k1, a->k2, a->alpha, a->beta, a->gamma};
         for (const uint64_t* q : sc)
@@ -610,7 +633,7 @@ int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_ar
     uint64_t* d_x = dalloc(N4 * 32);
     uint64_t* d_linv = dalloc(N4 * 32);
     uint64_t* d_t = dalloc(N4 * 32);
-    uint64_t* d_small = dalloc(6 * 32 + sizeof(bnp::Consts) + 64);
+    uint64_t* d_small = dalloc(6 * 32 + sizeof(bnp::Consts) + 64 + 9 * 32);
     auto done = [&](int32_t code) {
         (void)hipStreamSynchronize(st);
         for (void* p : tmp) ctx->release(p);
@@ -619,11 +642,13 @@ int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_ar
     if (!d_in || !d_ev || !d_x || !d_linv || !d_t || !d_small) return done(NLX_E_NOMEM);
     bnp::Consts* d_k = (bnp::Consts*)(d_small + 6 * 4);
     uint32_t* d_flag = (uint32_t*)((char*)d_k + sizeof(bnp::Consts));
+    uint64_t* d_blind = (uint64_t*)((char*)d_flag + 64);
     {
         uint64_t h[6 * 4];
         const uint64_t* src[6] = {a->coset_shift, a->k1, a->k2, a->alpha, a->beta, a->gamma};
         for (int i = 0; i < 6; i++) memcpy(h + 4 * i, src[i], 32);
         hipError_t e = hipMemcpyAsync(d_small, h, sizeof h, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && blinded) e = hipMemcpyAsync(d_blind, a->blinding, 9 * 32, hipMemcpyHostToDevice, st);   // caller-owned: outlives the sync below
         if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 8, st);   // [0] high chunk non-zero, [1] Z_H vanishes on the coset
         if (e == hipSuccess) e = hipStreamSynchronize(st);   // h leaves scope
         if (e != hipSuccess) return done(ctx->hip_fail(e, "hipMemcpyAsync"));
@@ -645,6 +670,7 @@ int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_ar
             e = hipMemcpy2DAsync(d_ev + (size_t)i * N4 * 4, 128, d_in + (size_t)i * n * 4, 32, 32, n, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return done(ctx->hip_fail(e, "hipMemcpy2DAsync"));
     }
+    if (blinded) hipLaunchKernelGGL(bnp::k_plonk_blind, dim3(1), dim3(64), 0, st, d_ev, d_blind, log_n);
     rc = nlx_bn254_ntt_batch_coset(ctx, d_ev, P, log_n + 2, 0, NLX_BN254_MONTGOMERY | NLX_BN254_BITREV_IN, a->coset_shift);
     if (rc) return done(rc);
     // 3. the quotient's values on the coset
@@ -655,13 +681,15 @@ int32_t nlx_bn254_plonk_quotient(nlx_ctx* ctx, const nlx_bn254_plonk_quotient_ar
     // 4. back to coefficients
     rc = nlx_bn254_ntt_batch_coset(ctx, d_t, 1, log_n + 2, 1, NLX_BN254_MONTGOMERY, a->coset_shift);
     if (rc) return done(rc);
-    hipLaunchKernelGGL(bnp::k_any_nonzero, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, st, d_t + 3 * n * 4, n * 4, d_flag);
+    // coefficients that must vanish: 3 n .. 4 n - 1 (3 n + 6 .. with blinding: the blinded wires raise the quotient's degree by six)
+    const size_t t_keep = blinded ? 3 * n + 6 : 3 * n;
+    hipLaunchKernelGGL(bnp::k_any_nonzero, dim3((unsigned)(((N4 - t_keep) * 4 + 255) / 256)), dim3(256), 0, st, d_t + t_keep * 4, (N4 - t_keep) * 4, d_flag);
     uint32_t flags[2] = {0, 0};
     hipError_t e = hipMemcpyAsync(flags, d_flag, 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return done(ctx->hip_fail(e, "copy out"));
     if (flags[1]) return done(ctx->fail(NLX_E_INVAL, "coset shift lies in the evaluation subgroup (x^n - 1 vanishes on the coset)"));
-    e = hipMemcpyAsync(t_out, d_t, 3 * n * 32, is_device_ptr(t_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st);
+    e = hipMemcpyAsync(t_out, d_t, (blinded ? N4 : 3 * n) * 32, is_device_ptr(t_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return done(ctx->hip_fail(e, "copy out"));
     hipError_t le = hipGetLastError();

@@ -439,3 +439,281 @@ def groth16_quotient(a, b, c, shift=5):
         out.append(co[j] * s % R)
         s = s * sinv % R
     return out
+
+
+# ---- row f.4, fourth piece: the proof in gnark's SHAPE - its fiat-shamir, its blinding, its batched opening, its bytes ----
+# gnark (backend/plonk/bn254 Prove / Verify, gnark-crypto fiat-shamir and kzg; Go, not in /root/reference: succinct.json:7-8
+# names the entry points that run it) restated from its published structure, from memory [U]: parity with gnark-produced bytes
+# is UNPINNED (no Go toolchain, no vector); what is pinned is that model and device prover emit the same bytes and that the
+# verifier below (the pairing replaced by the test SRS's trapdoor) accepts them and rejects tampering.
+#   transcript  fiatshamir.NewTranscript(sha256, "gamma", "beta", "alpha", "zeta"): challenge_i = SHA-256(name_i ||
+#               challenge_{i-1} (its 32 raw bytes, i > 0) || the bytes bound to name_i), read big-endian mod r;
+#               gamma <- the verifying key's S1 S2 S3 Ql Qr Qm Qo Qk, the public inputs, then [L] [R] [O]; beta <- nothing;
+#               alpha <- [Z]; zeta <- [H1] [H2] [H3]   (points as x || y, 64 bytes; scalars 32 bytes big-endian)
+#   blinding    l, r, o += (b0 + b1 X)(X^n - 1), z += (b0 + b1 X + b2 X^2)(X^n - 1)        (getBlindedPolynomial, orders 1, 1, 1, 2)
+#   quotient    h of 3 n + 6 coefficients, committed as h1 h2 h3 of n + 2 coefficients each
+#   openings    at zeta, ONE batched opening (kzg.BatchOpenSinglePoint) of [foldedH, linearised, l, r, o, s1, s2] with
+#               foldedH = h1 + zeta^(n+2) h2 + zeta^(2(n+2)) h3 and the combiner gamma' = SHA-256("gamma" || zeta || the seven
+#               digests || the seven claimed values) mod r; at w zeta, z alone
+#   bytes       Proof.WriteTo: LRO[3], Z, H[3] as compressed points (32 bytes, flags in the top two bits), the (empty) list of
+#               Bsb22 commitments (u32 count), BatchedProof.H, its claimed values (u32 count, 32 bytes each), ZShiftedOpening.H
+#               and its claimed value
+Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+
+def fr_bytes(x):
+    return (int(x) % R).to_bytes(32, "big")
+
+
+def g1_marshal(p):
+    """G1Affine.Marshal(): x || y big-endian; the point at infinity is the flag byte 0x40 and zeros"""
+    if p is None:
+        return bytes([0x40]) + bytes(63)
+    return int(p[0]).to_bytes(32, "big") + int(p[1]).to_bytes(32, "big")
+
+
+def g1_compress(p):
+    """G1Affine.Bytes(): x big-endian with 0b10 (y the smaller of y, q - y) or 0b11 (the larger) in the top two bits; 0b01 = infinity"""
+    if p is None:
+        return bytes([0x40]) + bytes(31)
+    b = bytearray(int(p[0]).to_bytes(32, "big"))
+    b[0] |= 0xC0 if int(p[1]) > (Q - 1) // 2 else 0x80
+    return bytes(b)
+
+
+def g1_decompress(b):
+    flag, x = b[0] >> 6, int.from_bytes(bytes([b[0] & 0x3F]) + b[1:], "big")
+    if flag == 1:
+        return None
+    y = pow((x * x * x + 3) % Q, (Q + 1) // 4, Q)
+    assert y * y % Q == (x * x * x + 3) % Q, "not on the curve"
+    if (y > (Q - 1) // 2) != (flag == 3):
+        y = Q - y
+    return (x, y)
+
+
+class GnarkTranscript:
+    def __init__(self, *names):
+        self.names, self.bound, self.value = list(names), {k: [] for k in names}, {}
+
+    def bind(self, name, data):
+        assert name not in self.value
+        self.bound[name].append(bytes(data))
+
+    def challenge(self, name):
+        i = self.names.index(name)
+        h = _hashlib.sha256(name.encode())
+        if i:
+            h.update(self.value[self.names[i - 1]])
+        for b in self.bound[name]:
+            h.update(b)
+        self.value[name] = h.digest()
+        return int.from_bytes(self.value[name], "big") % R
+
+
+def blind_coeffs(coeffs, n, b):
+    """coeffs (n of them) + (b[0] + b[1] X + ...)(X^n - 1)"""
+    out = [int(c) for c in coeffs] + [0] * len(b)
+    for i, bi in enumerate(b):
+        out[i] = (out[i] - bi) % R
+        out[n + i] = (out[n + i] + bi) % R
+    return out
+
+
+def _coset_evals_of_coeffs(c, n4, shift):
+    s, out = 1, []
+    for j in range(n4):
+        out.append((int(c[j]) * s % R) if j < len(c) else 0)
+        s = s * shift % R
+    return ntt(out)
+
+
+def gnark_quotient(co, n, shift, k1, k2, alpha, beta, gamma):
+    """co: coefficient lists (l r o z blinded: n + 2 / n + 3 long) -> the 4 n coefficients of h on the coset shift <w_4n>"""
+    n4, log_n = 4 * n, n.bit_length() - 1
+    ev = {k: _coset_evals_of_coeffs(v, n4, shift) for k, v in co.items()}
+    w4 = root_of_unity(log_n + 2)
+    t, x = [], shift
+    for i in range(n4):
+        l, r, o, z, zn = ev["l"][i], ev["r"][i], ev["o"][i], ev["z"][i], ev["z"][(i + 4) % n4]
+        gate = (ev["ql"][i] * l + ev["qr"][i] * r + ev["qm"][i] * l * r + ev["qo"][i] * o + ev["qk"][i] + (ev["pi"][i] if "pi" in ev else 0)) % R
+        f = (l + beta * x + gamma) * (r + beta * k1 * x + gamma) % R * (o + beta * k2 * x + gamma) % R * z % R
+        g = (l + beta * ev["s1"][i] + gamma) * (r + beta * ev["s2"][i] + gamma) % R * (o + beta * ev["s3"][i] + gamma) % R * zn % R
+        zh = (pow(x, n, R) - 1) % R
+        l1 = zh * pow(n * (x - 1) % R, R - 2, R) % R
+        t.append((gate + alpha * (f - g) + alpha * alpha % R * l1 % R * (z - 1)) % R * pow(zh, R - 2, R) % R)
+        x = x * w4 % R
+    c = ntt(t, inverse=True)
+    sinv, s, out = pow(shift, R - 2, R), 1, []
+    for j in range(n4):
+        out.append(c[j] * s % R)
+        s = s * sinv % R
+    return out
+
+
+def _bind_vk(fs, vk, public_inputs):
+    for k in ("s1", "s2", "s3", "ql", "qr", "qm", "qo", "qk"):
+        fs.bind("gamma", g1_marshal(vk[k]))
+    for x in public_inputs:
+        fs.bind("gamma", fr_bytes(x))
+
+
+def _batch_gamma(zeta, digests, claimed):
+    fs = GnarkTranscript("gamma")
+    fs.bind("gamma", fr_bytes(zeta))
+    for d in digests:
+        fs.bind("gamma", g1_marshal(d))
+    for v in claimed:
+        fs.bind("gamma", fr_bytes(v))
+    return fs.challenge("gamma")
+
+
+def _lin_scalars(l, r, o, s1, s2, zw, n, zeta, alpha, beta, gamma, k1, k2):
+    """the linearised polynomial's coefficients on qm ql qr qo qk z s3"""
+    zh = (pow(zeta, n, R) - 1) % R
+    l1 = zh * pow(n * (zeta - 1) % R, R - 2, R) % R
+    a_ = (l + beta * zeta + gamma) * (r + beta * k1 * zeta + gamma) % R * (o + beta * k2 * zeta + gamma) % R
+    b_ = (l + beta * s1 + gamma) * (r + beta * s2 + gamma) % R
+    return {"qm": l * r % R, "ql": l, "qr": r, "qo": o, "qk": 1, "z": (alpha * a_ + alpha * alpha % R * l1) % R,
+            "s3": (-alpha * b_ % R * beta % R * zw) % R}, l1, b_
+
+
+def gnark_plonk_prove_model(p, srs, k1, k2, public_inputs=(), blinding=(0,) * 9):
+    """p: plonk_witness()-style values on H WITHOUT z; public_inputs: the values of the public-input polynomial on the first
+    points of H (added to the gate's constant); blinding: b for l (2), r (2), o (2), z (3).  Returns (proof dict, bytes)."""
+    n = len(p["l"])
+    log_n = n.bit_length() - 1
+    w, u = root_of_unity(log_n), k1
+    com = lambda c: msm_g1(c, srs[:len(c)])
+    co = {k: ntt(p[k], inverse=True) for k in ("ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3", "l", "r", "o")}
+    vk = {k: com(co[k]) for k in ("ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3")}
+    pi_vals = [int(x) % R for x in public_inputs] + [0] * (n - len(public_inputs))
+    if public_inputs:
+        co["pi"] = ntt(pi_vals, inverse=True)
+    fs = GnarkTranscript("gamma", "beta", "alpha", "zeta")
+    _bind_vk(fs, vk, public_inputs)
+    b = [int(x) % R for x in blinding]
+    bl = {"l": blind_coeffs(co["l"], n, b[0:2]), "r": blind_coeffs(co["r"], n, b[2:4]), "o": blind_coeffs(co["o"], n, b[4:6])}
+    proof = {"lro": [com(bl["l"]), com(bl["r"]), com(bl["o"])]}
+    for c in proof["lro"]:
+        fs.bind("gamma", g1_marshal(c))
+    gamma = fs.challenge("gamma")
+    beta = fs.challenge("beta")
+    z, acc = [], 1
+    for i in range(n):
+        z.append(acc)
+        x = pow(w, i, R)
+        num = (p["l"][i] + beta * x + gamma) * (p["r"][i] + beta * k1 * x + gamma) * (p["o"][i] + beta * k2 * x + gamma) % R
+        den = (p["l"][i] + beta * p["s1"][i] + gamma) * (p["r"][i] + beta * p["s2"][i] + gamma) * (p["o"][i] + beta * p["s3"][i] + gamma) % R
+        acc = acc * num % R * pow(den, R - 2, R) % R
+    assert acc == 1, "the wires do not respect the copy constraints"
+    bl["z"] = blind_coeffs(ntt(z, inverse=True), n, b[6:9])
+    proof["z"] = com(bl["z"])
+    fs.bind("alpha", g1_marshal(proof["z"]))
+    alpha = fs.challenge("alpha")
+    qco = dict(co)
+    qco.update(bl)
+    h = gnark_quotient(qco, n, u, k1, k2, alpha, beta, gamma)
+    assert not any(h[3 * n + 6:]), "the witness does not satisfy the circuit"
+    hs = [h[0:n + 2], h[n + 2:2 * n + 4], h[2 * n + 4:3 * n + 6]]
+    proof["h"] = [com(c) for c in hs]
+    for c in proof["h"]:
+        fs.bind("zeta", g1_marshal(c))
+    zeta = fs.challenge("zeta")
+    ev = {k: eval_poly(bl[k], zeta) for k in ("l", "r", "o")}
+    ev["s1"], ev["s2"] = eval_poly(co["s1"], zeta), eval_poly(co["s2"], zeta)
+    zw, zq = kzg_open(bl["z"], zeta * w % R)
+    proof["z_shifted"] = {"h": com(zq), "value": zw}
+    sc, _, _ = _lin_scalars(ev["l"], ev["r"], ev["o"], ev["s1"], ev["s2"], zw, n, zeta, alpha, beta, gamma, k1, k2)
+    src = {"qm": co["qm"], "ql": co["ql"], "qr": co["qr"], "qo": co["qo"], "qk": co["qk"], "z": bl["z"], "s3": co["s3"]}
+    m = n + 3
+    lin = [sum(sc[k] * (src[k][i] if i < len(src[k]) else 0) for k in sc) % R for i in range(m)]
+    zn2 = pow(zeta, n + 2, R)
+    folded_h = [(hs[0][i] + zn2 * hs[1][i] + zn2 * zn2 % R * hs[2][i]) % R for i in range(n + 2)]
+    polys = [folded_h, lin, bl["l"], bl["r"], bl["o"], co["s1"], co["s2"]]
+    folded_h_digest = g1_add(g1_add(proof["h"][0], g1_mul(zn2, proof["h"][1])), g1_mul(zn2 * zn2 % R, proof["h"][2]))
+    digests = [folded_h_digest, com(lin)] + proof["lro"] + [vk["s1"], vk["s2"]]
+    claimed = [eval_poly(c, zeta) for c in polys]
+    gp = _batch_gamma(zeta, digests, claimed)
+    folded, g = [0] * m, 1
+    for c in polys:
+        for i, v in enumerate(c):
+            folded[i] = (folded[i] + g * int(v)) % R
+        g = g * gp % R
+    _, q = kzg_open(folded, zeta)
+    proof["batched"] = {"h": com(q), "values": claimed}
+    return proof, gnark_proof_bytes(proof)
+
+
+def gnark_proof_bytes(proof):
+    out = b"".join(g1_compress(c) for c in proof["lro"]) + g1_compress(proof["z"]) + b"".join(g1_compress(c) for c in proof["h"])
+    out += (0).to_bytes(4, "big")                                     # Bsb22Commitments: none
+    out += g1_compress(proof["batched"]["h"]) + len(proof["batched"]["values"]).to_bytes(4, "big")
+    out += b"".join(fr_bytes(v) for v in proof["batched"]["values"])
+    return out + g1_compress(proof["z_shifted"]["h"]) + fr_bytes(proof["z_shifted"]["value"])
+
+
+def gnark_proof_from_bytes(data):
+    pts = [g1_decompress(data[32 * i:32 * i + 32]) for i in range(7)]
+    off = 224
+    assert int.from_bytes(data[off:off + 4], "big") == 0
+    off += 4
+    bh = g1_decompress(data[off:off + 32])
+    off += 32
+    k = int.from_bytes(data[off:off + 4], "big")
+    off += 4
+    vals = [int.from_bytes(data[off + 32 * i:off + 32 * i + 32], "big") for i in range(k)]
+    off += 32 * k
+    zh = g1_decompress(data[off:off + 32])
+    zv = int.from_bytes(data[off + 32:off + 64], "big")
+    assert off + 64 == len(data) and all(v < R for v in vals + [zv])
+    return {"lro": pts[0:3], "z": pts[3], "h": pts[4:7], "batched": {"h": bh, "values": vals}, "z_shifted": {"h": zh, "value": zv}}
+
+
+def gnark_plonk_verify_trapdoor(data, vk, n, tau, k1, k2, public_inputs=()):
+    """gnark's Verify on the proof BYTES with the pairing replaced by the test SRS's trapdoor tau.  vk: the eight commitments."""
+    proof = gnark_proof_from_bytes(data)
+    w = root_of_unity(n.bit_length() - 1)
+    fs = GnarkTranscript("gamma", "beta", "alpha", "zeta")
+    _bind_vk(fs, vk, public_inputs)
+    for c in proof["lro"]:
+        fs.bind("gamma", g1_marshal(c))
+    gamma, beta = fs.challenge("gamma"), fs.challenge("beta")
+    fs.bind("alpha", g1_marshal(proof["z"]))
+    alpha = fs.challenge("alpha")
+    for c in proof["h"]:
+        fs.bind("zeta", g1_marshal(c))
+    zeta = fs.challenge("zeta")
+    vals = proof["batched"]["values"]
+    if len(vals) != 7:
+        return False
+    folded_h_zeta, lin_zeta, l, r, o, s1, s2 = vals
+    zw = proof["z_shifted"]["value"]
+    sc, l1, b_ = _lin_scalars(l, r, o, s1, s2, zw, n, zeta, alpha, beta, gamma, k1, k2)
+    zh = (pow(zeta, n, R) - 1) % R
+    # PI(zeta) = sum_i PI_i L_i(zeta), L_i(zeta) = w^i Z_H(zeta) / (n (zeta - w^i))
+    pi = 0
+    for i, x in enumerate(public_inputs):
+        wi = pow(w, i, R)
+        pi = (pi + int(x) * wi % R * zh % R * pow(n * (zeta - wi) % R, R - 2, R)) % R
+    # the identity at zeta: linearised + PI - alpha (l + beta s1 + gamma)(r + beta s2 + gamma)(o + gamma) z(w zeta) - alpha^2 L1 = foldedH Z_H
+    if (lin_zeta + pi - alpha * b_ % R * (o + gamma) % R * zw - alpha * alpha % R * l1) % R != folded_h_zeta * zh % R:
+        return False
+    pts = {"qm": vk["qm"], "ql": vk["ql"], "qr": vk["qr"], "qo": vk["qo"], "qk": vk["qk"], "z": proof["z"], "s3": vk["s3"]}
+    keys = list(sc)
+    lin_digest = msm_g1([sc[k] for k in keys], [pts[k] for k in keys])
+    zn2 = pow(zeta, n + 2, R)
+    folded_h_digest = g1_add(g1_add(proof["h"][0], g1_mul(zn2, proof["h"][1])), g1_mul(zn2 * zn2 % R, proof["h"][2]))
+    digests = [folded_h_digest, lin_digest] + proof["lro"] + [vk["s1"], vk["s2"]]
+    gp = _batch_gamma(zeta, digests, vals)
+    acc, g = None, 1
+    for d, v in zip(digests, vals):
+        term = g1_add(d, g1_neg(g1_mul(v, G1)))
+        acc = g1_add(acc, g1_mul(g, term)) if g != 0 else acc
+        g = g * gp % R
+    rhs = g1_mul((tau - zeta) % R, proof["batched"]["h"]) if proof["batched"]["h"] is not None else None
+    if acc != rhs:
+        return False
+    lhs2 = g1_add(proof["z"], g1_neg(g1_mul(zw, G1)))
+    rhs2 = g1_mul((tau - zeta * w) % R, proof["z_shifted"]["h"]) if proof["z_shifted"]["h"] is not None else None
+    return lhs2 == rhs2

@@ -208,3 +208,42 @@ def test_a_coset_shift_inside_the_subgroup_and_scalars_above_r_are_refused(nlx, 
         nlx.bn254_plonk.groth16_quotient(ctx, pack(a), pack(b), pack(c), coset_shift=bn.root_of_unity(log_n))
     assert ei.value.code == -1 and "evaluation subgroup" in str(ei.value)
     nlx.bn254_plonk.groth16_quotient(ctx, pack(a), pack(b), pack(c))
+
+
+@pytest.mark.parametrize("log_n,n_pi", [(3, 0), (4, 2), (6, 3), (8, 1), (10, 5)])
+def test_gnark_shaped_proof_bytes_equal_model_and_verify(nlx, ctx, bn, log_n, n_pi):
+    """The proof in gnark's shape (its fiat-shamir with the named challenges gamma, beta, alpha, zeta over SHA-256, blinded
+    l r o z, the quotient cut into h1 h2 h3 of n + 2 coefficients, BatchOpenSinglePoint with the hashed combiner, Proof.WriteTo's
+    byte layout): the device prover's BYTES equal the big-integer model's for the same blinding scalars, and the model's verifier
+    (pairing replaced by the test SRS's trapdoor) accepts them, with and without public inputs.  Parity with gnark itself stays
+    unpinned (Go, no vector in the reference): both sides restate the published protocol."""
+    n, k1, k2 = 1 << log_n, 5, 25
+    p, tau = _instance(bn, log_n, 90 + log_n)
+    rng = random.Random(7 * log_n)
+    pis = [rng.randrange(bn.R) for _ in range(n_pi)]
+    p["qk"] = [(a - (pis[i] if i < n_pi else 0)) % bn.R for i, a in enumerate(p["qk"])]   # the statement's qk leaves the public inputs out
+    blind = [rng.randrange(bn.R) for _ in range(9)]
+    srs_pts = bn.kzg_srs(tau, n + 3)
+    _, want = bn.gnark_plonk_prove_model(p, srs_pts, k1, k2, pis, blind)
+    P = nlx.bn254_plonk
+    pk = P.ProvingKey(ctx, p, nlx.bn254_g1_pack(srs_pts), k1, k2)
+    got = P.prove_gnark(pk, p["l"], p["r"], p["o"], pis, blind)
+    assert len(got) == len(want) == 7 * 32 + 4 + 32 + 4 + 7 * 32 + 32 + 32
+    assert got == want
+    vk = {k: nlx.bn254_g1_unpack(pk.commitments[k]) for k in pk.NAMES}
+    assert bn.gnark_plonk_verify_trapdoor(got, vk, n, tau, k1, k2, pis)
+    if n_pi:
+        assert not bn.gnark_plonk_verify_trapdoor(got, vk, n, tau, k1, k2, [(pis[0] + 1) % bn.R] + pis[1:])
+    bad = bytearray(got)
+    bad[-1] ^= 1                                                # z(w zeta)
+    assert not bn.gnark_plonk_verify_trapdoor(bytes(bad), vk, n, tau, k1, k2, pis)
+    # random blinding: other bytes, same verdict; a broken witness is refused
+    other = P.prove_gnark(pk, p["l"], p["r"], p["o"], pis)
+    assert other != got and bn.gnark_plonk_verify_trapdoor(other, vk, n, tau, k1, k2, pis)
+    if log_n == 4:
+        bad_o = list(p["o"])
+        bad_o[1] = (bad_o[1] + 1) % bn.R
+        with pytest.raises(ValueError):
+            P.prove_gnark(pk, p["l"], p["r"], bad_o, pis, blind)
+        with pytest.raises(ValueError):
+            P.prove(pk, p["l"], p["r"], p["o"], pis)               # the paper-shaped prover constrains no public inputs
