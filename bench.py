@@ -739,7 +739,7 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
     ctxs = st["ctxs"]
     outer_buf = cd._buf   # nlx_prove writes the proof here (prove_into returns its length)
     stark_jobs = [lambda: p256.prove(st["sha_msgs"]), lambda: p512.prove(st["sig_msgs"]), lambda: ped.prove(st["slot_words"])]
-    pool = ThreadPoolExecutor(max_workers=4)
+    pool = ThreadPoolExecutor(max_workers=6)   # three STARK threads, the running outer proof, one queued behind it
 
     def outer_job():
         return cd.prove_into(wires, pis.ctypes.data)
@@ -752,19 +752,26 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
 
     def run_steps(k, pipelined, acc):
         """k Sync proofs; returns the last step's (sha256, sha512, ed25519) results and outer proof length"""
-        res, prev_outer, outer_len = None, None, 0
+        res, outer_len, pending = None, 0, []
+
+        def outer_after(prev, acc_):
+            if prev is not None:
+                prev.result()
+            return timed(outer_job, 3, acc_)
         for _ in range(k):
             if pipelined:
                 futs = [pool.submit(timed, j, i, acc) for i, j in enumerate(stark_jobs)]
-                res = [f.result() for f in futs]            # this step's STARKs (the previous step's outer proof runs meanwhile)
-                if prev_outer is not None:
-                    outer_len = prev_outer.result()
-                prev_outer = pool.submit(timed, outer_job, 3, acc)
+                res = [f.result() for f in futs]            # this request's STARKs (earlier requests' outer proofs run meanwhile)
+                # its outer proof: queued behind the previous request's (one context proves one at a time), NOT waited for
+                # here - the next request's STARKs start at once; at most two outer proofs are ever outstanding
+                if len(pending) >= 2:
+                    outer_len = pending.pop(0).result()
+                pending.append(pool.submit(outer_after, pending[-1] if pending else None, acc))
             else:
                 res = [timed(j, i, acc) for i, j in enumerate(stark_jobs)]
                 outer_len = timed(outer_job, 3, acc)
-        if prev_outer is not None:
-            outer_len = prev_outer.result()
+        for f in pending:
+            outer_len = f.result()
         return res, outer_len
     scratch = [0.0] * 4
     if args.warmup:
@@ -845,8 +852,8 @@ def run_sync(args, nlx, torch, rank, world, local, dist):
             "config": {"workload": "one full Sync proof = SHA-256 STARK of %d header / next_bps messages (2^%d blocks, 2^%d x %d trace) + "
                                    "SHA-512 STARK of %d approval hashes (2^%d blocks) + Ed25519 STARK of %d validator slots, %d of them active = "
                                    "signed approvals, D mod L reduced in the AIR (2^%d slots, 2^%d rows) + outer plonky2 proof (standard_recursion_config, 2^%d rows, 135 wires, %d gate "
-                                   "kinds); the outer proof of a step starts when its three STARKs are done, the next step's "
-                                   "STARKs overlap it; replicas only"
+                                   "kinds); the outer proof of a request starts when its three STARKs are done (and the previous request's outer proof, "
+                                   "which shares its context); the next requests' STARKs overlap it, at most two outer proofs outstanding; replicas only"
                                    % (len(st["sha_msgs"]), st["lb256"], st["lb256"] + 2, p256.stark.desc.n_cols, st["n_sigs"], st["lb512"],
                                       st["n_validators"], st["n_sigs"], st["log_slots"], ped.stark.desc.degree_bits, args.log_n, st["syn"].num_gates),
                        "log_n_outer": args.log_n, "gate_mix_pct": GATE_MIXES[args.gate_mix],

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The HOST side of libnlx.so / libnlx_synth.so under AddressSanitizer + UndefinedBehaviorSanitizer (the device side cannot be:
 # no GPU sanitizers on the pool), then the CPU test suite through that build.  Run on the CPU box:
-#   bash tools/asan_host.sh            -> profiles/r03_asan_host.txt
+#   bash tools/asan_host.sh            -> profiles/r04_asan_host.txt
 # Left out: the two tests that force a failed host allocation (ASan's operator new aborts instead of throwing bad_alloc) and the
 # two that build their own host binaries with gcc -fsanitize (gcc's libasan cannot share a process tree with the preloaded clang runtime).
 set -e
@@ -23,5 +23,5 @@ rc=$?
   tail -3 /tmp/asan_suite.log
   echo "sanitizer reports: $(ls /tmp/nlx_asan_report* 2>/dev/null | wc -l)"
   for f in /tmp/nlx_asan_report*; do [ -f "$f" ] && head -20 "$f"; done
-} > profiles/r03_asan_host.txt
-cat profiles/r03_asan_host.txt
+} > profiles/r04_asan_host.txt
+cat profiles/r04_asan_host.txt
