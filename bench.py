@@ -466,7 +466,7 @@ def run_sha256(args, nlx, torch, rank, world, local, dist):
     pis_of = SA.digest_halves if wide else (lambda d: d)
     make_prover = SA.Sha512Prover if wide else SA.Sha256Prover
     ctx = nlx.Context(local)
-    sp = make_prover(ctx, args.log_blocks, segment_nodes=args.segment_nodes)
+    sp = make_prover(ctx, args.log_blocks, nlx.StarkConfig(batch_cols=args.stark_batch_cols), segment_nodes=args.segment_nodes)
 
     def prove_current(pis):
         """prove the trace generate_trace() left on the device (two rounds: the second is the binding accumulator)"""

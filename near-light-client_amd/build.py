@@ -50,9 +50,16 @@ def _generate_air_kernels():
         raise RuntimeError("airgen.py failed:\n%s\n%s" % (r.stdout, r.stderr))
 
 
+# The generated AIR kernels (~5 minutes of a clean build) go into the library of record only: the other candidate generator pair's
+# build (libnlx_gen2021.so, there for the parity suites) and NLX_NO_AIRGEN=1 builds run every program on the interpreter.
+WITH_AIRGEN = GEN_SET == "7" and os.environ.get("NLX_NO_AIRGEN", "") != "1"
+if not WITH_AIRGEN:
+    FLAGS.append("-DNLX_NO_AIRGEN")
+
+
 def _sources():
     top = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
-    gen = sorted(os.path.join("airgen", f) for f in os.listdir(AIRGEN) if f.endswith(".hip")) if os.path.isdir(AIRGEN) else []
+    gen = sorted(os.path.join("airgen", f) for f in os.listdir(AIRGEN) if f.endswith(".hip")) if WITH_AIRGEN and os.path.isdir(AIRGEN) else []
     return top + gen
 
 
@@ -80,7 +87,8 @@ def _compile(src, verbose):
 
 def build_lib(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    _generate_air_kernels()
+    if WITH_AIRGEN:
+        _generate_air_kernels()
     hm = _headers_mtime()
     todo, objs, synth_objs = [], [], []
     for src in _sources():

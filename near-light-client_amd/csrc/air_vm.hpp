@@ -58,6 +58,10 @@ inline uint64_t airgen_program_hash(const uint64_t* words, size_t n) {   // FNV-
         }
     return h;
 }
+#if defined(NLX_NO_AIRGEN)
+inline const AirGenEntry* airgen_find(uint64_t, uint32_t) { return nullptr; }   // a build without the generated kernels: the interpreter runs everything
+#else
 const AirGenEntry* airgen_find(uint64_t program_hash, uint32_t n_words);   // csrc/airgen/registry.hip
+#endif
 
 }  // namespace nlx
