@@ -63,13 +63,18 @@ def _sources():
     return top + gen
 
 
-def _headers_mtime():
+def _headers_mtime(only=None):
+    """newest header; `only`: the names a source is known to include (the generated AIR kernels include air_vm.hpp -> gl.hpp and
+    the public headers, nothing else - a change to any other header must not cost their five minutes of compilation)"""
     m = 0.0
     for root in (CSRC, os.path.join(HERE, "..", "include")):
         for f in os.listdir(root):
-            if f.endswith((".hpp", ".h", ".inc")):
+            if f.endswith((".hpp", ".h", ".inc")) and (only is None or f in only):
                 m = max(m, os.path.getmtime(os.path.join(root, f)))
     return m
+
+
+AIRGEN_HEADERS = ("air_vm.hpp", "gl.hpp", "nlx.h", "nlx_field.h")
 
 
 def _compile(src, verbose):
@@ -89,12 +94,12 @@ def build_lib(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     if WITH_AIRGEN:
         _generate_air_kernels()
-    hm = _headers_mtime()
+    hm, hm_gen = _headers_mtime(), _headers_mtime(AIRGEN_HEADERS)
     todo, objs, synth_objs = [], [], []
     for src in _sources():
         obj = os.path.join(OBJ, src.replace(os.sep, "_") + ".o")
         (synth_objs if src in SYNTH_SOURCES else objs).append(obj)
-        sm = max(os.path.getmtime(os.path.join(CSRC, src)), hm)
+        sm = max(os.path.getmtime(os.path.join(CSRC, src)), hm_gen if src.startswith("airgen" + os.sep) else hm)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < sm:
             todo.append(src)
     if todo:
