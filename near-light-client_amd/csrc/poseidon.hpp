@@ -12,9 +12,6 @@
 #include "gl32.hpp"
 #endif
 #include "poseidon_constants.inc"
-#if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)
-#include <immintrin.h>
-#endif
 
 namespace poseidon {
 
@@ -102,34 +99,10 @@ GL_HD uint64_t mds_fold(uint64_t al, uint64_t ah) {
     if (res < t1) res += gl::EPS;
     return res;
 }
-#if !defined(__HIP_DEVICE_COMPILE__) && defined(__AVX2__)
-// The HOST's linear layer (the Fiat-Shamir transcript: a STARK of a 4 745-column trace observes 19 000 opened values = 2 400
-// permutations on one host thread): the circulant as 4-lane multiply-adds - output rows r .. r + 3 need s[(i + r) mod 12] for
-// i = 0 .. 11, four CONSECUTIVE entries of the doubled array, so 72 vpmuludq + 72 vpaddq replace 288 scalar multiply-adds.
-inline void mds_layer(uint64_t (&s)[12]) {
-    constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    alignas(32) uint64_t lo[24], hi[24], al[12], ah[12];
-    for (int i = 0; i < 12; i++) {
-        lo[i] = lo[i + 12] = (uint32_t)s[i];
-        hi[i] = hi[i + 12] = s[i] >> 32;
-    }
-    __m256i a0 = _mm256_setzero_si256(), a1 = a0, a2 = a0, b0 = a0, b1 = a0, b2 = a0;
-    for (int i = 0; i < 12; i++) {
-        const __m256i c = _mm256_set1_epi64x(C[i]);
-        a0 = _mm256_add_epi64(a0, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(lo + i)), c));
-        a1 = _mm256_add_epi64(a1, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(lo + i + 4)), c));
-        a2 = _mm256_add_epi64(a2, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(lo + i + 8)), c));
-        b0 = _mm256_add_epi64(b0, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(hi + i)), c));
-        b1 = _mm256_add_epi64(b1, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(hi + i + 4)), c));
-        b2 = _mm256_add_epi64(b2, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i*)(hi + i + 8)), c));
-    }
-    _mm256_store_si256((__m256i*)al, a0); _mm256_store_si256((__m256i*)(al + 4), a1); _mm256_store_si256((__m256i*)(al + 8), a2);
-    _mm256_store_si256((__m256i*)ah, b0); _mm256_store_si256((__m256i*)(ah + 4), b1); _mm256_store_si256((__m256i*)(ah + 8), b2);
-    al[0] += lo[0] * 8u;     // the diagonal: 8 s[0] on output 0
-    ah[0] += hi[0] * 8u;
-    for (int r = 0; r < 12; r++) s[r] = mds_fold(al[r], ah[r]);
-}
-#else
+// (Round 4 tried the HOST's layer as AVX2 4-lane multiply-adds over a doubled array of the halves - 72 vpmuludq instead of 288
+// scalar multiply-adds: the transcript got SLOWER on the GPU box's EPYC, 2.99 -> 3.59 ms for the 19 000 openings of the SHA-512
+// proof; the 32-byte loads straddle the 8-byte stores that built the array, which defeats store forwarding.  Dropped; the scalar
+// loop below is what hipcc's host pass vectorises itself.  tests/test_host_challenger.py pins the host transcript either way.)
 GL_HD void mds_layer(uint64_t (&s)[12]) {
     constexpr uint32_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     uint32_t lo[12], hi[12];
@@ -153,7 +126,6 @@ GL_HD void mds_layer(uint64_t (&s)[12]) {
         s[r] = mds_fold(al, ah);
     }
 }
-#endif
 
 // In-place permutation; input loose, output loose.
 GL_HD void permute_loose(uint64_t (&s)[12]) {
