@@ -33,7 +33,17 @@ fr = lambda rows: np.concatenate([rs.randint(0, 1 << 60, size=(rows, 3), dtype=n
                                  axis=1).astype(np.uint64)                                           # fr.Element words below r
 plonk_polys = {k: fr(1 << 10) for k in ("ql", "qr", "qm", "qo", "qk", "s1", "s2", "s3", "l", "r", "o", "z")}
 kzg_poly, kzg_srs = fr(3000), nlx.bn254_g1_multiples(ctx, (1, 2), 2999)
+# round 4: commitment rounds in batches, a STARK whose constraints run on a generated kernel (SHA-256 at 2^7 blocks = 2^9 rows), the blinded
+# quotient chain, the natural-order transform without a reordering pass
+p256b = nlx.sha256_air.Sha256Prover(ctx, 7, nlx.StarkConfig(batch_cols=512))
+assert nlx.lib.dll.nlx_stark_quotient_kernel(p256b.prover.handle) == 1
+p512b = nlx.sha512_air.Sha512Prover(ctx, 5, nlx.StarkConfig(batch_cols=512))
+gl_cols = rs.randint(0, 1 << 62, size=(2, 1 << 20), dtype=np.int64).astype(np.uint64)
+blind = [int(x) for x in rs.randint(1, 1 << 60, size=9)]
 jobs = {"plonky2_2p13": lambda: cd.prove(syn.wires, syn.public_inputs), "sha256_2p6": lambda: p256.prove(msgs)[0],
+        "sha256_2p7_batches_generated_kernel": lambda: p256b.prove(msgs * 3)[0], "sha512_2p5_batches": lambda: p512b.prove(msgs)[0],
+        "bn254_plonk_quotient_2p10_blinded": lambda: nlx.bn254_plonk_quotient(ctx, plonk_polys, 5, 5, 25, 1234, 5678, 91011, blinding=blind)[0].tobytes(),
+        "ntt_2p20_natural_order": lambda: nlx.ntt(ctx, gl_cols).tobytes(),
         "plonky2_2p11_lookup_tables": lambda: cd_lk.prove(syn_lk.wires, syn_lk.public_inputs),
         "bn254_plonk_quotient_2p10": lambda: nlx.bn254_plonk_quotient(ctx, plonk_polys, 5, 5, 25, 1234, 5678, 91011)[0].tobytes(),
         "bn254_kzg_open_3000": lambda: b"".join(x.tobytes() for x in nlx.bn254_kzg_open(ctx, kzg_poly, 777, srs=kzg_srs)),
