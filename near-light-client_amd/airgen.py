@@ -67,20 +67,32 @@ def _emit_constraint(lines, expr):
     lines.append("    acc0 = gl::add(gl::mul(acc0, g.a0), c); acc1 = gl::add(gl::mul(acc1, g.a1), c);")
 
 
+SCHED_EVERY = 4
+
+
 def _segment_body(words, lo, hi):
-    """C++ statements for words[lo:hi]; every statement mirrors the interpreter's case for its opcode (csrc/stark.hip)"""
-    L, i = [], lo
+    """C++ statements for words[lo:hi]; every statement mirrors the interpreter's case for its opcode (csrc/stark.hip).
+    hipcc schedules a long straight-line block for instruction-level parallelism and keeps everything it hoisted alive: the
+    multiplier segments of the Ed25519 AIR (43 live values in the assembler's plan = 86 registers) came out at 214 - 241
+    registers, two waves per SIMD.  A barrier after every SCHED_EVERY register-writing words keeps the order the assembler
+    planned (its plan bounds the live values); the wave-level parallelism comes from the other waves."""
+    L, i, since = [], lo, 0
     R = lambda k: "r%d" % k
     while i < hi:
+        if since >= SCHED_EVERY:
+            L.append("    __builtin_amdgcn_sched_barrier(0);")
+            since = 0
+        if (int(words[i]) & 0xFF) in (LOCAL, NEXT, PUBLIC, CONST, ADD, SUB, MUL, PERIODIC, PACK_LOCAL, PACK_NEXT, XOR3, CH, MAJ, MAC):
+            since += 1
         w = int(words[i])
         op, dst, a, b, sh = w & 0xFF, (w >> 8) & 0xFFFF, (w >> 24) & 0xFFFF, (w >> 40) & 0xFFFF, (w >> 56) & 0x3F
         i += 1
         if op == LOCAL:
-            L.append("    %s = g.cols[%d][g.row];" % (R(dst), a))
+            L.append("    %s = COL(%d, g.row);" % (R(dst), a))
         elif op == NEXT:
-            L.append("    %s = g.cols[%d][g.row_next];" % (R(dst), a))
+            L.append("    %s = COL(%d, g.row_next);" % (R(dst), a))
         elif op == PUBLIC:
-            L.append("    %s = g.pis[%d];" % (R(dst), a))
+            L.append("    %s = PIS(%d);" % (R(dst), a))
         elif op == PERIODIC:
             L.append("    %s = g.per[(size_t)%d * g.per_stride + g.per_off];" % (R(dst), a))
         elif op == CONST:
@@ -106,7 +118,7 @@ def _segment_body(words, lo, hi):
             row = "g.row" if op == PACK_LOCAL else "g.row_next"
             L.append("    { uint64_t v[%d];" % b)
             for k in range(b):
-                L.append("      v[%d] = g.cols[%d][%s];" % (k, a + k, row))
+                L.append("      v[%d] = COL(%d, %s);" % (k, a + k, row))
             L.append("      uint64_t acc = 0;")
             for k in range(b):   # gl::add(0, v) = v for a canonical v: the interpreter's first step
                 L.append("      acc = gl::add(acc, mul_pow2(v[%d], %d));" % (k, k))
@@ -117,20 +129,20 @@ def _segment_body(words, lo, hi):
                 m = min(8, cnt - i0)
                 L.append("    { uint64_t v[%d];" % m)
                 for k in range(m):
-                    L.append("      v[%d] = g.cols[%d][g.row];" % (k, a + i0 + k))
+                    L.append("      v[%d] = COL(%d, g.row);" % (k, a + i0 + k))
                 for k in range(m):
                     L.append("      c = gl::mul(v[%d], gl::sub(v[%d], 1)); acc0 = gl::add(gl::mul(acc0, g.a0), c); acc1 = gl::add(gl::mul(acc1, g.a1), c);" % (k, k))
                 L.append("    }")
         elif op == EMIT_LOGUP:
-            L.append("    { const uint64_t al0 = g.pis[g.n_pis + %d], al1 = g.pis[g.n_pis + %d];" % (sh, sh + 1))
-            L.append("      const uint64_t h0 = g.cols[%d][g.row], h1 = g.cols[%d][g.row], v1 = g.cols[%d][g.row];" % (b, b + 1, a))
+            L.append("    { const uint64_t al0 = PIS(g.n_pis + %d), al1 = PIS(g.n_pis + %d);" % (sh, sh + 1))
+            L.append("      const uint64_t h0 = COL(%d, g.row), h1 = COL(%d, g.row), v1 = COL(%d, g.row);" % (b, b + 1, a))
             L.append("      uint64_t c0, c1;")
             if dst == 0xFFFF:
                 L.append("      const uint64_t d0 = gl::add(al0, v1);")
                 L.append("      c0 = gl::sub(gl::add(gl::mul(h0, d0), mul_pow2(gl::mul(h1, al1), 3)), gl::add(gl::mul(h1, al1), 1));")
                 L.append("      c1 = gl::add(gl::mul(h0, al1), gl::mul(h1, d0));")
             else:
-                L.append("      const uint64_t v2 = g.cols[%d][g.row];" % dst)
+                L.append("      const uint64_t v2 = COL(%d, g.row);" % dst)
                 L.append("      const uint64_t s2 = gl::add(gl::add(al0, al0), gl::add(v1, v2));")
                 L.append("      const uint64_t a1sq = gl::mul(al1, al1);")
                 L.append("      const uint64_t u0 = gl::add(gl::mul(gl::add(al0, v1), gl::add(al0, v2)), gl::sub(mul_pow2(a1sq, 3), a1sq));")
@@ -197,8 +209,17 @@ def generate_sources(name, words):
                '#include "../air_vm.hpp"', "", "namespace nlx {", "namespace %s {" % ns, "",
                "// what a segment needs of the point: passed BY VALUE (registers); the wave-uniform members are made scalar again inside",
                "// the function (readfirstlane), so a column's base address is a scalar load and its element ONE vector load",
-               "struct G {", "    const uint64_t* const* cols; const uint64_t* pis; const uint64_t* per;",
-               "    size_t row, row_next, per_stride, per_off; uint64_t a0, a1, z_last, l_first, l_last; uint32_t n_pis;", "};",
+               "// The column-pointer table and the public inputs are the same for every lane and constant for the launch: read through the",
+               "// constant address space they are scalar loads (s_load), and a column's value is then ONE global load with the pointer in",
+               "// SGPRs and the row's byte offset in a VGPR.  Through plain pointers hipcc made each a per-lane flat load with a wait",
+               "// between the pointer and the value (two memory latencies per column, two more VGPRs per load in flight).",
+               "// row / row_next are BYTE offsets (LDE rows * 8 < 2^32: the host selects these kernels for LDEs of <= 2^28 rows only).",
+               "typedef const uint64_t __attribute__((address_space(4)))* airgen_kptr;",
+               "typedef const char __attribute__((address_space(1)))* airgen_gptr;",
+               "#define COL(c, off) (*(const uint64_t __attribute__((address_space(1)))*)((airgen_gptr)((airgen_kptr)g.cols)[c] + (off)))",
+               "#define PIS(i) (((airgen_kptr)g.pis)[i])",
+               "struct G {", "    uint64_t cols, pis; const uint64_t* per;",
+               "    size_t per_stride, per_off; uint64_t a0, a1, z_last, l_first, l_last; uint32_t row, row_next, n_pis;", "};",
                "struct Acc { uint64_t a0, a1; };",
                "template <typename T> __device__ __forceinline__ T* uni(T* p) {",
                "    const uint64_t v = (uint64_t)p;",
@@ -236,8 +257,8 @@ def generate_sources(name, words):
             "    const uint64_t x = gl::mul(p.coset_base[rq], root_pow_(p.w_n_table, k, (uint32_t)(n >> 1)));",
             "    const uint64_t zh = gl::inv(p.zh_inv[rq]);",
             "    G g;",
-            "    g.cols = p.cols; g.pis = p.pis; g.per = p.periodic; g.n_pis = p.n_pis;",
-            "    g.row = ((size_t)r << p.log_n) + k; g.row_next = ((size_t)r << p.log_n) + ((k + 1) & (n - 1));",
+            "    g.cols = (uint64_t)p.cols; g.pis = (uint64_t)p.pis; g.per = p.periodic; g.n_pis = p.n_pis;",
+            "    g.row = (uint32_t)((((size_t)r << p.log_n) + k) << 3); g.row_next = (uint32_t)((((size_t)r << p.log_n) + ((k + 1) & (n - 1))) << 3);",
             "    g.per_stride = (size_t)1 << (p.qdb + p.period_bits);",
             "    g.per_off = ((size_t)rq << p.period_bits) + (k & ((1u << p.period_bits) - 1));",
             "    g.a0 = p.alphas[0]; g.a1 = p.alphas[1];",

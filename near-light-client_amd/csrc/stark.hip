@@ -534,11 +534,12 @@ int32_t nlx_stark_build(nlx_ctx* ctx, const nlx_stark_desc* desc, nlx_stark** ou
         }
     }
     air_digest_host(s->d, s->program, s->periodic, s->air_digest);
-    // a kernel generated from these very words (same hash, same length)?  Two challenges and whole blocks of AIRGEN_BLOCK points
-    // only; NLX_AIR_VM=1 keeps the interpreter (the parity reference of the generated code, tests/test_gpu_airgen.py)
+    // a kernel generated from these very words (same hash, same length)?  Two challenges, whole blocks of AIRGEN_BLOCK points and
+    // an LDE of at most 2^28 rows only (the generated code addresses a column by a 32-bit byte offset); NLX_AIR_VM=1 keeps the interpreter (the parity reference of the generated code, tests/test_gpu_airgen.py)
     {
         const char* force_vm = getenv("NLX_AIR_VM");
-        if (!(force_vm && force_vm[0] == '1') && s->d.num_challenges == 2 && ((size_t)1 << s->d.degree_bits) >= AIRGEN_BLOCK)
+        if (!(force_vm && force_vm[0] == '1') && s->d.num_challenges == 2 && ((size_t)1 << s->d.degree_bits) >= AIRGEN_BLOCK &&
+            s->d.degree_bits + s->d.rate_bits <= 28)
             s->gen = airgen_find(airgen_program_hash(s->program.data(), s->program.size()), (uint32_t)s->program.size());
     }
     for (int i = 0; i <= NLX_MAX_STAGES; i++)
