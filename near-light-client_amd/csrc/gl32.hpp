@@ -10,6 +10,7 @@
 // round 1, ~29 from hipcc's u64 code); the fold of an MDS accumulator pair: 4 (9 in round 1).
 #pragma once
 #include "gl.hpp"
+#include "poseidon_blocks.inc"   // generated tables of the fused partial rounds (tools/gen_poseidon_blocks.py)
 
 namespace gl32 {
 
@@ -305,6 +306,151 @@ __device__ __forceinline__ void mds_layer_mfma(F (&s)[12], const i32x4_t a, cons
             const uint64_t t = mad_u64(y[0][r], k16, ((uint64_t)x[1][r] << 32) | x[0][r]);
             s[r] = fold_pair(t, y[1][r], k16);
         }
+    }
+}
+
+// ---- Fused partial rounds (round 4; tables and derivation: tools/gen_poseidon_blocks.py -> poseidon_blocks.inc) ----------------
+// Three partial rounds are ONE pass of the state through the byte planes: the split (24 xor + 48 v_perm) and the recombination
+// happen once per block instead of once per round.  The block's matrix [M Q^2 | M Q e0 | M e0] has 22-bit entries: three balanced
+// base-256 digit matrices A_0 .. A_2, and digit p times byte plane b accumulates into output plane b + p INSIDE the matrix cores
+// (the C operand chains the instructions of one output plane), ten output planes.  The two S-box inputs inside the block are
+// twelve-term dot products with the small rows m0 and m0 Q on the vector pipe (24 multiply-adds each; as rows 12 / 13 of a first
+// matrix pass they cost sixteen more matrix instructions and nine waits for a chain's result: measured slower, 2.50 against
+// 2.6 G/s).  Every chain starts from the seed vector, which keeps
+// the plane sums non-negative whatever the (signed) digits and the biased bytes are; what the seeds add in total is a constant
+// per row that the generated constants absorb.  Plane sums stay below NLX_POSEIDON_BLOCK_DMAX (< 2^20), so x = d + 2^8 d' fits
+// 32 bits and the folds below cannot carry where they assume so (checked by the generator, `bounds`).
+struct BlockOperands {
+    i32x4_t a[3];    // this lane's A fragments of the three digit matrices
+    i32x16_t seed;   // chain seeds, one per output row
+};
+
+template <int G>
+__device__ __forceinline__ uint64_t mad_u64_imm(uint32_t a, uint64_t c) {   // a * G + c, G an inline constant
+    uint64_t r, sink;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sink) : "v"(a), "n"(G), "v"(c));
+    return r;
+}
+// t + 2^48 yh + 2^64 x2 (mod p) -> loose: fold_pair with the planes above 2^64 (x2 < 2^29) added to the word that EPS multiplies
+__device__ __forceinline__ F fold_pair_x(uint64_t t, uint32_t yh, uint32_t x2, uint32_t k16) {
+    uint64_t z, u, sink, sink2;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(z), "=s"(sink) : "v"(yh), "v"(k16));
+    const uint32_t e = (uint32_t)(z >> 32) + x2;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(u), "=s"(sink2) : "v"(e), "v"(t));
+    uint32_t r1, m;
+    asm("v_add_co_u32 %0, vcc, %2, %3\n\t"
+        "v_cndmask_b32_e64 %1, 0, -1, vcc"
+        : "=v"(r1), "=v"(m)
+        : "v"((uint32_t)(u >> 32)), "v"((uint32_t)z)
+        : "vcc");
+    return from_u64(mad_u64_one(m, ((uint64_t)r1 << 32) | (uint32_t)u));
+}
+__device__ __forceinline__ uint64_t mad_u64_sm(uint32_t a, uint32_t m_uniform, uint64_t c) {   // a * m + c, m from a scalar register
+    uint64_t r, sink;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sink) : "v"(a), "s"(m_uniform), "v"(c));
+    return r;
+}
+// sum_j rho[j] z_j + (klo + 2^32 khi) as the two accumulators fold_acc takes (value = al + 2^32 ah; rho[j] < 2^15: no overflow)
+template <typename RHO>
+__device__ __forceinline__ void dot12(const F (&z)[12], const RHO& rho, uint64_t klo, uint64_t khi, uint64_t& al, uint64_t& ah) {
+    al = klo;
+    ah = khi;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        al = mad_u64_sm(z[j].lo, rho.v[j], al);
+        ah = mad_u64_sm(z[j].hi, rho.v[j], ah);
+    }
+}
+struct BlockRho1 { static constexpr uint32_t v[12] = NLX_POSEIDON_BLOCK_RHO1_INIT; };
+struct BlockRho2 { static constexpr uint32_t v[12] = NLX_POSEIDON_BLOCK_RHO2_INIT; };
+
+// kap: this block's six wave-uniform words (low, high) x (output 0's constant, S-box input 1's, S-box input 2's); GAMMA21 = M[0][0]
+template <int GAMMA21>
+__device__ __forceinline__ void partial_block3(F (&s)[12], const BlockOperands& op, const uint64_t* __restrict__ kap) {
+    uint32_t k16 = 65536u;
+    asm("" : "+v"(k16));
+    s[0] = sbox7(s[0]);
+    // the S-box inputs of the block's second and third round, and their outputs
+    uint64_t al, ah;
+    dot12(s, BlockRho1{}, kap[2], kap[3], al, ah);
+    const F u1 = sbox7(fold_acc(al, ah));
+    dot12(s, BlockRho2{}, kap[4], kap[5], al, ah);
+    al = mad_u64_imm<GAMMA21>(u1.lo, al);
+    ah = mad_u64_imm<GAMMA21>(u1.hi, ah);
+    const F u2 = sbox7(fold_acc(al, ah));
+    uint32_t pl[8][3];
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            uint32_t p[4];
+            if (half == 0)
+                transpose_bytes4(s[4 * q].lo ^ 0x80808080u, s[4 * q + 1].lo ^ 0x80808080u, s[4 * q + 2].lo ^ 0x80808080u,
+                                 s[4 * q + 3].lo ^ 0x80808080u, p);
+            else
+                transpose_bytes4(s[4 * q].hi ^ 0x80808080u, s[4 * q + 1].hi ^ 0x80808080u, s[4 * q + 2].hi ^ 0x80808080u,
+                                 s[4 * q + 3].hi ^ 0x80808080u, p);
+#pragma unroll
+            for (int b = 0; b < 4; b++) pl[4 * half + b][q] = p[b];
+        }
+    // main pass: slots 12 / 13 carry u1 / u2
+    uint32_t w3[8];
+    {
+        const uint32_t a1l = u1.lo ^ 0x80808080u, a1h = u1.hi ^ 0x80808080u, a2l = u2.lo ^ 0x80808080u, a2h = u2.hi ^ 0x80808080u;
+        w3[0] = __builtin_amdgcn_perm(a2l, a1l, 0x00000400u); w3[1] = __builtin_amdgcn_perm(a2l, a1l, 0x00000501u);
+        w3[2] = __builtin_amdgcn_perm(a2l, a1l, 0x00000602u); w3[3] = __builtin_amdgcn_perm(a2l, a1l, 0x00000703u);
+        w3[4] = __builtin_amdgcn_perm(a2h, a1h, 0x00000400u); w3[5] = __builtin_amdgcn_perm(a2h, a1h, 0x00000501u);
+        w3[6] = __builtin_amdgcn_perm(a2h, a1h, 0x00000602u); w3[7] = __builtin_amdgcn_perm(a2h, a1h, 0x00000703u);
+    }
+    // a pair of output planes at a time: x = d + 2^8 d' (x0, y0, x1, y1, x2); what can be folded is folded as soon as its
+    // planes exist, so at most three twelve-register terms are alive beside the pair in flight
+    uint32_t x0[12], y0[12], y1[12];
+    uint64_t tt[12];   // [0]: the low accumulator of the seeded form; [r >= 1]: t = x0 + 2^16 y0 + 2^32 x1
+    uint64_t ah0 = 0;
+    auto chain = [&](int q) {
+        i32x16_t d = op.seed;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+            if (q - p >= 0 && q - p <= 7) {
+                i32x4_t bf;
+                bf.x = (int)pl[q - p][0]; bf.y = (int)pl[q - p][1]; bf.z = (int)pl[q - p][2]; bf.w = (int)w3[q - p];
+                d = __builtin_amdgcn_mfma_i32_32x32x32_i8(op.a[p], bf, d, 0, 0, 0);
+            }
+        return d;
+    };
+#pragma unroll
+    for (int pr = 0; pr < 5; pr++) {
+        i32x16_t d[2];
+        d[0] = chain(2 * pr);
+        d[1] = chain(2 * pr + 1);
+#pragma unroll
+        for (int r = 0; r < 12; r++) {
+            // the compiler's own shift-add: the matrix cores' results must NOT go straight into inline asm - the hazard recogniser
+            // that spaces a vector read from the matrix instruction that wrote the register does not look inside asm statements
+            // (seen: wrong sums).  The empty asm only stops the re-association of x2 + z1 into v_lshlrev + v_add3.
+            uint32_t x = ((uint32_t)d[1][r] << 8) + (uint32_t)d[0][r];
+            asm("" : "+v"(x));
+            if (pr == 0) x0[r] = x;
+            if (pr == 1) {
+                y0[r] = x;
+                if (r == 0) tt[0] = mad_u64_one(x0[0], mad_u64_sc(x, k16, kap[0]));
+            }
+            if (pr == 2) {
+                if (r == 0) ah0 = x;
+                else tt[r] = mad_u64(y0[r], k16, ((uint64_t)x << 32) | x0[r]);
+            }
+            if (pr == 3) {
+                y1[r] = x;
+                if (r == 0) ah0 = mad_u64_one((uint32_t)ah0, mad_u64_sc(x, k16, kap[1]));
+            }
+            if (pr == 4) {
+                if (r == 0) s[0] = fold_acc(tt[0], ah0 + ((uint64_t)x << 32));
+                else s[r] = fold_pair_x(tt[r], y1[r], x, k16);
+            }
+        }
+#ifndef NLX_PB_NO_BARRIER
+        __builtin_amdgcn_sched_barrier(0);   // a pair of planes is consumed before the next pair's sixteen-register results exist
+#endif
     }
 }
 

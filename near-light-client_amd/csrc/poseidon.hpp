@@ -23,52 +23,33 @@ constexpr int N_PARTIAL = 22;
 
 #if defined(__HIP__)
 __constant__ static const uint64_t RC_DEV[360] = NLX_POSEIDON_ROUND_CONSTANTS_INIT;
-// Seeds of the matrix-core linear layer's recombination (gl32::mds_layer_mfma): for layer l = 1 .. 29 and output r the low
-// ([r]) and high ([12 + r]) half of the constant that round l adds, zero-extended to the 64-bit scalar operand of the seed.
-//
-// The partial rounds' constants are MOVED, not changed in effect (round 4): only element 0 passes through an S-box in rounds
-// 4 .. 25, so the eleven other constants of a partial round can ride along as a known offset delta_r (delta_r[0] = 0) of the
-// state and be settled once: with t_r the state before round r's S-boxes and tt_r = t_r - delta_r the state the kernel holds,
-//   delta_4 = 0,  v = c_{r+1} + M delta_r,  cc_{r+1} = (v[0], 0, ..., 0),  delta_{r+1} = (0, v[1], ..., v[11])   (r + 1 = 5 .. 25)
-//   cc_26 = c_26 + M delta_25   (twelve constants again: delta_26 = 0, the full rounds see the true state).
-// Rounds 5 .. 25 then add ONE constant (to element 0) instead of twelve: eleven outputs of those 21 layers take the cheaper
-// recombination without a seed.  The permutation's outputs are the same field elements (tests: upstream's known answers).
-struct RcbTable {
-    uint64_t v[31 * 24];
-};
-constexpr uint64_t rcb_mulmod(uint64_t a, uint64_t b) { return (uint64_t)((unsigned __int128)a * b % gl::P); }
-constexpr uint64_t rcb_addmod(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a + b) % gl::P); }
-constexpr RcbTable make_rcb_table() {
-    constexpr uint64_t rc[360] = NLX_POSEIDON_ROUND_CONSTANTS_INIT;
-    constexpr uint64_t C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    RcbTable t{};
-    uint64_t delta[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int l = 1; l <= 29; l++) {
-        uint64_t c[12] = {};
-        for (int r = 0; r < 12; r++) c[r] = rc[l * 12 + r];
-        if (l >= HALF_FULL + 1 && l <= HALF_FULL + N_PARTIAL) {   // rounds 5 .. 26: add M delta
-            for (int r = 0; r < 12; r++) {
-                uint64_t acc = c[r];
-                for (int i = 0; i < 12; i++) acc = rcb_addmod(acc, rcb_mulmod(C[i], delta[(i + r) % 12]));
-                if (r == 0) acc = rcb_addmod(acc, rcb_mulmod(8, delta[0]));
-                c[r] = acc;
-            }
-            if (l < HALF_FULL + N_PARTIAL) {   // rounds 5 .. 25: keep element 0's constant, carry the rest
-                delta[0] = 0;
-                for (int r = 1; r < 12; r++) {
-                    delta[r] = c[r];
-                    c[r] = 0;
-                }
-            }
-        }
-        for (int r = 0; r < 12; r++) {
-            t.v[l * 24 + r] = c[r] & 0xFFFFFFFFull;
-            t.v[l * 24 + 12 + r] = c[r] >> 32;
-        }
+// Constants of the device schedule, GENERATED (tools/gen_poseidon_blocks.py -> poseidon_blocks.inc, checked there against the
+// naive permutation and upstream's known answers before they are written):
+//  * LAYER_RCB_DEV: seeds of a single layer's recombination (gl32::mds_layer_mfma): for layer l = 1 .. 29 and output r the low
+//    ([l * 24 + r]) and high ([l * 24 + 12 + r]) half of the constant round l adds, zero-extended to the seed's 64-bit scalar
+//    operand.  Layers 5 .. 25 are inside the fused blocks (rows unused); layer 26 also settles the offset the blocks carried.
+//  * BLOCK_*: the fused partial rounds (gl32::partial_block3): rounds 4 .. 24 run as seven blocks of three rounds.  Only element
+//    0 passes an S-box in a partial round, so the constants of elements 1 .. 11 are MOVED, not changed in effect: they ride along
+//    as a known offset delta of the state (the kernel holds t - delta, delta[0] = 0) together with what the chain seeds add,
+//    and are settled once, in layer 26's twelve constants.  The permutation's outputs are the same field elements.
+__constant__ static const uint64_t LAYER_RCB_DEV[31 * 24] = NLX_POSEIDON_LAYER_RCB_INIT;
+__constant__ static const uint32_t BLOCK_FRAGMENTS_DEV[NLX_POSEIDON_BLOCK_K * 64 * 4] = NLX_POSEIDON_BLOCK_FRAGMENTS_INIT;
+__constant__ static const uint32_t BLOCK_SEED_DEV[16] = NLX_POSEIDON_BLOCK_SEED_INIT;
+__constant__ static const uint64_t BLOCK_KAPPA_DEV[NLX_POSEIDON_N_BLOCKS * 2 * NLX_POSEIDON_BLOCK_K] = NLX_POSEIDON_BLOCK_KAPPA_INIT;
+static_assert(NLX_POSEIDON_BLOCK_K == 3 && NLX_POSEIDON_BLOCK_DMAX < (1 << 20), "gl32::partial_block3 is written for these");
+
+__device__ __forceinline__ gl32::BlockOperands block_operands() {
+    gl32::BlockOperands op;
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        const uint32_t* f = BLOCK_FRAGMENTS_DEV + (p * 64 + lane) * 4;
+        op.a[p].x = (int)f[0]; op.a[p].y = (int)f[1]; op.a[p].z = (int)f[2]; op.a[p].w = (int)f[3];
     }
-    return t;
+#pragma unroll
+    for (int i = 0; i < 16; i++) op.seed[i] = (int)BLOCK_SEED_DEV[i];
+    return op;
 }
-__constant__ static const RcbTable RCB_DEV = make_rcb_table();
 #endif
 static const uint64_t RC_HOST[360] = NLX_POSEIDON_ROUND_CONSTANTS_INIT;
 
@@ -133,14 +114,15 @@ GL_HD void permute_loose(uint64_t (&s)[12]) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // device: {lo, hi} u32 pairs with hand-placed carry chains (gl32.hpp); the linear layer runs on the matrix cores
     // (gl32::mds_layer_mfma: one state per lane, all of a wave's lanes together) and every round's constants seed the
-    // recombination of the PREVIOUS layer (only round 0 adds them explicitly; rounds 5 .. 25 have one constant each, see
-    // make_rcb_table).  CONTRACT: every lane of the wave reaches this call with EXEC all ones (gl32.hpp) - callers clamp
+    // recombination of the PREVIOUS layer (only round 0 adds them explicitly); rounds 4 .. 24 run as fused blocks of three
+    // (gl32::partial_block3).  CONTRACT: every lane of the wave reaches this call with EXEC all ones (gl32.hpp) - callers clamp
     // spare lanes to the last item instead of returning.
 #if defined(NLX_DEBUG)
     if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();
 #endif
-    const uint64_t* rcb = RCB_DEV.v;
+    const uint64_t* rcb = LAYER_RCB_DEV;
     const gl32::i32x4_t a = gl32::mds_a_fragment();
+    const gl32::BlockOperands op = block_operands();
     gl32::F t[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) t[i] = gl32::add_const(gl32::from_u64(s[i]), rc[i]);
@@ -151,11 +133,9 @@ GL_HD void permute_loose(uint64_t (&s)[12]) {
         gl32::mds_layer_mfma<2>(t, a, rcb + (r + 1) * 24);
     }
 #pragma unroll 1
-    for (int r = HALF_FULL; r < HALF_FULL + N_PARTIAL - 1; r++) {
-        t[0] = gl32::sbox7(t[0]);
-        gl32::mds_layer_mfma<1>(t, a, rcb + (r + 1) * 24);
-    }
-    t[0] = gl32::sbox7(t[0]);
+    for (int b = 0; b < NLX_POSEIDON_N_BLOCKS; b++)   // rounds 4 .. 24, three at a time
+        gl32::partial_block3<NLX_POSEIDON_BLOCK_GAMMA21>(t, op, BLOCK_KAPPA_DEV + b * 6);
+    t[0] = gl32::sbox7(t[0]);                          // round 25
     gl32::mds_layer_mfma<2>(t, a, rcb + (HALF_FULL + N_PARTIAL) * 24);
 #pragma unroll 1
     for (int r = HALF_FULL + N_PARTIAL; r < N_ROUNDS - 1; r++) {

@@ -169,6 +169,51 @@ int rate(const char* name, uint32_t* d_out) {
     return 0;
 }
 
+
+// ---- does a matrix instruction overlap the vector pipe?  NV v_mad_u64_u32 + NM v_mfma_i32_32x32x32_i8 per iteration, the
+// matrix instructions on NM independent accumulators (each depends only on its own previous result, NV vector instructions away)
+typedef int pi32x4_t __attribute__((ext_vector_type(4)));
+typedef int pi32x16_t __attribute__((ext_vector_type(16)));
+template <int NV, int NM>
+__global__ __launch_bounds__(256) void k_mix(uint32_t* out, uint32_t a, uint32_t b, int iters) {
+    uint64_t y[8];
+    for (int i = 0; i < 8; i++) y[i] = threadIdx.x + i;
+    pi32x16_t acc[NM > 0 ? NM : 1];
+    for (int m = 0; m < (NM > 0 ? NM : 1); m++)
+        for (int i = 0; i < 16; i++) acc[m][i] = 0;
+    pi32x4_t fa, fb;
+    fa.x = (int)(threadIdx.x * 3u); fa.y = (int)a; fa.z = (int)b; fa.w = 1;
+    fb.x = (int)(threadIdx.x * 5u); fb.y = (int)b; fb.z = (int)a; fb.w = 2;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int m = 0; m < NM; m++) acc[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, acc[m], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NV; i++)
+            asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(y[i & 7]) : "v"(a), "v"(b) : "vcc");
+    }
+    uint32_t r = 0;
+    for (int i = 0; i < 8; i++) r ^= (uint32_t)y[i] ^ (uint32_t)(y[i] >> 32);
+    for (int m = 0; m < NM; m++)
+        for (int i = 0; i < 16; i++) r ^= (uint32_t)acc[m][i];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <int NV, int NM>
+int mix(uint32_t* d_out, int waves_per_simd) {
+    const int iters = 4096, blocks = 256 * waves_per_simd, threads = 256;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_mix<NV, NM>), dim3(blocks), dim3(threads), 0, 0, d_out, 12345u, 678u, 16);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_mix<NV, NM>), dim3(blocks), dim3(threads), 0, 0, d_out, 12345u, 678u, iters);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double per_simd_iters = (double)blocks * (threads / 64) * iters / 1024.0;
+    printf("mix %2d v_mad_u64_u32 + %d v_mfma_i32_32x32x32_i8, %d wave(s)/SIMD: %.3f ms -> %.1f ns per iteration per SIMD\n", NV, NM, waves_per_simd, ms,
+           ms * 1e6 / per_simd_iters);
+    return 0;
+}
+
 // ---- Poseidon variants ----
 namespace v1 {
 // MDS on three 22-bit limbs with full-rate 24-bit multiply-adds
@@ -408,8 +453,11 @@ __device__ __forceinline__ void permute_loose(uint64_t (&st)[12], const uint64_t
 
 __device__ uint64_t RCB_DEV[31 * 24];
 
+#ifndef PUB_WAVES
+#define PUB_WAVES 4
+#endif
 template <int V>
-__global__ __launch_bounds__(256, 4) void k_perm(uint64_t* states, size_t n, int reps) {
+__global__ __launch_bounds__(256, PUB_WAVES) void k_perm(uint64_t* states, size_t n, int reps) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     uint64_t s[12];
@@ -480,6 +528,10 @@ int main() {
     rate<37>("v_add_u32_sdwa", d_out);
     rate<38>("v_lshlrev_b32_sdwa", d_out);
     rate<39>("v_or_b32_sdwa preserve", d_out);
+    for (int w : {4, 8}) {
+        mix<16, 0>(d_out, w); mix<16, 1>(d_out, w); mix<16, 2>(d_out, w); mix<32, 1>(d_out, w); mix<64, 1>(d_out, w); mix<64, 0>(d_out, w);
+        mix<0, 1>(d_out, w); mix<0, 2>(d_out, w);
+    }
     unsigned long long* d_cyc;
     CK(hipMalloc(&d_cyc, 256 * 8 * 4 * 8));
     cycles<4>("v_add_u32", d_out, d_cyc);
