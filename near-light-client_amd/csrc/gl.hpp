@@ -137,31 +137,30 @@ GL_HD uint64_t reduce128_loose(uint64_t lo, uint64_t hi) {
 GL_HD uint64_t reduce128(uint64_t lo, uint64_t hi) { return canon(reduce128_loose(lo, hi)); }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// 64x64 -> 128 product and Goldilocks reduction as two asm blocks with VCC carry chains
-// (16 instructions; hipcc's u64 code needs 29).  See gl32.hpp for the measurements behind this.
+// 64x64 -> 128 product and Goldilocks reduction (16 instructions; hipcc's u64 code needs 29).  See gl32.hpp for the measurements
+// behind this.  The product is a chain of five multiply-adds none of which can overflow
+//   p0 = a0 b0;  p1 = a0 b1 + hi(p0);  p2 = a1 b0 + lo(p1);  p3 = a1 b1 + hi(p1) + hi(p2)   (w0 = lo(p0), w1 = lo(p2), (w3:w2) = p3)
+// - the three zero-extended addends cost a v_mov each, which issues at half the price of the add-with-carry instructions the
+// four-product form needed (round 4: the Poseidon micro-benchmark 2.56 -> 2.76 G/s on this change alone).
 __device__ __forceinline__ uint64_t mul_loose_asm(uint64_t a, uint64_t b) {
     const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
-    const uint64_t t = (uint64_t)a0 * b0, m = (uint64_t)a0 * b1, x = (uint64_t)a1 * b1;
-    uint64_t mid;
-    uint32_t x1;
-    asm("v_mad_u64_u32 %[mid], vcc, %[ah], %[bl], %[m]\n\t"
-        "v_addc_co_u32 %[x1], vcc, 0, %[xh], vcc"
-        : [mid] "=&v"(mid), [x1] "=v"(x1)
-        : [ah] "v"(a1), [bl] "v"(b0), [m] "v"(m), [xh] "v"((uint32_t)(x >> 32))
-        : "vcc");
-    // limbs w1..w3, then r = (w1:w0) - w3 [borrow -> -EPS]
-    uint32_t r0, r1, w1, w2, w3, t0;
-    asm("v_add_co_u32 %[w1], vcc, %[th], %[m0]\n\t"
-        "v_addc_co_u32 %[w2], vcc, %[x0], %[m1], vcc\n\t"
-        "v_addc_co_u32 %[w3], vcc, 0, %[x1], vcc\n\t"
-        "v_sub_co_u32 %[r0], vcc, %[w0], %[w3]\n\t"
+    // plain C++ for the four products: hipcc selects exactly v_mad_u64_u32 with a (value : 0) register pair for each addend and
+    // spaces nothing (between asm statements it puts an s_nop); the last addition as x * 1 + c saves the pair
+    const uint64_t p0 = (uint64_t)a0 * b0;
+    const uint64_t p1 = (uint64_t)a0 * b1 + (p0 >> 32);
+    const uint64_t p2 = (uint64_t)a1 * b0 + (uint32_t)p1;
+    uint64_t p3 = (uint64_t)a1 * b1 + (p1 >> 32), sink;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(p3), "=s"(sink) : "v"((uint32_t)(p2 >> 32)), "v"(p3));
+    // r = (w1:w0) - w3 [borrow -> -EPS]
+    uint32_t r0, r1, t0;
+    const uint32_t w2 = (uint32_t)p3;
+    asm("v_sub_co_u32 %[r0], vcc, %[w0], %[w3]\n\t"
         "v_subbrev_co_u32 %[r1], vcc, 0, %[w1], vcc\n\t"
         "v_cndmask_b32_e64 %[t0], 0, -1, vcc\n\t"
         "v_sub_co_u32 %[r0], vcc, %[r0], %[t0]\n\t"
         "v_subbrev_co_u32 %[r1], vcc, 0, %[r1], vcc"
-        : [r0] "=&v"(r0), [r1] "=&v"(r1), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [t0] "=&v"(t0)
-        : [w0] "v"((uint32_t)t), [th] "v"((uint32_t)(t >> 32)), [m0] "v"((uint32_t)mid), [x0] "v"((uint32_t)x),
-          [m1] "v"((uint32_t)(mid >> 32)), [x1] "v"(x1)
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [t0] "=&v"(t0)
+        : [w0] "v"((uint32_t)p0), [w1] "v"((uint32_t)p2), [w3] "v"((uint32_t)(p3 >> 32))
         : "vcc");
     // + w2 * EPS [carry -> +EPS]: ONE multiply-add (carry-out in VCC), carry -> mask, mask * 1 + r.  On gfx950 every
     // VCC-chained add issues as slowly as a multiply (profiles/r02_valu_ubench.txt), so these three replace seven.

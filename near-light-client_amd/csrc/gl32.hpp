@@ -50,8 +50,14 @@ __device__ __forceinline__ F reduce128(uint32_t w0, uint32_t w1, uint32_t w2, ui
     return add_w2_eps(((uint64_t)r1 << 32) | r0, w2);
 }
 
-// loose * loose -> loose
+__device__ __forceinline__ uint64_t mad_u64_one(uint32_t a, uint64_t c);
+
+// loose * loose -> loose.  The 128-bit product as a chain of five multiply-adds none of which can overflow
+//   p0 = al bl;  p1 = al bh + hi(p0);  p2 = ah bl + lo(p1);  p3 = ah bh + hi(p1) + hi(p2)   (w0 = lo(p0), w1 = lo(p2), (w3:w2) = p3)
+// instead of four products and four carry-chain additions: the three zero-extended addends cost a v_mov each, which issues at
+// half the price of an add-with-carry (profiles/r04_valu_issue_rates_v1.txt).
 __device__ __forceinline__ F mul(F a, F b) {
+#ifdef NLX_GL32_MUL_CARRY_CHAINS
     uint64_t t = (uint64_t)a.lo * b.lo;
     uint64_t m = (uint64_t)a.lo * b.hi;
     uint64_t x = (uint64_t)a.hi * b.hi;
@@ -78,6 +84,16 @@ __device__ __forceinline__ F mul(F a, F b) {
           [m1] "v"((uint32_t)(mid >> 32)), [x1] "v"(x1)
         : "vcc");
     return add_w2_eps(((uint64_t)r1 << 32) | r0, w2);
+#else
+    // plain C++ for the four products: hipcc selects exactly v_mad_u64_u32 with a (value : 0) register pair for each addend
+    // and spaces nothing (between asm statements it puts an s_nop); the last addition as x * 1 + c saves the pair
+    const uint64_t p0 = (uint64_t)a.lo * b.lo;
+    const uint64_t p1 = (uint64_t)a.lo * b.hi + (p0 >> 32);
+    const uint64_t p2 = (uint64_t)a.hi * b.lo + (uint32_t)p1;
+    uint64_t p3 = (uint64_t)a.hi * b.hi + (p1 >> 32);
+    p3 = mad_u64_one((uint32_t)(p2 >> 32), p3);
+    return reduce128((uint32_t)p0, (uint32_t)p2, (uint32_t)p3, (uint32_t)(p3 >> 32));
+#endif
 }
 
 // loose + canonical constant -> loose
