@@ -58,14 +58,9 @@ __global__ __launch_bounds__(256, 4) void k_hash_leaves_rowmajor(const uint64_t*
         if (live) store_digest(digests, row, s);
         return;
     }
-    uint32_t c = 0;
-    for (; c + 8 <= row_len; c += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = p[c + j];
-        poseidon::permute_loose(s);
-    }
-    if (c < row_len) {
-        uint32_t rem = row_len - c;
+#pragma unroll 1
+    for (uint32_t c = 0; c < row_len; c += 8) {   // one call site of the permutation (see k_hash_lde_leaves)
+        const uint32_t rem = row_len - c;
 #pragma unroll
         for (int j = 0; j < 8; j++)
             if ((uint32_t)j < rem) s[j] = p[c + j];
@@ -183,14 +178,11 @@ __global__ __launch_bounds__(256, 4) void k_hash_lde_leaves(const uint64_t* __re
         if (live) store_digest(digests, leaf, s);
         return;
     }
-    uint32_t c = 0;
-    for (; c + 8 <= n_cols; c += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = p[(size_t)(c + j) * col_stride];
-        poseidon::permute_loose(s);
-    }
-    if (c < n_cols) {
-        uint32_t rem = n_cols - c;
+    // ONE call site of the permutation (its code is ~56 KB: a second copy for the ragged last chunk doubled what the waves of a
+    // CU pull through the instruction cache); the chunk length is wave-uniform, so the guards are scalar branches
+#pragma unroll 1
+    for (uint32_t c = 0; c < n_cols; c += 8) {
+        const uint32_t rem = n_cols - c;
 #pragma unroll
         for (int j = 0; j < 8; j++)
             if ((uint32_t)j < rem) s[j] = p[(size_t)(c + j) * col_stride];
@@ -218,13 +210,8 @@ __global__ __launch_bounds__(256, 4) void k_hash_lde_groups(const uint64_t* __re
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = 0;
     const uint64_t* p = lde + pos;
-    uint32_t c = c0;
-    for (; c + 8 <= c1; c += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) s[j] = p[(size_t)(c + j) * col_stride];
-        poseidon::permute_loose(s);
-    }
-    if (c < c1) {
+#pragma unroll 1
+    for (uint32_t c = c0; c < c1; c += 8) {   // one call site of the permutation (see k_hash_lde_leaves)
         const uint32_t rem = c1 - c;
 #pragma unroll
         for (int j = 0; j < 8; j++)
