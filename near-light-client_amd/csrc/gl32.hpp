@@ -380,20 +380,30 @@ __device__ __forceinline__ void dot12(const F (&z)[12], const RHO& rho, uint64_t
 struct BlockRho1 { static constexpr uint32_t v[12] = NLX_POSEIDON_BLOCK_RHO1_INIT; };
 struct BlockRho2 { static constexpr uint32_t v[12] = NLX_POSEIDON_BLOCK_RHO2_INIT; };
 
+// What happens at the three S-boxes of a block.  The permutation applies them; PoseidonGate (prover_kernels.hip) is handed the
+// computed S-box input, emits `input - wire` and continues from the wire's S-box - the same linear maps either way.
+struct BlockSboxes {
+    __device__ __forceinline__ F first(F s0) const { return sbox7(s0); }            // round a: element 0 of the state
+    __device__ __forceinline__ F inner(int, F w) const { return sbox7(w); }         // rounds a + 1, a + 2: w_1, w_2
+    __device__ __forceinline__ void before_matrix_pass() const {}
+};
+
 // kap: this block's six wave-uniform words (low, high) x (output 0's constant, S-box input 1's, S-box input 2's); GAMMA21 = M[0][0]
-template <int GAMMA21>
-__device__ __forceinline__ void partial_block3(F (&s)[12], const BlockOperands& op, const uint64_t* __restrict__ kap) {
+template <int GAMMA21, class Sboxes = BlockSboxes>
+__device__ __forceinline__ void partial_block3(F (&s)[12], const BlockOperands& op, const uint64_t* __restrict__ kap,
+                                               Sboxes sb = Sboxes{}) {
     uint32_t k16 = 65536u;
     asm("" : "+v"(k16));
-    s[0] = sbox7(s[0]);
+    s[0] = sb.first(s[0]);
     // the S-box inputs of the block's second and third round, and their outputs
     uint64_t al, ah;
     dot12(s, BlockRho1{}, kap[2], kap[3], al, ah);
-    const F u1 = sbox7(fold_acc(al, ah));
+    const F u1 = sb.inner(1, fold_acc(al, ah));
     dot12(s, BlockRho2{}, kap[4], kap[5], al, ah);
     al = mad_u64_imm<GAMMA21>(u1.lo, al);
     ah = mad_u64_imm<GAMMA21>(u1.hi, ah);
-    const F u2 = sbox7(fold_acc(al, ah));
+    const F u2 = sb.inner(2, fold_acc(al, ah));
+    sb.before_matrix_pass();
     uint32_t pl[8][3];
 #pragma unroll
     for (int half = 0; half < 2; half++)

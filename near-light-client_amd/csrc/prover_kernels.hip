@@ -211,10 +211,20 @@ struct GateAcc {
     uint64_t a[8];
     uint32_t kc[8];
     uint32_t k;
+    uint64_t base[2];   // what stash() folded away so far (canonical)
     __device__ __forceinline__ void reset() {
 #pragma unroll
         for (int i = 0; i < 8; i++) { a[i] = 0; kc[i] = 0; }
         k = 0;
+        base[0] = base[1] = 0;
+    }
+    // the 24 registers of the columns -> two canonical sums (PoseidonGate's fused partial rounds need the registers for the
+    // matrix pass between two groups of constraints); the constraint counter keeps running
+    __device__ __forceinline__ void stash() {
+        base[0] = gl::add(base[0], fold_columns(a, kc));
+        base[1] = gl::add(base[1], fold_columns(a + 4, kc + 4));
+#pragma unroll
+        for (int i = 0; i < 8; i++) { a[i] = 0; kc[i] = 0; }
     }
     __device__ __forceinline__ void emit_at(uint32_t idx, uint64_t c) { mac(c, ap0[idx], ap1[idx]); }
     // sums 0 and 1 += c * b0, c * b1 (b0, b1 wave-uniform)
@@ -245,7 +255,7 @@ struct GateAcc {
     }
     __device__ __forceinline__ void emit(uint64_t c) { emit_at(k++, c); }
     // sum for challenge ch: A0 + (A1 + A2) 2^32 + A3 2^64 + K0 2^64 + (K1 + K2) 2^96 + K3 2^128 (mod p)
-    __device__ __forceinline__ uint64_t finish(int ch) const { return fold_columns(a + 4 * ch, kc + 4 * ch); }
+    __device__ __forceinline__ uint64_t finish(int ch) const { return gl::add(fold_columns(a + 4 * ch, kc + 4 * ch), base[ch]); }
     // The four 64-bit columns and their carry counts as ONE 160-bit integer (t4 : t3 : t2 : t1 : t0), reduced with
     // 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32: (t1:t0) + t2 EPS - t3 - t4 2^32.  ~35 instructions (the first version
     // reduced every column on its own: ~110, twice per item of k_quotient).
@@ -354,14 +364,113 @@ __device__ __forceinline__ void mds_canon(uint64_t (&s)[12]) {
     for (int i = 0; i < 12; i++) s[i] = o[i];
 }
 
-// PoseidonGate::eval_unfiltered_base (fast partial-round formulation, as upstream), in three independent parts (bit mask):
-// every round of the gate restarts from WIRES (the round's S-box inputs are wires, the constraint ties them to the state
-// computed from the previous round's wires), so the 123 constraints split wherever the state is reloaded:
+// PoseidonGate::eval_unfiltered_base, in three independent parts (bit mask): every round of the gate restarts from WIRES (the
+// round's S-box inputs are wires, the constraint ties them to the state computed from the previous round's wires), so the 123
+// constraints split wherever the state is reloaded:
 //   1: swap bit, deltas, full rounds 0-2 and the check of round 3's inputs            constraints 0 .. 40
 //   2: full round 3 from its input wires, the 22 partial rounds, the check of round 26's inputs      41 .. 74
 //   4: full rounds 26-29 and the output wires                                                        75 .. 122
-// Each part is its own work item of k_quotient (part 2 alone is two thirds of the gate and a fifth of the whole kernel);
-// constraint k always meets alpha^k (GateAcc::emit_at).
+// Each part is its own work item of k_quotient; constraint k always meets alpha^k (GateAcc::emit_at).
+//
+// Upstream evaluates the partial rounds in its fast formulation (sparse matrices, constants pushed onto element 0).  With the
+// S-box inputs FREE (they are wires here) the constraints `computed input - wire` and the twelve values after round 25 are the
+// same polynomials in the naive formulation - checked numerically against tools/gen_poseidon_fast.py's tables, and by every
+// proof-byte comparison with the oracle, which evaluates the fast formulation - so the whole gate runs on the permutation's
+// own device schedule (round 4): linear layers on the matrix cores with the next round's constants in the recombination
+// (gl32::mds_layer_mfma), rounds 4 .. 24 as seven fused blocks whose S-box hooks emit `computed - wire` and continue from the
+// wire (gl32::partial_block3).  NLX_POSEIDON_GATE_FAST_BASIS keeps round 3's evaluation (vector-pipe layers, fast formulation).
+#ifndef NLX_POSEIDON_GATE_FAST_BASIS
+template <class WireFn>
+struct GateBlockSboxes {
+    GateAcc& acc;
+    WireFn W;
+    uint32_t r0;   // the block's first partial round (0 .. 18): its S-box input is wire 65 + r0, its constraint 41 + r0
+    __device__ __forceinline__ gl32::F at(uint32_t r, gl32::F computed) const {
+        const uint64_t in = W(65 + r);
+        acc.emit_at(41 + r, gl::sub(gl32::to_u64(computed), in));
+        const gl32::F u = gl32::sbox7(gl32::from_u64(in));
+        __builtin_amdgcn_sched_barrier(0);
+        return u;
+    }
+    __device__ __forceinline__ gl32::F first(gl32::F s0) const { return at(r0, s0); }
+    __device__ __forceinline__ gl32::F inner(int i, gl32::F w) const { return at(r0 + (uint32_t)i, w); }
+    __device__ __forceinline__ void before_matrix_pass() const { acc.stash(); }
+};
+
+template <class WireFn>
+__device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t parts) {
+    const uint64_t* RC = poseidon::RC_DEV;
+    const uint64_t* rcb = poseidon::LAYER_RCB_DEV;   // [l * 24 ..]: the constants round l adds, as the recombination's seeds
+    const gl32::i32x4_t afrag = gl32::mds_a_fragment();
+    gl32::F t[12];
+    // S-boxes one at a time (a fence each): interleaved they buy nothing and their temporaries were what k_quotient spilled
+    auto sbox_of_wires = [&](uint32_t w0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            t[i] = gl32::sbox7(gl32::from_u64(W(w0 + i)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto check_against_wires = [&](uint32_t c0, uint32_t w0) {   // constraints c0 + i: computed state - wire w0 + i
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            acc.emit_at(c0 + i, gl::sub(gl32::to_u64(t[i]), W(w0 + i)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (parts & 1u) {
+        const uint64_t swap = W(24);
+        acc.emit_at(0, gl::mul(swap, gl::sub(swap, 1)));
+        uint64_t st[12];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint64_t lhs = W(i), rhs = W(i + 4), delta = W(25 + i);
+            acc.emit_at(1 + i, gl::sub(gl::mul(swap, gl::sub(rhs, lhs)), delta));
+            st[i] = gl::add(lhs, delta);
+            st[i + 4] = gl::sub(rhs, delta);
+        }
+#pragma unroll
+        for (int i = 8; i < 12; i++) st[i] = W(i);
+        // rounds 0 .. 2 in full, each followed by the check of the next round's S-box inputs (wires), from which the next
+        // round restarts; round 3 itself belongs to part 2
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            t[i] = gl32::sbox7(gl32::from_u64(gl::add_loose(st[i], RC[i])));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll 1
+        for (int r = 0; r < 3; r++) {
+            if (r) sbox_of_wires(29 + 12 * (r - 1));
+            gl32::mds_layer_mfma<2>(t, afrag, rcb + (r + 1) * 24);
+            check_against_wires(5 + 12 * r, 29 + 12 * r);
+        }
+    }
+    if (parts & 2u) {
+        const gl32::BlockOperands op = poseidon::block_operands();
+        sbox_of_wires(29 + 24);                              // round 3's S-box inputs are wires
+        gl32::mds_layer_mfma<2>(t, afrag, rcb + 4 * 24);
+#pragma unroll 1
+        for (uint32_t b = 0; b < NLX_POSEIDON_N_BLOCKS; b++)   // partial rounds 0 .. 20 (rounds 4 .. 24)
+            gl32::partial_block3<NLX_POSEIDON_BLOCK_GAMMA21>(t, op, poseidon::BLOCK_KAPPA_DEV + b * 6, GateBlockSboxes<WireFn>{acc, W, 3 * b});
+        t[0] = GateBlockSboxes<WireFn>{acc, W, 21}.first(t[0]);   // partial round 21 (round 25)
+        gl32::mds_layer_mfma<2>(t, afrag, rcb + 26 * 24);
+        check_against_wires(63, 87);
+    }
+    if (parts & 4u) {
+#pragma unroll 1
+        for (int r = 0; r < 4; r++) {
+            sbox_of_wires(87 + 12 * r);
+            if (r < 3) {
+                gl32::mds_layer_mfma<2>(t, afrag, rcb + (27 + r) * 24);
+                check_against_wires(63 + 12 * (r + 1), 87 + 12 * (r + 1));
+            } else {
+                gl32::mds_layer_mfma<0>(t, afrag, rcb);
+                check_against_wires(111, 12);
+            }
+        }
+    }
+}
+#else
 template <class WireFn>
 __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t parts) {
     const uint64_t* RC = poseidon::RC_DEV;
@@ -463,6 +572,7 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t p
         for (int i = 0; i < 12; i++) acc.emit_at(111 + i, gl::sub(st[i], W(12 + i)));
     }
 }
+#endif
 
 // One gate's unfiltered constraints at this lane's point, folded into `acc` with the alpha powers (Gate::eval_unfiltered_base).
 // W(c): wire c of the point; CC(c): constants column c (selectors first) of the point; n = 2^log_n.
