@@ -206,11 +206,18 @@ __device__ __forceinline__ void mds_layer(F (&s)[12], const uint64_t* __restrict
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x16_t __attribute__((ext_vector_type(16)));
 
+// Rows 12 .. 15 of a result are never read.  Left at that, hipcc treats those four registers of the sixteen-register result as
+// dead from the start: it has overlapped them with the SAME instruction's B operand and handed them to other values while the
+// instruction was in flight (seen in k_quotient, where PoseidonGate's three parts share a function: wrong sums that came and
+// went with the register allocation).  An empty asm statement that takes the whole result after its last real use keeps all
+// sixteen registers allocated to it until then, at no instruction.
+__device__ __forceinline__ void keep_whole(const i32x16_t& d) { asm volatile("" : : "v"(d)); }
+
 // this lane's A operand: A[row = lane & 31][k = 16 (lane >> 5) + j], j = 0 .. 15 (the same k order as the B operand below,
 // whatever the hardware's order inside a lane's sixteen bytes is); slots 12 .. 14 carry the bias correction (see above)
-__device__ __forceinline__ i32x4_t mds_a_fragment() {
+__device__ __forceinline__ i32x4_t mds_a_fragment(uint32_t lane = threadIdx.x & 63) {
     constexpr int C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    const uint32_t lane = threadIdx.x & 63, rho = lane & 31, h = lane >> 5;
+    const uint32_t rho = lane & 31, h = lane >> 5;
     const uint32_t g = (rho >> 2) & 1, r = (rho & 3) + 4 * (rho >> 3);
     uint32_t w[4] = {0, 0, 0, 0};
     if (h == g && rho < 24) {
@@ -310,6 +317,8 @@ __device__ __forceinline__ void mds_layer_mfma(F (&s)[12], const i32x4_t a, cons
             x[half][r] = ((uint32_t)d[1][r] << 8) + (uint32_t)d[0][r];
             y[half][r] = ((uint32_t)d[3][r] << 8) + (uint32_t)d[2][r];
         }
+#pragma unroll
+        for (int b = 0; b < 4; b++) keep_whole(d[b]);
         __builtin_amdgcn_sched_barrier(0);   // the low half's sixteen-register results are dead before the high half's exist
     }
 #pragma unroll
@@ -474,6 +483,8 @@ __device__ __forceinline__ void partial_block3(F (&s)[12], const BlockOperands& 
                 else s[r] = fold_pair_x(tt[r], y1[r], x, k16);
             }
         }
+        keep_whole(d[0]);
+        keep_whole(d[1]);
 #ifndef NLX_PB_NO_BARRIER
         __builtin_amdgcn_sched_barrier(0);   // a pair of planes is consumed before the next pair's sixteen-register results exist
 #endif

@@ -38,16 +38,18 @@ __constant__ static const uint32_t BLOCK_SEED_DEV[16] = NLX_POSEIDON_BLOCK_SEED_
 __constant__ static const uint64_t BLOCK_KAPPA_DEV[NLX_POSEIDON_N_BLOCKS * 2 * NLX_POSEIDON_BLOCK_K] = NLX_POSEIDON_BLOCK_KAPPA_INIT;
 static_assert(NLX_POSEIDON_BLOCK_K == 3 && NLX_POSEIDON_BLOCK_DMAX < (1 << 20), "gl32::partial_block3 is written for these");
 
-__device__ __forceinline__ gl32::BlockOperands block_operands() {
+__device__ __forceinline__ gl32::BlockOperands block_operands(uint32_t lane = threadIdx.x & 63) {
     gl32::BlockOperands op;
-    const uint32_t lane = threadIdx.x & 63;
 #pragma unroll
     for (int p = 0; p < 3; p++) {
         const uint32_t* f = BLOCK_FRAGMENTS_DEV + (p * 64 + lane) * 4;
         op.a[p].x = (int)f[0]; op.a[p].y = (int)f[1]; op.a[p].z = (int)f[2]; op.a[p].w = (int)f[3];
     }
+    // lane >> 6 is zero; where the caller made the lane index opaque (k_quotient: see gate_poseidon_mx) it ties the seeds to that
+    // point as well, elsewhere it folds away
+    const uint32_t zero = lane >> 6;
 #pragma unroll
-    for (int i = 0; i < 16; i++) op.seed[i] = (int)BLOCK_SEED_DEV[i];
+    for (int i = 0; i < 16; i++) op.seed[i] = (int)(BLOCK_SEED_DEV[i] + zero);
     return op;
 }
 #endif

@@ -84,6 +84,12 @@ uint32_t gate_eval_cost(const nlx_gate_desc& g) {
 }
 // PoseidonGate's three parts (prover_kernels.hip gate_poseidon): part mask, share of the gate's cost in percent
 constexpr uint32_t POSEIDON_PARTS[3][2] = {{1, 17}, {2, 59}, {4, 24}};   // measured 440 / 1 490 / 610
+// Part 2 (the 22 partial rounds) runs in a kernel of its own before k_quotient (launch_quotient_poseidon: the permutation's
+// fused-block schedule, prover_kernels.hip) unless NLX_QUOTIENT_POSEIDON_INLINE=1 keeps it among k_quotient's items.
+bool poseidon_part2_separate_default() {
+    const char* e = getenv("NLX_QUOTIENT_POSEIDON_INLINE");
+    return !(e && e[0] == '1');
+}
 }  // namespace
 
 struct nlx_circuit {
@@ -97,6 +103,8 @@ struct nlx_circuit {
     uint64_t* d_sigma_values = nullptr; // [routed][n]
     GateDev* d_gates = nullptr;
     uint32_t* d_work = nullptr;         // k_quotient's work split: [quotient_waves()][work_stride]
+    bool poseidon_part2_separate = poseidon_part2_separate_default();
+    std::vector<uint32_t> poseidon_gates;   // PoseidonGates whose part 2 runs in k_quotient_poseidon
     uint32_t work_stride = 0;
     uint64_t* d_small = nullptr;        // k_is | coset_base | zh_inv | w_R_inv_pows | chunk_scale | w_A_inv_pows
     uint64_t *d_k_is = nullptr, *d_coset_base = nullptr, *d_zh_inv = nullptr, *d_wR_inv = nullptr,
@@ -344,7 +352,13 @@ int32_t nlx_circuit_build(nlx_ctx* ctx, const nlx_circuit_desc* desc, const uint
         for (uint32_t g = 0; g < d.num_gates; g++) {
             const uint32_t cost = gate_eval_cost(c->gates[g]);
             if (c->gates[g].kind == NLX_GATE_POSEIDON) {
-                for (const auto& part : POSEIDON_PARTS) items.push_back({cost * part[1] / 100, g | (part[0] << 16)});
+                for (const auto& part : POSEIDON_PARTS) {
+                    if (part[0] == 2 && c->poseidon_part2_separate) {
+                        c->poseidon_gates.push_back(g);
+                        continue;
+                    }
+                    items.push_back({cost * part[1] / 100, g | (part[0] << 16)});
+                }
             } else {
                 items.push_back({cost, g});
             }
@@ -584,6 +598,10 @@ int32_t quotient_stage(nlx_circuit* c, const nlx_commit* cw, const nlx_commit* c
             qp.accumulate = 1;
         }
         ctx->begin_kernel("quotient", 8.0 * L * (c->n_cs + d.num_wires + c->n_zs + nc) + 8.0 * L * nc);
+        for (uint32_t g : c->poseidon_gates) {   // their part 2 ahead of the main kernel, which adds the rest
+            launch_quotient_poseidon(st, qp, g, qp.accumulate != 0);
+            qp.accumulate = 1;
+        }
         launch_quotient(st, qp);
         ctx->end_kernel();
         stage("quotient_intt");

@@ -51,6 +51,7 @@ struct QuotientParams {
     uint32_t work_stride;
 };
 void launch_quotient(hipStream_t st, const QuotientParams& p);
+void launch_quotient_poseidon(hipStream_t st, const QuotientParams& p, uint32_t gate, bool add);   // PoseidonGate part 2, before launch_quotient
 size_t quotient_lds_bytes(uint32_t num_wires, uint32_t n_consts_all);
 uint32_t quotient_waves();
 void launch_l0_table(hipStream_t st, uint64_t* d_out, unsigned log_n, unsigned rate_bits, const uint64_t* d_coset_base,

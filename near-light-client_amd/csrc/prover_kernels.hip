@@ -379,7 +379,6 @@ __device__ __forceinline__ void mds_canon(uint64_t (&s)[12]) {
 // own device schedule (round 4): linear layers on the matrix cores with the next round's constants in the recombination
 // (gl32::mds_layer_mfma), rounds 4 .. 24 as seven fused blocks whose S-box hooks emit `computed - wire` and continue from the
 // wire (gl32::partial_block3).  NLX_POSEIDON_GATE_FAST_BASIS keeps round 3's evaluation (vector-pipe layers, fast formulation).
-#ifndef NLX_POSEIDON_GATE_FAST_BASIS
 template <class WireFn>
 struct GateBlockSboxes {
     GateAcc& acc;
@@ -398,10 +397,15 @@ struct GateBlockSboxes {
 };
 
 template <class WireFn>
-__device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t parts) {
+__device__ __forceinline__ void gate_poseidon_mx(WireFn W, GateAcc& acc, uint32_t parts) {
     const uint64_t* RC = poseidon::RC_DEV;
     const uint64_t* rcb = poseidon::LAYER_RCB_DEV;   // [l * 24 ..]: the constants round l adds, as the recombination's seeds
-    const gl32::i32x4_t afrag = gl32::mds_a_fragment();
+    // The matrix operands depend on the lane only: left to itself hipcc hoists them out of k_quotient's item loop - ~32 registers
+    // pinned under EVERY gate (the kernel's empty-list time went 0.23 -> 0.38 ms per 2^19 points, every item a few percent
+    // slower).  The lane index is tied to the item here (an empty asm with the part mask as input), so they are built per item.
+    uint32_t lane = threadIdx.x & 63;
+    asm("" : "+v"(lane) : "s"(parts));
+    const gl32::i32x4_t afrag = gl32::mds_a_fragment(lane);
     gl32::F t[12];
     // S-boxes one at a time (a fence each): interleaved they buy nothing and their temporaries were what k_quotient spilled
     auto sbox_of_wires = [&](uint32_t w0) {
@@ -446,7 +450,7 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t p
         }
     }
     if (parts & 2u) {
-        const gl32::BlockOperands op = poseidon::block_operands();
+        const gl32::BlockOperands op = poseidon::block_operands(lane);
         sbox_of_wires(29 + 24);                              // round 3's S-box inputs are wires
         gl32::mds_layer_mfma<2>(t, afrag, rcb + 4 * 24);
 #pragma unroll 1
@@ -470,9 +474,11 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t p
         }
     }
 }
-#else
+
+// round 3's evaluation (vector-pipe layers, upstream's fast formulation of the partial rounds): kept for the parts NLX_PGATE_MX
+// leaves to it, and as the ablation reference
 template <class WireFn>
-__device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t parts) {
+__device__ __forceinline__ void gate_poseidon_fast(WireFn W, GateAcc& acc, uint32_t parts) {
     const uint64_t* RC = poseidon::RC_DEV;
     uint64_t st[12];
     if (parts & 1u) {
@@ -572,7 +578,23 @@ __device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t p
         for (int i = 0; i < 12; i++) acc.emit_at(111 + i, gl::sub(st[i], W(12 + i)));
     }
 }
+
+// Inside k_quotient the gate's parts run in round 3's form.  The matrix-core schedule was tried there and lost (round 4): parts 1
+// and 3 - seven full rounds - measured 440 -> 720 and 610 -> 1 040 us per 2^19 points in the calibration build
+// (profiles/r04_quotient_calibrate_poseidon_gate_mx7_v1.txt); part 2 measured 1 490 -> 990 there but made the KERNEL slower, 6.8 ->
+// 8.6 ms at 2^18 rows: the block needs ~122 registers beside GateAcc's 28 at this kernel's 128, the handful of spilled registers
+// it reloads per block are scratch round trips, and in k_quotient a tile's eight waves run different items, so one wave's
+// memory latency is the tile's critical path (with every wave on the same item the latency hides).  Part 2 therefore has a
+// kernel of its own, k_quotient_poseidon below, where every wave runs it and 168 registers are allowed; NLX_PGATE_MX selects
+// parts for the in-kernel experiment.
+#ifndef NLX_PGATE_MX
+#define NLX_PGATE_MX 0u
 #endif
+template <class WireFn>
+__device__ __forceinline__ void gate_poseidon(WireFn W, GateAcc& acc, uint32_t parts) {
+    if (parts & NLX_PGATE_MX) gate_poseidon_mx(W, acc, parts & NLX_PGATE_MX);
+    if (parts & ~NLX_PGATE_MX) gate_poseidon_fast(W, acc, parts & ~NLX_PGATE_MX);
+}
 
 // One gate's unfiltered constraints at this lane's point, folded into `acc` with the alpha powers (Gate::eval_unfiltered_base).
 // W(c): wire c of the point; CC(c): constants column c (selectors first) of the point; n = 2^log_n.
@@ -1039,6 +1061,44 @@ void launch_quotient(hipStream_t st, const QuotientParams& p) {
     // more than the default 64 KB of dynamic LDS: the attribute is per function and device, setting it again is free
     (void)hipFuncSetAttribute((const void*)k_quotient, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_quotient, dim3((unsigned)((L + 63) / 64)), dim3(64 * QW), lds, st, p);
+}
+
+// PoseidonGate's part 2 (the 22 partial rounds: constraints 41 .. 74) for every point, one lane per point, on the permutation's
+// fused-block schedule (gate_poseidon_mx): filter x sum_k alpha^k c_k for both challenges goes into (add = 0) or onto (add = 1)
+// the sums k_quotient completes (QuotientParams::accumulate, as the lookup terms').  Wires and the selector are read straight
+// from the LDE tables (46 columns, coalesced); every lane stays active (the matrix instructions read all 64), spare lanes redo the
+// last point and store nothing.
+__global__ __launch_bounds__(256, 3) void k_quotient_poseidon(QuotientParams p, uint32_t gate, uint32_t add) {
+    const unsigned log_L = p.log_n + p.rate_bits;
+    const size_t L = (size_t)1 << log_L;
+    const size_t pos_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = pos_raw < L;
+    const size_t pos = live ? pos_raw : L - 1;
+    auto W = [&](uint32_t c) { return p.wires[(size_t)c * L + pos]; };
+    const GateDev gd = p.gates[gate];
+    const uint64_t s = p.cs[(size_t)gd.selector_index * L + pos];
+    uint64_t f = 1;
+    for (uint32_t i = gd.group_start; i < gd.group_end; i++)
+        if (i != gd.index) f = gl::mul(f, gl::sub((uint64_t)i, s));
+    if (p.n_selectors > 1) f = gl::mul(f, gl::sub(0xFFFFFFFFULL, s));
+    const uint32_t T0 = p.nc + p.nc * (p.npp + 1) + p.nc * p.n_lk_terms;
+    GateAcc acc;
+    acc.ap0 = p.alpha_pows + T0;
+    acc.ap1 = p.alpha_pows + p.alpha_stride + T0;
+    acc.reset();
+    gate_poseidon_mx(W, acc, 2u);
+    uint64_t t0 = gl::mul(f, acc.finish(0)), t1 = gl::mul(f, acc.finish(1));
+    if (!live) return;
+    if (add) {
+        t0 = gl::add(t0, p.out[pos]);
+        if (p.nc > 1) t1 = gl::add(t1, p.out[L + pos]);
+    }
+    p.out[pos] = t0;
+    if (p.nc > 1) p.out[L + pos] = t1;
+}
+void launch_quotient_poseidon(hipStream_t st, const QuotientParams& p, uint32_t gate, bool add) {
+    const size_t L = (size_t)1 << (p.log_n + p.rate_bits);
+    hipLaunchKernelGGL(k_quotient_poseidon, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, p, gate, add ? 1u : 0u);
 }
 
 // l0_scaled[pos] = 1 / (n * (x_pos - 1)), batch-inverted 8 per thread
