@@ -322,3 +322,24 @@ def test_batch_prove_two_devices(nlx, orc):
     assert nlx.batch_prove(workers, jobs) == expect
     for c in ctxs:
         c.close()
+
+
+def test_poseidon_gate_in_kernel_and_in_its_own_kernel_give_the_same_proof(nlx, ctx, orc, monkeypatch):
+    """PoseidonGate's partial rounds run in k_quotient_poseidon (the permutation's fused-block schedule, naive formulation) by
+    default and as an item of k_quotient (upstream's fast formulation) under NLX_QUOTIENT_POSEIDON_INLINE=1, read at circuit
+    build: both give the oracle's bytes.  (Circuits with lookup tables, whose terms reach the sums through the same accumulate
+    path, run on the default in tests/test_gpu_lookup.py.)"""
+    for log_n, kw in ((10, dict(pct_poseidon=30, pct_arithmetic=30, pct_base_sum=5, pct_constant=5)),
+                      (9, dict(pct_poseidon=10, pct_arithmetic=10, pct_base_sum=5, pct_constant=5, pct_extension=10, pct_misc=20, pct_u32=30))):
+        syn = nlx.SyntheticCircuit(log_n, seed=500 + log_n, **kw)
+        ref = orc.Circuit.from_synthetic(syn)
+        want = ref.prove(syn.wires, syn.public_inputs)
+        proofs = []
+        for inline in ("0", "1"):
+            monkeypatch.setenv("NLX_QUOTIENT_POSEIDON_INLINE", inline)
+            cd = nlx.CircuitData.from_synthetic(ctx, syn)
+            proofs.append(cd.prove(syn.wires, syn.public_inputs))
+            cd.close()
+        _assert_same_bytes(proofs[0], want, "own kernel")
+        _assert_same_bytes(proofs[1], want, "in k_quotient")
+        ref.close()
