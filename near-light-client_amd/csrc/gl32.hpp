@@ -209,8 +209,11 @@ typedef int i32x16_t __attribute__((ext_vector_type(16)));
 // Rows 12 .. 15 of a result are never read.  Left at that, hipcc treats those four registers of the sixteen-register result as
 // dead from the start: it has overlapped them with the SAME instruction's B operand and handed them to other values while the
 // instruction was in flight (seen in k_quotient, where PoseidonGate's three parts share a function: wrong sums that came and
-// went with the register allocation).  An empty asm statement that takes the whole result after its last real use keeps all
-// sixteen registers allocated to it until then, at no instruction.
+// went with the register allocation).  An empty asm statement that takes the whole result keeps all sixteen registers allocated
+// to it up to that point, at no instruction.  It stands right after the last matrix instruction of a group is issued: that covers
+// the instruction's own operands and everything scheduled before it; what follows is compiler-generated code reading the
+// results (it waits for them), and any write into a register the matrix cores have yet to write is spaced by the hazard
+// recogniser as long as it is not inline asm - the first asm statement comes after every result of the group was read.
 __device__ __forceinline__ void keep_whole(const i32x16_t& d) { asm volatile("" : : "v"(d)); }
 
 // this lane's A operand: A[row = lane & 31][k = 16 (lane >> 5) + j], j = 0 .. 15 (the same k order as the B operand below,
@@ -313,12 +316,12 @@ __device__ __forceinline__ void mds_layer_mfma(F (&s)[12], const i32x4_t a, cons
             d[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf, zero, 0, 0, 0);
         }
 #pragma unroll
+        for (int b = 0; b < 4; b++) keep_whole(d[b]);   // after the LAST instruction is issued, before the first result is read
+#pragma unroll
         for (int r = 0; r < 12; r++) {
             x[half][r] = ((uint32_t)d[1][r] << 8) + (uint32_t)d[0][r];
             y[half][r] = ((uint32_t)d[3][r] << 8) + (uint32_t)d[2][r];
         }
-#pragma unroll
-        for (int b = 0; b < 4; b++) keep_whole(d[b]);
         __builtin_amdgcn_sched_barrier(0);   // the low half's sixteen-register results are dead before the high half's exist
     }
 #pragma unroll
@@ -458,6 +461,8 @@ __device__ __forceinline__ void partial_block3(F (&s)[12], const BlockOperands& 
         i32x16_t d[2];
         d[0] = chain(2 * pr);
         d[1] = chain(2 * pr + 1);
+        keep_whole(d[0]);
+        keep_whole(d[1]);
 #pragma unroll
         for (int r = 0; r < 12; r++) {
             // the compiler's own shift-add: the matrix cores' results must NOT go straight into inline asm - the hazard recogniser
@@ -483,8 +488,6 @@ __device__ __forceinline__ void partial_block3(F (&s)[12], const BlockOperands& 
                 else s[r] = fold_pair_x(tt[r], y1[r], x, k16);
             }
         }
-        keep_whole(d[0]);
-        keep_whole(d[1]);
 #ifndef NLX_PB_NO_BARRIER
         __builtin_amdgcn_sched_barrier(0);   // a pair of planes is consumed before the next pair's sixteen-register results exist
 #endif
