@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # instruction were free: 1 024 SIMDs x 64 lanes / (4 768 x 1.99 ns) = 6.9 G permutations/s (the matrix pipe's own bound, 240 MFMAs
 # of 32 cycles per 64 permutations and SIMD, is ~17 G/s).  The kernel issues 12.1 k vector instructions per permutation at the end of
 # round 4 (rounds 4 .. 24 as fused blocks of three partial rounds; 14.2 k before that, 15.7 k in round 3; reductions, carry chains,
-# byte transposes: profiles/r04_pmc_traffic_outer_2p18_v6.json), nearly all of them
+# byte transposes: profiles/r04_pmc_traffic_outer_2p18_v8.json), nearly all of them
 # at ~1.9 ns - only plain 32-bit add / sub / logic / move issue at 1.1 ns (profiles/r04_valu_issue_rates_v1.txt).  The bound
 # below is ROUND 3's, unchanged, so that the fractions of rounds 3 and 4 compare.  Round 2's model (all multiply-adds on the vector
 # pipe: 10 528 per permutation, 3.13 G/s) is kept in the note so that the fractions of the two rounds can be compared.
@@ -58,15 +58,15 @@ VALU_PEAK_GPERM = 1024 * 64 / (VALU_MULS_PER_PERM * VALU_NS_PER_MUL)
 VALU_PEAK_NOTE = ("1 024 SIMDs x 64 lanes / (4 768 irreducible vector multiply-adds per permutation - 1 888 in the S-boxes, 96 per layer "
                   "recombining the matrix cores' byte-plane sums - x 1.99 ns measured issue cost per wave-instruction per SIMD, "
                   "tools/ubench/poseidon_ubench.hip -> profiles/r03_poseidon_occupancy.txt; the same bound as in round 3); the permutation "
-                  "micro-benchmark itself reaches 2.79 Gperm/s at the end of round 4 (2.35 before the fused partial rounds and the carry-free product, 2.09 - 2.15 in round 3; 1.74 with the linear layer on the vector pipe, "
+                  "micro-benchmark itself reaches 2.81 Gperm/s at the end of round 4 (2.35 before the fused partial rounds and the carry-free product, 2.09 - 2.15 in round 3; 1.74 with the linear layer on the vector pipe, "
                   "round 2, whose bound was 10 528 multiply-adds = 3.13 Gperm/s: this line's achieved / 3.13 compares with round 2's fractions)")
 
 
 def stored_traffic(key, alg_bytes):
-    """HBM bytes per launch from the committed PMC pass (profiles/r04_pmc_traffic_outer_2p18_v6.json: FETCH_SIZE x 2 + WRITE_SIZE
+    """HBM bytes per launch from the committed PMC pass (profiles/r04_pmc_traffic_outer_2p18_v8.json: FETCH_SIZE x 2 + WRITE_SIZE
     per the microarch guide, separate rocprofv3 --pmc runs of the outer proof at the headline's 2^18 rows, tools/pmc_ratio.py):
     measured ratio traffic / algorithmic bytes x this run's algorithmic bytes.  Not measured in this process (counters need their own run) - labelled "stored"."""
-    for name in ("r04_pmc_traffic_outer_2p18_v6.json", "r04_pmc_traffic_outer_2p18_v4.json", "r04_pmc_traffic_outer_2p18_v1.json", "r03_pmc_traffic_outer_2p18.json", "r02_pmc_traffic_v5.json", "r02_pmc_traffic_v2.json"):
+    for name in ("r04_pmc_traffic_outer_2p18_v8.json", "r04_pmc_traffic_outer_2p18_v6.json", "r04_pmc_traffic_outer_2p18_v4.json", "r04_pmc_traffic_outer_2p18_v1.json", "r03_pmc_traffic_outer_2p18.json", "r02_pmc_traffic_v5.json", "r02_pmc_traffic_v2.json"):
         prof = os.path.join(ROOT, "profiles", name)
         if os.path.exists(prof):
             try:
