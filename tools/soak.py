@@ -36,7 +36,10 @@ kzg_poly, kzg_srs = fr(3000), nlx.bn254_g1_multiples(ctx, (1, 2), 2999)
 # round 4: commitment rounds in batches, a STARK whose constraints run on a generated kernel (SHA-256 at 2^7 blocks = 2^9 rows), the blinded
 # quotient chain, the natural-order transform without a reordering pass
 p256b = nlx.sha256_air.Sha256Prover(ctx, 7, nlx.StarkConfig(batch_cols=512))
-assert nlx.lib.dll.nlx_stark_quotient_kernel(p256b.prover.handle) == 1
+# the generated kernels exist in the library of record only (build.py WITH_AIRGEN: not in the generator-set-2021 variant, not
+# under NLX_NO_AIRGEN / NLX_AIR_VM); elsewhere the same job runs on the interpreter
+_generated_expected = os.environ.get("NLX_GL_GENERATOR_SET", "7") == "7" and os.environ.get("NLX_AIR_VM") != "1" and os.environ.get("NLX_NO_AIRGEN") != "1"
+assert nlx.lib.dll.nlx_stark_quotient_kernel(p256b.prover.handle) == (1 if _generated_expected else 0)
 p512b = nlx.sha512_air.Sha512Prover(ctx, 5, nlx.StarkConfig(batch_cols=512))
 gl_cols = rs.randint(0, 1 << 62, size=(2, 1 << 20), dtype=np.int64).astype(np.uint64)
 blind = [int(x) for x in rs.randint(1, 1 << 60, size=9)]
