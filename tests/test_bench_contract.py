@@ -206,3 +206,15 @@ def test_exchange_primitives_two_ranks_rccl():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     _run_dist_units("nccl", 29653, 2)
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_wrap_quotient_chain_split_schedule_under_gloo(n):
+    """the PLONK quotient chain split over ranks - transforms by column, one all-to-all of point slices
+    (z with its four-point halo), pointwise by points, the inverse transform on rank 0 - gives the unsplit chain's coefficients.
+    The schedule is near-light-client_amd/plonk_split.py; the arithmetic in this rehearsal is the big-integer model's."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(29660 + n), os.path.join(ROOT, "tests", "tools", "plonk_split_rehearsal.py"), "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("plonk_split ok") == n, r.stdout[-2000:]
